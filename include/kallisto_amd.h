@@ -1,0 +1,160 @@
+/* include/kallisto_amd.h -- C ABI of libkallisto_amd.so, the MI355X (gfx950) implementation of the `kallisto quant`
+ * hot path of pachterlab/kallisto v0.51.1.
+ *
+ * kallisto has no plugin/FFI interface; the hot path is reached by ordinary C++ calls inside one binary.  Each entry
+ * point below replaces one of those seams; the reference-side binding a maintainer would add is
+ * shown in INTEGRATION.md.  Conventions: plain pointers and sizes only (no C++/torch types), integer return codes
+ * (0 = ok, <0 = error; kamd_last_error() holds the message), the caller owns host buffers it passes in, the library
+ * owns everything it allocates (device and host) and frees it in the matching *_free / *_destroy call.  Pointers named
+ * d_* are DEVICE pointers on the context's GPU; everything else is host memory.  All device work is enqueued on the
+ * hipStream_t passed to kamd_ctx_create (0 = the null stream) so that a PyTorch caller can hand over its current stream.
+ *
+ * Reference interfaces replaced (file:line in the reference tree):
+ *   S1  KmerIndex::load                          src/KmerIndex.cpp:1330-1559      -> kamd_index_load / kamd_index_upload
+ *   S2  ReadProcessor::processBuffer             src/ProcessReads.cpp:968-1237    -> kamd_pseudoalign
+ *       (KmerIndex::match src/KmerIndex.cpp:1698, MinCollector::intersectKmers src/MinCollector.cpp:160,
+ *        KmerIndex::mapPair src/KmerIndex.cpp:1622, KmerIndex::findPosition src/KmerIndex.cpp:2188)
+ *       MasterProcessor::update / processReads   src/ProcessReads.cpp:424-499,323-334 -> kamd_ec_finalize (+ kamd_ec_* exchange helpers)
+ *       FastqSequenceReader::fetchSequences      src/ProcessReads.cpp:3128-3267   -> kamd_pack_reads (2-bit packing of a parsed batch)
+ *   S3  EMAlgorithm ctor + run                   src/EMAlgorithm.h:26-48,95-223   -> kamd_em_run
+ *   S4  Bootstrap::run_em / Multinomial::sample  src/Bootstrap.cpp:4-14, src/Multinomial.hpp:33-51 -> kamd_bootstrap
+ */
+#ifndef KALLISTO_AMD_H
+#define KALLISTO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAMD_MAX_FRAG_LEN 1000   /* src/MinCollector.h:15 */
+#define KAMD_SLOTS_PER_BUCKET 4  /* 4 x 16 B = one 64-byte line */
+
+typedef struct kamd_index kamd_index; /* host-side flattened index (owned by the library) */
+typedef struct kamd_ctx kamd_ctx;     /* one GPU: device copy of the index + work buffers */
+
+/* Read-only view of the flattened index; arrays stay valid until kamd_index_free. */
+typedef struct {
+  int32_t k;
+  uint64_t n_kmers, n_unitigs, n_blocks, n_uec, n_ecs, ec_nnz, n_targets, dlist_size;
+  uint64_t n_buckets;             /* home buckets; table holds (n_buckets + pad_buckets) * 4 slots */
+  uint64_t pad_buckets;
+  const uint64_t* table;          /* slot i = {table[2i] = key | flags, table[2i+1] = payload} */
+  const uint32_t* slot_block;     /* per slot: global block id          (aux table, FLD / positional paths only) */
+  const uint32_t* slot_dist;      /* per slot: k-mer offset on its unitig (aux table) */
+  const uint32_t* uec_ec;         /* (unitig, transcript-set) class -> de-duplicated transcript-set id */
+  const uint64_t* ec_off;         /* [n_ecs + 1] */
+  const uint32_t* ec_ids;         /* [ec_nnz] sorted transcript ids per set */
+  const uint64_t* unitig_blk_off; /* [n_unitigs + 1] */
+  const uint32_t* unitig_len;     /* bp */
+  const uint32_t* blk_unitig;     /* per block */
+  const uint32_t* blk_lb;
+  const uint32_t* blk_ub;
+  const uint32_t* blk_ec;
+  const uint64_t* blk_pos_off;    /* [n_blocks + 1] into blk_posw / blk_sense (parallel to the block's transcript set) */
+  const uint32_t* blk_posw;       /* first raw position word per (block, transcript); bit31 = reverse */
+  const uint8_t* blk_sense;       /* 1 forward, 0 reverse, 2 ambiguous */
+  const int32_t* target_lens;     /* [n_targets] */
+  const uint32_t* onlist_bits;    /* bit t set = transcript t is on-list */
+  uint64_t onlist_words;
+} kamd_index_view;
+
+typedef struct {
+  int32_t paired;           /* 0 = --single */
+  double fld;               /* -l (0 = estimate from the data; paired only) */
+  double sd;                /* -s */
+  int32_t single_overhang;  /* --single-overhang */
+  int32_t strand;           /* 0 unstranded, 1 --fr-stranded, 2 --rf-stranded */
+} kamd_quant_opts;
+
+/* ---- errors ---- */
+const char* kamd_last_error(void);
+
+/* ---- S1: index ---- */
+int kamd_index_load(const char* path, int threads, kamd_index** out);
+void kamd_index_free(kamd_index*);
+int kamd_index_get_view(const kamd_index*, kamd_index_view* out);
+const char* kamd_index_target_name(const kamd_index*, uint64_t i);
+
+/* ---- context ---- */
+int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out);
+void kamd_ctx_destroy(kamd_ctx*);
+int kamd_index_upload(kamd_ctx*, const kamd_index*);
+
+/* ---- reads: 2-bit packing of one parsed batch (what fetchSequences hands to processBuffer) ----
+ * Record layout per read: words_per_read u32 of 2-bit bases (base i at bits 2*(i&15) of word i>>4; A0 C1 G2 T3,
+ * case-insensitive) followed by mask_words u32 (bit i&31 of word i>>5 set = base i is not ACGT).  A pair is two
+ * consecutive records (mate 1, mate 2).  max_len fixes the stride: words_per_read = ceil(max_len/16),
+ * mask_words = ceil(max_len/32). */
+uint64_t kamd_packed_record_words(int32_t max_len);
+/* host packer: seqs = concatenated sequences (no terminators needed), off[i]/len[i] locate read i */
+int kamd_pack_reads_host(const char* seqs, const uint64_t* off, const int32_t* len, uint64_t n_reads, int32_t max_len,
+                         uint32_t* out_words, uint16_t* out_len);
+/* device packer: same, d_* are device pointers; runs on the context stream */
+int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off, const int32_t* d_len, uint64_t n_reads,
+                           int32_t max_len, uint32_t* d_out_words, uint16_t* d_out_len);
+
+/* ---- S2: pseudoalignment of one batch resident in HBM ----
+ * n_items = pairs (paired) or reads (single).  Accumulates into the context's EC state; call kamd_ec_finalize after
+ * the last batch.  If d_tl is non-NULL it receives, per item, the fragment length KmerIndex::mapPair would return
+ * (0 = none) and d_card the cardinality class of the item's equivalence class is resolved later by kamd_fld_from_prefix. */
+int kamd_pseudoalign(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
+                     int32_t max_len);
+/* fragment-length histogram from the first 10000 qualifying pairs in input order of the given batch
+ * (src/ProcessReads.cpp:981-1017,1174-1181 at -t 1).  flens: KAMD_MAX_FRAG_LEN u32 (host). */
+int kamd_fld_from_batch(kamd_ctx*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items, int32_t max_len,
+                        uint32_t* flens, uint64_t* n_used);
+
+/* statistics of the batches processed so far */
+typedef struct {
+  uint64_t n_processed;     /* items seen */
+  uint64_t n_single;        /* items whose hits carried one transcript set */
+  uint64_t n_multi;         /* items that needed an intersection */
+  uint64_t n_probes;        /* k-mer table probes */
+  uint64_t n_bucket_reads;  /* 64-byte bucket reads (>= n_probes) */
+  uint64_t n_distinct_tuples;
+} kamd_align_stats;
+int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
+
+/* ---- EC state exchange (multi-GPU; one process per GPU, the caller runs the collectives) ----
+ * The EC state is (a) a dense count vector over index transcript sets and (b) a list of (tuple of index set ids,
+ * count) for items whose hits carried several sets.  Both are keyed by index set ids, which are identical on every
+ * rank, so ranks merge by all-reduce(a) + all-gather(b). */
+int kamd_ec_dense_counts(kamd_ctx*, uint32_t** d_counts, uint64_t* n);            /* device pointer into the context */
+int kamd_ec_tuples_export(kamd_ctx*, uint64_t* n_words, uint64_t* n_tuples);      /* compacts; sizes for the gather */
+int kamd_ec_tuples_copy(kamd_ctx*, uint32_t* d_out_words);                         /* [count, m, e0..e(m-1)] records */
+int kamd_ec_tuples_replace(kamd_ctx*, const uint32_t* d_words, uint64_t n_words);  /* install the gathered records */
+
+/* ---- finalize: resolve intersections, apply the on-list mask, merge equal sets ----
+ * Produces the EC multiset {sorted transcript set -> count} as CSR, on device and (optionally) host. */
+typedef struct {
+  uint64_t n_ecs, nnz, n_pseudoaligned;
+  const uint64_t* d_ec_off;  /* [n_ecs + 1] device */
+  const uint32_t* d_ec_ids;  /* [nnz] device */
+  const uint32_t* d_counts;  /* [n_ecs] device */
+} kamd_ec_result;
+int kamd_ec_finalize(kamd_ctx*, kamd_ec_result* out);
+int kamd_ec_download(kamd_ctx*, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts);
+
+/* ---- S3: EM ---- */
+/* Runs EMAlgorithm::run(n_iter, min_rounds) on the finalized EC result (or on caller-provided device CSR when
+ * d_ec_off != NULL).  eff_lens: host [n_targets].  Outputs (host): alpha, alpha_before_zeroes [n_targets], rounds. */
+int kamd_em_run(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts, uint64_t n_ecs,
+                const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds, double* alpha,
+                double* alpha_before_zeroes, int32_t* rounds);
+
+/* ---- S4: bootstrap ---- */
+int kamd_bootstrap(kamd_ctx*, uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha, int32_t* rounds);
+
+/* ---- host-side helpers of the quant driver (FLD model, effective lengths; FP64 on the host, bit-exact) ---- */
+void kamd_mean_frag_lens_trunc(const uint32_t* flens, double* mean_fl_trunc);
+void kamd_trunc_gaussian_fld(int32_t start, int32_t stop, double mean, double sd, double* out);
+void kamd_eff_lens(const int32_t* target_lens, uint64_t n, const double* mean_fl_trunc, double* eff_lens);
+void kamd_counts_to_tpm(const double* est_counts, const double* eff_lens, uint64_t n, double* tpm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

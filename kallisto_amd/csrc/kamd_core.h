@@ -1,0 +1,302 @@
+// kamd_core.h -- per-item logic of the pseudoalignment kernels, written once as host/device inline functions.
+//
+// The __global__ kernels in kamd_kernels.hip are thin wrappers (LDS staging, wave-aggregated output, atomics) around
+// the functions below.  They are also compilable for the host so that tests/emu can drive exactly the same logic on a
+// CPU-only box (hipcc cross-compiles here but there is no GPU); that emulation build is TEST infrastructure, the
+// product library never calls it.
+//
+// Reference semantics restated here (file:line in the reference tree):
+//   KmerIterator                 ext/bifrost/src/KmerIterator.cpp:6-63
+//   CompactedDBG::find           ext/bifrost/src/CompactedDBG.tcc:999-1119  (as an exact k-mer dictionary)
+//   KmerIndex::match             src/KmerIndex.cpp:1698-1940  (default flags; quirks Q1-Q4 of SURVEY.md section 8a)
+//   MinCollector::intersectKmers src/MinCollector.cpp:160-218,425-496
+//   KmerIndex::mapPair           src/KmerIndex.cpp:1622-1693
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KAMD_HD __host__ __device__ __forceinline__
+#else
+#define KAMD_HD inline
+#endif
+
+namespace kamd {
+
+// ---------------------------------------------------------------------------------------------------------------
+// k-mer table layout (built by kamd_index.cpp, probed by the kernels)
+//
+//   slot    = {key, payload}, 16 bytes; bucket = 4 slots = one 64-byte line.
+//   key     = canonical k-mer, MSB-first 2-bit, right-aligned (<= 62 bits).  Empty slot = KEY_EMPTY (all ones in the low
+//             62 bits, never canonical because its reverse complement is 0).  Bit 63 of slot 0's key is the bucket's
+//             "continue" flag: some key whose home is <= this bucket was placed beyond it.
+//   payload = rem_f[15:0] | rem_b[31:16] | uec[62:32] | fwd_is_canon[63]
+//             rem_f = (ub-1-dist), rem_b = (dist-lb): k-mers left to the end of the mosaic block when walking the unitig
+//             forward / backward, saturated at 65535 (exact for reads shorter than 65535+k);
+//             uec   = id of the (unitig, transcript-set) class of the block: two hits satisfy
+//                     "isSameReferenceUnitig && ec == ec" (KmerIndex.cpp:1810) iff their uec are equal.
+//   Keys are laid out in home-bucket order (Robin-Hood linear probing at bucket granularity), so a lookup reads the home
+//   bucket and follows continue flags; at load <= 0.5 that is 1.0x bucket reads.
+// ---------------------------------------------------------------------------------------------------------------
+static const uint64_t KEY_MASK = (1ULL << 62) - 1;
+static const uint64_t KEY_EMPTY = KEY_MASK;
+static const uint64_t KEY_CONT = 1ULL << 63;
+static const uint32_t REM_CAP = 65535u;
+static const uint32_t NO_UEC = 0x7FFFFFFFu;
+
+KAMD_HD uint64_t mix64(uint64_t x) {
+  x ^= x >> 31; x *= 0x7fb5d329728ea185ULL;
+  x ^= x >> 27; x *= 0x81dadef4bc2dd44dULL;
+  x ^= x >> 33;
+  return x;
+}
+// home bucket of a canonical k-mer: fastrange (monotone in the hash so that sorting by hash == sorting by home)
+KAMD_HD uint64_t home_bucket(uint64_t canon, uint64_t n_buckets) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(mix64(canon), n_buckets);
+#else
+  return (uint64_t)(((unsigned __int128)mix64(canon) * n_buckets) >> 64);
+#endif
+}
+KAMD_HD uint64_t make_payload(uint32_t rem_f, uint32_t rem_b, uint32_t uec, bool fwd_is_canon) {
+  if (rem_f > REM_CAP) rem_f = REM_CAP;
+  if (rem_b > REM_CAP) rem_b = REM_CAP;
+  return (uint64_t)rem_f | ((uint64_t)rem_b << 16) | ((uint64_t)(uec & 0x7FFFFFFFu) << 32) | ((uint64_t)fwd_is_canon << 63);
+}
+
+// reverse the order of the 2-bit bases of a 64-bit word
+KAMD_HD uint64_t rev_bases64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = __brevll(x);
+#else
+  x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = __builtin_bswap64(x);
+#endif
+  return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);  // un-swap the two bits of each base
+}
+
+// MSB-first value of the reverse complement of an MSB-first right-aligned k-mer
+KAMD_HD uint64_t revcomp_msb(uint64_t v, int k) { return rev_bases64(~v) >> (64 - 2 * k) ; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// packed reads: base i at bits 2*(i&15) of word i>>4 (LSB-first), N mask bit i&31 of mask word i>>5
+// ---------------------------------------------------------------------------------------------------------------
+struct ReadView {
+  const uint32_t* seq;   // 2-bit words (LDS on the device)
+  const uint32_t* mask;  // non-ACGT mask words
+  int len;               // bases
+};
+
+// bits [2w, 2w+2k) of the read, LSB-first: x = sum base[w+i] << 2i
+KAMD_HD uint64_t window_lsb(const ReadView& r, int w, int k) {
+  int bit = 2 * w;
+  int wi = bit >> 5, sh = bit & 31;
+  uint64_t lo = (uint64_t)r.seq[wi] | ((uint64_t)r.seq[wi + 1] << 32);
+  uint64_t x = lo >> sh;
+  if (sh + 2 * k > 64) x |= (uint64_t)r.seq[wi + 2] << (64 - sh);  // third word only when the window reaches it
+  return x & ((k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1));
+}
+// mask bits of bases [w, w+k) (k <= 32)
+KAMD_HD uint32_t window_mask(const ReadView& r, int w, int k) {
+  int wi = w >> 5, sh = w & 31;
+  uint64_t lo = (uint64_t)r.mask[wi] | ((uint64_t)r.mask[wi + 1] << 32);  // records carry one pad word per plane
+  return (uint32_t)(lo >> sh) & (uint32_t)((1ULL << k) - 1);
+}
+// first window start >= t whose k bases are all ACGT and that fits in the read; -1 if none   (KmerIterator::operator++)
+KAMD_HD int next_valid_window(const ReadView& r, int t, int k) {
+  while (t + k <= r.len) {
+    uint32_t m = window_mask(r, t, k);
+    if (m == 0) return t;
+    t += 32 - __builtin_clz(m);  // jump past the last non-ACGT base of the window
+  }
+  return -1;
+}
+// KmerIterator::operator+=(n) applied to an iterator standing on window w (n >= 0)
+KAMD_HD int advance_window(const ReadView& r, int w, int n, int k) {
+  if (n == 0) return w;
+  if (n == 1) return next_valid_window(r, w + 1, k);
+  if (w + n + k > r.len) return -1;  // str[pos_e + n - 1] == '\0'
+  return next_valid_window(r, w + n, k);
+}
+
+// canonical MSB-first key of the k-mer at window w; *is_fwd_canon = read-forward k-mer is the canonical one
+KAMD_HD uint64_t window_canon(const ReadView& r, int w, int k, bool* is_fwd_canon) {
+  uint64_t x = window_lsb(r, w, k);
+  uint64_t fwd = rev_bases64(x) >> (64 - 2 * k);                    // MSB-first value of the read k-mer
+  uint64_t rc = (~x) & ((1ULL << (2 * k)) - 1);                     // MSB-first value of its reverse complement
+  *is_fwd_canon = fwd < rc;
+  return fwd < rc ? fwd : rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// table probe
+// ---------------------------------------------------------------------------------------------------------------
+struct Table {
+  const uint64_t* slots;  // 2 words per slot
+  uint64_t n_buckets;
+};
+struct Probe {
+  bool found;
+  bool strand;      // read k-mer equals the unitig's forward text (const_UnitigMap::strand)
+  uint32_t uec;
+  uint32_t dist;    // "dist" of KmerIndex.cpp:1789: k-mers to the end of the block in read direction
+  uint64_t slot;    // slot index (for the aux tables)
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long __attribute__((ext_vector_type(2))) kamd_u64x2;
+#endif
+
+KAMD_HD Probe probe_table(const Table& t, uint64_t canon, bool is_fwd_canon, uint32_t* bucket_reads) {
+  Probe p; p.found = false; p.strand = false; p.uec = NO_UEC; p.dist = 0; p.slot = 0;
+  uint64_t b = home_bucket(canon, t.n_buckets);
+  for (;;) {
+    const uint64_t* bp = t.slots + b * 8;
+    uint64_t k0, p0, k1, p1, k2, p2, k3, p3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // four 16-byte loads of one 64-byte line, issued back to back
+    kamd_u64x2 s0 = ((const kamd_u64x2*)bp)[0];
+    kamd_u64x2 s1 = ((const kamd_u64x2*)bp)[1];
+    kamd_u64x2 s2 = ((const kamd_u64x2*)bp)[2];
+    kamd_u64x2 s3 = ((const kamd_u64x2*)bp)[3];
+    k0 = s0.x; p0 = s0.y; k1 = s1.x; p1 = s1.y; k2 = s2.x; p2 = s2.y; k3 = s3.x; p3 = s3.y;
+#else
+    k0 = bp[0]; p0 = bp[1]; k1 = bp[2]; p1 = bp[3]; k2 = bp[4]; p2 = bp[5]; k3 = bp[6]; p3 = bp[7];
+#endif
+    if (bucket_reads) ++*bucket_reads;
+    uint64_t pay = 0; int hit = -1;
+    if ((k0 & KEY_MASK) == canon) { pay = p0; hit = 0; }
+    else if (k1 == canon) { pay = p1; hit = 1; }
+    else if (k2 == canon) { pay = p2; hit = 2; }
+    else if (k3 == canon) { pay = p3; hit = 3; }
+    if (hit >= 0) {
+      bool fwd_is_canon = (pay >> 63) != 0;
+      p.found = true;
+      p.strand = (is_fwd_canon == fwd_is_canon);
+      p.uec = (uint32_t)(pay >> 32) & 0x7FFFFFFFu;
+      p.dist = p.strand ? (uint32_t)(pay & 0xFFFF) : (uint32_t)((pay >> 16) & 0xFFFF);
+      p.slot = b * 4 + (uint64_t)hit;
+      return p;
+    }
+    if (!(k0 & KEY_CONT)) return p;
+    ++b;  // the table carries pad buckets at the end, so this never runs off
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-item accumulation of distinct transcript-set ids (sorted, unique, bounded)
+// ---------------------------------------------------------------------------------------------------------------
+struct EcList {
+  uint32_t* e;   // `cap` entries (LDS in the main kernel, global scratch in the overflow kernel)
+  int cap;
+  int n;
+  bool overflow; // more than `cap` distinct sets: the item is re-run by the overflow kernel with a larger list
+};
+KAMD_HD void eclist_add(EcList& l, uint32_t ec) {
+  int i = 0;
+  while (i < l.n && l.e[i] < ec) ++i;
+  if (i < l.n && l.e[i] == ec) return;
+  if (l.n == l.cap) { l.overflow = true; return; }
+  for (int j = l.n; j > i; --j) l.e[j] = l.e[j - 1];
+  l.e[i] = ec;
+  ++l.n;
+}
+
+struct MateInfo {
+  int n_hits;        // v.size()
+  int n_nonempty;    // != 0 when some hit carries a non-empty transcript set
+  // first pushed hit == findFirstMappingKmer (smallest recorded position, first wins) == mapPair's first present k-mer
+  uint64_t first_slot;
+  int first_pos;
+  bool first_strand;
+  uint32_t probes, bucket_reads;
+};
+
+// KmerIndex::match for one mate.  `sink` receives every pushed hit's transcript-set id (uec -> ec through uec_ec) once.
+KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* ec_nonempty, const ReadView& r, int k,
+                        EcList& ecs, MateInfo& mi) {
+  mi.n_hits = 0; mi.n_nonempty = 0; mi.first_slot = 0; mi.first_pos = -1; mi.first_strand = false;
+  mi.probes = 0; mi.bucket_reads = 0;
+  const int l = r.len;
+  uint32_t last_uec = NO_UEC;
+  // push = v.push_back({um, pos}) : only the set id matters downstream, plus the very first hit
+#define KAMD_PUSH(P, POS)                                                          \
+  do {                                                                             \
+    if (mi.n_hits == 0) { mi.first_slot = (P).slot; mi.first_pos = (POS); mi.first_strand = (P).strand; } \
+    ++mi.n_hits;                                                                   \
+    if ((P).uec != last_uec) {                                                     \
+      last_uec = (P).uec;                                                          \
+      uint32_t ec_ = uec_ec[(P).uec];                                              \
+      if (ec_nonempty == nullptr || ec_nonempty[ec_]) { eclist_add(ecs, ec_); mi.n_nonempty = 1; } \
+    }                                                                              \
+  } while (0)
+
+  int w = next_valid_window(r, 0, k);
+  while (w >= 0) {
+    bool fc; uint64_t canon = window_canon(r, w, k, &fc);
+    ++mi.probes;
+    Probe um = probe_table(t, canon, fc, &mi.bucket_reads);
+    if (um.found) {
+      const int pos = w;
+      KAMD_PUSH(um, pos);                                                          // KmerIndex.cpp:1774
+      const int dist = (int)um.dist;                                               // :1789
+      if (dist >= 2) {                                                             // :1792
+        int nextPos = pos + dist;
+        if (pos + dist >= l - k) nextPos = l - k;                                  // :1796-1799
+        int w2 = advance_window(r, w, nextPos - pos, k);                           // :1802-1803
+        if (w2 < 0) break;                                                         // :1882-1886 (Q4)
+        bool fc2; uint64_t c2 = window_canon(r, w2, k, &fc2);
+        ++mi.probes;
+        Probe um2 = probe_table(t, c2, fc2, &mi.bucket_reads);
+        bool found2 = false; int found2pos = pos + dist;
+        if (!um2.found) { found2 = true; found2pos = pos; }                        // :1807-1809 (Q2)
+        else if (um2.uec == um.uec) { found2 = true; }                             // :1810-1815
+        if (found2) {
+          if (found2pos >= l - k) { KAMD_PUSH(um, l - k); break; }                 // :1819-1822
+          KAMD_PUSH(um, found2pos); w = w2;                                        // :1823-1826
+        } else {
+          bool foundMiddle = false;
+          if (dist > 4) {                                                          // :1831
+            int middlePos = (pos + nextPos) / 2;
+            int w3 = advance_window(r, w, middlePos - pos, k);
+            if (w3 >= 0) {
+              bool fc3; uint64_t c3 = window_canon(r, w3, k, &fc3);
+              ++mi.probes;
+              Probe um3 = probe_table(t, c3, fc3, &mi.bucket_reads);
+              if (um3.found && (um3.uec == um.uec || um3.uec == um2.uec)) {        // :1842-1850
+                foundMiddle = true;
+                KAMD_PUSH(um3, 0);                                                 // :1866 (position irrelevant: not first)
+                if (nextPos >= l - k) break;                                       // :1867-1868
+                w = w2;                                                            // :1870 (Q3)
+              }
+            }
+          }
+          if (!foundMiddle) {                                                      // :1876-1925 with Q1: one-step back-off
+            w = next_valid_window(r, w + 1, k);
+            if (w < 0) break;
+            bool fc4; uint64_t c4 = window_canon(r, w, k, &fc4);
+            ++mi.probes;
+            Probe um4 = probe_table(t, c4, fc4, &mi.bucket_reads);
+            if (um4.found) KAMD_PUSH(um4, w);
+          }
+        }
+      }
+    }
+    w = next_valid_window(r, w + 1, k);
+  }
+#undef KAMD_PUSH
+}
+
+// Outcome of intersectKmers' emptiness rules (MinCollector.cpp:172-202) given per-mate facts.
+// Returns true when the item is pseudoaligned to the intersection of the collected (non-empty) sets.
+KAMD_HD bool pair_is_mapped(const MateInfo& a, const MateInfo& b) {
+  bool u1_empty = (a.n_nonempty == 0), u2_empty = (b.n_nonempty == 0);
+  if (u1_empty && u2_empty) return false;
+  if (u1_empty) return a.n_hits == 0;
+  if (u2_empty) return b.n_hits == 0;
+  return true;
+}
+
+}  // namespace kamd

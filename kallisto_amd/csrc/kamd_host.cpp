@@ -1,0 +1,91 @@
+// kamd_host.cpp -- host-side pieces of the quant driver that stay FP64/serial on the CPU, bit-exact with the reference:
+// the fragment-length model and effective lengths (src/MinCollector.cpp:629-651, src/weights.cpp:7-79,248-271),
+// counts_to_tpm (src/PlaintextWriter.cpp:5-27), the host read packer, and error reporting.
+#include "../../include/kallisto_amd.h"
+#include "kamd_host.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace kamd {
+static thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+}  // namespace kamd
+
+extern "C" const char* kamd_last_error(void) { return kamd::g_err.c_str(); }
+
+extern "C" uint64_t kamd_packed_record_words(int32_t max_len) {
+  return (uint64_t)((max_len + 15) / 16 + 1) + (uint64_t)((max_len + 31) / 32 + 1);
+}
+
+extern "C" int kamd_pack_reads_host(const char* seqs, const uint64_t* off, const int32_t* len, uint64_t n_reads,
+                                    int32_t max_len, uint32_t* out_words, uint16_t* out_len) {
+  if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pack_reads: max_len must be in [1, 65535]");
+  const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
+  for (uint64_t r = 0; r < n_reads; r++) {
+    if (len[r] < 0 || len[r] > max_len) return kamd::fail(-1, "kamd_pack_reads: read longer than max_len");
+    uint32_t* w = out_words + r * rec;
+    memset(w, 0, rec * 4);
+    const char* s = seqs + off[r];
+    for (int32_t i = 0; i < len[r]; i++) {
+      unsigned char ch = (unsigned char)s[i] & 0xDF;  // case mask of KmerIterator.cpp:12
+      uint32_t code;
+      switch (ch) {
+        case 'A': code = 0; break;
+        case 'C': code = 1; break;
+        case 'G': code = 2; break;
+        case 'T': code = 3; break;
+        default: code = 4;
+      }
+      if (code < 4) w[i >> 4] |= code << (2 * (i & 15));
+      else w[sw + (i >> 5)] |= 1u << (i & 31);
+    }
+    out_len[r] = (uint16_t)len[r];
+  }
+  return 0;
+}
+
+extern "C" void kamd_mean_frag_lens_trunc(const uint32_t* flens, double* out) {  // src/MinCollector.cpp:629-651
+  std::vector<int> counts(KAMD_MAX_FRAG_LEN, 0);
+  std::vector<double> mass(KAMD_MAX_FRAG_LEN, 0.0);
+  for (int i = 0; i < KAMD_MAX_FRAG_LEN; i++) out[i] = 0.0;
+  counts[0] = (int)flens[0];
+  for (size_t i = 1; i < KAMD_MAX_FRAG_LEN; ++i) {
+    mass[i] = static_cast<double>((size_t)flens[i] * i) + mass[i - 1];
+    counts[i] = (int)flens[i] + counts[i - 1];
+    if (counts[i] > 0) out[i] = mass[i] / static_cast<double>(counts[i]);
+  }
+}
+
+extern "C" void kamd_trunc_gaussian_fld(int32_t start, int32_t stop, double mean, double sd, double* out) {  // src/weights.cpp:248-271
+  size_t n = (size_t)(stop - start);
+  double total_mass = 0.0, total_density = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    out[i] = 0.0;
+    double x = static_cast<double>(start + (int)i);
+    x = (x - mean) / sd;
+    double cur_density = std::exp(-0.5 * x * x) / sd;
+    total_mass += cur_density * i;
+    total_density += cur_density;
+    if (total_mass > 0) out[i] = total_mass / total_density;
+  }
+}
+
+extern "C" void kamd_eff_lens(const int32_t* target_lens, uint64_t n, const double* t, double* eff) {  // src/weights.cpp:7-28,58-79
+  const double marginal = t[KAMD_MAX_FRAG_LEN - 1];
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t len = (uint32_t)target_lens[i];
+    double mean = len >= KAMD_MAX_FRAG_LEN ? marginal : t[len];
+    double cur = static_cast<double>(len);
+    double e = cur - mean + 1;
+    if (e < 1.0) e = cur;
+    eff[i] = e;
+  }
+}
+
+extern "C" void kamd_counts_to_tpm(const double* est, const double* eff, uint64_t n, double* tpm) {  // src/PlaintextWriter.cpp:5-27
+  double total = 0.0;
+  for (uint64_t i = 0; i < n; i++) { tpm[i] = est[i] / eff[i]; total += tpm[i]; }
+  for (uint64_t i = 0; i < n; i++) tpm[i] = (tpm[i] / total) * 1e6;
+}

@@ -1,0 +1,402 @@
+// kamd_index.cpp -- host side of seam S1: read a kallisto index (format v13) and flatten it into the tables the
+// gfx950 kernels consume.  Replaces KmerIndex::load (src/KmerIndex.cpp:1330-1559) for the quant path.
+//
+// What is kept from the file: the graph section's 2-bit unitigs (ext/bifrost/src/IO.tcc:1635-1738), the per-unitig
+// mosaic blocks with their transcript sets and position words (src/Node.hpp:63-72, src/BlockArray.hpp:441-471,
+// src/SparseVector.tcc:424-515), target lengths/names and the on-list.  Bifrost's minimizer index and the BooPHF blob
+// are skipped: k-mer lookup is served by our own bucketed Robin-Hood table (layout in kamd_core.h) built here by
+// enumerating every k-mer of every unitig, which reproduces CompactedDBG::find exactly because each canonical k-mer
+// occurs exactly once in a compacted de Bruijn graph.
+#include "../../include/kallisto_amd.h"
+#include "kamd_core.h"
+#include "kamd_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct Cursor {
+  const uint8_t* p; size_t n; size_t pos = 0; bool bad = false;
+  template <class T> T get() {
+    T v{};
+    if (pos + sizeof(T) > n) { bad = true; return v; }
+    memcpy(&v, p + pos, sizeof(T)); pos += sizeof(T);
+    return v;
+  }
+  const uint8_t* take(size_t len) {
+    if (pos + len > n) { bad = true; return nullptr; }
+    const uint8_t* r = p + pos; pos += len; return r;
+  }
+};
+
+// --- Roaring readers (formats: ext/bifrost/src/roaring.c:8554-8629 "native", :10555-10700 portable) -------------------
+bool roaring_portable(const uint8_t* b, size_t n, std::vector<uint32_t>& out) {
+  Cursor c{b, n};
+  uint32_t cookie = c.get<uint32_t>();
+  int32_t size; bool hasrun = false;
+  if ((cookie & 0xFFFF) == 12347) { size = (int32_t)(cookie >> 16) + 1; hasrun = true; }
+  else if (cookie == 12346) size = c.get<int32_t>();
+  else return false;
+  if (size < 0 || size > 65536) return false;
+  const uint8_t* runbm = hasrun ? c.take((size_t)(size + 7) / 8) : nullptr;
+  const uint8_t* kc = c.take((size_t)size * 4);
+  if (!hasrun || size >= 4) c.take((size_t)size * 4);
+  if (c.bad) return false;
+  for (int32_t i = 0; i < size; i++) {
+    uint16_t key, cm1; memcpy(&key, kc + 4 * i, 2); memcpy(&cm1, kc + 4 * i + 2, 2);
+    uint32_t card = (uint32_t)cm1 + 1, hi = (uint32_t)key << 16;
+    bool isrun = hasrun && (runbm[i / 8] & (1 << (i % 8)));
+    if (isrun) {
+      uint16_t nr = c.get<uint16_t>();
+      for (uint16_t r = 0; r < nr; r++) {
+        uint16_t st = c.get<uint16_t>(), ln = c.get<uint16_t>();
+        for (uint32_t x = st; x <= (uint32_t)st + ln; x++) out.push_back(hi | x);
+      }
+    } else if (card > 4096) {
+      const uint8_t* w = c.take(8192);
+      if (!w) return false;
+      for (uint32_t j = 0; j < 1024; j++) {
+        uint64_t word; memcpy(&word, w + 8 * j, 8);
+        while (word) { out.push_back(hi | (j * 64 + (uint32_t)__builtin_ctzll(word))); word &= word - 1; }
+      }
+    } else {
+      const uint8_t* a = c.take((size_t)card * 2);
+      if (!a) return false;
+      for (uint32_t j = 0; j < card; j++) { uint16_t x; memcpy(&x, a + 2 * j, 2); out.push_back(hi | x); }
+    }
+    if (c.bad) return false;
+  }
+  return true;
+}
+bool roaring_native(const uint8_t* b, size_t n, std::vector<uint32_t>& out) {
+  out.clear();
+  if (n < 1) return false;
+  if (b[0] == 1) {
+    if (n < 5) return false;
+    uint32_t card; memcpy(&card, b + 1, 4);
+    if (5 + (size_t)card * 4 > n) return false;
+    out.resize(card);
+    memcpy(out.data(), b + 5, (size_t)card * 4);
+    return true;
+  }
+  if (b[0] == 2) return roaring_portable(b + 1, n - 1, out);
+  return false;
+}
+
+struct VecHash {
+  size_t operator()(const std::vector<uint32_t>& v) const {
+    uint64_t h = 0x9e3779b97f4a7c15ULL ^ v.size();
+    for (uint32_t x : v) h = kamd::mix64(h ^ x);
+    return (size_t)h;
+  }
+};
+
+struct RawBlock { uint32_t lb, ub, ec; uint64_t pos_off; };
+
+}  // namespace
+
+struct kamd_index {
+  int32_t k = 0;
+  uint64_t n_kmers = 0, n_unitigs = 0, n_long = 0, n_short = 0, n_abund = 0, dlist_size = 0;
+  std::vector<uint32_t> unitig_len;
+  std::vector<uint64_t> unitig_blk_off;
+  std::vector<uint32_t> blk_unitig, blk_lb, blk_ub, blk_ec, blk_uec;
+  std::vector<uint64_t> blk_pos_off;
+  std::vector<uint32_t> blk_posw;
+  std::vector<uint8_t> blk_sense;
+  std::vector<uint32_t> uec_ec;
+  std::vector<uint64_t> ec_off;
+  std::vector<uint32_t> ec_ids;
+  std::vector<int32_t> target_lens;
+  std::vector<std::string> target_names;
+  std::vector<uint32_t> onlist_bits;
+  uint64_t n_buckets = 0, pad_buckets = 0;
+  std::vector<uint64_t> table;
+  std::vector<uint32_t> slot_block, slot_dist;
+};
+
+namespace {
+
+// k-mers of one unitig, MSB-first right-aligned, forward orientation; calls f(dist, fwd_value)
+template <class F>
+inline void for_each_kmer(const uint8_t* packed, uint64_t len, int k, F&& f) {
+  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  uint64_t v = 0;
+  for (uint64_t j = 0; j < len; j++) {
+    uint64_t b = (packed[j >> 2] >> ((j & 3) << 1)) & 3;  // CompressedSequence::getChar (CompressedSequence.cpp:311-314)
+    v = ((v << 2) | b) & mask;
+    if (j + 1 >= (uint64_t)k) f((uint32_t)(j + 1 - k), v);
+  }
+}
+
+}  // namespace
+
+extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) {
+  if (!out) return kamd::fail(-1, "kamd_index_load: null output pointer");
+  *out = nullptr;
+  if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min(threads, 64);
+  std::vector<uint8_t> buf;
+  {
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    if (!in) return kamd::fail(-2, std::string("index input file could not be opened: ") + path);
+    std::streamsize sz = in.tellg();
+    in.seekg(0);
+    buf.resize((size_t)sz);
+    if (!in.read((char*)buf.data(), sz)) return kamd::fail(-2, "index: short read");
+  }
+  Cursor c{buf.data(), buf.size()};
+  std::unique_ptr<kamd_index> ix(new kamd_index);
+
+  // 1. version (KmerIndex.cpp:1351-1360)
+  if (c.get<uint64_t>() != 13) return kamd::fail(-3, "incompatible index: expected version 13");
+  // 2. graph section
+  uint64_t dbg_bytes = c.get<uint64_t>() & (~0ULL >> 1);
+  size_t pos1 = c.pos;
+  if ((c.get<uint64_t>() >> 32) != 0x7e215f3fULL) return kamd::fail(-3, "index: bad graph header");
+  int32_t k = c.get<int32_t>();
+  (void)c.get<int32_t>();  // g
+  if (k < 3 || k > 31 || !(k & 1)) return kamd::fail(-3, "index: unsupported k (need odd k <= 31)");
+  ix->k = k;
+  ix->n_long = c.get<uint64_t>();
+  struct U { const uint8_t* data; uint64_t len; };
+  std::vector<U> units;
+  units.reserve(ix->n_long);
+  uint64_t n_kmers = 0;
+  for (uint64_t i = 0; i < ix->n_long; i++) {
+    uint64_t len = c.get<uint64_t>();
+    const uint8_t* d = c.take((len + 3) / 4);
+    if (c.bad || len < (uint64_t)k) return kamd::fail(-3, "index: bad unitig record");
+    units.push_back({d, len});
+    n_kmers += len - k + 1;
+  }
+  ix->n_short = c.get<uint64_t>();
+  const uint8_t* short_p = c.take(ix->n_short * 8);
+  ix->n_abund = c.get<uint64_t>();
+  const uint8_t* abund_p = c.take(ix->n_abund * 8);
+  if (c.bad) return kamd::fail(-3, "index: bad short/abundant unitig section");
+  ix->n_unitigs = ix->n_long + ix->n_short + ix->n_abund;
+  ix->n_kmers = n_kmers + ix->n_short + ix->n_abund;
+  ix->unitig_len.resize(ix->n_unitigs);
+  for (uint64_t i = 0; i < ix->n_long; i++) ix->unitig_len[i] = (uint32_t)units[i].len;
+  for (uint64_t i = ix->n_long; i < ix->n_unitigs; i++) ix->unitig_len[i] = (uint32_t)k;
+  // forward k-mer of a short/abundant unitig: stored left-aligned MSB-first (Kmer.cpp:92-107) -> right-align
+  auto single_kmer = [&](uint64_t i) -> uint64_t {
+    uint64_t raw;
+    if (i < ix->n_long + ix->n_short) memcpy(&raw, short_p + 8 * (i - ix->n_long), 8);
+    else memcpy(&raw, abund_p + 8 * (i - ix->n_long - ix->n_short), 8);
+    return raw >> (64 - 2 * k);
+  };
+  // head k-mer (forward text) -> unitig id, to attach node records (KmerIndex.cpp:1420-1428 uses dbg.find(head))
+  std::unordered_map<uint64_t, uint32_t> head_of;
+  head_of.reserve(ix->n_unitigs * 2);
+  for (uint64_t i = 0; i < ix->n_unitigs; i++) {
+    uint64_t v = 0;
+    if (i < ix->n_long) {
+      for (int j = 0; j < k; j++) v = (v << 2) | ((units[i].data[j >> 2] >> ((j & 3) << 1)) & 3);
+    } else v = single_kmer(i);
+    head_of.emplace(v, (uint32_t)i);
+    head_of.emplace(kamd::revcomp_msb(v, k), (uint32_t)i);
+  }
+  // skip minimizer index + BooPHF (KmerIndex.cpp:1368-1376)
+  c.pos = pos1 + dbg_bytes;
+  { uint64_t mphf = c.get<uint64_t>(); c.take(mphf); }
+  if (c.bad) return kamd::fail(-3, "index: bad mphf section");
+  // 2.2 D-list (KmerIndex.cpp:1386-1403)
+  ix->dlist_size = c.get<uint64_t>();
+  (void)c.get<uint64_t>();
+  c.take(ix->dlist_size * 8);
+  if (ix->dlist_size != 0) return kamd::fail(-4, "index carries a D-list: not supported by this build (SURVEY.md section 8f item 2)");
+
+  // 3. nodes
+  uint64_t n_nodes = c.get<uint64_t>();
+  std::vector<std::vector<RawBlock>> ublocks(ix->n_unitigs);
+  std::unordered_map<std::vector<uint32_t>, uint32_t, VecHash> ec_of;
+  std::vector<uint32_t> set, tmp, posw_all; std::vector<uint8_t> sense_all;
+  ix->ec_off.push_back(0);
+  for (uint64_t i = 0; i < n_nodes; i++) {
+    const uint8_t* hs = c.take((size_t)k);
+    if (!hs) return kamd::fail(-3, "index: truncated node table");
+    uint64_t head = 0;
+    for (int j = 0; j < k; j++) { uint64_t ch = hs[j]; uint64_t x = (ch & 4) >> 1; head = (head << 2) | (x + ((x ^ (ch & 2)) >> 1)); }
+    uint32_t node_size = c.get<uint32_t>();
+    size_t node_end = c.pos + node_size;
+    auto it = head_of.find(head);
+    if (it == head_of.end()) return kamd::fail(-3, "Corrupted index; unitig not found");
+    uint32_t gid = it->second;
+    (void)c.get<uint32_t>();  // Node::id: only a sort key in the reference
+    uint8_t flag = c.get<uint8_t>();
+    uint64_t nb = flag == 0 ? 0 : (flag == 1 ? 1 : c.get<uint64_t>());
+    auto& bl = ublocks[gid];
+    bl.clear();
+    for (uint64_t b = 0; b < nb; b++) {
+      RawBlock rb; rb.lb = c.get<uint32_t>(); rb.ub = c.get<uint32_t>(); rb.pos_off = posw_all.size();
+      uint64_t sz = c.get<uint64_t>();
+      const uint8_t* rp = c.take(sz);
+      if (!rp || !roaring_native(rp, sz, set)) return kamd::fail(-3, "index: bad transcript set");
+      uint64_t vsz = c.get<uint64_t>();
+      if (vsz != set.size()) return kamd::fail(-3, "index: SparseVector size mismatch");
+      for (uint64_t t = 0; t < vsz; t++) {
+        uint64_t s2 = c.get<uint64_t>();
+        const uint8_t* pp = c.take(s2);
+        if (!pp || !roaring_native(pp, s2, tmp) || tmp.empty()) return kamd::fail(-3, "index: bad position set");
+        uint32_t mn = tmp.front(), mx = tmp.back();
+        posw_all.push_back(mn);
+        bool smin = (mn & 0x7FFFFFFFu) == mn, smax = (mx & 0x7FFFFFFFu) == mx;
+        sense_all.push_back(smin != smax ? 2 : (uint8_t)smin);
+      }
+      auto ins = ec_of.emplace(set, (uint32_t)ec_of.size());
+      if (ins.second) { ix->ec_ids.insert(ix->ec_ids.end(), set.begin(), set.end()); ix->ec_off.push_back(ix->ec_ids.size()); }
+      rb.ec = ins.first->second;
+      bl.push_back(rb);
+    }
+    std::stable_sort(bl.begin(), bl.end(), [](const RawBlock& a, const RawBlock& b) { return a.lb < b.lb; });
+    if (c.bad || c.pos != node_end) return kamd::fail(-3, "index: node size mismatch");
+  }
+  // flatten blocks; assign (unitig, set) classes
+  ix->unitig_blk_off.assign(ix->n_unitigs + 1, 0);
+  for (uint64_t u = 0; u < ix->n_unitigs; u++) {
+    ix->unitig_blk_off[u] = ix->blk_lb.size();
+    auto& bl = ublocks[u];
+    if (bl.empty()) return kamd::fail(-3, "index: unitig without a node record");
+    size_t first = ix->blk_lb.size();
+    for (auto& rb : bl) {
+      uint32_t uec = 0xFFFFFFFFu;
+      for (size_t j = first; j < ix->blk_lb.size(); j++) if (ix->blk_ec[j] == rb.ec) { uec = ix->blk_uec[j]; break; }
+      if (uec == 0xFFFFFFFFu) { uec = (uint32_t)ix->uec_ec.size(); ix->uec_ec.push_back(rb.ec); }
+      ix->blk_unitig.push_back((uint32_t)u); ix->blk_lb.push_back(rb.lb); ix->blk_ub.push_back(rb.ub);
+      ix->blk_ec.push_back(rb.ec); ix->blk_uec.push_back(uec);
+      ix->blk_pos_off.push_back(ix->blk_posw.size());
+      uint64_t n = ix->ec_off[rb.ec + 1] - ix->ec_off[rb.ec];
+      ix->blk_posw.insert(ix->blk_posw.end(), posw_all.begin() + rb.pos_off, posw_all.begin() + rb.pos_off + n);
+      ix->blk_sense.insert(ix->blk_sense.end(), sense_all.begin() + rb.pos_off, sense_all.begin() + rb.pos_off + n);
+    }
+    std::vector<RawBlock>().swap(bl);
+  }
+  ix->unitig_blk_off[ix->n_unitigs] = ix->blk_lb.size();
+  ix->blk_pos_off.push_back(ix->blk_posw.size());
+  if (ix->uec_ec.size() >= kamd::NO_UEC) return kamd::fail(-3, "index: too many (unitig, set) classes");
+
+  // 4-6. targets (KmerIndex.cpp:1470-1519)
+  int32_t nt = c.get<int32_t>();
+  if (c.bad || nt < 0) return kamd::fail(-3, "index: bad target count");
+  ix->target_lens.resize((size_t)nt);
+  for (int32_t i = 0; i < nt; i++) ix->target_lens[i] = c.get<int32_t>();
+  for (int32_t i = 0; i < nt; i++) {
+    uint64_t n = c.get<uint64_t>();
+    const uint8_t* s = c.take(n);
+    if (!s) return kamd::fail(-3, "index: bad target name");
+    ix->target_names.emplace_back((const char*)s, n);
+  }
+  // 7. on-list (KmerIndex.cpp:1522-1526)
+  {
+    uint64_t n = c.get<uint64_t>();
+    const uint8_t* s = c.take(n);
+    std::vector<uint32_t> ol;
+    if (!s || !roaring_portable(s, n, ol)) return kamd::fail(-3, "index: bad on-list");
+    ix->onlist_bits.assign(((size_t)nt + 31) / 32 + 1, 0);
+    for (uint32_t t : ol) if (t < (uint32_t)nt) ix->onlist_bits[t >> 5] |= 1u << (t & 31);
+  }
+  if (c.bad) return kamd::fail(-3, "index: truncated file");
+
+  // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
+  const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers + 1) / 2);  // load factor 0.5 over 4-slot buckets
+  ix->n_buckets = nb;
+  std::vector<uint32_t> fill(nb + 1, 0);
+  auto fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data());
+  auto run_parallel = [&](auto&& body) {
+    std::vector<std::thread> th;
+    std::atomic<uint64_t> next{0};
+    const uint64_t chunk = 256;
+    for (int t = 0; t < threads; t++) th.emplace_back([&] {
+      for (;;) {
+        uint64_t s = next.fetch_add(chunk);
+        if (s >= ix->n_unitigs) break;
+        uint64_t e = std::min(ix->n_unitigs, s + chunk);
+        for (uint64_t u = s; u < e; u++) body(u);
+      }
+    });
+    for (auto& t : th) t.join();
+  };
+  auto canon_of = [&](uint64_t v, bool* fwd_is_canon) {
+    uint64_t rc = kamd::revcomp_msb(v, k);
+    *fwd_is_canon = v < rc;
+    return v < rc ? v : rc;
+  };
+  run_parallel([&](uint64_t u) {
+    auto count = [&](uint32_t, uint64_t v) { bool f; uint64_t cn = canon_of(v, &f); fill_atomic[kamd::home_bucket(cn, nb)].fetch_add(1, std::memory_order_relaxed); };
+    if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, count); else count(0, single_kmer(u));
+  });
+  // placement: keys grouped by home bucket are laid down sequentially, never before their home (Robin Hood order)
+  std::vector<uint64_t> base(nb);
+  uint64_t cursor = 0;
+  std::vector<uint8_t> cont(nb + 1, 0);
+  for (uint64_t b = 0; b < nb; b++) {
+    cursor = std::max(cursor, b * 4);
+    base[b] = cursor;
+    cursor += fill[b];
+    if (cursor > (b + 1) * 4) cont[b] = 1;
+  }
+  uint64_t total_buckets = std::max(nb, (cursor + 3) / 4) + 1;
+  ix->pad_buckets = total_buckets - nb;
+  std::vector<uint8_t> cont_all(total_buckets, 0);
+  for (uint64_t b = 0; b < nb; b++) cont_all[b] = cont[b];
+  for (uint64_t b = nb; b < total_buckets; b++) cont_all[b] = (cursor > (b + 1) * 4);
+  ix->table.assign(total_buckets * 8, 0);
+  for (uint64_t s = 0; s < total_buckets * 4; s++) ix->table[2 * s] = kamd::KEY_EMPTY;
+  ix->slot_block.assign(total_buckets * 4, 0xFFFFFFFFu);
+  ix->slot_dist.assign(total_buckets * 4, 0);
+  std::fill(fill.begin(), fill.end(), 0);
+  run_parallel([&](uint64_t u) {
+    uint64_t b0 = ix->unitig_blk_off[u], b1 = ix->unitig_blk_off[u + 1];
+    uint64_t cur = b0;
+    auto place = [&](uint32_t dist, uint64_t v) {
+      // block containing dist: BlockArray::get_block_at = last block with lb <= dist (BlockArray.hpp:306-322)
+      if (b1 - b0 > 1) { while (cur + 1 < b1 && ix->blk_lb[cur + 1] <= dist) ++cur; }
+      bool f; uint64_t cn = canon_of(v, &f);
+      uint64_t hb = kamd::home_bucket(cn, nb);
+      uint64_t slot = base[hb] + fill_atomic[hb].fetch_add(1, std::memory_order_relaxed);
+      uint32_t lb = ix->blk_lb[cur], ub = ix->blk_ub[cur];
+      uint32_t rem_f = ub - 1 - dist, rem_b = dist - lb;   // KmerIndex.cpp:1780-1789
+      ix->table[2 * slot] = cn;
+      ix->table[2 * slot + 1] = kamd::make_payload(rem_f, rem_b, ix->blk_uec[cur], f);
+      ix->slot_block[slot] = (uint32_t)cur;
+      ix->slot_dist[slot] = dist;
+    };
+    if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, place); else place(0, single_kmer(u));
+  });
+  for (uint64_t b = 0; b < total_buckets; b++) if (cont_all[b]) ix->table[8 * b] |= kamd::KEY_CONT;
+  *out = ix.release();
+  return 0;
+}
+
+extern "C" void kamd_index_free(kamd_index* ix) { delete ix; }
+
+extern "C" int kamd_index_get_view(const kamd_index* ix, kamd_index_view* v) {
+  if (!ix || !v) return kamd::fail(-1, "kamd_index_get_view: null argument");
+  memset(v, 0, sizeof *v);
+  v->k = ix->k; v->n_kmers = ix->n_kmers; v->n_unitigs = ix->n_unitigs; v->n_blocks = ix->blk_lb.size();
+  v->n_uec = ix->uec_ec.size(); v->n_ecs = ix->ec_off.size() - 1; v->ec_nnz = ix->ec_ids.size();
+  v->n_targets = ix->target_lens.size(); v->dlist_size = ix->dlist_size;
+  v->n_buckets = ix->n_buckets; v->pad_buckets = ix->pad_buckets;
+  v->table = ix->table.data(); v->slot_block = ix->slot_block.data(); v->slot_dist = ix->slot_dist.data();
+  v->uec_ec = ix->uec_ec.data(); v->ec_off = ix->ec_off.data(); v->ec_ids = ix->ec_ids.data();
+  v->unitig_blk_off = ix->unitig_blk_off.data(); v->unitig_len = ix->unitig_len.data();
+  v->blk_unitig = ix->blk_unitig.data(); v->blk_lb = ix->blk_lb.data(); v->blk_ub = ix->blk_ub.data(); v->blk_ec = ix->blk_ec.data();
+  v->blk_pos_off = ix->blk_pos_off.data(); v->blk_posw = ix->blk_posw.data(); v->blk_sense = ix->blk_sense.data();
+  v->target_lens = ix->target_lens.data(); v->onlist_bits = ix->onlist_bits.data(); v->onlist_words = ix->onlist_bits.size();
+  return 0;
+}
+
+extern "C" const char* kamd_index_target_name(const kamd_index* ix, uint64_t i) {
+  return (ix && i < ix->target_names.size()) ? ix->target_names[i].c_str() : nullptr;
+}
