@@ -123,9 +123,11 @@ int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
  * count) for items whose hits carried several sets.  Both are keyed by index set ids, which are identical on every
  * rank, so ranks merge by all-reduce(a) + all-gather(b). */
 int kamd_ec_dense_counts(kamd_ctx*, uint32_t** d_counts, uint64_t* n);            /* device pointer into the context */
-int kamd_ec_tuples_export(kamd_ctx*, uint64_t* n_words, uint64_t* n_tuples);      /* compacts; sizes for the gather */
-int kamd_ec_tuples_copy(kamd_ctx*, uint32_t* d_out_words);                         /* [count, m, e0..e(m-1)] records */
-int kamd_ec_tuples_replace(kamd_ctx*, const uint32_t* d_words, uint64_t n_words);  /* install the gathered records */
+int kamd_ec_tuples_export(kamd_ctx*, uint64_t* n_words, uint64_t* n_tuples);      /* de-duplicates; sizes for the gather */
+/* [count, m, e0..e(m-1)] records + the word offset of each record */
+int kamd_ec_tuples_copy(kamd_ctx*, uint32_t* d_out_words, uint64_t* d_out_rec_off);
+/* install gathered records (offsets rebased by the caller to the concatenated buffer) */
+int kamd_ec_tuples_replace(kamd_ctx*, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off, uint64_t n_recs);
 
 /* ---- finalize: resolve intersections, apply the on-list mask, merge equal sets ----
  * Produces the EC multiset {sorted transcript set -> count} as CSR, on device and (optionally) host. */

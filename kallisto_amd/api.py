@@ -1,0 +1,455 @@
+"""ctypes mirror of include/kallisto_amd.h plus the `quant` driver flow of the reference (src/main.cpp:2620-2798).
+
+Names follow the reference: an *index* (KmerIndex), *pseudoalignment* of read batches into equivalence-class (EC)
+counts (ProcessReads / MinCollector), the fragment-length distribution (FLD), effective lengths, the EM
+(EMAlgorithm::run) and TPM.  Everything that computes goes through libkallisto_amd.so; if the library or a GPU is
+missing the calls raise KallistoAmdError -- there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_FRAG_LEN = 1000
+
+
+class KallistoAmdError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return os.path.join(HERE, "libkallisto_amd.so")
+
+
+class _View(C.Structure):
+    _fields_ = ([("k", C.c_int32)] +
+                [(n, C.c_uint64) for n in ("n_kmers", "n_unitigs", "n_blocks", "n_uec", "n_ecs", "ec_nnz", "n_targets",
+                                           "dlist_size", "n_buckets", "pad_buckets")] +
+                [(n, C.c_void_p) for n in ("table", "slot_block", "slot_dist", "uec_ec", "ec_off", "ec_ids",
+                                           "unitig_blk_off", "unitig_len", "blk_unitig", "blk_lb", "blk_ub", "blk_ec",
+                                           "blk_pos_off", "blk_posw", "blk_sense", "target_lens", "onlist_bits")] +
+                [("onlist_words", C.c_uint64)])
+
+
+class QuantOpts(C.Structure):
+    """kamd_quant_opts: the subset of ProgramOptions (src/common.h:93-209) the hot path reads."""
+    _fields_ = [("paired", C.c_int32), ("fld", C.c_double), ("sd", C.c_double), ("single_overhang", C.c_int32),
+                ("strand", C.c_int32)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_processed", "n_single", "n_multi", "n_probes", "n_bucket_reads",
+                                          "n_distinct_tuples")]
+
+
+class _EcResult(C.Structure):
+    _fields_ = [("n_ecs", C.c_uint64), ("nnz", C.c_uint64), ("n_pseudoaligned", C.c_uint64), ("d_ec_off", C.c_void_p),
+                ("d_ec_ids", C.c_void_p), ("d_counts", C.c_void_p)]
+
+
+_LIB = None
+
+_SYMBOLS = {
+    # name: (restype, argtypes)
+    "kamd_last_error": (C.c_char_p, []),
+    "kamd_index_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "kamd_index_free": (None, [C.c_void_p]),
+    "kamd_index_get_view": (C.c_int, [C.c_void_p, C.POINTER(_View)]),
+    "kamd_index_target_name": (C.c_char_p, [C.c_void_p, C.c_uint64]),
+    "kamd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "kamd_ctx_destroy": (None, [C.c_void_p]),
+    "kamd_index_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kamd_packed_record_words": (C.c_uint64, [C.c_int32]),
+    "kamd_pack_reads_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
+                                         C.c_void_p]),
+    "kamd_pseudoalign": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
+    "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
+                                      C.POINTER(C.c_uint64)]),
+    "kamd_align_stats_get": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
+    "kamd_ec_dense_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "kamd_ec_tuples_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "kamd_ec_tuples_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kamd_ec_tuples_replace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "kamd_ec_finalize": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
+    "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "kamd_bootstrap": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32)]),
+    "kamd_mean_frag_lens_trunc": (None, [C.c_void_p, C.c_void_p]),
+    "kamd_trunc_gaussian_fld": (None, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
+    "kamd_eff_lens": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "kamd_counts_to_tpm": (None, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/kallisto_amd.h declares (used by the symbol-presence test)."""
+    return sorted(_SYMBOLS)
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise KallistoAmdError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(hipcc --offload-arch=gfx950); kallisto_amd has no CPU path")
+        lib = C.CDLL(path)
+        for name, (res, args) in _SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise KallistoAmdError(f"{what} failed ({rc}): {load_library().kamd_last_error().decode(errors='replace')}")
+
+
+def packed_record_words(max_len: int) -> int:
+    return int(load_library().kamd_packed_record_words(max_len))
+
+
+def _np(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=int(n))
+
+
+class Index:
+    """Flattened kallisto index (format v13).  Mirrors KmerIndex::load (src/KmerIndex.cpp:1330)."""
+
+    def __init__(self, path: str, threads: int = 0):
+        lib = load_library()
+        self._h = C.c_void_p()
+        _check(lib.kamd_index_load(os.fsencode(path), threads, C.byref(self._h)), "kamd_index_load")
+        self.view = _View()
+        _check(lib.kamd_index_get_view(self._h, C.byref(self.view)), "kamd_index_get_view")
+        v = self.view
+        self.k = v.k
+        self.num_kmers, self.num_unitigs, self.num_blocks = v.n_kmers, v.n_unitigs, v.n_blocks
+        self.num_ecs, self.num_targets = v.n_ecs, v.n_targets
+        self.target_lens = _np(v.target_lens, v.n_targets, np.int32).copy()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def target_names(self):
+        lib = load_library()
+        return [lib.kamd_index_target_name(self._h, i).decode() for i in range(self.num_targets)]
+
+    def ec_sets(self):
+        """(ec_off, ec_ids) of the de-duplicated index transcript sets (host views)."""
+        v = self.view
+        return _np(v.ec_off, v.n_ecs + 1, np.uint64), _np(v.ec_ids, v.ec_nnz, np.uint32)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().kamd_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class ECs:
+    """EC multiset {sorted transcript set -> count} as CSR (index.ecmapinv x MinCollector::counts)."""
+    ec_off: np.ndarray
+    ec_ids: np.ndarray
+    counts: np.ndarray
+
+    def multiset(self):
+        return {tuple(self.ec_ids[self.ec_off[i]:self.ec_off[i + 1]].tolist()): int(self.counts[i])
+                for i in range(len(self.counts))}
+
+
+class Context:
+    """One GPU: device copy of the index and the EC state.  All work runs on torch's current stream of `device`."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise KallistoAmdError("no GPU visible: kallisto_amd has no CPU path")
+        self.torch = torch
+        self.device = device
+        torch.cuda.set_device(device)
+        self.stream = torch.cuda.current_stream(device)
+        self._h = C.c_void_p()
+        _check(load_library().kamd_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(self._h)), "kamd_ctx_create")
+        self.index = None
+
+    def upload(self, index: Index):
+        _check(load_library().kamd_index_upload(self._h, index.handle), "kamd_index_upload")
+        self.index = index
+
+    # ---- reads ----
+    def pack_reads(self, seqs_u8, max_len: int | None = None):
+        """(n_reads, L) uint8 ASCII tensor on the device -> (words, lens) packed records (kamd_pack_reads_device)."""
+        torch = self.torch
+        assert seqs_u8.dtype == torch.uint8 and seqs_u8.is_cuda and seqs_u8.dim() == 2
+        seqs_u8 = seqs_u8.contiguous()
+        n, L = seqs_u8.shape
+        max_len = max_len or L
+        rec = packed_record_words(max_len)
+        off = torch.arange(n, device=seqs_u8.device, dtype=torch.int64) * L
+        ln = torch.full((n,), L, device=seqs_u8.device, dtype=torch.int32)
+        words = torch.empty(n * rec, device=seqs_u8.device, dtype=torch.int32)
+        lens = torch.empty(n, device=seqs_u8.device, dtype=torch.int16)
+        _check(load_library().kamd_pack_reads_device(self._h, seqs_u8.data_ptr(), off.data_ptr(), ln.data_ptr(), n, max_len,
+                                                     words.data_ptr(), lens.data_ptr()), "kamd_pack_reads_device")
+        return words, lens
+
+    def pack_reads_host(self, seqs, max_len: int | None = None):
+        """list of bytes -> packed device tensors through the host packer (kamd_pack_reads_host)."""
+        torch = self.torch
+        n = len(seqs)
+        lens = np.array([len(s) for s in seqs], np.int32)
+        max_len = max_len or int(lens.max(initial=1))
+        off = np.zeros(n, np.uint64)
+        if n:
+            off[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+        buf = b"".join(seqs)
+        rec = packed_record_words(max_len)
+        words = np.zeros(n * rec, np.uint32)
+        l16 = np.zeros(n, np.uint16)
+        _check(load_library().kamd_pack_reads_host(buf, off.ctypes.data, lens.ctypes.data, n, max_len, words.ctypes.data,
+                                                   l16.ctypes.data), "kamd_pack_reads_host")
+        dw = torch.from_numpy(words.view(np.int32)).to(f"cuda:{self.device}")
+        dl = torch.from_numpy(l16.view(np.int16)).to(f"cuda:{self.device}")
+        return dw, dl, max_len
+
+    # ---- pseudoalignment ----
+    def pseudoalign(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
+        _check(load_library().kamd_pseudoalign(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len),
+               "kamd_pseudoalign")
+
+    def fld_from_batch(self, words, lens, n_items: int, max_len: int):
+        flens = np.zeros(MAX_FRAG_LEN, np.uint32)
+        used = C.c_uint64(0)
+        _check(load_library().kamd_fld_from_batch(self._h, words.data_ptr(), lens.data_ptr(), n_items, max_len,
+                                                  flens.ctypes.data, C.byref(used)), "kamd_fld_from_batch")
+        return flens, int(used.value)
+
+    def stats(self) -> dict:
+        s = _Stats()
+        _check(load_library().kamd_align_stats_get(self._h, C.byref(s)), "kamd_align_stats_get")
+        return {n: int(getattr(s, n)) for n, _ in _Stats._fields_}
+
+    # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
+    def dense_counts(self):
+        """The dense per-index-set count vector as a torch tensor aliasing the context's device memory."""
+        torch = self.torch
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(load_library().kamd_ec_dense_counts(self._h, C.byref(p), C.byref(n)), "kamd_ec_dense_counts")
+        return _alias_tensor(torch, p.value, int(n.value), torch.int32, self.device)
+
+    def tuples_export(self):
+        torch = self.torch
+        nw, nt = C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().kamd_ec_tuples_export(self._h, C.byref(nw), C.byref(nt)), "kamd_ec_tuples_export")
+        words = torch.zeros(max(int(nw.value), 1), dtype=torch.int32, device=f"cuda:{self.device}")
+        offs = torch.zeros(max(int(nt.value), 1), dtype=torch.int64, device=f"cuda:{self.device}")
+        _check(load_library().kamd_ec_tuples_copy(self._h, words.data_ptr(), offs.data_ptr()), "kamd_ec_tuples_copy")
+        return words[:int(nw.value)], offs[:int(nt.value)]
+
+    def tuples_replace(self, words, offs):
+        _check(load_library().kamd_ec_tuples_replace(self._h, words.data_ptr() if words.numel() else None, words.numel(),
+                                                     offs.data_ptr() if offs.numel() else None, offs.numel()),
+               "kamd_ec_tuples_replace")
+
+    def allreduce_ec_counts(self, group=None):
+        """Merge the EC state of all ranks (MasterProcessor::update's locked `tc.counts[i] += c[i]`,
+        src/ProcessReads.cpp:424-499): one RCCL all-reduce of the dense count vector over xGMI plus an all-gather of
+        the (tuple of index set ids, count) records, whose keys are identical on every rank."""
+        import torch.distributed as dist
+        torch = self.torch
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        world = dist.get_world_size(group)
+        dense = self.dense_counts()
+        dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
+        words, offs = self.tuples_export()
+        sizes = torch.tensor([words.numel(), offs.numel()], dtype=torch.int64, device=words.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        all_sizes = torch.stack(all_sizes).cpu()
+        mw, mo = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+        pw = torch.zeros(max(mw, 1), dtype=torch.int32, device=words.device)
+        po = torch.zeros(max(mo, 1), dtype=torch.int64, device=words.device)
+        pw[:words.numel()] = words
+        po[:offs.numel()] = offs
+        gw = [torch.empty_like(pw) for _ in range(world)]
+        go = [torch.empty_like(po) for _ in range(world)]
+        dist.all_gather(gw, pw, group=group)
+        dist.all_gather(go, po, group=group)
+        cat_w, cat_o, base = [], [], 0
+        for r in range(world):
+            nw, no = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+            cat_w.append(gw[r][:nw])
+            cat_o.append(go[r][:no] + base)
+            base += nw
+        self.tuples_replace(torch.cat(cat_w).contiguous(), torch.cat(cat_o).contiguous())
+
+    # ---- finalize / EM ----
+    def finalize(self, download: bool = True):
+        res = _EcResult()
+        _check(load_library().kamd_ec_finalize(self._h, C.byref(res)), "kamd_ec_finalize")
+        self.ec_result = res
+        if not download:
+            return None
+        ec_off = np.zeros(res.n_ecs + 1, np.uint64)
+        ec_ids = np.zeros(max(res.nnz, 1), np.uint32)
+        counts = np.zeros(max(res.n_ecs, 1), np.uint32)
+        _check(load_library().kamd_ec_download(self._h, ec_off.ctypes.data, ec_ids.ctypes.data, counts.ctypes.data),
+               "kamd_ec_download")
+        return ECs(ec_off, ec_ids[:res.nnz], counts[:res.n_ecs])
+
+    def em_run(self, eff_lens: np.ndarray, n_iter: int = 10000, min_rounds: int = 50, csr=None):
+        """EMAlgorithm(counts, ...).run(n_iter, min_rounds) on the finalized ECs (or on a device CSR triple)."""
+        eff = np.ascontiguousarray(eff_lens, np.float64)
+        T = len(eff)
+        alpha = np.zeros(T, np.float64)
+        abz = np.zeros(T, np.float64)
+        rounds = C.c_int32(0)
+        if csr is None:
+            args = (None, None, None, 0)
+        else:
+            off, ids, cnt = csr
+            args = (off.data_ptr(), ids.data_ptr(), cnt.data_ptr(), cnt.numel())
+        _check(load_library().kamd_em_run(self._h, *args, eff.ctypes.data, T, n_iter, min_rounds, alpha.ctypes.data,
+                                          abz.ctypes.data, C.byref(rounds)), "kamd_em_run")
+        return alpha, abz, int(rounds.value)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().kamd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _alias_tensor(torch, ptr: int, n: int, dtype, device: int):
+    """torch tensor over device memory owned by the library (no copy) via __cuda_array_interface__."""
+    class _Holder:
+        pass
+    h = _Holder()
+    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device=f"cuda:{device}")
+
+
+# ---- host-side FP64 helpers (bit-exact with the reference) ------------------------------------------------------------
+
+def mean_frag_lens_trunc(flens: np.ndarray) -> np.ndarray:
+    fl = np.ascontiguousarray(flens, np.uint32)
+    out = np.zeros(MAX_FRAG_LEN, np.float64)
+    load_library().kamd_mean_frag_lens_trunc(fl.ctypes.data, out.ctypes.data)
+    return out
+
+
+def trunc_gaussian_fld(mean: float, sd: float) -> np.ndarray:
+    out = np.zeros(MAX_FRAG_LEN, np.float64)
+    load_library().kamd_trunc_gaussian_fld(0, MAX_FRAG_LEN, mean, sd, out.ctypes.data)
+    return out
+
+
+def eff_lens(target_lens: np.ndarray, mean_fl_trunc: np.ndarray) -> np.ndarray:
+    tl = np.ascontiguousarray(target_lens, np.int32)
+    t = np.ascontiguousarray(mean_fl_trunc, np.float64)
+    out = np.zeros(len(tl), np.float64)
+    load_library().kamd_eff_lens(tl.ctypes.data, len(tl), t.ctypes.data, out.ctypes.data)
+    return out
+
+
+def counts_to_tpm(est_counts: np.ndarray, eff: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(est_counts, np.float64)
+    e = np.ascontiguousarray(eff, np.float64)
+    out = np.zeros(len(a), np.float64)
+    load_library().kamd_counts_to_tpm(a.ctypes.data, e.ctypes.data, len(a), out.ctypes.data)
+    return out
+
+
+@dataclass
+class QuantResult:
+    n_processed: int
+    n_pseudoaligned: int
+    n_unique: int
+    ecs: ECs | None
+    flens: np.ndarray
+    eff_lens: np.ndarray
+    est_counts: np.ndarray
+    alpha_before_zeroes: np.ndarray
+    tpm: np.ndarray
+    em_rounds: int
+    stats: dict = field(default_factory=dict)
+
+
+def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, group=None) -> QuantResult:
+    """The `kallisto quant` flow (src/main.cpp:2654-2730) over device-resident read batches.
+
+    batches: iterable of (words, lens, n_items, max_len).  With torch.distributed initialised, every rank passes its
+    own shard of the reads; EC counts are merged with one all-reduce + all-gather before the EM, which every rank runs.
+    """
+    index = ctx.index
+    batches = list(batches)
+    n_proc = 0
+    for words, lens, n_items, max_len in batches:
+        ctx.pseudoalign(opts, words, lens, n_items, max_len)
+        n_proc += n_items
+    # FLD: estimated from the first 10000 qualifying pairs of the input (rank 0's first batch) or given by -l/-s
+    if opts.fld == 0.0:
+        words, lens, n_items, max_len = batches[0]
+        flens, _ = ctx.fld_from_batch(words, lens, n_items, max_len)
+        if group is not None or _dist_on():
+            flens = _broadcast_np(ctx, flens, group)
+        mft = mean_frag_lens_trunc(flens)
+    else:
+        flens = np.zeros(MAX_FRAG_LEN, np.uint32)
+        mft = trunc_gaussian_fld(opts.fld, opts.sd)
+    ctx.allreduce_ec_counts(group)
+    ecs = ctx.finalize(download=download_ecs)
+    eff = eff_lens(index.target_lens, mft)
+    alpha, abz, rounds = ctx.em_run(eff)
+    tpm = counts_to_tpm(alpha, eff)
+    n_aln = n_uniq = 0
+    if ecs is not None:
+        n_aln = int(ecs.counts.sum(dtype=np.uint64))
+        sizes = np.diff(ecs.ec_off.astype(np.int64))
+        n_uniq = int(ecs.counts[sizes == 1].sum(dtype=np.uint64))
+    return QuantResult(n_proc, n_aln, n_uniq, ecs, flens, eff, alpha, abz, tpm, rounds, ctx.stats())
+
+
+def _dist_on() -> bool:
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        return False
+
+
+def _broadcast_np(ctx: Context, arr: np.ndarray, group=None) -> np.ndarray:
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(arr.astype(np.int64)).to(f"cuda:{ctx.device}")
+    dist.broadcast(t, src=0, group=group)
+    return t.cpu().numpy().astype(arr.dtype)

@@ -1,0 +1,1051 @@
+// kamd_kernels.hip -- gfx950 (MI355X) kernels and device-side driver of libkallisto_amd.so.
+//
+// Kernel A  k_pseudoalign   one work-item per read / read pair: 2-bit packed reads staged in LDS, k-mer probes into the
+//                           bucketed Robin-Hood table in HBM (one 64-byte line per probe), KmerIndex::match jump logic,
+//                           per-item list of distinct transcript-set ids kept in LDS; single-set items bump a dense count
+//                           vector, multi-set items are appended to a tuple stream with one wave-aggregated allocation
+//                           (prefix sum across the wavefront).
+//           k_rec_insert / k_rec_verify   exact, wait-free de-duplication of variable-length records (tuples of set ids,
+//                           later whole transcript sets): 64-bit tag CAS + owner = smallest record, then content
+//                           verification against the owner; mismatching tags retry under another seed.
+//           k_resolve       one wavefront per distinct tuple: sorted-set intersection with ballot + popcount prefix
+//                           compaction, on-list mask applied (MinCollector::intersectKmers, ProcessReads.cpp:1072).
+// Kernel B  k_em_*          EM E/M steps over the EC x transcript CSR (EMAlgorithm::run), FP64.
+//
+// The per-item semantics live in kamd_core.h (shared with the CPU emulation used by the tests).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kallisto_amd.h"
+#include "kamd_core.h"
+#include "kamd_host.h"
+
+#define HIPC(x)                                                                                   \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess) return kamd::fail(-100, std::string(#x) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int BLOCK = 256;
+constexpr int TUPLE_CAP = 16;        // distinct set ids kept in LDS per item; more -> overflow kernel
+constexpr int TUPLE_CAP_BIG = 1024;  // per-item capacity of the overflow kernel (global scratch)
+
+struct DevIndex {
+  const u64* table; u64 n_buckets;
+  const u32* slot_block; const u32* slot_dist;
+  const u32* uec_ec;
+  const u64* ec_off; const u32* ec_ids; const uint8_t* ec_nonempty;
+  const u32* onlist_bits;
+  u64 n_ecs; int k;
+};
+
+// device-resident cursors and statistics
+struct DevState {
+  u64 stream_words, n_recs, n_overflow, n_retry;
+  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads;
+  u64 n_list, bound_words;       // generic append cursor / size bound accumulator
+  u64 cand_words, cand_recs;     // candidate transcript-set stream
+};
+
+struct TSlot { u64 tag, owner, count; };
+
+// ------------------------------------------------------------------------------------------------------------------
+// wavefront helpers (64 lanes)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, d, 64); if (lane_id() >= d) v += t; }
+  return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ u64 rec_hash(const u32* w, u32 n, u64 seed) {
+  u64 h = kamd::mix64(seed ^ (0x9e3779b97f4a7c15ULL * (n + 1)));
+  for (u32 i = 0; i < n; i++) h = kamd::mix64(h ^ w[i]);
+  return h | 1ULL;  // 0 is the empty tag
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel A
+// ------------------------------------------------------------------------------------------------------------------
+struct AlignOut {
+  u32* dense_counts;   // [n_ecs]
+  u32* stream;         // records [cnt, m, e0..e(m-1)]
+  u64* rec_off;        // word offset of each record
+  u64* overflow_items; // item indices for the overflow kernel
+  DevState* st;
+};
+
+template <bool PAIRED>
+__global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* __restrict__ words,
+                                                       const uint16_t* __restrict__ lens, u64 n_items, int seq_words,
+                                                       int rec_words, AlignOut out) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const int item_words = rec_words * (PAIRED ? 2 : 1);
+  u32* lds_reads = lds;
+  u32* lds_ecs = lds + (size_t)BLOCK * item_words;
+  const u64 item0 = (u64)blockIdx.x * BLOCK;
+  const int n_valid = (int)min((u64)BLOCK, n_items - item0);
+  // stage this block's packed reads: one contiguous, 16-byte aligned region of HBM -> LDS
+  {
+    const u32* src = words + item0 * item_words;
+    const int total = n_valid * item_words;
+    const int nvec = total >> 2;
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);
+    uint4* dst4 = reinterpret_cast<uint4*>(lds_reads);
+    for (int i = threadIdx.x; i < nvec; i += BLOCK) dst4[i] = src4[i];
+    for (int i = (nvec << 2) + threadIdx.x; i < total; i += BLOCK) lds_reads[i] = src[i];
+  }
+  __syncthreads();
+
+  const int tid = threadIdx.x;
+  const bool active = tid < n_valid;
+  kamd::EcList ecs; ecs.e = lds_ecs + tid * TUPLE_CAP; ecs.cap = TUPLE_CAP; ecs.n = 0; ecs.overflow = false;
+  kamd::MateInfo m0, m1;
+  m0.n_hits = m1.n_hits = 0; m0.n_nonempty = m1.n_nonempty = 0; m0.probes = m1.probes = 0; m0.bucket_reads = m1.bucket_reads = 0;
+  if (active) {
+    kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+    const u64 item = item0 + tid;
+    const u32* rec = lds_reads + tid * item_words;
+    kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
+    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
+    if (PAIRED) {
+      kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
+      kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+    }
+  }
+  // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow
+  int kind = 0;
+  if (active) {
+    if (ecs.overflow) kind = 3;
+    else if (kamd::pair_is_mapped(m0, m1)) kind = ecs.n == 1 ? 1 : 2;
+  }
+  if (kind == 1) atomicAdd(&out.dense_counts[ecs.e[0]], 1u);
+  // tuple stream: one allocation per wavefront (prefix sum of record sizes across the lanes)
+  const u32 need = kind == 2 ? (u32)ecs.n + 2u : 0u;
+  const u32 incl = wave_incl_scan(need);
+  const u32 wave_total = __shfl(incl, 63, 64);
+  const u64 multi_mask = __ballot(kind == 2);
+  u64 base_words = 0, base_recs = 0;
+  if (wave_total) {
+    if (lane_id() == 0) {
+      base_words = atomicAdd(&out.st->stream_words, (u64)wave_total);
+      base_recs = atomicAdd(&out.st->n_recs, (u64)__popcll(multi_mask));
+    }
+    base_words = __shfl(base_words, 0, 64);
+    base_recs = __shfl(base_recs, 0, 64);
+    if (kind == 2) {
+      const u64 off = base_words + (incl - need);
+      const u64 ridx = base_recs + (u64)__popcll(multi_mask & ((1ULL << lane_id()) - 1));
+      u32* w = out.stream + off;
+      w[0] = 1u; w[1] = (u32)ecs.n;
+      for (int i = 0; i < ecs.n; i++) w[2 + i] = ecs.e[i];
+      out.rec_off[ridx] = off;
+    }
+  }
+  if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item0 + tid; }
+  // statistics: one atomic per wavefront and counter
+  u64 s_probes = wave_sum64((u64)(m0.probes + m1.probes));
+  u64 s_reads = wave_sum64((u64)(m0.bucket_reads + m1.bucket_reads));
+  u64 s_single = (u64)__popcll(__ballot(kind == 1));
+  u64 s_multi = (u64)__popcll(multi_mask);
+  u64 s_proc = (u64)__popcll(__ballot(active));
+  if (lane_id() == 0) {
+    atomicAdd(&out.st->st_probes, s_probes);
+    atomicAdd(&out.st->st_bucket_reads, s_reads);
+    if (s_single) atomicAdd(&out.st->st_single, s_single);
+    if (s_multi) atomicAdd(&out.st->st_multi, s_multi);
+    atomicAdd(&out.st->st_processed, s_proc);
+  }
+}
+
+// items whose hits carried more than TUPLE_CAP distinct sets: same logic, lists in global scratch, reads from HBM
+template <bool PAIRED>
+__global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const u32* __restrict__ words,
+                                                             const uint16_t* __restrict__ lens, const u64* items, u64 n,
+                                                             int seq_words, int rec_words, u32* scratch, AlignOut out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 item = items[i];
+  const int item_words = rec_words * (PAIRED ? 2 : 1);
+  kamd::EcList ecs; ecs.e = scratch + i * TUPLE_CAP_BIG; ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
+  kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0;
+  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const u32* rec = words + item * item_words;
+  kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
+  if (PAIRED) {
+    kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
+    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+  }
+  if (ecs.overflow || !kamd::pair_is_mapped(m0, m1)) return;  // > TUPLE_CAP_BIG distinct sets cannot occur for 16-bit read lengths
+  u64 off = atomicAdd(&out.st->stream_words, (u64)ecs.n + 2);
+  u64 ridx = atomicAdd(&out.st->n_recs, 1ULL);
+  u32* w = out.stream + off;
+  w[0] = 1u; w[1] = (u32)ecs.n;
+  for (int j = 0; j < ecs.n; j++) w[2 + j] = ecs.e[j];
+  out.rec_off[ridx] = off;
+  atomicAdd(&out.st->st_multi, 1ULL);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// exact de-duplication of records [cnt, n, w0..w(n-1)]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_table_init(TSlot* t, u64 cap) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) { t[i].tag = 0; t[i].owner = ~0ULL; t[i].count = 0; }
+}
+// idx == nullptr: records r0..r0+n-1 ; else records idx[0..n-1]
+__global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restrict__ rec_off, const u64* __restrict__ idx,
+                             u64 r0, u64 n, TSlot* table, u64 mask, u64 seed, u64* rec_slot) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 r = idx ? idx[i] : r0 + i;
+  const u64 off = rec_off[r];
+  const u32 m = stream[off + 1];
+  const u64 tag = rec_hash(stream + off + 1, m + 1, seed);
+  u64 s = (tag >> 1) & mask;
+  for (;;) {
+    u64 old = atomicCAS(&table[s].tag, 0ULL, tag);
+    if (old == 0ULL || old == tag) break;
+    s = (s + 1) & mask;
+  }
+  atomicMin(&table[s].owner, off);
+  rec_slot[r] = s;
+}
+__global__ void k_rec_verify(const u32* __restrict__ stream, const u64* __restrict__ rec_off, const u64* __restrict__ idx,
+                             u64 r0, u64 n, TSlot* table, const u64* __restrict__ rec_slot, u64* retry, DevState* st) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 r = idx ? idx[i] : r0 + i;
+  const u64 off = rec_off[r];
+  const u64 s = rec_slot[r];
+  const u64 own = table[s].owner;
+  const u32 m = stream[off + 1];
+  bool same = stream[own + 1] == m;
+  for (u32 j = 0; same && j < m; j++) same = stream[own + 2 + j] == stream[off + 2 + j];
+  if (same) atomicAdd(&table[s].count, (u64)stream[off]);
+  else { u64 k = atomicAdd(&st->n_retry, 1ULL); retry[k] = r; }
+}
+// list the owners (one per distinct record) of a table
+__global__ void k_table_list(const TSlot* table, u64 cap, u64* list, DevState* st) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  if (table[i].tag != 0 && table[i].count != 0) { u64 k = atomicAdd(&st->n_list, 1ULL); list[k] = i; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// resolve: candidates = transcript sets of (a) index sets with a non-zero dense count, (b) distinct tuples
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool onlisted(const u32* bits, u32 t) { return (bits[t >> 5] >> (t & 31)) & 1u; }
+__device__ __forceinline__ bool set_contains(const u32* ids, u32 n, u32 x) {
+  u32 lo = 0, hi = n;
+  while (lo < hi) { u32 mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
+  return lo < n && ids[lo] == x;
+}
+// upper bound of the candidate stream size: sum over candidates of (smallest list + 2)
+__global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n,
+                               DevState* st) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b = 0;
+  if (i < n) {
+    const u64 off = table[list[i]].owner;
+    const u32 m = stream[off + 1];
+    u64 mn = ~0ULL;
+    for (u32 j = 0; j < m; j++) { u32 e = stream[off + 2 + j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; mn = sz < mn ? sz : mn; }
+    b = mn + 2;
+  }
+  b = wave_sum64(b);
+  if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
+}
+__global__ void k_bound_singles(DevIndex ix, const u32* __restrict__ dense, DevState* st) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b = 0;
+  if (e < ix.n_ecs && dense[e]) b = ix.ec_off[e + 1] - ix.ec_off[e] + 2;
+  b = wave_sum64(b);
+  if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
+}
+// (a) one thread per index set with a count: copy its on-listed members as a candidate record
+__global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, u32* cand, u64* cand_off, DevState* st) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ix.n_ecs || dense[e] == 0) return;
+  const u32* ids = ix.ec_ids + ix.ec_off[e];
+  const u32 n = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]);
+  u32 keep = 0;
+  for (u32 j = 0; j < n; j++) keep += onlisted(ix.onlist_bits, ids[j]);
+  if (keep == 0) return;
+  u64 off = atomicAdd(&st->cand_words, (u64)keep + 2);
+  u64 r = atomicAdd(&st->cand_recs, 1ULL);
+  u32* w = cand + off;
+  w[0] = dense[e]; w[1] = keep;
+  u32 o = 0;
+  for (u32 j = 0; j < n; j++) if (onlisted(ix.onlist_bits, ids[j])) w[2 + o++] = ids[j];
+  cand_off[r] = off;
+}
+// (b) one wavefront per distinct tuple: intersect the m sorted sets; 64 candidates of the smallest set per step,
+//     membership by binary search in the others, survivors compacted with ballot + popcount prefix
+__global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
+                                                   const u64* list, u64 n, u32* cand, u64* cand_off, DevState* st) {
+  const u64 wid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wid >= n) return;
+  const int lane = lane_id();
+  const TSlot sl = table[list[wid]];
+  const u64 off = sl.owner;
+  const u32 m = stream[off + 1];
+  const u32* es = stream + off + 2;
+  // smallest set drives
+  u32 best = 0; u64 best_sz = ~0ULL;
+  for (u32 j = 0; j < m; j++) { u32 e = es[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
+  const u32* base = ix.ec_ids + ix.ec_off[es[best]];
+  const u32 nb = (u32)best_sz;
+  u64 out_off = 0;
+  u32 total = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    u32 written = 0;
+    for (u32 c0 = 0; c0 < nb; c0 += 64) {
+      const u32 c = c0 + lane;
+      bool ok = c < nb;
+      u32 x = ok ? base[c] : 0;
+      if (ok) ok = onlisted(ix.onlist_bits, x);
+      for (u32 j = 0; j < m; j++) {
+        if (j == best) continue;
+        const u32 e = es[j];
+        if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+      }
+      const u64 bal = __ballot(ok);
+      if (pass == 1 && ok) cand[out_off + 2 + written + __popcll(bal & ((1ULL << lane) - 1))] = x;
+      written += (u32)__popcll(bal);
+    }
+    if (pass == 0) {
+      total = written;
+      if (total == 0) return;  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
+      if (lane == 0) {
+        out_off = atomicAdd(&st->cand_words, (u64)total + 2);
+        u64 r = atomicAdd(&st->cand_recs, 1ULL);
+        cand[out_off] = (u32)sl.count; cand[out_off + 1] = total;
+        cand_off[r] = out_off;
+      }
+      out_off = __shfl(out_off, 0, 64);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// exclusive scan of u32 sizes into u64 offsets (three kernels; sizes up to 2^31 elements)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SCAN_ELEMS = 2048;  // per block: 256 threads x 8
+__global__ __launch_bounds__(BLOCK) void k_scan_local(const u32* __restrict__ in, u64 n, u64* out, u64* block_sums) {
+  __shared__ u64 wsum[BLOCK / 64];
+  const u64 b0 = (u64)blockIdx.x * SCAN_ELEMS + (u64)threadIdx.x * 8;
+  u64 v[8]; u64 run = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { u64 x = (b0 + j < n) ? in[b0 + j] : 0; v[j] = run; run += x; }
+  // scan of per-thread totals across the block
+  u64 incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += t; }
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 63) wsum[w] = incl;
+  __syncthreads();
+  u64 woff = 0;
+  for (int j = 0; j < w; j++) woff += wsum[j];
+  const u64 excl = woff + incl - run;
+#pragma unroll
+  for (int j = 0; j < 8; j++) if (b0 + j < n) out[b0 + j] = excl + v[j];
+  if (threadIdx.x == BLOCK - 1) block_sums[blockIdx.x] = woff + incl;
+}
+__global__ void k_scan_blocks(u64* block_sums, u64 nblocks, u64* total) {  // single thread block, serial over chunks
+  if (threadIdx.x == 0) {
+    u64 run = 0;
+    for (u64 i = 0; i < nblocks; i++) { u64 x = block_sums[i]; block_sums[i] = run; run += x; }
+    *total = run;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_scan_add(u64* out, u64 n, const u64* block_sums) {
+  const u64 b0 = (u64)blockIdx.x * SCAN_ELEMS + (u64)threadIdx.x * 8;
+  const u64 add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; j++) if (b0 + j < n) out[b0 + j] += add;
+}
+
+// final CSR from the distinct candidate sets
+__global__ void k_final_sizes(const u32* __restrict__ cand, const TSlot* table, const u64* list, u64 n, u32* sizes) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sizes[i] = cand[table[list[i]].owner + 1];
+}
+__global__ void k_final_write(const u32* __restrict__ cand, const TSlot* table, const u64* list, u64 n, const u64* ec_off,
+                              u32* ec_ids, u32* counts) {
+  const u64 wid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wid >= n) return;
+  const TSlot sl = table[list[wid]];
+  const u32 sz = cand[sl.owner + 1];
+  const u64 o = ec_off[wid];
+  for (u32 j = lane_id(); j < sz; j += 64) ec_ids[o + j] = cand[sl.owner + 2 + j];
+  if (lane_id() == 0) counts[wid] = (u32)sl.count;
+}
+__global__ void k_set_last(u64* ec_off, u64 n, const u64* total) { if (threadIdx.x == 0 && blockIdx.x == 0) ec_off[n] = *total; }
+
+// export of distinct tuple records for the multi-GPU exchange
+__global__ void k_tuple_export_size(const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n, DevState* st) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 b = 0;
+  if (i < n) b = (u64)stream[table[list[i]].owner + 1] + 2;
+  b = wave_sum64(b);
+  if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
+}
+// records are self-delimiting only from the start of a buffer, so the exporter also emits their word offsets
+__global__ void k_tuple_export_offsets(const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n, u32* out,
+                                       u64* out_off, DevState* st) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const TSlot sl = table[list[i]];
+  const u32 m = stream[sl.owner + 1];
+  u64 off = atomicAdd(&st->cand_words, (u64)m + 2);
+  u64 r = atomicAdd(&st->cand_recs, 1ULL);
+  out[off] = (u32)sl.count; out[off + 1] = m;
+  for (u32 j = 0; j < m; j++) out[off + 2 + j] = stream[sl.owner + 2 + j];
+  out_off[r] = off;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FLD probe kernel: per item the fragment length KmerIndex::mapPair would return and |u| (first items only)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
+                                               u64 n_items, int seq_words, int rec_words, u32* scratch, int32_t* tl_out,
+                                               u32* card_out) {
+  u64 item = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  const int item_words = rec_words * 2;
+  kamd::EcList ecs; ecs.e = scratch + item * TUPLE_CAP_BIG; ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
+  kamd::MateInfo m0, m1;
+  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const u32* rec = words + item * item_words;
+  kamd::ReadView r0{rec, rec + seq_words, (int)lens[2 * item]};
+  kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+  int32_t tl = -1; u32 card = 0;
+  if (!ecs.overflow && kamd::pair_is_mapped(m0, m1)) {
+    // |u| : thread-serial intersection size (first items only, tiny)
+    u32 best = 0; u64 best_sz = ~0ULL;
+    for (int j = 0; j < ecs.n; j++) { u32 e = ecs.e[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = (u32)j; } }
+    const u32* base = ix.ec_ids + ix.ec_off[ecs.e[best]];
+    for (u32 c = 0; c < (u32)best_sz; c++) {
+      u32 x = base[c];
+      bool ok = onlisted(ix.onlist_bits, x);
+      for (int j = 0; ok && j < ecs.n; j++) {
+        if ((u32)j == best) continue;
+        u32 e = ecs.e[j];
+        ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+      }
+      card += ok;
+    }
+    if (m0.n_hits > 0 && m1.n_hits > 0) {  // KmerIndex::mapPair (KmerIndex.cpp:1622-1693) on the first present k-mers
+      const u32 b0 = ix.slot_block[m0.first_slot], b1 = ix.slot_block[m1.first_slot];
+      if (b0 == b1 && (m0.first_strand != m1.first_strand)) {  // same unitig + same set + same block end <=> same block
+        const int d0 = (int)ix.slot_dist[m0.first_slot], d1 = (int)ix.slot_dist[m1.first_slot];
+        const int p1 = m0.first_strand ? d0 - m0.first_pos : d0 + ix.k + m0.first_pos;
+        const int p2 = m1.first_strand ? d1 - m1.first_pos : d1 + ix.k + m1.first_pos;
+        tl = p1 > p2 ? p1 - p2 : p2 - p1;
+      }
+    }
+  }
+  tl_out[item] = tl; card_out[item] = card;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// read packer (ASCII -> 2-bit + non-ACGT mask), one thread per output word
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restrict__ off, const int32_t* __restrict__ len,
+                             u64 n_reads, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 r = gid / (u64)rec_words;
+  int w = (int)(gid % (u64)rec_words);
+  if (r >= n_reads) return;
+  const char* s = seqs + off[r];
+  const int L = len[r];
+  u32 v = 0;
+  if (w < seq_words) {
+    for (int j = 0; j < 16; j++) {
+      int i = w * 16 + j;
+      if (i >= L) break;
+      unsigned char ch = (unsigned char)s[i] & 0xDF;
+      u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
+      v |= code << (2 * j);
+    }
+  } else {
+    const int mw = w - seq_words;
+    for (int j = 0; j < 32; j++) {
+      int i = mw * 32 + j;
+      if (i >= L) break;
+      unsigned char ch = (unsigned char)s[i] & 0xDF;
+      if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) v |= 1u << j;
+    }
+  }
+  out[gid] = v;
+  if (w == 0) out_len[r] = (uint16_t)L;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel B: EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223)
+// ------------------------------------------------------------------------------------------------------------------
+struct EmState {
+  int iter;        // current round index i
+  int chcount;
+  int final_round; // finalRound
+  int done;
+  int rounds;      // i at exit ("ran for i rounds")
+  int zero_now;    // the stop test fired in this round: snapshot alpha_before_zeroes and clamp
+};
+
+// E step + accumulation, one wavefront per EC row group: rows are short, so each lane owns one row when |row| is small
+__global__ __launch_bounds__(BLOCK) void k_em_estep(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids,
+                                                    const u32* __restrict__ counts, const u32* __restrict__ wcounts,
+                                                    u64 n_ecs, const double* __restrict__ eff, const double* __restrict__ alpha,
+                                                    double* next, const EmState* st) {
+  if (st->done) return;
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  const u32 cnt = counts[e];
+  if (b - a == 1) { unsafeAtomicAdd(&next[ec_ids[a]], (double)cnt); return; }  // :119-123 (next starts at 0; a transcript has one singleton set)
+  if (cnt == 0) return;                                        // :133-135
+  const double wc = (double)wcounts[e];
+  double denom = 0.0;
+  for (u64 j = a; j < b; j++) { u32 t = ec_ids[j]; denom += alpha[t] * (wc / eff[t]); }  // weights.cpp:236, EMAlgorithm.h:152-154
+  if (denom < 4.9406564584124654e-324) return;                 // TOLERANCE = denorm_min (:19,:156-158)
+  const double countNorm = cnt / denom;                        // :161
+  for (u64 j = a; j < b; j++) {
+    u32 t = ec_ids[j];
+    unsafeAtomicAdd(&next[t], ((wc / eff[t]) * alpha[t]) * countNorm);  // :162-164
+  }
+}
+// M step bookkeeping per transcript (:176-199) + clamp of the final round (:212-221)
+__global__ void k_em_update(u64 n_tr, double* alpha, double* next, double* alpha_before_zeroes, EmState* st) {
+  if (st->done) return;
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  int ch = 0;
+  if (t < n_tr) {
+    const double nx = next[t], al = alpha[t];
+    if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ch = 1;
+    alpha[t] = nx;
+    next[t] = 0.0;
+  }
+  u64 bal = __ballot(ch);
+  if (lane_id() == 0 && bal) atomicAdd(&st->chcount, (int)__popcll(bal));
+}
+__global__ void k_em_control(EmState* st, int n_iter, int min_rounds) {
+  if (st->done) return;
+  const int i = st->iter;
+  const bool stopEM = (st->chcount == 0 && i > min_rounds);  // :202-205
+  st->chcount = 0;
+  st->zero_now = 0;
+  if (st->final_round) { st->done = 1; st->rounds = i; return; }  // :207-209 (break: i is not incremented)
+  if (stopEM) { st->final_round = 1; st->zero_now = 1; }
+  st->iter = i + 1;
+  if (i + 1 >= n_iter) { st->done = 1; st->rounds = i + 1; }      // loop ran out
+}
+__global__ void k_em_zero(u64 n_tr, double* alpha, double* alpha_before_zeroes, const EmState* st) {
+  if (!st->zero_now) return;
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tr) return;
+  const double a = alpha[t];
+  alpha_before_zeroes[t] = a;
+  if (a < 1e-7 / 10.0) alpha[t] = 0.0;  // alpha_limit/10 (:217-219)
+}
+__global__ void k_fill_f64(double* p, u64 n, double v) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+struct DBuf {
+  void* p = nullptr; size_t cap = 0;
+  // grow to at least `bytes`; `keep` bytes of the old contents are preserved
+  int ensure(size_t bytes, size_t keep, hipStream_t s) {
+    if (bytes <= cap) return 0;
+    size_t ncap = std::max(bytes, cap + cap / 2);
+    void* np = nullptr;
+    HIPC(hipMalloc(&np, ncap));
+    if (keep && p) HIPC(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, s));
+    if (p) { HIPC(hipStreamSynchronize(s)); HIPC(hipFree(p)); }
+    p = np; cap = ncap;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+inline unsigned grid_for(u64 n, int block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+struct kamd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool has_index = false;
+  DevIndex ix{};
+  std::vector<void*> index_allocs;
+  u64 n_ecs = 0, n_targets = 0;
+  DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
+  DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
+  DBuf ec_off, ec_ids, ec_counts;
+  DBuf em_alpha, em_next, em_abz, em_eff, em_state;
+  DevState host_state{};
+  u64 tcap = 0, ccap = 0;
+  u64 n_distinct_tuples = 0;
+  bool tuples_counted = false;   // the tuple table reflects every record of the stream
+  u64 recs_counted = 0;
+  kamd_ec_result result{};
+  bool finalized = false;
+};
+
+namespace {
+
+int sync_state(kamd_ctx* c) {
+  HIPC(hipMemcpyAsync(&c->host_state, c->state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int push_state(kamd_ctx* c) {
+  HIPC(hipMemcpyAsync(c->state.p, &c->host_state, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+template <class T>
+int upload(kamd_ctx* c, const T* host, size_t n, const T** dev) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  HIPC(hipMalloc(&p, bytes));
+  c->index_allocs.push_back(p);
+  if (n) HIPC(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  *dev = reinterpret_cast<const T*>(p);
+  return 0;
+}
+
+// exact de-duplication of records [r0, r1) of a record stream into `table` (capacity cap, power of two)
+int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u64 r1, TSlot* table, u64 cap, DBuf& slot_buf) {
+  const u64 n = r1 - r0;
+  if (n == 0) return 0;
+  if (int rc = slot_buf.ensure(r1 * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->retry.ensure(2 * n * sizeof(u64), 0, c->stream)) return rc;
+  u64* retry_a = c->retry.as<u64>();
+  u64* retry_b = retry_a + n;
+  const u64* idx = nullptr;
+  u64 count = n;
+  for (u64 seed = 1; count; seed++) {
+    c->host_state.n_retry = 0;
+    HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_retry, &c->host_state.n_retry, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_rec_insert, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
+                       table, cap - 1, seed, slot_buf.as<u64>());
+    hipLaunchKernelGGL(k_rec_verify, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
+                       table, slot_buf.as<u64>(), retry_b, (DevState*)c->state.p);
+    HIPC(hipGetLastError());
+    if (int rc = sync_state(c)) return rc;
+    count = c->host_state.n_retry;
+    std::swap(retry_a, retry_b);
+    idx = retry_a;
+    if (seed > 64) return kamd::fail(-101, "dedup_records: tag collisions did not resolve");
+  }
+  return 0;
+}
+
+int list_table(kamd_ctx* c, const TSlot* table, u64 cap, DBuf& list, u64* n_out) {
+  if (int rc = list.ensure(cap * sizeof(u64) / 2 + 64, 0, c->stream)) return rc;
+  u64 zero = 0;
+  HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_list, &zero, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_table_list, dim3(grid_for(cap, BLOCK)), dim3(BLOCK), 0, c->stream, table, cap, list.as<u64>(), (DevState*)c->state.p);
+  HIPC(hipGetLastError());
+  if (int rc = sync_state(c)) return rc;
+  *n_out = c->host_state.n_list;
+  return 0;
+}
+
+int exclusive_scan(kamd_ctx* c, const u32* sizes, u64 n, u64* out, u64* d_total) {
+  const u64 nblocks = std::max<u64>(1, (n + SCAN_ELEMS - 1) / SCAN_ELEMS);
+  if (int rc = c->block_sums.ensure((nblocks + 2) * sizeof(u64), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblocks), dim3(BLOCK), 0, c->stream, sizes, n, out, c->block_sums.as<u64>());
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(64), 0, c->stream, c->block_sums.as<u64>(), nblocks, d_total);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblocks), dim3(BLOCK), 0, c->stream, out, n, c->block_sums.as<u64>());
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+u64 pow2_at_least(u64 x) { u64 p = 1024; while (p < x) p <<= 1; return p; }
+
+// bring the tuple table up to date with the stream: distinct tuples and their counts
+int count_tuples(kamd_ctx* c) {
+  const u64 n_recs = c->host_state.n_recs;
+  if (c->tuples_counted && c->recs_counted == n_recs) return 0;
+  // (re)build from scratch: the table is sized for the final record count
+  c->tcap = pow2_at_least(2 * n_recs + 16);
+  if (int rc = c->ttable.ensure(c->tcap * sizeof(TSlot), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
+  if (int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot)) return rc;
+  if (int rc = list_table(c, c->ttable.as<TSlot>(), c->tcap, c->list, &c->n_distinct_tuples)) return rc;
+  c->tuples_counted = true; c->recs_counted = n_recs;
+  return 0;
+}
+
+}  // namespace
+
+// ======================================================================================================================
+// C ABI
+// ======================================================================================================================
+extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
+  if (!out) return kamd::fail(-1, "kamd_ctx_create: null output pointer");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return kamd::fail(-102, "kamd_ctx_create: no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return kamd::fail(-1, "kamd_ctx_create: bad device ordinal");
+  HIPC(hipSetDevice(device));
+  kamd_ctx* c = new kamd_ctx;
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;
+  if (c->state.ensure(sizeof(DevState), 0, c->stream)) { delete c; return -100; }
+  memset(&c->host_state, 0, sizeof c->host_state);
+  if (push_state(c)) { delete c; return -100; }
+  *out = c;
+  return 0;
+}
+
+extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->index_allocs) (void)hipFree(p);
+  for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
+                  &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes,
+                  &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_abz, &c->em_eff,
+                  &c->em_state})
+    b->release();
+  delete c;
+}
+
+extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
+  if (!c || !hix) return kamd::fail(-1, "kamd_index_upload: null argument");
+  HIPC(hipSetDevice(c->device));
+  kamd_index_view v;
+  if (int rc = kamd_index_get_view(hix, &v)) return rc;
+  for (void* p : c->index_allocs) (void)hipFree(p);
+  c->index_allocs.clear();
+  DevIndex d{};
+  d.k = v.k; d.n_buckets = v.n_buckets; d.n_ecs = v.n_ecs;
+  const u64 slots = (v.n_buckets + v.pad_buckets) * KAMD_SLOTS_PER_BUCKET;
+  if (int rc = upload(c, (const u64*)v.table, slots * 2, &d.table)) return rc;
+  if (int rc = upload(c, v.slot_block, slots, &d.slot_block)) return rc;
+  if (int rc = upload(c, v.slot_dist, slots, &d.slot_dist)) return rc;
+  if (int rc = upload(c, v.uec_ec, v.n_uec, &d.uec_ec)) return rc;
+  if (int rc = upload(c, (const u64*)v.ec_off, v.n_ecs + 1, &d.ec_off)) return rc;
+  if (int rc = upload(c, v.ec_ids, v.ec_nnz, &d.ec_ids)) return rc;
+  std::vector<uint8_t> ne(v.n_ecs + 1);
+  for (u64 e = 0; e < v.n_ecs; e++) ne[e] = v.ec_off[e + 1] > v.ec_off[e];
+  if (int rc = upload(c, ne.data(), v.n_ecs, &d.ec_nonempty)) return rc;
+  if (int rc = upload(c, v.onlist_bits, v.onlist_words, &d.onlist_bits)) return rc;
+  HIPC(hipStreamSynchronize(c->stream));  // `ne` is a stack-owned staging buffer
+  c->ix = d; c->has_index = true; c->n_ecs = v.n_ecs; c->n_targets = v.n_targets;
+  if (int rc = c->dense.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;
+  HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(v.n_ecs, 1) * sizeof(u32), c->stream));
+  memset(&c->host_state, 0, sizeof c->host_state);
+  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0;
+  return push_state(c);
+}
+
+extern "C" int kamd_pack_reads_device(kamd_ctx* c, const char* d_seqs, const uint64_t* d_off, const int32_t* d_len,
+                                      uint64_t n_reads, int32_t max_len, uint32_t* d_out_words, uint16_t* d_out_len) {
+  if (!c) return kamd::fail(-1, "kamd_pack_reads_device: null context");
+  if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pack_reads: max_len must be in [1, 65535]");
+  HIPC(hipSetDevice(c->device));
+  const int seq_words = (max_len + 15) / 16 + 1;
+  const int rec_words = (int)kamd_packed_record_words(max_len);
+  const u64 total = n_reads * (u64)rec_words;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, c->stream, d_seqs, (const u64*)d_off, d_len,
+                     (u64)n_reads, seq_words, rec_words, d_out_words, d_out_len);
+  HIPC(hipGetLastError());
+  return 0;
+}
+
+extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uint32_t* d_words, const uint16_t* d_len,
+                                uint64_t n_items, int32_t max_len) {
+  if (!c || !o) return kamd::fail(-1, "kamd_pseudoalign: null argument");
+  if (!c->has_index) return kamd::fail(-1, "kamd_pseudoalign: no index uploaded");
+  if (o->strand != 0) return kamd::fail(-4, "kamd_pseudoalign: --fr/--rf-stranded not implemented on the device yet");
+  if (!o->paired && !o->single_overhang)
+    return kamd::fail(-4, "kamd_pseudoalign: single-end reads need the findPosition filter (not on the device yet); pass single_overhang=1");
+  if (o->paired && o->fld > 0.0 && !o->single_overhang)
+    return kamd::fail(-4, "kamd_pseudoalign: paired reads with -l need the findPosition filter for orphan mates (not on the device yet)");
+  if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pseudoalign: max_len must be in [1, 65535]");
+  if (n_items == 0) return 0;
+  HIPC(hipSetDevice(c->device));
+  const int seq_words = (max_len + 15) / 16 + 1;
+  const int rec_words = (int)kamd_packed_record_words(max_len);
+  const int item_words = rec_words * (o->paired ? 2 : 1);
+  const size_t lds_bytes = (size_t)BLOCK * item_words * 4 + (size_t)BLOCK * TUPLE_CAP * 4;
+  if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-staged kernel");
+  // capacity for the worst case of this batch
+  const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
+  if (int rc = c->stream_buf.ensure((cur_words + n_items * (TUPLE_CAP + 2)) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
+  if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
+  if (int rc = c->overflow_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
+  AlignOut out{c->dense.as<u32>(), c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(), (DevState*)c->state.p};
+  const unsigned grid = grid_for(n_items, BLOCK);
+  if (o->paired) {
+    HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k_pseudoalign<true>, dim3(grid), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, (u64)n_items,
+                       seq_words, rec_words, out);
+  } else {
+    HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k_pseudoalign<false>, dim3(grid), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, (u64)n_items,
+                       seq_words, rec_words, out);
+  }
+  HIPC(hipGetLastError());
+  if (int rc = sync_state(c)) return rc;
+  if (c->host_state.n_overflow) {
+    const u64 nov = c->host_state.n_overflow;
+    if (int rc = c->overflow_scratch.ensure(nov * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc;
+    const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
+    if (int rc = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc;
+    if (int rc = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc;
+    out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+    if (o->paired)
+      hipLaunchKernelGGL(k_pseudoalign_overflow<true>, dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
+                         c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), out);
+    else
+      hipLaunchKernelGGL(k_pseudoalign_overflow<false>, dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
+                         c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), out);
+    HIPC(hipGetLastError());
+    if (int rc = sync_state(c)) return rc;
+    c->host_state.n_overflow = 0;
+    if (int rc = push_state(c)) return rc;
+  }
+  c->tuples_counted = false; c->finalized = false;
+  return 0;
+}
+
+extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
+  if (!c || !s) return kamd::fail(-1, "kamd_align_stats_get: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = sync_state(c)) return rc;
+  s->n_processed = c->host_state.st_processed; s->n_single = c->host_state.st_single; s->n_multi = c->host_state.st_multi;
+  s->n_probes = c->host_state.st_probes; s->n_bucket_reads = c->host_state.st_bucket_reads;
+  s->n_distinct_tuples = c->n_distinct_tuples;
+  return 0;
+}
+
+extern "C" int kamd_fld_from_batch(kamd_ctx* c, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
+                                   int32_t max_len, uint32_t* flens, uint64_t* n_used) {
+  if (!c || !flens) return kamd::fail(-1, "kamd_fld_from_batch: null argument");
+  if (!c->has_index) return kamd::fail(-1, "kamd_fld_from_batch: no index uploaded");
+  HIPC(hipSetDevice(c->device));
+  memset(flens, 0, KAMD_MAX_FRAG_LEN * sizeof(uint32_t));
+  const int seq_words = (max_len + 15) / 16 + 1;
+  const int rec_words = (int)kamd_packed_record_words(max_len);
+  u64 found = 0, done = 0;
+  const u64 chunk = 16384;
+  DBuf tl, card, scratch;
+  std::vector<int32_t> h_tl(chunk); std::vector<u32> h_card(chunk);
+  int rc = 0;
+  while (done < n_items && found < 10000 && rc == 0) {
+    const u64 n = std::min(chunk, n_items - done);
+    if ((rc = tl.ensure(n * 4, 0, c->stream))) break;
+    if ((rc = card.ensure(n * 4, 0, c->stream))) break;
+    if ((rc = scratch.ensure(n * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
+    const u64 woff = done * (u64)rec_words * 2;
+    hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, d_words + woff, d_len + 2 * done, n,
+                       seq_words, rec_words, scratch.as<u32>(), tl.as<int32_t>(), card.as<u32>());
+    if (hipGetLastError() != hipSuccess) { rc = kamd::fail(-100, "k_fld launch failed"); break; }
+    if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+    // first 10000 qualifying pairs in input order (ProcessReads.cpp:981-1017,1174-1181 at -t 1)
+    for (u64 i = 0; i < n && found < 10000; i++)
+      if (h_card[i] == 1 && h_tl[i] > 0 && h_tl[i] < KAMD_MAX_FRAG_LEN) { flens[h_tl[i]]++; found++; }
+    done += n;
+  }
+  tl.release(); card.release(); scratch.release();
+  if (n_used) *n_used = found;
+  return rc;
+}
+
+// ---- exchange helpers -------------------------------------------------------------------------------------------------
+extern "C" int kamd_ec_dense_counts(kamd_ctx* c, uint32_t** d_counts, uint64_t* n) {
+  if (!c || !d_counts || !n) return kamd::fail(-1, "kamd_ec_dense_counts: null argument");
+  *d_counts = c->dense.as<u32>(); *n = c->n_ecs;
+  return 0;
+}
+extern "C" int kamd_ec_tuples_export(kamd_ctx* c, uint64_t* n_words, uint64_t* n_tuples) {
+  if (!c || !n_words || !n_tuples) return kamd::fail(-1, "kamd_ec_tuples_export: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = sync_state(c)) return rc;
+  if (int rc = count_tuples(c)) return rc;
+  c->host_state.bound_words = 0;
+  if (int rc = push_state(c)) return rc;
+  const u64 n = c->n_distinct_tuples;
+  if (n) hipLaunchKernelGGL(k_tuple_export_size, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->stream_buf.as<u32>(),
+                            c->ttable.as<TSlot>(), c->list.as<u64>(), n, (DevState*)c->state.p);
+  HIPC(hipGetLastError());
+  if (int rc = sync_state(c)) return rc;
+  *n_words = c->host_state.bound_words; *n_tuples = n;
+  return 0;
+}
+extern "C" int kamd_ec_tuples_copy(kamd_ctx* c, uint32_t* d_out_words, uint64_t* d_out_rec_off) {
+  if (!c || !d_out_words || !d_out_rec_off) return kamd::fail(-1, "kamd_ec_tuples_copy: null argument");
+  HIPC(hipSetDevice(c->device));
+  const u64 n = c->n_distinct_tuples;
+  c->host_state.cand_words = 0; c->host_state.cand_recs = 0;
+  if (int rc = push_state(c)) return rc;
+  if (n) hipLaunchKernelGGL(k_tuple_export_offsets, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->stream_buf.as<u32>(),
+                            c->ttable.as<TSlot>(), c->list.as<u64>(), n, d_out_words, (u64*)d_out_rec_off, (DevState*)c->state.p);
+  HIPC(hipGetLastError());
+  return sync_state(c);
+}
+extern "C" int kamd_ec_tuples_replace(kamd_ctx* c, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off,
+                                      uint64_t n_recs) {
+  if (!c) return kamd::fail(-1, "kamd_ec_tuples_replace: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = sync_state(c)) return rc;
+  if (int rc = c->stream_buf.ensure(std::max<u64>(n_words, 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->rec_off.ensure((n_recs + 1) * sizeof(u64), 0, c->stream)) return rc;
+  if (n_words) HIPC(hipMemcpyAsync(c->stream_buf.p, d_words, n_words * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+  if (n_recs) HIPC(hipMemcpyAsync(c->rec_off.p, d_rec_off, n_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+  c->host_state.stream_words = n_words; c->host_state.n_recs = n_recs;
+  c->tuples_counted = false; c->finalized = false;
+  return push_state(c);
+}
+
+// ---- finalize ---------------------------------------------------------------------------------------------------------
+extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
+  if (!c) return kamd::fail(-1, "kamd_ec_finalize: null context");
+  if (!c->has_index) return kamd::fail(-1, "kamd_ec_finalize: no index uploaded");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = sync_state(c)) return rc;
+  if (int rc = count_tuples(c)) return rc;
+  DevState* dst = (DevState*)c->state.p;
+  const u64 n_t = c->n_distinct_tuples;
+  // size bound of the candidate stream
+  c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0;
+  if (int rc = push_state(c)) return rc;
+  hipLaunchKernelGGL(k_bound_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(), dst);
+  if (n_t) hipLaunchKernelGGL(k_bound_tuples, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, dst);
+  HIPC(hipGetLastError());
+  if (int rc = sync_state(c)) return rc;
+  const u64 bound = c->host_state.bound_words;
+  const u64 max_cands = c->n_ecs + n_t;
+  if (int rc = c->cand.ensure((bound + 2) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->cand_off.ensure((max_cands + 1) * sizeof(u64), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
+                     c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
+  if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * 64, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
+  HIPC(hipGetLastError());
+  if (int rc = sync_state(c)) return rc;
+  const u64 n_cand = c->host_state.cand_recs;
+  // merge equal transcript sets
+  c->ccap = pow2_at_least(2 * n_cand + 16);
+  if (int rc = c->ctable.ensure(c->ccap * sizeof(TSlot), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->ccap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ctable.as<TSlot>(), c->ccap);
+  if (int rc = dedup_records(c, c->cand.as<u32>(), c->cand_off.as<u64>(), 0, n_cand, c->ctable.as<TSlot>(), c->ccap, c->cand_slot)) return rc;
+  u64 n_final = 0;
+  if (int rc = list_table(c, c->ctable.as<TSlot>(), c->ccap, c->clist, &n_final)) return rc;
+  // CSR
+  if (int rc = c->sizes.ensure((n_final + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->ec_off.ensure((n_final + 2) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->ec_counts.ensure((n_final + 1) * sizeof(u32), 0, c->stream)) return rc;
+  u64 nnz = 0;
+  if (n_final) {
+    hipLaunchKernelGGL(k_final_sizes, dim3(grid_for(n_final, BLOCK)), dim3(BLOCK), 0, c->stream, c->cand.as<u32>(), c->ctable.as<TSlot>(),
+                       c->clist.as<u64>(), n_final, c->sizes.as<u32>());
+    if (int rc = exclusive_scan(c, c->sizes.as<u32>(), n_final, c->ec_off.as<u64>(), &dst->bound_words)) return rc;
+    hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, c->stream, c->ec_off.as<u64>(), n_final, &dst->bound_words);
+    if (int rc = sync_state(c)) return rc;
+    nnz = c->host_state.bound_words;
+    if (int rc = c->ec_ids.ensure((nnz + 1) * sizeof(u32), 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_final_write, dim3(grid_for(n_final * 64, BLOCK)), dim3(BLOCK), 0, c->stream, c->cand.as<u32>(), c->ctable.as<TSlot>(),
+                       c->clist.as<u64>(), n_final, c->ec_off.as<u64>(), c->ec_ids.as<u32>(), c->ec_counts.as<u32>());
+    HIPC(hipGetLastError());
+  } else {
+    HIPC(hipMemsetAsync(c->ec_off.p, 0, sizeof(u64), c->stream));
+    if (int rc = c->ec_ids.ensure(sizeof(u32), 0, c->stream)) return rc;
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  c->result.n_ecs = n_final; c->result.nnz = nnz;
+  c->result.d_ec_off = c->ec_off.as<uint64_t>(); c->result.d_ec_ids = c->ec_ids.as<u32>(); c->result.d_counts = c->ec_counts.as<u32>();
+  c->result.n_pseudoaligned = 0;  // filled by kamd_ec_download callers from the counts; kept for ABI symmetry
+  c->finalized = true;
+  if (out) *out = c->result;
+  return 0;
+}
+
+extern "C" int kamd_ec_download(kamd_ctx* c, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts) {
+  if (!c || !c->finalized) return kamd::fail(-1, "kamd_ec_download: call kamd_ec_finalize first");
+  HIPC(hipSetDevice(c->device));
+  HIPC(hipMemcpyAsync(ec_off, c->ec_off.p, (c->result.n_ecs + 1) * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  if (c->result.nnz) HIPC(hipMemcpyAsync(ec_ids, c->ec_ids.p, c->result.nnz * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  if (c->result.n_ecs) HIPC(hipMemcpyAsync(counts, c->ec_counts.p, c->result.n_ecs * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- EM ----------------------------------------------------------------------------------------------------------------
+extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
+                           uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds,
+                           double* alpha, double* alpha_before_zeroes, int32_t* rounds) {
+  if (!c || !eff_lens || !alpha) return kamd::fail(-1, "kamd_em_run: null argument");
+  HIPC(hipSetDevice(c->device));
+  const u32* d_wcounts = d_counts;
+  if (!d_ec_off) {
+    if (!c->finalized) return kamd::fail(-1, "kamd_em_run: no EC result (call kamd_ec_finalize or pass a CSR)");
+    d_ec_off = c->result.d_ec_off; d_ec_ids = c->result.d_ec_ids; d_counts = c->result.d_counts; d_wcounts = d_counts;
+    n_ecs = c->result.n_ecs;
+  }
+  const u64 T = n_targets;
+  if (T == 0) return kamd::fail(-1, "kamd_em_run: no targets");
+  for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_abz, &c->em_eff}) if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
+  if (int rc = c->em_state.ensure(sizeof(EmState), 0, c->stream)) return rc;
+  HIPC(hipMemcpyAsync(c->em_eff.p, eff_lens, T * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemsetAsync(c->em_next.p, 0, T * sizeof(double), c->stream));
+  HIPC(hipMemsetAsync(c->em_abz.p, 0, T * sizeof(double), c->stream));
+  HIPC(hipMemsetAsync(c->em_state.p, 0, sizeof(EmState), c->stream));
+  hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_alpha.as<double>(), T, 1.0 / (double)T);
+  EmState hs{};
+  const int chunk = 64;
+  while (!hs.done) {
+    for (int it = 0; it < chunk; it++) {
+      if (n_ecs) hipLaunchKernelGGL(k_em_estep, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
+                                    d_counts, d_wcounts, (u64)n_ecs, c->em_eff.as<double>(), c->em_alpha.as<double>(),
+                                    c->em_next.as<double>(), (const EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_update, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_alpha.as<double>(),
+                         c->em_next.as<double>(), c->em_abz.as<double>(), (EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, c->stream, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds);
+      hipLaunchKernelGGL(k_em_zero, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_alpha.as<double>(),
+                         c->em_abz.as<double>(), (const EmState*)c->em_state.p);
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
+  HIPC(hipMemcpyAsync(alpha, c->em_alpha.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (alpha_before_zeroes) HIPC(hipMemcpyAsync(alpha_before_zeroes, c->em_abz.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (rounds) *rounds = hs.rounds;
+  return 0;
+}
+
+extern "C" int kamd_bootstrap(kamd_ctx*, uint64_t, const double*, uint64_t, double*, int32_t*) {
+  return kamd::fail(-4, "kamd_bootstrap: not implemented yet (SURVEY.md section 8a rows 16-17)");
+}

@@ -1,0 +1,135 @@
+"""Generate the golden fixtures under tests/golden/ with the UNMODIFIED reference (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Each case directory holds
+    index.idx            built by `kallisto index` (reference binary)
+    reads_1.txt.gz [reads_2.txt.gz]   one read per line
+    expected_<variant>.txt            output of oracle/_ref/dump_ec quant ... (NPROC / EC / FLEN / TR [/ BS] lines)
+    case.json                         how the case was made (seeds, options per variant)
+The fixtures are small on purpose (a few hundred kB each); they pin the oracle (tests/test_oracle_golden.py) and the
+HIP path (tests/test_gpu_parity.py) without needing /root/reference at test time.
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from kallisto_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+KALLISTO = os.path.join(REF, "kallisto")
+DUMP = os.path.join(REF, "dump_ec")
+
+
+def write_lines(path, reads):
+    with gzip.open(path, "wb", compresslevel=9) as f:
+        for r in reads:
+            f.write(bytes(r) + b"\n")
+
+
+def write_fastq(path, reads):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            s = bytes(r)
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+
+
+def make_case(name, fasta_path, reads1, reads2, variants, k=31, note=""):
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    idx = os.path.join(d, "index.idx")
+    subprocess.check_call([KALLISTO, "index", "-k", str(k), "-i", idx, fasta_path], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL)
+    write_lines(os.path.join(d, "reads_1.txt.gz"), reads1)
+    if reads2 is not None:
+        write_lines(os.path.join(d, "reads_2.txt.gz"), reads2)
+    with tempfile.TemporaryDirectory() as tmp:
+        f1 = os.path.join(tmp, "r1.fq")
+        write_fastq(f1, reads1)
+        files = [f1]
+        if reads2 is not None:
+            f2 = os.path.join(tmp, "r2.fq")
+            write_fastq(f2, reads2)
+            files.append(f2)
+        for vname, extra in variants.items():
+            out = subprocess.run([DUMP, "quant", idx, "1", *extra, *files], check=True, stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL).stdout
+            with open(os.path.join(d, f"expected_{vname}.txt"), "wb") as f:
+                f.write(out)
+    with open(os.path.join(d, "case.json"), "w") as f:
+        json.dump({"name": name, "k": k, "paired": reads2 is not None, "n": len(reads1), "variants": variants,
+                   "note": note, "reference": "pachterlab/kallisto v0.51.1 via oracle/_ref/dump_ec (unmodified sources)"},
+                  f, indent=1)
+    print(name, "index bytes", os.path.getsize(idx))
+
+
+def read_fastq_gz(path):
+    out = []
+    with gzip.open(path, "rb") as f:
+        for i, line in enumerate(f):
+            if i % 4 == 1:
+                out.append(line.rstrip(b"\r\n"))
+    return out
+
+
+def main():
+    if not (os.path.exists(KALLISTO) and os.path.exists(DUMP)):
+        sys.exit("oracle/_ref is not built: run `make -C oracle ref` in the build container")
+    tmp = tempfile.mkdtemp()
+    # 1. the reference's own test data (BASELINE config #1): 14 transcripts, 10 000 PE-50 pairs
+    T = "/root/reference/test/"
+    fa = os.path.join(tmp, "t.fa")
+    with gzip.open(T + "transcripts.fasta.gz", "rb") as fi, open(fa, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    make_case("ref_test_pe", fa, read_fastq_gz(T + "reads_1.fastq.gz"), read_fastq_gz(T + "reads_2.fastq.gz"),
+              {"pe": [], "pe_boot": ["--boot", "3", "--seed", "42"], "pe_l200": ["-l", "200", "-s", "20"],
+               "pe_rf": ["--rf"], "pe_fr": ["--fr"]},
+              note="test/transcripts.fasta.gz + test/reads_{1,2}.fastq.gz of the reference repository")
+    # 2. yeast-like (config #2 shape, scaled down): single-end with errors and N's
+    seqs = synth.yeast_like(n_tr=300, seed=1)
+    fa = os.path.join(tmp, "y.fa")
+    synth.write_fasta(fa, seqs)
+    r1, _ = synth.simulate_reads(seqs, 6000, 100, paired=False, frag_mean=200, frag_sd=20, err=0.01, n_frac=0.02, seed=21)
+    se = ["--single", "-l", "200", "-s", "20"]
+    make_case("yeast_se", fa, list(r1), None,
+              {"se": se, "se_overhang": se + ["--single-overhang"], "se_fr": se + ["--fr"], "se_rf": se + ["--rf"]},
+              note="synth.yeast_like(300, seed=1); simulate_reads(6000 SE-100, err 1%, 2% reads with an N, seed=21)")
+    # 3. human-like (config #3 shape, scaled down): isoform families -> mosaic ECs; paired-end
+    seqs = synth.human_like(n_genes=60, seed=2)
+    fa = os.path.join(tmp, "h.fa")
+    synth.write_fasta(fa, seqs)
+    r1, r2 = synth.simulate_reads(seqs, 5000, 100, paired=True, err=0.005, n_frac=0.01, seed=22)
+    # a few ragged / degenerate reads: shorter than k, all-N, lower case, trailing N runs
+    r1 = [bytes(x) for x in r1]
+    r2 = [bytes(x) for x in r2]
+    r1[10] = r1[10][:20]; r2[11] = r2[11][:30]; r1[12] = b"N" * 100; r2[13] = r2[13].lower()
+    r1[14] = r1[14][:60] + b"N" * 40; r2[15] = b"N" * 35 + r2[15][35:]; r1[16] = r1[16][:31]; r2[17] = r2[17][:75]
+    make_case("human_pe", fa, r1, r2, {"pe": [], "pe_boot": ["--boot", "2", "--seed", "7"], "pe_l180": ["-l", "180", "-s", "25"],
+                                        "pe_rf": ["--rf"]},
+              note="synth.human_like(60 genes, seed=2); simulate_reads(5000 PE-100, seed=22) + ragged/degenerate reads")
+    # 4. small k, very short reads (the shape of func_tests/runtests.sh): k=7
+    rng = np.random.default_rng(5)
+    seqs = [synth._ACGT[rng.integers(0, 4, int(l))] for l in rng.integers(60, 200, 12)]
+    fa = os.path.join(tmp, "s.fa")
+    synth.write_fasta(fa, seqs)
+    r1, _ = synth.simulate_reads(seqs, 3000, 24, paired=False, frag_mean=40, frag_sd=5, err=0.01, n_frac=0.01, seed=23)
+    se = ["--single", "-l", "40", "-s", "5"]
+    make_case("tiny_k7_se", fa, list(r1), None, {"se": se, "se_overhang": se + ["--single-overhang"]}, k=7,
+              note="12 random transcripts of 60-200 bp, k=7, 3000 SE-24 reads (func_tests-like)")
+    shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    main()
