@@ -92,6 +92,26 @@ def exported_symbols():
     return sorted(_SYMBOLS)
 
 
+def _load_hip_runtime():
+    """libkallisto_amd.so carries no DT_NEEDED for the HIP runtime (see csrc/Makefile): bind it to the runtime this
+    process uses -- PyTorch's bundled libamdhip64.so when torch is importable, else the ROCm installation's."""
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise KallistoAmdError("no HIP runtime (libamdhip64.so) found")
+
+
 def load_library():
     global _LIB
     if _LIB is None:
@@ -99,6 +119,7 @@ def load_library():
         if not os.path.exists(path):
             raise KallistoAmdError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                    "(hipcc --offload-arch=gfx950); kallisto_amd has no CPU path")
+        _load_hip_runtime()
         lib = C.CDLL(path)
         for name, (res, args) in _SYMBOLS.items():
             fn = getattr(lib, name)
