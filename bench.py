@@ -1,0 +1,298 @@
+#!/usr/bin/env python
+"""bench.py -- the BASELINE.json metric on MI355X: M paired-end reads/s pseudoaligned + quantified against a
+human-transcriptome-sized index (BASELINE.json configs[2]; configs[3] is the same workload on N GPUs).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One *step* = one full `kallisto quant` pass over this rank's batch of synthetic read pairs already resident in HBM in
+the 2-bit packed layout: k-mer pseudoalignment (kernel A) -> EC counts -> [N>1: RCCL all-reduce of the dense EC count
+vector + all-gather of the tuple records] -> EC resolution/merge -> fragment-length sample -> EM (kernel B) -> TPM.
+Scaling is weak: every rank processes its own `--pairs` read pairs (different seeds), so the job is N x pairs per step.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- kernel A (k_pseudoalign): algorithmic bytes of one launch / its HIP-event duration vs the 8 TB/s HBM peak
+  cpu_baseline -- the unmodified reference (oracle/_ref/kallisto quant, built from /root/reference) on this box's host
+                  cores over a bounded sample of the same reads, same index file; plus a parity check of the GPU path
+                  against that run on the same sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+CACHE = os.environ.get("KAMD_BENCH_CACHE", "/tmp/kallisto_amd_cache")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "kallisto")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def wait_for(path, timeout=3600):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise RuntimeError(f"timed out waiting for {path}")
+        time.sleep(1.0)
+
+
+def prepare_workload(name: str, genes: int, is_builder: bool):
+    """Synthetic transcriptome + index built by the reference binary; cached under CACHE."""
+    from kallisto_amd import synth
+    os.makedirs(CACHE, exist_ok=True)
+    tag = f"{name}_g{genes}_v1"
+    npz, idx, done = (os.path.join(CACHE, tag + ext) for ext in (".npz", ".idx", ".done"))
+    if not os.path.exists(done):
+        if is_builder:
+            t0 = time.time()
+            seqs = synth.human_like(n_genes=genes, seed=2) if name == "human" else synth.yeast_like(n_tr=genes, seed=1)
+            lens = np.array([len(s) for s in seqs], np.int64)
+            cat = np.concatenate(seqs)
+            np.savez(npz, cat=cat, lens=lens)
+            log(f"synthetic transcriptome: {len(seqs)} transcripts, {cat.size/1e6:.1f} Mbp in {time.time()-t0:.0f}s")
+            if not os.path.exists(REF_BIN):
+                raise RuntimeError(f"{REF_BIN} missing: the index is built by the reference binary (make -C oracle ref)")
+            fa = os.path.join(CACHE, tag + ".fa")
+            synth.write_fasta(fa, seqs)
+            t0 = time.time()
+            threads = min(os.cpu_count() or 8, 32)
+            subprocess.check_call([REF_BIN, "index", "-t", str(threads), "-i", idx + ".tmp", fa], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+            os.replace(idx + ".tmp", idx)
+            os.remove(fa)
+            log(f"reference `kallisto index -t {threads}`: {time.time()-t0:.0f}s, {os.path.getsize(idx)/1e6:.0f} MB")
+            open(done, "w").write("ok")
+        else:
+            wait_for(done)
+    z = np.load(npz)
+    return z["cat"], z["lens"], idx
+
+
+def write_fastq_fast(path, reads: np.ndarray):
+    n, L = reads.shape
+    ids = np.char.zfill(np.arange(n).astype("U9"), 9).astype("S9")
+    line = np.zeros((n, 2 + 9 + 1 + L + 1 + 2 + L + 1), np.uint8)
+    line[:, 0] = ord("@"); line[:, 1] = ord("r")
+    line[:, 2:11] = np.frombuffer(ids.tobytes(), np.uint8).reshape(n, 9)
+    line[:, 11] = 10
+    line[:, 12:12 + L] = reads
+    line[:, 12 + L] = 10
+    line[:, 13 + L] = ord("+"); line[:, 14 + L] = 10
+    line[:, 15 + L:15 + 2 * L] = ord("I")
+    line[:, 15 + 2 * L] = 10
+    with open(path, "wb") as f:
+        f.write(line.tobytes())
+
+
+def cpu_reference_baseline(idx_path, r1: np.ndarray, r2: np.ndarray, threads: int):
+    """Time the unmodified reference on the host cores: `kallisto quant -t threads` on the sample; the clock starts when
+    the index has been loaded (first '[quant]' line after '[index]') and stops at process exit."""
+    tmp = os.path.join(CACHE, f"cpu_baseline_{os.getpid()}")
+    os.makedirs(tmp, exist_ok=True)
+    f1, f2 = os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq")
+    write_fastq_fast(f1, r1)
+    write_fastq_fast(f2, r2)
+    out = os.path.join(tmp, "out")
+    cmd = [REF_BIN, "quant", "-i", idx_path, "-o", out, "-t", str(threads), "--plaintext", f1, f2]
+    t_start = time.time()
+    p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    t_loaded = None
+    for raw in p.stderr:
+        line = raw.decode(errors="replace")
+        if t_loaded is None and line.startswith("[quant] running in"):
+            t_loaded = time.time()
+    p.wait()
+    t_end = time.time()
+    if p.returncode != 0:
+        raise RuntimeError("reference kallisto quant failed")
+    info = json.load(open(os.path.join(out, "run_info.json")))
+    est = np.loadtxt(os.path.join(out, "abundance.tsv"), skiprows=1, usecols=(3,))
+    shutil.rmtree(tmp, ignore_errors=True)
+    t_loaded = t_loaded or t_start
+    return {"seconds": t_end - t_loaded, "index_load_s": t_loaded - t_start, "n_processed": info["n_processed"],
+            "n_pseudoaligned": info["n_pseudoaligned"], "n_unique": info["n_unique"], "est_counts": est}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=30_000_000, help="read pairs per GPU per step (BASELINE config #3: 30 M)")
+    ap.add_argument("--workload", default="human", choices=["human", "yeast"])
+    ap.add_argument("--genes", type=int, default=None, help="scale of the synthetic transcriptome (default: full config)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs given to the CPU reference (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import kallisto_amd as ka
+    from kallisto_amd.synth_gpu import ReadSimulator
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    genes = args.genes or (20000 if args.workload == "human" else 6000)
+    cat, tlens, idx_path = prepare_workload(args.workload, genes, is_builder=(rank == 0))
+    t0 = time.time()
+    index = ka.Index(idx_path)
+    log(f"index flattened in {time.time()-t0:.1f}s: k={index.k} targets={index.num_targets} k-mers={index.num_kmers} "
+        f"unitigs={index.num_unitigs} index ECs={index.num_ecs}")
+    ctx = ka.Context(local)
+    ctx.upload(index)
+
+    # ---- this rank's reads, generated on the device and packed into the 2-bit layout (resident in HBM) ----
+    L = 100
+    sim = ReadSimulator(cat, tlens, dev, seed=1000 + rank, read_len=L)
+    n = args.pairs
+    rec = ka.packed_record_words(L)
+    words = torch.empty(n * 2 * rec, dtype=torch.int32, device=dev)
+    lens = torch.empty(n * 2, dtype=torch.int16, device=dev)
+    chunk = 2_000_000
+    sample = None
+    t0 = time.time()
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        r1, r2 = sim.draw(m)
+        inter = torch.stack([r1, r2], 1).reshape(2 * m, L)  # mate 1, mate 2 interleaved (ProcessReads.cpp:1034-1041)
+        w, l = ctx.pack_reads(inter, L)
+        words[s * 2 * rec:(s + m) * 2 * rec] = w
+        lens[2 * s:2 * (s + m)] = l
+        if s == 0 and rank == 0 and args.cpu_sample and not args.no_cpu_baseline:
+            k = min(args.cpu_sample, m)
+            sample = (r1[:k].cpu().numpy(), r2[:k].cpu().numpy())
+        del r1, r2, inter, w, l
+    torch.cuda.synchronize()
+    log(f"{n} synthetic PE-{L} pairs generated + packed on the device in {time.time()-t0:.1f}s ({words.numel()*4/1e9:.2f} GB in HBM)")
+
+    opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
+
+    def step():
+        ctx.reset()
+        return ka.quant(ctx, opts, [(words, lens, n, L)], download_ecs=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    align_ms, em_ms, em_iters = [], [], []
+    for _ in range(args.steps):
+        res = step()
+        pr = ctx.profile()
+        align_ms.append(pr["align_kernel_ms"]); em_ms.append(pr["em_ms"]); em_iters.append(pr["em_iters"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = res.stats
+    total_pairs = n * world * args.steps
+
+    out = None
+    if rank == 0:
+        # roofline of kernel A: algorithmic bytes of ONE launch: packed reads in + 16 B (key+payload)
+        # per k-mer probe + what the launch writes (4 B per single-set count, the tuple record and its 8-byte offset)
+        # (the counters are reset every step, so `st` describes exactly one launch)
+        rec_bytes = 2 * rec * 4 + 2 * 2
+        alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_single"] + 4 * st["n_stream_words"] + 8 * st["n_multi"]
+        a_ms = float(np.mean(align_ms))
+        achieved = alg_bytes / (a_ms * 1e-3) / 1e9
+        out = {
+            "metric": "M paired-end reads/sec quantified (human txome index)",
+            "value": round(total_pairs / elapsed / 1e6, 4),
+            "unit": "M read pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64+f64", "data": "synthetic",
+            "config": {
+                "workload": (f"BASELINE config #3: synthetic human-like transcriptome ({index.num_targets} transcripts, "
+                             f"{index.num_kmers} k-mers, k={index.k}; index built by the reference `kallisto index`), "
+                             f"{n} PE-{L} read pairs per GPU resident in HBM (2-bit packed), full quant per step"
+                             if args.workload == "human" and genes == 20000 else
+                             f"REDUCED {args.workload} genes={genes} pairs={n} (not the BASELINE configuration)"),
+                "pairs_per_gpu": n, "read_len": L, "paired": True, "targets": int(index.num_targets),
+                "kmers": int(index.num_kmers), "parallelism": f"reads sharded over {world} GPU(s), EC counts all-reduced",
+            },
+            "breakdown_ms": {"pseudoalign_kernel": round(a_ms, 3), "em": round(float(np.mean(em_ms)), 3),
+                             "em_rounds": int(em_iters[-1]), "step_total": round(elapsed / args.steps * 1e3, 3)},
+            "counters": {"probes_per_pair": round(st["n_probes"] / n, 3),
+                         "bucket_reads_per_probe": round(st["n_bucket_reads"] / max(st["n_probes"], 1), 4),
+                         "single_set_pairs": st["n_single"], "multi_set_pairs": st["n_multi"],
+                         "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
+                         "em_rounds": res.em_rounds},
+            "roofline": {"kernel": "k_pseudoalign", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
+                         "bucket_line_bytes_per_launch": int(64 * st["n_bucket_reads"])},
+        }
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                tj = json.load(open(prof))
+                if tj.get("pairs") == n and tj.get("workload") == args.workload and tj.get("genes") == genes:
+                    out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tj.get("source")
+            except Exception:
+                pass
+    # ---- CPU baseline (rank 0, N=1 only) + parity of the GPU path against it on the same sample ----
+    if rank == 0 and world == 1 and sample is not None:
+        threads = min(os.cpu_count() or 1, 64)
+        k = sample[0].shape[0]
+        log(f"CPU baseline: reference `kallisto quant -t {threads}` on the first {k} pairs ...")
+        try:
+            cb = cpu_reference_baseline(idx_path, sample[0], sample[1], threads)
+            ctx.reset()
+            sres = ka.quant(ctx, opts, [(words[:k * 2 * rec], lens[:2 * k], k, L)], download_ecs=True)
+            big = cb["est_counts"] > 1e-7
+            rel = float(np.max(np.abs(sres.est_counts[big] - cb["est_counts"][big]) / cb["est_counts"][big])) if big.any() else 0.0
+            out["cpu_baseline"] = {"value": round(k / cb["seconds"] / 1e6, 4), "unit": "M read pairs/s", "cores": threads,
+                                   "kind": "reference",
+                                   "sample": f"first {k} pairs of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
+                                             f"--plaintext`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
+                                             f"{cb['index_load_s']:.1f}s excluded)"}
+            out["parity_check"] = {"sample_pairs": k, "n_pseudoaligned_gpu": sres.n_pseudoaligned,
+                                   "n_pseudoaligned_ref": cb["n_pseudoaligned"], "n_unique_gpu": sres.n_unique,
+                                   "n_unique_ref": cb["n_unique"],
+                                   "est_counts_max_rel_err_printed_precision": rel,
+                                   "ok": bool(sres.n_pseudoaligned == cb["n_pseudoaligned"] and sres.n_unique == cb["n_unique"])}
+        except Exception as e:  # the baseline is reported, never required for the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "M read pairs/s", "cores": threads, "kind": "reference",
+                                   "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

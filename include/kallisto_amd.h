@@ -82,6 +82,7 @@ const char* kamd_index_target_name(const kamd_index*, uint64_t i);
 int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out);
 void kamd_ctx_destroy(kamd_ctx*);
 int kamd_index_upload(kamd_ctx*, const kamd_index*);
+int kamd_ec_reset(kamd_ctx*);  /* forget all EC counts (a new MinCollector, src/MinCollector.h:22) */
 
 /* ---- reads: 2-bit packing of one parsed batch (what fetchSequences hands to processBuffer) ----
  * Record layout per read: words_per_read u32 of 2-bit bases (base i at bits 2*(i&15) of word i>>4; A0 C1 G2 T3,
@@ -115,8 +116,17 @@ typedef struct {
   uint64_t n_probes;        /* k-mer table probes */
   uint64_t n_bucket_reads;  /* 64-byte bucket reads (>= n_probes) */
   uint64_t n_distinct_tuples;
+  uint64_t n_stream_words;  /* u32 words appended to the tuple stream ([cnt, m, e0..] records) */
 } kamd_align_stats;
 int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
+
+/* durations measured with HIP events on the context stream (bench.py's roofline figures) */
+typedef struct {
+  float last_align_kernel_ms;  /* the k_pseudoalign launch of the last kamd_pseudoalign call */
+  float last_em_ms;            /* all EM launches of the last kamd_em_run call */
+  uint64_t last_em_iters;      /* EM rounds executed by it */
+} kamd_profile;
+int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 
 /* ---- EC state exchange (multi-GPU; one process per GPU, the caller runs the collectives) ----
  * The EC state is (a) a dense count vector over index transcript sets and (b) a list of (tuple of index set ids,

@@ -43,7 +43,11 @@ class QuantOpts(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_processed", "n_single", "n_multi", "n_probes", "n_bucket_reads",
-                                          "n_distinct_tuples")]
+                                          "n_distinct_tuples", "n_stream_words")]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64)]
 
 
 class _EcResult(C.Structure):
@@ -63,6 +67,7 @@ _SYMBOLS = {
     "kamd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "kamd_ctx_destroy": (None, [C.c_void_p]),
     "kamd_index_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kamd_ec_reset": (C.c_int, [C.c_void_p]),
     "kamd_packed_record_words": (C.c_uint64, [C.c_int32]),
     "kamd_pack_reads_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
@@ -71,6 +76,7 @@ _SYMBOLS = {
     "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                       C.POINTER(C.c_uint64)]),
     "kamd_align_stats_get": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
+    "kamd_profile_get": (C.c_int, [C.c_void_p, C.POINTER(_Profile)]),
     "kamd_ec_dense_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -216,6 +222,9 @@ class Context:
         _check(load_library().kamd_index_upload(self._h, index.handle), "kamd_index_upload")
         self.index = index
 
+    def reset(self):
+        _check(load_library().kamd_ec_reset(self._h), "kamd_ec_reset")
+
     # ---- reads ----
     def pack_reads(self, seqs_u8, max_len: int | None = None):
         """(n_reads, L) uint8 ASCII tensor on the device -> (words, lens) packed records (kamd_pack_reads_device)."""
@@ -269,6 +278,11 @@ class Context:
         _check(load_library().kamd_align_stats_get(self._h, C.byref(s)), "kamd_align_stats_get")
         return {n: int(getattr(s, n)) for n, _ in _Stats._fields_}
 
+    def profile(self) -> dict:
+        p = _Profile()
+        _check(load_library().kamd_profile_get(self._h, C.byref(p)), "kamd_profile_get")
+        return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters)}
+
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):
         """The dense per-index-set count vector as a torch tensor aliasing the context's device memory."""
@@ -292,37 +306,15 @@ class Context:
                "kamd_ec_tuples_replace")
 
     def allreduce_ec_counts(self, group=None):
-        """Merge the EC state of all ranks (MasterProcessor::update's locked `tc.counts[i] += c[i]`,
-        src/ProcessReads.cpp:424-499): one RCCL all-reduce of the dense count vector over xGMI plus an all-gather of
-        the (tuple of index set ids, count) records, whose keys are identical on every rank."""
+        """Merge the EC state of all ranks: one RCCL all-reduce of the dense count vector over xGMI plus an all-gather
+        of the tuple records (kallisto_amd/exchange.py)."""
         import torch.distributed as dist
-        torch = self.torch
+        from .exchange import merge_ec_state
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
-        world = dist.get_world_size(group)
-        dense = self.dense_counts()
-        dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
         words, offs = self.tuples_export()
-        sizes = torch.tensor([words.numel(), offs.numel()], dtype=torch.int64, device=words.device)
-        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes, group=group)
-        all_sizes = torch.stack(all_sizes).cpu()
-        mw, mo = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-        pw = torch.zeros(max(mw, 1), dtype=torch.int32, device=words.device)
-        po = torch.zeros(max(mo, 1), dtype=torch.int64, device=words.device)
-        pw[:words.numel()] = words
-        po[:offs.numel()] = offs
-        gw = [torch.empty_like(pw) for _ in range(world)]
-        go = [torch.empty_like(po) for _ in range(world)]
-        dist.all_gather(gw, pw, group=group)
-        dist.all_gather(go, po, group=group)
-        cat_w, cat_o, base = [], [], 0
-        for r in range(world):
-            nw, no = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-            cat_w.append(gw[r][:nw])
-            cat_o.append(go[r][:no] + base)
-            base += nw
-        self.tuples_replace(torch.cat(cat_w).contiguous(), torch.cat(cat_o).contiguous())
+        words, offs = merge_ec_state(self.dense_counts(), words, offs, group)
+        self.tuples_replace(words, offs)
 
     # ---- finalize / EM ----
     def finalize(self, download: bool = True):

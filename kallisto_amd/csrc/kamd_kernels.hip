@@ -611,6 +611,9 @@ struct kamd_ctx {
   u64 recs_counted = 0;
   kamd_ec_result result{};
   bool finalized = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_align_ms = 0.f, last_em_ms = 0.f;
+  uint64_t last_em_iters = 0;
 };
 
 namespace {
@@ -718,6 +721,7 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (c->state.ensure(sizeof(DevState), 0, c->stream)) { delete c; return -100; }
   memset(&c->host_state, 0, sizeof c->host_state);
   if (push_state(c)) { delete c; return -100; }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
   *out = c;
   return 0;
 }
@@ -726,6 +730,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes,
@@ -761,6 +767,15 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(v.n_ecs, 1) * sizeof(u32), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
   c->tuples_counted = false; c->finalized = false; c->recs_counted = 0;
+  return push_state(c);
+}
+
+extern "C" int kamd_ec_reset(kamd_ctx* c) {
+  if (!c || !c->has_index) return kamd::fail(-1, "kamd_ec_reset: no context / index");
+  HIPC(hipSetDevice(c->device));
+  HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
+  memset(&c->host_state, 0, sizeof c->host_state);
+  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0;
   return push_state(c);
 }
 
@@ -803,6 +818,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   if (int rc = c->overflow_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
   AlignOut out{c->dense.as<u32>(), c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(), (DevState*)c->state.p};
   const unsigned grid = grid_for(n_items, BLOCK);
+  HIPC(hipEventRecord(c->ev0, c->stream));
   if (o->paired) {
     HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(k_pseudoalign<true>, dim3(grid), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, (u64)n_items,
@@ -812,8 +828,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     hipLaunchKernelGGL(k_pseudoalign<false>, dim3(grid), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, (u64)n_items,
                        seq_words, rec_words, out);
   }
+  HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
+  HIPC(hipEventElapsedTime(&c->last_align_ms, c->ev0, c->ev1));
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
     if (int rc = c->overflow_scratch.ensure(nov * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc;
@@ -842,7 +860,7 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   if (int rc = sync_state(c)) return rc;
   s->n_processed = c->host_state.st_processed; s->n_single = c->host_state.st_single; s->n_multi = c->host_state.st_multi;
   s->n_probes = c->host_state.st_probes; s->n_bucket_reads = c->host_state.st_bucket_reads;
-  s->n_distinct_tuples = c->n_distinct_tuples;
+  s->n_distinct_tuples = c->n_distinct_tuples; s->n_stream_words = c->host_state.stream_words;
   return 0;
 }
 
@@ -1024,6 +1042,7 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_alpha.as<double>(), T, 1.0 / (double)T);
   EmState hs{};
   const int chunk = 64;
+  HIPC(hipEventRecord(c->ev0, c->stream));
   while (!hs.done) {
     for (int it = 0; it < chunk; it++) {
       if (n_ecs) hipLaunchKernelGGL(k_em_estep, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
@@ -1039,10 +1058,20 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
     HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
   }
+  HIPC(hipEventRecord(c->ev1, c->stream));
+  HIPC(hipEventSynchronize(c->ev1));
+  HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
+  c->last_em_iters = (uint64_t)hs.rounds + 1;
   HIPC(hipMemcpyAsync(alpha, c->em_alpha.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (alpha_before_zeroes) HIPC(hipMemcpyAsync(alpha_before_zeroes, c->em_abz.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   if (rounds) *rounds = hs.rounds;
+  return 0;
+}
+
+extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
+  if (!c || !p) return kamd::fail(-1, "kamd_profile_get: null argument");
+  p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
   return 0;
 }
 

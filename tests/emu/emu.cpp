@@ -49,3 +49,73 @@ int64_t emu_pseudoalign(const kamd_index_view* v, const uint32_t* words, const u
   return (int64_t)o;
 }
 }
+
+// ---- CPU stand-ins for kernel A's outputs and for kamd_ec_finalize, used to test the multi-rank merge on gloo ----
+#include <map>
+extern "C" {
+// dense[n_ecs] += single-set items; tuple records [1, m, e0..] appended to stream (capacity cap words)
+int64_t emu_ec_state(const kamd_index_view* v, const uint32_t* words, const uint16_t* lens, uint64_t n_items, int paired,
+                     int32_t max_len, uint32_t* dense, uint32_t* stream, uint64_t cap, uint64_t* rec_off, uint64_t* n_recs) {
+  using namespace kamd;
+  const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
+  Table t{v->table, v->n_buckets};
+  std::vector<uint8_t> nonempty(v->n_ecs);
+  for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
+  uint64_t o = 0, nr = 0;
+  uint32_t ecbuf[1024];
+  for (uint64_t i = 0; i < n_items; i++) {
+    EcList ecs{ecbuf, 1024, 0, false};
+    MateInfo m[2]; memset(m, 0, sizeof m);
+    for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
+      uint64_t r = paired ? 2 * i + mate : i;
+      ReadView rv{words + r * rec, words + r * rec + sw, lens[r]};
+      match_mate(t, v->uec_ec, nonempty.data(), rv, v->k, ecs, m[mate]);
+    }
+    if (ecs.overflow) return -1;
+    if (!pair_is_mapped(m[0], m[1])) continue;
+    if (ecs.n == 1) { dense[ecs.e[0]]++; continue; }
+    if (o + ecs.n + 2 > cap) return -2;
+    rec_off[nr++] = o;
+    stream[o++] = 1; stream[o++] = (uint32_t)ecs.n;
+    for (int j = 0; j < ecs.n; j++) stream[o++] = ecs.e[j];
+  }
+  *n_recs = nr;
+  return (int64_t)o;
+}
+// resolve dense counts + weighted tuple records into the EC multiset (CSR); returns number of ECs
+int64_t emu_resolve(const kamd_index_view* v, const uint32_t* dense, const uint32_t* stream, const uint64_t* rec_off,
+                    uint64_t n_recs, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts, uint64_t cap_ecs, uint64_t cap_ids) {
+  std::map<std::vector<uint32_t>, uint64_t> tuples, sets;
+  for (uint64_t r = 0; r < n_recs; r++) {
+    const uint32_t* w = stream + rec_off[r];
+    tuples[std::vector<uint32_t>(w + 2, w + 2 + w[1])] += w[0];
+  }
+  auto onl = [&](uint32_t tr) { return (v->onlist_bits[tr >> 5] >> (tr & 31)) & 1; };
+  for (uint64_t e = 0; e < v->n_ecs; e++) if (dense[e]) {
+    std::vector<uint32_t> s;
+    for (uint64_t j = v->ec_off[e]; j < v->ec_off[e + 1]; j++) if (onl(v->ec_ids[j])) s.push_back(v->ec_ids[j]);
+    if (!s.empty()) sets[s] += dense[e];
+  }
+  for (auto& kv : tuples) {
+    const auto& es = kv.first;
+    std::vector<uint32_t> cur(v->ec_ids + v->ec_off[es[0]], v->ec_ids + v->ec_off[es[0] + 1]);
+    for (size_t j = 1; j < es.size(); j++) {
+      std::vector<uint32_t> nx;
+      std::set_intersection(cur.begin(), cur.end(), v->ec_ids + v->ec_off[es[j]], v->ec_ids + v->ec_off[es[j] + 1], std::back_inserter(nx));
+      cur.swap(nx);
+    }
+    std::vector<uint32_t> s;
+    for (uint32_t tr : cur) if (onl(tr)) s.push_back(tr);
+    if (!s.empty()) sets[s] += kv.second;
+  }
+  uint64_t n = 0, o = 0;
+  ec_off[0] = 0;
+  for (auto& kv : sets) {
+    if (n >= cap_ecs || o + kv.first.size() > cap_ids) return -1;
+    for (uint32_t tr : kv.first) ec_ids[o++] = tr;
+    counts[n++] = (uint32_t)kv.second;
+    ec_off[n] = o;
+  }
+  return (int64_t)n;
+}
+}

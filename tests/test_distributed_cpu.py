@@ -1,0 +1,73 @@
+"""World-size-2 test of the multi-GPU merge on CPU (gloo): each rank turns its shard of the reads into the EC state
+kernel A would produce (dense counts + tuple records, via the CPU emulation of the per-item logic), the states are
+merged with kallisto_amd.exchange.merge_ec_state (all-reduce + all-gather), resolved, and the result must equal the
+reference's EC multiset for the WHOLE input -- i.e. sharding reads over ranks does not change EC counts."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import common
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kallisto_amd.exchange import merge_ec_state
+        from tests import emu_binding as E
+        meta, idx_path, r1, r2 = common.load_case(case)
+        paired = r2 is not None
+        n = len(r1)
+        lo, hi = rank * n // world, (rank + 1) * n // world  # contiguous shard of the reads
+        ix = E.EmuIndex(idx_path)
+        words, l16, max_len = E.pack(common.interleave(r1[lo:hi], r2[lo:hi] if paired else None), 100)
+        dense, stream, rec_off = E.ec_state(ix, words, l16, hi - lo, paired, max_len)
+        d = torch.from_numpy(dense.view(np.int32).copy())
+        w, o = merge_ec_state(d, torch.from_numpy(stream.view(np.int32).copy()), torch.from_numpy(rec_off.astype(np.int64)))
+        ms = E.resolve(ix, d.numpy().view(np.uint32), w.numpy().view(np.uint32), o.numpy().astype(np.uint64))
+        q.put((rank, ms))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("ref_test_pe", "pe"), ("yeast_se", "se_overhang")])
+def test_sharded_ec_counts_equal_reference(case, variant):
+    exp = common.load_expected(case, variant)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert results[0] == results[1] == exp["ecs"]
+
+
+def test_merge_is_identity_without_process_group():
+    from kallisto_amd.exchange import merge_ec_state
+    d = torch.arange(5, dtype=torch.int32)
+    w = torch.tensor([1, 2, 3, 4], dtype=torch.int32)
+    o = torch.tensor([0], dtype=torch.int64)
+    w2, o2 = merge_ec_state(d, w, o)
+    assert torch.equal(w, w2) and torch.equal(o, o2) and d.tolist() == [0, 1, 2, 3, 4]
