@@ -299,4 +299,150 @@ KAMD_HD bool pair_is_mapped(const MateInfo& a, const MateInfo& b) {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// positional filters of ReadProcessor::processBuffer (src/ProcessReads.cpp:1095-1145)
+//   - fragment-length compatibility of single-end reads / orphan mates via KmerIndex::findPosition
+//     (src/KmerIndex.cpp:2188-2292)
+//   - doStrandSpecificity (src/ProcessReads.cpp:61-124, non-comprehensive branch)
+// Both replace u by {tr in u : keep(tr)} where keep() only depends on the first mapping k-mer of a mate
+// (findFirstMappingKmer) and on tr, so the final set is u filtered by the conjunction of the predicates.
+// ---------------------------------------------------------------------------------------------------------------
+struct PosTables {
+  const uint64_t* unitig_blk_off;  // [n_unitigs+1]
+  const uint32_t* unitig_len;      // bp
+  const uint32_t* blk_unitig;
+  const uint32_t* blk_lb;
+  const uint32_t* blk_ub;
+  const uint32_t* blk_ec;
+  const uint64_t* blk_pos_off;     // into blk_posw / blk_sense
+  const uint32_t* blk_posw;
+  const uint8_t* blk_sense;
+  const uint64_t* ec_off;
+  const uint32_t* ec_ids;
+  const int32_t* target_lens;
+  int k;
+};
+struct FirstHit {      // findFirstMappingKmer(v): um + p
+  bool valid;
+  uint32_t block;      // global block id of the hit (slot_block)
+  uint32_t dist;       // um.dist (slot_dist)
+  bool strand;         // um.strand
+  int pos;             // p
+};
+
+// rank of tr in the transcript set of block b, or -1
+KAMD_HD int64_t blk_rank(const PosTables& pt, uint64_t b, uint32_t tr) {
+  const uint32_t ec = pt.blk_ec[b];
+  const uint32_t* ids = pt.ec_ids + pt.ec_off[ec];
+  uint64_t n = pt.ec_off[ec + 1] - pt.ec_off[ec], lo = 0, hi = n;
+  while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (ids[m] < tr) lo = m + 1; else hi = m; }
+  return (lo < n && ids[lo] == tr) ? (int64_t)lo : -1;
+}
+// BlockArray::get_block_at(idx) with the reference's wrap-around for idx = (uint32)-1 (BlockArray.hpp:306-322)
+KAMD_HD uint64_t block_at(const PosTables& pt, uint64_t b0, uint64_t b1, int64_t idx) {
+  if (b1 - b0 == 1) return b0;
+  if (idx < 0) return b1 - 1;
+  uint64_t a = b0, b = b1;
+  while (a < b) { uint64_t m = (a + b) >> 1; if ((int64_t)pt.blk_lb[m] <= idx) a = m + 1; else b = m; }
+  return a == b0 ? b0 : a - 1;
+}
+
+// KmerIndex::findPosition(tr, km, um, p) -> (pos, sense)
+KAMD_HD int find_position(const PosTables& pt, uint32_t tr, const FirstHit& um, bool* sense_out) {
+  const int k = pt.k;
+  const uint32_t gid = pt.blk_unitig[um.block];
+  const uint64_t b0 = pt.unitig_blk_off[gid], b1 = pt.unitig_blk_off[gid + 1];
+  const uint64_t vb = um.block;                 // ecs.back(): the block containing um.dist
+  const int64_t nlead = (int64_t)(vb - b0) + 1; // get_leading_vals(um.dist).size()
+  const int p = um.pos;
+  const bool csense = um.strand;
+  int64_t rk = blk_rank(pt, vb, tr);
+  if (rk < 0) { *sense_out = true; return -1; }
+  const uint32_t rawpos = pt.blk_posw[pt.blk_pos_off[vb] + (uint64_t)rk];
+  const int trpos = (int)(rawpos & 0x7FFFFFFFu);
+  const bool trsense = ((uint32_t)trpos == rawpos);
+  uint32_t mc_first = pt.blk_lb[vb], mc_second = pt.blk_ub[vb];
+  const int64_t um_size = pt.unitig_len[gid], um_dist = um.dist;
+  int64_t ret; bool rsense;
+  if (trsense) {
+    if (csense) {                                                                    // Case I   :2213-2225
+      int64_t padding = 0;
+      if (trpos == 0) {
+        for (int64_t i = nlead - 2; i >= 0; i--) {
+          if (blk_rank(pt, b0 + (uint64_t)i, tr) < 0) { padding = mc_first; break; }
+          uint64_t nb = block_at(pt, b0, b1, (int64_t)mc_first - 1);
+          mc_first = pt.blk_lb[nb]; mc_second = pt.blk_ub[nb];
+        }
+      }
+      ret = (int64_t)trpos - p + um_dist + 1 - padding; rsense = csense;
+    } else {                                                                         // Case III :2226-2240
+      const int64_t initial = mc_second;
+      int right_one = 0, left_one = 0;
+      for (int64_t i = nlead - 1; i >= 0; i--) {
+        if (i == nlead - 1) right_one = (int)mc_second;
+        if (blk_rank(pt, b0 + (uint64_t)i, tr) < 0) { left_one = (int)mc_second; break; }
+        else if (i == 0) left_one = 0;
+        uint64_t nb = block_at(pt, b0, b1, (int64_t)mc_first - 1);
+        mc_first = pt.blk_lb[nb]; mc_second = pt.blk_ub[nb];
+      }
+      const int64_t padding = -((int64_t)left_one + right_one - um_size + k - 1);
+      ret = (int64_t)trpos + p + k - (um_size - k - um_dist) + initial - 1 + padding; rsense = csense;
+    }
+  } else {                                                                           // Cases IV / II :2243-2288
+    int64_t curr_mc = 0; int left_one = 0, right_one = 0, unmapped_len = 0; bool found_first_mapped = false;
+    for (uint64_t i = 0; i < b1 - b0; i++) {
+      const uint64_t mb = block_at(pt, b0, b1, curr_mc);
+      const bool has = blk_rank(pt, b0 + i, tr) >= 0;
+      if (!has && found_first_mapped) {
+        if (unmapped_len == 0) left_one = (int)pt.blk_lb[mb];
+        right_one = (int)pt.blk_ub[mb];
+        unmapped_len += (int)(pt.blk_ub[mb] - pt.blk_lb[mb]);
+      }
+      if (has) found_first_mapped = true;
+      curr_mc = pt.blk_ub[mb];
+    }
+    if (csense) {
+      int64_t start = 0;
+      start -= right_one - left_one;
+      start += um_size - k;
+      ret = (int64_t)trpos + (-(um_dist - start)) + k + p; rsense = !csense;
+    } else {
+      unmapped_len = right_one - left_one;
+      const int64_t padding = um_size - um_dist - unmapped_len - k + 1;
+      ret = (int64_t)trpos + padding - p; rsense = !csense;
+    }
+  }
+  *sense_out = rsense;
+  return (int)ret;
+}
+
+struct FilterCfg {
+  bool fraglen;   // !single_overhang && has_mean_fl && (single-end || one mate without hits)
+  int fl;         // (int) tc.get_mean_frag_len()
+  int strand;     // 0 none, 1 FR, 2 RF
+};
+// keep(tr) for one item: h1 / h2 = first mapping k-mers of mate 1 / 2 (valid = the mate has hits)
+KAMD_HD bool keep_transcript(const PosTables& pt, const FilterCfg& cfg, const FirstHit& h1, const FirstHit& h2, uint32_t tr) {
+  if (cfg.fraglen) {
+    const FirstHit& um = h2.valid ? h2 : h1;  // ProcessReads.cpp:1104-1115: mate 2's k-mer wins when both are set
+    bool sense; int x = find_position(pt, tr, um, &sense);
+    bool keep = false;
+    if (sense && x + cfg.fl <= (int)pt.target_lens[tr]) keep = true;    // :1122-1126
+    if (!sense && x - cfg.fl >= 0) keep = true;                          // :1127-1131
+    if (!keep) return false;
+  }
+  if (cfg.strand) {
+    for (int mate = 0; mate < 2; mate++) {
+      const FirstHit& um = mate ? h2 : h1;
+      if (!um.valid) continue;
+      const bool want = mate ? (cfg.strand == 2) : (cfg.strand == 1);   // :87 firstStrand = FR, :106 secondStrand = RF
+      int64_t rk = blk_rank(pt, um.block, tr);
+      if (rk < 0) return false;                                          // u &= ec
+      const int sense = pt.blk_sense[pt.blk_pos_off[um.block] + (uint64_t)rk];
+      if (!(((um.strand == (sense != 0)) == want) || sense == 2)) return false;  // :98
+    }
+  }
+  return true;
+}
+
 }  // namespace kamd
