@@ -296,50 +296,58 @@ __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, u32* 
   for (u32 j = 0; j < n; j++) if (onlisted(ix.onlist_bits, ids[j])) w[2 + o++] = ids[j];
   cand_off[r] = off;
 }
-// (b) one wavefront per distinct tuple: intersect the m sorted sets; 64 candidates of the smallest set per step,
-//     membership by binary search in the others, survivors compacted with ballot + popcount prefix
+// (b) one 16-lane group per distinct tuple (4 tuples per wavefront): intersect the m sorted sets; 16 candidates of the
+//     smallest set per step, membership by binary search in the others, survivors compacted with ballot + popcount
+//     prefix over the group's 16 bits of the wavefront mask
+constexpr int RES_LANES = 16;
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
                                                    const u64* list, u64 n, u32* cand, u64* cand_off, DevState* st) {
-  const u64 wid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wid >= n) return;
+  const u64 gid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / RES_LANES;
+  if (gid >= n) return;
   const int lane = lane_id();
-  const TSlot sl = table[list[wid]];
+  const int sub = lane & (RES_LANES - 1);
+  const int gsh = lane & ~(RES_LANES - 1);  // bit position of this group inside the wavefront mask
+  const TSlot sl = table[list[gid]];
   const u64 off = sl.owner;
   const u32 m = stream[off + 1];
   const u32* es = stream + off + 2;
-  // smallest set drives
   u32 best = 0; u64 best_sz = ~0ULL;
   for (u32 j = 0; j < m; j++) { u32 e = es[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
   const u32* base = ix.ec_ids + ix.ec_off[es[best]];
   const u32 nb = (u32)best_sz;
   u64 out_off = 0;
-  u32 total = 0;
+  u32 total = 0, first_mask = 0;
   for (int pass = 0; pass < 2; pass++) {
     u32 written = 0;
-    for (u32 c0 = 0; c0 < nb; c0 += 64) {
-      const u32 c = c0 + lane;
+    for (u32 c0 = 0; c0 < nb; c0 += RES_LANES) {
+      const u32 c = c0 + sub;
       bool ok = c < nb;
       u32 x = ok ? base[c] : 0;
-      if (ok) ok = onlisted(ix.onlist_bits, x);
-      for (u32 j = 0; j < m; j++) {
-        if (j == best) continue;
-        const u32 e = es[j];
-        if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+      u32 gmask;
+      if (pass == 1 && c0 == 0) gmask = first_mask;  // the first 16 candidates were classified in pass 0
+      else {
+        if (ok) ok = onlisted(ix.onlist_bits, x);
+        for (u32 j = 0; j < m; j++) {
+          if (j == best) continue;
+          const u32 e = es[j];
+          if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+        }
+        gmask = (u32)((__ballot(ok) >> gsh) & 0xFFFFu);
+        if (pass == 0 && c0 == 0) first_mask = gmask;
       }
-      const u64 bal = __ballot(ok);
-      if (pass == 1 && ok) cand[out_off + 2 + written + __popcll(bal & ((1ULL << lane) - 1))] = x;
-      written += (u32)__popcll(bal);
+      if (pass == 1 && ((gmask >> sub) & 1u)) cand[out_off + 2 + written + __popc(gmask & ((1u << sub) - 1))] = x;
+      written += (u32)__popc(gmask);
     }
     if (pass == 0) {
       total = written;
       if (total == 0) return;  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
-      if (lane == 0) {
+      if (sub == 0) {
         out_off = atomicAdd(&st->cand_words, (u64)total + 2);
         u64 r = atomicAdd(&st->cand_recs, 1ULL);
         cand[out_off] = (u32)sl.count; cand[out_off + 1] = total;
         cand_off[r] = out_off;
       }
-      out_off = __shfl(out_off, 0, 64);
+      out_off = __shfl(out_off, gsh, 64);
     }
   }
 }
@@ -424,13 +432,15 @@ __global__ void k_tuple_export_offsets(const u32* __restrict__ stream, const TSl
 // ------------------------------------------------------------------------------------------------------------------
 // FLD probe kernel: per item the fragment length KmerIndex::mapPair would return and |u| (first items only)
 // ------------------------------------------------------------------------------------------------------------------
+constexpr u32 FLD_OVERFLOW = 0xFFFFFFFFu;
 __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
-                                               u64 n_items, int seq_words, int rec_words, u32* scratch, int32_t* tl_out,
-                                               u32* card_out) {
-  u64 item = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= n_items) return;
+                                               const u64* __restrict__ items, u64 n_items, int seq_words, int rec_words,
+                                               u32* scratch, int cap, int32_t* tl_out, u32* card_out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  const u64 item = items ? items[i] : i;
   const int item_words = rec_words * 2;
-  kamd::EcList ecs; ecs.e = scratch + item * TUPLE_CAP_BIG; ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
+  kamd::EcList ecs; ecs.e = scratch + i * (u64)cap; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
   kamd::MateInfo m0, m1;
   kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
   const u32* rec = words + item * item_words;
@@ -464,6 +474,7 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
       }
     }
   }
+  if (ecs.overflow) card = FLD_OVERFLOW;  // re-run by the host with a larger list
   tl_out[item] = tl; card_out[item] = card;
 }
 
@@ -501,71 +512,166 @@ __global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Kernel B: EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223)
+// Kernel B: EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223), FP64, four launches per round and no atomics on the data:
+//   k_em_rows   one EC row per 4-lane group: denom_e = sum_t alpha[t] * w[e,t]  ->  cn[e] = counts[e] / denom_e
+//   k_em_seg    the transposed (transcript-major) copy of the matrix, cut into segments of <= 64 entries:
+//               partial[s] = sum_{e in segment} (w[e,t] * alpha[t]) * cn[e]   (+ counts[e] for singleton rows)
+//   k_em_final  next[t] = sum of t's segment sums and the convergence test of :176-199
+//   k_em_control (one thread) the loop control of :202-221.
+// alpha is double-buffered (round i reads A[i&1], writes A[(i+1)&1]); the clamp of the final round (:212-221) is applied
+// on read, so the unclamped buffer is alpha_before_zeroes_.
 // ------------------------------------------------------------------------------------------------------------------
 struct EmState {
-  int iter;        // current round index i
+  int iter;         // round index i
   int chcount;
-  int final_round; // finalRound
+  int blocks_done;
+  int final_round;  // finalRound: this round reads the clamped alpha and is the last one
   int done;
-  int rounds;      // i at exit ("ran for i rounds")
-  int zero_now;    // the stop test fired in this round: snapshot alpha_before_zeroes and clamp
+  int rounds;       // i at exit ("ran for i rounds")
 };
+constexpr u32 EM_SINGLE = 0x80000000u;
 
-// E step + accumulation, one wavefront per EC row group: rows are short, so each lane owns one row when |row| is small
-__global__ __launch_bounds__(BLOCK) void k_em_estep(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids,
-                                                    const u32* __restrict__ counts, const u32* __restrict__ wcounts,
-                                                    u64 n_ecs, const double* __restrict__ eff, const double* __restrict__ alpha,
-                                                    double* next, const EmState* st) {
-  if (st->done) return;
+__device__ __forceinline__ double em_alpha(const double* a, u32 t, int clamp) {
+  double v = a[t];
+  return (clamp && v < 1e-7 / 10.0) ? 0.0 : v;  // alpha_limit/10 (:217-219)
+}
+
+// per-nnz weights w[e,t] = weight_counts[e] / eff_lens[t] (calc_weights, src/weights.cpp:220-246) + column counts
+__global__ void k_em_prepare(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ wcounts,
+                             u64 n_ecs, const double* __restrict__ eff, double* w_row, u32* col_cnt) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const double wc = (double)wcounts[e];
+  for (u64 j = ec_off[e]; j < ec_off[e + 1]; j++) {
+    const u32 t = ec_ids[j];
+    w_row[j] = wc / eff[t];
+    atomicAdd(&col_cnt[t], 1u);
+  }
+}
+__global__ void k_em_transpose(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs,
+                               const double* __restrict__ w_row, const u64* __restrict__ col_off, u32* col_fill, u32* col_row,
+                               double* col_w) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_ecs) return;
   const u64 a = ec_off[e], b = ec_off[e + 1];
-  const u32 cnt = counts[e];
-  if (b - a == 1) { unsafeAtomicAdd(&next[ec_ids[a]], (double)cnt); return; }  // :119-123 (next starts at 0; a transcript has one singleton set)
-  if (cnt == 0) return;                                        // :133-135
-  const double wc = (double)wcounts[e];
-  double denom = 0.0;
-  for (u64 j = a; j < b; j++) { u32 t = ec_ids[j]; denom += alpha[t] * (wc / eff[t]); }  // weights.cpp:236, EMAlgorithm.h:152-154
-  if (denom < 4.9406564584124654e-324) return;                 // TOLERANCE = denorm_min (:19,:156-158)
-  const double countNorm = cnt / denom;                        // :161
+  const u32 tag = (b - a == 1) ? EM_SINGLE : 0u;
   for (u64 j = a; j < b; j++) {
-    u32 t = ec_ids[j];
-    unsafeAtomicAdd(&next[t], ((wc / eff[t]) * alpha[t]) * countNorm);  // :162-164
+    const u32 t = ec_ids[j];
+    const u64 pos = col_off[t] + atomicAdd(&col_fill[t], 1u);
+    col_row[pos] = (u32)e | tag;
+    col_w[pos] = w_row[j];
   }
 }
-// M step bookkeeping per transcript (:176-199) + clamp of the final round (:212-221)
-__global__ void k_em_update(u64 n_tr, double* alpha, double* next, double* alpha_before_zeroes, EmState* st) {
+
+constexpr int EM_ROW_LANES = 4;
+__global__ __launch_bounds__(BLOCK) void k_em_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids,
+                                                   const u32* __restrict__ counts, u64 n_ecs, const double* __restrict__ w_row,
+                                                   const double* __restrict__ alpha0, const double* __restrict__ alpha1,
+                                                   double* __restrict__ cn, const EmState* st) {
   if (st->done) return;
+  const double* alpha = (st->iter & 1) ? alpha1 : alpha0;
+  const int clamp = st->final_round;
+  const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_ROW_LANES;
+  const int sub = threadIdx.x & (EM_ROW_LANES - 1);
+  double denom = 0.0;
+  u64 a = 0, b = 0;
+  if (g < n_ecs) { a = ec_off[g]; b = ec_off[g + 1]; }
+  for (u64 j = a + sub; j < b; j += EM_ROW_LANES) denom += em_alpha(alpha, ec_ids[j], clamp) * w_row[j];  // :152-154
+#pragma unroll
+  for (int d = 1; d < EM_ROW_LANES; d <<= 1) denom += __shfl_xor(denom, d, 64);
+  if (g < n_ecs && sub == 0) {
+    const u32 cnt = counts[g];
+    // rows that the reference skips (count 0, or denom < TOLERANCE = denorm_min, :133-135,:156-158) contribute nothing
+    cn[g] = (b - a == 1 || cnt == 0 || denom < 4.9406564584124654e-324) ? 0.0 : cnt / denom;  // countNorm (:161)
+  }
+}
+
+// The transcript-major pass is balanced over nnz, not over transcripts (a highly expressed transcript sits in thousands
+// of ECs): every column is cut into segments of at most EM_SEG entries; k_em_seg reduces one segment per 16-lane group
+// (4 independent loads in flight per lane), k_em_final adds a transcript's segment sums in a fixed order.
+constexpr int EM_SEG = 64;
+constexpr int EM_SEG_LANES = 16;
+constexpr int EM_FIN_LANES = 8;
+__global__ void k_em_nseg(const u32* __restrict__ col_cnt, u64 n_tr, u32* nseg) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  int ch = 0;
-  if (t < n_tr) {
-    const double nx = next[t], al = alpha[t];
-    if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ch = 1;
-    alpha[t] = nx;
-    next[t] = 0.0;
-  }
-  u64 bal = __ballot(ch);
-  if (lane_id() == 0 && bal) atomicAdd(&st->chcount, (int)__popcll(bal));
+  if (t < n_tr) nseg[t] = (col_cnt[t] + EM_SEG - 1) / EM_SEG;
 }
-__global__ void k_em_control(EmState* st, int n_iter, int min_rounds) {
-  if (st->done) return;
-  const int i = st->iter;
-  const bool stopEM = (st->chcount == 0 && i > min_rounds);  // :202-205
-  st->chcount = 0;
-  st->zero_now = 0;
-  if (st->final_round) { st->done = 1; st->rounds = i; return; }  // :207-209 (break: i is not incremented)
-  if (stopEM) { st->final_round = 1; st->zero_now = 1; }
-  st->iter = i + 1;
-  if (i + 1 >= n_iter) { st->done = 1; st->rounds = i + 1; }      // loop ran out
-}
-__global__ void k_em_zero(u64 n_tr, double* alpha, double* alpha_before_zeroes, const EmState* st) {
-  if (!st->zero_now) return;
+__global__ void k_em_segsetup(const u64* __restrict__ col_off, const u64* __restrict__ seg_off, u64 n_tr, u32* seg_t) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tr) return;
-  const double a = alpha[t];
-  alpha_before_zeroes[t] = a;
-  if (a < 1e-7 / 10.0) alpha[t] = 0.0;  // alpha_limit/10 (:217-219)
+  for (u64 s = seg_off[t]; s < seg_off[t + 1]; s++) seg_t[s] = (u32)t;
+}
+__global__ __launch_bounds__(BLOCK) void k_em_seg(const u64* __restrict__ col_off, const u64* __restrict__ seg_off,
+                                                  const u32* __restrict__ seg_t, u64 n_seg, const u32* __restrict__ col_row,
+                                                  const double* __restrict__ col_w, const u32* __restrict__ counts,
+                                                  const double* __restrict__ cn, const double* __restrict__ alpha0,
+                                                  const double* __restrict__ alpha1, double* __restrict__ partial,
+                                                  const EmState* st) {
+  if (st->done) return;
+  const double* alpha = (st->iter & 1) ? alpha1 : alpha0;
+  const int clamp = st->final_round;
+  const u64 sidx = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_SEG_LANES;
+  const int sub = threadIdx.x & (EM_SEG_LANES - 1);
+  double acc = 0.0;
+  if (sidx < n_seg) {
+    const u32 t = seg_t[sidx];
+    const double al = em_alpha(alpha, t, clamp);
+    const u64 begin = col_off[t] + (sidx - seg_off[t]) * EM_SEG;
+    const u64 end = min(col_off[t + 1], begin + EM_SEG);
+    u32 r[EM_SEG / EM_SEG_LANES]; double w[EM_SEG / EM_SEG_LANES];
+#pragma unroll
+    for (int i = 0; i < EM_SEG / EM_SEG_LANES; i++) {
+      const u64 j = begin + sub + (u64)i * EM_SEG_LANES;
+      const bool in = j < end;
+      r[i] = in ? col_row[j] : EM_SINGLE;  // a padding lane acts as a singleton row with ...
+      w[i] = in ? col_w[j] : -1.0;         // ... a negative weight marker (skipped below)
+    }
+#pragma unroll
+    for (int i = 0; i < EM_SEG / EM_SEG_LANES; i++) {
+      if (w[i] < 0.0) continue;
+      if (r[i] & EM_SINGLE) acc += (double)counts[r[i] & ~EM_SINGLE];  // :119-123
+      else acc += (w[i] * al) * cn[r[i]];                                // :162-164
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < EM_SEG_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
+  if (sidx < n_seg && sub == 0) partial[sidx] = acc;
+}
+__global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_off, const double* __restrict__ partial,
+                                                    u64 n_tr, double* alpha0, double* alpha1, EmState* st) {
+  if (st->done) return;
+  const int it = st->iter;
+  const double* alpha = (it & 1) ? alpha1 : alpha0;
+  double* next = (it & 1) ? alpha0 : alpha1;
+  const int clamp = st->final_round;
+  const u64 t = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_FIN_LANES;
+  const int sub = threadIdx.x & (EM_FIN_LANES - 1);
+  double acc = 0.0, al = 0.0;
+  if (t < n_tr) {
+    al = em_alpha(alpha, (u32)t, clamp);
+    for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
+  }
+#pragma unroll
+  for (int d = 1; d < EM_FIN_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
+  int ch = 0;
+  if (t < n_tr && sub == 0) {
+    if (acc > 1e-2 && (fabs(acc - al) / acc) > 1e-2) ch = 1;        // :177-179
+    next[t] = acc;
+  }
+  const u64 bal = __ballot(ch);
+  if (lane_id() == 0 && bal) atomicAdd(&st->chcount, (int)__popcll(bal));
+}
+// loop control of :202-221, one thread, after the round's k_em_final (a kernel boundary orders it behind every block;
+// an in-kernel "last block" hand-off would need an agent-scope fence per block, which flushes the L2 each time)
+__global__ void k_em_control(EmState* st, int n_iter, int min_rounds) {
+  if (st->done) return;
+  const int it = st->iter;
+  const bool stopEM = (st->chcount == 0 && it > min_rounds);     // :202-205
+  st->chcount = 0;
+  if (st->final_round) { st->done = 1; st->rounds = it; return; } // :207-209
+  if (stopEM) st->final_round = 1;                                // :212-221 (clamp applied on read next round)
+  st->iter = it + 1;
+  if (it + 1 >= n_iter) { st->done = 1; st->rounds = it + 1; }
 }
 __global__ void k_fill_f64(double* p, u64 n, double v) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -603,7 +709,7 @@ struct kamd_ctx {
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
   DBuf ec_off, ec_ids, ec_counts;
-  DBuf em_alpha, em_next, em_abz, em_eff, em_state;
+  DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
   u64 n_distinct_tuples = 0;
@@ -735,8 +841,9 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes,
-                  &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_abz, &c->em_eff,
-                  &c->em_state})
+                  &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
+                  &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
+                  &c->em_segoff, &c->em_segt, &c->em_partial})
     b->release();
   delete c;
 }
@@ -873,28 +980,46 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const uint32_t* d_words, const u
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
   u64 found = 0, done = 0;
-  const u64 chunk = 16384;
-  DBuf tl, card, scratch;
-  std::vector<int32_t> h_tl(chunk); std::vector<u32> h_card(chunk);
+  const int cap_small = 64;
+  u64 chunk = 131072;
+  DBuf tl, card, scratch, items;
+  std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
   int rc = 0;
   while (done < n_items && found < 10000 && rc == 0) {
     const u64 n = std::min(chunk, n_items - done);
+    h_tl.resize(n); h_card.resize(n);
     if ((rc = tl.ensure(n * 4, 0, c->stream))) break;
     if ((rc = card.ensure(n * 4, 0, c->stream))) break;
-    if ((rc = scratch.ensure(n * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
-    const u64 woff = done * (u64)rec_words * 2;
-    hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, d_words + woff, d_len + 2 * done, n,
-                       seq_words, rec_words, scratch.as<u32>(), tl.as<int32_t>(), card.as<u32>());
+    if ((rc = scratch.ensure(n * cap_small * 4, 0, c->stream))) break;
+    const u32* w = d_words + done * (u64)rec_words * 2;
+    const uint16_t* l = d_len + 2 * done;
+    hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, (const u64*)nullptr, n, seq_words,
+                       rec_words, scratch.as<u32>(), cap_small, tl.as<int32_t>(), card.as<u32>());
     if (hipGetLastError() != hipSuccess) { rc = kamd::fail(-100, "k_fld launch failed"); break; }
     if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+    // items with more than cap_small distinct sets: same kernel again with the large list
+    h_items.clear();
+    for (u64 i = 0; i < n; i++) if (h_card[i] == FLD_OVERFLOW) h_items.push_back(i);
+    if (!h_items.empty()) {
+      const u64 no = h_items.size();
+      if ((rc = items.ensure(no * 8, 0, c->stream))) break;
+      if ((rc = scratch.ensure(no * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
+      if (hipMemcpyAsync(items.p, h_items.data(), no * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+      hipLaunchKernelGGL(k_fld, dim3(grid_for(no, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, items.as<u64>(), no, seq_words,
+                         rec_words, scratch.as<u32>(), TUPLE_CAP_BIG, tl.as<int32_t>(), card.as<u32>());
+      if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+    }
     // first 10000 qualifying pairs in input order (ProcessReads.cpp:981-1017,1174-1181 at -t 1)
     for (u64 i = 0; i < n && found < 10000; i++)
       if (h_card[i] == 1 && h_tl[i] > 0 && h_tl[i] < KAMD_MAX_FRAG_LEN) { flens[h_tl[i]]++; found++; }
     done += n;
+    chunk = std::min<u64>(chunk * 4, 2097152);
   }
-  tl.release(); card.release(); scratch.release();
+  tl.release(); card.release(); scratch.release(); items.release();
   if (n_used) *n_used = found;
   return rc;
 }
@@ -968,7 +1093,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   if (int rc = c->cand_off.ensure((max_cands + 1) * sizeof(u64), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
                      c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
-  if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * 64, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+  if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
                               c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
@@ -1033,26 +1158,63 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   }
   const u64 T = n_targets;
   if (T == 0) return kamd::fail(-1, "kamd_em_run: no targets");
-  for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_abz, &c->em_eff}) if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
+  u64 nnz = 0;
+  if (n_ecs) {
+    HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
+  for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_eff}) if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
   if (int rc = c->em_state.ensure(sizeof(EmState), 0, c->stream)) return rc;
+  if (int rc = c->em_wrow.ensure((nnz + 1) * sizeof(double), 0, c->stream)) return rc;
+  if (int rc = c->em_colw.ensure((nnz + 1) * sizeof(double), 0, c->stream)) return rc;
+  if (int rc = c->em_colrow.ensure((nnz + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->em_cn.ensure((n_ecs + 1) * sizeof(double), 0, c->stream)) return rc;
+  if (int rc = c->em_colcnt.ensure(3 * (T + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->em_segoff.ensure((T + 2) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->em_coloff.ensure((T + 2) * sizeof(u64), 0, c->stream)) return rc;
+  u32* col_cnt = c->em_colcnt.as<u32>();
+  u32* col_fill = col_cnt + (T + 1);
   HIPC(hipMemcpyAsync(c->em_eff.p, eff_lens, T * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPC(hipMemsetAsync(c->em_next.p, 0, T * sizeof(double), c->stream));
-  HIPC(hipMemsetAsync(c->em_abz.p, 0, T * sizeof(double), c->stream));
+  HIPC(hipMemsetAsync(col_cnt, 0, 2 * (T + 1) * sizeof(u32), c->stream));
   HIPC(hipMemsetAsync(c->em_state.p, 0, sizeof(EmState), c->stream));
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  // transposed (transcript-major) copy of the EC x transcript matrix, built once per run
+  if (n_ecs) hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
+                                d_wcounts, (u64)n_ecs, c->em_eff.as<double>(), c->em_wrow.as<double>(), col_cnt);
+  if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
+  if (n_ecs) hipLaunchKernelGGL(k_em_transpose, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
+                                (u64)n_ecs, c->em_wrow.as<double>(), c->em_coloff.as<u64>(), col_fill, c->em_colrow.as<u32>(),
+                                c->em_colw.as<double>());
   hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_alpha.as<double>(), T, 1.0 / (double)T);
+  // column segments
+  u32* nseg = col_cnt + 2 * (T + 1);
+  hipLaunchKernelGGL(k_em_nseg, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, col_cnt, T, nseg);
+  if (int rc = exclusive_scan(c, nseg, T, c->em_segoff.as<u64>(), c->em_segoff.as<u64>() + T)) return rc;
+  u64 n_seg = 0;
+  HIPC(hipMemcpyAsync(&n_seg, c->em_segoff.as<u64>() + T, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (int rc = c->em_segt.ensure((n_seg + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->em_partial.ensure((n_seg + 1) * sizeof(double), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_em_segsetup, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(), T,
+                     c->em_segt.as<u32>());
+  HIPC(hipGetLastError());
   EmState hs{};
   const int chunk = 64;
-  HIPC(hipEventRecord(c->ev0, c->stream));
+  const unsigned grid_rows = grid_for(std::max<u64>(n_ecs, 1) * EM_ROW_LANES, BLOCK);
+  const unsigned grid_seg = grid_for(std::max<u64>(n_seg, 1) * EM_SEG_LANES, BLOCK);
+  const unsigned grid_fin = grid_for(T * EM_FIN_LANES, BLOCK);
   while (!hs.done) {
     for (int it = 0; it < chunk; it++) {
-      if (n_ecs) hipLaunchKernelGGL(k_em_estep, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
-                                    d_counts, d_wcounts, (u64)n_ecs, c->em_eff.as<double>(), c->em_alpha.as<double>(),
-                                    c->em_next.as<double>(), (const EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_update, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_alpha.as<double>(),
-                         c->em_next.as<double>(), c->em_abz.as<double>(), (EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_rows, dim3(grid_rows), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, d_counts, (u64)n_ecs,
+                         c->em_wrow.as<double>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_cn.as<double>(),
+                         (const EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_seg, dim3(grid_seg), dim3(BLOCK), 0, c->stream, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(),
+                         c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_colw.as<double>(), d_counts,
+                         c->em_cn.as<double>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_partial.as<double>(),
+                         (const EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, c->stream, c->em_segoff.as<u64>(), c->em_partial.as<double>(), T,
+                         c->em_alpha.as<double>(), c->em_next.as<double>(), (EmState*)c->em_state.p);
       hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, c->stream, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds);
-      hipLaunchKernelGGL(k_em_zero, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_alpha.as<double>(),
-                         c->em_abz.as<double>(), (const EmState*)c->em_state.p);
     }
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, c->stream));
@@ -1061,9 +1223,15 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipEventSynchronize(c->ev1));
   HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
-  c->last_em_iters = (uint64_t)hs.rounds + 1;
-  HIPC(hipMemcpyAsync(alpha, c->em_alpha.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (alpha_before_zeroes) HIPC(hipMemcpyAsync(alpha_before_zeroes, c->em_abz.p, T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  c->last_em_iters = (uint64_t)hs.rounds + (hs.final_round ? 1 : 0);
+  // result = the buffer the last executed round wrote; alpha_before_zeroes = the (unclamped) buffer it read
+  double* bufs[2] = {c->em_alpha.as<double>(), c->em_next.as<double>()};
+  const int last_read = hs.final_round ? (hs.rounds & 1) : ((hs.rounds - 1) & 1);
+  HIPC(hipMemcpyAsync(alpha, bufs[last_read ^ 1], T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (alpha_before_zeroes) {
+    if (hs.final_round) HIPC(hipMemcpyAsync(alpha_before_zeroes, bufs[last_read], T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    else memset(alpha_before_zeroes, 0, T * sizeof(double));
+  }
   HIPC(hipStreamSynchronize(c->stream));
   if (rounds) *rounds = hs.rounds;
   return 0;
