@@ -105,8 +105,8 @@ int kamd_pseudoalign(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words,
                      int32_t max_len);
 /* fragment-length histogram from the first 10000 qualifying pairs in input order of the given batch
  * (src/ProcessReads.cpp:981-1017,1174-1181 at -t 1).  flens: KAMD_MAX_FRAG_LEN u32 (host). */
-int kamd_fld_from_batch(kamd_ctx*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items, int32_t max_len,
-                        uint32_t* flens, uint64_t* n_used);
+int kamd_fld_from_batch(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
+                        int32_t max_len, uint32_t* flens, uint64_t* n_used);
 
 /* statistics of the batches processed so far */
 typedef struct {
@@ -138,6 +138,12 @@ int kamd_ec_tuples_export(kamd_ctx*, uint64_t* n_words, uint64_t* n_tuples);    
 int kamd_ec_tuples_copy(kamd_ctx*, uint32_t* d_out_words, uint64_t* d_out_rec_off);
 /* install gathered records (offsets rebased by the caller to the concatenated buffer) */
 int kamd_ec_tuples_replace(kamd_ctx*, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off, uint64_t n_recs);
+
+/* records [1, n, t0..t(n-1)] of items whose set was changed by a positional filter (findPosition / strand); content-keyed,
+ * so ranks simply concatenate them */
+int kamd_ec_explicit_export(kamd_ctx*, uint64_t* n_words, uint64_t* n_recs);
+int kamd_ec_explicit_copy(kamd_ctx*, uint32_t* d_out_words, uint64_t* d_out_rec_off);
+int kamd_ec_explicit_replace(kamd_ctx*, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off, uint64_t n_recs);
 
 /* ---- finalize: resolve intersections, apply the on-list mask, merge equal sets ----
  * Produces the EC multiset {sorted transcript set -> count} as CSR, on device and (optionally) host. */

@@ -73,7 +73,7 @@ _SYMBOLS = {
     "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "kamd_pseudoalign": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
-    "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
+    "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                       C.POINTER(C.c_uint64)]),
     "kamd_align_stats_get": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "kamd_profile_get": (C.c_int, [C.c_void_p, C.POINTER(_Profile)]),
@@ -81,6 +81,9 @@ _SYMBOLS = {
     "kamd_ec_tuples_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_ec_tuples_replace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "kamd_ec_explicit_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "kamd_ec_explicit_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kamd_ec_explicit_replace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     "kamd_ec_finalize": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
     "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -266,10 +269,10 @@ class Context:
         _check(load_library().kamd_pseudoalign(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len),
                "kamd_pseudoalign")
 
-    def fld_from_batch(self, words, lens, n_items: int, max_len: int):
+    def fld_from_batch(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
         flens = np.zeros(MAX_FRAG_LEN, np.uint32)
         used = C.c_uint64(0)
-        _check(load_library().kamd_fld_from_batch(self._h, words.data_ptr(), lens.data_ptr(), n_items, max_len,
+        _check(load_library().kamd_fld_from_batch(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len,
                                                   flens.ctypes.data, C.byref(used)), "kamd_fld_from_batch")
         return flens, int(used.value)
 
@@ -305,6 +308,20 @@ class Context:
                                                      offs.data_ptr() if offs.numel() else None, offs.numel()),
                "kamd_ec_tuples_replace")
 
+    def explicit_export(self):
+        torch = self.torch
+        nw, nr = C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().kamd_ec_explicit_export(self._h, C.byref(nw), C.byref(nr)), "kamd_ec_explicit_export")
+        words = torch.zeros(max(int(nw.value), 1), dtype=torch.int32, device=f"cuda:{self.device}")
+        offs = torch.zeros(max(int(nr.value), 1), dtype=torch.int64, device=f"cuda:{self.device}")
+        _check(load_library().kamd_ec_explicit_copy(self._h, words.data_ptr(), offs.data_ptr()), "kamd_ec_explicit_copy")
+        return words[:int(nw.value)], offs[:int(nr.value)]
+
+    def explicit_replace(self, words, offs):
+        _check(load_library().kamd_ec_explicit_replace(self._h, words.data_ptr() if words.numel() else None, words.numel(),
+                                                       offs.data_ptr() if offs.numel() else None, offs.numel()),
+               "kamd_ec_explicit_replace")
+
     def allreduce_ec_counts(self, group=None):
         """Merge the EC state of all ranks: one RCCL all-reduce of the dense count vector over xGMI plus an all-gather
         of the tuple records (kallisto_amd/exchange.py)."""
@@ -312,9 +329,13 @@ class Context:
         from .exchange import merge_ec_state
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
+        from .exchange import gather_records
         words, offs = self.tuples_export()
         words, offs = merge_ec_state(self.dense_counts(), words, offs, group)
         self.tuples_replace(words, offs)
+        ew, eo = self.explicit_export()
+        ew, eo = gather_records(ew, eo, group)
+        self.explicit_replace(ew, eo)
 
     # ---- finalize / EM ----
     def finalize(self, download: bool = True):
@@ -432,7 +453,7 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
     # FLD: estimated from the first 10000 qualifying pairs of the input (rank 0's first batch) or given by -l/-s
     if opts.fld == 0.0:
         words, lens, n_items, max_len = batches[0]
-        flens, _ = ctx.fld_from_batch(words, lens, n_items, max_len)
+        flens, _ = ctx.fld_from_batch(opts, words, lens, n_items, max_len)
         if group is not None or _dist_on():
             flens = _broadcast_np(ctx, flens, group)
         mft = mean_frag_lens_trunc(flens)

@@ -46,13 +46,21 @@ struct DevIndex {
   const u64* ec_off; const u32* ec_ids; const uint8_t* ec_nonempty;
   const u32* onlist_bits;
   u64 n_ecs; int k;
+  // positional tables (findPosition / strand filters)
+  const u64* unitig_blk_off; const u32* unitig_len; const u32* blk_unitig; const u32* blk_lb; const u32* blk_ub; const u32* blk_ec;
+  const u64* blk_pos_off; const u32* blk_posw; const uint8_t* blk_sense; const int32_t* target_lens;
 };
+
+// the filters of processBuffer that depend on the position of the first mapping k-mer (ProcessReads.cpp:1095-1145)
+struct FilterDev { int single_overhang, has_mean_fl, fl, strand; };
 
 // device-resident cursors and statistics
 struct DevState {
   u64 stream_words, n_recs, n_overflow, n_retry;
   u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads;
   u64 n_list, bound_words;       // generic append cursor / size bound accumulator
+  u64 n_explicit, n_explicit_big; // items whose set was changed by a positional filter (from the main / overflow kernel)
+  u64 exp_words, exp_recs;       // explicit transcript-set stream
   u64 cand_words, cand_recs;     // candidate transcript-set stream
 };
 
@@ -79,6 +87,60 @@ __device__ __forceinline__ u64 rec_hash(const u32* w, u32 n, u64 seed) {
   return h | 1ULL;  // 0 is the empty tag
 }
 
+__device__ __forceinline__ bool onlisted(const u32* bits, u32 t) { return (bits[t >> 5] >> (t & 31)) & 1u; }
+__device__ __forceinline__ bool set_contains(const u32* ids, u32 n, u32 x) {
+  u32 lo = 0, hi = n;
+  while (lo < hi) { u32 mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
+  return lo < n && ids[lo] == x;
+}
+// f(tr) for every on-listed member of the intersection of the item's transcript sets (thread-serial)
+template <class F>
+__device__ __forceinline__ void for_each_member(const DevIndex& ix, const kamd::EcList& ecs, F&& f) {
+  u32 best = 0; u64 best_sz = ~0ULL;
+  for (int j = 0; j < ecs.n; j++) { u32 e = ecs.e[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = (u32)j; } }
+  const u32* base = ix.ec_ids + ix.ec_off[ecs.e[best]];
+  for (u32 c = 0; c < (u32)best_sz; c++) {
+    const u32 x = base[c];
+    bool ok = onlisted(ix.onlist_bits, x);
+    for (int j = 0; ok && j < ecs.n; j++) {
+      if ((u32)j == best) continue;
+      const u32 e = ecs.e[j];
+      ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+    }
+    if (ok) f(x);
+  }
+}
+__device__ __forceinline__ kamd::PosTables pos_tables(const DevIndex& ix) {
+  return kamd::PosTables{(const uint64_t*)ix.unitig_blk_off, ix.unitig_len, ix.blk_unitig, ix.blk_lb, ix.blk_ub, ix.blk_ec,
+                         (const uint64_t*)ix.blk_pos_off, ix.blk_posw, ix.blk_sense, (const uint64_t*)ix.ec_off, ix.ec_ids,
+                         ix.target_lens, ix.k};
+}
+__device__ __forceinline__ kamd::FirstHit first_hit(const DevIndex& ix, const kamd::MateInfo& m) {
+  kamd::FirstHit h; h.valid = m.n_hits > 0;
+  h.block = h.valid ? ix.slot_block[m.first_slot] : 0u; h.dist = h.valid ? ix.slot_dist[m.first_slot] : 0u;
+  h.strand = m.first_strand; h.pos = m.first_pos;
+  return h;
+}
+__device__ __forceinline__ kamd::FilterCfg item_filter_cfg(const FilterDev& fd, bool paired, const kamd::MateInfo& m0,
+                                                           const kamd::MateInfo& m1) {
+  kamd::FilterCfg cfg;
+  cfg.fraglen = !fd.single_overhang && fd.has_mean_fl && (!paired || m0.n_hits == 0 || m1.n_hits == 0);  // ProcessReads.cpp:1095
+  cfg.fl = fd.fl; cfg.strand = fd.strand;
+  return cfg;
+}
+// 0 = the filters leave the set unchanged, 1 = they empty it, 2 = they change it (*kept = new size)
+__device__ __forceinline__ int filter_outcome(const DevIndex& ix, const FilterDev& fd, bool paired, const kamd::MateInfo& m0,
+                                              const kamd::MateInfo& m1, const kamd::EcList& ecs, u32* kept) {
+  const kamd::FilterCfg cfg = item_filter_cfg(fd, paired, m0, m1);
+  if (!cfg.fraglen && !cfg.strand) return 0;
+  const kamd::PosTables pt = pos_tables(ix);
+  const kamd::FirstHit h0 = first_hit(ix, m0), h1 = first_hit(ix, m1);
+  u32 total = 0, keep = 0;
+  for_each_member(ix, ecs, [&](u32 tr) { ++total; keep += kamd::keep_transcript(pt, cfg, h0, h1, tr) ? 1u : 0u; });
+  *kept = keep;
+  return keep == total ? 0 : (keep == 0 ? 1 : 2);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Kernel A
 // ------------------------------------------------------------------------------------------------------------------
@@ -87,13 +149,15 @@ struct AlignOut {
   u32* stream;         // records [cnt, m, e0..e(m-1)]
   u64* rec_off;        // word offset of each record
   u64* overflow_items; // item indices for the overflow kernel
+  u64* explicit_items; // items whose set a positional filter changed (re-run by k_explicit_write)
+  u64* explicit_items_big;
   DevState* st;
 };
 
-template <bool PAIRED>
+template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* __restrict__ words,
                                                        const uint16_t* __restrict__ lens, u64 n_items, int seq_words,
-                                                       int rec_words, AlignOut out) {
+                                                       int rec_words, FilterDev fd, AlignOut out) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const int item_words = rec_words * (PAIRED ? 2 : 1);
   u32* lds_reads = lds;
@@ -128,11 +192,22 @@ __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* _
       kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
     }
   }
-  // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow
+  // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow, 4 explicit set (positional filter changed it)
   int kind = 0;
   if (active) {
     if (ecs.overflow) kind = 3;
     else if (kamd::pair_is_mapped(m0, m1)) kind = ecs.n == 1 ? 1 : 2;
+  }
+  if (FILTER && (kind == 1 || kind == 2)) {
+    u32 kept = 0;
+    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+    if (oc == 1) kind = 0;
+    else if (oc == 2) {
+      kind = 4;
+      const u64 k = atomicAdd(&out.st->n_explicit, 1ULL);
+      out.explicit_items[k] = item0 + tid;
+      atomicAdd(&out.st->exp_words, (u64)kept + 2);
+    }
   }
   if (kind == 1) atomicAdd(&out.dense_counts[ecs.e[0]], 1u);
   // tuple stream: one allocation per wavefront (prefix sum of record sizes across the lanes)
@@ -174,10 +249,11 @@ __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* _
 }
 
 // items whose hits carried more than TUPLE_CAP distinct sets: same logic, lists in global scratch, reads from HBM
-template <bool PAIRED>
+template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const u32* __restrict__ words,
                                                              const uint16_t* __restrict__ lens, const u64* items, u64 n,
-                                                             int seq_words, int rec_words, u32* scratch, AlignOut out) {
+                                                             int seq_words, int rec_words, u32* scratch, FilterDev fd,
+                                                             AlignOut out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 item = items[i];
@@ -193,6 +269,17 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
     kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
   }
   if (ecs.overflow || !kamd::pair_is_mapped(m0, m1)) return;  // > TUPLE_CAP_BIG distinct sets cannot occur for 16-bit read lengths
+  if (FILTER) {
+    u32 kept = 0;
+    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+    if (oc == 1) return;
+    if (oc == 2) {
+      const u64 k = atomicAdd(&out.st->n_explicit_big, 1ULL);
+      out.explicit_items_big[k] = item;
+      atomicAdd(&out.st->exp_words, (u64)kept + 2);
+      return;
+    }
+  }
   u64 off = atomicAdd(&out.st->stream_words, (u64)ecs.n + 2);
   u64 ridx = atomicAdd(&out.st->n_recs, 1ULL);
   u32* w = out.stream + off;
@@ -200,6 +287,49 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
   for (int j = 0; j < ecs.n; j++) w[2 + j] = ecs.e[j];
   out.rec_off[ridx] = off;
   atomicAdd(&out.st->st_multi, 1ULL);
+}
+
+// items whose transcript set was changed by a positional filter: write the filtered set as an explicit record
+// [1, n, t0..t(n-1)] (same format as the candidate stream of the finalize step)
+template <bool PAIRED>
+__global__ __launch_bounds__(64) void k_explicit_write(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
+                                                       const u64* items, u64 n, int seq_words, int rec_words, u32* scratch,
+                                                       int cap, FilterDev fd, u32* exp_stream, u64* exp_off, DevState* st) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 item = items[i];
+  const int item_words = rec_words * (PAIRED ? 2 : 1);
+  kamd::EcList ecs; ecs.e = scratch + i * (u64)cap; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
+  kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0; m1.first_slot = 0; m1.first_pos = -1; m1.first_strand = false;
+  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const u32* rec = words + item * item_words;
+  kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
+  if (PAIRED) {
+    kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
+    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+  }
+  const kamd::FilterCfg cfg = item_filter_cfg(fd, PAIRED, m0, m1);
+  const kamd::PosTables pt = pos_tables(ix);
+  const kamd::FirstHit h0 = first_hit(ix, m0), h1 = first_hit(ix, m1);
+  u32 keep = 0;
+  for_each_member(ix, ecs, [&](u32 tr) { keep += kamd::keep_transcript(pt, cfg, h0, h1, tr) ? 1u : 0u; });
+  const u64 off = atomicAdd(&st->cand_words, (u64)keep + 2);   // cursor of this pass (exp_words holds the bound)
+  const u64 r = atomicAdd(&st->exp_recs, 1ULL);
+  u32* w = exp_stream + off;
+  w[0] = 1u; w[1] = keep;
+  u32 o = 0;
+  for_each_member(ix, ecs, [&](u32 tr) { if (kamd::keep_transcript(pt, cfg, h0, h1, tr)) w[2 + o++] = tr; });
+  exp_off[r] = off;
+}
+// append the explicit records to the candidate stream (offsets rebased)
+__global__ void k_copy_words(const u32* __restrict__ src, u64 n, u32* dst) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+__global__ void k_copy_offsets(const u64* __restrict__ src, u64 n, u64 base, u64* dst) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] + base;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -251,12 +381,6 @@ __global__ void k_table_list(const TSlot* table, u64 cap, u64* list, DevState* s
 // ------------------------------------------------------------------------------------------------------------------
 // resolve: candidates = transcript sets of (a) index sets with a non-zero dense count, (b) distinct tuples
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool onlisted(const u32* bits, u32 t) { return (bits[t >> 5] >> (t & 31)) & 1u; }
-__device__ __forceinline__ bool set_contains(const u32* ids, u32 n, u32 x) {
-  u32 lo = 0, hi = n;
-  while (lo < hi) { u32 mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
-  return lo < n && ids[lo] == x;
-}
 // upper bound of the candidate stream size: sum over candidates of (smallest list + 2)
 __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n,
                                DevState* st) {
@@ -435,7 +559,7 @@ __global__ void k_tuple_export_offsets(const u32* __restrict__ stream, const TSl
 constexpr u32 FLD_OVERFLOW = 0xFFFFFFFFu;
 __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                const u64* __restrict__ items, u64 n_items, int seq_words, int rec_words,
-                                               u32* scratch, int cap, int32_t* tl_out, u32* card_out) {
+                                               u32* scratch, int cap, FilterDev fd, int32_t* tl_out, u32* card_out) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const u64 item = items ? items[i] : i;
@@ -450,19 +574,14 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
   kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
   int32_t tl = -1; u32 card = 0;
   if (!ecs.overflow && kamd::pair_is_mapped(m0, m1)) {
-    // |u| : thread-serial intersection size (first items only, tiny)
-    u32 best = 0; u64 best_sz = ~0ULL;
-    for (int j = 0; j < ecs.n; j++) { u32 e = ecs.e[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = (u32)j; } }
-    const u32* base = ix.ec_ids + ix.ec_off[ecs.e[best]];
-    for (u32 c = 0; c < (u32)best_sz; c++) {
-      u32 x = base[c];
-      bool ok = onlisted(ix.onlist_bits, x);
-      for (int j = 0; ok && j < ecs.n; j++) {
-        if ((u32)j == best) continue;
-        u32 e = ecs.e[j];
-        ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
-      }
-      card += ok;
+    // |u| after the strand filter (the fragment-length filter cannot be active while the FLD is being estimated)
+    {
+      const kamd::FilterCfg cfg = item_filter_cfg(fd, true, m0, m1);
+      const kamd::PosTables pt = pos_tables(ix);
+      const kamd::FirstHit h0 = first_hit(ix, m0), h1 = first_hit(ix, m1);
+      for_each_member(ix, ecs, [&](u32 tr) {
+        card += (!(cfg.fraglen || cfg.strand) || kamd::keep_transcript(pt, cfg, h0, h1, tr)) ? 1u : 0u;
+      });
     }
     if (m0.n_hits > 0 && m1.n_hits > 0) {  // KmerIndex::mapPair (KmerIndex.cpp:1622-1693) on the first present k-mers
       const u32 b0 = ix.slot_block[m0.first_slot], b1 = ix.slot_block[m1.first_slot];
@@ -708,6 +827,7 @@ struct kamd_ctx {
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
+  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial;
   DevState host_state{};
@@ -717,6 +837,7 @@ struct kamd_ctx {
   u64 recs_counted = 0;
   kamd_ec_result result{};
   bool finalized = false;
+  u64 exp_words_done = 0;        // words of the explicit-set stream actually written
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_align_ms = 0.f, last_em_ms = 0.f;
   uint64_t last_em_iters = 0;
@@ -840,7 +961,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
-                  &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes,
+                  &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
                   &c->em_segoff, &c->em_segt, &c->em_partial})
@@ -868,12 +990,22 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   for (u64 e = 0; e < v.n_ecs; e++) ne[e] = v.ec_off[e + 1] > v.ec_off[e];
   if (int rc = upload(c, ne.data(), v.n_ecs, &d.ec_nonempty)) return rc;
   if (int rc = upload(c, v.onlist_bits, v.onlist_words, &d.onlist_bits)) return rc;
+  if (int rc = upload(c, (const u64*)v.unitig_blk_off, v.n_unitigs + 1, &d.unitig_blk_off)) return rc;
+  if (int rc = upload(c, v.unitig_len, v.n_unitigs, &d.unitig_len)) return rc;
+  if (int rc = upload(c, v.blk_unitig, v.n_blocks, &d.blk_unitig)) return rc;
+  if (int rc = upload(c, v.blk_lb, v.n_blocks, &d.blk_lb)) return rc;
+  if (int rc = upload(c, v.blk_ub, v.n_blocks, &d.blk_ub)) return rc;
+  if (int rc = upload(c, v.blk_ec, v.n_blocks, &d.blk_ec)) return rc;
+  if (int rc = upload(c, (const u64*)v.blk_pos_off, v.n_blocks + 1, &d.blk_pos_off)) return rc;
+  if (int rc = upload(c, v.blk_posw, (size_t)v.blk_pos_off[v.n_blocks], &d.blk_posw)) return rc;
+  if (int rc = upload(c, v.blk_sense, (size_t)v.blk_pos_off[v.n_blocks], &d.blk_sense)) return rc;
+  if (int rc = upload(c, v.target_lens, v.n_targets, &d.target_lens)) return rc;
   HIPC(hipStreamSynchronize(c->stream));  // `ne` is a stack-owned staging buffer
   c->ix = d; c->has_index = true; c->n_ecs = v.n_ecs; c->n_targets = v.n_targets;
   if (int rc = c->dense.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(v.n_ecs, 1) * sizeof(u32), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0;
+  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->exp_words_done = 0;
   return push_state(c);
 }
 
@@ -882,7 +1014,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipSetDevice(c->device));
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0;
+  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0;
   return push_state(c);
 }
 
@@ -901,15 +1033,30 @@ extern "C" int kamd_pack_reads_device(kamd_ctx* c, const char* d_seqs, const uin
   return 0;
 }
 
+namespace {
+template <bool PAIRED, bool FILTER>
+int launch_align(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, size_t lds_bytes,
+                 const FilterDev& fd, const AlignOut& out) {
+  HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<PAIRED, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_pseudoalign<PAIRED, FILTER>), dim3(grid_for(n_items, BLOCK)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words,
+                     d_len, n_items, seq_words, rec_words, fd, out);
+  return 0;
+}
+template <bool PAIRED, bool FILTER>
+void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
+                     const AlignOut& out) {
+  hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
+                     c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, out);
+}
+}  // namespace
+
 extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uint32_t* d_words, const uint16_t* d_len,
                                 uint64_t n_items, int32_t max_len) {
   if (!c || !o) return kamd::fail(-1, "kamd_pseudoalign: null argument");
   if (!c->has_index) return kamd::fail(-1, "kamd_pseudoalign: no index uploaded");
-  if (o->strand != 0) return kamd::fail(-4, "kamd_pseudoalign: --fr/--rf-stranded not implemented on the device yet");
-  if (!o->paired && !o->single_overhang)
-    return kamd::fail(-4, "kamd_pseudoalign: single-end reads need the findPosition filter (not on the device yet); pass single_overhang=1");
-  if (o->paired && o->fld > 0.0 && !o->single_overhang)
-    return kamd::fail(-4, "kamd_pseudoalign: paired reads with -l need the findPosition filter for orphan mates (not on the device yet)");
+  if (!o->paired && !(o->fld > 0.0 && o->sd > 0.0))
+    return kamd::fail(-1, "kamd_pseudoalign: fragment length mean and sd must be supplied for single-end reads (-l, -s)");
+  if (o->strand < 0 || o->strand > 2) return kamd::fail(-1, "kamd_pseudoalign: bad strand option");
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pseudoalign: max_len must be in [1, 65535]");
   if (n_items == 0) return 0;
   HIPC(hipSetDevice(c->device));
@@ -918,44 +1065,80 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   const int item_words = rec_words * (o->paired ? 2 : 1);
   const size_t lds_bytes = (size_t)BLOCK * item_words * 4 + (size_t)BLOCK * TUPLE_CAP * 4;
   if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-staged kernel");
+  // positional filters (ProcessReads.cpp:1095-1145): has_mean_fl is set by -l only (MinCollector::init_mean_fl_trunc);
+  // with an estimated FLD it stays false while reads are processed
+  FilterDev fd{o->single_overhang, o->fld > 0.0 ? 1 : 0, 0, o->strand};
+  if (fd.has_mean_fl) {
+    std::vector<double> t(KAMD_MAX_FRAG_LEN);
+    kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, o->fld, o->sd, t.data());
+    fd.fl = (int)t[KAMD_MAX_FRAG_LEN - 1];  // (int) tc.get_mean_frag_len() (ProcessReads.cpp:1098)
+  }
+  const bool filter = fd.strand != 0 || (!fd.single_overhang && fd.has_mean_fl);
   // capacity for the worst case of this batch
   const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
   if (int rc = c->stream_buf.ensure((cur_words + n_items * (TUPLE_CAP + 2)) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
   if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
   if (int rc = c->overflow_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
-  AlignOut out{c->dense.as<u32>(), c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(), (DevState*)c->state.p};
-  const unsigned grid = grid_for(n_items, BLOCK);
-  HIPC(hipEventRecord(c->ev0, c->stream));
-  if (o->paired) {
-    HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(k_pseudoalign<true>, dim3(grid), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, (u64)n_items,
-                       seq_words, rec_words, out);
-  } else {
-    HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(k_pseudoalign<false>, dim3(grid), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, (u64)n_items,
-                       seq_words, rec_words, out);
+  if (filter) {
+    if (int rc = c->explicit_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
+    if (int rc = c->explicit_items_big.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
   }
+  AlignOut out{c->dense.as<u32>(), c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
+               c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  int rc = 0;
+  if (o->paired) rc = filter ? launch_align<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
+                             : launch_align<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
+  else rc = filter ? launch_align<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
+                   : launch_align<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
+  if (rc) return rc;
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipGetLastError());
-  if (int rc = sync_state(c)) return rc;
+  if (int rc2 = sync_state(c)) return rc2;
   HIPC(hipEventElapsedTime(&c->last_align_ms, c->ev0, c->ev1));
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
-    if (int rc = c->overflow_scratch.ensure(nov * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc;
+    if (int rc2 = c->overflow_scratch.ensure(nov * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
     const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
-    if (int rc = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc;
-    if (int rc = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc;
+    if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
+    if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
     out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-    if (o->paired)
-      hipLaunchKernelGGL(k_pseudoalign_overflow<true>, dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
-                         c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), out);
-    else
-      hipLaunchKernelGGL(k_pseudoalign_overflow<false>, dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
-                         c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), out);
+    if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
+                     else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out); }
+    else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
+           else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out); }
     HIPC(hipGetLastError());
-    if (int rc = sync_state(c)) return rc;
+    if (int rc2 = sync_state(c)) return rc2;
     c->host_state.n_overflow = 0;
-    if (int rc = push_state(c)) return rc;
+    if (int rc2 = push_state(c)) return rc2;
+  }
+  if (filter && (c->host_state.n_explicit || c->host_state.n_explicit_big)) {
+    // second pass over the items whose set was changed: write the filtered sets as explicit records
+    const u64 ne = c->host_state.n_explicit, nb = c->host_state.n_explicit_big;
+    const u64 have_w = c->exp_words_done, have_r = c->host_state.exp_recs;
+    if (int rc2 = c->exp_stream.ensure((c->host_state.exp_words + 2) * sizeof(u32), have_w * sizeof(u32), c->stream)) return rc2;
+    if (int rc2 = c->exp_off.ensure((have_r + ne + nb + 1) * sizeof(u64), have_r * sizeof(u64), c->stream)) return rc2;
+    c->host_state.cand_words = have_w;  // write cursor of this pass
+    if (int rc2 = push_state(c)) return rc2;
+    for (int big = 0; big < 2; big++) {
+      const u64 n = big ? nb : ne;
+      if (!n) continue;
+      const int cap = big ? TUPLE_CAP_BIG : TUPLE_CAP;
+      if (int rc2 = c->exp_scratch.ensure(n * (u64)cap * sizeof(u32), 0, c->stream)) return rc2;
+      const u64* items = big ? c->explicit_items_big.as<u64>() : c->explicit_items.as<u64>();
+      if (o->paired) hipLaunchKernelGGL(k_explicit_write<true>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
+                                        seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(),
+                                        c->exp_off.as<u64>(), (DevState*)c->state.p);
+      else hipLaunchKernelGGL(k_explicit_write<false>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
+                              seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(), c->exp_off.as<u64>(),
+                              (DevState*)c->state.p);
+      HIPC(hipGetLastError());
+      HIPC(hipStreamSynchronize(c->stream));  // exp_scratch is reused by the second launch
+    }
+    if (int rc2 = sync_state(c)) return rc2;
+    c->exp_words_done = c->host_state.cand_words;
+    c->host_state.n_explicit = 0; c->host_state.n_explicit_big = 0;
+    if (int rc2 = push_state(c)) return rc2;
   }
   c->tuples_counted = false; c->finalized = false;
   return 0;
@@ -971,9 +1154,11 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   return 0;
 }
 
-extern "C" int kamd_fld_from_batch(kamd_ctx* c, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
-                                   int32_t max_len, uint32_t* flens, uint64_t* n_used) {
-  if (!c || !flens) return kamd::fail(-1, "kamd_fld_from_batch: null argument");
+extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const uint32_t* d_words, const uint16_t* d_len,
+                                   uint64_t n_items, int32_t max_len, uint32_t* flens, uint64_t* n_used) {
+  if (!c || !flens || !o) return kamd::fail(-1, "kamd_fld_from_batch: null argument");
+  if (!o->paired || o->fld != 0.0) return kamd::fail(-1, "kamd_fld_from_batch: the FLD is only estimated for paired reads without -l");
+  const FilterDev fd{o->single_overhang, 0, 0, o->strand};
   if (!c->has_index) return kamd::fail(-1, "kamd_fld_from_batch: no index uploaded");
   HIPC(hipSetDevice(c->device));
   memset(flens, 0, KAMD_MAX_FRAG_LEN * sizeof(uint32_t));
@@ -994,7 +1179,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const uint32_t* d_words, const u
     const u32* w = d_words + done * (u64)rec_words * 2;
     const uint16_t* l = d_len + 2 * done;
     hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, (const u64*)nullptr, n, seq_words,
-                       rec_words, scratch.as<u32>(), cap_small, tl.as<int32_t>(), card.as<u32>());
+                       rec_words, scratch.as<u32>(), cap_small, fd, tl.as<int32_t>(), card.as<u32>());
     if (hipGetLastError() != hipSuccess) { rc = kamd::fail(-100, "k_fld launch failed"); break; }
     if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1008,7 +1193,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const uint32_t* d_words, const u
       if ((rc = scratch.ensure(no * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
       if (hipMemcpyAsync(items.p, h_items.data(), no * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
       hipLaunchKernelGGL(k_fld, dim3(grid_for(no, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, items.as<u64>(), no, seq_words,
-                         rec_words, scratch.as<u32>(), TUPLE_CAP_BIG, tl.as<int32_t>(), card.as<u32>());
+                         rec_words, scratch.as<u32>(), TUPLE_CAP_BIG, fd, tl.as<int32_t>(), card.as<u32>());
       if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
           hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
           hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
@@ -1070,6 +1255,36 @@ extern "C" int kamd_ec_tuples_replace(kamd_ctx* c, const uint32_t* d_words, uint
   return push_state(c);
 }
 
+// explicit transcript-set records (positional filters): plain copies, the records are content-keyed
+extern "C" int kamd_ec_explicit_export(kamd_ctx* c, uint64_t* n_words, uint64_t* n_recs) {
+  if (!c || !n_words || !n_recs) return kamd::fail(-1, "kamd_ec_explicit_export: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = sync_state(c)) return rc;
+  *n_words = c->exp_words_done; *n_recs = c->host_state.exp_recs;
+  return 0;
+}
+extern "C" int kamd_ec_explicit_copy(kamd_ctx* c, uint32_t* d_out_words, uint64_t* d_out_rec_off) {
+  if (!c) return kamd::fail(-1, "kamd_ec_explicit_copy: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (c->exp_words_done) HIPC(hipMemcpyAsync(d_out_words, c->exp_stream.p, c->exp_words_done * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+  if (c->host_state.exp_recs) HIPC(hipMemcpyAsync(d_out_rec_off, c->exp_off.p, c->host_state.exp_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int kamd_ec_explicit_replace(kamd_ctx* c, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off,
+                                        uint64_t n_recs) {
+  if (!c) return kamd::fail(-1, "kamd_ec_explicit_replace: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = sync_state(c)) return rc;
+  if (int rc = c->exp_stream.ensure(std::max<u64>(n_words, 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->exp_off.ensure((n_recs + 1) * sizeof(u64), 0, c->stream)) return rc;
+  if (n_words) HIPC(hipMemcpyAsync(c->exp_stream.p, d_words, n_words * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+  if (n_recs) HIPC(hipMemcpyAsync(c->exp_off.p, d_rec_off, n_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+  c->exp_words_done = n_words; c->host_state.exp_recs = n_recs; c->host_state.exp_words = n_words;
+  c->finalized = false;
+  return push_state(c);
+}
+
 // ---- finalize ---------------------------------------------------------------------------------------------------------
 extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   if (!c) return kamd::fail(-1, "kamd_ec_finalize: null context");
@@ -1087,8 +1302,9 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
                               c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, dst);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
-  const u64 bound = c->host_state.bound_words;
-  const u64 max_cands = c->n_ecs + n_t;
+  const u64 n_exp_w = c->exp_words_done, n_exp_r = c->host_state.exp_recs;
+  const u64 bound = c->host_state.bound_words + n_exp_w;
+  const u64 max_cands = c->n_ecs + n_t + n_exp_r;
   if (int rc = c->cand.ensure((bound + 2) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->cand_off.ensure((max_cands + 1) * sizeof(u64), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
@@ -1097,6 +1313,15 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
                               c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
+  if (n_exp_r) {  // sets produced by the positional filters join the candidates
+    const u64 wbase = c->host_state.cand_words, rbase = c->host_state.cand_recs;
+    hipLaunchKernelGGL(k_copy_words, dim3(grid_for(n_exp_w, BLOCK)), dim3(BLOCK), 0, c->stream, c->exp_stream.as<u32>(), n_exp_w,
+                       c->cand.as<u32>() + wbase);
+    hipLaunchKernelGGL(k_copy_offsets, dim3(grid_for(n_exp_r, BLOCK)), dim3(BLOCK), 0, c->stream, c->exp_off.as<u64>(), n_exp_r, wbase,
+                       c->cand_off.as<u64>() + rbase);
+    HIPC(hipGetLastError());
+    c->host_state.cand_words = wbase + n_exp_w; c->host_state.cand_recs = rbase + n_exp_r;
+  }
   const u64 n_cand = c->host_state.cand_recs;
   // merge equal transcript sets
   c->ccap = pow2_at_least(2 * n_cand + 16);

@@ -19,8 +19,16 @@ def merge_ec_state(dense: torch.Tensor, words: torch.Tensor, offs: torch.Tensor,
     Returns (words_all, offs_all) -- the records of every rank concatenated in rank order, offsets rebased."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return words, offs
-    world = dist.get_world_size(group)
     dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
+    return gather_records(words, offs, group)
+
+
+def gather_records(words: torch.Tensor, offs: torch.Tensor, group=None):
+    """All-gather variable-length record buffers: (words, offsets) of every rank concatenated, offsets rebased."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return words, offs
+    world = dist.get_world_size(group)
+    dense = words
     sizes = torch.tensor([words.numel(), offs.numel()], dtype=torch.int64, device=dense.device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)

@@ -50,6 +50,59 @@ int64_t emu_pseudoalign(const kamd_index_view* v, const uint32_t* words, const u
 }
 }
 
+// same as emu_pseudoalign, plus the positional filters of processBuffer (fragment-length compatibility via findPosition,
+// strand specificity) evaluated by kamd_core.h's keep_transcript on each member of the intersection
+extern "C" int64_t emu_pseudoalign_opts(const kamd_index_view* v, const uint32_t* words, const uint16_t* lens, uint64_t n_items,
+                                        int paired, int32_t max_len, int single_overhang, int strand, int fl, int has_mean_fl,
+                                        uint64_t* out_off, uint32_t* out_ids, uint64_t cap) {
+  using namespace kamd;
+  const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
+  Table t{v->table, v->n_buckets};
+  PosTables pt{v->unitig_blk_off, v->unitig_len, v->blk_unitig, v->blk_lb, v->blk_ub, v->blk_ec, v->blk_pos_off, v->blk_posw,
+               v->blk_sense, v->ec_off, v->ec_ids, v->target_lens, v->k};
+  std::vector<uint8_t> nonempty(v->n_ecs);
+  for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
+  uint64_t o = 0;
+  uint32_t ecbuf[1024];
+  for (uint64_t i = 0; i < n_items; i++) {
+    out_off[i] = o;
+    EcList ecs{ecbuf, 1024, 0, false};
+    MateInfo m[2]; memset(m, 0, sizeof m);
+    for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
+      uint64_t r = paired ? 2 * i + mate : i;
+      ReadView rv{words + r * rec, words + r * rec + sw, lens[r]};
+      match_mate(t, v->uec_ec, nonempty.data(), rv, v->k, ecs, m[mate]);
+    }
+    if (ecs.overflow) return -1;
+    if (!pair_is_mapped(m[0], m[1])) continue;
+    FirstHit h[2];
+    for (int mate = 0; mate < 2; mate++) {
+      h[mate].valid = m[mate].n_hits > 0;
+      h[mate].block = h[mate].valid ? v->slot_block[m[mate].first_slot] : 0;
+      h[mate].dist = h[mate].valid ? v->slot_dist[m[mate].first_slot] : 0;
+      h[mate].strand = m[mate].first_strand; h[mate].pos = m[mate].first_pos;
+    }
+    FilterCfg cfg;
+    cfg.fraglen = !single_overhang && has_mean_fl && (!paired || m[0].n_hits == 0 || m[1].n_hits == 0);
+    cfg.fl = fl; cfg.strand = strand;
+    std::vector<uint32_t> cur(v->ec_ids + v->ec_off[ecs.e[0]], v->ec_ids + v->ec_off[ecs.e[0] + 1]);
+    for (int j = 1; j < ecs.n; j++) {
+      std::vector<uint32_t> nx;
+      std::set_intersection(cur.begin(), cur.end(), v->ec_ids + v->ec_off[ecs.e[j]], v->ec_ids + v->ec_off[ecs.e[j] + 1],
+                            std::back_inserter(nx));
+      cur.swap(nx);
+    }
+    for (uint32_t tr : cur) {
+      if (!(v->onlist_bits[tr >> 5] >> (tr & 31) & 1)) continue;
+      if ((cfg.fraglen || cfg.strand) && !keep_transcript(pt, cfg, h[0], h[1], tr)) continue;
+      if (o >= cap) return -2;
+      out_ids[o++] = tr;
+    }
+  }
+  out_off[n_items] = o;
+  return (int64_t)o;
+}
+
 // ---- CPU stand-ins for kernel A's outputs and for kamd_ec_finalize, used to test the multi-rank merge on gloo ----
 #include <map>
 extern "C" {

@@ -51,6 +51,8 @@ def _worker(rank, world, port, case, q):
 @pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("ref_test_pe", "pe"), ("yeast_se", "se_overhang")])
 def test_sharded_ec_counts_equal_reference(case, variant):
     exp = common.load_expected(case, variant)
+    from tests import emu_binding
+    emu_binding.lib()  # build the emulation library once, before the ranks race for it
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -34,16 +34,6 @@ def ctxs(ka):
         c.close()
 
 
-def _supported(o):
-    if o["strand"]:
-        return False
-    if not o["paired"] and not o["single_overhang"]:
-        return False
-    if o["paired"] and o["fld"] > 0 and not o["single_overhang"]:
-        return False
-    return True
-
-
 @pytest.mark.parametrize("case,variant", common.all_variants())
 def test_quant_matches_reference(case, variant, ka, ctxs):
     meta, idx_path, r1, r2 = common.load_case(case)
@@ -54,10 +44,6 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
     reads = common.interleave(r1, r2 if o["paired"] else None)
     words, lens, max_len = ctx.pack_reads_host(reads)
     opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"])
-    if not _supported(o):
-        with pytest.raises(ka.KallistoAmdError):
-            ctx.pseudoalign(opts, words, lens, len(r1), max_len)
-        pytest.skip("variant not on the device yet (documented in DESIGN.md)")
     res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
     assert res.n_processed == exp["nproc"]
     assert res.ecs.multiset() == exp["ecs"]
@@ -65,6 +51,15 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
     assert np.array_equal(res.eff_lens, exp["eff"])
     common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
     common.assert_abundance_close(res.alpha_before_zeroes, exp["abz"], "alpha_before_zeroes", floor=1e-9)
+
+
+def test_single_end_needs_fragment_length(ka, ctxs):
+    """CheckOptionsEM (src/main.cpp:1658-1688): --single requires -l and -s; the library refuses loudly."""
+    meta, idx_path, r1, r2 = common.load_case("yeast_se")
+    index, ctx = ctxs("yeast_se")
+    words, lens, max_len = ctx.pack_reads_host(r1[:10])
+    with pytest.raises(ka.KallistoAmdError):
+        ctx.pseudoalign(ka.QuantOpts(0, 0.0, 0.0, 0, 0), words, lens, 10, max_len)
 
 
 def test_device_packer_equals_host_packer(ka, ctxs):

@@ -65,6 +65,23 @@ def test_per_item_logic_matches_oracle(case, idx):
     assert breads >= probes > 0
 
 
+@pytest.mark.parametrize("case,variant", common.all_variants())
+def test_positional_filters_match_oracle(case, variant, idx):
+    """findPosition fragment-length filter (single-end / orphan mates) and --fr/--rf strand filter, per read."""
+    e, o = idx(case)
+    meta, _, r1, r2 = common.load_case(case)
+    ov = common.parse_variant(meta["variants"][variant])
+    paired = bool(ov["paired"])
+    words, l16, max_len = E.pack(common.interleave(r1, r2 if paired else None))
+    has_fl = ov["fld"] > 0
+    mean_fl = float(O.trunc_gaussian_fld(ov["fld"], ov["sd"])[-1]) if has_fl else 0.0
+    off, ids = E.pseudoalign_opts(e, words, l16, len(r1), paired, max_len, ov["single_overhang"], ov["strand"], int(mean_fl), has_fl)
+    opts = O.Opts(ov["paired"], ov["fld"], ov["sd"], ov["single_overhang"], ov["strand"])
+    for i in range(len(r1)):
+        s, _, _ = o.pseudoalign(opts, r1[i], r2[i] if paired else None, mean_fl, has_fl)
+        assert ids[off[i]:off[i + 1]].tolist() == s, (case, variant, i)
+
+
 def test_probe_counts_match_oracle(idx):
     e, o = idx("ref_test_pe")
     meta, _, r1, r2 = common.load_case("ref_test_pe")
