@@ -157,14 +157,24 @@ int kamd_ec_finalize(kamd_ctx*, kamd_ec_result* out);
 int kamd_ec_download(kamd_ctx*, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts);
 
 /* ---- S3: EM ---- */
-/* Runs EMAlgorithm::run(n_iter, min_rounds) on the finalized EC result (or on caller-provided device CSR when
- * d_ec_off != NULL).  eff_lens: host [n_targets].  Outputs (host): alpha, alpha_before_zeroes [n_targets], rounds. */
-int kamd_em_run(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts, uint64_t n_ecs,
-                const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds, double* alpha,
-                double* alpha_before_zeroes, int32_t* rounds);
+/* Runs EMAlgorithm(counts, ...).run(n_iter, min_rounds) (src/EMAlgorithm.h:26-48,95-223) on the finalized EC result
+ * (d_ec_off == NULL) or on a caller-provided device CSR.  d_weight_counts: the counts the weights w = count/eff_len are
+ * computed from (tc_.counts; NULL = d_counts -- they only differ in bootstraps).  eff_lens: host [n_targets].
+ * Outputs (host): alpha, alpha_before_zeroes (nullable) [n_targets], rounds ("ran for i rounds"). */
+int kamd_em_run(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
+                const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
+                uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds);
 
 /* ---- S4: bootstrap ---- */
-int kamd_bootstrap(kamd_ctx*, uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha, int32_t* rounds);
+/* One replicate of Bootstrap::run_em (src/Bootstrap.cpp:4-14): Multinomial(counts, seed).sample() with libstdc++'s
+ * minstd_rand0 + discrete_distribution semantics (identical sample for an identical EC order), then a fresh EM
+ * run(10000, 50).  seed = seeds[b] of src/main.cpp:2746-2752 (kamd_bootstrap_seeds).  CSR: finalized result when
+ * d_ec_off == NULL.  sample_out (nullable, host [n_ecs]) receives the resampled counts. */
+int kamd_bootstrap(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts, uint64_t n_ecs,
+                   uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha, int32_t* rounds,
+                   uint32_t* sample_out);
+/* seeds[b] = std::mt19937_64(seed)() for b = 0..n-1 (src/main.cpp:2746-2752) */
+void kamd_bootstrap_seeds(uint64_t seed, int32_t n, uint64_t* seeds);
 
 /* ---- host-side helpers of the quant driver (FLD model, effective lengths; FP64 on the host, bit-exact) ---- */
 void kamd_mean_frag_lens_trunc(const uint32_t* flens, double* mean_fl_trunc);

@@ -86,9 +86,11 @@ _SYMBOLS = {
     "kamd_ec_explicit_replace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     "kamd_ec_finalize": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
     "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+    "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
-    "kamd_bootstrap": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32)]),
+    "kamd_bootstrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                 C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "kamd_bootstrap_seeds": (None, [C.c_uint64, C.c_int32, C.c_void_p]),
     "kamd_mean_frag_lens_trunc": (None, [C.c_void_p, C.c_void_p]),
     "kamd_trunc_gaussian_fld": (None, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
     "kamd_eff_lens": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -359,13 +361,30 @@ class Context:
         abz = np.zeros(T, np.float64)
         rounds = C.c_int32(0)
         if csr is None:
-            args = (None, None, None, 0)
+            args = (None, None, None, None, 0)
         else:
             off, ids, cnt = csr
-            args = (off.data_ptr(), ids.data_ptr(), cnt.data_ptr(), cnt.numel())
+            args = (off.data_ptr(), ids.data_ptr(), cnt.data_ptr(), None, cnt.numel())
         _check(load_library().kamd_em_run(self._h, *args, eff.ctypes.data, T, n_iter, min_rounds, alpha.ctypes.data,
                                           abz.ctypes.data, C.byref(rounds)), "kamd_em_run")
         return alpha, abz, int(rounds.value)
+
+    def bootstrap(self, seed: int, eff_lens: np.ndarray, csr=None, want_sample: bool = False):
+        """One bootstrap replicate (Bootstrap::run_em): multinomial resample of the EC counts + EM.  Returns
+        (alpha, rounds[, resampled counts])."""
+        eff = np.ascontiguousarray(eff_lens, np.float64)
+        T = len(eff)
+        alpha = np.zeros(T, np.float64)
+        rounds = C.c_int32(0)
+        if csr is None:
+            args, n = (None, None, None, 0), int(self.ec_result.n_ecs)
+        else:
+            off, ids, cnt = csr
+            args, n = (off.data_ptr(), ids.data_ptr(), cnt.data_ptr(), cnt.numel()), cnt.numel()
+        samp = np.zeros(max(n, 1), np.uint32) if want_sample else None
+        _check(load_library().kamd_bootstrap(self._h, *args, int(seed), eff.ctypes.data, T, alpha.ctypes.data, C.byref(rounds),
+                                             samp.ctypes.data if want_sample else None), "kamd_bootstrap")
+        return (alpha, int(rounds.value), samp[:n]) if want_sample else (alpha, int(rounds.value))
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
@@ -412,6 +431,12 @@ def eff_lens(target_lens: np.ndarray, mean_fl_trunc: np.ndarray) -> np.ndarray:
     t = np.ascontiguousarray(mean_fl_trunc, np.float64)
     out = np.zeros(len(tl), np.float64)
     load_library().kamd_eff_lens(tl.ctypes.data, len(tl), t.ctypes.data, out.ctypes.data)
+    return out
+
+
+def bootstrap_seeds(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, np.uint64)
+    load_library().kamd_bootstrap_seeds(int(seed), n, out.ctypes.data)
     return out
 
 

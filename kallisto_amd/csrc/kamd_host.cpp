@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <random>
 #include <vector>
 
 namespace kamd {
@@ -82,6 +83,12 @@ extern "C" void kamd_eff_lens(const int32_t* target_lens, uint64_t n, const doub
     if (e < 1.0) e = cur;
     eff[i] = e;
   }
+}
+
+extern "C" void kamd_bootstrap_seeds(uint64_t seed, int32_t n, uint64_t* seeds) {  // src/main.cpp:2746-2752
+  std::mt19937_64 rand;
+  rand.seed(seed);
+  for (int32_t s = 0; s < n; ++s) seeds[s] = rand();
 }
 
 extern "C" void kamd_counts_to_tpm(const double* est, const double* eff, uint64_t n, double* tpm) {  // src/PlaintextWriter.cpp:5-27

@@ -827,7 +827,7 @@ struct kamd_ctx {
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
-  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch;
+  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial;
   DevState host_state{};
@@ -962,7 +962,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
                   &c->em_segoff, &c->em_segt, &c->em_partial})
@@ -1371,16 +1371,17 @@ extern "C" int kamd_ec_download(kamd_ctx* c, uint64_t* ec_off, uint32_t* ec_ids,
 
 // ---- EM ----------------------------------------------------------------------------------------------------------------
 extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
-                           uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds,
-                           double* alpha, double* alpha_before_zeroes, int32_t* rounds) {
+                           const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets,
+                           uint32_t n_iter, uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds) {
   if (!c || !eff_lens || !alpha) return kamd::fail(-1, "kamd_em_run: null argument");
   HIPC(hipSetDevice(c->device));
-  const u32* d_wcounts = d_counts;
   if (!d_ec_off) {
     if (!c->finalized) return kamd::fail(-1, "kamd_em_run: no EC result (call kamd_ec_finalize or pass a CSR)");
-    d_ec_off = c->result.d_ec_off; d_ec_ids = c->result.d_ec_ids; d_counts = c->result.d_counts; d_wcounts = d_counts;
-    n_ecs = c->result.n_ecs;
+    d_ec_off = c->result.d_ec_off; d_ec_ids = c->result.d_ec_ids; n_ecs = c->result.n_ecs;
+    if (!d_counts) d_counts = c->result.d_counts;
+    if (!d_weight_counts) d_weight_counts = c->result.d_counts;
   }
+  const u32* d_wcounts = d_weight_counts ? d_weight_counts : d_counts;
   const u64 T = n_targets;
   if (T == 0) return kamd::fail(-1, "kamd_em_run: no targets");
   u64 nnz = 0;
@@ -1468,6 +1469,76 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   return 0;
 }
 
-extern "C" int kamd_bootstrap(kamd_ctx*, uint64_t, const double*, uint64_t, double*, int32_t*) {
-  return kamd::fail(-4, "kamd_bootstrap: not implemented yet (SURVEY.md section 8a rows 16-17)");
+// ---- bootstrap (Bootstrap::run_em, src/Bootstrap.cpp:4-14; Multinomial::sample, src/Multinomial.hpp:33-51) -----------
+namespace {
+constexpr u64 LCG_M = 2147483647ULL, LCG_A = 16807ULL;  // std::minstd_rand0 (libstdc++ default_random_engine)
+__host__ __device__ inline u64 lcg_pow(u64 e) { u64 r = 1, b = LCG_A; while (e) { if (e & 1) r = r * b % LCG_M; b = b * b % LCG_M; e >>= 1; } return r; }
+constexpr int DRAWS_PER_THREAD = 64;
+// Draw i consumes engine outputs 2i+1 and 2i+2 (generate_canonical<double,53> makes two calls), so a thread can start
+// anywhere by LCG skip-ahead: the sample is identical to the reference's N sequential draws.
+__global__ void k_multinomial(const double* __restrict__ cp, u64 n, u64 n_draws, u64 x0, double r2, u32* samp) {
+  const u64 first = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * DRAWS_PER_THREAD;
+  if (first >= n_draws) return;
+  u64 x = x0 * lcg_pow(2 * first) % LCG_M;
+  const u64 last = min(n_draws, first + DRAWS_PER_THREAD);
+  for (u64 d = first; d < last; d++) {
+    x = x * LCG_A % LCG_M; const u64 g1 = x;
+    x = x * LCG_A % LCG_M; const u64 g2 = x;
+    // generate_canonical (bits/random.tcc): sum = (g1-min)*1 + (g2-min)*R, ret = sum / R^2 -- separate roundings, no FMA
+    double sum = __dmul_rn((double)(g1 - 1), 1.0);
+    sum = __dadd_rn(sum, __dmul_rn((double)(g2 - 1), 2147483646.0));
+    double p = __ddiv_rn(sum, r2);
+    if (p >= 1.0) p = 0.99999999999999989;  // nextafter(1.0, 0.0)
+    u64 lo = 0, hi = n;                      // std::lower_bound(cp.begin(), cp.end(), p)
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (cp[mid] < p) lo = mid + 1; else hi = mid; }
+    atomicAdd(&samp[lo], 1u);
+  }
+}
+}  // namespace
+
+extern "C" int kamd_bootstrap(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
+                              uint64_t n_ecs, uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha,
+                              int32_t* rounds, uint32_t* sample_out) {
+  if (!c || !eff_lens || !alpha) return kamd::fail(-1, "kamd_bootstrap: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (!d_ec_off) {
+    if (!c->finalized) return kamd::fail(-1, "kamd_bootstrap: no EC result (call kamd_ec_finalize or pass a CSR)");
+    d_ec_off = c->result.d_ec_off; d_ec_ids = c->result.d_ec_ids; d_counts = c->result.d_counts; n_ecs = c->result.n_ecs;
+  }
+  if (n_ecs == 0) return kamd::fail(-1, "kamd_bootstrap: no equivalence classes");
+  // discrete_distribution<int>(counts): p = counts / sum, cp = partial_sum(p) (sequential FP64 adds), cp.back() = 1
+  std::vector<u32> counts(n_ecs);
+  HIPC(hipMemcpyAsync(counts.data(), d_counts, n_ecs * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  double sum = 0.0; u64 N = 0;
+  for (u64 i = 0; i < n_ecs; i++) { sum += (double)counts[i]; N += counts[i]; }
+  const int nsamp = (int)N;  // Multinomial::n_ is an int
+  if (nsamp < 1) return kamd::fail(-1, "kamd_bootstrap: nothing to resample");
+  std::vector<double> cp(n_ecs);
+  double acc = 0.0;
+  for (u64 i = 0; i < n_ecs; i++) { acc += (double)counts[i] / sum; cp[i] = acc; }
+  cp[n_ecs - 1] = 1.0;
+  if (int rc = c->bs_cp.ensure(n_ecs * sizeof(double), 0, c->stream)) return rc;
+  if (int rc = c->bs_samp.ensure(n_ecs * sizeof(u32), 0, c->stream)) return rc;
+  HIPC(hipMemcpyAsync(c->bs_cp.p, cp.data(), n_ecs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemsetAsync(c->bs_samp.p, 0, n_ecs * sizeof(u32), c->stream));
+  if (n_ecs < 2) {  // _M_cp is empty: every draw returns 0
+    const u32 all = (u32)nsamp;
+    HIPC(hipMemcpyAsync(c->bs_samp.p, &all, sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  } else {
+    u64 x0 = seed % LCG_M; if (x0 == 0) x0 = 1;                 // linear_congruential_engine::seed
+    const double r2 = (double)(2147483646.0L * 2147483646.0L);  // __tmp after two `__tmp *= __r` (long double) steps
+    const u64 threads = ((u64)nsamp + DRAWS_PER_THREAD - 1) / DRAWS_PER_THREAD;
+    hipLaunchKernelGGL(k_multinomial, dim3(grid_for(threads, BLOCK)), dim3(BLOCK), 0, c->stream, c->bs_cp.as<double>(), (u64)n_ecs,
+                       (u64)nsamp, x0, r2, c->bs_samp.as<u32>());
+    HIPC(hipGetLastError());
+  }
+  HIPC(hipStreamSynchronize(c->stream));  // cp is a host staging buffer
+  if (sample_out) {
+    HIPC(hipMemcpyAsync(sample_out, c->bs_samp.p, n_ecs * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
+  // fresh EMAlgorithm on the resampled counts; the weights still come from the original counts (EMAlgorithm.h:46);
+  // run(10000, 50, false, false)
+  return kamd_em_run(c, d_ec_off, d_ec_ids, c->bs_samp.as<u32>(), d_counts, n_ecs, eff_lens, n_targets, 10000, 50, alpha, nullptr, rounds);
 }

@@ -108,3 +108,44 @@ def test_em_against_oracle_on_given_csr(ka, ctxs):
     alpha, abz, rounds = ctx.em_run(exp["eff"], csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32)))
     assert rounds == rounds_o
     common.assert_abundance_close(alpha, alpha_o, "alpha")
+
+
+@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe_boot"), ("human_pe", "pe_boot")])
+def test_bootstrap_matches_reference(case, variant, ka, ctxs):
+    """Bootstrap::run_em: the multinomial resample is bit-identical to libstdc++'s (same EC order as the reference at
+    -t 1, which the oracle reproduces), the replicate's EM within 1e-4 of the reference's BS output."""
+    import torch
+    from oracle import oracle as O
+    import kallisto_amd.api as A
+    meta, idx_path, r1, r2 = common.load_case(case)
+    o = common.parse_variant(meta["variants"][variant])
+    exp = common.load_expected(case, variant)
+    index, ctx = ctxs(case)
+    oix = O.Index(idx_path)
+    buf, off, lens = O.pack_reads(common.interleave(r1, r2))
+    ores = O.process_reads(oix, O.Opts(1, 0.0, 0.0, 0, 0), buf, off, lens)   # ECs in the reference's discovery order
+    seeds = A.bootstrap_seeds(o["seed"], o["boot"])
+    assert np.array_equal(seeds, O.bootstrap_seeds(o["seed"], o["boot"]))
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda()
+    csr = (d(ores.ec_off, np.int64), d(ores.ec_ids, np.int32), d(ores.counts, np.int32))
+    for b in range(o["boot"]):
+        alpha, rounds, samp = ctx.bootstrap(int(seeds[b]), exp["eff"], csr=csr, want_sample=True)
+        assert np.array_equal(samp, O.multinomial_sample(ores.counts, int(seeds[b])))
+        common.assert_abundance_close(alpha, np.array(exp["bs"][b]), f"bootstrap {b}")
+
+
+def test_bootstrap_on_finalized_result(ka, ctxs):
+    """kamd_bootstrap on the context's own EC result: the sample is a multinomial over the EC counts (sums to N, never
+    hits an EC the data did not) and equals the oracle's sampler applied to the same count vector."""
+    from oracle import oracle as O
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    exp = common.load_expected("human_pe", "pe")
+    index, ctx = ctxs("human_pe")
+    words, lens, max_len = ctx.pack_reads_host(common.interleave(r1, r2), 100)
+    ctx.pseudoalign(ka.QuantOpts(1, 0.0, 0.0, 0, 0), words, lens, len(r1), max_len)
+    ecs = ctx.finalize()
+    alpha, rounds, samp = ctx.bootstrap(12345, exp["eff"], want_sample=True)
+    assert samp.sum() == ecs.counts.sum() and np.array_equal(samp, O.multinomial_sample(ecs.counts, 12345))
+    a_o, _, r_o = O.em_run(ecs.ec_off, ecs.ec_ids, samp, exp["eff"], index.num_targets, weight_counts=ecs.counts)
+    assert rounds == r_o
+    common.assert_abundance_close(alpha, a_o, "bootstrap alpha")
