@@ -103,8 +103,9 @@ int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off,
  * (0 = none) and d_card the cardinality class of the item's equivalence class is resolved later by kamd_fld_from_prefix. */
 int kamd_pseudoalign(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
                      int32_t max_len);
-/* fragment-length histogram from the first 10000 qualifying pairs in input order of the given batch
- * (src/ProcessReads.cpp:981-1017,1174-1181 at -t 1).  flens: KAMD_MAX_FRAG_LEN u32 (host). */
+/* fragment-length histogram from the first 10000 qualifying pairs in input order (src/ProcessReads.cpp:981-1017,
+ * 1174-1181 at -t 1).  flens: KAMD_MAX_FRAG_LEN u32 (host) and *n_used accumulate across calls: zero both, then call once
+ * per batch in input order until *n_used reaches 10000 (or the input ends). */
 int kamd_fld_from_batch(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
                         int32_t max_len, uint32_t* flens, uint64_t* n_used);
 

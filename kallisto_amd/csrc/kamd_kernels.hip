@@ -1161,10 +1161,9 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   const FilterDev fd{o->single_overhang, 0, 0, o->strand};
   if (!c->has_index) return kamd::fail(-1, "kamd_fld_from_batch: no index uploaded");
   HIPC(hipSetDevice(c->device));
-  memset(flens, 0, KAMD_MAX_FRAG_LEN * sizeof(uint32_t));
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
-  u64 found = 0, done = 0;
+  u64 found = n_used ? *n_used : 0, done = 0;  // continues a sample started on earlier batches
   const int cap_small = 64;
   u64 chunk = 131072;
   DBuf tl, card, scratch, items;

@@ -1,0 +1,306 @@
+// quant_main.cpp -- `kallisto_amd quant`: the command-line surface of `kallisto quant` (src/main.cpp:211-392 option
+// parsing, :1600-1805 checks, :2620-2798 driver) on top of the C ABI of include/kallisto_amd.h.  Same flags, same
+// index file, same abundance.tsv / run_info.json (PlaintextWriter.cpp:29-65,140-197), bs_abundance_N.tsv bootstraps.
+// Host code only: FASTQ reading (FastqSequenceReader::fetchSequences, src/ProcessReads.cpp:3128-3267), batching,
+// writers.  Everything that computes runs on the GPU through libkallisto_amd.so.
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/kallisto_amd.h"
+
+namespace {
+
+const char* KALLISTO_COMPAT_VERSION = "0.51.1";  // src/common.h:4
+
+struct Options {
+  std::string index, output;
+  std::vector<std::string> files;
+  bool single = false, single_overhang = false, plaintext = false, verbose = false;
+  int strand = 0, bootstrap = 0, threads = 1;
+  double fld = 0.0, sd = 0.0;
+  uint64_t seed = 42;
+  uint64_t batch = 4u << 20;  // reads (or pairs) per device batch
+};
+
+void usage() {
+  std::cout << "kallisto_amd " << KALLISTO_COMPAT_VERSION << "-compatible (MI355X)\n"
+            << "Computes equivalence classes for reads and quantifies abundances\n\n"
+            << "Usage: kallisto_amd quant [arguments] FASTQ-files\n\n"
+            << "Required arguments:\n"
+            << "-i, --index=STRING            Filename for the kallisto index to be used for\n"
+            << "                              quantification\n"
+            << "-o, --output-dir=STRING       Directory to write output to\n\n"
+            << "Optional arguments:\n"
+            << "-b, --bootstrap-samples=INT   Number of bootstrap samples (default: 0)\n"
+            << "    --seed=INT                Seed for the bootstrap sampling (default: 42)\n"
+            << "    --plaintext               Output plaintext (always on: abundance.h5 is not written)\n"
+            << "    --single                  Quantify single-end reads\n"
+            << "    --single-overhang         Include reads where unobserved rest of fragment is\n"
+            << "                              predicted to lie outside a transcript\n"
+            << "    --fr-stranded             Strand specific reads, first read forward\n"
+            << "    --rf-stranded             Strand specific reads, first read reverse\n"
+            << "-l, --fragment-length=DOUBLE  Estimated average fragment length\n"
+            << "-s, --sd=DOUBLE               Estimated standard deviation of fragment length\n"
+            << "-t, --threads=INT             Host threads for index loading (default: 1)\n"
+            << "    --verbose                 Print out progress information\n";
+}
+
+bool take(const std::string& a, const char* shortf, const char* longf, int& i, int argc, char** argv, std::string& val) {
+  std::string lf = std::string(longf) + "=";
+  if (a.rfind(lf, 0) == 0) { val = a.substr(lf.size()); return true; }
+  if (a == longf || (shortf && a == shortf)) { if (i + 1 >= argc) { std::cerr << "Error: missing value for " << a << std::endl; exit(1); } val = argv[++i]; return true; }
+  return false;
+}
+
+// ---- FASTA/FASTQ reader over gzFile (plain or gzip), one record at a time ----
+class SeqReader {
+ public:
+  explicit SeqReader(const std::string& path) : buf_(1 << 22) {
+    f_ = gzopen(path.c_str(), "r");
+    if (!f_) { std::cerr << "Error: could not open file " << path << std::endl; exit(1); }
+    gzbuffer(f_, 1 << 20);
+  }
+  ~SeqReader() { if (f_) gzclose(f_); }
+  // next sequence appended to `out`; returns false at end of file
+  bool next(std::string& out) {
+    std::string line;
+    if (!pending_header_) { do { if (!getline(line)) return false; } while (line.empty()); }
+    else { line = header_; pending_header_ = false; }
+    if (line[0] == '@') {  // FASTQ: sequence (possibly multi-line) up to '+', then as many quality chars
+      out.clear();
+      for (;;) { if (!getline(line)) return !out.empty(); if (!line.empty() && line[0] == '+') break; out += line; }
+      size_t q = 0;
+      while (q < out.size()) { if (!getline(line)) break; q += line.size(); }
+      return true;
+    }
+    if (line[0] == '>') {
+      out.clear();
+      while (getline(line)) { if (!line.empty() && (line[0] == '>' || line[0] == '@')) { header_ = line; pending_header_ = true; break; } out += line; }
+      return true;
+    }
+    std::cerr << "Error: malformed sequence file" << std::endl; exit(1);
+  }
+
+ private:
+  bool getline(std::string& s) {
+    s.clear();
+    for (;;) {
+      if (pos_ == len_) { int n = gzread(f_, buf_.data(), (unsigned)buf_.size()); if (n <= 0) return !s.empty(); len_ = (size_t)n; pos_ = 0; }
+      char* b = buf_.data() + pos_;
+      char* e = (char*)memchr(b, '\n', len_ - pos_);
+      if (e) { s.append(b, e - b); pos_ = (size_t)(e - buf_.data()) + 1; if (!s.empty() && s.back() == '\r') s.pop_back(); return true; }
+      s.append(b, len_ - pos_); pos_ = len_;
+    }
+  }
+  gzFile f_ = nullptr;
+  std::vector<char> buf_;
+  size_t pos_ = 0, len_ = 0;
+  std::string header_;
+  bool pending_header_ = false;
+};
+
+#define HIPX(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::cerr << "Error: " #x ": " << hipGetErrorString(e_) << std::endl; exit(1); } } while (0)
+#define KX(x) do { if ((x) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; exit(1); } } while (0)
+
+std::string to_json(const std::string& id, const std::string& val, bool quote, bool comma = true) {  // PlaintextWriter.cpp:113-137
+  std::string out = "\t\"" + id + "\": ";
+  if (quote) out += '"';
+  out += val;
+  if (quote) out += '"';
+  if (comma) out += ',';
+  return out;
+}
+
+void write_abundance(const std::string& path, const kamd_index* idx, const kamd_index_view& v, const std::vector<double>& alpha,
+                     const std::vector<double>& eff) {  // plaintext_writer, PlaintextWriter.cpp:29-65
+  std::ofstream of(path);
+  if (!of.is_open()) { std::cerr << "Error: Couldn't open file: " << path << std::endl; exit(1); }
+  std::vector<double> tpm(alpha.size());
+  kamd_counts_to_tpm(alpha.data(), eff.data(), alpha.size(), tpm.data());
+  of << "target_id" << "\t" << "length" << "\t" << "eff_length" << "\t" << "est_counts" << "\t" << "tpm" << std::endl;
+  for (size_t i = 0; i < alpha.size(); ++i)
+    of << kamd_index_target_name(idx, i) << '\t' << (uint32_t)v.target_lens[i] << '\t' << eff[i] << '\t' << alpha[i] << '\t' << tpm[i] << std::endl;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2 || std::string(argv[1]) != "quant") { usage(); return argc < 2 ? 1 : (std::string(argv[1]) == "version" ? (std::cout << "kallisto_amd, compatible with kallisto " << KALLISTO_COMPAT_VERSION << std::endl, 0) : 1); }
+  Options opt;
+  std::string val;
+  for (int i = 2; i < argc; i++) {
+    std::string a = argv[i];
+    if (take(a, "-i", "--index", i, argc, argv, val)) opt.index = val;
+    else if (take(a, "-o", "--output-dir", i, argc, argv, val)) opt.output = val;
+    else if (take(a, "-b", "--bootstrap-samples", i, argc, argv, val)) opt.bootstrap = atoi(val.c_str());
+    else if (take(a, nullptr, "--seed", i, argc, argv, val)) opt.seed = strtoull(val.c_str(), nullptr, 10);
+    else if (take(a, "-l", "--fragment-length", i, argc, argv, val)) opt.fld = atof(val.c_str());
+    else if (take(a, "-s", "--sd", i, argc, argv, val)) opt.sd = atof(val.c_str());
+    else if (take(a, "-t", "--threads", i, argc, argv, val)) opt.threads = atoi(val.c_str());
+    else if (take(a, nullptr, "--batch", i, argc, argv, val)) opt.batch = strtoull(val.c_str(), nullptr, 10);
+    else if (a == "--single") opt.single = true;
+    else if (a == "--single-overhang") opt.single_overhang = true;
+    else if (a == "--fr-stranded") opt.strand = 1;
+    else if (a == "--rf-stranded") opt.strand = 2;
+    else if (a == "--plaintext") opt.plaintext = true;
+    else if (a == "--verbose") opt.verbose = true;
+    else if (a == "--bias" || a == "--fusion" || a == "--pseudobam" || a == "--genomebam" || a == "--long" || a == "-p" || a == "--priors" ||
+             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes") {
+      std::cerr << "Error: option " << a << " is outside the GPU quant path; use the reference kallisto for it" << std::endl; return 1;
+    } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage(); return 1; }
+    else opt.files.push_back(a);
+  }
+  // CheckOptionsEM (src/main.cpp:1600-1805)
+  bool ok = true;
+  if (opt.index.empty()) { std::cerr << "Error: kallisto index file missing" << std::endl; ok = false; }
+  if (opt.output.empty()) { std::cerr << "Error: need to specify output directory " << opt.output << std::endl; ok = false; }
+  if (opt.files.empty()) { std::cerr << "Error: Missing read files" << std::endl; ok = false; }
+  if (!opt.single && opt.files.size() % 2 != 0) { std::cerr << "Error: paired-end mode requires an even number of input files\n       (use --single for processing single-end reads)" << std::endl; ok = false; }
+  if ((opt.fld != 0.0 && opt.sd == 0.0) || (opt.sd != 0.0 && opt.fld == 0.0)) { std::cerr << "Error: cannot supply mean/sd without supplying both -l and -s" << std::endl; ok = false; }
+  if (opt.single && (opt.fld == 0.0 || opt.sd == 0.0)) { std::cerr << "Error: fragment length mean and sd must be supplied for single-end reads using -l and -s" << std::endl; ok = false; }
+  if (opt.fld < 0.0 || opt.sd < 0.0) { std::cerr << "Error: invalid value for mean fragment length or sd" << std::endl; ok = false; }
+  if (opt.bootstrap < 0) { std::cerr << "Error: number of bootstrap samples must be a non-negative integer" << std::endl; ok = false; }
+  if (!ok) { usage(); return 1; }
+  struct stat st;
+  if (stat(opt.output.c_str(), &st) != 0) { if (mkdir(opt.output.c_str(), 0777) != 0) { std::cerr << "Error: could not create directory " << opt.output << std::endl; return 1; } }
+  std::time_t tt = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
+  std::string start_time = std::ctime(&tt);
+  if (!start_time.empty() && start_time.back() == '\n') start_time.pop_back();
+  std::string call;
+  for (int i = 0; i < argc; i++) { if (i) call += ' '; call += argv[i]; }
+
+  // index (KmerIndex::load) + device context
+  kamd_index* idx = nullptr;
+  KX(kamd_index_load(opt.index.c_str(), opt.threads, &idx));
+  kamd_index_view v; KX(kamd_index_get_view(idx, &v));
+  std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
+  kamd_ctx* ctx = nullptr;
+  KX(kamd_ctx_create(0, nullptr, &ctx));
+  KX(kamd_index_upload(ctx, idx));
+
+  const bool paired = !opt.single;
+  kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand};
+  std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
+  uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
+  uint64_t fld_used = 0, n_processed = 0;
+  std::string seqs; std::vector<uint64_t> off; std::vector<int32_t> len;
+  std::vector<uint32_t> words; std::vector<uint16_t> l16;
+  uint32_t* d_words = nullptr; uint16_t* d_len = nullptr; size_t cap_words = 0, cap_len = 0;
+  auto flush = [&]() {
+    const uint64_t n_reads = off.size();
+    if (!n_reads) return;
+    int32_t max_len = 1;
+    for (auto l : len) max_len = std::max(max_len, l);
+    const uint64_t rec = kamd_packed_record_words(max_len);
+    words.resize(n_reads * rec); l16.resize(n_reads);
+    KX(kamd_pack_reads_host(seqs.data(), off.data(), len.data(), n_reads, max_len, words.data(), l16.data()));
+    if (words.size() > cap_words) { if (d_words) HIPX(hipFree(d_words)); cap_words = words.size() * 5 / 4; HIPX(hipMalloc((void**)&d_words, cap_words * 4)); }
+    if (l16.size() > cap_len) { if (d_len) HIPX(hipFree(d_len)); cap_len = l16.size() * 5 / 4; HIPX(hipMalloc((void**)&d_len, cap_len * 2)); }
+    HIPX(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+    HIPX(hipMemcpy(d_len, l16.data(), l16.size() * 2, hipMemcpyHostToDevice));
+    const uint64_t n_items = paired ? n_reads / 2 : n_reads;
+    KX(kamd_pseudoalign(ctx, &qo, d_words, d_len, n_items, max_len));
+    if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, d_words, d_len, n_items, max_len, flens, &fld_used));
+    n_processed += n_items;
+    if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
+    seqs.clear(); off.clear(); len.clear();
+  };
+  for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
+    std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
+    if (paired) std::cerr << "                             " << opt.files[fi + 1] << std::endl;
+    SeqReader r1(opt.files[fi]);
+    SeqReader* r2 = paired ? new SeqReader(opt.files[fi + 1]) : nullptr;
+    std::string s1, s2;
+    while (r1.next(s1)) {
+      if (paired && !r2->next(s2)) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
+      if (s1.size() > 65535 || s2.size() > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; return 1; }
+      off.push_back(seqs.size()); len.push_back((int32_t)s1.size()); seqs += s1;
+      if (paired) { off.push_back(seqs.size()); len.push_back((int32_t)s2.size()); seqs += s2; }
+      if (off.size() >= opt.batch * (paired ? 2 : 1)) flush();
+    }
+    delete r2;
+  }
+  flush();
+  std::cerr << "[quant] finding pseudoalignments for the reads ... done" << std::endl;
+
+  kamd_ec_result ec;
+  KX(kamd_ec_finalize(ctx, &ec));
+  std::vector<uint64_t> ec_off(ec.n_ecs + 1); std::vector<uint32_t> ec_ids(std::max<uint64_t>(ec.nnz, 1)), counts(std::max<uint64_t>(ec.n_ecs, 1));
+  KX(kamd_ec_download(ctx, ec_off.data(), ec_ids.data(), counts.data()));
+  uint64_t num_pseudoaligned = 0, num_unique = 0;  // src/main.cpp:2704-2709
+  for (uint64_t e = 0; e < ec.n_ecs; e++) { num_pseudoaligned += counts[e]; if (ec_off[e + 1] - ec_off[e] == 1) num_unique += counts[e]; }
+  std::cerr << "[quant] processed " << n_processed << " reads, " << num_pseudoaligned << " reads pseudoaligned" << std::endl;
+  if (num_pseudoaligned == 0) std::cerr << "[~warn] Warning, zero reads pseudoaligned check your input files and index" << std::endl;
+
+  std::vector<double> mft(KAMD_MAX_FRAG_LEN);
+  if (opt.fld == 0.0) {
+    if (fld_used == 0 && num_pseudoaligned > 0) {  // MinCollector::get_mean_frag_len (MinCollector.cpp:594-601)
+      std::cerr << "Error: could not determine mean fragment length from paired end reads, no pairs mapped to a unique transcript.\n"
+                << "       Run kallisto quant again with a pre-specified fragment length (option -l)." << std::endl;
+      return 1;
+    }
+    kamd_mean_frag_lens_trunc(flens, mft.data());
+    std::cerr << "[quant] estimated average fragment length: " << mft[KAMD_MAX_FRAG_LEN - 1] << std::endl;
+  } else kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, opt.fld, opt.sd, mft.data());
+  std::vector<double> eff(v.n_targets), alpha(v.n_targets), abz(v.n_targets);
+  kamd_eff_lens(v.target_lens, v.n_targets, mft.data(), eff.data());
+  int32_t rounds = 0;
+  if (num_pseudoaligned > 0) {
+    KX(kamd_em_run(ctx, nullptr, nullptr, nullptr, nullptr, 0, eff.data(), v.n_targets, 10000, 50, alpha.data(), abz.data(), &rounds));
+    std::cerr << "[   em] quantifying the abundances ... done\n[   em] the Expectation-Maximization algorithm ran for " << rounds << " rounds" << std::endl;
+  }
+  // run_info.json (plaintext_aux, PlaintextWriter.cpp:140-197; src/main.cpp:2715-2727)
+  {
+    uint64_t n_on = 0;
+    for (uint64_t t = 0; t < v.n_targets; t++) n_on += (v.onlist_bits[t >> 5] >> (t & 31)) & 1u;
+    double p_uniq = 0.0, p_aln = 0.0;
+    if (n_processed > 0) { p_uniq = 100.0 * (double)num_unique / (double)n_processed; p_aln = 100.0 * (double)num_pseudoaligned / (double)n_processed; }
+    std::stringstream s1, s2; s1 << std::fixed << std::setprecision(1) << p_uniq; s2 << std::fixed << std::setprecision(1) << p_aln;
+    std::ofstream of(opt.output + "/run_info.json");
+    of << "{" << std::endl
+       << to_json("n_targets", std::to_string(n_on), false) << std::endl
+       << to_json("n_bootstraps", std::to_string(opt.bootstrap), false) << std::endl
+       << to_json("n_processed", std::to_string(n_processed), false) << std::endl
+       << to_json("n_pseudoaligned", std::to_string(num_pseudoaligned), false) << std::endl
+       << to_json("n_unique", std::to_string(num_unique), false) << std::endl
+       << to_json("p_pseudoaligned", s2.str(), false) << std::endl
+       << to_json("p_unique", s1.str(), false) << std::endl
+       << to_json("kallisto_version", KALLISTO_COMPAT_VERSION, true) << std::endl
+       << to_json("index_version", "13", false) << std::endl
+       << to_json("k-mer length", std::to_string(v.k), false) << std::endl
+       << to_json("start_time", start_time, true) << std::endl
+       << to_json("call", call, true, false) << std::endl
+       << "}" << std::endl;
+  }
+  write_abundance(opt.output + "/abundance.tsv", idx, v, alpha, eff);
+  if (opt.bootstrap > 0 && num_pseudoaligned > 0) {  // src/main.cpp:2744-2782 (plaintext branch)
+    std::vector<uint64_t> seeds(opt.bootstrap);
+    kamd_bootstrap_seeds(opt.seed, opt.bootstrap, seeds.data());
+    std::vector<double> a(v.n_targets);
+    for (int b = 0; b < opt.bootstrap; b++) {
+      std::cerr << "[bstrp] running EM for the bootstrap: " << b + 1 << "\r";
+      int32_t r = 0;
+      KX(kamd_bootstrap(ctx, nullptr, nullptr, nullptr, 0, seeds[b], eff.data(), v.n_targets, a.data(), &r, nullptr));
+      write_abundance(opt.output + "/bs_abundance_" + std::to_string(b) + ".tsv", idx, v, a, eff);
+    }
+    std::cerr << std::endl;
+  }
+  if (d_words) HIPX(hipFree(d_words));
+  if (d_len) HIPX(hipFree(d_len));
+  kamd_ctx_destroy(ctx);
+  kamd_index_free(idx);
+  return num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797
+}

@@ -68,6 +68,21 @@ def make_case(name, fasta_path, reads1, reads2, variants, k=31, note=""):
                                  stderr=subprocess.DEVNULL).stdout
             with open(os.path.join(d, f"expected_{vname}.txt"), "wb") as f:
                 f.write(out)
+            # the reference CLI itself (`kallisto quant -t 1 --plaintext`): abundance.tsv, bs_abundance_*.tsv, run_info.json
+            cli = [a.replace("--fr", "--fr-stranded").replace("--rf", "--rf-stranded") for a in extra]
+            cli = ["-b" if a == "--boot" else a for a in cli]
+            od = os.path.join(tmp, "q_" + vname)
+            subprocess.run([KALLISTO, "quant", "-i", idx, "-o", od, "-t", "1", "--plaintext", *cli, *files], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            cd = os.path.join(d, "cli_" + vname)
+            os.makedirs(cd, exist_ok=True)
+            for fn in sorted(os.listdir(od)):
+                if fn.endswith(".tsv"):
+                    shutil.copy(os.path.join(od, fn), os.path.join(cd, fn))
+            info = json.load(open(os.path.join(od, "run_info.json")))
+            for key in ("start_time", "call"):
+                info.pop(key, None)
+            json.dump(info, open(os.path.join(cd, "run_info.json"), "w"), indent=1)
     with open(os.path.join(d, "case.json"), "w") as f:
         json.dump({"name": name, "k": k, "paired": reads2 is not None, "n": len(reads1), "variants": variants,
                    "note": note, "reference": "pachterlab/kallisto v0.51.1 via oracle/_ref/dump_ec (unmodified sources)"},

@@ -1,0 +1,80 @@
+"""The `kallisto quant`-compatible front-end (kallisto_amd/kallisto_amd_quant) against the reference CLI's own output
+(`kallisto quant -t 1 --plaintext`, stored under tests/golden/<case>/cli_<variant>/ by make_golden.py)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
+
+
+def _fastq(path, reads):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+
+
+def _table(path):
+    rows = [l.rstrip("\n").split("\t") for l in open(path)]
+    return rows[0], rows[1:]
+
+
+@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_boot"), ("ref_test_pe", "pe_rf"),
+                                          ("yeast_se", "se"), ("yeast_se", "se_fr"), ("human_pe", "pe"),
+                                          ("human_pe", "pe_l180"), ("tiny_k7_se", "se")])
+def test_cli_matches_reference_cli(case, variant, tmp_path):
+    assert os.path.exists(EXE), "build kallisto_amd_quant with `make -C kallisto_amd/csrc all`"
+    meta, idx_path, r1, r2 = common.load_case(case)
+    extra = meta["variants"][variant]
+    cli = [a.replace("--fr", "--fr-stranded").replace("--rf", "--rf-stranded") for a in extra]
+    cli = ["-b" if a == "--boot" else a for a in cli]
+    f1 = str(tmp_path / "r_1.fq")
+    _fastq(f1, r1)
+    files = [f1]
+    if r2 is not None and "--single" not in extra:
+        f2 = str(tmp_path / "r_2.fq")
+        _fastq(f2, r2)
+        files.append(f2)
+    out = str(tmp_path / "out")
+    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--batch", "1500", *cli, *files],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    gold = os.path.join(common.case_dir(case), "cli_" + variant)
+    # run_info.json: same keys in the same order, same values (start_time / call excluded)
+    info = json.load(open(os.path.join(out, "run_info.json")))
+    keys = list(info)
+    assert keys == ["n_targets", "n_bootstraps", "n_processed", "n_pseudoaligned", "n_unique", "p_pseudoaligned", "p_unique",
+                    "kallisto_version", "index_version", "k-mer length", "start_time", "call"]
+    ginfo = json.load(open(os.path.join(gold, "run_info.json")))
+    for k, v in ginfo.items():
+        assert info[k] == v, k
+    for fn in sorted(os.listdir(gold)):
+        if not fn.endswith(".tsv"):
+            continue
+        if fn.startswith("bs_abundance"):
+            # a bootstrap replicate is a multinomial resample over the EC count vector IN EC-ID ORDER; the reference's ids
+            # are discovery-order (thread-schedule dependent), ours are not, so replicates are not comparable file by
+            # file (the sampler itself is pinned with identical EC order in test_gpu_parity.test_bootstrap_matches_reference)
+            h, rows = _table(os.path.join(out, fn))
+            assert abs(sum(float(r[3]) for r in rows) - info["n_pseudoaligned"]) < 1e-3 * info["n_pseudoaligned"]
+            continue
+        h, rows = _table(os.path.join(out, fn))
+        gh, grows = _table(os.path.join(gold, fn))
+        assert h == gh and len(rows) == len(grows)
+        for a, b in zip(rows, grows):
+            assert a[:3] == b[:3], (fn, a, b)            # target_id, length, eff_length: identical text
+        est = np.array([float(r[3]) for r in rows]); gest = np.array([float(r[3]) for r in grows])
+        tpm = np.array([float(r[4]) for r in rows]); gtpm = np.array([float(r[4]) for r in grows])
+        common.assert_abundance_close(est, gest, fn + " est_counts", rel=1e-4, floor=1e-5)
+        common.assert_abundance_close(tpm, gtpm, fn + " tpm", rel=1e-4, floor=1e-5)
+    if case == "ref_test_pe" and variant == "pe":
+        # BASELINE config #1: the md5 the survey pinned for the reference's abundance.tsv
+        md5 = hashlib.md5(open(os.path.join(out, "abundance.tsv"), "rb").read()).hexdigest()
+        assert md5 == "0bd5087aba9db4b681073bb84de3fe5f"
