@@ -202,11 +202,11 @@ def main():
         res = step()
     fence()
     t0 = time.perf_counter()
-    align_ms, em_ms, em_iters = [], [], []
+    align_ms, em_ms, em_iters, cls_ms = [], [], [], []
     for _ in range(args.steps):
         res = step()
         pr = ctx.profile()
-        align_ms.append(pr["align_kernel_ms"]); em_ms.append(pr["em_ms"]); em_iters.append(pr["em_iters"])
+        align_ms.append(pr["align_kernel_ms"]); em_ms.append(pr["em_ms"]); em_iters.append(pr["em_iters"]); cls_ms.append(pr["classify_ms"])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -242,14 +242,15 @@ def main():
                 "pairs_per_gpu": n, "read_len": L, "paired": True, "targets": int(index.num_targets),
                 "kmers": int(index.num_kmers), "parallelism": f"reads sharded over {world} GPU(s), EC counts all-reduced",
             },
-            "breakdown_ms": {"pseudoalign_kernel": round(a_ms, 3), "em": round(float(np.mean(em_ms)), 3),
+            "breakdown_ms": {"pseudoalign_kernel": round(a_ms, 3), "classify_kernel": round(float(np.mean(cls_ms)), 3),
+                             "kernel_a_version": pr["kernel_a_version"], "em": round(float(np.mean(em_ms)), 3),
                              "em_rounds": int(em_iters[-1]), "step_total": round(elapsed / args.steps * 1e3, 3)},
             "counters": {"probes_per_pair": round(st["n_probes"] / n, 3),
                          "bucket_reads_per_probe": round(st["n_bucket_reads"] / max(st["n_probes"], 1), 4),
                          "single_set_pairs": st["n_single"], "multi_set_pairs": st["n_multi"],
                          "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
                          "em_rounds": res.em_rounds},
-            "roofline": {"kernel": "k_pseudoalign", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_match_v2" if pr["kernel_a_version"] == 2 else "k_pseudoalign", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
                          "bucket_line_bytes_per_launch": int(64 * st["n_bucket_reads"])},

@@ -123,9 +123,11 @@ int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
 
 /* durations measured with HIP events on the context stream (bench.py's roofline figures) */
 typedef struct {
-  float last_align_kernel_ms;  /* the k_pseudoalign launch of the last kamd_pseudoalign call */
+  float last_align_kernel_ms;  /* kernel A (k_match_v2, or k_pseudoalign) of the last kamd_pseudoalign call */
   float last_em_ms;            /* all EM launches of the last kamd_em_run call */
   uint64_t last_em_iters;      /* EM rounds executed by it */
+  float last_classify_ms;      /* k_classify of the same call (0 for the block-staged kernel, which classifies inline) */
+  int32_t kernel_a_version;    /* 2 = k_match_v2 + k_classify (default), 1 = k_pseudoalign (env KAMD_KERNEL_A=1) */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

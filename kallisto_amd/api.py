@@ -47,7 +47,8 @@ class _Stats(C.Structure):
 
 
 class _Profile(C.Structure):
-    _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64)]
+    _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64),
+                ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32)]
 
 
 class _EcResult(C.Structure):
@@ -286,7 +287,8 @@ class Context:
     def profile(self) -> dict:
         p = _Profile()
         _check(load_library().kamd_profile_get(self._h, C.byref(p)), "kamd_profile_get")
-        return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters)}
+        return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters),
+                "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

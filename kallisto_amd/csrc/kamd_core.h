@@ -87,21 +87,22 @@ struct ReadView {
   const uint32_t* seq;   // 2-bit words (LDS on the device)
   const uint32_t* mask;  // non-ACGT mask words
   int len;               // bases
+  int stride = 1;        // distance between consecutive words (64 for the lane-transposed LDS layout of kernel A v2)
 };
 
 // bits [2w, 2w+2k) of the read, LSB-first: x = sum base[w+i] << 2i
 KAMD_HD uint64_t window_lsb(const ReadView& r, int w, int k) {
   int bit = 2 * w;
   int wi = bit >> 5, sh = bit & 31;
-  uint64_t lo = (uint64_t)r.seq[wi] | ((uint64_t)r.seq[wi + 1] << 32);
+  uint64_t lo = (uint64_t)r.seq[wi * r.stride] | ((uint64_t)r.seq[(wi + 1) * r.stride] << 32);
   uint64_t x = lo >> sh;
-  if (sh + 2 * k > 64) x |= (uint64_t)r.seq[wi + 2] << (64 - sh);  // third word only when the window reaches it
+  if (sh + 2 * k > 64) x |= (uint64_t)r.seq[(wi + 2) * r.stride] << (64 - sh);  // third word only when the window reaches it
   return x & ((k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1));
 }
 // mask bits of bases [w, w+k) (k <= 32)
 KAMD_HD uint32_t window_mask(const ReadView& r, int w, int k) {
   int wi = w >> 5, sh = w & 31;
-  uint64_t lo = (uint64_t)r.mask[wi] | ((uint64_t)r.mask[wi + 1] << 32);  // records carry one pad word per plane
+  uint64_t lo = (uint64_t)r.mask[wi * r.stride] | ((uint64_t)r.mask[(wi + 1) * r.stride] << 32);  // one pad word per plane
   return (uint32_t)(lo >> sh) & (uint32_t)((1ULL << k) - 1);
 }
 // first window start >= t whose k bases are all ACGT and that fits in the read; -1 if none   (KmerIterator::operator++)
@@ -287,6 +288,124 @@ KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* e
     w = next_valid_window(r, w + 1, k);
   }
 #undef KAMD_PUSH
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same match() as a resumable state machine that asks for exactly ONE table probe per step.  Kernel A (v2) keeps one
+// of these per lane so that every loop iteration issues one probe for every lane (no serialised probe sites), and a lane
+// that finishes a read immediately starts the next one.  States follow the probe sites of KmerIndex::match:
+//   SCAN (:1753)  JUMP (:1804)  MIDDLE (:1839)  BACKOFF (:1900)
+// ---------------------------------------------------------------------------------------------------------------
+enum { PH_SCAN = 0, PH_JUMP = 1, PH_MIDDLE = 2, PH_BACKOFF = 3, PH_DONE = 4 };
+struct MatchState {
+  int phase;
+  int w;        // window the next probe must look up
+  int w0;       // window of the hit under examination (the iterator position `kit`)
+  int w2;       // jump target window (`kit2`)
+  int dist;     // :1789
+  int nextPos;  // :1794-1799
+  uint32_t um_uec, um2_uec;
+};
+// distinct (unitig, set) classes seen by one item: entry = uec | mate flags (bit 30: mate 1, bit 31: mate 2)
+struct UecList {
+  uint32_t* e; int cap; int n; bool overflow;
+};
+KAMD_HD void ueclist_add(UecList& l, uint32_t uec, int mate) {
+  const uint32_t flag = mate ? 0x80000000u : 0x40000000u;
+  for (int i = l.n - 1; i >= 0; --i)
+    if ((l.e[i] & 0x3FFFFFFFu) == uec) { l.e[i] |= flag; return; }
+  if (l.n == l.cap) { l.overflow = true; return; }
+  l.e[l.n++] = uec | flag;
+}
+struct MateFirst { int n_hits; uint64_t slot; int pos; bool strand; };
+
+KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
+  st.w = next_valid_window(r, 0, k);
+  st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
+  st.w0 = st.w2 = st.dist = st.nextPos = 0; st.um_uec = st.um2_uec = NO_UEC;
+}
+// consume the probe result of window st.w
+KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf) {
+  const int l = r.len;
+  bool backoff = false;
+  switch (st.phase) {
+    case PH_SCAN: {
+      if (p.found) {
+        if (mf.n_hits == 0) { mf.slot = p.slot; mf.pos = st.w; mf.strand = p.strand; }
+        ++mf.n_hits; ueclist_add(list, p.uec, mate);                               // :1774
+        if ((int)p.dist >= 2) {                                                    // :1792
+          const int pos = st.w, dist = (int)p.dist;
+          int nextPos = pos + dist;
+          if (pos + dist >= l - k) nextPos = l - k;                                // :1796-1799
+          const int w2 = advance_window(r, st.w, nextPos - pos, k);                // :1802-1803
+          if (w2 < 0) { st.phase = PH_DONE; return; }                              // :1882-1886 (Q4)
+          st.w0 = st.w; st.w2 = w2; st.dist = dist; st.nextPos = nextPos; st.um_uec = p.uec;
+          st.phase = PH_JUMP; st.w = w2;
+          return;
+        }
+      }
+      st.w = next_valid_window(r, st.w + 1, k);
+      if (st.w < 0) st.phase = PH_DONE;
+      return;
+    }
+    case PH_JUMP: {
+      const int pos = st.w0;
+      const bool found2 = !p.found || p.uec == st.um_uec;                          // :1807-1815
+      if (found2) {
+        const int found2pos = p.found ? pos + st.dist : pos;                       // (Q2)
+        ++mf.n_hits;                                                               // push {um, found2pos | l-k}
+        if (found2pos >= l - k) { st.phase = PH_DONE; return; }                    // :1819-1822
+        st.w = next_valid_window(r, st.w2 + 1, k);                                 // kit = kit2; ++kit
+        st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
+        return;
+      }
+      st.um2_uec = p.uec;
+      if (st.dist > 4) {                                                           // :1831
+        const int middlePos = (pos + st.nextPos) / 2;
+        const int w3 = advance_window(r, st.w0, middlePos - pos, k);
+        if (w3 >= 0) { st.phase = PH_MIDDLE; st.w = w3; return; }
+      }
+      backoff = true;
+      break;
+    }
+    case PH_MIDDLE: {
+      if (p.found && (p.uec == st.um_uec || p.uec == st.um2_uec)) {                // :1842-1850
+        ++mf.n_hits; ueclist_add(list, p.uec, mate);                               // :1866 (Q3)
+        if (st.nextPos >= l - k) { st.phase = PH_DONE; return; }                   // :1867-1868
+        st.w = next_valid_window(r, st.w2 + 1, k);
+        st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
+        return;
+      }
+      backoff = true;
+      break;
+    }
+    case PH_BACKOFF: {
+      if (p.found) { ++mf.n_hits; ueclist_add(list, p.uec, mate); }                // :1900-1917
+      st.w = next_valid_window(r, st.w + 1, k);
+      st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
+      return;
+    }
+    default: return;
+  }
+  if (backoff) {                                                                   // :1876-1925 with Q1: one-step back-off
+    st.w = next_valid_window(r, st.w0 + 1, k);
+    st.phase = st.w >= 0 ? PH_BACKOFF : PH_DONE;
+  }
+}
+
+// map the item's (unitig, set) classes to sorted distinct non-empty transcript-set ids; reports per mate whether any of
+// its hits carried a non-empty set (MinCollector::intersectECs skips empty sets, MinCollector.cpp:463-471)
+KAMD_HD void uecs_to_ecs(const uint32_t* uecs, int n, const uint32_t* uec_ec, const uint8_t* ec_nonempty, EcList& out,
+                         bool* nonempty0, bool* nonempty1) {
+  *nonempty0 = *nonempty1 = false;
+  for (int i = 0; i < n; i++) {
+    const uint32_t u = uecs[i];
+    const uint32_t ec = uec_ec[u & 0x3FFFFFFFu];
+    if (ec_nonempty != nullptr && !ec_nonempty[ec]) continue;
+    if (u & 0x40000000u) *nonempty0 = true;
+    if (u & 0x80000000u) *nonempty1 = true;
+    eclist_add(out, ec);
+  }
 }
 
 // Outcome of intersectKmers' emptiness rules (MinCollector.cpp:172-202) given per-mate facts.

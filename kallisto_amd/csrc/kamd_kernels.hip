@@ -154,6 +154,63 @@ struct AlignOut {
   DevState* st;
 };
 
+// Common tail of kernel A: classify one item per lane and emit it (must be called by all 64 lanes of the wavefront).
+//   single non-empty set  -> dense count vector;  several sets -> tuple record, ONE allocation per wavefront (inclusive
+//   scan of the record sizes across the lanes);  list overflow -> overflow kernel;  set changed by a positional filter
+//   -> explicit-set pass.
+template <bool PAIRED, bool FILTER>
+__device__ __forceinline__ void emit_item(const DevIndex& ix, const FilterDev& fd, const AlignOut& out, const kamd::EcList& ecs,
+                                          const kamd::MateInfo& m0, const kamd::MateInfo& m1, u64 item, bool active) {
+  // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow, 4 explicit set (positional filter changed it)
+  int kind = 0;
+  if (active) {
+    if (ecs.overflow) kind = 3;
+    else if (kamd::pair_is_mapped(m0, m1)) kind = ecs.n == 1 ? 1 : 2;
+  }
+  if (FILTER && (kind == 1 || kind == 2)) {
+    u32 kept = 0;
+    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+    if (oc == 1) kind = 0;
+    else if (oc == 2) {
+      kind = 4;
+      const u64 k = atomicAdd(&out.st->n_explicit, 1ULL);
+      out.explicit_items[k] = item;
+      atomicAdd(&out.st->exp_words, (u64)kept + 2);
+    }
+  }
+  if (kind == 1) atomicAdd(&out.dense_counts[ecs.e[0]], 1u);
+  const u32 need = kind == 2 ? (u32)ecs.n + 2u : 0u;
+  const u32 incl = wave_incl_scan(need);
+  const u32 wave_total = __shfl(incl, 63, 64);
+  const u64 multi_mask = __ballot(kind == 2);
+  u64 base_words = 0, base_recs = 0;
+  if (wave_total) {
+    if (lane_id() == 0) {
+      base_words = atomicAdd(&out.st->stream_words, (u64)wave_total);
+      base_recs = atomicAdd(&out.st->n_recs, (u64)__popcll(multi_mask));
+    }
+    base_words = __shfl(base_words, 0, 64);
+    base_recs = __shfl(base_recs, 0, 64);
+    if (kind == 2) {
+      const u64 off = base_words + (incl - need);
+      const u64 ridx = base_recs + (u64)__popcll(multi_mask & ((1ULL << lane_id()) - 1));
+      u32* w = out.stream + off;
+      w[0] = 1u; w[1] = (u32)ecs.n;
+      for (int i = 0; i < ecs.n; i++) w[2 + i] = ecs.e[i];
+      out.rec_off[ridx] = off;
+    }
+  }
+  if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item; }
+  const u64 s_single = (u64)__popcll(__ballot(kind == 1));
+  const u64 s_multi = (u64)__popcll(multi_mask);
+  const u64 s_proc = (u64)__popcll(__ballot(active));
+  if (lane_id() == 0) {
+    if (s_single) atomicAdd(&out.st->st_single, s_single);
+    if (s_multi) atomicAdd(&out.st->st_multi, s_multi);
+    atomicAdd(&out.st->st_processed, s_proc);
+  }
+}
+
 template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* __restrict__ words,
                                                        const uint16_t* __restrict__ lens, u64 n_items, int seq_words,
@@ -192,60 +249,166 @@ __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* _
       kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
     }
   }
-  // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow, 4 explicit set (positional filter changed it)
-  int kind = 0;
-  if (active) {
-    if (ecs.overflow) kind = 3;
-    else if (kamd::pair_is_mapped(m0, m1)) kind = ecs.n == 1 ? 1 : 2;
-  }
-  if (FILTER && (kind == 1 || kind == 2)) {
-    u32 kept = 0;
-    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
-    if (oc == 1) kind = 0;
-    else if (oc == 2) {
-      kind = 4;
-      const u64 k = atomicAdd(&out.st->n_explicit, 1ULL);
-      out.explicit_items[k] = item0 + tid;
-      atomicAdd(&out.st->exp_words, (u64)kept + 2);
-    }
-  }
-  if (kind == 1) atomicAdd(&out.dense_counts[ecs.e[0]], 1u);
-  // tuple stream: one allocation per wavefront (prefix sum of record sizes across the lanes)
-  const u32 need = kind == 2 ? (u32)ecs.n + 2u : 0u;
-  const u32 incl = wave_incl_scan(need);
-  const u32 wave_total = __shfl(incl, 63, 64);
-  const u64 multi_mask = __ballot(kind == 2);
-  u64 base_words = 0, base_recs = 0;
-  if (wave_total) {
-    if (lane_id() == 0) {
-      base_words = atomicAdd(&out.st->stream_words, (u64)wave_total);
-      base_recs = atomicAdd(&out.st->n_recs, (u64)__popcll(multi_mask));
-    }
-    base_words = __shfl(base_words, 0, 64);
-    base_recs = __shfl(base_recs, 0, 64);
-    if (kind == 2) {
-      const u64 off = base_words + (incl - need);
-      const u64 ridx = base_recs + (u64)__popcll(multi_mask & ((1ULL << lane_id()) - 1));
-      u32* w = out.stream + off;
-      w[0] = 1u; w[1] = (u32)ecs.n;
-      for (int i = 0; i < ecs.n; i++) w[2 + i] = ecs.e[i];
-      out.rec_off[ridx] = off;
-    }
-  }
-  if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item0 + tid; }
-  // statistics: one atomic per wavefront and counter
+  emit_item<PAIRED, FILTER>(ix, fd, out, ecs, m0, m1, item0 + tid, active);
+  // probe statistics: one atomic per wavefront and counter
   u64 s_probes = wave_sum64((u64)(m0.probes + m1.probes));
   u64 s_reads = wave_sum64((u64)(m0.bucket_reads + m1.bucket_reads));
-  u64 s_single = (u64)__popcll(__ballot(kind == 1));
-  u64 s_multi = (u64)__popcll(multi_mask);
-  u64 s_proc = (u64)__popcll(__ballot(active));
   if (lane_id() == 0) {
     atomicAdd(&out.st->st_probes, s_probes);
     atomicAdd(&out.st->st_bucket_reads, s_reads);
-    if (s_single) atomicAdd(&out.st->st_single, s_single);
-    if (s_multi) atomicAdd(&out.st->st_multi, s_multi);
-    atomicAdd(&out.st->st_processed, s_proc);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel A, version 2: one table probe per lane per loop iteration.
+//   k_match_v2   each lane owns a resumable match() state machine (kamd_core.h MatchState); every iteration all busy lanes
+//                issue exactly one bucket load together, and a lane that finishes its item takes the next one of the
+//                wavefront's chunk (LDS cursor), its packed reads being fetched while the others probe.  Reads live in a
+//                lane-transposed LDS layout (word j of lane i at [j*64+i]: conflict-free).  Output: one raw record per
+//                item {header, distinct (unitig,set) classes}.
+//   k_classify   one thread per item: classes -> sorted distinct transcript-set ids, then the common emit_item tail.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int STAGE_WORDS = 36;  // packed words of one item fetched ahead in registers (PE-150 = 34)
+constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
+
+template <bool PAIRED, bool FILTER>
+__global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
+                                                    u64 n_items, int seq_words, int rec_words, int items_per_wave, u32* raw,
+                                                    int raw_stride, DevState* st) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  constexpr int WAVES = BLOCK / 64;
+  const int item_words = rec_words * (PAIRED ? 2 : 1);
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  u32* my_words = lds + (size_t)wv * 64 * item_words + lane;  // word j at my_words[j * 64]
+  u32* my_list = lds + (size_t)WAVES * 64 * item_words + (size_t)threadIdx.x * TUPLE_CAP;
+  u32* cursor = lds + (size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP;
+  const u64 wave_global = (u64)blockIdx.x * WAVES + wv;
+  const u64 chunk0 = wave_global * (u64)items_per_wave;
+  const u32 chunk_n = chunk0 < n_items ? (u32)min((u64)items_per_wave, n_items - chunk0) : 0u;
+  if (lane == 0) cursor[wv] = 64u;  // the first 64 items of the chunk are pre-assigned, one per lane
+  const kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const int k = ix.k;
+
+  kamd::MatchState ms; ms.phase = kamd::PH_DONE;
+  kamd::UecList ul{my_list, TUPLE_CAP, 0, false};
+  kamd::MateFirst mf0{0, 0, -1, false}, mf1{0, 0, -1, false};
+  int mate = 0, len0 = 0, len1 = 0;
+  u32 my_idx = (u32)lane;
+  bool have = false;      // the lane owns an item whose raw record is not written yet
+  bool busy = false;      // ... and its state machine still wants probes
+  bool exhausted = false, first = true;
+  u32 probes = 0, breads = 0;
+
+  for (;;) {
+    // 1. lanes without an item take the next one of the chunk and start fetching its packed reads into registers
+    u32 stage[STAGE_WORDS];
+    bool loading = false;
+    const u32* src = nullptr;
+    if (!have && !exhausted) {
+      if (!first) my_idx = atomicAdd(&cursor[wv], 1u);
+      first = false;
+      if (my_idx >= chunk_n) exhausted = true;
+      else {
+        loading = true;
+        const u64 item = chunk0 + my_idx;
+        src = words + item * item_words;
+#pragma unroll
+        for (int j = 0; j < STAGE_WORDS; j++) stage[j] = j < item_words ? src[j] : 0u;
+        len0 = PAIRED ? (int)lens[2 * item] : (int)lens[item];
+        len1 = PAIRED ? (int)lens[2 * item + 1] : 0;
+      }
+    }
+    if (__ballot(have || loading) == 0ULL) break;
+    // 2.+3. every busy lane: one probe, then advance its state machine
+    if (have && busy) {
+      const u32* base = my_words + (size_t)(mate ? rec_words : 0) * 64;
+      kamd::ReadView rv{base, base + (size_t)seq_words * 64, mate ? len1 : len0, 64};
+      bool fc;
+      const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
+      const kamd::Probe p = kamd::probe_table(t, canon, fc, &breads);
+      ++probes;
+      kamd::match_feed(ms, rv, k, p, ul, mate, mate ? mf1 : mf0);
+      if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
+        mate = 1;
+        const u32* b1 = my_words + (size_t)rec_words * 64;
+        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64};
+        kamd::match_init(ms, r1, k);
+      }
+      busy = ms.phase != kamd::PH_DONE;
+    }
+    // 4. lanes that fetched an item: registers -> LDS (lane-transposed), start mate 1
+    if (loading) {
+#pragma unroll
+      for (int j = 0; j < STAGE_WORDS; j++) if (j < item_words) my_words[(size_t)j * 64] = stage[j];
+      for (int j = STAGE_WORDS; j < item_words; j++) my_words[(size_t)j * 64] = src[j];  // reads longer than the staging window
+      ul.n = 0; ul.overflow = false;
+      mf0 = kamd::MateFirst{0, 0, -1, false}; mf1 = kamd::MateFirst{0, 0, -1, false};
+      mate = 0;
+      kamd::ReadView r0{my_words, my_words + (size_t)seq_words * 64, len0, 64};
+      kamd::match_init(ms, r0, k);
+      if (ms.phase == kamd::PH_DONE && PAIRED) {
+        mate = 1;
+        const u32* b1 = my_words + (size_t)rec_words * 64;
+        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64};
+        kamd::match_init(ms, r1, k);
+      }
+      have = true;
+      busy = ms.phase != kamd::PH_DONE;
+    }
+    // 5. finished items: write the raw record (plain stores, nothing waits for them) and free the lane
+    if (have && !busy) {
+      u32* o = raw + (chunk0 + my_idx) * (u64)raw_stride;
+      o[0] = (u32)ul.n | (ul.overflow ? RAW_OVERFLOW : 0u) | (mf0.n_hits > 0 ? RAW_HIT0 : 0u) | (mf1.n_hits > 0 ? RAW_HIT1 : 0u);
+      for (int j = 0; j < ul.n; j++) o[1 + j] = ul.e[j];
+      if (FILTER) {
+        o[1 + TUPLE_CAP] = (u32)mf0.slot; o[2 + TUPLE_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
+        o[3 + TUPLE_CAP] = (u32)mf1.slot; o[4 + TUPLE_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
+      }
+      have = false;
+    }
+  }
+  const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads);
+  if (lane == 0) { atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); }
+}
+
+template <bool PAIRED, bool FILTER>
+__global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, const u32* __restrict__ raw, int raw_stride, u64 n_items, FilterDev fd,
+                                                    AlignOut out) {
+  __shared__ u32 lds_ecs[BLOCK * TUPLE_CAP];
+  const u64 item = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = item < n_items;
+  kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; ecs.n = 0; ecs.overflow = false;
+  kamd::MateInfo m0, m1;
+  m0.n_hits = m1.n_hits = 0; m0.n_nonempty = m1.n_nonempty = 0; m0.first_slot = m1.first_slot = 0;
+  m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
+  if (active) {
+    const u32* r = raw + item * (u64)raw_stride;
+    const u32 h = r[0];
+    const int n = (int)(h & 0xFFu);
+    u32 uecs[TUPLE_CAP];
+#pragma unroll
+    for (int j = 0; j < TUPLE_CAP; j++) uecs[j] = j < n ? r[1 + j] : 0u;
+    u32 ec[TUPLE_CAP];
+#pragma unroll
+    for (int j = 0; j < TUPLE_CAP; j++) ec[j] = j < n ? ix.uec_ec[uecs[j] & 0x3FFFFFFFu] : 0u;   // independent loads, issued together
+    bool ne0 = false, ne1 = false;
+#pragma unroll
+    for (int j = 0; j < TUPLE_CAP; j++) {
+      if (j < n && ix.ec_nonempty[ec[j]]) {
+        if (uecs[j] & 0x40000000u) ne0 = true;
+        if (uecs[j] & 0x80000000u) ne1 = true;
+        kamd::eclist_add(ecs, ec[j]);
+      }
+    }
+    ecs.overflow = (h & RAW_OVERFLOW) != 0;
+    m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
+    m0.n_nonempty = ne0; m1.n_nonempty = ne1;
+    if (FILTER) {
+      m0.first_slot = r[1 + TUPLE_CAP]; m0.first_pos = (int)(r[2 + TUPLE_CAP] & 0xFFFF); m0.first_strand = (r[2 + TUPLE_CAP] >> 16) & 1u;
+      m1.first_slot = r[3 + TUPLE_CAP]; m1.first_pos = (int)(r[4 + TUPLE_CAP] & 0xFFFF); m1.first_strand = (r[4 + TUPLE_CAP] >> 16) & 1u;
+    }
+  }
+  emit_item<PAIRED, FILTER>(ix, fd, out, ecs, m0, m1, item, active);
 }
 
 // items whose hits carried more than TUPLE_CAP distinct sets: same logic, lists in global scratch, reads from HBM
@@ -827,7 +990,7 @@ struct kamd_ctx {
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
-  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp;
+  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial;
   DevState host_state{};
@@ -839,7 +1002,9 @@ struct kamd_ctx {
   bool finalized = false;
   u64 exp_words_done = 0;        // words of the explicit-set stream actually written
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_align_ms = 0.f, last_em_ms = 0.f;
+  float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
+  hipEvent_t ev2 = nullptr;
+  int kernel_a_version = 2, items_per_wave = 512;
   uint64_t last_em_iters = 0;
 };
 
@@ -948,7 +1113,9 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (c->state.ensure(sizeof(DevState), 0, c->stream)) { delete c; return -100; }
   memset(&c->host_state, 0, sizeof c->host_state);
   if (push_state(c)) { delete c; return -100; }
-  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
+  if (const char* e = getenv("KAMD_KERNEL_A")) c->kernel_a_version = atoi(e) == 1 ? 1 : 2;   // 1 = block-staged kernel, 2 = one probe per iteration
+  if (const char* e = getenv("KAMD_ITEMS_PER_WAVE")) c->items_per_wave = std::max(64, atoi(e));
   *out = c;
   return 0;
 }
@@ -959,10 +1126,11 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
                   &c->em_segoff, &c->em_segt, &c->em_partial})
@@ -1043,6 +1211,25 @@ int launch_align(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_i
   return 0;
 }
 template <bool PAIRED, bool FILTER>
+int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
+                    const AlignOut& out) {
+  constexpr int WAVES = BLOCK / 64;
+  const int item_words = rec_words * (PAIRED ? 2 : 1);
+  const int raw_stride = 1 + TUPLE_CAP + (FILTER ? 4 : 0);
+  if (int rc = c->raw.ensure(n_items * (u64)raw_stride * sizeof(u32), 0, c->stream)) return rc;
+  const size_t lds_bytes = ((size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP + WAVES) * sizeof(u32);
+  if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-resident kernel");
+  const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
+  HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
+                     n_items, seq_words, rec_words, c->items_per_wave, c->raw.as<u32>(), raw_stride, (DevState*)c->state.p);
+  HIPC(hipEventRecord(c->ev1, c->stream));
+  hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid_for(n_items, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->raw.as<u32>(),
+                     raw_stride, n_items, fd, out);
+  HIPC(hipEventRecord(c->ev2, c->stream));
+  return 0;
+}
+template <bool PAIRED, bool FILTER>
 void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
                      const AlignOut& out) {
   hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
@@ -1087,15 +1274,25 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
                c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
   HIPC(hipEventRecord(c->ev0, c->stream));
   int rc = 0;
-  if (o->paired) rc = filter ? launch_align<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
-                             : launch_align<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
-  else rc = filter ? launch_align<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
-                   : launch_align<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
-  if (rc) return rc;
-  HIPC(hipEventRecord(c->ev1, c->stream));
+  if (c->kernel_a_version == 2) {
+    if (o->paired) rc = filter ? launch_align_v2<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
+                               : launch_align_v2<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+    else rc = filter ? launch_align_v2<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
+                     : launch_align_v2<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+    if (rc) return rc;
+  } else {
+    if (o->paired) rc = filter ? launch_align<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
+                               : launch_align<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
+    else rc = filter ? launch_align<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
+                     : launch_align<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
+    if (rc) return rc;
+    HIPC(hipEventRecord(c->ev1, c->stream));
+    HIPC(hipEventRecord(c->ev2, c->stream));
+  }
   HIPC(hipGetLastError());
   if (int rc2 = sync_state(c)) return rc2;
   HIPC(hipEventElapsedTime(&c->last_align_ms, c->ev0, c->ev1));
+  HIPC(hipEventElapsedTime(&c->last_classify_ms, c->ev1, c->ev2));
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
     if (int rc2 = c->overflow_scratch.ensure(nov * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
@@ -1465,6 +1662,7 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
 extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   if (!c || !p) return kamd::fail(-1, "kamd_profile_get: null argument");
   p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
+  p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
   return 0;
 }
 

@@ -50,6 +50,54 @@ int64_t emu_pseudoalign(const kamd_index_view* v, const uint32_t* words, const u
 }
 }
 
+// the resumable one-probe-per-step state machine (kernel A v2): per item the sorted distinct set ids it collects, the
+// mapped flag and the probe count -- must equal what match_mate produces
+extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, const uint16_t* lens, uint64_t n_items, int paired,
+                              int32_t max_len, int use_stepper, uint32_t* out, uint64_t stride, uint64_t* probes) {
+  using namespace kamd;
+  const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
+  Table t{v->table, v->n_buckets};
+  std::vector<uint8_t> nonempty(v->n_ecs);
+  for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
+  uint32_t ecbuf[1024], uecbuf[1024];
+  for (uint64_t i = 0; i < n_items; i++) {
+    EcList ecs{ecbuf, 1024, 0, false};
+    bool mapped;
+    if (!use_stepper) {
+      MateInfo m[2]; memset(m, 0, sizeof m);
+      for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
+        uint64_t r = paired ? 2 * i + mate : i;
+        ReadView rv{words + r * rec, words + r * rec + sw, lens[r]};
+        match_mate(t, v->uec_ec, nonempty.data(), rv, v->k, ecs, m[mate]);
+        *probes += m[mate].probes;
+      }
+      mapped = pair_is_mapped(m[0], m[1]);
+    } else {
+      UecList ul{uecbuf, 1024, 0, false};
+      MateFirst mf[2] = {{0, 0, -1, false}, {0, 0, -1, false}};
+      for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
+        uint64_t r = paired ? 2 * i + mate : i;
+        ReadView rv{words + r * rec, words + r * rec + sw, lens[r]};
+        MatchState st; match_init(st, rv, v->k);
+        while (st.phase != PH_DONE) {
+          bool fc; uint64_t canon = window_canon(rv, st.w, v->k, &fc);
+          Probe p = probe_table(t, canon, fc, nullptr);
+          ++*probes;
+          match_feed(st, rv, v->k, p, ul, mate, mf[mate]);
+        }
+      }
+      bool ne0, ne1;
+      uecs_to_ecs(ul.e, ul.n, v->uec_ec, nonempty.data(), ecs, &ne0, &ne1);
+      MateInfo a, b; a.n_hits = mf[0].n_hits; a.n_nonempty = ne0; b.n_hits = mf[1].n_hits; b.n_nonempty = ne1;
+      mapped = pair_is_mapped(a, b);
+    }
+    uint32_t* o = out + i * stride;
+    o[0] = mapped ? (uint32_t)ecs.n : 0xFFFFFFFFu;
+    for (int j = 0; j < ecs.n && (uint64_t)j + 1 < stride; j++) o[1 + j] = ecs.e[j];
+  }
+  return 0;
+}
+
 // same as emu_pseudoalign, plus the positional filters of processBuffer (fragment-length compatibility via findPosition,
 // strand specificity) evaluated by kamd_core.h's keep_transcript on each member of the intersection
 extern "C" int64_t emu_pseudoalign_opts(const kamd_index_view* v, const uint32_t* words, const uint16_t* lens, uint64_t n_items,

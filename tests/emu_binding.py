@@ -94,6 +94,18 @@ def pseudoalign_opts(ix: EmuIndex, words, l16, n_items, paired, max_len, single_
     return out_off, out_ids
 
 
+def tuples(ix: EmuIndex, words, l16, n_items, paired, max_len, use_stepper, stride=40):
+    L = lib()
+    L.emu_tuples.restype = C.c_int64
+    out = np.zeros(n_items * stride, np.uint32)
+    pr = C.c_uint64(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    r = L.emu_tuples(C.byref(ix.view), p(words), p(l16), C.c_uint64(n_items), int(paired), C.c_int32(max_len), int(use_stepper),
+                     p(out), C.c_uint64(stride), C.byref(pr))
+    assert r == 0
+    return out.reshape(n_items, stride), pr.value
+
+
 def ec_state(ix: EmuIndex, words, l16, n_items, paired, max_len):
     L = lib()
     dense = np.zeros(max(ix.view.n_ecs, 1), np.uint32)

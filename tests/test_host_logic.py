@@ -82,6 +82,18 @@ def test_positional_filters_match_oracle(case, variant, idx):
         assert ids[off[i]:off[i + 1]].tolist() == s, (case, variant, i)
 
 
+@pytest.mark.parametrize("case", common.CASES)
+def test_resumable_state_machine_equals_match(case, idx):
+    """kernel A v2's one-probe-per-step state machine vs the straight-line match(): same sets, same probe count."""
+    e, _ = idx(case)
+    meta, _, r1, r2 = common.load_case(case)
+    paired = r2 is not None
+    words, l16, max_len = E.pack(common.interleave(r1, r2))
+    a, pa = E.tuples(e, words, l16, len(r1), paired, max_len, 0)
+    b, pb = E.tuples(e, words, l16, len(r1), paired, max_len, 1)
+    assert pa == pb and np.array_equal(a, b)
+
+
 def test_probe_counts_match_oracle(idx):
     e, o = idx("ref_test_pe")
     meta, _, r1, r2 = common.load_case("ref_test_pe")
