@@ -222,7 +222,10 @@ def main():
         # per k-mer probe + what the launch writes (4 B per single-set count, the tuple record and its 8-byte offset)
         # (the counters are reset every step, so `st` describes exactly one launch)
         rec_bytes = 2 * rec * 4 + 2 * 2
-        alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_single"] + 4 * st["n_stream_words"] + 8 * st["n_multi"]
+        if pr["kernel_a_version"] == 2:   # k_match_v2 writes one raw record per item: header + distinct (unitig,set) classes
+            alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_raw_words"]
+        else:
+            alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_single"] + 4 * st["n_stream_words"] + 8 * st["n_multi"]
         a_ms = float(np.mean(align_ms))
         achieved = alg_bytes / (a_ms * 1e-3) / 1e9
         out = {

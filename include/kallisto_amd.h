@@ -117,7 +117,8 @@ typedef struct {
   uint64_t n_probes;        /* k-mer table probes */
   uint64_t n_bucket_reads;  /* 64-byte bucket reads (>= n_probes) */
   uint64_t n_distinct_tuples;
-  uint64_t n_stream_words;  /* u32 words appended to the tuple stream ([cnt, m, e0..] records) */
+  uint64_t n_stream_words;  /* u32 words of the record stream (fixed slots of kernel A v2 included) */
+  uint64_t n_raw_words;     /* u32 words k_match_v2 wrote: per item 1 header + its distinct (unitig,set) classes */
 } kamd_align_stats;
 int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
 

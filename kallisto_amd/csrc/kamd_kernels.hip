@@ -57,7 +57,7 @@ struct FilterDev { int single_overhang, has_mean_fl, fl, strand; };
 // device-resident cursors and statistics
 struct DevState {
   u64 stream_words, n_recs, n_overflow, n_retry;
-  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads;
+  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words;
   u64 n_list, bound_words;       // generic append cursor / size bound accumulator
   u64 n_explicit, n_explicit_big; // items whose set was changed by a positional filter (from the main / overflow kernel)
   u64 exp_words, exp_recs;       // explicit transcript-set stream
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
   bool have = false;      // the lane owns an item whose raw record is not written yet
   bool busy = false;      // ... and its state machine still wants probes
   bool exhausted = false, first = true;
-  u32 probes = 0, breads = 0;
+  u32 probes = 0, breads = 0, raw_words = 0;
 
   for (;;) {
     // 1. lanes without an item take the next one of the chunk and start fetching its packed reads into registers
@@ -360,29 +360,42 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       u32* o = raw + (chunk0 + my_idx) * (u64)raw_stride;
       o[0] = (u32)ul.n | (ul.overflow ? RAW_OVERFLOW : 0u) | (mf0.n_hits > 0 ? RAW_HIT0 : 0u) | (mf1.n_hits > 0 ? RAW_HIT1 : 0u);
       for (int j = 0; j < ul.n; j++) o[1 + j] = ul.e[j];
+      raw_words += 1u + (u32)ul.n;
       if (FILTER) {
-        o[1 + TUPLE_CAP] = (u32)mf0.slot; o[2 + TUPLE_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
-        o[3 + TUPLE_CAP] = (u32)mf1.slot; o[4 + TUPLE_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
+        o[2 + TUPLE_CAP] = (u32)mf0.slot; o[3 + TUPLE_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
+        o[4 + TUPLE_CAP] = (u32)mf1.slot; o[5 + TUPLE_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
       }
       have = false;
     }
   }
-  const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads);
-  if (lane == 0) { atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); }
+  const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads), s_raw = wave_sum64((u64)raw_words);
+  if (lane == 0) { atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); atomicAdd(&st->st_raw_words, s_raw); }
 }
 
+// Persistent blocks (grid-stride over 256-item tiles) so that the per-launch bookkeeping costs a handful of same-address
+// atomics per BLOCK instead of per wavefront (a device-scope atomic on one address retires every ~12 ns: half a million
+// wavefronts x 5 counters was most of kernel A v1's time).  Each item's slot of the stream is rewritten IN PLACE as a
+// tuple record [1, m, e0..] (or [0, ..] when the item is not a tuple), so no stream allocation is needed at all; counts
+// of single-set items go through an LDS cache that absorbs the hot sets before touching the dense vector.
+constexpr int DENSE_CACHE = 2048;
 template <bool PAIRED, bool FILTER>
-__global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, const u32* __restrict__ raw, int raw_stride, u64 n_items, FilterDev fd,
-                                                    AlignOut out) {
+__global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict__ slots, int stride, u64 n_items, u64 slot_base,
+                                                    u64 rec_base, FilterDev fd, AlignOut out) {
   __shared__ u32 lds_ecs[BLOCK * TUPLE_CAP];
-  const u64 item = (u64)blockIdx.x * BLOCK + threadIdx.x;
-  const bool active = item < n_items;
-  kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; ecs.n = 0; ecs.overflow = false;
-  kamd::MateInfo m0, m1;
-  m0.n_hits = m1.n_hits = 0; m0.n_nonempty = m1.n_nonempty = 0; m0.first_slot = m1.first_slot = 0;
-  m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
-  if (active) {
-    const u32* r = raw + item * (u64)raw_stride;
+  __shared__ u32 cache_key[DENSE_CACHE];
+  __shared__ u32 cache_cnt[DENSE_CACHE];
+  __shared__ u32 blk_stats[3];
+  for (int i = threadIdx.x; i < DENSE_CACHE; i += BLOCK) { cache_key[i] = 0xFFFFFFFFu; cache_cnt[i] = 0u; }
+  if (threadIdx.x < 3) blk_stats[threadIdx.x] = 0u;
+  __syncthreads();
+  u32 s_single = 0, s_multi = 0, s_proc = 0;
+  for (u64 tile = blockIdx.x; tile * BLOCK < n_items; tile += gridDim.x) {
+    const u64 item = tile * BLOCK + threadIdx.x;
+    if (item >= n_items) continue;
+    kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; ecs.n = 0; ecs.overflow = false;
+    kamd::MateInfo m0, m1;
+    m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
+    u32* r = slots + item * (u64)stride;
     const u32 h = r[0];
     const int n = (int)(h & 0xFFu);
     u32 uecs[TUPLE_CAP];
@@ -404,11 +417,53 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, const u32* __re
     m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
     m0.n_nonempty = ne0; m1.n_nonempty = ne1;
     if (FILTER) {
-      m0.first_slot = r[1 + TUPLE_CAP]; m0.first_pos = (int)(r[2 + TUPLE_CAP] & 0xFFFF); m0.first_strand = (r[2 + TUPLE_CAP] >> 16) & 1u;
-      m1.first_slot = r[3 + TUPLE_CAP]; m1.first_pos = (int)(r[4 + TUPLE_CAP] & 0xFFFF); m1.first_strand = (r[4 + TUPLE_CAP] >> 16) & 1u;
+      m0.first_slot = r[2 + TUPLE_CAP]; m0.first_pos = (int)(r[3 + TUPLE_CAP] & 0xFFFF); m0.first_strand = (r[3 + TUPLE_CAP] >> 16) & 1u;
+      m1.first_slot = r[4 + TUPLE_CAP]; m1.first_pos = (int)(r[5 + TUPLE_CAP] & 0xFFFF); m1.first_strand = (r[5 + TUPLE_CAP] >> 16) & 1u;
     }
+    // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow, 4 explicit set (positional filter changed it)
+    int kind = 0;
+    if (ecs.overflow) kind = 3;
+    else if (kamd::pair_is_mapped(m0, m1)) kind = ecs.n == 1 ? 1 : 2;
+    if (FILTER && (kind == 1 || kind == 2)) {
+      u32 kept = 0;
+      const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+      if (oc == 1) kind = 0;
+      else if (oc == 2) {
+        kind = 4;
+        const u64 k = atomicAdd(&out.st->n_explicit, 1ULL);
+        out.explicit_items[k] = item;
+        atomicAdd(&out.st->exp_words, (u64)kept + 2);
+      }
+    }
+    ++s_proc;
+    if (kind == 1) {
+      ++s_single;
+      const u32 e = ecs.e[0];
+      const u32 hh = (e * 2654435761u) >> (32 - 11);
+      const u32 old = atomicCAS(&cache_key[hh], 0xFFFFFFFFu, e);
+      if (old == 0xFFFFFFFFu || old == e) atomicAdd(&cache_cnt[hh], 1u);
+      else atomicAdd(&out.dense_counts[e], 1u);
+    }
+    if (kind == 2) {
+      ++s_multi;
+      r[1] = (u32)ecs.n;
+      for (int j = 0; j < ecs.n; j++) r[2 + j] = ecs.e[j];
+    }
+    r[0] = kind == 2 ? 1u : 0u;  // record count: 0 = not a tuple record (skipped by the de-duplication)
+    out.rec_off[rec_base + item] = slot_base + item * (u64)stride;
+    if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item; }
   }
-  emit_item<PAIRED, FILTER>(ix, fd, out, ecs, m0, m1, item, active);
+  // flush: block-level statistics and the cached single-set counts
+  const u64 w_single = wave_sum64((u64)s_single), w_multi = wave_sum64((u64)s_multi), w_proc = wave_sum64((u64)s_proc);
+  if (lane_id() == 0) { atomicAdd(&blk_stats[0], (u32)w_single); atomicAdd(&blk_stats[1], (u32)w_multi); atomicAdd(&blk_stats[2], (u32)w_proc); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < DENSE_CACHE; i += BLOCK)
+    if (cache_cnt[i]) atomicAdd(&out.dense_counts[cache_key[i]], cache_cnt[i]);
+  if (threadIdx.x == 0) {
+    if (blk_stats[0]) atomicAdd(&out.st->st_single, (u64)blk_stats[0]);
+    if (blk_stats[1]) atomicAdd(&out.st->st_multi, (u64)blk_stats[1]);
+    atomicAdd(&out.st->st_processed, (u64)blk_stats[2]);
+  }
 }
 
 // items whose hits carried more than TUPLE_CAP distinct sets: same logic, lists in global scratch, reads from HBM
@@ -509,6 +564,7 @@ __global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restri
   if (i >= n) return;
   const u64 r = idx ? idx[i] : r0 + i;
   const u64 off = rec_off[r];
+  if (stream[off] == 0u) return;  // slot of an item that is not a tuple record
   const u32 m = stream[off + 1];
   const u64 tag = rec_hash(stream + off + 1, m + 1, seed);
   u64 s = (tag >> 1) & mask;
@@ -526,6 +582,7 @@ __global__ void k_rec_verify(const u32* __restrict__ stream, const u64* __restri
   if (i >= n) return;
   const u64 r = idx ? idx[i] : r0 + i;
   const u64 off = rec_off[r];
+  if (stream[off] == 0u) return;
   const u64 s = rec_slot[r];
   const u64 own = table[s].owner;
   const u32 m = stream[off + 1];
@@ -1001,6 +1058,7 @@ struct kamd_ctx {
   kamd_ec_result result{};
   bool finalized = false;
   u64 exp_words_done = 0;        // words of the explicit-set stream actually written
+  u64 tuple_bound = 0;           // upper bound of the number of tuple records in the stream (sizes the tuple table)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
   hipEvent_t ev2 = nullptr;
@@ -1085,7 +1143,7 @@ int count_tuples(kamd_ctx* c) {
   const u64 n_recs = c->host_state.n_recs;
   if (c->tuples_counted && c->recs_counted == n_recs) return 0;
   // (re)build from scratch: the table is sized for the final record count
-  c->tcap = pow2_at_least(2 * n_recs + 16);
+  c->tcap = pow2_at_least(2 * std::min<u64>(n_recs, c->tuple_bound) + 16);
   if (int rc = c->ttable.ensure(c->tcap * sizeof(TSlot), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
   if (int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot)) return rc;
@@ -1173,7 +1231,7 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   if (int rc = c->dense.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(v.n_ecs, 1) * sizeof(u32), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->exp_words_done = 0;
+  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->exp_words_done = 0; c->tuple_bound = 0;
   return push_state(c);
 }
 
@@ -1182,7 +1240,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipSetDevice(c->device));
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0;
+  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0; c->tuple_bound = 0;
   return push_state(c);
 }
 
@@ -1212,20 +1270,30 @@ int launch_align(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_i
 }
 template <bool PAIRED, bool FILTER>
 int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
-                    const AlignOut& out) {
+                    AlignOut& out) {
   constexpr int WAVES = BLOCK / 64;
   const int item_words = rec_words * (PAIRED ? 2 : 1);
-  const int raw_stride = 1 + TUPLE_CAP + (FILTER ? 4 : 0);
-  if (int rc = c->raw.ensure(n_items * (u64)raw_stride * sizeof(u32), 0, c->stream)) return rc;
+  const int stride = 2 + TUPLE_CAP + (FILTER ? 4 : 0);
+  // every item owns a fixed slot of the stream: raw record from k_match_v2, rewritten in place by k_classify
+  const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
+  if (int rc = c->stream_buf.ensure((cur_words + n_items * (u64)stride) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
+  if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
+  out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+  c->host_state.stream_words = cur_words + n_items * (u64)stride;
+  c->host_state.n_recs = cur_recs + n_items;
+  if (int rc = push_state(c)) return rc;
   const size_t lds_bytes = ((size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP + WAVES) * sizeof(u32);
   if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-resident kernel");
   const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
+  u32* slots = c->stream_buf.as<u32>() + cur_words;
+  HIPC(hipEventRecord(c->ev0, c->stream));
   HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
-                     n_items, seq_words, rec_words, c->items_per_wave, c->raw.as<u32>(), raw_stride, (DevState*)c->state.p);
+                     n_items, seq_words, rec_words, c->items_per_wave, slots, stride, (DevState*)c->state.p);
   HIPC(hipEventRecord(c->ev1, c->stream));
-  hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid_for(n_items, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->raw.as<u32>(),
-                     raw_stride, n_items, fd, out);
+  const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
+  hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
+                     fd, out);
   HIPC(hipEventRecord(c->ev2, c->stream));
   return 0;
 }
@@ -1272,8 +1340,8 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   }
   AlignOut out{c->dense.as<u32>(), c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
                c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
-  HIPC(hipEventRecord(c->ev0, c->stream));
   int rc = 0;
+  if (c->kernel_a_version != 2) HIPC(hipEventRecord(c->ev0, c->stream));
   if (c->kernel_a_version == 2) {
     if (o->paired) rc = filter ? launch_align_v2<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
                                : launch_align_v2<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
@@ -1337,6 +1405,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     c->host_state.n_explicit = 0; c->host_state.n_explicit_big = 0;
     if (int rc2 = push_state(c)) return rc2;
   }
+  c->tuple_bound = c->host_state.st_multi;
   c->tuples_counted = false; c->finalized = false;
   return 0;
 }
@@ -1348,6 +1417,7 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   s->n_processed = c->host_state.st_processed; s->n_single = c->host_state.st_single; s->n_multi = c->host_state.st_multi;
   s->n_probes = c->host_state.st_probes; s->n_bucket_reads = c->host_state.st_bucket_reads;
   s->n_distinct_tuples = c->n_distinct_tuples; s->n_stream_words = c->host_state.stream_words;
+  s->n_raw_words = c->host_state.st_raw_words;
   return 0;
 }
 
@@ -1447,6 +1517,7 @@ extern "C" int kamd_ec_tuples_replace(kamd_ctx* c, const uint32_t* d_words, uint
   if (n_words) HIPC(hipMemcpyAsync(c->stream_buf.p, d_words, n_words * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
   if (n_recs) HIPC(hipMemcpyAsync(c->rec_off.p, d_rec_off, n_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
   c->host_state.stream_words = n_words; c->host_state.n_recs = n_recs;
+  c->tuple_bound = n_recs;
   c->tuples_counted = false; c->finalized = false;
   return push_state(c);
 }
