@@ -576,20 +576,34 @@ __global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restri
   atomicMin(&table[s].owner, off);
   rec_slot[r] = s;
 }
-__global__ void k_rec_verify(const u32* __restrict__ stream, const u64* __restrict__ rec_off, const u64* __restrict__ idx,
-                             u64 r0, u64 n, TSlot* table, const u64* __restrict__ rec_slot, u64* retry, DevState* st) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 r = idx ? idx[i] : r0 + i;
-  const u64 off = rec_off[r];
-  if (stream[off] == 0u) return;
-  const u64 s = rec_slot[r];
-  const u64 own = table[s].owner;
-  const u32 m = stream[off + 1];
-  bool same = stream[own + 1] == m;
-  for (u32 j = 0; same && j < m; j++) same = stream[own + 2 + j] == stream[off + 2 + j];
-  if (same) atomicAdd(&table[s].count, (u64)stream[off]);
-  else { u64 k = atomicAdd(&st->n_retry, 1ULL); retry[k] = r; }
+// `list` receives the table slot of every distinct record exactly once (appended by the record that owns the slot;
+// one global atomic per block)
+__global__ __launch_bounds__(BLOCK) void k_rec_verify(const u32* __restrict__ stream, const u64* __restrict__ rec_off,
+                                                      const u64* __restrict__ idx, u64 r0, u64 n, TSlot* table,
+                                                      const u64* __restrict__ rec_slot, u64* retry, u64* list, DevState* st) {
+  __shared__ u32 blk_n; __shared__ u64 blk_base;
+  if (threadIdx.x == 0) blk_n = 0;
+  __syncthreads();
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  bool is_owner = false; u64 s = 0; u32 my = 0;
+  if (i < n) {
+    const u64 r = idx ? idx[i] : r0 + i;
+    const u64 off = rec_off[r];
+    if (stream[off] != 0u) {
+      s = rec_slot[r];
+      const u64 own = table[s].owner;
+      const u32 m = stream[off + 1];
+      bool same = stream[own + 1] == m;
+      for (u32 j = 0; same && j < m; j++) same = stream[own + 2 + j] == stream[off + 2 + j];
+      if (same) { atomicAdd(&table[s].count, (u64)stream[off]); is_owner = (own == off); }
+      else { u64 k = atomicAdd(&st->n_retry, 1ULL); retry[k] = r; }
+    }
+  }
+  if (is_owner) my = atomicAdd(&blk_n, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&st->n_list, (u64)blk_n);
+  __syncthreads();
+  if (is_owner) list[blk_base + my] = s;
 }
 // list the owners (one per distinct record) of a table
 __global__ void k_table_list(const TSlot* table, u64 cap, u64* list, DevState* st) {
@@ -983,22 +997,34 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
   const double* alpha = (it & 1) ? alpha1 : alpha0;
   double* next = (it & 1) ? alpha0 : alpha1;
   const int clamp = st->final_round;
-  const u64 t = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_FIN_LANES;
   const int sub = threadIdx.x & (EM_FIN_LANES - 1);
-  double acc = 0.0, al = 0.0;
-  if (t < n_tr) {
-    al = em_alpha(alpha, (u32)t, clamp);
-    for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
-  }
-#pragma unroll
-  for (int d = 1; d < EM_FIN_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
+  __shared__ int blk_ch;
+  if (threadIdx.x == 0) blk_ch = 0;
+  __syncthreads();
   int ch = 0;
-  if (t < n_tr && sub == 0) {
-    if (acc > 1e-2 && (fabs(acc - al) / acc) > 1e-2) ch = 1;        // :177-179
-    next[t] = acc;
+  // grid-stride over groups of BLOCK / EM_FIN_LANES transcripts: the convergence counter costs one atomic per block
+  for (u64 t0 = (u64)blockIdx.x * (BLOCK / EM_FIN_LANES); t0 < n_tr; t0 += (u64)gridDim.x * (BLOCK / EM_FIN_LANES)) {
+    const u64 t = t0 + threadIdx.x / EM_FIN_LANES;
+    double acc = 0.0, al = 0.0;
+    if (t < n_tr) {
+      al = em_alpha(alpha, (u32)t, clamp);
+      for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
+    }
+#pragma unroll
+    for (int d = 1; d < EM_FIN_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
+    if (t < n_tr && sub == 0) {
+      if (acc > 1e-2 && (fabs(acc - al) / acc) > 1e-2) ++ch;        // :177-179
+      next[t] = acc;
+    }
   }
-  const u64 bal = __ballot(ch);
-  if (lane_id() == 0 && bal) atomicAdd(&st->chcount, (int)__popcll(bal));
+  const u64 bal = __ballot(ch != 0);
+  // (each lane counted at most a few transcripts; sum them within the wavefront first)
+  int wsum = ch;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
+  if (lane_id() == 0 && bal) atomicAdd(&blk_ch, wsum);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_ch) atomicAdd(&st->chcount, blk_ch);
 }
 // loop control of :202-221, one thread, after the round's k_em_final (a kernel boundary orders it behind every block;
 // an in-kernel "last block" hand-off would need an agent-scope fence per block, which flushes the L2 each time)
@@ -1062,6 +1088,7 @@ struct kamd_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
   hipEvent_t ev2 = nullptr;
+  hipStream_t em_stream = nullptr;
   int kernel_a_version = 2, items_per_wave = 512;
   uint64_t last_em_iters = 0;
 };
@@ -1089,8 +1116,11 @@ int upload(kamd_ctx* c, const T* host, size_t n, const T** dev) {
 }
 
 // exact de-duplication of records [r0, r1) of a record stream into `table` (capacity cap, power of two)
-int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u64 r1, TSlot* table, u64 cap, DBuf& slot_buf) {
+int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u64 r1, TSlot* table, u64 cap, DBuf& slot_buf,
+                  u64* list) {
   const u64 n = r1 - r0;
+  c->host_state.n_list = 0;
+  HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_list, &c->host_state.n_list, sizeof(u64), hipMemcpyHostToDevice, c->stream));
   if (n == 0) return 0;
   if (int rc = slot_buf.ensure(r1 * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = c->retry.ensure(2 * n * sizeof(u64), 0, c->stream)) return rc;
@@ -1104,7 +1134,7 @@ int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u6
     hipLaunchKernelGGL(k_rec_insert, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
                        table, cap - 1, seed, slot_buf.as<u64>());
     hipLaunchKernelGGL(k_rec_verify, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
-                       table, slot_buf.as<u64>(), retry_b, (DevState*)c->state.p);
+                       table, slot_buf.as<u64>(), retry_b, list, (DevState*)c->state.p);
     HIPC(hipGetLastError());
     if (int rc = sync_state(c)) return rc;
     count = c->host_state.n_retry;
@@ -1146,8 +1176,10 @@ int count_tuples(kamd_ctx* c) {
   c->tcap = pow2_at_least(2 * std::min<u64>(n_recs, c->tuple_bound) + 16);
   if (int rc = c->ttable.ensure(c->tcap * sizeof(TSlot), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
-  if (int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot)) return rc;
-  if (int rc = list_table(c, c->ttable.as<TSlot>(), c->tcap, c->list, &c->n_distinct_tuples)) return rc;
+  if (int rc = c->list.ensure((std::min<u64>(n_recs, c->tuple_bound) + 1) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot,
+                             c->list.as<u64>())) return rc;
+  c->n_distinct_tuples = c->host_state.n_list;
   c->tuples_counted = true; c->recs_counted = n_recs;
   return 0;
 }
@@ -1185,6 +1217,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->em_stream) (void)hipStreamDestroy(c->em_stream);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
@@ -1432,7 +1465,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   const int rec_words = (int)kamd_packed_record_words(max_len);
   u64 found = n_used ? *n_used : 0, done = 0;  // continues a sample started on earlier batches
   const int cap_small = 64;
-  u64 chunk = 131072;
+  u64 chunk = 1048576;
   DBuf tl, card, scratch, items;
   std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
   int rc = 0;
@@ -1594,9 +1627,11 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   c->ccap = pow2_at_least(2 * n_cand + 16);
   if (int rc = c->ctable.ensure(c->ccap * sizeof(TSlot), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->ccap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ctable.as<TSlot>(), c->ccap);
-  if (int rc = dedup_records(c, c->cand.as<u32>(), c->cand_off.as<u64>(), 0, n_cand, c->ctable.as<TSlot>(), c->ccap, c->cand_slot)) return rc;
+  if (int rc = c->clist.ensure((n_cand + 1) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = dedup_records(c, c->cand.as<u32>(), c->cand_off.as<u64>(), 0, n_cand, c->ctable.as<TSlot>(), c->ccap, c->cand_slot,
+                             c->clist.as<u64>())) return rc;
   u64 n_final = 0;
-  if (int rc = list_table(c, c->ctable.as<TSlot>(), c->ccap, c->clist, &n_final)) return rc;
+  n_final = c->host_state.n_list;
   // CSR
   if (int rc = c->sizes.ensure((n_final + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->ec_off.ensure((n_final + 2) * sizeof(u64), 0, c->stream)) return rc;
@@ -1695,24 +1730,46 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   const int chunk = 64;
   const unsigned grid_rows = grid_for(std::max<u64>(n_ecs, 1) * EM_ROW_LANES, BLOCK);
   const unsigned grid_seg = grid_for(std::max<u64>(n_seg, 1) * EM_SEG_LANES, BLOCK);
-  const unsigned grid_fin = grid_for(T * EM_FIN_LANES, BLOCK);
-  while (!hs.done) {
+  const unsigned grid_fin = (unsigned)std::min<u64>(grid_for(T * EM_FIN_LANES, BLOCK), 1024);
+  // The launch-bound inner loop is captured once as a hipGraph of `chunk` rounds (4 kernels each) on a private stream
+  // and replayed until the device-side state says done; all loop state lives in device memory, so every replay is
+  // the same graph.  KAMD_EM_GRAPH=0 falls back to plain launches.
+  auto enqueue_rounds = [&](hipStream_t s) {
     for (int it = 0; it < chunk; it++) {
-      hipLaunchKernelGGL(k_em_rows, dim3(grid_rows), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, d_counts, (u64)n_ecs,
+      hipLaunchKernelGGL(k_em_rows, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, (u64)n_ecs,
                          c->em_wrow.as<double>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_cn.as<double>(),
                          (const EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_seg, dim3(grid_seg), dim3(BLOCK), 0, c->stream, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(),
+      hipLaunchKernelGGL(k_em_seg, dim3(grid_seg), dim3(BLOCK), 0, s, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(),
                          c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_colw.as<double>(), d_counts,
                          c->em_cn.as<double>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_partial.as<double>(),
                          (const EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, c->stream, c->em_segoff.as<u64>(), c->em_partial.as<double>(), T,
+      hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, s, c->em_segoff.as<u64>(), c->em_partial.as<double>(), T,
                          c->em_alpha.as<double>(), c->em_next.as<double>(), (EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, c->stream, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds);
+      hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, s, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds);
     }
-    HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+  };
+  const char* eg = getenv("KAMD_EM_GRAPH");
+  bool use_graph = !(eg && atoi(eg) == 0);
+  hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+  hipStream_t es = c->stream;
+  if (use_graph) {
+    if (!c->em_stream) HIPC(hipStreamCreateWithFlags(&c->em_stream, hipStreamNonBlocking));
+    es = c->em_stream;
+    HIPC(hipEventRecord(c->ev2, c->stream));           // the private stream starts after the preparation kernels
+    HIPC(hipStreamWaitEvent(es, c->ev2, 0));
+    HIPC(hipStreamBeginCapture(es, hipStreamCaptureModeThreadLocal));
+    enqueue_rounds(es);
+    HIPC(hipStreamEndCapture(es, &graph));
+    HIPC(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
   }
+  while (!hs.done) {
+    if (use_graph) HIPC(hipGraphLaunch(gexec, es)); else enqueue_rounds(es);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, es));
+    HIPC(hipStreamSynchronize(es));
+  }
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipEventSynchronize(c->ev1));
   HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
