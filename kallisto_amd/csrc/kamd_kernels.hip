@@ -882,60 +882,69 @@ struct EmState {
   int done;
   int rounds;       // i at exit ("ran for i rounds")
 };
-constexpr u32 EM_SINGLE = 0x80000000u;
-
-__device__ __forceinline__ double em_alpha(const double* a, u32 t, int clamp) {
-  double v = a[t];
-  return (clamp && v < 1e-7 / 10.0) ? 0.0 : v;  // alpha_limit/10 (:217-219)
+// Algebra used by the kernels.  With a_t = alpha_t / eff_len_t the reference's row pass
+//     denom_e = sum_t alpha_t * (wc_e / eff_t) = wc_e * S_e,  S_e = sum_t a_t          (:152-154, weights.cpp:236)
+// and its update  (w_et * alpha_t) * (count_e / denom_e) = a_t * g_e,  g_e = count_e / S_e   (:161-164; wc_e cancels,
+// which is why bootstraps may keep the original weights), so that
+//     next_t = count(singleton row of t) + a_t * sum_{multi rows e containing t} g_e .
+// Per nnz this streams 4 B (id) + gathers 8 B in each pass instead of 20 B; the FP64 rounding differs from the
+// reference's operation order at the 1e-16 level (tolerance of the path: 1e-4), the round count is unchanged.
+__device__ __forceinline__ double em_clamped(const double* alpha, const double* a, u32 t, int clamp) {
+  if (clamp && alpha[t] < 1e-7 / 10.0) return 0.0;  // alpha_limit/10 (:217-219), applied on read in the final round
+  return a[t];
 }
 
-// per-nnz weights w[e,t] = weight_counts[e] / eff_lens[t] (calc_weights, src/weights.cpp:220-246) + column counts
-__global__ void k_em_prepare(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ wcounts,
-                             u64 n_ecs, const double* __restrict__ eff, double* w_row, u32* col_cnt) {
-  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_ecs) return;
-  const double wc = (double)wcounts[e];
-  for (u64 j = ec_off[e]; j < ec_off[e + 1]; j++) {
-    const u32 t = ec_ids[j];
-    w_row[j] = wc / eff[t];
-    atomicAdd(&col_cnt[t], 1u);
-  }
-}
-__global__ void k_em_transpose(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs,
-                               const double* __restrict__ w_row, const u64* __restrict__ col_off, u32* col_fill, u32* col_row,
-                               double* col_w) {
+// column counts of the multi-transcript rows + the singleton row count of every transcript
+__global__ void k_em_prepare(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts,
+                             u64 n_ecs, u32* col_cnt, double* single) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_ecs) return;
   const u64 a = ec_off[e], b = ec_off[e + 1];
-  const u32 tag = (b - a == 1) ? EM_SINGLE : 0u;
+  if (b - a == 1) { single[ec_ids[a]] = (double)counts[e]; return; }  // :119-123 (a transcript has at most one singleton set)
+  for (u64 j = a; j < b; j++) atomicAdd(&col_cnt[ec_ids[j]], 1u);
+}
+__global__ void k_em_transpose(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs,
+                               const u64* __restrict__ col_off, u32* col_fill, u32* col_row) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  if (b - a == 1) return;
   for (u64 j = a; j < b; j++) {
     const u32 t = ec_ids[j];
-    const u64 pos = col_off[t] + atomicAdd(&col_fill[t], 1u);
-    col_row[pos] = (u32)e | tag;
-    col_w[pos] = w_row[j];
+    col_row[col_off[t] + atomicAdd(&col_fill[t], 1u)] = (u32)e;
   }
+}
+__global__ void k_em_init(u64 n_tr, const double* __restrict__ eff, double* alpha, double* a) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_tr) { const double al = 1.0 / (double)n_tr; alpha[t] = al; a[t] = al / eff[t]; }  // :38
 }
 
 constexpr int EM_ROW_LANES = 4;
 __global__ __launch_bounds__(BLOCK) void k_em_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids,
-                                                   const u32* __restrict__ counts, u64 n_ecs, const double* __restrict__ w_row,
+                                                   const u32* __restrict__ counts, const u32* __restrict__ wcounts, u64 n_ecs,
                                                    const double* __restrict__ alpha0, const double* __restrict__ alpha1,
-                                                   double* __restrict__ cn, const EmState* st) {
+                                                   const double* __restrict__ a0, const double* __restrict__ a1,
+                                                   double* __restrict__ g, const EmState* st) {
   if (st->done) return;
-  const double* alpha = (st->iter & 1) ? alpha1 : alpha0;
+  const int odd = st->iter & 1;
+  const double* alpha = odd ? alpha1 : alpha0;
+  const double* av = odd ? a1 : a0;
   const int clamp = st->final_round;
-  const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_ROW_LANES;
+  const u64 e = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_ROW_LANES;
   const int sub = threadIdx.x & (EM_ROW_LANES - 1);
-  double denom = 0.0;
+  double S = 0.0;
   u64 a = 0, b = 0;
-  if (g < n_ecs) { a = ec_off[g]; b = ec_off[g + 1]; }
-  for (u64 j = a + sub; j < b; j += EM_ROW_LANES) denom += em_alpha(alpha, ec_ids[j], clamp) * w_row[j];  // :152-154
+  if (e < n_ecs) { a = ec_off[e]; b = ec_off[e + 1]; }
+  if (b - a > 1) {
+    if (clamp) for (u64 j = a + sub; j < b; j += EM_ROW_LANES) S += em_clamped(alpha, av, ec_ids[j], 1);
+    else for (u64 j = a + sub; j < b; j += EM_ROW_LANES) S += av[ec_ids[j]];
+  }
 #pragma unroll
-  for (int d = 1; d < EM_ROW_LANES; d <<= 1) denom += __shfl_xor(denom, d, 64);
-  if (g < n_ecs && sub == 0) {
-    const u32 cnt = counts[g];
-    // rows that the reference skips (count 0, or denom < TOLERANCE = denorm_min, :133-135,:156-158) contribute nothing
-    cn[g] = (b - a == 1 || cnt == 0 || denom < 4.9406564584124654e-324) ? 0.0 : cnt / denom;  // countNorm (:161)
+  for (int d = 1; d < EM_ROW_LANES; d <<= 1) S += __shfl_xor(S, d, 64);
+  if (e < n_ecs && sub == 0) {
+    const u32 cnt = counts[e];
+    // rows the reference skips contribute nothing: count 0 (:133-135) or denom = wc*S below denorm_min, i.e. zero (:156-158)
+    g[e] = (b - a == 1 || cnt == 0 || (double)wcounts[e] * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
   }
 }
 
@@ -956,46 +965,37 @@ __global__ void k_em_segsetup(const u64* __restrict__ col_off, const u64* __rest
 }
 __global__ __launch_bounds__(BLOCK) void k_em_seg(const u64* __restrict__ col_off, const u64* __restrict__ seg_off,
                                                   const u32* __restrict__ seg_t, u64 n_seg, const u32* __restrict__ col_row,
-                                                  const double* __restrict__ col_w, const u32* __restrict__ counts,
-                                                  const double* __restrict__ cn, const double* __restrict__ alpha0,
-                                                  const double* __restrict__ alpha1, double* __restrict__ partial,
-                                                  const EmState* st) {
+                                                  const double* __restrict__ g, double* __restrict__ partial, const EmState* st) {
   if (st->done) return;
-  const double* alpha = (st->iter & 1) ? alpha1 : alpha0;
-  const int clamp = st->final_round;
   const u64 sidx = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_SEG_LANES;
   const int sub = threadIdx.x & (EM_SEG_LANES - 1);
   double acc = 0.0;
   if (sidx < n_seg) {
     const u32 t = seg_t[sidx];
-    const double al = em_alpha(alpha, t, clamp);
     const u64 begin = col_off[t] + (sidx - seg_off[t]) * EM_SEG;
     const u64 end = min(col_off[t + 1], begin + EM_SEG);
-    u32 r[EM_SEG / EM_SEG_LANES]; double w[EM_SEG / EM_SEG_LANES];
+    u32 r[EM_SEG / EM_SEG_LANES];
 #pragma unroll
     for (int i = 0; i < EM_SEG / EM_SEG_LANES; i++) {
       const u64 j = begin + sub + (u64)i * EM_SEG_LANES;
-      const bool in = j < end;
-      r[i] = in ? col_row[j] : EM_SINGLE;  // a padding lane acts as a singleton row with ...
-      w[i] = in ? col_w[j] : -1.0;         // ... a negative weight marker (skipped below)
+      r[i] = j < end ? col_row[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int i = 0; i < EM_SEG / EM_SEG_LANES; i++) {
-      if (w[i] < 0.0) continue;
-      if (r[i] & EM_SINGLE) acc += (double)counts[r[i] & ~EM_SINGLE];  // :119-123
-      else acc += (w[i] * al) * cn[r[i]];                                // :162-164
-    }
+    for (int i = 0; i < EM_SEG / EM_SEG_LANES; i++) if (r[i] != 0xFFFFFFFFu) acc += g[r[i]];
   }
 #pragma unroll
   for (int d = 1; d < EM_SEG_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
   if (sidx < n_seg && sub == 0) partial[sidx] = acc;
 }
 __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_off, const double* __restrict__ partial,
-                                                    u64 n_tr, double* alpha0, double* alpha1, EmState* st) {
+                                                    const double* __restrict__ single, const double* __restrict__ eff, u64 n_tr,
+                                                    double* alpha0, double* alpha1, double* a0, double* a1, EmState* st) {
   if (st->done) return;
-  const int it = st->iter;
-  const double* alpha = (it & 1) ? alpha1 : alpha0;
-  double* next = (it & 1) ? alpha0 : alpha1;
+  const int it = st->iter, odd = it & 1;
+  const double* alpha = odd ? alpha1 : alpha0;
+  const double* av = odd ? a1 : a0;
+  double* next = odd ? alpha0 : alpha1;
+  double* anext = odd ? a0 : a1;
   const int clamp = st->final_round;
   const int sub = threadIdx.x & (EM_FIN_LANES - 1);
   __shared__ int blk_ch;
@@ -1005,20 +1005,21 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
   // grid-stride over groups of BLOCK / EM_FIN_LANES transcripts: the convergence counter costs one atomic per block
   for (u64 t0 = (u64)blockIdx.x * (BLOCK / EM_FIN_LANES); t0 < n_tr; t0 += (u64)gridDim.x * (BLOCK / EM_FIN_LANES)) {
     const u64 t = t0 + threadIdx.x / EM_FIN_LANES;
-    double acc = 0.0, al = 0.0;
-    if (t < n_tr) {
-      al = em_alpha(alpha, (u32)t, clamp);
-      for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
-    }
+    double acc = 0.0;
+    if (t < n_tr) for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
 #pragma unroll
     for (int d = 1; d < EM_FIN_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
     if (t < n_tr && sub == 0) {
-      if (acc > 1e-2 && (fabs(acc - al) / acc) > 1e-2) ++ch;        // :177-179
-      next[t] = acc;
+      double al = alpha[t];
+      if (clamp && al < 1e-7 / 10.0) al = 0.0;
+      const double at = clamp ? em_clamped(alpha, av, (u32)t, 1) : av[t];
+      const double nx = single[t] + at * acc;
+      if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ++ch;          // :177-179
+      next[t] = nx;
+      anext[t] = nx / eff[t];
     }
   }
   const u64 bal = __ballot(ch != 0);
-  // (each lane counted at most a few transcripts; sum them within the wavefront first)
   int wsum = ch;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
@@ -1075,7 +1076,7 @@ struct kamd_ctx {
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw;
   DBuf ec_off, ec_ids, ec_counts;
-  DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial;
+  DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
   u64 n_distinct_tuples = 0;
@@ -1224,7 +1225,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
-                  &c->em_segoff, &c->em_segt, &c->em_partial})
+                  &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single})
     b->release();
   delete c;
 }
@@ -1691,10 +1692,9 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
     HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
   }
-  for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_eff}) if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
+  for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_eff, &c->em_a0, &c->em_a1, &c->em_single})
+    if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
   if (int rc = c->em_state.ensure(sizeof(EmState), 0, c->stream)) return rc;
-  if (int rc = c->em_wrow.ensure((nnz + 1) * sizeof(double), 0, c->stream)) return rc;
-  if (int rc = c->em_colw.ensure((nnz + 1) * sizeof(double), 0, c->stream)) return rc;
   if (int rc = c->em_colrow.ensure((nnz + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->em_cn.ensure((n_ecs + 1) * sizeof(double), 0, c->stream)) return rc;
   if (int rc = c->em_colcnt.ensure(3 * (T + 1) * sizeof(u32), 0, c->stream)) return rc;
@@ -1704,16 +1704,17 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   u32* col_fill = col_cnt + (T + 1);
   HIPC(hipMemcpyAsync(c->em_eff.p, eff_lens, T * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPC(hipMemsetAsync(col_cnt, 0, 2 * (T + 1) * sizeof(u32), c->stream));
+  HIPC(hipMemsetAsync(c->em_single.p, 0, T * sizeof(double), c->stream));
   HIPC(hipMemsetAsync(c->em_state.p, 0, sizeof(EmState), c->stream));
   HIPC(hipEventRecord(c->ev0, c->stream));
-  // transposed (transcript-major) copy of the EC x transcript matrix, built once per run
+  // transposed (transcript-major) structure of the multi-transcript rows, built once per run
   if (n_ecs) hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
-                                d_wcounts, (u64)n_ecs, c->em_eff.as<double>(), c->em_wrow.as<double>(), col_cnt);
+                                d_counts, (u64)n_ecs, col_cnt, c->em_single.as<double>());
   if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
   if (n_ecs) hipLaunchKernelGGL(k_em_transpose, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
-                                (u64)n_ecs, c->em_wrow.as<double>(), c->em_coloff.as<u64>(), col_fill, c->em_colrow.as<u32>(),
-                                c->em_colw.as<double>());
-  hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_alpha.as<double>(), T, 1.0 / (double)T);
+                                (u64)n_ecs, c->em_coloff.as<u64>(), col_fill, c->em_colrow.as<u32>());
+  hipLaunchKernelGGL(k_em_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_eff.as<double>(), c->em_alpha.as<double>(),
+                     c->em_a0.as<double>());
   // column segments
   u32* nseg = col_cnt + 2 * (T + 1);
   hipLaunchKernelGGL(k_em_nseg, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, col_cnt, T, nseg);
@@ -1736,15 +1737,15 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   // the same graph.  KAMD_EM_GRAPH=0 falls back to plain launches.
   auto enqueue_rounds = [&](hipStream_t s) {
     for (int it = 0; it < chunk; it++) {
-      hipLaunchKernelGGL(k_em_rows, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, (u64)n_ecs,
-                         c->em_wrow.as<double>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_cn.as<double>(),
-                         (const EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_rows, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, (u64)n_ecs,
+                         c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(), c->em_a1.as<double>(),
+                         c->em_cn.as<double>(), (const EmState*)c->em_state.p);
       hipLaunchKernelGGL(k_em_seg, dim3(grid_seg), dim3(BLOCK), 0, s, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(),
-                         c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_colw.as<double>(), d_counts,
-                         c->em_cn.as<double>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_partial.as<double>(),
+                         c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_cn.as<double>(), c->em_partial.as<double>(),
                          (const EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, s, c->em_segoff.as<u64>(), c->em_partial.as<double>(), T,
-                         c->em_alpha.as<double>(), c->em_next.as<double>(), (EmState*)c->em_state.p);
+      hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, s, c->em_segoff.as<u64>(), c->em_partial.as<double>(),
+                         c->em_single.as<double>(), c->em_eff.as<double>(), T, c->em_alpha.as<double>(), c->em_next.as<double>(),
+                         c->em_a0.as<double>(), c->em_a1.as<double>(), (EmState*)c->em_state.p);
       hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, s, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds);
     }
   };
