@@ -228,6 +228,16 @@ def main():
             alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_single"] + 4 * st["n_stream_words"] + 8 * st["n_multi"]
         a_ms = float(np.mean(align_ms))
         achieved = alg_bytes / (a_ms * 1e-3) / 1e9
+        # EM round: rows pass nnz_multi*(4 id + 8 gather) + per row (8 off + 4 count + 4 weight count +
+        # 8 g); column pass nnz_multi*(4 row + 8 gather) + per segment (4 + 8 + 8); final per transcript 64 B + 8 per segment
+        T = int(index.num_targets)
+        em_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 24 + pr["em_nseg"] * 28 + T * 64
+        em_round_ms = float(np.mean(em_ms)) / max(int(em_iters[-1]), 1)
+        em_ach = em_bytes / (em_round_ms * 1e-3) / 1e9
+        em_roof = {"kernel": "EM round (k_em_rows + k_em_seg + k_em_final)", "bound": "hbm", "achieved": round(em_ach, 2),
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(em_ach / HBM_PEAK_GBS, 5), "traffic": None,
+                   "algorithmic_bytes_per_launch": int(em_bytes), "launch_ms": round(em_round_ms, 5),
+                   "rounds": int(em_iters[-1]), "nnz": pr["em_nnz"], "nnz_multi": pr["em_nnz_multi"], "rows": pr["em_necs"]}
         out = {
             "metric": "M paired-end reads/sec quantified (human txome index)",
             "value": round(total_pairs / elapsed / 1e6, 4),
@@ -253,18 +263,22 @@ def main():
                          "single_set_pairs": st["n_single"], "multi_set_pairs": st["n_multi"],
                          "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
                          "em_rounds": res.em_rounds},
-            "roofline": {"kernel": "k_match_v2" if pr["kernel_a_version"] == 2 else "k_pseudoalign", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
-                         "bucket_line_bytes_per_launch": int(64 * st["n_bucket_reads"])},
+            # dominant kernel by time: one EM round = k_em_rows + k_em_seg + k_em_final (+ one-thread control)
+            "roofline": em_roof,
+            "roofline_kernel_a": {"kernel": "k_match_v2" if pr["kernel_a_version"] == 2 else "k_pseudoalign", "bound": "hbm",
+                                  "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                                  "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
+                                  "bucket_line_bytes_per_launch": int(64 * st["n_bucket_reads"])},
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
                 tj = json.load(open(prof))
                 if tj.get("pairs") == n and tj.get("workload") == args.workload and tj.get("genes") == genes:
-                    out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = tj.get("source")
+                    out["roofline"]["traffic"] = tj.get("em_round_hbm_bytes")
+                    out["roofline_kernel_a"]["traffic"] = tj.get("kernel_a_hbm_bytes")
+                    out["roofline"]["traffic_source"] = out["roofline_kernel_a"]["traffic_source"] = tj.get("source")
             except Exception:
                 pass
     # ---- CPU baseline (rank 0, N=1 only) + parity of the GPU path against it on the same sample ----
@@ -276,8 +290,11 @@ def main():
             cb = cpu_reference_baseline(idx_path, sample[0], sample[1], threads)
             ctx.reset()
             sres = ka.quant(ctx, opts, [(words[:k * 2 * rec], lens[:2 * k], k, L)], download_ecs=True)
-            big = cb["est_counts"] > 1e-7
-            rel = float(np.max(np.abs(sres.est_counts[big] - cb["est_counts"][big]) / cb["est_counts"][big])) if big.any() else 0.0
+            # vs the reference CLI: pseudoaligned / unique read counts must be identical.  est_counts are only compared
+            # for transcripts >= 1000 bp: at -t>1 the reference's fragment-length sample is thread-schedule dependent,
+            # which moves the effective length of short transcripts.
+            long_tr = (index.target_lens >= 1000) & (cb["est_counts"] > 1.0)
+            rel = float(np.max(np.abs(sres.est_counts[long_tr] - cb["est_counts"][long_tr]) / cb["est_counts"][long_tr])) if long_tr.any() else 0.0
             out["cpu_baseline"] = {"value": round(k / cb["seconds"] / 1e6, 4), "unit": "M read pairs/s", "cores": threads,
                                    "kind": "reference",
                                    "sample": f"first {k} pairs of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
@@ -286,8 +303,30 @@ def main():
             out["parity_check"] = {"sample_pairs": k, "n_pseudoaligned_gpu": sres.n_pseudoaligned,
                                    "n_pseudoaligned_ref": cb["n_pseudoaligned"], "n_unique_gpu": sres.n_unique,
                                    "n_unique_ref": cb["n_unique"],
-                                   "est_counts_max_rel_err_printed_precision": rel,
+                                   "est_counts_max_rel_err_vs_ref_cli_len_ge_1000": rel,
                                    "ok": bool(sres.n_pseudoaligned == cb["n_pseudoaligned"] and sres.n_unique == cb["n_unique"])}
+            # vs the oracle (deterministic -t 1 semantics) on a sub-sample: EC multiset bit-exact, est_counts 1e-4
+            try:
+                from oracle import oracle as O
+                ks = min(k, 200_000)
+                oix = O.Index(idx_path)
+                buf, off, ln = O.pack_read_matrix(sample[0][:ks], sample[1][:ks])
+                ores = O.process_reads(oix, O.Opts(1, 0.0, 0.0, 0, 0), buf, off, ln)
+                ctx.reset()
+                gres = ka.quant(ctx, opts, [(words[:ks * 2 * rec], lens[:2 * ks], ks, L)], download_ecs=True)
+                eff_o, _ = O.eff_lens(oix.target_lens, O.mean_frag_lens_trunc(ores.flens))
+                a_o, _, r_o = O.em_run(ores.ec_off, ores.ec_ids, ores.counts, eff_o, oix.num_targets)
+                m = a_o > 1e-7
+                out["parity_check"]["oracle"] = {
+                    "sample_pairs": ks, "ec_multiset_equal": bool(gres.ecs.multiset() == ores.multiset()),
+                    "flens_equal": bool(np.array_equal(gres.flens, ores.flens)), "eff_lens_equal": bool(np.array_equal(gres.eff_lens, eff_o)),
+                    "em_rounds": [gres.em_rounds, r_o],
+                    "est_counts_max_rel_err": float(np.max(np.abs(gres.est_counts[m] - a_o[m]) / a_o[m])) if m.any() else 0.0,
+                    "zero_pattern_equal": bool(np.array_equal(gres.est_counts == 0, a_o == 0))}
+                out["parity_check"]["ok"] = bool(out["parity_check"]["ok"] and out["parity_check"]["oracle"]["ec_multiset_equal"]
+                                                 and out["parity_check"]["oracle"]["flens_equal"])
+            except Exception as e:
+                out["parity_check"]["oracle"] = {"error": str(e)}
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "M read pairs/s", "cores": threads, "kind": "reference",
                                    "sample": f"failed: {e}"}

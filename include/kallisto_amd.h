@@ -129,8 +129,17 @@ typedef struct {
   uint64_t last_em_iters;      /* EM rounds executed by it */
   float last_classify_ms;      /* k_classify of the same call (0 for the block-staged kernel, which classifies inline) */
   int32_t kernel_a_version;    /* 2 = k_match_v2 + k_classify (default), 1 = k_pseudoalign (env KAMD_KERNEL_A=1) */
+  uint64_t last_em_nnz;        /* shape of the EM problem of the last kamd_em_run: nnz of the EC x transcript matrix, */
+  uint64_t last_em_nnz_multi;  /* nnz in multi-transcript rows, */
+  uint64_t last_em_nseg;       /* column segments, */
+  uint64_t last_em_necs;       /* rows */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
+
+/* diagnostic: rate of dependent random 64-byte bucket reads of the uploaded k-mer table at a given launch shape -- the
+ * practical ceiling of kernel A's probe stream (profiles/README.md) */
+int kamd_debug_random_lines(kamd_ctx*, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, double* gbytes_per_s,
+                            double* mlines_per_s);
 
 /* ---- EC state exchange (multi-GPU; one process per GPU, the caller runs the collectives) ----
  * The EC state is (a) a dense count vector over index transcript sets and (b) a list of (tuple of index set ids,

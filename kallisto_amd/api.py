@@ -48,7 +48,8 @@ class _Stats(C.Structure):
 
 class _Profile(C.Structure):
     _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64),
-                ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32)]
+                ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32), ("last_em_nnz", C.c_uint64),
+                ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64)]
 
 
 class _EcResult(C.Structure):
@@ -78,6 +79,7 @@ _SYMBOLS = {
                                       C.POINTER(C.c_uint64)]),
     "kamd_align_stats_get": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "kamd_profile_get": (C.c_int, [C.c_void_p, C.POINTER(_Profile)]),
+    "kamd_debug_random_lines": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "kamd_ec_dense_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -284,11 +286,18 @@ class Context:
         _check(load_library().kamd_align_stats_get(self._h, C.byref(s)), "kamd_align_stats_get")
         return {n: int(getattr(s, n)) for n, _ in _Stats._fields_}
 
+    def random_lines(self, n_blocks: int, block_threads: int = 256, iters: int = 256):
+        g, m = C.c_double(0), C.c_double(0)
+        _check(load_library().kamd_debug_random_lines(self._h, n_blocks, block_threads, iters, C.byref(g), C.byref(m)), "kamd_debug_random_lines")
+        return g.value, m.value
+
     def profile(self) -> dict:
         p = _Profile()
         _check(load_library().kamd_profile_get(self._h, C.byref(p)), "kamd_profile_get")
         return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters),
-                "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version)}
+                "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version),
+                "em_nnz": int(p.last_em_nnz), "em_nnz_multi": int(p.last_em_nnz_multi), "em_nseg": int(p.last_em_nseg),
+                "em_necs": int(p.last_em_necs)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

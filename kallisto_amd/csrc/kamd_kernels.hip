@@ -273,8 +273,8 @@ constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
 
 template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
-                                                    u64 n_items, int seq_words, int rec_words, int items_per_wave, u32* raw,
-                                                    int raw_stride, DevState* st) {
+                                                    u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
+                                                    u32* raw, int raw_stride, DevState* st) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   constexpr int WAVES = BLOCK / 64;
   const int item_words = rec_words * (PAIRED ? 2 : 1);
@@ -304,7 +304,11 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
     u32 stage[STAGE_WORDS];
     bool loading = false;
     const u32* src = nullptr;
-    if (!have && !exhausted) {
+    // refills are batched: the (wave-uniform) fetch path runs only when at least REFILL_MIN lanes are free or nothing is
+    // left to probe, so its ~40 load/store instructions are not paid on every iteration
+    const u64 idle_mask = __ballot(!have && !exhausted);
+    const bool do_refill = idle_mask != 0ULL && (__popcll(idle_mask) >= refill_min || __ballot(have) == 0ULL);
+    if (do_refill && !have && !exhausted) {
       if (!first) my_idx = atomicAdd(&cursor[wv], 1u);
       first = false;
       if (my_idx >= chunk_n) exhausted = true;
@@ -1090,8 +1094,8 @@ struct kamd_ctx {
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
   hipEvent_t ev2 = nullptr;
   hipStream_t em_stream = nullptr;
-  int kernel_a_version = 2, items_per_wave = 512;
-  uint64_t last_em_iters = 0;
+  int kernel_a_version = 2, items_per_wave = 512, refill_min = 8;
+  uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
 };
 
 namespace {
@@ -1207,6 +1211,7 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
   if (const char* e = getenv("KAMD_KERNEL_A")) c->kernel_a_version = atoi(e) == 1 ? 1 : 2;   // 1 = block-staged kernel, 2 = one probe per iteration
   if (const char* e = getenv("KAMD_ITEMS_PER_WAVE")) c->items_per_wave = std::max(64, atoi(e));
+  if (const char* e = getenv("KAMD_REFILL_MIN")) c->refill_min = std::min(64, std::max(1, atoi(e)));
   *out = c;
   return 0;
 }
@@ -1323,7 +1328,7 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   HIPC(hipEventRecord(c->ev0, c->stream));
   HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
-                     n_items, seq_words, rec_words, c->items_per_wave, slots, stride, (DevState*)c->state.p);
+                     n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
   HIPC(hipEventRecord(c->ev1, c->stream));
   const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
   hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
@@ -1722,6 +1727,9 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   u64 n_seg = 0;
   HIPC(hipMemcpyAsync(&n_seg, c->em_segoff.as<u64>() + T, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  u64 nnz_multi = 0;
+  HIPC(hipMemcpy(&nnz_multi, c->em_coloff.as<u64>() + T, sizeof(u64), hipMemcpyDeviceToHost));
+  c->last_em_nnz = nnz; c->last_em_nnz_multi = nnz_multi; c->last_em_nseg = n_seg; c->last_em_necs = n_ecs;
   if (int rc = c->em_segt.ensure((n_seg + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->em_partial.ensure((n_seg + 1) * sizeof(double), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_em_segsetup, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(), T,
@@ -1788,10 +1796,48 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   return 0;
 }
 
+// ---- diagnostics: ceiling of the k-mer table's access pattern ---------------------------------------------------------
+// Every lane follows a dependent chain of random 64-byte bucket reads (4 x 16 B, the probe's loads) with nothing in
+// between: the rate this reaches at a given occupancy is the practical roofline of kernel A's probe stream.
+namespace {
+__global__ void k_random_lines(const u64* __restrict__ table, u64 n_buckets, int iters, u64* sink) {
+  const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 x = kamd::mix64(gid + 1);
+  u64 acc = 0;
+  for (int i = 0; i < iters; i++) {
+    const u64 b = __umul64hi(x, n_buckets);
+    const ulonglong2* bp = (const ulonglong2*)(table + b * 8);
+    const ulonglong2 s0 = bp[0], s1 = bp[1], s2 = bp[2], s3 = bp[3];
+    const u64 v = s0.x ^ s0.y ^ s1.x ^ s1.y ^ s2.x ^ s2.y ^ s3.x ^ s3.y;
+    acc ^= v;
+    x = kamd::mix64(x ^ v);  // the next address depends on the loaded line
+  }
+  if (acc == 0x1234567ULL) sink[0] = acc;
+}
+}  // namespace
+extern "C" int kamd_debug_random_lines(kamd_ctx* c, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, double* gbytes_per_s,
+                                       double* mlines_per_s) {
+  if (!c || !c->has_index) return kamd::fail(-1, "kamd_debug_random_lines: no context / index");
+  HIPC(hipSetDevice(c->device));
+  if (int rc = c->sizes.ensure(64, 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_random_lines, dim3(n_blocks), dim3(block_threads), 0, c->stream, c->ix.table, c->ix.n_buckets, 8, c->sizes.as<u64>());
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(k_random_lines, dim3(n_blocks), dim3(block_threads), 0, c->stream, c->ix.table, c->ix.n_buckets, (int)iters, c->sizes.as<u64>());
+  HIPC(hipEventRecord(c->ev1, c->stream));
+  HIPC(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  const double lines = (double)n_blocks * block_threads * iters;
+  if (mlines_per_s) *mlines_per_s = lines / (ms * 1e-3) / 1e6;
+  if (gbytes_per_s) *gbytes_per_s = lines * 64.0 / (ms * 1e-3) / 1e9;
+  return 0;
+}
+
 extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   if (!c || !p) return kamd::fail(-1, "kamd_profile_get: null argument");
   p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
   p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
+  p->last_em_nnz = c->last_em_nnz; p->last_em_nnz_multi = c->last_em_nnz_multi; p->last_em_nseg = c->last_em_nseg; p->last_em_necs = c->last_em_necs;
   return 0;
 }
 
