@@ -662,55 +662,73 @@ __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, u32* 
 //     smallest set per step, membership by binary search in the others, survivors compacted with ballot + popcount
 //     prefix over the group's 16 bits of the wavefront mask
 constexpr int RES_LANES = 16;
+constexpr int RES_GROUPS = BLOCK / RES_LANES;
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
                                                    const u64* list, u64 n, u32* cand, u64* cand_off, DevState* st) {
+  __shared__ u32 grp_total[RES_GROUPS];
+  __shared__ u64 grp_off[RES_GROUPS];
+  __shared__ u64 grp_rec[RES_GROUPS];
   const u64 gid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / RES_LANES;
-  if (gid >= n) return;
+  const int grp = threadIdx.x / RES_LANES;
+  const bool valid = gid < n;
   const int lane = lane_id();
   const int sub = lane & (RES_LANES - 1);
   const int gsh = lane & ~(RES_LANES - 1);  // bit position of this group inside the wavefront mask
-  const TSlot sl = table[list[gid]];
-  const u64 off = sl.owner;
-  const u32 m = stream[off + 1];
-  const u32* es = stream + off + 2;
-  u32 best = 0; u64 best_sz = ~0ULL;
-  for (u32 j = 0; j < m; j++) { u32 e = es[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
-  const u32* base = ix.ec_ids + ix.ec_off[es[best]];
-  const u32 nb = (u32)best_sz;
-  u64 out_off = 0;
-  u32 total = 0, first_mask = 0;
-  for (int pass = 0; pass < 2; pass++) {
-    u32 written = 0;
+  TSlot sl; sl.owner = 0; sl.count = 0; sl.tag = 0;
+  u32 m = 0, best = 0, nb = 0;
+  const u32* es = nullptr; const u32* base = nullptr;
+  if (valid) {
+    sl = table[list[gid]];
+    m = stream[sl.owner + 1];
+    es = stream + sl.owner + 2;
+    u64 best_sz = ~0ULL;
+    for (u32 j = 0; j < m; j++) { u32 e = es[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
+    base = ix.ec_ids + ix.ec_off[es[best]];
+    nb = (u32)best_sz;
+  }
+  // classify the candidates of the smallest set: membership in every other set (binary search) and the on-list mask;
+  // `mask_of(c0)` is recomputed in the write pass except for the first 16 candidates
+  auto chunk_mask = [&](u32 c0, u32* x_out) -> u32 {
+    const u32 c = c0 + sub;
+    bool ok = c < nb;
+    const u32 x = ok ? base[c] : 0;
+    if (ok) ok = onlisted(ix.onlist_bits, x);
+    for (u32 j = 0; j < m; j++) {
+      if (j == best) continue;
+      const u32 e = es[j];
+      if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+    }
+    *x_out = x;
+    return (u32)((__ballot(ok) >> gsh) & 0xFFFFu);
+  };
+  u32 total = 0, first_mask = 0, x0 = 0;
+  if (valid) {
     for (u32 c0 = 0; c0 < nb; c0 += RES_LANES) {
-      const u32 c = c0 + sub;
-      bool ok = c < nb;
-      u32 x = ok ? base[c] : 0;
-      u32 gmask;
-      if (pass == 1 && c0 == 0) gmask = first_mask;  // the first 16 candidates were classified in pass 0
-      else {
-        if (ok) ok = onlisted(ix.onlist_bits, x);
-        for (u32 j = 0; j < m; j++) {
-          if (j == best) continue;
-          const u32 e = es[j];
-          if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
-        }
-        gmask = (u32)((__ballot(ok) >> gsh) & 0xFFFFu);
-        if (pass == 0 && c0 == 0) first_mask = gmask;
-      }
-      if (pass == 1 && ((gmask >> sub) & 1u)) cand[out_off + 2 + written + __popc(gmask & ((1u << sub) - 1))] = x;
-      written += (u32)__popc(gmask);
+      u32 x; const u32 gm = chunk_mask(c0, &x);
+      if (c0 == 0) { first_mask = gm; x0 = x; }
+      total += (u32)__popc(gm);
     }
-    if (pass == 0) {
-      total = written;
-      if (total == 0) return;  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
-      if (sub == 0) {
-        out_off = atomicAdd(&st->cand_words, (u64)total + 2);
-        u64 r = atomicAdd(&st->cand_recs, 1ULL);
-        cand[out_off] = (u32)sl.count; cand[out_off + 1] = total;
-        cand_off[r] = out_off;
-      }
-      out_off = __shfl(out_off, gsh, 64);
-    }
+  }
+  // one allocation of the candidate stream per BLOCK (16 tuples), not per tuple: the cursor is a single address
+  if (sub == 0) grp_total[grp] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 words = 0, recs = 0;
+    for (int g = 0; g < RES_GROUPS; g++) if (grp_total[g]) { words += (u64)grp_total[g] + 2; recs++; }
+    u64 wbase = 0, rbase = 0;
+    if (recs) { wbase = atomicAdd(&st->cand_words, words); rbase = atomicAdd(&st->cand_recs, recs); }
+    for (int g = 0; g < RES_GROUPS; g++) if (grp_total[g]) { grp_off[g] = wbase; grp_rec[g] = rbase; wbase += (u64)grp_total[g] + 2; rbase++; }
+  }
+  __syncthreads();
+  if (!valid || total == 0) return;  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
+  const u64 out_off = grp_off[grp];
+  if (sub == 0) { cand[out_off] = (u32)sl.count; cand[out_off + 1] = total; cand_off[grp_rec[grp]] = out_off; }
+  u32 written = 0;
+  for (u32 c0 = 0; c0 < nb; c0 += RES_LANES) {
+    u32 x, gm;
+    if (c0 == 0) { gm = first_mask; x = x0; } else gm = chunk_mask(c0, &x);
+    if ((gm >> sub) & 1u) cand[out_off + 2 + written + __popc(gm & ((1u << sub) - 1))] = x;
+    written += (u32)__popc(gm);
   }
 }
 
@@ -923,7 +941,7 @@ __global__ void k_em_init(u64 n_tr, const double* __restrict__ eff, double* alph
   if (t < n_tr) { const double al = 1.0 / (double)n_tr; alpha[t] = al; a[t] = al / eff[t]; }  // :38
 }
 
-constexpr int EM_ROW_LANES = 4;
+template <int EM_ROW_LANES>
 __global__ __launch_bounds__(BLOCK) void k_em_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids,
                                                    const u32* __restrict__ counts, const u32* __restrict__ wcounts, u64 n_ecs,
                                                    const double* __restrict__ alpha0, const double* __restrict__ alpha1,
@@ -957,7 +975,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_rows(const u64* __restrict__ ec_of
 // (4 independent loads in flight per lane), k_em_final adds a transcript's segment sums in a fixed order.
 constexpr int EM_SEG = 64;
 constexpr int EM_SEG_LANES = 16;
-constexpr int EM_FIN_LANES = 8;
+constexpr int EM_FIN_LANES = 4;
 __global__ void k_em_nseg(const u32* __restrict__ col_cnt, u64 n_tr, u32* nseg) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n_tr) nseg[t] = (col_cnt[t] + EM_SEG - 1) / EM_SEG;
@@ -1737,17 +1755,24 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   HIPC(hipGetLastError());
   EmState hs{};
   const int chunk = 64;
-  const unsigned grid_rows = grid_for(std::max<u64>(n_ecs, 1) * EM_ROW_LANES, BLOCK);
+  int row_lanes = 4;
+  if (const char* e = getenv("KAMD_EM_ROW_LANES")) row_lanes = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
+  const unsigned grid_rows = grid_for(std::max<u64>(n_ecs, 1) * row_lanes, BLOCK);
   const unsigned grid_seg = grid_for(std::max<u64>(n_seg, 1) * EM_SEG_LANES, BLOCK);
-  const unsigned grid_fin = (unsigned)std::min<u64>(grid_for(T * EM_FIN_LANES, BLOCK), 1024);
+  unsigned fin_cap = 1024;
+  if (const char* e = getenv("KAMD_EM_FIN_BLOCKS")) fin_cap = (unsigned)std::max(64, atoi(e));
+  const unsigned grid_fin = (unsigned)std::min<u64>(grid_for(T * EM_FIN_LANES, BLOCK), fin_cap);
   // The launch-bound inner loop is captured once as a hipGraph of `chunk` rounds (4 kernels each) on a private stream
   // and replayed until the device-side state says done; all loop state lives in device memory, so every replay is
   // the same graph.  KAMD_EM_GRAPH=0 falls back to plain launches.
   auto enqueue_rounds = [&](hipStream_t s) {
     for (int it = 0; it < chunk; it++) {
-      hipLaunchKernelGGL(k_em_rows, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, (u64)n_ecs,
-                         c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(), c->em_a1.as<double>(),
-                         c->em_cn.as<double>(), (const EmState*)c->em_state.p);
+#define KAMD_LAUNCH_ROWS(L)                                                                                                        \
+  hipLaunchKernelGGL(k_em_rows<L>, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, (u64)n_ecs, \
+                     c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(), c->em_a1.as<double>(),              \
+                     c->em_cn.as<double>(), (const EmState*)c->em_state.p)
+      if (row_lanes == 8) KAMD_LAUNCH_ROWS(8); else if (row_lanes == 2) KAMD_LAUNCH_ROWS(2); else KAMD_LAUNCH_ROWS(4);
+#undef KAMD_LAUNCH_ROWS
       hipLaunchKernelGGL(k_em_seg, dim3(grid_seg), dim3(BLOCK), 0, s, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(),
                          c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_cn.as<double>(), c->em_partial.as<double>(),
                          (const EmState*)c->em_state.p);
