@@ -36,7 +36,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int BLOCK = 256;
-constexpr int TUPLE_CAP = 16;        // distinct set ids kept in LDS per item; more -> overflow kernel
+constexpr int TUPLE_CAP = 12;        // distinct set ids kept in LDS per item; more -> overflow kernel
 constexpr int TUPLE_CAP_BIG = 1024;  // per-item capacity of the overflow kernel (global scratch)
 
 struct DevIndex {
@@ -1112,7 +1112,7 @@ struct kamd_ctx {
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
   hipEvent_t ev2 = nullptr;
   hipStream_t em_stream = nullptr;
-  int kernel_a_version = 2, items_per_wave = 512, refill_min = 8;
+  int kernel_a_version = 2, items_per_wave = 1024, refill_min = 8;
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
 };
 
