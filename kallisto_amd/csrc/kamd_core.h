@@ -324,73 +324,70 @@ KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
   st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
   st.w0 = st.w2 = st.dist = st.nextPos = 0; st.um_uec = st.um2_uec = NO_UEC;
 }
-// consume the probe result of window st.w
+// consume the probe result of window st.w.  Written data-flow style: every phase only decides (a) whether the hit is
+// recorded, (b) where the next window search starts and (c) the phase that follows; the list insertion and the single
+// next_valid_window call are shared by all phases, so a wavefront whose lanes are in different phases executes them once.
 KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf) {
-  const int l = r.len;
-  bool backoff = false;
-  switch (st.phase) {
-    case PH_SCAN: {
-      if (p.found) {
-        if (mf.n_hits == 0) { mf.slot = p.slot; mf.pos = st.w; mf.strand = p.strand; }
-        ++mf.n_hits; ueclist_add(list, p.uec, mate);                               // :1774
-        if ((int)p.dist >= 2) {                                                    // :1792
-          const int pos = st.w, dist = (int)p.dist;
-          int nextPos = pos + dist;
-          if (pos + dist >= l - k) nextPos = l - k;                                // :1796-1799
-          const int w2 = advance_window(r, st.w, nextPos - pos, k);                // :1802-1803
-          if (w2 < 0) { st.phase = PH_DONE; return; }                              // :1882-1886 (Q4)
-          st.w0 = st.w; st.w2 = w2; st.dist = dist; st.nextPos = nextPos; st.um_uec = p.uec;
-          st.phase = PH_JUMP; st.w = w2;
-          return;
-        }
+  const int lk = r.len - k;
+  const int ph = st.phase;
+  bool hit = false, add = false, done = false;
+  int start = -1;              // next_valid_window(start) decides the next window ...
+  bool guard_len = false;      // ... after operator+='s end-of-string test (start + k > len -> end), KmerIterator.cpp:47-60
+  bool stay = false;           // advance by 0: the iterator stays on st.w0 (Q4)
+  int ph_ok = PH_SCAN;
+  bool fallback_backoff = false;  // the middle window does not exist: take the back-off path instead
+
+  if (ph == PH_SCAN) {
+    start = st.w + 1;
+    if (p.found) {
+      hit = add = true;
+      if (mf.n_hits == 0) { mf.slot = p.slot; mf.pos = st.w; mf.strand = p.strand; }
+      const int dist = (int)p.dist;                                                // :1789
+      if (dist >= 2) {                                                             // :1792
+        const int pos = st.w;
+        const int nextPos = (pos + dist >= lk) ? lk : pos + dist;                  // :1794-1799
+        const int n = nextPos - pos;                                               // kit2 += nextPos - pos (:1803)
+        st.w0 = pos; st.dist = dist; st.nextPos = nextPos; st.um_uec = p.uec;
+        ph_ok = PH_JUMP;
+        if (n == 0) stay = true; else { start = pos + n; guard_len = n >= 2; }
       }
-      st.w = next_valid_window(r, st.w + 1, k);
-      if (st.w < 0) st.phase = PH_DONE;
-      return;
     }
-    case PH_JUMP: {
-      const int pos = st.w0;
-      const bool found2 = !p.found || p.uec == st.um_uec;                          // :1807-1815
-      if (found2) {
-        const int found2pos = p.found ? pos + st.dist : pos;                       // (Q2)
-        ++mf.n_hits;                                                               // push {um, found2pos | l-k}
-        if (found2pos >= l - k) { st.phase = PH_DONE; return; }                    // :1819-1822
-        st.w = next_valid_window(r, st.w2 + 1, k);                                 // kit = kit2; ++kit
-        st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
-        return;
-      }
+  } else if (ph == PH_JUMP) {
+    const bool found2 = !p.found || p.uec == st.um_uec;                            // :1807-1815
+    if (found2) {
+      hit = true;                                                                  // push {um, found2pos}: um's class is in the list
+      const int found2pos = p.found ? st.w0 + st.dist : st.w0;                     // (Q2)
+      if (found2pos >= lk) done = true;                                            // :1819-1822
+      else start = st.w2 + 1;                                                      // kit = kit2; ++kit
+    } else {
       st.um2_uec = p.uec;
-      if (st.dist > 4) {                                                           // :1831
-        const int middlePos = (pos + st.nextPos) / 2;
-        const int w3 = advance_window(r, st.w0, middlePos - pos, k);
-        if (w3 >= 0) { st.phase = PH_MIDDLE; st.w = w3; return; }
+      start = st.w0 + 1; ph_ok = PH_BACKOFF;                                       // :1876-1925 with Q1: one-step back-off
+      if (st.dist > 4) {                                                           // :1831: try the middle k-mer first
+        const int n = (st.w0 + st.nextPos) / 2 - st.w0;                            // middlePos - pos
+        ph_ok = PH_MIDDLE; fallback_backoff = true;
+        if (n == 0) stay = true; else { start = st.w0 + n; guard_len = n >= 2; }
       }
-      backoff = true;
-      break;
     }
-    case PH_MIDDLE: {
-      if (p.found && (p.uec == st.um_uec || p.uec == st.um2_uec)) {                // :1842-1850
-        ++mf.n_hits; ueclist_add(list, p.uec, mate);                               // :1866 (Q3)
-        if (st.nextPos >= l - k) { st.phase = PH_DONE; return; }                   // :1867-1868
-        st.w = next_valid_window(r, st.w2 + 1, k);
-        st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
-        return;
-      }
-      backoff = true;
-      break;
-    }
-    case PH_BACKOFF: {
-      if (p.found) { ++mf.n_hits; ueclist_add(list, p.uec, mate); }                // :1900-1917
-      st.w = next_valid_window(r, st.w + 1, k);
-      st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
-      return;
-    }
-    default: return;
+  } else if (ph == PH_MIDDLE) {
+    if (p.found && (p.uec == st.um_uec || p.uec == st.um2_uec)) {                  // :1842-1850
+      hit = add = true;                                                            // :1866 (Q3)
+      if (st.nextPos >= lk) done = true;                                           // :1867-1868
+      else start = st.w2 + 1;
+    } else { start = st.w0 + 1; ph_ok = PH_BACKOFF; }
+  } else {  // PH_BACKOFF
+    if (p.found) hit = add = true;                                                 // :1900-1917
+    start = st.w + 1;
   }
-  if (backoff) {                                                                   // :1876-1925 with Q1: one-step back-off
-    st.w = next_valid_window(r, st.w0 + 1, k);
-    st.phase = st.w >= 0 ? PH_BACKOFF : PH_DONE;
-  }
+  if (hit) ++mf.n_hits;
+  if (add) ueclist_add(list, p.uec, mate);
+  if (done) { st.phase = PH_DONE; return; }
+  int w;
+  if (stay) w = st.w0;
+  else w = (guard_len && start + k > r.len) ? -1 : next_valid_window(r, start, k);
+  if (w < 0 && fallback_backoff) { w = next_valid_window(r, st.w0 + 1, k); ph_ok = PH_BACKOFF; }
+  if (ph_ok == PH_JUMP) { if (w < 0) { st.phase = PH_DONE; return; } st.w2 = w; }  // :1882-1886 (Q4)
+  st.w = w;
+  st.phase = w >= 0 ? ph_ok : PH_DONE;
 }
 
 // map the item's (unitig, set) classes to sorted distinct non-empty transcript-set ids; reports per mate whether any of
