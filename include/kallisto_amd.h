@@ -178,6 +178,19 @@ int kamd_em_run(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, c
                 const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
                 uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds);
 
+/* The same EM over `world` GPUs (one process per GPU).  The EC x transcript matrix is block diagonal over the connected
+ * components of the transcript/EC graph and EMAlgorithm::run never couples two components, so every rank runs the
+ * unchanged EM on the components it owns (hash of the component label mod world) -- there is no per-round collective.
+ * Only the stop rule is global: after every chunk of rounds the library calls sum_cb(user, d_counts, n), which must
+ * replace the n device ints (per-round numbers of transcripts that still change, src/EMAlgorithm.h:176-199) by their sum
+ * over all ranks, e.g. ncclAllReduce(ncclInt32, ncclSum); all ranks then stop at the round the reference would.
+ * Requires every rank to hold the same finalized EC result.  alpha / alpha_before_zeroes receive this rank's transcripts
+ * and zeros elsewhere: the caller sums them over the ranks. */
+typedef int (*kamd_em_sum_cb)(void* user, int32_t* d_counts, int32_t n);
+int kamd_em_run_partitioned(kamd_ctx*, uint32_t rank, uint32_t world, kamd_em_sum_cb sum_cb, void* user, const double* eff_lens,
+                            uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds, double* alpha, double* alpha_before_zeroes,
+                            int32_t* rounds);
+
 /* ---- S4: bootstrap ---- */
 /* One replicate of Bootstrap::run_em (src/Bootstrap.cpp:4-14): Multinomial(counts, seed).sample() with libstdc++'s
  * minstd_rand0 + discrete_distribution semantics (identical sample for an identical EC order), then a fresh EM

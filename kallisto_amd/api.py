@@ -91,6 +91,8 @@ _SYMBOLS = {
     "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "kamd_em_run_partitioned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "kamd_bootstrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                  C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "kamd_bootstrap_seeds": (None, [C.c_uint64, C.c_int32, C.c_void_p]),
@@ -380,6 +382,38 @@ class Context:
                                           abz.ctypes.data, C.byref(rounds)), "kamd_em_run")
         return alpha, abz, int(rounds.value)
 
+    def em_run_partitioned(self, eff_lens: np.ndarray, group=None, n_iter: int = 10000, min_rounds: int = 50):
+        """The EM over all ranks of `group`: every rank (holding the same finalized ECs) runs the connected components it
+        owns; the only collective inside is the sum of the per-round change counters once per chunk of rounds, plus
+        one all-reduce of the result.  Returns the same (alpha, alpha_before_zeroes, rounds) on every rank."""
+        import torch.distributed as dist
+        torch = self.torch
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        eff = np.ascontiguousarray(eff_lens, np.float64)
+        T = len(eff)
+        alpha = np.zeros(T, np.float64)
+        abz = np.zeros(T, np.float64)
+        rounds = C.c_int32(0)
+        device = self.device
+
+        def _sum(user, d_counts, n):
+            try:
+                t = _alias_tensor(torch, d_counts, int(n), torch.int32, device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32)(_sum)
+        _check(load_library().kamd_em_run_partitioned(self._h, rank, world, cb, None, eff.ctypes.data, T, n_iter, min_rounds,
+                                                      alpha.ctypes.data, abz.ctypes.data, C.byref(rounds)), "kamd_em_run_partitioned")
+        both = torch.from_numpy(np.stack([alpha, abz])).to(f"cuda:{device}")
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)  # every transcript is non-zero on exactly one rank
+        both = both.cpu().numpy()
+        return both[0].copy(), both[1].copy(), int(rounds.value)
+
     def bootstrap(self, seed: int, eff_lens: np.ndarray, csr=None, want_sample: bool = False):
         """One bootstrap replicate (Bootstrap::run_em): multinomial resample of the EC counts + EM.  Returns
         (alpha, rounds[, resampled counts])."""
@@ -499,7 +533,10 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
     ctx.allreduce_ec_counts(group)
     ecs = ctx.finalize(download=download_ecs)
     eff = eff_lens(index.target_lens, mft)
-    alpha, abz, rounds = ctx.em_run(eff)
+    if _dist_on():
+        alpha, abz, rounds = ctx.em_run_partitioned(eff, group)
+    else:
+        alpha, abz, rounds = ctx.em_run(eff)
     tpm = counts_to_tpm(alpha, eff)
     n_aln = n_uniq = 0
     if ecs is not None:

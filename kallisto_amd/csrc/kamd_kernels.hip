@@ -1051,9 +1051,19 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
 }
 // loop control of :202-221, one thread, after the round's k_em_final (a kernel boundary orders it behind every block;
 // an in-kernel "last block" hand-off would need an agent-scope fence per block, which flushes the L2 each time)
-__global__ void k_em_control(EmState* st, int n_iter, int min_rounds) {
+// spec_hist != nullptr (EM partitioned over several GPUs): no rank may decide alone, so the round's count of changed
+// transcripts is only recorded (spec_hist[round]) and the loop keeps going; the host sums the history over the ranks after
+// every chunk of rounds and rewinds to the round at which the global test fires (em_run_impl).
+__global__ void k_em_control(EmState* st, int n_iter, int min_rounds, int* spec_hist) {
   if (st->done) return;
   const int it = st->iter;
+  if (spec_hist) {
+    spec_hist[it] = st->chcount;
+    st->chcount = 0;
+    if (st->final_round) { st->done = 1; st->rounds = it; return; }
+    st->iter = it + 1;
+    return;
+  }
   const bool stopEM = (st->chcount == 0 && it > min_rounds);     // :202-205
   st->chcount = 0;
   if (st->final_round) { st->done = 1; st->rounds = it; return; } // :207-209
@@ -1064,6 +1074,58 @@ __global__ void k_em_control(EmState* st, int n_iter, int min_rounds) {
 __global__ void k_fill_f64(double* p, u64 n, double v) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// EM over several GPUs: the EC x transcript matrix is block diagonal over the connected components of the
+// transcript/EC graph (gene families), and the EM update never crosses a component, so each rank runs the unchanged
+// EM on the components it owns -- no per-round collective.  Components: min-label propagation along rows + pointer
+// jumping.  Ownership: hash(label) mod world.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_cc_init(u32* label, u64 n) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) label[t] = (u32)t;
+}
+__global__ void k_cc_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, u32* label, int* changed) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  if (b - a < 2) return;
+  u32 m = 0xFFFFFFFFu;
+  for (u64 j = a; j < b; j++) m = min(m, label[ec_ids[j]]);
+  bool ch = false;
+  for (u64 j = a; j < b; j++) { const u32 t = ec_ids[j]; if (label[t] > m) { atomicMin(&label[t], m); ch = true; } }
+  if (ch) *changed = 1;
+}
+__global__ void k_cc_jump(u32* label, u64 n) {  // label[t] <- label[label[t]] (labels are transcript ids, roots label themselves)
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  u32 l = label[t];
+  for (int i = 0; i < 8; i++) { const u32 ll = label[l]; if (ll == l) break; l = ll; }
+  label[t] = l;
+}
+__device__ __forceinline__ u32 cc_owner(u32 label, u32 world) { return (u32)(kamd::mix64((u64)label + 0x51ULL) % world); }
+__global__ void k_part_sizes(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ label,
+                             u32 rank, u32 world, u32* row_flag, u32* row_len) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  const bool mine = b > a && cc_owner(label[ec_ids[a]], world) == rank;
+  row_flag[e] = mine ? 1u : 0u;
+  row_len[e] = mine ? (u32)(b - a) : 0u;
+}
+__global__ void k_part_copy(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts,
+                            const u32* __restrict__ wcounts, u64 n_ecs, const u32* __restrict__ row_flag,
+                            const u64* __restrict__ row_pos, const u64* __restrict__ nnz_pos, u64* out_off, u32* out_ids,
+                            u32* out_counts, u32* out_wcounts) {
+  u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs || !row_flag[e]) return;
+  const u64 r = row_pos[e], o = nnz_pos[e];
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  out_off[r] = o;
+  for (u64 j = a; j < b; j++) out_ids[o + (j - a)] = ec_ids[j];
+  out_counts[r] = counts[e];
+  out_wcounts[r] = wcounts[e];
 }
 
 struct DBuf {
@@ -1099,6 +1161,7 @@ struct kamd_ctx {
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single;
+  DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
   u64 n_distinct_tuples = 0;
@@ -1248,7 +1311,9 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
-                  &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single})
+                  &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->pt_label, &c->pt_flag, &c->pt_len,
+                  &c->pt_rowpos, &c->pt_nnzpos, &c->pt_off, &c->pt_ids, &c->pt_counts, &c->pt_wcounts, &c->pt_hist, &c->pt_ck_alpha,
+                  &c->pt_ck_a})
     b->release();
   delete c;
 }
@@ -1696,9 +1761,34 @@ extern "C" int kamd_ec_download(kamd_ctx* c, uint64_t* ec_off, uint32_t* ec_ids,
 }
 
 // ---- EM ----------------------------------------------------------------------------------------------------------------
+namespace {
+struct EmPartition { uint32_t rank = 0, world = 1; kamd_em_sum_cb cb = nullptr; void* user = nullptr; };
+int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
+                const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
+                uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds, const EmPartition& part);
+}  // namespace
+
 extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
                            const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets,
                            uint32_t n_iter, uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds) {
+  return em_run_impl(c, d_ec_off, d_ec_ids, d_counts, d_weight_counts, n_ecs, eff_lens, n_targets, n_iter, min_rounds, alpha,
+                     alpha_before_zeroes, rounds, EmPartition{});
+}
+
+extern "C" int kamd_em_run_partitioned(kamd_ctx* c, uint32_t rank, uint32_t world, kamd_em_sum_cb sum_cb, void* user,
+                                       const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds,
+                                       double* alpha, double* alpha_before_zeroes, int32_t* rounds) {
+  if (world == 0 || rank >= world) return kamd::fail(-1, "kamd_em_run_partitioned: bad rank / world");
+  if (world > 1 && !sum_cb) return kamd::fail(-1, "kamd_em_run_partitioned: a sum callback is required when world > 1");
+  EmPartition p; p.rank = rank; p.world = world; p.cb = sum_cb; p.user = user;
+  return em_run_impl(c, nullptr, nullptr, nullptr, nullptr, 0, eff_lens, n_targets, n_iter, min_rounds, alpha, alpha_before_zeroes,
+                     rounds, p);
+}
+
+namespace {
+int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
+                const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
+                uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds, const EmPartition& part) {
   if (!c || !eff_lens || !alpha) return kamd::fail(-1, "kamd_em_run: null argument");
   HIPC(hipSetDevice(c->device));
   if (!d_ec_off) {
@@ -1710,6 +1800,50 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   const u32* d_wcounts = d_weight_counts ? d_weight_counts : d_counts;
   const u64 T = n_targets;
   if (T == 0) return kamd::fail(-1, "kamd_em_run: no targets");
+  const bool spec = part.world > 1;
+  if (spec && n_ecs) {
+    // connected components of the transcript/EC graph, then the rows of the components this rank owns as a compact CSR
+    u64 nnz_all = 0;
+    HIPC(hipMemcpyAsync(&nnz_all, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
+    if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
+    for (int it = 0;; it++) {
+      HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(k_cc_rows, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, (u64)n_ecs,
+                         c->pt_label.as<u32>(), (int*)c->pt_hist.p);
+      hipLaunchKernelGGL(k_cc_jump, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
+      int changed = 0;
+      HIPC(hipMemcpyAsync(&changed, c->pt_hist.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      if (!changed) break;
+      if (it > 10000) return kamd::fail(-101, "kamd_em_run_partitioned: component labelling did not converge");
+    }
+    for (DBuf* b : {&c->pt_flag, &c->pt_len}) if (int rc = b->ensure((n_ecs + 1) * sizeof(u32), 0, c->stream)) return rc;
+    for (DBuf* b : {&c->pt_rowpos, &c->pt_nnzpos}) if (int rc = b->ensure((n_ecs + 2) * sizeof(u64), 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_part_sizes, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, (u64)n_ecs,
+                       c->pt_label.as<u32>(), part.rank, part.world, c->pt_flag.as<u32>(), c->pt_len.as<u32>());
+    if (int rc = exclusive_scan(c, c->pt_flag.as<u32>(), n_ecs, c->pt_rowpos.as<u64>(), c->pt_rowpos.as<u64>() + n_ecs)) return rc;
+    if (int rc = exclusive_scan(c, c->pt_len.as<u32>(), n_ecs, c->pt_nnzpos.as<u64>(), c->pt_nnzpos.as<u64>() + n_ecs)) return rc;
+    u64 n_local = 0, nnz_local = 0;
+    HIPC(hipMemcpyAsync(&n_local, c->pt_rowpos.as<u64>() + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(&nnz_local, c->pt_nnzpos.as<u64>() + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (int rc = c->pt_off.ensure((n_local + 2) * sizeof(u64), 0, c->stream)) return rc;
+    if (int rc = c->pt_ids.ensure((nnz_local + 1) * sizeof(u32), 0, c->stream)) return rc;
+    if (int rc = c->pt_counts.ensure((n_local + 1) * sizeof(u32), 0, c->stream)) return rc;
+    if (int rc = c->pt_wcounts.ensure((n_local + 1) * sizeof(u32), 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_part_copy, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, d_counts,
+                       d_wcounts, (u64)n_ecs, c->pt_flag.as<u32>(), c->pt_rowpos.as<u64>(), c->pt_nnzpos.as<u64>(), c->pt_off.as<u64>(),
+                       c->pt_ids.as<u32>(), c->pt_counts.as<u32>(), c->pt_wcounts.as<u32>());
+    HIPC(hipMemcpyAsync(c->pt_off.as<u64>() + n_local, &nnz_local, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));  // nnz_local is a stack variable
+    HIPC(hipGetLastError());
+    d_ec_off = c->pt_off.as<uint64_t>(); d_ec_ids = c->pt_ids.as<u32>(); d_counts = c->pt_counts.as<u32>(); d_wcounts = c->pt_wcounts.as<u32>();
+    n_ecs = n_local;
+    (void)nnz_all;
+  }
   u64 nnz = 0;
   if (n_ecs) {
     HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -1765,8 +1899,16 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   // The launch-bound inner loop is captured once as a hipGraph of `chunk` rounds (4 kernels each) on a private stream
   // and replayed until the device-side state says done; all loop state lives in device memory, so every replay is
   // the same graph.  KAMD_EM_GRAPH=0 falls back to plain launches.
-  auto enqueue_rounds = [&](hipStream_t s) {
-    for (int it = 0; it < chunk; it++) {
+  int* spec_hist = nullptr;
+  if (spec) {
+    if (int rc = c->pt_hist.ensure(((size_t)n_iter + 2 * chunk + 8) * sizeof(int), 0, c->stream)) return rc;
+    HIPC(hipMemsetAsync(c->pt_hist.p, 0, ((size_t)n_iter + 2 * chunk + 8) * sizeof(int), c->stream));
+    spec_hist = (int*)c->pt_hist.p;
+    if (int rc = c->pt_ck_alpha.ensure(T * sizeof(double), 0, c->stream)) return rc;
+    if (int rc = c->pt_ck_a.ensure(T * sizeof(double), 0, c->stream)) return rc;
+  }
+  auto enqueue_rounds = [&](hipStream_t s, int n_rounds) {
+    for (int it = 0; it < n_rounds; it++) {
 #define KAMD_LAUNCH_ROWS(L)                                                                                                        \
   hipLaunchKernelGGL(k_em_rows<L>, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, (u64)n_ecs, \
                      c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(), c->em_a1.as<double>(),              \
@@ -1779,31 +1921,73 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
       hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, s, c->em_segoff.as<u64>(), c->em_partial.as<double>(),
                          c->em_single.as<double>(), c->em_eff.as<double>(), T, c->em_alpha.as<double>(), c->em_next.as<double>(),
                          c->em_a0.as<double>(), c->em_a1.as<double>(), (EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, s, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds);
+      hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, s, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds, spec_hist);
     }
   };
-  const char* eg = getenv("KAMD_EM_GRAPH");
-  bool use_graph = !(eg && atoi(eg) == 0);
-  hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
-  hipStream_t es = c->stream;
-  if (use_graph) {
-    if (!c->em_stream) HIPC(hipStreamCreateWithFlags(&c->em_stream, hipStreamNonBlocking));
-    es = c->em_stream;
-    HIPC(hipEventRecord(c->ev2, c->stream));           // the private stream starts after the preparation kernels
-    HIPC(hipStreamWaitEvent(es, c->ev2, 0));
-    HIPC(hipStreamBeginCapture(es, hipStreamCaptureModeThreadLocal));
-    enqueue_rounds(es);
-    HIPC(hipStreamEndCapture(es, &graph));
-    HIPC(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+  double* bufs_alpha[2] = {c->em_alpha.as<double>(), c->em_next.as<double>()};
+  double* bufs_a[2] = {c->em_a0.as<double>(), c->em_a1.as<double>()};
+  if (!spec) {
+    const char* eg = getenv("KAMD_EM_GRAPH");
+    bool use_graph = !(eg && atoi(eg) == 0);
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    hipStream_t es = c->stream;
+    if (use_graph) {
+      if (!c->em_stream) HIPC(hipStreamCreateWithFlags(&c->em_stream, hipStreamNonBlocking));
+      es = c->em_stream;
+      HIPC(hipEventRecord(c->ev2, c->stream));           // the private stream starts after the preparation kernels
+      HIPC(hipStreamWaitEvent(es, c->ev2, 0));
+      HIPC(hipStreamBeginCapture(es, hipStreamCaptureModeThreadLocal));
+      enqueue_rounds(es, chunk);
+      HIPC(hipStreamEndCapture(es, &graph));
+      HIPC(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    }
+    while (!hs.done) {
+      if (use_graph) HIPC(hipGraphLaunch(gexec, es)); else enqueue_rounds(es, chunk);
+      HIPC(hipGetLastError());
+      HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, es));
+      HIPC(hipStreamSynchronize(es));
+    }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+  } else {
+    // Partitioned EM: run a chunk of rounds speculatively, sum the per-round change counts over the ranks (the callback;
+    // also the only synchronisation between ranks), find the first round s at which the reference's test
+    // "chcount == 0 && s > min_rounds" (:202-205) holds globally, rewind to the chunk's checkpoint and replay up to s,
+    // then the final round.  Every rank sees the same history, so every rank takes the same decision.
+    std::vector<int> hist(chunk);
+    int base = 0;
+    for (;;) {
+      HIPC(hipMemcpyAsync(c->pt_ck_alpha.p, bufs_alpha[base & 1], T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPC(hipMemcpyAsync(c->pt_ck_a.p, bufs_a[base & 1], T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      const int n_run = (int)std::min<long>(chunk, (long)n_iter - base);
+      enqueue_rounds(c->stream, n_run);
+      HIPC(hipGetLastError());
+      HIPC(hipStreamSynchronize(c->stream));
+      if (int rc = part.cb(part.user, spec_hist + base, n_run)) return kamd::fail(-103, "kamd_em_run_partitioned: the sum callback failed (" + std::to_string(rc) + ")");
+      HIPC(hipMemcpy(hist.data(), spec_hist + base, n_run * sizeof(int), hipMemcpyDeviceToHost));
+      int stop = -1;
+      for (int i = 0; i < n_run; i++) if (hist[i] == 0 && base + i > (int)min_rounds) { stop = base + i; break; }
+      if (stop < 0) {
+        base += n_run;
+        if (base >= (int)n_iter) { hs.done = 1; hs.rounds = (int)n_iter; hs.final_round = 0; break; }  // the loop ran out
+        continue;
+      }
+      // rewind + replay rounds base..stop, then the clamped final round
+      HIPC(hipMemcpyAsync(bufs_alpha[base & 1], c->pt_ck_alpha.p, T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPC(hipMemcpyAsync(bufs_a[base & 1], c->pt_ck_a.p, T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      EmState st0{}; st0.iter = base;
+      HIPC(hipMemcpyAsync(c->em_state.p, &st0, sizeof(EmState), hipMemcpyHostToDevice, c->stream));
+      enqueue_rounds(c->stream, stop - base + 1);
+      EmState st1{}; st1.iter = stop + 1; st1.final_round = 1;
+      HIPC(hipStreamSynchronize(c->stream));  // st0 is a stack variable
+      HIPC(hipMemcpyAsync(c->em_state.p, &st1, sizeof(EmState), hipMemcpyHostToDevice, c->stream));
+      enqueue_rounds(c->stream, 1);
+      HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      if (!hs.done || hs.rounds != stop + 1) return kamd::fail(-101, "kamd_em_run_partitioned: replay did not end on the final round");
+      break;
+    }
   }
-  while (!hs.done) {
-    if (use_graph) HIPC(hipGraphLaunch(gexec, es)); else enqueue_rounds(es);
-    HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, es));
-    HIPC(hipStreamSynchronize(es));
-  }
-  if (gexec) (void)hipGraphExecDestroy(gexec);
-  if (graph) (void)hipGraphDestroy(graph);
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipEventSynchronize(c->ev1));
   HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
@@ -1820,6 +2004,7 @@ extern "C" int kamd_em_run(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t
   if (rounds) *rounds = hs.rounds;
   return 0;
 }
+}  // namespace
 
 // ---- diagnostics: ceiling of the k-mer table's access pattern ---------------------------------------------------------
 // Every lane follows a dependent chain of random 64-byte bucket reads (4 x 16 B, the probe's loads) with nothing in

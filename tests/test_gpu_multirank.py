@@ -57,7 +57,12 @@ def _worker(rank, world, port, case, variant, q):
         ew, eo = gather_records(ew.cpu(), eo.cpu())
         ctx.explicit_replace(ew.cuda(), eo.cuda())
         ecs = ctx.finalize()
-        q.put((rank, ecs.multiset()))
+        # EM partitioned over the ranks by connected component (gloo all-reduce on the device tensors)
+        import kallisto_amd.api as A
+        exp = common.load_expected(case, variant)
+        alpha, abz, rounds = ctx.em_run_partitioned(exp["eff"])
+        alpha1, abz1, rounds1 = ctx.em_run(exp["eff"])          # the single-GPU EM on the same ECs
+        q.put((rank, ecs.multiset(), alpha, abz, rounds, alpha1, abz1, rounds1))
     finally:
         dist.destroy_process_group()
 
@@ -71,8 +76,16 @@ def test_two_ranks_one_gpu(case, variant):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case, variant, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=600) for _ in range(2))
+    got = [q.get(timeout=600) for _ in range(2)]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert results[0] == results[1] == exp["ecs"]
+    results = {g[0]: g for g in got}
+    assert results[0][1] == results[1][1] == exp["ecs"]
+    for r in (0, 1):
+        _, _, alpha, abz, rounds, alpha1, abz1, rounds1 = results[r]
+        assert rounds == rounds1                                    # the partitioned EM stops at the same round
+        common.assert_abundance_close(alpha, exp["alpha"], "partitioned EM vs reference")
+        common.assert_abundance_close(alpha, alpha1, "partitioned EM vs single-GPU EM", rel=1e-9)
+        common.assert_abundance_close(abz, abz1, "alpha_before_zeroes", rel=1e-9, floor=1e-12)
+    assert np.array_equal(results[0][2], results[1][2])             # every rank ends with the same vector
