@@ -23,11 +23,20 @@ def merge_ec_state(dense: torch.Tensor, words: torch.Tensor, offs: torch.Tensor,
     return gather_records(words, offs, group)
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    """gloo has no all_gather for device tensors: stage through the host (tests / single-GPU smoke runs only)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def gather_records(words: torch.Tensor, offs: torch.Tensor, group=None):
     """All-gather variable-length record buffers: (words, offsets) of every rank concatenated, offsets rebased."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return words, offs
     world = dist.get_world_size(group)
+    if _via_host(words, group):
+        dev = words.device
+        w, o = gather_records(words.cpu(), offs.cpu(), group)
+        return w.to(dev), o.to(dev)
     dense = words
     sizes = torch.tensor([words.numel(), offs.numel()], dtype=torch.int64, device=dense.device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]

@@ -149,3 +149,24 @@ def test_bootstrap_on_finalized_result(ka, ctxs):
     a_o, _, r_o = O.em_run(ecs.ec_off, ecs.ec_ids, samp, exp["eff"], index.num_targets, weight_counts=ecs.counts)
     assert rounds == r_o
     common.assert_abundance_close(alpha, a_o, "bootstrap alpha")
+
+
+def test_degenerate_batches(ka, ctxs):
+    """Empty batch, a single pair, and a batch in which nothing pseudoaligns (all N / shorter than k)."""
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    index, ctx = ctxs("human_pe")
+    opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
+    words, lens, max_len = ctx.pack_reads_host([b"N" * 100, b"N" * 100, b"ACGT", b"ACGTACGT", b"", b""], 100)
+    ctx.pseudoalign(opts, words, lens, 0, max_len)              # n_items = 0 is a no-op
+    ctx.pseudoalign(opts, words, lens, 3, max_len)
+    ecs = ctx.finalize()
+    assert len(ecs.counts) == 0 and ctx.stats()["n_processed"] == 3
+    alpha, abz, rounds = ctx.em_run(np.ones(index.num_targets))
+    assert not alpha.any()                                      # nothing to distribute
+    ctx.reset()
+    words, lens, max_len = ctx.pack_reads_host([r1[0], r2[0]], 100)
+    ctx.pseudoalign(opts, words, lens, 1, max_len)
+    ecs = ctx.finalize()
+    from oracle import oracle as O
+    u, _, _ = O.Index(idx_path).pseudoalign(O.Opts(1, 0.0, 0.0, 0, 0), r1[0], r2[0])
+    assert ecs.multiset() == ({tuple(u): 1} if u else {})
