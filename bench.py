@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--genes", type=int, default=None, help="scale of the synthetic transcriptome (default: full config)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs given to the CPU reference (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bootstraps", type=int, default=0,
+                    help="BASELINE config #5: also time B bootstrap replicates (multinomial resample + EM), split over the ranks")
     args = ap.parse_args()
 
     import torch
@@ -223,6 +225,28 @@ def main():
         elapsed = float(t.item())
     st = res.stats
     total_pairs = n * world * args.steps
+    # ---- BASELINE config #5 (optional): B bootstrap replicates of the last step's ECs, replicate b on rank b % world ----
+    boot = None
+    if args.bootstraps > 0:
+        import kallisto_amd.api as A
+        seeds = A.bootstrap_seeds(42, args.bootstraps)
+        mine = [b for b in range(args.bootstraps) if b % world == rank]
+        fence()
+        tb = time.perf_counter()
+        rounds_b = []
+        for b in mine:
+            _, r_b = ctx.bootstrap(int(seeds[b]), res.eff_lens)
+            rounds_b.append(r_b)
+        fence()
+        tb = time.perf_counter() - tb
+        if world > 1:
+            t = torch.tensor([tb], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tb = float(t.item())
+        boot = {"replicates": args.bootstraps, "seconds": round(tb, 4), "replicates_per_s": round(args.bootstraps / tb, 3),
+                "ms_per_replicate_per_gpu": round(tb / max(len(mine), 1) * 1e3, 2),
+                "em_rounds_first": rounds_b[:3], "note": "Bootstrap::run_em per replicate: multinomial resample of the EC counts "
+                "(N = pseudoaligned pairs draws, libstdc++ semantics) + EM run(10000, 50); replicate b runs on rank b % world"}
 
     out = None
     if rank == 0:
@@ -342,6 +366,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "M read pairs/s", "cores": threads, "kind": "reference",
                                    "sample": f"failed: {e}"}
     if rank == 0:
+        if boot is not None:
+            out["bootstrap"] = boot
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

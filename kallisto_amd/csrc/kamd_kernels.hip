@@ -1,16 +1,20 @@
 // kamd_kernels.hip -- gfx950 (MI355X) kernels and device-side driver of libkallisto_amd.so.
 //
-// Kernel A  k_pseudoalign   one work-item per read / read pair: 2-bit packed reads staged in LDS, k-mer probes into the
-//                           bucketed Robin-Hood table in HBM (one 64-byte line per probe), KmerIndex::match jump logic,
-//                           per-item list of distinct transcript-set ids kept in LDS; single-set items bump a dense count
-//                           vector, multi-set items are appended to a tuple stream with one wave-aggregated allocation
-//                           (prefix sum across the wavefront).
+// Kernel A  k_match_v2      one resumable KmerIndex::match state machine per lane, ONE table probe per lane per loop
+//                           iteration (bucketed Robin-Hood k-mer table in HBM, one 64-byte line per probe), packed reads and
+//                           per-item class lists in LDS, lanes refill from their wavefront's chunk of items.
+//           k_classify      persistent blocks: classes -> transcript-set ids, intersectKmers' rules, positional filters;
+//                           single-set items -> dense count vector through an LDS cache, tuples rewritten in place.
+//           k_pseudoalign   the first version of kernel A (block-staged, straight-line match per lane), kept for A/B runs
+//                           and as the overflow / explicit-set / FLD code path.
 //           k_rec_insert / k_rec_verify   exact, wait-free de-duplication of variable-length records (tuples of set ids,
 //                           later whole transcript sets): 64-bit tag CAS + owner = smallest record, then content
 //                           verification against the owner; mismatching tags retry under another seed.
-//           k_resolve       one wavefront per distinct tuple: sorted-set intersection with ballot + popcount prefix
+//           k_resolve       one 16-lane group per distinct tuple: sorted-set intersection with ballot + popcount prefix
 //                           compaction, on-list mask applied (MinCollector::intersectKmers, ProcessReads.cpp:1072).
-// Kernel B  k_em_*          EM E/M steps over the EC x transcript CSR (EMAlgorithm::run), FP64.
+// Kernel B  k_em_*          EM rounds over the EC x transcript matrix (EMAlgorithm::run), FP64, no data atomics;
+//                           partitioned over several GPUs by connected component (em_run_impl).
+//           k_multinomial   bootstrap resampling with LCG skip-ahead (Multinomial::sample).
 //
 // The per-item semantics live in kamd_core.h (shared with the CPU emulation used by the tests).
 #include <hip/hip_runtime.h>
@@ -609,12 +613,6 @@ __global__ __launch_bounds__(BLOCK) void k_rec_verify(const u32* __restrict__ st
   __syncthreads();
   if (is_owner) list[blk_base + my] = s;
 }
-// list the owners (one per distinct record) of a table
-__global__ void k_table_list(const TSlot* table, u64 cap, u64* list, DevState* st) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cap) return;
-  if (table[i].tag != 0 && table[i].count != 0) { u64 k = atomicAdd(&st->n_list, 1ULL); list[k] = i; }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // resolve: candidates = transcript sets of (a) index sets with a non-zero dense count, (b) distinct tuples
@@ -1071,10 +1069,6 @@ __global__ void k_em_control(EmState* st, int n_iter, int min_rounds, int* spec_
   st->iter = it + 1;
   if (it + 1 >= n_iter) { st->done = 1; st->rounds = it + 1; }
 }
-__global__ void k_fill_f64(double* p, u64 n, double v) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // EM over several GPUs: the EC x transcript matrix is block diagonal over the connected components of the
@@ -1160,7 +1154,7 @@ struct kamd_ctx {
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw;
   DBuf ec_off, ec_ids, ec_counts;
-  DBuf em_alpha, em_next, em_eff, em_state, em_wrow, em_cn, em_colcnt, em_coloff, em_colrow, em_colw, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single;
+  DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
@@ -1231,16 +1225,6 @@ int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u6
   return 0;
 }
 
-int list_table(kamd_ctx* c, const TSlot* table, u64 cap, DBuf& list, u64* n_out) {
-  if (int rc = list.ensure(cap * sizeof(u64) / 2 + 64, 0, c->stream)) return rc;
-  u64 zero = 0;
-  HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_list, &zero, sizeof(u64), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_table_list, dim3(grid_for(cap, BLOCK)), dim3(BLOCK), 0, c->stream, table, cap, list.as<u64>(), (DevState*)c->state.p);
-  HIPC(hipGetLastError());
-  if (int rc = sync_state(c)) return rc;
-  *n_out = c->host_state.n_list;
-  return 0;
-}
 
 int exclusive_scan(kamd_ctx* c, const u32* sizes, u64 n, u64* out, u64* d_total) {
   const u64 nblocks = std::max<u64>(1, (n + SCAN_ELEMS - 1) / SCAN_ELEMS);
@@ -1310,7 +1294,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
-                  &c->em_state, &c->em_wrow, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow, &c->em_colw,
+                  &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->pt_label, &c->pt_flag, &c->pt_len,
                   &c->pt_rowpos, &c->pt_nnzpos, &c->pt_off, &c->pt_ids, &c->pt_counts, &c->pt_wcounts, &c->pt_hist, &c->pt_ck_alpha,
                   &c->pt_ck_a})
