@@ -885,23 +885,39 @@ __global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Kernel B: EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223), FP64, four launches per round and no atomics on the data:
+// Kernel B: EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223), FP64, three launches per round and no atomics on the data:
 //   k_em_rows   one EC row per 4-lane group: denom_e = sum_t alpha[t] * w[e,t]  ->  cn[e] = counts[e] / denom_e
 //   k_em_seg    the transposed (transcript-major) copy of the matrix, cut into segments of <= 64 entries:
 //               partial[s] = sum_{e in segment} (w[e,t] * alpha[t]) * cn[e]   (+ counts[e] for singleton rows)
 //   k_em_final  next[t] = sum of t's segment sums and the convergence test of :176-199
-//   k_em_control (one thread) the loop control of :202-221.
+// (the loop control of :202-221 is evaluated by every block from the previous round's record -- see EmState)
 // alpha is double-buffered (round i reads A[i&1], writes A[(i+1)&1]); the clamp of the final round (:212-221) is applied
 // on read, so the unclamped buffer is alpha_before_zeroes_.
 // ------------------------------------------------------------------------------------------------------------------
+// Loop control without a control kernel.  Two records, indexed by the parity of the launch: the kernels of a round read
+// the record the PREVIOUS round left (iter, final flag, number of transcripts that still changed) and every block derives
+// from it -- identically -- what the reference's loop would do next (:202-221); block 0 of k_em_rows publishes that as this
+// round's record, k_em_final accumulates the round's change count into it.  Nothing is read and written in the same launch.
 struct EmState {
-  int iter;         // round index i
-  int chcount;
-  int blocks_done;
-  int final_round;  // finalRound: this round reads the clamped alpha and is the last one
+  int iter;         // round index i this record's round ran as (-1: before the first round)
+  int chcount;      // transcripts with next > 1e-2 that moved by more than 1 % in that round (:177-179)
+  int final_round;  // finalRound: the round read the clamped alpha and was the last one
   int done;
   int rounds;       // i at exit ("ran for i rounds")
+  int force_final;  // host request (partitioned EM): the next round is the final round
+  int pad[2];
 };
+struct EmNow { int it, fin, done, rounds; };
+__host__ __device__ inline EmNow em_next_round(const EmState& prev, int n_iter, int min_rounds, bool spec) {
+  EmNow n; n.it = prev.iter; n.fin = prev.final_round; n.done = prev.done; n.rounds = prev.rounds;
+  if (n.done) return n;                                                              // (fin keeps telling how the loop ended)
+  if (prev.final_round) { n.done = 1; n.rounds = prev.iter; return n; }              // :207-209 (break: i is not incremented)
+  const bool stopEM = !spec && prev.chcount == 0 && prev.iter > min_rounds;          // :202-205
+  n.it = prev.iter + 1;
+  n.fin = (stopEM || prev.force_final) ? 1 : 0;                                      // :212-221 (clamp applied on read)
+  if (n.it >= n_iter) { n.done = 1; n.rounds = n_iter; }                             // the loop ran out
+  return n;
+}
 // Algebra used by the kernels.  With a_t = alpha_t / eff_len_t the reference's row pass
 //     denom_e = sum_t alpha_t * (wc_e / eff_t) = wc_e * S_e,  S_e = sum_t a_t          (:152-154, weights.cpp:236)
 // and its update  (w_et * alpha_t) * (count_e / denom_e) = a_t * g_e,  g_e = count_e / S_e   (:161-164; wc_e cancels,
@@ -944,12 +960,21 @@ __global__ __launch_bounds__(BLOCK) void k_em_rows(const u64* __restrict__ ec_of
                                                    const u32* __restrict__ counts, const u32* __restrict__ wcounts, u64 n_ecs,
                                                    const double* __restrict__ alpha0, const double* __restrict__ alpha1,
                                                    const double* __restrict__ a0, const double* __restrict__ a1,
-                                                   double* __restrict__ g, const EmState* st) {
-  if (st->done) return;
-  const int odd = st->iter & 1;
+                                                   double* __restrict__ g, EmState* st, int parity, int n_iter, int min_rounds,
+                                                   int* spec_hist) {
+  const EmState prev = st[parity ^ 1];
+  const EmNow now = em_next_round(prev, n_iter, min_rounds, spec_hist != nullptr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // publish this round's record (chcount starts at 0 for k_em_final)
+    EmState r; r.iter = now.it; r.chcount = 0; r.final_round = now.fin; r.done = now.done; r.rounds = now.rounds; r.force_final = 0;
+    r.pad[0] = r.pad[1] = 0;
+    st[parity] = r;
+    if (spec_hist && !prev.done && prev.iter >= 0) spec_hist[prev.iter] = prev.chcount;
+  }
+  if (now.done) return;
+  const int odd = now.it & 1;
   const double* alpha = odd ? alpha1 : alpha0;
   const double* av = odd ? a1 : a0;
-  const int clamp = st->final_round;
+  const int clamp = now.fin;
   const u64 e = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_ROW_LANES;
   const int sub = threadIdx.x & (EM_ROW_LANES - 1);
   double S = 0.0;
@@ -985,8 +1010,9 @@ __global__ void k_em_segsetup(const u64* __restrict__ col_off, const u64* __rest
 }
 __global__ __launch_bounds__(BLOCK) void k_em_seg(const u64* __restrict__ col_off, const u64* __restrict__ seg_off,
                                                   const u32* __restrict__ seg_t, u64 n_seg, const u32* __restrict__ col_row,
-                                                  const double* __restrict__ g, double* __restrict__ partial, const EmState* st) {
-  if (st->done) return;
+                                                  const double* __restrict__ g, double* __restrict__ partial, const EmState* st,
+                                                  int parity, int n_iter, int min_rounds, int spec) {
+  if (em_next_round(st[parity ^ 1], n_iter, min_rounds, spec != 0).done) return;
   const u64 sidx = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / EM_SEG_LANES;
   const int sub = threadIdx.x & (EM_SEG_LANES - 1);
   double acc = 0.0;
@@ -1009,14 +1035,16 @@ __global__ __launch_bounds__(BLOCK) void k_em_seg(const u64* __restrict__ col_of
 }
 __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_off, const double* __restrict__ partial,
                                                     const double* __restrict__ single, const double* __restrict__ eff, u64 n_tr,
-                                                    double* alpha0, double* alpha1, double* a0, double* a1, EmState* st) {
-  if (st->done) return;
-  const int it = st->iter, odd = it & 1;
+                                                    double* alpha0, double* alpha1, double* a0, double* a1, EmState* st, int parity,
+                                                    int n_iter, int min_rounds, int spec) {
+  const EmNow now = em_next_round(st[parity ^ 1], n_iter, min_rounds, spec != 0);
+  if (now.done) return;
+  const int it = now.it, odd = it & 1;
   const double* alpha = odd ? alpha1 : alpha0;
   const double* av = odd ? a1 : a0;
   double* next = odd ? alpha0 : alpha1;
   double* anext = odd ? a0 : a1;
-  const int clamp = st->final_round;
+  const int clamp = now.fin;
   const int sub = threadIdx.x & (EM_FIN_LANES - 1);
   __shared__ int blk_ch;
   if (threadIdx.x == 0) blk_ch = 0;
@@ -1045,31 +1073,8 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
   for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
   if (lane_id() == 0 && bal) atomicAdd(&blk_ch, wsum);
   __syncthreads();
-  if (threadIdx.x == 0 && blk_ch) atomicAdd(&st->chcount, blk_ch);
+  if (threadIdx.x == 0 && blk_ch) atomicAdd(&st[parity].chcount, blk_ch);
 }
-// loop control of :202-221, one thread, after the round's k_em_final (a kernel boundary orders it behind every block;
-// an in-kernel "last block" hand-off would need an agent-scope fence per block, which flushes the L2 each time)
-// spec_hist != nullptr (EM partitioned over several GPUs): no rank may decide alone, so the round's count of changed
-// transcripts is only recorded (spec_hist[round]) and the loop keeps going; the host sums the history over the ranks after
-// every chunk of rounds and rewinds to the round at which the global test fires (em_run_impl).
-__global__ void k_em_control(EmState* st, int n_iter, int min_rounds, int* spec_hist) {
-  if (st->done) return;
-  const int it = st->iter;
-  if (spec_hist) {
-    spec_hist[it] = st->chcount;
-    st->chcount = 0;
-    if (st->final_round) { st->done = 1; st->rounds = it; return; }
-    st->iter = it + 1;
-    return;
-  }
-  const bool stopEM = (st->chcount == 0 && it > min_rounds);     // :202-205
-  st->chcount = 0;
-  if (st->final_round) { st->done = 1; st->rounds = it; return; } // :207-209
-  if (stopEM) st->final_round = 1;                                // :212-221 (clamp applied on read next round)
-  st->iter = it + 1;
-  if (it + 1 >= n_iter) { st->done = 1; st->rounds = it + 1; }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // EM over several GPUs: the EC x transcript matrix is block diagonal over the connected components of the
 // transcript/EC graph (gene families), and the EM update never crosses a component, so each rank runs the unchanged
@@ -1835,7 +1840,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   }
   for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_eff, &c->em_a0, &c->em_a1, &c->em_single})
     if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
-  if (int rc = c->em_state.ensure(sizeof(EmState), 0, c->stream)) return rc;
+  if (int rc = c->em_state.ensure(2 * sizeof(EmState), 0, c->stream)) return rc;
   if (int rc = c->em_colrow.ensure((nnz + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->em_cn.ensure((n_ecs + 1) * sizeof(double), 0, c->stream)) return rc;
   if (int rc = c->em_colcnt.ensure(3 * (T + 1) * sizeof(u32), 0, c->stream)) return rc;
@@ -1846,7 +1851,11 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   HIPC(hipMemcpyAsync(c->em_eff.p, eff_lens, T * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPC(hipMemsetAsync(col_cnt, 0, 2 * (T + 1) * sizeof(u32), c->stream));
   HIPC(hipMemsetAsync(c->em_single.p, 0, T * sizeof(double), c->stream));
-  HIPC(hipMemsetAsync(c->em_state.p, 0, sizeof(EmState), c->stream));
+  // the record "before round 0" lives in slot 1 (round 0 has parity 0): iter -1 with a non-zero change count
+  EmState st_init[2]; memset(st_init, 0, sizeof st_init);
+  st_init[1].iter = -1; st_init[1].chcount = 1;
+  HIPC(hipMemcpyAsync(c->em_state.p, st_init, sizeof st_init, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));  // st_init is a stack buffer
   HIPC(hipEventRecord(c->ev0, c->stream));
   // transposed (transcript-major) structure of the multi-transcript rows, built once per run
   if (n_ecs) hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
@@ -1891,25 +1900,36 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     if (int rc = c->pt_ck_alpha.ensure(T * sizeof(double), 0, c->stream)) return rc;
     if (int rc = c->pt_ck_a.ensure(T * sizeof(double), 0, c->stream)) return rc;
   }
+  int parity = 0;  // parity of the next round to enqueue (round r uses record r & 1 and reads record (r & 1) ^ 1)
   auto enqueue_rounds = [&](hipStream_t s, int n_rounds) {
-    for (int it = 0; it < n_rounds; it++) {
+    for (int it = 0; it < n_rounds; it++, parity ^= 1) {
 #define KAMD_LAUNCH_ROWS(L)                                                                                                        \
   hipLaunchKernelGGL(k_em_rows<L>, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, (u64)n_ecs, \
                      c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(), c->em_a1.as<double>(),              \
-                     c->em_cn.as<double>(), (const EmState*)c->em_state.p)
+                     c->em_cn.as<double>(), (EmState*)c->em_state.p, parity, (int)n_iter, (int)min_rounds, spec_hist)
       if (row_lanes == 8) KAMD_LAUNCH_ROWS(8); else if (row_lanes == 2) KAMD_LAUNCH_ROWS(2); else KAMD_LAUNCH_ROWS(4);
 #undef KAMD_LAUNCH_ROWS
       hipLaunchKernelGGL(k_em_seg, dim3(grid_seg), dim3(BLOCK), 0, s, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(),
                          c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_cn.as<double>(), c->em_partial.as<double>(),
-                         (const EmState*)c->em_state.p);
+                         (const EmState*)c->em_state.p, parity, (int)n_iter, (int)min_rounds, spec ? 1 : 0);
       hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, s, c->em_segoff.as<u64>(), c->em_partial.as<double>(),
                          c->em_single.as<double>(), c->em_eff.as<double>(), T, c->em_alpha.as<double>(), c->em_next.as<double>(),
-                         c->em_a0.as<double>(), c->em_a1.as<double>(), (EmState*)c->em_state.p);
-      hipLaunchKernelGGL(k_em_control, dim3(1), dim3(1), 0, s, (EmState*)c->em_state.p, (int)n_iter, (int)min_rounds, spec_hist);
+                         c->em_a0.as<double>(), c->em_a1.as<double>(), (EmState*)c->em_state.p, parity, (int)n_iter, (int)min_rounds,
+                         spec ? 1 : 0);
     }
+  };
+  // state after the rounds enqueued so far: apply the loop rule once more to the last record (the round that notices
+  // "the previous round was final" has not run yet)
+  EmState recs[2];
+  auto read_state = [&](hipStream_t s, EmNow* now) -> int {
+    HIPC(hipMemcpyAsync(recs, c->em_state.p, sizeof recs, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    *now = em_next_round(recs[parity ^ 1], (int)n_iter, (int)min_rounds, spec);
+    return 0;
   };
   double* bufs_alpha[2] = {c->em_alpha.as<double>(), c->em_next.as<double>()};
   double* bufs_a[2] = {c->em_a0.as<double>(), c->em_a1.as<double>()};
+  EmNow now{};
   if (!spec) {
     const char* eg = getenv("KAMD_EM_GRAPH");
     bool use_graph = !(eg && atoi(eg) == 0);
@@ -1921,18 +1941,19 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
       HIPC(hipEventRecord(c->ev2, c->stream));           // the private stream starts after the preparation kernels
       HIPC(hipStreamWaitEvent(es, c->ev2, 0));
       HIPC(hipStreamBeginCapture(es, hipStreamCaptureModeThreadLocal));
-      enqueue_rounds(es, chunk);
+      enqueue_rounds(es, chunk);                         // chunk is even: the captured parities 0,1,0,1... repeat on replay
       HIPC(hipStreamEndCapture(es, &graph));
       HIPC(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     }
-    while (!hs.done) {
+    for (;;) {
       if (use_graph) HIPC(hipGraphLaunch(gexec, es)); else enqueue_rounds(es, chunk);
       HIPC(hipGetLastError());
-      HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, es));
-      HIPC(hipStreamSynchronize(es));
+      if (int rc = read_state(es, &now)) return rc;
+      if (now.done) break;
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
+    hs.done = 1; hs.rounds = now.rounds; hs.final_round = now.fin;
   } else {
     // Partitioned EM: run a chunk of rounds speculatively, sum the per-round change counts over the ranks (the callback;
     // also the only synchronisation between ranks), find the first round s at which the reference's test
@@ -1946,7 +1967,9 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
       const int n_run = (int)std::min<long>(chunk, (long)n_iter - base);
       enqueue_rounds(c->stream, n_run);
       HIPC(hipGetLastError());
-      HIPC(hipStreamSynchronize(c->stream));
+      if (int rc = read_state(c->stream, &now)) return rc;
+      // the history entry of a round is written by the NEXT round's k_em_rows; the chunk's last one is still in its record
+      HIPC(hipMemcpy(spec_hist + base + n_run - 1, &recs[parity ^ 1].chcount, sizeof(int), hipMemcpyHostToDevice));
       if (int rc = part.cb(part.user, spec_hist + base, n_run)) return kamd::fail(-103, "kamd_em_run_partitioned: the sum callback failed (" + std::to_string(rc) + ")");
       HIPC(hipMemcpy(hist.data(), spec_hist + base, n_run * sizeof(int), hipMemcpyDeviceToHost));
       int stop = -1;
@@ -1959,16 +1982,20 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
       // rewind + replay rounds base..stop, then the clamped final round
       HIPC(hipMemcpyAsync(bufs_alpha[base & 1], c->pt_ck_alpha.p, T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       HIPC(hipMemcpyAsync(bufs_a[base & 1], c->pt_ck_a.p, T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      EmState st0{}; st0.iter = base;
-      HIPC(hipMemcpyAsync(c->em_state.p, &st0, sizeof(EmState), hipMemcpyHostToDevice, c->stream));
+      EmState st0[2]; memset(st0, 0, sizeof st0);
+      st0[1].iter = base - 1; st0[1].chcount = 1;                  // "the round before `base`" in slot 1, next parity 0
+      HIPC(hipMemcpyAsync(c->em_state.p, st0, sizeof st0, hipMemcpyHostToDevice, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));                       // st0 is a stack buffer
+      parity = 0;
       enqueue_rounds(c->stream, stop - base + 1);
-      EmState st1{}; st1.iter = stop + 1; st1.final_round = 1;
-      HIPC(hipStreamSynchronize(c->stream));  // st0 is a stack variable
-      HIPC(hipMemcpyAsync(c->em_state.p, &st1, sizeof(EmState), hipMemcpyHostToDevice, c->stream));
+      if (int rc = read_state(c->stream, &now)) return rc;
+      const int one = 1;                                           // ask for the final round
+      HIPC(hipMemcpy(&((EmState*)c->em_state.p)[parity ^ 1].force_final, &one, sizeof(int), hipMemcpyHostToDevice));
       enqueue_rounds(c->stream, 1);
-      HIPC(hipMemcpyAsync(&hs, c->em_state.p, sizeof(EmState), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
-      if (!hs.done || hs.rounds != stop + 1) return kamd::fail(-101, "kamd_em_run_partitioned: replay did not end on the final round");
+      if (int rc = read_state(c->stream, &now)) return rc;
+      if (!now.done || now.rounds != stop + 1 || !now.fin)
+        return kamd::fail(-101, "kamd_em_run_partitioned: replay did not end on the final round");
+      hs.done = 1; hs.rounds = now.rounds; hs.final_round = 1;
       break;
     }
   }
