@@ -950,9 +950,19 @@ __global__ void k_em_transpose(const u64* __restrict__ ec_off, const u32* __rest
     col_row[col_off[t] + atomicAdd(&col_fill[t], 1u)] = (u32)e;
   }
 }
-__global__ void k_em_init(u64 n_tr, const double* __restrict__ eff, double* alpha, double* a) {
+// alpha_ = 1/T (:38).  A transcript that is in no EC at all gets next = 0 in every round and is never read by another
+// transcript's update, so it is kept at 0 from the start and left out of k_em_final's work list (same outputs).
+__global__ void k_em_active(u64 n_tr, const u32* __restrict__ col_cnt, const double* __restrict__ single, u32* flag) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_tr) { const double al = 1.0 / (double)n_tr; alpha[t] = al; a[t] = al / eff[t]; }  // :38
+  if (t < n_tr) flag[t] = (col_cnt[t] != 0u || single[t] != 0.0) ? 1u : 0u;
+}
+__global__ void k_em_init(u64 n_tr, const double* __restrict__ eff, const u32* __restrict__ flag, const u64* __restrict__ pos,
+                          double* alpha0, double* alpha1, double* a0, double* a1, u32* active) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tr) return;
+  const double al = flag[t] ? 1.0 / (double)n_tr : 0.0;
+  alpha0[t] = al; a0[t] = al / eff[t]; alpha1[t] = 0.0; a1[t] = 0.0;
+  if (flag[t]) active[pos[t]] = (u32)t;
 }
 
 template <int EM_ROW_LANES>
@@ -1034,7 +1044,8 @@ __global__ __launch_bounds__(BLOCK) void k_em_seg(const u64* __restrict__ col_of
   if (sidx < n_seg && sub == 0) partial[sidx] = acc;
 }
 __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_off, const double* __restrict__ partial,
-                                                    const double* __restrict__ single, const double* __restrict__ eff, u64 n_tr,
+                                                    const double* __restrict__ single, const double* __restrict__ eff,
+                                                    const u32* __restrict__ active, u64 n_tr,
                                                     double* alpha0, double* alpha1, double* a0, double* a1, EmState* st, int parity,
                                                     int n_iter, int min_rounds, int spec) {
   const EmNow now = em_next_round(st[parity ^ 1], n_iter, min_rounds, spec != 0);
@@ -1052,12 +1063,14 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
   int ch = 0;
   // grid-stride over groups of BLOCK / EM_FIN_LANES transcripts: the convergence counter costs one atomic per block
   for (u64 t0 = (u64)blockIdx.x * (BLOCK / EM_FIN_LANES); t0 < n_tr; t0 += (u64)gridDim.x * (BLOCK / EM_FIN_LANES)) {
-    const u64 t = t0 + threadIdx.x / EM_FIN_LANES;
+    const u64 ai = t0 + threadIdx.x / EM_FIN_LANES;  // n_tr = number of active transcripts
+    const bool ok = ai < n_tr;
+    const u64 t = ok ? active[ai] : 0;
     double acc = 0.0;
-    if (t < n_tr) for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
+    if (ok) for (u64 s = seg_off[t] + sub; s < seg_off[t + 1]; s += EM_FIN_LANES) acc += partial[s];
 #pragma unroll
     for (int d = 1; d < EM_FIN_LANES; d <<= 1) acc += __shfl_xor(acc, d, 64);
-    if (t < n_tr && sub == 0) {
+    if (ok && sub == 0) {
       double al = alpha[t];
       if (clamp && al < 1e-7 / 10.0) al = 0.0;
       const double at = clamp ? em_clamped(alpha, av, (u32)t, 1) : av[t];
@@ -1159,7 +1172,7 @@ struct kamd_ctx {
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw;
   DBuf ec_off, ec_ids, ec_counts;
-  DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single;
+  DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
@@ -1300,7 +1313,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
-                  &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->pt_label, &c->pt_flag, &c->pt_len,
+                  &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
                   &c->pt_rowpos, &c->pt_nnzpos, &c->pt_off, &c->pt_ids, &c->pt_counts, &c->pt_wcounts, &c->pt_hist, &c->pt_ck_alpha,
                   &c->pt_ck_a})
     b->release();
@@ -1863,8 +1876,18 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
   if (n_ecs) hipLaunchKernelGGL(k_em_transpose, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
                                 (u64)n_ecs, c->em_coloff.as<u64>(), col_fill, c->em_colrow.as<u32>());
-  hipLaunchKernelGGL(k_em_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_eff.as<double>(), c->em_alpha.as<double>(),
-                     c->em_a0.as<double>());
+  // work list of k_em_final: transcripts that occur in some EC
+  if (int rc = c->em_actflag.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->em_actpos.ensure((T + 2) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->em_active.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_em_active, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, col_cnt, c->em_single.as<double>(),
+                     c->em_actflag.as<u32>());
+  if (int rc = exclusive_scan(c, c->em_actflag.as<u32>(), T, c->em_actpos.as<u64>(), c->em_actpos.as<u64>() + T)) return rc;
+  hipLaunchKernelGGL(k_em_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_eff.as<double>(), c->em_actflag.as<u32>(),
+                     c->em_actpos.as<u64>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(),
+                     c->em_a1.as<double>(), c->em_active.as<u32>());
+  u64 n_active = 0;
+  HIPC(hipMemcpyAsync(&n_active, c->em_actpos.as<u64>() + T, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   // column segments
   u32* nseg = col_cnt + 2 * (T + 1);
   hipLaunchKernelGGL(k_em_nseg, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, col_cnt, T, nseg);
@@ -1888,7 +1911,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   const unsigned grid_seg = grid_for(std::max<u64>(n_seg, 1) * EM_SEG_LANES, BLOCK);
   unsigned fin_cap = 1024;
   if (const char* e = getenv("KAMD_EM_FIN_BLOCKS")) fin_cap = (unsigned)std::max(64, atoi(e));
-  const unsigned grid_fin = (unsigned)std::min<u64>(grid_for(T * EM_FIN_LANES, BLOCK), fin_cap);
+  const unsigned grid_fin = (unsigned)std::min<u64>(grid_for(std::max<u64>(n_active, 1) * EM_FIN_LANES, BLOCK), fin_cap);
   // The launch-bound inner loop is captured once as a hipGraph of `chunk` rounds (4 kernels each) on a private stream
   // and replayed until the device-side state says done; all loop state lives in device memory, so every replay is
   // the same graph.  KAMD_EM_GRAPH=0 falls back to plain launches.
@@ -1913,7 +1936,8 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
                          c->em_segt.as<u32>(), n_seg, c->em_colrow.as<u32>(), c->em_cn.as<double>(), c->em_partial.as<double>(),
                          (const EmState*)c->em_state.p, parity, (int)n_iter, (int)min_rounds, spec ? 1 : 0);
       hipLaunchKernelGGL(k_em_final, dim3(grid_fin), dim3(BLOCK), 0, s, c->em_segoff.as<u64>(), c->em_partial.as<double>(),
-                         c->em_single.as<double>(), c->em_eff.as<double>(), T, c->em_alpha.as<double>(), c->em_next.as<double>(),
+                         c->em_single.as<double>(), c->em_eff.as<double>(), c->em_active.as<u32>(), n_active, c->em_alpha.as<double>(),
+                         c->em_next.as<double>(),
                          c->em_a0.as<double>(), c->em_a1.as<double>(), (EmState*)c->em_state.p, parity, (int)n_iter, (int)min_rounds,
                          spec ? 1 : 0);
     }
