@@ -93,6 +93,10 @@ uint64_t kamd_packed_record_words(int32_t max_len);
 /* host packer: seqs = concatenated sequences (no terminators needed), off[i]/len[i] locate read i */
 int kamd_pack_reads_host(const char* seqs, const uint64_t* off, const int32_t* len, uint64_t n_reads, int32_t max_len,
                          uint32_t* out_words, uint16_t* out_len);
+/* same, writing read r to record slot rec_first + r * rec_stride (mates of a pair from two files: stride 2, first 0 / 1);
+ * re-entrant, so a front-end may pack disjoint ranges from several threads */
+int kamd_pack_reads_host_strided(const char* seqs, const uint64_t* off, const int32_t* len, uint64_t n_reads, int32_t max_len,
+                                 uint32_t* out_words, uint16_t* out_len, uint64_t rec_stride, uint64_t rec_first);
 /* device packer: same, d_* are device pointers; runs on the context stream */
 int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off, const int32_t* d_len, uint64_t n_reads,
                            int32_t max_len, uint32_t* d_out_words, uint16_t* d_out_len);

@@ -72,6 +72,8 @@ _SYMBOLS = {
     "kamd_ec_reset": (C.c_int, [C.c_void_p]),
     "kamd_packed_record_words": (C.c_uint64, [C.c_int32]),
     "kamd_pack_reads_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "kamd_pack_reads_host_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_uint64, C.c_uint64]),
     "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "kamd_pseudoalign": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),

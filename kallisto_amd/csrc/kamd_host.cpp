@@ -22,11 +22,19 @@ extern "C" uint64_t kamd_packed_record_words(int32_t max_len) {
 
 extern "C" int kamd_pack_reads_host(const char* seqs, const uint64_t* off, const int32_t* len, uint64_t n_reads,
                                     int32_t max_len, uint32_t* out_words, uint16_t* out_len) {
+  return kamd_pack_reads_host_strided(seqs, off, len, n_reads, max_len, out_words, out_len, 1, 0);
+}
+
+extern "C" int kamd_pack_reads_host_strided(const char* seqs, const uint64_t* off, const int32_t* len, uint64_t n_reads,
+                                            int32_t max_len, uint32_t* out_words, uint16_t* out_len, uint64_t rec_stride,
+                                            uint64_t rec_first) {
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pack_reads: max_len must be in [1, 65535]");
+  if (rec_stride == 0) return kamd::fail(-1, "kamd_pack_reads: record stride must be positive");
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
   for (uint64_t r = 0; r < n_reads; r++) {
     if (len[r] < 0 || len[r] > max_len) return kamd::fail(-1, "kamd_pack_reads: read longer than max_len");
-    uint32_t* w = out_words + r * rec;
+    const uint64_t slot = rec_first + r * rec_stride;
+    uint32_t* w = out_words + slot * rec;
     memset(w, 0, rec * 4);
     const char* s = seqs + off[r];
     for (int32_t i = 0; i < len[r]; i++) {
@@ -42,7 +50,7 @@ extern "C" int kamd_pack_reads_host(const char* seqs, const uint64_t* off, const
       if (code < 4) w[i >> 4] |= code << (2 * (i & 15));
       else w[sw + (i >> 5)] |= 1u << (i & 31);
     }
-    out_len[r] = (uint16_t)len[r];
+    out_len[slot] = (uint16_t)len[r];
   }
   return 0;
 }

@@ -16,7 +16,11 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/kallisto_amd.h"
@@ -110,6 +114,84 @@ class SeqReader {
   size_t pos_ = 0, len_ = 0;
   std::string header_;
   bool pending_header_ = false;
+};
+
+// ---- fast path for plain (uncompressed) 4-line FASTQ: mmap + one parser thread per chunk --------------------------------
+// FastqSequenceReader::fetchSequences (src/ProcessReads.cpp:3128-3267) parses serially under a lock; here every thread scans
+// its slice of the file for record starts and the records are paired by index afterwards.
+struct MappedFastq {
+  const char* data = nullptr; size_t size = 0; int fd = -1;
+  std::vector<uint64_t> off; std::vector<int32_t> len;   // sequence line of every record
+  bool open(const std::string& path) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size == 0) return false;
+    size = (size_t)st.st_size;
+    void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) return false;
+    madvise(p, size, MADV_SEQUENTIAL);
+    data = (const char*)p;
+    return true;
+  }
+  void close() { if (data) munmap((void*)data, size); if (fd >= 0) ::close(fd); data = nullptr; fd = -1; }
+  static bool is_gzip(const std::string& path) {
+    unsigned char m[2] = {0, 0};
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    size_t n = fread(m, 1, 2, f); fclose(f);
+    return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+  }
+  const char* next_line(const char* p) const { const char* e = (const char*)memchr(p, '\n', data + size - p); return e ? e + 1 : data + size; }
+  // first record start at or after p: a line starting with '@' whose third line starts with '+' and whose second and
+  // fourth lines have equal length (a quality line may itself start with '@')
+  const char* find_record(const char* p) const {
+    const char* end = data + size;
+    if (p != data) { const char* q = (const char*)memchr(p - 1, '\n', end - (p - 1)); p = q ? q + 1 : end; }
+    while (p < end) {
+      if (*p == '@') {
+        const char* l1 = next_line(p); const char* l2 = next_line(l1); const char* l3 = next_line(l2); const char* l4 = next_line(l3);
+        if (l2 < end && *l2 == '+') {
+          const int64_t seq_len = (l2 - l1) - ((l2 > l1 && l2[-1] == '\n') ? 1 : 0);
+          const int64_t qual_len = (l4 - l3) - ((l4 > l3 && l4[-1] == '\n') ? 1 : 0);
+          if (seq_len == qual_len) return p;
+        }
+      }
+      p = next_line(p);
+    }
+    return end;
+  }
+  // returns false if the file is not plain 4-line FASTQ (the caller then uses the serial reader)
+  bool index_records(int threads) {
+    if (size == 0 || data[0] != '@') return false;
+    size_t min_chunk = 1 << 20;
+    if (const char* e = getenv("KAMD_FASTQ_CHUNK")) min_chunk = std::max<size_t>(64, strtoull(e, nullptr, 10));
+    threads = std::max(1, std::min(threads, (int)(size / min_chunk) + 1));
+    std::vector<const char*> starts(threads + 1);
+    starts[0] = data; starts[threads] = data + size;
+    for (int t = 1; t < threads; t++) starts[t] = find_record(data + size / threads * t);
+    std::vector<std::vector<uint64_t>> offs(threads); std::vector<std::vector<int32_t>> lens(threads);
+    std::vector<char> ok(threads, 1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back([&, t] {
+      const char* p = starts[t]; const char* end = starts[t + 1];
+      while (p < end) {
+        if (*p != '@') { ok[t] = 0; return; }
+        const char* l1 = next_line(p); const char* l2 = next_line(l1);
+        if (l1 >= data + size || l2 > data + size || (l2 < data + size && *l2 != '+')) { ok[t] = 0; return; }
+        int64_t n = (l2 - l1) - ((l2 > l1 && l2[-1] == '\n') ? 1 : 0);
+        if (n > 0 && l1[n - 1] == '\r') --n;
+        offs[t].push_back((uint64_t)(l1 - data)); lens[t].push_back((int32_t)n);
+        p = next_line(next_line(l2));
+      }
+    });
+    for (auto& x : th) x.join();
+    size_t total = 0;
+    for (int t = 0; t < threads; t++) { if (!ok[t]) return false; total += offs[t].size(); }
+    off.reserve(total); len.reserve(total);
+    for (int t = 0; t < threads; t++) { off.insert(off.end(), offs[t].begin(), offs[t].end()); len.insert(len.end(), lens[t].begin(), lens[t].end()); }
+    return true;
+  }
 };
 
 #define HIPX(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::cerr << "Error: " #x ": " << hipGetErrorString(e_) << std::endl; exit(1); } } while (0)
@@ -218,9 +300,51 @@ int main(int argc, char** argv) {
     if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
     seqs.clear(); off.clear(); len.clear();
   };
+  const int host_threads = std::max(1, opt.threads);
   for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
     std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
     if (paired) std::cerr << "                             " << opt.files[fi + 1] << std::endl;
+    // plain 4-line FASTQ: memory-map, index the records with all host threads, pack batches in parallel
+    if (!MappedFastq::is_gzip(opt.files[fi]) && (!paired || !MappedFastq::is_gzip(opt.files[fi + 1]))) {
+      MappedFastq m1, m2;
+      bool fast = m1.open(opt.files[fi]) && m1.index_records(host_threads);
+      if (fast && paired) fast = m2.open(opt.files[fi + 1]) && m2.index_records(host_threads);
+      if (fast) {
+        if (paired && m1.off.size() != m2.off.size()) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
+        flush();  // anything buffered by the serial reader of an earlier file
+        const uint64_t n_items_total = m1.off.size();
+        for (uint64_t b0 = 0; b0 < n_items_total; b0 += opt.batch) {
+          const uint64_t nb = std::min<uint64_t>(opt.batch, n_items_total - b0);
+          int32_t max_len = 1;
+          for (uint64_t i = b0; i < b0 + nb; i++) { max_len = std::max(max_len, m1.len[i]); if (paired) max_len = std::max(max_len, m2.len[i]); }
+          if (max_len > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; return 1; }
+          const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
+          words.resize(n_reads * rec); l16.resize(n_reads);
+          std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0);
+          for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
+            const uint64_t a = b0 + nb * t / host_threads, e = b0 + nb * (t + 1) / host_threads;
+            if (e == a) return;
+            const uint64_t first = (a - b0) * (paired ? 2 : 1);
+            rcs[t] = kamd_pack_reads_host_strided(m1.data, m1.off.data() + a, m1.len.data() + a, e - a, max_len, words.data(), l16.data(), paired ? 2 : 1, first);
+            if (paired && rcs[t] == 0)
+              rcs[t] = kamd_pack_reads_host_strided(m2.data, m2.off.data() + a, m2.len.data() + a, e - a, max_len, words.data(), l16.data(), 2, first + 1);
+          });
+          for (auto& x : th) x.join();
+          for (int rc : rcs) if (rc) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+          if (words.size() > cap_words) { if (d_words) HIPX(hipFree(d_words)); cap_words = words.size() * 5 / 4; HIPX(hipMalloc((void**)&d_words, cap_words * 4)); }
+          if (l16.size() > cap_len) { if (d_len) HIPX(hipFree(d_len)); cap_len = l16.size() * 5 / 4; HIPX(hipMalloc((void**)&d_len, cap_len * 2)); }
+          HIPX(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+          HIPX(hipMemcpy(d_len, l16.data(), l16.size() * 2, hipMemcpyHostToDevice));
+          KX(kamd_pseudoalign(ctx, &qo, d_words, d_len, nb, max_len));
+          if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, d_words, d_len, nb, max_len, flens, &fld_used));
+          n_processed += nb;
+          if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
+        }
+        m1.close(); m2.close();
+        continue;
+      }
+      m1.close(); m2.close();
+    }
     SeqReader r1(opt.files[fi]);
     SeqReader* r2 = paired ? new SeqReader(opt.files[fi + 1]) : nullptr;
     std::string s1, s2;

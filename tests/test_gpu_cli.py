@@ -43,8 +43,9 @@ def test_cli_matches_reference_cli(case, variant, tmp_path):
         _fastq(f2, r2)
         files.append(f2)
     out = str(tmp_path / "out")
-    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--batch", "1500", *cli, *files],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    # -t 7 + a tiny chunk size force the parallel memory-mapped FASTQ reader to split these small files into many chunks
+    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--batch", "1500", "-t", "7", *cli, *files],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KAMD_FASTQ_CHUNK="3000"))
     assert p.returncode == 0, p.stderr.decode()
     gold = os.path.join(common.case_dir(case), "cli_" + variant)
     # run_info.json: same keys in the same order, same values (start_time / call excluded)
@@ -74,6 +75,18 @@ def test_cli_matches_reference_cli(case, variant, tmp_path):
         tpm = np.array([float(r[4]) for r in rows]); gtpm = np.array([float(r[4]) for r in grows])
         common.assert_abundance_close(est, gest, fn + " est_counts", rel=1e-4, floor=1e-5)
         common.assert_abundance_close(tpm, gtpm, fn + " tpm", rel=1e-4, floor=1e-5)
+    if case == "human_pe" and variant == "pe":
+        # gzip input goes through the serial zlib reader: same result
+        import gzip
+        gz = []
+        for f in files:
+            with open(f, "rb") as fi, gzip.open(f + ".gz", "wb") as fo:
+                fo.write(fi.read())
+            gz.append(f + ".gz")
+        out2 = str(tmp_path / "out_gz")
+        p2 = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out2, "--plaintext", *cli, *gz], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p2.returncode == 0, p2.stderr.decode()
+        assert open(os.path.join(out2, "abundance.tsv")).read() == open(os.path.join(out, "abundance.tsv")).read()
     if case == "ref_test_pe" and variant == "pe":
         # BASELINE config #1: the md5 the survey pinned for the reference's abundance.tsv
         md5 = hashlib.md5(open(os.path.join(out, "abundance.tsv"), "rb").read()).hexdigest()
