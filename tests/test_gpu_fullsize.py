@@ -1,0 +1,109 @@
+"""BASELINE.json's full size (config #3: human-sized index, 30 M PE-100 pairs on one GPU) through size-independent
+properties -- the oracle cannot run at this size in test time, so the HIP path is checked against itself and against
+conservation laws of the algorithm:
+  * batching invariance: one 30 M batch == several ragged batches (EC multiset identical);
+  * sharding linearity: multiset(shard A) + multiset(shard B) == multiset(A u B)  (what the multi-GPU merge relies on);
+  * conservation: sum of EC counts == pairs reported pseudoaligned; the EM conserves mass (sum alpha == sum counts),
+    TPM sums to 1e6, a bootstrap resample keeps N;
+  * a 20 k-pair prefix against the oracle, bit-exact.
+The index is built by the reference binary (oracle/_ref/kallisto, travels with the repo); skipped when it is absent."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    import bench
+    import kallisto_amd as ka
+    from kallisto_amd.synth_gpu import ReadSimulator
+    if not os.path.exists(bench.REF_BIN):
+        pytest.skip("oracle/_ref/kallisto not built: cannot create the human-sized index")
+    cat, tlens, idx_path = bench.prepare_workload("human", 20000, True)
+    index = ka.Index(idx_path)
+    ctx = ka.Context(0)
+    ctx.upload(index)
+    dev = torch.device("cuda", 0)
+    L, n = 100, 30_000_000
+    sim = ReadSimulator(cat, tlens, dev, seed=4242, read_len=L)
+    rec = ka.packed_record_words(L)
+    words = torch.empty(n * 2 * rec, dtype=torch.int32, device=dev)
+    lens = torch.empty(n * 2, dtype=torch.int16, device=dev)
+    prefix = None
+    for s in range(0, n, 2_000_000):
+        r1, r2 = sim.draw(2_000_000)
+        if s == 0:
+            prefix = (r1[:20000].cpu().numpy(), r2[:20000].cpu().numpy())
+        w, l = ctx.pack_reads(torch.stack([r1, r2], 1).reshape(-1, L), L)
+        words[s * 2 * rec:(s + 2_000_000) * 2 * rec] = w
+        lens[2 * s:2 * (s + 2_000_000)] = l
+    del sim
+    yield dict(ka=ka, ctx=ctx, index=index, idx_path=idx_path, words=words, lens=lens, n=n, L=L, rec=rec, prefix=prefix)
+    ctx.close()
+
+
+def _run(w, ranges):
+    ctx, ka = w["ctx"], w["ka"]
+    ctx.reset()
+    opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
+    for a, b in ranges:
+        ctx.pseudoalign(opts, w["words"][a * 2 * w["rec"]:b * 2 * w["rec"]], w["lens"][2 * a:2 * b], b - a, w["L"])
+    st = ctx.stats()
+    return ctx.finalize(), st
+
+
+def test_full_size_properties(world):
+    w = world
+    n = w["n"]
+    whole, st = _run(w, [(0, n)])
+    m_whole = whole.multiset()
+    assert st["n_processed"] == n
+    total = int(whole.counts.sum(dtype=np.uint64))
+    assert 0.99 * n < total <= n                                       # almost every synthetic pair pseudoaligns
+    assert len(m_whole) == len(whole.counts)                            # final ECs are distinct sets
+    # batching invariance (ragged batch sizes, one of them tiny)
+    cuts = [0, 1, 7_000_003, 7_000_260, 19_999_999, n]
+    batched, _ = _run(w, list(zip(cuts[:-1], cuts[1:])))
+    assert batched.multiset() == m_whole
+    # sharding linearity
+    a, _ = _run(w, [(0, n // 2)])
+    ma = a.multiset()
+    b, _ = _run(w, [(n // 2, n)])
+    for k, v in b.multiset().items():
+        ma[k] = ma.get(k, 0) + v
+    assert ma == m_whole
+    # EM conservation on the whole problem
+    import kallisto_amd.api as A
+    ctx, ka, index = w["ctx"], w["ka"], w["index"]
+    whole2, _ = _run(w, [(0, n)])
+    flens, used = ctx.fld_from_batch(ka.QuantOpts(1, 0.0, 0.0, 0, 0), w["words"], w["lens"], n, w["L"])
+    assert used == 10000 and flens.sum() == 10000
+    eff = A.eff_lens(index.target_lens, A.mean_frag_lens_trunc(flens))
+    alpha, abz, rounds = ctx.em_run(eff)
+    assert rounds > 50
+    assert abs(alpha.sum() - total) <= 1e-6 * total                     # each EM round redistributes the counts
+    tpm = A.counts_to_tpm(alpha, eff)
+    assert abs(tpm.sum() - 1e6) < 1e-3
+    assert np.all(alpha[abz < 1e-8] == 0)                               # the final clamp (EMAlgorithm.h:217-219)
+    balpha, brounds, samp = ctx.bootstrap(12345, eff, want_sample=True)
+    assert int(samp.sum(dtype=np.uint64)) == total and abs(balpha.sum() - total) <= 1e-6 * total
+
+
+def test_prefix_against_oracle(world):
+    from oracle import oracle as O
+    w = world
+    ctx, ka = w["ctx"], w["ka"]
+    r1, r2 = w["prefix"]
+    k = r1.shape[0]
+    ctx.reset()
+    res = ka.quant(ctx, ka.QuantOpts(1, 0.0, 0.0, 0, 0), [(w["words"][:k * 2 * w["rec"]], w["lens"][:2 * k], k, w["L"])])
+    oix = O.Index(w["idx_path"])
+    buf, off, ln = O.pack_read_matrix(r1, r2)
+    ores = O.process_reads(oix, O.Opts(1, 0.0, 0.0, 0, 0), buf, off, ln)
+    assert res.ecs.multiset() == ores.multiset()
+    assert np.array_equal(res.flens, ores.flens)
