@@ -170,6 +170,13 @@ typedef struct {
   const uint32_t* d_ec_ids;  /* [nnz] device */
   const uint32_t* d_counts;  /* [n_ecs] device */
 } kamd_ec_result;
+/* on != 0: kamd_ec_finalize emits the sets ordered by the first read (pair) that produced them -- the ids the reference
+ * assigns at -t 1: new sets wait in MasterProcessor::newECcount (src/ProcessReads.h:314; an insertion-ordered
+ * ankerl::unordered_dense map in C++17 builds, src/common.h:19-27) and are appended by MinCollector::increaseCount
+ * (src/ProcessReads.cpp:452-464, src/MinCollector.cpp:251-269).  Only Bootstrap -- a multinomial over the count vector
+ * in id order, src/Bootstrap.cpp:4-14 -- depends on the ids.  Call before the first batch; single-process only (merged
+ * records of several ranks have no input order). */
+int kamd_ec_track_order(kamd_ctx*, int on);
 int kamd_ec_finalize(kamd_ctx*, kamd_ec_result* out);
 int kamd_ec_download(kamd_ctx*, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts);
 

@@ -70,6 +70,7 @@ _SYMBOLS = {
     "kamd_ctx_destroy": (None, [C.c_void_p]),
     "kamd_index_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kamd_ec_reset": (C.c_int, [C.c_void_p]),
+    "kamd_ec_track_order": (C.c_int, [C.c_void_p, C.c_int]),
     "kamd_packed_record_words": (C.c_uint64, [C.c_int32]),
     "kamd_pack_reads_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "kamd_pack_reads_host_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p,
@@ -236,6 +237,10 @@ class Context:
 
     def reset(self):
         _check(load_library().kamd_ec_reset(self._h), "kamd_ec_reset")
+
+    def track_order(self, on: bool = True):
+        """finalize() then emits the sets in first-occurrence order (the reference's ids at -t 1); call before the first batch."""
+        _check(load_library().kamd_ec_track_order(self._h, 1 if on else 0), "kamd_ec_track_order")
 
     # ---- reads ----
     def pack_reads(self, seqs_u8, max_len: int | None = None):

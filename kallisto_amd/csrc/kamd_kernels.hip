@@ -68,7 +68,7 @@ struct DevState {
   u64 cand_words, cand_recs;     // candidate transcript-set stream
 };
 
-struct TSlot { u64 tag, owner, count; };
+struct TSlot { u64 tag, owner, count, first; };  // first: smallest first-occurrence key of the merged records (candidate table)
 
 // ------------------------------------------------------------------------------------------------------------------
 // wavefront helpers (64 lanes)
@@ -150,6 +150,7 @@ __device__ __forceinline__ int filter_outcome(const DevIndex& ix, const FilterDe
 // ------------------------------------------------------------------------------------------------------------------
 struct AlignOut {
   u32* dense_counts;   // [n_ecs]
+  u64* dense_first;    // [n_ecs] record-stream offset of the first single-set item that hit the set (first-occurrence order)
   u32* stream;         // records [cnt, m, e0..e(m-1)]
   u64* rec_off;        // word offset of each record
   u64* overflow_items; // item indices for the overflow kernel
@@ -392,8 +393,9 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
   __shared__ u32 lds_ecs[BLOCK * TUPLE_CAP];
   __shared__ u32 cache_key[DENSE_CACHE];
   __shared__ u32 cache_cnt[DENSE_CACHE];
+  __shared__ u32 cache_min[DENSE_CACHE];  // smallest item index (within this launch) that hit the cached set
   __shared__ u32 blk_stats[3];
-  for (int i = threadIdx.x; i < DENSE_CACHE; i += BLOCK) { cache_key[i] = 0xFFFFFFFFu; cache_cnt[i] = 0u; }
+  for (int i = threadIdx.x; i < DENSE_CACHE; i += BLOCK) { cache_key[i] = 0xFFFFFFFFu; cache_cnt[i] = 0u; cache_min[i] = 0xFFFFFFFFu; }
   if (threadIdx.x < 3) blk_stats[threadIdx.x] = 0u;
   __syncthreads();
   u32 s_single = 0, s_multi = 0, s_proc = 0;
@@ -449,8 +451,8 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
       const u32 e = ecs.e[0];
       const u32 hh = (e * 2654435761u) >> (32 - 11);
       const u32 old = atomicCAS(&cache_key[hh], 0xFFFFFFFFu, e);
-      if (old == 0xFFFFFFFFu || old == e) atomicAdd(&cache_cnt[hh], 1u);
-      else atomicAdd(&out.dense_counts[e], 1u);
+      if (old == 0xFFFFFFFFu || old == e) { atomicAdd(&cache_cnt[hh], 1u); atomicMin(&cache_min[hh], (u32)item); }
+      else { atomicAdd(&out.dense_counts[e], 1u); if (out.dense_first) atomicMin(&out.dense_first[e], rec_base + item); }
     }
     if (kind == 2) {
       ++s_multi;
@@ -466,7 +468,10 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
   if (lane_id() == 0) { atomicAdd(&blk_stats[0], (u32)w_single); atomicAdd(&blk_stats[1], (u32)w_multi); atomicAdd(&blk_stats[2], (u32)w_proc); }
   __syncthreads();
   for (int i = threadIdx.x; i < DENSE_CACHE; i += BLOCK)
-    if (cache_cnt[i]) atomicAdd(&out.dense_counts[cache_key[i]], cache_cnt[i]);
+    if (cache_cnt[i]) {
+      atomicAdd(&out.dense_counts[cache_key[i]], cache_cnt[i]);
+      if (out.dense_first) atomicMin(&out.dense_first[cache_key[i]], rec_base + (u64)cache_min[i]);
+    }
   if (threadIdx.x == 0) {
     if (blk_stats[0]) atomicAdd(&out.st->st_single, (u64)blk_stats[0]);
     if (blk_stats[1]) atomicAdd(&out.st->st_multi, (u64)blk_stats[1]);
@@ -479,7 +484,7 @@ template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const u32* __restrict__ words,
                                                              const uint16_t* __restrict__ lens, const u64* items, u64 n,
                                                              int seq_words, int rec_words, u32* scratch, FilterDev fd,
-                                                             AlignOut out) {
+                                                             u64 rec_base, AlignOut out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 item = items[i];
@@ -507,7 +512,9 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
     }
   }
   u64 off = atomicAdd(&out.st->stream_words, (u64)ecs.n + 2);
-  u64 ridx = atomicAdd(&out.st->n_recs, 1ULL);
+  // v2: the item's own record (index rec_base + item, so record indices stay in input order) is redirected to the big
+  // record; v1 (rec_base == ~0): records are appended
+  const u64 ridx = rec_base == ~0ULL ? atomicAdd(&out.st->n_recs, 1ULL) : rec_base + item;
   u32* w = out.stream + off;
   w[0] = 1u; w[1] = (u32)ecs.n;
   for (int j = 0; j < ecs.n; j++) w[2 + j] = ecs.e[j];
@@ -520,7 +527,8 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
 template <bool PAIRED>
 __global__ __launch_bounds__(64) void k_explicit_write(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                        const u64* items, u64 n, int seq_words, int rec_words, u32* scratch,
-                                                       int cap, FilterDev fd, u32* exp_stream, u64* exp_off, DevState* st) {
+                                                       int cap, FilterDev fd, u32* exp_stream, u64* exp_off, u64* exp_key, u64 key_base,
+                                                       u64 key_stride, DevState* st) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 item = items[i];
@@ -547,6 +555,7 @@ __global__ __launch_bounds__(64) void k_explicit_write(DevIndex ix, const u32* _
   u32 o = 0;
   for_each_member(ix, ecs, [&](u32 tr) { if (kamd::keep_transcript(pt, cfg, h0, h1, tr)) w[2 + o++] = tr; });
   exp_off[r] = off;
+  if (exp_key) exp_key[r] = key_base + item * key_stride;  // position of the item in the input (first-occurrence order)
 }
 // append the explicit records to the candidate stream (offsets rebased)
 __global__ void k_copy_words(const u32* __restrict__ src, u64 n, u32* dst) {
@@ -563,7 +572,7 @@ __global__ void k_copy_offsets(const u64* __restrict__ src, u64 n, u64 base, u64
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void k_table_init(TSlot* t, u64 cap) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cap) { t[i].tag = 0; t[i].owner = ~0ULL; t[i].count = 0; }
+  if (i < cap) { t[i].tag = 0; t[i].owner = ~0ULL; t[i].count = 0; t[i].first = ~0ULL; }
 }
 // idx == nullptr: records r0..r0+n-1 ; else records idx[0..n-1]
 __global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restrict__ rec_off, const u64* __restrict__ idx,
@@ -588,7 +597,8 @@ __global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restri
 // one global atomic per block)
 __global__ __launch_bounds__(BLOCK) void k_rec_verify(const u32* __restrict__ stream, const u64* __restrict__ rec_off,
                                                       const u64* __restrict__ idx, u64 r0, u64 n, TSlot* table,
-                                                      const u64* __restrict__ rec_slot, u64* retry, u64* list, DevState* st) {
+                                                      const u64* __restrict__ rec_slot, u64* retry, u64* list,
+                                                      const u64* __restrict__ keys, int track, DevState* st) {
   __shared__ u32 blk_n; __shared__ u64 blk_base;
   if (threadIdx.x == 0) blk_n = 0;
   __syncthreads();
@@ -603,7 +613,10 @@ __global__ __launch_bounds__(BLOCK) void k_rec_verify(const u32* __restrict__ st
       const u32 m = stream[off + 1];
       bool same = stream[own + 1] == m;
       for (u32 j = 0; same && j < m; j++) same = stream[own + 2 + j] == stream[off + 2 + j];
-      if (same) { atomicAdd(&table[s].count, (u64)stream[off]); is_owner = (own == off); }
+      if (same) {
+        atomicAdd(&table[s].count, (u64)stream[off]); is_owner = (own == off);
+        if (track) atomicMin(&table[s].first, keys ? keys[r] : r);  // first occurrence: record indices follow the input order
+      }
       else { u64 k = atomicAdd(&st->n_retry, 1ULL); retry[k] = r; }
     }
   }
@@ -640,7 +653,8 @@ __global__ void k_bound_singles(DevIndex ix, const u32* __restrict__ dense, DevS
   if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
 }
 // (a) one thread per index set with a count: copy its on-listed members as a candidate record
-__global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, u32* cand, u64* cand_off, DevState* st) {
+__global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, const u64* __restrict__ dense_first, u32* cand,
+                               u64* cand_off, u64* cand_key, DevState* st) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ix.n_ecs || dense[e] == 0) return;
   const u32* ids = ix.ec_ids + ix.ec_off[e];
@@ -655,6 +669,7 @@ __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, u32* 
   u32 o = 0;
   for (u32 j = 0; j < n; j++) if (onlisted(ix.onlist_bits, ids[j])) w[2 + o++] = ids[j];
   cand_off[r] = off;
+  if (cand_key) cand_key[r] = dense_first[e];
 }
 // (b) one 16-lane group per distinct tuple (4 tuples per wavefront): intersect the m sorted sets; 16 candidates of the
 //     smallest set per step, membership by binary search in the others, survivors compacted with ballot + popcount
@@ -662,7 +677,7 @@ __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, u32* 
 constexpr int RES_LANES = 16;
 constexpr int RES_GROUPS = BLOCK / RES_LANES;
 __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
-                                                   const u64* list, u64 n, u32* cand, u64* cand_off, DevState* st) {
+                                                   const u64* list, u64 n, u32* cand, u64* cand_off, u64* cand_key, DevState* st) {
   __shared__ u32 grp_total[RES_GROUPS];
   __shared__ u64 grp_off[RES_GROUPS];
   __shared__ u64 grp_rec[RES_GROUPS];
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __res
   const int lane = lane_id();
   const int sub = lane & (RES_LANES - 1);
   const int gsh = lane & ~(RES_LANES - 1);  // bit position of this group inside the wavefront mask
-  TSlot sl; sl.owner = 0; sl.count = 0; sl.tag = 0;
+  TSlot sl; sl.owner = 0; sl.count = 0; sl.tag = 0; sl.first = ~0ULL;
   u32 m = 0, best = 0, nb = 0;
   const u32* es = nullptr; const u32* base = nullptr;
   if (valid) {
@@ -720,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __res
   __syncthreads();
   if (!valid || total == 0) return;  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
   const u64 out_off = grp_off[grp];
-  if (sub == 0) { cand[out_off] = (u32)sl.count; cand[out_off + 1] = total; cand_off[grp_rec[grp]] = out_off; }
+  if (sub == 0) { cand[out_off] = (u32)sl.count; cand[out_off + 1] = total; cand_off[grp_rec[grp]] = out_off; if (cand_key) cand_key[grp_rec[grp]] = sl.first; }
   u32 written = 0;
   for (u32 c0 = 0; c0 < nb; c0 += RES_LANES) {
     u32 x, gm;
@@ -769,6 +784,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan_add(u64* out, u64 n, const u64* 
 }
 
 // final CSR from the distinct candidate sets
+__global__ void k_final_keys(const TSlot* table, const u64* list, u64 n, u64* keys) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = table[list[i]].first;
+}
 __global__ void k_final_sizes(const u32* __restrict__ cand, const TSlot* table, const u64* list, u64 n, u32* sizes) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sizes[i] = cand[table[list[i]].owner + 1];
@@ -1170,7 +1189,7 @@ struct kamd_ctx {
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
-  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw;
+  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first, ord_perm, ord_sizes, ord_off, ord_ids, ord_counts;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
@@ -1188,6 +1207,7 @@ struct kamd_ctx {
   hipEvent_t ev2 = nullptr;
   hipStream_t em_stream = nullptr;
   int kernel_a_version = 2, items_per_wave = 1024, refill_min = 8;
+  bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
 };
 
@@ -1215,7 +1235,7 @@ int upload(kamd_ctx* c, const T* host, size_t n, const T** dev) {
 
 // exact de-duplication of records [r0, r1) of a record stream into `table` (capacity cap, power of two)
 int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u64 r1, TSlot* table, u64 cap, DBuf& slot_buf,
-                  u64* list) {
+                  u64* list, int track = 0, const u64* keys = nullptr) {
   const u64 n = r1 - r0;
   c->host_state.n_list = 0;
   HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_list, &c->host_state.n_list, sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -1232,7 +1252,7 @@ int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u6
     hipLaunchKernelGGL(k_rec_insert, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
                        table, cap - 1, seed, slot_buf.as<u64>());
     hipLaunchKernelGGL(k_rec_verify, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
-                       table, slot_buf.as<u64>(), retry_b, list, (DevState*)c->state.p);
+                       table, slot_buf.as<u64>(), retry_b, list, keys, track, (DevState*)c->state.p);
     HIPC(hipGetLastError());
     if (int rc = sync_state(c)) return rc;
     count = c->host_state.n_retry;
@@ -1266,7 +1286,7 @@ int count_tuples(kamd_ctx* c) {
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
   if (int rc = c->list.ensure((std::min<u64>(n_recs, c->tuple_bound) + 1) * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot,
-                             c->list.as<u64>())) return rc;
+                             c->list.as<u64>(), c->track_order ? 1 : 0)) return rc;
   c->n_distinct_tuples = c->host_state.n_list;
   c->tuples_counted = true; c->recs_counted = n_recs;
   return 0;
@@ -1310,7 +1330,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->ord_perm,
+                  &c->ord_sizes, &c->ord_off, &c->ord_ids, &c->ord_counts,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -1354,6 +1375,8 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   c->ix = d; c->has_index = true; c->n_ecs = v.n_ecs; c->n_targets = v.n_targets;
   if (int rc = c->dense.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(v.n_ecs, 1) * sizeof(u32), c->stream));
+  if (int rc = c->dense_first.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u64), 0, c->stream)) return rc;
+  HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(v.n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
   c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->exp_words_done = 0; c->tuple_bound = 0;
   return push_state(c);
@@ -1363,6 +1386,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   if (!c || !c->has_index) return kamd::fail(-1, "kamd_ec_reset: no context / index");
   HIPC(hipSetDevice(c->device));
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
+  HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(c->n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
   c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0; c->tuple_bound = 0;
   return push_state(c);
@@ -1423,9 +1447,9 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
 }
 template <bool PAIRED, bool FILTER>
 void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
-                     const AlignOut& out) {
+                     u64 rec_base, const AlignOut& out) {
   hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
-                     c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, out);
+                     c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out);
 }
 }  // namespace
 
@@ -1462,7 +1486,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc = c->explicit_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
     if (int rc = c->explicit_items_big.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
   }
-  AlignOut out{c->dense.as<u32>(), c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
+  AlignOut out{c->dense.as<u32>(), c->track_order ? c->dense_first.as<u64>() : nullptr, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
                c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
   int rc = 0;
   if (c->kernel_a_version != 2) HIPC(hipEventRecord(c->ev0, c->stream));
@@ -1492,10 +1516,11 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
     out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-    if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
-                     else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out); }
-    else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
-           else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out); }
+    const u64 ov_base = c->kernel_a_version == 2 ? cur_recs : ~0ULL;
+    if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
+                     else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
+    else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
+           else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
     HIPC(hipGetLastError());
     if (int rc2 = sync_state(c)) return rc2;
     c->host_state.n_overflow = 0;
@@ -1507,6 +1532,8 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     const u64 have_w = c->exp_words_done, have_r = c->host_state.exp_recs;
     if (int rc2 = c->exp_stream.ensure((c->host_state.exp_words + 2) * sizeof(u32), have_w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->exp_off.ensure((have_r + ne + nb + 1) * sizeof(u64), have_r * sizeof(u64), c->stream)) return rc2;
+    if (c->track_order) if (int rc2 = c->exp_key.ensure((have_r + ne + nb + 1) * sizeof(u64), have_r * sizeof(u64), c->stream)) return rc2;
+    u64* exp_key = c->track_order ? c->exp_key.as<u64>() : nullptr;
     c->host_state.cand_words = have_w;  // write cursor of this pass
     if (int rc2 = push_state(c)) return rc2;
     for (int big = 0; big < 2; big++) {
@@ -1517,10 +1544,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
       const u64* items = big ? c->explicit_items_big.as<u64>() : c->explicit_items.as<u64>();
       if (o->paired) hipLaunchKernelGGL(k_explicit_write<true>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
                                         seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(),
-                                        c->exp_off.as<u64>(), (DevState*)c->state.p);
+                                        c->exp_off.as<u64>(), exp_key, cur_recs, 1ULL, (DevState*)c->state.p);
       else hipLaunchKernelGGL(k_explicit_write<false>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
                               seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(), c->exp_off.as<u64>(),
-                              (DevState*)c->state.p);
+                              exp_key, cur_recs, 1ULL, (DevState*)c->state.p);
       HIPC(hipGetLastError());
       HIPC(hipStreamSynchronize(c->stream));  // exp_scratch is reused by the second launch
     }
@@ -1634,6 +1661,7 @@ extern "C" int kamd_ec_tuples_copy(kamd_ctx* c, uint32_t* d_out_words, uint64_t*
 extern "C" int kamd_ec_tuples_replace(kamd_ctx* c, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off,
                                       uint64_t n_recs) {
   if (!c) return kamd::fail(-1, "kamd_ec_tuples_replace: null argument");
+  if (c->track_order) return kamd::fail(-1, "kamd_ec_tuples_replace: merged records have no input order (kamd_ec_track_order is on)");
   HIPC(hipSetDevice(c->device));
   if (int rc = sync_state(c)) return rc;
   if (int rc = c->stream_buf.ensure(std::max<u64>(n_words, 1) * sizeof(u32), 0, c->stream)) return rc;
@@ -1665,6 +1693,7 @@ extern "C" int kamd_ec_explicit_copy(kamd_ctx* c, uint32_t* d_out_words, uint64_
 extern "C" int kamd_ec_explicit_replace(kamd_ctx* c, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off,
                                         uint64_t n_recs) {
   if (!c) return kamd::fail(-1, "kamd_ec_explicit_replace: null argument");
+  if (c->track_order) return kamd::fail(-1, "kamd_ec_explicit_replace: merged records have no input order (kamd_ec_track_order is on)");
   HIPC(hipSetDevice(c->device));
   if (int rc = sync_state(c)) return rc;
   if (int rc = c->exp_stream.ensure(std::max<u64>(n_words, 1) * sizeof(u32), 0, c->stream)) return rc;
@@ -1677,6 +1706,14 @@ extern "C" int kamd_ec_explicit_replace(kamd_ctx* c, const uint32_t* d_words, ui
 }
 
 // ---- finalize ---------------------------------------------------------------------------------------------------------
+extern "C" int kamd_ec_track_order(kamd_ctx* c, int on) {
+  if (!c) return kamd::fail(-1, "kamd_ec_track_order: null context");
+  if (on && c->kernel_a_version != 2) return kamd::fail(-1, "kamd_ec_track_order: needs kernel A version 2 (records in input order)");
+  if (c->host_state.st_processed != 0) return kamd::fail(-1, "kamd_ec_track_order: call before the first batch (or after kamd_ec_reset)");
+  c->track_order = on != 0;
+  return 0;
+}
+
 extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   if (!c) return kamd::fail(-1, "kamd_ec_finalize: null context");
   if (!c->has_index) return kamd::fail(-1, "kamd_ec_finalize: no index uploaded");
@@ -1698,10 +1735,12 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   const u64 max_cands = c->n_ecs + n_t + n_exp_r;
   if (int rc = c->cand.ensure((bound + 2) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->cand_off.ensure((max_cands + 1) * sizeof(u64), 0, c->stream)) return rc;
+  if (c->track_order) if (int rc = c->cand_key.ensure((max_cands + 1) * sizeof(u64), 0, c->stream)) return rc;
+  u64* cand_key = c->track_order ? c->cand_key.as<u64>() : nullptr;
   hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
-                     c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
+                     c->dense_first.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
   if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
-                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), dst);
+                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
   if (n_exp_r) {  // sets produced by the positional filters join the candidates
@@ -1710,6 +1749,8 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
                        c->cand.as<u32>() + wbase);
     hipLaunchKernelGGL(k_copy_offsets, dim3(grid_for(n_exp_r, BLOCK)), dim3(BLOCK), 0, c->stream, c->exp_off.as<u64>(), n_exp_r, wbase,
                        c->cand_off.as<u64>() + rbase);
+    if (cand_key) hipLaunchKernelGGL(k_copy_offsets, dim3(grid_for(n_exp_r, BLOCK)), dim3(BLOCK), 0, c->stream, c->exp_key.as<u64>(), n_exp_r,
+                                     0ULL, cand_key + rbase);
     HIPC(hipGetLastError());
     c->host_state.cand_words = wbase + n_exp_w; c->host_state.cand_recs = rbase + n_exp_r;
   }
@@ -1720,9 +1761,26 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->ccap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ctable.as<TSlot>(), c->ccap);
   if (int rc = c->clist.ensure((n_cand + 1) * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = dedup_records(c, c->cand.as<u32>(), c->cand_off.as<u64>(), 0, n_cand, c->ctable.as<TSlot>(), c->ccap, c->cand_slot,
-                             c->clist.as<u64>())) return rc;
-  u64 n_final = 0;
-  n_final = c->host_state.n_list;
+                             c->clist.as<u64>(), cand_key ? 2 : 0, cand_key)) return rc;
+  const u64 n_final = c->host_state.n_list;
+  if (c->track_order && n_final > 1) {
+    // first-occurrence order (what the reference produces at -t 1): sort the distinct sets by the index of the first item
+    // that produced them.  Keys are distinct (an item yields one set), so the order is total; the sort runs on the host
+    // (n_final is ~1e6 at most) and only when the caller asked for it.
+    if (int rc = c->ec_first.ensure(n_final * sizeof(u64), 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_final_keys, dim3(grid_for(n_final, BLOCK)), dim3(BLOCK), 0, c->stream, c->ctable.as<TSlot>(), c->clist.as<u64>(), n_final,
+                       c->ec_first.as<u64>());
+    std::vector<u64> keys(n_final), slots(n_final), sorted(n_final);
+    HIPC(hipMemcpyAsync(keys.data(), c->ec_first.p, n_final * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(slots.data(), c->clist.p, n_final * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    std::vector<u64> perm(n_final);
+    for (u64 i = 0; i < n_final; i++) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](u64 a, u64 b) { return keys[a] != keys[b] ? keys[a] < keys[b] : slots[a] < slots[b]; });
+    for (u64 i = 0; i < n_final; i++) sorted[i] = slots[perm[i]];
+    HIPC(hipMemcpyAsync(c->clist.p, sorted.data(), n_final * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
   // CSR
   if (int rc = c->sizes.ensure((n_final + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->ec_off.ensure((n_final + 2) * sizeof(u64), 0, c->stream)) return rc;

@@ -272,6 +272,8 @@ int main(int argc, char** argv) {
   kamd_ctx* ctx = nullptr;
   KX(kamd_ctx_create(0, nullptr, &ctx));
   KX(kamd_index_upload(ctx, idx));
+  // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
+  if (opt.bootstrap > 0) KX(kamd_ec_track_order(ctx, 1));
 
   const bool paired = !opt.single;
   kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand};

@@ -91,6 +91,40 @@ def test_batches_and_idempotence(ka, ctxs):
     assert st["n_processed"] == n and st["n_bucket_reads"] >= st["n_probes"] > 0
 
 
+@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_rf"), ("human_pe", "pe"), ("human_pe", "pe_l180"),
+                                          ("yeast_se", "se"), ("yeast_se", "se_fr"), ("tiny_k7_se", "se")])
+def test_first_occurrence_order(case, variant, ka, ctxs):
+    """kamd_ec_track_order: the finalized CSR lists the sets in the order the reference assigns ids at -t 1 (first read that
+    produced the set) -- the oracle's order, which the reference's bootstrap goldens pin (test_oracle_golden).  Several
+    batches, so record indices have to stay in input order across launches."""
+    from oracle import oracle as O
+    meta, idx_path, r1, r2 = common.load_case(case)
+    o = common.parse_variant(meta["variants"][variant])
+    index, ctx = ctxs(case)
+    opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"])
+    r2 = r2 if o["paired"] else None
+    ctx.track_order(True)
+    try:
+        n = len(r1)
+        cuts = [0, 3, 700, n // 2, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            reads = common.interleave(r1[a:b], r2[a:b] if r2 is not None else None)
+            words, lens, max_len = ctx.pack_reads_host(reads, max(len(x) for x in reads))
+            ctx.pseudoalign(opts, words, lens, b - a, max_len)
+        e = ctx.finalize()
+        with pytest.raises(ka.KallistoAmdError):
+            ctx.track_order(False)       # only before the first batch
+    finally:
+        ctx.reset()
+        ctx.track_order(False)
+    ix = O.Index(idx_path)
+    buf, off, lens = O.pack_reads(common.interleave(r1, r2))
+    res = O.process_reads(ix, O.Opts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"]), buf, off, lens)
+    assert np.array_equal(e.counts, res.counts)
+    assert np.array_equal(e.ec_off, res.ec_off)
+    assert np.array_equal(e.ec_ids, res.ec_ids)
+
+
 def test_em_against_oracle_on_given_csr(ka, ctxs):
     """EM kernel alone on a caller-provided CSR (the bootstrap entry shape) vs the oracle."""
     import torch
