@@ -135,8 +135,10 @@ typedef struct {
   int32_t kernel_a_version;    /* 2 = k_match_v2 + k_classify (default), 1 = k_pseudoalign (env KAMD_KERNEL_A=1) */
   uint64_t last_em_nnz;        /* shape of the EM problem of the last kamd_em_run: nnz of the EC x transcript matrix, */
   uint64_t last_em_nnz_multi;  /* nnz in multi-transcript rows, */
-  uint64_t last_em_nseg;       /* column segments, */
+  uint64_t last_em_nseg;       /* column segments (CSR form) or chunks per direction (streamed form), */
   uint64_t last_em_necs;       /* rows */
+  int32_t last_em_k;           /* streamed EM form: entries per lane (0: the CSR form ran -- partitioned runs, env KAMD_EM_STREAMED=0) */
+  uint32_t last_em_grid;       /* ... and the grid of its two per-round launches (blocks of 256 threads, one chunk per wavefront) */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

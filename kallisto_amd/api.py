@@ -49,7 +49,8 @@ class _Stats(C.Structure):
 class _Profile(C.Structure):
     _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64),
                 ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32), ("last_em_nnz", C.c_uint64),
-                ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64)]
+                ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64),
+                ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32)]
 
 
 class _EcResult(C.Structure):
@@ -306,7 +307,7 @@ class Context:
         return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters),
                 "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version),
                 "em_nnz": int(p.last_em_nnz), "em_nnz_multi": int(p.last_em_nnz_multi), "em_nseg": int(p.last_em_nseg),
-                "em_necs": int(p.last_em_necs)}
+                "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

@@ -1108,6 +1108,342 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
   if (threadIdx.x == 0 && blk_ch) atomicAdd(&st[parity].chcount, blk_ch);
 }
 // ------------------------------------------------------------------------------------------------------------------
+// Kernel B, streamed form: two launches per round (rows, columns) over a re-laid-out matrix.  At the sizes of a
+// transcriptome (a few 1e6 non-zeros) a round is bound by dependent-load latency and launch count, not by bytes: the CSR
+// form above chases row offsets -> ids -> a[] (three dependent latencies per kernel, three kernels).  Re-layout, once per run:
+//   * only rows with >= 2 transcripts and only transcripts that occur in such a row are kept ("m-space", compact ids);
+//     singleton rows are the constant single[] term of their transcript
+//   * both directions of the matrix are FLAGGED STREAMS: entry = index | PM_END on the last entry of a row (column).
+//     No offset arrays are read in the loop.  A wavefront owns one chunk of 64 x K consecutive entries (each lane K
+//     consecutive ones: K/4 16-byte loads, then K independent 8-byte gathers -- two dependent memory latencies per launch),
+//     reduces them with a lane-local pass + ONE segmented wavefront scan, stages the segment sums in LDS and finishes them
+//     lane-parallel (coalesced constants and stores, no divergent divisions)
+//   * a segment that crosses into a chunk from the left is re-read by that chunk if the part outside is short (<= 256
+//     entries, loads issued together with the chunk's own), else completed by a small fix-up launch from the chunks'
+//     left/right partial sums in chunk order (deterministic summation, no floating-point atomics); that launch only exists
+//     when such segments do
+// A persistent single-launch form with grid barriers was built and measured first (scratch/em_persistent_kernel_attempt):
+// one grid barrier costs 4.9-6.3 us on 256 CUs (kamd_debug_grid_barrier), a kernel boundary ~1.7 us, so launches win.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr u32 PM_END = 0x80000000u;
+constexpr u32 PM_NONE = 0xFFFFFFFFu;
+constexpr u32 PM_HEAVY = 0x80000000u;
+constexpr int PM_BLOCK = 256;         // 4 wavefronts = 4 chunks per block
+constexpr int PM_HEAD = 4;            // a crossing segment with <= 64 * PM_HEAD entries before the chunk is re-read by the chunk
+constexpr int PM_LDS_SLOTS = 512;     // segment sums staged per wavefront and window
+struct PmSide {
+  const u32* stream;     // [n_chunks * 64 * K] index | PM_END; the tail padding points at a sentinel whose value is 0
+  const u32* seg_base;   // [n_chunks] segment that contains the chunk's first entry
+  const u32* head;       // [n_chunks] entries of that segment before the chunk: 0, 1..64*PM_HEAD (re-read), PM_HEAVY (partials)
+  const u32* fix_first;  // [n_chunks] heavy crossing segment that ENDS in this chunk: the chunk it started in, else PM_NONE
+  double* lp;            // [n_chunks] sum of the chunk's entries up to its first segment end (all of them if there is none)
+  double* rp;            // [n_chunks] sum of the entries after the chunk's last segment end
+  u32 n_chunks;
+};
+struct PmArgs {
+  PmSide rows, cols;
+  const u64* cw;           // [R] count | weight count << 32 of the kept rows
+  double* g;               // [R + 1]; g[R] = 0 is the sentinel the column stream's padding points at
+  double* alpha0; double* alpha1; double* a0; double* a1;   // [M + 1]; a*[M] = 0 is the row stream's sentinel
+  double* ac0; double* ac1;   // [M + 1] a with the final round's clamp (alpha < alpha_limit / 10 -> 0, EMAlgorithm.h:212-221): what the final round reads
+  const double* single; const double* eff;   // [M]
+  u32 R, M;
+  int n_iter, min_rounds;
+  EmState* st;             // the two parity-indexed loop-control records (see EmState)
+};
+
+// what is done with a finished segment sum: load() fetches the segment's constants (issued before the sums are known,
+// coalesced: consecutive lanes finish consecutive segments), finish() consumes them with the sum
+struct PmRowEmit {   // g_e = count_e / S_e; rows the reference skips get 0: count 0 (:133-135), denom below denorm_min (:156-158)
+  const u64* cw; double* g;
+  using Ctx = u64;
+  __device__ __forceinline__ Ctx load(u32 r) const { return cw[r]; }
+  __device__ __forceinline__ void finish(u32 r, const Ctx& w, double S) const {
+    const u32 cnt = (u32)w, wc = (u32)(w >> 32);
+    g[r] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+  }
+};
+struct PmColEmit {   // next_t = single_t + a_t * sum_e g_e and the convergence test of :176-199
+  const double* alpha_cur; const double* a_cur; const double* single; const double* eff;
+  double* alpha_nx; double* a_nx; double* ac_nx; int* ch; int clamp;   // a_cur is the clamped copy in the final round
+  struct Ctx { double al, at, sg, ef; };
+  __device__ __forceinline__ Ctx load(u32 m) const { return Ctx{alpha_cur[m], a_cur[m], single[m], eff[m]}; }
+  __device__ __forceinline__ void finish(u32 m, const Ctx& x, double acc) const {
+    const double al = (clamp && x.al < 1e-7 / 10.0) ? 0.0 : x.al;
+    const double nx = x.sg + x.at * acc;
+    if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ++*ch;
+    const double an = nx / x.ef;
+    alpha_nx[m] = nx;
+    a_nx[m] = an;
+    ac_nx[m] = nx < 1e-7 / 10.0 ? 0.0 : an;
+  }
+};
+
+// one wavefront, one chunk: value of entry j = src[index_j]; every segment that ends in the chunk is finished here unless it
+// crossed in from far to the left (PM_HEAVY: pm_fix)
+template <int K, int PRE, class Emit>
+__device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, const double* __restrict__ src, double* lds, const Emit& em) {
+  const int lane = lane_id();
+  const u32* base = s.stream + (u64)c * (64 * K);
+  const uint4* p = reinterpret_cast<const uint4*>(base + lane * K);
+  u32 id[K];
+#pragma unroll
+  for (int q = 0; q < K / 4; q++) { const uint4 w = p[q]; id[4 * q] = w.x; id[4 * q + 1] = w.y; id[4 * q + 2] = w.z; id[4 * q + 3] = w.w; }
+  const u32 sb = s.seg_base[c];
+  const u32 hd = s.head[c];
+  const bool heavy = (hd & PM_HEAVY) != 0;
+  const u32 hlen = heavy ? 0u : hd;
+  u32 hid[PM_HEAD];
+#pragma unroll
+  for (int i = 0; i < PM_HEAD; i++) hid[i] = (u32)(lane + 64 * i) < hlen ? (*(base - hlen + lane + 64 * i) & ~PM_END) : PM_NONE;
+  u32 emask[(K + 31) / 32];   // bit k: the lane's k-th entry ends a segment
+#pragma unroll
+  for (int w = 0; w < (K + 31) / 32; w++) emask[w] = 0;
+  u32 ne = 0;
+#pragma unroll
+  for (int k = 0; k < K; k++) { const u32 e = id[k] >> 31; emask[k / 32] |= e << (k % 32); ne += e; id[k] &= ~PM_END; }
+  u32 incl = ne;   // segment ends in this and the lower lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+  const u32 ebase = incl - ne;
+  const u32 n_ends = __shfl(incl, 63, 64);
+  const u64 heads = __ballot(ne > 0);
+  const u32 skip = heavy ? 1u : 0u;   // a heavy crossing segment's end is finished by pm_fix
+  // (one window unless the chunk holds more segment ends than the wavefront's share of LDS; then the pass is repeated)
+  for (u32 w0 = skip; w0 == skip || w0 < n_ends; w0 += PM_LDS_SLOTS) {
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = src[id[k]];
+    double hsum = 0.0;
+    if (hlen) {
+#pragma unroll
+      for (int i = 0; i < PM_HEAD; i++) if (hid[i] != PM_NONE) hsum += src[hid[i]];
+    }
+    typename Emit::Ctx pre[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; i++) { const u32 j = w0 + lane + 64 * i; if (j < n_ends) pre[i] = em.load(sb + j); }
+    if (hlen) {
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) hsum += __shfl_xor(hsum, d, 64);
+    }
+    // lane-local pass in entry order: a segment that ends after an earlier end of the same lane is complete -> staged in LDS
+    // at its local index; the sum up to the lane's first end waits for the carry; the open tail feeds the wavefront scan
+    double run = 0.0, first_part = 0.0;
+    bool got = false;
+    u32 j = ebase;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      run += v[k];
+      if ((emask[k / 32] >> (k % 32)) & 1u) {
+        if (!got) { first_part = run; got = true; }
+        else if (j >= w0 && j < w0 + PM_LDS_SLOTS) lds[j - w0] = run;
+        ++j; run = 0.0;
+      }
+    }
+    double y = run;   // segmented inclusive scan; a lane that holds a segment end starts a new run with its tail
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double t = __shfl_up(y, d, 64);
+      if (lane >= d && ((heads >> (lane - d + 1)) & ((1ULL << d) - 1ULL)) == 0ULL) y += t;
+    }
+    double carry = __shfl_up(y, 1, 64);
+    if (lane == 0) carry = 0.0;
+    if (ebase == 0) carry += hsum;   // the chunk's first end also gets the re-read head
+    if (got && ebase >= w0 && ebase < w0 + PM_LDS_SLOTS) lds[ebase - w0] = carry + first_part;
+    if (w0 == skip) {  // partial sums for pm_fix: a chunk without any end lies wholly inside one segment (its sum is both)
+      if (lane == 63) { if (n_ends == 0) { s.lp[c] = y; s.rp[c] = y; } else s.rp[c] = y; }
+      if (heavy && got && ebase == 0) s.lp[c] = carry + first_part;
+    }
+    if (w0 >= n_ends) break;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u32 wn = min(n_ends - w0, (u32)PM_LDS_SLOTS);
+#pragma unroll
+    for (int i = 0; i < PRE; i++) { const u32 t = lane + 64 * i; if (t < wn) em.finish(sb + w0 + t, pre[i], lds[t]); }
+    for (u32 t = lane + 64 * PRE; t < wn; t += 128) {   // beyond the prefetched contexts: two segments per lane and trip
+      const u32 t1 = t + 64;
+      const bool h1 = t1 < wn;
+      const typename Emit::Ctx x0 = em.load(sb + w0 + t), x1 = h1 ? em.load(sb + w0 + t1) : x0;
+      em.finish(sb + w0 + t, x0, lds[t]);
+      if (h1) em.finish(sb + w0 + t1, x1, lds[t1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+// a heavy crossing segment that ends in chunk c: right partial of the chunk it started in + the chunks wholly inside it +
+// this chunk's left partial, in chunk order; one thread per chunk
+template <class Emit>
+__device__ __forceinline__ void pm_fix(const PmSide& s, u32 c, const Emit& em) {
+  if (c >= s.n_chunks) return;
+  const u32 f = s.fix_first[c];
+  if (f == PM_NONE) return;
+  const u32 seg = s.seg_base[c];
+  const typename Emit::Ctx cx = em.load(seg);
+  double S = s.rp[f];
+  for (u32 k = f + 1; k < c; k++) S += s.lp[k];
+  S += s.lp[c];
+  em.finish(seg, cx, S);
+}
+// change counter of the round: one atomic per block
+__device__ __forceinline__ void pm_count_changes(int ch, int* lds_ch, EmState* rec) {
+  if (threadIdx.x == 0) *lds_ch = 0;
+  __syncthreads();
+  if (__ballot(ch != 0)) {
+    int wsum = ch;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
+    if (lane_id() == 0) atomicAdd(lds_ch, wsum);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && *lds_ch) atomicAdd(&rec->chcount, *lds_ch);
+}
+
+// rows launch (first of the round: block 0 publishes the round's loop-control record, like k_em_rows)
+template <int K, int PRE>
+__global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity) {
+  __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
+  const EmState prev = A.st[parity ^ 1];
+  const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, false);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    EmState r; r.iter = now.it; r.chcount = 0; r.final_round = now.fin; r.done = now.done; r.rounds = now.rounds; r.force_final = 0;
+    r.pad[0] = r.pad[1] = 0;
+    A.st[parity] = r;
+  }
+  if (now.done) return;
+  const int odd = now.it & 1;
+  const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
+  if (c >= A.rows.n_chunks) return;
+  const PmRowEmit em{A.cw, A.g};
+  const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
+  pm_wave_pass<K, PRE>(A.rows, c, a_cur, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+}
+template <int K, int PRE>
+__global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity) {
+  __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
+  __shared__ int lds_ch;
+  const EmNow now = em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, false);
+  if (now.done) return;
+  const int odd = now.it & 1;
+  const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
+  int ch = 0;
+  const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
+  const PmColEmit em{odd ? A.alpha1 : A.alpha0, a_cur, A.single, A.eff, odd ? A.alpha0 : A.alpha1, odd ? A.a0 : A.a1, odd ? A.ac0 : A.ac1, &ch, now.fin};
+  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE>(A.cols, c, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  pm_count_changes(ch, &lds_ch, &A.st[parity]);
+}
+// fix-up launches (only enqueued when a direction has heavy crossing segments)
+__global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_fix(PmArgs A, int parity) {
+  if (em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, false).done) return;
+  const PmRowEmit em{A.cw, A.g};
+  pm_fix(A.rows, blockIdx.x * PM_BLOCK + threadIdx.x, em);
+}
+__global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_fix(PmArgs A, int parity) {
+  __shared__ int lds_ch;
+  const EmNow now = em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, false);
+  if (now.done) return;
+  const int odd = now.it & 1;
+  int ch = 0;
+  const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
+  const PmColEmit em{odd ? A.alpha1 : A.alpha0, a_cur, A.single, A.eff, odd ? A.alpha0 : A.alpha1, odd ? A.a0 : A.a1, odd ? A.ac0 : A.ac1, &ch, now.fin};
+  pm_fix(A.cols, blockIdx.x * PM_BLOCK + threadIdx.x, em);
+  pm_count_changes(ch, &lds_ch, &A.st[parity]);
+}
+
+// ---- one-time re-layout for the streamed form -------------------------------------------------------------------------
+// Kept rows are renumbered by their smallest transcript id (a counting sort): rows of one gene become neighbours, and since
+// the isoforms of a gene are neighbours in transcript space too, the 8-byte gathers of a wavefront fall into few cache
+// lines (the passes are bound by the L2 request rate of uncoalesced gathers, not by bytes).
+__global__ void k_pm_flags(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ col_cnt, u64 n_tr,
+                           u32* hist, u32* mflag) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_ecs) { const u64 a = ec_off[i]; if (ec_off[i + 1] - a >= 2) atomicAdd(&hist[ec_ids[a]], 1u); }   // sets are sorted: first = smallest
+  if (i < n_tr) mflag[i] = col_cnt[i] ? 1u : 0u;
+}
+__global__ void k_pm_rank(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u64* __restrict__ start, u32* fill,
+                          u64* rpos, u32* len_sorted) {
+  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], l = ec_off[e + 1] - a;
+  if (l < 2) return;
+  const u32 t0 = ec_ids[a];
+  const u64 r = start[t0] + atomicAdd(&fill[t0], 1u);
+  rpos[e] = r;
+  len_sorted[r] = (u32)l;
+}
+// kept row e -> entries of the row stream, its count word and offset; 8 lanes per row
+__global__ void k_pm_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts,
+                          const u32* __restrict__ wcounts, u64 n_ecs, const u64* __restrict__ rpos, const u64* __restrict__ roff,
+                          const u64* __restrict__ mpos, u32* stream, u64* cw) {
+  const u64 e = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+  const int sub = threadIdx.x & 7;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  if (b - a < 2) return;
+  const u64 r = rpos[e], base = roff[r];
+  for (u64 j = a + sub; j < b; j += 8) stream[base + (j - a)] = (u32)mpos[ec_ids[j]] | (j + 1 == b ? PM_END : 0u);
+  if (sub == 0) cw[r] = (u64)counts[e] | ((u64)wcounts[e] << 32);
+}
+__global__ void k_pm_cols(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u64* __restrict__ rpos,
+                          const u64* __restrict__ col_off, u32* col_fill, u32* stream) {
+  const u64 e = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+  const int sub = threadIdx.x & 7;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  if (b - a < 2) return;
+  const u32 r = (u32)rpos[e];
+  for (u64 j = a + sub; j < b; j += 8) {
+    const u32 t = ec_ids[j];
+    const u64 p = col_off[t] + atomicAdd(&col_fill[t], 1u);
+    stream[p] = r | (p + 1 == col_off[t + 1] ? PM_END : 0u);
+  }
+}
+__global__ void k_pm_fill(u32* p, u64 a, u64 b, u32 v) {
+  const u64 i = a + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b) p[i] = v;
+}
+// m-space vectors; alpha_ = 1/T for every transcript (:38)
+__global__ void k_pm_minit(u64 n_tr, const u32* __restrict__ mflag, const u64* __restrict__ mpos, const u64* __restrict__ col_off,
+                           const double* __restrict__ single, const double* __restrict__ eff, u64 M, u64* coff, double* single_m,
+                           double* eff_m, double* alpha0, double* alpha1, double* a0, double* a1, double* ac0, double* ac1) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) { coff[M] = col_off[n_tr]; alpha0[M] = alpha1[M] = a0[M] = a1[M] = ac0[M] = ac1[M] = 0.0; }
+  if (t >= n_tr || !mflag[t]) return;
+  const u64 m = mpos[t];
+  coff[m] = col_off[t]; single_m[m] = single[t]; eff_m[m] = eff[t];
+  const double al = 1.0 / (double)n_tr;
+  alpha0[m] = al; a0[m] = al / eff[t]; alpha1[m] = 0.0; a1[m] = 0.0;
+  ac0[m] = al < 1e-7 / 10.0 ? 0.0 : al / eff[t]; ac1[m] = 0.0;
+}
+// per chunk: the segment its first entry belongs to (binary search in the segment offsets) and how it is completed
+__global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 chunk, u32 n_chunks, u32* seg_base, u32* head,
+                            u32* fix_first, u32* n_fix) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  const u64 c0 = (u64)c * chunk, c1 = c0 + chunk;
+  u64 lo = 0, hi = n_seg;  // largest s in [0, n_seg) with off[s] <= c0 (off[0] = 0, offsets strictly increase)
+  while (hi - lo > 1) { const u64 mid = (lo + hi) / 2; if (off[mid] <= c0) lo = mid; else hi = mid; }
+  const u64 hs = off[lo], se = off[lo + 1];
+  const u64 hl = c0 - hs;  // entries of the segment before the chunk
+  const bool is_heavy = hl > 64ULL * PM_HEAD;
+  seg_base[c] = (u32)lo;
+  head[c] = hl == 0 ? 0u : (is_heavy ? PM_HEAVY : (u32)hl);
+  const bool fix = is_heavy && se <= c1;
+  fix_first[c] = fix ? (u32)(hs / chunk) : PM_NONE;
+  if (fix) atomicAdd(n_fix, 1u);
+}
+// back to transcript space: both buffers (result and alpha_before_zeroes are picked by the caller).  A transcript that
+// only has a singleton set holds that count in every buffer from round 1 on; one that is in no set stays 0.
+__global__ void k_pm_scatter(u64 n_tr, const u32* __restrict__ mflag, const u64* __restrict__ mpos, const double* __restrict__ single,
+                             const double* __restrict__ am0, const double* __restrict__ am1, double* out0, double* out1) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tr) return;
+  if (mflag[t]) { const u64 m = mpos[t]; out0[t] = am0[m]; out1[t] = am1[m]; }
+  else { out0[t] = single[t]; out1[t] = single[t]; }
+}
+// ------------------------------------------------------------------------------------------------------------------
 // EM over several GPUs: the EC x transcript matrix is block diagonal over the connected components of the
 // transcript/EC graph (gene families), and the EM update never crosses a component, so each rank runs the unchanged
 // EM on the components it owns -- no per-round collective.  Components: min-label propagation along rows + pointer
@@ -1189,9 +1525,10 @@ struct kamd_ctx {
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
-  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first, ord_perm, ord_sizes, ord_off, ord_ids, ord_counts;
+  DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
+  DBuf pm_a, pm_b;               // persistent EM: re-layout arenas
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
@@ -1208,6 +1545,7 @@ struct kamd_ctx {
   hipStream_t em_stream = nullptr;
   int kernel_a_version = 2, items_per_wave = 1024, refill_min = 8;
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
+  int n_cus = 0, last_em_k = 0; unsigned last_em_grid = 0;
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
 };
 
@@ -1330,8 +1668,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->ord_perm,
-                  &c->ord_sizes, &c->ord_off, &c->ord_ids, &c->ord_counts,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -1846,6 +2183,137 @@ extern "C" int kamd_em_run_partitioned(kamd_ctx* c, uint32_t rank, uint32_t worl
 }
 
 namespace {
+// ---- streamed EM: re-layout of the matrix (once per run) and the per-round launches -------------------------------------
+struct Carver {  // sub-allocations of one device arena, 256-byte aligned
+  size_t off = 0;
+  size_t take(size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; }
+};
+struct PmPlan {
+  PmArgs args{};
+  int k = 0;                 // entries per lane
+  u32 n_chunks = 0;
+  u32 n_fix[2] = {0, 0};     // heavy crossing segments per direction (0: no fix-up launch)
+  const u32* mflag = nullptr; const u64* mpos = nullptr;   // transcript -> m-space
+};
+constexpr int PM_KS[] = {8, 12, 16, 20, 24, 32};
+template <int K>
+void pm_launch_round(const PmPlan& P, hipStream_t s, int parity) {
+  const unsigned grid = grid_for(P.n_chunks, PM_BLOCK / 64);
+  constexpr int PRE_R = (K + 5) / 6 < 2 ? 2 : (K + 5) / 6;   // 64 * PRE >= ~chunk / 6 row ends
+  constexpr int PRE_C = K / 16 + 1;                           // 64 * PRE >= ~chunk / 16 column ends
+  hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  if (P.n_fix[0]) hipLaunchKernelGGL(k_pm_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, parity);
+  hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  if (P.n_fix[1]) hipLaunchKernelGGL(k_pm_cols_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, parity);
+}
+void pm_enqueue_round(const PmPlan& P, hipStream_t s, int parity) {
+  switch (P.k) {
+    case 8: pm_launch_round<8>(P, s, parity); break;
+    case 12: pm_launch_round<12>(P, s, parity); break;
+    case 16: pm_launch_round<16>(P, s, parity); break;
+    case 20: pm_launch_round<20>(P, s, parity); break;
+    case 24: pm_launch_round<24>(P, s, parity); break;
+    default: pm_launch_round<32>(P, s, parity); break;
+  }
+}
+
+// returns 0 = plan built (the rounds can be enqueued with pm_enqueue_round), 1 = not applicable (the caller uses the CSR
+// form), < 0 = error.  Needs col_cnt / em_coloff / em_single / em_eff of the caller (k_em_prepare + scan) and a zeroed col_fill.
+int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u32* counts, const u32* wcounts, u64 n_ecs, u64 T,
+                      const u32* col_cnt, u32* col_fill, PmPlan* P) {
+  if (n_ecs == 0) return 1;
+  if (c->n_cus == 0) {
+    int v = 0;
+    HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device));
+    c->n_cus = v > 0 ? v : 256;
+  }
+  // stage 1: which rows / transcripts are kept, and their new numbers (rows: counting sort by smallest transcript)
+  Carver s1;
+  const size_t o_hist = s1.take((T + 1) * 4), o_fill = s1.take((T + 1) * 4), o_mflag = s1.take(T * 4);
+  const size_t o_start = s1.take((T + 2) * 8), o_rpos = s1.take((n_ecs + 1) * 8), o_mpos = s1.take((T + 1) * 8);
+  const size_t o_len = s1.take((n_ecs + 1) * 4), o_roff = s1.take((n_ecs + 2) * 8);
+  if (int rc = c->pm_a.ensure(s1.off, 0, c->stream)) return rc;
+  char* b1 = (char*)c->pm_a.p;
+  u32* hist = (u32*)(b1 + o_hist); u32* fill = (u32*)(b1 + o_fill); u32* mflag = (u32*)(b1 + o_mflag);
+  u64* start = (u64*)(b1 + o_start); u64* rpos = (u64*)(b1 + o_rpos); u64* mpos = (u64*)(b1 + o_mpos);
+  u32* len_sorted = (u32*)(b1 + o_len); u64* roff = (u64*)(b1 + o_roff);
+  HIPC(hipMemsetAsync(hist, 0, (o_mflag - o_hist), c->stream));   // hist + fill
+  hipLaunchKernelGGL(k_pm_flags, dim3(grid_for(std::max(n_ecs, T), BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, col_cnt, T, hist,
+                     mflag);
+  if (int rc = exclusive_scan(c, hist, T, start, start + T)) return rc;
+  if (int rc = exclusive_scan(c, mflag, T, mpos, mpos + T)) return rc;
+  u64 R = 0, NZ = 0, M = 0;
+  HIPC(hipMemcpyAsync(&R, start + T, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(&M, mpos + T, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(&NZ, c->em_coloff.as<u64>() + T, 8, hipMemcpyDeviceToHost, c->stream));   // non-zeros of the kept rows
+  HIPC(hipStreamSynchronize(c->stream));
+  if (NZ == 0 || R == 0 || M == 0 || R >= 0x7FFFFFF0ULL || M >= 0x7FFFFFF0ULL || NZ >= (1ULL << 40)) return 1;
+  hipLaunchKernelGGL(k_pm_rank, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, start, fill, rpos, len_sorted);
+  if (int rc = exclusive_scan(c, len_sorted, R, roff, roff + R)) return rc;   // roff[R] = NZ
+  // entries per lane: the smallest K whose chunks fit the chip in one go at 16 wavefronts per CU (<= 128 VGPRs)
+  int K = PM_KS[sizeof(PM_KS) / sizeof(PM_KS[0]) - 1];
+  if (const char* e = getenv("KAMD_EM_K")) { const int v = atoi(e); for (int k : PM_KS) if (k == v) K = v; }
+  else for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 16) { K = k; break; }
+  const u32 chunk = 64u * (u32)K;
+  const u64 n_chunks64 = (NZ + chunk - 1) / chunk;
+  if (n_chunks64 >= 0x7FFFFFF0ULL) return 1;
+  const u32 n_chunks = (u32)n_chunks64;
+  const u64 nzpad = (u64)n_chunks * chunk;
+  // stage 2
+  Carver s2;
+  const size_t o_rs = s2.take(nzpad * 4), o_cs = s2.take(nzpad * 4);
+  size_t o_meta[2][5];
+  for (int s = 0; s < 2; s++) { for (int j = 0; j < 3; j++) o_meta[s][j] = s2.take((size_t)n_chunks * 4); for (int j = 3; j < 5; j++) o_meta[s][j] = s2.take((size_t)n_chunks * 8); }
+  const size_t o_cw = s2.take(R * 8), o_coff = s2.take((M + 1) * 8), o_g = s2.take((R + 1) * 8);
+  size_t o_vec[6];
+  for (int j = 0; j < 6; j++) o_vec[j] = s2.take((M + 1) * 8);
+  const size_t o_single = s2.take(M * 8), o_eff = s2.take(M * 8), o_nfix = s2.take(64);
+  if (int rc = c->pm_b.ensure(s2.off, 0, c->stream)) return rc;
+  char* b2 = (char*)c->pm_b.p;
+  u32* rs = (u32*)(b2 + o_rs); u32* cs = (u32*)(b2 + o_cs);
+  u64* cw = (u64*)(b2 + o_cw); u64* coff = (u64*)(b2 + o_coff);
+  double* g = (double*)(b2 + o_g);
+  double* vec[6]; for (int j = 0; j < 6; j++) vec[j] = (double*)(b2 + o_vec[j]);
+  double* single_m = (double*)(b2 + o_single); double* eff_m = (double*)(b2 + o_eff);
+  HIPC(hipMemsetAsync(b2 + o_nfix, 0, 64, c->stream));
+  HIPC(hipMemsetAsync(g + R, 0, 8, c->stream));
+  const u64* col_off = c->em_coloff.as<u64>();
+  hipLaunchKernelGGL(k_pm_rows, dim3(grid_for(n_ecs * 8, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, counts, wcounts, n_ecs, rpos, roff,
+                     mpos, rs, cw);
+  hipLaunchKernelGGL(k_pm_cols, dim3(grid_for(n_ecs * 8, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, rpos, col_off, col_fill, cs);
+  if (nzpad > NZ) {
+    hipLaunchKernelGGL(k_pm_fill, dim3(grid_for(nzpad - NZ, BLOCK)), dim3(BLOCK), 0, c->stream, rs, NZ, nzpad, (u32)M);
+    hipLaunchKernelGGL(k_pm_fill, dim3(grid_for(nzpad - NZ, BLOCK)), dim3(BLOCK), 0, c->stream, cs, NZ, nzpad, (u32)R);
+  }
+  hipLaunchKernelGGL(k_pm_minit, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, mflag, mpos, col_off, c->em_single.as<double>(),
+                     c->em_eff.as<double>(), M, coff, single_m, eff_m, vec[0], vec[1], vec[2], vec[3], vec[4], vec[5]);
+  PmSide sides[2];
+  for (int s = 0; s < 2; s++) {
+    PmSide& d = sides[s];
+    d.stream = s == 0 ? rs : cs;
+    u32* sb = (u32*)(b2 + o_meta[s][0]); u32* hd = (u32*)(b2 + o_meta[s][1]); u32* ff = (u32*)(b2 + o_meta[s][2]);
+    d.seg_base = sb; d.head = hd; d.fix_first = ff;
+    d.lp = (double*)(b2 + o_meta[s][3]); d.rp = (double*)(b2 + o_meta[s][4]);
+    d.n_chunks = n_chunks;
+    hipLaunchKernelGGL(k_pm_chunks, dim3(grid_for(n_chunks, BLOCK)), dim3(BLOCK), 0, c->stream, s == 0 ? roff : coff, s == 0 ? R : M, NZ, chunk,
+                       n_chunks, sb, hd, ff, (u32*)(b2 + o_nfix) + s);
+  }
+  HIPC(hipGetLastError());
+  PmArgs& A = P->args;
+  A.rows = sides[0]; A.cols = sides[1];
+  A.cw = cw; A.g = g;
+  A.alpha0 = vec[0]; A.alpha1 = vec[1]; A.a0 = vec[2]; A.a1 = vec[3]; A.ac0 = vec[4]; A.ac1 = vec[5];
+  A.single = single_m; A.eff = eff_m;
+  A.R = (u32)R; A.M = (u32)M;
+  A.st = (EmState*)c->em_state.p;
+  HIPC(hipMemcpyAsync(P->n_fix, b2 + o_nfix, sizeof P->n_fix, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos;
+  c->last_em_nnz_multi = NZ; c->last_em_nseg = n_chunks; c->last_em_necs = n_ecs; c->last_em_k = K;
+  c->last_em_grid = grid_for(n_chunks, PM_BLOCK / 64);
+  return 0;
+}
+
 int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
                 const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
                 uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds, const EmPartition& part) {
@@ -1932,6 +2400,24 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   if (n_ecs) hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
                                 d_counts, (u64)n_ecs, col_cnt, c->em_single.as<double>());
   if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
+  EmState hs{};
+  c->last_em_nnz = nnz; c->last_em_k = 0; c->last_em_grid = 0;
+  // the streamed form (two launches per round over the re-laid-out matrix) unless the run is partitioned over ranks or
+  // KAMD_EM_STREAMED=0 asks for the CSR form
+  PmPlan plan;
+  bool streamed = false;
+  {
+    const char* ep = getenv("KAMD_EM_STREAMED");
+    if (!spec && !(ep && atoi(ep) == 0)) {
+      const int rc = em_streamed_setup(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, T, col_cnt, col_fill, &plan);
+      if (rc < 0) return rc;
+      streamed = rc == 0;
+      if (!streamed) HIPC(hipMemsetAsync(col_fill, 0, (T + 1) * sizeof(u32), c->stream));
+      plan.args.n_iter = (int)n_iter; plan.args.min_rounds = (int)min_rounds;
+    }
+  }
+  u64 n_active = 0, n_seg = 0;
+  if (!streamed) {
   if (n_ecs) hipLaunchKernelGGL(k_em_transpose, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids,
                                 (u64)n_ecs, c->em_coloff.as<u64>(), col_fill, c->em_colrow.as<u32>());
   // work list of k_em_final: transcripts that occur in some EC
@@ -1944,13 +2430,11 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   hipLaunchKernelGGL(k_em_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, c->em_eff.as<double>(), c->em_actflag.as<u32>(),
                      c->em_actpos.as<u64>(), c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(),
                      c->em_a1.as<double>(), c->em_active.as<u32>());
-  u64 n_active = 0;
   HIPC(hipMemcpyAsync(&n_active, c->em_actpos.as<u64>() + T, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   // column segments
   u32* nseg = col_cnt + 2 * (T + 1);
   hipLaunchKernelGGL(k_em_nseg, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, col_cnt, T, nseg);
   if (int rc = exclusive_scan(c, nseg, T, c->em_segoff.as<u64>(), c->em_segoff.as<u64>() + T)) return rc;
-  u64 n_seg = 0;
   HIPC(hipMemcpyAsync(&n_seg, c->em_segoff.as<u64>() + T, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   u64 nnz_multi = 0;
@@ -1961,7 +2445,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   hipLaunchKernelGGL(k_em_segsetup, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->em_coloff.as<u64>(), c->em_segoff.as<u64>(), T,
                      c->em_segt.as<u32>());
   HIPC(hipGetLastError());
-  EmState hs{};
+  }  // !streamed
   const int chunk = 64;
   int row_lanes = 4;
   if (const char* e = getenv("KAMD_EM_ROW_LANES")) row_lanes = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
@@ -1984,6 +2468,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   int parity = 0;  // parity of the next round to enqueue (round r uses record r & 1 and reads record (r & 1) ^ 1)
   auto enqueue_rounds = [&](hipStream_t s, int n_rounds) {
     for (int it = 0; it < n_rounds; it++, parity ^= 1) {
+      if (streamed) { pm_enqueue_round(plan, s, parity); continue; }
 #define KAMD_LAUNCH_ROWS(L)                                                                                                        \
   hipLaunchKernelGGL(k_em_rows<L>, dim3(grid_rows), dim3(BLOCK), 0, s, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, (u64)n_ecs, \
                      c->em_alpha.as<double>(), c->em_next.as<double>(), c->em_a0.as<double>(), c->em_a1.as<double>(),              \
@@ -2081,6 +2566,11 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
       break;
     }
   }
+  if (streamed) {  // m-space -> transcript space, both buffers
+    hipLaunchKernelGGL(k_pm_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, plan.mflag, plan.mpos, c->em_single.as<double>(),
+                       plan.args.alpha0, plan.args.alpha1, c->em_alpha.as<double>(), c->em_next.as<double>());
+    HIPC(hipGetLastError());
+  }
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipEventSynchronize(c->ev1));
   HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
@@ -2141,6 +2631,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
   p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
   p->last_em_nnz = c->last_em_nnz; p->last_em_nnz_multi = c->last_em_nnz_multi; p->last_em_nseg = c->last_em_nseg; p->last_em_necs = c->last_em_necs;
+  p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid;
   return 0;
 }
 
