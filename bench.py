@@ -11,7 +11,8 @@ vector + all-gather of the tuple records] -> EC resolution/merge -> fragment-len
 Scaling is weak: every rank processes its own `--pairs` read pairs (different seeds), so the job is N x pairs per step.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- kernel A (k_pseudoalign): algorithmic bytes of one launch / its HIP-event duration vs the 8 TB/s HBM peak
+  roofline     -- the dominant kernel by time, one EM round (k_pm_rows_pass + k_pm_cols_pass): SURVEY.md 8(d)'s algorithmic bytes of
+                  an EM iteration / the round's HIP-event duration vs the 8 TB/s HBM peak; roofline_kernel_a: the same for k_match_v2
   cpu_baseline -- the unmodified reference (oracle/_ref/kallisto quant, built from /root/reference) on this box's host
                   cores over a bounded sample of the same reads, same index file; plus a parity check of the GPU path
                   against that run on the same sample.
@@ -260,16 +261,27 @@ def main():
             alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_single"] + 4 * st["n_stream_words"] + 8 * st["n_multi"]
         a_ms = float(np.mean(align_ms))
         achieved = alg_bytes / (a_ms * 1e-3) / 1e9
-        # EM round: rows pass nnz_multi*(4 id + 8 gather) + per row (8 off + 4 count + 4 weight count +
-        # 8 g); column pass nnz_multi*(4 row + 8 gather) + per segment (4 + 8 + 8); final per transcript 64 B + 8 per segment
+        # EM round = the two launches k_pm_rows_pass + k_pm_cols_pass (streamed form; CSR form: k_em_rows + k_em_seg + k_em_final).
+        # `achieved` uses SURVEY.md section 8(d)'s ALGORITHMIC bytes of one EM iteration, independent of the layout:
+        #   B_B = nnz*(4 id + 8 alpha gather + 8 next accumulate) + N_ec*(4 count + 8 offsets) + T*(8 alpha + 8 next + 8 eff_len)
+        # `layout_bytes_per_round` is what the streamed layout actually has to move per round:
+        #   2 passes * nnz_multi*(4 index + 8 gather) + rows*(8 count word + 8 g) + transcripts*(4 reads + 3 writes)*8
         T = int(index.num_targets)
-        em_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 24 + pr["em_nseg"] * 28 + T * 64
+        em_bytes = pr["em_nnz"] * 20 + pr["em_necs"] * 12 + T * 24
+        if pr["em_k"]:
+            layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 16 + T * 56
+            em_kernel = "EM round (k_pm_rows_pass + k_pm_cols_pass)"
+        else:
+            layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 24 + pr["em_nseg"] * 28 + T * 64
+            em_kernel = "EM round (k_em_rows + k_em_seg + k_em_final)"
         em_round_ms = float(np.mean(em_ms)) / max(int(em_iters[-1]), 1)
         em_ach = em_bytes / (em_round_ms * 1e-3) / 1e9
-        em_roof = {"kernel": "EM round (k_em_rows + k_em_seg + k_em_final)", "bound": "hbm", "achieved": round(em_ach, 2),
+        em_roof = {"kernel": em_kernel, "bound": "hbm", "achieved": round(em_ach, 2),
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(em_ach / HBM_PEAK_GBS, 5), "traffic": None,
-                   "algorithmic_bytes_per_launch": int(em_bytes), "launch_ms": round(em_round_ms, 5),
-                   "rounds": int(em_iters[-1]), "nnz": pr["em_nnz"], "nnz_multi": pr["em_nnz_multi"], "rows": pr["em_necs"]}
+                   "algorithmic_bytes_per_launch": int(em_bytes), "layout_bytes_per_round": int(layout_bytes),
+                   "launch_ms": round(em_round_ms, 5), "launch": "one EM round (all its launches; kamd_em_run's HIP-event time / rounds, set-up included)",
+                   "rounds": int(em_iters[-1]), "nnz": pr["em_nnz"], "nnz_multi": pr["em_nnz_multi"], "rows": pr["em_necs"],
+                   "entries_per_lane": pr["em_k"], "chunks": pr["em_nseg"] if pr["em_k"] else None}
         out = {
             "metric": "M paired-end reads/sec quantified (human txome index)",
             "value": round(total_pairs / elapsed / 1e6, 4),
@@ -298,7 +310,7 @@ def main():
                          "single_set_pairs": st["n_single"], "multi_set_pairs": st["n_multi"],
                          "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
                          "em_rounds": res.em_rounds},
-            # dominant kernel by time: one EM round = k_em_rows + k_em_seg + k_em_final (+ one-thread control)
+            # dominant kernel by time: one EM round
             "roofline": em_roof,
             "roofline_kernel_a": {"kernel": "k_match_v2" if pr["kernel_a_version"] == 2 else "k_pseudoalign", "bound": "hbm",
                                   "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1528,7 +1528,8 @@ struct kamd_ctx {
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
-  DBuf pm_a, pm_b;               // persistent EM: re-layout arenas
+  DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
+  DBuf fld_tl, fld_card, fld_scratch, fld_items;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
@@ -1668,7 +1669,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -1920,8 +1921,10 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   const int rec_words = (int)kamd_packed_record_words(max_len);
   u64 found = n_used ? *n_used : 0, done = 0;  // continues a sample started on earlier batches
   const int cap_small = 64;
-  u64 chunk = 1048576;
-  DBuf tl, card, scratch, items;
+  // the sample is the first 10000 qualifying pairs: start with a short prefix and grow (a quarter of the pairs qualify on
+  // typical data, so the first launch usually suffices)
+  u64 chunk = 65536;
+  DBuf &tl = c->fld_tl, &card = c->fld_card, &scratch = c->fld_scratch, &items = c->fld_items;
   std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
   int rc = 0;
   while (done < n_items && found < 10000 && rc == 0) {
@@ -1958,7 +1961,6 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
     done += n;
     chunk = std::min<u64>(chunk * 4, 2097152);
   }
-  tl.release(); card.release(); scratch.release(); items.release();
   if (n_used) *n_used = found;
   return rc;
 }

@@ -144,6 +144,66 @@ def test_em_against_oracle_on_given_csr(ka, ctxs):
     common.assert_abundance_close(alpha, alpha_o, "alpha")
 
 
+def _family_csr(n_genes, seed):
+    """Gene-family shaped EC matrix with the cases the streamed EM form has to get right: rows/columns that cross chunk
+    boundaries (always), very long rows and hub transcripts (heavy crossings -> fix-up launches), singleton rows,
+    transcripts that only occur in singleton rows or in no row, zero counts."""
+    rng = np.random.default_rng(seed)
+    iso = np.minimum(rng.geometric(0.12, n_genes), 40)
+    t0 = np.concatenate([[0], np.cumsum(iso)])
+    T = int(t0[-1]) + 5                      # 5 transcripts in no set at all
+    sets = {}
+    for g in range(n_genes):
+        for _ in range(rng.poisson(25)):
+            m = min(iso[g], max(1, rng.geometric(0.2)))
+            r = tuple(sorted(int(x) + int(t0[g]) for x in rng.choice(iso[g], m, replace=False)))
+            sets[r] = sets.get(r, 0) + int(rng.pareto(1.2) * 3) + (1 if rng.random() < 0.9 else 0)
+    for _ in range(3):                       # very long rows
+        r = tuple(sorted(int(x) for x in rng.choice(T - 5, min(1500, (T - 5) // 2), replace=False)))
+        sets[r] = 40
+    for h in rng.choice(T - 5, 3, replace=False):   # hub transcripts: columns with thousands of entries
+        for o in rng.choice(T - 5, 2500, replace=False):
+            if o != h:
+                r = tuple(sorted((int(h), int(o))))
+                sets[r] = sets.get(r, 0) + int(rng.integers(0, 4))
+    keys = list(sets)
+    rng.shuffle(keys)
+    off = np.zeros(len(keys) + 1, np.uint64)
+    off[1:] = np.cumsum([len(k) for k in keys])
+    ids = np.array([t for k in keys for t in k], np.uint32)
+    cnt = np.array([sets[k] for k in keys], np.uint32)
+    return off, ids, cnt, rng.uniform(150, 3000, T), T
+
+
+@pytest.mark.parametrize("k", [None, 8, 16, 32, "csr"])
+def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
+    """The streamed EM form (default and forced chunk sizes: 64 x 8 entries makes the long rows / hub columns span many
+    chunks -> fix-up launches) and the CSR form against the oracle's EMAlgorithm::run restatement."""
+    import torch
+    from oracle import oracle as O
+    off, ids, cnt, eff, T = _family_csr(400, 7)
+    alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
+    monkeypatch.setenv("KAMD_EM_STREAMED", "0" if k == "csr" else "1")
+    if isinstance(k, int):
+        monkeypatch.setenv("KAMD_EM_K", str(k))
+    else:
+        monkeypatch.delenv("KAMD_EM_K", raising=False)
+    ctx = ka.Context(0)
+    try:
+        d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda()
+        alpha, abz, rounds = ctx.em_run(eff, csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32)))
+        prof = ctx.profile()
+    finally:
+        ctx.close()
+    assert (prof["em_k"] == 0) == (k == "csr")
+    if isinstance(k, int):
+        assert prof["em_k"] == k
+    assert rounds == rounds_o
+    assert abs(alpha.sum() - cnt.sum()) < 1e-6 * cnt.sum()
+    common.assert_abundance_close(alpha, alpha_o, "alpha", rel=1e-9)
+    common.assert_abundance_close(abz, abz_o, "alpha_before_zeroes", rel=1e-9, floor=1e-12)
+
+
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe_boot"), ("human_pe", "pe_boot")])
 def test_bootstrap_matches_reference(case, variant, ka, ctxs):
     """Bootstrap::run_em: the multinomial resample is bit-identical to libstdc++'s (same EC order as the reference at
