@@ -1181,16 +1181,25 @@ struct PmColEmit {   // next_t = single_t + a_t * sum_e g_e and the convergence 
 
 // one wavefront, one chunk: value of entry j = src[index_j]; every segment that ends in the chunk is finished here unless it
 // crossed in from far to the left (PM_HEAVY: pm_fix)
+// (in two steps so that the kernels can issue the chunk's loads BEFORE they use the round's loop-control record: both are
+// first-touch reads of a cold L2, ~2 us each, overlapped instead of chained)
+template <int K>
+struct PmWave { u32 id[K]; u32 sb, hd; };
+template <int K>
+__device__ __forceinline__ void pm_wave_load(const PmSide& s, u32 c, PmWave<K>& w) {
+  const uint4* p = reinterpret_cast<const uint4*>(s.stream + (u64)c * (64 * K) + lane_id() * K);
+#pragma unroll
+  for (int q = 0; q < K / 4; q++) { const uint4 x = p[q]; w.id[4 * q] = x.x; w.id[4 * q + 1] = x.y; w.id[4 * q + 2] = x.z; w.id[4 * q + 3] = x.w; }
+  w.sb = s.seg_base[c];
+  w.hd = s.head[c];
+}
 template <int K, int PRE, class Emit>
-__device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, const double* __restrict__ src, double* lds, const Emit& em) {
+__device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& w, const double* __restrict__ src, double* lds, const Emit& em) {
   const int lane = lane_id();
   const u32* base = s.stream + (u64)c * (64 * K);
-  const uint4* p = reinterpret_cast<const uint4*>(base + lane * K);
-  u32 id[K];
-#pragma unroll
-  for (int q = 0; q < K / 4; q++) { const uint4 w = p[q]; id[4 * q] = w.x; id[4 * q + 1] = w.y; id[4 * q + 2] = w.z; id[4 * q + 3] = w.w; }
-  const u32 sb = s.seg_base[c];
-  const u32 hd = s.head[c];
+  u32 (&id)[K] = w.id;
+  const u32 sb = w.sb;
+  const u32 hd = w.hd;
   const bool heavy = (hd & PM_HEAVY) != 0;
   const u32 hlen = heavy ? 0u : hd;
   u32 hid[PM_HEAD];
@@ -1302,10 +1311,13 @@ __device__ __forceinline__ void pm_count_changes(int ch, int* lds_ch, EmState* r
 }
 
 // rows launch (first of the round: block 0 publishes the round's loop-control record, like k_em_rows)
-template <int K, int PRE>
+template <int K, int PRE, bool EARLY>
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity) {
   __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
   const EmState prev = A.st[parity ^ 1];
+  const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
+  PmWave<K> w;
+  if (EARLY && c < A.rows.n_chunks) pm_wave_load<K>(A.rows, c, w);
   const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, false);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     EmState r; r.iter = now.it; r.chcount = 0; r.final_round = now.fin; r.done = now.done; r.rounds = now.rounds; r.force_final = 0;
@@ -1314,24 +1326,28 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity)
   }
   if (now.done) return;
   const int odd = now.it & 1;
-  const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
   if (c >= A.rows.n_chunks) return;
+  if (!EARLY) pm_wave_load<K>(A.rows, c, w);
   const PmRowEmit em{A.cw, A.g};
   const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
-  pm_wave_pass<K, PRE>(A.rows, c, a_cur, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  pm_wave_pass<K, PRE>(A.rows, c, w, a_cur, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
 }
-template <int K, int PRE>
+template <int K, int PRE, bool EARLY>
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity) {
   __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
   __shared__ int lds_ch;
-  const EmNow now = em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, false);
-  if (now.done) return;
-  const int odd = now.it & 1;
+  const EmState prev = A.st[parity ^ 1];
   const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
+  PmWave<K> w;
+  if (EARLY && c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
+  const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, false);
+  if (now.done) return;
+  if (!EARLY && c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
+  const int odd = now.it & 1;
   int ch = 0;
   const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
   const PmColEmit em{odd ? A.alpha1 : A.alpha0, a_cur, A.single, A.eff, odd ? A.alpha0 : A.alpha1, odd ? A.a0 : A.a1, odd ? A.ac0 : A.ac1, &ch, now.fin};
-  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE>(A.cols, c, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE>(A.cols, c, w, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
   pm_count_changes(ch, &lds_ch, &A.st[parity]);
 }
 // fix-up launches (only enqueued when a direction has heavy crossing segments)
@@ -2193,19 +2209,22 @@ struct Carver {  // sub-allocations of one device arena, 256-byte aligned
 struct PmPlan {
   PmArgs args{};
   int k = 0;                 // entries per lane
+  bool early = true;         // the chunk's loads are issued before the loop-control record is used (KAMD_EM_EARLY=0: after; ~2.5 % slower)
   u32 n_chunks = 0;
   u32 n_fix[2] = {0, 0};     // heavy crossing segments per direction (0: no fix-up launch)
   const u32* mflag = nullptr; const u64* mpos = nullptr;   // transcript -> m-space
 };
-constexpr int PM_KS[] = {8, 12, 16, 20, 24, 32};
+constexpr int PM_KS[] = {8, 12, 16, 20, 24, 28, 32};
 template <int K>
 void pm_launch_round(const PmPlan& P, hipStream_t s, int parity) {
   const unsigned grid = grid_for(P.n_chunks, PM_BLOCK / 64);
   constexpr int PRE_R = (K + 5) / 6 < 2 ? 2 : (K + 5) / 6;   // 64 * PRE >= ~chunk / 6 row ends
   constexpr int PRE_C = K / 16 + 1;                           // 64 * PRE >= ~chunk / 16 column ends
-  hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  if (P.early) hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  else hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
   if (P.n_fix[0]) hipLaunchKernelGGL(k_pm_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, parity);
-  hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  if (P.early) hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  else hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
   if (P.n_fix[1]) hipLaunchKernelGGL(k_pm_cols_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, parity);
 }
 void pm_enqueue_round(const PmPlan& P, hipStream_t s, int parity) {
@@ -2215,6 +2234,7 @@ void pm_enqueue_round(const PmPlan& P, hipStream_t s, int parity) {
     case 16: pm_launch_round<16>(P, s, parity); break;
     case 20: pm_launch_round<20>(P, s, parity); break;
     case 24: pm_launch_round<24>(P, s, parity); break;
+    case 28: pm_launch_round<28>(P, s, parity); break;
     default: pm_launch_round<32>(P, s, parity); break;
   }
 }
@@ -2252,10 +2272,11 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   if (NZ == 0 || R == 0 || M == 0 || R >= 0x7FFFFFF0ULL || M >= 0x7FFFFFF0ULL || NZ >= (1ULL << 40)) return 1;
   hipLaunchKernelGGL(k_pm_rank, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, start, fill, rpos, len_sorted);
   if (int rc = exclusive_scan(c, len_sorted, R, roff, roff + R)) return rc;   // roff[R] = NZ
-  // entries per lane: the smallest K whose chunks fit the chip in one go at 16 wavefronts per CU (<= 128 VGPRs)
+  // entries per lane: the smallest K whose chunks fit the chip in one go at 12 wavefronts per CU (measured on config #3:
+  // 28.0 us per round at K = 24 / 3038 chunks against 32.7 at K = 20 / 3646 and 32.5 at K = 16 / 4557, same box)
   int K = PM_KS[sizeof(PM_KS) / sizeof(PM_KS[0]) - 1];
   if (const char* e = getenv("KAMD_EM_K")) { const int v = atoi(e); for (int k : PM_KS) if (k == v) K = v; }
-  else for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 16) { K = k; break; }
+  else for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 12) { K = k; break; }
   const u32 chunk = 64u * (u32)K;
   const u64 n_chunks64 = (NZ + chunk - 1) / chunk;
   if (n_chunks64 >= 0x7FFFFFF0ULL) return 1;
@@ -2310,6 +2331,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   A.st = (EmState*)c->em_state.p;
   HIPC(hipMemcpyAsync(P->n_fix, b2 + o_nfix, sizeof P->n_fix, hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  if (const char* e = getenv("KAMD_EM_EARLY")) P->early = atoi(e) != 0;
   P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos;
   c->last_em_nnz_multi = NZ; c->last_em_nseg = n_chunks; c->last_em_necs = n_ecs; c->last_em_k = K;
   c->last_em_grid = grid_for(n_chunks, PM_BLOCK / 64);

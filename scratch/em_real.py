@@ -20,13 +20,11 @@ flens, _ = ctx.fld_from_batch(opts, words, lens, n, L)
 ctx.finalize(download=False)
 eff = A.eff_lens(index.target_lens, A.mean_frag_lens_trunc(flens))
 ref = None
-for mode in [None, 12, 16, 20, 24]:
-    os.environ["KAMD_EM_STREAMED"] = "0" if mode == "csr" else "1"
-    if isinstance(mode, int): os.environ["KAMD_EM_K"] = str(mode)
-    else: os.environ.pop("KAMD_EM_K", None)
+for mode in [(0, 16), (1, 16), (0, 20), (1, 20), (0, 24), (1, 24), (0, 20), (1, 16)]:
+    os.environ["KAMD_EM_EARLY"] = str(mode[0]); os.environ["KAMD_EM_K"] = str(mode[1])
     for rep in range(2):
         a, z, r = ctx.em_run(eff)
     p = ctx.profile()
     if ref is None: ref = a
     rel = np.max(np.abs(a - ref) / np.maximum(np.abs(ref), 1e-6))
-    print(f"{str(mode):5s} rounds {r} em_ms {p['em_ms']:.2f} -> {1e3*p['em_ms']/max(p['em_iters'],1):.2f} us/round K {p['em_k']} chunks {p['em_nseg']} max rel vs csr {rel:.2e}", flush=True)
+    print(f"{str(mode):9s} rounds {r} em_ms {p['em_ms']:.2f} -> {1e3*p['em_ms']/max(p['em_iters'],1):.2f} us/round K {p['em_k']} chunks {p['em_nseg']} max rel vs csr {rel:.2e}", flush=True)

@@ -175,7 +175,7 @@ def _family_csr(n_genes, seed):
     return off, ids, cnt, rng.uniform(150, 3000, T), T
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 32, "csr"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "csr"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The streamed EM form (default and forced chunk sizes: 64 x 8 entries makes the long rows / hub columns span many
     chunks -> fix-up launches) and the CSR form against the oracle's EMAlgorithm::run restatement."""
@@ -201,7 +201,10 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     assert rounds == rounds_o
     assert abs(alpha.sum() - cnt.sum()) < 1e-6 * cnt.sum()
     common.assert_abundance_close(alpha, alpha_o, "alpha", rel=1e-9)
-    common.assert_abundance_close(abz, abz_o, "alpha_before_zeroes", rel=1e-9, floor=1e-12)
+    # alpha_before_zeroes decays geometrically for transcripts the data does not support; where exactly a value underflows to
+    # 0 depends on the summation order, so values below 1e-200 count as zero here (the final alpha clamps below 1e-8 anyway)
+    tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
+    common.assert_abundance_close(tiny(abz), tiny(abz_o), "alpha_before_zeroes", rel=1e-9, floor=1e-12)
 
 
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe_boot"), ("human_pe", "pe_boot")])
