@@ -1150,6 +1150,7 @@ struct PmArgs {
   u32 R, M;
   int n_iter, min_rounds;
   EmState* st;             // the two parity-indexed loop-control records (see EmState)
+  int* spec_hist;          // partitioned EM: per-round change counts of this rank (the stop rule is applied by the host); else null
 };
 
 // what is done with a finished segment sum: load() fetches the segment's constants (issued before the sums are known,
@@ -1318,11 +1319,12 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity)
   const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
   PmWave<K> w;
   if (EARLY && c < A.rows.n_chunks) pm_wave_load<K>(A.rows, c, w);
-  const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, false);
+  const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, A.spec_hist != nullptr);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     EmState r; r.iter = now.it; r.chcount = 0; r.final_round = now.fin; r.done = now.done; r.rounds = now.rounds; r.force_final = 0;
     r.pad[0] = r.pad[1] = 0;
     A.st[parity] = r;
+    if (A.spec_hist && !prev.done && prev.iter >= 0) A.spec_hist[prev.iter] = prev.chcount;
   }
   if (now.done) return;
   const int odd = now.it & 1;
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity)
   const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
   PmWave<K> w;
   if (EARLY && c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
-  const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, false);
+  const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, A.spec_hist != nullptr);
   if (now.done) return;
   if (!EARLY && c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
   const int odd = now.it & 1;
@@ -1352,13 +1354,13 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity)
 }
 // fix-up launches (only enqueued when a direction has heavy crossing segments)
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_fix(PmArgs A, int parity) {
-  if (em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, false).done) return;
+  if (em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, A.spec_hist != nullptr).done) return;
   const PmRowEmit em{A.cw, A.g};
   pm_fix(A.rows, blockIdx.x * PM_BLOCK + threadIdx.x, em);
 }
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_fix(PmArgs A, int parity) {
   __shared__ int lds_ch;
-  const EmNow now = em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, false);
+  const EmNow now = em_next_round(A.st[parity ^ 1], A.n_iter, A.min_rounds, A.spec_hist != nullptr);
   if (now.done) return;
   const int odd = now.it & 1;
   int ch = 0;
@@ -1936,10 +1938,11 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
   u64 found = n_used ? *n_used : 0, done = 0;  // continues a sample started on earlier batches
+  const u64 found0 = found;
   const int cap_small = 64;
-  // the sample is the first 10000 qualifying pairs: start with a short prefix and grow (a quarter of the pairs qualify on
-  // typical data, so the first launch usually suffices)
-  u64 chunk = 65536;
+  // the sample is the first 10000 qualifying pairs: start with a prefix that suffices when a few per cent of the pairs
+  // qualify (config #3: 7.5 %), then size the next prefix from the rate seen so far
+  u64 chunk = 262144;
   DBuf &tl = c->fld_tl, &card = c->fld_card, &scratch = c->fld_scratch, &items = c->fld_items;
   std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
   int rc = 0;
@@ -1975,7 +1978,8 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
     for (u64 i = 0; i < n && found < 10000; i++)
       if (h_card[i] == 1 && h_tl[i] > 0 && h_tl[i] < KAMD_MAX_FRAG_LEN) { flens[h_tl[i]]++; found++; }
     done += n;
-    chunk = std::min<u64>(chunk * 4, 2097152);
+    const double rate = std::max((double)(found - found0) / (double)done, 1e-4);
+    chunk = std::min<u64>(std::max<u64>((u64)((double)(10000 - std::min<u64>(found, 10000)) / rate * 1.5), 65536), 2097152);
   }
   if (n_used) *n_used = found;
   return rc;
@@ -2426,13 +2430,12 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
   EmState hs{};
   c->last_em_nnz = nnz; c->last_em_k = 0; c->last_em_grid = 0;
-  // the streamed form (two launches per round over the re-laid-out matrix) unless the run is partitioned over ranks or
-  // KAMD_EM_STREAMED=0 asks for the CSR form
+  // the streamed form (two launches per round over the re-laid-out matrix) unless KAMD_EM_STREAMED=0 asks for the CSR form
   PmPlan plan;
   bool streamed = false;
   {
     const char* ep = getenv("KAMD_EM_STREAMED");
-    if (!spec && !(ep && atoi(ep) == 0)) {
+    if (!(ep && atoi(ep) == 0)) {
       const int rc = em_streamed_setup(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, T, col_cnt, col_fill, &plan);
       if (rc < 0) return rc;
       streamed = rc == 0;
@@ -2486,9 +2489,31 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     if (int rc = c->pt_hist.ensure(((size_t)n_iter + 2 * chunk + 8) * sizeof(int), 0, c->stream)) return rc;
     HIPC(hipMemsetAsync(c->pt_hist.p, 0, ((size_t)n_iter + 2 * chunk + 8) * sizeof(int), c->stream));
     spec_hist = (int*)c->pt_hist.p;
-    if (int rc = c->pt_ck_alpha.ensure(T * sizeof(double), 0, c->stream)) return rc;
-    if (int rc = c->pt_ck_a.ensure(T * sizeof(double), 0, c->stream)) return rc;
   }
+  plan.args.spec_hist = spec_hist;
+  // state that a rewind of the partitioned run has to restore: {buffer of even rounds, buffer of odd rounds, doubles}
+  struct CkSet { double* buf[2]; size_t n; };
+  std::vector<CkSet> ck;
+  if (streamed) {
+    const size_t n = (size_t)plan.args.M + 1;
+    ck = {{{plan.args.alpha0, plan.args.alpha1}, n}, {{plan.args.a0, plan.args.a1}, n}, {{plan.args.ac0, plan.args.ac1}, n}};
+  } else {
+    ck = {{{c->em_alpha.as<double>(), c->em_next.as<double>()}, (size_t)T}, {{c->em_a0.as<double>(), c->em_a1.as<double>()}, (size_t)T}};
+  }
+  if (spec) {
+    size_t tot = 0;
+    for (const CkSet& k : ck) tot += k.n;
+    if (int rc = c->pt_ck_alpha.ensure(tot * sizeof(double), 0, c->stream)) return rc;
+  }
+  auto checkpoint = [&](int par, bool restore) -> int {
+    double* store = c->pt_ck_alpha.as<double>();
+    for (const CkSet& k : ck) {
+      if (restore) HIPC(hipMemcpyAsync(k.buf[par], store, k.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      else HIPC(hipMemcpyAsync(store, k.buf[par], k.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      store += k.n;
+    }
+    return 0;
+  };
   int parity = 0;  // parity of the next round to enqueue (round r uses record r & 1 and reads record (r & 1) ^ 1)
   auto enqueue_rounds = [&](hipStream_t s, int n_rounds) {
     for (int it = 0; it < n_rounds; it++, parity ^= 1) {
@@ -2518,8 +2543,6 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     *now = em_next_round(recs[parity ^ 1], (int)n_iter, (int)min_rounds, spec);
     return 0;
   };
-  double* bufs_alpha[2] = {c->em_alpha.as<double>(), c->em_next.as<double>()};
-  double* bufs_a[2] = {c->em_a0.as<double>(), c->em_a1.as<double>()};
   EmNow now{};
   if (!spec) {
     const char* eg = getenv("KAMD_EM_GRAPH");
@@ -2553,8 +2576,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     std::vector<int> hist(chunk);
     int base = 0;
     for (;;) {
-      HIPC(hipMemcpyAsync(c->pt_ck_alpha.p, bufs_alpha[base & 1], T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      HIPC(hipMemcpyAsync(c->pt_ck_a.p, bufs_a[base & 1], T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (int rc = checkpoint(base & 1, false)) return rc;
       const int n_run = (int)std::min<long>(chunk, (long)n_iter - base);
       enqueue_rounds(c->stream, n_run);
       HIPC(hipGetLastError());
@@ -2571,8 +2593,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
         continue;
       }
       // rewind + replay rounds base..stop, then the clamped final round
-      HIPC(hipMemcpyAsync(bufs_alpha[base & 1], c->pt_ck_alpha.p, T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      HIPC(hipMemcpyAsync(bufs_a[base & 1], c->pt_ck_a.p, T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (int rc = checkpoint(base & 1, true)) return rc;
       EmState st0[2]; memset(st0, 0, sizeof st0);
       st0[1].iter = base - 1; st0[1].chcount = 1;                  // "the round before `base`" in slot 1, next parity 0
       HIPC(hipMemcpyAsync(c->em_state.p, st0, sizeof st0, hipMemcpyHostToDevice, c->stream));
