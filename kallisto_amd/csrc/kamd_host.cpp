@@ -31,26 +31,32 @@ extern "C" int kamd_pack_reads_host_strided(const char* seqs, const uint64_t* of
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pack_reads: max_len must be in [1, 65535]");
   if (rec_stride == 0) return kamd::fail(-1, "kamd_pack_reads: record stride must be positive");
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
+  // byte -> 2-bit code, 4 = not ACGT (case-insensitive: KmerIterator.cpp:12 masks with 0xDF)
+  static const struct Lut { uint8_t v[256]; Lut() { memset(v, 4, sizeof v); v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } } lut;
   for (uint64_t r = 0; r < n_reads; r++) {
     if (len[r] < 0 || len[r] > max_len) return kamd::fail(-1, "kamd_pack_reads: read longer than max_len");
     const uint64_t slot = rec_first + r * rec_stride;
     uint32_t* w = out_words + slot * rec;
-    memset(w, 0, rec * 4);
-    const char* s = seqs + off[r];
-    for (int32_t i = 0; i < len[r]; i++) {
-      unsigned char ch = (unsigned char)s[i] & 0xDF;  // case mask of KmerIterator.cpp:12
-      uint32_t code;
-      switch (ch) {
-        case 'A': code = 0; break;
-        case 'C': code = 1; break;
-        case 'G': code = 2; break;
-        case 'T': code = 3; break;
-        default: code = 4;
-      }
-      if (code < 4) w[i >> 4] |= code << (2 * (i & 15));
-      else w[sw + (i >> 5)] |= 1u << (i & 31);
+    const unsigned char* s = (const unsigned char*)(seqs + off[r]);
+    const int32_t L = len[r];
+    // 32 bases per step: two sequence words and one mask word, built in registers and stored once
+    int32_t i = 0;
+    uint64_t wi = 0, mi = 0;
+    for (; i + 32 <= L; i += 32) {
+      uint64_t bits = 0; uint32_t m = 0;
+      for (int j = 0; j < 32; j++) { const uint32_t c = lut.v[s[i + j]]; bits |= (uint64_t)(c & 3u) << (2 * j); m |= (c >> 2) << j; }
+      w[wi++] = (uint32_t)bits; w[wi++] = (uint32_t)(bits >> 32); w[sw + mi++] = m;
     }
-    out_len[slot] = (uint16_t)len[r];
+    {
+      uint64_t bits = 0; uint32_t m = 0;
+      for (int j = 0; i + j < L; j++) { const uint32_t c = lut.v[s[i + j]]; bits |= (uint64_t)(c & 3u) << (2 * j); m |= (c >> 2) << j; }
+      if (wi < sw) w[wi++] = (uint32_t)bits;
+      if (wi < sw) w[wi++] = (uint32_t)(bits >> 32);
+      if (sw + mi < rec) w[sw + mi++] = m;
+    }
+    while (wi < sw) w[wi++] = 0;             // padding words of the record
+    while (sw + mi < rec) w[sw + mi++] = 0;
+    out_len[slot] = (uint16_t)L;
   }
   return 0;
 }

@@ -19,6 +19,9 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -197,6 +200,81 @@ struct MappedFastq {
 #define HIPX(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::cerr << "Error: " #x ": " << hipGetErrorString(e_) << std::endl; exit(1); } } while (0)
 #define KX(x) do { if ((x) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; exit(1); } } while (0)
 
+// Two-slot pipeline between the host (FASTQ parsing + 2-bit packing into pinned memory, all host threads) and the device
+// (H2D copy, kamd_pseudoalign, FLD sample): batch i+1 is packed while batch i runs.  One consumer thread, batches in input
+// order (the FLD sample and the first-occurrence EC ids depend on it).
+struct PackedBatch {
+  uint32_t* h_words = nullptr; uint16_t* h_len = nullptr; size_t hw_cap = 0, hl_cap = 0;   // pinned host memory
+  uint32_t* d_words = nullptr; uint16_t* d_len = nullptr; size_t dw_cap = 0, dl_cap = 0;
+  uint64_t n_items = 0, n_reads = 0, n_words = 0;
+  int32_t max_len = 1;
+  bool filled = false;
+};
+class DevicePipe {
+ public:
+  explicit DevicePipe(std::function<void(PackedBatch&)> run) : run_(std::move(run)), th_([this] { loop(); }) {}
+  // a free slot whose pinned buffers hold n_words / n_reads entries (blocks while both slots are in flight)
+  PackedBatch& acquire(uint64_t n_words, uint64_t n_reads) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !slot_[fill_].filled; });
+    lk.unlock();
+    wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    PackedBatch& b = slot_[fill_];
+    if (n_words > b.hw_cap) { if (b.h_words) HIPX(hipHostFree(b.h_words)); b.hw_cap = n_words * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_words, b.hw_cap * 4, hipHostMallocDefault)); }
+    if (n_reads > b.hl_cap) { if (b.h_len) HIPX(hipHostFree(b.h_len)); b.hl_cap = n_reads * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_len, b.hl_cap * 2, hipHostMallocDefault)); }
+    b.n_words = n_words; b.n_reads = n_reads;
+    return b;
+  }
+  void submit() {
+    { std::lock_guard<std::mutex> lk(m_); slot_[fill_].filled = true; }
+    cv_.notify_all();
+    fill_ ^= 1;
+  }
+  ~DevicePipe() { finish(); }   // also on the error returns of main
+  void finish() {
+    if (!th_.joinable()) return;
+    { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !slot_[0].filled && !slot_[1].filled; }); stop_ = true; }
+    cv_.notify_all();
+    th_.join();
+    for (PackedBatch& b : slot_) {
+      if (b.h_words) (void)hipHostFree(b.h_words);
+      if (b.h_len) (void)hipHostFree(b.h_len);
+      if (b.d_words) (void)hipFree(b.d_words);
+      if (b.d_len) (void)hipFree(b.d_len);
+    }
+  }
+  double wait_s = 0.0, device_s = 0.0;   // producer blocked on a free slot / consumer busy
+ private:
+  void loop() {
+    HIPX(hipSetDevice(0));
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return slot_[run_i_].filled || stop_; });
+      if (!slot_[run_i_].filled) return;
+      lk.unlock();
+      const auto t0 = std::chrono::steady_clock::now();
+      PackedBatch& b = slot_[run_i_];
+      if (b.n_words > b.dw_cap) { if (b.d_words) HIPX(hipFree(b.d_words)); b.dw_cap = b.n_words * 5 / 4; HIPX(hipMalloc((void**)&b.d_words, b.dw_cap * 4)); }
+      if (b.n_reads > b.dl_cap) { if (b.d_len) HIPX(hipFree(b.d_len)); b.dl_cap = b.n_reads * 5 / 4; HIPX(hipMalloc((void**)&b.d_len, b.dl_cap * 2)); }
+      HIPX(hipMemcpy(b.d_words, b.h_words, b.n_words * 4, hipMemcpyHostToDevice));
+      HIPX(hipMemcpy(b.d_len, b.h_len, b.n_reads * 2, hipMemcpyHostToDevice));
+      run_(b);
+      device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      { std::lock_guard<std::mutex> g(m_); b.filled = false; }
+      cv_.notify_all();
+      run_i_ ^= 1;
+    }
+  }
+  std::function<void(PackedBatch&)> run_;
+  PackedBatch slot_[2];
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+  int fill_ = 0, run_i_ = 0;
+  std::thread th_;   // last member: started when everything above exists
+};
+
 std::string to_json(const std::string& id, const std::string& val, bool quote, bool comma = true) {  // PlaintextWriter.cpp:113-137
   std::string out = "\t\"" + id + "\": ";
   if (quote) out += '"';
@@ -281,24 +359,24 @@ int main(int argc, char** argv) {
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;
   std::string seqs; std::vector<uint64_t> off; std::vector<int32_t> len;
-  std::vector<uint32_t> words; std::vector<uint16_t> l16;
-  uint32_t* d_words = nullptr; uint16_t* d_len = nullptr; size_t cap_words = 0, cap_len = 0;
-  auto flush = [&]() {
+  double pack_s = 0.0;
+  DevicePipe pipe([&](PackedBatch& b) {
+    KX(kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len));
+    if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used));
+  });
+  auto flush = [&]() {   // the serial reader's batch: pack on this thread
     const uint64_t n_reads = off.size();
     if (!n_reads) return;
     int32_t max_len = 1;
     for (auto l : len) max_len = std::max(max_len, l);
     const uint64_t rec = kamd_packed_record_words(max_len);
-    words.resize(n_reads * rec); l16.resize(n_reads);
-    KX(kamd_pack_reads_host(seqs.data(), off.data(), len.data(), n_reads, max_len, words.data(), l16.data()));
-    if (words.size() > cap_words) { if (d_words) HIPX(hipFree(d_words)); cap_words = words.size() * 5 / 4; HIPX(hipMalloc((void**)&d_words, cap_words * 4)); }
-    if (l16.size() > cap_len) { if (d_len) HIPX(hipFree(d_len)); cap_len = l16.size() * 5 / 4; HIPX(hipMalloc((void**)&d_len, cap_len * 2)); }
-    HIPX(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
-    HIPX(hipMemcpy(d_len, l16.data(), l16.size() * 2, hipMemcpyHostToDevice));
-    const uint64_t n_items = paired ? n_reads / 2 : n_reads;
-    KX(kamd_pseudoalign(ctx, &qo, d_words, d_len, n_items, max_len));
-    if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, d_words, d_len, n_items, max_len, flens, &fld_used));
-    n_processed += n_items;
+    PackedBatch& b = pipe.acquire(n_reads * rec, n_reads);
+    const auto t0 = std::chrono::steady_clock::now();
+    KX(kamd_pack_reads_host(seqs.data(), off.data(), len.data(), n_reads, max_len, b.h_words, b.h_len));
+    pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    b.n_items = paired ? n_reads / 2 : n_reads; b.max_len = max_len;
+    pipe.submit();
+    n_processed += b.n_items;
     if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
     seqs.clear(); off.clear(); len.clear();
   };
@@ -321,24 +399,22 @@ int main(int argc, char** argv) {
           for (uint64_t i = b0; i < b0 + nb; i++) { max_len = std::max(max_len, m1.len[i]); if (paired) max_len = std::max(max_len, m2.len[i]); }
           if (max_len > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; return 1; }
           const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
-          words.resize(n_reads * rec); l16.resize(n_reads);
+          PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
+          const auto t0 = std::chrono::steady_clock::now();
           std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0);
           for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
             const uint64_t a = b0 + nb * t / host_threads, e = b0 + nb * (t + 1) / host_threads;
             if (e == a) return;
             const uint64_t first = (a - b0) * (paired ? 2 : 1);
-            rcs[t] = kamd_pack_reads_host_strided(m1.data, m1.off.data() + a, m1.len.data() + a, e - a, max_len, words.data(), l16.data(), paired ? 2 : 1, first);
+            rcs[t] = kamd_pack_reads_host_strided(m1.data, m1.off.data() + a, m1.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, paired ? 2 : 1, first);
             if (paired && rcs[t] == 0)
-              rcs[t] = kamd_pack_reads_host_strided(m2.data, m2.off.data() + a, m2.len.data() + a, e - a, max_len, words.data(), l16.data(), 2, first + 1);
+              rcs[t] = kamd_pack_reads_host_strided(m2.data, m2.off.data() + a, m2.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, 2, first + 1);
           });
           for (auto& x : th) x.join();
           for (int rc : rcs) if (rc) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
-          if (words.size() > cap_words) { if (d_words) HIPX(hipFree(d_words)); cap_words = words.size() * 5 / 4; HIPX(hipMalloc((void**)&d_words, cap_words * 4)); }
-          if (l16.size() > cap_len) { if (d_len) HIPX(hipFree(d_len)); cap_len = l16.size() * 5 / 4; HIPX(hipMalloc((void**)&d_len, cap_len * 2)); }
-          HIPX(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
-          HIPX(hipMemcpy(d_len, l16.data(), l16.size() * 2, hipMemcpyHostToDevice));
-          KX(kamd_pseudoalign(ctx, &qo, d_words, d_len, nb, max_len));
-          if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, d_words, d_len, nb, max_len, flens, &fld_used));
+          pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          pb.n_items = nb; pb.max_len = max_len;
+          pipe.submit();
           n_processed += nb;
           if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
         }
@@ -360,6 +436,10 @@ int main(int argc, char** argv) {
     delete r2;
   }
   flush();
+  pipe.finish();
+  if (opt.verbose)
+    std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s << " s, host waited for the device "
+              << pipe.wait_s << " s" << std::endl;
   std::cerr << "[quant] finding pseudoalignments for the reads ... done" << std::endl;
 
   kamd_ec_result ec;
@@ -424,8 +504,6 @@ int main(int argc, char** argv) {
     }
     std::cerr << std::endl;
   }
-  if (d_words) HIPX(hipFree(d_words));
-  if (d_len) HIPX(hipFree(d_len));
   kamd_ctx_destroy(ctx);
   kamd_index_free(idx);
   return num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797
