@@ -119,6 +119,54 @@ class SeqReader {
   bool pending_header_ = false;
 };
 
+// ---- gzip / FASTA input: one decompress-and-parse thread per file hands over chunks of `n` sequences, so the two mates'
+// files inflate concurrently and the main thread only pairs chunks and packs them with all host threads ----
+struct SeqChunk { std::string seqs; std::vector<uint64_t> off; std::vector<int32_t> len; };
+class ChunkReader {
+ public:
+  ChunkReader(const std::string& path, uint64_t n) : r_(path), n_(n), th_([this] { loop(); }) {}
+  ~ChunkReader() { { std::lock_guard<std::mutex> g(m_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+  // next chunk (fewer than n sequences only at the end of the file); false when the file is exhausted
+  bool next(SeqChunk& out) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !q_.empty() || eof_; });
+    if (q_.empty()) return false;
+    out = std::move(q_.front()); q_.erase(q_.begin());
+    lk.unlock();
+    cv_.notify_all();
+    return true;
+  }
+ private:
+  void loop() {
+    std::string s;
+    for (;;) {
+      SeqChunk c;
+      while (c.off.size() < n_ && r_.next(s)) {
+        if (s.size() > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; exit(1); }
+        c.off.push_back(c.seqs.size()); c.len.push_back((int32_t)s.size()); c.seqs += s;
+      }
+      const bool last = c.off.size() < n_;
+      std::unique_lock<std::mutex> lk(m_);
+      if (!c.off.empty()) {
+        cv_.wait(lk, [&] { return q_.size() < 3 || stop_; });   // at most 3 chunks ahead
+        if (stop_) return;
+        q_.push_back(std::move(c));
+      }
+      if (last) eof_ = true;
+      lk.unlock();
+      cv_.notify_all();
+      if (last) return;
+    }
+  }
+  SeqReader r_;
+  uint64_t n_;
+  std::vector<SeqChunk> q_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool eof_ = false, stop_ = false;
+  std::thread th_;
+};
+
 // ---- fast path for plain (uncompressed) 4-line FASTQ: mmap + one parser thread per chunk --------------------------------
 // FastqSequenceReader::fetchSequences (src/ProcessReads.cpp:3128-3267) parses serially under a lock; here every thread scans
 // its slice of the file for record starts and the records are paired by index afterwards.
@@ -358,28 +406,11 @@ int main(int argc, char** argv) {
   std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;
-  std::string seqs; std::vector<uint64_t> off; std::vector<int32_t> len;
   double pack_s = 0.0;
   DevicePipe pipe([&](PackedBatch& b) {
     KX(kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len));
     if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used));
   });
-  auto flush = [&]() {   // the serial reader's batch: pack on this thread
-    const uint64_t n_reads = off.size();
-    if (!n_reads) return;
-    int32_t max_len = 1;
-    for (auto l : len) max_len = std::max(max_len, l);
-    const uint64_t rec = kamd_packed_record_words(max_len);
-    PackedBatch& b = pipe.acquire(n_reads * rec, n_reads);
-    const auto t0 = std::chrono::steady_clock::now();
-    KX(kamd_pack_reads_host(seqs.data(), off.data(), len.data(), n_reads, max_len, b.h_words, b.h_len));
-    pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    b.n_items = paired ? n_reads / 2 : n_reads; b.max_len = max_len;
-    pipe.submit();
-    n_processed += b.n_items;
-    if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
-    seqs.clear(); off.clear(); len.clear();
-  };
   const int host_threads = std::max(1, opt.threads);
   for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
     std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
@@ -391,7 +422,6 @@ int main(int argc, char** argv) {
       if (fast && paired) fast = m2.open(opt.files[fi + 1]) && m2.index_records(host_threads);
       if (fast) {
         if (paired && m1.off.size() != m2.off.size()) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
-        flush();  // anything buffered by the serial reader of an earlier file
         const uint64_t n_items_total = m1.off.size();
         for (uint64_t b0 = 0; b0 < n_items_total; b0 += opt.batch) {
           const uint64_t nb = std::min<uint64_t>(opt.batch, n_items_total - b0);
@@ -423,19 +453,38 @@ int main(int argc, char** argv) {
       }
       m1.close(); m2.close();
     }
-    SeqReader r1(opt.files[fi]);
-    SeqReader* r2 = paired ? new SeqReader(opt.files[fi + 1]) : nullptr;
-    std::string s1, s2;
-    while (r1.next(s1)) {
-      if (paired && !r2->next(s2)) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
-      if (s1.size() > 65535 || s2.size() > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; return 1; }
-      off.push_back(seqs.size()); len.push_back((int32_t)s1.size()); seqs += s1;
-      if (paired) { off.push_back(seqs.size()); len.push_back((int32_t)s2.size()); seqs += s2; }
-      if (off.size() >= opt.batch * (paired ? 2 : 1)) flush();
+    ChunkReader r1(opt.files[fi], opt.batch);
+    ChunkReader* r2 = paired ? new ChunkReader(opt.files[fi + 1], opt.batch) : nullptr;
+    SeqChunk c1, c2;
+    while (r1.next(c1)) {
+      if (paired && (!r2->next(c2) || c2.off.size() != c1.off.size())) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
+      const uint64_t nb = c1.off.size();
+      int32_t max_len = 1;
+      for (auto l : c1.len) max_len = std::max(max_len, l);
+      if (paired) for (auto l : c2.len) max_len = std::max(max_len, l);
+      const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
+      PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
+      const auto t0 = std::chrono::steady_clock::now();
+      std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0);
+      for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
+        const uint64_t a = nb * t / host_threads, e = nb * (t + 1) / host_threads;
+        if (e == a) return;
+        const uint64_t first = a * (paired ? 2 : 1);
+        rcs[t] = kamd_pack_reads_host_strided(c1.seqs.data(), c1.off.data() + a, c1.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, paired ? 2 : 1, first);
+        if (paired && rcs[t] == 0)
+          rcs[t] = kamd_pack_reads_host_strided(c2.seqs.data(), c2.off.data() + a, c2.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, 2, first + 1);
+      });
+      for (auto& x : th) x.join();
+      for (int rc : rcs) if (rc) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+      pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      pb.n_items = nb; pb.max_len = max_len;
+      pipe.submit();
+      n_processed += nb;
+      if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
     }
+    if (paired && r2->next(c2)) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
     delete r2;
   }
-  flush();
   pipe.finish();
   if (opt.verbose)
     std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s << " s, host waited for the device "

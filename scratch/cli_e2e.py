@@ -15,3 +15,11 @@ p = subprocess.run(["/root/repo/kallisto_amd/kallisto_amd_quant", "quant", "-i",
 dt = time.time() - t
 print("\n".join(l for l in p.stderr.decode().splitlines() if "processed" not in l)[-900:])
 print("CLI end-to-end: %.1f s for %d pairs (%.2f M pairs/s incl. index load)" % (dt, n, n / dt / 1e6))
+# gzip input (threaded readers: one inflate thread per file)
+m = 2_000_000
+os.system(f"head -n {4*m} /tmp/e2e_1.fq | gzip -1 > /tmp/e2e_1.fq.gz; head -n {4*m} /tmp/e2e_2.fq | gzip -1 > /tmp/e2e_2.fq.gz")
+t = time.time()
+p = subprocess.run(["/root/repo/kallisto_amd/kallisto_amd_quant", "quant", "-i", idx, "-o", "/tmp/e2e_out_gz", "-t", os.environ.get("THREADS", "32"), "--verbose", "/tmp/e2e_1.fq.gz", "/tmp/e2e_2.fq.gz"], stderr=subprocess.PIPE)
+dt = time.time() - t
+print("\n".join(l for l in p.stderr.decode().splitlines() if "host packing" in l or "rror" in l))
+print("CLI end-to-end, gzip input: %.1f s for %d pairs" % (dt, m))
