@@ -56,9 +56,17 @@ typedef struct {
   const uint64_t* blk_pos_off;    /* [n_blocks + 1] into blk_posw / blk_sense (parallel to the block's transcript set) */
   const uint32_t* blk_posw;       /* first raw position word per (block, transcript); bit31 = reverse */
   const uint8_t* blk_sense;       /* 1 forward, 0 reverse, 2 ambiguous */
-  const int32_t* target_lens;     /* [n_targets] */
+  const int32_t* target_lens;     /* [n_targets + dlist_size]: the D-list pseudo-targets (ids >= n_targets, off-list) have length 0 */
   const uint32_t* onlist_bits;    /* bit t set = transcript t is on-list */
   uint64_t onlist_words;
+  /* D-list (src/KmerIndex.cpp:1386-1403; match(): :1818-1826, :1928-1939): the distinguishing flanking k-mers as a second
+   * table of the k-mer table's layout (payload unused), and the hit pushed when a read contains one: um_dummy = the first
+   * D-list k-mer looked up in the graph.  n_dbuckets == 0 when the index carries no D-list. */
+  const uint64_t* dtable;
+  uint64_t n_dbuckets, dpad_buckets;
+  uint64_t dummy_slot;            /* slot of the dummy k-mer in `table` */
+  uint32_t dummy_uec;             /* its (unitig, transcript-set) class */
+  uint32_t dummy_strand;          /* const_UnitigMap::strand of um_dummy */
 } kamd_index_view;
 
 typedef struct {

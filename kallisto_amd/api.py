@@ -32,7 +32,8 @@ class _View(C.Structure):
                 [(n, C.c_void_p) for n in ("table", "slot_block", "slot_dist", "uec_ec", "ec_off", "ec_ids",
                                            "unitig_blk_off", "unitig_len", "blk_unitig", "blk_lb", "blk_ub", "blk_ec",
                                            "blk_pos_off", "blk_posw", "blk_sense", "target_lens", "onlist_bits")] +
-                [("onlist_words", C.c_uint64)])
+                [("onlist_words", C.c_uint64), ("dtable", C.c_void_p), ("n_dbuckets", C.c_uint64), ("dpad_buckets", C.c_uint64),
+                 ("dummy_slot", C.c_uint64), ("dummy_uec", C.c_uint32), ("dummy_strand", C.c_uint32)])
 
 
 class QuantOpts(C.Structure):

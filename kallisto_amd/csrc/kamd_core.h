@@ -137,6 +137,15 @@ KAMD_HD uint64_t window_canon(const ReadView& r, int w, int k, bool* is_fwd_cano
 struct Table {
   const uint64_t* slots;  // 2 words per slot
   uint64_t n_buckets;
+  // D-list (kb-python style indices): the distinguishing flanking k-mers as a second table of the same layout (payload
+  // unused), and the hit that is pushed when a read contains one of them -- um_dummy = dbg.find(first D-list k-mer),
+  // src/KmerIndex.cpp:1386-1403.  n_dbuckets == 0: the index carries no D-list.
+  const uint64_t* dslots = nullptr;
+  uint64_t n_dbuckets = 0;
+  uint32_t dummy_uec = 0;
+  uint64_t dummy_slot = 0;
+  bool dummy_strand = false;
+  bool partial = false;   // match(..., partial): single-end reads (src/ProcessReads.cpp:1058)
 };
 struct Probe {
   bool found;
@@ -287,6 +296,20 @@ KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* e
     }
     w = next_valid_window(r, w + 1, k);
   }
+  // D-list (:1928-1939): the first k-mer of the read that is a distinguishing flanking k-mer pushes the dummy hit.  (The
+  // early exit of :1818-1826 -- same test on the jump target in `partial` mode -- only ends the search sooner: the dummy
+  // hit is pushed either way, and it is the set of pushed classes that decides the outcome.)
+  if (t.n_dbuckets && (mi.n_hits > 0 || !t.partial)) {
+    const Table dt{t.dslots, t.n_dbuckets};
+    for (int wd = next_valid_window(r, 0, k); wd >= 0; wd = next_valid_window(r, wd + 1, k)) {
+      bool fcd; const uint64_t cd = window_canon(r, wd, k, &fcd);
+      if (probe_table(dt, cd, fcd, &mi.bucket_reads).found) {
+        Probe dm; dm.found = true; dm.strand = t.dummy_strand; dm.uec = t.dummy_uec; dm.dist = 0; dm.slot = t.dummy_slot;
+        KAMD_PUSH(dm, wd);
+        break;
+      }
+    }
+  }
 #undef KAMD_PUSH
 }
 
@@ -296,7 +319,7 @@ KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* e
 // that finishes a read immediately starts the next one.  States follow the probe sites of KmerIndex::match:
 //   SCAN (:1753)  JUMP (:1804)  MIDDLE (:1839)  BACKOFF (:1900)
 // ---------------------------------------------------------------------------------------------------------------
-enum { PH_SCAN = 0, PH_JUMP = 1, PH_MIDDLE = 2, PH_BACKOFF = 3, PH_DONE = 4 };
+enum { PH_SCAN = 0, PH_JUMP = 1, PH_MIDDLE = 2, PH_BACKOFF = 3, PH_DONE = 4, PH_DLIST = 5 };  // PH_DLIST: the D-list scan of :1928-1939
 struct MatchState {
   int phase;
   int w;        // window the next probe must look up
@@ -319,6 +342,16 @@ KAMD_HD void ueclist_add(UecList& l, uint32_t uec, int mate) {
 }
 struct MateFirst { int n_hits; uint64_t slot; int pos; bool strand; };
 
+// the table the pending probe of a phase goes to
+KAMD_HD Table phase_table(const Table& t, int phase) { return phase == PH_DLIST ? Table{t.dslots, t.n_dbuckets} : t; }
+// when match()'s loop is over: start the D-list scan if the index has one (:1928-1930)
+KAMD_HD void match_finish(MatchState& st, const ReadView& r, int k, const Table& t, const MateFirst& mf) {
+  st.phase = PH_DONE;
+  if (t.n_dbuckets && (mf.n_hits > 0 || !t.partial)) {
+    st.w = next_valid_window(r, 0, k);
+    if (st.w >= 0) st.phase = PH_DLIST;
+  }
+}
 KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
   st.w = next_valid_window(r, 0, k);
   st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
@@ -327,9 +360,21 @@ KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
 // consume the probe result of window st.w.  Written data-flow style: every phase only decides (a) whether the hit is
 // recorded, (b) where the next window search starts and (c) the phase that follows; the list insertion and the single
 // next_valid_window call are shared by all phases, so a wavefront whose lanes are in different phases executes them once.
-KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf) {
+KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf, const Table& t) {
   const int lk = r.len - k;
   const int ph = st.phase;
+  if (ph == PH_DLIST) {   // p = probe of the D-list table
+    if (p.found) {
+      if (mf.n_hits == 0) { mf.slot = t.dummy_slot; mf.pos = st.w; mf.strand = t.dummy_strand; }
+      ++mf.n_hits;
+      ueclist_add(list, t.dummy_uec, mate);
+      st.phase = PH_DONE;
+      return;
+    }
+    st.w = next_valid_window(r, st.w + 1, k);
+    if (st.w < 0) st.phase = PH_DONE;
+    return;
+  }
   bool hit = false, add = false, done = false;
   int start = -1;              // next_valid_window(start) decides the next window ...
   bool guard_len = false;      // ... after operator+='s end-of-string test (start + k > len -> end), KmerIterator.cpp:47-60
@@ -380,14 +425,15 @@ KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p
   }
   if (hit) ++mf.n_hits;
   if (add) ueclist_add(list, p.uec, mate);
-  if (done) { st.phase = PH_DONE; return; }
+  if (done) { match_finish(st, r, k, t, mf); return; }
   int w;
   if (stay) w = st.w0;
   else w = (guard_len && start + k > r.len) ? -1 : next_valid_window(r, start, k);
   if (w < 0 && fallback_backoff) { w = next_valid_window(r, st.w0 + 1, k); ph_ok = PH_BACKOFF; }
-  if (ph_ok == PH_JUMP) { if (w < 0) { st.phase = PH_DONE; return; } st.w2 = w; }  // :1882-1886 (Q4)
+  if (ph_ok == PH_JUMP) { if (w < 0) { match_finish(st, r, k, t, mf); return; } st.w2 = w; }  // :1882-1886 (Q4)
+  if (w < 0) { match_finish(st, r, k, t, mf); return; }
   st.w = w;
-  st.phase = w >= 0 ? ph_ok : PH_DONE;
+  st.phase = ph_ok;
 }
 
 // map the item's (unitig, set) classes to sorted distinct non-empty transcript-set ids; reports per mate whether any of

@@ -119,9 +119,15 @@ struct kamd_index {
   std::vector<int32_t> target_lens;
   std::vector<std::string> target_names;
   std::vector<uint32_t> onlist_bits;
+  uint64_t n_targets = 0;           // real targets (what abundance.tsv lists); target_lens also covers the D-list pseudo-targets
   uint64_t n_buckets = 0, pad_buckets = 0;
   std::vector<uint64_t> table;
   std::vector<uint32_t> slot_block, slot_dist;
+  // D-list
+  std::vector<uint64_t> dlist_keys;   // canonical, right-aligned; [0] = the dummy (the one that is in the graph)
+  uint64_t n_dbuckets = 0, dpad_buckets = 0;
+  std::vector<uint64_t> dtable;
+  uint64_t dummy_slot = 0; uint32_t dummy_uec = 0, dummy_strand = 0;
 };
 
 namespace {
@@ -213,9 +219,17 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   if (c.bad) return kamd::fail(-3, "index: bad mphf section");
   // 2.2 D-list (KmerIndex.cpp:1386-1403)
   ix->dlist_size = c.get<uint64_t>();
-  (void)c.get<uint64_t>();
-  c.take(ix->dlist_size * 8);
-  if (ix->dlist_size != 0) return kamd::fail(-4, "index carries a D-list: not supported by this build (SURVEY.md section 8f item 2)");
+  (void)c.get<uint64_t>();  // overhang: only used when the index is built
+  {
+    const uint8_t* dl = c.take(ix->dlist_size * 8);
+    if (ix->dlist_size && !dl) return kamd::fail(-3, "index: truncated D-list");
+    ix->dlist_keys.resize(ix->dlist_size);
+    for (uint64_t i = 0; i < ix->dlist_size; i++) {
+      uint64_t raw; memcpy(&raw, dl + 8 * i, 8);          // a Kmer object: base j at bits 62 - 2j (Kmer.cpp:92-114)
+      const uint64_t v = raw >> (64 - 2 * k), rc = kamd::revcomp_msb(v, k);
+      ix->dlist_keys[i] = v < rc ? v : rc;                 // stored as rep() already; canonicalised again for safety
+    }
+  }
 
   // 3. nodes
   uint64_t n_nodes = c.get<uint64_t>();
@@ -289,9 +303,15 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   // 4-6. targets (KmerIndex.cpp:1470-1519)
   int32_t nt = c.get<int32_t>();
   if (c.bad || nt < 0) return kamd::fail(-3, "index: bad target count");
-  ix->target_lens.resize((size_t)nt);
-  for (int32_t i = 0; i < nt; i++) ix->target_lens[i] = c.get<int32_t>();
-  for (int32_t i = 0; i < nt; i++) {
+  // the count includes one pseudo-target per D-list k-mer ("d_list.N", KmerIndex.cpp:940-960); lengths and names are only
+  // stored for the real ones (num_trans -= d_list.size(), :1297).  The pseudo-targets keep ids [n_real, nt) in the
+  // transcript sets (off-list); their length entries are 0 so that every id can index target_lens.
+  const int64_t n_real = (int64_t)nt - (int64_t)ix->dlist_size;
+  if (n_real < 0) return kamd::fail(-3, "index: bad target count");
+  ix->n_targets = (uint64_t)n_real;
+  ix->target_lens.assign((size_t)nt, 0);
+  for (int64_t i = 0; i < n_real; i++) ix->target_lens[i] = c.get<int32_t>();
+  for (int64_t i = 0; i < n_real; i++) {
     uint64_t n = c.get<uint64_t>();
     const uint8_t* s = c.take(n);
     if (!s) return kamd::fail(-3, "index: bad target name");
@@ -375,6 +395,36 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, place); else place(0, single_kmer(u));
   });
   for (uint64_t b = 0; b < total_buckets; b++) if (cont_all[b]) ix->table[8 * b] |= kamd::KEY_CONT;
+  // ---- D-list table (same bucket layout, built serially: it is small) and the dummy hit ----
+  if (ix->dlist_size) {
+    const uint64_t nd = ix->dlist_size, ndb = std::max<uint64_t>(16, (nd + 1) / 2);
+    std::vector<std::pair<uint64_t, uint64_t>> byhome(nd);   // (home bucket, key)
+    for (uint64_t i = 0; i < nd; i++) byhome[i] = {kamd::home_bucket(ix->dlist_keys[i], ndb), ix->dlist_keys[i]};
+    std::sort(byhome.begin(), byhome.end());
+    byhome.erase(std::unique(byhome.begin(), byhome.end()), byhome.end());
+    // Robin Hood order: keys of a home bucket are laid down sequentially, never before their home
+    std::vector<uint64_t> slot_of(byhome.size());
+    uint64_t cur = 0;
+    for (size_t i = 0; i < byhome.size(); i++) { cur = std::max(cur, byhome[i].first * 4); slot_of[i] = cur++; }
+    const uint64_t tb = std::max(ndb, (cur + 3) / 4) + 1;
+    ix->n_dbuckets = ndb; ix->dpad_buckets = tb - ndb;
+    ix->dtable.assign(tb * 8, 0);
+    for (uint64_t sl = 0; sl < tb * 4; sl++) ix->dtable[2 * sl] = kamd::KEY_EMPTY;
+    for (size_t i = 0; i < byhome.size(); i++) ix->dtable[2 * slot_of[i]] = byhome[i].second;
+    // a bucket continues into the next one when keys homed at or before it spill past its four slots
+    {
+      uint64_t reach = 0;  // one past the last slot used by keys homed in buckets <= b
+      size_t i = 0;
+      for (uint64_t b = 0; b < tb; b++) {
+        while (i < byhome.size() && byhome[i].first == b) { reach = slot_of[i] + 1; ++i; }
+        if (reach > (b + 1) * 4) ix->dtable[8 * b] |= kamd::KEY_CONT;
+      }
+    }
+    const kamd::Table mt{ix->table.data(), nb};
+    const kamd::Probe pd = kamd::probe_table(mt, ix->dlist_keys[0], true, nullptr);
+    if (!pd.found) return kamd::fail(-3, "index: Dummy k-mer not found in graph");   // KmerIndex.cpp:1398-1401
+    ix->dummy_slot = pd.slot; ix->dummy_uec = pd.uec; ix->dummy_strand = pd.strand ? 1 : 0;
+  }
   *out = ix.release();
   return 0;
 }
@@ -386,7 +436,7 @@ extern "C" int kamd_index_get_view(const kamd_index* ix, kamd_index_view* v) {
   memset(v, 0, sizeof *v);
   v->k = ix->k; v->n_kmers = ix->n_kmers; v->n_unitigs = ix->n_unitigs; v->n_blocks = ix->blk_lb.size();
   v->n_uec = ix->uec_ec.size(); v->n_ecs = ix->ec_off.size() - 1; v->ec_nnz = ix->ec_ids.size();
-  v->n_targets = ix->target_lens.size(); v->dlist_size = ix->dlist_size;
+  v->n_targets = ix->n_targets; v->dlist_size = ix->dlist_size;
   v->n_buckets = ix->n_buckets; v->pad_buckets = ix->pad_buckets;
   v->table = ix->table.data(); v->slot_block = ix->slot_block.data(); v->slot_dist = ix->slot_dist.data();
   v->uec_ec = ix->uec_ec.data(); v->ec_off = ix->ec_off.data(); v->ec_ids = ix->ec_ids.data();
@@ -394,6 +444,8 @@ extern "C" int kamd_index_get_view(const kamd_index* ix, kamd_index_view* v) {
   v->blk_unitig = ix->blk_unitig.data(); v->blk_lb = ix->blk_lb.data(); v->blk_ub = ix->blk_ub.data(); v->blk_ec = ix->blk_ec.data();
   v->blk_pos_off = ix->blk_pos_off.data(); v->blk_posw = ix->blk_posw.data(); v->blk_sense = ix->blk_sense.data();
   v->target_lens = ix->target_lens.data(); v->onlist_bits = ix->onlist_bits.data(); v->onlist_words = ix->onlist_bits.size();
+  v->dtable = ix->dtable.empty() ? nullptr : ix->dtable.data(); v->n_dbuckets = ix->n_dbuckets; v->dpad_buckets = ix->dpad_buckets;
+  v->dummy_slot = ix->dummy_slot; v->dummy_uec = ix->dummy_uec; v->dummy_strand = ix->dummy_strand;
   return 0;
 }
 

@@ -53,7 +53,16 @@ struct DevIndex {
   // positional tables (findPosition / strand filters)
   const u64* unitig_blk_off; const u32* unitig_len; const u32* blk_unitig; const u32* blk_lb; const u32* blk_ub; const u32* blk_ec;
   const u64* blk_pos_off; const u32* blk_posw; const uint8_t* blk_sense; const int32_t* target_lens;
+  // D-list (second k-mer table + the dummy hit); n_dbuckets == 0: none
+  const u64* dtable; u64 n_dbuckets; u64 dummy_slot; u32 dummy_uec; u32 dummy_strand;
 };
+// the k-mer table(s) as the per-item logic sees them; partial = match()'s `partial` argument = single-end reads
+__host__ __device__ inline kamd::Table make_table(const DevIndex& ix, bool partial) {
+  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  t.dslots = (const uint64_t*)ix.dtable; t.n_dbuckets = ix.n_dbuckets; t.dummy_uec = ix.dummy_uec; t.dummy_slot = ix.dummy_slot;
+  t.dummy_strand = ix.dummy_strand != 0; t.partial = partial;
+  return t;
+}
 
 // the filters of processBuffer that depend on the position of the first mapping k-mer (ProcessReads.cpp:1095-1145)
 struct FilterDev { int single_overhang, has_mean_fl, fl, strand; };
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* _
   kamd::MateInfo m0, m1;
   m0.n_hits = m1.n_hits = 0; m0.n_nonempty = m1.n_nonempty = 0; m0.probes = m1.probes = 0; m0.bucket_reads = m1.bucket_reads = 0;
   if (active) {
-    kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+    const kamd::Table t = make_table(ix, !PAIRED);
     const u64 item = item0 + tid;
     const u32* rec = lds_reads + tid * item_words;
     kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
   const u64 chunk0 = wave_global * (u64)items_per_wave;
   const u32 chunk_n = chunk0 < n_items ? (u32)min((u64)items_per_wave, n_items - chunk0) : 0u;
   if (lane == 0) cursor[wv] = 64u;  // the first 64 items of the chunk are pre-assigned, one per lane
-  const kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const kamd::Table t = make_table(ix, !PAIRED);
   const int k = ix.k;
 
   kamd::MatchState ms; ms.phase = kamd::PH_DONE;
@@ -334,9 +343,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       kamd::ReadView rv{base, base + (size_t)seq_words * 64, mate ? len1 : len0, 64};
       bool fc;
       const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
-      const kamd::Probe p = kamd::probe_table(t, canon, fc, &breads);
-      ++probes;
-      kamd::match_feed(ms, rv, k, p, ul, mate, mate ? mf1 : mf0);
+      const kamd::Probe p = kamd::probe_table(kamd::phase_table(t, ms.phase), canon, fc, &breads);
+      if (ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
+      kamd::match_feed(ms, rv, k, p, ul, mate, mate ? mf1 : mf0, t);
       if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
         mate = 1;
         const u32* b1 = my_words + (size_t)rec_words * 64;
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
   const int item_words = rec_words * (PAIRED ? 2 : 1);
   kamd::EcList ecs; ecs.e = scratch + i * TUPLE_CAP_BIG; ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
   kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0;
-  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const kamd::Table t = make_table(ix, !PAIRED);
   const u32* rec = words + item * item_words;
   kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
   kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(64) void k_explicit_write(DevIndex ix, const u32* _
   const int item_words = rec_words * (PAIRED ? 2 : 1);
   kamd::EcList ecs; ecs.e = scratch + i * (u64)cap; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
   kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0; m1.first_slot = 0; m1.first_pos = -1; m1.first_strand = false;
-  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const kamd::Table t = make_table(ix, !PAIRED);
   const u32* rec = words + item * item_words;
   kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
   kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
   const int item_words = rec_words * 2;
   kamd::EcList ecs; ecs.e = scratch + i * (u64)cap; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
   kamd::MateInfo m0, m1;
-  kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  const kamd::Table t = make_table(ix, false);
   const u32* rec = words + item * item_words;
   kamd::ReadView r0{rec, rec + seq_words, (int)lens[2 * item]};
   kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
@@ -1726,7 +1735,9 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   if (int rc = upload(c, (const u64*)v.blk_pos_off, v.n_blocks + 1, &d.blk_pos_off)) return rc;
   if (int rc = upload(c, v.blk_posw, (size_t)v.blk_pos_off[v.n_blocks], &d.blk_posw)) return rc;
   if (int rc = upload(c, v.blk_sense, (size_t)v.blk_pos_off[v.n_blocks], &d.blk_sense)) return rc;
-  if (int rc = upload(c, v.target_lens, v.n_targets, &d.target_lens)) return rc;
+  if (int rc = upload(c, v.target_lens, v.n_targets + v.dlist_size, &d.target_lens)) return rc;   // incl. the D-list pseudo-targets
+  d.dtable = nullptr; d.n_dbuckets = v.n_dbuckets; d.dummy_slot = v.dummy_slot; d.dummy_uec = v.dummy_uec; d.dummy_strand = v.dummy_strand;
+  if (v.n_dbuckets) if (int rc = upload(c, (const u64*)v.dtable, (size_t)(v.n_dbuckets + v.dpad_buckets) * 8, &d.dtable)) return rc;
   HIPC(hipStreamSynchronize(c->stream));  // `ne` is a stack-owned staging buffer
   c->ix = d; c->has_index = true; c->n_ecs = v.n_ecs; c->n_targets = v.n_targets;
   if (int rc = c->dense.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;

@@ -8,6 +8,14 @@
 #include <cstring>
 #include <vector>
 
+// the k-mer table(s) of the host view as the per-item logic sees them (mirrors make_table of kamd_kernels.hip)
+static kamd::Table emu_table(const kamd_index_view* v, bool partial) {
+  kamd::Table t{v->table, v->n_buckets};
+  t.dslots = v->dtable; t.n_dbuckets = v->n_dbuckets; t.dummy_uec = v->dummy_uec; t.dummy_slot = v->dummy_slot;
+  t.dummy_strand = v->dummy_strand != 0; t.partial = partial;
+  return t;
+}
+
 extern "C" {
 // For every item: the sorted intersection of the collected transcript sets (what the GPU resolves later per tuple) after
 // the on-list mask.  out_off[n_items+1], out_ids capacity cap; also per item n_hits of each mate and probe counts.
@@ -16,7 +24,7 @@ int64_t emu_pseudoalign(const kamd_index_view* v, const uint32_t* words, const u
                         uint64_t* probes, uint64_t* bucket_reads, uint32_t* tuple_sizes) {
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  Table t{v->table, v->n_buckets};
+  const Table t = emu_table(v, !paired);
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
   uint64_t o = 0;
@@ -56,7 +64,7 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
                               int32_t max_len, int use_stepper, uint32_t* out, uint64_t stride, uint64_t* probes) {
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  Table t{v->table, v->n_buckets};
+  const Table t = emu_table(v, !paired);
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
   uint32_t ecbuf[1024], uecbuf[1024];
@@ -81,9 +89,9 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
         MatchState st; match_init(st, rv, v->k);
         while (st.phase != PH_DONE) {
           bool fc; uint64_t canon = window_canon(rv, st.w, v->k, &fc);
-          Probe p = probe_table(t, canon, fc, nullptr);
-          ++*probes;
-          match_feed(st, rv, v->k, p, ul, mate, mf[mate]);
+          Probe p = probe_table(phase_table(t, st.phase), canon, fc, nullptr);
+          if (st.phase != PH_DLIST) ++*probes;   // dbg.find calls of match() only
+          match_feed(st, rv, v->k, p, ul, mate, mf[mate], t);
         }
       }
       bool ne0, ne1;
@@ -105,7 +113,7 @@ extern "C" int64_t emu_pseudoalign_opts(const kamd_index_view* v, const uint32_t
                                         uint64_t* out_off, uint32_t* out_ids, uint64_t cap) {
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  Table t{v->table, v->n_buckets};
+  const Table t = emu_table(v, !paired);
   PosTables pt{v->unitig_blk_off, v->unitig_len, v->blk_unitig, v->blk_lb, v->blk_ub, v->blk_ec, v->blk_pos_off, v->blk_posw,
                v->blk_sense, v->ec_off, v->ec_ids, v->target_lens, v->k};
   std::vector<uint8_t> nonempty(v->n_ecs);
@@ -159,7 +167,7 @@ int64_t emu_ec_state(const kamd_index_view* v, const uint32_t* words, const uint
                      int32_t max_len, uint32_t* dense, uint32_t* stream, uint64_t cap, uint64_t* rec_off, uint64_t* n_recs) {
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  Table t{v->table, v->n_buckets};
+  const Table t = emu_table(v, !paired);
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
   uint64_t o = 0, nr = 0;

@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from kallisto_amd import synth  # noqa: E402
 
+ONLY = set(sys.argv[1:])   # optional: only (re)generate the named cases
 REF = os.path.join(ROOT, "oracle", "_ref")
 KALLISTO = os.path.join(REF, "kallisto")
 DUMP = os.path.join(REF, "dump_ec")
@@ -46,11 +47,13 @@ def write_fastq(path, reads):
             f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
 
 
-def make_case(name, fasta_path, reads1, reads2, variants, k=31, note=""):
+def make_case(name, fasta_path, reads1, reads2, variants, k=31, note="", index_args=()):
+    if ONLY and name not in ONLY:
+        return
     d = os.path.join(HERE, name)
     os.makedirs(d, exist_ok=True)
     idx = os.path.join(d, "index.idx")
-    subprocess.check_call([KALLISTO, "index", "-k", str(k), "-i", idx, fasta_path], stdout=subprocess.DEVNULL,
+    subprocess.check_call([KALLISTO, "index", "-k", str(k), "-i", idx, *index_args, fasta_path], stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL)
     write_lines(os.path.join(d, "reads_1.txt.gz"), reads1)
     if reads2 is not None:
@@ -64,7 +67,8 @@ def make_case(name, fasta_path, reads1, reads2, variants, k=31, note=""):
             write_fastq(f2, reads2)
             files.append(f2)
         for vname, extra in variants.items():
-            out = subprocess.run([DUMP, "quant", idx, "1", *extra, *files], check=True, stdout=subprocess.PIPE,
+            vfiles = files[:1] if "--single" in extra else files   # single-end variants of a paired case use mate 1 only
+            out = subprocess.run([DUMP, "quant", idx, "1", *extra, *vfiles], check=True, stdout=subprocess.PIPE,
                                  stderr=subprocess.DEVNULL).stdout
             with open(os.path.join(d, f"expected_{vname}.txt"), "wb") as f:
                 f.write(out)
@@ -72,7 +76,7 @@ def make_case(name, fasta_path, reads1, reads2, variants, k=31, note=""):
             cli = [a.replace("--fr", "--fr-stranded").replace("--rf", "--rf-stranded") for a in extra]
             cli = ["-b" if a == "--boot" else a for a in cli]
             od = os.path.join(tmp, "q_" + vname)
-            subprocess.run([KALLISTO, "quant", "-i", idx, "-o", od, "-t", "1", "--plaintext", *cli, *files], check=True,
+            subprocess.run([KALLISTO, "quant", "-i", idx, "-o", od, "-t", "1", "--plaintext", *cli, *vfiles], check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             cd = os.path.join(d, "cli_" + vname)
             os.makedirs(cd, exist_ok=True)
@@ -143,6 +147,35 @@ def main():
     se = ["--single", "-l", "40", "-s", "5"]
     make_case("tiny_k7_se", fa, list(r1), None, {"se": se, "se_overhang": se + ["--single-overhang"]}, k=7,
               note="12 random transcripts of 60-200 bp, k=7, 3000 SE-24 reads (func_tests-like)")
+    # 5. an index with a D-list (`kallisto index --d-list`, what kb-python builds): "genomic" sequences that share a stretch
+    #    with a transcript and then diverge yield distinguishing flanking k-mers; reads drawn from them (pre-mRNA-like) cross
+    #    those k-mers and must be discarded (KmerIndex.cpp:1818-1826,1928-1939)
+    seqs = synth.human_like(n_genes=60, seed=2)
+    fa = os.path.join(tmp, "dt.fa")
+    synth.write_fasta(fa, seqs)
+    rng = np.random.default_rng(9)
+    genomic = []
+    for i in rng.choice(len(seqs), 80, replace=False):
+        s = seqs[i]
+        if len(s) < 400:
+            continue
+        a = int(rng.integers(0, len(s) - 300)); ln = int(rng.integers(150, 300))
+        genomic.append(np.concatenate([synth._ACGT[rng.integers(0, 4, 200)], s[a:a + ln], synth._ACGT[rng.integers(0, 4, 200)]]))
+    n_shared = len(genomic)
+    for _ in range(10):
+        genomic.append(synth._ACGT[rng.integers(0, 4, 1000)])
+    gfa = os.path.join(tmp, "dg.fa")
+    synth.write_fasta(gfa, genomic)
+    r1a, r2a = synth.simulate_reads(seqs, 3000, 100, paired=True, err=0.005, n_frac=0.01, seed=31)
+    r1b, r2b = synth.simulate_reads(genomic[:n_shared], 1500, 100, paired=True, frag_mean=180, frag_sd=20, err=0.002, n_frac=0.0, seed=32)
+    r1 = [bytes(x) for x in r1a] + [bytes(x) for x in r1b]
+    r2 = [bytes(x) for x in r2a] + [bytes(x) for x in r2b]
+    perm = np.random.default_rng(3).permutation(len(r1))
+    r1 = [r1[i] for i in perm]; r2 = [r2[i] for i in perm]
+    se = ["--single", "-l", "180", "-s", "20"]
+    make_case("dlist_pe", fa, r1, r2, {"pe": [], "pe_fr": ["--fr"], "se": se, "se_rf": se + ["--rf"]}, index_args=["--d-list=" + gfa],
+              note="synth.human_like(60 genes, seed=2) + a D-list of 80 transcript-fragment-in-random-flanks sequences and 10 random "
+                   "ones; 3000 PE-100 pairs from the transcripts + 1500 from the D-list sequences, shuffled")
     shutil.rmtree(tmp)
 
 
