@@ -345,9 +345,11 @@ struct MateFirst { int n_hits; uint64_t slot; int pos; bool strand; };
 // the table the pending probe of a phase goes to
 KAMD_HD Table phase_table(const Table& t, int phase) { return phase == PH_DLIST ? Table{t.dslots, t.n_dbuckets} : t; }
 // when match()'s loop is over: start the D-list scan if the index has one (:1928-1930)
+// (DL: the index has a D-list -- a compile-time switch so that kernels for ordinary indices carry none of this)
+template <bool DL>
 KAMD_HD void match_finish(MatchState& st, const ReadView& r, int k, const Table& t, const MateFirst& mf) {
   st.phase = PH_DONE;
-  if (t.n_dbuckets && (mf.n_hits > 0 || !t.partial)) {
+  if (DL && t.n_dbuckets && (mf.n_hits > 0 || !t.partial)) {
     st.w = next_valid_window(r, 0, k);
     if (st.w >= 0) st.phase = PH_DLIST;
   }
@@ -360,10 +362,11 @@ KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
 // consume the probe result of window st.w.  Written data-flow style: every phase only decides (a) whether the hit is
 // recorded, (b) where the next window search starts and (c) the phase that follows; the list insertion and the single
 // next_valid_window call are shared by all phases, so a wavefront whose lanes are in different phases executes them once.
+template <bool DL>
 KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf, const Table& t) {
   const int lk = r.len - k;
   const int ph = st.phase;
-  if (ph == PH_DLIST) {   // p = probe of the D-list table
+  if (DL && ph == PH_DLIST) {   // p = probe of the D-list table
     if (p.found) {
       if (mf.n_hits == 0) { mf.slot = t.dummy_slot; mf.pos = st.w; mf.strand = t.dummy_strand; }
       ++mf.n_hits;
@@ -425,13 +428,13 @@ KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p
   }
   if (hit) ++mf.n_hits;
   if (add) ueclist_add(list, p.uec, mate);
-  if (done) { match_finish(st, r, k, t, mf); return; }
+  if (done) { match_finish<DL>(st, r, k, t, mf); return; }
   int w;
   if (stay) w = st.w0;
   else w = (guard_len && start + k > r.len) ? -1 : next_valid_window(r, start, k);
   if (w < 0 && fallback_backoff) { w = next_valid_window(r, st.w0 + 1, k); ph_ok = PH_BACKOFF; }
-  if (ph_ok == PH_JUMP) { if (w < 0) { match_finish(st, r, k, t, mf); return; } st.w2 = w; }  // :1882-1886 (Q4)
-  if (w < 0) { match_finish(st, r, k, t, mf); return; }
+  if (ph_ok == PH_JUMP) { if (w < 0) { match_finish<DL>(st, r, k, t, mf); return; } st.w2 = w; }  // :1882-1886 (Q4)
+  if (w < 0) { match_finish<DL>(st, r, k, t, mf); return; }
   st.w = w;
   st.phase = ph_ok;
 }

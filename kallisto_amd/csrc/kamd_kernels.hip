@@ -285,7 +285,7 @@ __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* _
 constexpr int STAGE_WORDS = 36;  // packed words of one item fetched ahead in registers (PE-150 = 34)
 constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
 
-template <bool PAIRED, bool FILTER>
+template <bool PAIRED, bool FILTER, bool DL>
 __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                     u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
                                                     u32* raw, int raw_stride, DevState* st) {
@@ -343,9 +343,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       kamd::ReadView rv{base, base + (size_t)seq_words * 64, mate ? len1 : len0, 64};
       bool fc;
       const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
-      const kamd::Probe p = kamd::probe_table(kamd::phase_table(t, ms.phase), canon, fc, &breads);
-      if (ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
-      kamd::match_feed(ms, rv, k, p, ul, mate, mate ? mf1 : mf0, t);
+      const kamd::Probe p = kamd::probe_table(DL ? kamd::phase_table(t, ms.phase) : t, canon, fc, &breads);
+      if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
+      kamd::match_feed<DL>(ms, rv, k, p, ul, mate, mate ? mf1 : mf0, t);
       if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
         mate = 1;
         const u32* b1 = my_words + (size_t)rec_words * 64;
@@ -1802,9 +1802,15 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
   u32* slots = c->stream_buf.as<u32>() + cur_words;
   HIPC(hipEventRecord(c->ev0, c->stream));
-  HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
-                     n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
+  if (c->ix.n_dbuckets) {
+    HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER, true>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
+                       n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
+  } else {
+    HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER, false>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
+                       n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
+  }
   HIPC(hipEventRecord(c->ev1, c->stream));
   const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
   hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,

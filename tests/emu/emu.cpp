@@ -91,7 +91,7 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
           bool fc; uint64_t canon = window_canon(rv, st.w, v->k, &fc);
           Probe p = probe_table(phase_table(t, st.phase), canon, fc, nullptr);
           if (st.phase != PH_DLIST) ++*probes;   // dbg.find calls of match() only
-          match_feed(st, rv, v->k, p, ul, mate, mf[mate], t);
+          if (t.n_dbuckets) match_feed<true>(st, rv, v->k, p, ul, mate, mf[mate], t); else match_feed<false>(st, rv, v->k, p, ul, mate, mf[mate], t);
         }
       }
       bool ne0, ne1;
