@@ -1958,8 +1958,10 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   const u64 found0 = found;
   const int cap_small = 64;
   // the sample is the first 10000 qualifying pairs: start with a prefix that suffices when a few per cent of the pairs
-  // qualify (config #3: 7.5 %), then size the next prefix from the rate seen so far
-  u64 chunk = 262144;
+  // qualify (config #3: 3.6 % -- one transcript after the filters AND both mates on one block), then size the next prefix
+  // from the rate seen so far.  (Matching the prefix with kernel A's FILTER variant + a kernel over its raw records was
+  // tried: 0.5 + 1.0 ms per 262 k pairs plus 1.1 ms for the few items whose class list overflows -- not better than k_fld.)
+  u64 chunk = 393216;
   DBuf &tl = c->fld_tl, &card = c->fld_card, &scratch = c->fld_scratch, &items = c->fld_items;
   std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
   int rc = 0;
