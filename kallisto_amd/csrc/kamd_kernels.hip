@@ -604,7 +604,8 @@ __global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restri
 }
 // `list` receives the table slot of every distinct record exactly once (appended by the record that owns the slot;
 // one global atomic per block)
-__global__ __launch_bounds__(BLOCK) void k_rec_verify(const u32* __restrict__ stream, const u64* __restrict__ rec_off,
+constexpr int VERIFY_BLOCK = BLOCK;
+__global__ __launch_bounds__(VERIFY_BLOCK) void k_rec_verify(const u32* __restrict__ stream, const u64* __restrict__ rec_off,
                                                       const u64* __restrict__ idx, u64 r0, u64 n, TSlot* table,
                                                       const u64* __restrict__ rec_slot, u64* retry, u64* list,
                                                       const u64* __restrict__ keys, int track, DevState* st) {
@@ -684,8 +685,9 @@ __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, const
 //     smallest set per step, membership by binary search in the others, survivors compacted with ballot + popcount
 //     prefix over the group's 16 bits of the wavefront mask
 constexpr int RES_LANES = 16;
-constexpr int RES_GROUPS = BLOCK / RES_LANES;
-__global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
+constexpr int RES_BLOCK = BLOCK;   // (1024-thread blocks were slower: 5.9 against 3.9 ms, the block-wide allocation barrier waits for the slowest tuple)
+constexpr int RES_GROUPS = RES_BLOCK / RES_LANES;
+__global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
                                                    const u64* list, u64 n, u32* cand, u64* cand_off, u64* cand_key, DevState* st) {
   __shared__ u32 grp_total[RES_GROUPS];
   __shared__ u64 grp_off[RES_GROUPS];
@@ -699,14 +701,68 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __res
   TSlot sl; sl.owner = 0; sl.count = 0; sl.tag = 0; sl.first = ~0ULL;
   u32 m = 0, best = 0, nb = 0;
   const u32* es = nullptr; const u32* base = nullptr;
+  // Lane j of the group looks at set j: offset and size of all sets in ONE round of loads (a thread-serial scan of the m
+  // sets was 2 m dependent latencies), the smallest by a 16-lane min-reduction (first wins on ties, like the serial scan).
+  u64 my_off = 0; u32 my_sz = 0xFFFFFFFFu;
+  bool small = false;   // m <= TUPLE_CAP and every set has <= RES_LANES members: the all-pairs path below
   if (valid) {
     sl = table[list[gid]];
     m = stream[sl.owner + 1];
     es = stream + sl.owner + 2;
-    u64 best_sz = ~0ULL;
-    for (u32 j = 0; j < m; j++) { u32 e = es[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
-    base = ix.ec_ids + ix.ec_off[es[best]];
-    nb = (u32)best_sz;
+    if (m <= (u32)RES_LANES) {
+      if ((u32)sub < m) { const u32 e = es[sub]; my_off = ix.ec_off[e]; my_sz = (u32)(ix.ec_off[e + 1] - my_off); }
+    } else {
+      u64 best_sz = ~0ULL;
+      for (u32 j = 0; j < m; j++) { u32 e = es[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
+      base = ix.ec_ids + ix.ec_off[es[best]];
+      nb = (u32)best_sz;
+    }
+  }
+  {
+    u32 key = my_sz, arg = (u32)sub;   // (size, lane) minimum over the group
+#pragma unroll
+    for (int d = 1; d < RES_LANES; d <<= 1) {
+      const u32 k2 = __shfl_xor(key, d, RES_LANES), a2 = __shfl_xor(arg, d, RES_LANES);
+      if (k2 < key || (k2 == key && a2 < arg)) { key = k2; arg = a2; }
+    }
+    const u32 mx_in = ((u32)sub < m && m <= (u32)RES_LANES) ? my_sz : 0u;
+    u32 mx = mx_in;
+#pragma unroll
+    for (int d = 1; d < RES_LANES; d <<= 1) mx = max(mx, __shfl_xor(mx, d, RES_LANES));
+    if (valid && m <= (u32)RES_LANES) {
+      best = arg; nb = key;
+      const u64 boff = __shfl(my_off, (int)best, RES_LANES);
+      base = ix.ec_ids + boff;
+      small = mx <= (u32)RES_LANES && m <= (u32)TUPLE_CAP;   // (tuples of the overflow kernel can have more sets: serial path)
+    }
+  }
+  u32 total = 0, first_mask = 0, x0 = 0;
+  if (small) {
+    // all pairs in registers: lane c holds candidate c of the smallest set, lane i member i of every other set (<= 12 loads
+    // in flight per lane, ONE round); candidate c survives if every other set has a lane that holds it
+    const u32 x = (u32)sub < nb ? base[sub] : 0u;
+    u32 y[TUPLE_CAP];
+#pragma unroll
+    for (int j = 0; j < TUPLE_CAP; j++) {
+      const u64 oj = __shfl(my_off, j, RES_LANES); const u32 sj = __shfl(my_sz, j, RES_LANES);
+      y[j] = ((u32)j < m && (u32)j != best && (u32)sub < sj) ? ix.ec_ids[oj + sub] : 0xFFFFFFFFu;
+    }
+    bool okx = (u32)sub < nb && onlisted(ix.onlist_bits, x);
+    u32 keep = 0;
+    for (u32 c = 0; c < nb; c++) {
+      const u32 xc = __shfl(x, (int)c, RES_LANES);
+      bool okc = __shfl((int)okx, (int)c, RES_LANES) != 0;
+#pragma unroll
+      for (int j = 0; j < TUPLE_CAP; j++) {
+        if ((u32)j < m && (u32)j != best) {
+          const u32 hit = (u32)((__ballot(y[j] == xc) >> gsh) & 0xFFFFu);
+          okc = okc && hit != 0;
+        }
+      }
+      keep |= (okc ? 1u : 0u) << c;
+    }
+    first_mask = keep; x0 = x;
+    total = (u32)__popc(keep);
   }
   // classify the candidates of the smallest set: membership in every other set (binary search) and the on-list mask;
   // `mask_of(c0)` is recomputed in the write pass except for the first 16 candidates
@@ -723,8 +779,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DevIndex ix, const u32* __res
     *x_out = x;
     return (u32)((__ballot(ok) >> gsh) & 0xFFFFu);
   };
-  u32 total = 0, first_mask = 0, x0 = 0;
-  if (valid) {
+  if (valid && !small) {
     for (u32 c0 = 0; c0 < nb; c0 += RES_LANES) {
       u32 x; const u32 gm = chunk_mask(c0, &x);
       if (c0 == 0) { first_mask = gm; x0 = x; }
@@ -1617,7 +1672,7 @@ int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u6
     HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_retry, &c->host_state.n_retry, sizeof(u64), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_rec_insert, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
                        table, cap - 1, seed, slot_buf.as<u64>());
-    hipLaunchKernelGGL(k_rec_verify, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
+    hipLaunchKernelGGL(k_rec_verify, dim3(grid_for(count, VERIFY_BLOCK)), dim3(VERIFY_BLOCK), 0, c->stream, stream, rec_off, idx, r0, count,
                        table, slot_buf.as<u64>(), retry_b, list, keys, track, (DevState*)c->state.p);
     HIPC(hipGetLastError());
     if (int rc = sync_state(c)) return rc;
@@ -1961,7 +2016,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   // qualify (config #3: 3.6 % -- one transcript after the filters AND both mates on one block), then size the next prefix
   // from the rate seen so far.  (Matching the prefix with kernel A's FILTER variant + a kernel over its raw records was
   // tried: 0.5 + 1.0 ms per 262 k pairs plus 1.1 ms for the few items whose class list overflows -- not better than k_fld.)
-  u64 chunk = 393216;
+  u64 chunk = 524288;
   DBuf &tl = c->fld_tl, &card = c->fld_card, &scratch = c->fld_scratch, &items = c->fld_items;
   std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
   int rc = 0;
@@ -2117,7 +2172,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   u64* cand_key = c->track_order ? c->cand_key.as<u64>() : nullptr;
   hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
                      c->dense_first.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
-  if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+  if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
                               c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
