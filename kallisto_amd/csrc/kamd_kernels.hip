@@ -894,14 +894,18 @@ __global__ void k_tuple_export_offsets(const u32* __restrict__ stream, const TSl
 // FLD probe kernel: per item the fragment length KmerIndex::mapPair would return and |u| (first items only)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr u32 FLD_OVERFLOW = 0xFFFFFFFFu;
+// (scratch == nullptr: the per-item list of distinct transcript sets lives in LDS, TUPLE_CAP entries; an item that needs more
+// is reported as FLD_OVERFLOW and re-run with a TUPLE_CAP_BIG list in global memory)
 __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                const u64* __restrict__ items, u64 n_items, int seq_words, int rec_words,
                                                u32* scratch, int cap, FilterDev fd, int32_t* tl_out, u32* card_out) {
+  __shared__ u32 lds_list[BLOCK * TUPLE_CAP];
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const u64 item = items ? items[i] : i;
   const int item_words = rec_words * 2;
-  kamd::EcList ecs; ecs.e = scratch + i * (u64)cap; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
+  kamd::EcList ecs; ecs.n = 0; ecs.overflow = false;
+  if (scratch) { ecs.e = scratch + i * (u64)cap; ecs.cap = cap; } else { ecs.e = lds_list + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; }
   kamd::MateInfo m0, m1;
   const kamd::Table t = make_table(ix, false);
   const u32* rec = words + item * item_words;
@@ -1612,6 +1616,7 @@ struct kamd_ctx {
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
   DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
   DBuf fld_tl, fld_card, fld_scratch, fld_items;
+  void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
@@ -1748,6 +1753,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
   if (c->em_stream) (void)hipStreamDestroy(c->em_stream);
+  if (c->fld_host) (void)hipHostFree(c->fld_host);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
@@ -2011,30 +2017,37 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   const int rec_words = (int)kamd_packed_record_words(max_len);
   u64 found = n_used ? *n_used : 0, done = 0;  // continues a sample started on earlier batches
   const u64 found0 = found;
-  const int cap_small = 64;
   // the sample is the first 10000 qualifying pairs: start with a prefix that suffices when a few per cent of the pairs
   // qualify (config #3: 3.6 % -- one transcript after the filters AND both mates on one block), then size the next prefix
   // from the rate seen so far.  (Matching the prefix with kernel A's FILTER variant + a kernel over its raw records was
   // tried: 0.5 + 1.0 ms per 262 k pairs plus 1.1 ms for the few items whose class list overflows -- not better than k_fld.)
   u64 chunk = 524288;
+  const int cap_small = 64;   // list entries per item in global scratch (an LDS list of TUPLE_CAP entries sends too many items to the
+                              // re-run below, which costs ~1 ms per launch however few they are)
   DBuf &tl = c->fld_tl, &card = c->fld_card, &scratch = c->fld_scratch, &items = c->fld_items;
-  std::vector<int32_t> h_tl; std::vector<u32> h_card; std::vector<u64> h_items;
+  std::vector<u64> h_items;
   int rc = 0;
   while (done < n_items && found < 10000 && rc == 0) {
     const u64 n = std::min(chunk, n_items - done);
-    h_tl.resize(n); h_card.resize(n);
     if ((rc = tl.ensure(n * 4, 0, c->stream))) break;
     if ((rc = card.ensure(n * 4, 0, c->stream))) break;
     if ((rc = scratch.ensure(n * cap_small * 4, 0, c->stream))) break;
+    if (n > c->fld_host_cap) {   // pinned staging for the two result vectors
+      if (c->fld_host) (void)hipHostFree(c->fld_host);
+      c->fld_host = nullptr; c->fld_host_cap = 0;
+      if (hipHostMalloc(&c->fld_host, n * 8, hipHostMallocDefault) != hipSuccess) { rc = kamd::fail(-100, "kamd_fld_from_batch: pinned allocation failed"); break; }
+      c->fld_host_cap = n;
+    }
+    int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
     const u32* w = d_words + done * (u64)rec_words * 2;
     const uint16_t* l = d_len + 2 * done;
     hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, (const u64*)nullptr, n, seq_words,
                        rec_words, scratch.as<u32>(), cap_small, fd, tl.as<int32_t>(), card.as<u32>());
     if (hipGetLastError() != hipSuccess) { rc = kamd::fail(-100, "k_fld launch failed"); break; }
-    if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    if (hipMemcpyAsync(h_tl, tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(h_card, card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
-    // items with more than cap_small distinct sets: same kernel again with the large list
+    // items with more than cap_small distinct transcript sets: same kernel again with the large list
     h_items.clear();
     for (u64 i = 0; i < n; i++) if (h_card[i] == FLD_OVERFLOW) h_items.push_back(i);
     if (!h_items.empty()) {
@@ -2044,8 +2057,8 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
       if (hipMemcpyAsync(items.p, h_items.data(), no * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
       hipLaunchKernelGGL(k_fld, dim3(grid_for(no, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, items.as<u64>(), no, seq_words,
                          rec_words, scratch.as<u32>(), TUPLE_CAP_BIG, fd, tl.as<int32_t>(), card.as<u32>());
-      if (hipMemcpyAsync(h_tl.data(), tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-          hipMemcpyAsync(h_card.data(), card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      if (hipMemcpyAsync(h_tl, tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipMemcpyAsync(h_card, card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
           hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
     }
     // first 10000 qualifying pairs in input order (ProcessReads.cpp:981-1017,1174-1181 at -t 1)
