@@ -111,8 +111,7 @@ int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off,
 
 /* ---- S2: pseudoalignment of one batch resident in HBM ----
  * n_items = pairs (paired) or reads (single).  Accumulates into the context's EC state; call kamd_ec_finalize after
- * the last batch.  If d_tl is non-NULL it receives, per item, the fragment length KmerIndex::mapPair would return
- * (0 = none) and d_card the cardinality class of the item's equivalence class is resolved later by kamd_fld_from_prefix. */
+ * the last batch. */
 int kamd_pseudoalign(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
                      int32_t max_len);
 /* fragment-length histogram from the first 10000 qualifying pairs in input order (src/ProcessReads.cpp:981-1017,
@@ -120,6 +119,11 @@ int kamd_pseudoalign(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words,
  * per batch in input order until *n_used reaches 10000 (or the input ends). */
 int kamd_fld_from_batch(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
                         int32_t max_len, uint32_t* flens, uint64_t* n_used);
+/* optional: start the fragment-length kernel for the first prefix of this batch on a side stream and return at once.  Called
+ * BEFORE kamd_pseudoalign on the same batch, the (latency-bound) kernel runs underneath kernel A; the following
+ * kamd_fld_from_batch on the same pointers then only waits for it.  Purely a scheduling hint: results are identical. */
+int kamd_fld_prefetch(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
+                      int32_t max_len);
 
 /* statistics of the batches processed so far */
 typedef struct {

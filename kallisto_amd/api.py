@@ -80,6 +80,7 @@ _SYMBOLS = {
     "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "kamd_pseudoalign": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
+    "kamd_fld_prefetch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                       C.POINTER(C.c_uint64)]),
     "kamd_align_stats_get": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
@@ -284,6 +285,12 @@ class Context:
     def pseudoalign(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
         _check(load_library().kamd_pseudoalign(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len),
                "kamd_pseudoalign")
+
+    def fld_prefetch(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
+        """Start the FLD kernel for the first prefix of a batch on a side stream (kamd_fld_prefetch); fld_from_batch on the same
+        batch then only waits for it."""
+        _check(load_library().kamd_fld_prefetch(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len),
+               "kamd_fld_prefetch")
 
     def fld_from_batch(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
         flens = np.zeros(MAX_FRAG_LEN, np.uint32)
@@ -526,7 +533,9 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
     index = ctx.index
     batches = list(batches)
     n_proc = 0
-    for words, lens, n_items, max_len in batches:
+    for bi, (words, lens, n_items, max_len) in enumerate(batches):
+        if bi == 0 and opts.fld == 0.0 and opts.paired:
+            ctx.fld_prefetch(opts, words, lens, n_items, max_len)   # the FLD kernel of the first prefix runs underneath kernel A
         ctx.pseudoalign(opts, words, lens, n_items, max_len)
         n_proc += n_items
     # FLD: estimated from the first 10000 qualifying pairs of the input (rank 0's first batch) or given by -l/-s

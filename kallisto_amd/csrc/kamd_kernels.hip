@@ -1617,6 +1617,9 @@ struct kamd_ctx {
   DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
   DBuf fld_tl, fld_card, fld_scratch, fld_items;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
+  // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
+  hipStream_t fld_stream = nullptr; hipEvent_t fld_ev = nullptr, fld_ev_in = nullptr;
+  struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0; bool valid = false; } fld_pending;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   u64 tcap = 0, ccap = 0;
@@ -1753,6 +1756,9 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
   if (c->em_stream) (void)hipStreamDestroy(c->em_stream);
+  if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
+  if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
+  if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
   if (c->fld_host) (void)hipHostFree(c->fld_host);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
@@ -2006,6 +2012,57 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   return 0;
 }
 
+namespace {
+constexpr u64 FLD_FIRST_CHUNK = 524288;
+constexpr int FLD_CAP_SMALL = 64;   // list entries per item in global scratch (an LDS list of TUPLE_CAP entries sends too many items to
+                                    // the re-run, which costs ~1 ms per launch however few they are)
+// buffers for a prefix of n items + k_fld + the two result copies, all on stream s (no synchronisation)
+int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l, u64 n, int seq_words, int rec_words, hipStream_t s) {
+  if (int rc = c->fld_tl.ensure(n * 4, 0, c->stream)) return rc;
+  if (int rc = c->fld_card.ensure(n * 4, 0, c->stream)) return rc;
+  if (int rc = c->fld_scratch.ensure(n * FLD_CAP_SMALL * 4, 0, c->stream)) return rc;
+  if (n > c->fld_host_cap) {   // pinned staging for the two result vectors
+    if (c->fld_host) (void)hipHostFree(c->fld_host);
+    c->fld_host = nullptr; c->fld_host_cap = 0;
+    if (hipHostMalloc(&c->fld_host, n * 8, hipHostMallocDefault) != hipSuccess) return kamd::fail(-100, "kamd_fld_from_batch: pinned allocation failed");
+    c->fld_host_cap = n;
+  }
+  int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
+  hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, c->ix, w, l, (const u64*)nullptr, n, seq_words, rec_words,
+                     c->fld_scratch.as<u32>(), FLD_CAP_SMALL, fd, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>());
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(h_tl, c->fld_tl.p, n * 4, hipMemcpyDeviceToHost, s));
+  HIPC(hipMemcpyAsync(h_card, c->fld_card.p, n * 4, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+}  // namespace
+
+// The first prefix of kamd_fld_from_batch, launched on a side stream: call it BEFORE kamd_pseudoalign on the same batch and
+// the fragment-length kernel (latency-bound, few wavefronts) runs underneath kernel A instead of after it.
+extern "C" int kamd_fld_prefetch(kamd_ctx* c, const kamd_quant_opts* o, const uint32_t* d_words, const uint16_t* d_len,
+                                 uint64_t n_items, int32_t max_len) {
+  if (!c || !o) return kamd::fail(-1, "kamd_fld_prefetch: null argument");
+  if (!o->paired || o->fld != 0.0) return kamd::fail(-1, "kamd_fld_prefetch: the FLD is only estimated for paired reads without -l");
+  if (!c->has_index) return kamd::fail(-1, "kamd_fld_prefetch: no index uploaded");
+  HIPC(hipSetDevice(c->device));
+  if (n_items == 0) return 0;
+  if (!c->fld_stream) {
+    HIPC(hipStreamCreateWithFlags(&c->fld_stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&c->fld_ev, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&c->fld_ev_in, hipEventDisableTiming));
+  }
+  if (c->fld_pending.valid) { HIPC(hipStreamSynchronize(c->fld_stream)); c->fld_pending.valid = false; }
+  const FilterDev fd{o->single_overhang, 0, 0, o->strand};
+  const u64 n = std::min<u64>(FLD_FIRST_CHUNK, n_items);
+  HIPC(hipEventRecord(c->fld_ev_in, c->stream));            // the reads were produced on the context stream
+  HIPC(hipStreamWaitEvent(c->fld_stream, c->fld_ev_in, 0));
+  if (int rc = fld_launch(c, fd, d_words, d_len, n, (max_len + 15) / 16 + 1, (int)kamd_packed_record_words(max_len), c->fld_stream)) return rc;
+  HIPC(hipEventRecord(c->fld_ev, c->fld_stream));
+  c->fld_pending.w = d_words; c->fld_pending.l = d_len; c->fld_pending.n = n; c->fld_pending.max_len = max_len;
+  c->fld_pending.strand = o->strand; c->fld_pending.so = o->single_overhang; c->fld_pending.valid = true;
+  return 0;
+}
+
 extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const uint32_t* d_words, const uint16_t* d_len,
                                    uint64_t n_items, int32_t max_len, uint32_t* flens, uint64_t* n_used) {
   if (!c || !flens || !o) return kamd::fail(-1, "kamd_fld_from_batch: null argument");
@@ -2021,33 +2078,26 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   // qualify (config #3: 3.6 % -- one transcript after the filters AND both mates on one block), then size the next prefix
   // from the rate seen so far.  (Matching the prefix with kernel A's FILTER variant + a kernel over its raw records was
   // tried: 0.5 + 1.0 ms per 262 k pairs plus 1.1 ms for the few items whose class list overflows -- not better than k_fld.)
-  u64 chunk = 524288;
-  const int cap_small = 64;   // list entries per item in global scratch (an LDS list of TUPLE_CAP entries sends too many items to the
-                              // re-run below, which costs ~1 ms per launch however few they are)
+  u64 chunk = FLD_FIRST_CHUNK;
   DBuf &tl = c->fld_tl, &card = c->fld_card, &scratch = c->fld_scratch, &items = c->fld_items;
   std::vector<u64> h_items;
   int rc = 0;
   while (done < n_items && found < 10000 && rc == 0) {
     const u64 n = std::min(chunk, n_items - done);
-    if ((rc = tl.ensure(n * 4, 0, c->stream))) break;
-    if ((rc = card.ensure(n * 4, 0, c->stream))) break;
-    if ((rc = scratch.ensure(n * cap_small * 4, 0, c->stream))) break;
-    if (n > c->fld_host_cap) {   // pinned staging for the two result vectors
-      if (c->fld_host) (void)hipHostFree(c->fld_host);
-      c->fld_host = nullptr; c->fld_host_cap = 0;
-      if (hipHostMalloc(&c->fld_host, n * 8, hipHostMallocDefault) != hipSuccess) { rc = kamd::fail(-100, "kamd_fld_from_batch: pinned allocation failed"); break; }
-      c->fld_host_cap = n;
-    }
-    int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
     const u32* w = d_words + done * (u64)rec_words * 2;
     const uint16_t* l = d_len + 2 * done;
-    hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, (const u64*)nullptr, n, seq_words,
-                       rec_words, scratch.as<u32>(), cap_small, fd, tl.as<int32_t>(), card.as<u32>());
-    if (hipGetLastError() != hipSuccess) { rc = kamd::fail(-100, "k_fld launch failed"); break; }
-    if (hipMemcpyAsync(h_tl, tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipMemcpyAsync(h_card, card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
-    // items with more than cap_small distinct transcript sets: same kernel again with the large list
+    const bool prefetched = done == 0 && c->fld_pending.valid && c->fld_pending.w == w && c->fld_pending.l == l && c->fld_pending.n == n &&
+                            c->fld_pending.max_len == max_len && c->fld_pending.strand == o->strand && c->fld_pending.so == o->single_overhang;
+    if (c->fld_pending.valid) {   // either consumed now or stale
+      if (hipEventSynchronize(c->fld_ev) != hipSuccess) { rc = kamd::fail(-100, "k_fld (prefetched) failed"); break; }
+      c->fld_pending.valid = false;
+    }
+    if (!prefetched) {
+      if ((rc = fld_launch(c, fd, w, l, n, seq_words, rec_words, c->stream))) break;
+      if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+    }
+    int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
+    // items with more than FLD_CAP_SMALL distinct transcript sets: same kernel again with the large list
     h_items.clear();
     for (u64 i = 0; i < n; i++) if (h_card[i] == FLD_OVERFLOW) h_items.push_back(i);
     if (!h_items.empty()) {

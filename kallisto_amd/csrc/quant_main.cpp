@@ -408,6 +408,8 @@ int main(int argc, char** argv) {
   uint64_t fld_used = 0, n_processed = 0;
   double pack_s = 0.0;
   DevicePipe pipe([&](PackedBatch& b) {
+    const bool want_fld = paired && opt.fld == 0.0 && fld_used < 10000;
+    if (want_fld) KX(kamd_fld_prefetch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len));   // runs underneath kernel A
     KX(kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len));
     if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used));
   });
