@@ -366,7 +366,8 @@ int main(int argc, char** argv) {
     else if (a == "--plaintext") opt.plaintext = true;
     else if (a == "--verbose") opt.verbose = true;
     else if (a == "--bias" || a == "--fusion" || a == "--pseudobam" || a == "--genomebam" || a == "--long" || a == "-p" || a == "--priors" ||
-             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes") {
+             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--union" || a == "--no-jump" || a == "--dfk-onlist" ||
+             a == "-P" || a == "--platform" || a == "-N" || a == "--numReads") {
       std::cerr << "Error: option " << a << " is outside the GPU quant path; use the reference kallisto for it" << std::endl; return 1;
     } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage(); return 1; }
     else opt.files.push_back(a);
