@@ -4,10 +4,12 @@
 // Host code only: FASTQ reading (FastqSequenceReader::fetchSequences, src/ProcessReads.cpp:3128-3267), batching,
 // writers.  Everything that computes runs on the GPU through libkallisto_amd.so.
 #include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -53,7 +55,7 @@ void usage() {
             << "Optional arguments:\n"
             << "-b, --bootstrap-samples=INT   Number of bootstrap samples (default: 0)\n"
             << "    --seed=INT                Seed for the bootstrap sampling (default: 42)\n"
-            << "    --plaintext               Output plaintext (always on: abundance.h5 is not written)\n"
+            << "    --plaintext               Output plaintext only (abundance.h5 is written otherwise, when libhdf5 can be loaded)\n"
             << "    --single                  Quantify single-end reads\n"
             << "    --single-overhang         Include reads where unobserved rest of fragment is\n"
             << "                              predicted to lie outside a transcript\n"
@@ -323,6 +325,94 @@ class DevicePipe {
   std::thread th_;   // last member: started when everything above exists
 };
 
+// ---- abundance.h5 (H5Writer.cpp:4-69, h5utils.h:42-92): one chunk per dataset, deflate level 6, strings as fixed-size
+// NUL-terminated C strings of the longest entry + 1.  libhdf5 is loaded at run time (dlopen), so the front-end neither
+// needs it to build nor drags its dependencies into a process that already holds the HIP runtime.  Written without
+// `--plaintext`, like a reference build with USE_HDF5; without the library the front-end behaves like `--plaintext`.
+class H5Out {
+ public:
+  typedef int64_t hid_t; typedef unsigned long long hsize_t; typedef int herr_t;
+  bool load() {
+    const char* cands[] = {getenv("KAMD_HDF5_LIB"), "libhdf5.so", "libhdf5.so.103", "libhdf5_serial.so", "/opt/conda/lib/libhdf5.so"};
+    for (const char* c : cands) { if (!c) continue; lib_ = dlopen(c, RTLD_NOW | RTLD_LOCAL); if (lib_) break; }
+    if (!lib_) return false;
+#define KAMD_H5SYM(name) do { *(void**)(&name) = dlsym(lib_, #name); if (!name) return false; } while (0)
+    KAMD_H5SYM(H5open); KAMD_H5SYM(H5Fcreate); KAMD_H5SYM(H5Fclose); KAMD_H5SYM(H5Gcreate2); KAMD_H5SYM(H5Gopen2); KAMD_H5SYM(H5Gclose);
+    KAMD_H5SYM(H5Pcreate); KAMD_H5SYM(H5Pset_chunk); KAMD_H5SYM(H5Pset_deflate); KAMD_H5SYM(H5Pclose);
+    KAMD_H5SYM(H5Screate_simple); KAMD_H5SYM(H5Sclose); KAMD_H5SYM(H5Dcreate2); KAMD_H5SYM(H5Dwrite); KAMD_H5SYM(H5Dclose);
+    KAMD_H5SYM(H5Tcopy); KAMD_H5SYM(H5Tset_size); KAMD_H5SYM(H5Tclose);
+#undef KAMD_H5SYM
+    if (H5open() < 0) return false;
+    hid_t* g = nullptr;
+    if (!(g = (hid_t*)dlsym(lib_, "H5T_NATIVE_INT_g"))) return false; t_int_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5T_NATIVE_DOUBLE_g"))) return false; t_double_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5T_C_S1_g"))) return false; t_c_s1_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5P_CLS_DATASET_CREATE_ID_g"))) return false; p_dcreate_ = *g;
+    return true;
+  }
+  bool open(const std::string& path, bool with_bootstrap) {
+    file_ = H5Fcreate(path.c_str(), 0x0002u /* H5F_ACC_TRUNC */, 0, 0);
+    if (file_ < 0) return false;
+    root_ = H5Gopen2(file_, "/", 0);
+    aux_ = H5Gcreate2(file_, "/aux", 0, 0, 0);
+    if (with_bootstrap) bs_ = H5Gcreate2(file_, "/bootstrap", 0, 0, 0);
+    return root_ >= 0 && aux_ >= 0;
+  }
+  void close() {
+    if (file_ < 0) return;
+    if (bs_ >= 0) H5Gclose(bs_);
+    H5Gclose(aux_); H5Gclose(root_); H5Fclose(file_);
+    file_ = -1;
+  }
+  hid_t root() const { return root_; }
+  hid_t aux() const { return aux_; }
+  hid_t bs() const { return bs_; }
+  void ints(hid_t g, const char* name, const std::vector<int32_t>& v) { write(g, name, t_int_, v.size(), v.data()); }
+  void doubles(hid_t g, const char* name, const std::vector<double>& v) { write(g, name, t_double_, v.size(), v.data()); }
+  void strings(hid_t g, const char* name, const std::vector<std::string>& v) {   // vec_to_ptr / get_datatype_id, h5utils.cpp:4-52
+    size_t w = 0;
+    for (auto& x : v) w = std::max(w, x.size());
+    w += 1;
+    std::vector<char> pool(w * v.size(), 0);
+    for (size_t i = 0; i < v.size(); i++) memcpy(pool.data() + i * w, v[i].data(), v[i].size());
+    const hid_t t = H5Tcopy(t_c_s1_);
+    H5Tset_size(t, w);
+    write(g, name, t, v.size(), pool.data());
+    H5Tclose(t);
+  }
+ private:
+  void write(hid_t g, const char* name, hid_t type, size_t n, const void* data) {   // vector_to_h5, h5utils.h:42-92
+    hsize_t dims[1] = {(hsize_t)n};
+    const hid_t prop = H5Pcreate(p_dcreate_);
+    H5Pset_chunk(prop, 1, dims);          // chunk = the whole vector
+    H5Pset_deflate(prop, 6);
+    const hid_t space = H5Screate_simple(1, dims, nullptr);
+    const hid_t ds = H5Dcreate2(g, name, type, space, 0, prop, 0);
+    if (ds < 0 || H5Dwrite(ds, type, 0, 0, 0, data) < 0) { std::cerr << "Error: could not write dataset " << name << " of abundance.h5" << std::endl; exit(1); }
+    H5Pclose(prop); H5Dclose(ds); H5Sclose(space);
+  }
+  void* lib_ = nullptr;
+  hid_t file_ = -1, root_ = -1, aux_ = -1, bs_ = -1, t_int_ = -1, t_double_ = -1, t_c_s1_ = -1, p_dcreate_ = -1;
+  herr_t (*H5open)() = nullptr;
+  hid_t (*H5Fcreate)(const char*, unsigned, hid_t, hid_t) = nullptr;
+  herr_t (*H5Fclose)(hid_t) = nullptr;
+  hid_t (*H5Gcreate2)(hid_t, const char*, hid_t, hid_t, hid_t) = nullptr;
+  hid_t (*H5Gopen2)(hid_t, const char*, hid_t) = nullptr;
+  herr_t (*H5Gclose)(hid_t) = nullptr;
+  hid_t (*H5Pcreate)(hid_t) = nullptr;
+  herr_t (*H5Pset_chunk)(hid_t, int, const hsize_t*) = nullptr;
+  herr_t (*H5Pset_deflate)(hid_t, unsigned) = nullptr;
+  herr_t (*H5Pclose)(hid_t) = nullptr;
+  hid_t (*H5Screate_simple)(int, const hsize_t*, const hsize_t*) = nullptr;
+  herr_t (*H5Sclose)(hid_t) = nullptr;
+  hid_t (*H5Dcreate2)(hid_t, const char*, hid_t, hid_t, hid_t, hid_t, hid_t) = nullptr;
+  herr_t (*H5Dwrite)(hid_t, hid_t, hid_t, hid_t, hid_t, const void*) = nullptr;
+  herr_t (*H5Dclose)(hid_t) = nullptr;
+  hid_t (*H5Tcopy)(hid_t) = nullptr;
+  herr_t (*H5Tset_size)(hid_t, size_t) = nullptr;
+  herr_t (*H5Tclose)(hid_t) = nullptr;
+};
+
 std::string to_json(const std::string& id, const std::string& val, bool quote, bool comma = true) {  // PlaintextWriter.cpp:113-137
   std::string out = "\t\"" + id + "\": ";
   if (quote) out += '"';
@@ -543,8 +633,42 @@ int main(int argc, char** argv) {
        << to_json("call", call, true, false) << std::endl
        << "}" << std::endl;
   }
+  // abundance.h5 (src/main.cpp:2693-2702): written unless --plaintext, when libhdf5 is there
+  H5Out h5;
+  bool use_h5 = false;
+  if (!opt.plaintext) {
+    use_h5 = h5.load() && h5.open(opt.output + "/abundance.h5", opt.bootstrap > 0);
+    if (!use_h5) std::cerr << "Warning: libhdf5 could not be loaded (set KAMD_HDF5_LIB), abundance.h5 is not written; plaintext output only" << std::endl;
+  }
+  if (use_h5) {   // H5Writer::init + write_main
+    std::vector<int32_t> fld_v(KAMD_MAX_FRAG_LEN, 0);
+    if (opt.fld == 0.0) for (int i = 0; i < KAMD_MAX_FRAG_LEN; i++) fld_v[i] = (int32_t)flens[i];
+    else {   // trunc_gaussian_counts(0, MAX_FRAG_LEN, mean, sd, 10000), src/weights.cpp:273-296
+      double total_mass = 0.0;
+      for (int i = 0; i < KAMD_MAX_FRAG_LEN; i++) { const double x = ((double)i - opt.fld) / opt.sd; total_mass += std::exp(-0.5 * x * x) / opt.sd; }
+      for (int i = 0; i < KAMD_MAX_FRAG_LEN; i++) { const double x = ((double)i - opt.fld) / opt.sd; fld_v[i] = (int)std::round(std::exp(-0.5 * x * x) / opt.sd * 10000 / total_mass); }
+    }
+    h5.ints(h5.aux(), "num_bootstrap", {opt.bootstrap});
+    h5.ints(h5.aux(), "num_processed", {(int32_t)n_processed});
+    h5.ints(h5.aux(), "fld", fld_v);
+    h5.ints(h5.aux(), "bias_observed", std::vector<int32_t>(4096, 1));      // preBias without --bias (src/main.cpp:2676)
+    h5.doubles(h5.aux(), "bias_normalized", std::vector<double>(4096, 1.0));  // EMAlgorithm::post_bias_ (EMAlgorithm.h:37)
+    h5.strings(h5.aux(), "kallisto_version", {KALLISTO_COMPAT_VERSION});
+    h5.ints(h5.aux(), "index_version", {13});
+    h5.strings(h5.aux(), "call", {call});
+    h5.strings(h5.aux(), "start_time", {start_time});
+    h5.doubles(h5.root(), "est_counts", alpha);
+    std::vector<std::string> ids(v.n_targets);
+    for (uint64_t t = 0; t < v.n_targets; t++) ids[t] = kamd_index_target_name(idx, t);
+    h5.strings(h5.aux(), "ids", ids);
+    h5.doubles(h5.aux(), "eff_lengths", eff);
+    h5.ints(h5.aux(), "lengths", std::vector<int32_t>(v.target_lens, v.target_lens + v.n_targets));
+  }
   write_abundance(opt.output + "/abundance.tsv", idx, v, alpha, eff);
-  if (opt.bootstrap > 0 && num_pseudoaligned > 0) {  // src/main.cpp:2744-2782 (plaintext branch)
+  if (opt.bootstrap > 0 && num_pseudoaligned == 0 && use_h5) {   // nothing aligned: empty replicates (src/main.cpp:2733-2743)
+    for (int b = 0; b < opt.bootstrap; b++) h5.doubles(h5.bs(), ("bs" + std::to_string(b)).c_str(), alpha);
+  }
+  if (opt.bootstrap > 0 && num_pseudoaligned > 0) {  // src/main.cpp:2744-2782
     std::vector<uint64_t> seeds(opt.bootstrap);
     kamd_bootstrap_seeds(opt.seed, opt.bootstrap, seeds.data());
     std::vector<double> a(v.n_targets);
@@ -552,10 +676,12 @@ int main(int argc, char** argv) {
       std::cerr << "[bstrp] running EM for the bootstrap: " << b + 1 << "\r";
       int32_t r = 0;
       KX(kamd_bootstrap(ctx, nullptr, nullptr, nullptr, 0, seeds[b], eff.data(), v.n_targets, a.data(), &r, nullptr));
-      write_abundance(opt.output + "/bs_abundance_" + std::to_string(b) + ".tsv", idx, v, a, eff);
+      if (use_h5) h5.doubles(h5.bs(), ("bs" + std::to_string(b)).c_str(), a);   // H5Writer::write_bootstrap
+      else write_abundance(opt.output + "/bs_abundance_" + std::to_string(b) + ".tsv", idx, v, a, eff);
     }
     std::cerr << std::endl;
   }
+  h5.close();
   kamd_ctx_destroy(ctx);
   kamd_index_free(idx);
   return num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797

@@ -4,6 +4,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -86,3 +87,50 @@ def test_cli_matches_reference_cli(case, variant, tmp_path):
         # BASELINE config #1: the md5 the survey pinned for the reference's abundance.tsv
         md5 = hashlib.md5(open(os.path.join(out, "abundance.tsv"), "rb").read()).hexdigest()
         assert md5 == "0bd5087aba9db4b681073bb84de3fe5f"
+
+
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe_boot"), ("yeast_se", "se"), ("dlist_pe", "pe")])
+def test_cli_writes_the_reference_abundance_h5(case, variant, tmp_path):
+    """Without --plaintext the front-end writes abundance.h5 like a USE_HDF5 build of the reference (H5Writer.cpp:4-69): same
+    groups / datasets / types / chunking / deflate level / string sizes, same integers and strings, estimated counts and
+    bootstrap replicates within 1e-4.  Golden: h5dump of the reference's file (oracle/_ref/kallisto_h5, make_golden.py)."""
+    if not os.path.exists(H5DUMP):
+        pytest.skip("h5dump not installed")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import h5dump_tools as H
+    meta, idx_path, r1, r2 = common.load_case(case)
+    extra = meta["variants"][variant]
+    cli = [a.replace("--fr", "--fr-stranded").replace("--rf", "--rf-stranded") for a in extra]
+    cli = ["-b" if a == "--boot" else a for a in cli]
+    f1 = str(tmp_path / "r_1.fq")
+    _fastq(f1, r1)
+    files = [f1]
+    if r2 is not None and "--single" not in extra:
+        f2 = str(tmp_path / "r_2.fq")
+        _fastq(f2, r2)
+        files.append(f2)
+    out = str(tmp_path / "out")
+    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "-t", "4", *cli, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert os.path.exists(os.path.join(out, "abundance.h5")), p.stderr.decode()
+    assert not any(fn.startswith("bs_abundance") for fn in os.listdir(out))        # replicates live in the h5 file
+    dump = subprocess.run([H5DUMP, "-p", "-m", "%.12g", os.path.join(out, "abundance.h5")], check=True, stdout=subprocess.PIPE).stdout.decode()
+    got = H.parse(dump)
+    want = H.parse(open(os.path.join(common.case_dir(case), "cli_" + variant, "abundance.h5.dump")).read())
+    assert sorted(got) == sorted(want)
+    for name, w in want.items():
+        g = got[name]
+        if name in ("aux/call", "aux/start_time"):          # run-specific strings: only the layout is comparable
+            assert g["type"] == w["type"] and g["dims"] == w["dims"] == 1
+            continue
+        for key in ("type", "dims", "chunk", "deflate", "strsize"):
+            assert g[key] == w[key], (name, key, g[key], w[key])
+        if name == "est_counts" or name.startswith("bootstrap/"):
+            common.assert_abundance_close(np.array(g["values"]), np.array(w["values"]), name, rel=1e-4, floor=1e-5)
+        elif name == "aux/eff_lengths":
+            assert np.allclose(g["values"], w["values"], rtol=1e-11, atol=0), name
+        else:
+            assert g["values"] == w["values"], name
