@@ -1274,12 +1274,9 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   u32 hid[PM_HEAD];
 #pragma unroll
   for (int i = 0; i < PM_HEAD; i++) hid[i] = (u32)(lane + 64 * i) < hlen ? (*(base - hlen + lane + 64 * i) & ~PM_END) : PM_NONE;
-  u32 emask[(K + 31) / 32];   // bit k: the lane's k-th entry ends a segment
+  u32 ne = 0;   // (the END flag stays in id[k]: its sign is the "this entry ends a segment" test of the loops below)
 #pragma unroll
-  for (int w = 0; w < (K + 31) / 32; w++) emask[w] = 0;
-  u32 ne = 0;
-#pragma unroll
-  for (int k = 0; k < K; k++) { const u32 e = id[k] >> 31; emask[k / 32] |= e << (k % 32); ne += e; id[k] &= ~PM_END; }
+  for (int k = 0; k < K; k++) ne += id[k] >> 31;
   u32 incl = ne;   // segment ends in this and the lower lanes
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
@@ -1291,7 +1288,7 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   for (u32 w0 = skip; w0 == skip || w0 < n_ends; w0 += PM_LDS_SLOTS) {
     double v[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = src[id[k]];
+    for (int k = 0; k < K; k++) v[k] = src[id[k] & ~PM_END];
     double hsum = 0.0;
     if (hlen) {
 #pragma unroll
@@ -1312,17 +1309,21 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
 #pragma unroll
     for (int k = 0; k < K; k++) {
       run += v[k];
-      if ((emask[k / 32] >> (k % 32)) & 1u) {
+      if ((int32_t)id[k] < 0) {
         if (!got) { first_part = run; got = true; }
         else if (j >= w0 && j < w0 + PM_LDS_SLOTS) lds[j - w0] = run;
         ++j; run = 0.0;
       }
     }
     double y = run;   // segmented inclusive scan; a lane that holds a segment end starts a new run with its tail
+    // lane may add the partial sum of lane - d iff no lane in (lane - d, lane] holds an end, i.e. iff d <= its distance to the
+    // nearest end at or below it (the lane itself: 0; none: lane + 1 -- which also covers the lane >= d test)
+    const u64 below = heads & ((2ULL << lane) - 1ULL);
+    const int reach = below ? lane - (63 - __clzll((long long)below)) : lane + 1;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const double t = __shfl_up(y, d, 64);
-      if (lane >= d && ((heads >> (lane - d + 1)) & ((1ULL << d) - 1ULL)) == 0ULL) y += t;
+      if (d <= reach && lane >= d) y += t;
     }
     double carry = __shfl_up(y, 1, 64);
     if (lane == 0) carry = 0.0;
