@@ -1221,6 +1221,36 @@ struct PmArgs {
   int* spec_hist;          // partitioned EM: per-round change counts of this rank (the stop rule is applied by the host); else null
 };
 
+// Wavefront scans on the DPP data path (row_shr within the rows of 16 lanes, then row_bcast:15 / row_bcast:31 across
+// rows): six VALU steps instead of six LDS round trips (__shfl_up is ds_bpermute_b32, ~100+ cycles each, and the steps of
+// a scan depend on each other).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 pm_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double pm_dpp(double v) {
+  const u32 lo = pm_dpp<CTRL, ROW_MASK>((u32)__double2loint(v)), hi = pm_dpp<CTRL, ROW_MASK>((u32)__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ u32 pm_scan_incl(u32 x) {   // inclusive prefix sum over the 64 lanes
+  x += pm_dpp<0x111, 0xF>(x); x += pm_dpp<0x112, 0xF>(x); x += pm_dpp<0x114, 0xF>(x); x += pm_dpp<0x118, 0xF>(x);
+  x += pm_dpp<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3
+  x += pm_dpp<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// segmented inclusive sum: lane l gets the sum over lanes (l - reach, l] where reach = distance to the nearest segment
+// start at or below l (0: the lane starts a segment itself; l + 1: none below)
+__device__ __forceinline__ double pm_scan_seg(double y, int reach, int lane) {
+  const int r = lane & 15;   // position inside the row
+  { const double t = pm_dpp<0x111, 0xF>(y); if (reach >= 1 && r >= 1) y += t; }
+  { const double t = pm_dpp<0x112, 0xF>(y); if (reach >= 2 && r >= 2) y += t; }
+  { const double t = pm_dpp<0x114, 0xF>(y); if (reach >= 4 && r >= 4) y += t; }
+  { const double t = pm_dpp<0x118, 0xF>(y); if (reach >= 8 && r >= 8) y += t; }
+  // rows 1 and 3 take the total of the row before them if their run reaches back past the row's first lane
+  { const double t = pm_dpp<0x142, 0xA>(y); if ((lane & 16) && reach > r) y += t; }
+  // rows 2 and 3 take lane 31's value if their run reaches back past lane 32
+  { const double t = pm_dpp<0x143, 0xC>(y); if (lane >= 32 && reach > lane - 32) y += t; }
+  return y;
+}
 // what is done with a finished segment sum: load() fetches the segment's constants (issued before the sums are known,
 // coalesced: consecutive lanes finish consecutive segments), finish() consumes them with the sum
 struct PmRowEmit {   // g_e = count_e / S_e; rows the reference skips get 0: count 0 (:133-135), denom below denorm_min (:156-158)
@@ -1277,11 +1307,9 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   u32 ne = 0;   // (the END flag stays in id[k]: its sign is the "this entry ends a segment" test of the loops below)
 #pragma unroll
   for (int k = 0; k < K; k++) ne += id[k] >> 31;
-  u32 incl = ne;   // segment ends in this and the lower lanes
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+  const u32 incl = pm_scan_incl(ne);   // segment ends in this and the lower lanes
   const u32 ebase = incl - ne;
-  const u32 n_ends = __shfl(incl, 63, 64);
+  const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)incl, 63);
   const u64 heads = __ballot(ne > 0);
   const u32 skip = heavy ? 1u : 0u;   // a heavy crossing segment's end is finished by pm_fix
   // (one window unless the chunk holds more segment ends than the wavefront's share of LDS; then the pass is repeated)
@@ -1320,13 +1348,8 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
     // nearest end at or below it (the lane itself: 0; none: lane + 1 -- which also covers the lane >= d test)
     const u64 below = heads & ((2ULL << lane) - 1ULL);
     const int reach = below ? lane - (63 - __clzll((long long)below)) : lane + 1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double t = __shfl_up(y, d, 64);
-      if (d <= reach && lane >= d) y += t;
-    }
-    double carry = __shfl_up(y, 1, 64);
-    if (lane == 0) carry = 0.0;
+    y = pm_scan_seg(y, reach, lane);
+    double carry = pm_dpp<0x138, 0xF>(y);   // wave_shr:1 (lane 0 gets 0)
     if (ebase == 0) carry += hsum;   // the chunk's first end also gets the re-read head
     if (got && ebase >= w0 && ebase < w0 + PM_LDS_SLOTS) lds[ebase - w0] = carry + first_part;
     if (w0 == skip) {  // partial sums for pm_fix: a chunk without any end lies wholly inside one segment (its sum is both)
