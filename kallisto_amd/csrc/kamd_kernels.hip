@@ -1251,6 +1251,11 @@ __device__ __forceinline__ double pm_scan_seg(double y, int reach, int lane) {
   { const double t = pm_dpp<0x143, 0xC>(y); if (lane >= 32 && reach > lane - 32) y += t; }
   return y;
 }
+__device__ __forceinline__ double pm_wave_sum(double x) {   // sum over the 64 lanes, in every lane
+  x += pm_dpp<0x111, 0xF>(x); x += pm_dpp<0x112, 0xF>(x); x += pm_dpp<0x114, 0xF>(x); x += pm_dpp<0x118, 0xF>(x);
+  x += pm_dpp<0x142, 0xA>(x); x += pm_dpp<0x143, 0xC>(x);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
 // what is done with a finished segment sum: load() fetches the segment's constants (issued before the sums are known,
 // coalesced: consecutive lanes finish consecutive segments), finish() consumes them with the sum
 struct PmRowEmit {   // g_e = count_e / S_e; rows the reference skips get 0: count 0 (:133-135), denom below denorm_min (:156-158)
@@ -1292,7 +1297,7 @@ __device__ __forceinline__ void pm_wave_load(const PmSide& s, u32 c, PmWave<K>& 
   w.sb = s.seg_base[c];
   w.hd = s.head[c];
 }
-template <int K, int PRE, class Emit>
+template <int K, int PRE, bool WIN, class Emit>
 __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& w, const double* __restrict__ src, double* lds, const Emit& em) {
   const int lane = lane_id();
   const u32* base = s.stream + (u64)c * (64 * K);
@@ -1312,6 +1317,54 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)incl, 63);
   const u64 heads = __ballot(ne > 0);
   const u32 skip = heavy ? 1u : 0u;   // a heavy crossing segment's end is finished by pm_fix
+  if constexpr (!WIN) {
+    // every segment end of the chunk has its own LDS slot (all real chunks): no window tests, and the lane's first end is
+    // staged like the others and completed in place once the carry is known -- 6 instructions per entry instead of ~25
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = src[id[k] & ~PM_END];
+    double hsum = 0.0;
+    if (hlen) {
+#pragma unroll
+      for (int i = 0; i < PM_HEAD; i++) if (hid[i] != PM_NONE) hsum += src[hid[i]];
+    }
+    typename Emit::Ctx pre[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; i++) { const u32 j = skip + lane + 64 * i; if (j < n_ends) pre[i] = em.load(sb + j); }
+    if (hlen) hsum = pm_wave_sum(hsum);
+    double run = 0.0;
+    double* slot = lds + ebase;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      run += v[k];
+      if ((int32_t)id[k] < 0) { *slot++ = run; run = 0.0; }
+    }
+    const u64 below = heads & ((2ULL << lane) - 1ULL);
+    const int reach = below ? lane - (63 - __clzll((long long)below)) : lane + 1;
+    const double y = pm_scan_seg(run, reach, lane);
+    double carry = pm_dpp<0x138, 0xF>(y);   // wave_shr:1 (lane 0 gets 0)
+    if (ebase == 0) carry += hsum;
+    if (ne) {   // the lane's first end: what the lanes below it hold of that segment comes first in the sum
+      const double first = carry + lds[ebase];
+      lds[ebase] = first;
+      if (heavy && ebase == 0) s.lp[c] = first;
+    }
+    if (lane == 63) { if (n_ends == 0) { s.lp[c] = y; s.rp[c] = y; } else s.rp[c] = y; }
+    if (skip >= n_ends) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < PRE; i++) { const u32 t = skip + lane + 64 * i; if (t < n_ends) em.finish(sb + t, pre[i], lds[t]); }
+    for (u32 t = skip + lane + 64 * PRE; t < n_ends; t += 128) {
+      const u32 t1 = t + 64;
+      const bool h1 = t1 < n_ends;
+      const typename Emit::Ctx x0 = em.load(sb + t), x1 = h1 ? em.load(sb + t1) : x0;
+      em.finish(sb + t, x0, lds[t]);
+      if (h1) em.finish(sb + t1, x1, lds[t1]);
+    }
+    return;
+  } else {
   // (one window unless the chunk holds more segment ends than the wavefront's share of LDS; then the pass is repeated)
   for (u32 w0 = skip; w0 == skip || w0 < n_ends; w0 += PM_LDS_SLOTS) {
     double v[K];
@@ -1325,10 +1378,7 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
     typename Emit::Ctx pre[PRE];
 #pragma unroll
     for (int i = 0; i < PRE; i++) { const u32 j = w0 + lane + 64 * i; if (j < n_ends) pre[i] = em.load(sb + j); }
-    if (hlen) {
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) hsum += __shfl_xor(hsum, d, 64);
-    }
+    if (hlen) hsum = pm_wave_sum(hsum);
     // lane-local pass in entry order: a segment that ends after an earlier end of the same lane is complete -> staged in LDS
     // at its local index; the sum up to the lane's first end waits for the carry; the open tail feeds the wavefront scan
     double run = 0.0, first_part = 0.0;
@@ -1374,6 +1424,7 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  }
 }
 // a heavy crossing segment that ends in chunk c: right partial of the chunk it started in + the chunks wholly inside it +
 // this chunk's left partial, in chunk order; one thread per chunk
@@ -1404,13 +1455,13 @@ __device__ __forceinline__ void pm_count_changes(int ch, int* lds_ch, EmState* r
 }
 
 // rows launch (first of the round: block 0 publishes the round's loop-control record, like k_em_rows)
-template <int K, int PRE, bool EARLY>
+template <int K, int PRE, bool WIN>
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity) {
   __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
   const EmState prev = A.st[parity ^ 1];
   const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
   PmWave<K> w;
-  if (EARLY && c < A.rows.n_chunks) pm_wave_load<K>(A.rows, c, w);
+  if (c < A.rows.n_chunks) pm_wave_load<K>(A.rows, c, w);
   const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, A.spec_hist != nullptr);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     EmState r; r.iter = now.it; r.chcount = 0; r.final_round = now.fin; r.done = now.done; r.rounds = now.rounds; r.force_final = 0;
@@ -1421,27 +1472,25 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity)
   if (now.done) return;
   const int odd = now.it & 1;
   if (c >= A.rows.n_chunks) return;
-  if (!EARLY) pm_wave_load<K>(A.rows, c, w);
   const PmRowEmit em{A.cw, A.g};
   const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
-  pm_wave_pass<K, PRE>(A.rows, c, w, a_cur, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  pm_wave_pass<K, PRE, WIN>(A.rows, c, w, a_cur, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
 }
-template <int K, int PRE, bool EARLY>
+template <int K, int PRE, bool WIN>
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity) {
   __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
   __shared__ int lds_ch;
   const EmState prev = A.st[parity ^ 1];
   const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
   PmWave<K> w;
-  if (EARLY && c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
+  if (c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
   const EmNow now = em_next_round(prev, A.n_iter, A.min_rounds, A.spec_hist != nullptr);
   if (now.done) return;
-  if (!EARLY && c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
   const int odd = now.it & 1;
   int ch = 0;
   const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
   const PmColEmit em{odd ? A.alpha1 : A.alpha0, a_cur, A.single, A.eff, odd ? A.alpha0 : A.alpha1, odd ? A.a0 : A.a1, odd ? A.ac0 : A.ac1, &ch, now.fin};
-  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE>(A.cols, c, w, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE, WIN>(A.cols, c, w, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
   pm_count_changes(ch, &lds_ch, &A.st[parity]);
 }
 // fix-up launches (only enqueued when a direction has heavy crossing segments)
@@ -1529,7 +1578,7 @@ __global__ void k_pm_minit(u64 n_tr, const u32* __restrict__ mflag, const u64* _
 }
 // per chunk: the segment its first entry belongs to (binary search in the segment offsets) and how it is completed
 __global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 chunk, u32 n_chunks, u32* seg_base, u32* head,
-                            u32* fix_first, u32* n_fix) {
+                            u32* fix_first, u32* n_fix, u32* max_ends) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_chunks) return;
   const u64 c0 = (u64)c * chunk, c1 = c0 + chunk;
@@ -1543,6 +1592,10 @@ __global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 
   const bool fix = is_heavy && se <= c1;
   fix_first[c] = fix ? (u32)(hs / chunk) : PM_NONE;
   if (fix) atomicAdd(n_fix, 1u);
+  const u64 ce = c1 < nz ? c1 : nz;   // segment ends inside the chunk: segments lo .. l2 - 1, l2 = largest s in [0, n_seg] with off[s] <= ce
+  u64 l2 = lo; hi = n_seg + 1;
+  while (hi - l2 > 1) { const u64 mid = (l2 + hi) / 2; if (off[mid] <= ce) l2 = mid; else hi = mid; }
+  if (l2 - lo > (u64)PM_LDS_SLOTS) atomicMax(max_ends, (u32)(l2 - lo));
 }
 // back to transcript space: both buffers (result and alpha_before_zeroes are picked by the caller).  A transcript that
 // only has a singleton set holds that count in every buffer from round 1 on; one that is in no set stays 0.
@@ -2374,7 +2427,7 @@ struct Carver {  // sub-allocations of one device arena, 256-byte aligned
 struct PmPlan {
   PmArgs args{};
   int k = 0;                 // entries per lane
-  bool early = true;         // the chunk's loads are issued before the loop-control record is used (KAMD_EM_EARLY=0: after; ~2.5 % slower)
+  bool windowed = false;     // some chunk holds more segment ends than a wavefront's LDS slots (or KAMD_EM_WINDOWED=1): the general pass
   u32 n_chunks = 0;
   u32 n_fix[2] = {0, 0};     // heavy crossing segments per direction (0: no fix-up launch)
   const u32* mflag = nullptr; const u64* mpos = nullptr;   // transcript -> m-space
@@ -2385,10 +2438,10 @@ void pm_launch_round(const PmPlan& P, hipStream_t s, int parity) {
   const unsigned grid = grid_for(P.n_chunks, PM_BLOCK / 64);
   constexpr int PRE_R = (K + 5) / 6 < 2 ? 2 : (K + 5) / 6;   // 64 * PRE >= ~chunk / 6 row ends
   constexpr int PRE_C = K / 16 + 1;                           // 64 * PRE >= ~chunk / 16 column ends
-  if (P.early) hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  if (P.windowed) hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
   else hipLaunchKernelGGL((k_pm_rows_pass<K, PRE_R, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
   if (P.n_fix[0]) hipLaunchKernelGGL(k_pm_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, parity);
-  if (P.early) hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
+  if (P.windowed) hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
   else hipLaunchKernelGGL((k_pm_cols_pass<K, PRE_C, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, parity);
   if (P.n_fix[1]) hipLaunchKernelGGL(k_pm_cols_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, parity);
 }
@@ -2484,7 +2537,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
     d.lp = (double*)(b2 + o_meta[s][3]); d.rp = (double*)(b2 + o_meta[s][4]);
     d.n_chunks = n_chunks;
     hipLaunchKernelGGL(k_pm_chunks, dim3(grid_for(n_chunks, BLOCK)), dim3(BLOCK), 0, c->stream, s == 0 ? roff : coff, s == 0 ? R : M, NZ, chunk,
-                       n_chunks, sb, hd, ff, (u32*)(b2 + o_nfix) + s);
+                       n_chunks, sb, hd, ff, (u32*)(b2 + o_nfix) + s, (u32*)(b2 + o_nfix) + 2);
   }
   HIPC(hipGetLastError());
   PmArgs& A = P->args;
@@ -2494,9 +2547,12 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   A.single = single_m; A.eff = eff_m;
   A.R = (u32)R; A.M = (u32)M;
   A.st = (EmState*)c->em_state.p;
-  HIPC(hipMemcpyAsync(P->n_fix, b2 + o_nfix, sizeof P->n_fix, hipMemcpyDeviceToHost, c->stream));
+  u32 plan_words[3] = {0, 0, 0};   // heavy crossings per direction, largest number of segment ends in a chunk (if above the LDS slots)
+  HIPC(hipMemcpyAsync(plan_words, b2 + o_nfix, sizeof plan_words, hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
-  if (const char* e = getenv("KAMD_EM_EARLY")) P->early = atoi(e) != 0;
+  P->n_fix[0] = plan_words[0]; P->n_fix[1] = plan_words[1];
+  P->windowed = plan_words[2] > (u32)PM_LDS_SLOTS;
+  if (const char* e = getenv("KAMD_EM_WINDOWED")) { if (atoi(e) != 0) P->windowed = true; }
   P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos;
   c->last_em_nnz_multi = NZ; c->last_em_nseg = n_chunks; c->last_em_necs = n_ecs; c->last_em_k = K;
   c->last_em_grid = grid_for(n_chunks, PM_BLOCK / 64);

@@ -20,8 +20,8 @@ flens, _ = ctx.fld_from_batch(opts, words, lens, n, L)
 ctx.finalize(download=False)
 eff = A.eff_lens(index.target_lens, A.mean_frag_lens_trunc(flens))
 ref = None
-for mode in [(1, 24), (1, 28), (1, 32), (1, 24), (1, 28)]:
-    os.environ["KAMD_EM_EARLY"] = str(mode[0]); os.environ["KAMD_EM_K"] = str(mode[1])
+for mode in [(0, 24), (0, 20), (0, 16), (0, 28), (1, 24), (0, 24), (0, 20)]:
+    os.environ["KAMD_EM_WINDOWED"] = str(mode[0]); os.environ["KAMD_EM_K"] = str(mode[1])
     for rep in range(2):
         a, z, r = ctx.em_run(eff)
     p = ctx.profile()

@@ -175,13 +175,17 @@ def _family_csr(n_genes, seed):
     return off, ids, cnt, rng.uniform(150, 3000, T), T
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "csr"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The streamed EM form (default and forced chunk sizes: 64 x 8 entries makes the long rows / hub columns span many
-    chunks -> fix-up launches) and the CSR form against the oracle's EMAlgorithm::run restatement."""
+    chunks -> fix-up launches; "wK": the general pass for chunks with more segment ends than LDS slots, forced) and the CSR
+    form against the oracle's EMAlgorithm::run restatement."""
     import torch
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
+    monkeypatch.setenv("KAMD_EM_WINDOWED", "1" if isinstance(k, str) and k[0] == "w" else "0")
+    if isinstance(k, str) and k[0] == "w":
+        k = int(k[1:])
     alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
     monkeypatch.setenv("KAMD_EM_STREAMED", "0" if k == "csr" else "1")
     if isinstance(k, int):
