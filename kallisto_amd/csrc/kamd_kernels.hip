@@ -1200,10 +1200,14 @@ constexpr int PM_BLOCK = 256;         // 4 wavefronts = 4 chunks per block
 constexpr int PM_HEAD = 4;            // a crossing segment with <= 64 * PM_HEAD entries before the chunk is re-read by the chunk
 constexpr int PM_LDS_SLOTS = 512;     // segment sums staged per wavefront and window
 struct PmSide {
-  const u32* stream;     // [n_chunks * 64 * K] index | PM_END; the tail padding points at a sentinel whose value is 0
+  const u32* stream;     // [n_chunks * 64 * K] index | PM_END; the tail padding points at a sentinel whose value is 0; 64 * PM_HEAD
+                         // readable entries (any valid index) in front of it
   const u32* seg_base;   // [n_chunks] segment that contains the chunk's first entry
   const u32* head;       // [n_chunks] entries of that segment before the chunk: 0, 1..64*PM_HEAD (re-read), PM_HEAVY (partials)
   const u32* fix_first;  // [n_chunks] heavy crossing segment that ENDS in this chunk: the chunk it started in, else PM_NONE
+  const u32* lane_word;  // [n_chunks * 64] per lane of the chunk: segment ends below the lane | ends in the lane << 12 | distance to the
+                         // nearest lane at or below it that holds an end (lane + 1: none) << 18 -- what the passes would otherwise
+                         // recount from the END flags every round
   double* lp;            // [n_chunks] sum of the chunk's entries up to its first segment end (all of them if there is none)
   double* rp;            // [n_chunks] sum of the entries after the chunk's last segment end
   u32 n_chunks;
@@ -1288,46 +1292,51 @@ struct PmColEmit {   // next_t = single_t + a_t * sum_e g_e and the convergence 
 // (in two steps so that the kernels can issue the chunk's loads BEFORE they use the round's loop-control record: both are
 // first-touch reads of a cold L2, ~2 us each, overlapped instead of chained)
 template <int K>
-struct PmWave { u32 id[K]; u32 sb, hd; };
+struct PmWave { u32 id[K]; u32 hraw[PM_HEAD]; u32 sb, hd, lw; };
 template <int K>
 __device__ __forceinline__ void pm_wave_load(const PmSide& s, u32 c, PmWave<K>& w) {
   const uint4* p = reinterpret_cast<const uint4*>(s.stream + (u64)c * (64 * K) + lane_id() * K);
 #pragma unroll
   for (int q = 0; q < K / 4; q++) { const uint4 x = p[q]; w.id[4 * q] = x.x; w.id[4 * q + 1] = x.y; w.id[4 * q + 2] = x.z; w.id[4 * q + 3] = x.w; }
+  // the 64 * PM_HEAD entries before the chunk (the stream has that much padding in front): which of them belong to the
+  // segment that crosses into the chunk is known once head[c] is here, their addresses do not depend on it
+  const u32* hb = s.stream + (u64)c * (64 * K) + lane_id();
+#pragma unroll
+  for (int i = 0; i < PM_HEAD; i++) w.hraw[i] = *(hb - 64 * (i + 1));
   w.sb = s.seg_base[c];
   w.hd = s.head[c];
+  w.lw = s.lane_word[(u64)c * 64 + lane_id()];
 }
 template <int K, int PRE, bool WIN, class Emit>
 __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& w, const double* __restrict__ src, double* lds, const Emit& em) {
   const int lane = lane_id();
-  const u32* base = s.stream + (u64)c * (64 * K);
   u32 (&id)[K] = w.id;
   const u32 sb = w.sb;
   const u32 hd = w.hd;
   const bool heavy = (hd & PM_HEAVY) != 0;
   const u32 hlen = heavy ? 0u : hd;
-  u32 hid[PM_HEAD];
+  // lane l holds the entries 64 * (i + 1) - l before the chunk
+  auto head_sum = [&](void) -> double {
+    double hv[PM_HEAD];
 #pragma unroll
-  for (int i = 0; i < PM_HEAD; i++) hid[i] = (u32)(lane + 64 * i) < hlen ? (*(base - hlen + lane + 64 * i) & ~PM_END) : PM_NONE;
-  u32 ne = 0;   // (the END flag stays in id[k]: its sign is the "this entry ends a segment" test of the loops below)
+    for (int i = 0; i < PM_HEAD; i++) hv[i] = src[w.hraw[i] & ~PM_END];
+    double hs = 0.0;
 #pragma unroll
-  for (int k = 0; k < K; k++) ne += id[k] >> 31;
-  const u32 incl = pm_scan_incl(ne);   // segment ends in this and the lower lanes
-  const u32 ebase = incl - ne;
-  const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-  const u64 heads = __ballot(ne > 0);
+    for (int i = 0; i < PM_HEAD; i++) hs += (u32)(64 * (i + 1) - lane) <= hlen ? hv[i] : 0.0;
+    return hs;
+  };
   const u32 skip = heavy ? 1u : 0u;   // a heavy crossing segment's end is finished by pm_fix
+  // (the END flag stays in id[k]: its sign is the "this entry ends a segment" test of the loops below)
   if constexpr (!WIN) {
+    const u32 ebase = w.lw & 0xFFFu, ne = (w.lw >> 12) & 0x3Fu;
+    const int reach = (int)(w.lw >> 18);
+    const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)(ebase + ne), 63);
     // every segment end of the chunk has its own LDS slot (all real chunks): no window tests, and the lane's first end is
     // staged like the others and completed in place once the carry is known -- 6 instructions per entry instead of ~25
     double v[K];
 #pragma unroll
     for (int k = 0; k < K; k++) v[k] = src[id[k] & ~PM_END];
-    double hsum = 0.0;
-    if (hlen) {
-#pragma unroll
-      for (int i = 0; i < PM_HEAD; i++) if (hid[i] != PM_NONE) hsum += src[hid[i]];
-    }
+    double hsum = head_sum();
     typename Emit::Ctx pre[PRE];
 #pragma unroll
     for (int i = 0; i < PRE; i++) { const u32 j = skip + lane + 64 * i; if (j < n_ends) pre[i] = em.load(sb + j); }
@@ -1339,8 +1348,6 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
       run += v[k];
       if ((int32_t)id[k] < 0) { *slot++ = run; run = 0.0; }
     }
-    const u64 below = heads & ((2ULL << lane) - 1ULL);
-    const int reach = below ? lane - (63 - __clzll((long long)below)) : lane + 1;
     const double y = pm_scan_seg(run, reach, lane);
     double carry = pm_dpp<0x138, 0xF>(y);   // wave_shr:1 (lane 0 gets 0)
     if (ebase == 0) carry += hsum;
@@ -1365,16 +1372,19 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
     }
     return;
   } else {
+  u32 ne = 0;
+#pragma unroll
+  for (int k = 0; k < K; k++) ne += id[k] >> 31;
+  const u32 incl = pm_scan_incl(ne);   // segment ends in this and the lower lanes
+  const u32 ebase = incl - ne;
+  const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+  const u64 heads = __ballot(ne > 0);
   // (one window unless the chunk holds more segment ends than the wavefront's share of LDS; then the pass is repeated)
   for (u32 w0 = skip; w0 == skip || w0 < n_ends; w0 += PM_LDS_SLOTS) {
     double v[K];
 #pragma unroll
     for (int k = 0; k < K; k++) v[k] = src[id[k] & ~PM_END];
-    double hsum = 0.0;
-    if (hlen) {
-#pragma unroll
-      for (int i = 0; i < PM_HEAD; i++) if (hid[i] != PM_NONE) hsum += src[hid[i]];
-    }
+    double hsum = head_sum();
     typename Emit::Ctx pre[PRE];
 #pragma unroll
     for (int i = 0; i < PRE; i++) { const u32 j = w0 + lane + 64 * i; if (j < n_ends) pre[i] = em.load(sb + j); }
@@ -1596,6 +1606,20 @@ __global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 
   u64 l2 = lo; hi = n_seg + 1;
   while (hi - l2 > 1) { const u64 mid = (l2 + hi) / 2; if (off[mid] <= ce) l2 = mid; else hi = mid; }
   if (l2 - lo > (u64)PM_LDS_SLOTS) atomicMax(max_ends, (u32)(l2 - lo));
+}
+// per lane of every chunk: PmSide::lane_word; one wavefront per chunk, any K
+__global__ __launch_bounds__(PM_BLOCK) void k_pm_lanes(const u32* __restrict__ stream, u32 k, u32 n_chunks, u32* lane_word) {
+  const u32 c = blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = lane_id();
+  const u32* p = stream + (u64)c * (64 * k) + (u64)lane * k;
+  u32 ne = 0;
+  for (u32 i = 0; i < k; i++) ne += p[i] >> 31;
+  const u32 incl = pm_scan_incl(ne);
+  const u64 heads = __ballot(ne > 0);
+  const u64 below = heads & ((2ULL << lane) - 1ULL);
+  const u32 reach = below ? (u32)(lane - (63 - __clzll((long long)below))) : (u32)(lane + 1);
+  lane_word[(u64)c * 64 + lane] = (incl - ne) | (ne << 12) | (reach << 18);
 }
 // back to transcript space: both buffers (result and alpha_before_zeroes are picked by the caller).  A transcript that
 // only has a singleton set holds that count in every buffer from round 1 on; one that is in no set stays 0.
@@ -2502,16 +2526,24 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   const u64 nzpad = (u64)n_chunks * chunk;
   // stage 2
   Carver s2;
-  const size_t o_rs = s2.take(nzpad * 4), o_cs = s2.take(nzpad * 4);
+  const size_t front = 64 * PM_HEAD * 4;   // the passes read up to 64 * PM_HEAD entries before a chunk, also before chunk 0
+  const size_t o_rs = s2.take(front + nzpad * 4), o_cs = s2.take(front + nzpad * 4);
   size_t o_meta[2][5];
-  for (int s = 0; s < 2; s++) { for (int j = 0; j < 3; j++) o_meta[s][j] = s2.take((size_t)n_chunks * 4); for (int j = 3; j < 5; j++) o_meta[s][j] = s2.take((size_t)n_chunks * 8); }
+  size_t o_lane[2];
+  for (int s = 0; s < 2; s++) {
+    for (int j = 0; j < 3; j++) o_meta[s][j] = s2.take((size_t)n_chunks * 4);
+    for (int j = 3; j < 5; j++) o_meta[s][j] = s2.take((size_t)n_chunks * 8);
+    o_lane[s] = s2.take((size_t)n_chunks * 64 * 4);
+  }
   const size_t o_cw = s2.take(R * 8), o_coff = s2.take((M + 1) * 8), o_g = s2.take((R + 1) * 8);
   size_t o_vec[6];
   for (int j = 0; j < 6; j++) o_vec[j] = s2.take((M + 1) * 8);
   const size_t o_single = s2.take(M * 8), o_eff = s2.take(M * 8), o_nfix = s2.take(64);
   if (int rc = c->pm_b.ensure(s2.off, 0, c->stream)) return rc;
   char* b2 = (char*)c->pm_b.p;
-  u32* rs = (u32*)(b2 + o_rs); u32* cs = (u32*)(b2 + o_cs);
+  u32* rs = (u32*)(b2 + o_rs + front); u32* cs = (u32*)(b2 + o_cs + front);
+  HIPC(hipMemsetAsync(b2 + o_rs, 0, front, c->stream));
+  HIPC(hipMemsetAsync(b2 + o_cs, 0, front, c->stream));
   u64* cw = (u64*)(b2 + o_cw); u64* coff = (u64*)(b2 + o_coff);
   double* g = (double*)(b2 + o_g);
   double* vec[6]; for (int j = 0; j < 6; j++) vec[j] = (double*)(b2 + o_vec[j]);
@@ -2536,6 +2568,9 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
     d.seg_base = sb; d.head = hd; d.fix_first = ff;
     d.lp = (double*)(b2 + o_meta[s][3]); d.rp = (double*)(b2 + o_meta[s][4]);
     d.n_chunks = n_chunks;
+    u32* lw = (u32*)(b2 + o_lane[s]);
+    d.lane_word = lw;
+    hipLaunchKernelGGL(k_pm_lanes, dim3(grid_for(n_chunks, PM_BLOCK / 64)), dim3(PM_BLOCK), 0, c->stream, d.stream, chunk / 64, n_chunks, lw);
     hipLaunchKernelGGL(k_pm_chunks, dim3(grid_for(n_chunks, BLOCK)), dim3(BLOCK), 0, c->stream, s == 0 ? roff : coff, s == 0 ? R : M, NZ, chunk,
                        n_chunks, sb, hd, ff, (u32*)(b2 + o_nfix) + s, (u32*)(b2 + o_nfix) + 2);
   }
