@@ -75,6 +75,7 @@ typedef struct {
   double sd;                /* -s */
   int32_t single_overhang;  /* --single-overhang */
   int32_t strand;           /* 0 unstranded, 1 --fr-stranded, 2 --rf-stranded */
+  int32_t no_jump;          /* --no-jump: match() looks up every k-mer (src/KmerIndex.cpp:1776); not with a strand option */
 } kamd_quant_opts;
 
 /* ---- errors ---- */

@@ -146,6 +146,7 @@ struct Table {
   uint64_t dummy_slot = 0;
   bool dummy_strand = false;
   bool partial = false;   // match(..., partial): single-end reads (src/ProcessReads.cpp:1058)
+  bool no_jump = false;   // --no-jump: every k-mer of the read is looked up (KmerIndex.cpp:1776)
 };
 struct Probe {
   bool found;
@@ -252,7 +253,7 @@ KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* e
       const int pos = w;
       KAMD_PUSH(um, pos);                                                          // KmerIndex.cpp:1774
       const int dist = (int)um.dist;                                               // :1789
-      if (dist >= 2) {                                                             // :1792
+      if (!t.no_jump && dist >= 2) {                                               // :1776, :1792
         int nextPos = pos + dist;
         if (pos + dist >= l - k) nextPos = l - k;                                  // :1796-1799
         int w2 = advance_window(r, w, nextPos - pos, k);                           // :1802-1803
@@ -391,7 +392,7 @@ KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p
       hit = add = true;
       if (mf.n_hits == 0) { mf.slot = p.slot; mf.pos = st.w; mf.strand = p.strand; }
       const int dist = (int)p.dist;                                                // :1789
-      if (dist >= 2) {                                                             // :1792
+      if (!t.no_jump && dist >= 2) {                                               // :1776, :1792
         const int pos = st.w;
         const int nextPos = (pos + dist >= lk) ? lk : pos + dist;                  // :1794-1799
         const int n = nextPos - pos;                                               // kit2 += nextPos - pos (:1803)

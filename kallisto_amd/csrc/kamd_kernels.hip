@@ -55,12 +55,13 @@ struct DevIndex {
   const u64* blk_pos_off; const u32* blk_posw; const uint8_t* blk_sense; const int32_t* target_lens;
   // D-list (second k-mer table + the dummy hit); n_dbuckets == 0: none
   const u64* dtable; u64 n_dbuckets; u64 dummy_slot; u32 dummy_uec; u32 dummy_strand;
+  int no_jump;   // kamd_quant_opts::no_jump of the run (set by the entry points that take the options)
 };
 // the k-mer table(s) as the per-item logic sees them; partial = match()'s `partial` argument = single-end reads
 __host__ __device__ inline kamd::Table make_table(const DevIndex& ix, bool partial) {
   kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
   t.dslots = (const uint64_t*)ix.dtable; t.n_dbuckets = ix.n_dbuckets; t.dummy_uec = ix.dummy_uec; t.dummy_slot = ix.dummy_slot;
-  t.dummy_strand = ix.dummy_strand != 0; t.partial = partial;
+  t.dummy_strand = ix.dummy_strand != 0; t.partial = partial; t.no_jump = ix.no_jump != 0;
   return t;
 }
 
@@ -2001,6 +2002,9 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   if (!o->paired && !(o->fld > 0.0 && o->sd > 0.0))
     return kamd::fail(-1, "kamd_pseudoalign: fragment length mean and sd must be supplied for single-end reads (-l, -s)");
   if (o->strand < 0 || o->strand > 2) return kamd::fail(-1, "kamd_pseudoalign: bad strand option");
+  if (o->no_jump && o->strand)   // the reference then filters per hit (`comprehensive`, ProcessReads.cpp:62-82): not built here
+    return kamd::fail(-5, "kamd_pseudoalign: --no-jump together with --fr-stranded/--rf-stranded is not supported");
+  c->ix.no_jump = o->no_jump ? 1 : 0;
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pseudoalign: max_len must be in [1, 65535]");
   if (n_items == 0) return 0;
   HIPC(hipSetDevice(c->device));
@@ -2009,14 +2013,12 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   const int item_words = rec_words * (o->paired ? 2 : 1);
   const size_t lds_bytes = (size_t)BLOCK * item_words * 4 + (size_t)BLOCK * TUPLE_CAP * 4;
   if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-staged kernel");
-  // positional filters (ProcessReads.cpp:1095-1145): has_mean_fl is set by -l only (MinCollector::init_mean_fl_trunc);
-  // with an estimated FLD it stays false while reads are processed
-  FilterDev fd{o->single_overhang, o->fld > 0.0 ? 1 : 0, 0, o->strand};
-  if (fd.has_mean_fl) {
-    std::vector<double> t(KAMD_MAX_FRAG_LEN);
-    kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, o->fld, o->sd, t.data());
-    fd.fl = (int)t[KAMD_MAX_FRAG_LEN - 1];  // (int) tc.get_mean_frag_len() (ProcessReads.cpp:1098)
-  }
+  // positional filters (ProcessReads.cpp:1095-1145): has_mean_fl is set by -l only, and while the reads are processed
+  // mean_fl is the -l value itself (MinCollector constructor, MinCollector.h:38-41; the truncated-Gaussian mean of
+  // init_mean_fl_trunc -- 199.99999999999994 for -l 200 -s 25 -- replaces it only after ProcessReads, main.cpp:2668-2671);
+  // with an estimated FLD has_mean_fl stays false while reads are processed
+  FilterDev fd{o->single_overhang, o->fld != 0.0 ? 1 : 0, 0, o->strand};
+  if (fd.has_mean_fl) fd.fl = (int)o->fld;  // (int) tc.get_mean_frag_len() (ProcessReads.cpp:1098)
   const bool filter = fd.strand != 0 || (!fd.single_overhang && fd.has_mean_fl);
   // capacity for the worst case of this batch
   const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
@@ -2145,6 +2147,7 @@ extern "C" int kamd_fld_prefetch(kamd_ctx* c, const kamd_quant_opts* o, const ui
   if (!c || !o) return kamd::fail(-1, "kamd_fld_prefetch: null argument");
   if (!o->paired || o->fld != 0.0) return kamd::fail(-1, "kamd_fld_prefetch: the FLD is only estimated for paired reads without -l");
   if (!c->has_index) return kamd::fail(-1, "kamd_fld_prefetch: no index uploaded");
+  c->ix.no_jump = o->no_jump ? 1 : 0;
   HIPC(hipSetDevice(c->device));
   if (n_items == 0) return 0;
   if (!c->fld_stream) {
@@ -2170,6 +2173,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   if (!o->paired || o->fld != 0.0) return kamd::fail(-1, "kamd_fld_from_batch: the FLD is only estimated for paired reads without -l");
   const FilterDev fd{o->single_overhang, 0, 0, o->strand};
   if (!c->has_index) return kamd::fail(-1, "kamd_fld_from_batch: no index uploaded");
+  c->ix.no_jump = o->no_jump ? 1 : 0;
   HIPC(hipSetDevice(c->device));
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);

@@ -37,7 +37,7 @@ const char* KALLISTO_COMPAT_VERSION = "0.51.1";  // src/common.h:4
 struct Options {
   std::string index, output;
   std::vector<std::string> files;
-  bool single = false, single_overhang = false, plaintext = false, verbose = false;
+  bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false;
   int strand = 0, bootstrap = 0, threads = 1;
   double fld = 0.0, sd = 0.0;
   uint64_t seed = 42;
@@ -61,6 +61,7 @@ void usage() {
             << "                              predicted to lie outside a transcript\n"
             << "    --fr-stranded             Strand specific reads, first read forward\n"
             << "    --rf-stranded             Strand specific reads, first read reverse\n"
+            << "    --no-jump                 Look up every k-mer of a read (no jumping); not with a strand option\n"
             << "-l, --fragment-length=DOUBLE  Estimated average fragment length\n"
             << "-s, --sd=DOUBLE               Estimated standard deviation of fragment length\n"
             << "-t, --threads=INT             Host threads for index loading (default: 1)\n"
@@ -453,10 +454,11 @@ int main(int argc, char** argv) {
     else if (a == "--single-overhang") opt.single_overhang = true;
     else if (a == "--fr-stranded") opt.strand = 1;
     else if (a == "--rf-stranded") opt.strand = 2;
+    else if (a == "--no-jump") opt.no_jump = true;
     else if (a == "--plaintext") opt.plaintext = true;
     else if (a == "--verbose") opt.verbose = true;
     else if (a == "--bias" || a == "--fusion" || a == "--pseudobam" || a == "--genomebam" || a == "--long" || a == "-p" || a == "--priors" ||
-             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--union" || a == "--no-jump" || a == "--dfk-onlist" ||
+             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--union" || a == "--dfk-onlist" ||
              a == "-P" || a == "--platform" || a == "-N" || a == "--numReads") {
       std::cerr << "Error: option " << a << " is outside the GPU quant path; use the reference kallisto for it" << std::endl; return 1;
     } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage(); return 1; }
@@ -471,6 +473,7 @@ int main(int argc, char** argv) {
   if ((opt.fld != 0.0 && opt.sd == 0.0) || (opt.sd != 0.0 && opt.fld == 0.0)) { std::cerr << "Error: cannot supply mean/sd without supplying both -l and -s" << std::endl; ok = false; }
   if (opt.single && (opt.fld == 0.0 || opt.sd == 0.0)) { std::cerr << "Error: fragment length mean and sd must be supplied for single-end reads using -l and -s" << std::endl; ok = false; }
   if (opt.fld < 0.0 || opt.sd < 0.0) { std::cerr << "Error: invalid value for mean fragment length or sd" << std::endl; ok = false; }
+  if (opt.no_jump && opt.strand) { std::cerr << "Error: --no-jump together with --fr-stranded/--rf-stranded is outside the GPU quant path; use the reference kallisto for it" << std::endl; ok = false; }
   if (opt.bootstrap < 0) { std::cerr << "Error: number of bootstrap samples must be a non-negative integer" << std::endl; ok = false; }
   if (!ok) { usage(); return 1; }
   struct stat st;
@@ -493,7 +496,7 @@ int main(int argc, char** argv) {
   if (opt.bootstrap > 0) KX(kamd_ec_track_order(ctx, 1));
 
   const bool paired = !opt.single;
-  kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand};
+  kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand, opt.no_jump ? 1 : 0};
   std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;

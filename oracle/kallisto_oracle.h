@@ -45,7 +45,9 @@ typedef struct {
   double sd;            /* -s */
   int single_overhang;  /* --single-overhang */
   int strand;           /* 0 = unstranded, 1 = --fr-stranded, 2 = --rf-stranded */
+  int no_jump;          /* --no-jump: every k-mer of the read is looked up (src/KmerIndex.cpp:1776) */
 } ko_opts;
+#define KO_MATCH_NO_JUMP 2   /* ko_match: bit 1 of the `partial` argument */
 
 /* Result of pseudoaligning a batch of reads: the EC multiset (in first-seen order) and the fragment
  * length histogram, i.e. what MasterProcessor::update accumulates (src/ProcessReads.cpp:424-499). */

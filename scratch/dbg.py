@@ -9,7 +9,7 @@ o = common.parse_variant(meta["variants"][variant]); exp = common.load_expected(
 index = ka.Index(idx_path); ctx = ka.Context(0); ctx.upload(index)
 reads = common.interleave(r1, r2 if o["paired"] else None)
 words, lens, max_len = ctx.pack_reads_host(reads)
-opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"])
+opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"])
 ctx.pseudoalign(opts, words, lens, len(r1), max_len)
 print(ctx.stats())
 ecs = ctx.finalize()

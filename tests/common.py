@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["ref_test_pe", "yeast_se", "human_pe", "tiny_k7_se", "dlist_pe"]
+CASES = ["ref_test_pe", "yeast_se", "human_pe", "tiny_k7_se", "dlist_pe", "mosaic_pe"]
 MAX_FRAG_LEN = 1000
 
 
@@ -31,8 +31,8 @@ def load_case(name):
 
 
 def parse_variant(extra):
-    """dump_ec / kallisto quant flags -> dict(paired, fld, sd, single_overhang, strand, boot, seed)."""
-    o = dict(paired=1, fld=0.0, sd=0.0, single_overhang=0, strand=0, boot=0, seed=42)
+    """dump_ec / kallisto quant flags -> dict(paired, fld, sd, single_overhang, strand, no_jump, boot, seed)."""
+    o = dict(paired=1, fld=0.0, sd=0.0, single_overhang=0, strand=0, no_jump=0, boot=0, seed=42)
     it = iter(extra)
     for a in it:
         if a == "--single":
@@ -47,6 +47,8 @@ def parse_variant(extra):
             o["strand"] = 1
         elif a == "--rf":
             o["strand"] = 2
+        elif a == "--no-jump":
+            o["no_jump"] = 1
         elif a == "--boot":
             o["boot"] = int(next(it))
         elif a == "--seed":

@@ -9,10 +9,10 @@
 #include <vector>
 
 // the k-mer table(s) of the host view as the per-item logic sees them (mirrors make_table of kamd_kernels.hip)
-static kamd::Table emu_table(const kamd_index_view* v, bool partial) {
+static kamd::Table emu_table(const kamd_index_view* v, bool partial, bool no_jump = false) {
   kamd::Table t{v->table, v->n_buckets};
   t.dslots = v->dtable; t.n_dbuckets = v->n_dbuckets; t.dummy_uec = v->dummy_uec; t.dummy_slot = v->dummy_slot;
-  t.dummy_strand = v->dummy_strand != 0; t.partial = partial;
+  t.dummy_strand = v->dummy_strand != 0; t.partial = partial; t.no_jump = no_jump;
   return t;
 }
 
@@ -64,7 +64,8 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
                               int32_t max_len, int use_stepper, uint32_t* out, uint64_t stride, uint64_t* probes) {
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  const Table t = emu_table(v, !paired);
+  const Table t = emu_table(v, !paired, (use_stepper & 2) != 0);   // bit 1 of use_stepper: --no-jump
+  use_stepper &= 1;
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
   uint32_t ecbuf[1024], uecbuf[1024];
@@ -110,10 +111,10 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
 // strand specificity) evaluated by kamd_core.h's keep_transcript on each member of the intersection
 extern "C" int64_t emu_pseudoalign_opts(const kamd_index_view* v, const uint32_t* words, const uint16_t* lens, uint64_t n_items,
                                         int paired, int32_t max_len, int single_overhang, int strand, int fl, int has_mean_fl,
-                                        uint64_t* out_off, uint32_t* out_ids, uint64_t cap) {
+                                        int no_jump, uint64_t* out_off, uint32_t* out_ids, uint64_t cap) {
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  const Table t = emu_table(v, !paired);
+  const Table t = emu_table(v, !paired, no_jump != 0);
   PosTables pt{v->unitig_blk_off, v->unitig_len, v->blk_unitig, v->blk_lb, v->blk_ub, v->blk_ec, v->blk_pos_off, v->blk_posw,
                v->blk_sense, v->ec_off, v->ec_ids, v->target_lens, v->k};
   std::vector<uint8_t> nonempty(v->n_ecs);

@@ -80,7 +80,7 @@ def pseudoalign(ix: EmuIndex, words, l16, n_items, paired, max_len):
     return out_off, out_ids, nh, pr.value, br.value, ts
 
 
-def pseudoalign_opts(ix: EmuIndex, words, l16, n_items, paired, max_len, single_overhang, strand, fl, has_mean_fl):
+def pseudoalign_opts(ix: EmuIndex, words, l16, n_items, paired, max_len, single_overhang, strand, fl, has_mean_fl, no_jump=0):
     L = lib()
     L.emu_pseudoalign_opts.restype = C.c_int64
     out_off = np.zeros(n_items + 1, np.uint64)
@@ -88,7 +88,7 @@ def pseudoalign_opts(ix: EmuIndex, words, l16, n_items, paired, max_len, single_
     out_ids = np.zeros(cap, np.uint32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     r = L.emu_pseudoalign_opts(C.byref(ix.view), p(words), p(l16), C.c_uint64(n_items), int(paired), C.c_int32(max_len),
-                               int(single_overhang), int(strand), int(fl), int(has_mean_fl), p(out_off), p(out_ids), C.c_uint64(cap))
+                               int(single_overhang), int(strand), int(fl), int(has_mean_fl), int(no_jump), p(out_off), p(out_ids), C.c_uint64(cap))
     if r < 0:
         raise RuntimeError(f"emu_pseudoalign_opts failed {r}")
     return out_off, out_ids

@@ -130,7 +130,7 @@ def main():
         shutil.copyfileobj(fi, fo)
     make_case("ref_test_pe", fa, read_fastq_gz(T + "reads_1.fastq.gz"), read_fastq_gz(T + "reads_2.fastq.gz"),
               {"pe": [], "pe_boot": ["--boot", "3", "--seed", "42"], "pe_l200": ["-l", "200", "-s", "20"],
-               "pe_rf": ["--rf"], "pe_fr": ["--fr"]},
+               "pe_rf": ["--rf"], "pe_fr": ["--fr"], "pe_nojump": ["--no-jump"], "pe_nojump_fr": ["--no-jump", "--fr"]},
               note="test/transcripts.fasta.gz + test/reads_{1,2}.fastq.gz of the reference repository")
     # 2. yeast-like (config #2 shape, scaled down): single-end with errors and N's
     seqs = synth.yeast_like(n_tr=300, seed=1)
@@ -139,7 +139,8 @@ def main():
     r1, _ = synth.simulate_reads(seqs, 6000, 100, paired=False, frag_mean=200, frag_sd=20, err=0.01, n_frac=0.02, seed=21)
     se = ["--single", "-l", "200", "-s", "20"]
     make_case("yeast_se", fa, list(r1), None,
-              {"se": se, "se_overhang": se + ["--single-overhang"], "se_fr": se + ["--fr"], "se_rf": se + ["--rf"]},
+              {"se": se, "se_overhang": se + ["--single-overhang"], "se_fr": se + ["--fr"], "se_rf": se + ["--rf"],
+               "se_nojump": se + ["--no-jump"], "se_nojump_rf": se + ["--no-jump", "--rf"]},
               note="synth.yeast_like(300, seed=1); simulate_reads(6000 SE-100, err 1%, 2% reads with an N, seed=21)")
     # 3. human-like (config #3 shape, scaled down): isoform families -> mosaic ECs; paired-end
     seqs = synth.human_like(n_genes=60, seed=2)
@@ -152,7 +153,7 @@ def main():
     r1[10] = r1[10][:20]; r2[11] = r2[11][:30]; r1[12] = b"N" * 100; r2[13] = r2[13].lower()
     r1[14] = r1[14][:60] + b"N" * 40; r2[15] = b"N" * 35 + r2[15][35:]; r1[16] = r1[16][:31]; r2[17] = r2[17][:75]
     make_case("human_pe", fa, r1, r2, {"pe": [], "pe_boot": ["--boot", "2", "--seed", "7"], "pe_l180": ["-l", "180", "-s", "25"],
-                                        "pe_rf": ["--rf"]},
+                                        "pe_rf": ["--rf"], "pe_nojump": ["--no-jump"]},
               note="synth.human_like(60 genes, seed=2); simulate_reads(5000 PE-100, seed=22) + ragged/degenerate reads")
     # 4. small k, very short reads (the shape of func_tests/runtests.sh): k=7
     rng = np.random.default_rng(5)
@@ -189,9 +190,47 @@ def main():
     perm = np.random.default_rng(3).permutation(len(r1))
     r1 = [r1[i] for i in perm]; r2 = [r2[i] for i in perm]
     se = ["--single", "-l", "180", "-s", "20"]
-    make_case("dlist_pe", fa, r1, r2, {"pe": [], "pe_fr": ["--fr"], "se": se, "se_rf": se + ["--rf"]}, index_args=["--d-list=" + gfa],
+    make_case("dlist_pe", fa, r1, r2, {"pe": [], "pe_fr": ["--fr"], "se": se, "se_rf": se + ["--rf"], "pe_nojump": ["--no-jump"],
+                                    "se_nojump": se + ["--no-jump"]}, index_args=["--d-list=" + gfa],
               note="synth.human_like(60 genes, seed=2) + a D-list of 80 transcript-fragment-in-random-flanks sequences and 10 random "
                    "ones; 3000 PE-100 pairs from the transcripts + 1500 from the D-list sequences, shuffled")
+    # 6. reads that switch between close paralogs every 15-45 bases: here the jumps of match() skip k-mers that a full scan
+    #    sees, so `--no-jump` changes the outcome (on the cases above it does not)
+    rng = np.random.default_rng(11)
+    fam = []
+    for _ in range(25):
+        base = synth._ACGT[rng.integers(0, 4, int(rng.integers(500, 1200)))]
+        fam.append([base])
+        for _ in range(2):
+            m = base.copy()
+            sites = rng.random(len(m)) < 0.02
+            m[sites] = synth._ACGT[(np.searchsorted(synth._ACGT, m[sites]) + rng.integers(1, 4, int(sites.sum()))) % 4]
+            fam[-1].append(m)
+    seqs = [m for f in fam for m in f]
+    fa = os.path.join(tmp, "m.fa")
+    synth.write_fasta(fa, seqs)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def mosaic(f, a, ln):
+        out = np.empty(ln, np.uint8); i = 0
+        while i < ln:
+            seg = int(rng.integers(15, 46)); mem = f[int(rng.integers(0, 3))]
+            out[i:i + seg] = mem[a + i:a + min(i + seg, ln)]; i += seg
+        return bytes(out)
+    r1, r2 = [], []
+    for _ in range(4000):
+        f = fam[int(rng.integers(0, len(fam)))]
+        fl = int(rng.integers(150, 260)); a = int(rng.integers(0, len(f[0]) - fl))
+        m1 = mosaic(f, a, 75); m2 = mosaic(f, a + fl - 75, 75).translate(comp)[::-1]
+        if rng.random() < 0.5:
+            r1.append(m1); r2.append(m2)
+        else:
+            r1.append(m2); r2.append(m1)
+    se = ["--single", "-l", "200", "-s", "25"]
+    make_case("mosaic_pe", fa, r1, r2, {"pe": [], "pe_nojump": ["--no-jump"], "se": se, "se_nojump": se + ["--no-jump"],
+                                         "pe_nojump_rf": ["--no-jump", "--rf"], "pe_rf": ["--rf"]},
+              note="25 families of 3 paralogs (2 % divergence); 4000 PE-75 pairs whose mates switch between the paralogs every 15-45 "
+                   "bases -- the case where --no-jump differs from the default")
     shutil.rmtree(tmp)
 
 

@@ -44,7 +44,7 @@ def _worker(rank, world, port, case, variant, q):
         ctx = ka.Context(0)
         ctx.upload(index)
         words, lens, max_len = ctx.pack_reads_host(common.interleave(r1[lo:hi], r2[lo:hi] if paired else None), 100)
-        opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"])
+        opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"])
         ctx.pseudoalign(opts, words, lens, hi - lo, max_len)
         # device -> host -> gloo -> device (kallisto_amd.Context.allreduce_ec_counts does the same on RCCL without the hops)
         dense = ctx.dense_counts()

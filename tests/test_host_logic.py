@@ -72,26 +72,33 @@ def test_positional_filters_match_oracle(case, variant, idx):
     meta, _, r1, r2 = common.load_case(case)
     ov = common.parse_variant(meta["variants"][variant])
     paired = bool(ov["paired"])
+    if ov["no_jump"] and ov["strand"]:
+        pytest.skip("--no-jump with a strand option (per-hit `comprehensive` filter) is rejected by the library; oracle-only")
     words, l16, max_len = E.pack(common.interleave(r1, r2 if paired else None))
     has_fl = ov["fld"] > 0
-    mean_fl = float(O.trunc_gaussian_fld(ov["fld"], ov["sd"])[-1]) if has_fl else 0.0
-    off, ids = E.pseudoalign_opts(e, words, l16, len(r1), paired, max_len, ov["single_overhang"], ov["strand"], int(mean_fl), has_fl)
-    opts = O.Opts(ov["paired"], ov["fld"], ov["sd"], ov["single_overhang"], ov["strand"])
+    mean_fl = float(ov["fld"]) if has_fl else 0.0   # the -l value itself while reads are processed (MinCollector.h:38-41)
+    off, ids = E.pseudoalign_opts(e, words, l16, len(r1), paired, max_len, ov["single_overhang"], ov["strand"], int(mean_fl), has_fl, ov["no_jump"])
+    opts = O.Opts(ov["paired"], ov["fld"], ov["sd"], ov["single_overhang"], ov["strand"], ov["no_jump"])
     for i in range(len(r1)):
         s, _, _ = o.pseudoalign(opts, r1[i], r2[i] if paired else None, mean_fl, has_fl)
         assert ids[off[i]:off[i + 1]].tolist() == s, (case, variant, i)
 
 
+@pytest.mark.parametrize("no_jump", [0, 1])
 @pytest.mark.parametrize("case", common.CASES)
-def test_resumable_state_machine_equals_match(case, idx):
-    """kernel A v2's one-probe-per-step state machine vs the straight-line match(): same sets, same probe count."""
+def test_resumable_state_machine_equals_match(case, no_jump, idx):
+    """kernel A v2's one-probe-per-step state machine vs the straight-line match(): same sets, same probe count
+    (also with --no-jump, where every k-mer is looked up: up to read_len - k + 1 hits per mate)."""
     e, _ = idx(case)
     meta, _, r1, r2 = common.load_case(case)
     paired = r2 is not None
     words, l16, max_len = E.pack(common.interleave(r1, r2))
-    a, pa = E.tuples(e, words, l16, len(r1), paired, max_len, 0)
-    b, pb = E.tuples(e, words, l16, len(r1), paired, max_len, 1)
+    a, pa = E.tuples(e, words, l16, len(r1), paired, max_len, 0 | 2 * no_jump, stride=80)
+    b, pb = E.tuples(e, words, l16, len(r1), paired, max_len, 1 | 2 * no_jump, stride=80)
     assert pa == pb and np.array_equal(a, b)
+    if no_jump and case == "mosaic_pe":
+        c, pc = E.tuples(e, words, l16, len(r1), paired, max_len, 0, stride=80)
+        assert pa > pc and not np.array_equal(a, c)   # the flag does something on this case
 
 
 def test_probe_counts_match_oracle(idx):
