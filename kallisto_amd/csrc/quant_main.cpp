@@ -598,11 +598,8 @@ int main(int argc, char** argv) {
 
   std::vector<double> mft(KAMD_MAX_FRAG_LEN);
   if (opt.fld == 0.0) {
-    if (fld_used == 0 && num_pseudoaligned > 0) {  // MinCollector::get_mean_frag_len (MinCollector.cpp:594-601)
-      std::cerr << "Error: could not determine mean fragment length from paired end reads, no pairs mapped to a unique transcript.\n"
-                << "       Run kallisto quant again with a pre-specified fragment length (option -l)." << std::endl;
-      return 1;
-    }
+    // no pair gave a fragment length: like the reference (compute_mean_frag_lens_trunc on all-zero counts, src/main.cpp:2665-2667)
+    // the means stay 0 and eff_length = length + 1; MinCollector::get_mean_frag_len's error exit is not on this path
     kamd_mean_frag_lens_trunc(flens, mft.data());
     std::cerr << "[quant] estimated average fragment length: " << mft[KAMD_MAX_FRAG_LEN - 1] << std::endl;
   } else kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, opt.fld, opt.sd, mft.data());
