@@ -283,7 +283,6 @@ __global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* _
 //                item {header, distinct (unitig,set) classes}.
 //   k_classify   one thread per item: classes -> sorted distinct transcript-set ids, then the common emit_item tail.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int STAGE_WORDS = 36;  // packed words of one item fetched ahead in registers (PE-150 = 34)
 constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
 
 template <bool PAIRED, bool FILTER, bool DL>
@@ -293,8 +292,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   constexpr int WAVES = BLOCK / 64;
   const int item_words = rec_words * (PAIRED ? 2 : 1);
-  const int lane = lane_id(), wv = threadIdx.x >> 6;
-  u32* my_words = lds + (size_t)wv * 64 * item_words + lane;  // word j at my_words[j * 64]
+  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32* wave_words = lds + (size_t)wv * 64 * item_words;       // the wavefront's items, lane-transposed
+  u32* my_words = wave_words + lane;                          // word j at my_words[j * 64]
   u32* my_list = lds + (size_t)WAVES * 64 * item_words + (size_t)threadIdx.x * TUPLE_CAP;
   u32* cursor = lds + (size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP;
   const u64 wave_global = (u64)blockIdx.x * WAVES + wv;
@@ -315,12 +315,12 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
   u32 probes = 0, breads = 0, raw_words = 0;
 
   for (;;) {
-    // 1. lanes without an item take the next one of the chunk and start fetching its packed reads into registers
-    u32 stage[STAGE_WORDS];
+    // 1. lanes without an item take the next one of the chunk and start fetching its packed reads: LDS-DMA loads
+    // (global_load_lds_dword: every active lane gives its own source address, the data lands at M0 + lane * 4 -- exactly the
+    // lane-transposed layout), no staging registers and no ds_write pass; they are in flight during the probe below
     bool loading = false;
-    const u32* src = nullptr;
     // refills are batched: the (wave-uniform) fetch path runs only when at least REFILL_MIN lanes are free or nothing is
-    // left to probe, so its ~40 load/store instructions are not paid on every iteration
+    // left to probe
     const u64 idle_mask = __ballot(!have && !exhausted);
     const bool do_refill = idle_mask != 0ULL && (__popcll(idle_mask) >= refill_min || __ballot(have) == 0ULL);
     if (do_refill && !have && !exhausted) {
@@ -330,9 +330,11 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       else {
         loading = true;
         const u64 item = chunk0 + my_idx;
-        src = words + item * item_words;
-#pragma unroll
-        for (int j = 0; j < STAGE_WORDS; j++) stage[j] = j < item_words ? src[j] : 0u;
+        const u32* src = words + item * item_words;
+#pragma unroll 4
+        for (int j = 0; j < item_words; j++)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j),
+                                           (__attribute__((address_space(3))) void*)(wave_words + (size_t)j * 64), 4, 0, 0);
         len0 = PAIRED ? (int)lens[2 * item] : (int)lens[item];
         len1 = PAIRED ? (int)lens[2 * item + 1] : 0;
       }
@@ -355,11 +357,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       }
       busy = ms.phase != kamd::PH_DONE;
     }
-    // 4. lanes that fetched an item: registers -> LDS (lane-transposed), start mate 1
+    // 4. lanes that fetched an item: its words are in LDS once the DMA loads have landed; start mate 1
     if (loading) {
-#pragma unroll
-      for (int j = 0; j < STAGE_WORDS; j++) if (j < item_words) my_words[(size_t)j * 64] = stage[j];
-      for (int j = STAGE_WORDS; j < item_words; j++) my_words[(size_t)j * 64] = src[j];  // reads longer than the staging window
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ul.n = 0; ul.overflow = false;
       mf0 = kamd::MateFirst{0, 0, -1, false}; mf1 = kamd::MateFirst{0, 0, -1, false};
       mate = 0;
@@ -1966,8 +1966,10 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   c->host_state.stream_words = cur_words + n_items * (u64)stride;
   c->host_state.n_recs = cur_recs + n_items;
   if (int rc = push_state(c)) return rc;
-  const size_t lds_bytes = ((size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP + WAVES) * sizeof(u32);
+  size_t lds_bytes = ((size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP + WAVES) * sizeof(u32);
   if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-resident kernel");
+  // diagnostics: unused LDS per block lowers the number of resident wavefronts (how sensitive is kernel A to occupancy?)
+  if (const char* e = getenv("KAMD_LDS_PAD")) lds_bytes = std::min<size_t>(160 * 1024, lds_bytes + (size_t)std::max(0, atoi(e)));
   const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
   u32* slots = c->stream_buf.as<u32>() + cur_words;
   HIPC(hipEventRecord(c->ev0, c->stream));
