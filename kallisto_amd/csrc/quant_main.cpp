@@ -29,8 +29,10 @@
 #include <vector>
 
 #include "../../include/kallisto_amd.h"
+#include "kamd_fastq.h"
 
 namespace {
+using namespace kamd_io;
 
 const char* KALLISTO_COMPAT_VERSION = "0.51.1";  // src/common.h:4
 
@@ -75,179 +77,7 @@ bool take(const std::string& a, const char* shortf, const char* longf, int& i, i
   return false;
 }
 
-// ---- FASTA/FASTQ reader over gzFile (plain or gzip), one record at a time ----
-class SeqReader {
- public:
-  explicit SeqReader(const std::string& path) : buf_(1 << 22) {
-    f_ = gzopen(path.c_str(), "r");
-    if (!f_) { std::cerr << "Error: could not open file " << path << std::endl; exit(1); }
-    gzbuffer(f_, 1 << 20);
-  }
-  ~SeqReader() { if (f_) gzclose(f_); }
-  // next sequence appended to `out`; returns false at end of file
-  bool next(std::string& out) {
-    std::string line;
-    if (!pending_header_) { do { if (!getline(line)) return false; } while (line.empty()); }
-    else { line = header_; pending_header_ = false; }
-    if (line[0] == '@') {  // FASTQ: sequence (possibly multi-line) up to '+', then as many quality chars
-      out.clear();
-      for (;;) { if (!getline(line)) return !out.empty(); if (!line.empty() && line[0] == '+') break; out += line; }
-      size_t q = 0;
-      while (q < out.size()) { if (!getline(line)) break; q += line.size(); }
-      return true;
-    }
-    if (line[0] == '>') {
-      out.clear();
-      while (getline(line)) { if (!line.empty() && (line[0] == '>' || line[0] == '@')) { header_ = line; pending_header_ = true; break; } out += line; }
-      return true;
-    }
-    std::cerr << "Error: malformed sequence file" << std::endl; exit(1);
-  }
-
- private:
-  bool getline(std::string& s) {
-    s.clear();
-    for (;;) {
-      if (pos_ == len_) { int n = gzread(f_, buf_.data(), (unsigned)buf_.size()); if (n <= 0) return !s.empty(); len_ = (size_t)n; pos_ = 0; }
-      char* b = buf_.data() + pos_;
-      char* e = (char*)memchr(b, '\n', len_ - pos_);
-      if (e) { s.append(b, e - b); pos_ = (size_t)(e - buf_.data()) + 1; if (!s.empty() && s.back() == '\r') s.pop_back(); return true; }
-      s.append(b, len_ - pos_); pos_ = len_;
-    }
-  }
-  gzFile f_ = nullptr;
-  std::vector<char> buf_;
-  size_t pos_ = 0, len_ = 0;
-  std::string header_;
-  bool pending_header_ = false;
-};
-
-// ---- gzip / FASTA input: one decompress-and-parse thread per file hands over chunks of `n` sequences, so the two mates'
-// files inflate concurrently and the main thread only pairs chunks and packs them with all host threads ----
-struct SeqChunk { std::string seqs; std::vector<uint64_t> off; std::vector<int32_t> len; };
-class ChunkReader {
- public:
-  ChunkReader(const std::string& path, uint64_t n) : r_(path), n_(n), th_([this] { loop(); }) {}
-  ~ChunkReader() { { std::lock_guard<std::mutex> g(m_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
-  // next chunk (fewer than n sequences only at the end of the file); false when the file is exhausted
-  bool next(SeqChunk& out) {
-    std::unique_lock<std::mutex> lk(m_);
-    cv_.wait(lk, [&] { return !q_.empty() || eof_; });
-    if (q_.empty()) return false;
-    out = std::move(q_.front()); q_.erase(q_.begin());
-    lk.unlock();
-    cv_.notify_all();
-    return true;
-  }
- private:
-  void loop() {
-    std::string s;
-    for (;;) {
-      SeqChunk c;
-      while (c.off.size() < n_ && r_.next(s)) {
-        if (s.size() > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; exit(1); }
-        c.off.push_back(c.seqs.size()); c.len.push_back((int32_t)s.size()); c.seqs += s;
-      }
-      const bool last = c.off.size() < n_;
-      std::unique_lock<std::mutex> lk(m_);
-      if (!c.off.empty()) {
-        cv_.wait(lk, [&] { return q_.size() < 3 || stop_; });   // at most 3 chunks ahead
-        if (stop_) return;
-        q_.push_back(std::move(c));
-      }
-      if (last) eof_ = true;
-      lk.unlock();
-      cv_.notify_all();
-      if (last) return;
-    }
-  }
-  SeqReader r_;
-  uint64_t n_;
-  std::vector<SeqChunk> q_;
-  std::mutex m_;
-  std::condition_variable cv_;
-  bool eof_ = false, stop_ = false;
-  std::thread th_;
-};
-
-// ---- fast path for plain (uncompressed) 4-line FASTQ: mmap + one parser thread per chunk --------------------------------
-// FastqSequenceReader::fetchSequences (src/ProcessReads.cpp:3128-3267) parses serially under a lock; here every thread scans
-// its slice of the file for record starts and the records are paired by index afterwards.
-struct MappedFastq {
-  const char* data = nullptr; size_t size = 0; int fd = -1;
-  std::vector<uint64_t> off; std::vector<int32_t> len;   // sequence line of every record
-  bool open(const std::string& path) {
-    fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size == 0) return false;
-    size = (size_t)st.st_size;
-    void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (p == MAP_FAILED) return false;
-    madvise(p, size, MADV_SEQUENTIAL);
-    data = (const char*)p;
-    return true;
-  }
-  void close() { if (data) munmap((void*)data, size); if (fd >= 0) ::close(fd); data = nullptr; fd = -1; }
-  static bool is_gzip(const std::string& path) {
-    unsigned char m[2] = {0, 0};
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    size_t n = fread(m, 1, 2, f); fclose(f);
-    return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
-  }
-  const char* next_line(const char* p) const { const char* e = (const char*)memchr(p, '\n', data + size - p); return e ? e + 1 : data + size; }
-  // first record start at or after p: a line starting with '@' whose third line starts with '+' and whose second and
-  // fourth lines have equal length (a quality line may itself start with '@')
-  const char* find_record(const char* p) const {
-    const char* end = data + size;
-    if (p != data) { const char* q = (const char*)memchr(p - 1, '\n', end - (p - 1)); p = q ? q + 1 : end; }
-    while (p < end) {
-      if (*p == '@') {
-        const char* l1 = next_line(p); const char* l2 = next_line(l1); const char* l3 = next_line(l2); const char* l4 = next_line(l3);
-        if (l2 < end && *l2 == '+') {
-          const int64_t seq_len = (l2 - l1) - ((l2 > l1 && l2[-1] == '\n') ? 1 : 0);
-          const int64_t qual_len = (l4 - l3) - ((l4 > l3 && l4[-1] == '\n') ? 1 : 0);
-          if (seq_len == qual_len) return p;
-        }
-      }
-      p = next_line(p);
-    }
-    return end;
-  }
-  // returns false if the file is not plain 4-line FASTQ (the caller then uses the serial reader)
-  bool index_records(int threads) {
-    if (size == 0 || data[0] != '@') return false;
-    size_t min_chunk = 1 << 20;
-    if (const char* e = getenv("KAMD_FASTQ_CHUNK")) min_chunk = std::max<size_t>(64, strtoull(e, nullptr, 10));
-    threads = std::max(1, std::min(threads, (int)(size / min_chunk) + 1));
-    std::vector<const char*> starts(threads + 1);
-    starts[0] = data; starts[threads] = data + size;
-    for (int t = 1; t < threads; t++) starts[t] = find_record(data + size / threads * t);
-    std::vector<std::vector<uint64_t>> offs(threads); std::vector<std::vector<int32_t>> lens(threads);
-    std::vector<char> ok(threads, 1);
-    std::vector<std::thread> th;
-    for (int t = 0; t < threads; t++) th.emplace_back([&, t] {
-      const char* p = starts[t]; const char* end = starts[t + 1];
-      while (p < end) {
-        if (*p != '@') { ok[t] = 0; return; }
-        const char* l1 = next_line(p); const char* l2 = next_line(l1);
-        if (l1 >= data + size || l2 > data + size || (l2 < data + size && *l2 != '+')) { ok[t] = 0; return; }
-        int64_t n = (l2 - l1) - ((l2 > l1 && l2[-1] == '\n') ? 1 : 0);
-        if (n > 0 && l1[n - 1] == '\r') --n;
-        offs[t].push_back((uint64_t)(l1 - data)); lens[t].push_back((int32_t)n);
-        p = next_line(next_line(l2));
-      }
-    });
-    for (auto& x : th) x.join();
-    size_t total = 0;
-    for (int t = 0; t < threads; t++) { if (!ok[t]) return false; total += offs[t].size(); }
-    off.reserve(total); len.reserve(total);
-    for (int t = 0; t < threads; t++) { off.insert(off.end(), offs[t].begin(), offs[t].end()); len.insert(len.end(), lens[t].begin(), lens[t].end()); }
-    return true;
-  }
-};
-
+// FASTA/FASTQ input (SeqReader, ChunkReader, MappedFastq, BgzfSource): kamd_fastq.h
 #define HIPX(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::cerr << "Error: " #x ": " << hipGetErrorString(e_) << std::endl; exit(1); } } while (0)
 #define KX(x) do { if ((x) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; exit(1); } } while (0)
 
@@ -549,8 +379,9 @@ int main(int argc, char** argv) {
       }
       m1.close(); m2.close();
     }
-    ChunkReader r1(opt.files[fi], opt.batch);
-    ChunkReader* r2 = paired ? new ChunkReader(opt.files[fi + 1], opt.batch) : nullptr;
+    const int inflate_threads = std::max(1, opt.threads / (paired ? 2 : 1) - 1);   // BGZF input: block-parallel inflate
+    ChunkReader r1(opt.files[fi], opt.batch, inflate_threads);
+    ChunkReader* r2 = paired ? new ChunkReader(opt.files[fi + 1], opt.batch, inflate_threads) : nullptr;
     SeqChunk c1, c2;
     while (r1.next(c1)) {
       if (paired && (!r2->next(c2) || c2.off.size() != c1.off.size())) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
