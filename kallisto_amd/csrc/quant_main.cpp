@@ -267,7 +267,8 @@ void write_abundance(const std::string& path, const kamd_index* idx, const kamd_
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 2 || std::string(argv[1]) != "quant") { usage(); return argc < 2 ? 1 : (std::string(argv[1]) == "version" ? (std::cout << "kallisto_amd, compatible with kallisto " << KALLISTO_COMPAT_VERSION << std::endl, 0) : 1); }
+  if (argc >= 2 && std::string(argv[1]) == "version") { std::cout << "kallisto_amd, compatible with kallisto " << KALLISTO_COMPAT_VERSION << std::endl; return 0; }
+  if (argc < 2 || std::string(argv[1]) != "quant") { usage(); return 1; }
   Options opt;
   std::string val;
   for (int i = 2; i < argc; i++) {
@@ -294,20 +295,33 @@ int main(int argc, char** argv) {
     } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage(); return 1; }
     else opt.files.push_back(a);
   }
-  // CheckOptionsEM (src/main.cpp:1600-1805)
+  // CheckOptionsEM (src/main.cpp:1600-1805): same tests, same order, same messages
   bool ok = true;
+  struct stat st;
+  std::cerr << std::endl;
   if (opt.index.empty()) { std::cerr << "Error: kallisto index file missing" << std::endl; ok = false; }
-  if (opt.output.empty()) { std::cerr << "Error: need to specify output directory " << opt.output << std::endl; ok = false; }
+  else if (stat(opt.index.c_str(), &st) != 0) { std::cerr << "Error: kallisto index file not found " << opt.index << std::endl; ok = false; }
   if (opt.files.empty()) { std::cerr << "Error: Missing read files" << std::endl; ok = false; }
+  else for (const auto& fn : opt.files) if (stat(fn.c_str(), &st) != 0) { std::cerr << "Error: file not found " << fn << std::endl; ok = false; }
   if (!opt.single && opt.files.size() % 2 != 0) { std::cerr << "Error: paired-end mode requires an even number of input files\n       (use --single for processing single-end reads)" << std::endl; ok = false; }
   if ((opt.fld != 0.0 && opt.sd == 0.0) || (opt.sd != 0.0 && opt.fld == 0.0)) { std::cerr << "Error: cannot supply mean/sd without supplying both -l and -s" << std::endl; ok = false; }
   if (opt.single && (opt.fld == 0.0 || opt.sd == 0.0)) { std::cerr << "Error: fragment length mean and sd must be supplied for single-end reads using -l and -s" << std::endl; ok = false; }
-  if (opt.fld < 0.0 || opt.sd < 0.0) { std::cerr << "Error: invalid value for mean fragment length or sd" << std::endl; ok = false; }
+  else if (opt.fld == 0.0 && ok) std::cerr << "[quant] fragment length distribution will be estimated from the data" << std::endl;
+  else if (ok && opt.fld > 0.0 && opt.sd > 0.0) std::cerr << "[quant] fragment length distribution is truncated gaussian with mean = " << opt.fld << ", sd = " << opt.sd << std::endl;
+  if (!opt.single && opt.fld > 0.0 && opt.sd > 0.0) {
+    std::cerr << "[~warn] you specified using a gaussian but have paired end data" << std::endl;
+    std::cerr << "[~warn] we suggest omitting these parameters and let us estimate the distribution from data" << std::endl;
+  }
+  if (opt.fld < 0.0) { std::cerr << "Error: invalid value for mean fragment length " << opt.fld << std::endl; ok = false; }
+  if (opt.sd < 0.0) { std::cerr << "Error: invalid value for fragment length standard deviation " << opt.sd << std::endl; ok = false; }
   if (opt.no_jump && opt.strand) { std::cerr << "Error: --no-jump together with --fr-stranded/--rf-stranded is outside the GPU quant path; use the reference kallisto for it" << std::endl; ok = false; }
-  if (opt.bootstrap < 0) { std::cerr << "Error: number of bootstrap samples must be a non-negative integer" << std::endl; ok = false; }
-  if (!ok) { usage(); return 1; }
-  struct stat st;
-  if (stat(opt.output.c_str(), &st) != 0) { if (mkdir(opt.output.c_str(), 0777) != 0) { std::cerr << "Error: could not create directory " << opt.output << std::endl; return 1; } }
+  if (opt.output.empty()) { std::cerr << "Error: need to specify output directory " << opt.output << std::endl; ok = false; }
+  else if (stat(opt.output.c_str(), &st) == 0) {
+    if (!S_ISDIR(st.st_mode)) { std::cerr << "Error: file " << opt.output << " exists and is not a directory" << std::endl; ok = false; }
+  } else if (mkdir(opt.output.c_str(), 0777) == -1) { std::cerr << "Error: could not create directory " << opt.output << std::endl; ok = false; }
+  if (opt.threads <= 0) { std::cerr << "Error: invalid number of threads " << opt.threads << std::endl; ok = false; }
+  if (opt.bootstrap < 0) { std::cerr << "Error: number of bootstrap samples must be a non-negative integer." << std::endl; ok = false; }
+  if (!ok) { std::cerr << std::endl; usage(); return 1; }
   std::time_t tt = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
   std::string start_time = std::ctime(&tt);
   if (!start_time.empty() && start_time.back() == '\n') start_time.pop_back();

@@ -1,0 +1,67 @@
+"""Option checking of the front-end (CheckOptionsEM, src/main.cpp:1600-1805) -- runs without a GPU because every check
+happens before the device is touched.  Where the reference binary built by oracle/Makefile is present (the build
+container), its messages for the same command line are the expectation; the literal expectations below are what it
+printed when this test was written."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
+REF = os.path.join(ROOT, "oracle", "_ref", "kallisto")
+IDX = os.path.join(ROOT, "tests", "golden", "ref_test_pe", "index.idx")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(EXE), reason="front-end not built (make -C kallisto_amd/csrc all)")
+
+
+def _errors(exe, args, cwd):
+    p = subprocess.run([exe, "quant", *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = [l for l in p.stderr.decode().split("\n") if l.startswith("Error:") or l.startswith("       (use")]
+    return p.returncode, lines
+
+
+CASES = [
+    (["-o", "o", "a.fq", "b.fq"], ["Error: kallisto index file missing"]),
+    (["-i", "/nonexistent.idx", "-o", "o", "a.fq", "b.fq"], ["Error: kallisto index file not found /nonexistent.idx"]),
+    (["-i", IDX, "a.fq", "b.fq"], ["Error: need to specify output directory "]),
+    (["-i", IDX, "-o", "o"], ["Error: Missing read files"]),
+    (["-i", IDX, "-o", "o", "a.fq", "missing.fq"], ["Error: file not found missing.fq"]),
+    (["-i", IDX, "-o", "o", "a.fq"], ["Error: paired-end mode requires an even number of input files",
+                                     "       (use --single for processing single-end reads)"]),
+    (["-i", IDX, "-o", "o", "--single", "a.fq"],
+     ["Error: fragment length mean and sd must be supplied for single-end reads using -l and -s"]),
+    (["-i", IDX, "-o", "o", "-l", "200", "a.fq", "b.fq"], ["Error: cannot supply mean/sd without supplying both -l and -s"]),
+    (["-i", IDX, "-o", "o", "-l", "-5", "-s", "2", "a.fq", "b.fq"], ["Error: invalid value for mean fragment length -5"]),
+    (["-i", IDX, "-o", "o", "-l", "5", "-s", "-2", "a.fq", "b.fq"], ["Error: invalid value for fragment length standard deviation -2"]),
+    (["-i", IDX, "-o", "o", "-b", "-3", "a.fq", "b.fq"], ["Error: number of bootstrap samples must be a non-negative integer."]),
+    (["-i", IDX, "-o", "a.fq", "a.fq", "b.fq"], ["Error: file a.fq exists and is not a directory"]),
+    (["-i", IDX, "-o", "o", "-t", "0", "a.fq", "b.fq"], ["Error: invalid number of threads 0"]),
+    (["-o", "o", "-l", "3", "a.fq"], ["Error: kallisto index file missing", "Error: paired-end mode requires an even number of input files",
+                                      "       (use --single for processing single-end reads)",
+                                      "Error: cannot supply mean/sd without supplying both -l and -s"]),
+]
+
+
+@pytest.mark.parametrize("args,expected", CASES)
+def test_option_errors_match_the_reference(args, expected, tmp_path):
+    for f in ("a.fq", "b.fq"):
+        open(tmp_path / f, "w").close()
+    rc, got = _errors(EXE, args, str(tmp_path))
+    assert rc == 1 and got == expected
+    if os.path.exists(REF):
+        rrc, ref = _errors(REF, args, str(tmp_path))
+        assert rrc == 1 and ref == expected, "the reference binary prints something else now"
+
+
+@pytest.mark.parametrize("args", [["--union"], ["--bias"], ["--pseudobam"], ["--fusion"], ["--long"], ["--no-jump", "--fr-stranded"]])
+def test_options_outside_the_gpu_path_are_refused(args, tmp_path):
+    for f in ("a.fq", "b.fq"):
+        open(tmp_path / f, "w").close()
+    rc, got = _errors(EXE, ["-i", IDX, "-o", "o", *args, "a.fq", "b.fq"], str(tmp_path))
+    assert rc == 1 and len(got) == 1 and "outside the GPU quant path" in got[0]
+
+
+def test_version():
+    p = subprocess.run([EXE, "version"], stdout=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout.decode().strip() == "kallisto_amd, compatible with kallisto 0.51.1"
