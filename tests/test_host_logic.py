@@ -168,3 +168,21 @@ def test_product_does_not_touch_the_oracle():
                 txt = open(os.path.join(d, f)).read()
                 assert "oracle" not in txt.lower().replace("oracle/_ref/kallisto", "").replace("oracle ref", "") or f in ("synth.py",), \
                     f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("case", ["ref_test_pe", "dlist_pe"])
+def test_index_loader_refuses_damaged_files(case, tmp_path):
+    """kamd_index_load on a truncated index returns an error (with a message) instead of reading past the end; the
+    reference exits from inside Bifrost on such files."""
+    data = open(common.load_case(case)[1], "rb").read()
+    L = E.lib()
+    rng = np.random.default_rng(3)
+    cuts = [0, 1, 7, 8, 16, 24, 40, 100, 1000, len(data) - 8, len(data) - 1] + [int(x) for x in rng.integers(0, len(data), 12)]
+    for c in sorted(set(cuts)):
+        p = str(tmp_path / "t.idx")
+        open(p, "wb").write(data[:c])
+        h = C.c_void_p()
+        rc = L.kamd_index_load(p.encode(), 2, C.byref(h))
+        assert rc != 0 and L.kamd_last_error(), c
+    h = C.c_void_p()
+    assert L.kamd_index_load(str(tmp_path / "missing.idx").encode(), 2, C.byref(h)) != 0
