@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -162,6 +164,16 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   }
   Cursor c{buf.data(), buf.size()};
   std::unique_ptr<kamd_index> ix(new kamd_index);
+  // KAMD_INDEX_TIMING=1: seconds per phase on stderr
+  const bool timing = getenv("KAMD_INDEX_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[index] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
+  tick("read file");
 
   // 1. version (KmerIndex.cpp:1351-1360)
   if (c.get<uint64_t>() != 13) return kamd::fail(-3, "incompatible index: expected version 13");
@@ -213,6 +225,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     head_of.emplace(v, (uint32_t)i);
     head_of.emplace(kamd::revcomp_msb(v, k), (uint32_t)i);
   }
+  tick("unitigs + head map");
   // skip minimizer index + BooPHF (KmerIndex.cpp:1368-1376)
   c.pos = pos1 + dbg_bytes;
   { uint64_t mphf = c.get<uint64_t>(); c.take(mphf); }
@@ -276,6 +289,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     std::stable_sort(bl.begin(), bl.end(), [](const RawBlock& a, const RawBlock& b) { return a.lb < b.lb; });
     if (c.bad || c.pos != node_end) return kamd::fail(-3, "index: node size mismatch");
   }
+  tick("node records");
   // flatten blocks; assign (unitig, set) classes
   ix->unitig_blk_off.assign(ix->n_unitigs + 1, 0);
   for (uint64_t u = 0; u < ix->n_unitigs; u++) {
@@ -300,6 +314,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   ix->blk_pos_off.push_back(ix->blk_posw.size());
   if (ix->uec_ec.size() >= kamd::NO_UEC) return kamd::fail(-3, "index: too many (unitig, set) classes");
 
+  tick("flatten blocks");
   // 4-6. targets (KmerIndex.cpp:1470-1519)
   int32_t nt = c.get<int32_t>();
   if (c.bad || nt < 0) return kamd::fail(-3, "index: bad target count");
@@ -328,6 +343,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   }
   if (c.bad) return kamd::fail(-3, "index: truncated file");
 
+  tick("targets + on-list");
   // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
   const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers + 1) / 2);  // load factor 0.5 over 4-slot buckets
   ix->n_buckets = nb;
@@ -356,6 +372,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     auto count = [&](uint32_t, uint64_t v) { bool f; uint64_t cn = canon_of(v, &f); fill_atomic[kamd::home_bucket(cn, nb)].fetch_add(1, std::memory_order_relaxed); };
     if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, count); else count(0, single_kmer(u));
   });
+  tick("table: count pass");
   // placement: keys grouped by home bucket are laid down sequentially, never before their home (Robin Hood order)
   std::vector<uint64_t> base(nb);
   uint64_t cursor = 0;
@@ -376,6 +393,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   ix->slot_block.assign(total_buckets * 4, 0xFFFFFFFFu);
   ix->slot_dist.assign(total_buckets * 4, 0);
   std::fill(fill.begin(), fill.end(), 0);
+  tick("table: layout + allocation");
   run_parallel([&](uint64_t u) {
     uint64_t b0 = ix->unitig_blk_off[u], b1 = ix->unitig_blk_off[u + 1];
     uint64_t cur = b0;
@@ -395,6 +413,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, place); else place(0, single_kmer(u));
   });
   for (uint64_t b = 0; b < total_buckets; b++) if (cont_all[b]) ix->table[8 * b] |= kamd::KEY_CONT;
+  tick("table: place pass");
   // ---- D-list table (same bucket layout, built serially: it is small) and the dummy hit ----
   if (ix->dlist_size) {
     const uint64_t nd = ix->dlist_size, ndb = std::max<uint64_t>(16, (nd + 1) / 2);
