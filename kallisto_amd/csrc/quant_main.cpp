@@ -175,10 +175,14 @@ class H5Out {
 #undef KAMD_H5SYM
     if (H5open() < 0) return false;
     hid_t* g = nullptr;
-    if (!(g = (hid_t*)dlsym(lib_, "H5T_NATIVE_INT_g"))) return false; t_int_ = *g;
-    if (!(g = (hid_t*)dlsym(lib_, "H5T_NATIVE_DOUBLE_g"))) return false; t_double_ = *g;
-    if (!(g = (hid_t*)dlsym(lib_, "H5T_C_S1_g"))) return false; t_c_s1_ = *g;
-    if (!(g = (hid_t*)dlsym(lib_, "H5P_CLS_DATASET_CREATE_ID_g"))) return false; p_dcreate_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5T_NATIVE_INT_g"))) return false;
+    t_int_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5T_NATIVE_DOUBLE_g"))) return false;
+    t_double_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5T_C_S1_g"))) return false;
+    t_c_s1_ = *g;
+    if (!(g = (hid_t*)dlsym(lib_, "H5P_CLS_DATASET_CREATE_ID_g"))) return false;
+    p_dcreate_ = *g;
     return true;
   }
   bool open(const std::string& path, bool with_bootstrap) {
