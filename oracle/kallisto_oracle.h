@@ -46,6 +46,7 @@ typedef struct {
   int single_overhang;  /* --single-overhang */
   int strand;           /* 0 = unstranded, 1 = --fr-stranded, 2 = --rf-stranded */
   int no_jump;          /* --no-jump: every k-mer of the read is looked up (src/KmerIndex.cpp:1776) */
+  int do_union;         /* --union: per mate the union instead of the intersection of the hits' sets (src/MinCollector.cpp:163-169) */
 } ko_opts;
 #define KO_MATCH_NO_JUMP 2   /* ko_match: bit 1 of the `partial` argument */
 

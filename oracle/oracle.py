@@ -33,7 +33,7 @@ class Hit(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("paired", C.c_int), ("fld", C.c_double), ("sd", C.c_double), ("single_overhang", C.c_int),
-                ("strand", C.c_int), ("no_jump", C.c_int)]
+                ("strand", C.c_int), ("no_jump", C.c_int), ("do_union", C.c_int)]
 
 
 _lib = None

@@ -57,6 +57,7 @@ static int run_quant(int argc, char** argv) {
     else if (a == "--rf") { opt.strand_specific = true; opt.strand = ProgramOptions::StrandType::RF; }
     else if (a == "--single-overhang") opt.single_overhang = true;
     else if (a == "--no-jump") opt.no_jump = true;
+    else if (a == "--union") opt.do_union = true;
     else if (a == "--boot") boot = atoi(argv[++i]);
     else if (a == "--seed") opt.seed = strtoull(argv[++i], nullptr, 10);
     else opt.files.push_back(a);

@@ -32,7 +32,7 @@ def load_case(name):
 
 def parse_variant(extra):
     """dump_ec / kallisto quant flags -> dict(paired, fld, sd, single_overhang, strand, no_jump, boot, seed)."""
-    o = dict(paired=1, fld=0.0, sd=0.0, single_overhang=0, strand=0, no_jump=0, boot=0, seed=42)
+    o = dict(paired=1, fld=0.0, sd=0.0, single_overhang=0, strand=0, no_jump=0, union=0, boot=0, seed=42)
     it = iter(extra)
     for a in it:
         if a == "--single":
@@ -49,6 +49,8 @@ def parse_variant(extra):
             o["strand"] = 2
         elif a == "--no-jump":
             o["no_jump"] = 1
+        elif a == "--union":
+            o["union"] = 1
         elif a == "--boot":
             o["boot"] = int(next(it))
         elif a == "--seed":

@@ -130,7 +130,8 @@ def main():
         shutil.copyfileobj(fi, fo)
     make_case("ref_test_pe", fa, read_fastq_gz(T + "reads_1.fastq.gz"), read_fastq_gz(T + "reads_2.fastq.gz"),
               {"pe": [], "pe_boot": ["--boot", "3", "--seed", "42"], "pe_l200": ["-l", "200", "-s", "20"],
-               "pe_rf": ["--rf"], "pe_fr": ["--fr"], "pe_nojump": ["--no-jump"], "pe_nojump_fr": ["--no-jump", "--fr"]},
+               "pe_rf": ["--rf"], "pe_fr": ["--fr"], "pe_nojump": ["--no-jump"], "pe_nojump_fr": ["--no-jump", "--fr"],
+               "pe_union": ["--union"]},
               note="test/transcripts.fasta.gz + test/reads_{1,2}.fastq.gz of the reference repository")
     # 2. yeast-like (config #2 shape, scaled down): single-end with errors and N's
     seqs = synth.yeast_like(n_tr=300, seed=1)
@@ -153,7 +154,7 @@ def main():
     r1[10] = r1[10][:20]; r2[11] = r2[11][:30]; r1[12] = b"N" * 100; r2[13] = r2[13].lower()
     r1[14] = r1[14][:60] + b"N" * 40; r2[15] = b"N" * 35 + r2[15][35:]; r1[16] = r1[16][:31]; r2[17] = r2[17][:75]
     make_case("human_pe", fa, r1, r2, {"pe": [], "pe_boot": ["--boot", "2", "--seed", "7"], "pe_l180": ["-l", "180", "-s", "25"],
-                                        "pe_rf": ["--rf"], "pe_nojump": ["--no-jump"]},
+                                        "pe_rf": ["--rf"], "pe_nojump": ["--no-jump"], "pe_union": ["--union"]},
               note="synth.human_like(60 genes, seed=2); simulate_reads(5000 PE-100, seed=22) + ragged/degenerate reads")
     # 4. small k, very short reads (the shape of func_tests/runtests.sh): k=7
     rng = np.random.default_rng(5)
@@ -191,7 +192,7 @@ def main():
     r1 = [r1[i] for i in perm]; r2 = [r2[i] for i in perm]
     se = ["--single", "-l", "180", "-s", "20"]
     make_case("dlist_pe", fa, r1, r2, {"pe": [], "pe_fr": ["--fr"], "se": se, "se_rf": se + ["--rf"], "pe_nojump": ["--no-jump"],
-                                    "se_nojump": se + ["--no-jump"]}, index_args=["--d-list=" + gfa],
+                                    "se_nojump": se + ["--no-jump"], "pe_union": ["--union"]}, index_args=["--d-list=" + gfa],
               note="synth.human_like(60 genes, seed=2) + a D-list of 80 transcript-fragment-in-random-flanks sequences and 10 random "
                    "ones; 3000 PE-100 pairs from the transcripts + 1500 from the D-list sequences, shuffled")
     # 6. reads that switch between close paralogs every 15-45 bases: here the jumps of match() skip k-mers that a full scan
@@ -228,9 +229,12 @@ def main():
             r1.append(m2); r2.append(m1)
     se = ["--single", "-l", "200", "-s", "25"]
     make_case("mosaic_pe", fa, r1, r2, {"pe": [], "pe_nojump": ["--no-jump"], "se": se, "se_nojump": se + ["--no-jump"],
-                                         "pe_nojump_rf": ["--no-jump", "--rf"], "pe_rf": ["--rf"]},
+                                         "pe_nojump_rf": ["--no-jump", "--rf"], "pe_rf": ["--rf"], "pe_union": ["--union"],
+                                         "se_union_overhang": se + ["--single-overhang", "--union"], "pe_union_fr": ["--union", "--fr"]},
               note="25 families of 3 paralogs (2 % divergence); 4000 PE-75 pairs whose mates switch between the paralogs every 15-45 "
-                   "bases -- the case where --no-jump differs from the default")
+                   "bases -- the case where --no-jump differs from the default.  (--single --union without --single-overhang is "
+                   "not a variant: the reference itself dies there with 'Index not present in SparseVector' -- the union holds "
+                   "transcripts that the first mapping k-mer's set does not, and findPosition looks them up in it.)")
     shutil.rmtree(tmp)
 
 

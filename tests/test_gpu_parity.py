@@ -43,6 +43,8 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
     assert np.array_equal(index.target_lens, exp["lens"])
     reads = common.interleave(r1, r2 if o["paired"] else None)
     words, lens, max_len = ctx.pack_reads_host(reads)
+    if o["union"]:
+        pytest.skip("--union is oracle-only so far; the front-end refuses the flag (tests/test_cli_options.py)")
     opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"])
     if o["no_jump"] and o["strand"]:
         # the reference then applies the strand filter once per hit (`comprehensive`, ProcessReads.cpp:62-82): outside the GPU

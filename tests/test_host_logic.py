@@ -72,6 +72,8 @@ def test_positional_filters_match_oracle(case, variant, idx):
     meta, _, r1, r2 = common.load_case(case)
     ov = common.parse_variant(meta["variants"][variant])
     paired = bool(ov["paired"])
+    if ov["union"]:
+        pytest.skip("--union is oracle-only so far (tests/test_oracle_golden.py pins the restatement on the reference)")
     if ov["no_jump"] and ov["strand"]:
         pytest.skip("--no-jump with a strand option (per-hit `comprehensive` filter) is rejected by the library; oracle-only")
     words, l16, max_len = E.pack(common.interleave(r1, r2 if paired else None))

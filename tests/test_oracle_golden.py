@@ -26,7 +26,7 @@ def test_oracle_matches_reference(case, variant, indices):
     assert ix.k == meta["k"]
     assert np.array_equal(ix.target_lens, exp["lens"])
     buf, off, lens = O.pack_reads(common.interleave(r1, r2 if o["paired"] else None))
-    res = O.process_reads(ix, O.Opts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"]), buf, off, lens)
+    res = O.process_reads(ix, O.Opts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"]), buf, off, lens)
     assert res.n_processed == exp["nproc"]
     assert res.multiset() == exp["ecs"]                       # bit-exact EC counts
     assert np.array_equal(res.flens, exp["flens"])            # fragment length sample
