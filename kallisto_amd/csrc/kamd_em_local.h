@@ -1,0 +1,312 @@
+// kamd_em_local.h -- component-local EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223), NOT WIRED INTO kamd_em_run YET.
+//
+// The EC x transcript matrix is block diagonal over the connected components of the transcript/EC graph (gene families)
+// and the EM update never couples two components.  Components are therefore packed into GROUPS small enough for one
+// workgroup's LDS (local 16-bit indices in both directions) and a group iterates on its own: row pass, barrier, column
+// pass, barrier -- no kernel boundary and no global memory traffic per round (the streamed form of kamd_kernels.hip pays
+// two kernel boundaries and two dependent global round trips per round: 25.5 us).
+// Only the stop rule "chcount == 0 && i > min_rounds" (:202-205) is global.  It is handled like kamd_em_run_partitioned
+// does across ranks: a chunk of rounds runs speculatively from a checkpoint while every group adds its per-round change
+// count to a history, the first qualifying round is found, the chunk is replayed up to it, then the clamped final round.
+//
+// This header holds what can be checked without a GPU (tests/emu, tests/test_em_local.py against the oracle):
+//   * the plan (groups, local CSR in both directions) and a host reference builder for it,
+//   * the per-group round as host/device functions written for thread-strided execution,
+//   * the chunk / history / replay driver, templated on a backend (here: the serial CPU backend).
+// The device side (set-up kernels that build the same plan in HBM, the LDS-resident kernel that calls the same round
+// functions) is the next round's work; the plan built there can be validated against build_plan_host().
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#ifndef KAMD_HD
+#if defined(__HIPCC__)
+#define KAMD_HD __host__ __device__ __forceinline__
+#else
+#define KAMD_HD inline
+#endif
+#endif
+
+namespace kamd_em_local {
+
+// one group of components, as the round functions see it (pointers into the plan's arrays, or into LDS copies of them)
+struct Group {
+  uint32_t n_rows, n_tr;
+  const uint32_t* row_ptr;   // [n_rows + 1] offsets into row_tr, relative to the group's first entry
+  const uint16_t* row_tr;    // local transcript index of every entry, row by row
+  const uint32_t* col_ptr;   // [n_tr + 1] offsets into col_row, relative to the group's first entry
+  const uint16_t* col_row;   // local row index of every entry, transcript by transcript
+  const uint64_t* cw;        // [n_rows] count | weight count << 32
+  const double* single;      // [n_tr] count of the transcript's singleton set (0: none), :119-123
+  const double* eff;         // [n_tr] effective length
+};
+
+// LDS bytes a group needs in the kernel: both index directions (u16), both offset arrays, g + cw per row,
+// alpha / a (current and next) + single + eff per transcript
+KAMD_HD uint64_t group_bytes(uint64_t nnz, uint64_t rows, uint64_t tr) {
+  return nnz * 4 + (rows + 1) * 4 + (tr + 1) * 4 + rows * 16 + tr * 48;
+}
+
+// row pass of one round: g_e = count_e / S_e, S_e = sum of a_t over the row (a_t = alpha_t / eff_t; in the final round
+// alpha < alpha_limit / 10 reads as 0, :217-219); rows the reference skips get 0 (count 0, :133-135; denom below
+// denorm_min, :156-158).  Thread `tid` of `nthr` takes rows tid, tid + nthr, ...
+KAMD_HD void rows_pass(const Group& G, uint32_t tid, uint32_t nthr, const double* alpha, const double* a, int clamp, double* g) {
+  for (uint32_t r = tid; r < G.n_rows; r += nthr) {
+    double S = 0.0;
+    for (uint32_t j = G.row_ptr[r]; j < G.row_ptr[r + 1]; j++) {
+      const uint32_t t = G.row_tr[j];
+      S += (clamp && alpha[t] < 1e-7 / 10.0) ? 0.0 : a[t];
+    }
+    const uint64_t w = G.cw[r];
+    const uint32_t cnt = (uint32_t)w, wc = (uint32_t)(w >> 32);
+    g[r] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+  }
+}
+// column pass: next_t = single_t + a_t * sum of g_e over the transcript's rows; returns this thread's share of the round's
+// change count (:176-199)
+KAMD_HD int cols_pass(const Group& G, uint32_t tid, uint32_t nthr, const double* alpha, const double* a, int clamp, const double* g,
+                      double* alpha_nx, double* a_nx) {
+  int ch = 0;
+  for (uint32_t t = tid; t < G.n_tr; t += nthr) {
+    double acc = 0.0;
+    for (uint32_t j = G.col_ptr[t]; j < G.col_ptr[t + 1]; j++) acc += g[G.col_row[j]];
+    const bool z = clamp && alpha[t] < 1e-7 / 10.0;
+    const double al = z ? 0.0 : alpha[t], at = z ? 0.0 : a[t];
+    const double nx = G.single[t] + at * acc;
+    if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ++ch;
+    alpha_nx[t] = nx;
+    a_nx[t] = nx / G.eff[t];
+  }
+  return ch;
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// ---- the plan: groups in HBM (here: host vectors) --------------------------------------------------------------------
+struct Plan {
+  uint32_t n_groups = 0;
+  uint64_t T = 0;
+  std::vector<uint32_t> row_base, tr_base;   // [n_groups + 1] first row / first (m-space) transcript of a group
+  std::vector<uint64_t> nz_base;             // [n_groups + 1] first entry of a group (same in both directions)
+  std::vector<uint32_t> row_ptr;             // per group n_rows + 1 entries, concatenated: at row_base[g] + g
+  std::vector<uint16_t> row_tr;              // [NZ]
+  std::vector<uint32_t> col_ptr;             // per group n_tr + 1 entries, concatenated: at tr_base[g] + g
+  std::vector<uint16_t> col_row;             // [NZ]
+  std::vector<uint64_t> cw;                  // [R]
+  std::vector<double> single, eff;           // [M]
+  std::vector<uint32_t> tr_id;               // [M] transcript id of an m-space slot
+  std::vector<double> single_all;            // [T] singleton-set count of every transcript (what transcripts outside m-space keep)
+  uint64_t max_group_bytes = 0;
+  Group group(uint32_t g) const {
+    Group G;
+    G.n_rows = row_base[g + 1] - row_base[g]; G.n_tr = tr_base[g + 1] - tr_base[g];
+    G.row_ptr = row_ptr.data() + row_base[g] + g; G.row_tr = row_tr.data() + nz_base[g];
+    G.col_ptr = col_ptr.data() + tr_base[g] + g; G.col_row = col_row.data() + nz_base[g];
+    G.cw = cw.data() + row_base[g]; G.single = single.data() + tr_base[g]; G.eff = eff.data() + tr_base[g];
+    return G;
+  }
+};
+
+// Host reference builder.  Rows with one transcript are folded into `single` (a transcript has at most one singleton set);
+// rows with >= 2 transcripts and the transcripts that occur in them make up the groups.  Components are taken in the order
+// of their smallest transcript id (genes are contiguous in transcript space) and packed greedily: a group is closed when
+// the next component would push it over `budget_bytes` or over `target_nnz`.
+// Returns 0 = ok, 1 = not applicable (a single component exceeds the budget or the 16-bit local index range).
+inline int build_plan_host(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, const uint32_t* wcounts, uint64_t n_ecs,
+                           const double* eff, uint64_t T, uint64_t budget_bytes, uint64_t target_nnz, Plan* P) {
+  std::vector<uint32_t> parent(T);
+  std::iota(parent.begin(), parent.end(), 0u);
+  auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+  P->T = T;
+  P->single_all.assign(T, 0.0);
+  std::vector<uint8_t> in_multi(T, 0);
+  for (uint64_t e = 0; e < n_ecs; e++) {
+    const uint64_t a = ec_off[e], b = ec_off[e + 1];
+    if (b - a == 1) { P->single_all[ec_ids[a]] = (double)counts[e]; continue; }
+    if (b - a < 2) continue;
+    uint32_t r0 = find(ec_ids[a]);
+    in_multi[ec_ids[a]] = 1;
+    for (uint64_t j = a + 1; j < b; j++) {
+      in_multi[ec_ids[j]] = 1;
+      uint32_t r1 = find(ec_ids[j]);
+      if (r1 != r0) { if (r1 < r0) std::swap(r0, r1); parent[r1] = r0; }   // the root is the smallest id of the component
+    }
+  }
+  // per component: entries, rows, transcripts
+  std::vector<uint64_t> c_nnz(T, 0);
+  std::vector<uint32_t> c_rows(T, 0), c_tr(T, 0);
+  for (uint64_t e = 0; e < n_ecs; e++) {
+    const uint64_t a = ec_off[e], b = ec_off[e + 1];
+    if (b - a < 2) continue;
+    const uint32_t r = find(ec_ids[a]);
+    c_nnz[r] += b - a; c_rows[r] += 1;
+  }
+  for (uint64_t t = 0; t < T; t++) if (in_multi[t]) c_tr[find((uint32_t)t)] += 1;
+  // groups
+  std::vector<uint32_t> group_of(T, 0xFFFFFFFFu);   // by root
+  uint32_t ng = 0;
+  uint64_t g_nnz = 0, g_rows = 0, g_tr = 0;
+  bool open = false;
+  P->max_group_bytes = 0;
+  for (uint64_t r = 0; r < T; r++) {
+    if (c_rows[r] == 0) continue;
+    if (c_rows[r] > 65535 || c_tr[r] > 65535 || group_bytes(c_nnz[r], c_rows[r], c_tr[r]) > budget_bytes) return 1;
+    if (open && (group_bytes(g_nnz + c_nnz[r], g_rows + c_rows[r], g_tr + c_tr[r]) > budget_bytes || g_nnz + c_nnz[r] > target_nnz ||
+                 g_rows + c_rows[r] > 65535 || g_tr + c_tr[r] > 65535)) {
+      P->max_group_bytes = std::max(P->max_group_bytes, group_bytes(g_nnz, g_rows, g_tr));
+      ++ng; g_nnz = g_rows = g_tr = 0;
+    }
+    open = true;
+    group_of[r] = ng;
+    g_nnz += c_nnz[r]; g_rows += c_rows[r]; g_tr += c_tr[r];
+  }
+  if (open) { P->max_group_bytes = std::max(P->max_group_bytes, group_bytes(g_nnz, g_rows, g_tr)); ++ng; }
+  P->n_groups = ng;
+  // counting sort of rows and transcripts by group
+  P->row_base.assign(ng + 1, 0); P->tr_base.assign(ng + 1, 0); P->nz_base.assign(ng + 1, 0);
+  for (uint64_t e = 0; e < n_ecs; e++) {
+    const uint64_t a = ec_off[e], b = ec_off[e + 1];
+    if (b - a < 2) continue;
+    const uint32_t g = group_of[find(ec_ids[a])];
+    P->row_base[g + 1] += 1; P->nz_base[g + 1] += b - a;
+  }
+  for (uint64_t t = 0; t < T; t++) if (in_multi[t]) P->tr_base[group_of[find((uint32_t)t)] + 1] += 1;
+  for (uint32_t g = 0; g < ng; g++) { P->row_base[g + 1] += P->row_base[g]; P->tr_base[g + 1] += P->tr_base[g]; P->nz_base[g + 1] += P->nz_base[g]; }
+  const uint64_t R = P->row_base[ng], M = P->tr_base[ng], NZ = P->nz_base[ng];
+  std::vector<uint32_t> local_of(T, 0);     // m-space slot of a transcript, relative to its group
+  P->tr_id.assign(M, 0); P->single.assign(M, 0.0); P->eff.assign(M, 0.0);
+  {
+    std::vector<uint32_t> fill(ng, 0);
+    for (uint64_t t = 0; t < T; t++) {
+      if (!in_multi[t]) continue;
+      const uint32_t g = group_of[find((uint32_t)t)];
+      const uint32_t l = fill[g]++;
+      local_of[t] = l;
+      const uint64_t m = P->tr_base[g] + l;
+      P->tr_id[m] = (uint32_t)t; P->single[m] = P->single_all[t]; P->eff[m] = eff[t];
+    }
+  }
+  P->cw.assign(R, 0); P->row_ptr.assign(R + ng, 0); P->row_tr.assign(NZ, 0);
+  P->col_ptr.assign(M + ng, 0); P->col_row.assign(NZ, 0);
+  std::vector<uint32_t> row_local(n_ecs, 0);
+  {
+    std::vector<uint32_t> rfill(ng, 0);
+    std::vector<uint64_t> zfill(ng, 0);
+    for (uint64_t e = 0; e < n_ecs; e++) {
+      const uint64_t a = ec_off[e], b = ec_off[e + 1];
+      if (b - a < 2) continue;
+      const uint32_t g = group_of[find(ec_ids[a])];
+      const uint32_t r = rfill[g]++;
+      row_local[e] = r;
+      P->cw[P->row_base[g] + r] = (uint64_t)counts[e] | ((uint64_t)(wcounts ? wcounts[e] : counts[e]) << 32);
+      uint32_t* rp = P->row_ptr.data() + P->row_base[g] + g;
+      rp[r] = (uint32_t)zfill[g];
+      for (uint64_t j = a; j < b; j++) P->row_tr[P->nz_base[g] + zfill[g]++] = (uint16_t)local_of[ec_ids[j]];
+      rp[r + 1] = (uint32_t)zfill[g];
+    }
+  }
+  // transposed direction: count, scan, fill (rows in group order, so a column's rows are ascending)
+  for (uint64_t e = 0; e < n_ecs; e++) {
+    const uint64_t a = ec_off[e], b = ec_off[e + 1];
+    if (b - a < 2) continue;
+    const uint32_t g = group_of[find(ec_ids[a])];
+    uint32_t* cp = P->col_ptr.data() + P->tr_base[g] + g;
+    for (uint64_t j = a; j < b; j++) cp[local_of[ec_ids[j]] + 1] += 1;
+  }
+  for (uint32_t g = 0; g < ng; g++) {
+    uint32_t* cp = P->col_ptr.data() + P->tr_base[g] + g;
+    const uint32_t nt = P->tr_base[g + 1] - P->tr_base[g];
+    for (uint32_t t = 0; t < nt; t++) cp[t + 1] += cp[t];
+  }
+  {
+    std::vector<uint32_t> cfill(M, 0);
+    for (uint64_t e = 0; e < n_ecs; e++) {
+      const uint64_t a = ec_off[e], b = ec_off[e + 1];
+      if (b - a < 2) continue;
+      const uint32_t g = group_of[find(ec_ids[a])];
+      const uint32_t* cp = P->col_ptr.data() + P->tr_base[g] + g;
+      for (uint64_t j = a; j < b; j++) {
+        const uint32_t l = local_of[ec_ids[j]];
+        P->col_row[P->nz_base[g] + cp[l] + cfill[P->tr_base[g] + l]++] = (uint16_t)row_local[e];
+      }
+    }
+  }
+  return 0;
+}
+
+// ---- serial CPU backend: the groups one after the other, "one thread" each ------------------------------------------
+struct CpuBackend {
+  const Plan& P;
+  std::vector<double> alpha, a, alpha_nx, a_nx, g, ck_alpha, ck_a;
+  explicit CpuBackend(const Plan& p) : P(p) {
+    const uint64_t M = P.tr_base[P.n_groups], R = P.row_base[P.n_groups];
+    alpha.assign(M, 1.0 / (double)P.T);                    // alpha_ = 1/T for every transcript (:38)
+    a.resize(M); alpha_nx.resize(M); a_nx.resize(M); g.resize(R);
+    for (uint64_t m = 0; m < M; m++) a[m] = alpha[m] / P.eff[m];
+  }
+  void checkpoint() { ck_alpha = alpha; ck_a = a; }
+  void restore() { alpha = ck_alpha; a = ck_a; }
+  // n rounds for every group; hist[i] += change count of round i (if hist)
+  void run(int n, int clamp, int* hist) {
+    for (uint32_t gi = 0; gi < P.n_groups; gi++) {
+      const Group G = P.group(gi);
+      double* al = alpha.data() + P.tr_base[gi]; double* av = a.data() + P.tr_base[gi];
+      double* aln = alpha_nx.data() + P.tr_base[gi]; double* avn = a_nx.data() + P.tr_base[gi];
+      double* gg = g.data() + P.row_base[gi];
+      for (int i = 0; i < n; i++) {
+        rows_pass(G, 0, 1, al, av, clamp, gg);
+        const int ch = cols_pass(G, 0, 1, al, av, clamp, gg, aln, avn);
+        if (hist) hist[i] += ch;
+        std::swap(al, aln); std::swap(av, avn);
+      }
+      if (n & 1) {   // the result sits in the *_nx buffers of this group
+        memcpy(alpha.data() + P.tr_base[gi], alpha_nx.data() + P.tr_base[gi], G.n_tr * sizeof(double));
+        memcpy(a.data() + P.tr_base[gi], a_nx.data() + P.tr_base[gi], G.n_tr * sizeof(double));
+      }
+    }
+  }
+};
+
+// ---- the driver: EMAlgorithm::run's loop control over a backend that can only run whole chunks ----------------------
+// alpha_out / abz_out: [T].  Returns the number of rounds ("ran for i rounds").
+template <class Backend>
+int run(Backend& B, const Plan& P, int n_iter, int min_rounds, int chunk, double* alpha_out, double* abz_out) {
+  const uint64_t M = P.tr_base[P.n_groups];
+  std::vector<int> hist((size_t)chunk);
+  int base = 0, rounds = 0;
+  bool have_final = false;
+  std::vector<double> before;
+  for (;;) {
+    const int n = std::min(chunk, n_iter - base);
+    B.checkpoint();
+    std::fill(hist.begin(), hist.end(), 0);
+    B.run(n, 0, hist.data());
+    int stop = -1;
+    for (int i = 0; i < n; i++) if (hist[i] == 0 && base + i > min_rounds) { stop = base + i; break; }   // :202-205
+    if (stop < 0) {
+      base += n;
+      if (base >= n_iter) { rounds = n_iter; break; }            // the loop ran out: no final round
+      continue;
+    }
+    B.restore();
+    B.run(stop - base + 1, 0, nullptr);                          // replay rounds base..stop
+    before.assign(B.alpha.begin(), B.alpha.begin() + M);         // what the final round reads: alpha_before_zeroes_
+    B.run(1, 1, nullptr);                                        // the final round (:212-221, clamp applied on read)
+    have_final = true;
+    rounds = stop + 1;
+    break;
+  }
+  // back to transcript space: a transcript outside m-space keeps its singleton count from round 1 on (0 if in no set)
+  for (uint64_t t = 0; t < P.T; t++) { alpha_out[t] = P.single_all[t]; if (abz_out) abz_out[t] = have_final ? P.single_all[t] : 0.0; }
+  for (uint64_t m = 0; m < M; m++) {
+    alpha_out[P.tr_id[m]] = B.alpha[m];
+    if (abz_out) abz_out[P.tr_id[m]] = have_final ? before[m] : 0.0;
+  }
+  return rounds;
+}
+#endif  // !__HIP_DEVICE_COMPILE__
+
+}  // namespace kamd_em_local

@@ -1,0 +1,60 @@
+// tests/emu/em_local_emu.cpp -- TEST INFRASTRUCTURE: drives kallisto_amd/csrc/kamd_em_local.h (plan builder, per-group
+// rounds, chunk / history / replay driver) on the CPU so that it can be checked against the oracle's EMAlgorithm::run.
+#include "../../kallisto_amd/csrc/kamd_em_local.h"
+
+#include <map>
+
+extern "C" {
+// returns 0 = ran, 1 = not applicable (a component exceeds the budget / the 16-bit local index range)
+int emu_em_local(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs, const double* eff, uint64_t T,
+                 uint64_t budget_bytes, uint64_t target_nnz, int n_iter, int min_rounds, int chunk, double* alpha, double* abz,
+                 int32_t* rounds, uint32_t* n_groups, uint64_t* max_group_bytes) {
+  using namespace kamd_em_local;
+  Plan P;
+  if (int rc = build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return rc;
+  *n_groups = P.n_groups; *max_group_bytes = P.max_group_bytes;
+  CpuBackend B(P);
+  *rounds = run(B, P, n_iter, min_rounds, chunk, alpha, abz);
+  return 0;
+}
+// the plan must hold exactly the rows with >= 2 transcripts (as sets, with their counts), both directions must describe
+// the same matrix, every group must respect the budget; returns 0 = consistent, > 0 = which check failed
+int emu_em_local_check_plan(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs, const double* eff,
+                            uint64_t T, uint64_t budget_bytes, uint64_t target_nnz) {
+  using namespace kamd_em_local;
+  Plan P;
+  if (build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return -1;
+  std::map<std::vector<uint32_t>, uint64_t> want, got;
+  for (uint64_t e = 0; e < n_ecs; e++) {
+    if (ec_off[e + 1] - ec_off[e] < 2) continue;
+    want[std::vector<uint32_t>(ec_ids + ec_off[e], ec_ids + ec_off[e + 1])] += counts[e];
+  }
+  std::vector<uint8_t> seen(T, 0);
+  for (uint32_t g = 0; g < P.n_groups; g++) {
+    const Group G = P.group(g);
+    const uint64_t nnz = P.nz_base[g + 1] - P.nz_base[g];
+    if (group_bytes(nnz, G.n_rows, G.n_tr) > budget_bytes) return 1;
+    if (G.row_ptr[0] != 0 || G.row_ptr[G.n_rows] != nnz || G.col_ptr[0] != 0 || G.col_ptr[G.n_tr] != nnz) return 2;
+    for (uint32_t t = 0; t < G.n_tr; t++) {
+      const uint32_t id = P.tr_id[P.tr_base[g] + t];
+      if (id >= T || seen[id]) return 3;                       // a transcript belongs to exactly one group
+      seen[id] = 1;
+      if (G.eff[t] != eff[id]) return 4;
+    }
+    std::vector<std::vector<uint32_t>> from_cols(G.n_rows);
+    for (uint32_t t = 0; t < G.n_tr; t++)
+      for (uint32_t j = G.col_ptr[t]; j < G.col_ptr[t + 1]; j++) { if (G.col_row[j] >= G.n_rows) return 5; from_cols[G.col_row[j]].push_back(t); }
+    for (uint32_t r = 0; r < G.n_rows; r++) {
+      std::vector<uint32_t> loc(G.row_tr + G.row_ptr[r], G.row_tr + G.row_ptr[r + 1]), ids;
+      for (uint32_t l : loc) { if (l >= G.n_tr) return 6; ids.push_back(P.tr_id[P.tr_base[g] + l]); }
+      std::vector<uint32_t> a = loc, b = from_cols[r];
+      std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+      if (a != b) return 7;                                    // the two directions disagree
+      std::sort(ids.begin(), ids.end());
+      got[ids] += (uint32_t)G.cw[r];
+      if ((uint32_t)(G.cw[r] >> 32) != (uint32_t)G.cw[r]) return 8;   // weight counts default to the counts
+    }
+  }
+  return want == got ? 0 : 9;
+}
+}

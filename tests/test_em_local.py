@@ -1,0 +1,110 @@
+"""kallisto_amd/csrc/kamd_em_local.h on the CPU: the component-local form of EMAlgorithm::run (groups of connected
+components iterate on their own; only the stop rule is global and is resolved by speculative chunks + replay) must give
+the oracle's number of rounds and its abundances, for any group size and chunk length.  The header is not wired into
+kamd_em_run yet; this pins its plan builder, per-group rounds and driver before the device side is written."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import common, emu_binding as E
+
+
+def _gene_matrix(n_genes, seed, zero_frac=0.05):
+    """gene families only (one connected component per gene), some zero counts, singleton rows, transcripts in no row"""
+    rng = np.random.default_rng(seed)
+    iso = np.minimum(rng.geometric(0.12, n_genes), 40)
+    t0 = np.concatenate([[0], np.cumsum(iso)])
+    T = int(t0[-1]) + 4
+    sets = {}
+    for g in range(n_genes):
+        for _ in range(rng.poisson(20)):
+            m = min(iso[g], max(1, rng.geometric(0.25)))
+            r = tuple(sorted(int(x) + int(t0[g]) for x in rng.choice(iso[g], m, replace=False)))
+            sets[r] = sets.get(r, 0) + int(rng.pareto(1.2) * 3) + (0 if rng.random() < zero_frac else 1)
+    keys = list(sets)
+    rng.shuffle(keys)
+    off = np.zeros(len(keys) + 1, np.uint64)
+    off[1:] = np.cumsum([len(k) for k in keys])
+    ids = np.array([t for k in keys for t in k], np.uint32)
+    cnt = np.array([sets[k] for k in keys], np.uint32)
+    return off, ids, cnt, rng.uniform(150, 3000, T), T
+
+
+def _run(off, ids, cnt, eff, T, budget=64 * 1024, target=1 << 40, chunk=64, n_iter=10000, min_rounds=50):
+    L = E.lib()
+    alpha = np.zeros(T); abz = np.zeros(T)
+    rounds = C.c_int32(0); ng = C.c_uint32(0); mb = C.c_uint64(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    off = np.ascontiguousarray(off, np.uint64); ids = np.ascontiguousarray(ids, np.uint32); cnt = np.ascontiguousarray(cnt, np.uint32)
+    eff = np.ascontiguousarray(eff, np.float64)
+    rc = L.emu_em_local(p(off), p(ids), p(cnt), C.c_uint64(len(cnt)), p(eff), C.c_uint64(T), C.c_uint64(budget), C.c_uint64(target),
+                        int(n_iter), int(min_rounds), int(chunk), p(alpha), p(abz), C.byref(rounds), C.byref(ng), C.byref(mb))
+    return rc, alpha, abz, rounds.value, ng.value, mb.value
+
+
+def _check_plan(off, ids, cnt, eff, T, budget, target):
+    L = E.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    off = np.ascontiguousarray(off, np.uint64); ids = np.ascontiguousarray(ids, np.uint32); cnt = np.ascontiguousarray(cnt, np.uint32)
+    eff = np.ascontiguousarray(eff, np.float64)
+    return L.emu_em_local_check_plan(p(off), p(ids), p(cnt), C.c_uint64(len(cnt)), p(eff), C.c_uint64(T), C.c_uint64(budget), C.c_uint64(target))
+
+
+@pytest.mark.parametrize("budget,target", [(1 << 30, 1 << 40), (16 * 1024, 1 << 40), (1 << 30, 300), (6 * 1024, 150)])
+def test_plan_holds_the_matrix(budget, target):
+    off, ids, cnt, eff, T = _gene_matrix(200, 11)
+    assert _check_plan(off, ids, cnt, eff, T, budget, target) == 0
+
+
+@pytest.mark.parametrize("budget,target,chunk", [(1 << 30, 1 << 40, 64), (16 * 1024, 1 << 40, 64), (1 << 30, 400, 7), (8 * 1024, 200, 1),
+                                                 (1 << 30, 1 << 40, 10000)])
+def test_local_em_equals_the_oracle(budget, target, chunk):
+    off, ids, cnt, eff, T = _gene_matrix(150, 5)
+    a_o, abz_o, r_o = O.em_run(off, ids, cnt, eff, T)
+    rc, a, abz, r, ng, mb = _run(off, ids, cnt, eff, T, budget, target, chunk)
+    assert rc == 0 and mb <= budget
+    if target < 1000:
+        assert ng > 10                                     # really many groups
+    assert r == r_o
+    common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
+    tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
+    common.assert_abundance_close(tiny(abz), tiny(abz_o), "alpha_before_zeroes", rel=1e-9, floor=1e-12)
+
+
+def test_loop_that_runs_out_has_no_final_round():
+    off, ids, cnt, eff, T = _gene_matrix(60, 2)
+    a_o, abz_o, r_o = O.em_run(off, ids, cnt, eff, T, n_iter=37, min_rounds=50)
+    rc, a, abz, r, _, _ = _run(off, ids, cnt, eff, T, chunk=16, n_iter=37, min_rounds=50)
+    assert rc == 0 and r == r_o == 37
+    common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
+
+
+def test_a_component_that_does_not_fit_is_reported():
+    """the hub / long-row matrix of the GPU tests is one giant component: not applicable at a workgroup's LDS budget"""
+    from tests.test_gpu_parity import _family_csr
+    off, ids, cnt, eff, T = _family_csr(400, 7)
+    rc, *_ = _run(off, ids, cnt, eff, T, budget=150 * 1024)
+    assert rc == 1
+    rc, a, abz, r, ng, _ = _run(off, ids, cnt, eff, T, budget=1 << 30)     # with room for it: one group, same answer
+    a_o, _, r_o = O.em_run(off, ids, cnt, eff, T)
+    assert rc == 0 and ng == 1 and r == r_o
+    common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
+
+
+@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("human_pe", "pe"), ("yeast_se", "se"), ("mosaic_pe", "pe")])
+def test_local_em_on_the_golden_ec_matrices(case, variant):
+    meta, idx_path, r1, r2 = common.load_case(case)
+    o = common.parse_variant(meta["variants"][variant])
+    exp = common.load_expected(case, variant)
+    ix = O.Index(idx_path)
+    buf, off, lens = O.pack_reads(common.interleave(r1, r2 if o["paired"] else None))
+    res = O.process_reads(ix, O.Opts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"]), buf, off, lens)
+    eoff, eids, ecnt = res.ec_off, res.ec_ids, res.counts
+    eff = exp["eff"]
+    a_o, abz_o, r_o = O.em_run(eoff, eids, ecnt, eff, len(eff))
+    rc, a, abz, r, ng, _ = _run(eoff, eids, ecnt, eff, len(eff), target=64, chunk=32)
+    assert rc == 0 and r == r_o
+    common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
+    common.assert_abundance_close(a, exp["alpha"], "alpha vs the reference")       # 1e-4, like every other path
