@@ -1,4 +1,5 @@
-// kamd_em_local.h -- component-local EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223), NOT WIRED INTO kamd_em_run YET.
+// kamd_em_local.h -- component-local EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223).  EXPERIMENTAL: kamd_em_run only takes
+// this form with KAMD_EM_LOCAL=1; the CPU side below is tested against the oracle, the kernel has not run on hardware yet.
 //
 // The EC x transcript matrix is block diagonal over the connected components of the transcript/EC graph (gene families)
 // and the EM update never couples two components.  Components are therefore packed into GROUPS small enough for one
@@ -13,8 +14,9 @@
 //   * the plan (groups, local CSR in both directions) and a host reference builder for it,
 //   * the per-group round as host/device functions written for thread-strided execution,
 //   * the chunk / history / replay driver, templated on a backend (here: the serial CPU backend).
-// The device side (set-up kernels that build the same plan in HBM, the LDS-resident kernel that calls the same round
-// functions) is the next round's work; the plan built there can be validated against build_plan_host().
+// The device side: k_em_local in kamd_kernels.hip calls the same round functions on LDS copies of a group; its plan is
+// still built by build_plan_host() from a download of the CSR (slow: bring-up only).  Set-up kernels that build the same
+// plan in HBM are the next step; what they produce can be validated against build_plan_host().
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -84,7 +86,6 @@ KAMD_HD int cols_pass(const Group& G, uint32_t tid, uint32_t nthr, const double*
   return ch;
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 // ---- the plan: groups in HBM (here: host vectors) --------------------------------------------------------------------
 struct Plan {
   uint32_t n_groups = 0;
@@ -249,6 +250,7 @@ struct CpuBackend {
   }
   void checkpoint() { ck_alpha = alpha; ck_a = a; }
   void restore() { alpha = ck_alpha; a = ck_a; }
+  const std::vector<double>& host_alpha() { return alpha; }   // m-space alpha of the current state
   // n rounds for every group; hist[i] += change count of round i (if hist)
   void run(int n, int clamp, int* hist) {
     for (uint32_t gi = 0; gi < P.n_groups; gi++) {
@@ -293,7 +295,7 @@ int run(Backend& B, const Plan& P, int n_iter, int min_rounds, int chunk, double
     }
     B.restore();
     B.run(stop - base + 1, 0, nullptr);                          // replay rounds base..stop
-    before.assign(B.alpha.begin(), B.alpha.begin() + M);         // what the final round reads: alpha_before_zeroes_
+    { const std::vector<double>& cur = B.host_alpha(); before.assign(cur.begin(), cur.begin() + M); }   // what the final round reads: alpha_before_zeroes_
     B.run(1, 1, nullptr);                                        // the final round (:212-221, clamp applied on read)
     have_final = true;
     rounds = stop + 1;
@@ -301,12 +303,12 @@ int run(Backend& B, const Plan& P, int n_iter, int min_rounds, int chunk, double
   }
   // back to transcript space: a transcript outside m-space keeps its singleton count from round 1 on (0 if in no set)
   for (uint64_t t = 0; t < P.T; t++) { alpha_out[t] = P.single_all[t]; if (abz_out) abz_out[t] = have_final ? P.single_all[t] : 0.0; }
+  const std::vector<double>& fin = B.host_alpha();
   for (uint64_t m = 0; m < M; m++) {
-    alpha_out[P.tr_id[m]] = B.alpha[m];
+    alpha_out[P.tr_id[m]] = fin[m];
     if (abz_out) abz_out[P.tr_id[m]] = have_final ? before[m] : 0.0;
   }
   return rounds;
 }
-#endif  // !__HIP_DEVICE_COMPILE__
 
 }  // namespace kamd_em_local

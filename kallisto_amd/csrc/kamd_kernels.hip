@@ -27,6 +27,7 @@
 #include "../../include/kallisto_amd.h"
 #include "kamd_core.h"
 #include "kamd_host.h"
+#include "kamd_em_local.h"
 
 #define HIPC(x)                                                                                   \
   do {                                                                                            \
@@ -2600,6 +2601,144 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   return 0;
 }
 
+// ---- component-local EM (kamd_em_local.h), EXPERIMENTAL: only with KAMD_EM_LOCAL=1, not yet run on hardware -----------------
+// One workgroup per group of connected components; the group's whole state lives in LDS for the n_rounds of a launch (see
+// the header).  The plan is still built on the host here (download of the CSR + build_plan_host): good enough to bring the
+// kernel up, far too slow to be the default -- the device-side set-up is the next step.
+constexpr int EML_BLOCK = 256;
+struct EmLocalDev {
+  const u32* row_base; const u32* tr_base; const u64* nz_base;
+  const u32* row_ptr; const u32* col_ptr; const uint16_t* row_tr; const uint16_t* col_row;
+  const u64* cw; const double* single; const double* eff;
+};
+__global__ __launch_bounds__(EML_BLOCK) void k_em_local(EmLocalDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char eml_smem[];
+  __shared__ int s_ch;
+  const u32 g = blockIdx.x, tid = threadIdx.x;
+  const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
+  const u64 z0 = P.nz_base[g];
+  const u32 nz = (u32)(P.nz_base[g + 1] - z0);
+  // the layout kamd_em_local::group_bytes() prices: 8-byte arrays, then 4-byte, then 2-byte
+  double* s_al0 = reinterpret_cast<double*>(eml_smem);
+  double* s_a0 = s_al0 + nT; double* s_al1 = s_a0 + nT; double* s_a1 = s_al1 + nT;
+  double* s_single = s_a1 + nT; double* s_eff = s_single + nT; double* s_g = s_eff + nT;
+  u64* s_cw = reinterpret_cast<u64*>(s_g + nR);
+  u32* s_rowptr = reinterpret_cast<u32*>(s_cw + nR); u32* s_colptr = s_rowptr + nR + 1;
+  uint16_t* s_rowtr = reinterpret_cast<uint16_t*>(s_colptr + nT + 1); uint16_t* s_colrow = s_rowtr + nz;
+  for (u32 i = tid; i < nT; i += EML_BLOCK) { s_al0[i] = alpha[t0 + i]; s_a0[i] = a[t0 + i]; s_single[i] = P.single[t0 + i]; s_eff[i] = P.eff[t0 + i]; }
+  for (u32 i = tid; i < nR; i += EML_BLOCK) s_cw[i] = P.cw[r0 + i];
+  for (u32 i = tid; i <= nR; i += EML_BLOCK) s_rowptr[i] = P.row_ptr[r0 + g + i];
+  for (u32 i = tid; i <= nT; i += EML_BLOCK) s_colptr[i] = P.col_ptr[t0 + g + i];
+  for (u32 i = tid; i < nz; i += EML_BLOCK) { s_rowtr[i] = P.row_tr[z0 + i]; s_colrow[i] = P.col_row[z0 + i]; }
+  __syncthreads();
+  const kamd_em_local::Group G{nR, nT, s_rowptr, s_rowtr, s_colptr, s_colrow, reinterpret_cast<const uint64_t*>(s_cw), s_single, s_eff};
+  double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
+  for (int r = 0; r < n_rounds; r++) {
+    if (tid == 0) s_ch = 0;
+    kamd_em_local::rows_pass(G, tid, EML_BLOCK, al, av, clamp, s_g);
+    __syncthreads();
+    const int ch = kamd_em_local::cols_pass(G, tid, EML_BLOCK, al, av, clamp, s_g, aln, avn);
+    if (ch) atomicAdd(&s_ch, ch);
+    __syncthreads();
+    if (tid == 0 && hist && s_ch) atomicAdd(&hist[r], s_ch);
+    double* t1 = al; al = aln; aln = t1;
+    double* t2 = av; av = avn; avn = t2;
+  }
+  for (u32 i = tid; i < nT; i += EML_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
+}
+// the backend of kamd_em_local::run on the device; every method returns through `err` (0 = ok)
+struct EmLocalGpu {
+  kamd_ctx* c; const kamd_em_local::Plan& P; EmLocalDev dev{}; u64 M = 0; size_t lds = 0;
+  double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
+  std::vector<double> h_alpha; int err = 0; int hist_cap = 0;
+  EmLocalGpu(kamd_ctx* ctx, const kamd_em_local::Plan& p) : c(ctx), P(p) {}
+  int setup(int chunk);
+  void checkpoint() {
+    if (err) return;
+    if (hipMemcpyAsync(d_ck_alpha, d_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_ck_a, d_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+  }
+  void restore() {
+    if (err) return;
+    if (hipMemcpyAsync(d_alpha, d_ck_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_a, d_ck_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+  }
+  void run(int n, int clamp, int* hist) {
+    if (err || n <= 0) return;
+    if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
+    hipLaunchKernelGGL(k_em_local, dim3(P.n_groups), dim3(EML_BLOCK), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    if (hipGetLastError() != hipSuccess) { err = -104; return; }
+    if (hist && (hipMemcpyAsync(hist, d_hist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                 hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
+  }
+  const std::vector<double>& host_alpha() {
+    h_alpha.resize(M);
+    if (!err && (hipMemcpyAsync(h_alpha.data(), d_alpha, M * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                 hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
+    return h_alpha;
+  }
+};
+int EmLocalGpu::setup(int chunk) {
+  const u32 ng = P.n_groups;
+  M = P.tr_base[ng];
+  const u64 R = P.row_base[ng], NZ = P.nz_base[ng];
+  Carver cv;
+  const size_t o_rb = cv.take((ng + 1) * 4), o_tb = cv.take((ng + 1) * 4), o_zb = cv.take((ng + 1) * 8);
+  const size_t o_rp = cv.take((R + ng) * 4), o_cp = cv.take((M + ng) * 4), o_rt = cv.take(NZ * 2 + 2), o_cr = cv.take(NZ * 2 + 2);
+  const size_t o_cw = cv.take(R * 8 + 8), o_sg = cv.take(M * 8 + 8), o_ef = cv.take(M * 8 + 8);
+  if (int rc = c->pm_a.ensure(cv.off, 0, c->stream)) return rc;
+  char* b = (char*)c->pm_a.p;
+  auto up = [&](size_t o, const void* src, size_t bytes) -> int { if (bytes) HIPC(hipMemcpyAsync(b + o, src, bytes, hipMemcpyHostToDevice, c->stream)); return 0; };
+  if (up(o_rb, P.row_base.data(), (ng + 1) * 4) || up(o_tb, P.tr_base.data(), (ng + 1) * 4) || up(o_zb, P.nz_base.data(), (ng + 1) * 8) ||
+      up(o_rp, P.row_ptr.data(), (R + ng) * 4) || up(o_cp, P.col_ptr.data(), (M + ng) * 4) || up(o_rt, P.row_tr.data(), NZ * 2) ||
+      up(o_cr, P.col_row.data(), NZ * 2) || up(o_cw, P.cw.data(), R * 8) || up(o_sg, P.single.data(), M * 8) || up(o_ef, P.eff.data(), M * 8))
+    return -104;
+  dev = EmLocalDev{(const u32*)(b + o_rb), (const u32*)(b + o_tb), (const u64*)(b + o_zb), (const u32*)(b + o_rp), (const u32*)(b + o_cp),
+                   (const uint16_t*)(b + o_rt), (const uint16_t*)(b + o_cr), (const u64*)(b + o_cw), (const double*)(b + o_sg),
+                   (const double*)(b + o_ef)};
+  Carver sv;
+  const size_t o_al = sv.take(M * 8 + 8), o_a = sv.take(M * 8 + 8), o_cka = sv.take(M * 8 + 8), o_ckb = sv.take(M * 8 + 8), o_h = sv.take((size_t)chunk * 4 + 8);
+  if (int rc = c->pm_b.ensure(sv.off, 0, c->stream)) return rc;
+  char* sb = (char*)c->pm_b.p;
+  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = (double*)(sb + o_cka); d_ck_a = (double*)(sb + o_ckb); d_hist = (int*)(sb + o_h);
+  std::vector<double> al(M, 1.0 / (double)P.T), av(M);      // alpha_ = 1/T for every transcript (:38)
+  for (u64 m = 0; m < M; m++) av[m] = al[m] / P.eff[m];
+  if (M) { HIPC(hipMemcpyAsync(d_alpha, al.data(), M * 8, hipMemcpyHostToDevice, c->stream)); HIPC(hipMemcpyAsync(d_a, av.data(), M * 8, hipMemcpyHostToDevice, c->stream)); }
+  HIPC(hipStreamSynchronize(c->stream));                    // the staging vectors are locals
+  lds = (size_t)P.max_group_bytes + 16;
+  HIPC(hipFuncSetAttribute((const void*)k_em_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return 0;
+}
+// 0 = done, 1 = not applicable (the caller takes the streamed form), < 0 = error
+int em_local_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
+                        const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds) {
+  std::vector<uint64_t> off(n_ecs + 1); std::vector<u32> ids(std::max<u64>(nnz, 1)), cnt(n_ecs), wcn(n_ecs);
+  HIPC(hipMemcpyAsync(off.data(), d_ec_off, (n_ecs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  if (nnz) HIPC(hipMemcpyAsync(ids.data(), d_ec_ids, nnz * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(cnt.data(), d_counts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(wcn.data(), d_wcounts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
+  kamd_em_local::Plan P;
+  const u64 budget = 150 * 1024;                                          // of the CU's 160 KB
+  const u64 target = std::max<u64>(2048, (nnz + (u64)c->n_cus * 4 - 1) / ((u64)c->n_cus * 4));   // ~4 groups per CU
+  if (kamd_em_local::build_plan_host(off.data(), ids.data(), cnt.data(), wcn.data(), n_ecs, eff_lens, T, budget, target, &P)) return 1;
+  if (P.n_groups == 0) return 1;
+  const int chunk = 64;
+  EmLocalGpu B(c, P);
+  if (int rc = B.setup(chunk)) return rc;
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
+  if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
+  HIPC(hipEventRecord(c->ev1, c->stream));
+  HIPC(hipEventSynchronize(c->ev1));
+  HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
+  c->last_em_iters = (uint64_t)r + (r < n_iter ? 1 : 0);
+  c->last_em_nnz = nnz; c->last_em_k = -1; c->last_em_grid = P.n_groups; c->last_em_necs = n_ecs;
+  if (rounds) *rounds = r;
+  return 0;
+}
+
 int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
                 const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
                 uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds, const EmPartition& part) {
@@ -2662,6 +2801,14 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   if (n_ecs) {
     HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
+  }
+  if (!spec && n_ecs) {   // EXPERIMENTAL opt-in: the component-local form (kamd_em_local.h)
+    const char* el = getenv("KAMD_EM_LOCAL");
+    if (el && atoi(el) != 0) {
+      const int rc = em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
+                                         (int)min_rounds, alpha, alpha_before_zeroes, rounds);
+      if (rc <= 0) return rc;   // 1 = not applicable: fall through to the streamed form
+    }
   }
   for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_eff, &c->em_a0, &c->em_a1, &c->em_single})
     if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;

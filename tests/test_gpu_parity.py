@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI of libkallisto_amd.so) with the reference's golden vectors and with the
 oracle.  EC counts / fragment-length sample / effective lengths: bit-exact.  Estimated counts: 1e-4 relative
 (BASELINE.json), identical zero pattern."""
+import os
+
 import numpy as np
 import pytest
 
@@ -183,7 +185,13 @@ def _family_csr(n_genes, seed):
     return off, ids, cnt, rng.uniform(150, 3000, T), T
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr"])
+def _gene_csr(n_genes, seed):
+    """gene families only: one connected component per gene (what the component-local EM form needs)"""
+    from tests.test_em_local import _gene_matrix
+    return _gene_matrix(n_genes, seed)
+
+
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The streamed EM form (default and forced chunk sizes: 64 x 8 entries makes the long rows / hub columns span many
     chunks -> fix-up launches; "wK": the general pass for chunks with more segment ends than LDS slots, forced) and the CSR
@@ -191,6 +199,15 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     import torch
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
+    if k == "local":
+        # the component-local form (kamd_em_local.h) is opt-in and has not run on hardware yet: only with KAMD_TEST_EXPERIMENTAL=1
+        if os.environ.get("KAMD_TEST_EXPERIMENTAL") != "1":
+            pytest.skip("experimental EM form: set KAMD_TEST_EXPERIMENTAL=1")
+        off, ids, cnt, eff, T = _gene_csr(300, 7)
+        alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
+        monkeypatch.setenv("KAMD_EM_LOCAL", "1")
+    else:
+        monkeypatch.delenv("KAMD_EM_LOCAL", raising=False)
     monkeypatch.setenv("KAMD_EM_WINDOWED", "1" if isinstance(k, str) and k[0] == "w" else "0")
     if isinstance(k, str) and k[0] == "w":
         k = int(k[1:])
@@ -207,7 +224,10 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
         prof = ctx.profile()
     finally:
         ctx.close()
-    assert (prof["em_k"] == 0) == (k == "csr")
+    if k == "local":
+        assert prof["em_k"] == -1                          # the local form ran (kamd_profile.last_em_k)
+    else:
+        assert (prof["em_k"] == 0) == (k == "csr")
     if isinstance(k, int):
         assert prof["em_k"] == k
     assert rounds == rounds_o
