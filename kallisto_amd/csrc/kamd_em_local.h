@@ -1,5 +1,5 @@
 // kamd_em_local.h -- component-local EM (EMAlgorithm::run, src/EMAlgorithm.h:95-223).  EXPERIMENTAL: kamd_em_run only takes
-// this form with KAMD_EM_LOCAL=1; the CPU side below is tested against the oracle, the kernel has not run on hardware yet.
+// this form with KAMD_EM_LOCAL=1; the CPU side below is tested (tests/test_em_local.py), the kernel has not run on hardware yet.
 //
 // The EC x transcript matrix is block diagonal over the connected components of the transcript/EC graph (gene families)
 // and the EM update never couples two components.  Components are therefore packed into GROUPS small enough for one
@@ -10,7 +10,7 @@
 // does across ranks: a chunk of rounds runs speculatively from a checkpoint while every group adds its per-round change
 // count to a history, the first qualifying round is found, the chunk is replayed up to it, then the clamped final round.
 //
-// This header holds what can be checked without a GPU (tests/emu, tests/test_em_local.py against the oracle):
+// This header holds what can be checked without a GPU (tests/emu, tests/test_em_local.py):
 //   * the plan (groups, local CSR in both directions) and a host reference builder for it,
 //   * the per-group round as host/device functions written for thread-strided execution,
 //   * the chunk / history / replay driver, templated on a backend (here: the serial CPU backend).
