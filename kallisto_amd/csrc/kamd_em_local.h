@@ -238,6 +238,194 @@ inline int build_plan_host(const uint64_t* ec_off, const uint32_t* ec_ids, const
   return 0;
 }
 
+// ---- the same plan built the way the device will build it: data-parallel steps over flat arrays ---------------------------
+// Every step is a function of one index (a row, a transcript, a component root or a group) that only uses plain stores and
+// atomic adds, so a kernel is `step(blockIdx.x * blockDim.x + threadIdx.x, A)`; between the steps sit exclusive scans.  On
+// the host the steps run serially (build_plan_steps_host below), which is how tests/test_em_local.py checks them.  The order
+// of rows / transcripts inside a group comes from atomic cursors (any order is a valid plan).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KAMD_EML_ADD32(p, v) atomicAdd((p), (v))
+#else
+static inline uint32_t kamd_eml_add32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+#define KAMD_EML_ADD32(p, v) kamd_eml_add32((p), (v))
+#endif
+struct BuildArgs {
+  // input
+  const uint64_t* ec_off; const uint32_t* ec_ids; const uint32_t* counts; const uint32_t* wcounts; uint64_t n_ecs;
+  const double* eff; uint64_t T; const uint32_t* label;   // label[t] = smallest transcript id of t's component
+  uint64_t target_nnz;
+  // per transcript / per component root, [T] (+1 where scanned)
+  uint8_t* in_multi; double* single_all; uint32_t* c_nnz; uint32_t* c_rows; uint32_t* c_tr; const uint64_t* cum_nnz; uint32_t* local_of;
+  // per group, [n_groups] (+1 where scanned)
+  uint32_t n_groups; uint32_t* g_rows; uint32_t* g_tr; uint32_t* g_nnz; uint32_t* row_fill; uint32_t* tr_fill;
+  const uint32_t* row_base; const uint32_t* tr_base; const uint64_t* nz_base;
+  // per row
+  uint32_t* row_new;      // [n_ecs] new (group-major) index of a kept row
+  uint32_t* len_new;      // [R] length of the row at a new index
+  const uint64_t* row_abs;   // [R + 1] scan of len_new: absolute entry offset of a row
+  // per m-space transcript
+  uint32_t* col_cnt;      // [M]
+  const uint64_t* col_abs;   // [M + 1] scan of col_cnt
+  uint32_t* col_fill;     // [M]
+  // the plan's arrays
+  uint32_t* row_ptr; uint16_t* row_tr; uint32_t* col_ptr; uint16_t* col_row; uint64_t* cw; double* single; double* eff_m; uint32_t* tr_id;
+};
+KAMD_HD uint32_t eml_group_of(const BuildArgs& A, uint32_t root) { return (uint32_t)(A.cum_nnz[root] / A.target_nnz); }
+// A (per row): component sizes, which transcripts are in a kept row, singleton counts
+KAMD_HD void step_rows_a(uint64_t e, const BuildArgs& A) {
+  if (e >= A.n_ecs) return;
+  const uint64_t a = A.ec_off[e], b = A.ec_off[e + 1];
+  if (b - a == 1) { A.single_all[A.ec_ids[a]] = (double)A.counts[e]; return; }
+  if (b - a < 2) return;
+  const uint32_t root = A.label[A.ec_ids[a]];
+  KAMD_EML_ADD32(&A.c_nnz[root], (uint32_t)(b - a));   // (the caller refuses matrices with 2^32 entries or more)
+  KAMD_EML_ADD32(&A.c_rows[root], 1u);
+  for (uint64_t j = a; j < b; j++) A.in_multi[A.ec_ids[j]] = 1;
+}
+// B (per transcript): transcripts per component
+KAMD_HD void step_tr_b(uint64_t t, const BuildArgs& A) {
+  if (t < A.T && A.in_multi[t]) KAMD_EML_ADD32(&A.c_tr[A.label[t]], 1u);
+}
+// (scan c_nnz -> cum_nnz; n_groups = (NZ - 1) / target + 1)
+// D (per root): group sizes; a component lies wholly in the group its first entry falls into
+KAMD_HD void step_root_d(uint64_t r, const BuildArgs& A) {
+  if (r >= A.T || A.c_rows[r] == 0) return;
+  const uint32_t g = eml_group_of(A, (uint32_t)r);
+  KAMD_EML_ADD32(&A.g_rows[g], A.c_rows[r]);
+  KAMD_EML_ADD32(&A.g_tr[g], A.c_tr[r]);
+  KAMD_EML_ADD32(&A.g_nnz[g], A.c_nnz[r]);
+}
+// (scans of g_rows / g_tr / g_nnz -> row_base / tr_base / nz_base; the caller checks every group against the budget)
+// F (per transcript): m-space slot
+KAMD_HD void step_tr_f(uint64_t t, const BuildArgs& A) {
+  if (t >= A.T || !A.in_multi[t]) return;
+  const uint32_t g = eml_group_of(A, A.label[t]);
+  const uint32_t l = KAMD_EML_ADD32(&A.tr_fill[g], 1u);
+  A.local_of[t] = l;
+  const uint64_t m = (uint64_t)A.tr_base[g] + l;
+  A.tr_id[m] = (uint32_t)t; A.single[m] = A.single_all[t]; A.eff_m[m] = A.eff[t];
+}
+// G (per row): new row index, its length and count word
+KAMD_HD void step_rows_g(uint64_t e, const BuildArgs& A) {
+  if (e >= A.n_ecs) return;
+  const uint64_t a = A.ec_off[e], b = A.ec_off[e + 1];
+  if (b - a < 2) return;
+  const uint32_t g = eml_group_of(A, A.label[A.ec_ids[a]]);
+  const uint32_t rn = A.row_base[g] + KAMD_EML_ADD32(&A.row_fill[g], 1u);
+  A.row_new[e] = rn;
+  A.len_new[rn] = (uint32_t)(b - a);
+  A.cw[rn] = (uint64_t)A.counts[e] | ((uint64_t)(A.wcounts ? A.wcounts[e] : A.counts[e]) << 32);
+}
+// (scan len_new -> row_abs)
+// I (per row): the row's entries, its relative offset, column counts
+KAMD_HD void step_rows_i(uint64_t e, const BuildArgs& A) {
+  if (e >= A.n_ecs) return;
+  const uint64_t a = A.ec_off[e], b = A.ec_off[e + 1];
+  if (b - a < 2) return;
+  const uint32_t g = eml_group_of(A, A.label[A.ec_ids[a]]);
+  const uint32_t rn = A.row_new[e];
+  const uint64_t at = A.row_abs[rn];
+  A.row_ptr[(uint64_t)rn + g] = (uint32_t)(at - A.nz_base[g]);
+  for (uint64_t j = a; j < b; j++) {
+    const uint32_t l = A.local_of[A.ec_ids[j]];
+    A.row_tr[at + (j - a)] = (uint16_t)l;
+    KAMD_EML_ADD32(&A.col_cnt[(uint64_t)A.tr_base[g] + l], 1u);
+  }
+}
+// (scan col_cnt -> col_abs)
+// group that owns m-space slot m (slots are group-major): last g with tr_base[g] <= m
+KAMD_HD uint32_t eml_group_of_slot(const BuildArgs& A, uint64_t m) {
+  uint32_t lo = 0, hi = A.n_groups;
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (A.tr_base[mid] <= m) lo = mid; else hi = mid; }
+  return lo;
+}
+// J (per m-space transcript) + (per group): relative column offsets and the closing entry of both offset arrays
+KAMD_HD void step_m_j(uint64_t m, uint32_t g, const BuildArgs& A) {   // g = group of slot m (the caller knows it: slots are group-major)
+  A.col_ptr[m + g] = (uint32_t)(A.col_abs[m] - A.nz_base[g]);
+}
+KAMD_HD void step_group_j(uint64_t g, const BuildArgs& A) {
+  if (g >= A.n_groups) return;
+  const uint32_t nnz = (uint32_t)(A.nz_base[g + 1] - A.nz_base[g]);
+  A.row_ptr[(uint64_t)A.row_base[g + 1] + g] = nnz;
+  A.col_ptr[(uint64_t)A.tr_base[g + 1] + g] = nnz;
+}
+// K (per row): the transposed entries
+KAMD_HD void step_rows_k(uint64_t e, const BuildArgs& A) {
+  if (e >= A.n_ecs) return;
+  const uint64_t a = A.ec_off[e], b = A.ec_off[e + 1];
+  if (b - a < 2) return;
+  const uint32_t g = eml_group_of(A, A.label[A.ec_ids[a]]);
+  const uint32_t rl = A.row_new[e] - A.row_base[g];
+  for (uint64_t j = a; j < b; j++) {
+    const uint64_t m = (uint64_t)A.tr_base[g] + A.local_of[A.ec_ids[j]];
+    A.col_row[A.col_abs[m] + KAMD_EML_ADD32(&A.col_fill[m], 1u)] = (uint16_t)rl;
+  }
+}
+
+// labels the way the device computes them (k_cc_*: min-label propagation): smallest transcript id of the component
+inline std::vector<uint32_t> component_labels_host(const uint64_t* ec_off, const uint32_t* ec_ids, uint64_t n_ecs, uint64_t T) {
+  std::vector<uint32_t> parent(T);
+  std::iota(parent.begin(), parent.end(), 0u);
+  auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+  for (uint64_t e = 0; e < n_ecs; e++) {
+    const uint64_t a = ec_off[e], b = ec_off[e + 1];
+    if (b - a < 2) continue;
+    uint32_t r0 = find(ec_ids[a]);
+    for (uint64_t j = a + 1; j < b; j++) { uint32_t r1 = find(ec_ids[j]); if (r1 != r0) { if (r1 < r0) std::swap(r0, r1); parent[r1] = r0; } }
+  }
+  std::vector<uint32_t> lab(T);
+  for (uint64_t t = 0; t < T; t++) lab[t] = find((uint32_t)t);
+  return lab;
+}
+// the steps above, run serially, with std::exclusive_scan-like loops where the device has its scan kernel.
+// Returns 0 = ok, 1 = not applicable (some group exceeds the budget or the 16-bit range: the caller may retry with a smaller
+// target or take another EM form).
+inline int build_plan_steps_host(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, const uint32_t* wcounts, uint64_t n_ecs,
+                                 const double* eff, uint64_t T, uint64_t budget_bytes, uint64_t target_nnz, Plan* P) {
+  const std::vector<uint32_t> label = component_labels_host(ec_off, ec_ids, n_ecs, T);
+  auto scan32 = [](const std::vector<uint32_t>& in, uint64_t n, std::vector<uint64_t>& out) { out.assign(n + 1, 0); for (uint64_t i = 0; i < n; i++) out[i + 1] = out[i] + in[i]; };
+  BuildArgs A{};
+  A.ec_off = ec_off; A.ec_ids = ec_ids; A.counts = counts; A.wcounts = wcounts; A.n_ecs = n_ecs; A.eff = eff; A.T = T; A.label = label.data();
+  A.target_nnz = std::max<uint64_t>(1, target_nnz);
+  std::vector<uint8_t> in_multi(T, 0); std::vector<uint64_t> cum(T + 1, 0); std::vector<uint32_t> c_nnz(T, 0), c_rows(T, 0), c_tr(T, 0), local_of(T, 0);
+  P->T = T; P->single_all.assign(T, 0.0);
+  A.in_multi = in_multi.data(); A.single_all = P->single_all.data(); A.c_nnz = c_nnz.data(); A.c_rows = c_rows.data(); A.c_tr = c_tr.data(); A.local_of = local_of.data();
+  for (uint64_t e = 0; e < n_ecs; e++) step_rows_a(e, A);
+  for (uint64_t t = 0; t < T; t++) step_tr_b(t, A);
+  for (uint64_t t = 0; t < T; t++) cum[t + 1] = cum[t] + c_nnz[t];
+  A.cum_nnz = cum.data();
+  const uint64_t NZ = cum[T];
+  const uint32_t ng = NZ ? (uint32_t)((NZ - 1) / A.target_nnz + 1) : 0;
+  P->n_groups = ng; A.n_groups = ng;
+  std::vector<uint32_t> g_rows(ng, 0), g_tr(ng, 0), g_nnz(ng, 0), row_fill(ng, 0), tr_fill(ng, 0);
+  A.g_rows = g_rows.data(); A.g_tr = g_tr.data(); A.g_nnz = g_nnz.data(); A.row_fill = row_fill.data(); A.tr_fill = tr_fill.data();
+  for (uint64_t r = 0; r < T; r++) step_root_d(r, A);
+  P->row_base.assign(ng + 1, 0); P->tr_base.assign(ng + 1, 0); P->nz_base.assign(ng + 1, 0);
+  P->max_group_bytes = 0;
+  for (uint32_t g = 0; g < ng; g++) {
+    if (g_rows[g] > 65535 || g_tr[g] > 65535 || group_bytes(g_nnz[g], g_rows[g], g_tr[g]) > budget_bytes) return 1;
+    P->max_group_bytes = std::max(P->max_group_bytes, group_bytes(g_nnz[g], g_rows[g], g_tr[g]));
+    P->row_base[g + 1] = P->row_base[g] + g_rows[g]; P->tr_base[g + 1] = P->tr_base[g] + g_tr[g]; P->nz_base[g + 1] = P->nz_base[g] + g_nnz[g];
+  }
+  A.row_base = P->row_base.data(); A.tr_base = P->tr_base.data(); A.nz_base = P->nz_base.data();
+  const uint64_t R = ng ? P->row_base[ng] : 0, M = ng ? P->tr_base[ng] : 0;
+  P->tr_id.assign(M, 0); P->single.assign(M, 0.0); P->eff.assign(M, 0.0); P->cw.assign(R, 0);
+  P->row_ptr.assign(R + ng, 0); P->row_tr.assign(NZ, 0); P->col_ptr.assign(M + ng, 0); P->col_row.assign(NZ, 0);
+  std::vector<uint32_t> row_new(n_ecs, 0), len_new(R, 0), col_cnt(M, 0), col_fill(M, 0); std::vector<uint64_t> row_abs, col_abs;
+  A.row_new = row_new.data(); A.len_new = len_new.data(); A.col_cnt = col_cnt.data(); A.col_fill = col_fill.data();
+  A.row_ptr = P->row_ptr.data(); A.row_tr = P->row_tr.data(); A.col_ptr = P->col_ptr.data(); A.col_row = P->col_row.data();
+  A.cw = P->cw.data(); A.single = P->single.data(); A.eff_m = P->eff.data(); A.tr_id = P->tr_id.data();
+  for (uint64_t t = 0; t < T; t++) step_tr_f(t, A);
+  for (uint64_t e = 0; e < n_ecs; e++) step_rows_g(e, A);
+  scan32(len_new, R, row_abs); A.row_abs = row_abs.data();
+  for (uint64_t e = 0; e < n_ecs; e++) step_rows_i(e, A);
+  scan32(col_cnt, M, col_abs); A.col_abs = col_abs.data();
+  for (uint64_t m = 0; m < M; m++) step_m_j(m, eml_group_of_slot(A, m), A);   // (as the kernel does: the group by binary search)
+  for (uint64_t g = 0; g < ng; g++) step_group_j(g, A);
+  for (uint64_t e = 0; e < n_ecs; e++) step_rows_k(e, A);
+  return 0;
+}
+
 // ---- serial CPU backend: the groups one after the other, "one thread" each ------------------------------------------
 struct CpuBackend {
   const Plan& P;

@@ -8,10 +8,11 @@ extern "C" {
 // returns 0 = ran, 1 = not applicable (a component exceeds the budget / the 16-bit local index range)
 int emu_em_local(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs, const double* eff, uint64_t T,
                  uint64_t budget_bytes, uint64_t target_nnz, int n_iter, int min_rounds, int chunk, double* alpha, double* abz,
-                 int32_t* rounds, uint32_t* n_groups, uint64_t* max_group_bytes) {
+                 int32_t* rounds, uint32_t* n_groups, uint64_t* max_group_bytes, int builder) {
   using namespace kamd_em_local;
-  Plan P;
-  if (int rc = build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return rc;
+  Plan P;   // builder 0: the host reference (greedy packing), 1: the data-parallel steps the device set-up is made of
+  if (int rc = builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)
+                       : build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return rc;
   *n_groups = P.n_groups; *max_group_bytes = P.max_group_bytes;
   CpuBackend B(P);
   *rounds = run(B, P, n_iter, min_rounds, chunk, alpha, abz);
@@ -20,10 +21,11 @@ int emu_em_local(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t*
 // the plan must hold exactly the rows with >= 2 transcripts (as sets, with their counts), both directions must describe
 // the same matrix, every group must respect the budget; returns 0 = consistent, > 0 = which check failed
 int emu_em_local_check_plan(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs, const double* eff,
-                            uint64_t T, uint64_t budget_bytes, uint64_t target_nnz) {
+                            uint64_t T, uint64_t budget_bytes, uint64_t target_nnz, int builder) {
   using namespace kamd_em_local;
   Plan P;
-  if (build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return -1;
+  if (builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)
+              : build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return -1;
   std::map<std::vector<uint32_t>, uint64_t> want, got;
   for (uint64_t e = 0; e < n_ecs; e++) {
     if (ec_off[e + 1] - ec_off[e] < 2) continue;

@@ -32,7 +32,7 @@ def _gene_matrix(n_genes, seed, zero_frac=0.05):
     return off, ids, cnt, rng.uniform(150, 3000, T), T
 
 
-def _run(off, ids, cnt, eff, T, budget=64 * 1024, target=1 << 40, chunk=64, n_iter=10000, min_rounds=50):
+def _run(off, ids, cnt, eff, T, budget=64 * 1024, target=1 << 40, chunk=64, n_iter=10000, min_rounds=50, builder=0):
     L = E.lib()
     alpha = np.zeros(T); abz = np.zeros(T)
     rounds = C.c_int32(0); ng = C.c_uint32(0); mb = C.c_uint64(0)
@@ -40,22 +40,31 @@ def _run(off, ids, cnt, eff, T, budget=64 * 1024, target=1 << 40, chunk=64, n_it
     off = np.ascontiguousarray(off, np.uint64); ids = np.ascontiguousarray(ids, np.uint32); cnt = np.ascontiguousarray(cnt, np.uint32)
     eff = np.ascontiguousarray(eff, np.float64)
     rc = L.emu_em_local(p(off), p(ids), p(cnt), C.c_uint64(len(cnt)), p(eff), C.c_uint64(T), C.c_uint64(budget), C.c_uint64(target),
-                        int(n_iter), int(min_rounds), int(chunk), p(alpha), p(abz), C.byref(rounds), C.byref(ng), C.byref(mb))
+                        int(n_iter), int(min_rounds), int(chunk), p(alpha), p(abz), C.byref(rounds), C.byref(ng), C.byref(mb), int(builder))
     return rc, alpha, abz, rounds.value, ng.value, mb.value
 
 
-def _check_plan(off, ids, cnt, eff, T, budget, target):
+def _check_plan(off, ids, cnt, eff, T, budget, target, builder=0):
     L = E.lib()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     off = np.ascontiguousarray(off, np.uint64); ids = np.ascontiguousarray(ids, np.uint32); cnt = np.ascontiguousarray(cnt, np.uint32)
     eff = np.ascontiguousarray(eff, np.float64)
-    return L.emu_em_local_check_plan(p(off), p(ids), p(cnt), C.c_uint64(len(cnt)), p(eff), C.c_uint64(T), C.c_uint64(budget), C.c_uint64(target))
+    return L.emu_em_local_check_plan(p(off), p(ids), p(cnt), C.c_uint64(len(cnt)), p(eff), C.c_uint64(T), C.c_uint64(budget), C.c_uint64(target), int(builder))
 
 
 @pytest.mark.parametrize("budget,target", [(1 << 30, 1 << 40), (16 * 1024, 1 << 40), (1 << 30, 300), (6 * 1024, 150)])
 def test_plan_holds_the_matrix(budget, target):
     off, ids, cnt, eff, T = _gene_matrix(200, 11)
     assert _check_plan(off, ids, cnt, eff, T, budget, target) == 0
+
+
+@pytest.mark.parametrize("budget,target", [(1 << 30, 1 << 40), (1 << 30, 300), (12 * 1024, 150), (1 << 30, 1)])
+def test_plan_built_by_the_data_parallel_steps(budget, target):
+    """the steps the device set-up is made of (one index each, plain stores + atomic adds, scans in between), run serially"""
+    off, ids, cnt, eff, T = _gene_matrix(200, 11)
+    assert _check_plan(off, ids, cnt, eff, T, budget, target, builder=1) == 0
+    # a budget that some group cannot meet is reported, not violated
+    assert _check_plan(off, ids, cnt, eff, T, 2 * 1024, 1 << 40, builder=1) == -1
 
 
 @pytest.mark.parametrize("budget,target,chunk", [(1 << 30, 1 << 40, 64), (16 * 1024, 1 << 40, 64), (1 << 30, 400, 7), (8 * 1024, 200, 1),
@@ -67,6 +76,9 @@ def test_local_em_equals_the_oracle(budget, target, chunk):
     assert rc == 0 and mb <= budget
     if target < 1000:
         assert ng > 10                                     # really many groups
+        rc2, a2, abz2, r2, ng2, _ = _run(off, ids, cnt, eff, T, 1 << 30, target, chunk, builder=1)   # the other plan builder
+        assert rc2 == 0 and r2 == r_o and ng2 > 10
+        common.assert_abundance_close(a2, a_o, "alpha (plan from the data-parallel steps)", rel=1e-9)
     assert r == r_o
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
     tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
@@ -104,7 +116,7 @@ def test_local_em_on_the_golden_ec_matrices(case, variant):
     eoff, eids, ecnt = res.ec_off, res.ec_ids, res.counts
     eff = exp["eff"]
     a_o, abz_o, r_o = O.em_run(eoff, eids, ecnt, eff, len(eff))
-    rc, a, abz, r, ng, _ = _run(eoff, eids, ecnt, eff, len(eff), target=64, chunk=32)
+    rc, a, abz, r, ng, _ = _run(eoff, eids, ecnt, eff, len(eff), target=64, chunk=32, builder=1)
     assert rc == 0 and r == r_o
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
     common.assert_abundance_close(a, exp["alpha"], "alpha vs the reference")       # 1e-4, like every other path
