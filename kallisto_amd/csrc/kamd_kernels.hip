@@ -1718,6 +1718,7 @@ struct kamd_ctx {
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
   DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
+  DBuf eml_tmp;                  // component-local EM (experimental): set-up scratch
   DBuf fld_tl, fld_card, fld_scratch, fld_items;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
@@ -1866,7 +1867,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -2646,11 +2647,31 @@ __global__ __launch_bounds__(EML_BLOCK) void k_em_local(EmLocalDev P, double* al
   }
   for (u32 i = tid; i < nT; i += EML_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
 }
+__global__ void k_eml_init(double* alpha, double* a, const double* __restrict__ eff_m, u64 M, double a0) {   // alpha_ = 1/T (:38)
+  const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < M) { alpha[m] = a0; a[m] = a0 / eff_m[m]; }
+}
+// the data-parallel steps of kamd_em_local.h, one thread per index
+template <int S>
+__global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if constexpr (S == 0) kamd_em_local::step_rows_a(i, A);
+  else if constexpr (S == 1) kamd_em_local::step_tr_b(i, A);
+  else if constexpr (S == 2) kamd_em_local::step_root_d(i, A);
+  else if constexpr (S == 3) kamd_em_local::step_tr_f(i, A);
+  else if constexpr (S == 4) kamd_em_local::step_rows_g(i, A);
+  else if constexpr (S == 5) kamd_em_local::step_rows_i(i, A);
+  else if constexpr (S == 6) kamd_em_local::step_m_j(i, kamd_em_local::eml_group_of_slot(A, i), A);
+  else if constexpr (S == 7) kamd_em_local::step_group_j(i, A);
+  else kamd_em_local::step_rows_k(i, A);
+}
 // the backend of kamd_em_local::run on the device; every method returns through `err` (0 = ok)
 struct EmLocalGpu {
   kamd_ctx* c; const kamd_em_local::Plan& P; EmLocalDev dev{}; u64 M = 0; size_t lds = 0;
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
   std::vector<double> h_alpha; int err = 0; int hist_cap = 0;
+  bool dev_ready = false;   // `dev` already points at a plan built on the device (em_local_setup_device)
   EmLocalGpu(kamd_ctx* ctx, const kamd_em_local::Plan& p) : c(ctx), P(p) {}
   int setup(int chunk);
   void checkpoint() {
@@ -2682,52 +2703,162 @@ int EmLocalGpu::setup(int chunk) {
   const u32 ng = P.n_groups;
   M = P.tr_base[ng];
   const u64 R = P.row_base[ng], NZ = P.nz_base[ng];
-  Carver cv;
-  const size_t o_rb = cv.take((ng + 1) * 4), o_tb = cv.take((ng + 1) * 4), o_zb = cv.take((ng + 1) * 8);
-  const size_t o_rp = cv.take((R + ng) * 4), o_cp = cv.take((M + ng) * 4), o_rt = cv.take(NZ * 2 + 2), o_cr = cv.take(NZ * 2 + 2);
-  const size_t o_cw = cv.take(R * 8 + 8), o_sg = cv.take(M * 8 + 8), o_ef = cv.take(M * 8 + 8);
-  if (int rc = c->pm_a.ensure(cv.off, 0, c->stream)) return rc;
-  char* b = (char*)c->pm_a.p;
-  auto up = [&](size_t o, const void* src, size_t bytes) -> int { if (bytes) HIPC(hipMemcpyAsync(b + o, src, bytes, hipMemcpyHostToDevice, c->stream)); return 0; };
-  if (up(o_rb, P.row_base.data(), (ng + 1) * 4) || up(o_tb, P.tr_base.data(), (ng + 1) * 4) || up(o_zb, P.nz_base.data(), (ng + 1) * 8) ||
-      up(o_rp, P.row_ptr.data(), (R + ng) * 4) || up(o_cp, P.col_ptr.data(), (M + ng) * 4) || up(o_rt, P.row_tr.data(), NZ * 2) ||
-      up(o_cr, P.col_row.data(), NZ * 2) || up(o_cw, P.cw.data(), R * 8) || up(o_sg, P.single.data(), M * 8) || up(o_ef, P.eff.data(), M * 8))
-    return -104;
-  dev = EmLocalDev{(const u32*)(b + o_rb), (const u32*)(b + o_tb), (const u64*)(b + o_zb), (const u32*)(b + o_rp), (const u32*)(b + o_cp),
-                   (const uint16_t*)(b + o_rt), (const uint16_t*)(b + o_cr), (const u64*)(b + o_cw), (const double*)(b + o_sg),
-                   (const double*)(b + o_ef)};
+  if (!dev_ready) {   // upload the host-built plan
+    Carver cv;
+    const size_t o_rb = cv.take((ng + 1) * 4), o_tb = cv.take((ng + 1) * 4), o_zb = cv.take((ng + 1) * 8);
+    const size_t o_rp = cv.take((R + ng) * 4), o_cp = cv.take((M + ng) * 4), o_rt = cv.take(NZ * 2 + 2), o_cr = cv.take(NZ * 2 + 2);
+    const size_t o_cw = cv.take(R * 8 + 8), o_sg = cv.take(M * 8 + 8), o_ef = cv.take(M * 8 + 8);
+    if (int rc = c->pm_a.ensure(cv.off, 0, c->stream)) return rc;
+    char* b = (char*)c->pm_a.p;
+    auto up = [&](size_t o, const void* src, size_t bytes) -> int { if (bytes) HIPC(hipMemcpyAsync(b + o, src, bytes, hipMemcpyHostToDevice, c->stream)); return 0; };
+    if (up(o_rb, P.row_base.data(), (ng + 1) * 4) || up(o_tb, P.tr_base.data(), (ng + 1) * 4) || up(o_zb, P.nz_base.data(), (ng + 1) * 8) ||
+        up(o_rp, P.row_ptr.data(), (R + ng) * 4) || up(o_cp, P.col_ptr.data(), (M + ng) * 4) || up(o_rt, P.row_tr.data(), NZ * 2) ||
+        up(o_cr, P.col_row.data(), NZ * 2) || up(o_cw, P.cw.data(), R * 8) || up(o_sg, P.single.data(), M * 8) || up(o_ef, P.eff.data(), M * 8))
+      return -104;
+    dev = EmLocalDev{(const u32*)(b + o_rb), (const u32*)(b + o_tb), (const u64*)(b + o_zb), (const u32*)(b + o_rp), (const u32*)(b + o_cp),
+                     (const uint16_t*)(b + o_rt), (const uint16_t*)(b + o_cr), (const u64*)(b + o_cw), (const double*)(b + o_sg),
+                     (const double*)(b + o_ef)};
+  }
   Carver sv;
   const size_t o_al = sv.take(M * 8 + 8), o_a = sv.take(M * 8 + 8), o_cka = sv.take(M * 8 + 8), o_ckb = sv.take(M * 8 + 8), o_h = sv.take((size_t)chunk * 4 + 8);
   if (int rc = c->pm_b.ensure(sv.off, 0, c->stream)) return rc;
   char* sb = (char*)c->pm_b.p;
   d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = (double*)(sb + o_cka); d_ck_a = (double*)(sb + o_ckb); d_hist = (int*)(sb + o_h);
-  std::vector<double> al(M, 1.0 / (double)P.T), av(M);      // alpha_ = 1/T for every transcript (:38)
-  for (u64 m = 0; m < M; m++) av[m] = al[m] / P.eff[m];
-  if (M) { HIPC(hipMemcpyAsync(d_alpha, al.data(), M * 8, hipMemcpyHostToDevice, c->stream)); HIPC(hipMemcpyAsync(d_a, av.data(), M * 8, hipMemcpyHostToDevice, c->stream)); }
-  HIPC(hipStreamSynchronize(c->stream));                    // the staging vectors are locals
+  if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, dev.eff, M, 1.0 / (double)P.T);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(c->stream));                    // (also: the uploads above read host vectors)
   lds = (size_t)P.max_group_bytes + 16;
   HIPC(hipFuncSetAttribute((const void*)k_em_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
+// The plan built on the device (KAMD_EM_LOCAL=2): component labels by the kernels the partitioned EM uses, then the steps of
+// kamd_em_local.h with scans in between.  The host only sees the per-group sizes (budget check, bases) and, for the final
+// scatter, tr_id and the singleton counts.  0 = ok (P holds the host part, *dev the device part), 1 = not applicable.
+int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
+                          const double* eff_lens, u64 T, u64 budget, u64 target, kamd_em_local::Plan* P, EmLocalDev* dev) {
+  namespace L = kamd_em_local;
+  if (nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
+  // component labels (smallest transcript id of the component): min-label propagation + pointer jumping
+  if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
+  for (int it = 0;; it++) {
+    HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_cc_rows, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, c->pt_label.as<u32>(), (int*)c->pt_hist.p);
+    hipLaunchKernelGGL(k_cc_jump, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
+    int changed = 0;
+    HIPC(hipMemcpyAsync(&changed, c->pt_hist.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (!changed) break;
+    if (it > 10000) return kamd::fail(-101, "kamd_em_run: component labelling did not converge");
+  }
+  // scratch: per transcript / per root ...
+  Carver t1;
+  const size_t o_inm = t1.take(T + 8), o_sall = t1.take(T * 8 + 8), o_cn = t1.take(T * 4 + 8), o_cr = t1.take(T * 4 + 8), o_ct = t1.take(T * 4 + 8);
+  const size_t o_cum = t1.take((T + 2) * 8), o_loc = t1.take(T * 4 + 8), o_eff = t1.take(T * 8 + 8), o_rnew = t1.take(n_ecs * 4 + 8);
+  // ... and per group: at most nnz / target + 2 groups (the real number is known after the scan below)
+  const u64 ng_max = nnz / std::max<u64>(1, target) + 2;
+  const size_t o_gr = t1.take(ng_max * 4 + 8), o_gt = t1.take(ng_max * 4 + 8), o_gn = t1.take(ng_max * 4 + 8), o_rf = t1.take(ng_max * 4 + 8),
+               o_tf = t1.take(ng_max * 4 + 8);
+  if (int rc = c->eml_tmp.ensure(t1.off, 0, c->stream)) return rc;
+  char* tb = (char*)c->eml_tmp.p;
+  HIPC(hipMemsetAsync(tb, 0, o_cum, c->stream));   // in_multi, single_all, c_nnz, c_rows, c_tr
+  HIPC(hipMemcpyAsync(tb + o_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
+  L::BuildArgs A{};
+  A.ec_off = (const uint64_t*)d_ec_off; A.ec_ids = d_ec_ids; A.counts = d_counts; A.wcounts = d_wcounts; A.n_ecs = n_ecs;
+  A.eff = (const double*)(tb + o_eff); A.T = T; A.label = c->pt_label.as<u32>(); A.target_nnz = std::max<u64>(1, target);
+  A.in_multi = (uint8_t*)(tb + o_inm); A.single_all = (double*)(tb + o_sall); A.c_nnz = (u32*)(tb + o_cn); A.c_rows = (u32*)(tb + o_cr);
+  A.c_tr = (u32*)(tb + o_ct); A.cum_nnz = (const uint64_t*)(tb + o_cum); A.local_of = (u32*)(tb + o_loc); A.row_new = (u32*)(tb + o_rnew);
+  hipLaunchKernelGGL(k_eml_step<0>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  hipLaunchKernelGGL(k_eml_step<1>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
+  if (int rc = exclusive_scan(c, A.c_nnz, T, (u64*)(tb + o_cum), (u64*)(tb + o_cum) + T)) return rc;
+  u64 NZ = 0;
+  HIPC(hipMemcpyAsync(&NZ, (u64*)(tb + o_cum) + T, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (NZ == 0) return 1;
+  const u32 ng = (u32)((NZ - 1) / A.target_nnz + 1);
+  if ((u64)ng > ng_max) return kamd::fail(-105, "kamd_em_run: component-local EM: more groups than entries allow");
+  A.n_groups = ng;
+  HIPC(hipMemsetAsync(tb + o_gr, 0, t1.off - o_gr, c->stream));
+  A.g_rows = (u32*)(tb + o_gr); A.g_tr = (u32*)(tb + o_gt); A.g_nnz = (u32*)(tb + o_gn); A.row_fill = (u32*)(tb + o_rf); A.tr_fill = (u32*)(tb + o_tf);
+  hipLaunchKernelGGL(k_eml_step<2>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
+  std::vector<u32> g_rows(ng), g_tr(ng), g_nnz(ng);
+  HIPC(hipMemcpyAsync(g_rows.data(), A.g_rows, ng * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(g_tr.data(), A.g_tr, ng * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(g_nnz.data(), A.g_nnz, ng * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  P->n_groups = ng; P->T = T; P->max_group_bytes = 0;
+  P->row_base.assign(ng + 1, 0); P->tr_base.assign(ng + 1, 0); P->nz_base.assign(ng + 1, 0);
+  for (u32 g = 0; g < ng; g++) {
+    const u64 gb = L::group_bytes(g_nnz[g], g_rows[g], g_tr[g]);
+    if (g_rows[g] > 65535 || g_tr[g] > 65535 || gb > budget) return 1;
+    P->max_group_bytes = std::max<uint64_t>(P->max_group_bytes, gb);
+    P->row_base[g + 1] = P->row_base[g] + g_rows[g]; P->tr_base[g + 1] = P->tr_base[g] + g_tr[g]; P->nz_base[g + 1] = P->nz_base[g] + g_nnz[g];
+  }
+  const u64 R = P->row_base[ng], M = P->tr_base[ng];
+  if (P->nz_base[ng] != NZ) return kamd::fail(-105, "kamd_em_run: component-local EM: group sizes do not add up");
+  // the plan's arrays + the scratch that depends on R and M
+  Carver pv;
+  const size_t p_rb = pv.take((ng + 1) * 4), p_tb = pv.take((ng + 1) * 4), p_zb = pv.take((ng + 1) * 8);
+  const size_t p_rp = pv.take((R + ng) * 4 + 8), p_cp = pv.take((M + ng) * 4 + 8), p_rt = pv.take(NZ * 2 + 8), p_cr = pv.take(NZ * 2 + 8);
+  const size_t p_cw = pv.take(R * 8 + 8), p_sg = pv.take(M * 8 + 8), p_ef = pv.take(M * 8 + 8), p_id = pv.take(M * 4 + 8);
+  const size_t p_len = pv.take(R * 4 + 8), p_rabs = pv.take((R + 2) * 8), p_cc = pv.take(M * 4 + 8), p_cf = pv.take(M * 4 + 8), p_cabs = pv.take((M + 2) * 8);
+  if (int rc = c->pm_a.ensure(pv.off, 0, c->stream)) return rc;
+  char* pb = (char*)c->pm_a.p;
+  HIPC(hipMemcpyAsync(pb + p_rb, P->row_base.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemcpyAsync(pb + p_tb, P->tr_base.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemcpyAsync(pb + p_zb, P->nz_base.data(), (ng + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemsetAsync(pb + p_cc, 0, p_cabs - p_cc, c->stream));   // col_cnt, col_fill
+  A.row_base = (const u32*)(pb + p_rb); A.tr_base = (const u32*)(pb + p_tb); A.nz_base = (const uint64_t*)(pb + p_zb);
+  A.row_ptr = (u32*)(pb + p_rp); A.col_ptr = (u32*)(pb + p_cp); A.row_tr = (uint16_t*)(pb + p_rt); A.col_row = (uint16_t*)(pb + p_cr);
+  A.cw = (uint64_t*)(pb + p_cw); A.single = (double*)(pb + p_sg); A.eff_m = (double*)(pb + p_ef); A.tr_id = (u32*)(pb + p_id);
+  A.len_new = (u32*)(pb + p_len); A.row_abs = (const uint64_t*)(pb + p_rabs); A.col_cnt = (u32*)(pb + p_cc); A.col_fill = (u32*)(pb + p_cf);
+  A.col_abs = (const uint64_t*)(pb + p_cabs);
+  hipLaunchKernelGGL(k_eml_step<3>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
+  hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  if (int rc = exclusive_scan(c, A.len_new, R, (u64*)(pb + p_rabs), (u64*)(pb + p_rabs) + R)) return rc;
+  hipLaunchKernelGGL(k_eml_step<5>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  if (int rc = exclusive_scan(c, A.col_cnt, M, (u64*)(pb + p_cabs), (u64*)(pb + p_cabs) + M)) return rc;
+  hipLaunchKernelGGL(k_eml_step<6>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
+  hipLaunchKernelGGL(k_eml_step<7>, dim3(grid_for(ng, BLOCK)), dim3(BLOCK), 0, c->stream, A, (u64)ng);
+  hipLaunchKernelGGL(k_eml_step<8>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  HIPC(hipGetLastError());
+  // what the host needs for the final scatter
+  P->tr_id.resize(M); P->single_all.resize(T);
+  if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), A.tr_id, M * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(P->single_all.data(), A.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  *dev = EmLocalDev{(const u32*)(pb + p_rb), (const u32*)(pb + p_tb), (const u64*)(pb + p_zb), (const u32*)(pb + p_rp), (const u32*)(pb + p_cp),
+                    (const uint16_t*)(pb + p_rt), (const uint16_t*)(pb + p_cr), (const u64*)(pb + p_cw), (const double*)(pb + p_sg),
+                    (const double*)(pb + p_ef)};
+  return 0;
+}
 // 0 = done, 1 = not applicable (the caller takes the streamed form), < 0 = error
 int em_local_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                        const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds) {
-  std::vector<uint64_t> off(n_ecs + 1); std::vector<u32> ids(std::max<u64>(nnz, 1)), cnt(n_ecs), wcn(n_ecs);
-  HIPC(hipMemcpyAsync(off.data(), d_ec_off, (n_ecs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-  if (nnz) HIPC(hipMemcpyAsync(ids.data(), d_ec_ids, nnz * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipMemcpyAsync(cnt.data(), d_counts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipMemcpyAsync(wcn.data(), d_wcounts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+                        const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds, int level) {
   if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
   kamd_em_local::Plan P;
   const u64 budget = 150 * 1024;                                          // of the CU's 160 KB
   const u64 target = std::max<u64>(2048, (nnz + (u64)c->n_cus * 4 - 1) / ((u64)c->n_cus * 4));   // ~4 groups per CU
-  if (kamd_em_local::build_plan_host(off.data(), ids.data(), cnt.data(), wcn.data(), n_ecs, eff_lens, T, budget, target, &P)) return 1;
+  EmLocalDev dev{};
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  if (level >= 2) {   // the plan built on the device
+    const int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, budget, target, &P, &dev);
+    if (rc) return rc;
+  } else {            // bring-up: the plan built on the host from a download of the CSR
+    std::vector<uint64_t> off(n_ecs + 1); std::vector<u32> ids(std::max<u64>(nnz, 1)), cnt(n_ecs), wcn(n_ecs);
+    HIPC(hipMemcpyAsync(off.data(), d_ec_off, (n_ecs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (nnz) HIPC(hipMemcpyAsync(ids.data(), d_ec_ids, nnz * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(cnt.data(), d_counts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(wcn.data(), d_wcounts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (kamd_em_local::build_plan_host(off.data(), ids.data(), cnt.data(), wcn.data(), n_ecs, eff_lens, T, budget, target, &P)) return 1;
+  }
   if (P.n_groups == 0) return 1;
   const int chunk = 64;
   EmLocalGpu B(c, P);
+  if (level >= 2) { B.dev = dev; B.dev_ready = true; }
   if (int rc = B.setup(chunk)) return rc;
-  HIPC(hipEventRecord(c->ev0, c->stream));
   const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
   HIPC(hipEventRecord(c->ev1, c->stream));
@@ -2806,7 +2937,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     const char* el = getenv("KAMD_EM_LOCAL");
     if (el && atoi(el) != 0) {
       const int rc = em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
-                                         (int)min_rounds, alpha, alpha_before_zeroes, rounds);
+                                         (int)min_rounds, alpha, alpha_before_zeroes, rounds, atoi(el));
       if (rc <= 0) return rc;   // 1 = not applicable: fall through to the streamed form
     }
   }

@@ -191,7 +191,7 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local2"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The streamed EM form (default and forced chunk sizes: 64 x 8 entries makes the long rows / hub columns span many
     chunks -> fix-up launches; "wK": the general pass for chunks with more segment ends than LDS slots, forced) and the CSR
@@ -199,13 +199,14 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     import torch
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
-    if k == "local":
+    if k in ("local", "local2"):
         # the component-local form (kamd_em_local.h) is opt-in and has not run on hardware yet: only with KAMD_TEST_EXPERIMENTAL=1
         if os.environ.get("KAMD_TEST_EXPERIMENTAL") != "1":
             pytest.skip("experimental EM form: set KAMD_TEST_EXPERIMENTAL=1")
         off, ids, cnt, eff, T = _gene_csr(300, 7)
         alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
-        monkeypatch.setenv("KAMD_EM_LOCAL", "1")
+        monkeypatch.setenv("KAMD_EM_LOCAL", "1" if k == "local" else "2")   # 1: plan built on the host, 2: on the device
+        k = "local"
     else:
         monkeypatch.delenv("KAMD_EM_LOCAL", raising=False)
     monkeypatch.setenv("KAMD_EM_WINDOWED", "1" if isinstance(k, str) and k[0] == "w" else "0")
