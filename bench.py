@@ -98,8 +98,10 @@ def write_fastq_fast(path, reads: np.ndarray):
 
 
 def cpu_reference_baseline(idx_path, r1: np.ndarray, r2: np.ndarray, threads: int):
-    """Time the unmodified reference on the host cores: `kallisto quant -t threads` on the sample; the clock starts when
-    the index has been loaded (first '[quant]' line after '[index]') and stops at process exit."""
+    """Time the unmodified reference on the host cores: `kallisto quant -t threads` on the sample.  The clock starts when
+    the index has been loaded (the '[quant] running in' line) and stops at process exit; the stage markers the reference
+    prints on stderr split it into pseudoalignment (until the 'finding pseudoalignments ... done' line completes) and EM
+    (until 'the Expectation-Maximization algorithm ran for')."""
     tmp = os.path.join(CACHE, f"cpu_baseline_{os.getpid()}")
     os.makedirs(tmp, exist_ok=True)
     f1, f2 = os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq")
@@ -109,21 +111,52 @@ def cpu_reference_baseline(idx_path, r1: np.ndarray, r2: np.ndarray, threads: in
     cmd = [REF_BIN, "quant", "-i", idx_path, "-o", out, "-t", str(threads), "--plaintext", f1, f2]
     t_start = time.time()
     p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-    t_loaded = None
+    t_loaded = t_aligned = t_em = None
     for raw in p.stderr:
         line = raw.decode(errors="replace")
+        now = time.time()
         if t_loaded is None and line.startswith("[quant] running in"):
-            t_loaded = time.time()
+            t_loaded = now
+        elif t_aligned is None and line.startswith("[quant] finding pseudoalignments"):
+            t_aligned = now
+        elif t_em is None and "Expectation-Maximization algorithm ran for" in line:
+            t_em = now
     p.wait()
     t_end = time.time()
     if p.returncode != 0:
         raise RuntimeError("reference kallisto quant failed")
     info = json.load(open(os.path.join(out, "run_info.json")))
-    est = np.loadtxt(os.path.join(out, "abundance.tsv"), skiprows=1, usecols=(3,))
     shutil.rmtree(tmp, ignore_errors=True)
     t_loaded = t_loaded or t_start
-    return {"seconds": t_end - t_loaded, "index_load_s": t_loaded - t_start, "n_processed": info["n_processed"],
-            "n_pseudoaligned": info["n_pseudoaligned"], "n_unique": info["n_unique"], "est_counts": est}
+    t_aligned = t_aligned or t_loaded
+    t_em = t_em or t_end
+    return {"seconds": t_end - t_loaded, "index_load_s": t_loaded - t_start, "pseudoalign_s": t_aligned - t_loaded,
+            "em_s": t_em - t_aligned, "n_processed": info["n_processed"], "n_pseudoaligned": info["n_pseudoaligned"],
+            "n_unique": info["n_unique"]}
+
+
+def reference_parity(idx_path, r1: np.ndarray, r2: np.ndarray, res):
+    """The GPU result `res` (kallisto_amd.quant on exactly these pairs, ECs downloaded) against the unmodified reference run
+    deterministically (`-t 1`: the fragment-length sample is the first 10 000 qualifying pairs in input order,
+    src/ProcessReads.cpp:981-1017,1174-1181) through oracle/_ref/dump_ec, which prints what the CLI never does: the EC
+    multiset, flens, eff_lens and alpha of src/main.cpp:2632-2689."""
+    from oracle import oracle as O
+    tmp = os.path.join(CACHE, f"ref_parity_{os.getpid()}")
+    os.makedirs(tmp, exist_ok=True)
+    try:
+        f1, f2 = os.path.join(tmp, "p_1.fq"), os.path.join(tmp, "p_2.fq")
+        write_fastq_fast(f1, r1)
+        write_fastq_fast(f2, r2)
+        t0 = time.time()
+        ref = O.ref_dump_quant(idx_path, [f1, f2], threads=1)
+        rep = O.ref_parity_report(ref, res.ecs.multiset(), res.flens, res.eff_lens, res.est_counts, res.alpha_before_zeroes)
+        rep["sample_pairs"] = int(r1.shape[0])
+        rep["reference_seconds"] = round(time.time() - t0, 1)
+        rep["n_pseudoaligned"] = [int(res.n_pseudoaligned), int(sum(ref["ecs"].values()))]
+        rep["em_rounds_gpu"] = int(res.em_rounds)
+        return rep
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -136,6 +169,8 @@ def main():
     ap.add_argument("--genes", type=int, default=None, help="scale of the synthetic transcriptome (default: full config)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs given to the CPU reference (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=200_000,
+                    help="pairs of the CPU sample that also go through the reference at -t 1 for the parity gate")
     ap.add_argument("--bootstraps", type=int, default=0,
                     help="BASELINE config #5: also time B bootstrap replicates (multinomial resample + EM), split over the ranks")
     args = ap.parse_args()
@@ -328,55 +363,34 @@ def main():
                     out["roofline"]["traffic_source"] = out["roofline_kernel_a"]["traffic_source"] = tj.get("source")
             except Exception:
                 pass
-    # ---- CPU baseline (rank 0, N=1 only) + parity of the GPU path against it on the same sample ----
+    # ---- CPU baseline (rank 0, N=1 only): the reference at -t <cores> for the timing; parity against the reference at -t 1 ----
     if rank == 0 and world == 1 and sample is not None:
         threads = min(os.cpu_count() or 1, 64)
         k = sample[0].shape[0]
         log(f"CPU baseline: reference `kallisto quant -t {threads}` on the first {k} pairs ...")
         try:
             cb = cpu_reference_baseline(idx_path, sample[0], sample[1], threads)
-            ctx.reset()
-            sres = ka.quant(ctx, opts, [(words[:k * 2 * rec], lens[:2 * k], k, L)], download_ecs=True)
-            # vs the reference CLI: pseudoaligned / unique read counts must be identical.  est_counts are only compared
-            # for transcripts >= 1000 bp: at -t>1 the reference's fragment-length sample is thread-schedule dependent,
-            # which moves the effective length of short transcripts.
-            long_tr = (index.target_lens >= 1000) & (cb["est_counts"] > 1.0)
-            rel = float(np.max(np.abs(sres.est_counts[long_tr] - cb["est_counts"][long_tr]) / cb["est_counts"][long_tr])) if long_tr.any() else 0.0
             out["cpu_baseline"] = {"value": round(k / cb["seconds"] / 1e6, 4), "unit": "M read pairs/s", "cores": threads,
                                    "kind": "reference",
                                    "sample": f"first {k} pairs of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
                                              f"--plaintext`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
-                                             f"{cb['index_load_s']:.1f}s excluded)"}
-            out["parity_check"] = {"sample_pairs": k, "n_pseudoaligned_gpu": sres.n_pseudoaligned,
-                                   "n_pseudoaligned_ref": cb["n_pseudoaligned"], "n_unique_gpu": sres.n_unique,
-                                   "n_unique_ref": cb["n_unique"],
-                                   "est_counts_max_rel_err_vs_ref_cli_len_ge_1000": rel,
-                                   "ok": bool(sres.n_pseudoaligned == cb["n_pseudoaligned"] and sres.n_unique == cb["n_unique"])}
-            # vs the oracle (deterministic -t 1 semantics) on a sub-sample: EC multiset bit-exact, est_counts 1e-4
-            try:
-                from oracle import oracle as O
-                ks = min(k, 200_000)
-                oix = O.Index(idx_path)
-                buf, off, ln = O.pack_read_matrix(sample[0][:ks], sample[1][:ks])
-                ores = O.process_reads(oix, O.Opts(1, 0.0, 0.0, 0, 0), buf, off, ln)
-                ctx.reset()
-                gres = ka.quant(ctx, opts, [(words[:ks * 2 * rec], lens[:2 * ks], ks, L)], download_ecs=True)
-                eff_o, _ = O.eff_lens(oix.target_lens, O.mean_frag_lens_trunc(ores.flens))
-                a_o, _, r_o = O.em_run(ores.ec_off, ores.ec_ids, ores.counts, eff_o, oix.num_targets)
-                m = a_o > 1e-7
-                out["parity_check"]["oracle"] = {
-                    "sample_pairs": ks, "ec_multiset_equal": bool(gres.ecs.multiset() == ores.multiset()),
-                    "flens_equal": bool(np.array_equal(gres.flens, ores.flens)), "eff_lens_equal": bool(np.array_equal(gres.eff_lens, eff_o)),
-                    "em_rounds": [gres.em_rounds, r_o],
-                    "est_counts_max_rel_err": float(np.max(np.abs(gres.est_counts[m] - a_o[m]) / a_o[m])) if m.any() else 0.0,
-                    "zero_pattern_equal": bool(np.array_equal(gres.est_counts == 0, a_o == 0))}
-                out["parity_check"]["ok"] = bool(out["parity_check"]["ok"] and out["parity_check"]["oracle"]["ec_multiset_equal"]
-                                                 and out["parity_check"]["oracle"]["flens_equal"])
-            except Exception as e:
-                out["parity_check"]["oracle"] = {"error": str(e)}
+                                             f"{cb['index_load_s']:.1f}s excluded)",
+                                   "pseudoalign_seconds": round(cb["pseudoalign_s"], 2), "em_seconds": round(cb["em_s"], 2),
+                                   "pseudoalign_only_value": round(k / max(cb["pseudoalign_s"], 1e-9) / 1e6, 4),
+                                   "note": "the reference's EM is single-threaded and independent of the read count (it dominates "
+                                           "small samples); pseudoalign_only_value is the rate of the threaded stage alone"}
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "M read pairs/s", "cores": threads, "kind": "reference",
                                    "sample": f"failed: {e}"}
+        # parity gate: the same pairs through the HIP path and through the unmodified reference at -t 1
+        ks = min(k, args.parity_sample)
+        log(f"parity: reference `dump_ec quant -t 1` on the first {ks} pairs ...")
+        try:
+            ctx.reset()
+            gres = ka.quant(ctx, opts, [(words[:ks * 2 * rec], lens[:2 * ks], ks, L)], download_ecs=True)
+            out["parity_check"] = reference_parity(idx_path, sample[0][:ks], sample[1][:ks], gres)
+        except Exception as e:
+            out["parity_check"] = {"ok": False, "error": str(e)}
     if rank == 0:
         if boot is not None:
             out["bootstrap"] = boot

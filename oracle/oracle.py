@@ -316,3 +316,45 @@ def ref_dump_quant(idx: str, files, threads: int = 1, extra=()):
         elif f[0] == "BS":
             res["bs"].setdefault(int(f[1]), []).append(float(f[3]))
     return res
+
+
+def ref_parity_report(ref: dict, ecs_multiset: dict, flens, eff, est_counts, abz=None) -> dict:
+    """Compare one quant result with the unmodified reference's (`ref` = ref_dump_quant(..., threads=1) on the same reads)
+    under the tolerances of SURVEY.md section 8(d) / BASELINE.json: EC multiset identical, fragment-length sample identical,
+    effective lengths identical, est_counts and TPM within 1e-4 relative for TPM >= 1e-3 (below that: 1e-7 absolute), same
+    zero pattern except transcripts whose alpha_before_zeroes is within 1 % of the 1e-8 clamp (EMAlgorithm.h:217-219).
+    `ok` requires all of it."""
+    r_eff = np.array([t[1] for t in ref["tr"]], np.float64)
+    r_alpha = np.array([t[2] for t in ref["tr"]], np.float64)
+    r_abz = np.array([t[3] for t in ref["tr"]], np.float64)
+    eff = np.asarray(eff, np.float64)
+    est = np.asarray(est_counts, np.float64)
+
+    def tpm_of(a, e):
+        w = a / e
+        s = w.sum()
+        return w / s * 1e6 if s > 0 else w
+    r_tpm, g_tpm = tpm_of(r_alpha, r_eff), tpm_of(est, eff)
+    big = r_tpm >= 1e-3
+    rel_cnt = float(np.max(np.abs(est[big] - r_alpha[big]) / r_alpha[big])) if big.any() else 0.0
+    rel_tpm = float(np.max(np.abs(g_tpm[big] - r_tpm[big]) / r_tpm[big])) if big.any() else 0.0
+    abs_small = float(np.max(np.abs(g_tpm[~big] - r_tpm[~big]))) if (~big).any() else 0.0
+    near_clamp = np.abs(r_abz - 1e-8) <= 1e-10
+    zero_ok = bool(np.array_equal((est == 0)[~near_clamp], (r_alpha == 0)[~near_clamp]))
+    rep = {
+        "reference": "oracle/_ref/dump_ec quant -t 1 (unmodified reference: ProcessReads -> FLD -> EMAlgorithm::run)",
+        "n_processed_ref": int(ref["nproc"]),
+        "n_ecs_ref": len(ref["ecs"]), "n_ecs": len(ecs_multiset),
+        "ec_multiset_equal": bool(ecs_multiset == ref["ecs"]),
+        "flens_equal": bool(np.array_equal(np.asarray(flens, np.uint32), ref["flens"])),
+        "eff_length_equal": bool(np.array_equal(eff, r_eff)),
+        "est_counts_max_rel_err_tpm_ge_1e-3": rel_cnt,
+        "tpm_max_rel_err_tpm_ge_1e-3": rel_tpm,
+        "tpm_max_abs_err_below_floor": abs_small,
+        "zero_pattern_equal": zero_ok,
+        "tolerance": "EC multiset / flens / eff_length identical; est_counts and tpm <= 1e-4 relative for tpm >= 1e-3, "
+                     "<= 1e-7 absolute below; same zero pattern",
+    }
+    rep["ok"] = bool(rep["ec_multiset_equal"] and rep["flens_equal"] and rep["eff_length_equal"] and rel_cnt <= 1e-4 and
+                     rel_tpm <= 1e-4 and abs_small <= 1e-7 and zero_ok)
+    return rep

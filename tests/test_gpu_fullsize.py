@@ -5,7 +5,9 @@ conservation laws of the algorithm:
   * sharding linearity: multiset(shard A) + multiset(shard B) == multiset(A u B)  (what the multi-GPU merge relies on);
   * conservation: sum of EC counts == pairs reported pseudoaligned; the EM conserves mass (sum alpha == sum counts),
     TPM sums to 1e6, a bootstrap resample keeps N;
-  * a 20 k-pair prefix against the oracle, bit-exact.
+  * a 20 k-pair prefix against the oracle, bit-exact;
+  * a 200 k-pair prefix against the UNMODIFIED REFERENCE at -t 1 (oracle/_ref/dump_ec, prebuilt, travels with the snapshot):
+    EC multiset, flens and eff_length identical, est_counts / TPM within 1e-4 -- the tolerance BASELINE.json states.
 The index is built by the reference binary (oracle/_ref/kallisto, travels with the repo); skipped when it is absent."""
 import os
 
@@ -38,7 +40,7 @@ def world():
     for s in range(0, n, 2_000_000):
         r1, r2 = sim.draw(2_000_000)
         if s == 0:
-            prefix = (r1[:20000].cpu().numpy(), r2[:20000].cpu().numpy())
+            prefix = (r1[:200_000].cpu().numpy(), r2[:200_000].cpu().numpy())
         w, l = ctx.pack_reads(torch.stack([r1, r2], 1).reshape(-1, L), L)
         words[s * 2 * rec:(s + 2_000_000) * 2 * rec] = w
         lens[2 * s:2 * (s + 2_000_000)] = l
@@ -98,7 +100,7 @@ def test_prefix_against_oracle(world):
     from oracle import oracle as O
     w = world
     ctx, ka = w["ctx"], w["ka"]
-    r1, r2 = w["prefix"]
+    r1, r2 = w["prefix"][0][:20000], w["prefix"][1][:20000]
     k = r1.shape[0]
     ctx.reset()
     res = ka.quant(ctx, ka.QuantOpts(1, 0.0, 0.0, 0, 0), [(w["words"][:k * 2 * w["rec"]], w["lens"][:2 * k], k, w["L"])])
@@ -107,3 +109,21 @@ def test_prefix_against_oracle(world):
     ores = O.process_reads(oix, O.Opts(1, 0.0, 0.0, 0, 0), buf, off, ln)
     assert res.ecs.multiset() == ores.multiset()
     assert np.array_equal(res.flens, ores.flens)
+
+
+def test_prefix_against_reference(world):
+    """BASELINE config #3's index, 200 k pairs: the HIP path against the reference binary itself run deterministically."""
+    import bench
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
+        pytest.skip("oracle/_ref/dump_ec not built")
+    w = world
+    ctx, ka = w["ctx"], w["ka"]
+    r1, r2 = w["prefix"]
+    k = r1.shape[0]
+    ctx.reset()
+    res = ka.quant(ctx, ka.QuantOpts(1, 0.0, 0.0, 0, 0), [(w["words"][:k * 2 * w["rec"]], w["lens"][:2 * k], k, w["L"])])
+    rep = bench.reference_parity(w["idx_path"], r1, r2, res)
+    assert rep["ec_multiset_equal"] and rep["flens_equal"] and rep["eff_length_equal"], rep
+    assert rep["est_counts_max_rel_err_tpm_ge_1e-3"] <= 1e-4 and rep["tpm_max_rel_err_tpm_ge_1e-3"] <= 1e-4, rep
+    assert rep["tpm_max_abs_err_below_floor"] <= 1e-7 and rep["zero_pattern_equal"], rep
+    assert rep["ok"]
