@@ -2647,6 +2647,101 @@ __global__ __launch_bounds__(EML_BLOCK) void k_em_local(EmLocalDev P, double* al
   }
   for (u32 i = tid; i < nT; i += EML_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
 }
+// The same rounds with the work of a group spread over all lanes: a row is summed by 8 lanes, a column by 16 (one DPP row),
+// partial sums meet through row_shl adds; the divisions (g = count / S, a = next / eff) run lane-parallel in a second step
+// over values staged in LDS.  Every wavefront owns a contiguous range of the group's rows and transcripts, so the two steps
+// of a pass only need a wavefront-level fence between them: two block barriers per round.
+constexpr int EML2_BLOCK = 512;
+constexpr int EML_MAX_ROUNDS = 64;
+__device__ __forceinline__ void eml_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(EML2_BLOCK) void k_em_local2(EmLocalDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char eml_smem[];
+  __shared__ int s_hist[EML_MAX_ROUNDS];
+  constexpr int NW = EML2_BLOCK / 64;
+  const u32 g = blockIdx.x, tid = threadIdx.x;
+  const int lane = lane_id(), wv = (int)(tid >> 6);
+  const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
+  const u64 z0 = P.nz_base[g];
+  const u32 nz = (u32)(P.nz_base[g + 1] - z0);
+  double* s_al0 = reinterpret_cast<double*>(eml_smem);
+  double* s_a0 = s_al0 + nT; double* s_al1 = s_a0 + nT; double* s_a1 = s_al1 + nT;
+  double* s_single = s_a1 + nT; double* s_eff = s_single + nT; double* s_g = s_eff + nT;
+  u64* s_cw = reinterpret_cast<u64*>(s_g + nR);
+  u32* s_rowptr = reinterpret_cast<u32*>(s_cw + nR); u32* s_colptr = s_rowptr + nR + 1;
+  uint16_t* s_rowtr = reinterpret_cast<uint16_t*>(s_colptr + nT + 1); uint16_t* s_colrow = s_rowtr + nz;
+  for (u32 i = tid; i < nT; i += EML2_BLOCK) {
+    double al = alpha[t0 + i], av = a[t0 + i];
+    if (clamp && al < 1e-7 / 10.0) { al = 0.0; av = 0.0; }   // the final round reads alpha < alpha_limit / 10 as 0 (:212-221)
+    s_al0[i] = al; s_a0[i] = av; s_single[i] = P.single[t0 + i]; s_eff[i] = P.eff[t0 + i];
+  }
+  for (u32 i = tid; i < nR; i += EML2_BLOCK) s_cw[i] = P.cw[r0 + i];
+  for (u32 i = tid; i <= nR; i += EML2_BLOCK) s_rowptr[i] = P.row_ptr[r0 + g + i];
+  for (u32 i = tid; i <= nT; i += EML2_BLOCK) s_colptr[i] = P.col_ptr[t0 + g + i];
+  for (u32 i = tid; i < nz; i += EML2_BLOCK) { s_rowtr[i] = P.row_tr[z0 + i]; s_colrow[i] = P.col_row[z0 + i]; }
+  if (tid < EML_MAX_ROUNDS) s_hist[tid] = 0;
+  __syncthreads();
+  const u32 rlo = (u32)((u64)nR * wv / NW), rhi = (u32)((u64)nR * (wv + 1) / NW);
+  const u32 tlo = (u32)((u64)nT * wv / NW), thi = (u32)((u64)nT * (wv + 1) / NW);
+  double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
+  for (int r = 0; r < n_rounds; r++) {
+    // rows, step 1: S_e by 8 lanes per row
+    for (u32 rb = rlo; rb < rhi; rb += 8) {
+      const u32 row = rb + (u32)(lane >> 3);
+      const int sub = lane & 7;
+      const bool ok = row < rhi;
+      const u32 b = ok ? s_rowptr[row] : 0u, e = ok ? s_rowptr[row + 1] : 0u;
+      double S = 0.0;
+      for (u32 j = b + sub; j < e; j += 8) S += av[s_rowtr[j]];
+      S += pm_dpp<0x104, 0xF>(S); S += pm_dpp<0x102, 0xF>(S); S += pm_dpp<0x101, 0xF>(S);   // row_shl:4,2,1 -> lanes 0 and 8 of a DPP row
+      if (ok && sub == 0) s_g[row] = S;
+    }
+    eml_wave_fence();
+    // rows, step 2: g_e = count_e / S_e; rows the reference skips get 0 (count 0, :133-135; denom below denorm_min, :156-158)
+    for (u32 row = rlo + (u32)lane; row < rhi; row += 64) {
+      const double S = s_g[row];
+      const u64 w = s_cw[row];
+      const u32 cnt = (u32)w, wc = (u32)(w >> 32);
+      s_g[row] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+    }
+    __syncthreads();
+    // columns, step 1: sum of g over the transcript's rows by 16 lanes, staged in the next-alpha buffer
+    for (u32 tb = tlo; tb < thi; tb += 4) {
+      const u32 t = tb + (u32)(lane >> 4);
+      const int sub = lane & 15;
+      const bool ok = t < thi;
+      const u32 b = ok ? s_colptr[t] : 0u, e = ok ? s_colptr[t + 1] : 0u;
+      double acc = 0.0;
+      for (u32 j = b + sub; j < e; j += 16) acc += s_g[s_colrow[j]];
+      acc += pm_dpp<0x108, 0xF>(acc); acc += pm_dpp<0x104, 0xF>(acc); acc += pm_dpp<0x102, 0xF>(acc); acc += pm_dpp<0x101, 0xF>(acc);
+      if (ok && sub == 0) aln[t] = acc;
+    }
+    eml_wave_fence();
+    // columns, step 2: next_t = single_t + a_t * acc_t and the convergence test of :176-199
+    int ch = 0;
+    for (u32 t = tlo + (u32)lane; t < thi; t += 64) {
+      const double acc = aln[t], at = av[t], cur = al[t];
+      const double nx = s_single[t] + at * acc;
+      if (nx > 1e-2 && (fabs(nx - cur) / nx) > 1e-2) ++ch;
+      aln[t] = nx;
+      avn[t] = nx / s_eff[t];
+    }
+    if (__ballot(ch != 0)) {
+      int wsum = ch;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
+      if (lane == 0) atomicAdd(&s_hist[r], wsum);
+    }
+    __syncthreads();
+    double* t1 = al; al = aln; aln = t1;
+    double* t2 = av; av = avn; avn = t2;
+  }
+  for (u32 i = tid; i < nT; i += EML2_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
+  if (hist && (int)tid < n_rounds && s_hist[tid]) atomicAdd(&hist[tid], s_hist[tid]);
+}
 __global__ void k_eml_init(double* alpha, double* a, const double* __restrict__ eff_m, u64 M, double a0) {   // alpha_ = 1/T (:38)
   const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (m < M) { alpha[m] = a0; a[m] = a0 / eff_m[m]; }
@@ -2672,6 +2767,7 @@ struct EmLocalGpu {
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
   std::vector<double> h_alpha; int err = 0; int hist_cap = 0;
   bool dev_ready = false;   // `dev` already points at a plan built on the device (em_local_setup_device)
+  int kernel = 2;           // 2 = k_em_local2 (lanes share rows / columns), 1 = k_em_local (one thread per row / transcript)
   EmLocalGpu(kamd_ctx* ctx, const kamd_em_local::Plan& p) : c(ctx), P(p) {}
   int setup(int chunk);
   void checkpoint() {
@@ -2687,7 +2783,10 @@ struct EmLocalGpu {
   void run(int n, int clamp, int* hist) {
     if (err || n <= 0) return;
     if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
-    hipLaunchKernelGGL(k_em_local, dim3(P.n_groups), dim3(EML_BLOCK), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    if (kernel == 2 && n <= EML_MAX_ROUNDS)
+      hipLaunchKernelGGL(k_em_local2, dim3(P.n_groups), dim3(EML2_BLOCK), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    else
+      hipLaunchKernelGGL(k_em_local, dim3(P.n_groups), dim3(EML_BLOCK), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
     if (hipGetLastError() != hipSuccess) { err = -104; return; }
     if (hist && (hipMemcpyAsync(hist, d_hist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                  hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
@@ -2729,6 +2828,7 @@ int EmLocalGpu::setup(int chunk) {
   HIPC(hipStreamSynchronize(c->stream));                    // (also: the uploads above read host vectors)
   lds = (size_t)P.max_group_bytes + 16;
   HIPC(hipFuncSetAttribute((const void*)k_em_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPC(hipFuncSetAttribute((const void*)k_em_local2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return 0;
 }
 // The plan built on the device (KAMD_EM_LOCAL=2): component labels by the kernels the partitioned EM uses, then the steps of
@@ -2838,26 +2938,33 @@ int em_local_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, c
                         const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds, int level) {
   if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
   kamd_em_local::Plan P;
-  const u64 budget = 150 * 1024;                                          // of the CU's 160 KB
-  const u64 target = std::max<u64>(2048, (nnz + (u64)c->n_cus * 4 - 1) / ((u64)c->n_cus * 4));   // ~4 groups per CU
+  // two workgroups per CU (LDS: 160 KB): groups of at most 80 KB, cut at nnz / (2 x CUs) entries; if some group comes out
+  // larger (components are not split), the cut is halved
+  const u64 budget = 80 * 1024 - 1024;
   EmLocalDev dev{};
   HIPC(hipEventRecord(c->ev0, c->stream));
-  if (level >= 2) {   // the plan built on the device
-    const int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, budget, target, &P, &dev);
-    if (rc) return rc;
-  } else {            // bring-up: the plan built on the host from a download of the CSR
-    std::vector<uint64_t> off(n_ecs + 1); std::vector<u32> ids(std::max<u64>(nnz, 1)), cnt(n_ecs), wcn(n_ecs);
-    HIPC(hipMemcpyAsync(off.data(), d_ec_off, (n_ecs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    if (nnz) HIPC(hipMemcpyAsync(ids.data(), d_ec_ids, nnz * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipMemcpyAsync(cnt.data(), d_counts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipMemcpyAsync(wcn.data(), d_wcounts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    if (kamd_em_local::build_plan_host(off.data(), ids.data(), cnt.data(), wcn.data(), n_ecs, eff_lens, T, budget, target, &P)) return 1;
+  int prc = 1;
+  for (u64 div = 2; div <= 256 && prc == 1; div *= 2) {
+    const u64 target = std::max<u64>(2048, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
+    if (level >= 2) {   // the plan built on the device
+      prc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, budget, target, &P, &dev);
+    } else {            // bring-up: the plan built on the host from a download of the CSR
+      std::vector<uint64_t> off(n_ecs + 1); std::vector<u32> ids(std::max<u64>(nnz, 1)), cnt(n_ecs), wcn(n_ecs);
+      HIPC(hipMemcpyAsync(off.data(), d_ec_off, (n_ecs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+      if (nnz) HIPC(hipMemcpyAsync(ids.data(), d_ec_ids, nnz * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipMemcpyAsync(cnt.data(), d_counts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipMemcpyAsync(wcn.data(), d_wcounts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      prc = kamd_em_local::build_plan_host(off.data(), ids.data(), cnt.data(), wcn.data(), n_ecs, eff_lens, T, budget, target, &P);
+    }
+    if (target == 2048) break;
   }
+  if (prc) return prc;
   if (P.n_groups == 0) return 1;
   const int chunk = 64;
   EmLocalGpu B(c, P);
   if (level >= 2) { B.dev = dev; B.dev_ready = true; }
+  if (const char* e = getenv("KAMD_EML_KERNEL")) B.kernel = atoi(e) == 1 ? 1 : 2;
   if (int rc = B.setup(chunk)) return rc;
   const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");

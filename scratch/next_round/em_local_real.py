@@ -28,8 +28,9 @@ flens, _ = ctx.fld_from_batch(opts, words, lens, n, L)
 ctx.finalize(download=False)
 eff = A.eff_lens(index.target_lens, A.mean_frag_lens_trunc(flens))
 ref = None
-for level in (0, 1, 2, 2, 0):
+for level, kern in ((0, 2), (1, 1), (2, 1), (2, 2), (2, 2), (0, 2)):
     os.environ["KAMD_EM_LOCAL"] = str(level)
+    os.environ["KAMD_EML_KERNEL"] = str(kern)
     try:
         a, z, r = ctx.em_run(eff)
     except Exception as e:                      # keep going: the other levels are still informative
@@ -39,5 +40,5 @@ for level in (0, 1, 2, 2, 0):
     if ref is None:
         ref = (a, r)
     rel = np.max(np.abs(a - ref[0]) / np.maximum(np.abs(ref[0]), 1e-6))
-    print(f"KAMD_EM_LOCAL={level}: rounds {r} (streamed {ref[1]}) em_ms {p['em_ms']:.2f} form k={p['em_k']} groups/grid {p['em_grid']} "
+    print(f"KAMD_EM_LOCAL={level} kernel={kern}: rounds {r} (streamed {ref[1]}) em_ms {p['em_ms']:.2f} form k={p['em_k']} groups/grid {p['em_grid']} "
           f"max rel diff vs streamed {rel:.2e}", flush=True)
