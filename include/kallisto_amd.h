@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define KAMD_MAX_FRAG_LEN 1000   /* src/MinCollector.h:15 */
-#define KAMD_SLOTS_PER_BUCKET 4  /* 4 x 16 B = one 64-byte line */
+#define KAMD_SLOTS_PER_BUCKET 3  /* 3 x {key 8 B, payload 8 B, text position 4 B} + 4 spare bytes = one 64-byte line */
 
 typedef struct kamd_index kamd_index; /* host-side flattened index (owned by the library) */
 typedef struct kamd_ctx kamd_ctx;     /* one GPU: device copy of the index + work buffers */
@@ -39,9 +39,10 @@ typedef struct kamd_ctx kamd_ctx;     /* one GPU: device copy of the index + wor
 typedef struct {
   int32_t k;
   uint64_t n_kmers, n_unitigs, n_blocks, n_uec, n_ecs, ec_nnz, n_targets, dlist_size;
-  uint64_t n_buckets;             /* home buckets; table holds (n_buckets + pad_buckets) * 4 slots */
+  uint64_t n_buckets;             /* home buckets; table holds (n_buckets + pad_buckets) * KAMD_SLOTS_PER_BUCKET slots */
   uint64_t pad_buckets;
-  const uint64_t* table;          /* slot i = {table[2i] = key | flags, table[2i+1] = payload} */
+  const uint64_t* table;          /* bucket b = table[8b..8b+7] = {key0 | flags, key1, key2, payload0..2, text positions (3 x u32), spare};
+                                     slot index = b * KAMD_SLOTS_PER_BUCKET + j (kallisto_amd/csrc/kamd_core.h) */
   const uint32_t* slot_block;     /* per slot: global block id          (aux table, FLD / positional paths only) */
   const uint32_t* slot_dist;      /* per slot: k-mer offset on its unitig (aux table) */
   const uint32_t* uec_ec;         /* (unitig, transcript-set) class -> de-duplicated transcript-set id */
@@ -67,6 +68,12 @@ typedef struct {
   uint64_t dummy_slot;            /* slot of the dummy k-mer in `table` */
   uint32_t dummy_uec;             /* its (unitig, transcript-set) class */
   uint32_t dummy_strand;          /* const_UnitigMap::strand of um_dummy */
+  /* 2-bit text of all unitigs laid end to end (unitig-forward; base i at bits 2*(i&15) of word i>>4, the reads' packing):
+   * a k-mer that match() expects at a known offset of a unitig it already hit is compared with the text first */
+  const uint32_t* utext;
+  uint64_t utext_words;           /* incl. two words of padding */
+  uint64_t text_bases;
+  const uint64_t* unitig_gpos;    /* [n_unitigs + 1] first base of every unitig in utext */
 } kamd_index_view;
 
 typedef struct {
@@ -88,6 +95,28 @@ int kamd_index_get_view(const kamd_index*, kamd_index_view* out);
 const char* kamd_index_target_name(const kamd_index*, uint64_t i);
 
 /* ---- context ---- */
+/* Tuning knobs: which of the equivalent kernels / EM forms run and how they are shaped.  None of them changes a result.
+ * kamd_ctx_create sets the defaults (environment variables of the same names in upper case with a KAMD_ prefix, e.g.
+ * KAMD_KERNEL_A, KAMD_EM_FORM, are read once there, for experiments); kamd_ctx_tune overrides them for the following calls.
+ * 0 in a field = keep the current value; on/off fields use 1 = on, 2 = off. */
+typedef struct {
+  int32_t kernel_a;            /* pseudoalignment kernel: 3 = state machines + unitig text (default), 2 = state machines, 1 = block-staged */
+  int32_t text_verify;         /* kernel 3: jump / middle / back-off windows are compared with the unitig text first (default on) */
+  int32_t items_per_wave;      /* items per wavefront chunk of kernel A (default 1024, >= 64) */
+  int32_t refill_min;          /* free lanes that trigger a refill (default 8, 1..64) */
+  int32_t lds_pad;             /* diagnostic: unused LDS bytes added to every block of kernel A (lowers the occupancy); -1 = none */
+  int32_t em_form;             /* EM: 1 = streamed two-launch form, 2 = CSR three-launch form, 3 = component-local LDS form (falls back
+                                  to 1 when a connected component does not fit a workgroup), default 3 */
+  int32_t em_local_kernel;     /* component-local form: 2 = lanes share rows / columns (default), 1 = one thread per row / transcript */
+  int32_t em_entries_per_lane; /* streamed form: K in {8,12,...,32}; -1 = automatic (default) */
+  int32_t em_windowed;         /* streamed form: force the general windowed pass (test hook; default off) */
+  int32_t em_graph;            /* rounds of the streamed / CSR forms replayed as a hipGraph (default on) */
+  int32_t em_row_lanes;        /* CSR form: lanes per row, 2 / 4 (default) / 8 */
+  int32_t em_fin_blocks;       /* CSR form: blocks of the final pass (default 1024) */
+  int32_t reserved[4];
+} kamd_tuning;
+int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
+int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);
 int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out);
 void kamd_ctx_destroy(kamd_ctx*);
 int kamd_index_upload(kamd_ctx*, const kamd_index*);
@@ -135,7 +164,8 @@ typedef struct {
   uint64_t n_bucket_reads;  /* 64-byte bucket reads (>= n_probes) */
   uint64_t n_distinct_tuples;
   uint64_t n_stream_words;  /* u32 words of the record stream (fixed slots of kernel A v2 included) */
-  uint64_t n_raw_words;     /* u32 words k_match_v2 wrote: per item 1 header + its distinct (unitig,set) classes */
+  uint64_t n_raw_words;     /* u32 words kernel A wrote: per item 1 header + its distinct (unitig,set) classes */
+  uint64_t n_text_hits;     /* probes answered from the unitig text instead of the table (kernel A version 3) */
 } kamd_align_stats;
 int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
 

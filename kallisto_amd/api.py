@@ -33,7 +33,8 @@ class _View(C.Structure):
                                            "unitig_blk_off", "unitig_len", "blk_unitig", "blk_lb", "blk_ub", "blk_ec",
                                            "blk_pos_off", "blk_posw", "blk_sense", "target_lens", "onlist_bits")] +
                 [("onlist_words", C.c_uint64), ("dtable", C.c_void_p), ("n_dbuckets", C.c_uint64), ("dpad_buckets", C.c_uint64),
-                 ("dummy_slot", C.c_uint64), ("dummy_uec", C.c_uint32), ("dummy_strand", C.c_uint32)])
+                 ("dummy_slot", C.c_uint64), ("dummy_uec", C.c_uint32), ("dummy_strand", C.c_uint32),
+                 ("utext", C.c_void_p), ("utext_words", C.c_uint64), ("text_bases", C.c_uint64), ("unitig_gpos", C.c_void_p)])
 
 
 class QuantOpts(C.Structure):
@@ -44,7 +45,17 @@ class QuantOpts(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_processed", "n_single", "n_multi", "n_probes", "n_bucket_reads",
-                                          "n_distinct_tuples", "n_stream_words", "n_raw_words")]
+                                          "n_distinct_tuples", "n_stream_words", "n_raw_words", "n_text_hits")]
+
+
+class Tuning(C.Structure):
+    """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
+    _fields_ = [(n, C.c_int32) for n in ("kernel_a", "text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form",
+                                         "em_local_kernel", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
+                                         "em_fin_blocks")] + [("reserved", C.c_int32 * 4)]
+
+
+EM_FORMS = {"streamed": 1, "csr": 2, "local": 3}
 
 
 class _Profile(C.Structure):
@@ -70,6 +81,8 @@ _SYMBOLS = {
     "kamd_index_target_name": (C.c_char_p, [C.c_void_p, C.c_uint64]),
     "kamd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "kamd_ctx_destroy": (None, [C.c_void_p]),
+    "kamd_ctx_tune": (C.c_int, [C.c_void_p, C.POINTER(Tuning)]),
+    "kamd_ctx_get_tuning": (C.c_int, [C.c_void_p, C.POINTER(Tuning)]),
     "kamd_index_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kamd_ec_reset": (C.c_int, [C.c_void_p]),
     "kamd_ec_track_order": (C.c_int, [C.c_void_p, C.c_int]),
@@ -240,6 +253,20 @@ class Context:
 
     def reset(self):
         _check(load_library().kamd_ec_reset(self._h), "kamd_ec_reset")
+
+    def tune(self, **kw):
+        """kamd_ctx_tune: e.g. tune(kernel_a=2), tune(em_form="streamed", em_entries_per_lane=16).  Returns the tuning in force."""
+        t = Tuning()
+        for k, v in kw.items():
+            if k == "em_form" and isinstance(v, str):
+                v = EM_FORMS[v]
+            if isinstance(v, bool):
+                v = 1 if v else 2
+            setattr(t, k, int(v))
+        _check(load_library().kamd_ctx_tune(self._h, C.byref(t)), "kamd_ctx_tune")
+        cur = Tuning()
+        _check(load_library().kamd_ctx_get_tuning(self._h, C.byref(cur)), "kamd_ctx_get_tuning")
+        return {n: int(getattr(cur, n)) for n, _ in Tuning._fields_ if n != "reserved"}
 
     def track_order(self, on: bool = True):
         """finalize() then emits the sets in first-occurrence order (the reference's ids at -t 1); call before the first batch."""

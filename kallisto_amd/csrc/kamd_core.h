@@ -26,10 +26,17 @@ namespace kamd {
 // ---------------------------------------------------------------------------------------------------------------
 // k-mer table layout (built by kamd_index.cpp, probed by the kernels)
 //
-//   slot    = {key, payload}, 16 bytes; bucket = 4 slots = one 64-byte line.
+//   bucket  = one 64-byte line = 3 slots, stored as 8 u64 words {key0, key1, key2, pay0, pay1, pay2, gpos0 | gpos1 << 32,
+//             gpos2}: a slot is {key, payload, gpos} = 20 bytes, the last 4 bytes of the line are spare.
 //   key     = canonical k-mer, MSB-first 2-bit, right-aligned (<= 62 bits).  Empty slot = KEY_EMPTY (all ones in the low
 //             62 bits, never canonical because its reverse complement is 0).  Bit 63 of slot 0's key is the bucket's
 //             "continue" flag: some key whose home is <= this bucket was placed beyond it.
+//   gpos    = position of the k-mer's first base in `utext`, the 2-bit text of all unitigs laid end to end in unitig-forward
+//             orientation (same packing as the reads: base i at bits 2*(i&15) of word i>>4).  A k-mer that match() expects on
+//             the SAME unitig at a known offset from an earlier hit (the jump target, the middle k-mer, the back-off k-mer) is
+//             first compared with the text at that offset: equality is exactly the answer CompactedDBG::find would give (a
+//             k-mer occurs once in a compacted de Bruijn graph), and it costs a read of a small MALL-resident array instead
+//             of a random 64-byte line of the table; only a mismatch is looked up in the table.
 //   payload = rem_f[15:0] | rem_b[31:16] | uec[62:32] | fwd_is_canon[63]
 //             rem_f = (ub-1-dist), rem_b = (dist-lb): k-mers left to the end of the mosaic block when walking the unitig
 //             forward / backward, saturated at 65535 (exact for reads shorter than 65535+k);
@@ -43,6 +50,8 @@ static const uint64_t KEY_EMPTY = KEY_MASK;
 static const uint64_t KEY_CONT = 1ULL << 63;
 static const uint32_t REM_CAP = 65535u;
 static const uint32_t NO_UEC = 0x7FFFFFFFu;
+static const int BUCKET_SLOTS = 3;
+static const uint32_t UEC_MASK = 0x3FFFFFFFu;   // class lists keep two mate flags above 30 bits of uec
 
 KAMD_HD uint64_t mix64(uint64_t x) {
   x ^= x >> 31; x *= 0x7fb5d329728ea185ULL;
@@ -50,12 +59,19 @@ KAMD_HD uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
   return x;
 }
-// home bucket of a canonical k-mer: fastrange (monotone in the hash so that sorting by hash == sorting by home)
+// home bucket of a canonical k-mer: a 32-bit mix (ten 32-bit VALU operations on the device; mix64 + a 64-bit fastrange
+// were ~40) followed by fastrange, monotone in the hash so that sorting by hash == sorting by home.  n_buckets < 2^32.
+KAMD_HD uint32_t kmer_hash32(uint64_t canon) {
+  const uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+  uint32_t h = hi * 0x9E3779B1u; h ^= h >> 15;
+  uint32_t x = (lo ^ h) * 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
 KAMD_HD uint64_t home_bucket(uint64_t canon, uint64_t n_buckets) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __umul64hi(mix64(canon), n_buckets);
+  return (uint64_t)__umulhi(kmer_hash32(canon), (uint32_t)n_buckets);
 #else
-  return (uint64_t)(((unsigned __int128)mix64(canon) * n_buckets) >> 64);
+  return ((uint64_t)kmer_hash32(canon) * (uint32_t)n_buckets) >> 32;
 #endif
 }
 KAMD_HD uint64_t make_payload(uint32_t rem_f, uint32_t rem_b, uint32_t uec, bool fwd_is_canon) {
@@ -87,8 +103,13 @@ struct ReadView {
   const uint32_t* seq;   // 2-bit words (LDS on the device)
   const uint32_t* mask;  // non-ACGT mask words
   int len;               // bases
-  int stride = 1;        // distance between consecutive words (64 for the lane-transposed LDS layout of kernel A v2)
+  int stride = 1;        // distance between consecutive sequence words (64 for the lane-transposed LDS layout of kernel A)
+  int mask_stride = 1;   // ... and between mask words (kernel A v3 leaves the mask plane in global memory: 1)
+  bool has_n = true;     // false: the packer saw only ACGT (flag word of the record), the mask plane is never consulted
 };
+// the last sequence word of a packed record is padding (the bases fill at most seq_words - 1 words); the packers store the
+// "read has a non-ACGT base" flag there
+static const uint32_t REC_FLAG_HAS_N = 1u;
 
 // bits [2w, 2w+2k) of the read, LSB-first: x = sum base[w+i] << 2i
 KAMD_HD uint64_t window_lsb(const ReadView& r, int w, int k) {
@@ -102,11 +123,12 @@ KAMD_HD uint64_t window_lsb(const ReadView& r, int w, int k) {
 // mask bits of bases [w, w+k) (k <= 32)
 KAMD_HD uint32_t window_mask(const ReadView& r, int w, int k) {
   int wi = w >> 5, sh = w & 31;
-  uint64_t lo = (uint64_t)r.mask[wi * r.stride] | ((uint64_t)r.mask[(wi + 1) * r.stride] << 32);  // one pad word per plane
+  uint64_t lo = (uint64_t)r.mask[wi * r.mask_stride] | ((uint64_t)r.mask[(wi + 1) * r.mask_stride] << 32);  // one pad word per plane
   return (uint32_t)(lo >> sh) & (uint32_t)((1ULL << k) - 1);
 }
 // first window start >= t whose k bases are all ACGT and that fits in the read; -1 if none   (KmerIterator::operator++)
 KAMD_HD int next_valid_window(const ReadView& r, int t, int k) {
+  if (!r.has_n) return t + k <= r.len ? t : -1;
   while (t + k <= r.len) {
     uint32_t m = window_mask(r, t, k);
     if (m == 0) return t;
@@ -135,7 +157,7 @@ KAMD_HD uint64_t window_canon(const ReadView& r, int w, int k, bool* is_fwd_cano
 // table probe
 // ---------------------------------------------------------------------------------------------------------------
 struct Table {
-  const uint64_t* slots;  // 2 words per slot
+  const uint64_t* slots;  // 8 words per bucket
   uint64_t n_buckets;
   // D-list (kb-python style indices): the distinguishing flanking k-mers as a second table of the same layout (payload
   // unused), and the hit that is pushed when a read contains one of them -- um_dummy = dbg.find(first D-list k-mer),
@@ -154,6 +176,7 @@ struct Probe {
   uint32_t uec;
   uint32_t dist;    // "dist" of KmerIndex.cpp:1789: k-mers to the end of the block in read direction
   uint64_t slot;    // slot index (for the aux tables)
+  uint32_t gpos;    // position of the k-mer in the unitig text
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -161,39 +184,52 @@ typedef unsigned long long __attribute__((ext_vector_type(2))) kamd_u64x2;
 #endif
 
 KAMD_HD Probe probe_table(const Table& t, uint64_t canon, bool is_fwd_canon, uint32_t* bucket_reads) {
-  Probe p; p.found = false; p.strand = false; p.uec = NO_UEC; p.dist = 0; p.slot = 0;
+  Probe p; p.found = false; p.strand = false; p.uec = NO_UEC; p.dist = 0; p.slot = 0; p.gpos = 0;
   uint64_t b = home_bucket(canon, t.n_buckets);
   for (;;) {
     const uint64_t* bp = t.slots + b * 8;
-    uint64_t k0, p0, k1, p1, k2, p2, k3, p3;
+    uint64_t k0, k1, k2, p0, p1, p2, g01, g2;
 #if defined(__HIP_DEVICE_COMPILE__)
     // four 16-byte loads of one 64-byte line, issued back to back
     kamd_u64x2 s0 = ((const kamd_u64x2*)bp)[0];
     kamd_u64x2 s1 = ((const kamd_u64x2*)bp)[1];
     kamd_u64x2 s2 = ((const kamd_u64x2*)bp)[2];
     kamd_u64x2 s3 = ((const kamd_u64x2*)bp)[3];
-    k0 = s0.x; p0 = s0.y; k1 = s1.x; p1 = s1.y; k2 = s2.x; p2 = s2.y; k3 = s3.x; p3 = s3.y;
+    k0 = s0.x; k1 = s0.y; k2 = s1.x; p0 = s1.y; p1 = s2.x; p2 = s2.y; g01 = s3.x; g2 = s3.y;
 #else
-    k0 = bp[0]; p0 = bp[1]; k1 = bp[2]; p1 = bp[3]; k2 = bp[4]; p2 = bp[5]; k3 = bp[6]; p3 = bp[7];
+    k0 = bp[0]; k1 = bp[1]; k2 = bp[2]; p0 = bp[3]; p1 = bp[4]; p2 = bp[5]; g01 = bp[6]; g2 = bp[7];
 #endif
     if (bucket_reads) ++*bucket_reads;
-    uint64_t pay = 0; int hit = -1;
-    if ((k0 & KEY_MASK) == canon) { pay = p0; hit = 0; }
-    else if (k1 == canon) { pay = p1; hit = 1; }
-    else if (k2 == canon) { pay = p2; hit = 2; }
-    else if (k3 == canon) { pay = p3; hit = 3; }
+    uint64_t pay = 0; uint32_t gp = 0; int hit = -1;
+    if ((k0 & KEY_MASK) == canon) { pay = p0; gp = (uint32_t)g01; hit = 0; }
+    else if (k1 == canon) { pay = p1; gp = (uint32_t)(g01 >> 32); hit = 1; }
+    else if (k2 == canon) { pay = p2; gp = (uint32_t)g2; hit = 2; }
     if (hit >= 0) {
       bool fwd_is_canon = (pay >> 63) != 0;
       p.found = true;
       p.strand = (is_fwd_canon == fwd_is_canon);
       p.uec = (uint32_t)(pay >> 32) & 0x7FFFFFFFu;
       p.dist = p.strand ? (uint32_t)(pay & 0xFFFF) : (uint32_t)((pay >> 16) & 0xFFFF);
-      p.slot = b * 4 + (uint64_t)hit;
+      p.slot = b * BUCKET_SLOTS + (uint64_t)hit;
+      p.gpos = gp;
       return p;
     }
     if (!(k0 & KEY_CONT)) return p;
     ++b;  // the table carries pad buckets at the end, so this never runs off
   }
+}
+
+// The k-mer of the unitig text at base position g (unitig-forward): canonical MSB-first key, as window_canon gives for a read.
+// `utext` carries two words of padding at the end.
+KAMD_HD uint64_t text_canon(const uint32_t* utext, uint32_t g, int k) {
+  const uint32_t wi = g >> 4; const int sh = (int)(g & 15u) * 2;
+  const uint32_t a = utext[wi], b = utext[wi + 1], c = utext[wi + 2];
+  uint64_t x = ((uint64_t)a | ((uint64_t)b << 32)) >> sh;
+  if (sh + 2 * k > 64) x |= (uint64_t)c << (64 - sh);
+  x &= (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const uint64_t fwd = rev_bases64(x) >> (64 - 2 * k);
+  const uint64_t rc = (~x) & ((1ULL << (2 * k)) - 1);
+  return fwd < rc ? fwd : rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -305,7 +341,7 @@ KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* e
     for (int wd = next_valid_window(r, 0, k); wd >= 0; wd = next_valid_window(r, wd + 1, k)) {
       bool fcd; const uint64_t cd = window_canon(r, wd, k, &fcd);
       if (probe_table(dt, cd, fcd, &mi.bucket_reads).found) {
-        Probe dm; dm.found = true; dm.strand = t.dummy_strand; dm.uec = t.dummy_uec; dm.dist = 0; dm.slot = t.dummy_slot;
+        Probe dm; dm.found = true; dm.strand = t.dummy_strand; dm.uec = t.dummy_uec; dm.dist = 0; dm.slot = t.dummy_slot; dm.gpos = 0;
         KAMD_PUSH(dm, wd);
         break;
       }
@@ -329,17 +365,32 @@ struct MatchState {
   int dist;     // :1789
   int nextPos;  // :1794-1799
   uint32_t um_uec, um2_uec;
+  uint32_t um_gpos;   // text position of the hit under examination ...
+  bool um_strand;     // ... and its orientation: window w0 + n lies at um_gpos + n (strand) or um_gpos - n of the unitig text
+  bool text_tried;    // the pending window was compared with the text and differs: it goes to the table
 };
+// May the pending probe of a JUMP / MIDDLE / BACK-OFF step be answered from the unitig text?  Only while the window is
+// within `dist` k-mers of the hit (then it lies in the same block of the same unitig, :1780-1799) -- an iterator that had to
+// skip non-ACGT windows can land beyond it.
+KAMD_HD bool text_applies(const MatchState& st) {
+  return (st.phase == PH_JUMP || st.phase == PH_MIDDLE || st.phase == PH_BACKOFF) && !st.text_tried && st.w - st.w0 <= st.dist && st.w > st.w0;
+}
+KAMD_HD uint32_t text_pos_of(const MatchState& st) {
+  const uint32_t n = (uint32_t)(st.w - st.w0);
+  return st.um_strand ? st.um_gpos + n : st.um_gpos - n;
+}
 // distinct (unitig, set) classes seen by one item: entry = uec | mate flags (bit 30: mate 1, bit 31: mate 2)
 struct UecList {
   uint32_t* e; int cap; int n; bool overflow;
+  int stride = 1;   // distance between consecutive entries (kernel A v3 keeps the lists thread-transposed in LDS)
 };
 KAMD_HD void ueclist_add(UecList& l, uint32_t uec, int mate) {
   const uint32_t flag = mate ? 0x80000000u : 0x40000000u;
   for (int i = l.n - 1; i >= 0; --i)
-    if ((l.e[i] & 0x3FFFFFFFu) == uec) { l.e[i] |= flag; return; }
+    if ((l.e[i * l.stride] & 0x3FFFFFFFu) == uec) { l.e[i * l.stride] |= flag; return; }
   if (l.n == l.cap) { l.overflow = true; return; }
-  l.e[l.n++] = uec | flag;
+  l.e[l.n * l.stride] = uec | flag;
+  ++l.n;
 }
 struct MateFirst { int n_hits; uint64_t slot; int pos; bool strand; };
 
@@ -359,6 +410,7 @@ KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
   st.w = next_valid_window(r, 0, k);
   st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
   st.w0 = st.w2 = st.dist = st.nextPos = 0; st.um_uec = st.um2_uec = NO_UEC;
+  st.um_gpos = 0; st.um_strand = false; st.text_tried = false;
 }
 // consume the probe result of window st.w.  Written data-flow style: every phase only decides (a) whether the hit is
 // recorded, (b) where the next window search starts and (c) the phase that follows; the list insertion and the single
@@ -367,6 +419,7 @@ template <bool DL>
 KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf, const Table& t) {
   const int lk = r.len - k;
   const int ph = st.phase;
+  st.text_tried = false;
   if (DL && ph == PH_DLIST) {   // p = probe of the D-list table
     if (p.found) {
       if (mf.n_hits == 0) { mf.slot = t.dummy_slot; mf.pos = st.w; mf.strand = t.dummy_strand; }
@@ -397,6 +450,7 @@ KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p
         const int nextPos = (pos + dist >= lk) ? lk : pos + dist;                  // :1794-1799
         const int n = nextPos - pos;                                               // kit2 += nextPos - pos (:1803)
         st.w0 = pos; st.dist = dist; st.nextPos = nextPos; st.um_uec = p.uec;
+        st.um_gpos = p.gpos; st.um_strand = p.strand;
         ph_ok = PH_JUMP;
         if (n == 0) stay = true; else { start = pos + n; guard_len = n >= 2; }
       }

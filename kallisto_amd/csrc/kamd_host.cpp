@@ -42,10 +42,11 @@ extern "C" int kamd_pack_reads_host_strided(const char* seqs, const uint64_t* of
     // 32 bases per step: two sequence words and one mask word, built in registers and stored once
     int32_t i = 0;
     uint64_t wi = 0, mi = 0;
+    uint32_t any_n = 0;
     for (; i + 32 <= L; i += 32) {
       uint64_t bits = 0; uint32_t m = 0;
       for (int j = 0; j < 32; j++) { const uint32_t c = lut.v[s[i + j]]; bits |= (uint64_t)(c & 3u) << (2 * j); m |= (c >> 2) << j; }
-      w[wi++] = (uint32_t)bits; w[wi++] = (uint32_t)(bits >> 32); w[sw + mi++] = m;
+      w[wi++] = (uint32_t)bits; w[wi++] = (uint32_t)(bits >> 32); w[sw + mi++] = m; any_n |= m;
     }
     {
       uint64_t bits = 0; uint32_t m = 0;
@@ -53,9 +54,11 @@ extern "C" int kamd_pack_reads_host_strided(const char* seqs, const uint64_t* of
       if (wi < sw) w[wi++] = (uint32_t)bits;
       if (wi < sw) w[wi++] = (uint32_t)(bits >> 32);
       if (sw + mi < rec) w[sw + mi++] = m;
+      any_n |= m;
     }
     while (wi < sw) w[wi++] = 0;             // padding words of the record
     while (sw + mi < rec) w[sw + mi++] = 0;
+    w[sw - 1] = any_n ? 1u : 0u;             // flag word (kamd_core.h REC_FLAG_HAS_N): the bases never reach the last sequence word
     out_len[slot] = (uint16_t)L;
   }
   return 0;

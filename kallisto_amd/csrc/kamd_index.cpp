@@ -125,6 +125,9 @@ struct kamd_index {
   uint64_t n_buckets = 0, pad_buckets = 0;
   std::vector<uint64_t> table;
   std::vector<uint32_t> slot_block, slot_dist;
+  std::vector<uint32_t> utext;          // 2-bit text of all unitigs, end to end (read packing), + 2 words of padding
+  std::vector<uint64_t> unitig_gpos;    // first base of every unitig in it
+  uint64_t text_bases = 0;
   // D-list
   std::vector<uint64_t> dlist_keys;   // canonical, right-aligned; [0] = the dummy (the one that is in the graph)
   uint64_t n_dbuckets = 0, dpad_buckets = 0;
@@ -312,7 +315,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   }
   ix->unitig_blk_off[ix->n_unitigs] = ix->blk_lb.size();
   ix->blk_pos_off.push_back(ix->blk_posw.size());
-  if (ix->uec_ec.size() >= kamd::NO_UEC) return kamd::fail(-3, "index: too many (unitig, set) classes");
+  if (ix->uec_ec.size() >= kamd::UEC_MASK) return kamd::fail(-3, "index: too many (unitig, set) classes");   // class lists keep 30 bits
 
   tick("flatten blocks");
   // 4-6. targets (KmerIndex.cpp:1470-1519)
@@ -344,8 +347,21 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   if (c.bad) return kamd::fail(-3, "index: truncated file");
 
   tick("targets + on-list");
+  // ---- unitig text: every unitig's bases end to end, 16 per word (the reads' packing) ----
+  {
+    ix->unitig_gpos.assign(ix->n_unitigs + 1, 0);
+    uint64_t g = 0;
+    for (uint64_t u = 0; u < ix->n_unitigs; u++) { ix->unitig_gpos[u] = g; g += ix->unitig_len[u]; }
+    ix->unitig_gpos[ix->n_unitigs] = g;
+    ix->text_bases = g;
+    if (g >= 0xFFFFFF00ULL) return kamd::fail(-3, "index: unitig text exceeds 2^32 bases");
+    ix->utext.assign((g + 15) / 16 + 2, 0);
+  }
+  tick("unitig text: layout");
   // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
-  const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers + 1) / 2);  // load factor 0.5 over 4-slot buckets
+  constexpr uint64_t S = kamd::BUCKET_SLOTS;
+  const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers * 2 + S - 1) / S);  // load factor 0.5 over 3-slot buckets
+  if (nb >= 0xFFFFFFF0ULL) return kamd::fail(-3, "index: too many k-mers for 32-bit bucket numbers");
   ix->n_buckets = nb;
   std::vector<uint32_t> fill(nb + 1, 0);
   auto fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data());
@@ -378,25 +394,27 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   uint64_t cursor = 0;
   std::vector<uint8_t> cont(nb + 1, 0);
   for (uint64_t b = 0; b < nb; b++) {
-    cursor = std::max(cursor, b * 4);
+    cursor = std::max(cursor, b * S);
     base[b] = cursor;
     cursor += fill[b];
-    if (cursor > (b + 1) * 4) cont[b] = 1;
+    if (cursor > (b + 1) * S) cont[b] = 1;
   }
-  uint64_t total_buckets = std::max(nb, (cursor + 3) / 4) + 1;
+  uint64_t total_buckets = std::max(nb, (cursor + S - 1) / S) + 1;
   ix->pad_buckets = total_buckets - nb;
   std::vector<uint8_t> cont_all(total_buckets, 0);
   for (uint64_t b = 0; b < nb; b++) cont_all[b] = cont[b];
-  for (uint64_t b = nb; b < total_buckets; b++) cont_all[b] = (cursor > (b + 1) * 4);
+  for (uint64_t b = nb; b < total_buckets; b++) cont_all[b] = (cursor > (b + 1) * S);
   ix->table.assign(total_buckets * 8, 0);
-  for (uint64_t s = 0; s < total_buckets * 4; s++) ix->table[2 * s] = kamd::KEY_EMPTY;
-  ix->slot_block.assign(total_buckets * 4, 0xFFFFFFFFu);
-  ix->slot_dist.assign(total_buckets * 4, 0);
+  for (uint64_t b = 0; b < total_buckets; b++) for (uint64_t j = 0; j < S; j++) ix->table[8 * b + j] = kamd::KEY_EMPTY;
+  ix->slot_block.assign(total_buckets * S, 0xFFFFFFFFu);
+  ix->slot_dist.assign(total_buckets * S, 0);
   std::fill(fill.begin(), fill.end(), 0);
   tick("table: layout + allocation");
+  auto utext_atomic = reinterpret_cast<std::atomic<uint32_t>*>(ix->utext.data());
   run_parallel([&](uint64_t u) {
     uint64_t b0 = ix->unitig_blk_off[u], b1 = ix->unitig_blk_off[u + 1];
     uint64_t cur = b0;
+    const uint64_t g0 = ix->unitig_gpos[u];
     auto place = [&](uint32_t dist, uint64_t v) {
       // block containing dist: BlockArray::get_block_at = last block with lb <= dist (BlockArray.hpp:306-322)
       if (b1 - b0 > 1) { while (cur + 1 < b1 && ix->blk_lb[cur + 1] <= dist) ++cur; }
@@ -405,18 +423,32 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
       uint64_t slot = base[hb] + fill_atomic[hb].fetch_add(1, std::memory_order_relaxed);
       uint32_t lb = ix->blk_lb[cur], ub = ix->blk_ub[cur];
       uint32_t rem_f = ub - 1 - dist, rem_b = dist - lb;   // KmerIndex.cpp:1780-1789
-      ix->table[2 * slot] = cn;
-      ix->table[2 * slot + 1] = kamd::make_payload(rem_f, rem_b, ix->blk_uec[cur], f);
+      const uint64_t bk = slot / S, j = slot % S;
+      ix->table[8 * bk + j] = cn;
+      ix->table[8 * bk + S + j] = kamd::make_payload(rem_f, rem_b, ix->blk_uec[cur], f);
+      reinterpret_cast<uint32_t*>(&ix->table[8 * bk + 2 * S])[j] = (uint32_t)(g0 + dist);
       ix->slot_block[slot] = (uint32_t)cur;
       ix->slot_dist[slot] = dist;
     };
     if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, place); else place(0, single_kmer(u));
+    // the unitig's bases into the text (neighbouring unitigs share words: atomic OR)
+    const uint64_t len = ix->unitig_len[u];
+    const uint64_t sk = u < ix->n_long ? 0 : single_kmer(u);
+    uint32_t acc = 0; uint64_t wi = g0 >> 4;
+    for (uint64_t j = 0; j < len; j++) {
+      const uint64_t g = g0 + j;
+      if ((g >> 4) != wi) { if (acc) utext_atomic[wi].fetch_or(acc, std::memory_order_relaxed); acc = 0; wi = g >> 4; }
+      const uint32_t b = u < ix->n_long ? (uint32_t)((units[u].data[j >> 2] >> ((j & 3) << 1)) & 3)
+                                        : (uint32_t)((sk >> (2 * (k - 1 - (int)j))) & 3);
+      acc |= b << (2 * (g & 15));
+    }
+    if (acc) utext_atomic[wi].fetch_or(acc, std::memory_order_relaxed);
   });
   for (uint64_t b = 0; b < total_buckets; b++) if (cont_all[b]) ix->table[8 * b] |= kamd::KEY_CONT;
   tick("table: place pass");
   // ---- D-list table (same bucket layout, built serially: it is small) and the dummy hit ----
   if (ix->dlist_size) {
-    const uint64_t nd = ix->dlist_size, ndb = std::max<uint64_t>(16, (nd + 1) / 2);
+    const uint64_t nd = ix->dlist_size, ndb = std::max<uint64_t>(16, (nd * 2 + S - 1) / S);
     std::vector<std::pair<uint64_t, uint64_t>> byhome(nd);   // (home bucket, key)
     for (uint64_t i = 0; i < nd; i++) byhome[i] = {kamd::home_bucket(ix->dlist_keys[i], ndb), ix->dlist_keys[i]};
     std::sort(byhome.begin(), byhome.end());
@@ -424,19 +456,19 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     // Robin Hood order: keys of a home bucket are laid down sequentially, never before their home
     std::vector<uint64_t> slot_of(byhome.size());
     uint64_t cur = 0;
-    for (size_t i = 0; i < byhome.size(); i++) { cur = std::max(cur, byhome[i].first * 4); slot_of[i] = cur++; }
-    const uint64_t tb = std::max(ndb, (cur + 3) / 4) + 1;
+    for (size_t i = 0; i < byhome.size(); i++) { cur = std::max(cur, byhome[i].first * S); slot_of[i] = cur++; }
+    const uint64_t tb = std::max(ndb, (cur + S - 1) / S) + 1;
     ix->n_dbuckets = ndb; ix->dpad_buckets = tb - ndb;
     ix->dtable.assign(tb * 8, 0);
-    for (uint64_t sl = 0; sl < tb * 4; sl++) ix->dtable[2 * sl] = kamd::KEY_EMPTY;
-    for (size_t i = 0; i < byhome.size(); i++) ix->dtable[2 * slot_of[i]] = byhome[i].second;
-    // a bucket continues into the next one when keys homed at or before it spill past its four slots
+    for (uint64_t b = 0; b < tb; b++) for (uint64_t j = 0; j < S; j++) ix->dtable[8 * b + j] = kamd::KEY_EMPTY;
+    for (size_t i = 0; i < byhome.size(); i++) ix->dtable[8 * (slot_of[i] / S) + slot_of[i] % S] = byhome[i].second;
+    // a bucket continues into the next one when keys homed at or before it spill past its slots
     {
       uint64_t reach = 0;  // one past the last slot used by keys homed in buckets <= b
       size_t i = 0;
       for (uint64_t b = 0; b < tb; b++) {
         while (i < byhome.size() && byhome[i].first == b) { reach = slot_of[i] + 1; ++i; }
-        if (reach > (b + 1) * 4) ix->dtable[8 * b] |= kamd::KEY_CONT;
+        if (reach > (b + 1) * S) ix->dtable[8 * b] |= kamd::KEY_CONT;
       }
     }
     const kamd::Table mt{ix->table.data(), nb};
@@ -465,6 +497,8 @@ extern "C" int kamd_index_get_view(const kamd_index* ix, kamd_index_view* v) {
   v->target_lens = ix->target_lens.data(); v->onlist_bits = ix->onlist_bits.data(); v->onlist_words = ix->onlist_bits.size();
   v->dtable = ix->dtable.empty() ? nullptr : ix->dtable.data(); v->n_dbuckets = ix->n_dbuckets; v->dpad_buckets = ix->dpad_buckets;
   v->dummy_slot = ix->dummy_slot; v->dummy_uec = ix->dummy_uec; v->dummy_strand = ix->dummy_strand;
+  v->utext = ix->utext.data(); v->utext_words = ix->utext.size(); v->text_bases = ix->text_bases;
+  v->unitig_gpos = ix->unitig_gpos.data();
   return 0;
 }
 

@@ -56,6 +56,7 @@ struct DevIndex {
   const u64* blk_pos_off; const u32* blk_posw; const uint8_t* blk_sense; const int32_t* target_lens;
   // D-list (second k-mer table + the dummy hit); n_dbuckets == 0: none
   const u64* dtable; u64 n_dbuckets; u64 dummy_slot; u32 dummy_uec; u32 dummy_strand;
+  const u32* utext;   // 2-bit text of all unitigs (kamd_core.h: text_canon)
   int no_jump;   // kamd_quant_opts::no_jump of the run (set by the entry points that take the options)
 };
 // the k-mer table(s) as the per-item logic sees them; partial = match()'s `partial` argument = single-end reads
@@ -72,7 +73,7 @@ struct FilterDev { int single_overhang, has_mean_fl, fl, strand; };
 // device-resident cursors and statistics
 struct DevState {
   u64 stream_words, n_recs, n_overflow, n_retry;
-  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words;
+  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words, st_text_hits;
   u64 n_list, bound_words;       // generic append cursor / size bound accumulator
   u64 n_explicit, n_explicit_big; // items whose set was changed by a positional filter (from the main / overflow kernel)
   u64 exp_words, exp_recs;       // explicit transcript-set stream
@@ -390,6 +391,152 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
   }
   const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads), s_raw = wave_sum64((u64)raw_words);
   if (lane == 0) { atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); atomicAdd(&st->st_raw_words, s_raw); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel A, version 3: the state machines of version 2, with
+//   * the unitig text in front of the table: a JUMP / MIDDLE / BACK-OFF window that lies within the block of the hit under
+//     examination is compared with the text at its expected position (12 bytes of an 18 MB array that lives in L2 / MALL);
+//     a match is what the table would have answered, a mismatch sends the window to the table in the next iteration.  On
+//     config #3 a quarter of all probes (every successful jump) never touch the 2.4 GB table;
+//   * 24 words of LDS per lane instead of 38 (sequence words of both mates + 8 classes; the non-ACGT plane stays in global
+//     memory and is only read for items whose record carries the has-N flag): 24 wavefronts per CU instead of 16;
+//   * items handed out from a wavefront-uniform cursor (ballot + prefix count, no LDS atomic), class lists thread-transposed
+//     in LDS (conflict-free), and the 32-bit k-mer hash.
+// More than V3_LIST_CAP distinct classes (0.5 % of config #3's pairs): the item goes to the overflow kernel, as before.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int V3_LIST_CAP = 8;
+template <bool PAIRED, bool FILTER, bool DL, bool TEXT>
+__global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
+                                                    u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
+                                                    u32* raw, int raw_stride, DevState* st) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  constexpr int WAVES = BLOCK / 64;
+  constexpr int NM = PAIRED ? 2 : 1;
+  const int item_words = rec_words * NM;
+  const int lane_words = seq_words * NM;                      // words of an item kept in LDS: the sequence planes only
+  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32* wave_words = lds + (size_t)wv * 64 * lane_words;       // the wavefront's items, lane-transposed
+  u32* my_words = wave_words + lane;                          // word j at my_words[j * 64]
+  u32* my_list = lds + (size_t)WAVES * 64 * lane_words + threadIdx.x;   // entry j at my_list[j * BLOCK]
+  const u64 wave_global = (u64)blockIdx.x * WAVES + wv;
+  const u64 chunk0 = wave_global * (u64)items_per_wave;
+  const u32 chunk_n = chunk0 < n_items ? (u32)min((u64)items_per_wave, n_items - chunk0) : 0u;
+  u32 cursor = 0;                                             // next item of the chunk (wavefront-uniform)
+  const kamd::Table t = make_table(ix, !PAIRED);
+  const int k = ix.k;
+
+  kamd::MatchState ms; ms.phase = kamd::PH_DONE; ms.w = 0; ms.w0 = 0; ms.w2 = 0; ms.dist = 0; ms.nextPos = 0;
+  ms.um_uec = ms.um2_uec = kamd::NO_UEC; ms.um_gpos = 0; ms.um_strand = false; ms.text_tried = false;
+  kamd::UecList ul{my_list, V3_LIST_CAP, 0, false, BLOCK};
+  kamd::MateFirst mf0{0, 0, -1, false}, mf1{0, 0, -1, false};
+  int mate = 0, len0 = 0, len1 = 0;
+  bool n0 = false, n1 = false;   // has-N flags of the two mates
+  u32 my_idx = 0;
+  bool have = false;      // the lane owns an item whose raw record is not written yet
+  bool busy = false;      // ... and its state machine still wants probes
+  bool exhausted = false;
+  u32 probes = 0, breads = 0, raw_words = 0, text_hits = 0;
+
+  for (;;) {
+    // 1. lanes without an item take the next ones of the chunk; their sequence words come by LDS-DMA loads, in flight during
+    // the probe below.  Refills are batched (at least refill_min free lanes, or nothing left to probe).
+    bool loading = false;
+    const u64 idle_mask = __ballot(!have && !exhausted);
+    const bool do_refill = idle_mask != 0ULL && (__popcll(idle_mask) >= refill_min || __ballot(have) == 0ULL);
+    if (do_refill) {
+      if (!have && !exhausted) {
+        my_idx = cursor + (u32)__popcll(idle_mask & ((1ULL << lane) - 1ULL));
+        if (my_idx >= chunk_n) exhausted = true;
+        else {
+          loading = true;
+          const u64 item = chunk0 + my_idx;
+          const u32* src = words + item * item_words;
+#pragma unroll 4
+          for (int j = 0; j < seq_words; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j),
+                                             (__attribute__((address_space(3))) void*)(wave_words + (size_t)j * 64), 4, 0, 0);
+          if (PAIRED) {
+#pragma unroll 4
+            for (int j = 0; j < seq_words; j++)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + rec_words + j),
+                                               (__attribute__((address_space(3))) void*)(wave_words + (size_t)(seq_words + j) * 64), 4, 0, 0);
+          }
+          len0 = PAIRED ? (int)lens[2 * item] : (int)lens[item];
+          len1 = PAIRED ? (int)lens[2 * item + 1] : 0;
+        }
+      }
+      cursor += (u32)__popcll(idle_mask);
+    }
+    if (__ballot(have || loading) == 0ULL) break;
+    // 2. every busy lane: one probe -- of the unitig text where the window's place on the unitig is known, else of the table
+    if (have && busy) {
+      const u32* base = my_words + (size_t)(mate ? seq_words : 0) * 64;
+      const u32* mplane = words + (chunk0 + my_idx) * (u64)item_words + (size_t)(mate ? rec_words : 0) + seq_words;
+      kamd::ReadView rv{base, mplane, mate ? len1 : len0, 64, 1, mate ? n1 : n0};
+      bool fc;
+      const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
+      kamd::Probe p; p.found = false;
+      bool feed = true;
+      if (TEXT && kamd::text_applies(ms)) {
+        if (kamd::text_canon(ix.utext, kamd::text_pos_of(ms), k) == canon) {
+          p.found = true; p.strand = ms.um_strand; p.uec = ms.um_uec; p.dist = 0; p.slot = 0; p.gpos = 0;   // (only uec is looked at in these phases)
+          ++text_hits; ++probes;
+        } else { ms.text_tried = true; feed = false; }
+      } else {
+        p = kamd::probe_table(DL ? kamd::phase_table(t, ms.phase) : t, canon, fc, &breads);
+        if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
+      }
+      if (feed) {
+        kamd::match_feed<DL>(ms, rv, k, p, ul, mate, mate ? mf1 : mf0, t);
+        if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
+          mate = 1;
+          const u32* b1 = my_words + (size_t)seq_words * 64;
+          kamd::ReadView r1{b1, mplane + rec_words, len1, 64, 1, n1};
+          kamd::match_init(ms, r1, k);
+        }
+        busy = ms.phase != kamd::PH_DONE;
+      }
+    }
+    // 3. lanes that fetched an item: its words are in LDS once the DMA loads have landed; start mate 1
+    if (loading) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ul.n = 0; ul.overflow = false;
+      mf0 = kamd::MateFirst{0, 0, -1, false}; mf1 = kamd::MateFirst{0, 0, -1, false};
+      mate = 0;
+      n0 = (my_words[(size_t)(seq_words - 1) * 64] & kamd::REC_FLAG_HAS_N) != 0;
+      n1 = PAIRED ? (my_words[(size_t)(2 * seq_words - 1) * 64] & kamd::REC_FLAG_HAS_N) != 0 : false;
+      const u32* mplane = words + (chunk0 + my_idx) * (u64)item_words + seq_words;
+      kamd::ReadView r0{my_words, mplane, len0, 64, 1, n0};
+      kamd::match_init(ms, r0, k);
+      if (ms.phase == kamd::PH_DONE && PAIRED) {
+        mate = 1;
+        const u32* b1 = my_words + (size_t)seq_words * 64;
+        kamd::ReadView r1{b1, mplane + rec_words, len1, 64, 1, n1};
+        kamd::match_init(ms, r1, k);
+      }
+      have = true;
+      busy = ms.phase != kamd::PH_DONE;
+    }
+    // 4. finished items: write the raw record (plain stores, nothing waits for them) and free the lane
+    if (have && !busy) {
+      u32* o = raw + (chunk0 + my_idx) * (u64)raw_stride;
+      o[0] = (u32)ul.n | (ul.overflow ? RAW_OVERFLOW : 0u) | (mf0.n_hits > 0 ? RAW_HIT0 : 0u) | (mf1.n_hits > 0 ? RAW_HIT1 : 0u);
+#pragma unroll
+      for (int j = 0; j < V3_LIST_CAP; j++) if (j < ul.n) o[1 + j] = my_list[(size_t)j * BLOCK];
+      raw_words += 1u + (u32)ul.n;
+      if (FILTER) {
+        o[2 + TUPLE_CAP] = (u32)mf0.slot; o[3 + TUPLE_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
+        o[4 + TUPLE_CAP] = (u32)mf1.slot; o[5 + TUPLE_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
+      }
+      have = false;
+    }
+  }
+  const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads), s_raw = wave_sum64((u64)raw_words), s_text = wave_sum64((u64)text_hits);
+  if (lane == 0) {
+    atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); atomicAdd(&st->st_raw_words, s_raw);
+    if (s_text) atomicAdd(&st->st_text_hits, s_text);
+  }
 }
 
 // Persistent blocks (grid-stride over 256-item tiles) so that the per-launch bookkeeping costs a handful of same-address
@@ -952,7 +1099,12 @@ __global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restric
   const char* s = seqs + off[r];
   const int L = len[r];
   u32 v = 0;
-  if (w < seq_words) {
+  if (w == seq_words - 1) {   // flag word (kamd_core.h REC_FLAG_HAS_N): the bases never reach the last sequence word
+    for (int i = 0; i < L; i++) {
+      unsigned char ch = (unsigned char)s[i] & 0xDF;
+      if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) { v = kamd::REC_FLAG_HAS_N; break; }
+    }
+  } else if (w < seq_words) {
     for (int j = 0; j < 16; j++) {
       int i = w * 16 + j;
       if (i >= L) break;
@@ -1738,7 +1890,8 @@ struct kamd_ctx {
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
   hipEvent_t ev2 = nullptr;
   hipStream_t em_stream = nullptr;
-  int kernel_a_version = 2, items_per_wave = 1024, refill_min = 8;
+  int kernel_a_version = 3, items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
+  kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
   int n_cus = 0, last_em_k = 0; unsigned last_em_grid = 0;
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
@@ -1827,6 +1980,56 @@ int count_tuples(kamd_ctx* c) {
 
 }  // namespace
 
+// ---- tuning --------------------------------------------------------------------------------------------------------------
+namespace {
+void tuning_defaults(kamd_tuning* t) {
+  memset(t, 0, sizeof *t);
+  t->kernel_a = 3; t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
+  t->em_form = 3; t->em_local_kernel = 2; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_fin_blocks = 1024;
+}
+// 0 = keep; values outside a field's range are ignored
+void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
+  if (n.kernel_a >= 1 && n.kernel_a <= 3) t->kernel_a = n.kernel_a;
+  if (n.text_verify == 1 || n.text_verify == 2) t->text_verify = n.text_verify;
+  if (n.items_per_wave >= 64) t->items_per_wave = n.items_per_wave;
+  if (n.refill_min >= 1 && n.refill_min <= 64) t->refill_min = n.refill_min;
+  if (n.lds_pad != 0) t->lds_pad = n.lds_pad < 0 ? -1 : n.lds_pad;
+  if (n.em_form >= 1 && n.em_form <= 3) t->em_form = n.em_form;
+  if (n.em_local_kernel == 1 || n.em_local_kernel == 2) t->em_local_kernel = n.em_local_kernel;
+  if (n.em_entries_per_lane != 0) t->em_entries_per_lane = n.em_entries_per_lane < 0 ? -1 : n.em_entries_per_lane;
+  if (n.em_windowed == 1 || n.em_windowed == 2) t->em_windowed = n.em_windowed;
+  if (n.em_graph == 1 || n.em_graph == 2) t->em_graph = n.em_graph;
+  if (n.em_row_lanes == 2 || n.em_row_lanes == 4 || n.em_row_lanes == 8) t->em_row_lanes = n.em_row_lanes;
+  if (n.em_fin_blocks >= 64) t->em_fin_blocks = n.em_fin_blocks;
+}
+// experiments: the same knobs from the environment, read once when a context is created
+void tuning_from_env(kamd_tuning* t) {
+  kamd_tuning n; memset(&n, 0, sizeof n);
+  auto geti = [](const char* name, int32_t* dst) { if (const char* e = getenv(name)) *dst = atoi(e); };
+  auto onoff = [](const char* name, int32_t* dst) { if (const char* e = getenv(name)) *dst = atoi(e) != 0 ? 1 : 2; };
+  geti("KAMD_KERNEL_A", &n.kernel_a);
+  onoff("KAMD_TEXT_VERIFY", &n.text_verify);
+  geti("KAMD_ITEMS_PER_WAVE", &n.items_per_wave);
+  geti("KAMD_REFILL_MIN", &n.refill_min);
+  geti("KAMD_LDS_PAD", &n.lds_pad);
+  if (const char* e = getenv("KAMD_EM_FORM")) {
+    const std::string v(e);
+    n.em_form = v == "streamed" ? 1 : v == "csr" ? 2 : v == "local" ? 3 : atoi(e);
+  }
+  geti("KAMD_EM_LOCAL_KERNEL", &n.em_local_kernel);
+  geti("KAMD_EM_K", &n.em_entries_per_lane);
+  onoff("KAMD_EM_WINDOWED", &n.em_windowed);
+  onoff("KAMD_EM_GRAPH", &n.em_graph);
+  geti("KAMD_EM_ROW_LANES", &n.em_row_lanes);
+  geti("KAMD_EM_FIN_BLOCKS", &n.em_fin_blocks);
+  tuning_merge(t, n);
+}
+void apply_tuning(kamd_ctx* c) {
+  c->kernel_a_version = c->tune.kernel_a; c->items_per_wave = c->tune.items_per_wave; c->refill_min = c->tune.refill_min;
+}
+}  // namespace
+
 // ======================================================================================================================
 // C ABI
 // ======================================================================================================================
@@ -1845,10 +2048,23 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   memset(&c->host_state, 0, sizeof c->host_state);
   if (push_state(c)) { delete c; return -100; }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
-  if (const char* e = getenv("KAMD_KERNEL_A")) c->kernel_a_version = atoi(e) == 1 ? 1 : 2;   // 1 = block-staged kernel, 2 = one probe per iteration
-  if (const char* e = getenv("KAMD_ITEMS_PER_WAVE")) c->items_per_wave = std::max(64, atoi(e));
-  if (const char* e = getenv("KAMD_REFILL_MIN")) c->refill_min = std::min(64, std::max(1, atoi(e)));
+  tuning_defaults(&c->tune);
+  tuning_from_env(&c->tune);
+  apply_tuning(c);
   *out = c;
+  return 0;
+}
+
+extern "C" int kamd_ctx_tune(kamd_ctx* c, const kamd_tuning* t) {
+  if (!c || !t) return kamd::fail(-1, "kamd_ctx_tune: null argument");
+  if (t->kernel_a == 1 && c->track_order) return kamd::fail(-1, "kamd_ctx_tune: first-occurrence EC ids need kernel A version 2 or 3");
+  tuning_merge(&c->tune, *t);
+  apply_tuning(c);
+  return 0;
+}
+extern "C" int kamd_ctx_get_tuning(const kamd_ctx* c, kamd_tuning* out) {
+  if (!c || !out) return kamd::fail(-1, "kamd_ctx_get_tuning: null argument");
+  *out = c->tune;
   return 0;
 }
 
@@ -1887,7 +2103,7 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   DevIndex d{};
   d.k = v.k; d.n_buckets = v.n_buckets; d.n_ecs = v.n_ecs;
   const u64 slots = (v.n_buckets + v.pad_buckets) * KAMD_SLOTS_PER_BUCKET;
-  if (int rc = upload(c, (const u64*)v.table, slots * 2, &d.table)) return rc;
+  if (int rc = upload(c, (const u64*)v.table, (size_t)(v.n_buckets + v.pad_buckets) * 8, &d.table)) return rc;
   if (int rc = upload(c, v.slot_block, slots, &d.slot_block)) return rc;
   if (int rc = upload(c, v.slot_dist, slots, &d.slot_dist)) return rc;
   if (int rc = upload(c, v.uec_ec, v.n_uec, &d.uec_ec)) return rc;
@@ -1909,6 +2125,7 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   if (int rc = upload(c, v.target_lens, v.n_targets + v.dlist_size, &d.target_lens)) return rc;   // incl. the D-list pseudo-targets
   d.dtable = nullptr; d.n_dbuckets = v.n_dbuckets; d.dummy_slot = v.dummy_slot; d.dummy_uec = v.dummy_uec; d.dummy_strand = v.dummy_strand;
   if (v.n_dbuckets) if (int rc = upload(c, (const u64*)v.dtable, (size_t)(v.n_dbuckets + v.dpad_buckets) * 8, &d.dtable)) return rc;
+  if (int rc = upload(c, v.utext, (size_t)v.utext_words, &d.utext)) return rc;
   HIPC(hipStreamSynchronize(c->stream));  // `ne` is a stack-owned staging buffer
   c->ix = d; c->has_index = true; c->n_ecs = v.n_ecs; c->n_targets = v.n_targets;
   if (int rc = c->dense.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;
@@ -1971,7 +2188,7 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   size_t lds_bytes = ((size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP + WAVES) * sizeof(u32);
   if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-resident kernel");
   // diagnostics: unused LDS per block lowers the number of resident wavefronts (how sensitive is kernel A to occupancy?)
-  if (const char* e = getenv("KAMD_LDS_PAD")) lds_bytes = std::min<size_t>(160 * 1024, lds_bytes + (size_t)std::max(0, atoi(e)));
+  if (c->tune.lds_pad > 0) lds_bytes = std::min<size_t>(160 * 1024, lds_bytes + (size_t)c->tune.lds_pad);
   const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
   u32* slots = c->stream_buf.as<u32>() + cur_words;
   HIPC(hipEventRecord(c->ev0, c->stream));
@@ -1983,6 +2200,52 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
     HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER, false>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
                        n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
+  }
+  HIPC(hipEventRecord(c->ev1, c->stream));
+  const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
+  hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
+                     fd, out);
+  HIPC(hipEventRecord(c->ev2, c->stream));
+  return 0;
+}
+// items whose reads do not fit the LDS-resident kernel: every item is flagged for the overflow kernel, which reads from HBM
+__global__ void k_mark_overflow(u32* raw, int raw_stride, u64 n_items) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_items) raw[i * (u64)raw_stride] = RAW_OVERFLOW;
+}
+template <bool PAIRED, bool FILTER>
+int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
+                    AlignOut& out) {
+  constexpr int WAVES = BLOCK / 64;
+  const int lane_words = seq_words * (PAIRED ? 2 : 1);
+  const int stride = 2 + TUPLE_CAP + (FILTER ? 4 : 0);
+  // every item owns a fixed slot of the stream: raw record from k_match_v3, rewritten in place by k_classify
+  const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
+  if (int rc = c->stream_buf.ensure((cur_words + n_items * (u64)stride) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
+  if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
+  out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+  c->host_state.stream_words = cur_words + n_items * (u64)stride;
+  c->host_state.n_recs = cur_recs + n_items;
+  if (int rc = push_state(c)) return rc;
+  const size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * V3_LIST_CAP) * sizeof(u32);
+  const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
+  u32* slots = c->stream_buf.as<u32>() + cur_words;
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  if (lds_bytes > 64 * 1024) {
+    // reads of more than ~480 bases (pairs) / ~980 (single): the kernel would hold too few wavefronts per CU (or none: the
+    // CU has 160 KB) -- the reference has no length limit, so such batches take the HBM-resident path item by item
+    hipLaunchKernelGGL(k_mark_overflow, dim3(grid_for(n_items, BLOCK)), dim3(BLOCK), 0, c->stream, slots, stride, n_items);
+  } else {
+#define KAMD_LAUNCH_V3(DLV, TXT)                                                                                                         \
+  do {                                                                                                                                  \
+    HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, \
+                       d_len, n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);  \
+  } while (0)
+    const bool dl = c->ix.n_dbuckets != 0, txt = c->tune.text_verify != 0;
+    if (dl) { if (txt) KAMD_LAUNCH_V3(true, true); else KAMD_LAUNCH_V3(true, false); }
+    else { if (txt) KAMD_LAUNCH_V3(false, true); else KAMD_LAUNCH_V3(false, false); }
+#undef KAMD_LAUNCH_V3
   }
   HIPC(hipEventRecord(c->ev1, c->stream));
   const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
@@ -2016,7 +2279,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   const int rec_words = (int)kamd_packed_record_words(max_len);
   const int item_words = rec_words * (o->paired ? 2 : 1);
   const size_t lds_bytes = (size_t)BLOCK * item_words * 4 + (size_t)BLOCK * TUPLE_CAP * 4;
-  if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-staged kernel");
+  if (c->kernel_a_version == 1 && lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-staged kernel");
   // positional filters (ProcessReads.cpp:1095-1145): has_mean_fl is set by -l only, and while the reads are processed
   // mean_fl is the -l value itself (MinCollector constructor, MinCollector.h:38-41; the truncated-Gaussian mean of
   // init_mean_fl_trunc -- 199.99999999999994 for -l 200 -s 25 -- replaces it only after ProcessReads, main.cpp:2668-2671);
@@ -2036,8 +2299,14 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   AlignOut out{c->dense.as<u32>(), c->track_order ? c->dense_first.as<u64>() : nullptr, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
                c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
   int rc = 0;
-  if (c->kernel_a_version != 2) HIPC(hipEventRecord(c->ev0, c->stream));
-  if (c->kernel_a_version == 2) {
+  if (c->kernel_a_version == 1) HIPC(hipEventRecord(c->ev0, c->stream));
+  if (c->kernel_a_version == 3) {
+    if (o->paired) rc = filter ? launch_align_v3<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
+                               : launch_align_v3<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+    else rc = filter ? launch_align_v3<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
+                     : launch_align_v3<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+    if (rc) return rc;
+  } else if (c->kernel_a_version == 2) {
     if (o->paired) rc = filter ? launch_align_v2<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
                                : launch_align_v2<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
     else rc = filter ? launch_align_v2<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
@@ -2063,7 +2332,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
     out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-    const u64 ov_base = c->kernel_a_version == 2 ? cur_recs : ~0ULL;
+    const u64 ov_base = c->kernel_a_version >= 2 ? cur_recs : ~0ULL;
     if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
                      else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
     else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
@@ -2116,6 +2385,7 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   s->n_probes = c->host_state.st_probes; s->n_bucket_reads = c->host_state.st_bucket_reads;
   s->n_distinct_tuples = c->n_distinct_tuples; s->n_stream_words = c->host_state.stream_words;
   s->n_raw_words = c->host_state.st_raw_words;
+  s->n_text_hits = c->host_state.st_text_hits;
   return 0;
 }
 
@@ -2313,7 +2583,7 @@ extern "C" int kamd_ec_explicit_replace(kamd_ctx* c, const uint32_t* d_words, ui
 // ---- finalize ---------------------------------------------------------------------------------------------------------
 extern "C" int kamd_ec_track_order(kamd_ctx* c, int on) {
   if (!c) return kamd::fail(-1, "kamd_ec_track_order: null context");
-  if (on && c->kernel_a_version != 2) return kamd::fail(-1, "kamd_ec_track_order: needs kernel A version 2 (records in input order)");
+  if (on && c->kernel_a_version < 2) return kamd::fail(-1, "kamd_ec_track_order: needs kernel A version 2 or 3 (records in input order)");
   if (c->host_state.st_processed != 0) return kamd::fail(-1, "kamd_ec_track_order: call before the first batch (or after kamd_ec_reset)");
   c->track_order = on != 0;
   return 0;
@@ -2525,8 +2795,9 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   // entries per lane: the smallest K whose chunks fit the chip in one go at 12 wavefronts per CU (measured on config #3:
   // 28.0 us per round at K = 24 / 3038 chunks against 32.7 at K = 20 / 3646 and 32.5 at K = 16 / 4557, same box)
   int K = PM_KS[sizeof(PM_KS) / sizeof(PM_KS[0]) - 1];
-  if (const char* e = getenv("KAMD_EM_K")) { const int v = atoi(e); for (int k : PM_KS) if (k == v) K = v; }
-  else for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 12) { K = k; break; }
+  bool k_forced = false;
+  if (c->tune.em_entries_per_lane > 0) { for (int k : PM_KS) if (k == c->tune.em_entries_per_lane) { K = k; k_forced = true; } }
+  if (!k_forced) for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 12) { K = k; break; }
   const u32 chunk = 64u * (u32)K;
   const u64 n_chunks64 = (NZ + chunk - 1) / chunk;
   if (n_chunks64 >= 0x7FFFFFF0ULL) return 1;
@@ -2595,7 +2866,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   HIPC(hipStreamSynchronize(c->stream));
   P->n_fix[0] = plan_words[0]; P->n_fix[1] = plan_words[1];
   P->windowed = plan_words[2] > (u32)PM_LDS_SLOTS;
-  if (const char* e = getenv("KAMD_EM_WINDOWED")) { if (atoi(e) != 0) P->windowed = true; }
+  if (c->tune.em_windowed == 1) P->windowed = true;
   P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos;
   c->last_em_nnz_multi = NZ; c->last_em_nseg = n_chunks; c->last_em_necs = n_ecs; c->last_em_k = K;
   c->last_em_grid = grid_for(n_chunks, PM_BLOCK / 64);
@@ -2964,7 +3235,7 @@ int em_local_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, c
   const int chunk = 64;
   EmLocalGpu B(c, P);
   if (level >= 2) { B.dev = dev; B.dev_ready = true; }
-  if (const char* e = getenv("KAMD_EML_KERNEL")) B.kernel = atoi(e) == 1 ? 1 : 2;
+  B.kernel = c->tune.em_local_kernel == 1 ? 1 : 2;
   if (int rc = B.setup(chunk)) return rc;
   const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
@@ -3041,11 +3312,10 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     HIPC(hipStreamSynchronize(c->stream));
   }
   if (!spec && n_ecs) {   // EXPERIMENTAL opt-in: the component-local form (kamd_em_local.h)
-    const char* el = getenv("KAMD_EM_LOCAL");
-    if (el && atoi(el) != 0) {
+    if (c->tune.em_form == 3) {
       const int rc = em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
-                                         (int)min_rounds, alpha, alpha_before_zeroes, rounds, atoi(el));
-      if (rc <= 0) return rc;   // 1 = not applicable: fall through to the streamed form
+                                         (int)min_rounds, alpha, alpha_before_zeroes, rounds, 2);
+      if (rc <= 0) return rc;   // 1 = not applicable (a component does not fit a workgroup): the streamed form takes over
     }
   }
   for (DBuf* b : {&c->em_alpha, &c->em_next, &c->em_eff, &c->em_a0, &c->em_a1, &c->em_single})
@@ -3077,8 +3347,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   PmPlan plan;
   bool streamed = false;
   {
-    const char* ep = getenv("KAMD_EM_STREAMED");
-    if (!(ep && atoi(ep) == 0)) {
+    if (c->tune.em_form != 2) {
       const int rc = em_streamed_setup(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, T, col_cnt, col_fill, &plan);
       if (rc < 0) return rc;
       streamed = rc == 0;
@@ -3118,11 +3387,11 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   }  // !streamed
   const int chunk = 64;
   int row_lanes = 4;
-  if (const char* e = getenv("KAMD_EM_ROW_LANES")) row_lanes = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
+  row_lanes = c->tune.em_row_lanes;
   const unsigned grid_rows = grid_for(std::max<u64>(n_ecs, 1) * row_lanes, BLOCK);
   const unsigned grid_seg = grid_for(std::max<u64>(n_seg, 1) * EM_SEG_LANES, BLOCK);
   unsigned fin_cap = 1024;
-  if (const char* e = getenv("KAMD_EM_FIN_BLOCKS")) fin_cap = (unsigned)std::max(64, atoi(e));
+  fin_cap = (unsigned)c->tune.em_fin_blocks;
   const unsigned grid_fin = (unsigned)std::min<u64>(grid_for(std::max<u64>(n_active, 1) * EM_FIN_LANES, BLOCK), fin_cap);
   // The launch-bound inner loop is captured once as a hipGraph of `chunk` rounds (4 kernels each) on a private stream
   // and replayed until the device-side state says done; all loop state lives in device memory, so every replay is
@@ -3188,8 +3457,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   };
   EmNow now{};
   if (!spec) {
-    const char* eg = getenv("KAMD_EM_GRAPH");
-    bool use_graph = !(eg && atoi(eg) == 0);
+    bool use_graph = c->tune.em_graph != 2;
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     hipStream_t es = c->stream;
     if (use_graph) {
@@ -3288,7 +3556,7 @@ __global__ void k_random_lines(const u64* __restrict__ table, u64 n_buckets, int
   for (int i = 0; i < iters; i++) {
     const u64 b = __umul64hi(x, n_buckets);
     const ulonglong2* bp = (const ulonglong2*)(table + b * 8);
-    const ulonglong2 s0 = bp[0], s1 = bp[1], s2 = bp[2], s3 = bp[3];
+    const ulonglong2 s0 = bp[0], s1 = bp[1], s2 = bp[2], s3 = bp[3];   // (the whole 64-byte bucket)
     const u64 v = s0.x ^ s0.y ^ s1.x ^ s1.y ^ s2.x ^ s2.y ^ s3.x ^ s3.y;
     acc ^= v;
     x = kamd::mix64(x ^ v);  // the next address depends on the loaded line

@@ -65,6 +65,7 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
   using namespace kamd;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
   const Table t = emu_table(v, !paired, (use_stepper & 2) != 0);   // bit 1 of use_stepper: --no-jump
+  const bool use_text = (use_stepper & 4) != 0;                     // bit 2: the unitig text in front of the table (kernel A v3)
   use_stepper &= 1;
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
@@ -87,11 +88,21 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
       for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
         uint64_t r = paired ? 2 * i + mate : i;
         ReadView rv{words + r * rec, words + r * rec + sw, lens[r]};
+        // the packers' has-N flag word decides whether the mask plane is consulted (as in kernel A v3)
+        rv.has_n = (rv.seq[sw - 1] & REC_FLAG_HAS_N) != 0;
         MatchState st; match_init(st, rv, v->k);
         while (st.phase != PH_DONE) {
           bool fc; uint64_t canon = window_canon(rv, st.w, v->k, &fc);
-          Probe p = probe_table(phase_table(t, st.phase), canon, fc, nullptr);
-          if (st.phase != PH_DLIST) ++*probes;   // dbg.find calls of match() only
+          Probe p; p.found = false;
+          if (use_text && text_applies(st)) {
+            if (text_canon(v->utext, text_pos_of(st), v->k) == canon) {
+              p.found = true; p.strand = st.um_strand; p.uec = st.um_uec; p.dist = 0; p.slot = 0; p.gpos = 0;
+              ++*probes; ++probes[1];
+            } else { st.text_tried = true; continue; }
+          } else {
+            p = probe_table(phase_table(t, st.phase), canon, fc, nullptr);
+            if (st.phase != PH_DLIST) ++*probes;   // dbg.find calls of match() only
+          }
           if (t.n_dbuckets) match_feed<true>(st, rv, v->k, p, ul, mate, mf[mate], t); else match_feed<false>(st, rv, v->k, p, ul, mate, mf[mate], t);
         }
       }

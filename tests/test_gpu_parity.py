@@ -191,35 +191,34 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local2"])
-def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
-    """The streamed EM form (default and forced chunk sizes: 64 x 8 entries makes the long rows / hub columns span many
-    chunks -> fix-up launches; "wK": the general pass for chunks with more segment ends than LDS slots, forced) and the CSR
-    form against the oracle's EMAlgorithm::run restatement."""
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local1", "fallback"])
+def test_em_forms_agree_with_oracle(k, ka):
+    """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
+    64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
+    with more segment ends than LDS slots, forced), the CSR form, and the component-local LDS form (both kernels) on a matrix
+    of gene-sized components; "fallback": the component-local form asked for on a matrix whose hub component does not fit a
+    workgroup -- the streamed form must take over."""
     import torch
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
-    if k in ("local", "local2"):
-        # the component-local form (kamd_em_local.h) is opt-in and has not run on hardware yet: only with KAMD_TEST_EXPERIMENTAL=1
-        if os.environ.get("KAMD_TEST_EXPERIMENTAL") != "1":
-            pytest.skip("experimental EM form: set KAMD_TEST_EXPERIMENTAL=1")
+    tune = {}
+    if k in ("local", "local1"):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
-        alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
-        monkeypatch.setenv("KAMD_EM_LOCAL", "1" if k == "local" else "2")   # 1: plan built on the host, 2: on the device
+        tune = dict(em_form="local", em_local_kernel=2 if k == "local" else 1)
         k = "local"
+    elif k == "fallback":
+        tune = dict(em_form="local")
     else:
-        monkeypatch.delenv("KAMD_EM_LOCAL", raising=False)
-    monkeypatch.setenv("KAMD_EM_WINDOWED", "1" if isinstance(k, str) and k[0] == "w" else "0")
-    if isinstance(k, str) and k[0] == "w":
-        k = int(k[1:])
+        tune = dict(em_form="csr" if k == "csr" else "streamed")
+        if isinstance(k, str) and k[0] == "w":
+            tune["em_windowed"] = True
+            k = int(k[1:])
+        if isinstance(k, int):
+            tune["em_entries_per_lane"] = k
     alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
-    monkeypatch.setenv("KAMD_EM_STREAMED", "0" if k == "csr" else "1")
-    if isinstance(k, int):
-        monkeypatch.setenv("KAMD_EM_K", str(k))
-    else:
-        monkeypatch.delenv("KAMD_EM_K", raising=False)
     ctx = ka.Context(0)
     try:
+        ctx.tune(**tune)
         d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda()
         alpha, abz, rounds = ctx.em_run(eff, csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32)))
         prof = ctx.profile()
@@ -227,6 +226,8 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
         ctx.close()
     if k == "local":
         assert prof["em_k"] == -1                          # the local form ran (kamd_profile.last_em_k)
+    elif k == "fallback":
+        assert prof["em_k"] > 0                            # the streamed form took over
     else:
         assert (prof["em_k"] == 0) == (k == "csr")
     if isinstance(k, int):

@@ -39,11 +39,28 @@ def test_flattened_index_matches_oracle_parse(case, idx):
     mine = {tuple(ec_ids[ec_off[i]:ec_off[i + 1]].tolist()) for i in range(v.n_ecs)}
     theirs = {tuple(o.ec(i)) for i in range(o.num_ecs)}
     assert mine == theirs
-    # table invariants: every k-mer placed once, load factor <= 0.5 over 4-slot buckets
-    table = _np(v.table, (v.n_buckets + v.pad_buckets) * 8, np.uint64)
-    keys = table[0::2] & np.uint64((1 << 62) - 1)
-    assert int((keys != np.uint64((1 << 62) - 1)).sum()) == v.n_kmers
-    assert v.n_kmers <= 2 * v.n_buckets + 2
+    # table invariants: every k-mer placed once, load factor <= 0.5 over 3-slot buckets (words 0..2 of each 64-byte bucket)
+    table = _np(v.table, (v.n_buckets + v.pad_buckets) * 8, np.uint64).reshape(-1, 8)
+    keys = table[:, 0:3] & np.uint64((1 << 62) - 1)
+    used = keys != np.uint64((1 << 62) - 1)
+    assert int(used.sum()) == v.n_kmers
+    assert 2 * v.n_kmers <= 3 * v.n_buckets + 6
+    # text positions: every k-mer's slot points at its own bases in the unitig text
+    gpos = np.ascontiguousarray(table[:, 6:8]).view(np.uint32).reshape(-1, 4)[:, 0:3]
+    text = _np(v.utext, v.utext_words, np.uint32)
+    assert v.text_bases == int(_np(v.unitig_len, v.n_unitigs, np.uint32).sum())
+    bases = ((text[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).reshape(-1).astype(np.uint64)
+    kk = int(v.k)
+    sel = np.argwhere(used)[:: max(1, int(used.sum()) // 4000)]   # a sample of the slots
+    for b, j in sel:
+        g = int(gpos[b, j])
+        fwd = 0
+        for x in bases[g:g + kk]:
+            fwd = (fwd << 2) | int(x)
+        rc = 0
+        for x in bases[g:g + kk][::-1]:
+            rc = (rc << 2) | (3 - int(x))
+        assert min(fwd, rc) == int(keys[b, j]), (case, b, j)
 
 
 @pytest.mark.parametrize("case", common.CASES)
@@ -98,6 +115,12 @@ def test_resumable_state_machine_equals_match(case, no_jump, idx):
     a, pa = E.tuples(e, words, l16, len(r1), paired, max_len, 0 | 2 * no_jump, stride=80)
     b, pb = E.tuples(e, words, l16, len(r1), paired, max_len, 1 | 2 * no_jump, stride=80)
     assert pa == pb and np.array_equal(a, b)
+    # kernel A v3: jump / middle / back-off windows answered from the unitig text where they match it -- same sets, same
+    # number of dbg.find calls, some of them without touching the table
+    t, pt = E.tuples(e, words, l16, len(r1), paired, max_len, 1 | 2 * no_jump | 4, stride=80)
+    assert pt == pa and np.array_equal(a, t)
+    if not no_jump and case in ("ref_test_pe", "human_pe", "yeast_se"):
+        assert E.tuples.last_text_hits > 0
     if no_jump and case == "mosaic_pe":
         c, pc = E.tuples(e, words, l16, len(r1), paired, max_len, 0, stride=80)
         assert pa > pc and not np.array_equal(a, c)   # the flag does something on this case
