@@ -107,13 +107,16 @@ typedef struct {
   int32_t lds_pad;             /* diagnostic: unused LDS bytes added to every block of kernel A (lowers the occupancy); -1 = none */
   int32_t em_form;             /* EM: 1 = streamed two-launch form, 2 = CSR three-launch form, 3 = component-local LDS form (falls back
                                   to 1 when a connected component does not fit a workgroup), default 3 */
-  int32_t em_local_kernel;     /* component-local form: 2 = lanes share rows / columns (default), 1 = one thread per row / transcript */
+  int32_t em_local_kernel;     /* component-local form: 3 = sliced-ELLPACK layout, one lane per segment (default), 2 = CSR, lanes share rows /
+                                  columns, 1 = CSR, one thread per row / transcript */
   int32_t em_entries_per_lane; /* streamed form: K in {8,12,...,32}; -1 = automatic (default) */
   int32_t em_windowed;         /* streamed form: force the general windowed pass (test hook; default off) */
   int32_t em_graph;            /* rounds of the streamed / CSR forms replayed as a hipGraph (default on) */
   int32_t em_row_lanes;        /* CSR form: lanes per row, 2 / 4 (default) / 8 */
   int32_t em_fin_blocks;       /* CSR form: blocks of the final pass (default 1024) */
-  int32_t reserved[4];
+  int32_t em_local_block;      /* component-local form, kernel 3: threads per workgroup, 128 / 256 (default) / 512 */
+  int32_t em_group_div;        /* component-local form, kernel 3: groups hold about nnz / (CUs x this) entries (default 4) */
+  int32_t reserved[2];
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);
@@ -180,8 +183,10 @@ typedef struct {
   uint64_t last_em_nnz_multi;  /* nnz in multi-transcript rows, */
   uint64_t last_em_nseg;       /* column segments (CSR form) or chunks per direction (streamed form), */
   uint64_t last_em_necs;       /* rows */
-  int32_t last_em_k;           /* streamed EM form: entries per lane (0: the CSR form ran -- partitioned runs, env KAMD_EM_STREAMED=0) */
-  uint32_t last_em_grid;       /* ... and the grid of its two per-round launches (blocks of 256 threads, one chunk per wavefront) */
+  int32_t last_em_k;           /* streamed EM form: entries per lane; 0: the CSR form ran; -1 / -2: the component-local form (CSR / sliced ELLPACK) */
+  uint32_t last_em_grid;       /* streamed form: grid of its two per-round launches (blocks of 256 threads, one chunk per wavefront);
+                                  component-local form: number of groups (= workgroups per launch) */
+  uint32_t last_em_lds;        /* component-local form: LDS bytes per workgroup */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

@@ -52,7 +52,7 @@ class Tuning(C.Structure):
     """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
     _fields_ = [(n, C.c_int32) for n in ("kernel_a", "text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form",
                                          "em_local_kernel", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
-                                         "em_fin_blocks")] + [("reserved", C.c_int32 * 4)]
+                                         "em_fin_blocks", "em_local_block", "em_group_div")] + [("reserved", C.c_int32 * 2)]
 
 
 EM_FORMS = {"streamed": 1, "csr": 2, "local": 3}
@@ -62,7 +62,7 @@ class _Profile(C.Structure):
     _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64),
                 ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32), ("last_em_nnz", C.c_uint64),
                 ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64),
-                ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32)]
+                ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32), ("last_em_lds", C.c_uint32)]
 
 
 class _EcResult(C.Structure):
@@ -319,9 +319,12 @@ class Context:
         _check(load_library().kamd_fld_prefetch(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len),
                "kamd_fld_prefetch")
 
-    def fld_from_batch(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
-        flens = np.zeros(MAX_FRAG_LEN, np.uint32)
-        used = C.c_uint64(0)
+    def fld_from_batch(self, opts: QuantOpts, words, lens, n_items: int, max_len: int, flens=None, used: int = 0):
+        """Fragment-length sample of the first 10000 qualifying pairs in input order.  `flens` / `used` continue a sample
+        started on earlier batches (the reference carries tlencount across batches, src/ProcessReads.cpp:981-1008)."""
+        if flens is None:
+            flens = np.zeros(MAX_FRAG_LEN, np.uint32)
+        used = C.c_uint64(used)
         _check(load_library().kamd_fld_from_batch(self._h, C.byref(opts), words.data_ptr(), lens.data_ptr(), n_items, max_len,
                                                   flens.ctypes.data, C.byref(used)), "kamd_fld_from_batch")
         return flens, int(used.value)
@@ -342,7 +345,7 @@ class Context:
         return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters),
                 "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version),
                 "em_nnz": int(p.last_em_nnz), "em_nnz_multi": int(p.last_em_nnz_multi), "em_nseg": int(p.last_em_nseg),
-                "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid)}
+                "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid), "em_lds": int(p.last_em_lds)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):
@@ -560,20 +563,26 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
     index = ctx.index
     batches = list(batches)
     n_proc = 0
+    estimate_fld = opts.fld == 0.0 and bool(opts.paired)
+    flens = np.zeros(MAX_FRAG_LEN, np.uint32)
+    used = 0
     for bi, (words, lens, n_items, max_len) in enumerate(batches):
-        if bi == 0 and opts.fld == 0.0 and opts.paired:
+        if bi == 0 and estimate_fld:
             ctx.fld_prefetch(opts, words, lens, n_items, max_len)   # the FLD kernel of the first prefix runs underneath kernel A
         ctx.pseudoalign(opts, words, lens, n_items, max_len)
         n_proc += n_items
-    # FLD: estimated from the first 10000 qualifying pairs of the input (rank 0's first batch) or given by -l/-s
+        # FLD: the first 10000 qualifying pairs of the input in order, carried across batches until the sample is full
+        # (src/ProcessReads.cpp:981-1008: tlencount persists from batch to batch); rank 0's reads when several ranks run
+        if estimate_fld and used < 10000 and (not _dist_on() or _dist_rank(group) == 0):
+            flens, used = ctx.fld_from_batch(opts, words, lens, n_items, max_len, flens, used)
     if opts.fld == 0.0:
-        words, lens, n_items, max_len = batches[0]
-        flens, _ = ctx.fld_from_batch(opts, words, lens, n_items, max_len)
         if group is not None or _dist_on():
             flens = _broadcast_np(ctx, flens, group)
+            n_proc = _sum_int(ctx, n_proc, group)
         mft = mean_frag_lens_trunc(flens)
     else:
-        flens = np.zeros(MAX_FRAG_LEN, np.uint32)
+        if group is not None or _dist_on():
+            n_proc = _sum_int(ctx, n_proc, group)
         mft = trunc_gaussian_fld(opts.fld, opts.sd)
     ctx.allreduce_ec_counts(group)
     ecs = ctx.finalize(download=download_ecs)
@@ -597,6 +606,19 @@ def _dist_on() -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     except Exception:
         return False
+
+
+def _dist_rank(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_rank(group)
+
+
+def _sum_int(ctx: Context, v: int, group=None) -> int:
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(v)], dtype=torch.int64, device=f"cuda:{ctx.device}")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
 
 
 def _broadcast_np(ctx: Context, arr: np.ndarray, group=None) -> np.ndarray:

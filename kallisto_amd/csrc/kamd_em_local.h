@@ -462,8 +462,8 @@ struct CpuBackend {
 
 // ---- the driver: EMAlgorithm::run's loop control over a backend that can only run whole chunks ----------------------
 // alpha_out / abz_out: [T].  Returns the number of rounds ("ran for i rounds").
-template <class Backend>
-int run(Backend& B, const Plan& P, int n_iter, int min_rounds, int chunk, double* alpha_out, double* abz_out) {
+template <class Backend, class PlanT>
+int run(Backend& B, const PlanT& P, int n_iter, int min_rounds, int chunk, double* alpha_out, double* abz_out) {
   const uint64_t M = P.tr_base[P.n_groups];
   std::vector<int> hist((size_t)chunk);
   int base = 0, rounds = 0;

@@ -28,6 +28,7 @@
 #include "kamd_core.h"
 #include "kamd_host.h"
 #include "kamd_em_local.h"
+#include "kamd_em_sell.h"
 
 #define HIPC(x)                                                                                   \
   do {                                                                                            \
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
     // 2.+3. every busy lane: one probe, then advance its state machine
     if (have && busy) {
       const u32* base = my_words + (size_t)(mate ? rec_words : 0) * 64;
-      kamd::ReadView rv{base, base + (size_t)seq_words * 64, mate ? len1 : len0, 64};
+      kamd::ReadView rv{base, base + (size_t)seq_words * 64, mate ? len1 : len0, 64, 64};
       bool fc;
       const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
       const kamd::Probe p = kamd::probe_table(DL ? kamd::phase_table(t, ms.phase) : t, canon, fc, &breads);
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
         mate = 1;
         const u32* b1 = my_words + (size_t)rec_words * 64;
-        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64};
+        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64, 64};
         kamd::match_init(ms, r1, k);
       }
       busy = ms.phase != kamd::PH_DONE;
@@ -365,12 +366,12 @@ __global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __re
       ul.n = 0; ul.overflow = false;
       mf0 = kamd::MateFirst{0, 0, -1, false}; mf1 = kamd::MateFirst{0, 0, -1, false};
       mate = 0;
-      kamd::ReadView r0{my_words, my_words + (size_t)seq_words * 64, len0, 64};
+      kamd::ReadView r0{my_words, my_words + (size_t)seq_words * 64, len0, 64, 64};
       kamd::match_init(ms, r0, k);
       if (ms.phase == kamd::PH_DONE && PAIRED) {
         mate = 1;
         const u32* b1 = my_words + (size_t)rec_words * 64;
-        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64};
+        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64, 64};
         kamd::match_init(ms, r1, k);
       }
       have = true;
@@ -1870,7 +1871,7 @@ struct kamd_ctx {
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
   DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
-  DBuf eml_tmp;                  // component-local EM (experimental): set-up scratch
+  DBuf eml_tmp, ems_tmp, ems_plan;   // component-local EM: set-up scratch, sliced-ELLPACK plan
   DBuf fld_tl, fld_card, fld_scratch, fld_items;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
@@ -1893,7 +1894,7 @@ struct kamd_ctx {
   int kernel_a_version = 3, items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
-  int n_cus = 0, last_em_k = 0; unsigned last_em_grid = 0;
+  int n_cus = 0, last_em_k = 0; unsigned last_em_grid = 0, last_em_lds = 0;
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
 };
 
@@ -1985,7 +1986,7 @@ namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->kernel_a = 3; t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_kernel = 2; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 256; t->em_group_div = 4; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024;
 }
 // 0 = keep; values outside a field's range are ignored
@@ -1996,7 +1997,9 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.refill_min >= 1 && n.refill_min <= 64) t->refill_min = n.refill_min;
   if (n.lds_pad != 0) t->lds_pad = n.lds_pad < 0 ? -1 : n.lds_pad;
   if (n.em_form >= 1 && n.em_form <= 3) t->em_form = n.em_form;
-  if (n.em_local_kernel == 1 || n.em_local_kernel == 2) t->em_local_kernel = n.em_local_kernel;
+  if (n.em_local_kernel >= 1 && n.em_local_kernel <= 3) t->em_local_kernel = n.em_local_kernel;
+  if (n.em_local_block == 128 || n.em_local_block == 256 || n.em_local_block == 512) t->em_local_block = n.em_local_block;
+  if (n.em_group_div >= 1 && n.em_group_div <= 1024) t->em_group_div = n.em_group_div;
   if (n.em_entries_per_lane != 0) t->em_entries_per_lane = n.em_entries_per_lane < 0 ? -1 : n.em_entries_per_lane;
   if (n.em_windowed == 1 || n.em_windowed == 2) t->em_windowed = n.em_windowed;
   if (n.em_graph == 1 || n.em_graph == 2) t->em_graph = n.em_graph;
@@ -2018,6 +2021,8 @@ void tuning_from_env(kamd_tuning* t) {
     n.em_form = v == "streamed" ? 1 : v == "csr" ? 2 : v == "local" ? 3 : atoi(e);
   }
   geti("KAMD_EM_LOCAL_KERNEL", &n.em_local_kernel);
+  geti("KAMD_EM_LOCAL_BLOCK", &n.em_local_block);
+  geti("KAMD_EM_GROUP_DIV", &n.em_group_div);
   geti("KAMD_EM_K", &n.em_entries_per_lane);
   onoff("KAMD_EM_WINDOWED", &n.em_windowed);
   onoff("KAMD_EM_GRAPH", &n.em_graph);
@@ -2083,7 +2088,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -2242,7 +2247,7 @@ int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
     hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, \
                        d_len, n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);  \
   } while (0)
-    const bool dl = c->ix.n_dbuckets != 0, txt = c->tune.text_verify != 0;
+    const bool dl = c->ix.n_dbuckets != 0, txt = c->tune.text_verify == 1;
     if (dl) { if (txt) KAMD_LAUNCH_V3(true, true); else KAMD_LAUNCH_V3(true, false); }
     else { if (txt) KAMD_LAUNCH_V3(false, true); else KAMD_LAUNCH_V3(false, false); }
 #undef KAMD_LAUNCH_V3
@@ -2882,6 +2887,7 @@ struct EmLocalDev {
   const u32* row_base; const u32* tr_base; const u64* nz_base;
   const u32* row_ptr; const u32* col_ptr; const uint16_t* row_tr; const uint16_t* col_row;
   const u64* cw; const double* single; const double* eff;
+  const u32* tr_id = nullptr;   // (device-built plans only)
 };
 __global__ __launch_bounds__(EML_BLOCK) void k_em_local(EmLocalDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char eml_smem[];
@@ -3012,6 +3018,186 @@ __global__ __launch_bounds__(EML2_BLOCK) void k_em_local2(EmLocalDev P, double* 
   }
   for (u32 i = tid; i < nT; i += EML2_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
   if (hist && (int)tid < n_rounds && s_hist[tid]) atomicAdd(&hist[tid], s_hist[tid]);
+}
+// ---- component-local EM over the sliced-ELLPACK layout (kamd_em_sell.h) ---------------------------------------------------
+// One workgroup per group, the whole group in LDS for the rounds of a launch.  A wavefront takes whole slices: lane l walks
+// the entries of its segment at stream[j * 64 + l] (u16 local index -> gather of an FP64 value, padding points at a zero slot),
+// j < width of the slice -- no row pointers, no cross-lane reduction except in the few slices that hold split segments (one
+// segmented DPP scan).  The lane that completes a segment finishes it at once (g = count / S for a row; next alpha, the
+// convergence test and a = alpha / eff for a transcript), so a round has two block barriers.
+struct EmSellDev {
+  const u32* row_base; const u32* tr_base; const u32* rslice_base; const u32* cslice_base; const u64* rell_base; const u64* cell_base;
+  const u32* rdesc; const u32* cdesc; const uint16_t* rell; const uint16_t* cell;
+  const u64* cw; const double* single; const double* eff;
+};
+constexpr int EMS_MAX_BLOCK = 512;
+// sum over the lane's entries of one slice
+__device__ __forceinline__ double ems_slice_sum(const uint16_t* e, u32 width, const double* src) {
+  double S = 0.0;
+  u32 j = 0;
+  for (; j + 4 <= width; j += 4) {
+    const u32 i0 = e[(size_t)j * 64], i1 = e[(size_t)(j + 1) * 64], i2 = e[(size_t)(j + 2) * 64], i3 = e[(size_t)(j + 3) * 64];
+    const double v0 = src[i0], v1 = src[i1], v2 = src[i2], v3 = src[i3];
+    S += v0; S += v1; S += v2; S += v3;
+  }
+  for (; j < width; j++) S += src[e[(size_t)j * 64]];
+  return S;
+}
+__global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
+  __shared__ int s_hist[EML_MAX_ROUNDS];
+  namespace L = kamd_em_sell;
+  const u32 g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = lane_id();
+  const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = nthr >> 6;
+  const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
+  const u32 rs0 = P.rslice_base[g], nrs = P.rslice_base[g + 1] - rs0, cs0 = P.cslice_base[g], ncs = P.cslice_base[g + 1] - cs0;
+  const u64 re0 = P.rell_base[g], ce0 = P.cell_base[g];
+  const u32 nru = (u32)(P.rell_base[g + 1] - re0), ncu = (u32)(P.cell_base[g + 1] - ce0);
+  // the layout kamd_em_sell::group_bytes() prices
+  double* s_al0 = reinterpret_cast<double*>(ems_smem);
+  double* s_a0 = s_al0 + (nT + 1); double* s_al1 = s_a0 + (nT + 1); double* s_a1 = s_al1 + (nT + 1);
+  double* s_single = s_a1 + (nT + 1); double* s_eff = s_single + nT; double* s_g = s_eff + nT;
+  u64* s_cw = reinterpret_cast<u64*>(s_g + (nR + 1));
+  u32* s_rdesc = reinterpret_cast<u32*>(s_cw + nR); u32* s_cdesc = s_rdesc + 2 * nrs;
+  uint16_t* s_rell = reinterpret_cast<uint16_t*>(s_cdesc + 2 * ncs); uint16_t* s_cell = s_rell + ((nru + 1) & ~1u);
+  for (u32 i = tid; i < nT; i += nthr) {
+    double al = alpha[t0 + i], av = a[t0 + i];
+    if (clamp && al < 1e-7 / 10.0) { al = 0.0; av = 0.0; }   // the final round reads alpha < alpha_limit / 10 as 0 (:212-221)
+    s_al0[i] = al; s_a0[i] = av; s_single[i] = P.single[t0 + i]; s_eff[i] = P.eff[t0 + i];
+  }
+  for (u32 i = tid; i < nR; i += nthr) s_cw[i] = P.cw[r0 + i];
+  for (u32 i = tid; i < 2 * nrs; i += nthr) s_rdesc[i] = P.rdesc[2 * (u64)rs0 + i];
+  for (u32 i = tid; i < 2 * ncs; i += nthr) s_cdesc[i] = P.cdesc[2 * (u64)cs0 + i];
+  // streams: a padding entry becomes the index of the zero slot (metadata words never hold 0xFFFF halves)
+  for (u32 i = tid; i < nru; i += nthr) { const uint16_t v = P.rell[re0 + i]; s_rell[i] = v == (uint16_t)L::SELL_PAD ? (uint16_t)nT : v; }
+  for (u32 i = tid; i < ncu; i += nthr) { const uint16_t v = P.cell[ce0 + i]; s_cell[i] = v == (uint16_t)L::SELL_PAD ? (uint16_t)nR : v; }
+  if (tid == 0) { s_al0[nT] = s_a0[nT] = s_al1[nT] = s_a1[nT] = 0.0; s_g[nR] = 0.0; }
+  if (tid < EML_MAX_ROUNDS) s_hist[tid] = 0;
+  __syncthreads();
+  double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
+  for (int r = 0; r < n_rounds; r++) {
+    // rows: S_e over the row's transcripts, then g_e = count_e / S_e (rows the reference skips get 0: count 0, :133-135;
+    // denom below denorm_min, :156-158)
+    for (u32 s = wv; s < nrs; s += NW) {
+      const u32 d0 = s_rdesc[2 * s], d1 = s_rdesc[2 * s + 1];
+      const bool meta = (d0 & L::DESC_META) != 0;
+      const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
+      double S = ems_slice_sum(s_rell + off + (meta ? 2 * L::SELL_META_WORDS : 0u) + lane, width, av);
+      u32 seg = (d1 >> 16) + (u32)lane; bool fin = seg < nR;
+      if (meta) {
+        const u32 w = reinterpret_cast<const u32*>(s_rell + off)[lane];
+        S = pm_scan_seg(S, (int)((w >> 16) & 0x7Fu), lane);
+        seg = w & 0xFFFFu; fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
+      }
+      if (fin) {
+        const u64 cwv = s_cw[seg];
+        const u32 cnt = (u32)cwv, wc = (u32)(cwv >> 32);
+        s_g[seg] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+      }
+    }
+    __syncthreads();
+    // columns: next_t = single_t + a_t * sum of g over the transcript's rows, and the convergence test of :176-199
+    int ch = 0;
+    for (u32 s = wv; s < ncs; s += NW) {
+      const u32 d0 = s_cdesc[2 * s], d1 = s_cdesc[2 * s + 1];
+      const bool meta = (d0 & L::DESC_META) != 0;
+      const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
+      double acc = ems_slice_sum(s_cell + off + (meta ? 2 * L::SELL_META_WORDS : 0u) + lane, width, s_g);
+      u32 seg = (d1 >> 16) + (u32)lane; bool fin = seg < nT;
+      if (meta) {
+        const u32 w = reinterpret_cast<const u32*>(s_cell + off)[lane];
+        acc = pm_scan_seg(acc, (int)((w >> 16) & 0x7Fu), lane);
+        seg = w & 0xFFFFu; fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
+      }
+      if (fin) {
+        const double at = av[seg], cur = al[seg];
+        const double nx = s_single[seg] + at * acc;
+        if (nx > 1e-2 && (fabs(nx - cur) / nx) > 1e-2) ++ch;
+        aln[seg] = nx;
+        avn[seg] = nx / s_eff[seg];
+      }
+    }
+    if (__ballot(ch != 0)) {
+      int wsum = ch;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
+      if (lane == 0) atomicAdd(&s_hist[r], wsum);
+    }
+    __syncthreads();
+    double* t1 = al; al = aln; aln = t1;
+    double* t2 = av; av = avn; avn = t2;
+  }
+  for (u32 i = tid; i < nT; i += nthr) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
+  if (hist && (int)tid < n_rounds && s_hist[tid]) atomicAdd(&hist[tid], s_hist[tid]);
+}
+// ---- conversion of the device-built CSR plan (em_local_setup_device) into the sliced-ELLPACK layout --------------------------
+struct SellBuild {
+  // CSR plan (device)
+  const u32* row_base; const u32* tr_base; const u32* row_ptr; const u32* col_ptr; const uint16_t* row_tr; const uint16_t* col_row; const u64* nz_base;
+  const u64* cw; const double* single; const double* eff; const u32* tr_id; u32 n_groups; u32 R; u32 M;
+  // scratch
+  u32* rlen; u32* clen; u32* rnew; u32* cnew; u32* rlane; u32* clane; u32* rvl; u32* cvl; u32* gsz;   // gsz: 4 words per group
+  // SELL plan (device)
+  const u32* rslice_base; const u32* cslice_base; const u64* rell_base; const u64* cell_base;
+  u32* rdesc; u32* cdesc; uint16_t* rell; uint16_t* cell; u64* cw_new; double* single_new; double* eff_new; u32* tr_id_new;
+};
+__device__ __forceinline__ u32 sell_group_of(const u32* base, u32 n_groups, u32 i) {   // last g with base[g] <= i
+  u32 lo = 0, hi = n_groups;
+  while (hi - lo > 1) { const u32 mid = (lo + hi) / 2; if (base[mid] <= i) lo = mid; else hi = mid; }
+  return lo;
+}
+__global__ void k_sell_lens(SellBuild B) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B.R) { const u32 g = sell_group_of(B.row_base, B.n_groups, i); B.rlen[i] = B.row_ptr[(u64)i + g + 1] - B.row_ptr[(u64)i + g]; }
+  if (i < B.M) { const u32 g = sell_group_of(B.tr_base, B.n_groups, i); B.clen[i] = B.col_ptr[(u64)i + g + 1] - B.col_ptr[(u64)i + g]; }
+}
+__global__ void k_sell_sizes(SellBuild B) {
+  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B.n_groups) return;
+  kamd_em_sell::NullSink ns;
+  const kamd_em_sell::LayoutSize lr = kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], ns);
+  const kamd_em_sell::LayoutSize lc = kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], ns);
+  B.gsz[4 * g] = lr.n_slices; B.gsz[4 * g + 1] = lr.n_u16; B.gsz[4 * g + 2] = lc.n_slices; B.gsz[4 * g + 3] = lc.n_u16;
+}
+struct SellDevSink {
+  u32* new_id; u32* lane; u32* vlen; u32* desc; uint16_t* ell; u32 seg0; u32 desc0; u64 ell0;
+  __device__ void seg(u32 old, u32 id, u32 ln, u32, u32 vl) const { new_id[seg0 + old] = id; lane[seg0 + old] = ln; vlen[seg0 + old] = vl; }
+  __device__ void slice(u32 i, u32 d0, u32 d1) const { desc[2 * (u64)(desc0 + i)] = d0; desc[2 * (u64)(desc0 + i) + 1] = d1; }
+  __device__ void meta(u32 off, u32 l, u32 w) const { ell[ell0 + off + 2 * l] = (uint16_t)w; ell[ell0 + off + 2 * l + 1] = (uint16_t)(w >> 16); }
+};
+__global__ void k_sell_layout(SellBuild B) {
+  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B.n_groups) return;
+  SellDevSink sr{B.rnew, B.rlane, B.rvl, B.rdesc, B.rell, B.row_base[g], B.rslice_base[g], B.rell_base[g]};
+  SellDevSink sc{B.cnew, B.clane, B.cvl, B.cdesc, B.cell, B.tr_base[g], B.cslice_base[g], B.cell_base[g]};
+  kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], sr);
+  kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], sc);
+}
+// entries with the other direction's new ids, and the per-segment constants in the new order; one thread per old segment
+__global__ void k_sell_entries(SellBuild B) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B.R) {
+    const u32 g = sell_group_of(B.row_base, B.n_groups, i), r0 = B.row_base[g], t0 = B.tr_base[g];
+    B.cw_new[r0 + B.rnew[i]] = B.cw[i];
+    const u32* rd = B.rdesc + 2 * (u64)B.rslice_base[g];
+    const uint16_t* src = B.row_tr + B.nz_base[g];
+    const u32 b = B.row_ptr[(u64)i + g], e = B.row_ptr[(u64)i + g + 1];
+    const u32 ln = B.rlane[i], vl = B.rvl[i];
+    for (u32 j = b, q = 0; j < e; j++, q++)
+      B.rell[B.rell_base[g] + kamd_em_sell::entry_pos(rd, ln, vl, q)] = (uint16_t)B.cnew[t0 + src[j]];
+  }
+  if (i < B.M) {
+    const u32 g = sell_group_of(B.tr_base, B.n_groups, i), r0 = B.row_base[g], t0 = B.tr_base[g];
+    const u32 m = t0 + B.cnew[i];
+    B.single_new[m] = B.single[i]; B.eff_new[m] = B.eff[i]; B.tr_id_new[m] = B.tr_id[i];
+    const u32* cd = B.cdesc + 2 * (u64)B.cslice_base[g];
+    const uint16_t* src = B.col_row + B.nz_base[g];
+    const u32 b = B.col_ptr[(u64)i + g], e = B.col_ptr[(u64)i + g + 1];
+    const u32 ln = B.clane[i], vl = B.cvl[i];
+    for (u32 j = b, q = 0; j < e; j++, q++)
+      B.cell[B.cell_base[g] + kamd_em_sell::entry_pos(cd, ln, vl, q)] = (uint16_t)B.rnew[r0 + src[j]];
+  }
 }
 __global__ void k_eml_init(double* alpha, double* a, const double* __restrict__ eff_m, u64 M, double a0) {   // alpha_ = 1/T (:38)
   const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3201,7 +3387,149 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   HIPC(hipStreamSynchronize(c->stream));
   *dev = EmLocalDev{(const u32*)(pb + p_rb), (const u32*)(pb + p_tb), (const u64*)(pb + p_zb), (const u32*)(pb + p_rp), (const u32*)(pb + p_cp),
                     (const uint16_t*)(pb + p_rt), (const uint16_t*)(pb + p_cr), (const u64*)(pb + p_cw), (const double*)(pb + p_sg),
-                    (const double*)(pb + p_ef)};
+                    (const double*)(pb + p_ef), (const u32*)(pb + p_id)};
+  return 0;
+}
+// ---- the sliced-ELLPACK form: device plan + backend of kamd_em_local::run --------------------------------------------------
+struct EmSellGpu {
+  kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0; int block = 256;
+  double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
+  std::vector<double> h_alpha; int err = 0;
+  EmSellGpu(kamd_ctx* ctx, const kamd_em_sell::Plan& p) : c(ctx), P(p) {}
+  int setup(int chunk, const double* d_eff_new);
+  void checkpoint() {
+    if (err) return;
+    if (hipMemcpyAsync(d_ck_alpha, d_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_ck_a, d_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+  }
+  void restore() {
+    if (err) return;
+    if (hipMemcpyAsync(d_alpha, d_ck_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_a, d_ck_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+  }
+  void run(int n, int clamp, int* hist) {
+    if (err || n <= 0) return;
+    if (n > EML_MAX_ROUNDS) { err = -104; return; }
+    if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
+    hipLaunchKernelGGL(k_em_sell, dim3(P.n_groups), dim3(block), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    if (hipGetLastError() != hipSuccess) { err = -104; return; }
+    if (hist && (hipMemcpyAsync(hist, d_hist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                 hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
+  }
+  const std::vector<double>& host_alpha() {
+    h_alpha.resize(M);
+    if (!err && (hipMemcpyAsync(h_alpha.data(), d_alpha, M * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                 hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
+    return h_alpha;
+  }
+};
+int EmSellGpu::setup(int chunk, const double* d_eff_new) {
+  Carver sv;
+  const size_t o_al = sv.take(M * 8 + 8), o_a = sv.take(M * 8 + 8), o_cka = sv.take(M * 8 + 8), o_ckb = sv.take(M * 8 + 8), o_h = sv.take((size_t)chunk * 4 + 8);
+  if (int rc = c->pm_b.ensure(sv.off, 0, c->stream)) return rc;
+  char* sb = (char*)c->pm_b.p;
+  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = (double*)(sb + o_cka); d_ck_a = (double*)(sb + o_ckb); d_hist = (int*)(sb + o_h);
+  if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, d_eff_new, M, 1.0 / (double)P.T);
+  HIPC(hipGetLastError());
+  lds = (size_t)P.max_group_bytes;
+  HIPC(hipFuncSetAttribute((const void*)k_em_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return 0;
+}
+// 0 = plan built (P: the host part; *dev: the device part), 1 = not applicable, < 0 = error
+int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
+                         const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev) {
+  namespace S = kamd_em_sell;
+  kamd_em_local::Plan C;
+  EmLocalDev cd{};
+  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd)) return rc;
+  const u32 ng = C.n_groups;
+  const u64 R = C.row_base[ng], M = C.tr_base[ng];
+  if (R >= 0xFFFFFFF0ULL || M >= 0xFFFFFFF0ULL) return 1;
+  for (u32 g = 0; g < ng; g++)
+    if (C.row_base[g + 1] - C.row_base[g] >= S::SELL_PAD || C.tr_base[g + 1] - C.tr_base[g] >= S::SELL_PAD) return 1;
+  // scratch: lengths, new ids, lanes, per-group sizes
+  Carver tv;
+  const size_t o_rlen = tv.take(R * 4 + 8), o_clen = tv.take(M * 4 + 8), o_rnew = tv.take(R * 4 + 8), o_cnew = tv.take(M * 4 + 8);
+  const size_t o_rlane = tv.take(R * 4 + 8), o_clane = tv.take(M * 4 + 8), o_rvl = tv.take(R * 4 + 8), o_cvl = tv.take(M * 4 + 8), o_gsz = tv.take((size_t)ng * 16 + 16);
+  if (int rc = c->ems_tmp.ensure(tv.off, 0, c->stream)) return rc;
+  char* tb = (char*)c->ems_tmp.p;
+  SellBuild B{};
+  B.row_base = cd.row_base; B.tr_base = cd.tr_base; B.row_ptr = cd.row_ptr; B.col_ptr = cd.col_ptr; B.row_tr = cd.row_tr; B.col_row = cd.col_row;
+  B.nz_base = cd.nz_base; B.cw = cd.cw; B.single = cd.single; B.eff = cd.eff; B.tr_id = cd.tr_id; B.n_groups = ng; B.R = (u32)R; B.M = (u32)M;
+  B.rlen = (u32*)(tb + o_rlen); B.clen = (u32*)(tb + o_clen); B.rnew = (u32*)(tb + o_rnew); B.cnew = (u32*)(tb + o_cnew);
+  B.rlane = (u32*)(tb + o_rlane); B.clane = (u32*)(tb + o_clane); B.rvl = (u32*)(tb + o_rvl); B.cvl = (u32*)(tb + o_cvl); B.gsz = (u32*)(tb + o_gsz);
+  const u64 nseg = std::max(R, M);
+  hipLaunchKernelGGL(k_sell_lens, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
+  hipLaunchKernelGGL(k_sell_sizes, dim3(grid_for(ng, 64)), dim3(64), 0, c->stream, B);
+  std::vector<u32> gsz((size_t)ng * 4);
+  HIPC(hipMemcpyAsync(gsz.data(), B.gsz, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  P->n_groups = ng; P->T = T; P->row_base = C.row_base; P->tr_base = C.tr_base; P->single_all = C.single_all;
+  P->rslice_base.assign(ng + 1, 0); P->cslice_base.assign(ng + 1, 0); P->rell_base.assign(ng + 1, 0); P->cell_base.assign(ng + 1, 0);
+  P->max_group_bytes = 0;
+  for (u32 g = 0; g < ng; g++) {
+    const u64 gb = S::group_bytes(C.row_base[g + 1] - C.row_base[g], C.tr_base[g + 1] - C.tr_base[g], gsz[4 * g], gsz[4 * g + 2], gsz[4 * g + 1], gsz[4 * g + 3]);
+    if (gb > lds_budget) return 1;
+    P->max_group_bytes = std::max<uint64_t>(P->max_group_bytes, gb);
+    P->rslice_base[g + 1] = P->rslice_base[g] + gsz[4 * g]; P->rell_base[g + 1] = P->rell_base[g] + gsz[4 * g + 1];
+    P->cslice_base[g + 1] = P->cslice_base[g] + gsz[4 * g + 2]; P->cell_base[g + 1] = P->cell_base[g] + gsz[4 * g + 3];
+  }
+  const u64 nrs = P->rslice_base[ng], ncs = P->cslice_base[ng], nru = P->rell_base[ng], ncu = P->cell_base[ng];
+  Carver pv;
+  const size_t p_rsb = pv.take((ng + 1) * 4), p_csb = pv.take((ng + 1) * 4), p_reb = pv.take((ng + 1) * 8), p_ceb = pv.take((ng + 1) * 8);
+  const size_t p_rd = pv.take(nrs * 8 + 8), p_cdesc = pv.take(ncs * 8 + 8), p_re = pv.take(nru * 2 + 8), p_ce = pv.take(ncu * 2 + 8);
+  const size_t p_cw = pv.take(R * 8 + 8), p_sg = pv.take(M * 8 + 8), p_ef = pv.take(M * 8 + 8), p_id = pv.take(M * 4 + 8);
+  if (int rc = c->ems_plan.ensure(pv.off, 0, c->stream)) return rc;
+  char* pb = (char*)c->ems_plan.p;
+  HIPC(hipMemcpyAsync(pb + p_rsb, P->rslice_base.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemcpyAsync(pb + p_csb, P->cslice_base.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemcpyAsync(pb + p_reb, P->rell_base.data(), (ng + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemcpyAsync(pb + p_ceb, P->cell_base.data(), (ng + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemsetAsync(pb + p_re, 0xFF, nru * 2, c->stream));
+  HIPC(hipMemsetAsync(pb + p_ce, 0xFF, ncu * 2, c->stream));
+  B.rslice_base = (const u32*)(pb + p_rsb); B.cslice_base = (const u32*)(pb + p_csb); B.rell_base = (const u64*)(pb + p_reb); B.cell_base = (const u64*)(pb + p_ceb);
+  B.rdesc = (u32*)(pb + p_rd); B.cdesc = (u32*)(pb + p_cdesc); B.rell = (uint16_t*)(pb + p_re); B.cell = (uint16_t*)(pb + p_ce);
+  B.cw_new = (u64*)(pb + p_cw); B.single_new = (double*)(pb + p_sg); B.eff_new = (double*)(pb + p_ef); B.tr_id_new = (u32*)(pb + p_id);
+  hipLaunchKernelGGL(k_sell_layout, dim3(grid_for(ng, 64)), dim3(64), 0, c->stream, B);
+  hipLaunchKernelGGL(k_sell_entries, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
+  HIPC(hipGetLastError());
+  P->tr_id.resize(M);
+  if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), B.tr_id_new, M * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  *dev = EmSellDev{cd.row_base, cd.tr_base, B.rslice_base, B.cslice_base, B.rell_base, B.cell_base, B.rdesc, B.cdesc, B.rell, B.cell,
+                   B.cw_new, B.single_new, B.eff_new};
+  return 0;
+}
+int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
+                       const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds) {
+  if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
+  kamd_em_sell::Plan P;
+  EmSellDev dev{};
+  HIPC(hipEventRecord(c->ev0, c->stream));
+  // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not, the
+  // cut is halved, and a single component beyond the CU's 160 KB makes the form not applicable)
+  const u64 lds_budget = 160 * 1024 - 2048;
+  int prc = 1;
+  for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc == 1; div *= 2) {
+    const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
+    prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &P, &dev);
+    if (target == 1024) break;
+  }
+  if (prc) return prc;
+  if (P.n_groups == 0) return 1;
+  const int chunk = EML_MAX_ROUNDS;
+  EmSellGpu B(c, P);
+  B.dev = dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block == 512 ? 512 : (c->tune.em_local_block == 128 ? 128 : 256);
+  if (int rc = B.setup(chunk, dev.eff)) return rc;
+  const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
+  if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
+  HIPC(hipEventRecord(c->ev1, c->stream));
+  HIPC(hipEventSynchronize(c->ev1));
+  HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
+  c->last_em_iters = (uint64_t)r + (r < n_iter ? 1 : 0);
+  c->last_em_nnz = nnz; c->last_em_k = -2; c->last_em_grid = P.n_groups; c->last_em_necs = n_ecs;
+  c->last_em_lds = (uint32_t)P.max_group_bytes;
+  if (rounds) *rounds = r;
   return 0;
 }
 // 0 = done, 1 = not applicable (the caller takes the streamed form), < 0 = error
@@ -3313,7 +3641,10 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   }
   if (!spec && n_ecs) {   // EXPERIMENTAL opt-in: the component-local form (kamd_em_local.h)
     if (c->tune.em_form == 3) {
-      const int rc = em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
+      const int rc = c->tune.em_local_kernel == 3
+        ? em_sell_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter, (int)min_rounds,
+                             alpha, alpha_before_zeroes, rounds)
+        : em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
                                          (int)min_rounds, alpha, alpha_before_zeroes, rounds, 2);
       if (rc <= 0) return rc;   // 1 = not applicable (a component does not fit a workgroup): the streamed form takes over
     }
@@ -3587,7 +3918,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
   p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
   p->last_em_nnz = c->last_em_nnz; p->last_em_nnz_multi = c->last_em_nnz_multi; p->last_em_nseg = c->last_em_nseg; p->last_em_necs = c->last_em_necs;
-  p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid;
+  p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid; p->last_em_lds = c->last_em_lds;
   return 0;
 }
 

@@ -1,6 +1,7 @@
 // tests/emu/em_local_emu.cpp -- TEST INFRASTRUCTURE: drives kallisto_amd/csrc/kamd_em_local.h (plan builder, per-group
 // rounds, chunk / history / replay driver) on the CPU so that it can be checked against the oracle's EMAlgorithm::run.
 #include "../../kallisto_amd/csrc/kamd_em_local.h"
+#include "../../kallisto_amd/csrc/kamd_em_sell.h"
 
 #include <map>
 
@@ -10,10 +11,19 @@ int emu_em_local(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t*
                  uint64_t budget_bytes, uint64_t target_nnz, int n_iter, int min_rounds, int chunk, double* alpha, double* abz,
                  int32_t* rounds, uint32_t* n_groups, uint64_t* max_group_bytes, int builder) {
   using namespace kamd_em_local;
-  Plan P;   // builder 0: the host reference (greedy packing), 1: the data-parallel steps the device set-up is made of
+  Plan P;   // builder 0: the host reference (greedy packing), 1: the data-parallel steps the device set-up is made of,
+            // 2: 1 + conversion to the sliced-ELLPACK layout (kamd_em_sell.h) and its host model of the kernel's round
   if (int rc = builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)
                        : build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return rc;
   *n_groups = P.n_groups; *max_group_bytes = P.max_group_bytes;
+  if (builder == 2) {
+    kamd_em_sell::Plan S;
+    if (int rc = kamd_em_sell::from_csr_plan(P, budget_bytes, &S)) return rc;
+    *max_group_bytes = S.max_group_bytes;
+    kamd_em_sell::CpuBackend B(S);
+    *rounds = run(B, S, n_iter, min_rounds, chunk, alpha, abz);
+    return 0;
+  }
   CpuBackend B(P);
   *rounds = run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   return 0;

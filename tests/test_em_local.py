@@ -71,6 +71,7 @@ def test_plan_built_by_the_data_parallel_steps(budget, target):
                                                  (1 << 30, 1 << 40, 10000)])
 def test_local_em_equals_the_oracle(budget, target, chunk):
     off, ids, cnt, eff, T = _gene_matrix(150, 5)
+    tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
     a_o, abz_o, r_o = O.em_run(off, ids, cnt, eff, T)
     rc, a, abz, r, ng, mb = _run(off, ids, cnt, eff, T, budget, target, chunk)
     assert rc == 0 and mb <= budget
@@ -79,9 +80,13 @@ def test_local_em_equals_the_oracle(budget, target, chunk):
         rc2, a2, abz2, r2, ng2, _ = _run(off, ids, cnt, eff, T, 1 << 30, target, chunk, builder=1)   # the other plan builder
         assert rc2 == 0 and r2 == r_o and ng2 > 10
         common.assert_abundance_close(a2, a_o, "alpha (plan from the data-parallel steps)", rel=1e-9)
+    # the sliced-ELLPACK layout of the same groups (what k_em_sell iterates over) through its host model
+    rc3, a3, abz3, r3, ng3, mb3 = _run(off, ids, cnt, eff, T, 1 << 30, target, chunk, builder=2)
+    assert rc3 == 0 and r3 == r_o
+    common.assert_abundance_close(a3, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
+    common.assert_abundance_close(tiny(abz3), tiny(abz_o), "alpha_before_zeroes (sliced ELLPACK)", rel=1e-9, floor=1e-12)
     assert r == r_o
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
-    tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
     common.assert_abundance_close(tiny(abz), tiny(abz_o), "alpha_before_zeroes", rel=1e-9, floor=1e-12)
 
 
@@ -103,6 +108,11 @@ def test_a_component_that_does_not_fit_is_reported():
     a_o, _, r_o = O.em_run(off, ids, cnt, eff, T)
     assert rc == 0 and ng == 1 and r == r_o
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
+    # the same in the sliced-ELLPACK layout: rows with hundreds of transcripts and hub columns are split over the lanes of a
+    # slice (segmented combination of the lanes' partial sums)
+    rc, a, abz, r, ng, _ = _run(off, ids, cnt, eff, T, budget=1 << 30, builder=2)
+    assert rc == 0 and ng == 1 and r == r_o
+    common.assert_abundance_close(a, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
 
 
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("human_pe", "pe"), ("yeast_se", "se"), ("mosaic_pe", "pe")])
@@ -119,4 +129,7 @@ def test_local_em_on_the_golden_ec_matrices(case, variant):
     rc, a, abz, r, ng, _ = _run(eoff, eids, ecnt, eff, len(eff), target=64, chunk=32, builder=1)
     assert rc == 0 and r == r_o
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
+    rc, a, abz, r, ng, _ = _run(eoff, eids, ecnt, eff, len(eff), target=64, chunk=32, builder=2)
+    assert rc == 0 and r == r_o
+    common.assert_abundance_close(a, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
     common.assert_abundance_close(a, exp["alpha"], "alpha vs the reference")       # 1e-4, like every other path

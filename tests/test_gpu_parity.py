@@ -98,7 +98,7 @@ def test_batches_and_idempotence(ka, ctxs):
     e2 = ctx.finalize()
     assert e1.multiset() == exp["ecs"] == e2.multiset()
     st = ctx.stats()
-    assert st["n_processed"] == n and st["n_bucket_reads"] >= st["n_probes"] > 0
+    assert st["n_processed"] == n and st["n_bucket_reads"] + st["n_text_hits"] >= st["n_probes"] > 0
 
 
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_rf"), ("human_pe", "pe"), ("human_pe", "pe_l180"),
@@ -191,7 +191,7 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local1", "fallback"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local2", "local1", "hub"])
 def test_em_forms_agree_with_oracle(k, ka):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -202,11 +202,12 @@ def test_em_forms_agree_with_oracle(k, ka):
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
-    if k in ("local", "local1"):
+    if k in ("local", "local512", "local2", "local1"):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
-        tune = dict(em_form="local", em_local_kernel=2 if k == "local" else 1)
+        tune = dict(em_form="local", em_local_kernel={"local": 3, "local512": 3, "local2": 2, "local1": 1}[k],
+                    em_local_block=512 if k == "local512" else 256, em_group_div=64)
         k = "local"
-    elif k == "fallback":
+    elif k == "hub":
         tune = dict(em_form="local")
     else:
         tune = dict(em_form="csr" if k == "csr" else "streamed")
@@ -225,9 +226,10 @@ def test_em_forms_agree_with_oracle(k, ka):
     finally:
         ctx.close()
     if k == "local":
-        assert prof["em_k"] == -1                          # the local form ran (kamd_profile.last_em_k)
-    elif k == "fallback":
-        assert prof["em_k"] > 0                            # the streamed form took over
+        assert prof["em_k"] in (-1, -2)                    # the local form ran (kamd_profile.last_em_k)
+        assert prof["em_grid"] > 1                         # ... over several groups
+    elif k == "hub":
+        assert prof["em_k"] > 0 or prof["em_k"] == -2      # the streamed form took over, or the one group fitted
     else:
         assert (prof["em_k"] == 0) == (k == "csr")
     if isinstance(k, int):
