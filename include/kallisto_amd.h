@@ -114,9 +114,10 @@ typedef struct {
   int32_t em_graph;            /* rounds of the streamed / CSR forms replayed as a hipGraph (default on) */
   int32_t em_row_lanes;        /* CSR form: lanes per row, 2 / 4 (default) / 8 */
   int32_t em_fin_blocks;       /* CSR form: blocks of the final pass (default 1024) */
-  int32_t em_local_block;      /* component-local form, kernel 3: threads per workgroup, 128 / 256 (default) / 512 */
+  int32_t em_local_block;      /* component-local form, kernel 3: threads per workgroup, 128 / 256 / 512 (default) / 1024 */
   int32_t em_group_div;        /* component-local form, kernel 3: groups hold about nnz / (CUs x this) entries (default 4) */
-  int32_t reserved[2];
+  int32_t em_split_len;        /* component-local form, kernel 3: a row / column with more entries is split over several lanes (1..64) */
+  int32_t reserved[1];
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);

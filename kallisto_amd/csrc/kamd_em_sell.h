@@ -31,9 +31,11 @@ static const uint32_t SELL_META_WORDS = 64;       // u32 words of lane metadata 
 // lane metadata: segment id | reach << 16 (lanes below that belong to the same segment) | LAST << 23 | ACTIVE << 24
 static const uint32_t META_LAST = 1u << 23, META_ACTIVE = 1u << 24;
 
-// how a segment of `len` entries is spread over lanes
-KAMD_HD uint32_t seg_lanes(uint32_t len) { return len <= SELL_LANES ? 1u : (len + SELL_LANES - 1) / SELL_LANES > SELL_LANES ? SELL_LANES : (len + SELL_LANES - 1) / SELL_LANES; }
-KAMD_HD uint32_t seg_vlen(uint32_t len) { const uint32_t nv = seg_lanes(len); return (len + nv - 1) / nv; }
+// how a segment of `len` entries is spread over lanes: more than `cap` entries (1 <= cap <= 64) -> ceil(len / cap) lanes, at
+// most 64.  A small cap makes every slice short (balanced work for the wavefronts of a workgroup, a short dependent chain per
+// lane) at the price of one segmented scan in the slices that hold the split segments.
+KAMD_HD uint32_t seg_lanes(uint32_t len, uint32_t cap) { const uint32_t nv = (len + cap - 1) / cap; return len <= cap ? 1u : (nv > SELL_LANES ? SELL_LANES : nv); }
+KAMD_HD uint32_t seg_vlen(uint32_t len, uint32_t cap) { const uint32_t nv = seg_lanes(len, cap); return (len + nv - 1) / nv; }
 
 // slice descriptor (two u32 words)
 //   d0 = offset of the slice in the group's u16 stream (in u16 units; the metadata words, if any, come first) | HAS_META << 31
@@ -55,18 +57,18 @@ struct NullSink {
 
 // len[i * stride], i < n: segment lengths (>= 1) in the caller's ("old") order
 template <class Sink>
-KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, Sink& sink) {
+KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, Sink& sink) {
   uint32_t hist[SELL_LANES + 1];
   for (uint32_t b = 0; b <= SELL_LANES; b++) hist[b] = 0;
   uint32_t n_split = 0;
-  for (uint32_t i = 0; i < n; i++) { const uint32_t l = len[i]; if (l > SELL_LANES) ++n_split; else ++hist[l]; }
+  for (uint32_t i = 0; i < n; i++) { const uint32_t l = len[i]; if (l > cap) ++n_split; else ++hist[l]; }
   // 1. split segments, in the caller's order, packed into slices without straddling
   uint32_t lane = 0;          // absolute lane position (slice * 64 + lane in slice) of the next free lane
   uint32_t next_id = 0;
   for (uint32_t i = 0; i < n && n_split; i++) {
     const uint32_t l = len[i];
-    if (l <= SELL_LANES) continue;
-    const uint32_t nv = seg_lanes(l), vl = seg_vlen(l);
+    if (l <= cap) continue;
+    const uint32_t nv = seg_lanes(l, cap), vl = seg_vlen(l, cap);
     if ((lane % SELL_LANES) + nv > SELL_LANES) lane = (lane / SELL_LANES + 1) * SELL_LANES;   // does not fit: next slice
     sink.seg(i, next_id++, lane, nv, vl);
     lane += nv;
@@ -81,7 +83,7 @@ KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, Sink& sink) {
     for (uint32_t b = 0; b <= SELL_LANES; b++) cur[b] = 0;
     for (uint32_t i = 0; i < n; i++) {
       const uint32_t l = len[i];
-      if (l > SELL_LANES) continue;
+      if (l > cap) continue;
       const uint32_t p = start[l] + cur[l]++;
       sink.seg(i, n_split + (p - split_lanes), p, 1u, l);
     }
@@ -108,8 +110,8 @@ KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, Sink& sink) {
       ln = 0; id = 0;
       for (uint32_t i = 0; i < n; i++) {
         const uint32_t l = len[i];
-        if (l <= SELL_LANES) continue;
-        const uint32_t nv = seg_lanes(l), vl = seg_vlen(l);
+        if (l <= cap) continue;
+        const uint32_t nv = seg_lanes(l, cap), vl = seg_vlen(l, cap);
         if ((ln % SELL_LANES) + nv > SELL_LANES) ln = (ln / SELL_LANES + 1) * SELL_LANES;
         if (ln >= lo && ln < hi) {
           if (vl > width) width = vl;
@@ -149,6 +151,7 @@ KAMD_HD uint64_t group_bytes(uint64_t rows, uint64_t tr, uint64_t row_slices, ui
 struct Plan {
   uint32_t n_groups = 0;
   uint64_t T = 0;
+  uint32_t cap = SELL_LANES;                     // entries per lane above which a segment is split
   std::vector<uint32_t> row_base, tr_base;       // [n_groups + 1]
   std::vector<uint32_t> rslice_base, cslice_base;   // [n_groups + 1] first slice descriptor of a group (rows / columns)
   std::vector<uint64_t> rell_base, cell_base;    // [n_groups + 1] first u16 of a group's stream
@@ -178,8 +181,9 @@ KAMD_HD uint64_t entry_pos(const uint32_t* desc, uint32_t lane, uint32_t vlen, u
   return base + (uint64_t)j * SELL_LANES + (ln % SELL_LANES);
 }
 
-inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Plan* P) {
+inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Plan* P, uint32_t cap = SELL_LANES) {
   const uint32_t ng = C.n_groups;
+  P->cap = cap;
   P->n_groups = ng; P->T = C.T; P->row_base = C.row_base; P->tr_base = C.tr_base; P->single_all = C.single_all;
   const uint64_t R = C.row_base[ng], M = C.tr_base[ng];
   std::vector<uint32_t> rlen(R), clen(M), rnew(R), cnew(M), rlane(R), clane(M), rnv(R), cnv(M), rvl(R), cvl(M);
@@ -191,8 +195,8 @@ inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Pl
     for (uint32_t t = 0; t < G.n_tr; t++) clen[C.tr_base[g] + t] = G.col_ptr[t + 1] - G.col_ptr[t];
     if (G.n_rows >= SELL_PAD || G.n_tr >= SELL_PAD) return 1;
     NullSink ns;
-    const LayoutSize lr = layout_group(rlen.data() + C.row_base[g], G.n_rows, ns);
-    const LayoutSize lc = layout_group(clen.data() + C.tr_base[g], G.n_tr, ns);
+    const LayoutSize lr = layout_group(rlen.data() + C.row_base[g], G.n_rows, cap, ns);
+    const LayoutSize lc = layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, ns);
     const uint64_t gb = group_bytes(G.n_rows, G.n_tr, lr.n_slices, lc.n_slices, lr.n_u16, lc.n_u16);
     if (gb > budget_bytes) return 1;
     if (gb > P->max_group_bytes) P->max_group_bytes = gb;
@@ -205,8 +209,8 @@ inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Pl
     const kamd_em_local::Group G = C.group(g);
     VecSink sr{&rnew, &rlane, &rnv, &rvl, &P->rdesc, &P->rell, P->rell_base[g], P->rslice_base[g], C.row_base[g]};
     VecSink sc{&cnew, &clane, &cnv, &cvl, &P->cdesc, &P->cell, P->cell_base[g], P->cslice_base[g], C.tr_base[g]};
-    layout_group(rlen.data() + C.row_base[g], G.n_rows, sr);
-    layout_group(clen.data() + C.tr_base[g], G.n_tr, sc);
+    layout_group(rlen.data() + C.row_base[g], G.n_rows, cap, sr);
+    layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, sc);
   }
   // entries (indices renamed to the other direction's new ids) and the per-segment constants in the new order
   P->cw.assign(R, 0); P->single.assign(M, 0.0); P->eff.assign(M, 0.0); P->tr_id.assign(M, 0);

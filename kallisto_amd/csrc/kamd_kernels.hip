@@ -1986,7 +1986,7 @@ namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->kernel_a = 3; t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 256; t->em_group_div = 4; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 512; t->em_group_div = 4; t->em_split_len = 64; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024;
 }
 // 0 = keep; values outside a field's range are ignored
@@ -1998,7 +1998,8 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.lds_pad != 0) t->lds_pad = n.lds_pad < 0 ? -1 : n.lds_pad;
   if (n.em_form >= 1 && n.em_form <= 3) t->em_form = n.em_form;
   if (n.em_local_kernel >= 1 && n.em_local_kernel <= 3) t->em_local_kernel = n.em_local_kernel;
-  if (n.em_local_block == 128 || n.em_local_block == 256 || n.em_local_block == 512) t->em_local_block = n.em_local_block;
+  if (n.em_local_block == 128 || n.em_local_block == 256 || n.em_local_block == 512 || n.em_local_block == 1024) t->em_local_block = n.em_local_block;
+  if (n.em_split_len >= 1 && n.em_split_len <= 64) t->em_split_len = n.em_split_len;
   if (n.em_group_div >= 1 && n.em_group_div <= 1024) t->em_group_div = n.em_group_div;
   if (n.em_entries_per_lane != 0) t->em_entries_per_lane = n.em_entries_per_lane < 0 ? -1 : n.em_entries_per_lane;
   if (n.em_windowed == 1 || n.em_windowed == 2) t->em_windowed = n.em_windowed;
@@ -2023,6 +2024,7 @@ void tuning_from_env(kamd_tuning* t) {
   geti("KAMD_EM_LOCAL_KERNEL", &n.em_local_kernel);
   geti("KAMD_EM_LOCAL_BLOCK", &n.em_local_block);
   geti("KAMD_EM_GROUP_DIV", &n.em_group_div);
+  geti("KAMD_EM_SPLIT_LEN", &n.em_split_len);
   geti("KAMD_EM_K", &n.em_entries_per_lane);
   onoff("KAMD_EM_WINDOWED", &n.em_windowed);
   onoff("KAMD_EM_GRAPH", &n.em_graph);
@@ -3030,11 +3032,21 @@ struct EmSellDev {
   const u32* rdesc; const u32* cdesc; const uint16_t* rell; const uint16_t* cell;
   const u64* cw; const double* single; const double* eff;
 };
-constexpr int EMS_MAX_BLOCK = 512;
+constexpr int EMS_MAX_BLOCK = 1024;
 // sum over the lane's entries of one slice
 __device__ __forceinline__ double ems_slice_sum(const uint16_t* e, u32 width, const double* src) {
   double S = 0.0;
   u32 j = 0;
+  for (; j + 8 <= width; j += 8) {
+    u32 ix[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) ix[q] = e[(size_t)(j + q) * 64];
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = src[ix[q]];
+#pragma unroll
+    for (int q = 0; q < 8; q++) S += v[q];
+  }
   for (; j + 4 <= width; j += 4) {
     const u32 i0 = e[(size_t)j * 64], i1 = e[(size_t)(j + 1) * 64], i2 = e[(size_t)(j + 2) * 64], i3 = e[(size_t)(j + 3) * 64];
     const double v0 = src[i0], v1 = src[i1], v2 = src[i2], v3 = src[i3];
@@ -3135,7 +3147,7 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, double* 
 struct SellBuild {
   // CSR plan (device)
   const u32* row_base; const u32* tr_base; const u32* row_ptr; const u32* col_ptr; const uint16_t* row_tr; const uint16_t* col_row; const u64* nz_base;
-  const u64* cw; const double* single; const double* eff; const u32* tr_id; u32 n_groups; u32 R; u32 M;
+  const u64* cw; const double* single; const double* eff; const u32* tr_id; u32 n_groups; u32 R; u32 M; u32 cap;
   // scratch
   u32* rlen; u32* clen; u32* rnew; u32* cnew; u32* rlane; u32* clane; u32* rvl; u32* cvl; u32* gsz;   // gsz: 4 words per group
   // SELL plan (device)
@@ -3156,8 +3168,8 @@ __global__ void k_sell_sizes(SellBuild B) {
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B.n_groups) return;
   kamd_em_sell::NullSink ns;
-  const kamd_em_sell::LayoutSize lr = kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], ns);
-  const kamd_em_sell::LayoutSize lc = kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], ns);
+  const kamd_em_sell::LayoutSize lr = kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, ns);
+  const kamd_em_sell::LayoutSize lc = kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, ns);
   B.gsz[4 * g] = lr.n_slices; B.gsz[4 * g + 1] = lr.n_u16; B.gsz[4 * g + 2] = lc.n_slices; B.gsz[4 * g + 3] = lc.n_u16;
 }
 struct SellDevSink {
@@ -3171,8 +3183,8 @@ __global__ void k_sell_layout(SellBuild B) {
   if (g >= B.n_groups) return;
   SellDevSink sr{B.rnew, B.rlane, B.rvl, B.rdesc, B.rell, B.row_base[g], B.rslice_base[g], B.rell_base[g]};
   SellDevSink sc{B.cnew, B.clane, B.cvl, B.cdesc, B.cell, B.tr_base[g], B.cslice_base[g], B.cell_base[g]};
-  kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], sr);
-  kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], sc);
+  kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, sr);
+  kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, sc);
 }
 // entries with the other direction's new ids, and the per-segment constants in the new order; one thread per old segment
 __global__ void k_sell_entries(SellBuild B) {
@@ -3456,6 +3468,7 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   SellBuild B{};
   B.row_base = cd.row_base; B.tr_base = cd.tr_base; B.row_ptr = cd.row_ptr; B.col_ptr = cd.col_ptr; B.row_tr = cd.row_tr; B.col_row = cd.col_row;
   B.nz_base = cd.nz_base; B.cw = cd.cw; B.single = cd.single; B.eff = cd.eff; B.tr_id = cd.tr_id; B.n_groups = ng; B.R = (u32)R; B.M = (u32)M;
+  B.cap = (u32)std::min(64, std::max(1, c->tune.em_split_len));
   B.rlen = (u32*)(tb + o_rlen); B.clen = (u32*)(tb + o_clen); B.rnew = (u32*)(tb + o_rnew); B.cnew = (u32*)(tb + o_cnew);
   B.rlane = (u32*)(tb + o_rlane); B.clane = (u32*)(tb + o_clane); B.rvl = (u32*)(tb + o_rvl); B.cvl = (u32*)(tb + o_cvl); B.gsz = (u32*)(tb + o_gsz);
   const u64 nseg = std::max(R, M);
@@ -3519,7 +3532,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   if (P.n_groups == 0) return 1;
   const int chunk = EML_MAX_ROUNDS;
   EmSellGpu B(c, P);
-  B.dev = dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block == 512 ? 512 : (c->tune.em_local_block == 128 ? 128 : 256);
+  B.dev = dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block;
   if (int rc = B.setup(chunk, dev.eff)) return rc;
   const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");

@@ -16,9 +16,9 @@ int emu_em_local(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t*
   if (int rc = builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)
                        : build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return rc;
   *n_groups = P.n_groups; *max_group_bytes = P.max_group_bytes;
-  if (builder == 2) {
+  if (builder >= 2) {   // 2 / 3 / 4: segments of more than 64 / 16 / 3 entries are split over lanes
     kamd_em_sell::Plan S;
-    if (int rc = kamd_em_sell::from_csr_plan(P, budget_bytes, &S)) return rc;
+    if (int rc = kamd_em_sell::from_csr_plan(P, budget_bytes, &S, builder == 2 ? 64u : builder == 3 ? 16u : 3u)) return rc;
     *max_group_bytes = S.max_group_bytes;
     kamd_em_sell::CpuBackend B(S);
     *rounds = run(B, S, n_iter, min_rounds, chunk, alpha, abz);

@@ -81,10 +81,11 @@ def test_local_em_equals_the_oracle(budget, target, chunk):
         assert rc2 == 0 and r2 == r_o and ng2 > 10
         common.assert_abundance_close(a2, a_o, "alpha (plan from the data-parallel steps)", rel=1e-9)
     # the sliced-ELLPACK layout of the same groups (what k_em_sell iterates over) through its host model
-    rc3, a3, abz3, r3, ng3, mb3 = _run(off, ids, cnt, eff, T, 1 << 30, target, chunk, builder=2)
-    assert rc3 == 0 and r3 == r_o
-    common.assert_abundance_close(a3, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
-    common.assert_abundance_close(tiny(abz3), tiny(abz_o), "alpha_before_zeroes (sliced ELLPACK)", rel=1e-9, floor=1e-12)
+    for b in (2, 3, 4):   # segments of more than 64 / 16 / 3 entries split over the lanes of a slice
+        rc3, a3, abz3, r3, ng3, mb3 = _run(off, ids, cnt, eff, T, 1 << 30, target, chunk, builder=b)
+        assert rc3 == 0 and r3 == r_o
+        common.assert_abundance_close(a3, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
+        common.assert_abundance_close(tiny(abz3), tiny(abz_o), "alpha_before_zeroes (sliced ELLPACK)", rel=1e-9, floor=1e-12)
     assert r == r_o
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
     common.assert_abundance_close(tiny(abz), tiny(abz_o), "alpha_before_zeroes", rel=1e-9, floor=1e-12)
@@ -110,9 +111,10 @@ def test_a_component_that_does_not_fit_is_reported():
     common.assert_abundance_close(a, a_o, "alpha", rel=1e-9)
     # the same in the sliced-ELLPACK layout: rows with hundreds of transcripts and hub columns are split over the lanes of a
     # slice (segmented combination of the lanes' partial sums)
-    rc, a, abz, r, ng, _ = _run(off, ids, cnt, eff, T, budget=1 << 30, builder=2)
-    assert rc == 0 and ng == 1 and r == r_o
-    common.assert_abundance_close(a, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
+    for b in (2, 3, 4):
+        rc, a, abz, r, ng, _ = _run(off, ids, cnt, eff, T, budget=1 << 30, builder=b)
+        assert rc == 0 and ng == 1 and r == r_o
+        common.assert_abundance_close(a, a_o, "alpha (sliced ELLPACK)", rel=1e-9)
 
 
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("human_pe", "pe"), ("yeast_se", "se"), ("mosaic_pe", "pe")])
