@@ -170,6 +170,8 @@ typedef struct {
   uint64_t n_stream_words;  /* u32 words of the record stream (fixed slots of kernel A v2 included) */
   uint64_t n_raw_words;     /* u32 words kernel A wrote: per item 1 header + its distinct (unitig,set) classes */
   uint64_t n_text_hits;     /* probes answered from the unitig text instead of the table (kernel A version 3) */
+  uint64_t n_wave_iters;    /* kernel A version 3: loop trips summed over the wavefronts ... */
+  uint64_t n_lane_iters;    /* ... and lanes that issued a probe in them: n_lane_iters / (64 n_wave_iters) = lane utilisation */
 } kamd_align_stats;
 int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
 

@@ -45,7 +45,8 @@ class QuantOpts(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_processed", "n_single", "n_multi", "n_probes", "n_bucket_reads",
-                                          "n_distinct_tuples", "n_stream_words", "n_raw_words", "n_text_hits")]
+                                          "n_distinct_tuples", "n_stream_words", "n_raw_words", "n_text_hits", "n_wave_iters",
+                                          "n_lane_iters")]
 
 
 class Tuning(C.Structure):

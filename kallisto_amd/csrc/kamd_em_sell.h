@@ -50,18 +50,24 @@ static const uint32_t DESC_META = 1u << 31;
 struct LayoutSize { uint32_t n_slices; uint32_t n_u16; };
 
 struct NullSink {
+  static const bool wants_segments = false;
   KAMD_HD void seg(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) const {}
   KAMD_HD void slice(uint32_t, uint32_t, uint32_t) const {}
   KAMD_HD void meta(uint32_t, uint32_t, uint32_t) const {}
 };
 
 // len[i * stride], i < n: segment lengths (>= 1) in the caller's ("old") order
+// scratch: 3 * (SELL_LANES + 1) words with stride `ss` between consecutive words (the device keeps it in LDS, thread-transposed:
+// dynamically indexed private arrays would live in scratch memory, one global round trip per access)
+static const uint32_t LAYOUT_SCRATCH_WORDS = 3 * (SELL_LANES + 1);
 template <class Sink>
-KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, Sink& sink) {
-  uint32_t hist[SELL_LANES + 1];
-  for (uint32_t b = 0; b <= SELL_LANES; b++) hist[b] = 0;
+KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, Sink& sink, uint32_t* scratch, uint32_t ss) {
+#define hist(b) scratch[(size_t)(b) * ss]
+#define start(b) scratch[(size_t)(SELL_LANES + 1 + (b)) * ss]
+#define cur(b) scratch[(size_t)(2 * (SELL_LANES + 1) + (b)) * ss]
+  for (uint32_t b = 0; b <= SELL_LANES; b++) hist(b) = 0;
   uint32_t n_split = 0;
-  for (uint32_t i = 0; i < n; i++) { const uint32_t l = len[i]; if (l > cap) ++n_split; else ++hist[l]; }
+  for (uint32_t i = 0; i < n; i++) { const uint32_t l = len[i]; if (l > cap) ++n_split; else ++hist(l); }
   // 1. split segments, in the caller's order, packed into slices without straddling
   uint32_t lane = 0;          // absolute lane position (slice * 64 + lane in slice) of the next free lane
   uint32_t next_id = 0;
@@ -75,16 +81,15 @@ KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, S
   }
   const uint32_t split_lanes = lane;
   // 2. the other segments by decreasing length: start lane of every length
-  uint32_t start[SELL_LANES + 1];
-  { uint32_t c = split_lanes; for (uint32_t b = SELL_LANES; b >= 1; b--) { start[b] = c; c += hist[b]; } start[0] = c; }
-  const uint32_t total_lanes = start[0];
-  {
-    uint32_t cur[SELL_LANES + 1];
-    for (uint32_t b = 0; b <= SELL_LANES; b++) cur[b] = 0;
+  { uint32_t c = split_lanes; for (uint32_t b = SELL_LANES; b >= 1; b--) { start(b) = c; c += hist(b); } start(0) = c; }
+  const uint32_t total_lanes = start(0);
+  if (Sink::wants_segments) {
+    for (uint32_t b = 0; b <= SELL_LANES; b++) cur(b) = 0;
     for (uint32_t i = 0; i < n; i++) {
       const uint32_t l = len[i];
       if (l > cap) continue;
-      const uint32_t p = start[l] + cur[l]++;
+      const uint32_t p = start(l) + cur(l);
+      cur(l) = cur(l) + 1;
       sink.seg(i, n_split + (p - split_lanes), p, 1u, l);
     }
   }
@@ -127,7 +132,7 @@ KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, S
     if (plo < hi && plo < total_lanes) {
       // length of the lane at position plo: largest b with start[b] <= plo < start[b - 1 ... ] (start decreases with b)
       uint32_t b = SELL_LANES;
-      while (b > 1 && !(plo >= start[b] && plo < start[b] + hist[b])) --b;
+      while (b > 1 && !(plo >= start(b) && plo < start(b) + hist(b))) --b;
       if (b > width) width = b;
       if (has_meta) {
         const uint32_t phi = hi < total_lanes ? hi : total_lanes;
@@ -138,6 +143,9 @@ KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, S
     sink.slice(si, off | (has_meta ? DESC_META : 0u), width | (first_seg << 16));
     off += (has_meta ? 2 * SELL_META_WORDS : 0u) + width * SELL_LANES;
   }
+#undef hist
+#undef start
+#undef cur
   return LayoutSize{n_slices, off};
 }
 
@@ -166,6 +174,7 @@ struct Plan {
 
 // host reference: CSR plan (kamd_em_local::Plan) -> SELL plan.  Returns 0 = ok, 1 = not applicable (a group exceeds the budget)
 struct VecSink {
+  static const bool wants_segments = true;
   std::vector<uint32_t>* new_id; std::vector<uint32_t>* lane; std::vector<uint32_t>* nv; std::vector<uint32_t>* vlen;
   std::vector<uint32_t>* desc; std::vector<uint16_t>* ell; uint64_t ell0; uint32_t desc0; uint32_t seg0;
   void seg(uint32_t old, uint32_t id, uint32_t ln, uint32_t n, uint32_t vl) const { (*new_id)[seg0 + old] = id; (*lane)[seg0 + old] = ln; (*nv)[seg0 + old] = n; (*vlen)[seg0 + old] = vl; }
@@ -195,8 +204,9 @@ inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Pl
     for (uint32_t t = 0; t < G.n_tr; t++) clen[C.tr_base[g] + t] = G.col_ptr[t + 1] - G.col_ptr[t];
     if (G.n_rows >= SELL_PAD || G.n_tr >= SELL_PAD) return 1;
     NullSink ns;
-    const LayoutSize lr = layout_group(rlen.data() + C.row_base[g], G.n_rows, cap, ns);
-    const LayoutSize lc = layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, ns);
+    uint32_t scratch[LAYOUT_SCRATCH_WORDS];
+    const LayoutSize lr = layout_group(rlen.data() + C.row_base[g], G.n_rows, cap, ns, scratch, 1);
+    const LayoutSize lc = layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, ns, scratch, 1);
     const uint64_t gb = group_bytes(G.n_rows, G.n_tr, lr.n_slices, lc.n_slices, lr.n_u16, lc.n_u16);
     if (gb > budget_bytes) return 1;
     if (gb > P->max_group_bytes) P->max_group_bytes = gb;
@@ -209,8 +219,9 @@ inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Pl
     const kamd_em_local::Group G = C.group(g);
     VecSink sr{&rnew, &rlane, &rnv, &rvl, &P->rdesc, &P->rell, P->rell_base[g], P->rslice_base[g], C.row_base[g]};
     VecSink sc{&cnew, &clane, &cnv, &cvl, &P->cdesc, &P->cell, P->cell_base[g], P->cslice_base[g], C.tr_base[g]};
-    layout_group(rlen.data() + C.row_base[g], G.n_rows, cap, sr);
-    layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, sc);
+    uint32_t scratch[LAYOUT_SCRATCH_WORDS];
+    layout_group(rlen.data() + C.row_base[g], G.n_rows, cap, sr, scratch, 1);
+    layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, sc, scratch, 1);
   }
   // entries (indices renamed to the other direction's new ids) and the per-segment constants in the new order
   P->cw.assign(R, 0); P->single.assign(M, 0.0); P->eff.assign(M, 0.0); P->tr_id.assign(M, 0);

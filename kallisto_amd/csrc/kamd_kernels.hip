@@ -74,7 +74,7 @@ struct FilterDev { int single_overhang, has_mean_fl, fl, strand; };
 // device-resident cursors and statistics
 struct DevState {
   u64 stream_words, n_recs, n_overflow, n_retry;
-  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words, st_text_hits;
+  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words, st_text_hits, st_wave_iters, st_lane_iters;
   u64 n_list, bound_words;       // generic append cursor / size bound accumulator
   u64 n_explicit, n_explicit_big; // items whose set was changed by a positional filter (from the main / overflow kernel)
   u64 exp_words, exp_recs;       // explicit transcript-set stream
@@ -438,6 +438,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
   bool busy = false;      // ... and its state machine still wants probes
   bool exhausted = false;
   u32 probes = 0, breads = 0, raw_words = 0, text_hits = 0;
+  u32 wave_iters = 0, lane_iters = 0;   // loop trips of this wavefront / lanes that probed in them (lane utilisation of the kernel)
 
   for (;;) {
     // 1. lanes without an item take the next ones of the chunk; their sequence words come by LDS-DMA loads, in flight during
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
       cursor += (u32)__popcll(idle_mask);
     }
     if (__ballot(have || loading) == 0ULL) break;
+    ++wave_iters; lane_iters += (u32)__popcll(__ballot(have && busy));
     // 2. every busy lane: one probe -- of the unitig text where the window's place on the unitig is known, else of the table
     if (have && busy) {
       const u32* base = my_words + (size_t)(mate ? seq_words : 0) * 64;
@@ -527,8 +529,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
       for (int j = 0; j < V3_LIST_CAP; j++) if (j < ul.n) o[1 + j] = my_list[(size_t)j * BLOCK];
       raw_words += 1u + (u32)ul.n;
       if (FILTER) {
-        o[2 + TUPLE_CAP] = (u32)mf0.slot; o[3 + TUPLE_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
-        o[4 + TUPLE_CAP] = (u32)mf1.slot; o[5 + TUPLE_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
+        o[2 + V3_LIST_CAP] = (u32)mf0.slot; o[3 + V3_LIST_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
+        o[4 + V3_LIST_CAP] = (u32)mf1.slot; o[5 + V3_LIST_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
       }
       have = false;
     }
@@ -537,6 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
   if (lane == 0) {
     atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); atomicAdd(&st->st_raw_words, s_raw);
     if (s_text) atomicAdd(&st->st_text_hits, s_text);
+    atomicAdd(&st->st_wave_iters, (u64)wave_iters); atomicAdd(&st->st_lane_iters, (u64)lane_iters);
   }
 }
 
@@ -546,10 +549,10 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
 // tuple record [1, m, e0..] (or [0, ..] when the item is not a tuple), so no stream allocation is needed at all; counts
 // of single-set items go through an LDS cache that absorbs the hot sets before touching the dense vector.
 constexpr int DENSE_CACHE = 2048;
-template <bool PAIRED, bool FILTER>
+template <bool PAIRED, bool FILTER, int CAP>   // CAP: class entries of a raw record (12: kernel A v2, 8: v3)
 __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict__ slots, int stride, u64 n_items, u64 slot_base,
                                                     u64 rec_base, FilterDev fd, AlignOut out) {
-  __shared__ u32 lds_ecs[BLOCK * TUPLE_CAP];
+  __shared__ u32 lds_ecs[BLOCK * CAP];
   __shared__ u32 cache_key[DENSE_CACHE];
   __shared__ u32 cache_cnt[DENSE_CACHE];
   __shared__ u32 cache_min[DENSE_CACHE];  // smallest item index (within this launch) that hit the cached set
@@ -561,21 +564,21 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
   for (u64 tile = blockIdx.x; tile * BLOCK < n_items; tile += gridDim.x) {
     const u64 item = tile * BLOCK + threadIdx.x;
     if (item >= n_items) continue;
-    kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; ecs.n = 0; ecs.overflow = false;
+    kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * CAP; ecs.cap = CAP; ecs.n = 0; ecs.overflow = false;
     kamd::MateInfo m0, m1;
     m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
     u32* r = slots + item * (u64)stride;
     const u32 h = r[0];
     const int n = (int)(h & 0xFFu);
-    u32 uecs[TUPLE_CAP];
+    u32 uecs[CAP];
 #pragma unroll
-    for (int j = 0; j < TUPLE_CAP; j++) uecs[j] = j < n ? r[1 + j] : 0u;
-    u32 ec[TUPLE_CAP];
+    for (int j = 0; j < CAP; j++) uecs[j] = j < n ? r[1 + j] : 0u;
+    u32 ec[CAP];
 #pragma unroll
-    for (int j = 0; j < TUPLE_CAP; j++) ec[j] = j < n ? ix.uec_ec[uecs[j] & 0x3FFFFFFFu] : 0u;   // independent loads, issued together
+    for (int j = 0; j < CAP; j++) ec[j] = j < n ? ix.uec_ec[uecs[j] & 0x3FFFFFFFu] : 0u;   // independent loads, issued together
     bool ne0 = false, ne1 = false;
 #pragma unroll
-    for (int j = 0; j < TUPLE_CAP; j++) {
+    for (int j = 0; j < CAP; j++) {
       if (j < n && ix.ec_nonempty[ec[j]]) {
         if (uecs[j] & 0x40000000u) ne0 = true;
         if (uecs[j] & 0x80000000u) ne1 = true;
@@ -586,8 +589,8 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
     m0.n_nonempty = ne0; m1.n_nonempty = ne1;
     if (FILTER) {
-      m0.first_slot = r[2 + TUPLE_CAP]; m0.first_pos = (int)(r[3 + TUPLE_CAP] & 0xFFFF); m0.first_strand = (r[3 + TUPLE_CAP] >> 16) & 1u;
-      m1.first_slot = r[4 + TUPLE_CAP]; m1.first_pos = (int)(r[5 + TUPLE_CAP] & 0xFFFF); m1.first_strand = (r[5 + TUPLE_CAP] >> 16) & 1u;
+      m0.first_slot = r[2 + CAP]; m0.first_pos = (int)(r[3 + CAP] & 0xFFFF); m0.first_strand = (r[3 + CAP] >> 16) & 1u;
+      m1.first_slot = r[4 + CAP]; m1.first_pos = (int)(r[5 + CAP] & 0xFFFF); m1.first_strand = (r[5 + CAP] >> 16) & 1u;
     }
     // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow, 4 explicit set (positional filter changed it)
     int kind = 0;
@@ -740,7 +743,7 @@ __global__ void k_rec_insert(const u32* __restrict__ stream, const u64* __restri
   if (i >= n) return;
   const u64 r = idx ? idx[i] : r0 + i;
   const u64 off = rec_off[r];
-  if (stream[off] == 0u) return;  // slot of an item that is not a tuple record
+  if (off == ~0ULL || stream[off] == 0u) return;  // no record (empty intersection) / slot of an item that is not a tuple record
   const u32 m = stream[off + 1];
   const u64 tag = rec_hash(stream + off + 1, m + 1, seed);
   u64 s = (tag >> 1) & mask;
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(VERIFY_BLOCK) void k_rec_verify(const u32* __restri
   if (i < n) {
     const u64 r = idx ? idx[i] : r0 + i;
     const u64 off = rec_off[r];
-    if (stream[off] != 0u) {
+    if (off != ~0ULL && stream[off] != 0u) {
       s = rec_slot[r];
       const u64 own = table[s].owner;
       const u32 m = stream[off + 1];
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(VERIFY_BLOCK) void k_rec_verify(const u32* __restri
 // ------------------------------------------------------------------------------------------------------------------
 // upper bound of the candidate stream size: sum over candidates of (smallest list + 2)
 __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n,
-                               DevState* st) {
+                               u32* per_tuple, DevState* st) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 b = 0;
   if (i < n) {
@@ -801,6 +804,7 @@ __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, cons
     u64 mn = ~0ULL;
     for (u32 j = 0; j < m; j++) { u32 e = stream[off + 2 + j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; mn = sz < mn ? sz : mn; }
     b = mn + 2;
+    per_tuple[i] = (u32)b;   // the tuple's slot in the candidate stream (k_resolve writes there: no allocation at run time)
   }
   b = wave_sum64(b);
   if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
@@ -836,14 +840,14 @@ __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, const
 //     prefix over the group's 16 bits of the wavefront mask
 constexpr int RES_LANES = 16;
 constexpr int RES_BLOCK = BLOCK;   // (1024-thread blocks were slower: 5.9 against 3.9 ms, the block-wide allocation barrier waits for the slowest tuple)
-constexpr int RES_GROUPS = RES_BLOCK / RES_LANES;
 __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* __restrict__ stream, const TSlot* table,
-                                                   const u64* list, u64 n, u32* cand, u64* cand_off, u64* cand_key, DevState* st) {
-  __shared__ u32 grp_total[RES_GROUPS];
-  __shared__ u64 grp_off[RES_GROUPS];
-  __shared__ u64 grp_rec[RES_GROUPS];
+                                                   const u64* list, u64 n, const u64* __restrict__ slot_off, u32* cand, u64* cand_off,
+                                                   u64* cand_key, const DevState* st) {
+  // every tuple owns a slot of the candidate stream (offsets = scan of the bounds of k_bound_tuples, behind what
+  // k_cand_singles wrote) and record number cand_recs + its index: nothing is allocated here.  (The first version took two
+  // same-address atomics per block of 16 tuples -- 250 k of them at ~12 ns each were 3 of the kernel's 3.9 ms.)
+  const u64 base_words = st->cand_words, base_recs = st->cand_recs;
   const u64 gid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / RES_LANES;
-  const int grp = threadIdx.x / RES_LANES;
   const bool valid = gid < n;
   const int lane = lane_id();
   const int sub = lane & (RES_LANES - 1);
@@ -936,20 +940,10 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
       total += (u32)__popc(gm);
     }
   }
-  // one allocation of the candidate stream per BLOCK (16 tuples), not per tuple: the cursor is a single address
-  if (sub == 0) grp_total[grp] = total;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 words = 0, recs = 0;
-    for (int g = 0; g < RES_GROUPS; g++) if (grp_total[g]) { words += (u64)grp_total[g] + 2; recs++; }
-    u64 wbase = 0, rbase = 0;
-    if (recs) { wbase = atomicAdd(&st->cand_words, words); rbase = atomicAdd(&st->cand_recs, recs); }
-    for (int g = 0; g < RES_GROUPS; g++) if (grp_total[g]) { grp_off[g] = wbase; grp_rec[g] = rbase; wbase += (u64)grp_total[g] + 2; rbase++; }
-  }
-  __syncthreads();
-  if (!valid || total == 0) return;  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
-  const u64 out_off = grp_off[grp];
-  if (sub == 0) { cand[out_off] = (u32)sl.count; cand[out_off + 1] = total; cand_off[grp_rec[grp]] = out_off; if (cand_key) cand_key[grp_rec[grp]] = sl.first; }
+  if (!valid) return;
+  if (total == 0) { if (sub == 0) cand_off[base_recs + gid] = ~0ULL; return; }  // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
+  const u64 out_off = base_words + slot_off[gid];
+  if (sub == 0) { cand[out_off] = (u32)sl.count; cand[out_off + 1] = total; cand_off[base_recs + gid] = out_off; if (cand_key) cand_key[base_recs + gid] = sl.first; }
   u32 written = 0;
   for (u32 c0 = 0; c0 < nb; c0 += RES_LANES) {
     u32 x, gm;
@@ -1866,7 +1860,7 @@ struct kamd_ctx {
   std::vector<void*> index_allocs;
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
-  DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums;
+  DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums, tup_bound, tup_off;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
@@ -1986,7 +1980,7 @@ namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->kernel_a = 3; t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 512; t->em_group_div = 4; t->em_split_len = 64; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024;
 }
 // 0 = keep; values outside a field's range are ignored
@@ -2089,7 +2083,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->fld_host) (void)hipHostFree(c->fld_host);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
-                  &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->clist, &c->sizes, &c->explicit_items,
+                  &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
@@ -2210,7 +2204,7 @@ int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   }
   HIPC(hipEventRecord(c->ev1, c->stream));
   const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
-  hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
+  hipLaunchKernelGGL((k_classify<PAIRED, FILTER, TUPLE_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
                      fd, out);
   HIPC(hipEventRecord(c->ev2, c->stream));
   return 0;
@@ -2225,7 +2219,7 @@ int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
                     AlignOut& out) {
   constexpr int WAVES = BLOCK / 64;
   const int lane_words = seq_words * (PAIRED ? 2 : 1);
-  const int stride = 2 + TUPLE_CAP + (FILTER ? 4 : 0);
+  const int stride = 2 + V3_LIST_CAP + (FILTER ? 4 : 0);
   // every item owns a fixed slot of the stream: raw record from k_match_v3, rewritten in place by k_classify
   const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
   if (int rc = c->stream_buf.ensure((cur_words + n_items * (u64)stride) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
@@ -2256,7 +2250,7 @@ int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   }
   HIPC(hipEventRecord(c->ev1, c->stream));
   const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
-  hipLaunchKernelGGL((k_classify<PAIRED, FILTER>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
+  hipLaunchKernelGGL((k_classify<PAIRED, FILTER, V3_LIST_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
                      fd, out);
   HIPC(hipEventRecord(c->ev2, c->stream));
   return 0;
@@ -2393,6 +2387,7 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   s->n_distinct_tuples = c->n_distinct_tuples; s->n_stream_words = c->host_state.stream_words;
   s->n_raw_words = c->host_state.st_raw_words;
   s->n_text_hits = c->host_state.st_text_hits;
+  s->n_wave_iters = c->host_state.st_wave_iters; s->n_lane_iters = c->host_state.st_lane_iters;
   return 0;
 }
 
@@ -2608,9 +2603,16 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0;
   if (int rc = push_state(c)) return rc;
   hipLaunchKernelGGL(k_bound_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(), dst);
-  if (n_t) hipLaunchKernelGGL(k_bound_tuples, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
-                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, dst);
+  if (int rc = c->tup_bound.ensure((n_t + 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->tup_off.ensure((n_t + 2) * sizeof(u64), 0, c->stream)) return rc;
+  if (n_t) {
+    hipLaunchKernelGGL(k_bound_tuples, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+                       c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_bound.as<u32>(), dst);
+    if (int rc = exclusive_scan(c, c->tup_bound.as<u32>(), n_t, c->tup_off.as<u64>(), c->tup_off.as<u64>() + n_t)) return rc;
+  }
   HIPC(hipGetLastError());
+  u64 tup_words = 0;
+  if (n_t) HIPC(hipMemcpyAsync(&tup_words, c->tup_off.as<u64>() + n_t, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   if (int rc = sync_state(c)) return rc;
   const u64 n_exp_w = c->exp_words_done, n_exp_r = c->host_state.exp_recs;
   const u64 bound = c->host_state.bound_words + n_exp_w;
@@ -2622,9 +2624,13 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
                      c->dense_first.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
   if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
-                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
+                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
+                              cand_key, dst);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
+  // the tuples' slots and record numbers follow what k_cand_singles allocated
+  c->host_state.cand_words += tup_words; c->host_state.cand_recs += n_t;
+  if (int rc = push_state(c)) return rc;
   if (n_exp_r) {  // sets produced by the positional filters join the candidates
     const u64 wbase = c->host_state.cand_words, rbase = c->host_state.cand_recs;
     hipLaunchKernelGGL(k_copy_words, dim3(grid_for(n_exp_w, BLOCK)), dim3(BLOCK), 0, c->stream, c->exp_stream.as<u32>(), n_exp_w,
@@ -3164,27 +3170,31 @@ __global__ void k_sell_lens(SellBuild B) {
   if (i < B.R) { const u32 g = sell_group_of(B.row_base, B.n_groups, i); B.rlen[i] = B.row_ptr[(u64)i + g + 1] - B.row_ptr[(u64)i + g]; }
   if (i < B.M) { const u32 g = sell_group_of(B.tr_base, B.n_groups, i); B.clen[i] = B.col_ptr[(u64)i + g + 1] - B.col_ptr[(u64)i + g]; }
 }
-__global__ void k_sell_sizes(SellBuild B) {
+constexpr int SELL_BUILD_BLOCK = 64;   // one thread lays out one group; its three small tables live in LDS, thread-transposed
+__global__ __launch_bounds__(SELL_BUILD_BLOCK) void k_sell_sizes(SellBuild B) {
+  __shared__ u32 scratch[kamd_em_sell::LAYOUT_SCRATCH_WORDS * SELL_BUILD_BLOCK];
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B.n_groups) return;
   kamd_em_sell::NullSink ns;
-  const kamd_em_sell::LayoutSize lr = kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, ns);
-  const kamd_em_sell::LayoutSize lc = kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, ns);
+  const kamd_em_sell::LayoutSize lr = kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, ns, scratch + threadIdx.x, SELL_BUILD_BLOCK);
+  const kamd_em_sell::LayoutSize lc = kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, ns, scratch + threadIdx.x, SELL_BUILD_BLOCK);
   B.gsz[4 * g] = lr.n_slices; B.gsz[4 * g + 1] = lr.n_u16; B.gsz[4 * g + 2] = lc.n_slices; B.gsz[4 * g + 3] = lc.n_u16;
 }
 struct SellDevSink {
+  static const bool wants_segments = true;
   u32* new_id; u32* lane; u32* vlen; u32* desc; uint16_t* ell; u32 seg0; u32 desc0; u64 ell0;
   __device__ void seg(u32 old, u32 id, u32 ln, u32, u32 vl) const { new_id[seg0 + old] = id; lane[seg0 + old] = ln; vlen[seg0 + old] = vl; }
   __device__ void slice(u32 i, u32 d0, u32 d1) const { desc[2 * (u64)(desc0 + i)] = d0; desc[2 * (u64)(desc0 + i) + 1] = d1; }
   __device__ void meta(u32 off, u32 l, u32 w) const { ell[ell0 + off + 2 * l] = (uint16_t)w; ell[ell0 + off + 2 * l + 1] = (uint16_t)(w >> 16); }
 };
-__global__ void k_sell_layout(SellBuild B) {
+__global__ __launch_bounds__(SELL_BUILD_BLOCK) void k_sell_layout(SellBuild B) {
+  __shared__ u32 scratch[kamd_em_sell::LAYOUT_SCRATCH_WORDS * SELL_BUILD_BLOCK];
   const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B.n_groups) return;
   SellDevSink sr{B.rnew, B.rlane, B.rvl, B.rdesc, B.rell, B.row_base[g], B.rslice_base[g], B.rell_base[g]};
   SellDevSink sc{B.cnew, B.clane, B.cvl, B.cdesc, B.cell, B.tr_base[g], B.cslice_base[g], B.cell_base[g]};
-  kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, sr);
-  kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, sc);
+  kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, sr, scratch + threadIdx.x, SELL_BUILD_BLOCK);
+  kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, sc, scratch + threadIdx.x, SELL_BUILD_BLOCK);
 }
 // entries with the other direction's new ids, and the per-segment constants in the new order; one thread per old segment
 __global__ void k_sell_entries(SellBuild B) {
@@ -3473,7 +3483,7 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   B.rlane = (u32*)(tb + o_rlane); B.clane = (u32*)(tb + o_clane); B.rvl = (u32*)(tb + o_rvl); B.cvl = (u32*)(tb + o_cvl); B.gsz = (u32*)(tb + o_gsz);
   const u64 nseg = std::max(R, M);
   hipLaunchKernelGGL(k_sell_lens, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
-  hipLaunchKernelGGL(k_sell_sizes, dim3(grid_for(ng, 64)), dim3(64), 0, c->stream, B);
+  hipLaunchKernelGGL(k_sell_sizes, dim3(grid_for(ng, SELL_BUILD_BLOCK)), dim3(SELL_BUILD_BLOCK), 0, c->stream, B);
   std::vector<u32> gsz((size_t)ng * 4);
   HIPC(hipMemcpyAsync(gsz.data(), B.gsz, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -3503,7 +3513,7 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   B.rslice_base = (const u32*)(pb + p_rsb); B.cslice_base = (const u32*)(pb + p_csb); B.rell_base = (const u64*)(pb + p_reb); B.cell_base = (const u64*)(pb + p_ceb);
   B.rdesc = (u32*)(pb + p_rd); B.cdesc = (u32*)(pb + p_cdesc); B.rell = (uint16_t*)(pb + p_re); B.cell = (uint16_t*)(pb + p_ce);
   B.cw_new = (u64*)(pb + p_cw); B.single_new = (double*)(pb + p_sg); B.eff_new = (double*)(pb + p_ef); B.tr_id_new = (u32*)(pb + p_id);
-  hipLaunchKernelGGL(k_sell_layout, dim3(grid_for(ng, 64)), dim3(64), 0, c->stream, B);
+  hipLaunchKernelGGL(k_sell_layout, dim3(grid_for(ng, SELL_BUILD_BLOCK)), dim3(SELL_BUILD_BLOCK), 0, c->stream, B);
   hipLaunchKernelGGL(k_sell_entries, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
   HIPC(hipGetLastError());
   P->tr_id.resize(M);

@@ -45,6 +45,6 @@ for var in variants:
     dg = hashlib.md5(repr(items).encode()).hexdigest()[:12] if items else "-"
     digests[var] = dg
     print(f"{var:32s} kernel_ms {min(ts):7.3f} (runs {' '.join(f'{t:.2f}' for t in ts)}) classify {pr['classify_ms']:.2f} probes/pair {st['n_probes']/n:.3f} "
-          f"bucket_reads/pair {st['n_bucket_reads']/n:.3f} text_hits/pair {st['n_text_hits']/n:.3f} ECs {len(ecs.counts)} digest {dg}", flush=True)
+          f"bucket_reads/pair {st['n_bucket_reads']/n:.3f} text_hits/pair {st['n_text_hits']/n:.3f} wave_iters {st['n_wave_iters']} lane_util {st['n_lane_iters']/max(64*st['n_wave_iters'],1):.3f} ECs {len(ecs.counts)} digest {dg}", flush=True)
 ok = len(set(digests.values())) == 1
 print("EC multisets identical across variants:", ok)
