@@ -82,7 +82,10 @@ typedef struct {
   double sd;                /* -s */
   int32_t single_overhang;  /* --single-overhang */
   int32_t strand;           /* 0 unstranded, 1 --fr-stranded, 2 --rf-stranded */
-  int32_t no_jump;          /* --no-jump: match() looks up every k-mer (src/KmerIndex.cpp:1776); not with a strand option */
+  int32_t no_jump;          /* --no-jump: match() looks up every k-mer (src/KmerIndex.cpp:1776) */
+  int32_t do_union;         /* --union: per mate the union of the hits' transcript sets instead of their intersection
+                               (MinCollector::unionECs src/MinCollector.cpp:498, :163-169); match() runs with partial = false.
+                               With a strand option --union and --no-jump filter per hit (src/ProcessReads.cpp:62-82) */
 } kamd_quant_opts;
 
 /* ---- errors ---- */

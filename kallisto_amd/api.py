@@ -40,7 +40,7 @@ class _View(C.Structure):
 class QuantOpts(C.Structure):
     """kamd_quant_opts: the subset of ProgramOptions (src/common.h:93-209) the hot path reads."""
     _fields_ = [("paired", C.c_int32), ("fld", C.c_double), ("sd", C.c_double), ("single_overhang", C.c_int32),
-                ("strand", C.c_int32), ("no_jump", C.c_int32)]
+                ("strand", C.c_int32), ("no_jump", C.c_int32), ("do_union", C.c_int32)]
 
 
 class _Stats(C.Structure):

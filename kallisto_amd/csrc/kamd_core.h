@@ -183,47 +183,58 @@ struct Probe {
 typedef unsigned long long __attribute__((ext_vector_type(2))) kamd_u64x2;
 #endif
 
+// one 64-byte bucket, and what a probe finds in it
+struct BucketLine { uint64_t k0, k1, k2, p0, p1, p2, g01, g2; };
+KAMD_HD BucketLine load_bucket(const uint64_t* slots, uint64_t b) {
+  const uint64_t* bp = slots + b * 8;
+  BucketLine L;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // four 16-byte loads of one 64-byte line, issued back to back
+  const kamd_u64x2 s0 = ((const kamd_u64x2*)bp)[0];
+  const kamd_u64x2 s1 = ((const kamd_u64x2*)bp)[1];
+  const kamd_u64x2 s2 = ((const kamd_u64x2*)bp)[2];
+  const kamd_u64x2 s3 = ((const kamd_u64x2*)bp)[3];
+  L.k0 = s0.x; L.k1 = s0.y; L.k2 = s1.x; L.p0 = s1.y; L.p1 = s2.x; L.p2 = s2.y; L.g01 = s3.x; L.g2 = s3.y;
+#else
+  L.k0 = bp[0]; L.k1 = bp[1]; L.k2 = bp[2]; L.p0 = bp[3]; L.p1 = bp[4]; L.p2 = bp[5]; L.g01 = bp[6]; L.g2 = bp[7];
+#endif
+  return L;
+}
+enum { BUCKET_ABSENT = 0, BUCKET_FOUND = 1, BUCKET_CONTINUE = 2 };   // CONTINUE: the key may sit in the next bucket
+KAMD_HD int match_bucket(const BucketLine& L, uint64_t canon, bool is_fwd_canon, uint64_t b, Probe& p) {
+  p.found = false; p.strand = false; p.uec = NO_UEC; p.dist = 0; p.slot = 0; p.gpos = 0;
+  uint64_t pay = 0; uint32_t gp = 0; int hit = -1;
+  if ((L.k0 & KEY_MASK) == canon) { pay = L.p0; gp = (uint32_t)L.g01; hit = 0; }
+  else if (L.k1 == canon) { pay = L.p1; gp = (uint32_t)(L.g01 >> 32); hit = 1; }
+  else if (L.k2 == canon) { pay = L.p2; gp = (uint32_t)L.g2; hit = 2; }
+  if (hit < 0) return (L.k0 & KEY_CONT) ? BUCKET_CONTINUE : BUCKET_ABSENT;
+  const bool fwd_is_canon = (pay >> 63) != 0;
+  p.found = true;
+  p.strand = (is_fwd_canon == fwd_is_canon);
+  p.uec = (uint32_t)(pay >> 32) & 0x7FFFFFFFu;
+  p.dist = p.strand ? (uint32_t)(pay & 0xFFFF) : (uint32_t)((pay >> 16) & 0xFFFF);
+  p.slot = b * BUCKET_SLOTS + (uint64_t)hit;
+  p.gpos = gp;
+  return BUCKET_FOUND;
+}
 KAMD_HD Probe probe_table(const Table& t, uint64_t canon, bool is_fwd_canon, uint32_t* bucket_reads) {
-  Probe p; p.found = false; p.strand = false; p.uec = NO_UEC; p.dist = 0; p.slot = 0; p.gpos = 0;
+  Probe p;
   uint64_t b = home_bucket(canon, t.n_buckets);
   for (;;) {
-    const uint64_t* bp = t.slots + b * 8;
-    uint64_t k0, k1, k2, p0, p1, p2, g01, g2;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // four 16-byte loads of one 64-byte line, issued back to back
-    kamd_u64x2 s0 = ((const kamd_u64x2*)bp)[0];
-    kamd_u64x2 s1 = ((const kamd_u64x2*)bp)[1];
-    kamd_u64x2 s2 = ((const kamd_u64x2*)bp)[2];
-    kamd_u64x2 s3 = ((const kamd_u64x2*)bp)[3];
-    k0 = s0.x; k1 = s0.y; k2 = s1.x; p0 = s1.y; p1 = s2.x; p2 = s2.y; g01 = s3.x; g2 = s3.y;
-#else
-    k0 = bp[0]; k1 = bp[1]; k2 = bp[2]; p0 = bp[3]; p1 = bp[4]; p2 = bp[5]; g01 = bp[6]; g2 = bp[7];
-#endif
+    const BucketLine L = load_bucket(t.slots, b);
     if (bucket_reads) ++*bucket_reads;
-    uint64_t pay = 0; uint32_t gp = 0; int hit = -1;
-    if ((k0 & KEY_MASK) == canon) { pay = p0; gp = (uint32_t)g01; hit = 0; }
-    else if (k1 == canon) { pay = p1; gp = (uint32_t)(g01 >> 32); hit = 1; }
-    else if (k2 == canon) { pay = p2; gp = (uint32_t)g2; hit = 2; }
-    if (hit >= 0) {
-      bool fwd_is_canon = (pay >> 63) != 0;
-      p.found = true;
-      p.strand = (is_fwd_canon == fwd_is_canon);
-      p.uec = (uint32_t)(pay >> 32) & 0x7FFFFFFFu;
-      p.dist = p.strand ? (uint32_t)(pay & 0xFFFF) : (uint32_t)((pay >> 16) & 0xFFFF);
-      p.slot = b * BUCKET_SLOTS + (uint64_t)hit;
-      p.gpos = gp;
-      return p;
-    }
-    if (!(k0 & KEY_CONT)) return p;
+    if (match_bucket(L, canon, is_fwd_canon, b, p) != BUCKET_CONTINUE) return p;
     ++b;  // the table carries pad buckets at the end, so this never runs off
   }
 }
 
 // The k-mer of the unitig text at base position g (unitig-forward): canonical MSB-first key, as window_canon gives for a read.
 // `utext` carries two words of padding at the end.
-KAMD_HD uint64_t text_canon(const uint32_t* utext, uint32_t g, int k) {
-  const uint32_t wi = g >> 4; const int sh = (int)(g & 15u) * 2;
-  const uint32_t a = utext[wi], b = utext[wi + 1], c = utext[wi + 2];
+struct TextWords { uint32_t a, b, c; };
+KAMD_HD TextWords load_text(const uint32_t* utext, uint32_t g) { const uint32_t wi = g >> 4; return TextWords{utext[wi], utext[wi + 1], utext[wi + 2]}; }
+KAMD_HD uint64_t text_canon_of(const TextWords& w, uint32_t g, int k) {
+  const int sh = (int)(g & 15u) * 2;
+  const uint32_t a = w.a, b = w.b, c = w.c;
   uint64_t x = ((uint64_t)a | ((uint64_t)b << 32)) >> sh;
   if (sh + 2 * k > 64) x |= (uint64_t)c << (64 - sh);
   x &= (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
@@ -231,23 +242,28 @@ KAMD_HD uint64_t text_canon(const uint32_t* utext, uint32_t g, int k) {
   const uint64_t rc = (~x) & ((1ULL << (2 * k)) - 1);
   return fwd < rc ? fwd : rc;
 }
+KAMD_HD uint64_t text_canon(const uint32_t* utext, uint32_t g, int k) { return text_canon_of(load_text(utext, g), g, k); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // per-item accumulation of distinct transcript-set ids (sorted, unique, bounded)
 // ---------------------------------------------------------------------------------------------------------------
+// Entries are transcript-set ids; with --union they also carry which mate's hits had the set (EC_MATE1 / EC_MATE2: the union
+// is taken per mate, MinCollector.cpp:163-169), otherwise the flag bits are zero.
+static const uint32_t EC_MATE1 = 0x40000000u, EC_MATE2 = 0x80000000u, EC_ID_MASK = 0x3FFFFFFFu;
 struct EcList {
   uint32_t* e;   // `cap` entries (LDS in the main kernel, global scratch in the overflow kernel)
   int cap;
   int n;
   bool overflow; // more than `cap` distinct sets: the item is re-run by the overflow kernel with a larger list
 };
-KAMD_HD void eclist_add(EcList& l, uint32_t ec) {
+KAMD_HD void eclist_add(EcList& l, uint32_t ec_flags) {   // sorted by id; flags of equal ids are merged
+  const uint32_t ec = ec_flags & EC_ID_MASK;
   int i = 0;
-  while (i < l.n && l.e[i] < ec) ++i;
-  if (i < l.n && l.e[i] == ec) return;
+  while (i < l.n && (l.e[i] & EC_ID_MASK) < ec) ++i;
+  if (i < l.n && (l.e[i] & EC_ID_MASK) == ec) { l.e[i] |= ec_flags; return; }
   if (l.n == l.cap) { l.overflow = true; return; }
   for (int j = l.n; j > i; --j) l.e[j] = l.e[j - 1];
-  l.e[i] = ec;
+  l.e[i] = ec_flags;
   ++l.n;
 }
 
@@ -261,9 +277,21 @@ struct MateInfo {
   uint32_t probes, bucket_reads;
 };
 
-// KmerIndex::match for one mate.  `sink` receives every pushed hit's transcript-set id (uec -> ec through uec_ec) once.
+// distinct (slot_block, strand) pairs of a mate's hits -- what the per-hit (`comprehensive`) strand filter needs
+// (src/ProcessReads.cpp:62-82); entry = block << 1 | strand
+struct HitBlocks {
+  const uint32_t* slot_block; uint32_t* e; int cap; int n; bool overflow;
+};
+KAMD_HD void hitblocks_add(HitBlocks& h, uint64_t slot, bool strand) {
+  const uint32_t x = (h.slot_block[slot] << 1) | (strand ? 1u : 0u);
+  for (int i = 0; i < h.n; i++) if (h.e[i] == x) return;
+  if (h.n == h.cap) { h.overflow = true; return; }
+  h.e[h.n++] = x;
+}
+// KmerIndex::match for one mate.  `ecs` receives every pushed hit's transcript-set id (uec -> ec through uec_ec) once, with
+// `mflag` (0, EC_MATE1 or EC_MATE2) or-ed in; `hb` (optional) every hit's block and strand.
 KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* ec_nonempty, const ReadView& r, int k,
-                        EcList& ecs, MateInfo& mi) {
+                        EcList& ecs, MateInfo& mi, uint32_t mflag = 0, HitBlocks* hb = nullptr) {
   mi.n_hits = 0; mi.n_nonempty = 0; mi.first_slot = 0; mi.first_pos = -1; mi.first_strand = false;
   mi.probes = 0; mi.bucket_reads = 0;
   const int l = r.len;
@@ -273,10 +301,11 @@ KAMD_HD void match_mate(const Table& t, const uint32_t* uec_ec, const uint8_t* e
   do {                                                                             \
     if (mi.n_hits == 0) { mi.first_slot = (P).slot; mi.first_pos = (POS); mi.first_strand = (P).strand; } \
     ++mi.n_hits;                                                                   \
+    if (hb) hitblocks_add(*hb, (P).slot, (P).strand);                              \
     if ((P).uec != last_uec) {                                                     \
       last_uec = (P).uec;                                                          \
       uint32_t ec_ = uec_ec[(P).uec];                                              \
-      if (ec_nonempty == nullptr || ec_nonempty[ec_]) { eclist_add(ecs, ec_); mi.n_nonempty = 1; } \
+      if (ec_nonempty == nullptr || ec_nonempty[ec_]) { eclist_add(ecs, ec_ | mflag); mi.n_nonempty = 1; } \
     }                                                                              \
   } while (0)
 
@@ -368,6 +397,7 @@ struct MatchState {
   uint32_t um_gpos;   // text position of the hit under examination ...
   bool um_strand;     // ... and its orientation: window w0 + n lies at um_gpos + n (strand) or um_gpos - n of the unitig text
   bool text_tried;    // the pending window was compared with the text and differs: it goes to the table
+  uint32_t disp;      // buckets past the home bucket that have been read for the pending window (continue flags)
 };
 // May the pending probe of a JUMP / MIDDLE / BACK-OFF step be answered from the unitig text?  Only while the window is
 // within `dist` k-mers of the hit (then it lies in the same block of the same unitig, :1780-1799) -- an iterator that had to
@@ -410,7 +440,7 @@ KAMD_HD void match_init(MatchState& st, const ReadView& r, int k) {
   st.w = next_valid_window(r, 0, k);
   st.phase = st.w >= 0 ? PH_SCAN : PH_DONE;
   st.w0 = st.w2 = st.dist = st.nextPos = 0; st.um_uec = st.um2_uec = NO_UEC;
-  st.um_gpos = 0; st.um_strand = false; st.text_tried = false;
+  st.um_gpos = 0; st.um_strand = false; st.text_tried = false; st.disp = 0;
 }
 // consume the probe result of window st.w.  Written data-flow style: every phase only decides (a) whether the hit is
 // recorded, (b) where the next window search starts and (c) the phase that follows; the list insertion and the single
@@ -419,7 +449,7 @@ template <bool DL>
 KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p, UecList& list, int mate, MateFirst& mf, const Table& t) {
   const int lk = r.len - k;
   const int ph = st.phase;
-  st.text_tried = false;
+  st.text_tried = false; st.disp = 0;
   if (DL && ph == PH_DLIST) {   // p = probe of the D-list table
     if (p.found) {
       if (mf.n_hits == 0) { mf.slot = t.dummy_slot; mf.pos = st.w; mf.strand = t.dummy_strand; }
@@ -497,7 +527,7 @@ KAMD_HD void match_feed(MatchState& st, const ReadView& r, int k, const Probe& p
 // map the item's (unitig, set) classes to sorted distinct non-empty transcript-set ids; reports per mate whether any of
 // its hits carried a non-empty set (MinCollector::intersectECs skips empty sets, MinCollector.cpp:463-471)
 KAMD_HD void uecs_to_ecs(const uint32_t* uecs, int n, const uint32_t* uec_ec, const uint8_t* ec_nonempty, EcList& out,
-                         bool* nonempty0, bool* nonempty1) {
+                         bool* nonempty0, bool* nonempty1, bool keep_flags = false) {
   *nonempty0 = *nonempty1 = false;
   for (int i = 0; i < n; i++) {
     const uint32_t u = uecs[i];
@@ -505,8 +535,66 @@ KAMD_HD void uecs_to_ecs(const uint32_t* uecs, int n, const uint32_t* uec_ec, co
     if (ec_nonempty != nullptr && !ec_nonempty[ec]) continue;
     if (u & 0x40000000u) *nonempty0 = true;
     if (u & 0x80000000u) *nonempty1 = true;
-    eclist_add(out, ec);
+    eclist_add(out, keep_flags ? (ec | (u & 0xC0000000u)) : ec);   // (the class lists use the same two flag bits)
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The transcript set of an item before the on-list mask and the positional filters (MinCollector::intersectKmers,
+// src/MinCollector.cpp:160-218), enumerated in increasing order:
+//   default   the intersection of the collected sets (intersectECs per mate, then u1 & u2 -- one intersection of all)
+//   --union   (union of mate 1's sets) & (union of mate 2's sets); a mate without non-empty sets imposes nothing
+//             (unionECs :498-546; the emptiness rules of :172-202 are pair_is_mapped's)
+// `cur`: ecs.n words of scratch (cursors of the k-way merge), only used with --union.
+// ---------------------------------------------------------------------------------------------------------------
+struct SetTables { const uint64_t* ec_off; const uint32_t* ec_ids; };
+template <class F>
+KAMD_HD void for_each_in_set(const SetTables& st, const EcList& ecs, bool union_mode, uint32_t* cur, F&& f) {
+  if (ecs.n == 0) return;
+  if (!union_mode) {
+    int best = 0; uint64_t best_sz = ~0ULL;
+    for (int j = 0; j < ecs.n; j++) { const uint32_t e = ecs.e[j] & EC_ID_MASK; const uint64_t sz = st.ec_off[e + 1] - st.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = j; } }
+    const uint32_t* base = st.ec_ids + st.ec_off[ecs.e[best] & EC_ID_MASK];
+    for (uint64_t c = 0; c < best_sz; c++) {
+      const uint32_t x = base[c];
+      bool ok = true;
+      for (int j = 0; ok && j < ecs.n; j++) {
+        if (j == best) continue;
+        const uint32_t e = ecs.e[j] & EC_ID_MASK;
+        const uint32_t* ids = st.ec_ids + st.ec_off[e];
+        uint64_t lo = 0, hi = st.ec_off[e + 1] - st.ec_off[e];
+        const uint64_t n = hi;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
+        ok = lo < n && ids[lo] == x;
+      }
+      if (ok) f(x);
+    }
+    return;
+  }
+  bool has1 = false, has2 = false;
+  for (int j = 0; j < ecs.n; j++) { cur[j] = 0; has1 = has1 || (ecs.e[j] & EC_MATE1); has2 = has2 || (ecs.e[j] & EC_MATE2); }
+  for (;;) {
+    uint32_t x = 0xFFFFFFFFu;
+    for (int j = 0; j < ecs.n; j++) {
+      const uint32_t e = ecs.e[j] & EC_ID_MASK;
+      const uint64_t p = st.ec_off[e] + cur[j];
+      if (p < st.ec_off[e + 1]) { const uint32_t h = st.ec_ids[p]; if (h < x) x = h; }
+    }
+    if (x == 0xFFFFFFFFu) return;
+    bool in1 = false, in2 = false;
+    for (int j = 0; j < ecs.n; j++) {
+      const uint32_t e = ecs.e[j] & EC_ID_MASK;
+      const uint64_t p = st.ec_off[e] + cur[j];
+      if (p < st.ec_off[e + 1] && st.ec_ids[p] == x) { ++cur[j]; in1 = in1 || (ecs.e[j] & EC_MATE1); in2 = in2 || (ecs.e[j] & EC_MATE2); }
+    }
+    if ((in1 || !has1) && (in2 || !has2)) f(x);
+  }
+}
+// upper bound of the set's size (what a record of it may need): smallest list / sum of the lists
+KAMD_HD uint64_t set_size_bound(const SetTables& st, const uint32_t* e, int n, bool union_mode) {
+  uint64_t mn = ~0ULL, sum = 0;
+  for (int j = 0; j < n; j++) { const uint32_t x = e[j] & EC_ID_MASK; const uint64_t sz = st.ec_off[x + 1] - st.ec_off[x]; sum += sz; if (sz < mn) mn = sz; }
+  return union_mode ? sum : (n ? mn : 0);
 }
 
 // Outcome of intersectKmers' emptiness rules (MinCollector.cpp:172-202) given per-mate facts.
@@ -640,7 +728,21 @@ struct FilterCfg {
   bool fraglen;   // !single_overhang && has_mean_fl && (single-end || one mate without hits)
   int fl;         // (int) tc.get_mean_frag_len()
   int strand;     // 0 none, 1 FR, 2 RF
+  // --union / --no-jump switch doStrandSpecificity to its per-hit mode (src/ProcessReads.cpp:62-82, 1139-1140): the filter
+  // runs once per hit of mate 1 (that hit alone, then mate 2's first mapping k-mer) and once per hit of mate 2 (as written
+  // there: an empty first list, then mate 2's first mapping k-mer), and the results are united.  Every run is a predicate on
+  // the transcript, so: mate 2 has hits -> its first mapping k-mer alone decides (the runs of mate 1's hits give subsets);
+  // mate 2 has none -> a transcript is kept if ANY hit of mate 1 passes it (`hits1`, the distinct block / strand pairs).
+  bool comprehensive = false;
+  const uint32_t* hits1 = nullptr; int n_hits1 = 0;
 };
+// the test of doStrandSpecificity for one hit (:87-99): u &= ec, then sense against the wanted strand
+KAMD_HD bool strand_ok(const PosTables& pt, uint32_t block, bool um_strand, bool want, uint32_t tr) {
+  const int64_t rk = blk_rank(pt, block, tr);
+  if (rk < 0) return false;
+  const int sense = pt.blk_sense[pt.blk_pos_off[block] + (uint64_t)rk];
+  return (((um_strand == (sense != 0)) == want) || sense == 2);
+}
 // keep(tr) for one item: h1 / h2 = first mapping k-mers of mate 1 / 2 (valid = the mate has hits)
 KAMD_HD bool keep_transcript(const PosTables& pt, const FilterCfg& cfg, const FirstHit& h1, const FirstHit& h2, uint32_t tr) {
   if (cfg.fraglen) {
@@ -651,15 +753,18 @@ KAMD_HD bool keep_transcript(const PosTables& pt, const FilterCfg& cfg, const Fi
     if (!sense && x - cfg.fl >= 0) keep = true;                          // :1127-1131
     if (!keep) return false;
   }
+  if (cfg.strand && cfg.comprehensive) {
+    if (h2.valid) return strand_ok(pt, h2.block, h2.strand, cfg.strand == 2, tr);
+    for (int i = 0; i < cfg.n_hits1; i++)
+      if (strand_ok(pt, cfg.hits1[i] >> 1, (cfg.hits1[i] & 1u) != 0, cfg.strand == 1, tr)) return true;
+    return false;
+  }
   if (cfg.strand) {
     for (int mate = 0; mate < 2; mate++) {
       const FirstHit& um = mate ? h2 : h1;
       if (!um.valid) continue;
       const bool want = mate ? (cfg.strand == 2) : (cfg.strand == 1);   // :87 firstStrand = FR, :106 secondStrand = RF
-      int64_t rk = blk_rank(pt, um.block, tr);
-      if (rk < 0) return false;                                          // u &= ec
-      const int sense = pt.blk_sense[pt.blk_pos_off[um.block] + (uint64_t)rk];
-      if (!(((um.strand == (sense != 0)) == want) || sense == 2)) return false;  // :98
+      if (!strand_ok(pt, um.block, um.strand, want, tr)) return false;  // u &= ec; :98
     }
   }
   return true;

@@ -316,6 +316,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   ix->unitig_blk_off[ix->n_unitigs] = ix->blk_lb.size();
   ix->blk_pos_off.push_back(ix->blk_posw.size());
   if (ix->uec_ec.size() >= kamd::UEC_MASK) return kamd::fail(-3, "index: too many (unitig, set) classes");   // class lists keep 30 bits
+  if (ix->ec_off.size() - 1 >= kamd::EC_ID_MASK) return kamd::fail(-3, "index: too many transcript sets");        // set lists keep two mate flags
 
   tick("flatten blocks");
   // 4-6. targets (KmerIndex.cpp:1470-1519)

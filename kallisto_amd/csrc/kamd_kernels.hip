@@ -44,6 +44,7 @@ typedef unsigned int u32;
 constexpr int BLOCK = 256;
 constexpr int TUPLE_CAP = 12;        // distinct set ids kept in LDS per item; more -> overflow kernel
 constexpr int TUPLE_CAP_BIG = 1024;  // per-item capacity of the overflow kernel (global scratch)
+constexpr int EXPLICIT_HITS = 256;   // distinct (block, strand) pairs of a mate's hits kept for the per-hit strand filter
 
 struct DevIndex {
   const u64* table; u64 n_buckets;
@@ -59,17 +60,20 @@ struct DevIndex {
   const u64* dtable; u64 n_dbuckets; u64 dummy_slot; u32 dummy_uec; u32 dummy_strand;
   const u32* utext;   // 2-bit text of all unitigs (kamd_core.h: text_canon)
   int no_jump;   // kamd_quant_opts::no_jump of the run (set by the entry points that take the options)
+  int union_mode;     // kamd_quant_opts::do_union: per-mate unions instead of intersections (MinCollector.cpp:163-169)
+  int comprehensive;  // strand filter per hit (ProcessReads.cpp:62-82): a strand option together with --union / --no-jump
 };
 // the k-mer table(s) as the per-item logic sees them; partial = match()'s `partial` argument = single-end reads
 __host__ __device__ inline kamd::Table make_table(const DevIndex& ix, bool partial) {
   kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
   t.dslots = (const uint64_t*)ix.dtable; t.n_dbuckets = ix.n_dbuckets; t.dummy_uec = ix.dummy_uec; t.dummy_slot = ix.dummy_slot;
-  t.dummy_strand = ix.dummy_strand != 0; t.partial = partial; t.no_jump = ix.no_jump != 0;
+  t.dummy_strand = ix.dummy_strand != 0; t.partial = partial && !ix.union_mode;   // --union: match(..., partial = false) (KmerIndex.cpp:1704)
+  t.no_jump = ix.no_jump != 0;
   return t;
 }
 
 // the filters of processBuffer that depend on the position of the first mapping k-mer (ProcessReads.cpp:1095-1145)
-struct FilterDev { int single_overhang, has_mean_fl, fl, strand; };
+struct FilterDev { int single_overhang, has_mean_fl, fl, strand, comprehensive; };
 
 // device-resident cursors and statistics
 struct DevState {
@@ -77,6 +81,7 @@ struct DevState {
   u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words, st_text_hits, st_wave_iters, st_lane_iters;
   u64 n_list, bound_words;       // generic append cursor / size bound accumulator
   u64 n_explicit, n_explicit_big; // items whose set was changed by a positional filter (from the main / overflow kernel)
+  u64 n_hit_overflow;            // explicit-set pass: reads whose hits touched more than EXPLICIT_HITS blocks
   u64 exp_words, exp_recs;       // explicit transcript-set stream
   u64 cand_words, cand_recs;     // candidate transcript-set stream
 };
@@ -110,22 +115,12 @@ __device__ __forceinline__ bool set_contains(const u32* ids, u32 n, u32 x) {
   while (lo < hi) { u32 mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
   return lo < n && ids[lo] == x;
 }
-// f(tr) for every on-listed member of the intersection of the item's transcript sets (thread-serial)
+// f(tr) for every on-listed member of the item's transcript set (intersection of its sets, or the per-mate unions intersected
+// with --union), in increasing order; thread-serial.  cur: ecs.n words of scratch for the --union merge.
 template <class F>
-__device__ __forceinline__ void for_each_member(const DevIndex& ix, const kamd::EcList& ecs, F&& f) {
-  u32 best = 0; u64 best_sz = ~0ULL;
-  for (int j = 0; j < ecs.n; j++) { u32 e = ecs.e[j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; if (sz < best_sz) { best_sz = sz; best = (u32)j; } }
-  const u32* base = ix.ec_ids + ix.ec_off[ecs.e[best]];
-  for (u32 c = 0; c < (u32)best_sz; c++) {
-    const u32 x = base[c];
-    bool ok = onlisted(ix.onlist_bits, x);
-    for (int j = 0; ok && j < ecs.n; j++) {
-      if ((u32)j == best) continue;
-      const u32 e = ecs.e[j];
-      ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
-    }
-    if (ok) f(x);
-  }
+__device__ __forceinline__ void for_each_member(const DevIndex& ix, const kamd::EcList& ecs, u32* cur, F&& f) {
+  const kamd::SetTables st{(const uint64_t*)ix.ec_off, ix.ec_ids};
+  kamd::for_each_in_set(st, ecs, ix.union_mode != 0, cur, [&](u32 x) { if (onlisted(ix.onlist_bits, x)) f(x); });
 }
 __device__ __forceinline__ kamd::PosTables pos_tables(const DevIndex& ix) {
   return kamd::PosTables{(const uint64_t*)ix.unitig_blk_off, ix.unitig_len, ix.blk_unitig, ix.blk_lb, ix.blk_ub, ix.blk_ec,
@@ -143,17 +138,28 @@ __device__ __forceinline__ kamd::FilterCfg item_filter_cfg(const FilterDev& fd, 
   kamd::FilterCfg cfg;
   cfg.fraglen = !fd.single_overhang && fd.has_mean_fl && (!paired || m0.n_hits == 0 || m1.n_hits == 0);  // ProcessReads.cpp:1095
   cfg.fl = fd.fl; cfg.strand = fd.strand;
+  cfg.comprehensive = fd.comprehensive != 0 && fd.strand != 0;   // (hits1 stays empty: see needs_hit_list)
   return cfg;
+}
+// per-hit strand filter and mate 2 without hits: the outcome depends on every hit of mate 1, which only the explicit-set pass
+// collects (kamd_core.h FilterCfg) -- such items always take that pass
+__device__ __forceinline__ bool needs_hit_list(const FilterDev& fd, const kamd::MateInfo& m1) {
+  return fd.comprehensive != 0 && fd.strand != 0 && m1.n_hits == 0;
 }
 // 0 = the filters leave the set unchanged, 1 = they empty it, 2 = they change it (*kept = new size)
 __device__ __forceinline__ int filter_outcome(const DevIndex& ix, const FilterDev& fd, bool paired, const kamd::MateInfo& m0,
-                                              const kamd::MateInfo& m1, const kamd::EcList& ecs, u32* kept) {
+                                              const kamd::MateInfo& m1, const kamd::EcList& ecs, u32* kept, u32* cur) {
   const kamd::FilterCfg cfg = item_filter_cfg(fd, paired, m0, m1);
   if (!cfg.fraglen && !cfg.strand) return 0;
+  if (needs_hit_list(fd, m1)) {   // decided by the explicit-set pass; the record is at most the unfiltered set
+    const kamd::SetTables st{(const uint64_t*)ix.ec_off, ix.ec_ids};
+    *kept = (u32)kamd::set_size_bound(st, ecs.e, ecs.n, ix.union_mode != 0);
+    return 2;
+  }
   const kamd::PosTables pt = pos_tables(ix);
   const kamd::FirstHit h0 = first_hit(ix, m0), h1 = first_hit(ix, m1);
   u32 total = 0, keep = 0;
-  for_each_member(ix, ecs, [&](u32 tr) { ++total; keep += kamd::keep_transcript(pt, cfg, h0, h1, tr) ? 1u : 0u; });
+  for_each_member(ix, ecs, cur, [&](u32 tr) { ++total; keep += kamd::keep_transcript(pt, cfg, h0, h1, tr) ? 1u : 0u; });
   *kept = keep;
   return keep == total ? 0 : (keep == 0 ? 1 : 2);
 }
@@ -187,7 +193,8 @@ __device__ __forceinline__ void emit_item(const DevIndex& ix, const FilterDev& f
   }
   if (FILTER && (kind == 1 || kind == 2)) {
     u32 kept = 0;
-    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+    u32 cur[TUPLE_CAP];
+    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept, cur);
     if (oc == 1) kind = 0;
     else if (oc == 2) {
       kind = 4;
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
   const int k = ix.k;
 
   kamd::MatchState ms; ms.phase = kamd::PH_DONE; ms.w = 0; ms.w0 = 0; ms.w2 = 0; ms.dist = 0; ms.nextPos = 0;
-  ms.um_uec = ms.um2_uec = kamd::NO_UEC; ms.um_gpos = 0; ms.um_strand = false; ms.text_tried = false;
+  ms.um_uec = ms.um2_uec = kamd::NO_UEC; ms.um_gpos = 0; ms.um_strand = false; ms.text_tried = false; ms.disp = 0;
   kamd::UecList ul{my_list, V3_LIST_CAP, 0, false, BLOCK};
   kamd::MateFirst mf0{0, 0, -1, false}, mf1{0, 0, -1, false};
   int mate = 0, len0 = 0, len1 = 0;
@@ -472,25 +479,31 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
     }
     if (__ballot(have || loading) == 0ULL) break;
     ++wave_iters; lane_iters += (u32)__popcll(__ballot(have && busy));
-    // 2. every busy lane: one probe -- of the unitig text where the window's place on the unitig is known, else of the table
+    // 2. every busy lane: ONE memory request -- the unitig text where the window's place on the unitig is known, else a bucket
+    // of the table -- all of them issued before any is waited for; a text mismatch or a bucket whose continue flag sends the
+    // key to the next bucket costs the lane another iteration, never the wavefront a second round trip
     if (have && busy) {
       const u32* base = my_words + (size_t)(mate ? seq_words : 0) * 64;
       const u32* mplane = words + (chunk0 + my_idx) * (u64)item_words + (size_t)(mate ? rec_words : 0) + seq_words;
       kamd::ReadView rv{base, mplane, mate ? len1 : len0, 64, 1, mate ? n1 : n0};
       bool fc;
       const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
-      kamd::Probe p; p.found = false;
+      const bool use_text = TEXT && kamd::text_applies(ms);
+      const kamd::Table pt = DL ? kamd::phase_table(t, ms.phase) : t;
+      const u32 tpos = use_text ? kamd::text_pos_of(ms) : 0u;
+      const uint64_t bucket = kamd::home_bucket(canon, pt.n_buckets) + ms.disp;
+      kamd::TextWords tw{0u, 0u, 0u};
+      kamd::BucketLine bl{0, 0, 0, 0, 0, 0, 0, 0};
+      if (use_text) tw = kamd::load_text(ix.utext, tpos);
+      else { bl = kamd::load_bucket(pt.slots, bucket); ++breads; }
+      kamd::Probe p; p.found = false; p.strand = false; p.uec = kamd::NO_UEC; p.dist = 0; p.slot = 0; p.gpos = 0;
       bool feed = true;
-      if (TEXT && kamd::text_applies(ms)) {
-        if (kamd::text_canon(ix.utext, kamd::text_pos_of(ms), k) == canon) {
-          p.found = true; p.strand = ms.um_strand; p.uec = ms.um_uec; p.dist = 0; p.slot = 0; p.gpos = 0;   // (only uec is looked at in these phases)
-          ++text_hits; ++probes;
-        } else { ms.text_tried = true; feed = false; }
-      } else {
-        p = kamd::probe_table(DL ? kamd::phase_table(t, ms.phase) : t, canon, fc, &breads);
-        if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
-      }
+      if (use_text) {
+        if (kamd::text_canon_of(tw, tpos, k) == canon) { p.found = true; p.strand = ms.um_strand; p.uec = ms.um_uec; ++text_hits; }   // (only uec is looked at in these phases)
+        else { ms.text_tried = true; feed = false; }
+      } else if (kamd::match_bucket(bl, canon, fc, bucket, p) == kamd::BUCKET_CONTINUE) { ++ms.disp; feed = false; }
       if (feed) {
+        if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
         kamd::match_feed<DL>(ms, rv, k, p, ul, mate, mate ? mf1 : mf0, t);
         if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
           mate = 1;
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
       if (j < n && ix.ec_nonempty[ec[j]]) {
         if (uecs[j] & 0x40000000u) ne0 = true;
         if (uecs[j] & 0x80000000u) ne1 = true;
-        kamd::eclist_add(ecs, ec[j]);
+        kamd::eclist_add(ecs, ix.union_mode ? (ec[j] | (uecs[j] & 0xC0000000u)) : ec[j]);   // --union keeps the mates apart
       }
     }
     ecs.overflow = (h & RAW_OVERFLOW) != 0;
@@ -598,7 +611,8 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     else if (kamd::pair_is_mapped(m0, m1)) kind = ecs.n == 1 ? 1 : 2;
     if (FILTER && (kind == 1 || kind == 2)) {
       u32 kept = 0;
-      const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+      u32 cur[CAP];
+      const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept, cur);
       if (oc == 1) kind = 0;
       else if (oc == 2) {
         kind = 4;
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     ++s_proc;
     if (kind == 1) {
       ++s_single;
-      const u32 e = ecs.e[0];
+      const u32 e = ecs.e[0] & kamd::EC_ID_MASK;
       const u32 hh = (e * 2654435761u) >> (32 - 11);
       const u32 old = atomicCAS(&cache_key[hh], 0xFFFFFFFFu, e);
       if (old == 0xFFFFFFFFu || old == e) { atomicAdd(&cache_cnt[hh], 1u); atomicMin(&cache_min[hh], (u32)item); }
@@ -651,20 +665,22 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
   if (i >= n) return;
   const u64 item = items[i];
   const int item_words = rec_words * (PAIRED ? 2 : 1);
-  kamd::EcList ecs; ecs.e = scratch + i * TUPLE_CAP_BIG; ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
+  // scratch of an item: the list, then as many words for the cursors of the --union merge
+  kamd::EcList ecs; ecs.e = scratch + i * (2 * TUPLE_CAP_BIG); ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
+  u32* cur = scratch + i * (2 * TUPLE_CAP_BIG) + TUPLE_CAP_BIG;
   kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0;
   const kamd::Table t = make_table(ix, !PAIRED);
   const u32* rec = words + item * item_words;
   kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
-  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0, ix.union_mode ? kamd::EC_MATE1 : 0u);
   if (PAIRED) {
     kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
-    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1, ix.union_mode ? kamd::EC_MATE2 : 0u);
   }
   if (ecs.overflow || !kamd::pair_is_mapped(m0, m1)) return;  // > TUPLE_CAP_BIG distinct sets cannot occur for 16-bit read lengths
   if (FILTER) {
     u32 kept = 0;
-    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept);
+    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept, cur);
     if (oc == 1) return;
     if (oc == 2) {
       const u64 k = atomicAdd(&out.st->n_explicit_big, 1ULL);
@@ -695,27 +711,35 @@ __global__ __launch_bounds__(64) void k_explicit_write(DevIndex ix, const u32* _
   if (i >= n) return;
   const u64 item = items[i];
   const int item_words = rec_words * (PAIRED ? 2 : 1);
-  kamd::EcList ecs; ecs.e = scratch + i * (u64)cap; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
+  // scratch of an item: the list (cap words), the cursors of the --union merge (cap), the distinct block / strand pairs of
+  // mate 1's hits for the per-hit strand filter (EXPLICIT_HITS)
+  u32* sbase = scratch + i * (u64)(2 * cap + EXPLICIT_HITS);
+  kamd::EcList ecs; ecs.e = sbase; ecs.cap = cap; ecs.n = 0; ecs.overflow = false;
+  u32* cur = sbase + cap;
+  kamd::HitBlocks hb{ix.slot_block, sbase + 2 * cap, EXPLICIT_HITS, 0, false};
   kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0; m1.first_slot = 0; m1.first_pos = -1; m1.first_strand = false;
   const kamd::Table t = make_table(ix, !PAIRED);
   const u32* rec = words + item * item_words;
   kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
-  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0, ix.union_mode ? kamd::EC_MATE1 : 0u,
+                   (fd.comprehensive && fd.strand) ? &hb : nullptr);   // (only looked at when mate 2 has no hits)
   if (PAIRED) {
     kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
-    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1, ix.union_mode ? kamd::EC_MATE2 : 0u);
   }
-  const kamd::FilterCfg cfg = item_filter_cfg(fd, PAIRED, m0, m1);
+  kamd::FilterCfg cfg = item_filter_cfg(fd, PAIRED, m0, m1);
+  cfg.hits1 = hb.e; cfg.n_hits1 = hb.n;
   const kamd::PosTables pt = pos_tables(ix);
   const kamd::FirstHit h0 = first_hit(ix, m0), h1 = first_hit(ix, m1);
   u32 keep = 0;
-  for_each_member(ix, ecs, [&](u32 tr) { keep += kamd::keep_transcript(pt, cfg, h0, h1, tr) ? 1u : 0u; });
+  if (!hb.overflow) for_each_member(ix, ecs, cur, [&](u32 tr) { keep += kamd::keep_transcript(pt, cfg, h0, h1, tr) ? 1u : 0u; });
+  else atomicAdd(&st->n_hit_overflow, 1ULL);   // (reported as an error by the caller: EXPLICIT_HITS distinct blocks per read is far beyond real data)
   const u64 off = atomicAdd(&st->cand_words, (u64)keep + 2);   // cursor of this pass (exp_words holds the bound)
   const u64 r = atomicAdd(&st->exp_recs, 1ULL);
   u32* w = exp_stream + off;
-  w[0] = 1u; w[1] = keep;
+  w[0] = keep ? 1u : 0u; w[1] = keep;   // count 0: the filters left nothing (the record is skipped downstream)
   u32 o = 0;
-  for_each_member(ix, ecs, [&](u32 tr) { if (kamd::keep_transcript(pt, cfg, h0, h1, tr)) w[2 + o++] = tr; });
+  for_each_member(ix, ecs, cur, [&](u32 tr) { if (keep && kamd::keep_transcript(pt, cfg, h0, h1, tr)) w[2 + o++] = tr; });
   exp_off[r] = off;
   if (exp_key) exp_key[r] = key_base + item * key_stride;  // position of the item in the input (first-occurrence order)
 }
@@ -801,9 +825,8 @@ __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, cons
   if (i < n) {
     const u64 off = table[list[i]].owner;
     const u32 m = stream[off + 1];
-    u64 mn = ~0ULL;
-    for (u32 j = 0; j < m; j++) { u32 e = stream[off + 2 + j]; u64 sz = ix.ec_off[e + 1] - ix.ec_off[e]; mn = sz < mn ? sz : mn; }
-    b = mn + 2;
+    const kamd::SetTables stt{(const uint64_t*)ix.ec_off, ix.ec_ids};
+    b = kamd::set_size_bound(stt, stream + off + 2, (int)m, ix.union_mode != 0) + 2;   // smallest set / sum of the sets (--union)
     per_tuple[i] = (u32)b;   // the tuple's slot in the candidate stream (k_resolve writes there: no allocation at run time)
   }
   b = wave_sum64(b);
@@ -953,6 +976,27 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
   }
 }
 
+// --union: (union of mate 1's sets) & (union of mate 2's sets) of a distinct tuple (entries carry the mate flags), one
+// thread per tuple -- a k-way merge in increasing order (kamd_core.h for_each_in_set); the option is rare, the kernel plain
+__global__ void k_resolve_union(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n,
+                                const u64* __restrict__ slot_off, u32* cand, u64* cand_off, u64* cand_key, u32* cur_scratch,
+                                const DevState* st) {
+  const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const u64 base_words = st->cand_words, base_recs = st->cand_recs;
+  const TSlot sl = table[list[gid]];
+  const u32 m = stream[sl.owner + 1];
+  kamd::EcList ecs; ecs.e = const_cast<u32*>(stream + sl.owner + 2); ecs.cap = (int)m; ecs.n = (int)m; ecs.overflow = false;
+  u32 cur_small[TUPLE_CAP];
+  u32* cur = m <= (u32)TUPLE_CAP ? cur_small : cur_scratch + gid * (u64)TUPLE_CAP_BIG;   // (long tuples come from the overflow kernel)
+  const u64 out_off = base_words + slot_off[gid];
+  u32 total = 0;
+  for_each_member(ix, ecs, cur, [&](u32 tr) { cand[out_off + 2 + total++] = tr; });
+  if (total == 0) { cand_off[base_recs + gid] = ~0ULL; return; }
+  cand[out_off] = (u32)sl.count; cand[out_off + 1] = total; cand_off[base_recs + gid] = out_off;
+  if (cand_key) cand_key[base_recs + gid] = sl.first;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // exclusive scan of u32 sizes into u64 offsets (three kernels; sizes up to 2^31 elements)
 // ------------------------------------------------------------------------------------------------------------------
@@ -1049,14 +1093,16 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
   const u64 item = items ? items[i] : i;
   const int item_words = rec_words * 2;
   kamd::EcList ecs; ecs.n = 0; ecs.overflow = false;
-  if (scratch) { ecs.e = scratch + i * (u64)cap; ecs.cap = cap; } else { ecs.e = lds_list + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; }
+  u32 cur_small[TUPLE_CAP];
+  u32* cur = cur_small;   // cursors of the --union merge: behind the list in the item's scratch (2 x cap words per item)
+  if (scratch) { ecs.e = scratch + i * (u64)(2 * cap); ecs.cap = cap; cur = ecs.e + cap; } else { ecs.e = lds_list + threadIdx.x * TUPLE_CAP; ecs.cap = TUPLE_CAP; }
   kamd::MateInfo m0, m1;
   const kamd::Table t = make_table(ix, false);
   const u32* rec = words + item * item_words;
   kamd::ReadView r0{rec, rec + seq_words, (int)lens[2 * item]};
   kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
-  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
-  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0, ix.union_mode ? kamd::EC_MATE1 : 0u);
+  kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1, ix.union_mode ? kamd::EC_MATE2 : 0u);
   int32_t tl = -1; u32 card = 0;
   if (!ecs.overflow && kamd::pair_is_mapped(m0, m1)) {
     // |u| after the strand filter (the fragment-length filter cannot be active while the FLD is being estimated)
@@ -1064,7 +1110,9 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
       const kamd::FilterCfg cfg = item_filter_cfg(fd, true, m0, m1);
       const kamd::PosTables pt = pos_tables(ix);
       const kamd::FirstHit h0 = first_hit(ix, m0), h1 = first_hit(ix, m1);
-      for_each_member(ix, ecs, [&](u32 tr) {
+      // (with the per-hit strand filter only mate 2's first mapping k-mer matters whenever it has hits -- and a pair
+      // without hits on mate 2 has no fragment length)
+      for_each_member(ix, ecs, cur, [&](u32 tr) {
         card += (!(cfg.fraglen || cfg.strand) || kamd::keep_transcript(pt, cfg, h0, h1, tr)) ? 1u : 0u;
       });
     }
@@ -1888,6 +1936,7 @@ struct kamd_ctx {
   int kernel_a_version = 3, items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
+  bool had_overflow_items = false;   // some item went through the overflow kernel (tuples of more than TUPLE_CAP sets may exist)
   int n_cus = 0, last_em_k = 0; unsigned last_em_grid = 0, last_em_lds = 0;
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
 };
@@ -2025,6 +2074,12 @@ void tuning_from_env(kamd_tuning* t) {
   geti("KAMD_EM_ROW_LANES", &n.em_row_lanes);
   geti("KAMD_EM_FIN_BLOCKS", &n.em_fin_blocks);
   tuning_merge(t, n);
+}
+// the options of the run that the per-item logic reads from the device index
+void apply_quant_opts(kamd_ctx* c, const kamd_quant_opts* o) {
+  c->ix.no_jump = o->no_jump ? 1 : 0;
+  c->ix.union_mode = o->do_union ? 1 : 0;
+  c->ix.comprehensive = (o->strand != 0 && (o->no_jump || o->do_union)) ? 1 : 0;   // ProcessReads.cpp:1139-1140
 }
 void apply_tuning(kamd_ctx* c) {
   c->kernel_a_version = c->tune.kernel_a; c->items_per_wave = c->tune.items_per_wave; c->refill_min = c->tune.refill_min;
@@ -2270,9 +2325,13 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   if (!o->paired && !(o->fld > 0.0 && o->sd > 0.0))
     return kamd::fail(-1, "kamd_pseudoalign: fragment length mean and sd must be supplied for single-end reads (-l, -s)");
   if (o->strand < 0 || o->strand > 2) return kamd::fail(-1, "kamd_pseudoalign: bad strand option");
-  if (o->no_jump && o->strand)   // the reference then filters per hit (`comprehensive`, ProcessReads.cpp:62-82): not built here
-    return kamd::fail(-5, "kamd_pseudoalign: --no-jump together with --fr-stranded/--rf-stranded is not supported");
-  c->ix.no_jump = o->no_jump ? 1 : 0;
+  if (!o->paired && o->do_union && !o->single_overhang)
+    // (the reference itself aborts there: findPosition looks the union's transcripts up in the first mapping k-mer's set,
+    // "Index not present in SparseVector")
+    return kamd::fail(-5, "kamd_pseudoalign: --single with --union needs --single-overhang");
+  if ((o->do_union || (o->no_jump && o->strand)) && c->kernel_a_version == 1)
+    return kamd::fail(-5, "kamd_pseudoalign: --union and the per-hit strand filter need kernel A version 2 or 3");
+  apply_quant_opts(c, o);
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pseudoalign: max_len must be in [1, 65535]");
   if (n_items == 0) return 0;
   HIPC(hipSetDevice(c->device));
@@ -2285,7 +2344,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   // mean_fl is the -l value itself (MinCollector constructor, MinCollector.h:38-41; the truncated-Gaussian mean of
   // init_mean_fl_trunc -- 199.99999999999994 for -l 200 -s 25 -- replaces it only after ProcessReads, main.cpp:2668-2671);
   // with an estimated FLD has_mean_fl stays false while reads are processed
-  FilterDev fd{o->single_overhang, o->fld != 0.0 ? 1 : 0, 0, o->strand};
+  FilterDev fd{o->single_overhang, o->fld != 0.0 ? 1 : 0, 0, o->strand, c->ix.comprehensive};
   if (fd.has_mean_fl) fd.fl = (int)o->fld;  // (int) tc.get_mean_frag_len() (ProcessReads.cpp:1098)
   const bool filter = fd.strand != 0 || (!fd.single_overhang && fd.has_mean_fl);
   // capacity for the worst case of this batch
@@ -2328,7 +2387,8 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   HIPC(hipEventElapsedTime(&c->last_classify_ms, c->ev1, c->ev2));
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
-    if (int rc2 = c->overflow_scratch.ensure(nov * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
+    c->had_overflow_items = true;
+    if (int rc2 = c->overflow_scratch.ensure(nov * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
     const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
     if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
@@ -2357,7 +2417,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
       const u64 n = big ? nb : ne;
       if (!n) continue;
       const int cap = big ? TUPLE_CAP_BIG : TUPLE_CAP;
-      if (int rc2 = c->exp_scratch.ensure(n * (u64)cap * sizeof(u32), 0, c->stream)) return rc2;
+      if (int rc2 = c->exp_scratch.ensure(n * (u64)(2 * cap + EXPLICIT_HITS) * sizeof(u32), 0, c->stream)) return rc2;
       const u64* items = big ? c->explicit_items_big.as<u64>() : c->explicit_items.as<u64>();
       if (o->paired) hipLaunchKernelGGL(k_explicit_write<true>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
                                         seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(),
@@ -2369,6 +2429,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
       HIPC(hipStreamSynchronize(c->stream));  // exp_scratch is reused by the second launch
     }
     if (int rc2 = sync_state(c)) return rc2;
+    if (c->host_state.n_hit_overflow) return kamd::fail(-4, "kamd_pseudoalign: a read's hits touch more blocks than the per-hit strand filter keeps");
     c->exp_words_done = c->host_state.cand_words;
     c->host_state.n_explicit = 0; c->host_state.n_explicit_big = 0;
     if (int rc2 = push_state(c)) return rc2;
@@ -2399,7 +2460,7 @@ constexpr int FLD_CAP_SMALL = 64;   // list entries per item in global scratch (
 int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l, u64 n, int seq_words, int rec_words, hipStream_t s) {
   if (int rc = c->fld_tl.ensure(n * 4, 0, c->stream)) return rc;
   if (int rc = c->fld_card.ensure(n * 4, 0, c->stream)) return rc;
-  if (int rc = c->fld_scratch.ensure(n * FLD_CAP_SMALL * 4, 0, c->stream)) return rc;
+  if (int rc = c->fld_scratch.ensure(n * 2 * FLD_CAP_SMALL * 4, 0, c->stream)) return rc;
   if (n > c->fld_host_cap) {   // pinned staging for the two result vectors
     if (c->fld_host) (void)hipHostFree(c->fld_host);
     c->fld_host = nullptr; c->fld_host_cap = 0;
@@ -2423,7 +2484,7 @@ extern "C" int kamd_fld_prefetch(kamd_ctx* c, const kamd_quant_opts* o, const ui
   if (!c || !o) return kamd::fail(-1, "kamd_fld_prefetch: null argument");
   if (!o->paired || o->fld != 0.0) return kamd::fail(-1, "kamd_fld_prefetch: the FLD is only estimated for paired reads without -l");
   if (!c->has_index) return kamd::fail(-1, "kamd_fld_prefetch: no index uploaded");
-  c->ix.no_jump = o->no_jump ? 1 : 0;
+  apply_quant_opts(c, o);
   HIPC(hipSetDevice(c->device));
   if (n_items == 0) return 0;
   if (!c->fld_stream) {
@@ -2432,7 +2493,7 @@ extern "C" int kamd_fld_prefetch(kamd_ctx* c, const kamd_quant_opts* o, const ui
     HIPC(hipEventCreateWithFlags(&c->fld_ev_in, hipEventDisableTiming));
   }
   if (c->fld_pending.valid) { HIPC(hipStreamSynchronize(c->fld_stream)); c->fld_pending.valid = false; }
-  const FilterDev fd{o->single_overhang, 0, 0, o->strand};
+  const FilterDev fd{o->single_overhang, 0, 0, o->strand, c->ix.comprehensive};
   const u64 n = std::min<u64>(FLD_FIRST_CHUNK, n_items);
   HIPC(hipEventRecord(c->fld_ev_in, c->stream));            // the reads were produced on the context stream
   HIPC(hipStreamWaitEvent(c->fld_stream, c->fld_ev_in, 0));
@@ -2447,9 +2508,9 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
                                    uint64_t n_items, int32_t max_len, uint32_t* flens, uint64_t* n_used) {
   if (!c || !flens || !o) return kamd::fail(-1, "kamd_fld_from_batch: null argument");
   if (!o->paired || o->fld != 0.0) return kamd::fail(-1, "kamd_fld_from_batch: the FLD is only estimated for paired reads without -l");
-  const FilterDev fd{o->single_overhang, 0, 0, o->strand};
   if (!c->has_index) return kamd::fail(-1, "kamd_fld_from_batch: no index uploaded");
-  c->ix.no_jump = o->no_jump ? 1 : 0;
+  apply_quant_opts(c, o);
+  const FilterDev fd{o->single_overhang, 0, 0, o->strand, c->ix.comprehensive};
   HIPC(hipSetDevice(c->device));
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
@@ -2484,7 +2545,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
     if (!h_items.empty()) {
       const u64 no = h_items.size();
       if ((rc = items.ensure(no * 8, 0, c->stream))) break;
-      if ((rc = scratch.ensure(no * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
+      if ((rc = scratch.ensure(no * 2 * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
       if (hipMemcpyAsync(items.p, h_items.data(), no * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
       hipLaunchKernelGGL(k_fld, dim3(grid_for(no, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, items.as<u64>(), no, seq_words,
                          rec_words, scratch.as<u32>(), TUPLE_CAP_BIG, fd, tl.as<int32_t>(), card.as<u32>());
@@ -2623,7 +2684,14 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   u64* cand_key = c->track_order ? c->cand_key.as<u64>() : nullptr;
   hipLaunchKernelGGL(k_cand_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(),
                      c->dense_first.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(), cand_key, dst);
-  if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+  if (n_t && c->ix.union_mode) {
+    // (cursors for tuples longer than TUPLE_CAP: only the overflow kernel produces them, so the buffer is sized when it ran)
+    const bool big = c->had_overflow_items;
+    if (big) if (int rc = c->overflow_scratch.ensure(n_t * (u64)TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_resolve_union, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+                       c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
+                       cand_key, big ? c->overflow_scratch.as<u32>() : nullptr, dst);
+  } else if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
                               c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
                               cand_key, dst);
   HIPC(hipGetLastError());

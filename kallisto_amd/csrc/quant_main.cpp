@@ -39,7 +39,7 @@ const char* KALLISTO_COMPAT_VERSION = "0.51.1";  // src/common.h:4
 struct Options {
   std::string index, output;
   std::vector<std::string> files;
-  bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false;
+  bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false, do_union = false;
   int strand = 0, bootstrap = 0, threads = 1;
   double fld = 0.0, sd = 0.0;
   uint64_t seed = 42;
@@ -290,10 +290,11 @@ int main(int argc, char** argv) {
     else if (a == "--fr-stranded") opt.strand = 1;
     else if (a == "--rf-stranded") opt.strand = 2;
     else if (a == "--no-jump") opt.no_jump = true;
+    else if (a == "--union") opt.do_union = true;
     else if (a == "--plaintext") opt.plaintext = true;
     else if (a == "--verbose") opt.verbose = true;
     else if (a == "--bias" || a == "--fusion" || a == "--pseudobam" || a == "--genomebam" || a == "--long" || a == "-p" || a == "--priors" ||
-             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--union" || a == "--dfk-onlist" ||
+             a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--dfk-onlist" ||
              a == "-P" || a == "--platform" || a == "-N" || a == "--numReads") {
       std::cerr << "Error: option " << a << " is outside the GPU quant path; use the reference kallisto for it" << std::endl; return 1;
     } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage(); return 1; }
@@ -318,7 +319,6 @@ int main(int argc, char** argv) {
   }
   if (opt.fld < 0.0) { std::cerr << "Error: invalid value for mean fragment length " << opt.fld << std::endl; ok = false; }
   if (opt.sd < 0.0) { std::cerr << "Error: invalid value for fragment length standard deviation " << opt.sd << std::endl; ok = false; }
-  if (opt.no_jump && opt.strand) { std::cerr << "Error: --no-jump together with --fr-stranded/--rf-stranded is outside the GPU quant path; use the reference kallisto for it" << std::endl; ok = false; }
   if (opt.output.empty()) { std::cerr << "Error: need to specify output directory " << opt.output << std::endl; ok = false; }
   else if (stat(opt.output.c_str(), &st) == 0) {
     if (!S_ISDIR(st.st_mode)) { std::cerr << "Error: file " << opt.output << " exists and is not a directory" << std::endl; ok = false; }
@@ -344,7 +344,7 @@ int main(int argc, char** argv) {
   if (opt.bootstrap > 0) KX(kamd_ec_track_order(ctx, 1));
 
   const bool paired = !opt.single;
-  kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand, opt.no_jump ? 1 : 0};
+  kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand, opt.no_jump ? 1 : 0, opt.do_union ? 1 : 0};
   std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;

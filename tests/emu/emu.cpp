@@ -99,6 +99,11 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
               p.found = true; p.strand = st.um_strand; p.uec = st.um_uec; p.dist = 0; p.slot = 0; p.gpos = 0;
               ++*probes; ++probes[1];
             } else { st.text_tried = true; continue; }
+          } else if (use_text) {   // as kernel A v3: one bucket per step, a continue flag costs another step
+            const Table pt = phase_table(t, st.phase);
+            const uint64_t b = home_bucket(canon, pt.n_buckets) + st.disp;
+            if (match_bucket(load_bucket(pt.slots, b), canon, fc, b, p) == BUCKET_CONTINUE) { ++st.disp; continue; }
+            if (st.phase != PH_DLIST) ++*probes;
           } else {
             p = probe_table(phase_table(t, st.phase), canon, fc, nullptr);
             if (st.phase != PH_DLIST) ++*probes;   // dbg.find calls of match() only
@@ -124,24 +129,30 @@ extern "C" int64_t emu_pseudoalign_opts(const kamd_index_view* v, const uint32_t
                                         int paired, int32_t max_len, int single_overhang, int strand, int fl, int has_mean_fl,
                                         int no_jump, uint64_t* out_off, uint32_t* out_ids, uint64_t cap) {
   using namespace kamd;
+  const bool do_union = (no_jump & 2) != 0;   // bit 1 of `no_jump`: --union
+  no_jump &= 1;
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
-  const Table t = emu_table(v, !paired, no_jump != 0);
+  const Table t = emu_table(v, !paired && !do_union, no_jump != 0);   // --union: match(..., partial = false) (KmerIndex.cpp:1704)
   PosTables pt{v->unitig_blk_off, v->unitig_len, v->blk_unitig, v->blk_lb, v->blk_ub, v->blk_ec, v->blk_pos_off, v->blk_posw,
                v->blk_sense, v->ec_off, v->ec_ids, v->target_lens, v->k};
+  const SetTables stt{v->ec_off, v->ec_ids};
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
   uint64_t o = 0;
-  uint32_t ecbuf[1024];
+  uint32_t ecbuf[1024], curbuf[1024], hbuf[1024];
+  const bool comprehensive = strand != 0 && (no_jump || do_union);   // ProcessReads.cpp:1139-1140
   for (uint64_t i = 0; i < n_items; i++) {
     out_off[i] = o;
     EcList ecs{ecbuf, 1024, 0, false};
     MateInfo m[2]; memset(m, 0, sizeof m);
+    HitBlocks hb{v->slot_block, hbuf, 1024, 0, false};
     for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
       uint64_t r = paired ? 2 * i + mate : i;
       ReadView rv{words + r * rec, words + r * rec + sw, lens[r]};
-      match_mate(t, v->uec_ec, nonempty.data(), rv, v->k, ecs, m[mate]);
+      match_mate(t, v->uec_ec, nonempty.data(), rv, v->k, ecs, m[mate], do_union ? (mate ? EC_MATE2 : EC_MATE1) : 0u,
+                 (comprehensive && mate == 0) ? &hb : nullptr);
     }
-    if (ecs.overflow) return -1;
+    if (ecs.overflow || hb.overflow) return -1;
     if (!pair_is_mapped(m[0], m[1])) continue;
     FirstHit h[2];
     for (int mate = 0; mate < 2; mate++) {
@@ -153,19 +164,15 @@ extern "C" int64_t emu_pseudoalign_opts(const kamd_index_view* v, const uint32_t
     FilterCfg cfg;
     cfg.fraglen = !single_overhang && has_mean_fl && (!paired || m[0].n_hits == 0 || m[1].n_hits == 0);
     cfg.fl = fl; cfg.strand = strand;
-    std::vector<uint32_t> cur(v->ec_ids + v->ec_off[ecs.e[0]], v->ec_ids + v->ec_off[ecs.e[0] + 1]);
-    for (int j = 1; j < ecs.n; j++) {
-      std::vector<uint32_t> nx;
-      std::set_intersection(cur.begin(), cur.end(), v->ec_ids + v->ec_off[ecs.e[j]], v->ec_ids + v->ec_off[ecs.e[j] + 1],
-                            std::back_inserter(nx));
-      cur.swap(nx);
-    }
-    for (uint32_t tr : cur) {
-      if (!(v->onlist_bits[tr >> 5] >> (tr & 31) & 1)) continue;
-      if ((cfg.fraglen || cfg.strand) && !keep_transcript(pt, cfg, h[0], h[1], tr)) continue;
-      if (o >= cap) return -2;
+    cfg.comprehensive = comprehensive; cfg.hits1 = hbuf; cfg.n_hits1 = hb.n;
+    int64_t err = 0;
+    for_each_in_set(stt, ecs, do_union, curbuf, [&](uint32_t tr) {
+      if (!(v->onlist_bits[tr >> 5] >> (tr & 31) & 1)) return;
+      if ((cfg.fraglen || cfg.strand) && !keep_transcript(pt, cfg, h[0], h[1], tr)) return;
+      if (o >= cap) { err = -2; return; }
       out_ids[o++] = tr;
-    }
+    });
+    if (err) return err;
   }
   out_off[n_items] = o;
   return (int64_t)o;

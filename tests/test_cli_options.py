@@ -54,7 +54,7 @@ def test_option_errors_match_the_reference(args, expected, tmp_path):
         assert rrc == 1 and ref == expected, "the reference binary prints something else now"
 
 
-@pytest.mark.parametrize("args", [["--union"], ["--bias"], ["--pseudobam"], ["--fusion"], ["--long"], ["--no-jump", "--fr-stranded"]])
+@pytest.mark.parametrize("args", [["--bias"], ["--pseudobam"], ["--fusion"], ["--long"], ["--dfk-onlist"]])
 def test_options_outside_the_gpu_path_are_refused(args, tmp_path):
     for f in ("a.fq", "b.fq"):
         open(tmp_path / f, "w").close()

@@ -30,7 +30,9 @@ def _table(path):
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_boot"), ("ref_test_pe", "pe_rf"),
                                           ("yeast_se", "se"), ("yeast_se", "se_fr"), ("human_pe", "pe"),
                                           ("human_pe", "pe_l180"), ("tiny_k7_se", "se"), ("dlist_pe", "pe"), ("dlist_pe", "se_rf"),
-                                          ("mosaic_pe", "pe_nojump"), ("mosaic_pe", "se_nojump"), ("mosaic_pe", "se")])
+                                          ("mosaic_pe", "pe_nojump"), ("mosaic_pe", "se_nojump"), ("mosaic_pe", "se"),
+                                          ("mosaic_pe", "pe_union"), ("mosaic_pe", "pe_union_fr"), ("mosaic_pe", "pe_nojump_rf"),
+                                          ("mosaic_pe", "se_union_overhang")])
 def test_cli_matches_reference_cli(case, variant, tmp_path):
     assert os.path.exists(EXE), "build kallisto_amd_quant with `make -C kallisto_amd/csrc all`"
     meta, idx_path, r1, r2 = common.load_case(case)

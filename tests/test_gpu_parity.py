@@ -45,15 +45,8 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
     assert np.array_equal(index.target_lens, exp["lens"])
     reads = common.interleave(r1, r2 if o["paired"] else None)
     words, lens, max_len = ctx.pack_reads_host(reads)
-    if o["union"]:
-        pytest.skip("--union is oracle-only so far; the front-end refuses the flag (tests/test_cli_options.py)")
-    opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"])
-    if o["no_jump"] and o["strand"]:
-        # the reference then applies the strand filter once per hit (`comprehensive`, ProcessReads.cpp:62-82): outside the GPU
-        # path (the oracle covers it, tests/test_oracle_golden.py) -- the library must say so instead of computing something else
-        with pytest.raises(ka.KallistoAmdError, match="no-jump"):
-            ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
-        return
+    # (--union: per-mate unions; with a strand option --union / --no-jump filter per hit, ProcessReads.cpp:62-82)
+    opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"])
     res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
     assert res.n_processed == exp["nproc"]
     assert res.ecs.multiset() == exp["ecs"]
@@ -102,7 +95,8 @@ def test_batches_and_idempotence(ka, ctxs):
 
 
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_rf"), ("human_pe", "pe"), ("human_pe", "pe_l180"),
-                                          ("yeast_se", "se"), ("yeast_se", "se_fr"), ("tiny_k7_se", "se"), ("mosaic_pe", "pe_nojump"), ("mosaic_pe", "se")])
+                                          ("yeast_se", "se"), ("yeast_se", "se_fr"), ("tiny_k7_se", "se"), ("mosaic_pe", "pe_nojump"), ("mosaic_pe", "se"),
+                                          ("mosaic_pe", "pe_union"), ("mosaic_pe", "pe_union_fr"), ("yeast_se", "se_nojump_rf")])
 def test_first_occurrence_order(case, variant, ka, ctxs):
     """kamd_ec_track_order: the finalized CSR lists the sets in the order the reference assigns ids at -t 1 (first read that
     produced the set) -- the oracle's order, which the reference's bootstrap goldens pin (test_oracle_golden).  Several
@@ -111,7 +105,7 @@ def test_first_occurrence_order(case, variant, ka, ctxs):
     meta, idx_path, r1, r2 = common.load_case(case)
     o = common.parse_variant(meta["variants"][variant])
     index, ctx = ctxs(case)
-    opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"])
+    opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"])
     r2 = r2 if o["paired"] else None
     ctx.track_order(True)
     try:
@@ -129,7 +123,7 @@ def test_first_occurrence_order(case, variant, ka, ctxs):
         ctx.track_order(False)
     ix = O.Index(idx_path)
     buf, off, lens = O.pack_reads(common.interleave(r1, r2))
-    res = O.process_reads(ix, O.Opts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"]), buf, off, lens)
+    res = O.process_reads(ix, O.Opts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"]), buf, off, lens)
     assert np.array_equal(e.counts, res.counts)
     assert np.array_equal(e.ec_off, res.ec_off)
     assert np.array_equal(e.ec_ids, res.ec_ids)

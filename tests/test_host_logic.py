@@ -89,15 +89,12 @@ def test_positional_filters_match_oracle(case, variant, idx):
     meta, _, r1, r2 = common.load_case(case)
     ov = common.parse_variant(meta["variants"][variant])
     paired = bool(ov["paired"])
-    if ov["union"]:
-        pytest.skip("--union is oracle-only so far (tests/test_oracle_golden.py pins the restatement on the reference)")
-    if ov["no_jump"] and ov["strand"]:
-        pytest.skip("--no-jump with a strand option (per-hit `comprehensive` filter) is rejected by the library; oracle-only")
     words, l16, max_len = E.pack(common.interleave(r1, r2 if paired else None))
     has_fl = ov["fld"] > 0
     mean_fl = float(ov["fld"]) if has_fl else 0.0   # the -l value itself while reads are processed (MinCollector.h:38-41)
-    off, ids = E.pseudoalign_opts(e, words, l16, len(r1), paired, max_len, ov["single_overhang"], ov["strand"], int(mean_fl), has_fl, ov["no_jump"])
-    opts = O.Opts(ov["paired"], ov["fld"], ov["sd"], ov["single_overhang"], ov["strand"], ov["no_jump"])
+    off, ids = E.pseudoalign_opts(e, words, l16, len(r1), paired, max_len, ov["single_overhang"], ov["strand"], int(mean_fl), has_fl,
+                                  ov["no_jump"] | 2 * ov["union"])   # --union, and the per-hit strand filter it / --no-jump switch on
+    opts = O.Opts(ov["paired"], ov["fld"], ov["sd"], ov["single_overhang"], ov["strand"], ov["no_jump"], ov["union"])
     for i in range(len(r1)):
         s, _, _ = o.pseudoalign(opts, r1[i], r2[i] if paired else None, mean_fl, has_fl)
         assert ids[off[i]:off[i + 1]].tolist() == s, (case, variant, i)
