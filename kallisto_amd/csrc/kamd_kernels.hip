@@ -51,6 +51,7 @@ struct DevIndex {
   const u32* slot_block; const u32* slot_dist;
   const u32* uec_ec;
   const u64* ec_off; const u32* ec_ids; const uint8_t* ec_nonempty;
+  const u32* uec_ecn;   // uec_ec with bit 31 = "the set is non-empty": one gather instead of two dependent ones in k_classify
   const u32* onlist_bits;
   u64 n_ecs; int k;
   // positional tables (findPosition / strand filters)
@@ -588,14 +589,15 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     for (int j = 0; j < CAP; j++) uecs[j] = j < n ? r[1 + j] : 0u;
     u32 ec[CAP];
 #pragma unroll
-    for (int j = 0; j < CAP; j++) ec[j] = j < n ? ix.uec_ec[uecs[j] & 0x3FFFFFFFu] : 0u;   // independent loads, issued together
+    for (int j = 0; j < CAP; j++) ec[j] = j < n ? ix.uec_ecn[uecs[j] & 0x3FFFFFFFu] : 0u;   // independent loads, issued together
     bool ne0 = false, ne1 = false;
 #pragma unroll
     for (int j = 0; j < CAP; j++) {
-      if (j < n && ix.ec_nonempty[ec[j]]) {
+      if (j < n && (ec[j] & 0x80000000u)) {   // the set is non-empty
+        const u32 id = ec[j] & kamd::EC_ID_MASK;
         if (uecs[j] & 0x40000000u) ne0 = true;
         if (uecs[j] & 0x80000000u) ne1 = true;
-        kamd::eclist_add(ecs, ix.union_mode ? (ec[j] | (uecs[j] & 0xC0000000u)) : ec[j]);   // --union keeps the mates apart
+        kamd::eclist_add(ecs, ix.union_mode ? (id | (uecs[j] & 0xC0000000u)) : id);   // --union keeps the mates apart
       }
     }
     ecs.overflow = (h & RAW_OVERFLOW) != 0;
@@ -2168,6 +2170,9 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   std::vector<uint8_t> ne(v.n_ecs + 1);
   for (u64 e = 0; e < v.n_ecs; e++) ne[e] = v.ec_off[e + 1] > v.ec_off[e];
   if (int rc = upload(c, ne.data(), v.n_ecs, &d.ec_nonempty)) return rc;
+  std::vector<u32> ecn(v.n_uec + 1);
+  for (u64 u = 0; u < v.n_uec; u++) ecn[u] = v.uec_ec[u] | (ne[v.uec_ec[u]] ? 0x80000000u : 0u);
+  if (int rc = upload(c, ecn.data(), v.n_uec, &d.uec_ecn)) return rc;
   if (int rc = upload(c, v.onlist_bits, v.onlist_words, &d.onlist_bits)) return rc;
   if (int rc = upload(c, (const u64*)v.unitig_blk_off, v.n_unitigs + 1, &d.unitig_blk_off)) return rc;
   if (int rc = upload(c, v.unitig_len, v.n_unitigs, &d.unitig_len)) return rc;

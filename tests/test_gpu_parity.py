@@ -53,7 +53,10 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
     assert np.array_equal(res.flens, exp["flens"])
     assert np.array_equal(res.eff_lens, exp["eff"])
     common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
-    common.assert_abundance_close(res.alpha_before_zeroes, exp["abz"], "alpha_before_zeroes", floor=1e-9)
+    # alpha_before_zeroes decays geometrically for transcripts the data does not support; where exactly a value underflows to 0
+    # depends on the summation order (the reference holds 8e-322 in one of these fixtures), so denormal-range values count as 0
+    tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
+    common.assert_abundance_close(tiny(res.alpha_before_zeroes), tiny(exp["abz"]), "alpha_before_zeroes", floor=1e-9)
 
 
 def test_single_end_needs_fragment_length(ka, ctxs):
