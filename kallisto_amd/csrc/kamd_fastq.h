@@ -186,27 +186,62 @@ class SeqReader {
     pos_ = (size_t)(e4 + 1 - buf_.data());
     return 1;
   }
-  // next sequence appended to `out`; returns false at end of file
+  // next sequence into `out`; returns false at end of file.  Character-level semantics of the reference's reader (kseq.h
+  // kseq_read, ext/bifrost/src/kseq.h as used by src/ProcessReads.cpp:3128-3267): a record starts at the next '>' or '@'
+  // anywhere in the stream (leading junk is skipped -- the reference's own functional tests write "\@>t1" headers), the rest
+  // of that line is the name; sequence lines follow until a line that starts with '>', '@' or '+' (empty lines skipped,
+  // trailing '\r' dropped); after '+' as many quality characters as there were bases are consumed.
   bool next(std::string& out) {
-    std::string line;
-    if (!pending_header_) { do { if (!getline(line)) return false; } while (line.empty()); }
-    else { line = header_; pending_header_ = false; }
-    if (line[0] == '@') {  // FASTQ: sequence (possibly multi-line) up to '+', then as many quality chars
-      out.clear();
-      for (;;) { if (!getline(line)) return !out.empty(); if (!line.empty() && line[0] == '+') break; out += line; }
-      size_t q = 0;
-      while (q < out.size()) { if (!getline(line)) break; q += line.size(); }
-      return true;
+    int c;
+    if (!pending_header_) {
+      while ((c = getch()) >= 0 && c != '>' && c != '@') {}
+      if (c < 0) return false;
     }
-    if (line[0] == '>') {
-      out.clear();
-      while (getline(line)) { if (!line.empty() && (line[0] == '>' || line[0] == '@')) { header_ = line; pending_header_ = true; break; } out += line; }
-      return true;
+    pending_header_ = false;
+    while ((c = getch()) >= 0 && c != '\n') {}            // name and comment
+    if (c < 0) return false;
+    out.clear();
+    while ((c = getch()) >= 0 && c != '>' && c != '+' && c != '@') {
+      if (c == '\n') continue;
+      out.push_back((char)c);
+      append_line(out);
     }
-    std::cerr << "Error: malformed sequence file" << std::endl; exit(1);
+    if (c == '>' || c == '@') pending_header_ = true;      // the first character of the next header has been read
+    if (c != '+') return true;                             // FASTA record, or the file ends here
+    while ((c = getch()) >= 0 && c != '\n') {}            // rest of the '+' line
+    size_t q = 0;
+    std::string ql;
+    while (q < out.size()) { ql.clear(); if (!append_line(ql)) break; q += ql.size(); }
+    return true;
   }
 
  private:
+  int getch() {
+    if (pos_ == len_) {
+      const int n = bgzf_ ? bgzf_->read(buf_.data(), buf_.size()) : gzread(f_, buf_.data(), (unsigned)buf_.size());
+      if (n <= 0) return -1;
+      len_ = (size_t)n; pos_ = 0;
+    }
+    return (unsigned char)buf_[pos_++];
+  }
+  // the rest of the current line appended to s (without the line end); false if the stream ended before any byte was read
+  bool append_line(std::string& s) {
+    bool any = false;
+    for (;;) {
+      if (pos_ == len_) {
+        const int n = bgzf_ ? bgzf_->read(buf_.data(), buf_.size()) : gzread(f_, buf_.data(), (unsigned)buf_.size());
+        if (n <= 0) break;
+        len_ = (size_t)n; pos_ = 0;
+      }
+      any = true;
+      char* b = buf_.data() + pos_;
+      char* e = (char*)memchr(b, '\n', len_ - pos_);
+      if (e) { s.append(b, e - b); pos_ = (size_t)(e - buf_.data()) + 1; break; }
+      s.append(b, len_ - pos_); pos_ = len_;
+    }
+    if (!s.empty() && s.back() == '\r') s.pop_back();
+    return any;
+  }
   bool getline(std::string& s) {
     s.clear();
     for (;;) {
@@ -225,8 +260,7 @@ class SeqReader {
   BgzfSource* bgzf_ = nullptr;
   std::vector<char> buf_;
   size_t pos_ = 0, len_ = 0;
-  std::string header_;
-  bool pending_header_ = false;
+  bool pending_header_ = false;   // the '>' / '@' of the next record has already been consumed
 };
 
 // ---- gzip / FASTA input: one decompress-and-parse thread per file hands over chunks of `n` sequences, so the two mates'

@@ -74,6 +74,7 @@ bool take(const std::string& a, const char* shortf, const char* longf, int& i, i
   std::string lf = std::string(longf) + "=";
   if (a.rfind(lf, 0) == 0) { val = a.substr(lf.size()); return true; }
   if (a == longf || (shortf && a == shortf)) { if (i + 1 >= argc) { std::cerr << "Error: missing value for " << a << std::endl; exit(1); } val = argv[++i]; return true; }
+  if (shortf && a.size() > 2 && a.compare(0, 2, shortf) == 0) { val = a.substr(2); return true; }   // getopt's attached form: -t4, -l200
   return false;
 }
 
@@ -93,7 +94,11 @@ struct PackedBatch {
 };
 class DevicePipe {
  public:
-  explicit DevicePipe(std::function<void(PackedBatch&)> run) : run_(std::move(run)), th_([this] { loop(); }) {}
+  // run: device work of one batch; returns 0 or an error code with the message in `err` (reported by the main thread: the
+  // consumer never exits the process itself)
+  explicit DevicePipe(std::function<int(PackedBatch&, std::string&)> run) : run_(std::move(run)), th_([this] { loop(); }) {}
+  bool failed() { std::lock_guard<std::mutex> lk(m_); return failed_; }
+  std::string error() { std::lock_guard<std::mutex> lk(m_); return error_; }
   // a free slot whose pinned buffers hold n_words / n_reads entries (blocks while both slots are in flight)
   PackedBatch& acquire(uint64_t n_words, uint64_t n_reads) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -140,14 +145,16 @@ class DevicePipe {
       if (b.n_reads > b.dl_cap) { if (b.d_len) HIPX(hipFree(b.d_len)); b.dl_cap = b.n_reads * 5 / 4; HIPX(hipMalloc((void**)&b.d_len, b.dl_cap * 2)); }
       HIPX(hipMemcpy(b.d_words, b.h_words, b.n_words * 4, hipMemcpyHostToDevice));
       HIPX(hipMemcpy(b.d_len, b.h_len, b.n_reads * 2, hipMemcpyHostToDevice));
-      run_(b);
+      std::string err;
+      const int rc = failed_ ? 0 : run_(b, err);   // after a failure the remaining batches are only drained
       device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      { std::lock_guard<std::mutex> g(m_); b.filled = false; }
+      { std::lock_guard<std::mutex> g(m_); b.filled = false; if (rc) { failed_ = true; error_ = err; } }
       cv_.notify_all();
       run_i_ ^= 1;
     }
   }
-  std::function<void(PackedBatch&)> run_;
+  std::function<int(PackedBatch&, std::string&)> run_;
+  bool failed_ = false; std::string error_;
   PackedBatch slot_[2];
   std::mutex m_;
   std::condition_variable cv_;
@@ -349,11 +356,14 @@ int main(int argc, char** argv) {
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;
   double pack_s = 0.0;
-  DevicePipe pipe([&](PackedBatch& b) {
+  DevicePipe pipe([&](PackedBatch& b, std::string& err) -> int {
     const bool want_fld = paired && opt.fld == 0.0 && fld_used < 10000;
-    if (want_fld) KX(kamd_fld_prefetch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len));   // runs underneath kernel A
-    KX(kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len));
-    if (paired && opt.fld == 0.0 && fld_used < 10000) KX(kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used));
+    int rc = 0;
+    if (want_fld) rc = kamd_fld_prefetch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);   // runs underneath kernel A
+    if (!rc) rc = kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);
+    if (!rc && want_fld) rc = kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used);
+    if (rc) err = kamd_last_error();
+    return rc;
   });
   const int host_threads = std::max(1, opt.threads);
   for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
@@ -375,7 +385,7 @@ int main(int argc, char** argv) {
           const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
           PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
           const auto t0 = std::chrono::steady_clock::now();
-          std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0);
+          std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0); std::vector<std::string> errs(host_threads); std::vector<std::string> errs(host_threads);
           for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
             const uint64_t a = b0 + nb * t / host_threads, e = b0 + nb * (t + 1) / host_threads;
             if (e == a) return;
@@ -383,12 +393,14 @@ int main(int argc, char** argv) {
             rcs[t] = kamd_pack_reads_host_strided(m1.data, m1.off.data() + a, m1.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, paired ? 2 : 1, first);
             if (paired && rcs[t] == 0)
               rcs[t] = kamd_pack_reads_host_strided(m2.data, m2.off.data() + a, m2.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, 2, first + 1);
+            if (rcs[t]) errs[t] = kamd_last_error();   // (the library keeps its message per thread)
           });
           for (auto& x : th) x.join();
-          for (int rc : rcs) if (rc) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+          for (int t = 0; t < host_threads; t++) if (rcs[t]) { std::cerr << "Error: " << errs[t] << std::endl; return 1; }
           pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
           pb.n_items = nb; pb.max_len = max_len;
           pipe.submit();
+          if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
           n_processed += nb;
           if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
         }
@@ -410,7 +422,7 @@ int main(int argc, char** argv) {
       const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
       PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
       const auto t0 = std::chrono::steady_clock::now();
-      std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0);
+      std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0); std::vector<std::string> errs(host_threads);
       for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
         const uint64_t a = nb * t / host_threads, e = nb * (t + 1) / host_threads;
         if (e == a) return;
@@ -418,12 +430,14 @@ int main(int argc, char** argv) {
         rcs[t] = kamd_pack_reads_host_strided(c1.seqs.data(), c1.off.data() + a, c1.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, paired ? 2 : 1, first);
         if (paired && rcs[t] == 0)
           rcs[t] = kamd_pack_reads_host_strided(c2.seqs.data(), c2.off.data() + a, c2.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, 2, first + 1);
+        if (rcs[t]) errs[t] = kamd_last_error();
       });
       for (auto& x : th) x.join();
-      for (int rc : rcs) if (rc) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+      for (int t = 0; t < host_threads; t++) if (rcs[t]) { std::cerr << "Error: " << errs[t] << std::endl; return 1; }
       pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       pb.n_items = nb; pb.max_len = max_len;
       pipe.submit();
+      if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
       n_processed += nb;
       if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
     }
@@ -431,6 +445,7 @@ int main(int argc, char** argv) {
     delete r2;
   }
   pipe.finish();
+  if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
   if (opt.verbose)
     std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s << " s, host waited for the device "
               << pipe.wait_s << " s" << std::endl;
