@@ -385,7 +385,7 @@ int main(int argc, char** argv) {
           const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
           PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
           const auto t0 = std::chrono::steady_clock::now();
-          std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0); std::vector<std::string> errs(host_threads); std::vector<std::string> errs(host_threads);
+          std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0); std::vector<std::string> errs(host_threads);
           for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
             const uint64_t a = b0 + nb * t / host_threads, e = b0 + nb * (t + 1) / host_threads;
             if (e == a) return;
