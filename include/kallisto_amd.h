@@ -218,6 +218,40 @@ int kamd_ec_explicit_export(kamd_ctx*, uint64_t* n_words, uint64_t* n_recs);
 int kamd_ec_explicit_copy(kamd_ctx*, uint32_t* d_out_words, uint64_t* d_out_rec_off);
 int kamd_ec_explicit_replace(kamd_ctx*, const uint32_t* d_words, uint64_t n_words, const uint64_t* d_rec_off, uint64_t n_recs);
 
+/* ---- several GPUs: one process (or host thread) per GPU, collectives inside the library --------------------------------------
+ * A communicator binds a context to its place among `world` ranks.  Two backends:
+ *   RCCL       kamd_comm_create_rccl: ncclCommInitRank on the context's device (librccl is loaded at run time: the copy the
+ *              process already holds -- PyTorch's -- else KAMD_RCCL_LIB, else the ROCm installation's); every collective is
+ *              enqueued on the context stream, over xGMI between the GPUs of a node.  Rank 0 obtains the 128-byte id with
+ *              kamd_comm_unique_id and the launcher hands it to the other ranks (torch.distributed broadcast, a file, shared
+ *              memory between the threads of one process ...).
+ *   callbacks  kamd_comm_create_callbacks: the caller supplies the collectives (device pointers, context stream already
+ *              synchronised) -- how the tests drive two ranks on one GPU / on the CPU through gloo.
+ * Replaces the reference's merge under a mutex, MasterProcessor::update (src/ProcessReads.cpp:424-481). */
+typedef struct kamd_comm kamd_comm;
+#define KAMD_COMM_ID_BYTES 128
+typedef struct {
+  /* element type: 0 = u32, 1 = i32, 2 = u64, 3 = f64.  All return 0 on success. */
+  int (*allreduce_sum)(void* user, void* d_buf, uint64_t count, int32_t type);
+  int (*allgather)(void* user, const void* d_send, void* d_recv, uint64_t bytes_per_rank);   /* d_recv: world x bytes_per_rank, rank order */
+  int (*broadcast)(void* user, void* d_buf, uint64_t bytes, int32_t root);
+} kamd_comm_callbacks;
+int kamd_comm_unique_id(void* id128);
+int kamd_comm_create_rccl(kamd_ctx*, int32_t rank, int32_t world, const void* id128, kamd_comm** out);
+int kamd_comm_create_callbacks(kamd_ctx*, int32_t rank, int32_t world, const kamd_comm_callbacks*, void* user, kamd_comm** out);
+void kamd_comm_destroy(kamd_comm*);
+/* merge the EC state of all ranks: ONE all-reduce (sum) of the dense count vector + an all-gather of the de-duplicated tuple
+ * records and of the explicit-set records; afterwards every rank holds the state of the whole input (call kamd_ec_finalize
+ * next, on every rank).  Not with kamd_ec_track_order. */
+int kamd_ec_allreduce(kamd_ctx*, kamd_comm*);
+/* host helpers on the same communicator (small values of the quant driver): fragment-length sample of rank `root`, sums */
+int kamd_comm_broadcast_host(kamd_ctx*, kamd_comm*, void* buf, uint64_t bytes, int32_t root);
+int kamd_comm_sum_u64_host(kamd_ctx*, kamd_comm*, uint64_t* values, uint64_t count);
+/* kamd_em_run_partitioned with the communicator's all-reduce as the sum callback, and the per-rank results summed: every
+ * rank returns the same alpha / alpha_before_zeroes / rounds */
+int kamd_em_run_comm(kamd_ctx*, kamd_comm*, const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds,
+                     double* alpha, double* alpha_before_zeroes, int32_t* rounds);
+
 /* ---- finalize: resolve intersections, apply the on-list mask, merge equal sets ----
  * Produces the EC multiset {sorted transcript set -> count} as CSR, on device and (optionally) host. */
 typedef struct {

@@ -5,5 +5,5 @@ package is the thin Python mirror of that ABI used by the tests and bench.py; Py
 streams and torch.distributed.  There is no CPU path: every compute entry point fails loudly without the extension
 and a GPU.
 """
-from .api import (Context, Index, QuantOpts, QuantResult, KallistoAmdError, library_path, load_library, quant,  # noqa: F401
+from .api import (Comm, Context, Index, QuantOpts, QuantResult, KallistoAmdError, library_path, load_library, quant,  # noqa: F401
                   packed_record_words)

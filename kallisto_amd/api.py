@@ -107,6 +107,15 @@ _SYMBOLS = {
     "kamd_ec_explicit_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kamd_ec_explicit_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_ec_explicit_replace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "kamd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "kamd_comm_create_rccl": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "kamd_comm_create_callbacks": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "kamd_comm_destroy": (None, [C.c_void_p]),
+    "kamd_ec_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kamd_comm_broadcast_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
+    "kamd_comm_sum_u64_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kamd_em_run_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_int32)]),
     "kamd_ec_finalize": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
     "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -399,6 +408,23 @@ class Context:
         ew, eo = gather_records(ew, eo, group)
         self.explicit_replace(ew, eo)
 
+    def ec_allreduce(self, comm: "Comm"):
+        """kamd_ec_allreduce: merge the EC state of all ranks inside the library (one all-reduce of the dense count vector +
+        all-gathers of the tuple / explicit-set records, RCCL over xGMI)."""
+        _check(load_library().kamd_ec_allreduce(self._h, comm._h), "kamd_ec_allreduce")
+
+    def em_run_comm(self, comm: "Comm", eff_lens: np.ndarray, n_iter: int = 10000, min_rounds: int = 50):
+        """kamd_em_run_comm: the EM partitioned over the communicator's ranks by connected component; every rank returns the
+        same (alpha, alpha_before_zeroes, rounds)."""
+        eff = np.ascontiguousarray(eff_lens, np.float64)
+        T = len(eff)
+        alpha = np.zeros(T, np.float64)
+        abz = np.zeros(T, np.float64)
+        rounds = C.c_int32(0)
+        _check(load_library().kamd_em_run_comm(self._h, comm._h, eff.ctypes.data, T, n_iter, min_rounds, alpha.ctypes.data,
+                                               abz.ctypes.data, C.byref(rounds)), "kamd_em_run_comm")
+        return alpha, abz, int(rounds.value)
+
     # ---- finalize / EM ----
     def finalize(self, download: bool = True):
         res = _EcResult()
@@ -493,12 +519,132 @@ class Context:
             pass
 
 
+class _CommCallbacks(C.Structure):
+    _fields_ = [("allreduce_sum", C.c_void_p), ("allgather", C.c_void_p), ("broadcast", C.c_void_p)]
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """kamd_comm: the context's place among `world` ranks (one process per GPU).
+
+    Comm.rccl(ctx, rank, world, uid): RCCL inside the library (ncclCommInitRank; uid = Comm.unique_id() of rank 0, handed to
+    the other ranks by the launcher).  Comm.over_process_group(ctx, group): the collectives of torch.distributed as callbacks
+    (gloo in the tests -- two ranks on one GPU; device buffers are staged through the host there).
+    Comm.for_context(ctx): RCCL when the default process group runs on nccl (the id is broadcast through it), else callbacks."""
+
+    def __init__(self, ctx: "Context", handle, keep=None):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(load_library().kamd_comm_unique_id(buf), "kamd_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx: "Context", rank: int, world: int, uid: bytes | None):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
+        _check(load_library().kamd_comm_create_rccl(ctx._h, rank, world, buf, C.byref(h)), "kamd_comm_create_rccl")
+        return cls(ctx, h)
+
+    @classmethod
+    def over_process_group(cls, ctx: "Context", group=None):
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        device = ctx.device
+        via_host = dist.get_backend(group) == "gloo"
+        tmap = {0: (torch.int32, 4), 1: (torch.int32, 4), 2: (torch.int64, 8), 3: (torch.float64, 8)}   # sums of u32 / u64 as signed: same bits
+
+        def _wrap(fn):
+            def g(*a):
+                try:
+                    fn(*a)
+                    torch.cuda.synchronize(device)
+                    return 0
+                except Exception:   # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return g
+
+        def _allreduce(user, d_buf, count, typ):
+            dt, _ = tmap[int(typ)]
+            t = _alias_tensor(torch, d_buf, int(count), dt, device)
+            if via_host:
+                h = t.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group); t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+        def _allgather(user, d_send, d_recv, nbytes):
+            n = int(nbytes)
+            if n == 0:
+                return
+            src = _alias_tensor(torch, d_send, n, torch.uint8, device)
+            dst = _alias_tensor(torch, d_recv, n * world, torch.uint8, device)
+            if via_host:
+                parts = [torch.empty(n, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, src.cpu(), group=group)
+                dst.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(dst, src, group=group)
+
+        def _broadcast(user, d_buf, nbytes, root):
+            t = _alias_tensor(torch, d_buf, int(nbytes), torch.uint8, device)
+            if via_host:
+                h = t.cpu(); dist.broadcast(h, src=int(root), group=group); t.copy_(h)
+            else:
+                dist.broadcast(t, src=int(root), group=group)
+
+        f1 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32)(_wrap(_allreduce))
+        f2 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)(_wrap(_allgather))
+        f3 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32)(_wrap(_broadcast))
+        cbs = _CommCallbacks(C.cast(f1, C.c_void_p), C.cast(f2, C.c_void_p), C.cast(f3, C.c_void_p))
+        h = C.c_void_p()
+        _check(load_library().kamd_comm_create_callbacks(ctx._h, rank, world, C.byref(cbs), None, C.byref(h)), "kamd_comm_create_callbacks")
+        return cls(ctx, h, keep=(f1, f2, f3, cbs))
+
+    @classmethod
+    def for_context(cls, ctx: "Context", group=None):
+        import torch.distributed as dist
+        if dist.get_backend(group) != "nccl" or os.environ.get("KAMD_COMM") == "callbacks":
+            return cls.over_process_group(ctx, group)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls.rccl(ctx, rank, world, box[0])
+
+    def broadcast_np(self, arr: np.ndarray, root: int = 0) -> np.ndarray:
+        a = np.ascontiguousarray(arr).copy()
+        _check(load_library().kamd_comm_broadcast_host(self.ctx._h, self._h, a.ctypes.data, a.nbytes, root), "kamd_comm_broadcast_host")
+        return a
+
+    def sum_int(self, v: int) -> int:
+        a = np.array([int(v)], np.uint64)
+        _check(load_library().kamd_comm_sum_u64_host(self.ctx._h, self._h, a.ctypes.data, 1), "kamd_comm_sum_u64_host")
+        return int(a[0])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().kamd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _alias_tensor(torch, ptr: int, n: int, dtype, device: int):
     """torch tensor over device memory owned by the library (no copy) via __cuda_array_interface__."""
     class _Holder:
         pass
     h = _Holder()
-    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
+    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1", torch.float64: "<f8"}[dtype]
     h.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
     return torch.as_tensor(h, device=f"cuda:{device}")
 
@@ -555,41 +701,48 @@ class QuantResult:
     stats: dict = field(default_factory=dict)
 
 
-def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, group=None) -> QuantResult:
+def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, group=None, comm: Comm | None = None) -> QuantResult:
     """The `kallisto quant` flow (src/main.cpp:2654-2730) over device-resident read batches.
 
-    batches: iterable of (words, lens, n_items, max_len).  With torch.distributed initialised, every rank passes its
-    own shard of the reads; EC counts are merged with one all-reduce + all-gather before the EM, which every rank runs.
+    batches: iterable of (words, lens, n_items, max_len).  Several ranks (torch.distributed initialised, or `comm` given):
+    every rank passes its own shard of the reads; the EC counts are merged inside the library (kamd_ec_allreduce: one
+    all-reduce + all-gathers over RCCL) before the EM, which runs partitioned over the ranks (kamd_em_run_comm).
     """
     index = ctx.index
     batches = list(batches)
     n_proc = 0
+    if comm is None and (group is not None or _dist_on()):
+        comm = getattr(ctx, "_comm", None)
+        if comm is None:
+            comm = ctx._comm = Comm.for_context(ctx, group)
+    multi = comm is not None
+    rank0 = (not multi) or _dist_rank_of(comm, group) == 0
     estimate_fld = opts.fld == 0.0 and bool(opts.paired)
     flens = np.zeros(MAX_FRAG_LEN, np.uint32)
     used = 0
     for bi, (words, lens, n_items, max_len) in enumerate(batches):
-        if bi == 0 and estimate_fld:
+        if bi == 0 and estimate_fld and rank0:
             ctx.fld_prefetch(opts, words, lens, n_items, max_len)   # the FLD kernel of the first prefix runs underneath kernel A
         ctx.pseudoalign(opts, words, lens, n_items, max_len)
         n_proc += n_items
         # FLD: the first 10000 qualifying pairs of the input in order, carried across batches until the sample is full
         # (src/ProcessReads.cpp:981-1008: tlencount persists from batch to batch); rank 0's reads when several ranks run
-        if estimate_fld and used < 10000 and (not _dist_on() or _dist_rank(group) == 0):
+        if estimate_fld and used < 10000 and rank0:
             flens, used = ctx.fld_from_batch(opts, words, lens, n_items, max_len, flens, used)
+    if multi:
+        n_proc = comm.sum_int(n_proc)
     if opts.fld == 0.0:
-        if group is not None or _dist_on():
-            flens = _broadcast_np(ctx, flens, group)
-            n_proc = _sum_int(ctx, n_proc, group)
+        if multi:
+            flens = comm.broadcast_np(flens, 0)
         mft = mean_frag_lens_trunc(flens)
     else:
-        if group is not None or _dist_on():
-            n_proc = _sum_int(ctx, n_proc, group)
         mft = trunc_gaussian_fld(opts.fld, opts.sd)
-    ctx.allreduce_ec_counts(group)
+    if multi:
+        ctx.ec_allreduce(comm)
     ecs = ctx.finalize(download=download_ecs)
     eff = eff_lens(index.target_lens, mft)
-    if _dist_on():
-        alpha, abz, rounds = ctx.em_run_partitioned(eff, group)
+    if multi:
+        alpha, abz, rounds = ctx.em_run_comm(comm, eff)
     else:
         alpha, abz, rounds = ctx.em_run(eff)
     tpm = counts_to_tpm(alpha, eff)
@@ -599,6 +752,16 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
         sizes = np.diff(ecs.ec_off.astype(np.int64))
         n_uniq = int(ecs.counts[sizes == 1].sum(dtype=np.uint64))
     return QuantResult(n_proc, n_aln, n_uniq, ecs, flens, eff, alpha, abz, tpm, rounds, ctx.stats())
+
+
+def _dist_rank_of(comm: Comm, group=None) -> int:
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(group)
+    except Exception:
+        pass
+    return getattr(comm, "rank", 0)
 
 
 def _dist_on() -> bool:

@@ -19,6 +19,8 @@
 // The per-item semantics live in kamd_core.h (shared with the CPU emulation used by the tests).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -4090,4 +4092,254 @@ extern "C" int kamd_bootstrap(kamd_ctx* c, const uint64_t* d_ec_off, const uint3
   // fresh EMAlgorithm on the resampled counts; the weights still come from the original counts (EMAlgorithm.h:46);
   // run(10000, 50, false, false)
   return kamd_em_run(c, d_ec_off, d_ec_ids, c->bs_samp.as<u32>(), d_counts, n_ecs, eff_lens, n_targets, 10000, 50, alpha, nullptr, rounds);
+}
+
+// ======================================================================================================================
+// several GPUs: communicators (RCCL loaded at run time, or caller-supplied collectives) and what runs over them
+// ======================================================================================================================
+namespace {
+// the part of rccl.h this file needs (the library is bound at run time: see kamd_comm_create_rccl)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[KAMD_COMM_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { kNcclSum = 0, kNcclUint8 = 1, kNcclInt32 = 2, kNcclUint32 = 3, kNcclUint64 = 5, kNcclFloat64 = 8 };
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void* h = nullptr;
+  // the copy the process already holds (PyTorch ships its own librccl.so: two copies in one process would each open the GPUs)
+  for (const char* n : {"librccl.so", "librccl.so.1"}) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }
+  if (!h) if (const char* e = getenv("KAMD_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (!h) return kamd::fail(-106, std::string("kamd_comm: librccl.so could not be loaded (") + (dlerror() ? dlerror() : "not found") + "); set KAMD_RCCL_LIB");
+  RcclApi a; a.lib = h;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+  a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+  a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather || !a.Broadcast)
+    return kamd::fail(-106, "kamd_comm: librccl.so lacks an expected entry point");
+  g_rccl = a;
+  return 0;
+}
+int rccl_fail(ncclResult_t r, const char* what) {
+  return kamd::fail(-107, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error") + " (" + std::to_string(r) + ")");
+}
+}  // namespace
+
+struct kamd_comm {
+  kamd_ctx* ctx = nullptr;
+  int rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;            // RCCL backend
+  kamd_comm_callbacks cb{}; void* user = nullptr; bool use_cb = false;
+  DBuf tmp_a, tmp_b, tmp_c, tmp_d;      // staging of the record exchange
+};
+
+namespace {
+int comm_allreduce(kamd_comm* m, void* d_buf, u64 count, int type) {   // type: 0 u32, 1 i32, 2 u64, 3 f64
+  if ((m->world == 1 && !m->nccl) || count == 0) return 0;   // (a world of one on RCCL still goes through the library: see the tests)
+  kamd_ctx* c = m->ctx;
+  if (m->use_cb) {
+    HIPC(hipStreamSynchronize(c->stream));
+    if (int rc = m->cb.allreduce_sum(m->user, d_buf, count, type)) return kamd::fail(-107, "kamd_comm: the all-reduce callback failed (" + std::to_string(rc) + ")");
+    return 0;
+  }
+  static const int dt[4] = {kNcclUint32, kNcclInt32, kNcclUint64, kNcclFloat64};
+  const ncclResult_t r = g_rccl.AllReduce(d_buf, d_buf, (size_t)count, dt[type], kNcclSum, m->nccl, c->stream);
+  return r ? rccl_fail(r, "ncclAllReduce") : 0;
+}
+int comm_allgather(kamd_comm* m, const void* d_send, void* d_recv, u64 bytes) {
+  kamd_ctx* c = m->ctx;
+  if (m->world == 1 && !m->nccl) { if (bytes) HIPC(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->stream)); return 0; }
+  if (bytes == 0) return 0;
+  if (m->use_cb) {
+    HIPC(hipStreamSynchronize(c->stream));
+    if (int rc = m->cb.allgather(m->user, d_send, d_recv, bytes)) return kamd::fail(-107, "kamd_comm: the all-gather callback failed (" + std::to_string(rc) + ")");
+    return 0;
+  }
+  const ncclResult_t r = g_rccl.AllGather(d_send, d_recv, (size_t)bytes, kNcclUint8, m->nccl, c->stream);
+  return r ? rccl_fail(r, "ncclAllGather") : 0;
+}
+int comm_broadcast(kamd_comm* m, void* d_buf, u64 bytes, int root) {
+  if ((m->world == 1 && !m->nccl) || bytes == 0) return 0;
+  kamd_ctx* c = m->ctx;
+  if (m->use_cb) {
+    HIPC(hipStreamSynchronize(c->stream));
+    if (int rc = m->cb.broadcast(m->user, d_buf, bytes, root)) return kamd::fail(-107, "kamd_comm: the broadcast callback failed (" + std::to_string(rc) + ")");
+    return 0;
+  }
+  const ncclResult_t r = g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, kNcclUint8, root, m->nccl, c->stream);
+  return r ? rccl_fail(r, "ncclBroadcast") : 0;
+}
+// all-gather of variable-length record buffers (words + word offsets of the records): every rank's records concatenated in
+// rank order, offsets rebased.  Results in m->tmp_c (words) / m->tmp_d (offsets).
+int comm_gather_records(kamd_comm* m, const u32* d_words, u64 n_words, const u64* d_off, u64 n_recs, u64* tot_words, u64* tot_recs) {
+  kamd_ctx* c = m->ctx;
+  const int W = m->world;
+  // sizes of every rank
+  if (int rc = m->tmp_a.ensure((size_t)(2 + 2 * W) * sizeof(u64), 0, c->stream)) return rc;
+  u64 mine[2] = {n_words, n_recs};
+  u64* d_sizes = m->tmp_a.as<u64>();
+  HIPC(hipMemcpyAsync(d_sizes, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));   // `mine` is a stack buffer
+  if (int rc = comm_allgather(m, d_sizes, d_sizes + 2, sizeof mine)) return rc;
+  std::vector<u64> all((size_t)2 * W);
+  HIPC(hipMemcpyAsync(all.data(), d_sizes + 2, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  u64 mw = 1, mr = 1, tw = 0, tr = 0;
+  for (int r = 0; r < W; r++) { mw = std::max(mw, all[2 * r]); mr = std::max(mr, all[2 * r + 1]); tw += all[2 * r]; tr += all[2 * r + 1]; }
+  // padded send buffers, one all-gather each
+  if (int rc = m->tmp_a.ensure((size_t)(2 + 2 * W) * sizeof(u64) + mw * sizeof(u32) + mr * sizeof(u64) + 64, (size_t)(2 + 2 * W) * sizeof(u64), c->stream)) return rc;
+  char* sa = (char*)m->tmp_a.p + (((size_t)(2 + 2 * W) * sizeof(u64) + 15) & ~(size_t)15);
+  u32* send_w = (u32*)sa; u64* send_o = (u64*)(sa + ((mw * sizeof(u32) + 15) & ~(size_t)15));
+  if (int rc = m->tmp_b.ensure((size_t)W * (mw * sizeof(u32) + mr * sizeof(u64)) + 64, 0, c->stream)) return rc;
+  u32* recv_w = m->tmp_b.as<u32>(); u64* recv_o = (u64*)((char*)m->tmp_b.p + (((size_t)W * mw * sizeof(u32) + 15) & ~(size_t)15));
+  HIPC(hipMemsetAsync(send_w, 0, mw * sizeof(u32), c->stream));
+  HIPC(hipMemsetAsync(send_o, 0, mr * sizeof(u64), c->stream));
+  if (n_words) HIPC(hipMemcpyAsync(send_w, d_words, n_words * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+  if (n_recs) HIPC(hipMemcpyAsync(send_o, d_off, n_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+  if (int rc = comm_allgather(m, send_w, recv_w, mw * sizeof(u32))) return rc;
+  if (int rc = comm_allgather(m, send_o, recv_o, mr * sizeof(u64))) return rc;
+  // concatenate
+  if (int rc = m->tmp_c.ensure(std::max<u64>(tw, 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = m->tmp_d.ensure(std::max<u64>(tr, 1) * sizeof(u64), 0, c->stream)) return rc;
+  u64 bw = 0, br = 0;
+  for (int r = 0; r < W; r++) {
+    const u64 nw = all[2 * r], nr = all[2 * r + 1];
+    if (nw) HIPC(hipMemcpyAsync(m->tmp_c.as<u32>() + bw, recv_w + (size_t)r * mw, nw * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    if (nr) hipLaunchKernelGGL(k_copy_offsets, dim3(grid_for(nr, BLOCK)), dim3(BLOCK), 0, c->stream, recv_o + (size_t)r * mr, nr, bw, m->tmp_d.as<u64>() + br);
+    bw += nw; br += nr;
+  }
+  HIPC(hipGetLastError());
+  *tot_words = tw; *tot_recs = tr;
+  return 0;
+}
+int comm_sum_cb(void* user, int32_t* d_counts, int32_t n) { return comm_allreduce((kamd_comm*)user, d_counts, (u64)n, 1); }
+}  // namespace
+
+extern "C" int kamd_comm_unique_id(void* id128) {
+  if (!id128) return kamd::fail(-1, "kamd_comm_unique_id: null argument");
+  if (int rc = rccl_load()) return rc;
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r) return rccl_fail(r, "ncclGetUniqueId");
+  memcpy(id128, id.internal, KAMD_COMM_ID_BYTES);
+  return 0;
+}
+extern "C" int kamd_comm_create_rccl(kamd_ctx* c, int32_t rank, int32_t world, const void* id128, kamd_comm** out) {
+  if (!c || !out || (world > 1 && !id128)) return kamd::fail(-1, "kamd_comm_create_rccl: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return kamd::fail(-1, "kamd_comm_create_rccl: bad rank / world");
+  *out = nullptr;
+  HIPC(hipSetDevice(c->device));
+  kamd_comm* m = new kamd_comm;
+  m->ctx = c; m->rank = rank; m->world = world;
+  if (world > 1 || id128) {
+    if (int rc = rccl_load()) { delete m; return rc; }
+    ncclUniqueId id; memcpy(id.internal, id128, KAMD_COMM_ID_BYTES);
+    const ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, id, rank);
+    if (r) { delete m; return rccl_fail(r, "ncclCommInitRank"); }
+  }
+  *out = m;
+  return 0;
+}
+extern "C" int kamd_comm_create_callbacks(kamd_ctx* c, int32_t rank, int32_t world, const kamd_comm_callbacks* cb, void* user, kamd_comm** out) {
+  if (!c || !out || !cb || !cb->allreduce_sum || !cb->allgather || !cb->broadcast) return kamd::fail(-1, "kamd_comm_create_callbacks: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return kamd::fail(-1, "kamd_comm_create_callbacks: bad rank / world");
+  kamd_comm* m = new kamd_comm;
+  m->ctx = c; m->rank = rank; m->world = world; m->cb = *cb; m->user = user; m->use_cb = true;
+  *out = m;
+  return 0;
+}
+extern "C" void kamd_comm_destroy(kamd_comm* m) {
+  if (!m) return;
+  if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+  if (m->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->nccl);
+  for (DBuf* b : {&m->tmp_a, &m->tmp_b, &m->tmp_c, &m->tmp_d}) b->release();
+  delete m;
+}
+extern "C" int kamd_ec_allreduce(kamd_ctx* c, kamd_comm* m) {
+  if (!c || !m || m->ctx != c) return kamd::fail(-1, "kamd_ec_allreduce: null argument / communicator of another context");
+  if (m->world == 1 && !m->nccl) return 0;
+  if (c->track_order) return kamd::fail(-1, "kamd_ec_allreduce: merged records have no input order (kamd_ec_track_order is on)");
+  HIPC(hipSetDevice(c->device));
+  // (a) one all-reduce of the dense count vector over the index's transcript sets
+  if (int rc = comm_allreduce(m, c->dense.p, c->n_ecs, 0)) return rc;
+  // (b) the de-duplicated tuple records of every rank
+  uint64_t nw = 0, nt = 0; u64 tw = 0, tr = 0;
+  if (int rc = kamd_ec_tuples_export(c, &nw, &nt)) return rc;
+  DBuf w, o;
+  if (int rc = w.ensure(std::max<u64>(nw, 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = o.ensure(std::max<u64>(nt, 1) * sizeof(u64), 0, c->stream)) { w.release(); return rc; }
+  int rc = kamd_ec_tuples_copy(c, w.as<u32>(), o.as<uint64_t>());
+  if (!rc) rc = comm_gather_records(m, w.as<u32>(), nw, o.as<u64>(), nt, &tw, &tr);
+  if (!rc) rc = kamd_ec_tuples_replace(c, m->tmp_c.as<u32>(), tw, m->tmp_d.as<uint64_t>(), tr);
+  // (c) explicit-set records (positional filters): content-keyed, simply concatenated
+  uint64_t ew = 0, er = 0;
+  if (!rc) rc = kamd_ec_explicit_export(c, &ew, &er);
+  if (!rc) rc = w.ensure(std::max<u64>(ew, 1) * sizeof(u32), 0, c->stream);
+  if (!rc) rc = o.ensure(std::max<u64>(er, 1) * sizeof(u64), 0, c->stream);
+  if (!rc) rc = kamd_ec_explicit_copy(c, w.as<u32>(), o.as<uint64_t>());
+  if (!rc) rc = comm_gather_records(m, w.as<u32>(), ew, o.as<u64>(), er, &tw, &tr);
+  if (!rc) rc = kamd_ec_explicit_replace(c, m->tmp_c.as<u32>(), tw, m->tmp_d.as<uint64_t>(), tr);
+  if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = kamd::fail(-100, "kamd_ec_allreduce: stream error");
+  w.release(); o.release();
+  return rc;
+}
+extern "C" int kamd_comm_broadcast_host(kamd_ctx* c, kamd_comm* m, void* buf, uint64_t bytes, int32_t root) {
+  if (!c || !m || !buf) return kamd::fail(-1, "kamd_comm_broadcast_host: null argument");
+  if ((m->world == 1 && !m->nccl) || bytes == 0) return 0;
+  HIPC(hipSetDevice(c->device));
+  if (int rc = m->tmp_a.ensure(bytes, 0, c->stream)) return rc;
+  HIPC(hipMemcpyAsync(m->tmp_a.p, buf, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (int rc = comm_broadcast(m, m->tmp_a.p, bytes, root)) return rc;
+  HIPC(hipMemcpyAsync(buf, m->tmp_a.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int kamd_comm_sum_u64_host(kamd_ctx* c, kamd_comm* m, uint64_t* values, uint64_t count) {
+  if (!c || !m || !values) return kamd::fail(-1, "kamd_comm_sum_u64_host: null argument");
+  if ((m->world == 1 && !m->nccl) || count == 0) return 0;
+  HIPC(hipSetDevice(c->device));
+  if (int rc = m->tmp_a.ensure(count * sizeof(u64), 0, c->stream)) return rc;
+  HIPC(hipMemcpyAsync(m->tmp_a.p, values, count * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (int rc = comm_allreduce(m, m->tmp_a.p, count, 2)) return rc;
+  HIPC(hipMemcpyAsync(values, m->tmp_a.p, count * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int kamd_em_run_comm(kamd_ctx* c, kamd_comm* m, const double* eff_lens, uint64_t n_targets, uint32_t n_iter, uint32_t min_rounds,
+                                double* alpha, double* alpha_before_zeroes, int32_t* rounds) {
+  if (!c || !m || !eff_lens || !alpha) return kamd::fail(-1, "kamd_em_run_comm: null argument");
+  if (m->world == 1) return kamd_em_run(c, nullptr, nullptr, nullptr, nullptr, 0, eff_lens, n_targets, n_iter, min_rounds, alpha, alpha_before_zeroes, rounds);
+  std::vector<double> abz_local;
+  double* abz = alpha_before_zeroes;
+  if (!abz) { abz_local.assign(n_targets, 0.0); abz = abz_local.data(); }
+  if (int rc = kamd_em_run_partitioned(c, (uint32_t)m->rank, (uint32_t)m->world, comm_sum_cb, m, eff_lens, n_targets, n_iter, min_rounds, alpha, abz, rounds)) return rc;
+  // every transcript is non-zero on exactly one rank: the sum over the ranks is the result
+  HIPC(hipSetDevice(c->device));
+  if (int rc = m->tmp_a.ensure(2 * n_targets * sizeof(double), 0, c->stream)) return rc;
+  double* d = m->tmp_a.as<double>();
+  HIPC(hipMemcpyAsync(d, alpha, n_targets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemcpyAsync(d + n_targets, abz, n_targets * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  if (int rc = comm_allreduce(m, d, 2 * n_targets, 3)) return rc;
+  HIPC(hipMemcpyAsync(alpha, d, n_targets * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(abz, d + n_targets, n_targets * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
 }

@@ -1,8 +1,9 @@
 """Two ranks on ONE GPU (gloo for the collectives, since RCCL needs one device per rank): each rank pseudoaligns its
-shard on the device, the EC states are exported from the device, merged with kallisto_amd.exchange (all-reduce of the dense
-vector + all-gather of tuple / explicit records) and installed back; both ranks must then finalize to the reference's EC
-multiset for the WHOLE input and run the same EM.  This exercises every device-side piece of the multi-GPU path
-(kamd_ec_dense_counts, kamd_ec_tuples_{export,copy,replace}, kamd_ec_explicit_*) that the 8-GPU bench relies on."""
+shard on the device, the library merges the EC states (kamd_ec_allreduce over a communicator whose collectives are gloo's:
+all-reduce of the dense vector + all-gathers of the tuple / explicit-set records), both ranks finalize to the reference's EC
+multiset for the WHOLE input and run the EM partitioned over the ranks (kamd_em_run_comm).  Every device-side piece of the
+multi-GPU path that the 8-GPU bench relies on runs here; only the transport differs (RCCL there).  test_rccl_world_of_one
+drives the RCCL backend itself (ncclCommInitRank, all-reduce, all-gather, broadcast) on the one GPU this box has."""
 import os
 import socket
 import sys
@@ -34,7 +35,6 @@ def _worker(rank, world, port, case, variant, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import kallisto_amd as ka
-        from kallisto_amd.exchange import gather_records, merge_ec_state
         meta, idx_path, r1, r2 = common.load_case(case)
         o = common.parse_variant(meta["variants"][variant])
         paired = bool(o["paired"])
@@ -46,22 +46,21 @@ def _worker(rank, world, port, case, variant, q):
         words, lens, max_len = ctx.pack_reads_host(common.interleave(r1[lo:hi], r2[lo:hi] if paired else None), 100)
         opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"])
         ctx.pseudoalign(opts, words, lens, hi - lo, max_len)
-        # device -> host -> gloo -> device (kallisto_amd.Context.allreduce_ec_counts does the same on RCCL without the hops)
-        dense = ctx.dense_counts()
-        d_cpu = dense.cpu()
-        w, offs = ctx.tuples_export()
-        w, offs = merge_ec_state(d_cpu, w.cpu(), offs.cpu())
-        dense.copy_(d_cpu)
-        ctx.tuples_replace(w.cuda(), offs.cuda())
-        ew, eo = ctx.explicit_export()
-        ew, eo = gather_records(ew.cpu(), eo.cpu())
-        ctx.explicit_replace(ew.cuda(), eo.cuda())
+        # the library's own merge (kamd_ec_allreduce: all-reduce of the dense vector + all-gathers of the tuple / explicit-set
+        # records) over a communicator whose collectives are gloo's -- on a node with one GPU per rank the same calls run on RCCL
+        comm = ka.Comm.over_process_group(ctx)
+        ctx.ec_allreduce(comm)
         ecs = ctx.finalize()
-        # EM partitioned over the ranks by connected component (gloo all-reduce on the device tensors)
-        import kallisto_amd.api as A
+        # EM partitioned over the ranks by connected component (kamd_em_run_comm)
         exp = common.load_expected(case, variant)
-        alpha, abz, rounds = ctx.em_run_partitioned(exp["eff"])
-        alpha1, abz1, rounds1 = ctx.em_run(exp["eff"])          # the single-GPU EM on the same ECs
+        alpha, abz, rounds = ctx.em_run_comm(comm, exp["eff"])
+        ctx.tune(em_form="streamed")
+        alpha1, abz1, rounds1 = ctx.em_run(exp["eff"])          # the single-GPU EM on the same ECs (same form as the partitioned run)
+        ctx.tune(em_form="local")
+        alpha2, abz2, rounds2 = ctx.em_run(exp["eff"])          # ... and the component-local form
+        assert rounds2 == rounds1
+        common.assert_abundance_close(alpha2, alpha1, "component-local EM vs streamed EM", rel=1e-9)
+        comm.close()
         q.put((rank, ecs.multiset(), alpha, abz, rounds, alpha1, abz1, rounds1))
     finally:
         dist.destroy_process_group()
@@ -89,3 +88,29 @@ def test_two_ranks_one_gpu(case, variant):
         common.assert_abundance_close(alpha, alpha1, "partitioned EM vs single-GPU EM", rel=1e-9)
         common.assert_abundance_close(abz, abz1, "alpha_before_zeroes", rel=1e-9, floor=1e-12)
     assert np.array_equal(results[0][2], results[1][2])             # every rank ends with the same vector
+
+
+def test_rccl_world_of_one():
+    """The RCCL backend on one rank: the library finds librccl, creates a communicator from its own unique id and runs every
+    collective it uses (a world of one leaves the data unchanged)."""
+    import kallisto_amd as ka
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    index = ka.Index(idx_path)
+    ctx = ka.Context(0)
+    try:
+        ctx.upload(index)
+        uid = ka.Comm.unique_id()
+        assert len(uid) == 128 and any(uid)
+        comm = ka.Comm.rccl(ctx, 0, 1, uid)
+        words, lens, max_len = ctx.pack_reads_host(common.interleave(r1, r2), 100)
+        opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
+        res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)], comm=comm)
+        exp = common.load_expected("human_pe", "pe")
+        assert res.ecs.multiset() == exp["ecs"] and res.n_processed == len(r1)
+        assert np.array_equal(res.flens, exp["flens"])
+        common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
+        assert comm.sum_int(7) == 7
+        assert np.array_equal(comm.broadcast_np(np.arange(5, dtype=np.uint32)), np.arange(5, dtype=np.uint32))
+        comm.close()
+    finally:
+        ctx.close()
