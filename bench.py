@@ -270,9 +270,9 @@ def main():
         fence()
         tb = time.perf_counter()
         rounds_b = []
-        for b in mine:
-            _, r_b = ctx.bootstrap(int(seeds[b]), res.eff_lens)
-            rounds_b.append(r_b)
+        if mine:
+            _, rb = ctx.bootstrap_batch(seeds[mine], res.eff_lens)   # one multinomial launch, EMs on the cached plan
+            rounds_b = [int(x) for x in rb]
         fence()
         tb = time.perf_counter() - tb
         if world > 1:
@@ -282,7 +282,8 @@ def main():
         boot = {"replicates": args.bootstraps, "seconds": round(tb, 4), "replicates_per_s": round(args.bootstraps / tb, 3),
                 "ms_per_replicate_per_gpu": round(tb / max(len(mine), 1) * 1e3, 2),
                 "em_rounds_first": rounds_b[:3], "note": "Bootstrap::run_em per replicate: multinomial resample of the EC counts "
-                "(N = pseudoaligned pairs draws, libstdc++ semantics) + EM run(10000, 50); replicate b runs on rank b % world"}
+                "(N = pseudoaligned pairs draws, libstdc++ semantics; all replicates of a rank drawn in one launch) + EM run(10000, 50) on "
+                "the cached plan of the EC matrix; replicate b runs on rank b % world (every rank holds the merged ECs)"}
 
     out = None
     if rank == 0:

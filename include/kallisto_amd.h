@@ -193,6 +193,7 @@ typedef struct {
   uint32_t last_em_grid;       /* streamed form: grid of its two per-round launches (blocks of 256 threads, one chunk per wavefront);
                                   component-local form: number of groups (= workgroups per launch) */
   uint32_t last_em_lds;        /* component-local form: LDS bytes per workgroup */
+  int32_t last_em_plan_cached; /* component-local form: 1 = the plan of an earlier run on the same matrix was reused */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 
@@ -300,6 +301,11 @@ int kamd_em_run_partitioned(kamd_ctx*, uint32_t rank, uint32_t world, kamd_em_su
 int kamd_bootstrap(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts, uint64_t n_ecs,
                    uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha, int32_t* rounds,
                    uint32_t* sample_out);
+/* n_rep replicates on the finalized EC result (the pool of src/Bootstrap.cpp:15-92, src/main.cpp:2764-2782): all multinomial
+ * samples are drawn in one launch; the EMs reuse the plan of the matrix (component-local form) and only refresh its counts.
+ * alpha: n_rep x n_targets (row b = replicate b = seeds[b]); rounds: n_rep (nullable). */
+int kamd_bootstrap_batch(kamd_ctx*, const uint64_t* seeds, int32_t n_rep, const double* eff_lens, uint64_t n_targets, double* alpha,
+                         int32_t* rounds);
 /* seeds[b] = std::mt19937_64(seed)() for b = 0..n-1 (src/main.cpp:2746-2752) */
 void kamd_bootstrap_seeds(uint64_t seed, int32_t n, uint64_t* seeds);
 

@@ -63,7 +63,8 @@ class _Profile(C.Structure):
     _fields_ = [("last_align_kernel_ms", C.c_float), ("last_em_ms", C.c_float), ("last_em_iters", C.c_uint64),
                 ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32), ("last_em_nnz", C.c_uint64),
                 ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64),
-                ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32), ("last_em_lds", C.c_uint32)]
+                ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32), ("last_em_lds", C.c_uint32),
+                ("last_em_plan_cached", C.c_int32)]
 
 
 class _EcResult(C.Structure):
@@ -124,6 +125,7 @@ _SYMBOLS = {
                                           C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "kamd_bootstrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                  C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "kamd_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "kamd_bootstrap_seeds": (None, [C.c_uint64, C.c_int32, C.c_void_p]),
     "kamd_mean_frag_lens_trunc": (None, [C.c_void_p, C.c_void_p]),
     "kamd_trunc_gaussian_fld": (None, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
@@ -355,7 +357,8 @@ class Context:
         return {"align_kernel_ms": float(p.last_align_kernel_ms), "em_ms": float(p.last_em_ms), "em_iters": int(p.last_em_iters),
                 "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version),
                 "em_nnz": int(p.last_em_nnz), "em_nnz_multi": int(p.last_em_nnz_multi), "em_nseg": int(p.last_em_nseg),
-                "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid), "em_lds": int(p.last_em_lds)}
+                "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid), "em_lds": int(p.last_em_lds),
+                "em_plan_cached": int(p.last_em_plan_cached)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):
@@ -503,6 +506,17 @@ class Context:
         _check(load_library().kamd_bootstrap(self._h, *args, int(seed), eff.ctypes.data, T, alpha.ctypes.data, C.byref(rounds),
                                              samp.ctypes.data if want_sample else None), "kamd_bootstrap")
         return (alpha, int(rounds.value), samp[:n]) if want_sample else (alpha, int(rounds.value))
+
+    def bootstrap_batch(self, seeds, eff_lens: np.ndarray):
+        """kamd_bootstrap_batch: len(seeds) replicates on the finalized ECs -> (alpha [n_rep, T], rounds [n_rep])."""
+        eff = np.ascontiguousarray(eff_lens, np.float64)
+        sd = np.ascontiguousarray(seeds, np.uint64)
+        T, n = len(eff), len(sd)
+        alpha = np.zeros((n, T), np.float64)
+        rounds = np.zeros(n, np.int32)
+        _check(load_library().kamd_bootstrap_batch(self._h, sd.ctypes.data, n, eff.ctypes.data, T, alpha.ctypes.data, rounds.ctypes.data),
+               "kamd_bootstrap_batch")
+        return alpha, rounds
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)

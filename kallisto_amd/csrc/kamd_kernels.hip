@@ -1904,6 +1904,7 @@ inline unsigned grid_for(u64 n, int block) { return (unsigned)((n + block - 1) /
 
 }  // namespace
 
+namespace { struct SellCache; void sell_cache_free(SellCache*); }
 struct kamd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -1917,7 +1918,10 @@ struct kamd_ctx {
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
   DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
-  DBuf eml_tmp, ems_tmp, ems_plan;   // component-local EM: set-up scratch, sliced-ELLPACK plan
+  DBuf eml_tmp, ems_tmp, ems_plan, ems_maps;   // component-local EM: set-up scratch, sliced-ELLPACK plan, what a replicate re-uses
+  SellCache* sell_cache = nullptr;   // plan of the finalized matrix, kept for bootstrap replicates (allocated on first use)
+  u64 ec_generation = 0;         // bumped whenever the finalized EC result is rebuilt (plans of an older result are stale)
+  int last_em_plan_cached = 0;
   DBuf fld_tl, fld_card, fld_scratch, fld_items;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
@@ -2140,10 +2144,11 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
   if (c->fld_host) (void)hipHostFree(c->fld_host);
+  if (c->sell_cache) sell_cache_free(c->sell_cache);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -2765,6 +2770,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
     if (int rc = c->ec_ids.ensure(sizeof(u32), 0, c->stream)) return rc;
   }
   HIPC(hipStreamSynchronize(c->stream));
+  ++c->ec_generation;
   c->result.n_ecs = n_final; c->result.nnz = nnz;
   c->result.d_ec_off = c->ec_off.as<uint64_t>(); c->result.d_ec_ids = c->ec_ids.as<u32>(); c->result.d_counts = c->ec_counts.as<u32>();
   c->result.n_pseudoaligned = 0;  // filled by kamd_ec_download callers from the counts; kept for ABI symmetry
@@ -3389,7 +3395,8 @@ int EmLocalGpu::setup(int chunk) {
 // kamd_em_local.h with scans in between.  The host only sees the per-group sizes (budget check, bases) and, for the final
 // scatter, tr_id and the singleton counts.  0 = ok (P holds the host part, *dev the device part), 1 = not applicable.
 int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                          const double* eff_lens, u64 T, u64 budget, u64 target, kamd_em_local::Plan* P, EmLocalDev* dev) {
+                          const double* eff_lens, u64 T, u64 budget, u64 target, kamd_em_local::Plan* P, EmLocalDev* dev,
+                          kamd_em_local::BuildArgs* args_out = nullptr) {
   namespace L = kamd_em_local;
   if (nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
   // component labels (smallest transcript id of the component): min-label propagation + pointer jumping
@@ -3485,8 +3492,60 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   *dev = EmLocalDev{(const u32*)(pb + p_rb), (const u32*)(pb + p_tb), (const u64*)(pb + p_zb), (const u32*)(pb + p_rp), (const u32*)(pb + p_cp),
                     (const uint16_t*)(pb + p_rt), (const uint16_t*)(pb + p_cr), (const u64*)(pb + p_cw), (const double*)(pb + p_sg),
                     (const double*)(pb + p_ef), (const u32*)(pb + p_id)};
+  if (args_out) *args_out = A;
   return 0;
 }
+// ---- what a second EM on the same matrix re-uses (bootstrap replicates: only the counts change, EMAlgorithm.h:46) ---------------
+// row_final[e]: position of EC e's count word in the plan (multi-transcript rows), SELL_NONE otherwise; mslot[t]: slot of
+// transcript t in the plan's transcript vectors, SELL_NONE if it is in no multi-transcript row
+constexpr u32 SELL_NONE = 0xFFFFFFFFu;
+__global__ void k_sell_maps(kamd_em_local::BuildArgs A, SellBuild B, u32* row_final, u32* mslot) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < A.n_ecs) {
+    const u64 a = A.ec_off[i], b = A.ec_off[i + 1];
+    u32 rf = SELL_NONE;
+    if (b - a >= 2) {
+      const u32 rn = A.row_new[i];
+      const u32 g = sell_group_of(B.row_base, B.n_groups, rn);
+      rf = B.row_base[g] + B.rnew[rn];
+    }
+    row_final[i] = rf;
+  }
+  if (i < A.T) {
+    u32 ms = SELL_NONE;
+    if (A.in_multi[i]) {
+      const u32 g = kamd_em_local::eml_group_of(A, A.label[i]);
+      const u32 old_m = B.tr_base[g] + A.local_of[i];
+      ms = B.tr_base[g] + B.cnew[old_m];
+    }
+    mslot[i] = ms;
+  }
+}
+// new counts / effective lengths into a cached plan
+__global__ void k_sell_refresh(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts,
+                               const u32* __restrict__ wcounts, u64 n_ecs, const double* __restrict__ eff, u64 T,
+                               const u32* __restrict__ row_final, const u32* __restrict__ mslot, u64* cw, double* single_m,
+                               double* eff_m, double* single_all) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_ecs) {
+    const u64 a = ec_off[i], b = ec_off[i + 1];
+    if (b - a == 1) {   // a transcript has at most one singleton set (:119-123)
+      const u32 t = ec_ids[a];
+      single_all[t] = (double)counts[i];
+      if (mslot[t] != SELL_NONE) single_m[mslot[t]] = (double)counts[i];
+    } else if (b - a >= 2) cw[row_final[i]] = (u64)counts[i] | ((u64)wcounts[i] << 32);
+  }
+  if (i < T && mslot[i] != SELL_NONE) eff_m[mslot[i]] = eff[i];
+}
+struct SellCache {
+  bool valid = false;
+  const u64* d_ec_off = nullptr; const u32* d_ec_ids = nullptr; u64 n_ecs = 0, nnz = 0, T = 0, generation = 0;
+  int split_len = 0, group_div = 0;
+  kamd_em_sell::Plan P;      // host part (tr_id, single_all, bases)
+  EmSellDev dev{};           // device part, in ctx->ems_plan
+  u32* row_final = nullptr; u32* mslot = nullptr; double* single_all = nullptr; double* d_eff = nullptr;   // in ctx->ems_maps
+};
+
 // ---- the sliced-ELLPACK form: device plan + backend of kamd_em_local::run --------------------------------------------------
 struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0; int block = 256;
@@ -3534,11 +3593,12 @@ int EmSellGpu::setup(int chunk, const double* d_eff_new) {
 }
 // 0 = plan built (P: the host part; *dev: the device part), 1 = not applicable, < 0 = error
 int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                         const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev) {
+                         const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev, SellCache* cache) {
   namespace S = kamd_em_sell;
   kamd_em_local::Plan C;
   EmLocalDev cd{};
-  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd)) return rc;
+  kamd_em_local::BuildArgs A{};
+  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A)) return rc;
   const u32 ng = C.n_groups;
   const u64 R = C.row_base[ng], M = C.tr_base[ng];
   if (R >= 0xFFFFFFF0ULL || M >= 0xFFFFFFF0ULL) return 1;
@@ -3593,32 +3653,67 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   HIPC(hipGetLastError());
   P->tr_id.resize(M);
   if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), B.tr_id_new, M * 4, hipMemcpyDeviceToHost, c->stream));
+  // the group bases live in the CSR plan's arena (pm_a), which other EM forms reuse: copy them next to the plan
+  Carver bv;
+  const size_t b_rb = bv.take((ng + 1) * 4), b_tb = bv.take((ng + 1) * 4), b_rf = bv.take(n_ecs * 4 + 8), b_ms = bv.take(T * 4 + 8), b_sa = bv.take(T * 8 + 8),
+               b_ef = bv.take(T * 8 + 8);
+  if (int rc = c->ems_maps.ensure(bv.off, 0, c->stream)) return rc;
+  char* mb = (char*)c->ems_maps.p;
+  HIPC(hipMemcpyAsync(mb + b_rb, cd.row_base, (ng + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPC(hipMemcpyAsync(mb + b_tb, cd.tr_base, (ng + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_sell_maps, dim3(grid_for(std::max<u64>(n_ecs, T), BLOCK)), dim3(BLOCK), 0, c->stream, A, B, (u32*)(mb + b_rf), (u32*)(mb + b_ms));
+  HIPC(hipMemcpyAsync(mb + b_sa, A.single_all, T * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(c->stream));
-  *dev = EmSellDev{cd.row_base, cd.tr_base, B.rslice_base, B.cslice_base, B.rell_base, B.cell_base, B.rdesc, B.cdesc, B.rell, B.cell,
+  *dev = EmSellDev{(const u32*)(mb + b_rb), (const u32*)(mb + b_tb), B.rslice_base, B.cslice_base, B.rell_base, B.cell_base, B.rdesc, B.cdesc, B.rell, B.cell,
                    B.cw_new, B.single_new, B.eff_new};
+  if (cache) { cache->row_final = (u32*)(mb + b_rf); cache->mslot = (u32*)(mb + b_ms); cache->single_all = (double*)(mb + b_sa); cache->d_eff = (double*)(mb + b_ef); }
   return 0;
 }
+void sell_cache_free(SellCache* k) { delete k; }
 int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
                        const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds) {
   if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
-  kamd_em_sell::Plan P;
-  EmSellDev dev{};
+  if (!c->sell_cache) c->sell_cache = new SellCache;
+  SellCache& K = *c->sell_cache;
   HIPC(hipEventRecord(c->ev0, c->stream));
-  // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not, the
-  // cut is halved, and a single component beyond the CU's 160 KB makes the form not applicable)
-  const u64 lds_budget = 160 * 1024 - 2048;
-  int prc = 1;
-  for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc == 1; div *= 2) {
-    const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
-    prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &P, &dev);
-    if (target == 1024) break;
+  // the plan of the context's own finalized matrix is kept: a bootstrap replicate (same matrix, other counts) only refreshes
+  // the count words, the singleton counts and the effective lengths
+  const bool own = c->finalized && d_ec_off == (const u64*)c->result.d_ec_off && d_ec_ids == c->result.d_ec_ids;
+  const bool hit = own && K.valid && K.d_ec_off == d_ec_off && K.d_ec_ids == d_ec_ids && K.n_ecs == n_ecs && K.nnz == nnz && K.T == T &&
+                   K.generation == c->ec_generation && K.split_len == c->tune.em_split_len && K.group_div == c->tune.em_group_div;
+  if (hit) {
+    HIPC(hipMemcpyAsync(K.d_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemsetAsync(K.single_all, 0, T * 8, c->stream));
+    hipLaunchKernelGGL(k_sell_refresh, dim3(grid_for(std::max<u64>(n_ecs, T), BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, d_counts, d_wcounts,
+                       n_ecs, K.d_eff, T, K.row_final, K.mslot, const_cast<u64*>(K.dev.cw), const_cast<double*>(K.dev.single), const_cast<double*>(K.dev.eff),
+                       K.single_all);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(K.P.single_all.data(), K.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  } else {
+    K.valid = false;
+    // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not, the
+    // cut is halved, and a single component beyond the CU's 160 KB makes the form not applicable)
+    const u64 lds_budget = 160 * 1024 - 2048;
+    int prc = 1;
+    for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc == 1; div *= 2) {
+      const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
+      prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K);
+      if (target == 1024) break;
+    }
+    if (prc) return prc;
+    if (K.P.n_groups == 0) return 1;
+    if (own) {
+      K.valid = true; K.d_ec_off = d_ec_off; K.d_ec_ids = d_ec_ids; K.n_ecs = n_ecs; K.nnz = nnz; K.T = T; K.generation = c->ec_generation;
+      K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div;
+    }
   }
-  if (prc) return prc;
-  if (P.n_groups == 0) return 1;
+  const kamd_em_sell::Plan& P = K.P;
   const int chunk = EML_MAX_ROUNDS;
   EmSellGpu B(c, P);
-  B.dev = dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block;
-  if (int rc = B.setup(chunk, dev.eff)) return rc;
+  B.dev = K.dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block;
+  if (int rc = B.setup(chunk, K.dev.eff)) return rc;
   const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
   HIPC(hipEventRecord(c->ev1, c->stream));
@@ -3627,6 +3722,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   c->last_em_iters = (uint64_t)r + (r < n_iter ? 1 : 0);
   c->last_em_nnz = nnz; c->last_em_k = -2; c->last_em_grid = P.n_groups; c->last_em_necs = n_ecs;
   c->last_em_lds = (uint32_t)P.max_group_bytes;
+  c->last_em_plan_cached = hit ? 1 : 0;
   if (rounds) *rounds = r;
   return 0;
 }
@@ -4016,7 +4112,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
   p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
   p->last_em_nnz = c->last_em_nnz; p->last_em_nnz_multi = c->last_em_nnz_multi; p->last_em_nseg = c->last_em_nseg; p->last_em_necs = c->last_em_necs;
-  p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid; p->last_em_lds = c->last_em_lds;
+  p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid; p->last_em_lds = c->last_em_lds; p->last_em_plan_cached = c->last_em_plan_cached;
   return 0;
 }
 
@@ -4027,9 +4123,12 @@ __host__ __device__ inline u64 lcg_pow(u64 e) { u64 r = 1, b = LCG_A; while (e) 
 constexpr int DRAWS_PER_THREAD = 64;
 // Draw i consumes engine outputs 2i+1 and 2i+2 (generate_canonical<double,53> makes two calls), so a thread can start
 // anywhere by LCG skip-ahead: the sample is identical to the reference's N sequential draws.
-__global__ void k_multinomial(const double* __restrict__ cp, u64 n, u64 n_draws, u64 x0, double r2, u32* samp) {
+// (blockIdx.y = replicate: x0s[b] is its seed, its sample goes to samp + b * n)
+__global__ void k_multinomial(const double* __restrict__ cp, u64 n, u64 n_draws, const u64* __restrict__ x0s, double r2, u32* samp_all) {
   const u64 first = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * DRAWS_PER_THREAD;
   if (first >= n_draws) return;
+  const u64 x0 = x0s[blockIdx.y];
+  u32* samp = samp_all + (u64)blockIdx.y * n;
   u64 x = x0 * lcg_pow(2 * first) % LCG_M;
   const u64 last = min(n_draws, first + DRAWS_PER_THREAD);
   for (u64 d = first; d < last; d++) {
@@ -4047,16 +4146,9 @@ __global__ void k_multinomial(const double* __restrict__ cp, u64 n, u64 n_draws,
 }
 }  // namespace
 
-extern "C" int kamd_bootstrap(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
-                              uint64_t n_ecs, uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha,
-                              int32_t* rounds, uint32_t* sample_out) {
-  if (!c || !eff_lens || !alpha) return kamd::fail(-1, "kamd_bootstrap: null argument");
-  HIPC(hipSetDevice(c->device));
-  if (!d_ec_off) {
-    if (!c->finalized) return kamd::fail(-1, "kamd_bootstrap: no EC result (call kamd_ec_finalize or pass a CSR)");
-    d_ec_off = c->result.d_ec_off; d_ec_ids = c->result.d_ec_ids; d_counts = c->result.d_counts; n_ecs = c->result.n_ecs;
-  }
-  if (n_ecs == 0) return kamd::fail(-1, "kamd_bootstrap: no equivalence classes");
+namespace {
+// Multinomial(counts, seed_b).sample() for replicates b = 0..n_rep-1 in ONE launch: samples at bs_samp + b * n_ecs
+int resample_all(kamd_ctx* c, const uint32_t* d_counts, u64 n_ecs, const uint64_t* seeds, int n_rep) {
   // discrete_distribution<int>(counts): p = counts / sum, cp = partial_sum(p) (sequential FP64 adds), cp.back() = 1
   std::vector<u32> counts(n_ecs);
   HIPC(hipMemcpyAsync(counts.data(), d_counts, n_ecs * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -4069,22 +4161,41 @@ extern "C" int kamd_bootstrap(kamd_ctx* c, const uint64_t* d_ec_off, const uint3
   double acc = 0.0;
   for (u64 i = 0; i < n_ecs; i++) { acc += (double)counts[i] / sum; cp[i] = acc; }
   cp[n_ecs - 1] = 1.0;
-  if (int rc = c->bs_cp.ensure(n_ecs * sizeof(double), 0, c->stream)) return rc;
-  if (int rc = c->bs_samp.ensure(n_ecs * sizeof(u32), 0, c->stream)) return rc;
+  std::vector<u64> x0s((size_t)n_rep);
+  for (int b = 0; b < n_rep; b++) { u64 x0 = seeds[b] % LCG_M; if (x0 == 0) x0 = 1; x0s[b] = x0; }   // linear_congruential_engine::seed
+  if (int rc = c->bs_cp.ensure(n_ecs * sizeof(double) + (size_t)n_rep * sizeof(u64) + 64, 0, c->stream)) return rc;
+  if (int rc = c->bs_samp.ensure((size_t)n_rep * n_ecs * sizeof(u32), 0, c->stream)) return rc;
+  u64* d_x0 = (u64*)((char*)c->bs_cp.p + ((n_ecs * sizeof(double) + 15) & ~(size_t)15));
   HIPC(hipMemcpyAsync(c->bs_cp.p, cp.data(), n_ecs * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPC(hipMemsetAsync(c->bs_samp.p, 0, n_ecs * sizeof(u32), c->stream));
+  HIPC(hipMemcpyAsync(d_x0, x0s.data(), (size_t)n_rep * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemsetAsync(c->bs_samp.p, 0, (size_t)n_rep * n_ecs * sizeof(u32), c->stream));
   if (n_ecs < 2) {  // _M_cp is empty: every draw returns 0
-    const u32 all = (u32)nsamp;
-    HIPC(hipMemcpyAsync(c->bs_samp.p, &all, sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    std::vector<u32> all((size_t)n_rep, (u32)nsamp);
+    HIPC(hipMemcpyAsync(c->bs_samp.p, all.data(), (size_t)n_rep * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
   } else {
-    u64 x0 = seed % LCG_M; if (x0 == 0) x0 = 1;                 // linear_congruential_engine::seed
     const double r2 = (double)(2147483646.0L * 2147483646.0L);  // __tmp after two `__tmp *= __r` (long double) steps
     const u64 threads = ((u64)nsamp + DRAWS_PER_THREAD - 1) / DRAWS_PER_THREAD;
-    hipLaunchKernelGGL(k_multinomial, dim3(grid_for(threads, BLOCK)), dim3(BLOCK), 0, c->stream, c->bs_cp.as<double>(), (u64)n_ecs,
-                       (u64)nsamp, x0, r2, c->bs_samp.as<u32>());
+    hipLaunchKernelGGL(k_multinomial, dim3(grid_for(threads, BLOCK), (unsigned)n_rep), dim3(BLOCK), 0, c->stream, c->bs_cp.as<double>(), (u64)n_ecs,
+                       (u64)nsamp, (const u64*)d_x0, r2, c->bs_samp.as<u32>());
     HIPC(hipGetLastError());
   }
-  HIPC(hipStreamSynchronize(c->stream));  // cp is a host staging buffer
+  HIPC(hipStreamSynchronize(c->stream));  // cp / x0s are host staging buffers
+  return 0;
+}
+}  // namespace
+
+extern "C" int kamd_bootstrap(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
+                              uint64_t n_ecs, uint64_t seed, const double* eff_lens, uint64_t n_targets, double* alpha,
+                              int32_t* rounds, uint32_t* sample_out) {
+  if (!c || !eff_lens || !alpha) return kamd::fail(-1, "kamd_bootstrap: null argument");
+  HIPC(hipSetDevice(c->device));
+  if (!d_ec_off) {
+    if (!c->finalized) return kamd::fail(-1, "kamd_bootstrap: no EC result (call kamd_ec_finalize or pass a CSR)");
+    d_ec_off = c->result.d_ec_off; d_ec_ids = c->result.d_ec_ids; d_counts = c->result.d_counts; n_ecs = c->result.n_ecs;
+  }
+  if (n_ecs == 0) return kamd::fail(-1, "kamd_bootstrap: no equivalence classes");
+  if (int rc = resample_all(c, d_counts, n_ecs, &seed, 1)) return rc;
   if (sample_out) {
     HIPC(hipMemcpyAsync(sample_out, c->bs_samp.p, n_ecs * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
@@ -4092,6 +4203,27 @@ extern "C" int kamd_bootstrap(kamd_ctx* c, const uint64_t* d_ec_off, const uint3
   // fresh EMAlgorithm on the resampled counts; the weights still come from the original counts (EMAlgorithm.h:46);
   // run(10000, 50, false, false)
   return kamd_em_run(c, d_ec_off, d_ec_ids, c->bs_samp.as<u32>(), d_counts, n_ecs, eff_lens, n_targets, 10000, 50, alpha, nullptr, rounds);
+}
+
+// n_rep replicates of Bootstrap::run_em on the finalized EC result: every replicate's multinomial sample is drawn in one launch,
+// the EMs run one after the other on the plan of the matrix (component-local form: built once -- by this call if need be --
+// and only refreshed with each replicate's counts).  alpha: n_rep x n_targets, row b = replicate b.
+extern "C" int kamd_bootstrap_batch(kamd_ctx* c, const uint64_t* seeds, int32_t n_rep, const double* eff_lens, uint64_t n_targets,
+                                    double* alpha, int32_t* rounds) {
+  if (!c || !seeds || !eff_lens || !alpha || n_rep < 0) return kamd::fail(-1, "kamd_bootstrap_batch: bad argument");
+  if (!c->finalized) return kamd::fail(-1, "kamd_bootstrap_batch: no EC result (call kamd_ec_finalize first)");
+  if (n_rep == 0) return 0;
+  HIPC(hipSetDevice(c->device));
+  const u64 n_ecs = c->result.n_ecs;
+  if (n_ecs == 0) return kamd::fail(-1, "kamd_bootstrap_batch: no equivalence classes");
+  if (int rc = resample_all(c, c->result.d_counts, n_ecs, seeds, n_rep)) return rc;
+  for (int b = 0; b < n_rep; b++) {
+    int32_t r = 0;
+    if (int rc = kamd_em_run(c, c->result.d_ec_off, c->result.d_ec_ids, c->bs_samp.as<u32>() + (u64)b * n_ecs, c->result.d_counts, n_ecs, eff_lens,
+                             n_targets, 10000, 50, alpha + (u64)b * n_targets, nullptr, &r)) return rc;
+    if (rounds) rounds[b] = r;
+  }
+  return 0;
 }
 
 // ======================================================================================================================

@@ -535,13 +535,18 @@ int main(int argc, char** argv) {
   if (opt.bootstrap > 0 && num_pseudoaligned > 0) {  // src/main.cpp:2744-2782
     std::vector<uint64_t> seeds(opt.bootstrap);
     kamd_bootstrap_seeds(opt.seed, opt.bootstrap, seeds.data());
-    std::vector<double> a(v.n_targets);
-    for (int b = 0; b < opt.bootstrap; b++) {
-      std::cerr << "[bstrp] running EM for the bootstrap: " << b + 1 << "\r";
-      int32_t r = 0;
-      KX(kamd_bootstrap(ctx, nullptr, nullptr, nullptr, 0, seeds[b], eff.data(), v.n_targets, a.data(), &r, nullptr));
-      if (use_h5) h5.doubles(h5.bs(), ("bs" + std::to_string(b)).c_str(), a);   // H5Writer::write_bootstrap
-      else write_abundance(opt.output + "/bs_abundance_" + std::to_string(b) + ".tsv", idx, v, a, eff);
+    // replicates in batches: one launch draws the batch's multinomial samples, the EMs reuse the plan of the EC matrix
+    const int batch = 32;
+    std::vector<double> ab((size_t)batch * v.n_targets), a(v.n_targets);
+    for (int b0 = 0; b0 < opt.bootstrap; b0 += batch) {
+      const int nb = std::min(batch, opt.bootstrap - b0);
+      std::cerr << "[bstrp] running EM for the bootstrap: " << b0 + nb << "\r";
+      KX(kamd_bootstrap_batch(ctx, seeds.data() + b0, nb, eff.data(), v.n_targets, ab.data(), nullptr));
+      for (int b = b0; b < b0 + nb; b++) {
+        a.assign(ab.begin() + (size_t)(b - b0) * v.n_targets, ab.begin() + (size_t)(b - b0 + 1) * v.n_targets);
+        if (use_h5) h5.doubles(h5.bs(), ("bs" + std::to_string(b)).c_str(), a);   // H5Writer::write_bootstrap
+        else write_abundance(opt.output + "/bs_abundance_" + std::to_string(b) + ".tsv", idx, v, a, eff);
+      }
     }
     std::cerr << std::endl;
   }

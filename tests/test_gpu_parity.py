@@ -281,6 +281,35 @@ def test_bootstrap_on_finalized_result(ka, ctxs):
     common.assert_abundance_close(alpha, a_o, "bootstrap alpha")
 
 
+def test_bootstrap_batch_reuses_the_plan(ka, ctxs):
+    """kamd_bootstrap_batch: all samples from one launch, the EMs on the cached plan of the EC matrix (only counts refreshed);
+    every replicate must equal the one-at-a-time path and the oracle's EM on the same sample."""
+    from oracle import oracle as O
+    import kallisto_amd.api as A
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    exp = common.load_expected("human_pe", "pe")
+    index, ctx = ctxs("human_pe")
+    words, lens, max_len = ctx.pack_reads_host(common.interleave(r1, r2), 100)
+    ctx.reset()
+    ctx.pseudoalign(ka.QuantOpts(1, 0.0, 0.0, 0, 0), words, lens, len(r1), max_len)
+    ecs = ctx.finalize()
+    a0, _, r0 = ctx.em_run(exp["eff"])                       # builds the plan
+    seeds = A.bootstrap_seeds(42, 5)
+    alphas, rounds = ctx.bootstrap_batch(seeds, exp["eff"])
+    assert ctx.profile()["em_plan_cached"] == 1              # the replicates did not rebuild it
+    for b in range(5):
+        samp = O.multinomial_sample(ecs.counts, int(seeds[b]))
+        a_o, _, r_o = O.em_run(ecs.ec_off, ecs.ec_ids, samp, exp["eff"], index.num_targets, weight_counts=ecs.counts)
+        assert rounds[b] == r_o
+        common.assert_abundance_close(alphas[b], a_o, f"bootstrap {b} (batch)")
+        a1, r1_ = ctx.bootstrap(int(seeds[b]), exp["eff"])
+        assert r1_ == r_o
+        common.assert_abundance_close(a1, alphas[b], f"bootstrap {b} one at a time vs batch", rel=1e-12)
+    a2, _, r2_ = ctx.em_run(exp["eff"])                      # and the original counts again, through the refresh path
+    assert r2_ == r0
+    common.assert_abundance_close(a2, a0, "EM after the replicates", rel=1e-12)
+
+
 def test_degenerate_batches(ka, ctxs):
     """Empty batch, a single pair, and a batch in which nothing pseudoaligns (all N / shorter than k)."""
     meta, idx_path, r1, r2 = common.load_case("human_pe")
