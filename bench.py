@@ -6,16 +6,24 @@ human-transcriptome-sized index (BASELINE.json configs[2]; configs[3] is the sam
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One *step* = one full `kallisto quant` pass over this rank's batch of synthetic read pairs already resident in HBM in
-the 2-bit packed layout: k-mer pseudoalignment (kernel A) -> EC counts -> [N>1: RCCL all-reduce of the dense EC count
-vector + all-gather of the tuple records] -> EC resolution/merge -> fragment-length sample -> EM (kernel B) -> TPM.
-Scaling is weak: every rank processes its own `--pairs` read pairs (different seeds), so the job is N x pairs per step.
+the 2-bit packed layout: k-mer pseudoalignment (kernel A) -> EC counts -> [N>1, inside the library over RCCL: all-reduce of
+the dense EC count vector + all-gathers of the tuple records] -> EC resolution/merge -> fragment-length sample -> EM
+(kernel B; N>1: partitioned over the ranks by connected component) -> TPM.
+Scaling: weak by default (every rank processes its own `--pairs` read pairs, different seeds); `--scaling strong` shards
+`--pairs` over the ranks (BASELINE config #4).  With N > 1 the other mode is measured in the same run and reported as
+`other_scaling`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel by time, one EM round (k_pm_rows_pass + k_pm_cols_pass): SURVEY.md 8(d)'s algorithmic bytes of
-                  an EM iteration / the round's HIP-event duration vs the 8 TB/s HBM peak; roofline_kernel_a: the same for k_match_v2
-  cpu_baseline -- the unmodified reference (oracle/_ref/kallisto quant, built from /root/reference) on this box's host
-                  cores over a bounded sample of the same reads, same index file; plus a parity check of the GPU path
-                  against that run on the same sample.
+  roofline           -- the dominant kernel by time, kernel A (k_match_v3): SURVEY.md 8(d)'s algorithmic bytes of the launch / its
+                        HIP-event duration vs the 8 TB/s HBM peak; roofline_em: one EM round (LDS-resident: against the LDS pipe,
+                        with the HBM-equivalent figure next to it); roofline_finalize: the EC resolution kernels
+  cpu_baseline       -- the unmodified reference (oracle/_ref/kallisto quant, built from /root/reference) on this box's host
+                        cores over a bounded sample of the same reads, same index file, split into pseudoalignment and EM seconds
+  parity_check       -- the GPU path against the unmodified reference run deterministically (-t 1, oracle/_ref/dump_ec) on a
+                        prefix of the same reads: EC multiset, flens, eff_length identical, est_counts / TPM <= 1e-4; `ok` gates on all
+  end_to_end         -- (--end-to-end P) the C++ front-end from FASTQ files, plain and gzip, index load stated separately
+  bootstrap          -- (--bootstraps B) BASELINE config #5: B replicates of multinomial resample + EM
+`--workload yeast` is BASELINE config #2 (10 M single-end reads, ~6 k transcripts).
 """
 from __future__ import annotations
 
@@ -159,20 +167,76 @@ def reference_parity(idx_path, r1: np.ndarray, r2: np.ndarray, res):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra):
+    """The C++ front-end (kallisto_amd/kallisto_amd_quant) from FASTQ files on disk: plain text and gzip.  Wall-clock per stage
+    from its --verbose timing lines; never part of `value`."""
+    exe = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
+    if not os.path.exists(exe):
+        return {"error": "kallisto_amd_quant not built"}
+    import gzip
+    tmp = os.path.join(CACHE, f"e2e_{os.getpid()}")
+    os.makedirs(tmp, exist_ok=True)
+    out = {}
+    try:
+        n = int(r1.shape[0])
+        f1, f2 = os.path.join(tmp, "e_1.fq"), os.path.join(tmp, "e_2.fq")
+        write_fastq_fast(f1, r1)
+        if paired:
+            write_fastq_fast(f2, r2)
+        ngz = min(n, 1_000_000)
+        g1, g2 = os.path.join(tmp, "g_1.fq.gz"), os.path.join(tmp, "g_2.fq.gz")
+        for src, dst in ((f1, g1), (f2, g2)) if paired else ((f1, g1),):
+            per = os.path.getsize(src) // n
+            with open(src, "rb") as fi, gzip.open(dst, "wb", compresslevel=1) as fo:
+                fo.write(fi.read(per * ngz))
+        for kind, files, cnt in (("plain", [f1, f2] if paired else [f1], n), ("gzip", [g1, g2] if paired else [g1], ngz)):
+            cmd = [exe, "quant", "-i", idx_path, "-o", os.path.join(tmp, "out_" + kind), "-t", str(threads), "--plaintext", "--verbose", *extra, *files]
+            t0 = time.time()
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            wall = time.time() - t0
+            if p.returncode != 0:
+                out[kind] = {"error": p.stderr.decode(errors="replace")[-300:]}
+                continue
+            tm = {}
+            for line in p.stderr.decode(errors="replace").splitlines():
+                if line.startswith("[timing] index file read"):
+                    w = line.split()
+                    tm["index_load_s"] = float(w[7]); tm["index_on_device_s"] = float(w[-2])
+                elif line.startswith("[timing] reads parsed"):
+                    tm["reads_done_s"] = float(line.split()[-2])
+                elif line.startswith("[timing] total"):
+                    tm["total_s"] = float(line.split()[-2])
+            reads_s = tm.get("reads_done_s", wall) - tm.get("index_on_device_s", 0.0)
+            out[kind] = {"pairs" if paired else "reads": cnt, "wall_s": round(wall, 2), **{k: round(v, 3) for k, v in tm.items()},
+                         "input_to_ecs_M_per_s": round(cnt / max(reads_s, 1e-9) / 1e6, 3),
+                         "whole_run_M_per_s": round(cnt / wall / 1e6, 3), "host_threads": threads}
+        out["note"] = ("kallisto_amd_quant from FASTQ on local disk (plain: mmap + all host threads; gzip: one inflate thread per file); "
+                       "input_to_ecs = parsing + packing + H2D + pseudoalignment (index load excluded), whole_run = process start to exit")
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=30_000_000, help="read pairs per GPU per step (BASELINE config #3: 30 M)")
-    ap.add_argument("--workload", default="human", choices=["human", "yeast"])
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs (reads) per GPU per step; default: BASELINE config #3: 30 M "
+                    "(human), config #2: 10 M single-end reads (yeast)")
+    ap.add_argument("--workload", default="human", choices=["human", "yeast"],
+                    help="human = BASELINE configs #3/#4/#5 (paired-end); yeast = config #2 (single-end, -l 200 -s 20)")
     ap.add_argument("--genes", type=int, default=None, help="scale of the synthetic transcriptome (default: full config)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --pairs per GPU (default); strong = --pairs in total, sharded over the GPUs (BASELINE config #4). "
+                         "The other mode is measured too and reported in the same line.")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs given to the CPU reference (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=200_000,
                     help="pairs of the CPU sample that also go through the reference at -t 1 for the parity gate")
     ap.add_argument("--bootstraps", type=int, default=0,
                     help="BASELINE config #5: also time B bootstrap replicates (multinomial resample + EM), split over the ranks")
+    ap.add_argument("--end-to-end", type=int, default=0, help="also run the C++ front-end from FASTQ files with this many pairs (N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -199,7 +263,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    paired = args.workload == "human"
     genes = args.genes or (20000 if args.workload == "human" else 6000)
+    n_default = 30_000_000 if paired else 10_000_000
+    n_arg = args.pairs or n_default
+    # weak: n_arg per GPU; strong: n_arg in total.  Each rank generates max(weak, strong) share once and both modes run on prefixes.
+    n_weak, n_strong = n_arg, max(n_arg // world, 1)
+    n = n_weak if args.scaling == "weak" else n_strong
+    n_gen = max(n_weak, n_strong) if world > 1 else n_arg
     cat, tlens, idx_path = prepare_workload(args.workload, genes, is_builder=(rank == 0))
     t0 = time.time()
     index = ka.Index(idx_path)
@@ -211,32 +282,35 @@ def main():
     # ---- this rank's reads, generated on the device and packed into the 2-bit layout (resident in HBM) ----
     L = 100
     sim = ReadSimulator(cat, tlens, dev, seed=1000 + rank, read_len=L)
-    n = args.pairs
     rec = ka.packed_record_words(L)
-    words = torch.empty(n * 2 * rec, dtype=torch.int32, device=dev)
-    lens = torch.empty(n * 2, dtype=torch.int16, device=dev)
+    per = 2 if paired else 1
+    words = torch.empty(n_gen * per * rec, dtype=torch.int32, device=dev)
+    lens = torch.empty(n_gen * per, dtype=torch.int16, device=dev)
     chunk = 2_000_000
     sample = None
+    e2e_sample = None
     t0 = time.time()
-    for s in range(0, n, chunk):
-        m = min(chunk, n - s)
+    for s in range(0, n_gen, chunk):
+        m = min(chunk, n_gen - s)
         r1, r2 = sim.draw(m)
-        inter = torch.stack([r1, r2], 1).reshape(2 * m, L)  # mate 1, mate 2 interleaved (ProcessReads.cpp:1034-1041)
+        inter = torch.stack([r1, r2], 1).reshape(2 * m, L) if paired else r1  # mate 1, mate 2 interleaved (ProcessReads.cpp:1034-1041)
         w, l = ctx.pack_reads(inter, L)
-        words[s * 2 * rec:(s + m) * 2 * rec] = w
-        lens[2 * s:2 * (s + m)] = l
-        if s == 0 and rank == 0 and args.cpu_sample and not args.no_cpu_baseline:
-            k = min(args.cpu_sample, m)
-            sample = (r1[:k].cpu().numpy(), r2[:k].cpu().numpy())
+        words[s * per * rec:(s + m) * per * rec] = w
+        lens[per * s:per * (s + m)] = l
+        if s == 0 and rank == 0 and world == 1:
+            if args.cpu_sample and not args.no_cpu_baseline:
+                k = min(args.cpu_sample, m)
+                sample = (r1[:k].cpu().numpy(), r2[:k].cpu().numpy())
+            if args.end_to_end:
+                k = min(args.end_to_end, m)
+                e2e_sample = (r1[:k].cpu().numpy(), r2[:k].cpu().numpy())
         del r1, r2, inter, w, l
     torch.cuda.synchronize()
-    log(f"{n} synthetic PE-{L} pairs generated + packed on the device in {time.time()-t0:.1f}s ({words.numel()*4/1e9:.2f} GB in HBM)")
+    log(f"{n_gen} synthetic {'PE' if paired else 'SE'}-{L} {'pairs' if paired else 'reads'} generated + packed on the device in "
+        f"{time.time()-t0:.1f}s ({words.numel()*4/1e9:.2f} GB in HBM)")
 
-    opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
-
-    def step():
-        ctx.reset()
-        return ka.quant(ctx, opts, [(words, lens, n, L)], download_ecs=False)
+    opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0) if paired else ka.QuantOpts(0, 200.0, 20.0, 0, 0)
+    cli_extra = [] if paired else ["--single", "-l", "200", "-s", "20"]
 
     def fence():
         torch.cuda.synchronize()
@@ -244,27 +318,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    fence()
-    t0 = time.perf_counter()
-    align_ms, em_ms, em_iters, cls_ms = [], [], [], []
-    for _ in range(args.steps):
-        res = step()
-        pr = ctx.profile()
-        align_ms.append(pr["align_kernel_ms"]); em_ms.append(pr["em_ms"]); em_iters.append(pr["em_iters"]); cls_ms.append(pr["classify_ms"])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_items):
+        """W untimed + K timed steps on the first n_items items of this rank; returns (seconds max over ranks, last result, per-step profiles)"""
+        def step():
+            ctx.reset()
+            return ka.quant(ctx, opts, [(words[:n_items * per * rec], lens[:per * n_items], n_items, L)], download_ecs=False)
+        for _ in range(args.warmup):
+            res = step()
+        fence()
+        t0 = time.perf_counter()
+        profs = []
+        for _ in range(args.steps):
+            res = step()
+            profs.append(ctx.profile())
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res, profs
+
+    elapsed, res, profs = timed(n)
+    pr = profs[-1]
+    align_ms = [p["align_kernel_ms"] for p in profs]; em_ms = [p["em_ms"] for p in profs]
+    cls_ms = [p["classify_ms"] for p in profs]; fin_ms = [p["finalize_ms"] for p in profs]
+    em_iters = [p["em_iters"] for p in profs]
     st = res.stats
-    total_pairs = n * world * args.steps
+    total_items = n * world * args.steps
+    other = None
+    if world > 1:   # the other scaling mode, same run
+        n_o = n_strong if args.scaling == "weak" else n_weak
+        el_o, _, _ = timed(n_o)
+        other = {"scaling": "strong" if args.scaling == "weak" else "weak", "pairs_per_gpu": n_o, "pairs_total_per_step": n_o * world,
+                 "value": round(n_o * world * args.steps / el_o / 1e6, 4), "unit": "M read pairs/s", "ms_per_step": round(el_o / args.steps * 1e3, 3),
+                 "note": "BASELINE config #4 is the strong case: the same 30 M pairs sharded over the GPUs; the EC merge (one all-reduce + "
+                         "all-gathers) and the EM (partitioned by connected component, stop rule summed over the ranks) do not shrink with "
+                         "1/N, so strong scaling is bounded by them" }
     # ---- BASELINE config #5 (optional): B bootstrap replicates of the last step's ECs, replicate b on rank b % world ----
     boot = None
     if args.bootstraps > 0:
         import kallisto_amd.api as A
+        ctx.reset()
+        res = ka.quant(ctx, opts, [(words[:n * per * rec], lens[:per * n], n, L)], download_ecs=False)
         seeds = A.bootstrap_seeds(42, args.bootstraps)
         mine = [b for b in range(args.bootstraps) if b % world == rank]
         fence()
@@ -287,85 +383,110 @@ def main():
 
     out = None
     if rank == 0:
-        # roofline of kernel A: algorithmic bytes of ONE launch: packed reads in + 16 B (key+payload)
-        # per k-mer probe + what the launch writes (4 B per single-set count, the tuple record and its 8-byte offset)
-        # (the counters are reset every step, so `st` describes exactly one launch)
-        rec_bytes = 2 * rec * 4 + 2 * 2
-        if pr["kernel_a_version"] == 2:   # k_match_v2 writes one raw record per item: header + distinct (unitig,set) classes
-            alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_raw_words"]
-        else:
-            alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_single"] + 4 * st["n_stream_words"] + 8 * st["n_multi"]
+        # roofline of kernel A (the dominant kernel by time): ALGORITHMIC bytes of ONE launch (DESIGN.md
+        # section 3): packed reads in + 16 B (key + payload) per k-mer probe (dbg.find call of the reference) + the raw record out
+        rec_bytes = per * rec * 4 + per * 2
+        alg_bytes = n * rec_bytes + 16 * st["n_probes"] + 4 * st["n_raw_words"]
         a_ms = float(np.mean(align_ms))
         achieved = alg_bytes / (a_ms * 1e-3) / 1e9
-        # EM round = the two launches k_pm_rows_pass + k_pm_cols_pass (streamed form; CSR form: k_em_rows + k_em_seg + k_em_final).
-        # `achieved` uses SURVEY.md section 8(d)'s ALGORITHMIC bytes of one EM iteration, independent of the layout:
-        #   B_B = nnz*(4 id + 8 alpha gather + 8 next accumulate) + N_ec*(4 count + 8 offsets) + T*(8 alpha + 8 next + 8 eff_len)
-        # `layout_bytes_per_round` is what the streamed layout actually has to move per round:
-        #   2 passes * nnz_multi*(4 index + 8 gather) + rows*(8 count word + 8 g) + transcripts*(4 reads + 3 writes)*8
         T = int(index.num_targets)
+        # EM round: SURVEY 8(d)'s algorithmic bytes of one iteration, independent of the layout:
+        #   B_B = nnz*(4 id + 8 alpha gather + 8 next accumulate) + N_ec*(4 count + 8 offsets) + T*(8 alpha + 8 next + 8 eff_len)
         em_bytes = pr["em_nnz"] * 20 + pr["em_necs"] * 12 + T * 24
-        if pr["em_k"]:
-            layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 16 + T * 56
-            em_kernel = "EM round (k_pm_rows_pass + k_pm_cols_pass)"
-        else:
-            layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 24 + pr["em_nseg"] * 28 + T * 64
-            em_kernel = "EM round (k_em_rows + k_em_seg + k_em_final)"
         em_round_ms = float(np.mean(em_ms)) / max(int(em_iters[-1]), 1)
         em_ach = em_bytes / (em_round_ms * 1e-3) / 1e9
-        em_roof = {"kernel": em_kernel, "bound": "hbm", "achieved": round(em_ach, 2),
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(em_ach / HBM_PEAK_GBS, 5), "traffic": None,
-                   "algorithmic_bytes_per_launch": int(em_bytes), "layout_bytes_per_round": int(layout_bytes),
-                   "launch_ms": round(em_round_ms, 5), "launch": "one EM round (all its launches; kamd_em_run's HIP-event time / rounds, set-up included)",
-                   "rounds": int(em_iters[-1]), "nnz": pr["em_nnz"], "nnz_multi": pr["em_nnz_multi"], "rows": pr["em_necs"],
-                   "entries_per_lane": pr["em_k"], "chunks": pr["em_nseg"] if pr["em_k"] else None}
+        local_form = pr["em_k"] < 0
+        if local_form:
+            # component-local form: the matrix sits in LDS for the rounds of a launch; a round gathers one FP64 value and reads one
+            # 16-bit index per entry and direction out of LDS -- the bound is the LDS pipe, HBM only sees the per-launch load / store
+            lds_bytes = 2 * pr["em_nnz"] * (8 + 2)
+            lds_peak = 256 * 128 * 2.4   # GB/s: 256 CUs x 128 B/clk x 2.4 GHz (MI355X_MICROARCH.md)
+            em_roof = {"kernel": "EM round inside k_em_sell (component-local, sliced ELLPACK in LDS)", "bound": "lds",
+                       "achieved": round(lds_bytes / (em_round_ms * 1e-3) / 1e9, 2), "peak": round(lds_peak, 1), "unit": "GB/s",
+                       "frac": round(lds_bytes / (em_round_ms * 1e-3) / 1e9 / lds_peak, 5), "traffic": None,
+                       "algorithmic_lds_bytes_per_round": int(lds_bytes),
+                       "hbm_algorithmic_bytes_per_round": int(em_bytes), "hbm_equivalent_GBps": round(em_ach, 2),
+                       "hbm_equivalent_frac": round(em_ach / HBM_PEAK_GBS, 5),
+                       "launch_ms": round(em_round_ms, 5), "launch": "one EM round = kamd_em_run's HIP-event time / rounds (plan set-up, "
+                       "64-round launches, speculative chunk + replay included)",
+                       "rounds": int(em_iters[-1]), "nnz": pr["em_nnz"], "rows": pr["em_necs"], "groups": pr["em_grid"],
+                       "lds_bytes_per_workgroup": pr["em_lds"]}
+        else:
+            layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 16 + T * 56
+            em_roof = {"kernel": "EM round (k_pm_rows_pass + k_pm_cols_pass)" if pr["em_k"] else "EM round (k_em_rows + k_em_seg + k_em_final)",
+                       "bound": "hbm", "achieved": round(em_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(em_ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(em_bytes),
+                       "layout_bytes_per_round": int(layout_bytes), "launch_ms": round(em_round_ms, 5), "rounds": int(em_iters[-1]),
+                       "nnz": pr["em_nnz"], "rows": pr["em_necs"], "entries_per_lane": pr["em_k"]}
+        # EC resolution (kamd_ec_finalize): records de-duplicated twice (insert + verify) + candidate sets written, merged, emitted
+        f_ms = float(np.mean(fin_ms))
+        fin_bytes = 2 * 4 * pr["fin_stream_words"] + 16 * pr["fin_records"] + 3 * 4 * pr["fin_cand_words"]
+        fin_roof = {"kernel": "kamd_ec_finalize (k_rec_insert + k_rec_verify, k_bound_tuples, k_resolve, k_cand_singles, merge, CSR)", "bound": "hbm",
+                    "achieved": round(fin_bytes / (f_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(fin_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(fin_bytes), "launch_ms": round(f_ms, 3),
+                    "note": "dependent gathers (table slot -> owner record -> set offsets -> members): latency-, not bandwidth-bound"}
+        unit_name = "pairs" if paired else "reads"
         out = {
-            "metric": "M paired-end reads/sec quantified (human txome index)",
-            "value": round(total_pairs / elapsed / 1e6, 4),
-            "unit": "M read pairs/s",
+            "metric": "M paired-end reads/sec quantified (human txome index)" if paired else "M single-end reads/sec quantified (yeast-sized index)",
+            "value": round(total_items / elapsed / 1e6, 4),
+            "unit": "M read pairs/s" if paired else "M reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64+f64", "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE config #3: synthetic human-like transcriptome ({index.num_targets} transcripts, "
-                             f"{index.num_kmers} k-mers, k={index.k}; index built by the reference `kallisto index`), "
-                             f"{n} PE-{L} read pairs per GPU resident in HBM (2-bit packed), full quant per step"
-                             if args.workload == "human" and genes == 20000 else
-                             f"REDUCED {args.workload} genes={genes} pairs={n} (not the BASELINE configuration)"),
-                "pairs_per_gpu": n, "read_len": L, "paired": True, "targets": int(index.num_targets),
+                "workload": ((f"BASELINE config #{3 if world == 1 else 4}: synthetic human-like transcriptome ({index.num_targets} transcripts, "
+                              f"{index.num_kmers} k-mers, k={index.k}; index built by the reference `kallisto index`), "
+                              f"{n} PE-{L} read pairs per GPU resident in HBM (2-bit packed), full quant per step"
+                              if paired else
+                              f"BASELINE config #2: synthetic yeast-like transcriptome ({index.num_targets} transcripts, {index.num_kmers} k-mers, "
+                              f"k={index.k}), {n} SE-{L} reads per GPU resident in HBM, --single -l 200 -s 20, full quant per step")
+                             if genes == (20000 if paired else 6000) and n_arg == n_default else
+                             f"REDUCED {args.workload} genes={genes} {unit_name}={n} (not the BASELINE configuration)"),
+                f"{unit_name}_per_gpu": n, "read_len": L, "paired": paired, "targets": int(index.num_targets),
                 "kmers": int(index.num_kmers),
-                "parallelism": (f"{world} ranks, one per GPU: reads sharded, EC counts all-reduced + tuple records all-gathered (RCCL), "
-                                f"EM partitioned over the ranks by connected component" if world > 1 else "1 GPU"),
-                "collective_backend": backend if world > 1 else None,
+                "parallelism": (f"{world} ranks, one per GPU: reads sharded; in the library (RCCL): one all-reduce of the dense EC count vector + "
+                                f"all-gathers of the tuple records, then the EM partitioned over the ranks by connected component"
+                                if world > 1 else "1 GPU"),
+                "collective_backend": ("rccl (kamd_comm, inside libkallisto_amd.so)" if backend == "nccl" else backend) if world > 1 else None,
             },
             "breakdown_ms": {"pseudoalign_kernel": round(a_ms, 3), "classify_kernel": round(float(np.mean(cls_ms)), 3),
-                             "kernel_a_version": pr["kernel_a_version"], "em": round(float(np.mean(em_ms)), 3),
+                             "kernel_a_version": pr["kernel_a_version"], "ec_finalize": round(f_ms, 3), "em": round(float(np.mean(em_ms)), 3),
                              "em_rounds": int(em_iters[-1]), "step_total": round(elapsed / args.steps * 1e3, 3)},
             "counters": {"probes_per_pair": round(st["n_probes"] / n, 3),
-                         "bucket_reads_per_probe": round(st["n_bucket_reads"] / max(st["n_probes"], 1), 4),
+                         "bucket_reads_per_pair": round(st["n_bucket_reads"] / n, 3), "text_answers_per_pair": round(st["n_text_hits"] / n, 3),
+                         "lane_utilisation": round(st["n_lane_iters"] / max(64 * st["n_wave_iters"], 1), 4),
                          "single_set_pairs": st["n_single"], "multi_set_pairs": st["n_multi"],
                          "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
                          "em_rounds": res.em_rounds},
-            # dominant kernel by time: one EM round
-            "roofline": em_roof,
-            "roofline_kernel_a": {"kernel": "k_match_v2" if pr["kernel_a_version"] == 2 else "k_pseudoalign", "bound": "hbm",
-                                  "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                                  "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
-                                  "bucket_line_bytes_per_launch": int(64 * st["n_bucket_reads"])},
+            # dominant kernel by time: kernel A
+            "roofline": {"kernel": {3: "k_match_v3", 2: "k_match_v2", 1: "k_pseudoalign"}[pr["kernel_a_version"]], "bound": "hbm",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
+                         "launch": "one k_match_v3 launch over the step's batch, HIP events on the context stream (the FLD kernel of the first "
+                                   "prefix runs underneath it on a side stream)",
+                         "table_line_bytes_per_launch": int(64 * st["n_bucket_reads"]), "text_bytes_per_launch": int(12 * st["n_text_hits"])},
+            "roofline_em": em_roof,
+            "roofline_finalize": fin_roof,
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
                 tj = json.load(open(prof))
-                if tj.get("pairs") == n and tj.get("workload") == args.workload and tj.get("genes") == genes:
-                    out["roofline"]["traffic"] = tj.get("em_round_hbm_bytes")
-                    out["roofline_kernel_a"]["traffic"] = tj.get("kernel_a_hbm_bytes")
-                    out["roofline"]["traffic_source"] = out["roofline_kernel_a"]["traffic_source"] = tj.get("source")
+                if tj.get("pairs") == n and tj.get("workload") == args.workload and tj.get("genes") == genes and world == 1:
+                    out["roofline"]["traffic"] = tj.get("kernel_a_hbm_bytes")
+                    out["roofline_em"]["traffic"] = tj.get("em_round_hbm_bytes")
+                    out["roofline_finalize"]["traffic"] = tj.get("finalize_hbm_bytes")
+                    for k in ("roofline", "roofline_em", "roofline_finalize"):
+                        out[k]["traffic_source"] = "static: " + str(tj.get("source"))
             except Exception:
                 pass
+        if other is not None:
+            out["other_scaling"] = other
     # ---- CPU baseline (rank 0, N=1 only): the reference at -t <cores> for the timing; parity against the reference at -t 1 ----
-    if rank == 0 and world == 1 and sample is not None:
+    if rank == 0 and world == 1 and sample is not None and paired:
         threads = min(os.cpu_count() or 1, 64)
         k = sample[0].shape[0]
         log(f"CPU baseline: reference `kallisto quant -t {threads}` on the first {k} pairs ...")
@@ -392,6 +513,13 @@ def main():
             out["parity_check"] = reference_parity(idx_path, sample[0][:ks], sample[1][:ks], gres)
         except Exception as e:
             out["parity_check"] = {"ok": False, "error": str(e)}
+    if rank == 0 and world == 1 and e2e_sample is not None:
+        log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {'pairs' if paired else 'reads'}) ...")
+        ctx.close()   # the front-end is its own process on the same GPU
+        try:
+            out["end_to_end"] = end_to_end(idx_path, e2e_sample[0], e2e_sample[1], paired, min(os.cpu_count() or 1, 64), cli_extra)
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)}
     if rank == 0:
         if boot is not None:
             out["bootstrap"] = boot

@@ -194,6 +194,10 @@ typedef struct {
                                   component-local form: number of groups (= workgroups per launch) */
   uint32_t last_em_lds;        /* component-local form: LDS bytes per workgroup */
   int32_t last_em_plan_cached; /* component-local form: 1 = the plan of an earlier run on the same matrix was reused */
+  float last_finalize_ms;      /* kamd_ec_finalize: record de-duplication, resolution of the tuples, merge of equal sets, CSR (HIP events around it) */
+  uint64_t last_fin_records;   /* ... records it de-duplicated (one slot per item), */
+  uint64_t last_fin_stream_words;  /* u32 words of the record stream it read, */
+  uint64_t last_fin_cand_words;    /* u32 words of candidate transcript sets it wrote and merged */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

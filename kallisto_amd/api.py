@@ -64,7 +64,8 @@ class _Profile(C.Structure):
                 ("last_classify_ms", C.c_float), ("kernel_a_version", C.c_int32), ("last_em_nnz", C.c_uint64),
                 ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64),
                 ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32), ("last_em_lds", C.c_uint32),
-                ("last_em_plan_cached", C.c_int32)]
+                ("last_em_plan_cached", C.c_int32), ("last_finalize_ms", C.c_float), ("last_fin_records", C.c_uint64),
+                ("last_fin_stream_words", C.c_uint64), ("last_fin_cand_words", C.c_uint64)]
 
 
 class _EcResult(C.Structure):
@@ -358,7 +359,9 @@ class Context:
                 "classify_ms": float(p.last_classify_ms), "kernel_a_version": int(p.kernel_a_version),
                 "em_nnz": int(p.last_em_nnz), "em_nnz_multi": int(p.last_em_nnz_multi), "em_nseg": int(p.last_em_nseg),
                 "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid), "em_lds": int(p.last_em_lds),
-                "em_plan_cached": int(p.last_em_plan_cached)}
+                "em_plan_cached": int(p.last_em_plan_cached), "finalize_ms": float(p.last_finalize_ms),
+                "fin_records": int(p.last_fin_records), "fin_stream_words": int(p.last_fin_stream_words),
+                "fin_cand_words": int(p.last_fin_cand_words)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

@@ -1939,7 +1939,8 @@ struct kamd_ctx {
   u64 tuple_bound = 0;           // upper bound of the number of tuple records in the stream (sizes the tuple table)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
-  hipEvent_t ev2 = nullptr;
+  hipEvent_t ev2 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
+  float last_finalize_ms = 0.f; u64 last_fin_records = 0, last_fin_stream_words = 0, last_fin_cand_words = 0;
   hipStream_t em_stream = nullptr;
   int kernel_a_version = 3, items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
@@ -2139,6 +2140,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev_fin0) (void)hipEventDestroy(c->ev_fin0);
+  if (c->ev_fin1) (void)hipEventDestroy(c->ev_fin1);
   if (c->em_stream) (void)hipStreamDestroy(c->em_stream);
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
@@ -2668,6 +2671,8 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   if (!c) return kamd::fail(-1, "kamd_ec_finalize: null context");
   if (!c->has_index) return kamd::fail(-1, "kamd_ec_finalize: no index uploaded");
   HIPC(hipSetDevice(c->device));
+  if (!c->ev_fin0) { HIPC(hipEventCreate(&c->ev_fin0)); HIPC(hipEventCreate(&c->ev_fin1)); }
+  HIPC(hipEventRecord(c->ev_fin0, c->stream));
   if (int rc = sync_state(c)) return rc;
   if (int rc = count_tuples(c)) return rc;
   DevState* dst = (DevState*)c->state.p;
@@ -2769,7 +2774,10 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
     HIPC(hipMemsetAsync(c->ec_off.p, 0, sizeof(u64), c->stream));
     if (int rc = c->ec_ids.ensure(sizeof(u32), 0, c->stream)) return rc;
   }
+  HIPC(hipEventRecord(c->ev_fin1, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  HIPC(hipEventElapsedTime(&c->last_finalize_ms, c->ev_fin0, c->ev_fin1));
+  c->last_fin_records = c->host_state.n_recs; c->last_fin_stream_words = c->host_state.stream_words; c->last_fin_cand_words = c->host_state.cand_words;
   ++c->ec_generation;
   c->result.n_ecs = n_final; c->result.nnz = nnz;
   c->result.d_ec_off = c->ec_off.as<uint64_t>(); c->result.d_ec_ids = c->ec_ids.as<u32>(); c->result.d_counts = c->ec_counts.as<u32>();
@@ -4113,6 +4121,8 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
   p->last_em_nnz = c->last_em_nnz; p->last_em_nnz_multi = c->last_em_nnz_multi; p->last_em_nseg = c->last_em_nseg; p->last_em_necs = c->last_em_necs;
   p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid; p->last_em_lds = c->last_em_lds; p->last_em_plan_cached = c->last_em_plan_cached;
+  p->last_finalize_ms = c->last_finalize_ms; p->last_fin_records = c->last_fin_records; p->last_fin_stream_words = c->last_fin_stream_words;
+  p->last_fin_cand_words = c->last_fin_cand_words;
   return 0;
 }
 

@@ -341,12 +341,16 @@ int main(int argc, char** argv) {
 
   // index (KmerIndex::load) + device context
   kamd_index* idx = nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
   KX(kamd_index_load(opt.index.c_str(), opt.threads, &idx));
   kamd_index_view v; KX(kamd_index_get_view(idx, &v));
+  const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
   kamd_ctx* ctx = nullptr;
   KX(kamd_ctx_create(0, nullptr, &ctx));
   KX(kamd_index_upload(ctx, idx));
+  const double index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
   // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
   if (opt.bootstrap > 0) KX(kamd_ec_track_order(ctx, 1));
 
@@ -446,6 +450,7 @@ int main(int argc, char** argv) {
   }
   pipe.finish();
   if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
+  if (opt.verbose) std::cerr << "[timing] reads parsed, packed and pseudoaligned after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
   if (opt.verbose)
     std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s << " s, host waited for the device "
               << pipe.wait_s << " s" << std::endl;
@@ -551,6 +556,7 @@ int main(int argc, char** argv) {
     std::cerr << std::endl;
   }
   h5.close();
+  if (opt.verbose) std::cerr << "[timing] total " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
   kamd_ctx_destroy(ctx);
   kamd_index_free(idx);
   return num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797
