@@ -8,6 +8,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -40,6 +42,7 @@ struct Options {
   std::string index, output;
   std::vector<std::string> files;
   bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false, do_union = false;
+  int gpus = 1;
   int strand = 0, bootstrap = 0, threads = 1;
   double fld = 0.0, sd = 0.0;
   uint64_t seed = 42;
@@ -67,7 +70,9 @@ void usage() {
             << "-l, --fragment-length=DOUBLE  Estimated average fragment length\n"
             << "-s, --sd=DOUBLE               Estimated standard deviation of fragment length\n"
             << "-t, --threads=INT             Host threads for index loading (default: 1)\n"
-            << "    --verbose                 Print out progress information\n";
+            << "    --verbose                 Print out progress information\n"
+            << "    --gpus=INT                GPUs of this node to use (default: 1): batches of reads go round the GPUs, the EC counts\n"
+            << "                              are merged with one RCCL all-reduce + all-gathers, the EM runs partitioned over them\n";
 }
 
 bool take(const std::string& a, const char* shortf, const char* longf, int& i, int argc, char** argv, std::string& val) {
@@ -96,7 +101,7 @@ class DevicePipe {
  public:
   // run: device work of one batch; returns 0 or an error code with the message in `err` (reported by the main thread: the
   // consumer never exits the process itself)
-  explicit DevicePipe(std::function<int(PackedBatch&, std::string&)> run) : run_(std::move(run)), th_([this] { loop(); }) {}
+  explicit DevicePipe(std::function<int(PackedBatch&, std::string&)> run, int device = 0) : run_(std::move(run)), device_(device), th_([this] { loop(); }) {}
   bool failed() { std::lock_guard<std::mutex> lk(m_); return failed_; }
   std::string error() { std::lock_guard<std::mutex> lk(m_); return error_; }
   // a free slot whose pinned buffers hold n_words / n_reads entries (blocks while both slots are in flight)
@@ -107,8 +112,8 @@ class DevicePipe {
     lk.unlock();
     wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     PackedBatch& b = slot_[fill_];
-    if (n_words > b.hw_cap) { if (b.h_words) HIPX(hipHostFree(b.h_words)); b.hw_cap = n_words * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_words, b.hw_cap * 4, hipHostMallocDefault)); }
-    if (n_reads > b.hl_cap) { if (b.h_len) HIPX(hipHostFree(b.h_len)); b.hl_cap = n_reads * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_len, b.hl_cap * 2, hipHostMallocDefault)); }
+    if (n_words > b.hw_cap) { if (b.h_words) HIPX(hipHostFree(b.h_words)); b.hw_cap = n_words * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_words, b.hw_cap * 4, hipHostMallocPortable)); }
+    if (n_reads > b.hl_cap) { if (b.h_len) HIPX(hipHostFree(b.h_len)); b.hl_cap = n_reads * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_len, b.hl_cap * 2, hipHostMallocPortable)); }
     b.n_words = n_words; b.n_reads = n_reads;
     return b;
   }
@@ -123,6 +128,7 @@ class DevicePipe {
     { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !slot_[0].filled && !slot_[1].filled; }); stop_ = true; }
     cv_.notify_all();
     th_.join();
+    (void)hipSetDevice(device_);
     for (PackedBatch& b : slot_) {
       if (b.h_words) (void)hipHostFree(b.h_words);
       if (b.h_len) (void)hipHostFree(b.h_len);
@@ -133,7 +139,7 @@ class DevicePipe {
   double wait_s = 0.0, device_s = 0.0;   // producer blocked on a free slot / consumer busy
  private:
   void loop() {
-    HIPX(hipSetDevice(0));
+    HIPX(hipSetDevice(device_));
     for (;;) {
       std::unique_lock<std::mutex> lk(m_);
       cv_.wait(lk, [&] { return slot_[run_i_].filled || stop_; });
@@ -155,12 +161,36 @@ class DevicePipe {
   }
   std::function<int(PackedBatch&, std::string&)> run_;
   bool failed_ = false; std::string error_;
+  int device_ = 0;
   PackedBatch slot_[2];
   std::mutex m_;
   std::condition_variable cv_;
   bool stop_ = false;
   int fill_ = 0, run_i_ = 0;
   std::thread th_;   // last member: started when everything above exists
+};
+
+// One pipeline per GPU; the producer's next batch goes to the GPU route() names (round robin -- except that batches go to GPU 0
+// while the fragment-length sample, the first 10 000 qualifying pairs of the input IN ORDER, is still being collected there).
+class MultiPipe {
+ public:
+  MultiPipe(int n, std::function<int(int, PackedBatch&, std::string&)> run, std::function<bool()> pin_to_first) : pin_(std::move(pin_to_first)) {
+    for (int g = 0; g < n; g++) pipes_.emplace_back(new DevicePipe([run, g](PackedBatch& b, std::string& e) { return run(g, b, e); }, g));
+  }
+  PackedBatch& acquire(uint64_t n_words, uint64_t n_reads) {
+    cur_ = pin_() ? 0 : (int)(rr_++ % pipes_.size());
+    return pipes_[cur_]->acquire(n_words, n_reads);
+  }
+  void submit() { pipes_[cur_]->submit(); }
+  bool failed() { for (auto& p : pipes_) if (p->failed()) return true; return false; }
+  std::string error() { for (auto& p : pipes_) if (p->failed()) return p->error(); return ""; }
+  void finish() { for (auto& p : pipes_) p->finish(); }
+  double wait_s() const { double x = 0; for (auto& p : pipes_) x += p->wait_s; return x; }
+  double device_s() const { double x = 0; for (auto& p : pipes_) x = std::max(x, p->device_s); return x; }
+ private:
+  std::vector<std::unique_ptr<DevicePipe>> pipes_;
+  std::function<bool()> pin_;
+  int cur_ = 0; uint64_t rr_ = 0;
 };
 
 // ---- abundance.h5 (H5Writer.cpp:4-69, h5utils.h:42-92): one chunk per dataset, deflate level 6, strings as fixed-size
@@ -292,6 +322,7 @@ int main(int argc, char** argv) {
     else if (take(a, "-s", "--sd", i, argc, argv, val)) opt.sd = atof(val.c_str());
     else if (take(a, "-t", "--threads", i, argc, argv, val)) opt.threads = atoi(val.c_str());
     else if (take(a, nullptr, "--batch", i, argc, argv, val)) opt.batch = strtoull(val.c_str(), nullptr, 10);
+    else if (take(a, nullptr, "--gpus", i, argc, argv, val)) opt.gpus = atoi(val.c_str());
     else if (a == "--single") opt.single = true;
     else if (a == "--single-overhang") opt.single_overhang = true;
     else if (a == "--fr-stranded") opt.strand = 1;
@@ -346,29 +377,45 @@ int main(int argc, char** argv) {
   kamd_index_view v; KX(kamd_index_get_view(idx, &v));
   const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
-  kamd_ctx* ctx = nullptr;
-  KX(kamd_ctx_create(0, nullptr, &ctx));
-  KX(kamd_index_upload(ctx, idx));
+  int n_dev = 0;
+  HIPX(hipGetDeviceCount(&n_dev));
+  const int n_gpus = std::max(1, opt.gpus);
+  if (n_gpus > n_dev) { std::cerr << "Error: --gpus " << n_gpus << " but only " << n_dev << " HIP device(s) are visible" << std::endl; return 1; }
+  std::vector<kamd_ctx*> ctxs((size_t)n_gpus, nullptr);
+  {
+    std::vector<std::thread> th; std::vector<int> rcs((size_t)n_gpus, 0); std::vector<std::string> errs((size_t)n_gpus);
+    for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {   // the index is replicated in every GPU's HBM
+      rcs[g] = kamd_ctx_create(g, nullptr, &ctxs[g]);
+      if (!rcs[g]) rcs[g] = kamd_index_upload(ctxs[g], idx);
+      if (rcs[g]) errs[g] = kamd_last_error();
+    });
+    for (auto& x : th) x.join();
+    for (int g = 0; g < n_gpus; g++) if (rcs[g]) { std::cerr << "Error: " << errs[g] << std::endl; return 1; }
+  }
+  kamd_ctx* ctx = ctxs[0];
   const double index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
   // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
-  if (opt.bootstrap > 0) KX(kamd_ec_track_order(ctx, 1));
+  // (one GPU only: records merged from several GPUs have no input order -- like the reference at -t > 1)
+  if (opt.bootstrap > 0 && n_gpus == 1) KX(kamd_ec_track_order(ctx, 1));
 
   const bool paired = !opt.single;
   kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand, opt.no_jump ? 1 : 0, opt.do_union ? 1 : 0};
   std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;
+  std::atomic<bool> fld_open{paired && opt.fld == 0.0};   // the fragment-length sample is still being collected (on GPU 0)
   double pack_s = 0.0;
-  DevicePipe pipe([&](PackedBatch& b, std::string& err) -> int {
-    const bool want_fld = paired && opt.fld == 0.0 && fld_used < 10000;
+  MultiPipe pipe(n_gpus, [&](int g, PackedBatch& b, std::string& err) -> int {
+    const bool want_fld = g == 0 && paired && opt.fld == 0.0 && fld_used < 10000;
     int rc = 0;
-    if (want_fld) rc = kamd_fld_prefetch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);   // runs underneath kernel A
-    if (!rc) rc = kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);
-    if (!rc && want_fld) rc = kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used);
+    if (want_fld) rc = kamd_fld_prefetch(ctxs[g], &qo, b.d_words, b.d_len, b.n_items, b.max_len);   // runs underneath kernel A
+    if (!rc) rc = kamd_pseudoalign(ctxs[g], &qo, b.d_words, b.d_len, b.n_items, b.max_len);
+    if (!rc && want_fld) rc = kamd_fld_from_batch(ctxs[g], &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used);
+    if (g == 0 && fld_used >= 10000) fld_open = false;
     if (rc) err = kamd_last_error();
     return rc;
-  });
+  }, [&] { return n_gpus > 1 && fld_open.load(); });
   const int host_threads = std::max(1, opt.threads);
   for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
     std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
@@ -452,10 +499,29 @@ int main(int argc, char** argv) {
   if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
   if (opt.verbose) std::cerr << "[timing] reads parsed, packed and pseudoaligned after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
   if (opt.verbose)
-    std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s << " s, host waited for the device "
-              << pipe.wait_s << " s" << std::endl;
+    std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s() << " s, host waited for the device "
+              << pipe.wait_s() << " s" << std::endl;
   std::cerr << "[quant] finding pseudoalignments for the reads ... done" << std::endl;
 
+  // several GPUs: every GPU's EC state becomes the state of the whole input (kamd_ec_allreduce over RCCL), then each finalizes
+  std::vector<kamd_comm*> comms((size_t)n_gpus, nullptr);
+  auto on_all_gpus = [&](std::function<int(int)> f) -> bool {   // f(g) on one host thread per GPU (collectives need all of them)
+    std::vector<std::thread> th; std::vector<int> rcs((size_t)n_gpus, 0); std::vector<std::string> errs((size_t)n_gpus);
+    for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] { rcs[g] = f(g); if (rcs[g]) errs[g] = kamd_last_error(); });
+    for (auto& x : th) x.join();
+    for (int g = 0; g < n_gpus; g++) if (rcs[g]) { std::cerr << "Error: " << errs[g] << std::endl; return false; }
+    return true;
+  };
+  if (n_gpus > 1) {
+    unsigned char uid[KAMD_COMM_ID_BYTES];
+    KX(kamd_comm_unique_id(uid));
+    if (!on_all_gpus([&](int g) {
+          int rc = kamd_comm_create_rccl(ctxs[g], g, n_gpus, uid, &comms[g]);
+          if (!rc) rc = kamd_ec_allreduce(ctxs[g], comms[g]);
+          if (!rc && g != 0) rc = kamd_ec_finalize(ctxs[g], nullptr);
+          return rc;
+        })) return 1;
+  }
   kamd_ec_result ec;
   KX(kamd_ec_finalize(ctx, &ec));
   std::vector<uint64_t> ec_off(ec.n_ecs + 1); std::vector<uint32_t> ec_ids(std::max<uint64_t>(ec.nnz, 1)), counts(std::max<uint64_t>(ec.n_ecs, 1));
@@ -476,7 +542,13 @@ int main(int argc, char** argv) {
   kamd_eff_lens(v.target_lens, v.n_targets, mft.data(), eff.data());
   int32_t rounds = 0;
   if (num_pseudoaligned > 0) {
-    KX(kamd_em_run(ctx, nullptr, nullptr, nullptr, nullptr, 0, eff.data(), v.n_targets, 10000, 50, alpha.data(), abz.data(), &rounds));
+    if (n_gpus == 1) KX(kamd_em_run(ctx, nullptr, nullptr, nullptr, nullptr, 0, eff.data(), v.n_targets, 10000, 50, alpha.data(), abz.data(), &rounds));
+    else {   // partitioned over the GPUs by connected component; every GPU returns the same vectors
+      std::vector<std::vector<double>> al((size_t)n_gpus, std::vector<double>(v.n_targets)), az((size_t)n_gpus, std::vector<double>(v.n_targets));
+      std::vector<int32_t> rr((size_t)n_gpus, 0);
+      if (!on_all_gpus([&](int g) { return kamd_em_run_comm(ctxs[g], comms[g], eff.data(), v.n_targets, 10000, 50, al[g].data(), az[g].data(), &rr[g]); })) return 1;
+      alpha = al[0]; abz = az[0]; rounds = rr[0];
+    }
     std::cerr << "[   em] quantifying the abundances ... done\n[   em] the Expectation-Maximization algorithm ran for " << rounds << " rounds" << std::endl;
   }
   // run_info.json (plaintext_aux, PlaintextWriter.cpp:140-197; src/main.cpp:2715-2727)
@@ -541,12 +613,17 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> seeds(opt.bootstrap);
     kamd_bootstrap_seeds(opt.seed, opt.bootstrap, seeds.data());
     // replicates in batches: one launch draws the batch's multinomial samples, the EMs reuse the plan of the EC matrix
-    const int batch = 32;
+    // (several GPUs: every GPU holds the merged ECs; the replicates of a batch are dealt round the GPUs)
+    const int batch = 32 * n_gpus;
     std::vector<double> ab((size_t)batch * v.n_targets), a(v.n_targets);
     for (int b0 = 0; b0 < opt.bootstrap; b0 += batch) {
       const int nb = std::min(batch, opt.bootstrap - b0);
       std::cerr << "[bstrp] running EM for the bootstrap: " << b0 + nb << "\r";
-      KX(kamd_bootstrap_batch(ctx, seeds.data() + b0, nb, eff.data(), v.n_targets, ab.data(), nullptr));
+      if (n_gpus == 1) KX(kamd_bootstrap_batch(ctx, seeds.data() + b0, nb, eff.data(), v.n_targets, ab.data(), nullptr));
+      else if (!on_all_gpus([&](int g) {   // GPU g: replicates [lo, hi) of this batch
+             const int lo = (int)((int64_t)nb * g / n_gpus), hi = (int)((int64_t)nb * (g + 1) / n_gpus);
+             return hi > lo ? kamd_bootstrap_batch(ctxs[g], seeds.data() + b0 + lo, hi - lo, eff.data(), v.n_targets, ab.data() + (size_t)lo * v.n_targets, nullptr) : 0;
+           })) return 1;
       for (int b = b0; b < b0 + nb; b++) {
         a.assign(ab.begin() + (size_t)(b - b0) * v.n_targets, ab.begin() + (size_t)(b - b0 + 1) * v.n_targets);
         if (use_h5) h5.doubles(h5.bs(), ("bs" + std::to_string(b)).c_str(), a);   // H5Writer::write_bootstrap
@@ -557,7 +634,8 @@ int main(int argc, char** argv) {
   }
   h5.close();
   if (opt.verbose) std::cerr << "[timing] total " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
-  kamd_ctx_destroy(ctx);
+  for (kamd_comm* m : comms) kamd_comm_destroy(m);
+  for (kamd_ctx* x : ctxs) kamd_ctx_destroy(x);
   kamd_index_free(idx);
   return num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797
 }
