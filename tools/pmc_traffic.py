@@ -2,7 +2,7 @@
 """Per-kernel HBM-side traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as
 MI355X_MICROARCH.md prescribes) of `python bench.py --steps 1 --warmup 0 --no-cpu-baseline`.
 
-usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_dir> <prefix> [pairs]
+usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_dir> <prefix> [pairs [em_rounds_executed]]
 
 Writes <out_dir>/<prefix>_pmc_fetch_size_per_kernel.csv, <out_dir>/<prefix>_pmc_write_size_per_kernel.csv and
 <out_dir>/traffic.json (read by bench.py into roofline.traffic):
@@ -50,18 +50,27 @@ def main():
     def kb(pred):
         return sum(res[t][0][k] for t in ("fetch", "write") for k in res[t][0] if pred(k))
 
-    a_kb = kb(lambda k: k.startswith("k_match_v2") or k.startswith("k_pseudoalign<"))
+    a_kb = kb(lambda k: k.startswith("k_match_v3") or k.startswith("k_match_v2") or k.startswith("k_pseudoalign<"))
     em_pred = lambda k: k.startswith("k_pm_rows_pass") or k.startswith("k_pm_cols_pass") or k.startswith("k_pm_rows_fix") or \
-        k.startswith("k_pm_cols_fix") or k.startswith("k_em_rows") or k.startswith("k_em_seg") or k.startswith("k_em_final")
+        k.startswith("k_pm_cols_fix") or k.startswith("k_em_rows") or k.startswith("k_em_seg") or k.startswith("k_em_final") or \
+        k.startswith("k_em_sell") or k.startswith("k_em_local")
     em_kb = kb(em_pred)
+    fin_pred = lambda k: k.startswith("k_rec_insert") or k.startswith("k_rec_verify") or k.startswith("k_bound_") or k.startswith("k_resolve") or \
+        k.startswith("k_cand_singles") or k.startswith("k_final_") or k.startswith("k_table_init") or k.startswith("k_scan_")
+    fin_kb = kb(fin_pred)
     calls = res["fetch"][1]
+    local_launches = sum(calls[k] for k in calls if k.startswith("k_em_sell") or k.startswith("k_em_local"))
     rounds = max([calls[k] for k in calls if k.startswith("k_pm_rows_pass") or k.startswith("k_em_rows")] + [1])
+    if local_launches:   # component-local form: launches of up to 64 rounds (the bench line's em_rounds says how many ran)
+        rounds = int(sys.argv[6]) if len(sys.argv) > 6 else 64 * local_launches
     out = {"workload": "human", "genes": 20000, "pairs": pairs,
            "kernel_a_hbm_bytes": int(a_kb * 1024), "em_round_hbm_bytes": int(em_kb * 1024 / rounds), "em_rounds_in_pass": rounds,
+           "em_launches_in_pass": local_launches, "finalize_hbm_bytes": int(fin_kb * 1024),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py --steps 1 --warmup 0), per launch = "
                      "(FETCH_SIZE + WRITE_SIZE) x 1024 B, raw counters (no x2: the dominant traffic of k_match_v2 is random 64-byte "
                      "bucket lines, for which FETCH_SIZE matched the kernel's own count of 64 B x bucket reads to 2.5 %; see "
-                     "profiles/README.md); EM: all launches of the pass kernels / rounds"}
+                     "profiles/README.md); EM: all launches of the EM kernels / rounds executed (component-local form: the per-launch "
+                     "load and store of the groups, nothing per round); finalize: the kernels of kamd_ec_finalize, one step"}
     json.dump(out, open(f"{out_dir}/traffic.json", "w"), indent=1)
     print(json.dumps(out))
 
