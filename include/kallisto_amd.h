@@ -14,10 +14,12 @@
  *   S2  ReadProcessor::processBuffer             src/ProcessReads.cpp:968-1237    -> kamd_pseudoalign
  *       (KmerIndex::match src/KmerIndex.cpp:1698, MinCollector::intersectKmers src/MinCollector.cpp:160,
  *        KmerIndex::mapPair src/KmerIndex.cpp:1622, KmerIndex::findPosition src/KmerIndex.cpp:2188)
- *       MasterProcessor::update / processReads   src/ProcessReads.cpp:424-499,323-334 -> kamd_ec_finalize (+ kamd_ec_* exchange helpers)
+ *       MasterProcessor::update / processReads   src/ProcessReads.cpp:424-499,323-334 -> kamd_ec_finalize; over several GPUs kamd_ec_allreduce
+ *                                                (kamd_comm: RCCL inside the library) + kamd_em_run_comm
  *       FastqSequenceReader::fetchSequences      src/ProcessReads.cpp:3128-3267   -> kamd_pack_reads (2-bit packing of a parsed batch)
  *   S3  EMAlgorithm ctor + run                   src/EMAlgorithm.h:26-48,95-223   -> kamd_em_run
- *   S4  Bootstrap::run_em / Multinomial::sample  src/Bootstrap.cpp:4-14, src/Multinomial.hpp:33-51 -> kamd_bootstrap
+ *   S4  Bootstrap::run_em / Multinomial::sample  src/Bootstrap.cpp:4-14, src/Multinomial.hpp:33-51 -> kamd_bootstrap, kamd_bootstrap_batch
+ *       (the replicate pool of src/Bootstrap.cpp:15-92, src/main.cpp:2764-2782)
  */
 #ifndef KALLISTO_AMD_H
 #define KALLISTO_AMD_H
