@@ -276,6 +276,14 @@ typedef struct {
 int kamd_ec_track_order(kamd_ctx*, int on);
 int kamd_ec_finalize(kamd_ctx*, kamd_ec_result* out);
 int kamd_ec_download(kamd_ctx*, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts);
+/* `quant-tcc` (src/main.cpp:2802-3220): the equivalence classes come from a file (KmerIndex::loadECsFromFile,
+ * src/KmerIndex.cpp:1561-1600) and every sample / cell brings its own count vector (EM_lambda: `collection.counts[ec] = count`,
+ * src/main.cpp:2989-2996).  kamd_ec_upload makes a host CSR (sorted distinct transcript ids per class, no empty class; counts may be
+ * NULL = zeros) the context's EC result, exactly as if kamd_ec_finalize had produced it: kamd_em_run(ctx, NULL, ...),
+ * kamd_bootstrap(_batch) and kamd_ec_download work on it.  kamd_ec_set_counts replaces only the counts ([n_ecs], host): the next
+ * kamd_em_run reuses the EM plan of the matrix, like a bootstrap replicate does. */
+int kamd_ec_upload(kamd_ctx*, const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs);
+int kamd_ec_set_counts(kamd_ctx*, const uint32_t* counts);
 
 /* ---- S3: EM ---- */
 /* Runs EMAlgorithm(counts, ...).run(n_iter, min_rounds) (src/EMAlgorithm.h:26-48,95-223) on the finalized EC result

@@ -120,6 +120,8 @@ _SYMBOLS = {
                                    C.POINTER(C.c_int32)]),
     "kamd_ec_finalize": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
     "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kamd_ec_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kamd_ec_set_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kamd_em_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "kamd_em_run_partitioned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
@@ -444,6 +446,19 @@ class Context:
         _check(load_library().kamd_ec_download(self._h, ec_off.ctypes.data, ec_ids.ctypes.data, counts.ctypes.data),
                "kamd_ec_download")
         return ECs(ec_off, ec_ids[:res.nnz], counts[:res.n_ecs])
+
+    def ec_upload(self, ec_off, ec_ids, counts=None):
+        """quant-tcc: the ECs of a file become the context's EC result (KmerIndex::loadECsFromFile + the TCC counts of one sample)."""
+        off = np.ascontiguousarray(ec_off, np.uint64)
+        ids = np.ascontiguousarray(ec_ids, np.uint32)
+        cnt = None if counts is None else np.ascontiguousarray(counts, np.uint32)
+        _check(load_library().kamd_ec_upload(self._h, off.ctypes.data, ids.ctypes.data if ids.size else None,
+                                             None if cnt is None else cnt.ctypes.data, len(off) - 1), "kamd_ec_upload")
+
+    def ec_set_counts(self, counts):
+        """Another sample's counts on the same EC matrix (the EM plan is reused)."""
+        cnt = np.ascontiguousarray(counts, np.uint32)
+        _check(load_library().kamd_ec_set_counts(self._h, cnt.ctypes.data), "kamd_ec_set_counts")
 
     def em_run(self, eff_lens: np.ndarray, n_iter: int = 10000, min_rounds: int = 50, csr=None):
         """EMAlgorithm(counts, ...).run(n_iter, min_rounds) on the finalized ECs (or on a device CSR triple)."""

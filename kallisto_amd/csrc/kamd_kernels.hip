@@ -2797,6 +2797,46 @@ extern "C" int kamd_ec_download(kamd_ctx* c, uint64_t* ec_off, uint32_t* ec_ids,
   return 0;
 }
 
+// ---- ECs supplied by the caller (`quant-tcc`: src/main.cpp:2813-2900 reads the TCC matrix, KmerIndex::loadECsFromFile
+// src/KmerIndex.cpp:1561-1600 the EC list; EM_lambda :2989-3000 sets `collection.counts[ec] = count` per sample) ------------------
+// The context's EC result becomes the given CSR: kamd_em_run(ctx, NULL...), kamd_bootstrap(_batch) and the plan cache then work as
+// after kamd_ec_finalize.  kamd_ec_set_counts replaces only the counts (same matrix: the EM plan of the previous sample is reused).
+extern "C" int kamd_ec_upload(kamd_ctx* c, const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs) {
+  if (!c || !ec_off || (n_ecs && !ec_ids)) return kamd::fail(-1, "kamd_ec_upload: null argument");
+  if (ec_off[0] != 0) return kamd::fail(-1, "kamd_ec_upload: ec_off[0] must be 0");
+  for (u64 e = 0; e < n_ecs; e++) {
+    if (ec_off[e + 1] <= ec_off[e]) return kamd::fail(-1, "kamd_ec_upload: empty equivalence class or offsets not increasing");
+    for (u64 j = ec_off[e] + 1; j < ec_off[e + 1]; j++)
+      if (ec_ids[j] <= ec_ids[j - 1]) return kamd::fail(-1, "kamd_ec_upload: the transcripts of an equivalence class must be sorted and distinct");
+  }
+  HIPC(hipSetDevice(c->device));
+  const u64 nnz = ec_off[n_ecs];
+  if (int rc = c->ec_off.ensure((n_ecs + 1) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->ec_ids.ensure(std::max<u64>(nnz, 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->ec_counts.ensure(std::max<u64>(n_ecs, 1) * sizeof(u32), 0, c->stream)) return rc;
+  HIPC(hipMemcpyAsync(c->ec_off.p, ec_off, (n_ecs + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  if (nnz) HIPC(hipMemcpyAsync(c->ec_ids.p, ec_ids, nnz * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  if (n_ecs) {
+    if (counts) HIPC(hipMemcpyAsync(c->ec_counts.p, counts, n_ecs * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    else HIPC(hipMemsetAsync(c->ec_counts.p, 0, n_ecs * sizeof(u32), c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  ++c->ec_generation;
+  c->result.n_ecs = n_ecs; c->result.nnz = nnz;
+  c->result.d_ec_off = c->ec_off.as<uint64_t>(); c->result.d_ec_ids = c->ec_ids.as<u32>(); c->result.d_counts = c->ec_counts.as<u32>();
+  c->result.n_pseudoaligned = 0;
+  c->finalized = true;
+  return 0;
+}
+extern "C" int kamd_ec_set_counts(kamd_ctx* c, const uint32_t* counts) {
+  if (!c || !counts) return kamd::fail(-1, "kamd_ec_set_counts: null argument");
+  if (!c->finalized) return kamd::fail(-1, "kamd_ec_set_counts: no EC result (call kamd_ec_upload or kamd_ec_finalize first)");
+  HIPC(hipSetDevice(c->device));
+  if (c->result.n_ecs) HIPC(hipMemcpyAsync(c->ec_counts.p, counts, c->result.n_ecs * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ---- EM ----------------------------------------------------------------------------------------------------------------
 namespace {
 struct EmPartition { uint32_t rank = 0, world = 1; kamd_em_sum_cb cb = nullptr; void* user = nullptr; };

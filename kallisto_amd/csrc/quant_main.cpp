@@ -1,42 +1,12 @@
-// quant_main.cpp -- `kallisto_amd quant`: the command-line surface of `kallisto quant` (src/main.cpp:211-392 option
+// quant_main.cpp -- `kallisto_amd_quant quant` (+ dispatch of `bus` / `quant-tcc`, bus_main.cpp): the command-line surface of `kallisto quant` (src/main.cpp:211-392 option
 // parsing, :1600-1805 checks, :2620-2798 driver) on top of the C ABI of include/kallisto_amd.h.  Same flags, same
 // index file, same abundance.tsv / run_info.json (PlaintextWriter.cpp:29-65,140-197), bs_abundance_N.tsv bootstraps.
 // Host code only: FASTQ reading (FastqSequenceReader::fetchSequences, src/ProcessReads.cpp:3128-3267), batching,
 // writers.  Everything that computes runs on the GPU through libkallisto_amd.so.
-#include <hip/hip_runtime_api.h>
-#include <dlfcn.h>
-#include <zlib.h>
-
-#include <algorithm>
-#include <atomic>
-#include <memory>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <ctime>
-#include <fstream>
-#include <iomanip>
-#include <iostream>
-#include <sstream>
-#include <string>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <thread>
-#include <unistd.h>
-#include <vector>
-
-#include "../../include/kallisto_amd.h"
-#include "kamd_fastq.h"
+#include "kamd_frontend.h"
 
 namespace {
-using namespace kamd_io;
-
-const char* KALLISTO_COMPAT_VERSION = "0.51.1";  // src/common.h:4
+using namespace kamd_fe;
 
 struct Options {
   std::string index, output;
@@ -75,123 +45,6 @@ void usage() {
             << "                              are merged with one RCCL all-reduce + all-gathers, the EM runs partitioned over them\n";
 }
 
-bool take(const std::string& a, const char* shortf, const char* longf, int& i, int argc, char** argv, std::string& val) {
-  std::string lf = std::string(longf) + "=";
-  if (a.rfind(lf, 0) == 0) { val = a.substr(lf.size()); return true; }
-  if (a == longf || (shortf && a == shortf)) { if (i + 1 >= argc) { std::cerr << "Error: missing value for " << a << std::endl; exit(1); } val = argv[++i]; return true; }
-  if (shortf && a.size() > 2 && a.compare(0, 2, shortf) == 0) { val = a.substr(2); return true; }   // getopt's attached form: -t4, -l200
-  return false;
-}
-
-// FASTA/FASTQ input (SeqReader, ChunkReader, MappedFastq, BgzfSource): kamd_fastq.h
-#define HIPX(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::cerr << "Error: " #x ": " << hipGetErrorString(e_) << std::endl; exit(1); } } while (0)
-#define KX(x) do { if ((x) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; exit(1); } } while (0)
-
-// Two-slot pipeline between the host (FASTQ parsing + 2-bit packing into pinned memory, all host threads) and the device
-// (H2D copy, kamd_pseudoalign, FLD sample): batch i+1 is packed while batch i runs.  One consumer thread, batches in input
-// order (the FLD sample and the first-occurrence EC ids depend on it).
-struct PackedBatch {
-  uint32_t* h_words = nullptr; uint16_t* h_len = nullptr; size_t hw_cap = 0, hl_cap = 0;   // pinned host memory
-  uint32_t* d_words = nullptr; uint16_t* d_len = nullptr; size_t dw_cap = 0, dl_cap = 0;
-  uint64_t n_items = 0, n_reads = 0, n_words = 0;
-  int32_t max_len = 1;
-  bool filled = false;
-};
-class DevicePipe {
- public:
-  // run: device work of one batch; returns 0 or an error code with the message in `err` (reported by the main thread: the
-  // consumer never exits the process itself)
-  explicit DevicePipe(std::function<int(PackedBatch&, std::string&)> run, int device = 0) : run_(std::move(run)), device_(device), th_([this] { loop(); }) {}
-  bool failed() { std::lock_guard<std::mutex> lk(m_); return failed_; }
-  std::string error() { std::lock_guard<std::mutex> lk(m_); return error_; }
-  // a free slot whose pinned buffers hold n_words / n_reads entries (blocks while both slots are in flight)
-  PackedBatch& acquire(uint64_t n_words, uint64_t n_reads) {
-    const auto t0 = std::chrono::steady_clock::now();
-    std::unique_lock<std::mutex> lk(m_);
-    cv_.wait(lk, [&] { return !slot_[fill_].filled; });
-    lk.unlock();
-    wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    PackedBatch& b = slot_[fill_];
-    if (n_words > b.hw_cap) { if (b.h_words) HIPX(hipHostFree(b.h_words)); b.hw_cap = n_words * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_words, b.hw_cap * 4, hipHostMallocPortable)); }
-    if (n_reads > b.hl_cap) { if (b.h_len) HIPX(hipHostFree(b.h_len)); b.hl_cap = n_reads * 5 / 4; HIPX(hipHostMalloc((void**)&b.h_len, b.hl_cap * 2, hipHostMallocPortable)); }
-    b.n_words = n_words; b.n_reads = n_reads;
-    return b;
-  }
-  void submit() {
-    { std::lock_guard<std::mutex> lk(m_); slot_[fill_].filled = true; }
-    cv_.notify_all();
-    fill_ ^= 1;
-  }
-  ~DevicePipe() { finish(); }   // also on the error returns of main
-  void finish() {
-    if (!th_.joinable()) return;
-    { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return !slot_[0].filled && !slot_[1].filled; }); stop_ = true; }
-    cv_.notify_all();
-    th_.join();
-    (void)hipSetDevice(device_);
-    for (PackedBatch& b : slot_) {
-      if (b.h_words) (void)hipHostFree(b.h_words);
-      if (b.h_len) (void)hipHostFree(b.h_len);
-      if (b.d_words) (void)hipFree(b.d_words);
-      if (b.d_len) (void)hipFree(b.d_len);
-    }
-  }
-  double wait_s = 0.0, device_s = 0.0;   // producer blocked on a free slot / consumer busy
- private:
-  void loop() {
-    HIPX(hipSetDevice(device_));
-    for (;;) {
-      std::unique_lock<std::mutex> lk(m_);
-      cv_.wait(lk, [&] { return slot_[run_i_].filled || stop_; });
-      if (!slot_[run_i_].filled) return;
-      lk.unlock();
-      const auto t0 = std::chrono::steady_clock::now();
-      PackedBatch& b = slot_[run_i_];
-      if (b.n_words > b.dw_cap) { if (b.d_words) HIPX(hipFree(b.d_words)); b.dw_cap = b.n_words * 5 / 4; HIPX(hipMalloc((void**)&b.d_words, b.dw_cap * 4)); }
-      if (b.n_reads > b.dl_cap) { if (b.d_len) HIPX(hipFree(b.d_len)); b.dl_cap = b.n_reads * 5 / 4; HIPX(hipMalloc((void**)&b.d_len, b.dl_cap * 2)); }
-      HIPX(hipMemcpy(b.d_words, b.h_words, b.n_words * 4, hipMemcpyHostToDevice));
-      HIPX(hipMemcpy(b.d_len, b.h_len, b.n_reads * 2, hipMemcpyHostToDevice));
-      std::string err;
-      const int rc = failed_ ? 0 : run_(b, err);   // after a failure the remaining batches are only drained
-      device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      { std::lock_guard<std::mutex> g(m_); b.filled = false; if (rc) { failed_ = true; error_ = err; } }
-      cv_.notify_all();
-      run_i_ ^= 1;
-    }
-  }
-  std::function<int(PackedBatch&, std::string&)> run_;
-  bool failed_ = false; std::string error_;
-  int device_ = 0;
-  PackedBatch slot_[2];
-  std::mutex m_;
-  std::condition_variable cv_;
-  bool stop_ = false;
-  int fill_ = 0, run_i_ = 0;
-  std::thread th_;   // last member: started when everything above exists
-};
-
-// One pipeline per GPU; the producer's next batch goes to the GPU route() names (round robin -- except that batches go to GPU 0
-// while the fragment-length sample, the first 10 000 qualifying pairs of the input IN ORDER, is still being collected there).
-class MultiPipe {
- public:
-  MultiPipe(int n, std::function<int(int, PackedBatch&, std::string&)> run, std::function<bool()> pin_to_first) : pin_(std::move(pin_to_first)) {
-    for (int g = 0; g < n; g++) pipes_.emplace_back(new DevicePipe([run, g](PackedBatch& b, std::string& e) { return run(g, b, e); }, g));
-  }
-  PackedBatch& acquire(uint64_t n_words, uint64_t n_reads) {
-    cur_ = pin_() ? 0 : (int)(rr_++ % pipes_.size());
-    return pipes_[cur_]->acquire(n_words, n_reads);
-  }
-  void submit() { pipes_[cur_]->submit(); }
-  bool failed() { for (auto& p : pipes_) if (p->failed()) return true; return false; }
-  std::string error() { for (auto& p : pipes_) if (p->failed()) return p->error(); return ""; }
-  void finish() { for (auto& p : pipes_) p->finish(); }
-  double wait_s() const { double x = 0; for (auto& p : pipes_) x += p->wait_s; return x; }
-  double device_s() const { double x = 0; for (auto& p : pipes_) x = std::max(x, p->device_s); return x; }
- private:
-  std::vector<std::unique_ptr<DevicePipe>> pipes_;
-  std::function<bool()> pin_;
-  int cur_ = 0; uint64_t rr_ = 0;
-};
 
 // ---- abundance.h5 (H5Writer.cpp:4-69, h5utils.h:42-92): one chunk per dataset, deflate level 6, strings as fixed-size
 // NUL-terminated C strings of the longest entry + 1.  libhdf5 is loaded at run time (dlopen), so the front-end neither
@@ -285,30 +138,12 @@ class H5Out {
   herr_t (*H5Tclose)(hid_t) = nullptr;
 };
 
-std::string to_json(const std::string& id, const std::string& val, bool quote, bool comma = true) {  // PlaintextWriter.cpp:113-137
-  std::string out = "\t\"" + id + "\": ";
-  if (quote) out += '"';
-  out += val;
-  if (quote) out += '"';
-  if (comma) out += ',';
-  return out;
-}
-
-void write_abundance(const std::string& path, const kamd_index* idx, const kamd_index_view& v, const std::vector<double>& alpha,
-                     const std::vector<double>& eff) {  // plaintext_writer, PlaintextWriter.cpp:29-65
-  std::ofstream of(path);
-  if (!of.is_open()) { std::cerr << "Error: Couldn't open file: " << path << std::endl; exit(1); }
-  std::vector<double> tpm(alpha.size());
-  kamd_counts_to_tpm(alpha.data(), eff.data(), alpha.size(), tpm.data());
-  of << "target_id" << "\t" << "length" << "\t" << "eff_length" << "\t" << "est_counts" << "\t" << "tpm" << std::endl;
-  for (size_t i = 0; i < alpha.size(); ++i)
-    of << kamd_index_target_name(idx, i) << '\t' << (uint32_t)v.target_lens[i] << '\t' << eff[i] << '\t' << alpha[i] << '\t' << tpm[i] << std::endl;
-}
-
 }  // namespace
 
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "version") { std::cout << "kallisto_amd, compatible with kallisto " << KALLISTO_COMPAT_VERSION << std::endl; return 0; }
+  if (argc >= 2 && std::string(argv[1]) == "bus") return bus_main(argc, argv);
+  if (argc >= 2 && std::string(argv[1]) == "quant-tcc") return tcc_main(argc, argv);
   if (argc < 2 || std::string(argv[1]) != "quant") { usage(); return 1; }
   Options opt;
   std::string val;
@@ -364,11 +199,7 @@ int main(int argc, char** argv) {
   if (opt.threads <= 0) { std::cerr << "Error: invalid number of threads " << opt.threads << std::endl; ok = false; }
   if (opt.bootstrap < 0) { std::cerr << "Error: number of bootstrap samples must be a non-negative integer." << std::endl; ok = false; }
   if (!ok) { std::cerr << std::endl; usage(); return 1; }
-  std::time_t tt = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
-  std::string start_time = std::ctime(&tt);
-  if (!start_time.empty() && start_time.back() == '\n') start_time.pop_back();
-  std::string call;
-  for (int i = 0; i < argc; i++) { if (i) call += ' '; call += argv[i]; }
+  const std::string start_time = now_string(), call = call_string(argc, argv);
 
   // index (KmerIndex::load) + device context
   kamd_index* idx = nullptr;
@@ -416,85 +247,11 @@ int main(int argc, char** argv) {
     if (rc) err = kamd_last_error();
     return rc;
   }, [&] { return n_gpus > 1 && fld_open.load(); });
-  const int host_threads = std::max(1, opt.threads);
   for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
     std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
     if (paired) std::cerr << "                             " << opt.files[fi + 1] << std::endl;
-    // plain 4-line FASTQ: memory-map, index the records with all host threads, pack batches in parallel
-    if (!MappedFastq::is_gzip(opt.files[fi]) && (!paired || !MappedFastq::is_gzip(opt.files[fi + 1]))) {
-      MappedFastq m1, m2;
-      bool fast = m1.open(opt.files[fi]) && m1.index_records(host_threads);
-      if (fast && paired) fast = m2.open(opt.files[fi + 1]) && m2.index_records(host_threads);
-      if (fast) {
-        if (paired && m1.off.size() != m2.off.size()) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
-        const uint64_t n_items_total = m1.off.size();
-        for (uint64_t b0 = 0; b0 < n_items_total; b0 += opt.batch) {
-          const uint64_t nb = std::min<uint64_t>(opt.batch, n_items_total - b0);
-          int32_t max_len = 1;
-          for (uint64_t i = b0; i < b0 + nb; i++) { max_len = std::max(max_len, m1.len[i]); if (paired) max_len = std::max(max_len, m2.len[i]); }
-          if (max_len > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; return 1; }
-          const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
-          PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
-          const auto t0 = std::chrono::steady_clock::now();
-          std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0); std::vector<std::string> errs(host_threads);
-          for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
-            const uint64_t a = b0 + nb * t / host_threads, e = b0 + nb * (t + 1) / host_threads;
-            if (e == a) return;
-            const uint64_t first = (a - b0) * (paired ? 2 : 1);
-            rcs[t] = kamd_pack_reads_host_strided(m1.data, m1.off.data() + a, m1.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, paired ? 2 : 1, first);
-            if (paired && rcs[t] == 0)
-              rcs[t] = kamd_pack_reads_host_strided(m2.data, m2.off.data() + a, m2.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, 2, first + 1);
-            if (rcs[t]) errs[t] = kamd_last_error();   // (the library keeps its message per thread)
-          });
-          for (auto& x : th) x.join();
-          for (int t = 0; t < host_threads; t++) if (rcs[t]) { std::cerr << "Error: " << errs[t] << std::endl; return 1; }
-          pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-          pb.n_items = nb; pb.max_len = max_len;
-          pipe.submit();
-          if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
-          n_processed += nb;
-          if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
-        }
-        m1.close(); m2.close();
-        continue;
-      }
-      m1.close(); m2.close();
-    }
-    const int inflate_threads = std::max(1, opt.threads / (paired ? 2 : 1) - 1);   // BGZF input: block-parallel inflate
-    ChunkReader r1(opt.files[fi], opt.batch, inflate_threads);
-    ChunkReader* r2 = paired ? new ChunkReader(opt.files[fi + 1], opt.batch, inflate_threads) : nullptr;
-    SeqChunk c1, c2;
-    while (r1.next(c1)) {
-      if (paired && (!r2->next(c2) || c2.off.size() != c1.off.size())) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
-      const uint64_t nb = c1.off.size();
-      int32_t max_len = 1;
-      for (auto l : c1.len) max_len = std::max(max_len, l);
-      if (paired) for (auto l : c2.len) max_len = std::max(max_len, l);
-      const uint64_t rec = kamd_packed_record_words(max_len), n_reads = nb * (paired ? 2 : 1);
-      PackedBatch& pb = pipe.acquire(n_reads * rec, n_reads);
-      const auto t0 = std::chrono::steady_clock::now();
-      std::vector<std::thread> th; std::vector<int> rcs(host_threads, 0); std::vector<std::string> errs(host_threads);
-      for (int t = 0; t < host_threads; t++) th.emplace_back([&, t] {
-        const uint64_t a = nb * t / host_threads, e = nb * (t + 1) / host_threads;
-        if (e == a) return;
-        const uint64_t first = a * (paired ? 2 : 1);
-        rcs[t] = kamd_pack_reads_host_strided(c1.seqs.data(), c1.off.data() + a, c1.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, paired ? 2 : 1, first);
-        if (paired && rcs[t] == 0)
-          rcs[t] = kamd_pack_reads_host_strided(c2.seqs.data(), c2.off.data() + a, c2.len.data() + a, e - a, max_len, pb.h_words, pb.h_len, 2, first + 1);
-        if (rcs[t]) errs[t] = kamd_last_error();
-      });
-      for (auto& x : th) x.join();
-      for (int t = 0; t < host_threads; t++) if (rcs[t]) { std::cerr << "Error: " << errs[t] << std::endl; return 1; }
-      pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      pb.n_items = nb; pb.max_len = max_len;
-      pipe.submit();
-      if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
-      n_processed += nb;
-      if (opt.verbose) std::cerr << "[quant] processed " << n_processed << (paired ? " pairs" : " reads") << std::endl;
-    }
-    if (paired && r2->next(c2)) { std::cerr << "Error: paired-end files have different numbers of reads" << std::endl; return 1; }
-    delete r2;
   }
+  if (feed_files(opt.files, paired, opt.batch, std::max(1, opt.threads), opt.threads, opt.verbose, pipe, n_processed, pack_s)) return 1;
   pipe.finish();
   if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
   if (opt.verbose) std::cerr << "[timing] reads parsed, packed and pseudoaligned after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
@@ -552,28 +309,7 @@ int main(int argc, char** argv) {
     std::cerr << "[   em] quantifying the abundances ... done\n[   em] the Expectation-Maximization algorithm ran for " << rounds << " rounds" << std::endl;
   }
   // run_info.json (plaintext_aux, PlaintextWriter.cpp:140-197; src/main.cpp:2715-2727)
-  {
-    uint64_t n_on = 0;
-    for (uint64_t t = 0; t < v.n_targets; t++) n_on += (v.onlist_bits[t >> 5] >> (t & 31)) & 1u;
-    double p_uniq = 0.0, p_aln = 0.0;
-    if (n_processed > 0) { p_uniq = 100.0 * (double)num_unique / (double)n_processed; p_aln = 100.0 * (double)num_pseudoaligned / (double)n_processed; }
-    std::stringstream s1, s2; s1 << std::fixed << std::setprecision(1) << p_uniq; s2 << std::fixed << std::setprecision(1) << p_aln;
-    std::ofstream of(opt.output + "/run_info.json");
-    of << "{" << std::endl
-       << to_json("n_targets", std::to_string(n_on), false) << std::endl
-       << to_json("n_bootstraps", std::to_string(opt.bootstrap), false) << std::endl
-       << to_json("n_processed", std::to_string(n_processed), false) << std::endl
-       << to_json("n_pseudoaligned", std::to_string(num_pseudoaligned), false) << std::endl
-       << to_json("n_unique", std::to_string(num_unique), false) << std::endl
-       << to_json("p_pseudoaligned", s2.str(), false) << std::endl
-       << to_json("p_unique", s1.str(), false) << std::endl
-       << to_json("kallisto_version", KALLISTO_COMPAT_VERSION, true) << std::endl
-       << to_json("index_version", "13", false) << std::endl
-       << to_json("k-mer length", std::to_string(v.k), false) << std::endl
-       << to_json("start_time", start_time, true) << std::endl
-       << to_json("call", call, true, false) << std::endl
-       << "}" << std::endl;
-  }
+  write_run_info(opt.output + "/run_info.json", onlist_targets(v), opt.bootstrap, n_processed, num_pseudoaligned, num_unique, v.k, start_time, call);
   // abundance.h5 (src/main.cpp:2693-2702): written unless --plaintext, when libhdf5 is there
   H5Out h5;
   bool use_h5 = false;

@@ -65,3 +65,38 @@ def test_options_outside_the_gpu_path_are_refused(args, tmp_path):
 def test_version():
     p = subprocess.run([EXE, "version"], stdout=subprocess.PIPE)
     assert p.returncode == 0 and p.stdout.decode().strip() == "kallisto_amd, compatible with kallisto 0.51.1"
+
+
+def _sub_errors(exe, sub, args, cwd):
+    p = subprocess.run([exe, sub, *args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.returncode, [l for l in p.stderr.decode().split("\n") if l.startswith("Error:")]
+
+
+BUS_CASES = [
+    ("bus", ["-i", IDX, "-o", "o", "a.fq"], ["Error: the technology must be specified via -x, use \"bulk\" for regular RNA-seq reads"]),
+    ("bus", ["-x", "bulk", "-o", "o", "a.fq"], ["Error: kallisto index file missing"]),
+    ("bus", ["-x", "bulk", "-i", IDX, "-o", "o", "--paired", "a.fq"], ["Error: paired-end mode requires an even number of input files"]),
+    ("bus", ["-x", "bulk", "-i", IDX, "-o", "o", "a.fq", "missing.fq"], ["Error: file not found missing.fq"]),
+    ("quant-tcc", ["-i", IDX, "-o", "o", "-e", "a.fq"], ["Error: transcript-compatibility counts file missing"]),
+    ("quant-tcc", ["-i", IDX, "-o", "o", "-e", "a.fq", "-l", "200", "-s", "20", "-f", "b.fq", "a.fq"],
+     ["Error: cannot supply mean or sd while also supplying a fragment length distribution file"]),
+    ("quant-tcc", ["-i", IDX, "-o", "o", "-e", "missing.ec", "a.fq"], ["Error: equivalence class file not found missing.ec"]),
+]
+
+
+@pytest.mark.parametrize("sub,args,expected", BUS_CASES)
+def test_bus_and_quant_tcc_option_errors(sub, args, expected, tmp_path):
+    """CheckOptionsBus (the `-x bulk` branch, src/main.cpp:1048-1107) / CheckOptionsTCCQuant (src/main.cpp:1807-1960)."""
+    for f in ("a.fq", "b.fq"):
+        open(tmp_path / f, "w").close()
+    rc, got = _sub_errors(EXE, sub, args, str(tmp_path))
+    assert rc == 1 and got == expected
+    if os.path.exists(REF):
+        rrc, ref = _sub_errors(REF, sub, args, str(tmp_path))
+        assert rrc == 1 and ref == expected, "the reference binary prints something else now"
+
+
+def test_single_cell_technologies_are_refused(tmp_path):
+    open(tmp_path / "a.fq", "w").close()
+    rc, got = _sub_errors(EXE, "bus", ["-x", "10xv3", "-i", IDX, "-o", "o", "a.fq"], str(tmp_path))
+    assert rc == 1 and got == ["Error: only `-x bulk` runs on the GPU path; single-cell technologies stay with the reference kallisto"]
