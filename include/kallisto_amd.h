@@ -122,7 +122,7 @@ typedef struct {
   int32_t em_local_block;      /* component-local form, kernel 3: threads per workgroup, 128 / 256 / 512 (default) / 1024 */
   int32_t em_group_div;        /* component-local form, kernel 3: groups hold about nnz / (CUs x this) entries (default 4) */
   int32_t em_split_len;        /* component-local form, kernel 3: a row / column with more entries is split over several lanes (1..64) */
-  int32_t reserved[1];
+  int32_t dedup_form;          /* record de-duplication: 1 = insert + verify launches, 2 = one launch (tag and owner in one CAS; default) */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);

@@ -53,7 +53,7 @@ class Tuning(C.Structure):
     """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
     _fields_ = [(n, C.c_int32) for n in ("kernel_a", "text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form",
                                          "em_local_kernel", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
-                                         "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len")] + [("reserved", C.c_int32 * 1)]
+                                         "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form")]
 
 
 EM_FORMS = {"streamed": 1, "csr": 2, "local": 3}
@@ -281,7 +281,7 @@ class Context:
         _check(load_library().kamd_ctx_tune(self._h, C.byref(t)), "kamd_ctx_tune")
         cur = Tuning()
         _check(load_library().kamd_ctx_get_tuning(self._h, C.byref(cur)), "kamd_ctx_get_tuning")
-        return {n: int(getattr(cur, n)) for n, _ in Tuning._fields_ if n != "reserved"}
+        return {n: int(getattr(cur, n)) for n, _ in Tuning._fields_}
 
     def track_order(self, on: bool = True):
         """finalize() then emits the sets in first-occurrence order (the reference's ids at -t 1); call before the first batch."""

@@ -818,6 +818,52 @@ __global__ __launch_bounds__(VERIFY_BLOCK) void k_rec_verify(const u32* __restri
   if (is_owner) list[blk_base + my] = s;
 }
 
+// The same de-duplication in ONE launch: the slot's tag word holds 32 bits of the hash AND the stream offset (+1) of the record that
+// installed it, so a single compare-and-swap elects the owner and publishes where its contents are; a later record with the
+// same 32 hash bits compares itself with that record at once (equal: its count is added; different contents -- a collision
+// of the 32 bits -- : next slot).  Exact, no second pass, no per-record slot array, no retries.
+// max_probe: give up after that many slots (counted in st->n_retry; the host then repeats the run with a larger table) -- lets the
+// table be sized for the EXPECTED number of distinct records instead of the number of records.
+__global__ __launch_bounds__(BLOCK) void k_rec_dedup(const u32* __restrict__ stream, const u64* __restrict__ rec_off, u64 r0, u64 n, TSlot* table,
+                                                     u64 mask, u64* list, const u64* __restrict__ keys, int track, u32 max_probe, DevState* st) {
+  __shared__ u32 blk_n; __shared__ u64 blk_base;
+  if (threadIdx.x == 0) blk_n = 0;
+  __syncthreads();
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  bool is_owner = false; u64 s = 0; u32 my = 0;
+  if (i < n) {
+    const u64 r = r0 + i;
+    const u64 off = rec_off[r];
+    if (off != ~0ULL && stream[off] != 0u) {
+      const u32 m = stream[off + 1];
+      const u64 h = rec_hash(stream + off + 1, m + 1, 1);
+      const u64 mine = (h & 0xFFFFFFFF00000000ULL) | (off + 1);   // off + 1 < 2^32 (checked by the host), so the word is never 0
+      s = (h >> 1) & mask;
+      bool placed = false;
+      for (u32 probes = 0; probes < max_probe; probes++) {
+        const u64 old = atomicCAS(&table[s].tag, 0ULL, mine);
+        if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }   // (owner: read by the kernels after this one)
+        if ((old >> 32) == (mine >> 32)) {
+          const u64 ooff = (old & 0xFFFFFFFFULL) - 1;
+          bool same = stream[ooff + 1] == m;
+          for (u32 j = 0; same && j < m; j++) same = stream[ooff + 2 + j] == stream[off + 2 + j];
+          if (same) { placed = true; break; }
+        }
+        s = (s + 1) & mask;
+      }
+      if (placed) {
+        atomicAdd(&table[s].count, (u64)stream[off]);
+        if (track) atomicMin(&table[s].first, keys ? keys[r] : r);   // first occurrence: record indices follow the input order
+      } else atomicAdd(&st->n_retry, 1ULL);
+    }
+  }
+  if (is_owner) my = atomicAdd(&blk_n, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&st->n_list, (u64)blk_n);
+  __syncthreads();
+  if (is_owner) list[blk_base + my] = s;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // resolve: candidates = transcript sets of (a) index sets with a non-zero dense count, (b) distinct tuples
 // ------------------------------------------------------------------------------------------------------------------
@@ -1086,13 +1132,58 @@ __global__ void k_tuple_export_offsets(const u32* __restrict__ stream, const TSl
 // FLD probe kernel: per item the fragment length KmerIndex::mapPair would return and |u| (first items only)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr u32 FLD_OVERFLOW = 0xFFFFFFFFu;
+// Phase 1 of the sample: KmerIndex::mapPair's own test and nothing else -- the first present k-mer of either mate by a linear
+// scan (KmerIndex.cpp:1636-1668; it is also match()'s first hit), same block, opposite strands, 0 < tl < MAX_FRAG_LEN.  One or
+// two probes per mate, no class lists.  Only the pairs that pass (a few per cent) go on to k_fld, which adds |u| == 1.
+__global__ __launch_bounds__(BLOCK) void k_fld_first(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens, u64 n_items,
+                                                     int seq_words, int rec_words, int32_t* tl_out, u32* card_out, u64* cand, u32* n_cand) {
+  const u64 item = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  bool pass = false;
+  if (item < n_items) {
+    const kamd::Table t = make_table(ix, false);
+    const u32* rec = words + item * (u64)(rec_words * 2);
+    u64 slot[2] = {0, 0}; int pos[2] = {0, 0}; bool strand[2] = {false, false}, found[2] = {false, false};
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const u32* rm = rec + m * rec_words;
+      kamd::ReadView r{rm, rm + seq_words, (int)lens[2 * item + m]};
+      r.has_n = (rm[seq_words - 1] & kamd::REC_FLAG_HAS_N) != 0;
+      int w = kamd::next_valid_window(r, 0, ix.k);
+      while (w >= 0) {
+        bool fc; const u64 canon = kamd::window_canon(r, w, ix.k, &fc);
+        const kamd::Probe p = kamd::probe_table(t, canon, fc, nullptr);
+        if (p.found) { slot[m] = p.slot; pos[m] = w; strand[m] = p.strand; found[m] = true; break; }
+        w = kamd::next_valid_window(r, w + 1, ix.k);
+      }
+      if (!found[m]) break;
+    }
+    int32_t tl = -1;
+    if (found[0] && found[1] && strand[0] != strand[1] && ix.slot_block[slot[0]] == ix.slot_block[slot[1]]) {
+      const int d0 = (int)ix.slot_dist[slot[0]], d1 = (int)ix.slot_dist[slot[1]];
+      const int p1 = strand[0] ? d0 - pos[0] : d0 + ix.k + pos[0];
+      const int p2 = strand[1] ? d1 - pos[1] : d1 + ix.k + pos[1];
+      tl = p1 > p2 ? p1 - p2 : p2 - p1;
+    }
+    pass = tl > 0 && tl < KAMD_MAX_FRAG_LEN;
+    tl_out[item] = pass ? tl : -1; card_out[item] = 0;
+  }
+  const u64 bal = __ballot(pass);
+  if (bal) {
+    u32 base = 0;
+    if (lane_id() == 0) base = atomicAdd(n_cand, (u32)__popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (pass) cand[base + __popcll(bal & ((1ULL << lane_id()) - 1))] = item;
+  }
+}
 // (scratch == nullptr: the per-item list of distinct transcript sets lives in LDS, TUPLE_CAP entries; an item that needs more
 // is reported as FLD_OVERFLOW and re-run with a TUPLE_CAP_BIG list in global memory)
 __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                const u64* __restrict__ items, u64 n_items, int seq_words, int rec_words,
-                                               u32* scratch, int cap, FilterDev fd, int32_t* tl_out, u32* card_out) {
+                                               u32* scratch, int cap, FilterDev fd, int32_t* tl_out, u32* card_out,
+                                               const u32* __restrict__ n_items_dev = nullptr) {
   __shared__ u32 lds_list[BLOCK * TUPLE_CAP];
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_items_dev) n_items = *n_items_dev;   // the candidate list of k_fld_first: its length never visits the host
   if (i >= n_items) return;
   const u64 item = items ? items[i] : i;
   const int item_words = rec_words * 2;
@@ -1130,8 +1221,46 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
       }
     }
   }
-  if (ecs.overflow) card = FLD_OVERFLOW;  // re-run by the host with a larger list
+  if (ecs.overflow) {   // re-run by the host with a larger list (counted next to the candidate count, so the host need not search)
+    card = FLD_OVERFLOW;
+    if (n_items_dev) atomicAdd(const_cast<u32*>(n_items_dev) + 1, 1u);
+  }
   tl_out[item] = tl; card_out[item] = card;
+}
+
+// The sample in input order, on the device: out[r] = fragment length of the r-th qualifying pair (|u| == 1, 0 < tl < MAX_FRAG_LEN)
+// of the prefix, r < want; head[2] = qualifying pairs seen (all of them when fewer than `want`).  One block walks the prefix
+// 1024 items at a time and stops when it has enough: the host then reads 40 KB instead of searching two 4 MB vectors.
+constexpr int FLD_RANK_BLOCK = 1024, FLD_RANK_PER = 8;   // 8192 items per trip of the block
+__global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_rank(const int32_t* __restrict__ tl, const u32* __restrict__ card, u64 n, u32 want,
+                                                            int32_t* out, u32* head) {
+  __shared__ u32 wsum[FLD_RANK_BLOCK / 64];
+  const int tid = (int)threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  u32 base = 0;
+  for (u64 b0 = 0; b0 < n && base < want; b0 += (u64)FLD_RANK_BLOCK * FLD_RANK_PER) {
+    const u64 i0 = b0 + (u64)tid * FLD_RANK_PER;
+    int32_t t[FLD_RANK_PER];
+    u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < FLD_RANK_PER; j++) {
+      const u64 i = i0 + j;
+      t[j] = (i < n && card[i] == 1u) ? tl[i] : -1;
+      if (!(t[j] > 0 && t[j] < KAMD_MAX_FRAG_LEN)) t[j] = -1;
+      mine += t[j] > 0;
+    }
+    const u32 incl = wave_incl_scan(mine);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    u32 before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < FLD_RANK_BLOCK / 64; k++) { const u32 x = wsum[k]; total += x; if (k < wv) before += x; }
+    u32 r = base + before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < FLD_RANK_PER; j++) if (t[j] > 0) { if (r < want) out[r] = t[j]; ++r; }
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) head[2] = base;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1922,7 +2051,7 @@ struct kamd_ctx {
   SellCache* sell_cache = nullptr;   // plan of the finalized matrix, kept for bootstrap replicates (allocated on first use)
   u64 ec_generation = 0;         // bumped whenever the finalized EC result is rebuilt (plans of an older result are stale)
   int last_em_plan_cached = 0;
-  DBuf fld_tl, fld_card, fld_scratch, fld_items;
+  DBuf fld_tl, fld_card, fld_scratch, fld_items, fld_cand;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
   hipStream_t fld_stream = nullptr; hipEvent_t fld_ev = nullptr, fld_ev_in = nullptr;
@@ -1973,12 +2102,22 @@ int upload(kamd_ctx* c, const T* host, size_t n, const T** dev) {
 }
 
 // exact de-duplication of records [r0, r1) of a record stream into `table` (capacity cap, power of two)
+// max_probe != 0 (single-launch form only): returns 2 when some record found no slot within max_probe steps -- table too small
 int dedup_records(kamd_ctx* c, const u32* stream, const u64* rec_off, u64 r0, u64 r1, TSlot* table, u64 cap, DBuf& slot_buf,
-                  u64* list, int track = 0, const u64* keys = nullptr) {
+                  u64* list, int track = 0, const u64* keys = nullptr, u32 max_probe = 0, u64 stream_words = ~0ULL) {
   const u64 n = r1 - r0;
   c->host_state.n_list = 0;
   HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_list, &c->host_state.n_list, sizeof(u64), hipMemcpyHostToDevice, c->stream));
   if (n == 0) return 0;
+  if (c->tune.dedup_form != 1 && stream_words < 0xFFFFFFFFULL) {   // one launch (record offsets fit the low half of the tag word)
+    c->host_state.n_retry = 0;
+    HIPC(hipMemcpyAsync(&((DevState*)c->state.p)->n_retry, &c->host_state.n_retry, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_rec_dedup, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, stream, rec_off, r0, n, table, cap - 1, list, keys, track,
+                       max_probe ? max_probe : 0xFFFFFFFFu, (DevState*)c->state.p);
+    HIPC(hipGetLastError());
+    if (int rc = sync_state(c)) return rc;
+    return c->host_state.n_retry ? 2 : 0;
+  }
   if (int rc = slot_buf.ensure(r1 * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = c->retry.ensure(2 * n * sizeof(u64), 0, c->stream)) return rc;
   u64* retry_a = c->retry.as<u64>();
@@ -2020,12 +2159,22 @@ int count_tuples(kamd_ctx* c) {
   const u64 n_recs = c->host_state.n_recs;
   if (c->tuples_counted && c->recs_counted == n_recs) return 0;
   // (re)build from scratch: the table is sized for the final record count
-  c->tcap = pow2_at_least(2 * std::min<u64>(n_recs, c->tuple_bound) + 16);
-  if (int rc = c->ttable.ensure(c->tcap * sizeof(TSlot), 0, c->stream)) return rc;
-  hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
+  // A table for every record would be 2 x 21.7 M slots (2 GB, 0.3 ms to clear, every probe an HBM line) on config #3, where the
+  // records collapse to 2.0 M distinct tuples.  The single-launch form starts with a quarter of the records (64 MB per million
+  // slots: MALL-resident) and a probe limit; only if some record found no slot is the run repeated with four times the slots.
+  const u64 full = pow2_at_least(2 * std::min<u64>(n_recs, c->tuple_bound) + 16);
   if (int rc = c->list.ensure((std::min<u64>(n_recs, c->tuple_bound) + 1) * sizeof(u64), 0, c->stream)) return rc;
-  if (int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot,
-                             c->list.as<u64>(), c->track_order ? 1 : 0)) return rc;
+  u64 cap = c->tune.dedup_form != 1 ? std::min<u64>(full, pow2_at_least(std::min<u64>(n_recs, c->tuple_bound) / 4 + 16)) : full;
+  for (;;) {
+    c->tcap = cap;
+    if (int rc = c->ttable.ensure(c->tcap * sizeof(TSlot), 0, c->stream)) return rc;
+    hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
+    const int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot,
+                                 c->list.as<u64>(), c->track_order ? 1 : 0, nullptr, cap < full ? 64u : 0u, c->host_state.stream_words);
+    if (rc == 2 && cap < full) { cap = std::min<u64>(full, cap * 4); continue; }
+    if (rc) return rc == 2 ? kamd::fail(-101, "dedup_records: table full") : rc;
+    break;
+  }
   c->n_distinct_tuples = c->host_state.n_list;
   c->tuples_counted = true; c->recs_counted = n_recs;
   return 0;
@@ -2039,12 +2188,13 @@ void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->kernel_a = 3; t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
   t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
-  t->em_fin_blocks = 1024;
+  t->em_fin_blocks = 1024; t->dedup_form = 2;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.kernel_a >= 1 && n.kernel_a <= 3) t->kernel_a = n.kernel_a;
   if (n.text_verify == 1 || n.text_verify == 2) t->text_verify = n.text_verify;
+  if (n.dedup_form == 1 || n.dedup_form == 2) t->dedup_form = n.dedup_form;
   if (n.items_per_wave >= 64) t->items_per_wave = n.items_per_wave;
   if (n.refill_min >= 1 && n.refill_min <= 64) t->refill_min = n.refill_min;
   if (n.lds_pad != 0) t->lds_pad = n.lds_pad < 0 ? -1 : n.lds_pad;
@@ -2076,6 +2226,7 @@ void tuning_from_env(kamd_tuning* t) {
   geti("KAMD_EM_LOCAL_KERNEL", &n.em_local_kernel);
   geti("KAMD_EM_LOCAL_BLOCK", &n.em_local_block);
   geti("KAMD_EM_GROUP_DIV", &n.em_group_div);
+  geti("KAMD_DEDUP_FORM", &n.dedup_form);
   geti("KAMD_EM_SPLIT_LEN", &n.em_split_len);
   geti("KAMD_EM_K", &n.em_entries_per_lane);
   onoff("KAMD_EM_WINDOWED", &n.em_windowed);
@@ -2151,7 +2302,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
@@ -2468,26 +2619,37 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
 }
 
 namespace {
-constexpr u64 FLD_FIRST_CHUNK = 524288;
+constexpr u64 FLD_FIRST_CHUNK = 1048576;   // ~20 000 qualifying pairs at config #3's rate: one pass, with a margin for sparser data
 constexpr int FLD_CAP_SMALL = 64;   // list entries per item in global scratch (an LDS list of TUPLE_CAP entries sends too many items to
                                     // the re-run, which costs ~1 ms per launch however few they are)
-// buffers for a prefix of n items + k_fld + the two result copies, all on stream s (no synchronisation)
+// buffers for a prefix of n items + k_fld_first / k_fld / k_fld_rank + the copy of the ranked sample, all on stream s (no synchronisation)
+constexpr u32 FLD_WANT = 10000;   // pairs in the sample (ProcessReads.cpp:981-985)
+int32_t* fld_host_sample(kamd_ctx* c) { return (int32_t*)((u32*)c->fld_host + 2 * c->fld_host_cap + 4); }   // [FLD_WANT], behind the two vectors + head
+u32* fld_host_head(kamd_ctx* c) { return (u32*)c->fld_host + 2 * c->fld_host_cap; }                          // {candidates, list overflows, qualifying}
 int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l, u64 n, int seq_words, int rec_words, hipStream_t s) {
   if (int rc = c->fld_tl.ensure(n * 4, 0, c->stream)) return rc;
   if (int rc = c->fld_card.ensure(n * 4, 0, c->stream)) return rc;
   if (int rc = c->fld_scratch.ensure(n * 2 * FLD_CAP_SMALL * 4, 0, c->stream)) return rc;
-  if (n > c->fld_host_cap) {   // pinned staging for the two result vectors
+  if (n > c->fld_host_cap) {   // pinned staging: the two result vectors (only copied when a class list overflowed), head, ranked sample
     if (c->fld_host) (void)hipHostFree(c->fld_host);
     c->fld_host = nullptr; c->fld_host_cap = 0;
-    if (hipHostMalloc(&c->fld_host, n * 8, hipHostMallocDefault) != hipSuccess) return kamd::fail(-100, "kamd_fld_from_batch: pinned allocation failed");
+    if (hipHostMalloc(&c->fld_host, n * 8 + 16 + FLD_WANT * 4, hipHostMallocDefault) != hipSuccess) return kamd::fail(-100, "kamd_fld_from_batch: pinned allocation failed");
     c->fld_host_cap = n;
   }
-  int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
-  hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, c->ix, w, l, (const u64*)nullptr, n, seq_words, rec_words,
-                     c->fld_scratch.as<u32>(), FLD_CAP_SMALL, fd, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>());
+  // k_fld_first leaves the pairs mapPair gives a usable length for; k_fld (the whole match + |u|) runs on those only
+  if (int rc = c->fld_cand.ensure((n + 2) * 8 + FLD_WANT * 4, 0, c->stream)) return rc;
+  u32* head = (u32*)c->fld_cand.p;                  // {candidates, list overflows, qualifying, -}
+  u64* cand = c->fld_cand.as<u64>() + 2;
+  int32_t* sample = (int32_t*)(cand + n);
+  HIPC(hipMemsetAsync(head, 0, 16, s));
+  hipLaunchKernelGGL(k_fld_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, c->ix, w, l, n, seq_words, rec_words, c->fld_tl.as<int32_t>(),
+                     c->fld_card.as<u32>(), cand, head);
+  hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, c->ix, w, l, (const u64*)cand, n, seq_words, rec_words,
+                     c->fld_scratch.as<u32>(), FLD_CAP_SMALL, fd, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>(), (const u32*)head);
+  hipLaunchKernelGGL(k_fld_rank, dim3(1), dim3(FLD_RANK_BLOCK), 0, s, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>(), n, FLD_WANT, sample, head);
   HIPC(hipGetLastError());
-  HIPC(hipMemcpyAsync(h_tl, c->fld_tl.p, n * 4, hipMemcpyDeviceToHost, s));
-  HIPC(hipMemcpyAsync(h_card, c->fld_card.p, n * 4, hipMemcpyDeviceToHost, s));
+  HIPC(hipMemcpyAsync(fld_host_head(c), head, 16, hipMemcpyDeviceToHost, s));
+  HIPC(hipMemcpyAsync(fld_host_sample(c), sample, FLD_WANT * 4, hipMemcpyDeviceToHost, s));
   return 0;
 }
 }  // namespace
@@ -2553,24 +2715,32 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
       if ((rc = fld_launch(c, fd, w, l, n, seq_words, rec_words, c->stream))) break;
       if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
     }
-    int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
-    // items with more than FLD_CAP_SMALL distinct transcript sets: same kernel again with the large list
-    h_items.clear();
-    for (u64 i = 0; i < n; i++) if (h_card[i] == FLD_OVERFLOW) h_items.push_back(i);
-    if (!h_items.empty()) {
+    // items with more than FLD_CAP_SMALL distinct transcript sets (the head counts them): same kernel again with the large list,
+    // then the sample is taken on the host from the two full vectors
+    const u32* head = fld_host_head(c);
+    if (head[1]) {
+      int32_t* h_tl = (int32_t*)c->fld_host; u32* h_card = (u32*)c->fld_host + n;
+      if (hipMemcpyAsync(h_card, card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+      h_items.clear();
+      for (u64 i = 0; i < n; i++) if (h_card[i] == FLD_OVERFLOW) h_items.push_back(i);
       const u64 no = h_items.size();
       if ((rc = items.ensure(no * 8, 0, c->stream))) break;
-      if ((rc = scratch.ensure(no * 2 * TUPLE_CAP_BIG * 4, 0, c->stream))) break;
+      if ((rc = scratch.ensure(std::max<u64>(no * 2 * TUPLE_CAP_BIG * 4, n * 2 * FLD_CAP_SMALL * 4), 0, c->stream))) break;
       if (hipMemcpyAsync(items.p, h_items.data(), no * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
       hipLaunchKernelGGL(k_fld, dim3(grid_for(no, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, w, l, items.as<u64>(), no, seq_words,
                          rec_words, scratch.as<u32>(), TUPLE_CAP_BIG, fd, tl.as<int32_t>(), card.as<u32>());
       if (hipMemcpyAsync(h_tl, tl.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
           hipMemcpyAsync(h_card, card.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
           hipStreamSynchronize(c->stream) != hipSuccess) { rc = kamd::fail(-100, "k_fld copy failed"); break; }
+      // first 10000 qualifying pairs in input order (ProcessReads.cpp:981-1017,1174-1181 at -t 1)
+      for (u64 i = 0; i < n && found < 10000; i++)
+        if (h_card[i] == 1 && h_tl[i] > 0 && h_tl[i] < KAMD_MAX_FRAG_LEN) { flens[h_tl[i]]++; found++; }
+    } else {
+      // k_fld_rank's list: the qualifying pairs of the prefix in input order
+      const int32_t* smp = fld_host_sample(c);
+      const u32 have = std::min<u32>(head[2], FLD_WANT);
+      for (u32 r = 0; r < have && found < 10000; r++) { flens[smp[r]]++; found++; }
     }
-    // first 10000 qualifying pairs in input order (ProcessReads.cpp:981-1017,1174-1181 at -t 1)
-    for (u64 i = 0; i < n && found < 10000; i++)
-      if (h_card[i] == 1 && h_tl[i] > 0 && h_tl[i] < KAMD_MAX_FRAG_LEN) { flens[h_tl[i]]++; found++; }
     done += n;
     const double rate = std::max((double)(found - found0) / (double)done, 1e-4);
     chunk = std::min<u64>(std::max<u64>((u64)((double)(10000 - std::min<u64>(found, 10000)) / rate * 1.5), 65536), 2097152);
@@ -2734,7 +2904,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->ccap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ctable.as<TSlot>(), c->ccap);
   if (int rc = c->clist.ensure((n_cand + 1) * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = dedup_records(c, c->cand.as<u32>(), c->cand_off.as<u64>(), 0, n_cand, c->ctable.as<TSlot>(), c->ccap, c->cand_slot,
-                             c->clist.as<u64>(), cand_key ? 2 : 0, cand_key)) return rc;
+                             c->clist.as<u64>(), cand_key ? 2 : 0, cand_key, 0, c->host_state.cand_words)) return rc;
   const u64 n_final = c->host_state.n_list;
   if (c->track_order && n_final > 1) {
     // first-occurrence order (what the reference produces at -t 1): sort the distinct sets by the index of the first item
@@ -3299,15 +3469,105 @@ __global__ void k_sell_lens(SellBuild B) {
   if (i < B.R) { const u32 g = sell_group_of(B.row_base, B.n_groups, i); B.rlen[i] = B.row_ptr[(u64)i + g + 1] - B.row_ptr[(u64)i + g]; }
   if (i < B.M) { const u32 g = sell_group_of(B.tr_base, B.n_groups, i); B.clen[i] = B.col_ptr[(u64)i + g + 1] - B.col_ptr[(u64)i + g]; }
 }
-constexpr int SELL_BUILD_BLOCK = 64;   // one thread lays out one group; its three small tables live in LDS, thread-transposed
-__global__ __launch_bounds__(SELL_BUILD_BLOCK) void k_sell_sizes(SellBuild B) {
-  __shared__ u32 scratch[kamd_em_sell::LAYOUT_SCRATCH_WORDS * SELL_BUILD_BLOCK];
-  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+// kamd_em_sell::layout_group for one direction of one group by ONE WAVEFRONT (the header's version is what one thread -- or the CPU
+// emulation -- runs; one thread per group left the chip idle: 1009 threads, ~1 ms per pass).  Same layout rules: split segments
+// first, in the caller's order, never straddling a slice; then the others by decreasing length; a slice's width is its longest
+// lane; slices that hold split lanes carry a word of metadata per lane.  Which of two segments of EQUAL length comes first is
+// decided by an LDS atomic here (by index on the host) -- nothing depends on it: a segment's entries keep their order.
+constexpr int SELL_BUILD_WAVES = 4;    // wavefronts (group directions) per block
+struct SellWaveScratch { u32 hist[kamd_em_sell::SELL_LANES + 1], start[kamd_em_sell::SELL_LANES + 1], cur[kamd_em_sell::SELL_LANES + 1]; };
+template <class Sink>
+__device__ kamd_em_sell::LayoutSize sell_layout_wave(const u32* __restrict__ len, u32 n, u32 cap, Sink& sink, SellWaveScratch& S) {
+  namespace L = kamd_em_sell;
+  const int lane = lane_id();
+  for (u32 b = lane; b <= L::SELL_LANES; b += 64) { S.hist[b] = 0; S.cur[b] = 0; }
+  __builtin_amdgcn_wave_barrier();
+  // 1. histogram of the unsplit lengths; the split segments are laid out as they are met (their order is the caller's)
+  u32 n_split = 0, pos = 0;            // pos: next free absolute lane of the split part (wave-uniform)
+  u32 off = 0;                         // u16 offset of the slice that is open (wave-uniform)
+  u32 width = 0;                       // its width so far
+  u32 mw = 0;                          // this lane's metadata word in the open slice
+  u32 closed = 0;                      // slices closed so far
+  for (u32 c0 = 0; c0 < n; c0 += 64) {
+    const u32 i = c0 + lane;
+    const u32 l = i < n ? len[i] : 0;
+    if (i < n && l <= cap) atomicAdd(&S.hist[l], 1u);
+    u64 m = __ballot(i < n && l > cap);
+    while (m) {
+      const int b = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      const u32 lb = (u32)__shfl((int)l, b, 64);
+      const u32 nv = L::seg_lanes(lb, cap), vl = L::seg_vlen(lb, cap);
+      if ((pos % L::SELL_LANES) + nv > L::SELL_LANES) {   // does not fit: close the slice, the rest of its lanes stay inactive
+        sink.meta(off, lane, mw);
+        if (lane == 0) sink.slice(closed, off | L::DESC_META, width);
+        off += 2 * L::SELL_META_WORDS + width * L::SELL_LANES; ++closed; width = 0; mw = 0;
+        pos = (pos / L::SELL_LANES + 1) * L::SELL_LANES;
+      }
+      if (Sink::wants_segments && lane == b) sink.seg(c0 + b, n_split, pos, nv, vl);
+      const u32 rel = pos % L::SELL_LANES;
+      if ((u32)lane >= rel && (u32)lane < rel + nv) {
+        const u32 v = (u32)lane - rel;
+        mw = n_split | (v << 16) | (v + 1 == nv ? L::META_LAST : 0u) | L::META_ACTIVE;
+      }
+      width = vl > width ? vl : width;
+      pos += nv; ++n_split;
+      if (pos % L::SELL_LANES == 0) {                        // exactly full
+        sink.meta(off, lane, mw);
+        if (lane == 0) sink.slice(closed, off | L::DESC_META, width);
+        off += 2 * L::SELL_META_WORDS + width * L::SELL_LANES; ++closed; width = 0; mw = 0;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const u32 split_lanes = pos;
+  // 2. start lane of every length (decreasing), by lane 0; 64 LDS reads
+  if (lane == 0) { u32 c = split_lanes; for (u32 b = L::SELL_LANES; b >= 1; b--) { S.start[b] = c; c += S.hist[b]; } S.start[0] = c; }
+  __builtin_amdgcn_wave_barrier();
+  const u32 total_lanes = S.start[0];
+  if (Sink::wants_segments) {
+    for (u32 c0 = 0; c0 < n; c0 += 64) {
+      const u32 i = c0 + lane;
+      if (i < n) {
+        const u32 l = len[i];
+        if (l <= cap) { const u32 p = S.start[l] + atomicAdd(&S.cur[l], 1u); sink.seg(i, n_split + (p - split_lanes), p, 1u, l); }
+      }
+    }
+  }
+  // 3. the slice the split part left open takes the longest unsplit segments; then the plain slices, 64 at a time
+  auto len_at = [&](u32 p) -> u32 {   // length of the unsplit segment at absolute lane p (split_lanes <= p < total_lanes)
+    u32 b = L::SELL_LANES;
+    while (b > 1 && !(p >= S.start[b] && p < S.start[b] + S.hist[b])) --b;
+    return b;
+  };
+  const u32 n_slices = (total_lanes + L::SELL_LANES - 1) / L::SELL_LANES;
+  if (split_lanes % L::SELL_LANES) {
+    const u32 lo = closed * L::SELL_LANES, p = lo + (u32)lane;
+    if (split_lanes < total_lanes) { const u32 b = len_at(split_lanes); width = b > width ? b : width; }
+    if (p >= split_lanes && p < total_lanes) mw = (n_split + (p - split_lanes)) | L::META_LAST | L::META_ACTIVE;
+    sink.meta(off, lane, mw);
+    if (lane == 0) sink.slice(closed, off | L::DESC_META, width);
+    off += 2 * L::SELL_META_WORDS + width * L::SELL_LANES; ++closed;
+  }
+  for (u32 s0 = closed; s0 < n_slices; s0 += 64) {
+    const u32 si = s0 + (u32)lane;
+    u32 w = 0;
+    if (si < n_slices) w = len_at(si * L::SELL_LANES);
+    const u32 mine = w * L::SELL_LANES;
+    const u32 incl = wave_incl_scan(mine);
+    if (si < n_slices) sink.slice(si, off + (incl - mine), w | ((n_split + (si * L::SELL_LANES - split_lanes)) << 16));
+    off += (u32)__shfl((int)incl, 63, 64);
+  }
+  return L::LayoutSize{n_slices, off};
+}
+__global__ __launch_bounds__(64 * SELL_BUILD_WAVES) void k_sell_sizes(SellBuild B) {
+  __shared__ SellWaveScratch scr[SELL_BUILD_WAVES];
+  const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) / 64, g = w >> 1;
   if (g >= B.n_groups) return;
   kamd_em_sell::NullSink ns;
-  const kamd_em_sell::LayoutSize lr = kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, ns, scratch + threadIdx.x, SELL_BUILD_BLOCK);
-  const kamd_em_sell::LayoutSize lc = kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, ns, scratch + threadIdx.x, SELL_BUILD_BLOCK);
-  B.gsz[4 * g] = lr.n_slices; B.gsz[4 * g + 1] = lr.n_u16; B.gsz[4 * g + 2] = lc.n_slices; B.gsz[4 * g + 3] = lc.n_u16;
+  const kamd_em_sell::LayoutSize z = (w & 1) ? sell_layout_wave(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, ns, scr[threadIdx.x / 64])
+                                             : sell_layout_wave(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, ns, scr[threadIdx.x / 64]);
+  if (lane_id() == 0) { B.gsz[4 * g + 2 * (w & 1)] = z.n_slices; B.gsz[4 * g + 2 * (w & 1) + 1] = z.n_u16; }
 }
 struct SellDevSink {
   static const bool wants_segments = true;
@@ -3316,14 +3576,17 @@ struct SellDevSink {
   __device__ void slice(u32 i, u32 d0, u32 d1) const { desc[2 * (u64)(desc0 + i)] = d0; desc[2 * (u64)(desc0 + i) + 1] = d1; }
   __device__ void meta(u32 off, u32 l, u32 w) const { ell[ell0 + off + 2 * l] = (uint16_t)w; ell[ell0 + off + 2 * l + 1] = (uint16_t)(w >> 16); }
 };
-__global__ __launch_bounds__(SELL_BUILD_BLOCK) void k_sell_layout(SellBuild B) {
-  __shared__ u32 scratch[kamd_em_sell::LAYOUT_SCRATCH_WORDS * SELL_BUILD_BLOCK];
-  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64 * SELL_BUILD_WAVES) void k_sell_layout(SellBuild B) {
+  __shared__ SellWaveScratch scr[SELL_BUILD_WAVES];
+  const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) / 64, g = w >> 1;
   if (g >= B.n_groups) return;
-  SellDevSink sr{B.rnew, B.rlane, B.rvl, B.rdesc, B.rell, B.row_base[g], B.rslice_base[g], B.rell_base[g]};
-  SellDevSink sc{B.cnew, B.clane, B.cvl, B.cdesc, B.cell, B.tr_base[g], B.cslice_base[g], B.cell_base[g]};
-  kamd_em_sell::layout_group(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, sr, scratch + threadIdx.x, SELL_BUILD_BLOCK);
-  kamd_em_sell::layout_group(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, sc, scratch + threadIdx.x, SELL_BUILD_BLOCK);
+  if (w & 1) {
+    SellDevSink sc{B.cnew, B.clane, B.cvl, B.cdesc, B.cell, B.tr_base[g], B.cslice_base[g], B.cell_base[g]};
+    sell_layout_wave(B.clen + B.tr_base[g], B.tr_base[g + 1] - B.tr_base[g], B.cap, sc, scr[threadIdx.x / 64]);
+  } else {
+    SellDevSink sr{B.rnew, B.rlane, B.rvl, B.rdesc, B.rell, B.row_base[g], B.rslice_base[g], B.rell_base[g]};
+    sell_layout_wave(B.rlen + B.row_base[g], B.row_base[g + 1] - B.row_base[g], B.cap, sr, scr[threadIdx.x / 64]);
+  }
 }
 // entries with the other direction's new ids, and the per-segment constants in the new order; one thread per old segment
 __global__ void k_sell_entries(SellBuild B) {
@@ -3666,7 +3929,7 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   B.rlane = (u32*)(tb + o_rlane); B.clane = (u32*)(tb + o_clane); B.rvl = (u32*)(tb + o_rvl); B.cvl = (u32*)(tb + o_cvl); B.gsz = (u32*)(tb + o_gsz);
   const u64 nseg = std::max(R, M);
   hipLaunchKernelGGL(k_sell_lens, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
-  hipLaunchKernelGGL(k_sell_sizes, dim3(grid_for(ng, SELL_BUILD_BLOCK)), dim3(SELL_BUILD_BLOCK), 0, c->stream, B);
+  hipLaunchKernelGGL(k_sell_sizes, dim3(grid_for(2 * (u64)ng, SELL_BUILD_WAVES)), dim3(64 * SELL_BUILD_WAVES), 0, c->stream, B);
   std::vector<u32> gsz((size_t)ng * 4);
   HIPC(hipMemcpyAsync(gsz.data(), B.gsz, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -3696,7 +3959,7 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   B.rslice_base = (const u32*)(pb + p_rsb); B.cslice_base = (const u32*)(pb + p_csb); B.rell_base = (const u64*)(pb + p_reb); B.cell_base = (const u64*)(pb + p_ceb);
   B.rdesc = (u32*)(pb + p_rd); B.cdesc = (u32*)(pb + p_cdesc); B.rell = (uint16_t*)(pb + p_re); B.cell = (uint16_t*)(pb + p_ce);
   B.cw_new = (u64*)(pb + p_cw); B.single_new = (double*)(pb + p_sg); B.eff_new = (double*)(pb + p_ef); B.tr_id_new = (u32*)(pb + p_id);
-  hipLaunchKernelGGL(k_sell_layout, dim3(grid_for(ng, SELL_BUILD_BLOCK)), dim3(SELL_BUILD_BLOCK), 0, c->stream, B);
+  hipLaunchKernelGGL(k_sell_layout, dim3(grid_for(2 * (u64)ng, SELL_BUILD_WAVES)), dim3(64 * SELL_BUILD_WAVES), 0, c->stream, B);
   hipLaunchKernelGGL(k_sell_entries, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
   HIPC(hipGetLastError());
   P->tr_id.resize(M);

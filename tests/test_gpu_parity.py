@@ -97,6 +97,29 @@ def test_batches_and_idempotence(ka, ctxs):
     assert st["n_processed"] == n and st["n_bucket_reads"] + st["n_text_hits"] >= st["n_probes"] > 0
 
 
+@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("mosaic_pe", "pe_union_fr"), ("yeast_se", "se")])
+def test_two_launch_dedup_agrees(case, variant, ka):
+    """kamd_tuning.dedup_form = 1 (insert + verify launches, the round-1 form) still gives the reference's ECs; the default
+    is the single-launch form every other test runs."""
+    meta, idx_path, r1, r2 = common.load_case(case)
+    o = common.parse_variant(meta["variants"][variant])
+    exp = common.load_expected(case, variant)
+    index = ka.Index(idx_path)
+    ctx = ka.Context(0)
+    try:
+        ctx.upload(index)
+        assert ctx.tune()["dedup_form"] == 2
+        ctx.tune(dedup_form=1)
+        reads = common.interleave(r1, r2 if o["paired"] else None)
+        words, lens, max_len = ctx.pack_reads_host(reads)
+        opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"])
+        res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
+        assert res.ecs.multiset() == exp["ecs"]
+        common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_rf"), ("human_pe", "pe"), ("human_pe", "pe_l180"),
                                           ("yeast_se", "se"), ("yeast_se", "se_fr"), ("tiny_k7_se", "se"), ("mosaic_pe", "pe_nojump"), ("mosaic_pe", "se"),
                                           ("mosaic_pe", "pe_union"), ("mosaic_pe", "pe_union_fr"), ("yeast_se", "se_nojump_rf")])
