@@ -3862,6 +3862,7 @@ struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0; int block = 256;
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
   std::vector<double> h_alpha; int err = 0;
+  const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
   EmSellGpu(kamd_ctx* ctx, const kamd_em_sell::Plan& p) : c(ctx), P(p) {}
   int setup(int chunk, const double* d_eff_new);
   void checkpoint() {
@@ -3878,8 +3879,12 @@ struct EmSellGpu {
     if (err || n <= 0) return;
     if (n > EML_MAX_ROUNDS) { err = -104; return; }
     if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
-    hipLaunchKernelGGL(k_em_sell, dim3(P.n_groups), dim3(block), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    if (P.n_groups) hipLaunchKernelGGL(k_em_sell, dim3(P.n_groups), dim3(block), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
     if (hipGetLastError() != hipSuccess) { err = -104; return; }
+    if (hist && part) {
+      if (hipStreamSynchronize(c->stream) != hipSuccess) { err = -104; return; }
+      if (part->cb(part->user, (int32_t*)d_hist, n)) { err = -103; return; }
+    }
     if (hist && (hipMemcpyAsync(hist, d_hist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                  hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
   }
@@ -3982,8 +3987,13 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   return 0;
 }
 void sell_cache_free(SellCache* k) { delete k; }
+// part (several ranks, each with the rows of the components it owns): the per-round change counts of a chunk are summed over the
+// ranks on the device before the host looks at them (the only coupling between components is the stop rule), and "this form does
+// not apply" is agreed on by all ranks, so that every rank issues the same collectives.
 int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                       const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds) {
+                       const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds,
+                       const EmPartition* part = nullptr) {
+  const bool multi = part && part->world > 1 && part->cb;
   if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
   if (!c->sell_cache) c->sell_cache = new SellCache;
   SellCache& K = *c->sell_cache;
@@ -4008,13 +4018,30 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
     // cut is halved, and a single component beyond the CU's 160 KB makes the form not applicable)
     const u64 lds_budget = 160 * 1024 - 2048;
     int prc = 1;
+    if (multi && n_ecs == 0) {   // a rank that owns no component still takes part in the collectives: an empty plan
+      K.P = kamd_em_sell::Plan{};
+      K.P.T = T; K.P.row_base.assign(1, 0); K.P.tr_base.assign(1, 0); K.P.single_all.assign(T, 0.0);
+      K.dev = EmSellDev{};
+      prc = 0;
+    } else
     for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc == 1; div *= 2) {
       const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
       prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K);
       if (target == 1024) break;
     }
-    if (prc) return prc;
-    if (K.P.n_groups == 0) return 1;
+    if (prc < 0) return prc;
+    bool not_applicable = prc == 1 || (!multi && K.P.n_groups == 0);
+    if (multi) {
+      int flag = not_applicable ? 1 : 0;
+      if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
+      HIPC(hipMemcpyAsync(c->pt_hist.p, &flag, sizeof(int), hipMemcpyHostToDevice, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      if (int rc = part->cb(part->user, (int32_t*)c->pt_hist.p, 1)) return kamd::fail(-103, "kamd_em_run_partitioned: the sum callback failed (" + std::to_string(rc) + ")");
+      HIPC(hipMemcpyAsync(&flag, c->pt_hist.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      not_applicable = flag != 0;
+    }
+    if (not_applicable) return 1;
     if (own) {
       K.valid = true; K.d_ec_off = d_ec_off; K.d_ec_ids = d_ec_ids; K.n_ecs = n_ecs; K.nnz = nnz; K.T = T; K.generation = c->ec_generation;
       K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div;
@@ -4023,7 +4050,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   const kamd_em_sell::Plan& P = K.P;
   const int chunk = EML_MAX_ROUNDS;
   EmSellGpu B(c, P);
-  B.dev = K.dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block;
+  B.dev = K.dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block; B.part = multi ? part : nullptr;
   if (int rc = B.setup(chunk, K.dev.eff)) return rc;
   const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
@@ -4144,11 +4171,11 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
   }
-  if (!spec && n_ecs) {   // EXPERIMENTAL opt-in: the component-local form (kamd_em_local.h)
-    if (c->tune.em_form == 3) {
+  if (n_ecs || spec) {   // the component-local form (kamd_em_local.h); over several ranks only its sliced-ELLPACK kernel
+    if (c->tune.em_form == 3 && (!spec || c->tune.em_local_kernel == 3)) {
       const int rc = c->tune.em_local_kernel == 3
         ? em_sell_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter, (int)min_rounds,
-                             alpha, alpha_before_zeroes, rounds)
+                             alpha, alpha_before_zeroes, rounds, spec ? &part : nullptr)
         : em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
                                          (int)min_rounds, alpha, alpha_before_zeroes, rounds, 2);
       if (rc <= 0) return rc;   // 1 = not applicable (a component does not fit a workgroup): the streamed form takes over

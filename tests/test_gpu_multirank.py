@@ -54,8 +54,15 @@ def _worker(rank, world, port, case, variant, q):
         # EM partitioned over the ranks by connected component (kamd_em_run_comm)
         exp = common.load_expected(case, variant)
         alpha, abz, rounds = ctx.em_run_comm(comm, exp["eff"])
+        # human_pe: the partitioned run used the component-local kernel (em_k == -2) on this rank's components; yeast_se's matrix
+        # is (almost) all singleton rows, where every rank agrees on the streamed form
+        form_k = ctx.profile()["em_k"]
+        assert form_k == -2 or case != "human_pe", form_k
         ctx.tune(em_form="streamed")
-        alpha1, abz1, rounds1 = ctx.em_run(exp["eff"])          # the single-GPU EM on the same ECs (same form as the partitioned run)
+        alpha_s, abz_s, rounds_s = ctx.em_run_comm(comm, exp["eff"])     # the same partitioned run, streamed kernels
+        assert rounds_s == rounds
+        common.assert_abundance_close(alpha_s, alpha, "partitioned EM: streamed vs component-local", rel=1e-9)
+        alpha1, abz1, rounds1 = ctx.em_run(exp["eff"])          # the single-GPU EM on the same ECs (streamed form)
         ctx.tune(em_form="local")
         alpha2, abz2, rounds2 = ctx.em_run(exp["eff"])          # ... and the component-local form
         assert rounds2 == rounds1
