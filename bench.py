@@ -461,7 +461,7 @@ def main():
                          "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
                          "em_rounds": res.em_rounds},
             # dominant kernel by time: kernel A
-            "roofline": {"kernel": {3: "k_match_v3", 2: "k_match_v2", 1: "k_pseudoalign"}[pr["kernel_a_version"]], "bound": "hbm",
+            "roofline": {"kernel": {3: "k_match_v3"}[pr["kernel_a_version"]], "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),

@@ -102,26 +102,24 @@ const char* kamd_index_target_name(const kamd_index*, uint64_t i);
 /* ---- context ---- */
 /* Tuning knobs: which of the equivalent kernels / EM forms run and how they are shaped.  None of them changes a result.
  * kamd_ctx_create sets the defaults (environment variables of the same names in upper case with a KAMD_ prefix, e.g.
- * KAMD_KERNEL_A, KAMD_EM_FORM, are read once there, for experiments); kamd_ctx_tune overrides them for the following calls.
+ * KAMD_TEXT_VERIFY, KAMD_EM_FORM, are read once there, for experiments); kamd_ctx_tune overrides them for the following calls.
  * 0 in a field = keep the current value; on/off fields use 1 = on, 2 = off. */
 typedef struct {
-  int32_t kernel_a;            /* pseudoalignment kernel: 3 = state machines + unitig text (default), 2 = state machines, 1 = block-staged */
-  int32_t text_verify;         /* kernel 3: jump / middle / back-off windows are compared with the unitig text first (default on) */
+  int32_t text_verify;         /* kernel A: jump / middle / back-off windows are compared with the unitig text first (default on) */
   int32_t items_per_wave;      /* items per wavefront chunk of kernel A (default 1024, >= 64) */
   int32_t refill_min;          /* free lanes that trigger a refill (default 8, 1..64) */
   int32_t lds_pad;             /* diagnostic: unused LDS bytes added to every block of kernel A (lowers the occupancy); -1 = none */
-  int32_t em_form;             /* EM: 1 = streamed two-launch form, 2 = CSR three-launch form, 3 = component-local LDS form (falls back
-                                  to 1 when a connected component does not fit a workgroup), default 3 */
-  int32_t em_local_kernel;     /* component-local form: 3 = sliced-ELLPACK layout, one lane per segment (default), 2 = CSR, lanes share rows /
-                                  columns, 1 = CSR, one thread per row / transcript */
+  int32_t em_form;             /* EM: 1 = streamed two-launch form, 2 = CSR three-launch form (also what degenerate matrices -- no row with two
+                                  transcripts -- run), 3 = component-local LDS form (falls back to 1 when a connected component does not
+                                  fit a workgroup), default 3 */
   int32_t em_entries_per_lane; /* streamed form: K in {8,12,...,32}; -1 = automatic (default) */
   int32_t em_windowed;         /* streamed form: force the general windowed pass (test hook; default off) */
   int32_t em_graph;            /* rounds of the streamed / CSR forms replayed as a hipGraph (default on) */
   int32_t em_row_lanes;        /* CSR form: lanes per row, 2 / 4 (default) / 8 */
   int32_t em_fin_blocks;       /* CSR form: blocks of the final pass (default 1024) */
-  int32_t em_local_block;      /* component-local form, kernel 3: threads per workgroup, 128 / 256 / 512 (default) / 1024 */
-  int32_t em_group_div;        /* component-local form, kernel 3: groups hold about nnz / (CUs x this) entries (default 4) */
-  int32_t em_split_len;        /* component-local form, kernel 3: a row / column with more entries is split over several lanes (1..64) */
+  int32_t em_local_block;      /* component-local form: threads per workgroup, 128 / 256 / 512 / 1024 (default) */
+  int32_t em_group_div;        /* component-local form: groups hold about nnz / (CUs x this) entries (default 4) */
+  int32_t em_split_len;        /* component-local form: a row / column with more entries is split over several lanes (1..64) */
   int32_t dedup_form;          /* record de-duplication: 1 = insert + verify launches, 2 = one launch (tag and owner in one CAS; default) */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);

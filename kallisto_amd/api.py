@@ -51,8 +51,7 @@ class _Stats(C.Structure):
 
 class Tuning(C.Structure):
     """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
-    _fields_ = [(n, C.c_int32) for n in ("kernel_a", "text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form",
-                                         "em_local_kernel", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
+    _fields_ = [(n, C.c_int32) for n in ("text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
                                          "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form")]
 
 
@@ -270,7 +269,7 @@ class Context:
         _check(load_library().kamd_ec_reset(self._h), "kamd_ec_reset")
 
     def tune(self, **kw):
-        """kamd_ctx_tune: e.g. tune(kernel_a=2), tune(em_form="streamed", em_entries_per_lane=16).  Returns the tuning in force."""
+        """kamd_ctx_tune: e.g. tune(text_verify=False), tune(em_form="streamed", em_entries_per_lane=16).  Returns the tuning in force."""
         t = Tuning()
         for k, v in kw.items():
             if k == "em_form" and isinstance(v, str):

@@ -1,19 +1,21 @@
 // kamd_kernels.hip -- gfx950 (MI355X) kernels and device-side driver of libkallisto_amd.so.
 //
-// Kernel A  k_match_v2      one resumable KmerIndex::match state machine per lane, ONE table probe per lane per loop
-//                           iteration (bucketed Robin-Hood k-mer table in HBM, one 64-byte line per probe), packed reads and
-//                           per-item class lists in LDS, lanes refill from their wavefront's chunk of items.
+// Kernel A  k_match_v3      one resumable KmerIndex::match state machine per lane, ONE memory access per lane per loop
+//                           iteration (bucketed Robin-Hood k-mer table in HBM, one 64-byte line per probe; the 2-bit unitig text
+//                           answers the probes that stay on the hit's unitig), packed reads and per-item class lists in LDS,
+//                           lanes refill from their wavefront's chunk of items.
 //           k_classify      persistent blocks: classes -> transcript-set ids, intersectKmers' rules, positional filters;
 //                           single-set items -> dense count vector through an LDS cache, tuples rewritten in place.
-//           k_pseudoalign   the first version of kernel A (block-staged, straight-line match per lane), kept for A/B runs
-//                           and as the overflow / explicit-set / FLD code path.
-//           k_rec_insert / k_rec_verify   exact, wait-free de-duplication of variable-length records (tuples of set ids,
-//                           later whole transcript sets): 64-bit tag CAS + owner = smallest record, then content
-//                           verification against the owner; mismatching tags retry under another seed.
+//           k_pseudoalign_overflow / k_explicit_write / k_fld   straight-line match per thread: items with long class lists,
+//                           items whose set a positional filter changed, the fragment-length sample.
+//           k_rec_dedup     exact de-duplication of variable-length records (tuples of set ids, later whole transcript sets) in
+//                           one launch: tag + owner in one CAS, contents compared with the owner's (k_rec_insert / k_rec_verify:
+//                           the two-launch form, for streams beyond 2^32 words).
 //           k_resolve       one 16-lane group per distinct tuple: sorted-set intersection with ballot + popcount prefix
 //                           compaction, on-list mask applied (MinCollector::intersectKmers, ProcessReads.cpp:1072).
-// Kernel B  k_em_*          EM rounds over the EC x transcript matrix (EMAlgorithm::run), FP64, no data atomics;
-//                           partitioned over several GPUs by connected component (em_run_impl).
+// Kernel B  k_em_sell       EM rounds (EMAlgorithm::run, FP64, no data atomics) per group of connected components, out of LDS;
+//           k_pm_* / k_em_*   the streamed and CSR forms (components that do not fit a workgroup; degenerate matrices);
+//                           all forms partition over several GPUs by connected component (em_run_impl).
 //           k_multinomial   bootstrap resampling with LCG skip-ahead (Multinomial::sample).
 //
 // The per-item semantics live in kamd_core.h (shared with the CPU emulation used by the tests).
@@ -239,170 +241,18 @@ __device__ __forceinline__ void emit_item(const DevIndex& ix, const FilterDev& f
   }
 }
 
-template <bool PAIRED, bool FILTER>
-__global__ __launch_bounds__(BLOCK) void k_pseudoalign(DevIndex ix, const u32* __restrict__ words,
-                                                       const uint16_t* __restrict__ lens, u64 n_items, int seq_words,
-                                                       int rec_words, FilterDev fd, AlignOut out) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  const int item_words = rec_words * (PAIRED ? 2 : 1);
-  u32* lds_reads = lds;
-  u32* lds_ecs = lds + (size_t)BLOCK * item_words;
-  const u64 item0 = (u64)blockIdx.x * BLOCK;
-  const int n_valid = (int)min((u64)BLOCK, n_items - item0);
-  // stage this block's packed reads: one contiguous, 16-byte aligned region of HBM -> LDS
-  {
-    const u32* src = words + item0 * item_words;
-    const int total = n_valid * item_words;
-    const int nvec = total >> 2;
-    const uint4* src4 = reinterpret_cast<const uint4*>(src);
-    uint4* dst4 = reinterpret_cast<uint4*>(lds_reads);
-    for (int i = threadIdx.x; i < nvec; i += BLOCK) dst4[i] = src4[i];
-    for (int i = (nvec << 2) + threadIdx.x; i < total; i += BLOCK) lds_reads[i] = src[i];
-  }
-  __syncthreads();
-
-  const int tid = threadIdx.x;
-  const bool active = tid < n_valid;
-  kamd::EcList ecs; ecs.e = lds_ecs + tid * TUPLE_CAP; ecs.cap = TUPLE_CAP; ecs.n = 0; ecs.overflow = false;
-  kamd::MateInfo m0, m1;
-  m0.n_hits = m1.n_hits = 0; m0.n_nonempty = m1.n_nonempty = 0; m0.probes = m1.probes = 0; m0.bucket_reads = m1.bucket_reads = 0;
-  if (active) {
-    const kamd::Table t = make_table(ix, !PAIRED);
-    const u64 item = item0 + tid;
-    const u32* rec = lds_reads + tid * item_words;
-    kamd::ReadView r0{rec, rec + seq_words, PAIRED ? (int)lens[2 * item] : (int)lens[item]};
-    kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r0, ix.k, ecs, m0);
-    if (PAIRED) {
-      kamd::ReadView r1{rec + rec_words, rec + rec_words + seq_words, (int)lens[2 * item + 1]};
-      kamd::match_mate(t, ix.uec_ec, ix.ec_nonempty, r1, ix.k, ecs, m1);
-    }
-  }
-  emit_item<PAIRED, FILTER>(ix, fd, out, ecs, m0, m1, item0 + tid, active);
-  // probe statistics: one atomic per wavefront and counter
-  u64 s_probes = wave_sum64((u64)(m0.probes + m1.probes));
-  u64 s_reads = wave_sum64((u64)(m0.bucket_reads + m1.bucket_reads));
-  if (lane_id() == 0) {
-    atomicAdd(&out.st->st_probes, s_probes);
-    atomicAdd(&out.st->st_bucket_reads, s_reads);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// Kernel A, version 2: one table probe per lane per loop iteration.
-//   k_match_v2   each lane owns a resumable match() state machine (kamd_core.h MatchState); every iteration all busy lanes
-//                issue exactly one bucket load together, and a lane that finishes its item takes the next one of the
-//                wavefront's chunk (LDS cursor), its packed reads being fetched while the others probe.  Reads live in a
-//                lane-transposed LDS layout (word j of lane i at [j*64+i]: conflict-free).  Output: one raw record per
-//                item {header, distinct (unitig,set) classes}.
+// Kernel A: per-lane match() state machines (kamd_core.h MatchState).
+//   k_match_v3   every lane owns a resumable match(); every iteration all busy lanes issue one memory access together, and a
+//                lane that finishes its item takes the next one of the wavefront's chunk, its packed reads being fetched while
+//                the others probe.  Reads live in a lane-transposed LDS layout (word j of lane i at [j*64+i]: conflict-free).
+//                Output: one raw record per item {header, distinct (unitig,set) classes}.
 //   k_classify   one thread per item: classes -> sorted distinct transcript-set ids, then the common emit_item tail.
+// (The two earlier versions -- block-staged reads with a straight-line match per lane, 42 ms; one table probe per iteration with
+// 12-entry lists, 14 ms -- were removed once version 3 had replaced them; the straight-line matcher lives on in the overflow,
+// explicit-set and fragment-length kernels.)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
-
-template <bool PAIRED, bool FILTER, bool DL>
-__global__ __launch_bounds__(BLOCK) void k_match_v2(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
-                                                    u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
-                                                    u32* raw, int raw_stride, DevState* st) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  constexpr int WAVES = BLOCK / 64;
-  const int item_words = rec_words * (PAIRED ? 2 : 1);
-  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  u32* wave_words = lds + (size_t)wv * 64 * item_words;       // the wavefront's items, lane-transposed
-  u32* my_words = wave_words + lane;                          // word j at my_words[j * 64]
-  u32* my_list = lds + (size_t)WAVES * 64 * item_words + (size_t)threadIdx.x * TUPLE_CAP;
-  u32* cursor = lds + (size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP;
-  const u64 wave_global = (u64)blockIdx.x * WAVES + wv;
-  const u64 chunk0 = wave_global * (u64)items_per_wave;
-  const u32 chunk_n = chunk0 < n_items ? (u32)min((u64)items_per_wave, n_items - chunk0) : 0u;
-  if (lane == 0) cursor[wv] = 64u;  // the first 64 items of the chunk are pre-assigned, one per lane
-  const kamd::Table t = make_table(ix, !PAIRED);
-  const int k = ix.k;
-
-  kamd::MatchState ms; ms.phase = kamd::PH_DONE;
-  kamd::UecList ul{my_list, TUPLE_CAP, 0, false};
-  kamd::MateFirst mf0{0, 0, -1, false}, mf1{0, 0, -1, false};
-  int mate = 0, len0 = 0, len1 = 0;
-  u32 my_idx = (u32)lane;
-  bool have = false;      // the lane owns an item whose raw record is not written yet
-  bool busy = false;      // ... and its state machine still wants probes
-  bool exhausted = false, first = true;
-  u32 probes = 0, breads = 0, raw_words = 0;
-
-  for (;;) {
-    // 1. lanes without an item take the next one of the chunk and start fetching its packed reads: LDS-DMA loads
-    // (global_load_lds_dword: every active lane gives its own source address, the data lands at M0 + lane * 4 -- exactly the
-    // lane-transposed layout), no staging registers and no ds_write pass; they are in flight during the probe below
-    bool loading = false;
-    // refills are batched: the (wave-uniform) fetch path runs only when at least REFILL_MIN lanes are free or nothing is
-    // left to probe
-    const u64 idle_mask = __ballot(!have && !exhausted);
-    const bool do_refill = idle_mask != 0ULL && (__popcll(idle_mask) >= refill_min || __ballot(have) == 0ULL);
-    if (do_refill && !have && !exhausted) {
-      if (!first) my_idx = atomicAdd(&cursor[wv], 1u);
-      first = false;
-      if (my_idx >= chunk_n) exhausted = true;
-      else {
-        loading = true;
-        const u64 item = chunk0 + my_idx;
-        const u32* src = words + item * item_words;
-#pragma unroll 4
-        for (int j = 0; j < item_words; j++)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j),
-                                           (__attribute__((address_space(3))) void*)(wave_words + (size_t)j * 64), 4, 0, 0);
-        len0 = PAIRED ? (int)lens[2 * item] : (int)lens[item];
-        len1 = PAIRED ? (int)lens[2 * item + 1] : 0;
-      }
-    }
-    if (__ballot(have || loading) == 0ULL) break;
-    // 2.+3. every busy lane: one probe, then advance its state machine
-    if (have && busy) {
-      const u32* base = my_words + (size_t)(mate ? rec_words : 0) * 64;
-      kamd::ReadView rv{base, base + (size_t)seq_words * 64, mate ? len1 : len0, 64, 64};
-      bool fc;
-      const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
-      const kamd::Probe p = kamd::probe_table(DL ? kamd::phase_table(t, ms.phase) : t, canon, fc, &breads);
-      if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
-      kamd::match_feed<DL>(ms, rv, k, p, ul, mate, mate ? mf1 : mf0, t);
-      if (ms.phase == kamd::PH_DONE && PAIRED && mate == 0) {
-        mate = 1;
-        const u32* b1 = my_words + (size_t)rec_words * 64;
-        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64, 64};
-        kamd::match_init(ms, r1, k);
-      }
-      busy = ms.phase != kamd::PH_DONE;
-    }
-    // 4. lanes that fetched an item: its words are in LDS once the DMA loads have landed; start mate 1
-    if (loading) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ul.n = 0; ul.overflow = false;
-      mf0 = kamd::MateFirst{0, 0, -1, false}; mf1 = kamd::MateFirst{0, 0, -1, false};
-      mate = 0;
-      kamd::ReadView r0{my_words, my_words + (size_t)seq_words * 64, len0, 64, 64};
-      kamd::match_init(ms, r0, k);
-      if (ms.phase == kamd::PH_DONE && PAIRED) {
-        mate = 1;
-        const u32* b1 = my_words + (size_t)rec_words * 64;
-        kamd::ReadView r1{b1, b1 + (size_t)seq_words * 64, len1, 64, 64};
-        kamd::match_init(ms, r1, k);
-      }
-      have = true;
-      busy = ms.phase != kamd::PH_DONE;
-    }
-    // 5. finished items: write the raw record (plain stores, nothing waits for them) and free the lane
-    if (have && !busy) {
-      u32* o = raw + (chunk0 + my_idx) * (u64)raw_stride;
-      o[0] = (u32)ul.n | (ul.overflow ? RAW_OVERFLOW : 0u) | (mf0.n_hits > 0 ? RAW_HIT0 : 0u) | (mf1.n_hits > 0 ? RAW_HIT1 : 0u);
-      for (int j = 0; j < ul.n; j++) o[1 + j] = ul.e[j];
-      raw_words += 1u + (u32)ul.n;
-      if (FILTER) {
-        o[2 + TUPLE_CAP] = (u32)mf0.slot; o[3 + TUPLE_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
-        o[4 + TUPLE_CAP] = (u32)mf1.slot; o[5 + TUPLE_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
-      }
-      have = false;
-    }
-  }
-  const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads), s_raw = wave_sum64((u64)raw_words);
-  if (lane == 0) { atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); atomicAdd(&st->st_raw_words, s_raw); }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Kernel A, version 3: the state machines of version 2, with
@@ -1229,38 +1079,72 @@ __global__ __launch_bounds__(BLOCK) void k_fld(DevIndex ix, const u32* __restric
 }
 
 // The sample in input order, on the device: out[r] = fragment length of the r-th qualifying pair (|u| == 1, 0 < tl < MAX_FRAG_LEN)
-// of the prefix, r < want; head[2] = qualifying pairs seen (all of them when fewer than `want`).  One block walks the prefix
-// 1024 items at a time and stops when it has enough: the host then reads 40 KB instead of searching two 4 MB vectors.
-constexpr int FLD_RANK_BLOCK = 1024, FLD_RANK_PER = 8;   // 8192 items per trip of the block
-__global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_rank(const int32_t* __restrict__ tl, const u32* __restrict__ card, u64 n, u32 want,
-                                                            int32_t* out, u32* head) {
-  __shared__ u32 wsum[FLD_RANK_BLOCK / 64];
-  const int tid = (int)threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  u32 base = 0;
-  for (u64 b0 = 0; b0 < n && base < want; b0 += (u64)FLD_RANK_BLOCK * FLD_RANK_PER) {
-    const u64 i0 = b0 + (u64)tid * FLD_RANK_PER;
-    int32_t t[FLD_RANK_PER];
-    u32 mine = 0;
+// of the prefix, r < want; head[2] = qualifying pairs of the prefix.  The host then reads 40 KB instead of searching two 4 MB
+// vectors.  Three small launches (count per block of 8192 items, scan of the block counts, emit): a single block walking the
+// prefix was starved by kernel A, which runs at the same time (5.6 ms for 65 trips).
+constexpr int FLD_RANK_BLOCK = 1024, FLD_RANK_PER = 8;   // 8192 items per block
+__device__ __forceinline__ u32 fld_rank_load(const int32_t* __restrict__ tl, const u32* __restrict__ card, u64 n, u64 i0, int32_t* t) {
+  u32 mine = 0;
 #pragma unroll
-    for (int j = 0; j < FLD_RANK_PER; j++) {
-      const u64 i = i0 + j;
-      t[j] = (i < n && card[i] == 1u) ? tl[i] : -1;
-      if (!(t[j] > 0 && t[j] < KAMD_MAX_FRAG_LEN)) t[j] = -1;
-      mine += t[j] > 0;
-    }
-    const u32 incl = wave_incl_scan(mine);
+  for (int j = 0; j < FLD_RANK_PER; j++) {
+    const u64 i = i0 + j;
+    t[j] = (i < n && card[i] == 1u) ? tl[i] : -1;
+    if (!(t[j] > 0 && t[j] < KAMD_MAX_FRAG_LEN)) t[j] = -1;
+    mine += t[j] > 0;
+  }
+  return mine;
+}
+__global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_count(const int32_t* __restrict__ tl, const u32* __restrict__ card, u64 n, u32* blk) {
+  __shared__ u32 tot;
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  int32_t t[FLD_RANK_PER];
+  const u32 mine = fld_rank_load(tl, card, n, ((u64)blockIdx.x * FLD_RANK_BLOCK + threadIdx.x) * FLD_RANK_PER, t);
+  const u32 w = (u32)wave_sum64(mine);
+  if (lane_id() == 0 && w) atomicAdd(&tot, w);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_scan(u32* blk, u32 n_blk, u32* head) {   // one block; n_blk <= a few hundred
+  __shared__ u32 wsum[FLD_RANK_BLOCK / 64];
+  __shared__ u32 carry_s;
+  const int tid = (int)threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 b0 = 0; b0 < n_blk; b0 += FLD_RANK_BLOCK) {
+    const u32 i = b0 + (u32)tid;
+    const u32 v = i < n_blk ? blk[i] : 0;
+    const u32 incl = wave_incl_scan(v);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     u32 before = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < FLD_RANK_BLOCK / 64; k++) { const u32 x = wsum[k]; total += x; if (k < wv) before += x; }
-    u32 r = base + before + incl - mine;
-#pragma unroll
-    for (int j = 0; j < FLD_RANK_PER; j++) if (t[j] > 0) { if (r < want) out[r] = t[j]; ++r; }
-    base += total;
+    const u32 carry = carry_s;
+    if (i < n_blk) blk[i] = carry + before + incl - v;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + total;
     __syncthreads();
   }
-  if (tid == 0) head[2] = base;
+  if (tid == 0) head[2] = carry_s;
+}
+__global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_emit(const int32_t* __restrict__ tl, const u32* __restrict__ card, u64 n, u32 want,
+                                                            const u32* __restrict__ blk, int32_t* out) {
+  __shared__ u32 wsum[FLD_RANK_BLOCK / 64];
+  const u32 base = blk[blockIdx.x];
+  if (base >= want) return;
+  const int tid = (int)threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  int32_t t[FLD_RANK_PER];
+  const u32 mine = fld_rank_load(tl, card, n, ((u64)blockIdx.x * FLD_RANK_BLOCK + threadIdx.x) * FLD_RANK_PER, t);
+  const u32 incl = wave_incl_scan(mine);
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  u32 before = 0;
+#pragma unroll
+  for (int k = 0; k < FLD_RANK_BLOCK / 64; k++) if (k < wv) before += wsum[k];
+  u32 r = base + before + incl - mine;
+#pragma unroll
+  for (int j = 0; j < FLD_RANK_PER; j++) if (t[j] > 0) { if (r < want) out[r] = t[j]; ++r; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2071,7 +1955,7 @@ struct kamd_ctx {
   hipEvent_t ev2 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   float last_finalize_ms = 0.f; u64 last_fin_records = 0, last_fin_stream_words = 0, last_fin_cand_words = 0;
   hipStream_t em_stream = nullptr;
-  int kernel_a_version = 3, items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
+  int items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
   bool had_overflow_items = false;   // some item went through the overflow kernel (tuples of more than TUPLE_CAP sets may exist)
@@ -2186,20 +2070,18 @@ int count_tuples(kamd_ctx* c) {
 namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
-  t->kernel_a = 3; t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_kernel = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
+  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
-  if (n.kernel_a >= 1 && n.kernel_a <= 3) t->kernel_a = n.kernel_a;
   if (n.text_verify == 1 || n.text_verify == 2) t->text_verify = n.text_verify;
   if (n.dedup_form == 1 || n.dedup_form == 2) t->dedup_form = n.dedup_form;
   if (n.items_per_wave >= 64) t->items_per_wave = n.items_per_wave;
   if (n.refill_min >= 1 && n.refill_min <= 64) t->refill_min = n.refill_min;
   if (n.lds_pad != 0) t->lds_pad = n.lds_pad < 0 ? -1 : n.lds_pad;
   if (n.em_form >= 1 && n.em_form <= 3) t->em_form = n.em_form;
-  if (n.em_local_kernel >= 1 && n.em_local_kernel <= 3) t->em_local_kernel = n.em_local_kernel;
   if (n.em_local_block == 128 || n.em_local_block == 256 || n.em_local_block == 512 || n.em_local_block == 1024) t->em_local_block = n.em_local_block;
   if (n.em_split_len >= 1 && n.em_split_len <= 64) t->em_split_len = n.em_split_len;
   if (n.em_group_div >= 1 && n.em_group_div <= 1024) t->em_group_div = n.em_group_div;
@@ -2214,7 +2096,6 @@ void tuning_from_env(kamd_tuning* t) {
   kamd_tuning n; memset(&n, 0, sizeof n);
   auto geti = [](const char* name, int32_t* dst) { if (const char* e = getenv(name)) *dst = atoi(e); };
   auto onoff = [](const char* name, int32_t* dst) { if (const char* e = getenv(name)) *dst = atoi(e) != 0 ? 1 : 2; };
-  geti("KAMD_KERNEL_A", &n.kernel_a);
   onoff("KAMD_TEXT_VERIFY", &n.text_verify);
   geti("KAMD_ITEMS_PER_WAVE", &n.items_per_wave);
   geti("KAMD_REFILL_MIN", &n.refill_min);
@@ -2223,7 +2104,6 @@ void tuning_from_env(kamd_tuning* t) {
     const std::string v(e);
     n.em_form = v == "streamed" ? 1 : v == "csr" ? 2 : v == "local" ? 3 : atoi(e);
   }
-  geti("KAMD_EM_LOCAL_KERNEL", &n.em_local_kernel);
   geti("KAMD_EM_LOCAL_BLOCK", &n.em_local_block);
   geti("KAMD_EM_GROUP_DIV", &n.em_group_div);
   geti("KAMD_DEDUP_FORM", &n.dedup_form);
@@ -2242,7 +2122,7 @@ void apply_quant_opts(kamd_ctx* c, const kamd_quant_opts* o) {
   c->ix.comprehensive = (o->strand != 0 && (o->no_jump || o->do_union)) ? 1 : 0;   // ProcessReads.cpp:1139-1140
 }
 void apply_tuning(kamd_ctx* c) {
-  c->kernel_a_version = c->tune.kernel_a; c->items_per_wave = c->tune.items_per_wave; c->refill_min = c->tune.refill_min;
+  c->items_per_wave = c->tune.items_per_wave; c->refill_min = c->tune.refill_min;
 }
 }  // namespace
 
@@ -2273,7 +2153,6 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
 
 extern "C" int kamd_ctx_tune(kamd_ctx* c, const kamd_tuning* t) {
   if (!c || !t) return kamd::fail(-1, "kamd_ctx_tune: null argument");
-  if (t->kernel_a == 1 && c->track_order) return kamd::fail(-1, "kamd_ctx_tune: first-occurrence EC ids need kernel A version 2 or 3");
   tuning_merge(&c->tune, *t);
   apply_tuning(c);
   return 0;
@@ -2385,51 +2264,6 @@ extern "C" int kamd_pack_reads_device(kamd_ctx* c, const char* d_seqs, const uin
 }
 
 namespace {
-template <bool PAIRED, bool FILTER>
-int launch_align(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, size_t lds_bytes,
-                 const FilterDev& fd, const AlignOut& out) {
-  HIPC(hipFuncSetAttribute((const void*)k_pseudoalign<PAIRED, FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((k_pseudoalign<PAIRED, FILTER>), dim3(grid_for(n_items, BLOCK)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words,
-                     d_len, n_items, seq_words, rec_words, fd, out);
-  return 0;
-}
-template <bool PAIRED, bool FILTER>
-int launch_align_v2(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
-                    AlignOut& out) {
-  constexpr int WAVES = BLOCK / 64;
-  const int item_words = rec_words * (PAIRED ? 2 : 1);
-  const int stride = 2 + TUPLE_CAP + (FILTER ? 4 : 0);
-  // every item owns a fixed slot of the stream: raw record from k_match_v2, rewritten in place by k_classify
-  const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
-  if (int rc = c->stream_buf.ensure((cur_words + n_items * (u64)stride) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
-  if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
-  out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-  c->host_state.stream_words = cur_words + n_items * (u64)stride;
-  c->host_state.n_recs = cur_recs + n_items;
-  if (int rc = push_state(c)) return rc;
-  size_t lds_bytes = ((size_t)WAVES * 64 * item_words + (size_t)BLOCK * TUPLE_CAP + WAVES) * sizeof(u32);
-  if (lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-resident kernel");
-  // diagnostics: unused LDS per block lowers the number of resident wavefronts (how sensitive is kernel A to occupancy?)
-  if (c->tune.lds_pad > 0) lds_bytes = std::min<size_t>(160 * 1024, lds_bytes + (size_t)c->tune.lds_pad);
-  const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
-  u32* slots = c->stream_buf.as<u32>() + cur_words;
-  HIPC(hipEventRecord(c->ev0, c->stream));
-  if (c->ix.n_dbuckets) {
-    HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER, true>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
-                       n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
-  } else {
-    HIPC(hipFuncSetAttribute((const void*)k_match_v2<PAIRED, FILTER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((k_match_v2<PAIRED, FILTER, false>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len,
-                       n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);
-  }
-  HIPC(hipEventRecord(c->ev1, c->stream));
-  const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
-  hipLaunchKernelGGL((k_classify<PAIRED, FILTER, TUPLE_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
-                     fd, out);
-  HIPC(hipEventRecord(c->ev2, c->stream));
-  return 0;
-}
 // items whose reads do not fit the LDS-resident kernel: every item is flagged for the overflow kernel, which reads from HBM
 __global__ void k_mark_overflow(u32* raw, int raw_stride, u64 n_items) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2495,17 +2329,12 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     // (the reference itself aborts there: findPosition looks the union's transcripts up in the first mapping k-mer's set,
     // "Index not present in SparseVector")
     return kamd::fail(-5, "kamd_pseudoalign: --single with --union needs --single-overhang");
-  if ((o->do_union || (o->no_jump && o->strand)) && c->kernel_a_version == 1)
-    return kamd::fail(-5, "kamd_pseudoalign: --union and the per-hit strand filter need kernel A version 2 or 3");
   apply_quant_opts(c, o);
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pseudoalign: max_len must be in [1, 65535]");
   if (n_items == 0) return 0;
   HIPC(hipSetDevice(c->device));
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
-  const int item_words = rec_words * (o->paired ? 2 : 1);
-  const size_t lds_bytes = (size_t)BLOCK * item_words * 4 + (size_t)BLOCK * TUPLE_CAP * 4;
-  if (c->kernel_a_version == 1 && lds_bytes > 160 * 1024) return kamd::fail(-4, "kamd_pseudoalign: reads too long for the LDS-staged kernel");
   // positional filters (ProcessReads.cpp:1095-1145): has_mean_fl is set by -l only, and while the reads are processed
   // mean_fl is the -l value itself (MinCollector constructor, MinCollector.h:38-41; the truncated-Gaussian mean of
   // init_mean_fl_trunc -- 199.99999999999994 for -l 200 -s 25 -- replaces it only after ProcessReads, main.cpp:2668-2671);
@@ -2525,28 +2354,11 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   AlignOut out{c->dense.as<u32>(), c->track_order ? c->dense_first.as<u64>() : nullptr, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
                c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
   int rc = 0;
-  if (c->kernel_a_version == 1) HIPC(hipEventRecord(c->ev0, c->stream));
-  if (c->kernel_a_version == 3) {
-    if (o->paired) rc = filter ? launch_align_v3<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
-                               : launch_align_v3<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
-    else rc = filter ? launch_align_v3<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
-                     : launch_align_v3<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
-    if (rc) return rc;
-  } else if (c->kernel_a_version == 2) {
-    if (o->paired) rc = filter ? launch_align_v2<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
-                               : launch_align_v2<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
-    else rc = filter ? launch_align_v2<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
-                     : launch_align_v2<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
-    if (rc) return rc;
-  } else {
-    if (o->paired) rc = filter ? launch_align<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
-                               : launch_align<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
-    else rc = filter ? launch_align<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out)
-                     : launch_align<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, lds_bytes, fd, out);
-    if (rc) return rc;
-    HIPC(hipEventRecord(c->ev1, c->stream));
-    HIPC(hipEventRecord(c->ev2, c->stream));
-  }
+  if (o->paired) rc = filter ? launch_align_v3<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
+                             : launch_align_v3<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+  else rc = filter ? launch_align_v3<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
+                   : launch_align_v3<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+  if (rc) return rc;
   HIPC(hipGetLastError());
   if (int rc2 = sync_state(c)) return rc2;
   HIPC(hipEventElapsedTime(&c->last_align_ms, c->ev0, c->ev1));
@@ -2559,7 +2371,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
     out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-    const u64 ov_base = c->kernel_a_version >= 2 ? cur_recs : ~0ULL;
+    const u64 ov_base = cur_recs;
     if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
                      else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
     else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
@@ -2637,7 +2449,7 @@ int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l
     c->fld_host_cap = n;
   }
   // k_fld_first leaves the pairs mapPair gives a usable length for; k_fld (the whole match + |u|) runs on those only
-  if (int rc = c->fld_cand.ensure((n + 2) * 8 + FLD_WANT * 4, 0, c->stream)) return rc;
+  if (int rc = c->fld_cand.ensure((n + 2) * 8 + FLD_WANT * 4 + (n / (FLD_RANK_BLOCK * FLD_RANK_PER) + 2) * 4, 0, c->stream)) return rc;
   u32* head = (u32*)c->fld_cand.p;                  // {candidates, list overflows, qualifying, -}
   u64* cand = c->fld_cand.as<u64>() + 2;
   int32_t* sample = (int32_t*)(cand + n);
@@ -2646,7 +2458,11 @@ int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l
                      c->fld_card.as<u32>(), cand, head);
   hipLaunchKernelGGL(k_fld, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, c->ix, w, l, (const u64*)cand, n, seq_words, rec_words,
                      c->fld_scratch.as<u32>(), FLD_CAP_SMALL, fd, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>(), (const u32*)head);
-  hipLaunchKernelGGL(k_fld_rank, dim3(1), dim3(FLD_RANK_BLOCK), 0, s, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>(), n, FLD_WANT, sample, head);
+  const u32 n_blk = (u32)grid_for(n, FLD_RANK_BLOCK * FLD_RANK_PER);
+  u32* blk = (u32*)(sample + FLD_WANT);
+  hipLaunchKernelGGL(k_fld_count, dim3(n_blk), dim3(FLD_RANK_BLOCK), 0, s, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>(), n, blk);
+  hipLaunchKernelGGL(k_fld_scan, dim3(1), dim3(FLD_RANK_BLOCK), 0, s, blk, n_blk, head);
+  hipLaunchKernelGGL(k_fld_emit, dim3(n_blk), dim3(FLD_RANK_BLOCK), 0, s, c->fld_tl.as<int32_t>(), c->fld_card.as<u32>(), n, FLD_WANT, blk, sample);
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(fld_host_head(c), head, 16, hipMemcpyDeviceToHost, s));
   HIPC(hipMemcpyAsync(fld_host_sample(c), sample, FLD_WANT * 4, hipMemcpyDeviceToHost, s));
@@ -2831,7 +2647,6 @@ extern "C" int kamd_ec_explicit_replace(kamd_ctx* c, const uint32_t* d_words, ui
 // ---- finalize ---------------------------------------------------------------------------------------------------------
 extern "C" int kamd_ec_track_order(kamd_ctx* c, int on) {
   if (!c) return kamd::fail(-1, "kamd_ec_track_order: null context");
-  if (on && c->kernel_a_version < 2) return kamd::fail(-1, "kamd_ec_track_order: needs kernel A version 2 or 3 (records in input order)");
   if (c->host_state.st_processed != 0) return kamd::fail(-1, "kamd_ec_track_order: call before the first batch (or after kamd_ec_reset)");
   c->track_order = on != 0;
   return 0;
@@ -3185,147 +3000,18 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   return 0;
 }
 
-// ---- component-local EM (kamd_em_local.h), EXPERIMENTAL: only with KAMD_EM_LOCAL=1, not yet run on hardware -----------------
-// One workgroup per group of connected components; the group's whole state lives in LDS for the n_rounds of a launch (see
-// the header).  The plan is still built on the host here (download of the CSR + build_plan_host): good enough to bring the
-// kernel up, far too slow to be the default -- the device-side set-up is the next step.
-constexpr int EML_BLOCK = 256;
+// ---- component-local EM (kamd_em_local.h) -------------------------------------------------------------------------------------
+// One workgroup per group of connected components; the group's whole state lives in LDS for the rounds of a launch.  The plan
+// is built on the device (em_local_setup_device) as a CSR in both directions and converted to the sliced-ELLPACK layout the
+// kernel iterates (kamd_em_sell.h).  (Two earlier kernels that iterated the CSR directly -- one thread per row, then 8 / 16
+// lanes per row / column -- were instruction-bound, ~7 000 wavefront instructions per group and round, and were removed.)
 struct EmLocalDev {
   const u32* row_base; const u32* tr_base; const u64* nz_base;
   const u32* row_ptr; const u32* col_ptr; const uint16_t* row_tr; const uint16_t* col_row;
   const u64* cw; const double* single; const double* eff;
   const u32* tr_id = nullptr;   // (device-built plans only)
 };
-__global__ __launch_bounds__(EML_BLOCK) void k_em_local(EmLocalDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char eml_smem[];
-  __shared__ int s_ch;
-  const u32 g = blockIdx.x, tid = threadIdx.x;
-  const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
-  const u64 z0 = P.nz_base[g];
-  const u32 nz = (u32)(P.nz_base[g + 1] - z0);
-  // the layout kamd_em_local::group_bytes() prices: 8-byte arrays, then 4-byte, then 2-byte
-  double* s_al0 = reinterpret_cast<double*>(eml_smem);
-  double* s_a0 = s_al0 + nT; double* s_al1 = s_a0 + nT; double* s_a1 = s_al1 + nT;
-  double* s_single = s_a1 + nT; double* s_eff = s_single + nT; double* s_g = s_eff + nT;
-  u64* s_cw = reinterpret_cast<u64*>(s_g + nR);
-  u32* s_rowptr = reinterpret_cast<u32*>(s_cw + nR); u32* s_colptr = s_rowptr + nR + 1;
-  uint16_t* s_rowtr = reinterpret_cast<uint16_t*>(s_colptr + nT + 1); uint16_t* s_colrow = s_rowtr + nz;
-  for (u32 i = tid; i < nT; i += EML_BLOCK) { s_al0[i] = alpha[t0 + i]; s_a0[i] = a[t0 + i]; s_single[i] = P.single[t0 + i]; s_eff[i] = P.eff[t0 + i]; }
-  for (u32 i = tid; i < nR; i += EML_BLOCK) s_cw[i] = P.cw[r0 + i];
-  for (u32 i = tid; i <= nR; i += EML_BLOCK) s_rowptr[i] = P.row_ptr[r0 + g + i];
-  for (u32 i = tid; i <= nT; i += EML_BLOCK) s_colptr[i] = P.col_ptr[t0 + g + i];
-  for (u32 i = tid; i < nz; i += EML_BLOCK) { s_rowtr[i] = P.row_tr[z0 + i]; s_colrow[i] = P.col_row[z0 + i]; }
-  __syncthreads();
-  const kamd_em_local::Group G{nR, nT, s_rowptr, s_rowtr, s_colptr, s_colrow, reinterpret_cast<const uint64_t*>(s_cw), s_single, s_eff};
-  double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
-  for (int r = 0; r < n_rounds; r++) {
-    if (tid == 0) s_ch = 0;
-    kamd_em_local::rows_pass(G, tid, EML_BLOCK, al, av, clamp, s_g);
-    __syncthreads();
-    const int ch = kamd_em_local::cols_pass(G, tid, EML_BLOCK, al, av, clamp, s_g, aln, avn);
-    if (ch) atomicAdd(&s_ch, ch);
-    __syncthreads();
-    if (tid == 0 && hist && s_ch) atomicAdd(&hist[r], s_ch);
-    double* t1 = al; al = aln; aln = t1;
-    double* t2 = av; av = avn; avn = t2;
-  }
-  for (u32 i = tid; i < nT; i += EML_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
-}
-// The same rounds with the work of a group spread over all lanes: a row is summed by 8 lanes, a column by 16 (one DPP row),
-// partial sums meet through row_shl adds; the divisions (g = count / S, a = next / eff) run lane-parallel in a second step
-// over values staged in LDS.  Every wavefront owns a contiguous range of the group's rows and transcripts, so the two steps
-// of a pass only need a wavefront-level fence between them: two block barriers per round.
-constexpr int EML2_BLOCK = 512;
-constexpr int EML_MAX_ROUNDS = 64;
-__device__ __forceinline__ void eml_wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__global__ __launch_bounds__(EML2_BLOCK) void k_em_local2(EmLocalDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char eml_smem[];
-  __shared__ int s_hist[EML_MAX_ROUNDS];
-  constexpr int NW = EML2_BLOCK / 64;
-  const u32 g = blockIdx.x, tid = threadIdx.x;
-  const int lane = lane_id(), wv = (int)(tid >> 6);
-  const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
-  const u64 z0 = P.nz_base[g];
-  const u32 nz = (u32)(P.nz_base[g + 1] - z0);
-  double* s_al0 = reinterpret_cast<double*>(eml_smem);
-  double* s_a0 = s_al0 + nT; double* s_al1 = s_a0 + nT; double* s_a1 = s_al1 + nT;
-  double* s_single = s_a1 + nT; double* s_eff = s_single + nT; double* s_g = s_eff + nT;
-  u64* s_cw = reinterpret_cast<u64*>(s_g + nR);
-  u32* s_rowptr = reinterpret_cast<u32*>(s_cw + nR); u32* s_colptr = s_rowptr + nR + 1;
-  uint16_t* s_rowtr = reinterpret_cast<uint16_t*>(s_colptr + nT + 1); uint16_t* s_colrow = s_rowtr + nz;
-  for (u32 i = tid; i < nT; i += EML2_BLOCK) {
-    double al = alpha[t0 + i], av = a[t0 + i];
-    if (clamp && al < 1e-7 / 10.0) { al = 0.0; av = 0.0; }   // the final round reads alpha < alpha_limit / 10 as 0 (:212-221)
-    s_al0[i] = al; s_a0[i] = av; s_single[i] = P.single[t0 + i]; s_eff[i] = P.eff[t0 + i];
-  }
-  for (u32 i = tid; i < nR; i += EML2_BLOCK) s_cw[i] = P.cw[r0 + i];
-  for (u32 i = tid; i <= nR; i += EML2_BLOCK) s_rowptr[i] = P.row_ptr[r0 + g + i];
-  for (u32 i = tid; i <= nT; i += EML2_BLOCK) s_colptr[i] = P.col_ptr[t0 + g + i];
-  for (u32 i = tid; i < nz; i += EML2_BLOCK) { s_rowtr[i] = P.row_tr[z0 + i]; s_colrow[i] = P.col_row[z0 + i]; }
-  if (tid < EML_MAX_ROUNDS) s_hist[tid] = 0;
-  __syncthreads();
-  const u32 rlo = (u32)((u64)nR * wv / NW), rhi = (u32)((u64)nR * (wv + 1) / NW);
-  const u32 tlo = (u32)((u64)nT * wv / NW), thi = (u32)((u64)nT * (wv + 1) / NW);
-  double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
-  for (int r = 0; r < n_rounds; r++) {
-    // rows, step 1: S_e by 8 lanes per row
-    for (u32 rb = rlo; rb < rhi; rb += 8) {
-      const u32 row = rb + (u32)(lane >> 3);
-      const int sub = lane & 7;
-      const bool ok = row < rhi;
-      const u32 b = ok ? s_rowptr[row] : 0u, e = ok ? s_rowptr[row + 1] : 0u;
-      double S = 0.0;
-      for (u32 j = b + sub; j < e; j += 8) S += av[s_rowtr[j]];
-      S += pm_dpp<0x104, 0xF>(S); S += pm_dpp<0x102, 0xF>(S); S += pm_dpp<0x101, 0xF>(S);   // row_shl:4,2,1 -> lanes 0 and 8 of a DPP row
-      if (ok && sub == 0) s_g[row] = S;
-    }
-    eml_wave_fence();
-    // rows, step 2: g_e = count_e / S_e; rows the reference skips get 0 (count 0, :133-135; denom below denorm_min, :156-158)
-    for (u32 row = rlo + (u32)lane; row < rhi; row += 64) {
-      const double S = s_g[row];
-      const u64 w = s_cw[row];
-      const u32 cnt = (u32)w, wc = (u32)(w >> 32);
-      s_g[row] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
-    }
-    __syncthreads();
-    // columns, step 1: sum of g over the transcript's rows by 16 lanes, staged in the next-alpha buffer
-    for (u32 tb = tlo; tb < thi; tb += 4) {
-      const u32 t = tb + (u32)(lane >> 4);
-      const int sub = lane & 15;
-      const bool ok = t < thi;
-      const u32 b = ok ? s_colptr[t] : 0u, e = ok ? s_colptr[t + 1] : 0u;
-      double acc = 0.0;
-      for (u32 j = b + sub; j < e; j += 16) acc += s_g[s_colrow[j]];
-      acc += pm_dpp<0x108, 0xF>(acc); acc += pm_dpp<0x104, 0xF>(acc); acc += pm_dpp<0x102, 0xF>(acc); acc += pm_dpp<0x101, 0xF>(acc);
-      if (ok && sub == 0) aln[t] = acc;
-    }
-    eml_wave_fence();
-    // columns, step 2: next_t = single_t + a_t * acc_t and the convergence test of :176-199
-    int ch = 0;
-    for (u32 t = tlo + (u32)lane; t < thi; t += 64) {
-      const double acc = aln[t], at = av[t], cur = al[t];
-      const double nx = s_single[t] + at * acc;
-      if (nx > 1e-2 && (fabs(nx - cur) / nx) > 1e-2) ++ch;
-      aln[t] = nx;
-      avn[t] = nx / s_eff[t];
-    }
-    if (__ballot(ch != 0)) {
-      int wsum = ch;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
-      if (lane == 0) atomicAdd(&s_hist[r], wsum);
-    }
-    __syncthreads();
-    double* t1 = al; al = aln; aln = t1;
-    double* t2 = av; av = avn; avn = t2;
-  }
-  for (u32 i = tid; i < nT; i += EML2_BLOCK) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
-  if (hist && (int)tid < n_rounds && s_hist[tid]) atomicAdd(&hist[tid], s_hist[tid]);
-}
+constexpr int EML_MAX_ROUNDS = 64;   // rounds per launch (the per-group change history of a launch lives in LDS)
 // ---- component-local EM over the sliced-ELLPACK layout (kamd_em_sell.h) ---------------------------------------------------
 // One workgroup per group, the whole group in LDS for the rounds of a launch.  A wavefront takes whole slices: lane l walks
 // the entries of its segment at stream[j * 64 + l] (u16 local index -> gather of an FP64 value, padding points at a zero slot),
@@ -3632,77 +3318,7 @@ __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   else if constexpr (S == 7) kamd_em_local::step_group_j(i, A);
   else kamd_em_local::step_rows_k(i, A);
 }
-// the backend of kamd_em_local::run on the device; every method returns through `err` (0 = ok)
-struct EmLocalGpu {
-  kamd_ctx* c; const kamd_em_local::Plan& P; EmLocalDev dev{}; u64 M = 0; size_t lds = 0;
-  double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
-  std::vector<double> h_alpha; int err = 0; int hist_cap = 0;
-  bool dev_ready = false;   // `dev` already points at a plan built on the device (em_local_setup_device)
-  int kernel = 2;           // 2 = k_em_local2 (lanes share rows / columns), 1 = k_em_local (one thread per row / transcript)
-  EmLocalGpu(kamd_ctx* ctx, const kamd_em_local::Plan& p) : c(ctx), P(p) {}
-  int setup(int chunk);
-  void checkpoint() {
-    if (err) return;
-    if (hipMemcpyAsync(d_ck_alpha, d_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
-        hipMemcpyAsync(d_ck_a, d_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
-  }
-  void restore() {
-    if (err) return;
-    if (hipMemcpyAsync(d_alpha, d_ck_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
-        hipMemcpyAsync(d_a, d_ck_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
-  }
-  void run(int n, int clamp, int* hist) {
-    if (err || n <= 0) return;
-    if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
-    if (kernel == 2 && n <= EML_MAX_ROUNDS)
-      hipLaunchKernelGGL(k_em_local2, dim3(P.n_groups), dim3(EML2_BLOCK), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
-    else
-      hipLaunchKernelGGL(k_em_local, dim3(P.n_groups), dim3(EML_BLOCK), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
-    if (hipGetLastError() != hipSuccess) { err = -104; return; }
-    if (hist && (hipMemcpyAsync(hist, d_hist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                 hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
-  }
-  const std::vector<double>& host_alpha() {
-    h_alpha.resize(M);
-    if (!err && (hipMemcpyAsync(h_alpha.data(), d_alpha, M * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                 hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
-    return h_alpha;
-  }
-};
-int EmLocalGpu::setup(int chunk) {
-  const u32 ng = P.n_groups;
-  M = P.tr_base[ng];
-  const u64 R = P.row_base[ng], NZ = P.nz_base[ng];
-  if (!dev_ready) {   // upload the host-built plan
-    Carver cv;
-    const size_t o_rb = cv.take((ng + 1) * 4), o_tb = cv.take((ng + 1) * 4), o_zb = cv.take((ng + 1) * 8);
-    const size_t o_rp = cv.take((R + ng) * 4), o_cp = cv.take((M + ng) * 4), o_rt = cv.take(NZ * 2 + 2), o_cr = cv.take(NZ * 2 + 2);
-    const size_t o_cw = cv.take(R * 8 + 8), o_sg = cv.take(M * 8 + 8), o_ef = cv.take(M * 8 + 8);
-    if (int rc = c->pm_a.ensure(cv.off, 0, c->stream)) return rc;
-    char* b = (char*)c->pm_a.p;
-    auto up = [&](size_t o, const void* src, size_t bytes) -> int { if (bytes) HIPC(hipMemcpyAsync(b + o, src, bytes, hipMemcpyHostToDevice, c->stream)); return 0; };
-    if (up(o_rb, P.row_base.data(), (ng + 1) * 4) || up(o_tb, P.tr_base.data(), (ng + 1) * 4) || up(o_zb, P.nz_base.data(), (ng + 1) * 8) ||
-        up(o_rp, P.row_ptr.data(), (R + ng) * 4) || up(o_cp, P.col_ptr.data(), (M + ng) * 4) || up(o_rt, P.row_tr.data(), NZ * 2) ||
-        up(o_cr, P.col_row.data(), NZ * 2) || up(o_cw, P.cw.data(), R * 8) || up(o_sg, P.single.data(), M * 8) || up(o_ef, P.eff.data(), M * 8))
-      return -104;
-    dev = EmLocalDev{(const u32*)(b + o_rb), (const u32*)(b + o_tb), (const u64*)(b + o_zb), (const u32*)(b + o_rp), (const u32*)(b + o_cp),
-                     (const uint16_t*)(b + o_rt), (const uint16_t*)(b + o_cr), (const u64*)(b + o_cw), (const double*)(b + o_sg),
-                     (const double*)(b + o_ef)};
-  }
-  Carver sv;
-  const size_t o_al = sv.take(M * 8 + 8), o_a = sv.take(M * 8 + 8), o_cka = sv.take(M * 8 + 8), o_ckb = sv.take(M * 8 + 8), o_h = sv.take((size_t)chunk * 4 + 8);
-  if (int rc = c->pm_b.ensure(sv.off, 0, c->stream)) return rc;
-  char* sb = (char*)c->pm_b.p;
-  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = (double*)(sb + o_cka); d_ck_a = (double*)(sb + o_ckb); d_hist = (int*)(sb + o_h);
-  if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, dev.eff, M, 1.0 / (double)P.T);
-  HIPC(hipGetLastError());
-  HIPC(hipStreamSynchronize(c->stream));                    // (also: the uploads above read host vectors)
-  lds = (size_t)P.max_group_bytes + 16;
-  HIPC(hipFuncSetAttribute((const void*)k_em_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPC(hipFuncSetAttribute((const void*)k_em_local2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  return 0;
-}
-// The plan built on the device (KAMD_EM_LOCAL=2): component labels by the kernels the partitioned EM uses, then the steps of
+// The plan built on the device: component labels by the kernels the partitioned EM uses, then the steps of
 // kamd_em_local.h with scans in between.  The host only sees the per-group sizes (budget check, bases) and, for the final
 // scatter, tr_id and the singleton counts.  0 = ok (P holds the host part, *dev the device part), 1 = not applicable.
 int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
@@ -4064,50 +3680,6 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   if (rounds) *rounds = r;
   return 0;
 }
-// 0 = done, 1 = not applicable (the caller takes the streamed form), < 0 = error
-int em_local_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                        const double* eff_lens, u64 T, int n_iter, int min_rounds, double* alpha, double* abz, int32_t* rounds, int level) {
-  if (c->n_cus == 0) { int v = 0; HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->n_cus = v > 0 ? v : 256; }
-  kamd_em_local::Plan P;
-  // two workgroups per CU (LDS: 160 KB): groups of at most 80 KB, cut at nnz / (2 x CUs) entries; if some group comes out
-  // larger (components are not split), the cut is halved
-  const u64 budget = 80 * 1024 - 1024;
-  EmLocalDev dev{};
-  HIPC(hipEventRecord(c->ev0, c->stream));
-  int prc = 1;
-  for (u64 div = 2; div <= 256 && prc == 1; div *= 2) {
-    const u64 target = std::max<u64>(2048, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
-    if (level >= 2) {   // the plan built on the device
-      prc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, budget, target, &P, &dev);
-    } else {            // bring-up: the plan built on the host from a download of the CSR
-      std::vector<uint64_t> off(n_ecs + 1); std::vector<u32> ids(std::max<u64>(nnz, 1)), cnt(n_ecs), wcn(n_ecs);
-      HIPC(hipMemcpyAsync(off.data(), d_ec_off, (n_ecs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-      if (nnz) HIPC(hipMemcpyAsync(ids.data(), d_ec_ids, nnz * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipMemcpyAsync(cnt.data(), d_counts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipMemcpyAsync(wcn.data(), d_wcounts, n_ecs * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
-      prc = kamd_em_local::build_plan_host(off.data(), ids.data(), cnt.data(), wcn.data(), n_ecs, eff_lens, T, budget, target, &P);
-    }
-    if (target == 2048) break;
-  }
-  if (prc) return prc;
-  if (P.n_groups == 0) return 1;
-  const int chunk = 64;
-  EmLocalGpu B(c, P);
-  if (level >= 2) { B.dev = dev; B.dev_ready = true; }
-  B.kernel = c->tune.em_local_kernel == 1 ? 1 : 2;
-  if (int rc = B.setup(chunk)) return rc;
-  const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
-  if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
-  HIPC(hipEventRecord(c->ev1, c->stream));
-  HIPC(hipEventSynchronize(c->ev1));
-  HIPC(hipEventElapsedTime(&c->last_em_ms, c->ev0, c->ev1));
-  c->last_em_iters = (uint64_t)r + (r < n_iter ? 1 : 0);
-  c->last_em_nnz = nnz; c->last_em_k = -1; c->last_em_grid = P.n_groups; c->last_em_necs = n_ecs;
-  if (rounds) *rounds = r;
-  return 0;
-}
-
 int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
                 const uint32_t* d_weight_counts, uint64_t n_ecs, const double* eff_lens, uint64_t n_targets, uint32_t n_iter,
                 uint32_t min_rounds, double* alpha, double* alpha_before_zeroes, int32_t* rounds, const EmPartition& part) {
@@ -4172,12 +3744,9 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     HIPC(hipStreamSynchronize(c->stream));
   }
   if (n_ecs || spec) {   // the component-local form (kamd_em_local.h); over several ranks only its sliced-ELLPACK kernel
-    if (c->tune.em_form == 3 && (!spec || c->tune.em_local_kernel == 3)) {
-      const int rc = c->tune.em_local_kernel == 3
-        ? em_sell_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter, (int)min_rounds,
-                             alpha, alpha_before_zeroes, rounds, spec ? &part : nullptr)
-        : em_local_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter,
-                                         (int)min_rounds, alpha, alpha_before_zeroes, rounds, 2);
+    if (c->tune.em_form == 3) {
+      const int rc = em_sell_run_device(c, (const u64*)d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, (int)n_iter, (int)min_rounds,
+                                        alpha, alpha_before_zeroes, rounds, spec ? &part : nullptr);
       if (rc <= 0) return rc;   // 1 = not applicable (a component does not fit a workgroup): the streamed form takes over
     }
   }
@@ -4448,7 +4017,7 @@ extern "C" int kamd_debug_random_lines(kamd_ctx* c, uint32_t n_blocks, uint32_t 
 extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   if (!c || !p) return kamd::fail(-1, "kamd_profile_get: null argument");
   p->last_align_kernel_ms = c->last_align_ms; p->last_em_ms = c->last_em_ms; p->last_em_iters = c->last_em_iters;
-  p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = c->kernel_a_version;
+  p->last_classify_ms = c->last_classify_ms; p->kernel_a_version = 3;
   p->last_em_nnz = c->last_em_nnz; p->last_em_nnz_multi = c->last_em_nnz_multi; p->last_em_nseg = c->last_em_nseg; p->last_em_necs = c->last_em_necs;
   p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid; p->last_em_lds = c->last_em_lds; p->last_em_plan_cached = c->last_em_plan_cached;
   p->last_finalize_ms = c->last_finalize_ms; p->last_fin_records = c->last_fin_records; p->last_fin_stream_words = c->last_fin_stream_words;

@@ -211,21 +211,21 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local2", "local1", "hub"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "hub"])
 def test_em_forms_agree_with_oracle(k, ka):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
-    with more segment ends than LDS slots, forced), the CSR form, and the component-local LDS form (both kernels) on a matrix
+    with more segment ends than LDS slots, forced), the CSR form, and the component-local LDS form (workgroup sizes, split length) on a matrix
     of gene-sized components; "fallback": the component-local form asked for on a matrix whose hub component does not fit a
     workgroup -- the streamed form must take over."""
     import torch
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
-    if k in ("local", "local512", "local2", "local1"):
+    if k in ("local", "local512", "local1024s8"):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
-        tune = dict(em_form="local", em_local_kernel={"local": 3, "local512": 3, "local2": 2, "local1": 1}[k],
-                    em_local_block=512 if k == "local512" else 256, em_group_div=64)
+        tune = dict(em_form="local", em_local_block={"local": 256, "local512": 512, "local1024s8": 1024}[k], em_group_div=64,
+                    em_split_len=8 if k == "local1024s8" else 32)
         k = "local"
     elif k == "hub":
         tune = dict(em_form="local")
