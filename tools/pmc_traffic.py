@@ -6,7 +6,7 @@ usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collec
 
 Writes <out_dir>/<prefix>_pmc_fetch_size_per_kernel.csv, <out_dir>/<prefix>_pmc_write_size_per_kernel.csv and
 <out_dir>/traffic.json (read by bench.py into roofline.traffic):
-    kernel_a_hbm_bytes = (FETCH_SIZE + WRITE_SIZE) x 1024 B of the one k_match_v2 launch
+    kernel_a_hbm_bytes = (FETCH_SIZE + WRITE_SIZE) x 1024 B of the one k_match_v3 launch
     em_round_hbm_bytes = the same for the EM pass kernels, summed, divided by the number of rounds
 Both counters are in KB.  Raw values are used (no x2): see profiles/README.md for the calibration against the kernel's
 own count of 64-byte bucket reads."""
@@ -55,7 +55,7 @@ def main():
         k.startswith("k_pm_cols_fix") or k.startswith("k_em_rows") or k.startswith("k_em_seg") or k.startswith("k_em_final") or \
         k.startswith("k_em_sell") or k.startswith("k_em_local")
     em_kb = kb(em_pred)
-    fin_pred = lambda k: k.startswith("k_rec_insert") or k.startswith("k_rec_verify") or k.startswith("k_bound_") or k.startswith("k_resolve") or \
+    fin_pred = lambda k: k.startswith("k_rec_dedup") or k.startswith("k_rec_insert") or k.startswith("k_rec_verify") or k.startswith("k_bound_") or k.startswith("k_resolve") or \
         k.startswith("k_cand_singles") or k.startswith("k_final_") or k.startswith("k_table_init") or k.startswith("k_scan_")
     fin_kb = kb(fin_pred)
     calls = res["fetch"][1]
@@ -67,7 +67,7 @@ def main():
            "kernel_a_hbm_bytes": int(a_kb * 1024), "em_round_hbm_bytes": int(em_kb * 1024 / rounds), "em_rounds_in_pass": rounds,
            "em_launches_in_pass": local_launches, "finalize_hbm_bytes": int(fin_kb * 1024),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py --steps 1 --warmup 0), per launch = "
-                     "(FETCH_SIZE + WRITE_SIZE) x 1024 B, raw counters (no x2: the dominant traffic of k_match_v2 is random 64-byte "
+                     "(FETCH_SIZE + WRITE_SIZE) x 1024 B, raw counters (no x2: the dominant traffic of kernel A is random 64-byte "
                      "bucket lines, for which FETCH_SIZE matched the kernel's own count of 64 B x bucket reads to 2.5 %; see "
                      "profiles/README.md); EM: all launches of the EM kernels / rounds executed (component-local form: the per-launch "
                      "load and store of the groups, nothing per round); finalize: the kernels of kamd_ec_finalize, one step"}
