@@ -205,6 +205,9 @@ int kamd_profile_get(kamd_ctx*, kamd_profile* out);
  * practical ceiling of kernel A's probe stream (profiles/README.md) */
 int kamd_debug_random_lines(kamd_ctx*, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, double* gbytes_per_s,
                             double* mlines_per_s);
+/* the same with the reads confined to the first span_mb MiB of the table (0 = all) and 64- or 8-byte accesses: HBM vs MALL vs L2 */
+int kamd_debug_random_lines_span(kamd_ctx*, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, uint32_t span_mb,
+                                 uint32_t access_bytes, double* gbytes_per_s, double* mlines_per_s);
 
 /* ---- EC state exchange (multi-GPU; one process per GPU, the caller runs the collectives) ----
  * The EC state is (a) a dense count vector over index transcript sets and (b) a list of (tuple of index set ids,

@@ -101,6 +101,8 @@ _SYMBOLS = {
     "kamd_align_stats_get": (C.c_int, [C.c_void_p, C.POINTER(_Stats)]),
     "kamd_profile_get": (C.c_int, [C.c_void_p, C.POINTER(_Profile)]),
     "kamd_debug_random_lines": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "kamd_debug_random_lines_span": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double)]),
     "kamd_ec_dense_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kamd_ec_tuples_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -348,9 +350,11 @@ class Context:
         _check(load_library().kamd_align_stats_get(self._h, C.byref(s)), "kamd_align_stats_get")
         return {n: int(getattr(s, n)) for n, _ in _Stats._fields_}
 
-    def random_lines(self, n_blocks: int, block_threads: int = 256, iters: int = 256):
+    def random_lines(self, n_blocks: int, block_threads: int = 256, iters: int = 256, span_mb: int = 0, access_bytes: int = 64):
+        """Diagnostic: (GB/s, M lines/s) of dependent random reads of the k-mer table (span_mb: only its first MiB; access_bytes 64 / 8)."""
         g, m = C.c_double(0), C.c_double(0)
-        _check(load_library().kamd_debug_random_lines(self._h, n_blocks, block_threads, iters, C.byref(g), C.byref(m)), "kamd_debug_random_lines")
+        _check(load_library().kamd_debug_random_lines_span(self._h, n_blocks, block_threads, iters, span_mb, access_bytes, C.byref(g), C.byref(m)),
+               "kamd_debug_random_lines_span")
         return g.value, m.value
 
     def profile(self) -> dict:

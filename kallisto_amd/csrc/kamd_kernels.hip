@@ -3981,29 +3981,41 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
 // Every lane follows a dependent chain of random 64-byte bucket reads (4 x 16 B, the probe's loads) with nothing in
 // between: the rate this reaches at a given occupancy is the practical roofline of kernel A's probe stream.
 namespace {
+template <int WORDS>   // 8: the whole 64-byte line (4 x 16-byte loads), 1: one 8-byte word of it
 __global__ void k_random_lines(const u64* __restrict__ table, u64 n_buckets, int iters, u64* sink) {
   const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 x = kamd::mix64(gid + 1);
   u64 acc = 0;
   for (int i = 0; i < iters; i++) {
     const u64 b = __umul64hi(x, n_buckets);
-    const ulonglong2* bp = (const ulonglong2*)(table + b * 8);
-    const ulonglong2 s0 = bp[0], s1 = bp[1], s2 = bp[2], s3 = bp[3];   // (the whole 64-byte bucket)
-    const u64 v = s0.x ^ s0.y ^ s1.x ^ s1.y ^ s2.x ^ s2.y ^ s3.x ^ s3.y;
+    u64 v;
+    if (WORDS == 8) {
+      const ulonglong2* bp = (const ulonglong2*)(table + b * 8);
+      const ulonglong2 s0 = bp[0], s1 = bp[1], s2 = bp[2], s3 = bp[3];   // (the whole 64-byte bucket)
+      v = s0.x ^ s0.y ^ s1.x ^ s1.y ^ s2.x ^ s2.y ^ s3.x ^ s3.y;
+    } else v = table[b * 8 + (x & 7)];
     acc ^= v;
     x = kamd::mix64(x ^ v);  // the next address depends on the loaded line
   }
   if (acc == 0x1234567ULL) sink[0] = acc;
 }
 }  // namespace
-extern "C" int kamd_debug_random_lines(kamd_ctx* c, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, double* gbytes_per_s,
-                                       double* mlines_per_s) {
+// span_mb: the reads fall into the first span_mb MiB of the table (0 = all of it) -- how does the rate depend on the footprint
+// (HBM vs the 256 MB MALL vs L2)?  access_bytes: 64 (whole line) or 8 (one word of it).
+extern "C" int kamd_debug_random_lines_span(kamd_ctx* c, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, uint32_t span_mb,
+                                            uint32_t access_bytes, double* gbytes_per_s, double* mlines_per_s) {
   if (!c || !c->has_index) return kamd::fail(-1, "kamd_debug_random_lines: no context / index");
   HIPC(hipSetDevice(c->device));
   if (int rc = c->sizes.ensure(64, 0, c->stream)) return rc;
-  hipLaunchKernelGGL(k_random_lines, dim3(n_blocks), dim3(block_threads), 0, c->stream, c->ix.table, c->ix.n_buckets, 8, c->sizes.as<u64>());
+  u64 nb = c->ix.n_buckets;
+  if (span_mb) nb = std::min<u64>(nb, (u64)span_mb * 1024 * 1024 / 64);
+  auto launch = [&](int it) {
+    if (access_bytes == 8) hipLaunchKernelGGL(k_random_lines<1>, dim3(n_blocks), dim3(block_threads), 0, c->stream, c->ix.table, nb, it, c->sizes.as<u64>());
+    else hipLaunchKernelGGL(k_random_lines<8>, dim3(n_blocks), dim3(block_threads), 0, c->stream, c->ix.table, nb, it, c->sizes.as<u64>());
+  };
+  launch(8);
   HIPC(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL(k_random_lines, dim3(n_blocks), dim3(block_threads), 0, c->stream, c->ix.table, c->ix.n_buckets, (int)iters, c->sizes.as<u64>());
+  launch((int)iters);
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipEventSynchronize(c->ev1));
   float ms = 0.f;
@@ -4012,6 +4024,10 @@ extern "C" int kamd_debug_random_lines(kamd_ctx* c, uint32_t n_blocks, uint32_t 
   if (mlines_per_s) *mlines_per_s = lines / (ms * 1e-3) / 1e6;
   if (gbytes_per_s) *gbytes_per_s = lines * 64.0 / (ms * 1e-3) / 1e9;
   return 0;
+}
+extern "C" int kamd_debug_random_lines(kamd_ctx* c, uint32_t n_blocks, uint32_t block_threads, uint32_t iters, double* gbytes_per_s,
+                                       double* mlines_per_s) {
+  return kamd_debug_random_lines_span(c, n_blocks, block_threads, iters, 0, 64, gbytes_per_s, mlines_per_s);
 }
 
 extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
