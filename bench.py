@@ -427,6 +427,18 @@ def main():
                     "algorithmic_bytes_per_launch": int(fin_bytes), "launch_ms": round(f_ms, 3),
                     "note": "dependent gathers (table slot -> owner record -> set offsets -> members): latency-, not bandwidth-bound"}
         unit_name = "pairs" if paired else "reads"
+        # what the memory system gives the kernel's access pattern: dependent random 64-byte reads of the k-mer table (measured live;
+        # the rate does not depend on the footprint or the access size -- profiles/README.md); the kernel's requests are its
+        # bucket lines + text reads + the packed reads
+        ceiling = None
+        try:
+            g_s, _ = ctx.random_lines(256 * 6, 256, 256)
+            req_bytes = 64.0 * (st["n_bucket_reads"] + st["n_text_hits"])
+            line_gbs = (req_bytes + n * per * rec * 4.0) / (a_ms * 1e-3) / 1e9
+            ceiling = {"GB/s_in_64B_lines": round(g_s, 1), "kernel_GB/s_in_64B_lines": round(line_gbs, 1), "frac": round(line_gbs / g_s, 4),
+                       "note": "kamd_debug_random_lines at 24 wavefronts/CU; a request-rate ceiling (same for 64 MB .. 2.4 GB footprints, 8 .. 64 B accesses)"}
+        except Exception as e:   # diagnostic only
+            ceiling = {"error": str(e)}
         out = {
             "metric": "M paired-end reads/sec quantified (human txome index)" if paired else "M single-end reads/sec quantified (yeast-sized index)",
             "value": round(total_items / elapsed / 1e6, 4),
@@ -467,7 +479,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(a_ms, 3),
                          "launch": "one k_match_v3 launch over the step's batch, HIP events on the context stream (the FLD kernel of the first "
                                    "prefix runs underneath it on a side stream)",
-                         "table_line_bytes_per_launch": int(64 * st["n_bucket_reads"]), "text_bytes_per_launch": int(12 * st["n_text_hits"])},
+                         "table_line_bytes_per_launch": int(64 * st["n_bucket_reads"]), "text_bytes_per_launch": int(12 * st["n_text_hits"]),
+                         "random_line_ceiling": ceiling},
             "roofline_em": em_roof,
             "roofline_finalize": fin_roof,
         }

@@ -352,3 +352,29 @@ def test_degenerate_batches(ka, ctxs):
     from oracle import oracle as O
     u, _, _ = O.Index(idx_path).pseudoalign(O.Opts(1, 0.0, 0.0, 0, 0), r1[0], r2[0])
     assert ecs.multiset() == ({tuple(u): 1} if u else {})
+
+
+@pytest.mark.parametrize("paired,n_join", [(1, 6), (0, 15), (1, 2)])
+def test_long_reads(paired, n_join, ka, ctxs):
+    """Reads longer than kernel A keeps in LDS (mates of more than ~480 bases, single reads of more than ~980) take the
+    HBM-resident matcher for the whole batch (the reference has no read-length limit); (1, 2) stays in LDS at 200
+    bases.  Long reads are made by repeating fixture reads."""
+    from oracle import oracle as O
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    index, ctx = ctxs("human_pe")
+    n = 300
+    # copies of one read with a spacer of N's: every piece hits the same transcripts, so the intersection is not empty
+    join = lambda rs, i: (rs[i] + b"NN") * (n_join - 1) + rs[i]
+    a = [join(r1, i) for i in range(n)]
+    b = [join(r2, i)[: len(a[i]) - 7 * (i % 3)] for i in range(n)]          # ragged mates
+    reads = common.interleave(a, b if paired else None)
+    max_len = max(len(x) for x in reads)
+    assert (max_len > 480 * (2 - paired) + 20) == (n_join > 2), max_len
+    opts = ka.QuantOpts(paired, 0.0 if paired else 200.0, 0.0 if paired else 20.0, 1, 0)
+    words, lens, ml = ctx.pack_reads_host(reads, max_len)
+    ctx.pseudoalign(opts, words, lens, n, ml)
+    ecs = ctx.finalize()
+    buf, off, ln = O.pack_reads(reads)
+    res = O.process_reads(O.Index(idx_path), O.Opts(paired, 0.0 if paired else 200.0, 0.0 if paired else 20.0, 1, 0, 0, 0), buf, off, ln)
+    want = {tuple(res.ec_ids[res.ec_off[i]:res.ec_off[i + 1]].tolist()): int(res.counts[i]) for i in range(len(res.counts)) if res.counts[i]}
+    assert ecs.multiset() == want and len(want) > 0
