@@ -538,8 +538,18 @@ def main():
             out["bootstrap"] = boot
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        # tear down in order while everything is alive: the library's communicator (ncclCommDestroy), the context, then torch's
+        # process group; the interpreter's own shutdown order is not one a C++ runtime survives reliably, and the line is printed
+        try:
+            comm = getattr(ctx, "_comm", None)
+            if comm is not None:
+                comm.close()
+            ctx.close()
+            dist.barrier()
+            dist.destroy_process_group()
+        finally:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
