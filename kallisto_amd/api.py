@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -648,8 +649,19 @@ class Comm:
         if dist.get_backend(group) != "nccl" or os.environ.get("KAMD_COMM") == "callbacks":
             return cls.over_process_group(ctx, group)
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        # RCCL inside the library; if the library cannot get at RCCL at all (no librccl to dlopen -- the same on every rank of a
+        # node) the same collectives run through torch.distributed's nccl backend as callbacks
+        try:
+            uid = cls.unique_id() if rank == 0 else None
+            ok = 1
+        except KallistoAmdError as e:
+            uid, ok = None, 0
+            if rank == 0:
+                print(f"[kallisto_amd] RCCL not reachable from the library ({e}); using torch.distributed callbacks", file=sys.stderr)
+        box = [uid, ok]
         dist.broadcast_object_list(box, src=0, group=group)
+        if not box[1]:
+            return cls.over_process_group(ctx, group)
         return cls.rccl(ctx, rank, world, box[0])
 
     def broadcast_np(self, arr: np.ndarray, root: int = 0) -> np.ndarray:
