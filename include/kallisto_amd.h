@@ -95,6 +95,10 @@ const char* kamd_last_error(void);
 
 /* ---- S1: index ---- */
 int kamd_index_load(const char* path, int threads, kamd_index** out);
+/* The flattened tables as a file: building them from a kallisto index takes seconds; kamd_index_save writes them once and
+ * kamd_index_load recognises such a file by its magic and reads it back with plain reads (same kamd_index).  Native byte order,
+ * format-versioned; not a replacement for the kallisto index, which stays the source of truth. */
+int kamd_index_save(const kamd_index*, const char* path);
 void kamd_index_free(kamd_index*);
 int kamd_index_get_view(const kamd_index*, kamd_index_view* out);
 const char* kamd_index_target_name(const kamd_index*, uint64_t i);

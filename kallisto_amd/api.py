@@ -80,6 +80,7 @@ _SYMBOLS = {
     "kamd_last_error": (C.c_char_p, []),
     "kamd_index_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "kamd_index_free": (None, [C.c_void_p]),
+    "kamd_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "kamd_index_get_view": (C.c_int, [C.c_void_p, C.POINTER(_View)]),
     "kamd_index_target_name": (C.c_char_p, [C.c_void_p, C.c_uint64]),
     "kamd_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -224,6 +225,10 @@ class Index:
         """(ec_off, ec_ids) of the de-duplicated index transcript sets (host views)."""
         v = self.view
         return _np(v.ec_off, v.n_ecs + 1, np.uint64), _np(v.ec_ids, v.ec_nnz, np.uint32)
+
+    def save(self, path: str):
+        """kamd_index_save: the flattened tables as a file that Index(path) / kamd_index_load reads back without rebuilding them."""
+        _check(load_library().kamd_index_save(self._h, path.encode()), "kamd_index_save")
 
     def close(self):
         if getattr(self, "_h", None):

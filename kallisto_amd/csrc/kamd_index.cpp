@@ -151,11 +151,89 @@ inline void for_each_kmer(const uint8_t* packed, uint64_t len, int k, F&& f) {
 
 }  // namespace
 
+// ---- the flattened index as a file (kamd_index_save / kamd_index_load on such a file) ------------------------------------------
+// Building the device tables from a kallisto index takes seconds (enumerate the k-mers of every unitig twice, hash, place); a
+// front-end that runs sample after sample against one index can write them once and read them back with plain reads.  Layout:
+// magic, format version, the scalars, then every array as {u64 count, bytes}; native endianness, for this machine's eyes only.
+namespace {
+const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '1'};
+struct FlatOut {
+  FILE* f; bool ok = true;
+  void raw(const void* p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+  template <class T> void scalar(const T& x) { raw(&x, sizeof x); }
+  template <class T> void vec(const std::vector<T>& v) { const uint64_t n = v.size(); scalar(n); raw(v.data(), n * sizeof(T)); }
+};
+struct FlatIn {
+  FILE* f; bool ok = true;
+  void raw(void* p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
+  template <class T> void scalar(T& x) { raw(&x, sizeof x); }
+  template <class T> void vec(std::vector<T>& v) {
+    uint64_t n = 0; scalar(n);
+    if (!ok || n > (1ULL << 40) / sizeof(T)) { ok = false; return; }
+    v.resize(n); raw(v.data(), n * sizeof(T));
+  }
+};
+template <class IO> void flat_fields(IO& io, kamd_index& x) {
+  io.scalar(x.k); io.scalar(x.n_kmers); io.scalar(x.n_unitigs); io.scalar(x.n_long); io.scalar(x.n_short); io.scalar(x.n_abund); io.scalar(x.dlist_size);
+  io.scalar(x.n_targets); io.scalar(x.n_buckets); io.scalar(x.pad_buckets); io.scalar(x.text_bases);
+  io.scalar(x.n_dbuckets); io.scalar(x.dpad_buckets); io.scalar(x.dummy_slot); io.scalar(x.dummy_uec); io.scalar(x.dummy_strand);
+  io.vec(x.unitig_len); io.vec(x.unitig_blk_off); io.vec(x.blk_unitig); io.vec(x.blk_lb); io.vec(x.blk_ub); io.vec(x.blk_ec); io.vec(x.blk_uec);
+  io.vec(x.blk_pos_off); io.vec(x.blk_posw); io.vec(x.blk_sense); io.vec(x.uec_ec); io.vec(x.ec_off); io.vec(x.ec_ids); io.vec(x.target_lens);
+  io.vec(x.onlist_bits); io.vec(x.table); io.vec(x.slot_block); io.vec(x.slot_dist); io.vec(x.utext); io.vec(x.unitig_gpos); io.vec(x.dlist_keys); io.vec(x.dtable);
+}
+int load_flat(const char* path, kamd_index** out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return kamd::fail(-2, std::string("index input file could not be opened: ") + path);
+  char magic[8];
+  FlatIn in{f};
+  in.raw(magic, 8);
+  std::unique_ptr<kamd_index> ix(new kamd_index);
+  flat_fields(in, *ix);
+  uint64_t n_names = 0; in.scalar(n_names);
+  if (in.ok && n_names < (1ULL << 32)) {
+    ix->target_names.resize(n_names);
+    for (uint64_t i = 0; i < n_names && in.ok; i++) { uint32_t l = 0; in.scalar(l); if (l > (1u << 20)) { in.ok = false; break; } ix->target_names[i].resize(l); in.raw(&ix->target_names[i][0], l); }
+  } else in.ok = false;
+  fclose(f);
+  // the arrays must be consistent with the scalars the kernels trust
+  const uint64_t S = kamd::BUCKET_SLOTS, nb = ix->n_buckets + ix->pad_buckets;
+  if (!in.ok || memcmp(magic, FLAT_MAGIC, 8) != 0 || ix->k < 3 || ix->k > 31 || ix->table.size() != nb * 8 || ix->slot_block.size() != nb * S ||
+      ix->slot_dist.size() != nb * S || ix->unitig_len.size() != ix->n_unitigs || ix->unitig_blk_off.size() != ix->n_unitigs + 1 ||
+      ix->unitig_gpos.size() != ix->n_unitigs + 1 || ix->ec_off.empty() || ix->ec_off.back() != ix->ec_ids.size() ||
+      ix->target_lens.size() < ix->n_targets || ix->target_names.size() < ix->n_targets || ix->utext.size() < (ix->text_bases + 15) / 16 ||
+      ix->dtable.size() != (ix->n_dbuckets ? (ix->n_dbuckets + ix->dpad_buckets) * 8 : 0))
+    return kamd::fail(-3, std::string("flattened index file is damaged or of another format version: ") + path);
+  *out = ix.release();
+  return 0;
+}
+}  // namespace
+
+extern "C" int kamd_index_save(const kamd_index* ix, const char* path) {
+  if (!ix || !path) return kamd::fail(-1, "kamd_index_save: null argument");
+  FILE* f = fopen(path, "wb");
+  if (!f) return kamd::fail(-2, std::string("kamd_index_save: could not open ") + path);
+  FlatOut o{f};
+  o.raw(FLAT_MAGIC, 8);
+  flat_fields(o, const_cast<kamd_index&>(*ix));
+  const uint64_t n_names = ix->target_names.size(); o.scalar(n_names);
+  for (const std::string& nm : ix->target_names) { const uint32_t l = (uint32_t)nm.size(); o.scalar(l); o.raw(nm.data(), l); }
+  const bool ok = o.ok && fclose(f) == 0;
+  if (!ok) return kamd::fail(-2, std::string("kamd_index_save: write failed: ") + path);
+  return 0;
+}
+
 extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) {
   if (!out) return kamd::fail(-1, "kamd_index_load: null output pointer");
   *out = nullptr;
   if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
   threads = std::min(threads, 64);
+  {   // a file written by kamd_index_save?
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    char magic[8] = {0};
+    const bool flat = f && fread(magic, 1, 8, f) == 8 && memcmp(magic, FLAT_MAGIC, 8) == 0;
+    if (f) fclose(f);
+    if (flat) return load_flat(path, out);
+  }
   std::vector<uint8_t> buf;
   {
     std::ifstream in(path, std::ios::binary | std::ios::ate);

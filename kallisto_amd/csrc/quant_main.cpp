@@ -142,6 +142,22 @@ class H5Out {
 
 int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "version") { std::cout << "kallisto_amd, compatible with kallisto " << KALLISTO_COMPAT_VERSION << std::endl; return 0; }
+  if (argc >= 2 && std::string(argv[1]) == "flatten") {   // kallisto_amd_quant flatten -i index.idx -o index.kamd [-t N]
+    // writes the device tables of a kallisto index as a file (kamd_index_save); `-i index.kamd` then loads in a fraction of the time
+    std::string in, out, val; int threads = 1;
+    for (int i = 2; i < argc; i++) {
+      std::string a = argv[i];
+      if (take(a, "-i", "--index", i, argc, argv, val)) in = val;
+      else if (take(a, "-o", "--output", i, argc, argv, val)) out = val;
+      else if (take(a, "-t", "--threads", i, argc, argv, val)) threads = atoi(val.c_str());
+      else { std::cerr << "Error: unknown argument " << a << "\nUsage: kallisto_amd_quant flatten -i index.idx -o index.kamd [-t threads]" << std::endl; return 1; }
+    }
+    if (in.empty() || out.empty()) { std::cerr << "Usage: kallisto_amd_quant flatten -i index.idx -o index.kamd [-t threads]" << std::endl; return 1; }
+    kamd_index* idx = nullptr;
+    if (kamd_index_load(in.c_str(), threads, &idx) != 0 || kamd_index_save(idx, out.c_str()) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+    kamd_index_free(idx);
+    return 0;
+  }
   if (argc >= 2 && std::string(argv[1]) == "bus") return bus_main(argc, argv);
   if (argc >= 2 && std::string(argv[1]) == "quant-tcc") return tcc_main(argc, argv);
   if (argc < 2 || std::string(argv[1]) != "quant") { usage(); return 1; }

@@ -137,3 +137,20 @@ def test_cli_writes_the_reference_abundance_h5(case, variant, tmp_path):
             assert np.allclose(g["values"], w["values"], rtol=1e-11, atol=0), name
         else:
             assert g["values"] == w["values"], name
+
+
+def test_cli_with_a_flattened_index(tmp_path):
+    """`flatten` writes the device tables as a file; `quant -i` on that file gives the result of the kallisto index."""
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    _fastq(f1, r1); _fastq(f2, r2)
+    flat = str(tmp_path / "index.kamd")
+    assert subprocess.run([EXE, "flatten", "-i", idx_path, "-o", flat]).returncode == 0
+    outs = []
+    for ipath, name in ((idx_path, "a"), (flat, "b")):
+        out = str(tmp_path / name)
+        p = subprocess.run([EXE, "quant", "-i", ipath, "-o", out, "--plaintext", f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        outs.append(_table(os.path.join(out, "abundance.tsv"))[1])
+    assert [r[:3] for r in outs[0]] == [r[:3] for r in outs[1]]
+    common.assert_abundance_close(np.array([float(r[3]) for r in outs[1]]), np.array([float(r[3]) for r in outs[0]]), "est_counts", rel=1e-9, floor=1e-9)

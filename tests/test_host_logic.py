@@ -208,3 +208,58 @@ def test_index_loader_refuses_damaged_files(case, tmp_path):
         assert rc != 0 and L.kamd_last_error(), c
     h = C.c_void_p()
     assert L.kamd_index_load(str(tmp_path / "missing.idx").encode(), 2, C.byref(h)) != 0
+
+
+@pytest.mark.parametrize("case", ["human_pe", "dlist_pe", "tiny_k7_se"])
+def test_flattened_index_file_round_trip(case, tmp_path):
+    """kamd_index_save / kamd_index_load on the saved file: every table of the view, the scalars and the target names come back
+    bit-identical (the front-end's `flatten` sub-command and `-i index.kamd`)."""
+    import ctypes as C
+    import subprocess
+    from kallisto_amd import api
+    idx_path = common.load_case(case)[1]
+    a = api.Index(idx_path)
+    flat = str(tmp_path / "index.kamd")
+    a.save(flat)
+    b = api.Index(flat)
+    va, vb = a.view, b.view
+    sizes = {"table": (va.n_buckets + va.pad_buckets) * 8 * 8, "slot_block": (va.n_buckets + va.pad_buckets) * 3 * 4,
+             "slot_dist": (va.n_buckets + va.pad_buckets) * 3 * 4, "uec_ec": va.n_uec * 4, "ec_off": (va.n_ecs + 1) * 8, "ec_ids": va.ec_nnz * 4,
+             "unitig_blk_off": (va.n_unitigs + 1) * 8, "unitig_len": va.n_unitigs * 4, "blk_unitig": va.n_blocks * 4, "blk_lb": va.n_blocks * 4,
+             "blk_ub": va.n_blocks * 4, "blk_ec": va.n_blocks * 4, "blk_pos_off": va.n_blocks * 8, "blk_sense": va.n_blocks,
+             "onlist_bits": va.onlist_words * 4, "utext": va.utext_words * 4, "unitig_gpos": (va.n_unitigs + 1) * 8,
+             "dtable": (va.n_dbuckets + va.dpad_buckets) * 8 * 8 if va.n_dbuckets else 0}
+    # blk_posw: one word per (block, transcript) pair, its length is the last block's offset + size -- compared through the offsets
+    n_posw = 0
+    if va.n_blocks:
+        po = np.frombuffer(C.string_at(C.cast(va.blk_pos_off, C.c_void_p), int(va.n_blocks) * 8), np.uint64)
+        be = np.frombuffer(C.string_at(C.cast(va.blk_ec, C.c_void_p), int(va.n_blocks) * 4), np.uint32)
+        eo = np.frombuffer(C.string_at(C.cast(va.ec_off, C.c_void_p), int(va.n_ecs + 1) * 8), np.uint64)
+        n_posw = int((po + (eo[be.astype(np.int64) + 1] - eo[be.astype(np.int64)])).max())
+    sizes["blk_posw"] = n_posw * 4
+    sizes["target_lens"] = len(a.target_lens) * 4
+    for name, typ in type(va)._fields_:
+        x, y = getattr(va, name), getattr(vb, name)
+        if typ is C.c_void_p:
+            n = int(sizes[name])
+            if n:
+                assert C.string_at(C.cast(x, C.c_void_p), n) == C.string_at(C.cast(y, C.c_void_p), n), name
+        else:
+            assert x == y, name
+    assert np.array_equal(a.target_lens, b.target_lens)
+    lib = api.load_library()
+    lib.kamd_index_target_name.restype = C.c_char_p
+    assert [lib.kamd_index_target_name(a._h, i) for i in range(a.num_targets)] == [lib.kamd_index_target_name(b._h, i) for i in range(b.num_targets)]
+    # the front-end's sub-command writes the same file
+    exe = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
+    if os.path.exists(exe):
+        flat2 = str(tmp_path / "cli.kamd")
+        assert subprocess.run([exe, "flatten", "-i", idx_path, "-o", flat2, "-t", "3"]).returncode == 0
+        c = api.Index(flat2)   # (a second build: the order of the k-mers inside a bucket depends on the builder's threads, so no byte equality)
+        assert (c.num_kmers, c.num_unitigs, c.num_ecs, c.num_targets) == (a.num_kmers, a.num_unitigs, a.num_ecs, a.num_targets)
+        assert all(np.array_equal(x, y) for x, y in zip(c.ec_sets(), a.ec_sets())) and np.array_equal(c.target_lens, a.target_lens)
+    # a damaged file is refused, not trusted
+    blob = bytearray(open(flat, "rb").read())
+    open(flat, "wb").write(blob[: len(blob) // 2])
+    with pytest.raises(api.KallistoAmdError):
+        api.Index(flat)
