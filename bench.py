@@ -189,13 +189,28 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra):
             per = os.path.getsize(src) // n
             with open(src, "rb") as fi, gzip.open(dst, "wb", compresslevel=1) as fo:
                 fo.write(fi.read(per * ngz))
+        # the same reads as BGZF (what `bgzip` writes: independent members of <= 64 KiB, inflated block-parallel by the front-end)
+        import struct
+        import zlib
+        b1, b2 = os.path.join(tmp, "b_1.fq.gz"), os.path.join(tmp, "b_2.fq.gz")
+        for src, dst in ((f1, b1), (f2, b2)) if paired else ((f1, b1),):
+            per = os.path.getsize(src) // n
+            with open(src, "rb") as fi, open(dst, "wb") as fo:
+                data = fi.read(per * ngz)
+                for a in list(range(0, len(data), 65280)) + [None]:
+                    chunk = b"" if a is None else data[a:a + 65280]
+                    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+                    comp = co.compress(chunk) + co.flush()
+                    fo.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+                             + comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
         # the device tables written once as a file (`kallisto_amd_quant flatten`): what a multi-sample front-end would load
         flat = os.path.join(tmp, "index.kamd")
         t0 = time.time()
         have_flat = subprocess.run([exe, "flatten", "-i", idx_path, "-o", flat, "-t", str(threads)], stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL).returncode == 0
         flatten_s = time.time() - t0
-        runs = [("plain", idx_path, [f1, f2] if paired else [f1], n), ("gzip", idx_path, [g1, g2] if paired else [g1], ngz)]
+        runs = [("plain", idx_path, [f1, f2] if paired else [f1], n), ("gzip", idx_path, [g1, g2] if paired else [g1], ngz),
+                ("bgzf", idx_path, [b1, b2] if paired else [b1], ngz)]
         if have_flat:
             runs.append(("plain_flattened_index", flat, [f1, f2] if paired else [f1], n))
         for kind, ipath, files, cnt in runs:
@@ -221,7 +236,7 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra):
                          "whole_run_M_per_s": round(cnt / wall / 1e6, 3), "host_threads": threads}
         if have_flat:
             out["flatten_s"] = round(flatten_s, 2)
-        out["note"] = ("kallisto_amd_quant from FASTQ on local disk (plain: mmap + all host threads; gzip: one inflate thread per file); "
+        out["note"] = ("kallisto_amd_quant from FASTQ on local disk (plain: mmap + all host threads; gzip: one inflate thread per file; bgzf: block-parallel inflate); "
                        "input_to_ecs = parsing + packing + H2D + pseudoalignment (index load excluded), whole_run = process start to exit")
         return out
     finally:
