@@ -2283,7 +2283,9 @@ int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   c->host_state.stream_words = cur_words + n_items * (u64)stride;
   c->host_state.n_recs = cur_recs + n_items;
   if (int rc = push_state(c)) return rc;
-  const size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * V3_LIST_CAP) * sizeof(u32);
+  size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * V3_LIST_CAP) * sizeof(u32);
+  // diagnostic: unused LDS per block lowers the number of resident wavefronts (occupancy sensitivity; room for another stream's kernels)
+  if (c->tune.lds_pad > 0 && lds_bytes <= 64 * 1024) lds_bytes = std::min<size_t>(64 * 1024, lds_bytes + (size_t)c->tune.lds_pad);
   const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
   u32* slots = c->stream_buf.as<u32>() + cur_words;
   HIPC(hipEventRecord(c->ev0, c->stream));
