@@ -150,6 +150,28 @@ int kamd_pack_reads_host_strided(const char* seqs, const uint64_t* off, const in
 int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off, const int32_t* d_len, uint64_t n_reads,
                            int32_t max_len, uint32_t* d_out_words, uint16_t* d_out_len);
 
+/* ---- reads: FASTQ text resident in HBM -> packed batch (the parsing half of FastqSequenceReader::fetchSequences,
+ * src/ProcessReads.cpp:3128-3267, i.e. kseq_read, src/kseq.h:174-215, for strict 4-line records) ----
+ * A *unit* is a piece of the (decompressed) text of one file -- or of the two mates' files -- that starts at the first byte of a
+ * record and ends behind the last newline of a record; the caller cuts units by counting newlines while it moves the bytes and
+ * tells how many records a unit holds (4 lines each).  The device finds the lines, verifies for every record that kseq_read would
+ * return exactly its second line (header starts with '@', the third line with '+', quality as long as the sequence, no empty
+ * sequence; a trailing '\r' is dropped as kseq does), and packs the sequences as kamd_pack_reads would: single-end -> item j =
+ * record j, paired -> items 2j / 2j + 1 = record j of file 0 / file 1.  status != 0: the unit is NOT packed and the caller must
+ * read this input with a general FASTA/FASTQ reader instead (multi-line records, FASTA, junk between records ...).
+ * d_text[f]: device pointers, 16-byte aligned; n_bytes[f] < 2^32.  Runs on the context stream and synchronises it once. */
+typedef struct {
+  const uint32_t* d_words;     /* packed batch, owned by the context, valid until the next kamd_fastq_unit_pack on it */
+  const uint16_t* d_len;
+  uint64_t n_items;            /* = n_records */
+  int32_t max_len;             /* longest read of the unit: the max_len to hand to kamd_pseudoalign / kamd_fld_* */
+  int32_t status;              /* 0 ok; 1 some record is not strict 4-line FASTQ (first_bad_record); 2 the text holds fewer than
+                                  4 x n_records lines; 3 a read is longer than 65535 bases */
+  uint64_t first_bad_record;
+} kamd_fastq_unit;
+int kamd_fastq_unit_pack(kamd_ctx*, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
+                         kamd_fastq_unit* out);
+
 /* ---- S2: pseudoalignment of one batch resident in HBM ----
  * n_items = pairs (paired) or reads (single).  Accumulates into the context's EC state; call kamd_ec_finalize after
  * the last batch. */
@@ -174,21 +196,21 @@ typedef struct {
   uint64_t n_probes;        /* k-mer table probes */
   uint64_t n_bucket_reads;  /* 64-byte bucket reads (>= n_probes) */
   uint64_t n_distinct_tuples;
-  uint64_t n_stream_words;  /* u32 words of the record stream (fixed slots of kernel A v2 included) */
+  uint64_t n_stream_words;  /* u32 words of the record stream (one fixed slot per item + the records of overflow items) */
   uint64_t n_raw_words;     /* u32 words kernel A wrote: per item 1 header + its distinct (unitig,set) classes */
-  uint64_t n_text_hits;     /* probes answered from the unitig text instead of the table (kernel A version 3) */
-  uint64_t n_wave_iters;    /* kernel A version 3: loop trips summed over the wavefronts ... */
+  uint64_t n_text_hits;     /* probes answered from the unitig text instead of the table */
+  uint64_t n_wave_iters;    /* kernel A: loop trips summed over the wavefronts ... */
   uint64_t n_lane_iters;    /* ... and lanes that issued a probe in them: n_lane_iters / (64 n_wave_iters) = lane utilisation */
 } kamd_align_stats;
 int kamd_align_stats_get(kamd_ctx*, kamd_align_stats* out);
 
 /* durations measured with HIP events on the context stream (bench.py's roofline figures) */
 typedef struct {
-  float last_align_kernel_ms;  /* kernel A (k_match_v2, or k_pseudoalign) of the last kamd_pseudoalign call */
+  float last_align_kernel_ms;  /* kernel A (k_match_v3) of the last kamd_pseudoalign call */
   float last_em_ms;            /* all EM launches of the last kamd_em_run call */
   uint64_t last_em_iters;      /* EM rounds executed by it */
-  float last_classify_ms;      /* k_classify of the same call (0 for the block-staged kernel, which classifies inline) */
-  int32_t kernel_a_version;    /* 2 = k_match_v2 + k_classify (default), 1 = k_pseudoalign (env KAMD_KERNEL_A=1) */
+  float last_classify_ms;      /* k_classify of the same call */
+  int32_t kernel_a_version;    /* 3 = k_match_v3 + k_classify (the only form; versions 1 and 2 were removed in round 2) */
   uint64_t last_em_nnz;        /* shape of the EM problem of the last kamd_em_run: nnz of the EC x transcript matrix, */
   uint64_t last_em_nnz_multi;  /* nnz in multi-transcript rows, */
   uint64_t last_em_nseg;       /* column segments (CSR form) or chunks per direction (streamed form), */

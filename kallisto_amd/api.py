@@ -410,21 +410,6 @@ class Context:
                                                        offs.data_ptr() if offs.numel() else None, offs.numel()),
                "kamd_ec_explicit_replace")
 
-    def allreduce_ec_counts(self, group=None):
-        """Merge the EC state of all ranks: one RCCL all-reduce of the dense count vector over xGMI plus an all-gather
-        of the tuple records (kallisto_amd/exchange.py)."""
-        import torch.distributed as dist
-        from .exchange import merge_ec_state
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
-            return
-        from .exchange import gather_records
-        words, offs = self.tuples_export()
-        words, offs = merge_ec_state(self.dense_counts(), words, offs, group)
-        self.tuples_replace(words, offs)
-        ew, eo = self.explicit_export()
-        ew, eo = gather_records(ew, eo, group)
-        self.explicit_replace(ew, eo)
-
     def ec_allreduce(self, comm: "Comm"):
         """kamd_ec_allreduce: merge the EC state of all ranks inside the library (one all-reduce of the dense count vector +
         all-gathers of the tuple / explicit-set records, RCCL over xGMI)."""
@@ -549,6 +534,12 @@ class Context:
         self.torch.cuda.synchronize(self.device)
 
     def close(self):
+        # a communicator cached by quant() holds this context's device and stream: it goes first (kamd_comm_destroy
+        # dereferences the context)
+        comm = getattr(self, "_comm", None)
+        if comm is not None:
+            comm.close()
+            self._comm = None
         if getattr(self, "_h", None):
             load_library().kamd_ctx_destroy(self._h)
             self._h = None
@@ -575,8 +566,10 @@ class Comm:
     (gloo in the tests -- two ranks on one GPU; device buffers are staged through the host there).
     Comm.for_context(ctx): RCCL when the default process group runs on nccl (the id is broadcast through it), else callbacks."""
 
-    def __init__(self, ctx: "Context", handle, keep=None):
+    def __init__(self, ctx: "Context", handle, keep=None, rank: int = 0, world: int = 1, transport: str = "callbacks"):
         self.ctx, self._h, self._keep = ctx, handle, keep
+        self.rank, self.world = int(rank), int(world)
+        self.transport = transport   # what actually carries the collectives: "rccl (inside libkallisto_amd.so)" or "callbacks over <backend>"
 
     @staticmethod
     def unique_id() -> bytes:
@@ -589,7 +582,7 @@ class Comm:
         h = C.c_void_p()
         buf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
         _check(load_library().kamd_comm_create_rccl(ctx._h, rank, world, buf, C.byref(h)), "kamd_comm_create_rccl")
-        return cls(ctx, h)
+        return cls(ctx, h, rank=rank, world=world, transport="rccl (kamd_comm, inside libkallisto_amd.so)")
 
     @classmethod
     def over_process_group(cls, ctx: "Context", group=None):
@@ -646,7 +639,8 @@ class Comm:
         cbs = _CommCallbacks(C.cast(f1, C.c_void_p), C.cast(f2, C.c_void_p), C.cast(f3, C.c_void_p))
         h = C.c_void_p()
         _check(load_library().kamd_comm_create_callbacks(ctx._h, rank, world, C.byref(cbs), None, C.byref(h)), "kamd_comm_create_callbacks")
-        return cls(ctx, h, keep=(f1, f2, f3, cbs))
+        return cls(ctx, h, keep=(f1, f2, f3, cbs), rank=rank, world=world,
+                   transport=f"callbacks over torch.distributed ({dist.get_backend(group)}{', staged through the host' if via_host else ''})")
 
     @classmethod
     def for_context(cls, ctx: "Context", group=None):
@@ -681,7 +675,8 @@ class Comm:
 
     def close(self):
         if getattr(self, "_h", None):
-            load_library().kamd_comm_destroy(self._h)
+            if getattr(self.ctx, "_h", None):   # the context is still alive (Context.close() closes its communicator first)
+                load_library().kamd_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -807,13 +802,7 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
 
 
 def _dist_rank_of(comm: Comm, group=None) -> int:
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(group)
-    except Exception:
-        pass
-    return getattr(comm, "rank", 0)
+    return int(comm.rank)   # the communicator knows its place (with or without torch.distributed)
 
 
 def _dist_on() -> bool:

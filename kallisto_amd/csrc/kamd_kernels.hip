@@ -30,6 +30,7 @@
 
 #include "../../include/kallisto_amd.h"
 #include "kamd_core.h"
+#include "kamd_fq_core.h"
 #include "kamd_host.h"
 #include "kamd_em_local.h"
 #include "kamd_em_sell.h"
@@ -1150,14 +1151,8 @@ __global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_emit(const int32_t* __re
 // ------------------------------------------------------------------------------------------------------------------
 // read packer (ASCII -> 2-bit + non-ACGT mask), one thread per output word
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restrict__ off, const int32_t* __restrict__ len,
-                             u64 n_reads, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
-  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u64 r = gid / (u64)rec_words;
-  int w = (int)(gid % (u64)rec_words);
-  if (r >= n_reads) return;
-  const char* s = seqs + off[r];
-  const int L = len[r];
+// word w of the packed record of a read s[0..L)
+__device__ __forceinline__ u32 pack_word_of(const char* __restrict__ s, int L, int w, int seq_words) {
   u32 v = 0;
   if (w == seq_words - 1) {   // flag word (kamd_core.h REC_FLAG_HAS_N): the bases never reach the last sequence word
     for (int i = 0; i < L; i++) {
@@ -1181,7 +1176,122 @@ __global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restric
       if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) v |= 1u << j;
     }
   }
-  out[gid] = v;
+  return v;
+}
+__global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restrict__ off, const int32_t* __restrict__ len,
+                             u64 n_reads, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 r = gid / (u64)rec_words;
+  int w = (int)(gid % (u64)rec_words);
+  if (r >= n_reads) return;
+  const int L = len[r];
+  out[gid] = pack_word_of(seqs + off[r], L, w, seq_words);
+  if (w == 0) out_len[r] = (uint16_t)L;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// FASTQ text resident in HBM -> packed reads (kamd_fq_core.h; the parsing half of FastqSequenceReader::fetchSequences,
+// src/ProcessReads.cpp:3128-3267 + kseq_read src/kseq.h:174-215, for strict 4-line records).  A unit of text starts at a record
+// and holds whole records; per file:
+//   k_fq_count    newlines per 4 KB tile (one block per tile, 16 bytes per thread)
+//   k_fq_scan     exclusive scan of the tile counts (one block: a unit has a few 10^4 tiles)
+//   k_fq_fill     position of every newline, in order
+// then k_fq_records checks the shape of every record (kamd_fq::fq_check_record) and emits {address, length} of its sequence
+// line, mates interleaved, and k_fq_pack writes the 2-bit records kernel A reads.
+// ------------------------------------------------------------------------------------------------------------------
+struct FqResult { u32 max_len; u32 n_bad; u64 first_bad; u64 n_lines[2]; };
+__device__ __forceinline__ u32 fq_thread_mask(const char* __restrict__ text, u64 n_bytes, u64 b0) {   // newline bits of bytes [b0, b0 + 16)
+  u32 m = 0;
+  if (b0 + 16 <= n_bytes) {
+    const uint4 v = *reinterpret_cast<const uint4*>(text + b0);   // (text is 16-byte aligned, b0 a multiple of 16)
+    m = kamd_fq::nl_mask4(v.x) | (kamd_fq::nl_mask4(v.y) << 4) | (kamd_fq::nl_mask4(v.z) << 8) | (kamd_fq::nl_mask4(v.w) << 12);
+  } else {
+    for (u32 i = 0; i < 16 && b0 + i < n_bytes; i++) if (text[b0 + i] == '\n') m |= 1u << i;
+  }
+  return m;
+}
+__global__ __launch_bounds__(BLOCK) void k_fq_count(const char* __restrict__ text, u64 n_bytes, u32* tile_count) {
+  __shared__ u32 wsum[BLOCK / 64];
+  const u64 b0 = (u64)blockIdx.x * kamd_fq::FQ_TILE + (u64)threadIdx.x * 16;
+  u32 c = b0 < n_bytes ? (u32)__popc(fq_thread_mask(text, n_bytes, b0)) : 0u;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int j = 0; j < BLOCK / 64; j++) t += wsum[j]; tile_count[blockIdx.x] = t; }
+}
+constexpr int FQ_SCAN_BLOCK = 1024;
+__global__ __launch_bounds__(FQ_SCAN_BLOCK) void k_fq_scan(const u32* __restrict__ tile_count, u32 n_tiles, u32* tile_base, u64* total) {
+  __shared__ u32 part[FQ_SCAN_BLOCK];
+  const u32 per = (n_tiles + FQ_SCAN_BLOCK - 1) / FQ_SCAN_BLOCK;
+  const u32 a = min(threadIdx.x * per, n_tiles), e = min(a + per, n_tiles);
+  u32 sum = 0;
+  for (u32 i = a; i < e; i++) sum += tile_count[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < FQ_SCAN_BLOCK; d <<= 1) {   // Hillis-Steele over the 1024 partial sums
+    const u32 v = threadIdx.x >= (u32)d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - sum;
+  for (u32 i = a; i < e; i++) { tile_base[i] = run; run += tile_count[i]; }
+  if (threadIdx.x == FQ_SCAN_BLOCK - 1) *total = (u64)part[FQ_SCAN_BLOCK - 1];
+}
+__global__ __launch_bounds__(BLOCK) void k_fq_fill(const char* __restrict__ text, u64 n_bytes, const u32* __restrict__ tile_base, u32* nlpos, u64 cap) {
+  __shared__ u32 wsum[BLOCK / 64];
+  const u64 b0 = (u64)blockIdx.x * kamd_fq::FQ_TILE + (u64)threadIdx.x * 16;
+  u32 m = b0 < n_bytes ? fq_thread_mask(text, n_bytes, b0) : 0u;
+  const u32 c = (u32)__popc(m);
+  const u32 incl = wave_incl_scan(c);
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  u32 before = 0;
+  for (u32 j = 0; j < (threadIdx.x >> 6); j++) before += wsum[j];
+  u64 o = (u64)tile_base[blockIdx.x] + before + incl - c;
+  while (m) {
+    const int i = __ffs((int)m) - 1;
+    m &= m - 1;
+    if (o < cap) nlpos[o] = (u32)(b0 + (u64)i);
+    ++o;
+  }
+}
+struct FqFiles { const char* text[2]; const u32* nlpos[2]; u64 n_bytes[2]; int n; };
+__global__ __launch_bounds__(BLOCK) void k_fq_records(FqFiles F, u64 n_records, u64* recs, FqResult* res) {
+  u32 mx = 0, bad = 0; u64 first = ~0ULL;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < n_records; j += (u64)gridDim.x * blockDim.x) {
+    for (int f = 0; f < F.n; f++) {
+      const u32* nl = F.nlpos[f] + 4 * j;
+      const u64 l0 = j ? (u64)nl[-1] + 1 : 0ULL;
+      kamd_fq::Record r; r.ok = false; r.seq_off = 0; r.seq_len = 0;
+      // (the positions are only trusted after this test: a unit with fewer newlines than the caller promised leaves stale entries)
+      if (l0 <= nl[0] && nl[0] < nl[1] && nl[1] < nl[2] && nl[2] < nl[3] && (u64)nl[3] < F.n_bytes[f])
+        r = kamd_fq::fq_check_record(F.text[f], l0, nl[0], nl[1], nl[2], nl[3]);
+      const bool ok = r.ok && r.seq_len <= kamd_fq::FQ_MAX_READ;
+      recs[j * (u64)F.n + f] = kamd_fq::rec_word(F.text[f] + r.seq_off, ok ? r.seq_len : 0u);
+      if (r.ok) mx = max(mx, r.seq_len);   // (a read beyond 65535 bases is reported through max_len, like the host reader does)
+      else { ++bad; first = min(first, j); }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    mx = max(mx, (u32)__shfl_down(mx, d, 64)); bad += __shfl_down(bad, d, 64);
+    const u64 o = __shfl_down(first, d, 64); first = min(first, o);
+  }
+  if (lane_id() == 0) {
+    if (mx) atomicMax(&res->max_len, mx);
+    if (bad) { atomicAdd(&res->n_bad, bad); atomicMin(&res->first_bad, first); }
+  }
+}
+__global__ void k_fq_pack(const u64* __restrict__ recs, u64 n_reads, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 r = gid / (u64)rec_words;
+  int w = (int)(gid % (u64)rec_words);
+  if (r >= n_reads) return;
+  const u64 rw = recs[r];
+  const int L = (int)(rw >> 48);
+  out[gid] = pack_word_of(reinterpret_cast<const char*>((uintptr_t)(rw & 0xFFFFFFFFFFFFULL)), L, w, seq_words);
   if (w == 0) out_len[r] = (uint16_t)L;
 }
 
@@ -1935,6 +2045,8 @@ struct kamd_ctx {
   SellCache* sell_cache = nullptr;   // plan of the finalized matrix, kept for bootstrap replicates (allocated on first use)
   u64 ec_generation = 0;         // bumped whenever the finalized EC result is rebuilt (plans of an older result are stale)
   int last_em_plan_cached = 0;
+  DBuf fq_tiles, fq_nlpos[2], fq_recs, fq_res, fq_words, fq_len;   // kamd_fastq_unit_pack: scratch and the packed batch it returns
+  void* fq_host = nullptr;       // pinned FqResult
   DBuf fld_tl, fld_card, fld_scratch, fld_items, fld_cand;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
@@ -1961,7 +2073,9 @@ struct kamd_ctx {
   bool had_overflow_items = false;   // some item went through the overflow kernel (tuples of more than TUPLE_CAP sets may exist)
   int n_cus = 0, last_em_k = 0; unsigned last_em_grid = 0, last_em_lds = 0;
   uint64_t last_em_iters = 0, last_em_nnz = 0, last_em_nnz_multi = 0, last_em_nseg = 0, last_em_necs = 0;
+  std::vector<struct kamd_comm*> comms;   // communicators bound to this context (detached by kamd_ctx_destroy, so that either may go first)
 };
+namespace { void comm_detach_all(kamd_ctx* c); }
 
 namespace {
 
@@ -2167,6 +2281,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  comm_detach_all(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -2177,6 +2292,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
   if (c->fld_host) (void)hipHostFree(c->fld_host);
+  if (c->fq_host) (void)hipHostFree(c->fq_host);
   if (c->sell_cache) sell_cache_free(c->sell_cache);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
@@ -2186,7 +2302,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,
                   &c->pt_rowpos, &c->pt_nnzpos, &c->pt_off, &c->pt_ids, &c->pt_counts, &c->pt_wcounts, &c->pt_hist, &c->pt_ck_alpha,
-                  &c->pt_ck_a})
+                  &c->pt_ck_a, &c->fq_tiles, &c->fq_nlpos[0], &c->fq_nlpos[1], &c->fq_recs, &c->fq_res, &c->fq_words, &c->fq_len})
     b->release();
   delete c;
 }
@@ -2245,6 +2361,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(c->n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
   c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0; c->tuple_bound = 0;
+  c->had_overflow_items = false;
   return push_state(c);
 }
 
@@ -2260,6 +2377,70 @@ extern "C" int kamd_pack_reads_device(kamd_ctx* c, const char* d_seqs, const uin
   hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, c->stream, d_seqs, (const u64*)d_off, d_len,
                      (u64)n_reads, seq_words, rec_words, d_out_words, d_out_len);
   HIPC(hipGetLastError());
+  return 0;
+}
+
+// One unit of strict 4-line FASTQ text already in HBM -> the packed batch kernel A reads (see k_fq_* above).  The caller cut the
+// unit at record boundaries (it counted the newlines while the bytes went by) and says how many records it holds; the device
+// finds the lines, checks every record's shape, and packs mate 1 / mate 2 of record j into items 2j / 2j + 1.  One host
+// synchronisation (max_len decides the record stride; the shape check decides whether the batch may be used at all).
+extern "C" int kamd_fastq_unit_pack(kamd_ctx* c, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
+                                    kamd_fastq_unit* out) {
+  if (!c || !d_text || !n_bytes || !out) return kamd::fail(-1, "kamd_fastq_unit_pack: null argument");
+  if (n_files < 1 || n_files > 2) return kamd::fail(-1, "kamd_fastq_unit_pack: n_files must be 1 or 2");
+  memset(out, 0, sizeof *out);
+  out->first_bad_record = ~0ULL;
+  if (n_records == 0) return 0;
+  for (int f = 0; f < n_files; f++) {
+    if (!d_text[f] || n_bytes[f] == 0 || n_bytes[f] >= 0xFFFFFFFFULL) return kamd::fail(-1, "kamd_fastq_unit_pack: a unit holds 1 .. 2^32-2 bytes of text per file");
+    if ((uintptr_t)d_text[f] & 15) return kamd::fail(-1, "kamd_fastq_unit_pack: the text must be 16-byte aligned");
+    if (n_records > n_bytes[f] / 8) return kamd::fail(-1, "kamd_fastq_unit_pack: more records than the text can hold");
+  }
+  HIPC(hipSetDevice(c->device));
+  if (!c->fq_host) { if (hipHostMalloc(&c->fq_host, sizeof(FqResult), hipHostMallocDefault) != hipSuccess) return kamd::fail(-100, "kamd_fastq_unit_pack: pinned allocation failed"); }
+  u64 tiles[2] = {0, 0}, tile_off[2] = {0, 0}, all_tiles = 0;
+  for (int f = 0; f < n_files; f++) { tiles[f] = (n_bytes[f] + kamd_fq::FQ_TILE - 1) / kamd_fq::FQ_TILE; tile_off[f] = all_tiles; all_tiles += tiles[f]; }
+  if (int rc = c->fq_tiles.ensure(2 * all_tiles * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->fq_res.ensure(sizeof(FqResult), 0, c->stream)) return rc;
+  const u64 nl_cap = 4 * n_records + 4;
+  for (int f = 0; f < n_files; f++) if (int rc = c->fq_nlpos[f].ensure(nl_cap * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->fq_recs.ensure(n_records * (u64)n_files * sizeof(u64), 0, c->stream)) return rc;
+  FqResult* res = c->fq_res.as<FqResult>();
+  FqResult init{}; init.first_bad = ~0ULL;
+  FqResult* h = (FqResult*)c->fq_host;
+  *h = init;
+  HIPC(hipMemcpyAsync(res, h, sizeof(FqResult), hipMemcpyHostToDevice, c->stream));
+  FqFiles F{};
+  F.n = n_files;
+  for (int f = 0; f < n_files; f++) {
+    u32* cnt = c->fq_tiles.as<u32>() + tile_off[f];
+    u32* base = c->fq_tiles.as<u32>() + all_tiles + tile_off[f];
+    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)tiles[f]), dim3(BLOCK), 0, c->stream, d_text[f], (u64)n_bytes[f], cnt);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(FQ_SCAN_BLOCK), 0, c->stream, (const u32*)cnt, (u32)tiles[f], base, &res->n_lines[f]);
+    hipLaunchKernelGGL(k_fq_fill, dim3((unsigned)tiles[f]), dim3(BLOCK), 0, c->stream, d_text[f], (u64)n_bytes[f], (const u32*)base,
+                       c->fq_nlpos[f].as<u32>(), nl_cap);
+    F.text[f] = d_text[f]; F.nlpos[f] = c->fq_nlpos[f].as<u32>(); F.n_bytes[f] = n_bytes[f];
+  }
+  hipLaunchKernelGGL(k_fq_records, dim3((unsigned)std::min<u64>(grid_for(n_records, BLOCK), 4096)), dim3(BLOCK), 0, c->stream, F, (u64)n_records,
+                     c->fq_recs.as<u64>(), res);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(h, res, sizeof(FqResult), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  out->n_items = n_records;
+  for (int f = 0; f < n_files; f++)
+    if (h->n_lines[f] < 4 * n_records) { out->status = 2; return 0; }   // fewer lines than promised (more: the caller's cut leaves the rest to the next unit -- not an error here)
+  if (h->n_bad) { out->status = 1; out->first_bad_record = h->first_bad; return 0; }
+  out->max_len = (int32_t)std::max<u32>(h->max_len, 1u);
+  if (h->max_len > kamd_fq::FQ_MAX_READ) { out->status = 3; return 0; }   // reads beyond the packed layout's 16-bit lengths
+  const int seq_words = (out->max_len + 15) / 16 + 1;
+  const int rec_words = (int)kamd_packed_record_words(out->max_len);
+  const u64 n_reads = n_records * (u64)n_files, total = n_reads * (u64)rec_words;
+  if (int rc = c->fq_words.ensure(total * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->fq_len.ensure(n_reads * sizeof(uint16_t), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_fq_pack, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)c->fq_recs.as<u64>(), n_reads, seq_words, rec_words,
+                     c->fq_words.as<u32>(), c->fq_len.as<uint16_t>());
+  HIPC(hipGetLastError());
+  out->d_words = c->fq_words.as<u32>(); out->d_len = c->fq_len.as<uint16_t>();
   return 0;
 }
 
@@ -2611,6 +2792,7 @@ extern "C" int kamd_ec_tuples_replace(kamd_ctx* c, const uint32_t* d_words, uint
   if (n_recs) HIPC(hipMemcpyAsync(c->rec_off.p, d_rec_off, n_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
   c->host_state.stream_words = n_words; c->host_state.n_recs = n_recs;
   c->tuple_bound = n_recs;
+  c->had_overflow_items = true;   // gathered records may hold another rank's long tuples (k_resolve_union's cursor scratch)
   c->tuples_counted = false; c->finalized = false;
   return push_state(c);
 }
@@ -4200,7 +4382,8 @@ int rccl_fail(ncclResult_t r, const char* what) {
 }  // namespace
 
 struct kamd_comm {
-  kamd_ctx* ctx = nullptr;
+  kamd_ctx* ctx = nullptr;              // nullptr once the context has been destroyed (kamd_ctx_destroy detaches its communicators)
+  int device = 0;
   int rank = 0, world = 1;
   ncclComm_t nccl = nullptr;            // RCCL backend
   kamd_comm_callbacks cb{}; void* user = nullptr; bool use_cb = false;
@@ -4208,6 +4391,7 @@ struct kamd_comm {
 };
 
 namespace {
+void comm_detach_all(kamd_ctx* c) { for (kamd_comm* m : c->comms) m->ctx = nullptr; c->comms.clear(); }
 int comm_allreduce(kamd_comm* m, void* d_buf, u64 count, int type) {   // type: 0 u32, 1 i32, 2 u64, 3 f64
   if ((m->world == 1 && !m->nccl) || count == 0) return 0;   // (a world of one on RCCL still goes through the library: see the tests)
   kamd_ctx* c = m->ctx;
@@ -4304,13 +4488,14 @@ extern "C" int kamd_comm_create_rccl(kamd_ctx* c, int32_t rank, int32_t world, c
   *out = nullptr;
   HIPC(hipSetDevice(c->device));
   kamd_comm* m = new kamd_comm;
-  m->ctx = c; m->rank = rank; m->world = world;
+  m->ctx = c; m->device = c->device; m->rank = rank; m->world = world;
   if (world > 1 || id128) {
     if (int rc = rccl_load()) { delete m; return rc; }
     ncclUniqueId id; memcpy(id.internal, id128, KAMD_COMM_ID_BYTES);
     const ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, id, rank);
     if (r) { delete m; return rccl_fail(r, "ncclCommInitRank"); }
   }
+  c->comms.push_back(m);
   *out = m;
   return 0;
 }
@@ -4318,13 +4503,19 @@ extern "C" int kamd_comm_create_callbacks(kamd_ctx* c, int32_t rank, int32_t wor
   if (!c || !out || !cb || !cb->allreduce_sum || !cb->allgather || !cb->broadcast) return kamd::fail(-1, "kamd_comm_create_callbacks: null argument");
   if (world < 1 || rank < 0 || rank >= world) return kamd::fail(-1, "kamd_comm_create_callbacks: bad rank / world");
   kamd_comm* m = new kamd_comm;
-  m->ctx = c; m->rank = rank; m->world = world; m->cb = *cb; m->user = user; m->use_cb = true;
+  m->ctx = c; m->device = c->device; m->rank = rank; m->world = world; m->cb = *cb; m->user = user; m->use_cb = true;
+  c->comms.push_back(m);
   *out = m;
   return 0;
 }
 extern "C" void kamd_comm_destroy(kamd_comm* m) {
   if (!m) return;
-  if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+  (void)hipSetDevice(m->device);
+  if (m->ctx) {
+    (void)hipStreamSynchronize(m->ctx->stream);
+    auto& v = m->ctx->comms;
+    v.erase(std::remove(v.begin(), v.end(), m), v.end());
+  } else (void)hipDeviceSynchronize();   // the context went first: its stream handle is no longer ours to touch
   if (m->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->nccl);
   for (DBuf* b : {&m->tmp_a, &m->tmp_b, &m->tmp_c, &m->tmp_d}) b->release();
   delete m;

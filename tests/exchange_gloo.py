@@ -1,4 +1,5 @@
-"""Multi-GPU merge of the EC state (one process per GPU; torch.distributed, backend "nccl" == RCCL over xGMI).
+"""Test helper (not product code: the product merges inside the library, kamd_ec_allreduce): the multi-GPU merge of the EC state written
+with torch.distributed, as the CPU gloo test of the merge logic uses it.
 
 The reference merges per-thread results under a mutex: `tc.counts[i] += c[i]` plus transfer of newly discovered ECs
 (MasterProcessor::update, src/ProcessReads.cpp:424-499).  Here every rank holds

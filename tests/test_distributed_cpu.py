@@ -1,6 +1,6 @@
 """World-size-2 test of the multi-GPU merge on CPU (gloo): each rank turns its shard of the reads into the EC state
 kernel A would produce (dense counts + tuple records, via the CPU emulation of the per-item logic), the states are
-merged with kallisto_amd.exchange.merge_ec_state (all-reduce + all-gather), resolved, and the result must equal the
+merged with tests/exchange_gloo.py merge_ec_state (all-reduce + all-gather), resolved, and the result must equal the
 reference's EC multiset for the WHOLE input -- i.e. sharding reads over ranks does not change EC counts."""
 import os
 import socket
@@ -31,7 +31,7 @@ def _worker(rank, world, port, case, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from kallisto_amd.exchange import merge_ec_state
+        from tests.exchange_gloo import merge_ec_state
         from tests import emu_binding as E
         meta, idx_path, r1, r2 = common.load_case(case)
         paired = r2 is not None
@@ -67,7 +67,7 @@ def test_sharded_ec_counts_equal_reference(case, variant):
 
 
 def test_merge_is_identity_without_process_group():
-    from kallisto_amd.exchange import merge_ec_state
+    from tests.exchange_gloo import merge_ec_state
     d = torch.arange(5, dtype=torch.int32)
     w = torch.tensor([1, 2, 3, 4], dtype=torch.int32)
     o = torch.tensor([0], dtype=torch.int64)

@@ -1,0 +1,155 @@
+"""Input side of the device FASTQ parser on the CPU (kallisto_amd/csrc/kamd_textsource.h + kamd_fq_core.h through tests/emu/fq_emu.cpp):
+host threads move the text of a file into a ring and count its newlines (TextSource: plain / gzip / BGZF), UnitCutter cuts the
+stream into units of whole 4-line records, and the per-unit parse (restated serially over the device's own host/device functions)
+must return exactly the sequences kseq_read returns (src/kseq.h:174-215) -- or decline, so that the front-end takes the general
+reader.  The kernels proper are checked on the GPU (tests/test_gpu_fastq_units.py)."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from tests import emu_binding as E
+from tests.test_fastq_input import _bgzf, _fastq_bytes, _reads
+
+
+def _units(p0, p1=None, ring=1 << 20, target=1 << 16, mx=None, threads=4, blk=1 << 14, cap=1 << 27):
+    L = E.lib()
+    L.io_units.restype = C.c_int64
+    buf = C.create_string_buffer(cap)
+    n_rec, n_units, max_len = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+    r = L.io_units(p0.encode(), (p1 or "").encode(), C.c_uint64(ring), C.c_uint64(target), C.c_uint64(mx or ring // 2), int(threads),
+                   C.c_uint64(blk), buf, C.c_uint64(cap), C.byref(n_rec), C.byref(n_units), C.byref(max_len))
+    if r < 0:
+        return r, None, 0, 0
+    return 0, buf.raw[:r].split(b"\n")[:-1], n_rec.value, n_units.value
+
+
+def test_newline_counting_primitives():
+    L = E.lib()
+    L.io_count_newlines.restype = C.c_uint64
+    L.io_after_kth_newline.restype = C.c_uint64
+    rng = np.random.default_rng(0)
+    for n in [0, 1, 15, 16, 17, 63, 64, 65, 1000, 4099]:
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        a[rng.random(n) < 0.1] = 10
+        b = a.tobytes()
+        pos = [i for i, c in enumerate(b) if c == 10]
+        assert L.io_count_newlines(b, C.c_uint64(n)) == len(pos)
+        for k in [1, 2, len(pos) // 2, len(pos)]:
+            if 1 <= k <= len(pos):
+                assert L.io_after_kth_newline(b, C.c_uint64(n), C.c_uint64(k)) == pos[k - 1] + 1
+        assert L.io_after_kth_newline(b, C.c_uint64(n), C.c_uint64(len(pos) + 1)) == n
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+@pytest.mark.parametrize("crlf", [False, True])
+def test_plain_units_single(tmp_path, threads, crlf):
+    reads = _reads(20000, 1)
+    p = str(tmp_path / "r.fq")
+    open(p, "wb").write(_fastq_bytes(reads, crlf=crlf))
+    # a ring of 256 KiB for ~3.5 MB of text: the readers wait for the consumer, blocks and units wrap around the ring's end
+    st, got, n, nu = _units(p, ring=1 << 18, target=1 << 15, threads=threads, blk=5000)
+    assert st == 0 and n == len(reads) and got == reads and nu > 20
+
+
+@pytest.mark.parametrize("kinds", [("plain", "plain"), ("gzip", "bgzf"), ("bgzf", "gzip"), ("bgzf", "bgzf")])
+def test_paired_units_all_sources(tmp_path, kinds):
+    r1, r2 = _reads(15000, 2), _reads(15000, 3, lo=30, hi=200)      # the mates' files differ in bytes per record
+    paths = []
+    for i, (reads, kind) in enumerate(zip((r1, r2), kinds)):
+        data = _fastq_bytes(reads, tricky_quals=(i == 0))
+        p = str(tmp_path / f"r{i}.fq") + ("" if kind == "plain" else ".gz")
+        if kind == "plain":
+            open(p, "wb").write(data)
+        elif kind == "gzip":
+            with gzip.open(p, "wb", compresslevel=4) as f:
+                f.write(data)
+        else:
+            open(p, "wb").write(_bgzf(data, block=30000))
+        paths.append(p)
+    st, got, n, nu = _units(paths[0], paths[1], ring=1 << 19, target=1 << 16, threads=5, blk=1 << 13)
+    assert st == 0 and n == len(r1) and nu > 5
+    assert got[0::2] == r1 and got[1::2] == r2
+
+
+def test_missing_final_newline_and_trailing_blank_lines(tmp_path):
+    reads = _reads(300, 5)
+    data = _fastq_bytes(reads)
+    p = str(tmp_path / "a.fq")
+    open(p, "wb").write(data[:-1])                       # no newline behind the last quality line
+    st, got, n, _ = _units(p, target=4096)
+    assert st == 0 and got == reads
+    open(p, "wb").write(data + b"\n\r\n  \n")              # blank lines at the end are junk kseq skips
+    st, got, n, _ = _units(p, target=4096)
+    assert st == 0 and got == reads
+    with gzip.open(p + ".gz", "wb") as f:
+        f.write(data[:-1])
+    st, got, n, _ = _units(p + ".gz", target=4096)
+    assert st == 0 and got == reads
+    open(p + ".b.gz", "wb").write(_bgzf(data[:-1], block=5000))
+    st, got, n, _ = _units(p + ".b.gz", target=4096)
+    assert st == 0 and got == reads
+
+
+def test_multi_member_gzip_is_one_text(tmp_path):
+    reads = _reads(900, 6)
+    data = _fastq_bytes(reads)
+    cut = data.index(b"\n", len(data) // 2) + 1           # anywhere, even inside a record
+    p = str(tmp_path / "m.fq.gz")
+    with open(p, "wb") as f:
+        f.write(gzip.compress(data[:cut]) + gzip.compress(data[cut:]) + b"\0" * 100)
+    st, got, n, _ = _units(p, target=8192)
+    assert st == 0 and got == reads
+
+
+@pytest.mark.parametrize("text", [
+    b">a\nACGT\n>b\nGG\n",                                  # FASTA
+    b"@a\nACGT\nAC\n+\nIIII\nII\n@b\nGGGG\n+\nIIII\n",      # sequence and quality over two lines
+    b"@a\nACGT\n+\nIIII\n\n@b\nGGGG\n+\nIIII\n",            # an empty line between two records
+    b"@a\nACGT\n+\nIII\n@b\nGGGG\n+\nIIII\n",               # quality shorter than the sequence
+    b"@a\nACGT\n+\nIIIII\n@b\nGGGG\n+\nIIII\n",             # ... longer
+    b"@a\n\n+\n\n@b\nGGGG\n+\nIIII\n",                      # empty sequence
+    b"@a\nACGT\n+\nIIII\n@b\nGGGG\n",                       # the file ends inside a record
+    b"@a\nACGT\n+\nIIII\nxyz",                               # junk behind the last record
+])
+def test_declines_what_is_not_strict_4_line_fastq(tmp_path, text):
+    p = str(tmp_path / "x.fq")
+    open(p, "wb").write(text)
+    st, got, _, _ = _units(p, target=64)
+    assert st in (-1, -11), st                            # the cutter (line counts, tail) or the record check says no
+
+
+def test_declines_late_violation_and_mate_count_mismatch(tmp_path):
+    reads = _reads(4000, 7)
+    data = bytearray(_fastq_bytes(reads, tricky_quals=False))
+    p = str(tmp_path / "late.fq")
+    i = data.rindex(b"\n+\n", 0, len(data) - 400)          # the '+' of a record near the end becomes a base: multi-line record
+    data[i + 1] = ord("A")
+    open(p, "wb").write(bytes(data))
+    st, _, _, _ = _units(p, target=8192)
+    assert st == -11
+    a, b = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    open(a, "wb").write(_fastq_bytes(reads))
+    open(b, "wb").write(_fastq_bytes(reads[:-3]))
+    assert _units(a, b, target=8192)[0] == -2
+    assert _units(b, a, target=8192)[0] == -2
+
+
+def test_record_larger_than_a_unit(tmp_path):
+    reads = [b"ACGT" * 10, b"A" * 50000, b"GGCC" * 5]
+    p = str(tmp_path / "big.fq")
+    open(p, "wb").write(_fastq_bytes(reads, tricky_quals=False))
+    st, got, _, _ = _units(p, ring=1 << 20, target=1024, mx=1 << 19, blk=4096)
+    assert st == 0 and got == reads                       # the cutter widens the unit until it holds a record
+    st, _, _, _ = _units(p, ring=1 << 16, target=1024, mx=1 << 15, blk=4096)
+    assert st == -4                                       # ... and gives up when the ring cannot hold one
+
+
+def test_carriage_return_rule_of_kseq(tmp_path):
+    # ks_getuntil2 drops a trailing '\r' only from a line of more than one character (src/kseq.h:137)
+    p = str(tmp_path / "cr.fq")
+    open(p, "wb").write(b"@a\r\nA\r\n+\r\nI\r\n@b\r\n\r\n+\r\n\r\n")
+    st, got, _, _ = _units(p, target=16)
+    assert st == 0 and got == [b"A", b"\r"]
