@@ -68,6 +68,11 @@ class _Profile(C.Structure):
                 ("last_fin_stream_words", C.c_uint64), ("last_fin_cand_words", C.c_uint64)]
 
 
+class _FastqUnit(C.Structure):
+    _fields_ = [("d_words", C.c_void_p), ("d_len", C.c_void_p), ("n_items", C.c_uint64), ("max_len", C.c_int32), ("status", C.c_int32),
+                ("first_bad_record", C.c_uint64)]
+
+
 class _EcResult(C.Structure):
     _fields_ = [("n_ecs", C.c_uint64), ("nnz", C.c_uint64), ("n_pseudoaligned", C.c_uint64), ("d_ec_off", C.c_void_p),
                 ("d_ec_ids", C.c_void_p), ("d_counts", C.c_void_p)]
@@ -96,6 +101,7 @@ _SYMBOLS = {
                                                C.c_uint64, C.c_uint64]),
     "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
+    "kamd_fastq_unit_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(_FastqUnit)]),
     "kamd_pseudoalign": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "kamd_fld_prefetch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
@@ -329,6 +335,31 @@ class Context:
         dw = torch.from_numpy(words.view(np.int32)).to(f"cuda:{self.device}")
         dl = torch.from_numpy(l16.view(np.int16)).to(f"cuda:{self.device}")
         return dw, dl, max_len
+
+    def fastq_unit_pack(self, texts, n_records: int):
+        """kamd_fastq_unit_pack: one unit of strict 4-line FASTQ text per file (bytes, or uint8 device tensors) -> the packed batch
+        (views of the context's buffers, valid until the next call).  Returns (words, lens, n_items, max_len, status, first_bad)."""
+        torch = self.torch
+        dev = f"cuda:{self.device}"
+        keep = []
+        for t in texts:
+            if isinstance(t, (bytes, bytearray)):
+                pad = torch.zeros(len(t) + 64, dtype=torch.uint8)
+                pad[:len(t)] = torch.frombuffer(bytearray(t), dtype=torch.uint8)
+                keep.append((pad.to(dev), len(t)))
+            else:
+                assert t.dtype == torch.uint8 and t.is_cuda
+                keep.append((t, t.numel()))
+        ptrs = (C.c_void_p * 2)(*[k[0].data_ptr() for k in keep], *([None] * (2 - len(keep))))
+        nb = (C.c_uint64 * 2)(*[k[1] for k in keep], *([0] * (2 - len(keep))))
+        u = _FastqUnit()
+        _check(load_library().kamd_fastq_unit_pack(self._h, ptrs, nb, len(keep), int(n_records), C.byref(u)), "kamd_fastq_unit_pack")
+        words = lens = None
+        if u.status == 0 and u.n_items:
+            n_reads = int(u.n_items) * len(keep)
+            words = _alias_tensor(torch, u.d_words, n_reads * packed_record_words(int(u.max_len)), torch.int32, self.device)
+            lens = _alias_tensor(torch, u.d_len, n_reads, torch.int16, self.device)
+        return words, lens, int(u.n_items), int(u.max_len), int(u.status), int(u.first_bad_record)
 
     # ---- pseudoalignment ----
     def pseudoalign(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):
@@ -691,7 +722,7 @@ def _alias_tensor(torch, ptr: int, n: int, dtype, device: int):
     class _Holder:
         pass
     h = _Holder()
-    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1", torch.float64: "<f8"}[dtype]
+    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1", torch.float64: "<f8", torch.int16: "<i2"}[dtype]
     h.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
     return torch.as_tensor(h, device=f"cuda:{device}")
 

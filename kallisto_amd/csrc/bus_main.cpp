@@ -182,21 +182,27 @@ int bus_main(int argc, char** argv) {
   std::vector<std::vector<uint32_t>> sample_flens(batch_ids.size(), std::vector<uint32_t>(KAMD_MAX_FRAG_LEN, 0));
   uint64_t n_processed = 0, num_pseudoaligned = 0, num_unique = 0;
   double pack_s = 0.0;
+  // one pipeline for all samples (text rings and buffers are allocated once); the sample under way is behind these two
+  uint32_t* flens = nullptr;
+  uint64_t fld_used = 0;
+  auto run_batch = [&](int, PackedBatch& b, std::string& err) -> int {
+    const bool want_fld = paired && fld_used < 10000;
+    int rc = 0;
+    if (want_fld) rc = kamd_fld_prefetch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);
+    if (!rc) rc = kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);
+    if (!rc && want_fld) rc = kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used);
+    if (rc) err = kamd_last_error();
+    return rc;
+  };
+  UnitFeeder feeder({ctx}, {0}, run_batch, [] { return false; });
   for (size_t sidx = 0; sidx < batch_files.size(); sidx++) {
     KX(kamd_ec_reset(ctx));                         // a sample starts from an empty collector
-    uint32_t* flens = sample_flens[sidx].data();
-    uint64_t fld_used = 0;                          // tlencounts[id]: the first 10 000 qualifying pairs of THIS sample (ProcessReads.cpp:1395-1399)
+    flens = sample_flens[sidx].data();
+    fld_used = 0;                                   // tlencounts[id]: the first 10 000 qualifying pairs of THIS sample (ProcessReads.cpp:1395-1399)
     {
-      MultiPipe pipe(1, [&](int, PackedBatch& b, std::string& err) -> int {
-        const bool want_fld = paired && fld_used < 10000;
-        int rc = 0;
-        if (want_fld) rc = kamd_fld_prefetch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);
-        if (!rc) rc = kamd_pseudoalign(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len);
-        if (!rc && want_fld) rc = kamd_fld_from_batch(ctx, &qo, b.d_words, b.d_len, b.n_items, b.max_len, flens, &fld_used);
-        if (rc) err = kamd_last_error();
-        return rc;
-      }, [] { return false; });
-      if (feed_files(batch_files[sidx], paired, batch, std::max(1, threads), threads, verbose, pipe, n_processed, pack_s)) return 1;
+      MultiPipe pipe(1, run_batch, [] { return false; });
+      auto reset_sample = [&]() -> int { std::fill(sample_flens[sidx].begin(), sample_flens[sidx].end(), 0u); fld_used = 0; return kamd_ec_reset(ctx); };
+      if (feed_files(batch_files[sidx], paired, batch, std::max(1, threads), threads, verbose, pipe, n_processed, pack_s, &feeder, reset_sample)) return 1;
       pipe.finish();
       if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
     }

@@ -31,6 +31,7 @@
 
 #include "../../include/kallisto_amd.h"
 #include "kamd_fastq.h"
+#include "kamd_textsource.h"
 
 namespace kamd_fe {
 using namespace kamd_io;
@@ -139,6 +140,10 @@ class MultiPipe {
   MultiPipe(int n, std::function<int(int, PackedBatch&, std::string&)> run, std::function<bool()> pin_to_first) : pin_(std::move(pin_to_first)) {
     for (int g = 0; g < n; g++) pipes_.emplace_back(new DevicePipe([run, g](PackedBatch& b, std::string& e) { return run(g, b, e); }, g));
   }
+  // pipeline g on HIP device devices[g] (several pipelines may share a device)
+  MultiPipe(const std::vector<int>& devices, std::function<int(int, PackedBatch&, std::string&)> run, std::function<bool()> pin_to_first) : pin_(std::move(pin_to_first)) {
+    for (size_t g = 0; g < devices.size(); g++) pipes_.emplace_back(new DevicePipe([run, g](PackedBatch& b, std::string& e) { return run((int)g, b, e); }, devices[g]));
+  }
   PackedBatch& acquire(uint64_t n_words, uint64_t n_reads) {
     cur_ = pin_() ? 0 : (int)(rr_++ % pipes_.size());
     return pipes_[cur_]->acquire(n_words, n_reads);
@@ -155,9 +160,284 @@ class MultiPipe {
   int cur_ = 0; uint64_t rr_ = 0;
 };
 
-// ---- abundance.h5 (H5Writer.cpp:4-69, h5utils.h:42-92): one chunk per dataset, deflate level 6, strings as fixed-size
-// NUL-terminated C strings of the longest entry + 1.  libhdf5 is loaded at run time (dlopen), so the front-end neither
-// needs it to build nor drags its dependencies into a process that already holds the HIP runtime.  Written without
+// ---- the device-parse pipeline --------------------------------------------------------------------------------------------
+// Strict 4-line FASTQ (plain, gzip or BGZF) never meets a host parser: host threads move the text of the file(s) into rings of
+// pinned memory and count newlines (kamd_textsource.h), the calling thread cuts units of whole records and deals them to the
+// GPUs (round robin; to GPU 0 while the fragment-length sample is open), a copy stream per GPU brings a unit's bytes into one of
+// its text buffers, and the GPU's consumer thread runs kamd_fastq_unit_pack (lines, record check, 2-bit packing on the device) and
+// then the same `run` callback the host-packed path uses.  Units are processed in input order on every GPU.  A unit the device
+// parser declines (multi-line records, FASTA ...) stops the feeder with DECLINED: the caller starts over with the general reader.
+class UnitFeeder {
+ public:
+  enum { OK = 0, FAILED = 1, DECLINED = 2 };
+  // ring: pinned bytes per file; target: bytes of file 0 per unit; max_unit: capacity of a device text buffer; block: bytes a reader
+  // thread moves (and counts) at a time
+  struct Sizes { size_t ring = 192u << 20, target = 32u << 20, max_unit = 64u << 20, block = 1u << 20; int bufs = 3; };
+  static Sizes sizes_from_env() {
+    Sizes z;
+    size_t t = 0;
+    if (const char* e = getenv("KAMD_FQ_UNIT_MB")) t = (size_t)std::max(1, atoi(e)) << 20;
+    if (const char* e = getenv("KAMD_FQ_UNIT_BYTES")) t = (size_t)std::max(256, atoi(e));   // (tests: many units from small files)
+    if (t) { z.target = t; z.max_unit = std::max<size_t>(2 * t, 1u << 20); z.block = std::min<size_t>(z.block, std::max<size_t>(t / 4, 64)); z.ring = std::max<size_t>(6 * t, z.max_unit + 4 * z.block + (1u << 16)); }
+    if (const char* e = getenv("KAMD_FQ_RING_MB")) z.ring = std::max((size_t)std::max(1, atoi(e)) << 20, z.max_unit + 4 * z.block + (1u << 16));
+    return z;
+  }
+  // ctxs[g] lives on HIP device devices[g] (several contexts may share a device)
+  UnitFeeder(std::vector<kamd_ctx*> ctxs, std::vector<int> devices, std::function<int(int, PackedBatch&, std::string&)> run,
+             std::function<bool()> pin_to_first, Sizes z = sizes_from_env())
+      : ctxs_(std::move(ctxs)), devs_(std::move(devices)), run_(std::move(run)), pin_(std::move(pin_to_first)), z_(z) {
+    for (size_t g = 0; g < ctxs_.size(); g++) gpus_.emplace_back(new Gpu);
+  }
+  ~UnitFeeder() {
+    stop_consumers();
+    for (size_t g = 0; g < gpus_.size(); g++) {
+      (void)hipSetDevice(devs_[g]);
+      Gpu& G = *gpus_[g];
+      for (auto& b : G.bufs) { for (int f = 0; f < 2; f++) if (b.d[f]) (void)hipFree(b.d[f]); if (b.copied) (void)hipEventDestroy(b.copied); }
+      if (G.copy) (void)hipStreamDestroy(G.copy);
+    }
+    for (int f = 0; f < 2; f++) if (ring_[f]) (void)hipHostFree(ring_[f]);
+  }
+  // pinned rings and device text buffers (slow: page pinning) -- callable from another thread while the index loads
+  int prepare(int n_files) {
+    std::lock_guard<std::mutex> lk(prep_m_);
+    for (int f = 0; f < n_files; f++)
+      if (!ring_[f] && hipHostMalloc((void**)&ring_[f], z_.ring, hipHostMallocPortable) != hipSuccess) { error_ = "pinned allocation of the text ring failed"; return FAILED; }
+    for (size_t g = 0; g < gpus_.size(); g++) {
+      Gpu& G = *gpus_[g];
+      if (hipSetDevice(devs_[g]) != hipSuccess) { error_ = "hipSetDevice failed"; return FAILED; }
+      if (!G.copy && hipStreamCreateWithFlags(&G.copy, hipStreamNonBlocking) != hipSuccess) { error_ = "hipStreamCreate failed"; return FAILED; }
+      if (G.bufs.empty()) G.bufs.resize((size_t)z_.bufs);
+      for (auto& b : G.bufs) {
+        for (int f = 0; f < n_files; f++)
+          if (!b.d[f] && hipMalloc((void**)&b.d[f], z_.max_unit + 64) != hipSuccess) { error_ = "device allocation of a text buffer failed"; return FAILED; }
+        if (!b.copied && hipEventCreateWithFlags(&b.copied, hipEventDisableTiming) != hipSuccess) { error_ = "hipEventCreate failed"; return FAILED; }
+      }
+    }
+    return OK;
+  }
+  const std::string& error() const { return error_; }
+  double wait_s = 0.0, device_s = 0.0;   // dispatcher blocked on a free text buffer / busiest consumer
+  uint64_t units = 0, bytes = 0;
+
+  // the reads of one file (single-end) or one pair of files; n_items receives the records handed to `run`
+  int feed(const std::string& f0, const std::string* f1, int io_threads, uint64_t& n_items, bool verbose) {
+    const int nf = f1 ? 2 : 1;
+    if (prepare(nf) != OK) return FAILED;
+    start_consumers();
+    const int per_file = std::max(1, io_threads / nf);
+    std::unique_ptr<TextSource> src[2];
+    for (int f = 0; f < nf; f++) {
+      src[f].reset(new TextSource(f ? *f1 : f0, ring_[f], z_.ring, per_file, z_.block));
+      if (src[f]->failed()) { error_ = src[f]->error(); return FAILED; }
+    }
+    UnitCutter cut(src[0].get(), nf == 2 ? src[1].get() : nullptr, z_.target, z_.max_unit);
+    tracker_.reset(src, nf);
+    UnitCut u;
+    int rc = OK;
+    for (;;) {
+      const int c = cut.next(u);
+      if (c == UnitCutter::DONE) break;
+      if (c == UnitCutter::IO_ERROR) { for (int f = 0; f < nf; f++) if (src[f]->failed()) error_ = src[f]->error(); rc = FAILED; break; }
+      if (c == UnitCutter::COUNT_MISMATCH) { error_ = "paired-end files have different numbers of reads"; rc = FAILED; break; }
+      if (c < 0) { rc = DECLINED; break; }   // NOT_STRICT, TOO_LONG: the general reader decides what this input is
+      if (state() != OK) break;
+      const int g = pin_() ? 0 : (int)(rr_++ % gpus_.size());
+      Gpu& G = *gpus_[g];
+      int bi;
+      {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::unique_lock<std::mutex> lk(G.m);
+        G.cv.wait(lk, [&] { for (auto& b : G.bufs) if (!b.busy) return true; return false; });
+        wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        bi = 0; while (G.bufs[bi].busy) ++bi;
+        G.bufs[bi].busy = true;
+      }
+      Buf& b = G.bufs[bi];
+      if (hipSetDevice(devs_[g]) != hipSuccess) { error_ = "hipSetDevice failed"; rc = FAILED; break; }
+      bool ok = true;
+      for (int f = 0; f < nf && ok; f++) {
+        const char* p[2]; size_t n[2];
+        const int np = src[f]->pieces(u.begin[f], u.end[f], p, n);
+        size_t at = 0;
+        for (int i = 0; i < np && ok; i++) { ok = hipMemcpyAsync(b.d[f] + at, p[i], n[i], hipMemcpyHostToDevice, G.copy) == hipSuccess; at += n[i]; }
+        b.n_bytes[f] = u.end[f] - u.begin[f];
+        bytes += b.n_bytes[f];
+      }
+      if (ok) ok = hipEventRecord(b.copied, G.copy) == hipSuccess;
+      if (!ok) { error_ = "copy of a unit of text to the device failed"; rc = FAILED; break; }
+      b.n_records = u.n_records; b.n_files = nf;
+      b.seq = tracker_.add(u.end);
+      { std::lock_guard<std::mutex> lk(G.m); G.queue.push_back(bi); }
+      G.cv.notify_all();
+      n_items += u.n_records; ++units;
+      if (verbose) std::cerr << "[quant] processed " << n_items << (nf == 2 ? " pairs" : " reads") << std::endl;
+    }
+    // every unit of this input leaves the rings before the sources go away
+    drain();
+    if (rc == OK) rc = state();
+    if (rc == FAILED && error_.empty()) error_ = fail_msg();
+    return rc;
+  }
+  void finish() { drain(); stop_consumers(); }
+  // after DECLINED: the next input (another sample) may try the device parser again
+  void clear_declined() { std::lock_guard<std::mutex> g(st_m_); if (state_ == DECLINED) state_ = OK; }
+
+ private:
+  struct Buf { char* d[2] = {nullptr, nullptr}; uint64_t n_bytes[2] = {0, 0}, n_records = 0, seq = 0; int n_files = 1; hipEvent_t copied = nullptr; bool busy = false; };
+  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue; std::mutex m; std::condition_variable cv; std::thread th; double busy_s = 0.0; };
+  // the rings are released in input order, whatever order the GPUs' copies complete in
+  struct Tracker {
+    std::mutex m; TextSource* s[2] = {nullptr, nullptr}; int nf = 0;
+    std::deque<std::pair<uint64_t, uint64_t>> ends; std::deque<char> done; uint64_t first = 0, next = 0;
+    void reset(std::unique_ptr<TextSource> src[2], int n) { std::lock_guard<std::mutex> g(m); nf = n; for (int f = 0; f < 2; f++) s[f] = f < n ? src[f].get() : nullptr; ends.clear(); done.clear(); first = next; }
+    uint64_t add(const uint64_t end[2]) { std::lock_guard<std::mutex> g(m); ends.emplace_back(end[0], end[1]); done.push_back(0); return next++; }
+    void complete(uint64_t seq) {
+      std::lock_guard<std::mutex> g(m);
+      if (seq < first) return;
+      done[(size_t)(seq - first)] = 1;
+      while (!done.empty() && done.front()) {
+        if (s[0]) s[0]->release(ends.front().first);
+        if (s[1]) s[1]->release(ends.front().second);
+        ends.pop_front(); done.pop_front(); ++first;
+      }
+    }
+    void detach() { std::lock_guard<std::mutex> g(m); s[0] = s[1] = nullptr; }
+  };
+  int state() { std::lock_guard<std::mutex> g(st_m_); return state_; }
+  std::string fail_msg() { std::lock_guard<std::mutex> g(st_m_); return fail_msg_; }
+  void set_state(int s, const std::string& msg) { std::lock_guard<std::mutex> g(st_m_); if (state_ == OK) { state_ = s; fail_msg_ = msg; } }
+  void start_consumers() {
+    if (started_) return;
+    started_ = true;
+    for (size_t g = 0; g < gpus_.size(); g++) gpus_[g]->th = std::thread([this, g] { consume((int)g); });
+  }
+  void stop_consumers() {
+    if (!started_) return;
+    for (auto& G : gpus_) { { std::lock_guard<std::mutex> lk(G->m); G->queue.push_back(-1); } G->cv.notify_all(); }
+    for (auto& G : gpus_) if (G->th.joinable()) G->th.join();
+    started_ = false;
+    device_s = 0.0;
+    for (auto& G : gpus_) device_s = std::max(device_s, G->busy_s);
+  }
+  void drain() {   // until no text buffer is in flight
+    for (auto& G : gpus_) {
+      std::unique_lock<std::mutex> lk(G->m);
+      G->cv.wait(lk, [&] { for (auto& b : G->bufs) if (b.busy) return false; return true; });
+    }
+    tracker_.detach();
+  }
+  void consume(int g) {
+    Gpu& G = *gpus_[g];
+    if (hipSetDevice(devs_[g]) != hipSuccess) { set_state(FAILED, "hipSetDevice failed"); }
+    for (;;) {
+      int bi;
+      {
+        std::unique_lock<std::mutex> lk(G.m);
+        G.cv.wait(lk, [&] { return !G.queue.empty(); });
+        bi = G.queue.front(); G.queue.pop_front();
+      }
+      if (bi < 0) return;
+      Buf& b = G.bufs[bi];
+      const auto t0 = std::chrono::steady_clock::now();
+      const bool copied = hipEventSynchronize(b.copied) == hipSuccess;
+      tracker_.complete(b.seq);   // the unit's bytes have left the ring
+      if (!copied) set_state(FAILED, "copy of a unit of text to the device failed");
+      if (state() == OK) {   // (after a failure or a declined unit the remaining units are only drained)
+        kamd_fastq_unit fu;
+        const char* txt[2] = {b.d[0], b.d[1]};
+        if (kamd_fastq_unit_pack(ctxs_[g], txt, b.n_bytes, b.n_files, b.n_records, &fu) != 0) set_state(FAILED, kamd_last_error());
+        else if (fu.status == 3) set_state(FAILED, "reads longer than 65535 bp are outside the short-read GPU path");
+        else if (fu.status != 0) set_state(DECLINED, "");
+        else {
+          PackedBatch pb;
+          pb.d_words = const_cast<uint32_t*>(fu.d_words); pb.d_len = const_cast<uint16_t*>(fu.d_len);
+          pb.n_items = fu.n_items; pb.n_reads = fu.n_items * (uint64_t)b.n_files; pb.max_len = fu.max_len; pb.filled = true;
+          std::string err;
+          if (run_(g, pb, err)) set_state(FAILED, err);
+        }
+      }
+      G.busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      { std::lock_guard<std::mutex> lk(G.m); b.busy = false; }
+      G.cv.notify_all();
+    }
+  }
+  std::vector<kamd_ctx*> ctxs_; std::vector<int> devs_;
+  std::function<int(int, PackedBatch&, std::string&)> run_;
+  std::function<bool()> pin_;
+  Sizes z_;
+  char* ring_[2] = {nullptr, nullptr};
+  std::vector<std::unique_ptr<Gpu>> gpus_;
+  Tracker tracker_;
+  std::mutex st_m_, prep_m_; int state_ = OK; std::string fail_msg_, error_;
+  bool started_ = false;
+  uint64_t rr_ = 0;
+};
+
+// ---- --share-device: the several-GPU flow of the front-end on ONE device --------------------------------------------------------
+// RCCL refuses two ranks on one device, so a single-GPU box could never execute `--gpus N` (one context, pipeline and host thread
+// per rank, EC merge, partitioned EM, replicates dealt round the ranks).  With --share-device every rank's context lives on
+// device 0 and the collectives are these callbacks (kamd_comm_create_callbacks): a barrier among the ranks' host threads, the data
+// staged through the host.  A test vehicle for the N > 1 code path, not a way to go faster.
+class SharedDeviceComm {
+ public:
+  explicit SharedDeviceComm(int world) : world_(world), stage_((size_t)world), ranks_((size_t)world) { for (int r = 0; r < world; r++) ranks_[r] = Rank{this, r}; }
+  struct Rank { SharedDeviceComm* self; int rank; };
+  void* user(int r) { return &ranks_[(size_t)r]; }
+  static kamd_comm_callbacks callbacks() { kamd_comm_callbacks cb; cb.allreduce_sum = &allreduce; cb.allgather = &allgather; cb.broadcast = &broadcast; return cb; }
+ private:
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m_);
+    const uint64_t gen = gen_;
+    if (++arrived_ == world_) { arrived_ = 0; ++gen_; cv_.notify_all(); }
+    else cv_.wait(lk, [&] { return gen_ != gen; });
+  }
+  static int allreduce(void* user, void* d_buf, uint64_t count, int32_t type) {
+    Rank* R = (Rank*)user; SharedDeviceComm* S = R->self;
+    const size_t esz = type <= 1 ? 4 : 8, bytes = (size_t)count * esz;
+    std::vector<unsigned char>& mine = S->stage_[(size_t)R->rank];
+    mine.resize(bytes);
+    if (hipMemcpy(mine.data(), d_buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    S->barrier();
+    std::vector<unsigned char> sum(bytes, 0);
+    for (int r = 0; r < S->world_; r++) {
+      const unsigned char* p = S->stage_[(size_t)r].data();
+      for (uint64_t i = 0; i < count; i++) {
+        if (type == 0) ((uint32_t*)sum.data())[i] += ((const uint32_t*)p)[i];
+        else if (type == 1) ((int32_t*)sum.data())[i] += ((const int32_t*)p)[i];
+        else if (type == 2) ((uint64_t*)sum.data())[i] += ((const uint64_t*)p)[i];
+        else ((double*)sum.data())[i] += ((const double*)p)[i];
+      }
+    }
+    S->barrier();   // everybody has read the staging buffers
+    return hipMemcpy(d_buf, sum.data(), bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+  }
+  static int allgather(void* user, const void* d_send, void* d_recv, uint64_t bytes) {
+    Rank* R = (Rank*)user; SharedDeviceComm* S = R->self;
+    std::vector<unsigned char>& mine = S->stage_[(size_t)R->rank];
+    mine.resize((size_t)bytes);
+    if (hipMemcpy(mine.data(), d_send, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    S->barrier();
+    int rc = 0;
+    for (int r = 0; r < S->world_ && !rc; r++)
+      rc = hipMemcpy((char*)d_recv + (size_t)r * bytes, S->stage_[(size_t)r].data(), (size_t)bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+    S->barrier();
+    return rc;
+  }
+  static int broadcast(void* user, void* d_buf, uint64_t bytes, int32_t root) {
+    Rank* R = (Rank*)user; SharedDeviceComm* S = R->self;
+    int rc = 0;
+    if (R->rank == root) { S->stage_[(size_t)root].resize((size_t)bytes); rc = hipMemcpy(S->stage_[(size_t)root].data(), d_buf, (size_t)bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1; }
+    S->barrier();
+    if (R->rank != root) rc = hipMemcpy(d_buf, S->stage_[(size_t)root].data(), (size_t)bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+    S->barrier();
+    return rc;
+  }
+  int world_;
+  std::vector<std::vector<unsigned char>> stage_;
+  std::vector<Rank> ranks_;
+  std::mutex m_; std::condition_variable cv_; int arrived_ = 0; uint64_t gen_ = 0;
+};
 
 inline std::string to_json(const std::string& id, const std::string& val, bool quote, bool comma = true) {  // PlaintextWriter.cpp:113-137
   std::string out = "\t\"" + id + "\": ";
@@ -183,8 +463,39 @@ inline void write_abundance(const std::string& path, const kamd_index* idx, cons
 // Reads the FASTA/FASTQ(.gz) files of one sample (FastqSequenceReader::fetchSequences, src/ProcessReads.cpp:3128-3267: mates in
 // consecutive files), packs batches of `batch` reads / pairs with all host threads and hands them to the pipeline in input
 // order.  Returns 0, or 1 after printing the error.
+// a file the device parser may take: a regular file that is gzip, or plain text that starts like a FASTQ record
+inline bool device_parse_candidate(const std::string& path) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) return false;
+  unsigned char m[2] = {0, 0};
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  const size_t n = fread(m, 1, 2, f); fclose(f);
+  return (n == 2 && m[0] == 0x1f && m[1] == 0x8b) || (n >= 1 && m[0] == '@');
+}
+
+// `units` (optional): the device-parse pipeline; strict 4-line FASTQ goes through it, and when it declines an input `reset` must put
+// the run back to its start (EC counts, fragment-length sample, whatever `run` accumulates): all files are then read again with
+// the general reader below.
 inline int feed_files(const std::vector<std::string>& files, bool paired, uint64_t batch, int host_threads, int io_threads, bool verbose,
-                      MultiPipe& pipe, uint64_t& n_processed, double& pack_s) {
+                      MultiPipe& pipe, uint64_t& n_processed, double& pack_s, UnitFeeder* units = nullptr,
+                      const std::function<int()>& reset = nullptr) {
+  const uint64_t n_before = n_processed;
+  if (units && !getenv("KAMD_HOST_PARSE")) {
+    bool all = true;
+    for (const auto& f : files) all = all && device_parse_candidate(f);
+    int rc = all ? UnitFeeder::OK : UnitFeeder::DECLINED;
+    for (size_t fi = 0; all && fi < files.size() && rc == UnitFeeder::OK; fi += paired ? 2 : 1)
+      rc = units->feed(files[fi], paired ? &files[fi + 1] : nullptr, io_threads, n_processed, verbose);
+    units->finish();
+    if (rc == UnitFeeder::OK) return 0;
+    if (rc == UnitFeeder::FAILED) { std::cerr << "Error: " << units->error() << std::endl; return 1; }
+    // declined: not (only) strict 4-line FASTQ -- start over with the general reader
+    if (all && verbose) std::cerr << "[quant] input is not strict 4-line FASTQ: reading it with the general FASTA/FASTQ reader" << std::endl;
+    if (all && reset && reset()) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+    units->clear_declined();
+    n_processed = n_before;
+  }
   auto pack_and_submit = [&](const char* d1, const uint64_t* off1, const int32_t* len1, const char* d2, const uint64_t* off2, const int32_t* len2,
                              uint64_t nb, int32_t max_len) -> int {
     if (max_len > 65535) { std::cerr << "Error: reads longer than 65535 bp are outside the short-read GPU path" << std::endl; return 1; }

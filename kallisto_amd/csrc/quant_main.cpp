@@ -11,7 +11,7 @@ using namespace kamd_fe;
 struct Options {
   std::string index, output;
   std::vector<std::string> files;
-  bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false, do_union = false;
+  bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false, do_union = false, share_device = false;
   int gpus = 1;
   int strand = 0, bootstrap = 0, threads = 1;
   double fld = 0.0, sd = 0.0;
@@ -42,7 +42,9 @@ void usage() {
             << "-t, --threads=INT             Host threads for index loading (default: 1)\n"
             << "    --verbose                 Print out progress information\n"
             << "    --gpus=INT                GPUs of this node to use (default: 1): batches of reads go round the GPUs, the EC counts\n"
-            << "                              are merged with one RCCL all-reduce + all-gathers, the EM runs partitioned over them\n";
+            << "                              are merged with one RCCL all-reduce + all-gathers, the EM runs partitioned over them\n"
+            << "    --share-device            with --gpus N: all N ranks on device 0, collectives staged through the host (runs the\n"
+            << "                              several-GPU code path on a single-GPU box; for testing)\n";
 }
 
 
@@ -182,6 +184,7 @@ int main(int argc, char** argv) {
     else if (a == "--union") opt.do_union = true;
     else if (a == "--plaintext") opt.plaintext = true;
     else if (a == "--verbose") opt.verbose = true;
+    else if (a == "--share-device") opt.share_device = true;
     else if (a == "--bias" || a == "--fusion" || a == "--pseudobam" || a == "--genomebam" || a == "--long" || a == "-p" || a == "--priors" ||
              a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--dfk-onlist" ||
              a == "-P" || a == "--platform" || a == "-N" || a == "--numReads") {
@@ -217,43 +220,24 @@ int main(int argc, char** argv) {
   if (!ok) { std::cerr << std::endl; usage(); return 1; }
   const std::string start_time = now_string(), call = call_string(argc, argv);
 
-  // index (KmerIndex::load) + device context
-  kamd_index* idx = nullptr;
+  // device contexts first (they do not need the index): the pinned text rings of the device-parse pipeline are allocated by a
+  // second thread while the index is read and flattened (KmerIndex::load)
   const auto t_start = std::chrono::steady_clock::now();
-  KX(kamd_index_load(opt.index.c_str(), opt.threads, &idx));
-  kamd_index_view v; KX(kamd_index_get_view(idx, &v));
-  const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
   int n_dev = 0;
   HIPX(hipGetDeviceCount(&n_dev));
   const int n_gpus = std::max(1, opt.gpus);
-  if (n_gpus > n_dev) { std::cerr << "Error: --gpus " << n_gpus << " but only " << n_dev << " HIP device(s) are visible" << std::endl; return 1; }
+  if (!opt.share_device && n_gpus > n_dev) { std::cerr << "Error: --gpus " << n_gpus << " but only " << n_dev << " HIP device(s) are visible" << std::endl; return 1; }
+  std::vector<int> devices((size_t)n_gpus);
+  for (int g = 0; g < n_gpus; g++) devices[g] = opt.share_device ? 0 : g;
   std::vector<kamd_ctx*> ctxs((size_t)n_gpus, nullptr);
-  {
-    std::vector<std::thread> th; std::vector<int> rcs((size_t)n_gpus, 0); std::vector<std::string> errs((size_t)n_gpus);
-    for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {   // the index is replicated in every GPU's HBM
-      rcs[g] = kamd_ctx_create(g, nullptr, &ctxs[g]);
-      if (!rcs[g]) rcs[g] = kamd_index_upload(ctxs[g], idx);
-      if (rcs[g]) errs[g] = kamd_last_error();
-    });
-    for (auto& x : th) x.join();
-    for (int g = 0; g < n_gpus; g++) if (rcs[g]) { std::cerr << "Error: " << errs[g] << std::endl; return 1; }
-  }
+  for (int g = 0; g < n_gpus; g++) KX(kamd_ctx_create(devices[g], nullptr, &ctxs[g]));
   kamd_ctx* ctx = ctxs[0];
-  const double index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
-  // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
-  // (one GPU only: records merged from several GPUs have no input order -- like the reference at -t > 1)
-  if (opt.bootstrap > 0 && n_gpus == 1) KX(kamd_ec_track_order(ctx, 1));
-
   const bool paired = !opt.single;
   kamd_quant_opts qo{paired ? 1 : 0, opt.fld, opt.sd, opt.single_overhang ? 1 : 0, opt.strand, opt.no_jump ? 1 : 0, opt.do_union ? 1 : 0};
-  std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;
   std::atomic<bool> fld_open{paired && opt.fld == 0.0};   // the fragment-length sample is still being collected (on GPU 0)
-  double pack_s = 0.0;
-  MultiPipe pipe(n_gpus, [&](int g, PackedBatch& b, std::string& err) -> int {
+  auto run_batch = [&](int g, PackedBatch& b, std::string& err) -> int {
     const bool want_fld = g == 0 && paired && opt.fld == 0.0 && fld_used < 10000;
     int rc = 0;
     if (want_fld) rc = kamd_fld_prefetch(ctxs[g], &qo, b.d_words, b.d_len, b.n_items, b.max_len);   // runs underneath kernel A
@@ -262,18 +246,60 @@ int main(int argc, char** argv) {
     if (g == 0 && fld_used >= 10000) fld_open = false;
     if (rc) err = kamd_last_error();
     return rc;
-  }, [&] { return n_gpus > 1 && fld_open.load(); });
+  };
+  auto pin_first = [&] { return n_gpus > 1 && fld_open.load(); };
+  UnitFeeder feeder(ctxs, devices, run_batch, pin_first);
+  std::thread prep([&] { (void)feeder.prepare(paired ? 2 : 1); });
+  // index: the flattened tables written by `kallisto_amd_quant flatten` are used when they lie beside the index (<index>.kamd, not older
+  // than it); the kallisto index stays the source of truth
+  std::string index_path = opt.index;
+  {
+    struct stat si, sf;
+    const std::string flat = opt.index + ".kamd";
+    if (!getenv("KAMD_NO_FLAT_INDEX") && stat(opt.index.c_str(), &si) == 0 && stat(flat.c_str(), &sf) == 0 && sf.st_mtime >= si.st_mtime) index_path = flat;
+  }
+  kamd_index* idx = nullptr;
+  if (kamd_index_load(index_path.c_str(), opt.threads, &idx) != 0) { const std::string e = kamd_last_error(); prep.join(); std::cerr << "Error: " << e << std::endl; return 1; }
+  kamd_index_view v; KX(kamd_index_get_view(idx, &v));
+  const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
+  {
+    std::vector<std::thread> th; std::vector<int> rcs((size_t)n_gpus, 0); std::vector<std::string> errs((size_t)n_gpus);
+    for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {   // the index is replicated in every GPU's HBM
+      rcs[g] = kamd_index_upload(ctxs[g], idx);
+      if (rcs[g]) errs[g] = kamd_last_error();
+    });
+    for (auto& x : th) x.join();
+    prep.join();
+    for (int g = 0; g < n_gpus; g++) if (rcs[g]) { std::cerr << "Error: " << errs[g] << std::endl; return 1; }
+  }
+  const double index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (opt.verbose && index_path != opt.index) std::cerr << "[index] using the flattened tables of " << index_path << std::endl;
+  if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
+  // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
+  // (one GPU only: records merged from several GPUs have no input order -- like the reference at -t > 1)
+  if (opt.bootstrap > 0 && n_gpus == 1) KX(kamd_ec_track_order(ctx, 1));
+  std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
+  double pack_s = 0.0;
+  MultiPipe pipe(devices, run_batch, pin_first);
+  // the device parser declined the input: the run starts over with the general reader
+  auto reset_run = [&]() -> int {
+    for (kamd_ctx* x : ctxs) if (int rc = kamd_ec_reset(x)) return rc;
+    memset(flens, 0, sizeof flens); fld_used = 0; fld_open = paired && opt.fld == 0.0;
+    return 0;
+  };
   for (size_t fi = 0; fi < opt.files.size(); fi += paired ? 2 : 1) {
     std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
     if (paired) std::cerr << "                             " << opt.files[fi + 1] << std::endl;
   }
-  if (feed_files(opt.files, paired, opt.batch, std::max(1, opt.threads), opt.threads, opt.verbose, pipe, n_processed, pack_s)) return 1;
+  if (feed_files(opt.files, paired, opt.batch, std::max(1, opt.threads), opt.threads, opt.verbose, pipe, n_processed, pack_s, &feeder, reset_run)) return 1;
   pipe.finish();
   if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
   if (opt.verbose) std::cerr << "[timing] reads parsed, packed and pseudoaligned after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
   if (opt.verbose)
-    std::cerr << "[quant] host packing " << pack_s << " s, device (copy + pseudoalignment) " << pipe.device_s() << " s, host waited for the device "
-              << pipe.wait_s() << " s" << std::endl;
+    std::cerr << "[quant] device parser: " << feeder.units << " units, " << feeder.bytes << " bytes of text, device (parse + pack + pseudoalignment) " << feeder.device_s
+              << " s, dispatcher waited for a text buffer " << feeder.wait_s << " s; general reader: host packing " << pack_s << " s, device "
+              << pipe.device_s() << " s, host waited " << pipe.wait_s() << " s" << std::endl;
   std::cerr << "[quant] finding pseudoalignments for the reads ... done" << std::endl;
 
   // several GPUs: every GPU's EC state becomes the state of the whole input (kamd_ec_allreduce over RCCL), then each finalizes
@@ -285,11 +311,16 @@ int main(int argc, char** argv) {
     for (int g = 0; g < n_gpus; g++) if (rcs[g]) { std::cerr << "Error: " << errs[g] << std::endl; return false; }
     return true;
   };
+  SharedDeviceComm shared(n_gpus);
+  const kamd_comm_callbacks shared_cb = SharedDeviceComm::callbacks();
   if (n_gpus > 1) {
     unsigned char uid[KAMD_COMM_ID_BYTES];
-    KX(kamd_comm_unique_id(uid));
+    if (!opt.share_device) KX(kamd_comm_unique_id(uid));
+    if (opt.verbose) std::cerr << "[quant] merging the equivalence classes of " << n_gpus << " ranks: "
+                               << (opt.share_device ? "host-staged callbacks, all ranks on device 0 (--share-device)" : "RCCL (kamd_comm, inside libkallisto_amd.so)") << std::endl;
     if (!on_all_gpus([&](int g) {
-          int rc = kamd_comm_create_rccl(ctxs[g], g, n_gpus, uid, &comms[g]);
+          int rc = opt.share_device ? kamd_comm_create_callbacks(ctxs[g], g, n_gpus, &shared_cb, shared.user(g), &comms[g])
+                                    : kamd_comm_create_rccl(ctxs[g], g, n_gpus, uid, &comms[g]);
           if (!rc) rc = kamd_ec_allreduce(ctxs[g], comms[g]);
           if (!rc && g != 0) rc = kamd_ec_finalize(ctxs[g], nullptr);
           return rc;

@@ -27,6 +27,9 @@ def _table(path):
     return rows[0], rows[1:]
 
 
+HOST_PARSED = {("ref_test_pe", "pe_boot"), ("yeast_se", "se"), ("human_pe", "pe"), ("mosaic_pe", "pe_union_fr")}   # also run through the general reader
+
+
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("ref_test_pe", "pe_boot"), ("ref_test_pe", "pe_rf"),
                                           ("yeast_se", "se"), ("yeast_se", "se_fr"), ("human_pe", "pe"),
                                           ("human_pe", "pe_l180"), ("tiny_k7_se", "se"), ("dlist_pe", "pe"), ("dlist_pe", "se_rf"),
@@ -47,10 +50,20 @@ def test_cli_matches_reference_cli(case, variant, tmp_path):
         _fastq(f2, r2)
         files.append(f2)
     out = str(tmp_path / "out")
-    # -t 7 + a tiny chunk size force the parallel memory-mapped FASTQ reader to split these small files into many chunks
-    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--batch", "1500", "-t", "7", *cli, *files],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KAMD_FASTQ_CHUNK="3000"))
+    # the device parser with units of ~20 KB of text (dozens of units even for these small files) ...
+    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", "-t", "7", *cli, *files],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KAMD_FQ_UNIT_BYTES="20000"))
     assert p.returncode == 0, p.stderr.decode()
+    assert "device parser: 0 units" not in p.stderr.decode()
+    if (case, variant) in HOST_PARSED:
+        # ... and the general reader: -t 7 + a tiny chunk size force the parallel memory-mapped FASTQ reader to split the files into many chunks
+        out_h = str(tmp_path / "out_host")
+        ph = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out_h, "--plaintext", "--batch", "1500", "-t", "7", *cli, *files],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KAMD_FASTQ_CHUNK="3000", KAMD_HOST_PARSE="1"))
+        assert ph.returncode == 0, ph.stderr.decode()
+        for fn in sorted(os.listdir(out)):
+            if fn.endswith(".tsv"):
+                assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(out_h, fn), "rb").read(), fn
     gold = os.path.join(common.case_dir(case), "cli_" + variant)
     # run_info.json: same keys in the same order, same values (start_time / call excluded)
     info = json.load(open(os.path.join(out, "run_info.json")))
@@ -154,3 +167,47 @@ def test_cli_with_a_flattened_index(tmp_path):
         outs.append(_table(os.path.join(out, "abundance.tsv"))[1])
     assert [r[:3] for r in outs[0]] == [r[:3] for r in outs[1]]
     common.assert_abundance_close(np.array([float(r[3]) for r in outs[1]]), np.array([float(r[3]) for r in outs[0]]), "est_counts", rel=1e-9, floor=1e-9)
+
+
+@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("ref_test_pe", "pe_boot"), ("yeast_se", "se"), ("mosaic_pe", "pe_union"),
+                                          ("mosaic_pe", "pe_nojump_rf"), ("dlist_pe", "pe")])
+def test_cli_several_ranks_on_one_device(case, variant, tmp_path):
+    """`--gpus 2 --share-device`: the several-GPU flow of the front-end (one context, pipeline and host thread per rank; units dealt
+    round the ranks, to rank 0 while the fragment-length sample is open; kamd_ec_allreduce; kamd_em_run_comm; replicates dealt round
+    the ranks) executes on a single-GPU box with host-staged collectives, and must reproduce the reference CLI's files
+    (MasterProcessor::update, src/ProcessReads.cpp:424-481, is the merge it replaces)."""
+    meta, idx_path, r1, r2 = common.load_case(case)
+    extra = meta["variants"][variant]
+    cli = [a.replace("--fr", "--fr-stranded").replace("--rf", "--rf-stranded") for a in extra]
+    cli = ["-b" if a == "--boot" else a for a in cli]
+    f1 = str(tmp_path / "r_1.fq")
+    _fastq(f1, r1)
+    files = [f1]
+    if r2 is not None and "--single" not in extra:
+        f2 = str(tmp_path / "r_2.fq")
+        _fastq(f2, r2)
+        files.append(f2)
+    gold = os.path.join(common.case_dir(case), "cli_" + variant)
+    ginfo = json.load(open(os.path.join(gold, "run_info.json")))
+    for mode, env in (("device", dict(KAMD_FQ_UNIT_BYTES="15000")), ("host", dict(KAMD_HOST_PARSE="1", KAMD_FASTQ_CHUNK="3000"))):
+        out = str(tmp_path / ("out_" + mode))
+        p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", "--gpus", "3", "--share-device", "--batch", "1500", "-t", "6",
+                            *cli, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()
+        assert "merging the equivalence classes of 3 ranks: host-staged callbacks" in p.stderr.decode()
+        info = json.load(open(os.path.join(out, "run_info.json")))
+        for k, v in ginfo.items():
+            assert info[k] == v, (mode, k)
+        h, rows = _table(os.path.join(out, "abundance.tsv"))
+        gh, grows = _table(os.path.join(gold, "abundance.tsv"))
+        assert h == gh and [r[:3] for r in rows] == [r[:3] for r in grows]     # eff_length: the fragment-length sample is rank 0's, in input order
+        common.assert_abundance_close(np.array([float(r[3]) for r in rows]), np.array([float(r[3]) for r in grows]), mode + " est_counts", rel=1e-4, floor=1e-5)
+        common.assert_abundance_close(np.array([float(r[4]) for r in rows]), np.array([float(r[4]) for r in grows]), mode + " tpm", rel=1e-4, floor=1e-5)
+        if "-b" in cli:
+            # EC ids of a merged result have no input order (like the reference at -t > 1), so the replicates are other draws than the
+            # golden ones: every replicate file must be there, complete, and sum to the number of pseudoaligned reads
+            nb = int(cli[cli.index("-b") + 1])
+            for b in range(nb):
+                _, brows = _table(os.path.join(out, f"bs_abundance_{b}.tsv"))
+                assert len(brows) == len(grows)
+                assert abs(sum(float(r[3]) for r in brows) - ginfo["n_pseudoaligned"]) < 1e-6 * ginfo["n_pseudoaligned"] + 1e-3
