@@ -21,7 +21,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                         cores over a bounded sample of the same reads, same index file, split into pseudoalignment and EM seconds
   parity_check       -- the GPU path against the unmodified reference run deterministically (-t 1, oracle/_ref/dump_ec) on a
                         prefix of the same reads: EC multiset, flens, eff_length identical, est_counts / TPM <= 1e-4; `ok` gates on all
-  end_to_end         -- (--end-to-end P) the C++ front-end from FASTQ files, plain and gzip, index load stated separately
+  parity_check_tail  -- the last pairs of the input, pseudoaligned as the final batch of a run over ALL pairs (record stream grown and
+                        reallocated, de-duplication table regrown): EC counts of the whole run minus those of the run without them must
+                        equal the reference's EC multiset of those pairs
+  pinned_pipeline    -- packed reads in pinned host memory -> H2D on a copy stream -> pseudoalignment, double buffered
+  end_to_end         -- the C++ front-end from FASTQ files (plain / BGZF / gzip), input -> ECs and whole-run rates, index load stated
   bootstrap          -- (--bootstraps B) BASELINE config #5: B replicates of multinomial resample + EM
 `--workload yeast` is BASELINE config #2 (10 M single-end reads, ~6 k transcripts).
 """
@@ -105,18 +109,20 @@ def write_fastq_fast(path, reads: np.ndarray):
         f.write(line.tobytes())
 
 
-def cpu_reference_baseline(idx_path, r1: np.ndarray, r2: np.ndarray, threads: int):
+def cpu_reference_baseline(idx_path, r1: np.ndarray, r2, threads: int, extra=()):
     """Time the unmodified reference on the host cores: `kallisto quant -t threads` on the sample.  The clock starts when
     the index has been loaded (the '[quant] running in' line) and stops at process exit; the stage markers the reference
     prints on stderr split it into pseudoalignment (until the 'finding pseudoalignments ... done' line completes) and EM
     (until 'the Expectation-Maximization algorithm ran for')."""
     tmp = os.path.join(CACHE, f"cpu_baseline_{os.getpid()}")
     os.makedirs(tmp, exist_ok=True)
-    f1, f2 = os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq")
-    write_fastq_fast(f1, r1)
-    write_fastq_fast(f2, r2)
+    files = [os.path.join(tmp, "s_1.fq")]
+    write_fastq_fast(files[0], r1)
+    if r2 is not None:
+        files.append(os.path.join(tmp, "s_2.fq"))
+        write_fastq_fast(files[1], r2)
     out = os.path.join(tmp, "out")
-    cmd = [REF_BIN, "quant", "-i", idx_path, "-o", out, "-t", str(threads), "--plaintext", f1, f2]
+    cmd = [REF_BIN, "quant", "-i", idx_path, "-o", out, "-t", str(threads), "--plaintext", *extra, *files]
     t_start = time.time()
     p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     t_loaded = t_aligned = t_em = None
@@ -143,86 +149,197 @@ def cpu_reference_baseline(idx_path, r1: np.ndarray, r2: np.ndarray, threads: in
             "n_unique": info["n_unique"]}
 
 
-def reference_parity(idx_path, r1: np.ndarray, r2: np.ndarray, res):
-    """The GPU result `res` (kallisto_amd.quant on exactly these pairs, ECs downloaded) against the unmodified reference run
-    deterministically (`-t 1`: the fragment-length sample is the first 10 000 qualifying pairs in input order,
-    src/ProcessReads.cpp:981-1017,1174-1181) through oracle/_ref/dump_ec, which prints what the CLI never does: the EC
-    multiset, flens, eff_lens and alpha of src/main.cpp:2632-2689."""
+def _ref_dump(idx_path, r1, r2, extra=()):
+    """oracle/_ref/dump_ec quant -t 1 on these reads (FASTQ written to the cache directory)"""
     from oracle import oracle as O
     tmp = os.path.join(CACHE, f"ref_parity_{os.getpid()}")
     os.makedirs(tmp, exist_ok=True)
     try:
-        f1, f2 = os.path.join(tmp, "p_1.fq"), os.path.join(tmp, "p_2.fq")
-        write_fastq_fast(f1, r1)
-        write_fastq_fast(f2, r2)
-        t0 = time.time()
-        ref = O.ref_dump_quant(idx_path, [f1, f2], threads=1)
-        rep = O.ref_parity_report(ref, res.ecs.multiset(), res.flens, res.eff_lens, res.est_counts, res.alpha_before_zeroes)
-        rep["sample_pairs"] = int(r1.shape[0])
-        rep["reference_seconds"] = round(time.time() - t0, 1)
-        rep["n_pseudoaligned"] = [int(res.n_pseudoaligned), int(sum(ref["ecs"].values()))]
-        rep["em_rounds_gpu"] = int(res.em_rounds)
-        return rep
+        files = [os.path.join(tmp, "p_1.fq")]
+        write_fastq_fast(files[0], r1)
+        if r2 is not None:
+            files.append(os.path.join(tmp, "p_2.fq"))
+            write_fastq_fast(files[1], r2)
+        return O.ref_dump_quant(idx_path, files, threads=1, extra=extra)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra):
-    """The C++ front-end (kallisto_amd/kallisto_amd_quant) from FASTQ files on disk: plain text and gzip.  Wall-clock per stage
+def reference_parity(idx_path, r1: np.ndarray, r2, res, extra=()):
+    """The GPU result `res` (kallisto_amd.quant on exactly these reads, ECs downloaded) against the unmodified reference run
+    deterministically (`-t 1`: the fragment-length sample is the first 10 000 qualifying pairs in input order,
+    src/ProcessReads.cpp:981-1017,1174-1181) through oracle/_ref/dump_ec, which prints what the CLI never does: the EC
+    multiset, flens, eff_lens and alpha of src/main.cpp:2632-2689."""
+    from oracle import oracle as O
+    t0 = time.time()
+    ref = _ref_dump(idx_path, r1, r2, extra)
+    rep = O.ref_parity_report(ref, res.ecs.multiset(), res.flens, res.eff_lens, res.est_counts, res.alpha_before_zeroes)
+    rep["sample"] = int(r1.shape[0])
+    rep["reference_seconds"] = round(time.time() - t0, 1)
+    rep["n_pseudoaligned"] = [int(res.n_pseudoaligned), int(sum(ref["ecs"].values()))]
+    rep["em_rounds_gpu"] = int(res.em_rounds)
+    return rep
+
+
+def tail_parity(ctx, opts, idx_path, words, lens, n, per, rec, L, t1, t2, extra=()):
+    """The LAST pairs of the input against the reference, in the state a full-size run leaves the context in: the whole input is
+    pseudoaligned with those pairs as the final batch (record stream grown and reallocated, de-duplication tables regrown, overflow
+    items redirected), then the input without them; the difference of the two EC multisets must be the reference's EC multiset of
+    those pairs alone (EC counts are additive over reads: MinCollector::increaseCount, src/MinCollector.cpp:251-269)."""
+    k = int(t1.shape[0])
+    t0 = time.time()
+
+    def ec_multiset(parts):
+        ctx.reset()
+        for a, b in parts:
+            if b > a:
+                ctx.pseudoalign(opts, words[a * per * rec:b * per * rec], lens[per * a:per * b], b - a, L)
+        return ctx.finalize(download=True).multiset()
+    whole = ec_multiset([(0, n - k), (n - k, n)])
+    head = ec_multiset([(0, n - k)])
+    diff = {}
+    bad = 0
+    for key, c in whole.items():
+        d = c - head.get(key, 0)
+        if d < 0:
+            bad += 1
+        elif d > 0:
+            diff[key] = d
+    bad += sum(1 for key in head if key not in whole)
+    ref = _ref_dump(idx_path, t1, t2, extra)
+    return {"pairs_or_reads": k, "position": f"items [{n - k}, {n}) of {n}, pseudoaligned as the final batch of a run over all of them",
+            "n_ecs_ref": len(ref["ecs"]), "n_ecs": len(diff), "counts_never_decrease": bad == 0,
+            "ec_multiset_equal": bool(diff == ref["ecs"]), "n_pseudoaligned": [int(sum(diff.values())), int(sum(ref["ecs"].values()))],
+            "seconds": round(time.time() - t0, 1), "ok": bool(bad == 0 and diff == ref["ecs"])}
+
+
+def pinned_pipeline(ka, ctx, opts, words, lens, n, per, rec, L, chunk_items=4_000_000):
+    """Packed reads in pinned host memory -> ECs: H2D copies on a side stream, double buffered, kamd_pseudoalign per chunk on the
+    context stream, then finalize ('pipeline reads/s from pinned host memory').  Never `value`."""
+    import torch
+    dev = words.device
+    hw = torch.empty(words.numel(), dtype=words.dtype, pin_memory=True)
+    hl = torch.empty(lens.numel(), dtype=lens.dtype, pin_memory=True)
+    hw.copy_(words); hl.copy_(lens)
+    torch.cuda.synchronize()
+    copy = torch.cuda.Stream(device=dev)
+    bufs = [(torch.empty(chunk_items * per * rec, dtype=words.dtype, device=dev), torch.empty(chunk_items * per, dtype=lens.dtype, device=dev),
+             torch.cuda.Event()) for _ in range(2)]
+    chunks = [(a, min(a + chunk_items, n)) for a in range(0, n, chunk_items)]
+
+    def issue(i):
+        a, b = chunks[i]
+        w, l, ev = bufs[i % 2]
+        with torch.cuda.stream(copy):
+            w[:(b - a) * per * rec].copy_(hw[a * per * rec:b * per * rec], non_blocking=True)
+            l[:(b - a) * per].copy_(hl[a * per:b * per], non_blocking=True)
+            ev.record(copy)
+    best = None
+    for _ in range(2):   # one warm-up pass
+        ctx.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        issue(0)
+        for i, (a, b) in enumerate(chunks):
+            bufs[i % 2][2].synchronize()
+            if i + 1 < len(chunks):
+                issue(i + 1)            # (the other buffer: its chunk was consumed by the previous, synchronous kamd_pseudoalign)
+            w, l, _ = bufs[i % 2]
+            ctx.pseudoalign(opts, w[:(b - a) * per * rec], l[:(b - a) * per], b - a, L)
+        ctx.finalize(download=False)
+        torch.cuda.synchronize()
+        best = time.perf_counter() - t0
+    gb = (hw.numel() * 4 + hl.numel() * 2) / 1e9
+    return {"items": n, "seconds": round(best, 4), "M_per_s": round(n / best / 1e6, 2), "host_GB": round(gb, 3), "h2d_GB_per_s": round(gb / best, 2),
+            "chunk_items": chunk_items, "note": "2-bit packed reads in pinned host memory, copies of chunk i+1 under the pseudoalignment of chunk i, "
+            "EC finalize included, no EM; bound by the host-to-device link (packed PE-100: 104 B per pair)"}
+
+
+def _bgzf_block(chunk: bytes) -> bytes:
+    import struct
+    import zlib
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    comp = co.compress(chunk) + co.flush()
+    return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+            + comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def _bgzf_part(args):
+    src, a, b = args
+    with open(src, "rb") as f:
+        f.seek(a)
+        data = f.read(b - a)
+    return b"".join(_bgzf_block(data[i:i + 65280]) for i in range(0, len(data), 65280))
+
+
+def write_bgzf(src, dst, procs):
+    """what `bgzip` writes: independent gzip members of <= 64 KiB (written by a pool of processes: zlib is slow)"""
+    import multiprocessing as mp
+    size = os.path.getsize(src)
+    step = 65280 * 256
+    parts = [(src, a, min(a + step, size)) for a in range(0, size, step)]
+    with mp.get_context("fork").Pool(procs) as pool, open(dst, "wb") as fo:
+        for blob in pool.imap(_bgzf_part, parts):
+            fo.write(blob)
+        fo.write(_bgzf_block(b""))
+
+
+def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, gz_items=2_000_000):
+    """The C++ front-end (kallisto_amd/kallisto_amd_quant) from FASTQ files on disk: plain text, BGZF and gzip.  Wall-clock per stage
     from its --verbose timing lines; never part of `value`."""
     exe = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
     if not os.path.exists(exe):
         return {"error": "kallisto_amd_quant not built"}
-    import gzip
     tmp = os.path.join(CACHE, f"e2e_{os.getpid()}")
     os.makedirs(tmp, exist_ok=True)
     out = {}
+    unit = "pairs" if paired else "reads"
     try:
         n = int(r1.shape[0])
         f1, f2 = os.path.join(tmp, "e_1.fq"), os.path.join(tmp, "e_2.fq")
+        t0 = time.time()
         write_fastq_fast(f1, r1)
         if paired:
             write_fastq_fast(f2, r2)
-        ngz = min(n, 1_000_000)
-        g1, g2 = os.path.join(tmp, "g_1.fq.gz"), os.path.join(tmp, "g_2.fq.gz")
-        for src, dst in ((f1, g1), (f2, g2)) if paired else ((f1, g1),):
-            per = os.path.getsize(src) // n
-            with open(src, "rb") as fi, gzip.open(dst, "wb", compresslevel=1) as fo:
+        plain = [f1, f2] if paired else [f1]
+        per = os.path.getsize(f1) // n
+        # the same reads as BGZF (block-parallel inflate) and, a subset, as one ordinary gzip member per file (`gzip -1`)
+        bg = [os.path.join(tmp, f"b_{i + 1}.fq.gz") for i in range(len(plain))]
+        for src, dst in zip(plain, bg):
+            write_bgzf(src, dst, min(threads, 48))
+        ngz = min(n, gz_items)
+        gz = []
+        procs = []
+        for i, src in enumerate(plain):
+            g = os.path.join(tmp, f"g_{i + 1}.fq")
+            with open(src, "rb") as fi, open(g, "wb") as fo:
                 fo.write(fi.read(per * ngz))
-        # the same reads as BGZF (what `bgzip` writes: independent members of <= 64 KiB, inflated block-parallel by the front-end)
-        import struct
-        import zlib
-        b1, b2 = os.path.join(tmp, "b_1.fq.gz"), os.path.join(tmp, "b_2.fq.gz")
-        for src, dst in ((f1, b1), (f2, b2)) if paired else ((f1, b1),):
-            per = os.path.getsize(src) // n
-            with open(src, "rb") as fi, open(dst, "wb") as fo:
-                data = fi.read(per * ngz)
-                for a in list(range(0, len(data), 65280)) + [None]:
-                    chunk = b"" if a is None else data[a:a + 65280]
-                    co = zlib.compressobj(1, zlib.DEFLATED, -15)
-                    comp = co.compress(chunk) + co.flush()
-                    fo.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
-                             + comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+            procs.append(subprocess.Popen(["gzip", "-1", "-f", g]))
+            gz.append(g + ".gz")
+        for p in procs:
+            p.wait()
+        prep_s = time.time() - t0
         # the device tables written once as a file (`kallisto_amd_quant flatten`): what a multi-sample front-end would load
         flat = os.path.join(tmp, "index.kamd")
         t0 = time.time()
         have_flat = subprocess.run([exe, "flatten", "-i", idx_path, "-o", flat, "-t", str(threads)], stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL).returncode == 0
         flatten_s = time.time() - t0
-        runs = [("plain", idx_path, [f1, f2] if paired else [f1], n), ("gzip", idx_path, [g1, g2] if paired else [g1], ngz),
-                ("bgzf", idx_path, [b1, b2] if paired else [b1], ngz)]
+        runs = [("plain", idx_path, plain, n, {}), ("bgzf", idx_path, bg, n, {}), ("gzip", idx_path, gz, ngz, {}),
+                ("plain_host_parsed", idx_path, plain, n, {"KAMD_HOST_PARSE": "1"})]
         if have_flat:
-            runs.append(("plain_flattened_index", flat, [f1, f2] if paired else [f1], n))
-        for kind, ipath, files, cnt in runs:
+            runs.append(("plain_flattened_index", flat, plain, n, {}))
+        for kind, ipath, files, cnt, env in runs:
             cmd = [exe, "quant", "-i", ipath, "-o", os.path.join(tmp, "out_" + kind), "-t", str(threads), "--plaintext", "--verbose", *extra, *files]
             t0 = time.time()
-            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **env))
             wall = time.time() - t0
             if p.returncode != 0:
                 out[kind] = {"error": p.stderr.decode(errors="replace")[-300:]}
                 continue
             tm = {}
-            for line in p.stderr.decode(errors="replace").splitlines():
+            text = p.stderr.decode(errors="replace")
+            for line in text.splitlines():
                 if line.startswith("[timing] index file read"):
                     w = line.split()
                     tm["index_load_s"] = float(w[7]); tm["index_on_device_s"] = float(w[-2])
@@ -231,13 +348,25 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra):
                 elif line.startswith("[timing] total"):
                     tm["total_s"] = float(line.split()[-2])
             reads_s = tm.get("reads_done_s", wall) - tm.get("index_on_device_s", 0.0)
-            out[kind] = {"pairs" if paired else "reads": cnt, "wall_s": round(wall, 2), **{k: round(v, 3) for k, v in tm.items()},
+            out[kind] = {unit: cnt, "file_GB": round(sum(os.path.getsize(f) for f in files) / 1e9, 3), "wall_s": round(wall, 2),
+                         **{k: round(v, 3) for k, v in tm.items()},
                          "input_to_ecs_M_per_s": round(cnt / max(reads_s, 1e-9) / 1e6, 3),
-                         "whole_run_M_per_s": round(cnt / wall / 1e6, 3), "host_threads": threads}
+                         "whole_run_M_per_s": round(cnt / wall / 1e6, 3), "host_threads": threads,
+                         "parser": "host (general reader)" if "device parser: 0 units" in text else "device (kamd_fastq_unit_parse)"}
         if have_flat:
             out["flatten_s"] = round(flatten_s, 2)
-        out["note"] = ("kallisto_amd_quant from FASTQ on local disk (plain: mmap + all host threads; gzip: one inflate thread per file; bgzf: block-parallel inflate); "
-                       "input_to_ecs = parsing + packing + H2D + pseudoalignment (index load excluded), whole_run = process start to exit")
+        out["file_preparation_s"] = round(prep_s, 1)
+        # the outputs of the device-parsed and the host-parsed run must be the same files
+        try:
+            a = open(os.path.join(tmp, "out_plain", "abundance.tsv"), "rb").read()
+            out["device_parser_equals_host_parser"] = all(a == open(os.path.join(tmp, "out_" + k, "abundance.tsv"), "rb").read()
+                                                          for k in ("plain_host_parsed", "bgzf"))
+        except OSError:
+            out["device_parser_equals_host_parser"] = None
+        out["note"] = ("kallisto_amd_quant from FASTQ on local disk (page cache warm).  plain / bgzf / gzip: host threads move bytes into pinned rings "
+                       "(pread; block-parallel inflate; one inflate thread per file) and count newlines, lines / record check / 2-bit packing on the GPU; "
+                       "plain_host_parsed: the general reader (KAMD_HOST_PARSE=1).  input_to_ecs = from index-on-device to the last pseudoalignment "
+                       "(reading, H2D, parsing, packing, pseudoalignment), whole_run = process start to exit (index load, EM, output files)")
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -256,7 +385,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --pairs per GPU (default); strong = --pairs in total, sharded over the GPUs (BASELINE config #4). "
                          "The other mode is measured too and reported in the same line.")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs given to the CPU reference (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="pairs (reads) given to the CPU reference (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=200_000,
                     help="pairs of the CPU sample that also go through the reference at -t 1 for the parity gate")
@@ -264,7 +393,8 @@ def main():
                     help="BASELINE config #5: also time B bootstrap replicates (multinomial resample + EM), split over the ranks")
     ap.add_argument("--in-flight", type=int, default=1, help="2: also measure two samples in flight on one GPU (two contexts / streams); reported "
                     "beside the headline value, never as it")
-    ap.add_argument("--end-to-end", type=int, default=0, help="also run the C++ front-end from FASTQ files with this many pairs (N = 1 only)")
+    ap.add_argument("--end-to-end", type=int, default=8_000_000, help="run the C++ front-end from FASTQ files with this many pairs / reads (N = 1 only; 0 = skip)")
+    ap.add_argument("--no-pinned-pipeline", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -315,8 +445,17 @@ def main():
     words = torch.empty(n_gen * per * rec, dtype=torch.int32, device=dev)
     lens = torch.empty(n_gen * per, dtype=torch.int16, device=dev)
     chunk = 2_000_000
-    sample = None
-    e2e_sample = None
+    sample = None      # first pairs: CPU baseline + parity
+    e2e_sample = None  # first pairs: front-end from FASTQ
+    tail_sample = None # last pairs: parity of the tail
+    want_head = 0
+    if rank == 0 and world == 1:
+        if args.cpu_sample and not args.no_cpu_baseline:
+            want_head = max(want_head, min(args.cpu_sample, n_gen))
+        if args.end_to_end:
+            want_head = max(want_head, min(args.end_to_end, n_gen))
+    want_tail = min(args.parity_sample, n_gen) if (rank == 0 and world == 1 and not args.no_cpu_baseline and args.parity_sample) else 0
+    head1, head2, have_head = [], [], 0
     t0 = time.time()
     for s in range(0, n_gen, chunk):
         m = min(chunk, n_gen - s)
@@ -325,14 +464,23 @@ def main():
         w, l = ctx.pack_reads(inter, L)
         words[s * per * rec:(s + m) * per * rec] = w
         lens[per * s:per * (s + m)] = l
-        if s == 0 and rank == 0 and world == 1:
-            if args.cpu_sample and not args.no_cpu_baseline:
-                k = min(args.cpu_sample, m)
-                sample = (r1[:k].cpu().numpy(), r2[:k].cpu().numpy())
-            if args.end_to_end:
-                k = min(args.end_to_end, m)
-                e2e_sample = (r1[:k].cpu().numpy(), r2[:k].cpu().numpy())
+        if have_head < want_head:
+            k = min(want_head - have_head, m)
+            head1.append(r1[:k].cpu().numpy()); head2.append(r2[:k].cpu().numpy())
+            have_head += k
+        if want_tail and s + m == n_gen:
+            k = min(want_tail, m)   # (the tail lies inside the last chunk: parity_sample <= chunk)
+            tail_sample = (r1[m - k:].cpu().numpy(), r2[m - k:].cpu().numpy() if paired else None)
         del r1, r2, inter, w, l
+    if want_head:
+        h1, h2 = np.concatenate(head1), np.concatenate(head2)
+        if args.cpu_sample and not args.no_cpu_baseline:
+            k = min(args.cpu_sample, n_gen)
+            sample = (h1[:k], h2[:k] if paired else None)
+        if args.end_to_end:
+            k = min(args.end_to_end, n_gen)
+            e2e_sample = (h1[:k], h2[:k] if paired else None)
+        del head1, head2
     torch.cuda.synchronize()
     log(f"{n_gen} synthetic {'PE' if paired else 'SE'}-{L} {'pairs' if paired else 'reads'} generated + packed on the device in "
         f"{time.time()-t0:.1f}s ({words.numel()*4/1e9:.2f} GB in HBM)")
@@ -529,7 +677,7 @@ def main():
                 "parallelism": (f"{world} ranks, one per GPU: reads sharded; in the library (RCCL): one all-reduce of the dense EC count vector + "
                                 f"all-gathers of the tuple records, then the EM partitioned over the ranks by connected component"
                                 if world > 1 else "1 GPU"),
-                "collective_backend": ("rccl (kamd_comm, inside libkallisto_amd.so)" if backend == "nccl" else backend) if world > 1 else None,
+                "collective_backend": (getattr(getattr(ctx, "_comm", None), "transport", None) or f"unknown ({backend})") if world > 1 else None,
             },
             "breakdown_ms": {"pseudoalign_kernel": round(a_ms, 3), "classify_kernel": round(float(np.mean(cls_ms)), 3),
                              "kernel_a_version": pr["kernel_a_version"], "ec_finalize": round(f_ms, 3), "em": round(float(np.mean(em_ms)), 3),
@@ -567,36 +715,54 @@ def main():
         if other is not None:
             out["other_scaling"] = other
     # ---- CPU baseline (rank 0, N=1 only): the reference at -t <cores> for the timing; parity against the reference at -t 1 ----
-    if rank == 0 and world == 1 and sample is not None and paired:
+    unit_name = "pairs" if paired else "reads"
+    rate_unit = "M read pairs/s" if paired else "M reads/s"
+    if rank == 0 and world == 1 and sample is not None:
         threads = min(os.cpu_count() or 1, 64)
         k = sample[0].shape[0]
-        log(f"CPU baseline: reference `kallisto quant -t {threads}` on the first {k} pairs ...")
+        log(f"CPU baseline: reference `kallisto quant -t {threads}` on the first {k} {unit_name} ...")
         try:
-            cb = cpu_reference_baseline(idx_path, sample[0], sample[1], threads)
-            out["cpu_baseline"] = {"value": round(k / cb["seconds"] / 1e6, 4), "unit": "M read pairs/s", "cores": threads,
+            cb = cpu_reference_baseline(idx_path, sample[0], sample[1], threads, cli_extra)
+            out["cpu_baseline"] = {"value": round(k / cb["seconds"] / 1e6, 4), "unit": rate_unit, "cores": threads,
                                    "kind": "reference",
-                                   "sample": f"first {k} pairs of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
-                                             f"--plaintext`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
+                                   "sample": f"first {k} {unit_name} of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
+                                             f"--plaintext {' '.join(cli_extra)}`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
                                              f"{cb['index_load_s']:.1f}s excluded)",
                                    "pseudoalign_seconds": round(cb["pseudoalign_s"], 2), "em_seconds": round(cb["em_s"], 2),
                                    "pseudoalign_only_value": round(k / max(cb["pseudoalign_s"], 1e-9) / 1e6, 4),
-                                   "note": "the reference's EM is single-threaded and independent of the read count (it dominates "
-                                           "small samples); pseudoalign_only_value is the rate of the threaded stage alone"}
+                                   "projected_value_at_full_size": round(n / (n / k * cb["pseudoalign_s"] + cb["em_s"] + (cb["seconds"] - cb["pseudoalign_s"] - cb["em_s"])) / 1e6, 4),
+                                   "note": "the reference's EM is single-threaded and independent of the read count; projected_value_at_full_size "
+                                           f"scales the threaded pseudoalignment stage to the {n} {unit_name} of the GPU workload and keeps the EM and output time"}
         except Exception as e:  # the baseline is reported, never required for the GPU number
-            out["cpu_baseline"] = {"value": None, "unit": "M read pairs/s", "cores": threads, "kind": "reference",
+            out["cpu_baseline"] = {"value": None, "unit": rate_unit, "cores": threads, "kind": "reference",
                                    "sample": f"failed: {e}"}
-        # parity gate: the same pairs through the HIP path and through the unmodified reference at -t 1
+        # parity gate: the same reads through the HIP path and through the unmodified reference at -t 1
         ks = min(k, args.parity_sample)
-        log(f"parity: reference `dump_ec quant -t 1` on the first {ks} pairs ...")
+        log(f"parity: reference `dump_ec quant -t 1` on the first {ks} {unit_name} ...")
         try:
             ctx.reset()
-            gres = ka.quant(ctx, opts, [(words[:ks * 2 * rec], lens[:2 * ks], ks, L)], download_ecs=True)
-            out["parity_check"] = reference_parity(idx_path, sample[0][:ks], sample[1][:ks], gres)
+            gres = ka.quant(ctx, opts, [(words[:ks * per * rec], lens[:per * ks], ks, L)], download_ecs=True)
+            out["parity_check"] = reference_parity(idx_path, sample[0][:ks], sample[1][:ks] if paired else None, gres, cli_extra)
         except Exception as e:
             out["parity_check"] = {"ok": False, "error": str(e)}
+        if tail_sample is not None:
+            log(f"parity: the last {tail_sample[0].shape[0]} {unit_name}, pseudoaligned as the final batch of a run over all {n} ...")
+            try:
+                out["parity_check_tail"] = tail_parity(ctx, opts, idx_path, words, lens, n, per, rec, L, tail_sample[0], tail_sample[1], cli_extra)
+            except Exception as e:
+                out["parity_check_tail"] = {"ok": False, "error": str(e)}
+    if rank == 0 and world == 1 and not args.no_pinned_pipeline:
+        log("pinned pipeline: packed reads in pinned host memory -> ECs ...")
+        try:
+            out["pinned_pipeline"] = pinned_pipeline(ka, ctx, opts, words, lens, n, per, rec, L)
+            out["pinned_pipeline"]["unit"] = rate_unit
+        except Exception as e:
+            out["pinned_pipeline"] = {"error": str(e)}
     if rank == 0 and world == 1 and e2e_sample is not None:
-        log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {'pairs' if paired else 'reads'}) ...")
+        log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {unit_name}) ...")
         ctx.close()   # the front-end is its own process on the same GPU
+        del words, lens
+        torch.cuda.empty_cache()
         try:
             out["end_to_end"] = end_to_end(idx_path, e2e_sample[0], e2e_sample[1], paired, min(os.cpu_count() or 1, 64), cli_extra)
         except Exception as e:

@@ -159,16 +159,23 @@ int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off,
  * sequence; a trailing '\r' is dropped as kseq does), and packs the sequences as kamd_pack_reads would: single-end -> item j =
  * record j, paired -> items 2j / 2j + 1 = record j of file 0 / file 1.  status != 0: the unit is NOT packed and the caller must
  * read this input with a general FASTA/FASTQ reader instead (multi-line records, FASTA, junk between records ...).
- * d_text[f]: device pointers, 16-byte aligned; n_bytes[f] < 2^32.  Runs on the context stream and synchronises it once. */
+ * d_text[f]: device pointers, 16-byte aligned; n_bytes[f] < 2^32.  Runs on the context stream and synchronises it once.
+ * A unit is what one host-to-device copy brings (tens of MB); a *batch* -- what kamd_pseudoalign is called on -- should be millions of
+ * reads, so parsing and packing are separate: kamd_fastq_unit_parse checks a unit and notes where its sequences are (the text must
+ * stay in place until the batch is packed), kamd_fastq_batch_pack packs the reads of all units parsed since the last batch, in
+ * order.  kamd_fastq_unit_pack = parse + pack of a single unit. */
 typedef struct {
-  const uint32_t* d_words;     /* packed batch, owned by the context, valid until the next kamd_fastq_unit_pack on it */
+  const uint32_t* d_words;     /* packed batch, owned by the context, valid until the next kamd_fastq_batch_pack / _unit_pack on it */
   const uint16_t* d_len;
-  uint64_t n_items;            /* = n_records */
-  int32_t max_len;             /* longest read of the unit: the max_len to hand to kamd_pseudoalign / kamd_fld_* */
+  uint64_t n_items;            /* unit_parse: = n_records; batch_pack: items of the batch */
+  int32_t max_len;             /* longest read of the unit / batch: the max_len to hand to kamd_pseudoalign / kamd_fld_* */
   int32_t status;              /* 0 ok; 1 some record is not strict 4-line FASTQ (first_bad_record); 2 the text holds fewer than
-                                  4 x n_records lines; 3 a read is longer than 65535 bases */
+                                  4 x n_records lines; 3 a read is longer than 65535 bases.  != 0: nothing was added to the batch */
   uint64_t first_bad_record;
 } kamd_fastq_unit;
+int kamd_fastq_unit_parse(kamd_ctx*, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
+                          kamd_fastq_unit* out);
+int kamd_fastq_batch_pack(kamd_ctx*, kamd_fastq_unit* out);
 int kamd_fastq_unit_pack(kamd_ctx*, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
                          kamd_fastq_unit* out);
 

@@ -102,6 +102,8 @@ _SYMBOLS = {
     "kamd_pack_reads_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                          C.c_void_p]),
     "kamd_fastq_unit_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(_FastqUnit)]),
+    "kamd_fastq_unit_parse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(_FastqUnit)]),
+    "kamd_fastq_batch_pack": (C.c_int, [C.c_void_p, C.POINTER(_FastqUnit)]),
     "kamd_pseudoalign": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "kamd_fld_prefetch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "kamd_fld_from_batch": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
@@ -336,9 +338,7 @@ class Context:
         dl = torch.from_numpy(l16.view(np.int16)).to(f"cuda:{self.device}")
         return dw, dl, max_len
 
-    def fastq_unit_pack(self, texts, n_records: int):
-        """kamd_fastq_unit_pack: one unit of strict 4-line FASTQ text per file (bytes, or uint8 device tensors) -> the packed batch
-        (views of the context's buffers, valid until the next call).  Returns (words, lens, n_items, max_len, status, first_bad)."""
+    def _fastq_texts(self, texts):
         torch = self.torch
         dev = f"cuda:{self.device}"
         keep = []
@@ -352,14 +352,41 @@ class Context:
                 keep.append((t, t.numel()))
         ptrs = (C.c_void_p * 2)(*[k[0].data_ptr() for k in keep], *([None] * (2 - len(keep))))
         nb = (C.c_uint64 * 2)(*[k[1] for k in keep], *([0] * (2 - len(keep))))
-        u = _FastqUnit()
-        _check(load_library().kamd_fastq_unit_pack(self._h, ptrs, nb, len(keep), int(n_records), C.byref(u)), "kamd_fastq_unit_pack")
+        return keep, ptrs, nb
+
+    def _fastq_result(self, u, n_files):
+        torch = self.torch
         words = lens = None
-        if u.status == 0 and u.n_items:
-            n_reads = int(u.n_items) * len(keep)
+        if u.status == 0 and u.n_items and u.d_words:
+            n_reads = int(u.n_items) * n_files
             words = _alias_tensor(torch, u.d_words, n_reads * packed_record_words(int(u.max_len)), torch.int32, self.device)
             lens = _alias_tensor(torch, u.d_len, n_reads, torch.int16, self.device)
         return words, lens, int(u.n_items), int(u.max_len), int(u.status), int(u.first_bad_record)
+
+    def fastq_unit_pack(self, texts, n_records: int):
+        """kamd_fastq_unit_pack: one unit of strict 4-line FASTQ text per file (bytes, or uint8 device tensors) -> the packed batch
+        (views of the context's buffers, valid until the next call).  Returns (words, lens, n_items, max_len, status, first_bad)."""
+        keep, ptrs, nb = self._fastq_texts(texts)
+        u = _FastqUnit()
+        _check(load_library().kamd_fastq_unit_pack(self._h, ptrs, nb, len(keep), int(n_records), C.byref(u)), "kamd_fastq_unit_pack")
+        return self._fastq_result(u, len(keep))
+
+    def fastq_unit_parse(self, texts, n_records: int):
+        """kamd_fastq_unit_parse: adds a unit to the batch under construction; the device copies of the texts are kept alive until
+        fastq_batch_pack.  Returns (status, first_bad, max_len)."""
+        keep, ptrs, nb = self._fastq_texts(texts)
+        u = _FastqUnit()
+        _check(load_library().kamd_fastq_unit_parse(self._h, ptrs, nb, len(keep), int(n_records), C.byref(u)), "kamd_fastq_unit_parse")
+        self._fq_keep = getattr(self, "_fq_keep", []) + [keep]
+        self._fq_files = len(keep)
+        return int(u.status), int(u.first_bad_record), int(u.max_len)
+
+    def fastq_batch_pack(self):
+        u = _FastqUnit()
+        _check(load_library().kamd_fastq_batch_pack(self._h, C.byref(u)), "kamd_fastq_batch_pack")
+        self.torch.cuda.synchronize(self.device)
+        self._fq_keep = []
+        return self._fastq_result(u, getattr(self, "_fq_files", 1))
 
     # ---- pseudoalignment ----
     def pseudoalign(self, opts: QuantOpts, words, lens, n_items: int, max_len: int):

@@ -172,13 +172,15 @@ class UnitFeeder {
   enum { OK = 0, FAILED = 1, DECLINED = 2 };
   // ring: pinned bytes per file; target: bytes of file 0 per unit; max_unit: capacity of a device text buffer; block: bytes a reader
   // thread moves (and counts) at a time
-  struct Sizes { size_t ring = 192u << 20, target = 32u << 20, max_unit = 64u << 20, block = 1u << 20; int bufs = 3; };
+  struct Sizes { size_t ring = 192u << 20, target = 32u << 20, max_unit = 48u << 20, block = 1u << 20; int bufs = 20; uint64_t batch_items = 2u << 20; };
   static Sizes sizes_from_env() {
     Sizes z;
     size_t t = 0;
     if (const char* e = getenv("KAMD_FQ_UNIT_MB")) t = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("KAMD_FQ_UNIT_BYTES")) t = (size_t)std::max(256, atoi(e));   // (tests: many units from small files)
-    if (t) { z.target = t; z.max_unit = std::max<size_t>(2 * t, 1u << 20); z.block = std::min<size_t>(z.block, std::max<size_t>(t / 4, 64)); z.ring = std::max<size_t>(6 * t, z.max_unit + 4 * z.block + (1u << 16)); }
+    if (const char* e = getenv("KAMD_FQ_BATCH_ITEMS")) z.batch_items = (uint64_t)std::max(1, atoi(e));
+    if (const char* e = getenv("KAMD_FQ_BUFS")) z.bufs = std::max(3, atoi(e));
+    if (t) { z.target = t; z.max_unit = std::max<size_t>(t + t / 2, 1u << 20); z.block = std::min<size_t>(z.block, std::max<size_t>(t / 4, 64)); z.ring = std::max<size_t>(6 * t, z.max_unit + 4 * z.block + (1u << 16)); }
     if (const char* e = getenv("KAMD_FQ_RING_MB")) z.ring = std::max((size_t)std::max(1, atoi(e)) << 20, z.max_unit + 4 * z.block + (1u << 16));
     return z;
   }
@@ -218,6 +220,7 @@ class UnitFeeder {
   }
   const std::string& error() const { return error_; }
   double wait_s = 0.0, device_s = 0.0;   // dispatcher blocked on a free text buffer / busiest consumer
+  double copy_wait_s = 0.0, parse_s = 0.0, run_s = 0.0, cut_s = 0.0;   // consumers (summed over GPUs): waiting for a unit's copy, kamd_fastq_unit_pack, the run callback; dispatcher: waiting for the cutter
   uint64_t units = 0, bytes = 0;
 
   // the reads of one file (single-end) or one pair of files; n_items receives the records handed to `run`
@@ -236,7 +239,9 @@ class UnitFeeder {
     UnitCut u;
     int rc = OK;
     for (;;) {
+      const auto tc0 = std::chrono::steady_clock::now();
       const int c = cut.next(u);
+      cut_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
       if (c == UnitCutter::DONE) break;
       if (c == UnitCutter::IO_ERROR) { for (int f = 0; f < nf; f++) if (src[f]->failed()) error_ = src[f]->error(); rc = FAILED; break; }
       if (c == UnitCutter::COUNT_MISMATCH) { error_ = "paired-end files have different numbers of reads"; rc = FAILED; break; }
@@ -285,7 +290,8 @@ class UnitFeeder {
 
  private:
   struct Buf { char* d[2] = {nullptr, nullptr}; uint64_t n_bytes[2] = {0, 0}, n_records = 0, seq = 0; int n_files = 1; hipEvent_t copied = nullptr; bool busy = false; };
-  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue; std::mutex m; std::condition_variable cv; std::thread th; double busy_s = 0.0; };
+  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue; std::mutex m; std::condition_variable cv; std::thread th;
+               double busy_s = 0.0, copy_wait_s = 0.0, parse_s = 0.0, run_s = 0.0; };
   // the rings are released in input order, whatever order the GPUs' copies complete in
   struct Tracker {
     std::mutex m; TextSource* s[2] = {nullptr, nullptr}; int nf = 0;
@@ -317,8 +323,8 @@ class UnitFeeder {
     for (auto& G : gpus_) { { std::lock_guard<std::mutex> lk(G->m); G->queue.push_back(-1); } G->cv.notify_all(); }
     for (auto& G : gpus_) if (G->th.joinable()) G->th.join();
     started_ = false;
-    device_s = 0.0;
-    for (auto& G : gpus_) device_s = std::max(device_s, G->busy_s);
+    device_s = copy_wait_s = parse_s = run_s = 0.0;
+    for (auto& G : gpus_) { device_s = std::max(device_s, G->busy_s); copy_wait_s += G->copy_wait_s; parse_s += G->parse_s; run_s += G->run_s; }
   }
   void drain() {   // until no text buffer is in flight
     for (auto& G : gpus_) {
@@ -327,39 +333,61 @@ class UnitFeeder {
     }
     tracker_.detach();
   }
+  // Units are parsed as they arrive; their reads are packed and pseudoaligned as ONE batch once z_.batch_items records have come
+  // together -- or the queue runs dry, when there is nothing better to do (kamd_pseudoalign has fixed costs of a few ms per call).
   void consume(int g) {
     Gpu& G = *gpus_[g];
     if (hipSetDevice(devs_[g]) != hipSuccess) { set_state(FAILED, "hipSetDevice failed"); }
-    for (;;) {
-      int bi;
-      {
-        std::unique_lock<std::mutex> lk(G.m);
-        G.cv.wait(lk, [&] { return !G.queue.empty(); });
-        bi = G.queue.front(); G.queue.pop_front();
-      }
-      if (bi < 0) return;
-      Buf& b = G.bufs[bi];
-      const auto t0 = std::chrono::steady_clock::now();
-      const bool copied = hipEventSynchronize(b.copied) == hipSuccess;
-      tracker_.complete(b.seq);   // the unit's bytes have left the ring
-      if (!copied) set_state(FAILED, "copy of a unit of text to the device failed");
-      if (state() == OK) {   // (after a failure or a declined unit the remaining units are only drained)
+    std::vector<int> pending;   // text buffers of the batch under construction
+    uint64_t pending_records = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&t0](double& acc) { const auto t1 = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(t1 - t0).count(); t0 = t1; };
+    auto flush = [&] {
+      if (pending.empty()) return;
+      t0 = std::chrono::steady_clock::now();
+      if (state() == OK) {
         kamd_fastq_unit fu;
-        const char* txt[2] = {b.d[0], b.d[1]};
-        if (kamd_fastq_unit_pack(ctxs_[g], txt, b.n_bytes, b.n_files, b.n_records, &fu) != 0) set_state(FAILED, kamd_last_error());
-        else if (fu.status == 3) set_state(FAILED, "reads longer than 65535 bp are outside the short-read GPU path");
-        else if (fu.status != 0) set_state(DECLINED, "");
-        else {
+        if (kamd_fastq_batch_pack(ctxs_[g], &fu) != 0) set_state(FAILED, kamd_last_error());
+        else if (fu.n_items) {
           PackedBatch pb;
           pb.d_words = const_cast<uint32_t*>(fu.d_words); pb.d_len = const_cast<uint16_t*>(fu.d_len);
-          pb.n_items = fu.n_items; pb.n_reads = fu.n_items * (uint64_t)b.n_files; pb.max_len = fu.max_len; pb.filled = true;
+          pb.n_items = fu.n_items; pb.n_reads = fu.n_items * (uint64_t)G.bufs[pending[0]].n_files; pb.max_len = fu.max_len; pb.filled = true;
           std::string err;
           if (run_(g, pb, err)) set_state(FAILED, err);
         }
       }
-      G.busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      { std::lock_guard<std::mutex> lk(G.m); b.busy = false; }
+      lap(G.run_s);
+      { std::lock_guard<std::mutex> lk(G.m); for (int bi : pending) G.bufs[bi].busy = false; }
       G.cv.notify_all();
+      pending.clear(); pending_records = 0;
+    };
+    for (;;) {
+      int bi;
+      {
+        std::unique_lock<std::mutex> lk(G.m);
+        if (G.queue.empty() && !pending.empty()) { lk.unlock(); flush(); lk.lock(); }
+        G.cv.wait(lk, [&] { return !G.queue.empty(); });
+        bi = G.queue.front(); G.queue.pop_front();
+      }
+      if (bi < 0) { flush(); G.busy_s = G.copy_wait_s + G.parse_s + G.run_s; return; }
+      Buf& b = G.bufs[bi];
+      t0 = std::chrono::steady_clock::now();
+      const bool copied = hipEventSynchronize(b.copied) == hipSuccess;
+      lap(G.copy_wait_s);
+      tracker_.complete(b.seq);   // the unit's bytes have left the ring
+      if (!copied) set_state(FAILED, "copy of a unit of text to the device failed");
+      pending.push_back(bi);
+      if (state() == OK) {   // (after a failure or a declined unit the remaining units are only drained)
+        kamd_fastq_unit fu;
+        const char* txt[2] = {b.d[0], b.d[1]};
+        const int prc = kamd_fastq_unit_parse(ctxs_[g], txt, b.n_bytes, b.n_files, b.n_records, &fu);
+        lap(G.parse_s);
+        if (prc != 0) set_state(FAILED, kamd_last_error());
+        else if (fu.status == 3) set_state(FAILED, "reads longer than 65535 bp are outside the short-read GPU path");
+        else if (fu.status != 0) set_state(DECLINED, "");
+        else pending_records += b.n_records;
+      }
+      if (state() != OK || pending_records >= z_.batch_items || pending.size() + 2 >= G.bufs.size()) flush();
     }
   }
   std::vector<kamd_ctx*> ctxs_; std::vector<int> devs_;

@@ -2047,6 +2047,7 @@ struct kamd_ctx {
   int last_em_plan_cached = 0;
   DBuf fq_tiles, fq_nlpos[2], fq_recs, fq_res, fq_words, fq_len;   // kamd_fastq_unit_pack: scratch and the packed batch it returns
   void* fq_host = nullptr;       // pinned FqResult
+  u64 fq_batch_reads = 0; int32_t fq_batch_max_len = 0, fq_batch_files = 0;   // reads parsed into fq_recs since the last kamd_fastq_batch_pack
   DBuf fld_tl, fld_card, fld_scratch, fld_items, fld_cand;
   void* fld_host = nullptr; u64 fld_host_cap = 0;   // pinned staging of kamd_fld_from_batch
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
@@ -2362,6 +2363,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   memset(&c->host_state, 0, sizeof c->host_state);
   c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0; c->tuple_bound = 0;
   c->had_overflow_items = false;
+  c->fq_batch_reads = 0; c->fq_batch_max_len = 0; c->fq_batch_files = 0;   // (units parsed but never packed belong to the abandoned run)
   return push_state(c);
 }
 
@@ -2380,31 +2382,35 @@ extern "C" int kamd_pack_reads_device(kamd_ctx* c, const char* d_seqs, const uin
   return 0;
 }
 
-// One unit of strict 4-line FASTQ text already in HBM -> the packed batch kernel A reads (see k_fq_* above).  The caller cut the
-// unit at record boundaries (it counted the newlines while the bytes went by) and says how many records it holds; the device
-// finds the lines, checks every record's shape, and packs mate 1 / mate 2 of record j into items 2j / 2j + 1.  One host
-// synchronisation (max_len decides the record stride; the shape check decides whether the batch may be used at all).
-extern "C" int kamd_fastq_unit_pack(kamd_ctx* c, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
-                                    kamd_fastq_unit* out) {
-  if (!c || !d_text || !n_bytes || !out) return kamd::fail(-1, "kamd_fastq_unit_pack: null argument");
-  if (n_files < 1 || n_files > 2) return kamd::fail(-1, "kamd_fastq_unit_pack: n_files must be 1 or 2");
+// Strict 4-line FASTQ text already in HBM -> the packed batch kernel A reads (see k_fq_* above).  The caller cut the text into
+// units at record boundaries (it counted the newlines while the bytes went by) and says how many records a unit holds; the device
+// finds the lines, checks every record's shape and notes {address, length} of every sequence (kamd_fastq_unit_parse: mate 1 /
+// mate 2 of record j become reads 2j / 2j + 1 of the unit); kamd_fastq_batch_pack then packs the reads of all units parsed since
+// the last batch in one launch -- a batch should be millions of reads (kamd_pseudoalign has fixed costs per call), a unit is what
+// one copy brings.  One host synchronisation per unit (the shape check decides whether the input may be used at all).
+extern "C" int kamd_fastq_unit_parse(kamd_ctx* c, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
+                                     kamd_fastq_unit* out) {
+  if (!c || !d_text || !n_bytes || !out) return kamd::fail(-1, "kamd_fastq_unit_parse: null argument");
+  if (n_files < 1 || n_files > 2) return kamd::fail(-1, "kamd_fastq_unit_parse: n_files must be 1 or 2");
+  if (c->fq_batch_reads && c->fq_batch_files != n_files) return kamd::fail(-1, "kamd_fastq_unit_parse: the batch under construction has another number of files");
   memset(out, 0, sizeof *out);
   out->first_bad_record = ~0ULL;
   if (n_records == 0) return 0;
   for (int f = 0; f < n_files; f++) {
-    if (!d_text[f] || n_bytes[f] == 0 || n_bytes[f] >= 0xFFFFFFFFULL) return kamd::fail(-1, "kamd_fastq_unit_pack: a unit holds 1 .. 2^32-2 bytes of text per file");
-    if ((uintptr_t)d_text[f] & 15) return kamd::fail(-1, "kamd_fastq_unit_pack: the text must be 16-byte aligned");
-    if (n_records > n_bytes[f] / 8) return kamd::fail(-1, "kamd_fastq_unit_pack: more records than the text can hold");
+    if (!d_text[f] || n_bytes[f] == 0 || n_bytes[f] >= 0xFFFFFFFFULL) return kamd::fail(-1, "kamd_fastq_unit_parse: a unit holds 1 .. 2^32-2 bytes of text per file");
+    if ((uintptr_t)d_text[f] & 15) return kamd::fail(-1, "kamd_fastq_unit_parse: the text must be 16-byte aligned");
+    if (n_records > n_bytes[f] / 8) return kamd::fail(-1, "kamd_fastq_unit_parse: more records than the text can hold");
   }
   HIPC(hipSetDevice(c->device));
-  if (!c->fq_host) { if (hipHostMalloc(&c->fq_host, sizeof(FqResult), hipHostMallocDefault) != hipSuccess) return kamd::fail(-100, "kamd_fastq_unit_pack: pinned allocation failed"); }
+  if (!c->fq_host) { if (hipHostMalloc(&c->fq_host, sizeof(FqResult), hipHostMallocDefault) != hipSuccess) return kamd::fail(-100, "kamd_fastq_unit_parse: pinned allocation failed"); }
   u64 tiles[2] = {0, 0}, tile_off[2] = {0, 0}, all_tiles = 0;
   for (int f = 0; f < n_files; f++) { tiles[f] = (n_bytes[f] + kamd_fq::FQ_TILE - 1) / kamd_fq::FQ_TILE; tile_off[f] = all_tiles; all_tiles += tiles[f]; }
   if (int rc = c->fq_tiles.ensure(2 * all_tiles * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->fq_res.ensure(sizeof(FqResult), 0, c->stream)) return rc;
   const u64 nl_cap = 4 * n_records + 4;
   for (int f = 0; f < n_files; f++) if (int rc = c->fq_nlpos[f].ensure(nl_cap * sizeof(u32), 0, c->stream)) return rc;
-  if (int rc = c->fq_recs.ensure(n_records * (u64)n_files * sizeof(u64), 0, c->stream)) return rc;
+  const u64 have = c->fq_batch_reads, n_reads = n_records * (u64)n_files;
+  if (int rc = c->fq_recs.ensure((have + n_reads) * sizeof(u64), have * sizeof(u64), c->stream)) return rc;
   FqResult* res = c->fq_res.as<FqResult>();
   FqResult init{}; init.first_bad = ~0ULL;
   FqResult* h = (FqResult*)c->fq_host;
@@ -2422,7 +2428,7 @@ extern "C" int kamd_fastq_unit_pack(kamd_ctx* c, const char* const* d_text, cons
     F.text[f] = d_text[f]; F.nlpos[f] = c->fq_nlpos[f].as<u32>(); F.n_bytes[f] = n_bytes[f];
   }
   hipLaunchKernelGGL(k_fq_records, dim3((unsigned)std::min<u64>(grid_for(n_records, BLOCK), 4096)), dim3(BLOCK), 0, c->stream, F, (u64)n_records,
-                     c->fq_recs.as<u64>(), res);
+                     c->fq_recs.as<u64>() + have, res);
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(h, res, sizeof(FqResult), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -2432,16 +2438,38 @@ extern "C" int kamd_fastq_unit_pack(kamd_ctx* c, const char* const* d_text, cons
   if (h->n_bad) { out->status = 1; out->first_bad_record = h->first_bad; return 0; }
   out->max_len = (int32_t)std::max<u32>(h->max_len, 1u);
   if (h->max_len > kamd_fq::FQ_MAX_READ) { out->status = 3; return 0; }   // reads beyond the packed layout's 16-bit lengths
+  c->fq_batch_reads = have + n_reads; c->fq_batch_files = n_files;
+  c->fq_batch_max_len = std::max(c->fq_batch_max_len, out->max_len);
+  return 0;
+}
+extern "C" int kamd_fastq_batch_pack(kamd_ctx* c, kamd_fastq_unit* out) {
+  if (!c || !out) return kamd::fail(-1, "kamd_fastq_batch_pack: null argument");
+  memset(out, 0, sizeof *out);
+  out->first_bad_record = ~0ULL;
+  const u64 n_reads = c->fq_batch_reads;
+  if (n_reads == 0) return 0;
+  HIPC(hipSetDevice(c->device));
+  out->max_len = c->fq_batch_max_len;
+  out->n_items = n_reads / (u64)c->fq_batch_files;
   const int seq_words = (out->max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(out->max_len);
-  const u64 n_reads = n_records * (u64)n_files, total = n_reads * (u64)rec_words;
+  const u64 total = n_reads * (u64)rec_words;
   if (int rc = c->fq_words.ensure(total * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->fq_len.ensure(n_reads * sizeof(uint16_t), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_fq_pack, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)c->fq_recs.as<u64>(), n_reads, seq_words, rec_words,
                      c->fq_words.as<u32>(), c->fq_len.as<uint16_t>());
   HIPC(hipGetLastError());
   out->d_words = c->fq_words.as<u32>(); out->d_len = c->fq_len.as<uint16_t>();
+  c->fq_batch_reads = 0; c->fq_batch_max_len = 0; c->fq_batch_files = 0;
   return 0;
+}
+// one unit = one batch
+extern "C" int kamd_fastq_unit_pack(kamd_ctx* c, const char* const* d_text, const uint64_t* n_bytes, int32_t n_files, uint64_t n_records,
+                                    kamd_fastq_unit* out) {
+  if (c && c->fq_batch_reads) return kamd::fail(-1, "kamd_fastq_unit_pack: a batch is under construction (kamd_fastq_batch_pack first)");
+  if (int rc = kamd_fastq_unit_parse(c, d_text, n_bytes, n_files, n_records, out)) return rc;
+  if (out->status != 0 || out->n_items == 0) return 0;
+  return kamd_fastq_batch_pack(c, out);
 }
 
 namespace {
@@ -4525,6 +4553,13 @@ extern "C" int kamd_ec_allreduce(kamd_ctx* c, kamd_comm* m) {
   if (m->world == 1 && !m->nccl) return 0;
   if (c->track_order) return kamd::fail(-1, "kamd_ec_allreduce: merged records have no input order (kamd_ec_track_order is on)");
   HIPC(hipSetDevice(c->device));
+  // a rank that was handed no batch never saw the options of the run, but resolves the merged records like everybody else:
+  // --union (mate flags inside the tuple entries) is agreed on here
+  {
+    uint64_t flags[1] = {c->ix.union_mode ? 1ULL : 0ULL};
+    if (int rc = kamd_comm_sum_u64_host(c, m, flags, 1)) return rc;
+    if (flags[0]) c->ix.union_mode = 1;
+  }
   // (a) one all-reduce of the dense count vector over the index's transcript sets
   if (int rc = comm_allreduce(m, c->dense.p, c->n_ecs, 0)) return rc;
   // (b) the de-duplicated tuple records of every rank

@@ -97,7 +97,11 @@ class TextSource {
       pad_nl_ = last != '\n';
       const uint64_t text = fsize_ + (pad_nl_ ? 1 : 0);
       for (uint64_t o = 0; o < text; o += blk_) blocks_.push_back(Blk{o, std::min<uint64_t>(o + blk_, text), 0, 0, 0, false});
-      for (int t = 0; t < std::min<int>(threads, (int)blocks_.size()); t++) workers_.emplace_back([this] { plain_worker(); });
+      // (a reader only copies page-cache bytes and counts newlines: a handful of threads saturate what the device can take over
+      // PCIe, and on the MI355X hosts measured here more than ~16 busy readers per file slowed everything else down)
+      int cap = 16;
+      if (const char* e = getenv("KAMD_FQ_PLAIN_THREADS")) cap = std::max(1, atoi(e));
+      for (int t = 0; t < std::min<int>(std::min(threads, cap), (int)blocks_.size()); t++) workers_.emplace_back([this] { plain_worker(); });
     } else if (kind_ == BGZF) {
       void* p = mmap(nullptr, fsize_, PROT_READ, MAP_PRIVATE, fd_, 0);
       if (p == MAP_FAILED) { fail("could not map " + path); return; }

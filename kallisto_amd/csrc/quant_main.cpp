@@ -297,8 +297,9 @@ int main(int argc, char** argv) {
   if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
   if (opt.verbose) std::cerr << "[timing] reads parsed, packed and pseudoaligned after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
   if (opt.verbose)
-    std::cerr << "[quant] device parser: " << feeder.units << " units, " << feeder.bytes << " bytes of text, device (parse + pack + pseudoalignment) " << feeder.device_s
-              << " s, dispatcher waited for a text buffer " << feeder.wait_s << " s; general reader: host packing " << pack_s << " s, device "
+    std::cerr << "[quant] device parser: " << feeder.units << " units, " << feeder.bytes << " bytes of text; consumers: waiting for copies " << feeder.copy_wait_s
+              << " s, parse + pack " << feeder.parse_s << " s, pseudoalignment " << feeder.run_s << " s; dispatcher: waiting for the cutter " << feeder.cut_s
+              << " s, for a text buffer " << feeder.wait_s << " s; general reader: host packing " << pack_s << " s, device "
               << pipe.device_s() << " s, host waited " << pipe.wait_s() << " s" << std::endl;
   std::cerr << "[quant] finding pseudoalignments for the reads ... done" << std::endl;
 

@@ -52,7 +52,7 @@ def test_cli_matches_reference_cli(case, variant, tmp_path):
     out = str(tmp_path / "out")
     # the device parser with units of ~20 KB of text (dozens of units even for these small files) ...
     p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", "-t", "7", *cli, *files],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KAMD_FQ_UNIT_BYTES="20000"))
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KAMD_FQ_UNIT_BYTES="20000", KAMD_FQ_BATCH_ITEMS="700"))
     assert p.returncode == 0, p.stderr.decode()
     assert "device parser: 0 units" not in p.stderr.decode()
     if (case, variant) in HOST_PARSED:
@@ -169,8 +169,8 @@ def test_cli_with_a_flattened_index(tmp_path):
     common.assert_abundance_close(np.array([float(r[3]) for r in outs[1]]), np.array([float(r[3]) for r in outs[0]]), "est_counts", rel=1e-9, floor=1e-9)
 
 
-@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("ref_test_pe", "pe_boot"), ("yeast_se", "se"), ("mosaic_pe", "pe_union"),
-                                          ("mosaic_pe", "pe_nojump_rf"), ("dlist_pe", "pe")])
+@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("human_pe", "pe_l180"), ("ref_test_pe", "pe_boot"), ("yeast_se", "se"), ("mosaic_pe", "pe_union"),
+                                          ("mosaic_pe", "pe_nojump_rf"), ("mosaic_pe", "se_union_overhang"), ("dlist_pe", "pe")])
 def test_cli_several_ranks_on_one_device(case, variant, tmp_path):
     """`--gpus 2 --share-device`: the several-GPU flow of the front-end (one context, pipeline and host thread per rank; units dealt
     round the ranks, to rank 0 while the fragment-length sample is open; kamd_ec_allreduce; kamd_em_run_comm; replicates dealt round
@@ -189,7 +189,7 @@ def test_cli_several_ranks_on_one_device(case, variant, tmp_path):
         files.append(f2)
     gold = os.path.join(common.case_dir(case), "cli_" + variant)
     ginfo = json.load(open(os.path.join(gold, "run_info.json")))
-    for mode, env in (("device", dict(KAMD_FQ_UNIT_BYTES="15000")), ("host", dict(KAMD_HOST_PARSE="1", KAMD_FASTQ_CHUNK="3000"))):
+    for mode, env in (("device", dict(KAMD_FQ_UNIT_BYTES="15000", KAMD_FQ_BATCH_ITEMS="500")), ("host", dict(KAMD_HOST_PARSE="1", KAMD_FASTQ_CHUNK="3000"))):
         out = str(tmp_path / ("out_" + mode))
         p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", "--gpus", "3", "--share-device", "--batch", "1500", "-t", "6",
                             *cli, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))

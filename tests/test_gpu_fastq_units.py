@@ -48,6 +48,25 @@ def test_paired_unit_interleaves_the_mates(ctx):
     assert mx == emx and np.array_equal(l.cpu().numpy(), el) and np.array_equal(w.cpu().numpy(), ew)
 
 
+def test_batch_of_several_units(ctx):
+    """kamd_fastq_unit_parse x 3 + kamd_fastq_batch_pack: the batch is the units' reads in order, at the longest read's stride; a unit
+    that is declined adds nothing."""
+    r1, r2 = _reads(9000, 21, lo=20, hi=90), _reads(9000, 22, lo=40, hi=151)
+    cuts = [0, 2500, 2501, 9000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == 2500:   # a bad unit in between: declined, the batch is unchanged
+            st, bad, _ = ctx.fastq_unit_parse([b"@x\nAC\n+\nI\n", b"@x\nAC\n+\nII\n"], 1)
+            assert st == 1 and bad == 0
+        st, _, _ = ctx.fastq_unit_parse([_fastq_bytes(r1[a:b]), _fastq_bytes(r2[a:b], tricky_quals=False)], b - a)
+        assert st == 0
+    w, l, n, mx, st, _ = ctx.fastq_batch_pack()
+    assert st == 0 and n == 9000
+    inter = [x for pair in zip(r1, r2) for x in pair]
+    ew, el, emx = _expect(ctx, inter)
+    assert mx == emx and np.array_equal(l.cpu().numpy(), el) and np.array_equal(w.cpu().numpy(), ew)
+    assert ctx.fastq_batch_pack()[2] == 0                 # nothing left
+
+
 def test_tiny_and_unaligned_sizes(ctx):
     for n in [1, 2, 3, 17, 255, 256, 257]:
         reads = _reads(n, 100 + n, lo=1, hi=40)
@@ -117,7 +136,7 @@ def test_front_end_device_parser_equals_general_reader(tmp_path, kind):
         else:
             open(p, "wb").write(_bgzf(data, block=20000))
         files.append(p)
-    small = {"KAMD_FQ_UNIT_MB": "1"}                       # several units even for these small files
+    small = {"KAMD_FQ_UNIT_BYTES": "300000", "KAMD_FQ_BATCH_ITEMS": "3000"}                       # several units even for these small files
     dev_tsv, dev_err = _run_cli(idx_path, files, str(tmp_path / "dev"), env=small)
     host_tsv, host_err = _run_cli(idx_path, files, str(tmp_path / "host"), env={"KAMD_HOST_PARSE": "1"})
     assert "device parser: 0 units" not in dev_err and "device parser: 0 units" in host_err
@@ -137,7 +156,7 @@ def test_front_end_restarts_with_the_general_reader_on_a_late_violation(tmp_path
     open(a, "wb").write(tail_multiline(d1)); open(b, "wb").write(tail_multiline(d2))
     ref_a, ref_b = str(tmp_path / "ra.fq"), str(tmp_path / "rb.fq")
     open(ref_a, "wb").write(d1); open(ref_b, "wb").write(d2)
-    got, err = _run_cli(idx_path, [a, b], str(tmp_path / "o1"), env={"KAMD_FQ_UNIT_MB": "1"})
+    got, err = _run_cli(idx_path, [a, b], str(tmp_path / "o1"), env={"KAMD_FQ_UNIT_BYTES": "300000", "KAMD_FQ_BATCH_ITEMS": "3000"})
     want, _ = _run_cli(idx_path, [ref_a, ref_b], str(tmp_path / "o2"))
     assert "general FASTA/FASTQ reader" in err
     assert got == want
