@@ -53,6 +53,24 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def effective_cpus():
+    """CPUs this process may keep busy: the cgroup's CPU quota (containers show all host processors in os.cpu_count()), the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                n = min(n, max(1, int(q / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def wait_for(path, timeout=3600):
     t0 = time.time()
     while not os.path.exists(path):
@@ -80,7 +98,7 @@ def prepare_workload(name: str, genes: int, is_builder: bool):
             fa = os.path.join(CACHE, tag + ".fa")
             synth.write_fasta(fa, seqs)
             t0 = time.time()
-            threads = min(os.cpu_count() or 8, 32)
+            threads = min(effective_cpus(), 32)
             subprocess.check_call([REF_BIN, "index", "-t", str(threads), "-i", idx + ".tmp", fa], stdout=subprocess.DEVNULL,
                                   stderr=subprocess.DEVNULL)
             os.replace(idx + ".tmp", idx)
@@ -306,7 +324,7 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         # the same reads as BGZF (block-parallel inflate) and, a subset, as one ordinary gzip member per file (`gzip -1`)
         bg = [os.path.join(tmp, f"b_{i + 1}.fq.gz") for i in range(len(plain))]
         for src, dst in zip(plain, bg):
-            write_bgzf(src, dst, min(threads, 48))
+            write_bgzf(src, dst, max(2, min(threads, 48)))
         ngz = min(n, gz_items)
         gz = []
         procs = []
@@ -718,13 +736,13 @@ def main():
     unit_name = "pairs" if paired else "reads"
     rate_unit = "M read pairs/s" if paired else "M reads/s"
     if rank == 0 and world == 1 and sample is not None:
-        threads = min(os.cpu_count() or 1, 64)
+        threads = min(effective_cpus(), 64)   # (the cgroup's CPU quota, not the host's processor count: more busy threads than that get throttled)
         k = sample[0].shape[0]
         log(f"CPU baseline: reference `kallisto quant -t {threads}` on the first {k} {unit_name} ...")
         try:
             cb = cpu_reference_baseline(idx_path, sample[0], sample[1], threads, cli_extra)
             out["cpu_baseline"] = {"value": round(k / cb["seconds"] / 1e6, 4), "unit": rate_unit, "cores": threads,
-                                   "kind": "reference",
+                                   "kind": "reference", "processors_visible": os.cpu_count(),
                                    "sample": f"first {k} {unit_name} of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
                                              f"--plaintext {' '.join(cli_extra)}`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
                                              f"{cb['index_load_s']:.1f}s excluded)",
@@ -764,7 +782,8 @@ def main():
         del words, lens
         torch.cuda.empty_cache()
         try:
-            out["end_to_end"] = end_to_end(idx_path, e2e_sample[0], e2e_sample[1], paired, min(os.cpu_count() or 1, 64), cli_extra)
+            out["end_to_end"] = end_to_end(idx_path, e2e_sample[0], e2e_sample[1], paired, min(effective_cpus(), 64), cli_extra)
+            out["end_to_end"]["host"] = {"cpus_available": effective_cpus(), "processors_visible": os.cpu_count()}
         except Exception as e:
             out["end_to_end"] = {"error": str(e)}
     if rank == 0:

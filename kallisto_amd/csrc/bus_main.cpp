@@ -159,6 +159,8 @@ int bus_main(int argc, char** argv) {
     }
   }
 
+  (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);   // (see quant_main.cpp)
+  threads = std::min(threads, effective_cpus());
   kamd_index* idx = nullptr;
   KX(kamd_index_load(index.c_str(), threads, &idx));
   kamd_index_view v; KX(kamd_index_get_view(idx, &v));

@@ -26,6 +26,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include <unistd.h>
 #include <vector>
 
@@ -44,6 +45,30 @@ inline bool take(const std::string& a, const char* shortf, const char* longf, in
   if (a == longf || (shortf && a == shortf)) { if (i + 1 >= argc) { std::cerr << "Error: missing value for " << a << std::endl; exit(1); } val = argv[++i]; return true; }
   if (shortf && a.size() > 2 && a.compare(0, 2, shortf) == 0) { val = a.substr(2); return true; }   // getopt's attached form: -t4, -l200
   return false;
+}
+
+// CPUs this process may actually keep busy: the CPU quota of its cgroup (containers routinely show all of the host's processors in
+// nproc while cpu.max grants a fraction; running more busy threads than the quota gets the whole group throttled for the rest of every
+// scheduling period, which stalls the thread that feeds the GPU), capped by the affinity mask and the processor count.
+inline int effective_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
+  auto quota = [](const char* path, const char* path_period) -> double {
+    std::ifstream f(path);
+    if (!f.is_open()) return 0.0;
+    std::string q; double period = 100000.0;
+    f >> q;
+    if (path_period) { std::ifstream g(path_period); if (g.is_open()) g >> period; } else f >> period;
+    if (q.empty() || q == "max" || q[0] == '-') return 0.0;
+    const double v = atof(q.c_str());
+    return (v > 0 && period > 0) ? v / period : 0.0;
+  };
+  double q = quota("/sys/fs/cgroup/cpu.max", nullptr);
+  if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+  if (q > 0) n = std::min(n, std::max(1, (int)(q + 0.5)));
+  if (const char* e = getenv("KAMD_CPUS")) n = std::max(1, atoi(e));
+  return std::max(1, n);
 }
 
 // FASTA/FASTQ input (SeqReader, ChunkReader, MappedFastq, BgzfSource): kamd_fastq.h
@@ -228,7 +253,8 @@ class UnitFeeder {
     const int nf = f1 ? 2 : 1;
     if (prepare(nf) != OK) return FAILED;
     start_consumers();
-    const int per_file = std::max(1, io_threads / nf);
+    // readers: what the caller allows, within the CPUs this process may keep busy minus the dispatcher, the consumer and the runtime's own threads
+    const int per_file = std::max(1, (std::min(io_threads, effective_cpus()) - 3) / nf);
     std::unique_ptr<TextSource> src[2];
     for (int f = 0; f < nf; f++) {
       src[f].reset(new TextSource(f ? *f1 : f0, ring_[f], z_.ring, per_file, z_.block));

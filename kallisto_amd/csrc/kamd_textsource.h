@@ -97,8 +97,7 @@ class TextSource {
       pad_nl_ = last != '\n';
       const uint64_t text = fsize_ + (pad_nl_ ? 1 : 0);
       for (uint64_t o = 0; o < text; o += blk_) blocks_.push_back(Blk{o, std::min<uint64_t>(o + blk_, text), 0, 0, 0, false});
-      // (a reader only copies page-cache bytes and counts newlines: a handful of threads saturate what the device can take over
-      // PCIe, and on the MI355X hosts measured here more than ~16 busy readers per file slowed everything else down)
+      // (a reader only copies page-cache bytes and counts newlines at ~4-5 GB/s: a dozen saturate what the device takes over PCIe)
       int cap = 16;
       if (const char* e = getenv("KAMD_FQ_PLAIN_THREADS")) cap = std::max(1, atoi(e));
       for (int t = 0; t < std::min<int>(std::min(threads, cap), (int)blocks_.size()); t++) workers_.emplace_back([this] { plain_worker(); });
@@ -245,14 +244,16 @@ class TextSource {
       uint64_t end = b.end;
       const bool padded = pad_nl_ && end == fsize_ + 1;
       if (padded) --end;
-      for (uint64_t pos = b.begin; pos < end;) {
-        const size_t o = (size_t)(pos % cap_), n = (size_t)std::min<uint64_t>(end - pos, cap_ - o);
+      uint64_t nl = 0;
+      for (uint64_t pos = b.begin; pos < end;) {   // 256 KB at a time: the count reads what the copy just wrote while it is in L2
+        const size_t o = (size_t)(pos % cap_), n = (size_t)std::min<uint64_t>(std::min<uint64_t>(end - pos, cap_ - o), 256u << 10);
         const ssize_t r = pread(fd_, ring_ + o, n, (off_t)pos);
         if (r <= 0) { fail("read error on " + path_); return; }
+        nl += count_newlines(ring_ + o, (size_t)r);
         pos += (uint64_t)r;
       }
-      if (padded) ring_[(size_t)(end % cap_)] = '\n';
-      finish_block(i, count_range(b.begin, b.end));
+      if (padded) { ring_[(size_t)(end % cap_)] = '\n'; ++nl; }
+      finish_block(i, nl);
     }
   }
   void bgzf_worker() {

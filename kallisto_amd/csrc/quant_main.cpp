@@ -223,6 +223,11 @@ int main(int argc, char** argv) {
   // device contexts first (they do not need the index): the pinned text rings of the device-parse pipeline are allocated by a
   // second thread while the index is read and flattened (KmerIndex::load)
   const auto t_start = std::chrono::steady_clock::now();
+  // threads that wait for the GPU sleep instead of spinning: the host's CPUs belong to the readers (the runtime's default burns one
+  // CPU per waiting thread, and a container's CPU quota is easily exceeded -- see effective_cpus())
+  (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+  const int host_cpus = effective_cpus();
+  if (opt.threads > host_cpus) { if (opt.verbose) std::cerr << "[quant] " << opt.threads << " threads asked for, " << host_cpus << " CPUs available to this process: using " << host_cpus << std::endl; opt.threads = host_cpus; }
   int n_dev = 0;
   HIPX(hipGetDeviceCount(&n_dev));
   const int n_gpus = std::max(1, opt.gpus);

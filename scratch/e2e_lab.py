@@ -65,20 +65,17 @@ def main():
         for l in lines: print("   ", l[:400], flush=True)
     for k in sys.argv[3:] if len(sys.argv) > 3 else []:
         pass
-    run("plain t64", [f1, f2], n)
+    run("plain t64 (capped to the cgroup)", [f1, f2], n)
     run("plain t64 again", [f1, f2], n)
-    run("plain t16", [f1, f2], n, threads=16)
-    run("plain t64 readers 4/file", [f1, f2], n, env={"KAMD_FQ_PLAIN_THREADS": "4"})
-    run("plain t64 readers 8/file", [f1, f2], n, env={"KAMD_FQ_PLAIN_THREADS": "8"})
-    run("plain t64 readers 32/file", [f1, f2], n, env={"KAMD_FQ_PLAIN_THREADS": "32"})
-    run("plain t64 batch 4M", [f1, f2], n, env={"KAMD_FQ_BATCH_ITEMS": "4000000", "KAMD_FQ_BUFS": "32"})
-    run("plain t64 batch 512k", [f1, f2], n, env={"KAMD_FQ_BATCH_ITEMS": "500000"})
-    run("plain t64 unit 64MB", [f1, f2], n, env={"KAMD_FQ_UNIT_MB": "64", "KAMD_FQ_BUFS": "12"})
+    run("plain KAMD_CPUS=12", [f1, f2], n, env={"KAMD_CPUS": "12"})
+    run("plain KAMD_CPUS=20", [f1, f2], n, env={"KAMD_CPUS": "20"})
+    run("plain unit 64MB", [f1, f2], n, env={"KAMD_FQ_UNIT_MB": "64", "KAMD_FQ_BUFS": "12"})
+    run("plain unit 16MB", [f1, f2], n, env={"KAMD_FQ_UNIT_MB": "16", "KAMD_FQ_BUFS": "40"})
+    run("plain ring 512MB", [f1, f2], n, env={"KAMD_FQ_RING_MB": "512"})
     run("plain host-parse", [f1, f2], n, env={"KAMD_HOST_PARSE": "1"})
     t0 = time.time(); make_bgzf(f1, tmp + "/b_1.fq.gz"); make_bgzf(f2, tmp + "/b_2.fq.gz"); print(f"bgzf written in {time.time()-t0:.1f}s", flush=True)
     run("bgzf t64", [tmp + "/b_1.fq.gz", tmp + "/b_2.fq.gz"], n)
-    run("bgzf t32", [tmp + "/b_1.fq.gz", tmp + "/b_2.fq.gz"], n, threads=32)
-    run("bgzf t96", [tmp + "/b_1.fq.gz", tmp + "/b_2.fq.gz"], n, threads=96)
+    run("bgzf KAMD_CPUS=20", [tmp + "/b_1.fq.gz", tmp + "/b_2.fq.gz"], n, env={"KAMD_CPUS": "20"})
     run("bgzf t64 zlib", [tmp + "/b_1.fq.gz", tmp + "/b_2.fq.gz"], n, env={"KAMD_NO_LIBDEFLATE": "1"})
     ng = min(n, 2_000_000); per = os.path.getsize(f1) // n
     for src, dst in ((f1, tmp + "/g_1.fq"), (f2, tmp + "/g_2.fq")):
