@@ -299,7 +299,7 @@ class UnitFeeder {
       if (!ok) { error_ = "copy of a unit of text to the device failed"; rc = FAILED; break; }
       b.n_records = u.n_records; b.n_files = nf;
       b.seq = tracker_.add(u.end);
-      { std::lock_guard<std::mutex> lk(G.m); G.queue.push_back(bi); }
+      { std::lock_guard<std::mutex> lk(G.m); G.queue.push_back(bi); G.copies.push_back(bi); }
       G.cv.notify_all();
       n_items += u.n_records; ++units;
       if (verbose) std::cerr << "[quant] processed " << n_items << (nf == 2 ? " pairs" : " reads") << std::endl;
@@ -316,7 +316,7 @@ class UnitFeeder {
 
  private:
   struct Buf { char* d[2] = {nullptr, nullptr}; uint64_t n_bytes[2] = {0, 0}, n_records = 0, seq = 0; int n_files = 1; hipEvent_t copied = nullptr; bool busy = false; };
-  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue; std::mutex m; std::condition_variable cv; std::thread th;
+  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue, copies; std::mutex m; std::condition_variable cv; std::thread th, rel;
                double busy_s = 0.0, copy_wait_s = 0.0, parse_s = 0.0, run_s = 0.0; };
   // the rings are released in input order, whatever order the GPUs' copies complete in
   struct Tracker {
@@ -342,12 +342,28 @@ class UnitFeeder {
   void start_consumers() {
     if (started_) return;
     started_ = true;
-    for (size_t g = 0; g < gpus_.size(); g++) gpus_[g]->th = std::thread([this, g] { consume((int)g); });
+    for (size_t g = 0; g < gpus_.size(); g++) { gpus_[g]->th = std::thread([this, g] { consume((int)g); }); gpus_[g]->rel = std::thread([this, g] { release_loop((int)g); }); }
+  }
+  // the ring's bytes of a unit are free once its copy has completed -- long before the consumer, busy with a batch, gets to the unit
+  void release_loop(int g) {
+    Gpu& G = *gpus_[g];
+    (void)hipSetDevice(devs_[g]);
+    for (;;) {
+      int bi;
+      {
+        std::unique_lock<std::mutex> lk(G.m);
+        G.cv.wait(lk, [&] { return !G.copies.empty(); });
+        bi = G.copies.front(); G.copies.pop_front();
+      }
+      if (bi < 0) return;
+      if (hipEventSynchronize(G.bufs[bi].copied) != hipSuccess) set_state(FAILED, "copy of a unit of text to the device failed");
+      tracker_.complete(G.bufs[bi].seq);
+    }
   }
   void stop_consumers() {
     if (!started_) return;
-    for (auto& G : gpus_) { { std::lock_guard<std::mutex> lk(G->m); G->queue.push_back(-1); } G->cv.notify_all(); }
-    for (auto& G : gpus_) if (G->th.joinable()) G->th.join();
+    for (auto& G : gpus_) { { std::lock_guard<std::mutex> lk(G->m); G->queue.push_back(-1); G->copies.push_back(-1); } G->cv.notify_all(); }
+    for (auto& G : gpus_) { if (G->th.joinable()) G->th.join(); if (G->rel.joinable()) G->rel.join(); }
     started_ = false;
     device_s = copy_wait_s = parse_s = run_s = 0.0;
     for (auto& G : gpus_) { device_s = std::max(device_s, G->busy_s); copy_wait_s += G->copy_wait_s; parse_s += G->parse_s; run_s += G->run_s; }
@@ -400,7 +416,6 @@ class UnitFeeder {
       t0 = std::chrono::steady_clock::now();
       const bool copied = hipEventSynchronize(b.copied) == hipSuccess;
       lap(G.copy_wait_s);
-      tracker_.complete(b.seq);   // the unit's bytes have left the ring
       if (!copied) set_state(FAILED, "copy of a unit of text to the device failed");
       pending.push_back(bi);
       if (state() == OK) {   // (after a failure or a declined unit the remaining units are only drained)

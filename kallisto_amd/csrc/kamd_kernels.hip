@@ -2011,7 +2011,7 @@ struct DBuf {
   // grow to at least `bytes`; `keep` bytes of the old contents are preserved
   int ensure(size_t bytes, size_t keep, hipStream_t s) {
     if (bytes <= cap) return 0;
-    size_t ncap = std::max(bytes, cap + cap / 2);
+    size_t ncap = std::max(bytes, 2 * cap);   // (doubling: a stream that grows batch by batch is reallocated O(log n) times)
     void* np = nullptr;
     HIPC(hipMalloc(&np, ncap));
     if (keep && p) HIPC(hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, s));
