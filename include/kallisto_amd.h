@@ -125,6 +125,9 @@ typedef struct {
   int32_t em_group_div;        /* component-local form: groups hold about nnz / (CUs x this) entries (default 4) */
   int32_t em_split_len;        /* component-local form: a row / column with more entries is split over several lanes (1..64) */
   int32_t dedup_form;          /* record de-duplication: 1 = insert + verify launches, 2 = one launch (tag and owner in one CAS; default) */
+  int32_t em_small_nnz;        /* component-local form: connected components of at most this many entries are packed into groups of about as
+                                  many entries that ONE WAVEFRONT iterates (no block barrier inside a round); larger components keep
+                                  workgroup-sized groups.  -1 = one size class only (every group a workgroup); default 384 */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);

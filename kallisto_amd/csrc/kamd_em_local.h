@@ -89,6 +89,7 @@ KAMD_HD int cols_pass(const Group& G, uint32_t tid, uint32_t nthr, const double*
 // ---- the plan: groups in HBM (here: host vectors) --------------------------------------------------------------------
 struct Plan {
   uint32_t n_groups = 0;
+  uint32_t n_small = 0;                      // groups [0, n_small) hold only small components (two size classes: build_plan_steps_host)
   uint64_t T = 0;
   std::vector<uint32_t> row_base, tr_base;   // [n_groups + 1] first row / first (m-space) transcript of a group
   std::vector<uint64_t> nz_base;             // [n_groups + 1] first entry of a group (same in both directions)
@@ -254,6 +255,11 @@ struct BuildArgs {
   const uint64_t* ec_off; const uint32_t* ec_ids; const uint32_t* counts; const uint32_t* wcounts; uint64_t n_ecs;
   const double* eff; uint64_t T; const uint32_t* label;   // label[t] = smallest transcript id of t's component
   uint64_t target_nnz;
+  // two size classes (cum_big != nullptr): components of at most small_limit entries are cut into groups of about target_nnz entries
+  // by cum_nnz (which then only counts them) -- groups [0, ng_small), one wavefront each in the kernel; the larger components
+  // follow in groups of about target_big entries by cum_big -- one workgroup each
+  const uint64_t* cum_big; uint64_t target_big; uint32_t small_limit; uint32_t ng_small;
+  uint32_t* c_small; uint32_t* c_big;   // scratch of the split: a component's entries in its own class, 0 in the other
   // per transcript / per component root, [T] (+1 where scanned)
   uint8_t* in_multi; double* single_all; uint32_t* c_nnz; uint32_t* c_rows; uint32_t* c_tr; const uint64_t* cum_nnz; uint32_t* local_of;
   // per group, [n_groups] (+1 where scanned)
@@ -270,7 +276,17 @@ struct BuildArgs {
   // the plan's arrays
   uint32_t* row_ptr; uint16_t* row_tr; uint32_t* col_ptr; uint16_t* col_row; uint64_t* cw; double* single; double* eff_m; uint32_t* tr_id;
 };
-KAMD_HD uint32_t eml_group_of(const BuildArgs& A, uint32_t root) { return (uint32_t)(A.cum_nnz[root] / A.target_nnz); }
+KAMD_HD uint32_t eml_group_of(const BuildArgs& A, uint32_t root) {
+  if (A.cum_big && A.c_nnz[root] > A.small_limit) return A.ng_small + (uint32_t)(A.cum_big[root] / A.target_big);
+  return (uint32_t)(A.cum_nnz[root] / A.target_nnz);
+}
+// C (per root, two size classes only): the component's entries in its class
+KAMD_HD void step_root_c(uint64_t r, const BuildArgs& A) {
+  if (r >= A.T) return;
+  const uint32_t n = A.c_nnz[r];
+  const bool big = n > A.small_limit;
+  A.c_small[r] = big ? 0u : n; A.c_big[r] = big ? n : 0u;
+}
 // A (per row): component sizes, which transcripts are in a kept row, singleton counts
 KAMD_HD void step_rows_a(uint64_t e, const BuildArgs& A) {
   if (e >= A.n_ecs) return;
@@ -380,8 +396,11 @@ inline std::vector<uint32_t> component_labels_host(const uint64_t* ec_off, const
 // the steps above, run serially, with std::exclusive_scan-like loops where the device has its scan kernel.
 // Returns 0 = ok, 1 = not applicable (some group exceeds the budget or the 16-bit range: the caller may retry with a smaller
 // target or take another EM form).
+// small_limit != 0: two size classes -- components of at most small_limit entries in groups of about target_small entries (the first
+// P->n_small groups), the others in groups of about target_nnz entries.
 inline int build_plan_steps_host(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, const uint32_t* wcounts, uint64_t n_ecs,
-                                 const double* eff, uint64_t T, uint64_t budget_bytes, uint64_t target_nnz, Plan* P) {
+                                 const double* eff, uint64_t T, uint64_t budget_bytes, uint64_t target_nnz, Plan* P, uint32_t small_limit = 0,
+                                 uint64_t target_small = 0) {
   const std::vector<uint32_t> label = component_labels_host(ec_off, ec_ids, n_ecs, T);
   auto scan32 = [](const std::vector<uint32_t>& in, uint64_t n, std::vector<uint64_t>& out) { out.assign(n + 1, 0); for (uint64_t i = 0; i < n; i++) out[i + 1] = out[i] + in[i]; };
   BuildArgs A{};
@@ -392,10 +411,26 @@ inline int build_plan_steps_host(const uint64_t* ec_off, const uint32_t* ec_ids,
   A.in_multi = in_multi.data(); A.single_all = P->single_all.data(); A.c_nnz = c_nnz.data(); A.c_rows = c_rows.data(); A.c_tr = c_tr.data(); A.local_of = local_of.data();
   for (uint64_t e = 0; e < n_ecs; e++) step_rows_a(e, A);
   for (uint64_t t = 0; t < T; t++) step_tr_b(t, A);
-  for (uint64_t t = 0; t < T; t++) cum[t + 1] = cum[t] + c_nnz[t];
+  std::vector<uint32_t> c_small, c_big; std::vector<uint64_t> cum_big;
+  uint32_t ng = 0;
+  uint64_t NZ = 0;
+  if (small_limit) {
+    c_small.assign(T, 0); c_big.assign(T, 0); cum_big.assign(T + 1, 0);
+    A.small_limit = small_limit; A.c_small = c_small.data(); A.c_big = c_big.data();
+    for (uint64_t r = 0; r < T; r++) step_root_c(r, A);
+    for (uint64_t t = 0; t < T; t++) { cum[t + 1] = cum[t] + c_small[t]; cum_big[t + 1] = cum_big[t] + c_big[t]; }
+    A.target_big = A.target_nnz; A.target_nnz = std::max<uint64_t>(1, target_small);
+    A.cum_big = cum_big.data();
+    A.ng_small = cum[T] ? (uint32_t)((cum[T] - 1) / A.target_nnz + 1) : 0;
+    ng = A.ng_small + (cum_big[T] ? (uint32_t)((cum_big[T] - 1) / A.target_big + 1) : 0);
+    NZ = cum[T] + cum_big[T];
+    P->n_small = A.ng_small;
+  } else {
+    for (uint64_t t = 0; t < T; t++) cum[t + 1] = cum[t] + c_nnz[t];
+    NZ = cum[T];
+    ng = NZ ? (uint32_t)((NZ - 1) / A.target_nnz + 1) : 0;
+  }
   A.cum_nnz = cum.data();
-  const uint64_t NZ = cum[T];
-  const uint32_t ng = NZ ? (uint32_t)((NZ - 1) / A.target_nnz + 1) : 0;
   P->n_groups = ng; A.n_groups = ng;
   std::vector<uint32_t> g_rows(ng, 0), g_tr(ng, 0), g_nnz(ng, 0), row_fill(ng, 0), tr_fill(ng, 0);
   A.g_rows = g_rows.data(); A.g_tr = g_tr.data(); A.g_nnz = g_nnz.data(); A.row_fill = row_fill.data(); A.tr_fill = tr_fill.data();

@@ -158,6 +158,7 @@ KAMD_HD uint64_t group_bytes(uint64_t rows, uint64_t tr, uint64_t row_slices, ui
 // ---- the plan ------------------------------------------------------------------------------------------------------------
 struct Plan {
   uint32_t n_groups = 0;
+  uint32_t n_small = 0;                          // groups [0, n_small): small components only, one wavefront each (k_em_sell_wave)
   uint64_t T = 0;
   uint32_t cap = SELL_LANES;                     // entries per lane above which a segment is split
   std::vector<uint32_t> row_base, tr_base;       // [n_groups + 1]
@@ -169,7 +170,8 @@ struct Plan {
   std::vector<double> single, eff;               // [M] new transcript order
   std::vector<uint32_t> tr_id;                   // [M] transcript id of an m-space slot
   std::vector<double> single_all;                // [T]
-  uint64_t max_group_bytes = 0;
+  uint64_t max_group_bytes = 0;                  // LDS bytes of the largest group (of the large class when there are two)
+  uint64_t max_small_bytes = 0;                  // ... of the largest small group
 };
 
 // host reference: CSR plan (kamd_em_local::Plan) -> SELL plan.  Returns 0 = ok, 1 = not applicable (a group exceeds the budget)
@@ -193,7 +195,7 @@ KAMD_HD uint64_t entry_pos(const uint32_t* desc, uint32_t lane, uint32_t vlen, u
 inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Plan* P, uint32_t cap = SELL_LANES) {
   const uint32_t ng = C.n_groups;
   P->cap = cap;
-  P->n_groups = ng; P->T = C.T; P->row_base = C.row_base; P->tr_base = C.tr_base; P->single_all = C.single_all;
+  P->n_groups = ng; P->n_small = C.n_small; P->T = C.T; P->row_base = C.row_base; P->tr_base = C.tr_base; P->single_all = C.single_all;
   const uint64_t R = C.row_base[ng], M = C.tr_base[ng];
   std::vector<uint32_t> rlen(R), clen(M), rnew(R), cnew(M), rlane(R), clane(M), rnv(R), cnv(M), rvl(R), cvl(M);
   P->rslice_base.assign(ng + 1, 0); P->cslice_base.assign(ng + 1, 0); P->rell_base.assign(ng + 1, 0); P->cell_base.assign(ng + 1, 0);
@@ -209,7 +211,8 @@ inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Pl
     const LayoutSize lc = layout_group(clen.data() + C.tr_base[g], G.n_tr, cap, ns, scratch, 1);
     const uint64_t gb = group_bytes(G.n_rows, G.n_tr, lr.n_slices, lc.n_slices, lr.n_u16, lc.n_u16);
     if (gb > budget_bytes) return 1;
-    if (gb > P->max_group_bytes) P->max_group_bytes = gb;
+    if (g < P->n_small) { if (gb > P->max_small_bytes) P->max_small_bytes = gb; }
+    else if (gb > P->max_group_bytes) P->max_group_bytes = gb;
     P->rslice_base[g + 1] = P->rslice_base[g] + lr.n_slices; P->cslice_base[g + 1] = P->cslice_base[g] + lc.n_slices;
     P->rell_base[g + 1] = P->rell_base[g] + lr.n_u16; P->cell_base[g + 1] = P->cell_base[g] + lc.n_u16;
   }

@@ -2068,6 +2068,7 @@ struct kamd_ctx {
   hipEvent_t ev2 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   float last_finalize_ms = 0.f; u64 last_fin_records = 0, last_fin_stream_words = 0, last_fin_cand_words = 0;
   hipStream_t em_stream = nullptr;
+  hipStream_t em_side_stream = nullptr; hipEvent_t em_ev_fork = nullptr, em_ev_join = nullptr;   // component-local EM: the small size class runs beside the large one
   int items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
@@ -2186,7 +2187,7 @@ namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_small_nnz = 384; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2;
 }
 // 0 = keep; values outside a field's range are ignored
@@ -2200,6 +2201,7 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.em_local_block == 128 || n.em_local_block == 256 || n.em_local_block == 512 || n.em_local_block == 1024) t->em_local_block = n.em_local_block;
   if (n.em_split_len >= 1 && n.em_split_len <= 64) t->em_split_len = n.em_split_len;
   if (n.em_group_div >= 1 && n.em_group_div <= 1024) t->em_group_div = n.em_group_div;
+  if (n.em_small_nnz != 0) t->em_small_nnz = n.em_small_nnz < 0 ? -1 : std::min(n.em_small_nnz, 4096);
   if (n.em_entries_per_lane != 0) t->em_entries_per_lane = n.em_entries_per_lane < 0 ? -1 : n.em_entries_per_lane;
   if (n.em_windowed == 1 || n.em_windowed == 2) t->em_windowed = n.em_windowed;
   if (n.em_graph == 1 || n.em_graph == 2) t->em_graph = n.em_graph;
@@ -2221,6 +2223,7 @@ void tuning_from_env(kamd_tuning* t) {
   }
   geti("KAMD_EM_LOCAL_BLOCK", &n.em_local_block);
   geti("KAMD_EM_GROUP_DIV", &n.em_group_div);
+  geti("KAMD_EM_SMALL_NNZ", &n.em_small_nnz);
   geti("KAMD_DEDUP_FORM", &n.dedup_form);
   geti("KAMD_EM_SPLIT_LEN", &n.em_split_len);
   geti("KAMD_EM_K", &n.em_entries_per_lane);
@@ -2289,6 +2292,9 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev_fin0) (void)hipEventDestroy(c->ev_fin0);
   if (c->ev_fin1) (void)hipEventDestroy(c->ev_fin1);
   if (c->em_stream) (void)hipStreamDestroy(c->em_stream);
+  if (c->em_side_stream) { (void)hipStreamSynchronize(c->em_side_stream); (void)hipStreamDestroy(c->em_side_stream); }
+  if (c->em_ev_fork) (void)hipEventDestroy(c->em_ev_fork);
+  if (c->em_ev_join) (void)hipEventDestroy(c->em_ev_join);
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
@@ -3258,19 +3264,25 @@ __device__ __forceinline__ double ems_slice_sum(const uint16_t* e, u32 width, co
   for (; j < width; j++) S += src[e[(size_t)j * 64]];
   return S;
 }
-__global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
-  __shared__ int s_hist[EML_MAX_ROUNDS];
+// One team of NW wavefronts iterates one group out of its own piece of LDS.  WAVE_TEAM: the team is a single wavefront (several
+// teams share a workgroup), so the two hand-overs of a round -- g after the rows pass, a / alpha after the columns pass -- need no
+// block barrier: a wavefront's LDS operations complete in order, the fence only keeps the compiler from moving them.
+template <bool WAVE_TEAM>
+__device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsigned char* smem, u32 tid, u32 nthr, double* alpha, double* a,
+                                                 int n_rounds, int clamp, int* s_hist) {
   namespace L = kamd_em_sell;
-  const u32 g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = lane_id();
-  const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = nthr >> 6;
+  const u32 wv = WAVE_TEAM ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = WAVE_TEAM ? 1u : nthr >> 6;
   const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
   const u32 rs0 = P.rslice_base[g], nrs = P.rslice_base[g + 1] - rs0, cs0 = P.cslice_base[g], ncs = P.cslice_base[g + 1] - cs0;
   const u64 re0 = P.rell_base[g], ce0 = P.cell_base[g];
   const u32 nru = (u32)(P.rell_base[g + 1] - re0), ncu = (u32)(P.cell_base[g + 1] - ce0);
+  auto team_sync = [] {
+    if (WAVE_TEAM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    else __syncthreads();
+  };
   // the layout kamd_em_sell::group_bytes() prices
-  double* s_al0 = reinterpret_cast<double*>(ems_smem);
+  double* s_al0 = reinterpret_cast<double*>(smem);
   double* s_a0 = s_al0 + (nT + 1); double* s_al1 = s_a0 + (nT + 1); double* s_a1 = s_al1 + (nT + 1);
   double* s_single = s_a1 + (nT + 1); double* s_eff = s_single + nT; double* s_g = s_eff + nT;
   u64* s_cw = reinterpret_cast<u64*>(s_g + (nR + 1));
@@ -3288,8 +3300,7 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, double* 
   for (u32 i = tid; i < nru; i += nthr) { const uint16_t v = P.rell[re0 + i]; s_rell[i] = v == (uint16_t)L::SELL_PAD ? (uint16_t)nT : v; }
   for (u32 i = tid; i < ncu; i += nthr) { const uint16_t v = P.cell[ce0 + i]; s_cell[i] = v == (uint16_t)L::SELL_PAD ? (uint16_t)nR : v; }
   if (tid == 0) { s_al0[nT] = s_a0[nT] = s_al1[nT] = s_a1[nT] = 0.0; s_g[nR] = 0.0; }
-  if (tid < EML_MAX_ROUNDS) s_hist[tid] = 0;
-  __syncthreads();
+  team_sync();
   double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
   for (int r = 0; r < n_rounds; r++) {
     // rows: S_e over the row's transcripts, then g_e = count_e / S_e (rows the reference skips get 0: count 0, :133-135;
@@ -3311,7 +3322,7 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, double* 
         s_g[seg] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
       }
     }
-    __syncthreads();
+    team_sync();
     // columns: next_t = single_t + a_t * sum of g over the transcript's rows, and the convergence test of :176-199
     int ch = 0;
     for (u32 s = wv; s < ncs; s += NW) {
@@ -3339,12 +3350,36 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, double* 
       for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
       if (lane == 0) atomicAdd(&s_hist[r], wsum);
     }
-    __syncthreads();
+    team_sync();
     double* t1 = al; al = aln; aln = t1;
     double* t2 = av; av = avn; avn = t2;
   }
   for (u32 i = tid; i < nT; i += nthr) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
-  if (hist && (int)tid < n_rounds && s_hist[tid]) atomicAdd(&hist[tid], s_hist[tid]);
+}
+// one workgroup per group (the large size class, or every group when there is only one class): groups g_first + blockIdx.x
+__global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, u32 g_first, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
+  __shared__ int s_hist[EML_MAX_ROUNDS];
+  if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  ems_group_rounds<false>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, n_rounds, clamp, s_hist);
+  __syncthreads();
+  if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+// one WAVEFRONT per group (the small size class): the wavefronts of a workgroup run their groups independently -- no block barrier
+// inside the rounds, so a CU holds a few dozen groups at different points of their rounds and the LDS pipe always has work
+constexpr int EMS_WAVE_TEAMS = 4;   // groups per workgroup
+__global__ __launch_bounds__(64 * EMS_WAVE_TEAMS) void k_em_sell_wave(EmSellDev P, u32 n_small, u32 team_bytes, double* alpha, double* a, int n_rounds,
+                                                                        int clamp, int* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
+  __shared__ int s_hist[EML_MAX_ROUNDS];
+  if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 team = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u32 g = blockIdx.x * EMS_WAVE_TEAMS + team;
+  if (g < n_small) ems_group_rounds<true>(P, g, ems_smem + (size_t)team * team_bytes, (u32)lane_id(), 64u, alpha, a, n_rounds, clamp, s_hist);
+  __syncthreads();
+  if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 // ---- conversion of the device-built CSR plan (em_local_setup_device) into the sliced-ELLPACK layout --------------------------
 struct SellBuild {
@@ -3528,14 +3563,17 @@ __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   else if constexpr (S == 5) kamd_em_local::step_rows_i(i, A);
   else if constexpr (S == 6) kamd_em_local::step_m_j(i, kamd_em_local::eml_group_of_slot(A, i), A);
   else if constexpr (S == 7) kamd_em_local::step_group_j(i, A);
+  else if constexpr (S == 9) kamd_em_local::step_root_c(i, A);
   else kamd_em_local::step_rows_k(i, A);
 }
 // The plan built on the device: component labels by the kernels the partitioned EM uses, then the steps of
 // kamd_em_local.h with scans in between.  The host only sees the per-group sizes (budget check, bases) and, for the final
 // scatter, tr_id and the singleton counts.  0 = ok (P holds the host part, *dev the device part), 1 = not applicable.
+// small_limit != 0: two size classes (kamd_em_local.h BuildArgs): components of at most small_limit entries in groups of about
+// target_small entries (P->n_small of them, first), the others in groups of about `target` entries.
 int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
                           const double* eff_lens, u64 T, u64 budget, u64 target, kamd_em_local::Plan* P, EmLocalDev* dev,
-                          kamd_em_local::BuildArgs* args_out = nullptr) {
+                          kamd_em_local::BuildArgs* args_out = nullptr, u32 small_limit = 0, u64 target_small = 0) {
   namespace L = kamd_em_local;
   if (nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
   // component labels (smallest transcript id of the component): min-label propagation + pointer jumping
@@ -3556,8 +3594,9 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   Carver t1;
   const size_t o_inm = t1.take(T + 8), o_sall = t1.take(T * 8 + 8), o_cn = t1.take(T * 4 + 8), o_cr = t1.take(T * 4 + 8), o_ct = t1.take(T * 4 + 8);
   const size_t o_cum = t1.take((T + 2) * 8), o_loc = t1.take(T * 4 + 8), o_eff = t1.take(T * 8 + 8), o_rnew = t1.take(n_ecs * 4 + 8);
+  const size_t o_cs = t1.take(small_limit ? T * 4 + 8 : 8), o_cb = t1.take(small_limit ? T * 4 + 8 : 8), o_cumb = t1.take(small_limit ? (T + 2) * 8 : 8);
   // ... and per group: at most nnz / target + 2 groups (the real number is known after the scan below)
-  const u64 ng_max = nnz / std::max<u64>(1, target) + 2;
+  const u64 ng_max = nnz / std::max<u64>(1, target) + 2 + (small_limit ? nnz / std::max<u64>(1, target_small) + 2 : 0);
   const size_t o_gr = t1.take(ng_max * 4 + 8), o_gt = t1.take(ng_max * 4 + 8), o_gn = t1.take(ng_max * 4 + 8), o_rf = t1.take(ng_max * 4 + 8),
                o_tf = t1.take(ng_max * 4 + 8);
   if (int rc = c->eml_tmp.ensure(t1.off, 0, c->stream)) return rc;
@@ -3571,12 +3610,31 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   A.c_tr = (u32*)(tb + o_ct); A.cum_nnz = (const uint64_t*)(tb + o_cum); A.local_of = (u32*)(tb + o_loc); A.row_new = (u32*)(tb + o_rnew);
   hipLaunchKernelGGL(k_eml_step<0>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   hipLaunchKernelGGL(k_eml_step<1>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
-  if (int rc = exclusive_scan(c, A.c_nnz, T, (u64*)(tb + o_cum), (u64*)(tb + o_cum) + T)) return rc;
   u64 NZ = 0;
-  HIPC(hipMemcpyAsync(&NZ, (u64*)(tb + o_cum) + T, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
-  if (NZ == 0) return 1;
-  const u32 ng = (u32)((NZ - 1) / A.target_nnz + 1);
+  u32 ng = 0;
+  P->n_small = 0;
+  if (small_limit) {
+    A.small_limit = small_limit; A.c_small = (u32*)(tb + o_cs); A.c_big = (u32*)(tb + o_cb);
+    hipLaunchKernelGGL(k_eml_step<9>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
+    if (int rc = exclusive_scan(c, A.c_small, T, (u64*)(tb + o_cum), (u64*)(tb + o_cum) + T)) return rc;
+    if (int rc = exclusive_scan(c, A.c_big, T, (u64*)(tb + o_cumb), (u64*)(tb + o_cumb) + T)) return rc;
+    u64 nz2[2] = {0, 0};
+    HIPC(hipMemcpyAsync(&nz2[0], (u64*)(tb + o_cum) + T, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(&nz2[1], (u64*)(tb + o_cumb) + T, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    NZ = nz2[0] + nz2[1];
+    if (NZ == 0) return 1;
+    A.target_big = A.target_nnz; A.target_nnz = std::max<u64>(1, target_small); A.cum_big = (const uint64_t*)(tb + o_cumb);
+    A.ng_small = nz2[0] ? (u32)((nz2[0] - 1) / A.target_nnz + 1) : 0u;
+    ng = A.ng_small + (nz2[1] ? (u32)((nz2[1] - 1) / A.target_big + 1) : 0u);
+    P->n_small = A.ng_small;
+  } else {
+    if (int rc = exclusive_scan(c, A.c_nnz, T, (u64*)(tb + o_cum), (u64*)(tb + o_cum) + T)) return rc;
+    HIPC(hipMemcpyAsync(&NZ, (u64*)(tb + o_cum) + T, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (NZ == 0) return 1;
+    ng = (u32)((NZ - 1) / A.target_nnz + 1);
+  }
   if ((u64)ng > ng_max) return kamd::fail(-105, "kamd_em_run: component-local EM: more groups than entries allow");
   A.n_groups = ng;
   HIPC(hipMemsetAsync(tb + o_gr, 0, t1.off - o_gr, c->stream));
@@ -3679,7 +3737,7 @@ __global__ void k_sell_refresh(const u64* __restrict__ ec_off, const u32* __rest
 struct SellCache {
   bool valid = false;
   const u64* d_ec_off = nullptr; const u32* d_ec_ids = nullptr; u64 n_ecs = 0, nnz = 0, T = 0, generation = 0;
-  int split_len = 0, group_div = 0;
+  int split_len = 0, group_div = 0, small_nnz = 0;
   kamd_em_sell::Plan P;      // host part (tr_id, single_all, bases)
   EmSellDev dev{};           // device part, in ctx->ems_plan
   u32* row_final = nullptr; u32* mslot = nullptr; double* single_all = nullptr; double* d_eff = nullptr;   // in ctx->ems_maps
@@ -3687,7 +3745,8 @@ struct SellCache {
 
 // ---- the sliced-ELLPACK form: device plan + backend of kamd_em_local::run --------------------------------------------------
 struct EmSellGpu {
-  kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0; int block = 256;
+  kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0, team_bytes = 0; int block = 256;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
   std::vector<double> h_alpha; int err = 0;
   const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
@@ -3707,8 +3766,15 @@ struct EmSellGpu {
     if (err || n <= 0) return;
     if (n > EML_MAX_ROUNDS) { err = -104; return; }
     if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
-    if (P.n_groups) hipLaunchKernelGGL(k_em_sell, dim3(P.n_groups), dim3(block), lds, c->stream, dev, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    // the two size classes run side by side: small groups (one wavefront each) on a second stream, forked from and joined to the context stream
+    const u32 n_big = P.n_groups - P.n_small;
+    const bool fork = P.n_small && n_big;
+    if (fork && (hipEventRecord(ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) { err = -104; return; }
+    if (n_big) hipLaunchKernelGGL(k_em_sell, dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
+    if (P.n_small) hipLaunchKernelGGL(k_em_sell_wave, dim3((P.n_small + EMS_WAVE_TEAMS - 1) / EMS_WAVE_TEAMS), dim3(64 * EMS_WAVE_TEAMS), (size_t)EMS_WAVE_TEAMS * team_bytes,
+                                      fork ? side : c->stream, dev, P.n_small, (u32)team_bytes, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
     if (hipGetLastError() != hipSuccess) { err = -104; return; }
+    if (fork && (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(c->stream, ev_join, 0) != hipSuccess)) { err = -104; return; }
     if (hist && part) {
       if (hipStreamSynchronize(c->stream) != hipSuccess) { err = -104; return; }
       if (part->cb(part->user, (int32_t*)d_hist, n)) { err = -103; return; }
@@ -3732,17 +3798,28 @@ int EmSellGpu::setup(int chunk, const double* d_eff_new) {
   if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, d_eff_new, M, 1.0 / (double)P.T);
   HIPC(hipGetLastError());
   lds = (size_t)P.max_group_bytes;
-  HIPC(hipFuncSetAttribute((const void*)k_em_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (P.n_groups > P.n_small) HIPC(hipFuncSetAttribute((const void*)k_em_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (P.n_small) {
+    team_bytes = ((size_t)P.max_small_bytes + 15) & ~(size_t)15;
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(EMS_WAVE_TEAMS * team_bytes)));
+    if (!c->em_side_stream) {
+      HIPC(hipStreamCreateWithFlags(&c->em_side_stream, hipStreamNonBlocking));
+      HIPC(hipEventCreateWithFlags(&c->em_ev_fork, hipEventDisableTiming));
+      HIPC(hipEventCreateWithFlags(&c->em_ev_join, hipEventDisableTiming));
+    }
+    side = c->em_side_stream; ev_fork = c->em_ev_fork; ev_join = c->em_ev_join;
+  }
   return 0;
 }
 // 0 = plan built (P: the host part; *dev: the device part), 1 = not applicable, < 0 = error
 int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                         const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev, SellCache* cache) {
+                         const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev, SellCache* cache,
+                         u32 small_limit = 0, u64 target_small = 0, u64 small_budget = 0) {
   namespace S = kamd_em_sell;
   kamd_em_local::Plan C;
   EmLocalDev cd{};
   kamd_em_local::BuildArgs A{};
-  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A)) return rc;
+  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A, small_limit, target_small)) return rc;
   const u32 ng = C.n_groups;
   const u64 R = C.row_base[ng], M = C.tr_base[ng];
   if (R >= 0xFFFFFFF0ULL || M >= 0xFFFFFFF0ULL) return 1;
@@ -3766,13 +3843,18 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   std::vector<u32> gsz((size_t)ng * 4);
   HIPC(hipMemcpyAsync(gsz.data(), B.gsz, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
-  P->n_groups = ng; P->T = T; P->row_base = C.row_base; P->tr_base = C.tr_base; P->single_all = C.single_all;
+  P->n_groups = ng; P->n_small = C.n_small; P->T = T; P->row_base = C.row_base; P->tr_base = C.tr_base; P->single_all = C.single_all;
   P->rslice_base.assign(ng + 1, 0); P->cslice_base.assign(ng + 1, 0); P->rell_base.assign(ng + 1, 0); P->cell_base.assign(ng + 1, 0);
-  P->max_group_bytes = 0;
+  P->max_group_bytes = 0; P->max_small_bytes = 0;
   for (u32 g = 0; g < ng; g++) {
     const u64 gb = S::group_bytes(C.row_base[g + 1] - C.row_base[g], C.tr_base[g + 1] - C.tr_base[g], gsz[4 * g], gsz[4 * g + 2], gsz[4 * g + 1], gsz[4 * g + 3]);
-    if (gb > lds_budget) return 1;
-    P->max_group_bytes = std::max<uint64_t>(P->max_group_bytes, gb);
+    if (g < P->n_small) {
+      if (gb > small_budget) return 2;   // a small group that does not fit a wavefront's share of the LDS: the caller drops the size classes
+      P->max_small_bytes = std::max<uint64_t>(P->max_small_bytes, gb);
+    } else {
+      if (gb > lds_budget) return 1;
+      P->max_group_bytes = std::max<uint64_t>(P->max_group_bytes, gb);
+    }
     P->rslice_base[g + 1] = P->rslice_base[g] + gsz[4 * g]; P->rell_base[g + 1] = P->rell_base[g] + gsz[4 * g + 1];
     P->cslice_base[g + 1] = P->cslice_base[g] + gsz[4 * g + 2]; P->cell_base[g + 1] = P->cell_base[g] + gsz[4 * g + 3];
   }
@@ -3830,7 +3912,8 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   // the count words, the singleton counts and the effective lengths
   const bool own = c->finalized && d_ec_off == (const u64*)c->result.d_ec_off && d_ec_ids == c->result.d_ec_ids;
   const bool hit = own && K.valid && K.d_ec_off == d_ec_off && K.d_ec_ids == d_ec_ids && K.n_ecs == n_ecs && K.nnz == nnz && K.T == T &&
-                   K.generation == c->ec_generation && K.split_len == c->tune.em_split_len && K.group_div == c->tune.em_group_div;
+                   K.generation == c->ec_generation && K.split_len == c->tune.em_split_len && K.group_div == c->tune.em_group_div &&
+                   K.small_nnz == c->tune.em_small_nnz;
   if (hit) {
     HIPC(hipMemcpyAsync(K.d_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemsetAsync(K.single_all, 0, T * 8, c->stream));
@@ -3852,10 +3935,19 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       K.dev = EmSellDev{};
       prc = 0;
     } else
-    for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc == 1; div *= 2) {
-      const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
-      prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K);
-      if (target == 1024) break;
+    {
+      // two size classes (em_small_nnz > 0): components of at most em_small_nnz entries go to groups of about that many entries, which
+      // one wavefront iterates (k_em_sell_wave); the larger ones to workgroup-sized groups as before.  A small group must fit a
+      // wavefront's share of a CU's LDS (24 KB: six or more workgroups of four per CU), else the classes are dropped.
+      u32 small = c->tune.em_small_nnz > 0 ? (u32)c->tune.em_small_nnz : 0u;
+      for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc >= 1; div *= 2) {
+        const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
+        prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K, small, small,
+                                   24 * 1024);
+        if (prc == 2) { small = 0; div /= 2; continue; }   // (same cut again, one class)
+        if (target == 1024) break;
+      }
+      if (prc == 2) prc = 1;
     }
     if (prc < 0) return prc;
     bool not_applicable = prc == 1 || (!multi && K.P.n_groups == 0);
@@ -3872,7 +3964,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
     if (not_applicable) return 1;
     if (own) {
       K.valid = true; K.d_ec_off = d_ec_off; K.d_ec_ids = d_ec_ids; K.n_ecs = n_ecs; K.nnz = nnz; K.T = T; K.generation = c->ec_generation;
-      K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div;
+      K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div; K.small_nnz = c->tune.em_small_nnz;
     }
   }
   const kamd_em_sell::Plan& P = K.P;

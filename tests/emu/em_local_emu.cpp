@@ -13,7 +13,10 @@ int emu_em_local(const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t*
   using namespace kamd_em_local;
   Plan P;   // builder 0: the host reference (greedy packing), 1: the data-parallel steps the device set-up is made of,
             // 2: 1 + conversion to the sliced-ELLPACK layout (kamd_em_sell.h) and its host model of the kernel's round
-  if (int rc = builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)
+  // builder >= 10: the steps with two size classes (components of at most 40 entries in groups of about 60), then builder - 10
+  const bool classes = builder >= 10;
+  if (classes) builder -= 10;
+  if (int rc = builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P, classes ? 40u : 0u, 60)
                        : build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return rc;
   *n_groups = P.n_groups; *max_group_bytes = P.max_group_bytes;
   if (builder >= 2) {   // 2 / 3 / 4: segments of more than 64 / 16 / 3 entries are split over lanes
@@ -34,8 +37,13 @@ int emu_em_local_check_plan(const uint64_t* ec_off, const uint32_t* ec_ids, cons
                             uint64_t T, uint64_t budget_bytes, uint64_t target_nnz, int builder) {
   using namespace kamd_em_local;
   Plan P;
-  if (builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)
+  const bool classes = builder >= 10;
+  if (classes) builder -= 10;
+  if (builder ? build_plan_steps_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P, classes ? 40u : 0u, 60)
               : build_plan_host(ec_off, ec_ids, counts, nullptr, n_ecs, eff, T, budget_bytes, target_nnz, &P)) return -1;
+  if (classes) {   // small groups first, and only small components in them (a group of the small class stays below limit + target entries)
+    for (uint32_t g = 0; g < P.n_small; g++) if (P.nz_base[g + 1] - P.nz_base[g] >= 40 + 60) return 10;
+  }
   std::map<std::vector<uint32_t>, uint64_t> want, got;
   for (uint64_t e = 0; e < n_ecs; e++) {
     if (ec_off[e + 1] - ec_off[e] < 2) continue;

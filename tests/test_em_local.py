@@ -67,6 +67,19 @@ def test_plan_built_by_the_data_parallel_steps(budget, target):
     assert _check_plan(off, ids, cnt, eff, T, 2 * 1024, 1 << 40, builder=1) == -1
 
 
+@pytest.mark.parametrize("target", [1 << 40, 300, 90])
+def test_two_size_classes_of_groups(target):
+    """components of at most 40 entries packed into small groups (one wavefront each on the device), the others into groups of
+    `target` entries: the plan still holds the matrix, small groups come first and stay small, and the EM is the oracle's"""
+    off, ids, cnt, eff, T = _gene_matrix(200, 11)
+    assert _check_plan(off, ids, cnt, eff, T, 1 << 30, target, builder=11) == 0
+    a_o, abz_o, r_o = O.em_run(off, ids, cnt, eff, T)
+    for b in (11, 12, 14):     # CSR rounds; sliced ELLPACK with segments split above 64 / 3 entries
+        rc, a, abz, r, ng, _ = _run(off, ids, cnt, eff, T, 1 << 30, target, 16, builder=b)
+        assert rc == 0 and r == r_o and ng > 20
+        common.assert_abundance_close(a, a_o, "alpha (two size classes)", rel=1e-9)
+
+
 @pytest.mark.parametrize("budget,target,chunk", [(1 << 30, 1 << 40, 64), (16 * 1024, 1 << 40, 64), (1 << 30, 400, 7), (8 * 1024, 200, 1),
                                                  (1 << 30, 1 << 40, 10000)])
 def test_local_em_equals_the_oracle(budget, target, chunk):

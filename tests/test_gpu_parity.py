@@ -211,7 +211,7 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "hub"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local_one_class", "local_small40", "local_all_small", "hub"])
 def test_em_forms_agree_with_oracle(k, ka):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -222,10 +222,18 @@ def test_em_forms_agree_with_oracle(k, ka):
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
-    if k in ("local", "local512", "local1024s8"):
+    if isinstance(k, str) and k.startswith("local"):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
-        tune = dict(em_form="local", em_local_block={"local": 256, "local512": 512, "local1024s8": 1024}[k], em_group_div=64,
+        tune = dict(em_form="local", em_local_block={"local": 256, "local512": 512}.get(k, 1024), em_group_div=64,
                     em_split_len=8 if k == "local1024s8" else 32)
+        # size classes of the groups: the default (components of <= 384 entries one wavefront each), one class only (every group a
+        # workgroup), a limit that splits this matrix's components between the two kernels, and everything in wavefront-sized groups
+        if k == "local_one_class":
+            tune["em_small_nnz"] = -1
+        elif k == "local_small40":
+            tune["em_small_nnz"] = 40
+        elif k == "local_all_small":
+            tune["em_small_nnz"] = 4096
         k = "local"
     elif k == "hub":
         tune = dict(em_form="local")
