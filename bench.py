@@ -634,7 +634,7 @@ def main():
             # component-local form: the matrix sits in LDS for the rounds of a launch; a round gathers one FP64 value and reads one
             # 16-bit index per entry and direction out of LDS -- the bound is the LDS pipe, HBM only sees the per-launch load / store
             lds_bytes = 2 * pr["em_nnz"] * (8 + 2)
-            lds_peak = 256 * 128 * 2.4   # GB/s: 256 CUs x 128 B/clk x 2.4 GHz (MI355X_MICROARCH.md)
+            lds_peak = 256 * 256 * 2.4   # GB/s: 256 CUs x 256 B/clk (ds_read_b64: 64 banks x 4 B, MI355X_MICROARCH.md LDS section) x 2.4 GHz
             em_roof = {"kernel": "EM round inside k_em_sell (component-local, sliced ELLPACK in LDS)", "bound": "lds",
                        "achieved": round(lds_bytes / (em_round_ms * 1e-3) / 1e9, 2), "peak": round(lds_peak, 1), "unit": "GB/s",
                        "frac": round(lds_bytes / (em_round_ms * 1e-3) / 1e9 / lds_peak, 5), "traffic": None,

@@ -127,7 +127,9 @@ typedef struct {
   int32_t dedup_form;          /* record de-duplication: 1 = insert + verify launches, 2 = one launch (tag and owner in one CAS; default) */
   int32_t em_small_nnz;        /* component-local form: connected components of at most this many entries are packed into groups of about as
                                   many entries that ONE WAVEFRONT iterates (no block barrier inside a round); larger components keep
-                                  workgroup-sized groups.  -1 = one size class only (every group a workgroup); default 384 */
+                                  workgroup-sized groups.  -1 = one size class only (every group a workgroup; the default: on the
+                                  human-sized workload most entries sit in components of more than a thousand entries, the two kernels
+                                  side by side were slower -- profiles/README.md) */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);

@@ -2187,7 +2187,7 @@ namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_small_nnz = 384; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2;
 }
 // 0 = keep; values outside a field's range are ignored

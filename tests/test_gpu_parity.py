@@ -226,10 +226,10 @@ def test_em_forms_agree_with_oracle(k, ka):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
         tune = dict(em_form="local", em_local_block={"local": 256, "local512": 512}.get(k, 1024), em_group_div=64,
                     em_split_len=8 if k == "local1024s8" else 32)
-        # size classes of the groups: the default (components of <= 384 entries one wavefront each), one class only (every group a
-        # workgroup), a limit that splits this matrix's components between the two kernels, and everything in wavefront-sized groups
+        # size classes of the groups: the default (one class: every group a workgroup), components of <= 384 entries one wavefront
+        # each, a limit that splits this matrix's components between the two kernels, and everything in wavefront-sized groups
         if k == "local_one_class":
-            tune["em_small_nnz"] = -1
+            tune["em_small_nnz"] = 384
         elif k == "local_small40":
             tune["em_small_nnz"] = 40
         elif k == "local_all_small":
