@@ -186,7 +186,9 @@ int kamd_fastq_unit_pack(kamd_ctx*, const char* const* d_text, const uint64_t* n
 
 /* ---- S2: pseudoalignment of one batch resident in HBM ----
  * n_items = pairs (paired) or reads (single).  Accumulates into the context's EC state; call kamd_ec_finalize after
- * the last batch. */
+ * the last batch.  The EC state is bounded by the number of DISTINCT classes, like MinCollector's (src/MinCollector.cpp:251-269): a
+ * dense count vector over the index's transcript sets plus a table of the distinct tuples of set ids seen so far; the per-item
+ * records of a batch are recycled when the call returns. */
 int kamd_pseudoalign(kamd_ctx*, const kamd_quant_opts*, const uint32_t* d_words, const uint16_t* d_len, uint64_t n_items,
                      int32_t max_len);
 /* fragment-length histogram from the first 10000 qualifying pairs in input order (src/ProcessReads.cpp:981-1017,
@@ -208,7 +210,8 @@ typedef struct {
   uint64_t n_probes;        /* k-mer table probes */
   uint64_t n_bucket_reads;  /* 64-byte bucket reads (>= n_probes) */
   uint64_t n_distinct_tuples;
-  uint64_t n_stream_words;  /* u32 words of the record stream (one fixed slot per item + the records of overflow items) */
+  uint64_t n_stream_words;  /* u32 words of the last batch's record stream (one fixed slot per item + the records of overflow items; recycled
+                               from batch to batch: its distinct tuple records move to the tuple store) */
   uint64_t n_raw_words;     /* u32 words kernel A wrote: per item 1 header + its distinct (unitig,set) classes */
   uint64_t n_text_hits;     /* probes answered from the unitig text instead of the table */
   uint64_t n_wave_iters;    /* kernel A: loop trips summed over the wavefronts ... */
@@ -232,10 +235,15 @@ typedef struct {
                                   component-local form: number of groups (= workgroups per launch) */
   uint32_t last_em_lds;        /* component-local form: LDS bytes per workgroup */
   int32_t last_em_plan_cached; /* component-local form: 1 = the plan of an earlier run on the same matrix was reused */
-  float last_finalize_ms;      /* kamd_ec_finalize: record de-duplication, resolution of the tuples, merge of equal sets, CSR (HIP events around it) */
-  uint64_t last_fin_records;   /* ... records it de-duplicated (one slot per item), */
-  uint64_t last_fin_stream_words;  /* u32 words of the record stream it read, */
+  float last_finalize_ms;      /* kamd_ec_finalize: resolution of the distinct tuples, merge of equal sets, CSR (HIP events around it) */
+  uint64_t last_fin_records;   /* ... distinct tuples it resolved, */
+  uint64_t last_fin_stream_words;  /* u32 words of the tuple store it read, */
   uint64_t last_fin_cand_words;    /* u32 words of candidate transcript sets it wrote and merged */
+  float absorb_ms;             /* since kamd_ec_reset: de-duplication of the batches' tuple records into the persistent tuple table
+                                  (inside kamd_pseudoalign, after k_classify; HIP events around it) */
+  uint64_t n_distinct_tuples;  /* entries of the tuple table; */
+  uint64_t tuple_store_words;  /* u32 words of distinct tuple records kept; */
+  uint64_t tuple_table_slots;  /* slots of the table (32 bytes each): what the EC state costs in HBM, whatever the number of reads */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

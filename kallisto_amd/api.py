@@ -65,7 +65,8 @@ class _Profile(C.Structure):
                 ("last_em_nnz_multi", C.c_uint64), ("last_em_nseg", C.c_uint64), ("last_em_necs", C.c_uint64),
                 ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32), ("last_em_lds", C.c_uint32),
                 ("last_em_plan_cached", C.c_int32), ("last_finalize_ms", C.c_float), ("last_fin_records", C.c_uint64),
-                ("last_fin_stream_words", C.c_uint64), ("last_fin_cand_words", C.c_uint64)]
+                ("last_fin_stream_words", C.c_uint64), ("last_fin_cand_words", C.c_uint64), ("absorb_ms", C.c_float),
+                ("n_distinct_tuples", C.c_uint64), ("tuple_store_words", C.c_uint64), ("tuple_table_slots", C.c_uint64)]
 
 
 class _FastqUnit(C.Structure):
@@ -430,7 +431,8 @@ class Context:
                 "em_necs": int(p.last_em_necs), "em_k": int(p.last_em_k), "em_grid": int(p.last_em_grid), "em_lds": int(p.last_em_lds),
                 "em_plan_cached": int(p.last_em_plan_cached), "finalize_ms": float(p.last_finalize_ms),
                 "fin_records": int(p.last_fin_records), "fin_stream_words": int(p.last_fin_stream_words),
-                "fin_cand_words": int(p.last_fin_cand_words)}
+                "fin_cand_words": int(p.last_fin_cand_words), "absorb_ms": float(p.absorb_ms), "n_distinct_tuples": int(p.n_distinct_tuples),
+                "tuple_store_words": int(p.tuple_store_words), "tuple_table_slots": int(p.tuple_table_slots)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

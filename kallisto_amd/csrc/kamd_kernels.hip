@@ -90,6 +90,7 @@ struct DevState {
   u64 n_hit_overflow;            // explicit-set pass: reads whose hits touched more than EXPLICIT_HITS blocks
   u64 exp_words, exp_recs;       // explicit transcript-set stream
   u64 cand_words, cand_recs;     // candidate transcript-set stream
+  u64 tl_n, ts_words, tl_fail;   // distinct tuples so far (entries of the tuple list), words of the tuple store, records of a batch that found no slot
 };
 
 struct TSlot { u64 tag, owner, count, first; };  // first: smallest first-occurrence key of the merged records (candidate table)
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
 constexpr int DENSE_CACHE = 2048;
 template <bool PAIRED, bool FILTER, int CAP>   // CAP: class entries of a raw record (12: kernel A v2, 8: v3)
 __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict__ slots, int stride, u64 n_items, u64 slot_base,
-                                                    u64 rec_base, FilterDev fd, AlignOut out) {
+                                                    u64 rec_base, u64 key_base, FilterDev fd, AlignOut out) {
   __shared__ u32 lds_ecs[BLOCK * CAP];
   __shared__ u32 cache_key[DENSE_CACHE];
   __shared__ u32 cache_cnt[DENSE_CACHE];
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
       const u32 hh = (e * 2654435761u) >> (32 - 11);
       const u32 old = atomicCAS(&cache_key[hh], 0xFFFFFFFFu, e);
       if (old == 0xFFFFFFFFu || old == e) { atomicAdd(&cache_cnt[hh], 1u); atomicMin(&cache_min[hh], (u32)item); }
-      else { atomicAdd(&out.dense_counts[e], 1u); if (out.dense_first) atomicMin(&out.dense_first[e], rec_base + item); }
+      else { atomicAdd(&out.dense_counts[e], 1u); if (out.dense_first) atomicMin(&out.dense_first[e], key_base + item); }
     }
     if (kind == 2) {
       ++s_multi;
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
   for (int i = threadIdx.x; i < DENSE_CACHE; i += BLOCK)
     if (cache_cnt[i]) {
       atomicAdd(&out.dense_counts[cache_key[i]], cache_cnt[i]);
-      if (out.dense_first) atomicMin(&out.dense_first[cache_key[i]], rec_base + (u64)cache_min[i]);
+      if (out.dense_first) atomicMin(&out.dense_first[cache_key[i]], key_base + (u64)cache_min[i]);
     }
   if (threadIdx.x == 0) {
     if (blk_stats[0]) atomicAdd(&out.st->st_single, (u64)blk_stats[0]);
@@ -713,6 +714,90 @@ __global__ __launch_bounds__(BLOCK) void k_rec_dedup(const u32* __restrict__ str
   if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&st->n_list, (u64)blk_n);
   __syncthreads();
   if (is_owner) list[blk_base + my] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The distinct tuples of a run, kept ACROSS batches (MinCollector keeps O(#ECs), src/MinCollector.cpp:251-269: so do we).
+// After every batch its tuple records are absorbed into a persistent table -- k_rec_dedup's scheme: tag = 32 hash bits + where the
+// owner's record lies, one compare-and-swap elects the owner, equal contents add their count -- whose owners live in the tuple
+// STORE, a compact stream of distinct records only; a record that opens a new slot is compared against in the batch's own stream
+// until k_tup_store has moved it into the store (bit 31 of the tag's offset tells which of the two streams it refers to).  The
+// batch's record stream is then recycled: device memory no longer grows with the number of reads, only with the number of
+// distinct tuples.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr u64 TAG_LOCAL = 0x80000000ULL;   // the tag's offset refers to the batch's stream (the record is not in the store yet)
+__global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ batch, const u32* __restrict__ store, const u64* __restrict__ rec_off,
+                                                      const u64* __restrict__ idx, u64 n, TSlot* table, u64 mask, u64* list, u64 key_base, int track,
+                                                      u32 max_probe, u64* fail, DevState* st) {
+  __shared__ u32 blk_n, blk_words; __shared__ u64 blk_base;
+  if (threadIdx.x == 0) { blk_n = 0; blk_words = 0; }
+  __syncthreads();
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  bool is_owner = false; u64 s = 0; u32 my = 0, m = 0;
+  if (i < n) {
+    const u64 r = idx ? idx[i] : i;
+    const u64 off = rec_off[r];
+    if (off != ~0ULL && batch[off] != 0u) {
+      m = batch[off + 1];
+      const u64 h = rec_hash(batch + off + 1, m + 1, 1);
+      const u64 mine = (h & 0xFFFFFFFF00000000ULL) | TAG_LOCAL | (off + 1);   // off + 1 < 2^31 (checked by the host)
+      s = (h >> 1) & mask;
+      bool placed = false;
+      for (u32 probes = 0; probes < max_probe; probes++) {
+        const u64 old = atomicCAS(&table[s].tag, 0ULL, mine);
+        if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }
+        if ((old >> 32) == (mine >> 32)) {
+          const u32* o = ((old & TAG_LOCAL) ? batch : store) + ((old & 0x7FFFFFFFULL) - 1);
+          bool same = o[1] == m;
+          for (u32 j = 0; same && j < m; j++) same = o[2 + j] == batch[off + 2 + j];
+          if (same) { placed = true; break; }
+        }
+        s = (s + 1) & mask;
+      }
+      if (placed) {
+        atomicAdd(&table[s].count, (u64)batch[off]);
+        if (track) atomicMin(&table[s].first, key_base + r);   // first occurrence: record indices follow the input order
+      } else fail[atomicAdd(&st->tl_fail, 1ULL)] = r;
+    }
+  }
+  if (is_owner) { my = atomicAdd(&blk_n, 1u); atomicAdd(&blk_words, m + 2u); }
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_n) { blk_base = atomicAdd(&st->tl_n, (u64)blk_n); atomicAdd(&st->bound_words, (u64)blk_words); }
+  __syncthreads();
+  if (is_owner) list[blk_base + my] = s;
+}
+// the records that opened a slot in the last k_tup_absorb move from the batch's stream into the store
+__global__ __launch_bounds__(BLOCK) void k_tup_store(const u32* __restrict__ batch, u32* store, TSlot* table, const u64* __restrict__ list, u64 first_new,
+                                                     u64 n_new, DevState* st) {
+  __shared__ u32 wsum[BLOCK / 64]; __shared__ u64 blk_base;
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 s = 0, off = 0; u32 need = 0;
+  if (i < n_new) { s = list[first_new + i]; off = table[s].owner; need = batch[off + 1] + 2u; }
+  const u32 incl = wave_incl_scan(need);
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int j = 0; j < BLOCK / 64; j++) t += wsum[j]; blk_base = t ? atomicAdd(&st->ts_words, (u64)t) : 0ULL; }
+  __syncthreads();
+  if (i >= n_new) return;
+  u32 before = 0;
+  for (u32 j = 0; j < (threadIdx.x >> 6); j++) before += wsum[j];
+  const u64 dst = blk_base + before + incl - need;
+  for (u32 j = 0; j < need; j++) store[dst + j] = batch[off + j];
+  table[s].owner = dst;
+  table[s].tag = (table[s].tag & 0xFFFFFFFF00000000ULL) | (dst + 1);   // (dst + 1 < 2^31: checked by the host)
+}
+// a larger table: every distinct tuple (all of them in the store by now) takes a slot of the new one, the list follows
+__global__ void k_tup_rehash(const u32* __restrict__ store, const TSlot* __restrict__ old, TSlot* nu, u64 mask, u64* list, u64 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const TSlot o = old[list[i]];
+  const u32 m = store[o.owner + 1];
+  const u64 h = rec_hash(store + o.owner + 1, m + 1, 1);
+  const u64 tag = (h & 0xFFFFFFFF00000000ULL) | (o.owner + 1);
+  u64 s = (h >> 1) & mask;
+  while (atomicCAS(&nu[s].tag, 0ULL, tag) != 0ULL) s = (s + 1) & mask;
+  nu[s].owner = o.owner; nu[s].count = o.count; nu[s].first = o.first;
+  list[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2055,14 +2140,16 @@ struct kamd_ctx {
   struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0; bool valid = false; } fld_pending;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
-  u64 tcap = 0, ccap = 0;
+  u64 tcap = 0, ccap = 0;        // slots of the tuple table (persistent over the batches of a run) / the candidate table
+  DBuf tstore;                   // the tuple store: the distinct tuple records of the run, compact
+  bool ttable_clean = false;     // the tuple table holds no entries (just initialised)
+  u64 recs_total = 0;            // records (items) of the batches absorbed so far: first-occurrence keys
+  u64 multi_before = 0;          // st_multi before the current batch
   u64 n_distinct_tuples = 0;
-  bool tuples_counted = false;   // the tuple table reflects every record of the stream
-  u64 recs_counted = 0;
+  float last_absorb_ms = 0.f; hipEvent_t ev_ab0 = nullptr, ev_ab1 = nullptr;
   kamd_ec_result result{};
   bool finalized = false;
   u64 exp_words_done = 0;        // words of the explicit-set stream actually written
-  u64 tuple_bound = 0;           // upper bound of the number of tuple records in the stream (sizes the tuple table)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
   hipEvent_t ev2 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
@@ -2154,29 +2241,89 @@ int exclusive_scan(kamd_ctx* c, const u32* sizes, u64 n, u64* out, u64* d_total)
 
 u64 pow2_at_least(u64 x) { u64 p = 1024; while (p < x) p <<= 1; return p; }
 
-// bring the tuple table up to date with the stream: distinct tuples and their counts
-int count_tuples(kamd_ctx* c) {
-  const u64 n_recs = c->host_state.n_recs;
-  if (c->tuples_counted && c->recs_counted == n_recs) return 0;
-  // (re)build from scratch: the table is sized for the final record count
-  // A table for every record would be 2 x 21.7 M slots (2 GB, 0.3 ms to clear, every probe an HBM line) on config #3, where the
-  // records collapse to 2.0 M distinct tuples.  The single-launch form starts with a quarter of the records (64 MB per million
-  // slots: MALL-resident) and a probe limit; only if some record found no slot is the run repeated with four times the slots.
-  const u64 full = pow2_at_least(2 * std::min<u64>(n_recs, c->tuple_bound) + 16);
-  if (int rc = c->list.ensure((std::min<u64>(n_recs, c->tuple_bound) + 1) * sizeof(u64), 0, c->stream)) return rc;
-  u64 cap = c->tune.dedup_form != 1 ? std::min<u64>(full, pow2_at_least(std::min<u64>(n_recs, c->tuple_bound) / 4 + 16)) : full;
-  for (;;) {
-    c->tcap = cap;
+// forget the distinct tuples (a new run, or records about to be replaced by merged ones)
+int tuples_clear(kamd_ctx* c) {
+  if (c->tcap && !c->ttable_clean) {
+    hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
+    HIPC(hipGetLastError());
+    c->ttable_clean = true;
+  }
+  c->host_state.tl_n = 0; c->host_state.ts_words = 0; c->host_state.tl_fail = 0;
+  c->n_distinct_tuples = 0;
+  return 0;
+}
+// the tuple table with `cap` slots; the distinct tuples it held move over (all of them are in the store)
+int tuples_resize(kamd_ctx* c, u64 cap) {
+  const u64 n = c->host_state.tl_n;
+  DBuf nu;
+  if (int rc = nu.ensure(cap * sizeof(TSlot), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_table_init, dim3(grid_for(cap, BLOCK)), dim3(BLOCK), 0, c->stream, nu.as<TSlot>(), cap);
+  if (n) hipLaunchKernelGGL(k_tup_rehash, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, (const u32*)c->tstore.as<u32>(), (const TSlot*)c->ttable.as<TSlot>(),
+                            nu.as<TSlot>(), cap - 1, c->list.as<u64>(), n);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(c->stream));
+  c->ttable.release();
+  c->ttable = nu; c->tcap = cap; c->ttable_clean = n == 0;
+  return 0;
+}
+// Absorb the tuple records of one batch (records 0 .. n-1 of `batch` through rec_off; key_base + r = position of record r in the
+// run's input) into the persistent tuple table and store.  The table starts at a quarter of the first batch's records (on config #3
+// 21.7 M tuple records collapse to 2.0 M distinct tuples; a table for every record would be gigabytes to clear and to miss in),
+// is kept at most half full, and a record that finds no slot within 64 probes makes it grow before that record is tried again.
+int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 batch_words, u64 key_base, u64 n_tuple_bound) {
+  if (n == 0) return 0;
+  if (batch_words >= 0x7FFFFFF0ULL) return kamd::fail(-1, "kamd_pseudoalign: the record stream of one batch must stay below 2^31 words (use smaller batches)");
+  DevState* dst = (DevState*)c->state.p;
+  if (!c->ev_ab0) { HIPC(hipEventCreate(&c->ev_ab0)); HIPC(hipEventCreate(&c->ev_ab1)); }
+  HIPC(hipEventRecord(c->ev_ab0, c->stream));
+  const u64 bound = std::min(n, n_tuple_bound);
+  u64 want = pow2_at_least(std::max<u64>(bound / 4, 2 * c->host_state.tl_n) + 16);
+  if (c->tcap == 0) {
+    c->tcap = want;
     if (int rc = c->ttable.ensure(c->tcap * sizeof(TSlot), 0, c->stream)) return rc;
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(c->tcap, BLOCK)), dim3(BLOCK), 0, c->stream, c->ttable.as<TSlot>(), c->tcap);
-    const int rc = dedup_records(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), 0, n_recs, c->ttable.as<TSlot>(), c->tcap, c->rec_slot,
-                                 c->list.as<u64>(), c->track_order ? 1 : 0, nullptr, cap < full ? 64u : 0u, c->host_state.stream_words);
-    if (rc == 2 && cap < full) { cap = std::min<u64>(full, cap * 4); continue; }
-    if (rc) return rc == 2 ? kamd::fail(-101, "dedup_records: table full") : rc;
-    break;
+    c->ttable_clean = true;
+  } else if (2 * c->host_state.tl_n + 16 > c->tcap) {
+    if (int rc = tuples_resize(c, pow2_at_least(4 * c->host_state.tl_n + 16))) return rc;
   }
-  c->n_distinct_tuples = c->host_state.n_list;
-  c->tuples_counted = true; c->recs_counted = n_recs;
+  if (int rc = c->list.ensure((c->host_state.tl_n + bound + 1) * sizeof(u64), c->host_state.tl_n * sizeof(u64), c->stream)) return rc;
+  if (int rc = c->retry.ensure(2 * (bound + 1) * sizeof(u64), 0, c->stream)) return rc;
+  u64* fail_a = c->retry.as<u64>();
+  u64* fail_b = fail_a + bound + 1;
+  const u64* idx = nullptr;
+  u64 count = n;
+  for (int round = 0; count; round++) {
+    if (round > 40) return kamd::fail(-101, "absorb_tuples: the tuple table does not settle");
+    const u64 tl_before = c->host_state.tl_n;
+    c->host_state.tl_fail = 0; c->host_state.bound_words = 0;
+    if (int rc = push_state(c)) return rc;
+    hipLaunchKernelGGL(k_tup_absorb, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), rec_off, idx, count,
+                       c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base, c->track_order ? 1 : 0, 64u, fail_a, dst);
+    HIPC(hipGetLastError());
+    c->ttable_clean = false;
+    if (int rc = sync_state(c)) return rc;
+    const u64 n_new = c->host_state.tl_n - tl_before, new_words = c->host_state.bound_words;
+    if (n_new) {
+      if (c->host_state.ts_words + new_words >= 0x7FFFFFF0ULL) return kamd::fail(-101, "absorb_tuples: more than 2^31 words of distinct tuples");
+      if (int rc = c->tstore.ensure((c->host_state.ts_words + new_words + 2) * sizeof(u32), c->host_state.ts_words * sizeof(u32), c->stream)) return rc;
+      hipLaunchKernelGGL(k_tup_store, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, c->stream, batch, c->tstore.as<u32>(), c->ttable.as<TSlot>(),
+                         (const u64*)c->list.as<u64>(), tl_before, n_new, dst);
+      HIPC(hipGetLastError());
+      c->host_state.ts_words += new_words;   // (k_tup_store advances the device copy by the same amount)
+    }
+    count = c->host_state.tl_fail;
+    if (count) {   // some records found no slot: a table four times the size, then those records again
+      if (int rc = tuples_resize(c, c->tcap * 4)) return rc;
+      std::swap(fail_a, fail_b);
+      idx = fail_b;
+    }
+  }
+  c->n_distinct_tuples = c->host_state.tl_n;
+  HIPC(hipEventRecord(c->ev_ab1, c->stream));
+  HIPC(hipEventSynchronize(c->ev_ab1));
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, c->ev_ab0, c->ev_ab1));
+  c->last_absorb_ms += ms;
   return 0;
 }
 
@@ -2291,6 +2438,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev2) (void)hipEventDestroy(c->ev2);
   if (c->ev_fin0) (void)hipEventDestroy(c->ev_fin0);
   if (c->ev_fin1) (void)hipEventDestroy(c->ev_fin1);
+  if (c->ev_ab0) (void)hipEventDestroy(c->ev_ab0);
+  if (c->ev_ab1) (void)hipEventDestroy(c->ev_ab1);
   if (c->em_stream) (void)hipStreamDestroy(c->em_stream);
   if (c->em_side_stream) { (void)hipStreamSynchronize(c->em_side_stream); (void)hipStreamDestroy(c->em_side_stream); }
   if (c->em_ev_fork) (void)hipEventDestroy(c->em_ev_fork);
@@ -2303,7 +2452,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->sell_cache) sell_cache_free(c->sell_cache);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
-                  &c->retry, &c->ttable, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
+                  &c->retry, &c->ttable, &c->tstore, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
@@ -2357,7 +2506,8 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   if (int rc = c->dense_first.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u64), 0, c->stream)) return rc;
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(v.n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->exp_words_done = 0; c->tuple_bound = 0;
+  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f;
+  if (int rc = tuples_clear(c)) return rc;
   return push_state(c);
 }
 
@@ -2367,7 +2517,8 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(c->n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->tuples_counted = false; c->finalized = false; c->recs_counted = 0; c->n_distinct_tuples = 0; c->exp_words_done = 0; c->tuple_bound = 0;
+  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f;
+  if (int rc = tuples_clear(c)) return rc;
   c->had_overflow_items = false;
   c->fq_batch_reads = 0; c->fq_batch_max_len = 0; c->fq_batch_files = 0;   // (units parsed but never packed belong to the abandoned run)
   return push_state(c);
@@ -2490,13 +2641,14 @@ int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   constexpr int WAVES = BLOCK / 64;
   const int lane_words = seq_words * (PAIRED ? 2 : 1);
   const int stride = 2 + V3_LIST_CAP + (FILTER ? 4 : 0);
-  // every item owns a fixed slot of the stream: raw record from k_match_v3, rewritten in place by k_classify
-  const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
-  if (int rc = c->stream_buf.ensure((cur_words + n_items * (u64)stride) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
-  if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
+  // every item owns a fixed slot of the batch's record stream: raw record from k_match_v3, rewritten in place by k_classify.  The
+  // stream belongs to this batch only (absorb_tuples moves what is new into the tuple store afterwards)
+  const u64 cur_words = 0, cur_recs = 0;
+  if (int rc = c->stream_buf.ensure(n_items * (u64)stride * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->rec_off.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
   out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-  c->host_state.stream_words = cur_words + n_items * (u64)stride;
-  c->host_state.n_recs = cur_recs + n_items;
+  c->host_state.stream_words = n_items * (u64)stride;
+  c->host_state.n_recs = n_items;
   if (int rc = push_state(c)) return rc;
   size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * V3_LIST_CAP) * sizeof(u32);
   // diagnostic: unused LDS per block lowers the number of resident wavefronts (occupancy sensitivity; room for another stream's kernels)
@@ -2523,7 +2675,7 @@ int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 
   HIPC(hipEventRecord(c->ev1, c->stream));
   const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
   hipLaunchKernelGGL((k_classify<PAIRED, FILTER, V3_LIST_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
-                     fd, out);
+                     c->recs_total, fd, out);
   HIPC(hipEventRecord(c->ev2, c->stream));
   return 0;
 }
@@ -2559,10 +2711,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   FilterDev fd{o->single_overhang, o->fld != 0.0 ? 1 : 0, 0, o->strand, c->ix.comprehensive};
   if (fd.has_mean_fl) fd.fl = (int)o->fld;  // (int) tc.get_mean_frag_len() (ProcessReads.cpp:1098)
   const bool filter = fd.strand != 0 || (!fd.single_overhang && fd.has_mean_fl);
-  // capacity for the worst case of this batch
-  const u64 cur_words = c->host_state.stream_words, cur_recs = c->host_state.n_recs;
-  if (int rc = c->stream_buf.ensure((cur_words + n_items * (TUPLE_CAP + 2)) * sizeof(u32), cur_words * sizeof(u32), c->stream)) return rc;
-  if (int rc = c->rec_off.ensure((cur_recs + n_items) * sizeof(u64), cur_recs * sizeof(u64), c->stream)) return rc;
+  // capacity for the worst case of this batch (its record stream is recycled from batch to batch)
+  const u64 key_base = c->recs_total;   // position of the batch's first item in the run's input (first-occurrence keys)
+  if (int rc = c->stream_buf.ensure(n_items * (TUPLE_CAP + 2) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->rec_off.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = c->overflow_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
   if (filter) {
     if (int rc = c->explicit_items.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
@@ -2588,7 +2740,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
     out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-    const u64 ov_base = cur_recs;
+    const u64 ov_base = 0;   // (record indices of the batch)
     if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
                      else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
     else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
@@ -2616,10 +2768,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
       const u64* items = big ? c->explicit_items_big.as<u64>() : c->explicit_items.as<u64>();
       if (o->paired) hipLaunchKernelGGL(k_explicit_write<true>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
                                         seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(),
-                                        c->exp_off.as<u64>(), exp_key, cur_recs, 1ULL, (DevState*)c->state.p);
+                                        c->exp_off.as<u64>(), exp_key, key_base, 1ULL, (DevState*)c->state.p);
       else hipLaunchKernelGGL(k_explicit_write<false>, dim3(grid_for(n, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len, items, n,
                               seq_words, rec_words, c->exp_scratch.as<u32>(), cap, fd, c->exp_stream.as<u32>(), c->exp_off.as<u64>(),
-                              exp_key, cur_recs, 1ULL, (DevState*)c->state.p);
+                              exp_key, key_base, 1ULL, (DevState*)c->state.p);
       HIPC(hipGetLastError());
       HIPC(hipStreamSynchronize(c->stream));  // exp_scratch is reused by the second launch
     }
@@ -2629,8 +2781,12 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     c->host_state.n_explicit = 0; c->host_state.n_explicit_big = 0;
     if (int rc2 = push_state(c)) return rc2;
   }
-  c->tuple_bound = c->host_state.st_multi;
-  c->tuples_counted = false; c->finalized = false;
+  // the batch's tuple records join the distinct tuples of the run; its record stream is free again
+  if (int rc2 = absorb_tuples(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->host_state.n_recs, c->host_state.stream_words, key_base,
+                              c->host_state.st_multi - c->multi_before)) return rc2;
+  c->multi_before = c->host_state.st_multi;
+  c->recs_total += n_items;
+  c->finalized = false;
   return 0;
 }
 
@@ -2792,11 +2948,10 @@ extern "C" int kamd_ec_tuples_export(kamd_ctx* c, uint64_t* n_words, uint64_t* n
   if (!c || !n_words || !n_tuples) return kamd::fail(-1, "kamd_ec_tuples_export: null argument");
   HIPC(hipSetDevice(c->device));
   if (int rc = sync_state(c)) return rc;
-  if (int rc = count_tuples(c)) return rc;
   c->host_state.bound_words = 0;
   if (int rc = push_state(c)) return rc;
   const u64 n = c->n_distinct_tuples;
-  if (n) hipLaunchKernelGGL(k_tuple_export_size, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->stream_buf.as<u32>(),
+  if (n) hipLaunchKernelGGL(k_tuple_export_size, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->tstore.as<u32>(),
                             c->ttable.as<TSlot>(), c->list.as<u64>(), n, (DevState*)c->state.p);
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
@@ -2809,7 +2964,7 @@ extern "C" int kamd_ec_tuples_copy(kamd_ctx* c, uint32_t* d_out_words, uint64_t*
   const u64 n = c->n_distinct_tuples;
   c->host_state.cand_words = 0; c->host_state.cand_recs = 0;
   if (int rc = push_state(c)) return rc;
-  if (n) hipLaunchKernelGGL(k_tuple_export_offsets, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->stream_buf.as<u32>(),
+  if (n) hipLaunchKernelGGL(k_tuple_export_offsets, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, c->stream, c->tstore.as<u32>(),
                             c->ttable.as<TSlot>(), c->list.as<u64>(), n, d_out_words, (u64*)d_out_rec_off, (DevState*)c->state.p);
   HIPC(hipGetLastError());
   return sync_state(c);
@@ -2820,15 +2975,13 @@ extern "C" int kamd_ec_tuples_replace(kamd_ctx* c, const uint32_t* d_words, uint
   if (c->track_order) return kamd::fail(-1, "kamd_ec_tuples_replace: merged records have no input order (kamd_ec_track_order is on)");
   HIPC(hipSetDevice(c->device));
   if (int rc = sync_state(c)) return rc;
-  if (int rc = c->stream_buf.ensure(std::max<u64>(n_words, 1) * sizeof(u32), 0, c->stream)) return rc;
-  if (int rc = c->rec_off.ensure((n_recs + 1) * sizeof(u64), 0, c->stream)) return rc;
-  if (n_words) HIPC(hipMemcpyAsync(c->stream_buf.p, d_words, n_words * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
-  if (n_recs) HIPC(hipMemcpyAsync(c->rec_off.p, d_rec_off, n_recs * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-  c->host_state.stream_words = n_words; c->host_state.n_recs = n_recs;
-  c->tuple_bound = n_recs;
+  // the distinct tuples of this rank give way to the records of all ranks: a fresh table, the gathered records absorbed as one batch
+  // (d_words / d_rec_off are only read)
+  if (int rc = tuples_clear(c)) return rc;
+  if (int rc = push_state(c)) return rc;
   c->had_overflow_items = true;   // gathered records may hold another rank's long tuples (k_resolve_union's cursor scratch)
-  c->tuples_counted = false; c->finalized = false;
-  return push_state(c);
+  c->finalized = false;
+  return absorb_tuples(c, d_words, (const u64*)d_rec_off, n_recs, n_words, 0, n_recs);
 }
 
 // explicit transcript-set records (positional filters): plain copies, the records are content-keyed
@@ -2877,9 +3030,8 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   if (!c->ev_fin0) { HIPC(hipEventCreate(&c->ev_fin0)); HIPC(hipEventCreate(&c->ev_fin1)); }
   HIPC(hipEventRecord(c->ev_fin0, c->stream));
   if (int rc = sync_state(c)) return rc;
-  if (int rc = count_tuples(c)) return rc;
   DevState* dst = (DevState*)c->state.p;
-  const u64 n_t = c->n_distinct_tuples;
+  const u64 n_t = c->n_distinct_tuples;   // (the batches' tuple records were absorbed as they came: absorb_tuples)
   // size bound of the candidate stream
   c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0;
   if (int rc = push_state(c)) return rc;
@@ -2887,7 +3039,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   if (int rc = c->tup_bound.ensure((n_t + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->tup_off.ensure((n_t + 2) * sizeof(u64), 0, c->stream)) return rc;
   if (n_t) {
-    hipLaunchKernelGGL(k_bound_tuples, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+    hipLaunchKernelGGL(k_bound_tuples, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
                        c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_bound.as<u32>(), dst);
     if (int rc = exclusive_scan(c, c->tup_bound.as<u32>(), n_t, c->tup_off.as<u64>(), c->tup_off.as<u64>() + n_t)) return rc;
   }
@@ -2908,10 +3060,10 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
     // (cursors for tuples longer than TUPLE_CAP: only the overflow kernel produces them, so the buffer is sized when it ran)
     const bool big = c->had_overflow_items;
     if (big) if (int rc = c->overflow_scratch.ensure(n_t * (u64)TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc;
-    hipLaunchKernelGGL(k_resolve_union, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+    hipLaunchKernelGGL(k_resolve_union, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
                        c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
                        cand_key, big ? c->overflow_scratch.as<u32>() : nullptr, dst);
-  } else if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->stream_buf.as<u32>(),
+  } else if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
                               c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
                               cand_key, dst);
   HIPC(hipGetLastError());
@@ -2980,7 +3132,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   HIPC(hipEventRecord(c->ev_fin1, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   HIPC(hipEventElapsedTime(&c->last_finalize_ms, c->ev_fin0, c->ev_fin1));
-  c->last_fin_records = c->host_state.n_recs; c->last_fin_stream_words = c->host_state.stream_words; c->last_fin_cand_words = c->host_state.cand_words;
+  c->last_fin_records = n_t; c->last_fin_stream_words = c->host_state.ts_words; c->last_fin_cand_words = c->host_state.cand_words;
   ++c->ec_generation;
   c->result.n_ecs = n_final; c->result.nnz = nnz;
   c->result.d_ec_off = c->ec_off.as<uint64_t>(); c->result.d_ec_ids = c->ec_ids.as<u32>(); c->result.d_counts = c->ec_counts.as<u32>();
@@ -4342,6 +4494,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_em_k = c->last_em_k; p->last_em_grid = c->last_em_grid; p->last_em_lds = c->last_em_lds; p->last_em_plan_cached = c->last_em_plan_cached;
   p->last_finalize_ms = c->last_finalize_ms; p->last_fin_records = c->last_fin_records; p->last_fin_stream_words = c->last_fin_stream_words;
   p->last_fin_cand_words = c->last_fin_cand_words;
+  p->absorb_ms = c->last_absorb_ms; p->n_distinct_tuples = c->n_distinct_tuples; p->tuple_store_words = c->host_state.ts_words; p->tuple_table_slots = c->tcap;
   return 0;
 }
 

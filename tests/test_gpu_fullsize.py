@@ -127,3 +127,4 @@ def test_prefix_against_reference(world):
     assert rep["est_counts_max_rel_err_tpm_ge_1e-3"] <= 1e-4 and rep["tpm_max_rel_err_tpm_ge_1e-3"] <= 1e-4, rep
     assert rep["tpm_max_abs_err_below_floor"] <= 1e-7 and rep["zero_pattern_equal"], rep
     assert rep["ok"]
+

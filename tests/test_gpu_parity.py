@@ -386,3 +386,42 @@ def test_long_reads(paired, n_join, ka, ctxs):
     res = O.process_reads(O.Index(idx_path), O.Opts(paired, 0.0 if paired else 200.0, 0.0 if paired else 20.0, 1, 0, 0, 0), buf, off, ln)
     want = {tuple(res.ec_ids[res.ec_off[i]:res.ec_off[i + 1]].tolist()): int(res.counts[i]) for i in range(len(res.counts)) if res.counts[i]}
     assert ecs.multiset() == want and len(want) > 0
+
+
+def test_ec_state_is_bounded_by_the_distinct_classes(ka):
+    """The per-item records of a batch are recycled: after every kamd_pseudoalign only the distinct tuples stay (MinCollector keeps
+    O(#ECs), src/MinCollector.cpp:251-269).  The same batch fed 20 times: the tuple table, the tuple store and the device memory in
+    use stop growing after the first batch, the ECs are 20 x those of one batch, and a run in one batch gives the same multiset."""
+    import torch
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    index = ka.Index(idx_path)
+    ctx = ka.Context(0)
+    try:
+        ctx.upload(index)
+        reads = common.interleave(r1, r2)
+        words, lens, max_len = ctx.pack_reads_host(reads)
+        opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
+        n = len(r1)
+        ctx.reset()
+        ctx.pseudoalign(opts, words, lens, n, max_len)
+        one = ctx.finalize(download=True).multiset()
+        ctx.reset()
+        seen = []
+        for i in range(20):
+            ctx.pseudoalign(opts, words, lens, n, max_len)
+            torch.cuda.synchronize()
+            p = ctx.profile()
+            seen.append((p["n_distinct_tuples"], p["tuple_store_words"], p["tuple_table_slots"], torch.cuda.mem_get_info(0)[0]))
+        assert len({s[:3] for s in seen}) == 1, seen          # distinct tuples, store, table: the same after every batch
+        assert len({s[3] for s in seen[1:]}) == 1, seen       # free device memory: constant from the second batch on
+        many = ctx.finalize(download=True).multiset()
+        assert many == {k: 20 * v for k, v in one.items()}
+        # different batches one after the other == the same reads in one batch (the table grows, tuples move to the store)
+        ctx.reset()
+        rec = ka.packed_record_words(max_len)
+        cuts = [0, n // 7, n // 3, n // 2 + 1, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.pseudoalign(opts, words[a * 2 * rec:b * 2 * rec], lens[2 * a:2 * b], b - a, max_len)
+        assert ctx.finalize(download=True).multiset() == one
+    finally:
+        ctx.close()

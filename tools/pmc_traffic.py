@@ -55,7 +55,7 @@ def main():
         k.startswith("k_pm_cols_fix") or k.startswith("k_em_rows") or k.startswith("k_em_seg") or k.startswith("k_em_final") or \
         k.startswith("k_em_sell") or k.startswith("k_em_local")
     em_kb = kb(em_pred)
-    fin_pred = lambda k: k.startswith("k_rec_dedup") or k.startswith("k_rec_insert") or k.startswith("k_rec_verify") or k.startswith("k_bound_") or k.startswith("k_resolve") or \
+    fin_pred = lambda k: k.startswith("k_tup_") or k.startswith("k_rec_dedup") or k.startswith("k_rec_insert") or k.startswith("k_rec_verify") or k.startswith("k_bound_") or k.startswith("k_resolve") or \
         k.startswith("k_cand_singles") or k.startswith("k_final_") or k.startswith("k_table_init") or k.startswith("k_scan_")
     fin_kb = kb(fin_pred)
     calls = res["fetch"][1]
