@@ -84,7 +84,7 @@ struct FilterDev { int single_overhang, has_mean_fl, fl, strand, comprehensive; 
 // device-resident cursors and statistics
 struct DevState {
   u64 stream_words, n_recs, n_overflow, n_retry;
-  u64 st_processed, st_single, st_multi, st_probes, st_bucket_reads, st_raw_words, st_text_hits, st_wave_iters, st_lane_iters;
+  u64 st_processed, st_single, st_multi;
   u64 n_list, bound_words;       // generic append cursor / size bound accumulator
   u64 n_explicit, n_explicit_big; // items whose set was changed by a positional filter (from the main / overflow kernel)
   u64 n_hit_overflow;            // explicit-set pass: reads whose hits touched more than EXPLICIT_HITS blocks
@@ -92,6 +92,9 @@ struct DevState {
   u64 cand_words, cand_recs;     // candidate transcript-set stream
   u64 tl_n, ts_words, tl_fail;   // distinct tuples so far (entries of the tuple list), words of the tuple store, records of a batch that found no slot
 };
+
+// counters of kernel A (their own struct: chunks of kernel A run on one stream while another copies DevState to and fro)
+struct DevStatsA { u64 probes, bucket_reads, raw_words, text_hits, wave_iters, lane_iters; };
 
 struct TSlot { u64 tag, owner, count, first; };  // first: smallest first-occurrence key of the merged records (candidate table)
 
@@ -272,7 +275,7 @@ constexpr int V3_LIST_CAP = 8;
 template <bool PAIRED, bool FILTER, bool DL, bool TEXT>
 __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                     u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
-                                                    u32* raw, int raw_stride, DevState* st) {
+                                                    u32* raw, int raw_stride, DevStatsA* st) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   constexpr int WAVES = BLOCK / 64;
   constexpr int NM = PAIRED ? 2 : 1;
@@ -405,9 +408,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
   }
   const u64 s_probes = wave_sum64((u64)probes), s_reads = wave_sum64((u64)breads), s_raw = wave_sum64((u64)raw_words), s_text = wave_sum64((u64)text_hits);
   if (lane == 0) {
-    atomicAdd(&st->st_probes, s_probes); atomicAdd(&st->st_bucket_reads, s_reads); atomicAdd(&st->st_raw_words, s_raw);
-    if (s_text) atomicAdd(&st->st_text_hits, s_text);
-    atomicAdd(&st->st_wave_iters, (u64)wave_iters); atomicAdd(&st->st_lane_iters, (u64)lane_iters);
+    atomicAdd(&st->probes, s_probes); atomicAdd(&st->bucket_reads, s_reads); atomicAdd(&st->raw_words, s_raw);
+    if (s_text) atomicAdd(&st->text_hits, s_text);
+    atomicAdd(&st->wave_iters, (u64)wave_iters); atomicAdd(&st->lane_iters, (u64)lane_iters);
   }
 }
 
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
 constexpr int DENSE_CACHE = 2048;
 template <bool PAIRED, bool FILTER, int CAP>   // CAP: class entries of a raw record (12: kernel A v2, 8: v3)
 __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict__ slots, int stride, u64 n_items, u64 slot_base,
-                                                    u64 rec_base, u64 key_base, FilterDev fd, AlignOut out) {
+                                                    u64 rec_base, u64 key_base, u64 item_base, FilterDev fd, AlignOut out) {
   __shared__ u32 lds_ecs[BLOCK * CAP];
   __shared__ u32 cache_key[DENSE_CACHE];
   __shared__ u32 cache_cnt[DENSE_CACHE];
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
       else if (oc == 2) {
         kind = 4;
         const u64 k = atomicAdd(&out.st->n_explicit, 1ULL);
-        out.explicit_items[k] = item;
+        out.explicit_items[k] = item_base + item;
         atomicAdd(&out.st->exp_words, (u64)kept + 2);
       }
     }
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     }
     r[0] = kind == 2 ? 1u : 0u;  // record count: 0 = not a tuple record (skipped by the de-duplication)
     out.rec_off[rec_base + item] = slot_base + item * (u64)stride;
-    if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item; }
+    if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item_base + item; }
   }
   // flush: block-level statistics and the cached single-set counts
   const u64 w_single = wave_sum64((u64)s_single), w_multi = wave_sum64((u64)s_multi), w_proc = wave_sum64((u64)s_proc);
@@ -2152,7 +2155,9 @@ struct kamd_ctx {
   u64 exp_words_done = 0;        // words of the explicit-set stream actually written
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_align_ms = 0.f, last_em_ms = 0.f, last_classify_ms = 0.f;
-  hipEvent_t ev2 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
+  hipEvent_t ev2 = nullptr, ev3 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
+  DBuf stats_a;                  // DevStatsA: kernel A's counters
+  hipStream_t al_stream = nullptr; hipEvent_t al_ev_in = nullptr, al_ev_out = nullptr; std::vector<hipEvent_t> al_ev_chunk;   // kamd_pseudoalign's side stream (WorkStream)
   float last_finalize_ms = 0.f; u64 last_fin_records = 0, last_fin_stream_words = 0, last_fin_cand_words = 0;
   hipStream_t em_stream = nullptr;
   hipStream_t em_side_stream = nullptr; hipEvent_t em_ev_fork = nullptr, em_ev_join = nullptr;   // component-local EM: the small size class runs beside the large one
@@ -2270,7 +2275,9 @@ int tuples_resize(kamd_ctx* c, u64 cap) {
 // run's input) into the persistent tuple table and store.  The table starts at a quarter of the first batch's records (on config #3
 // 21.7 M tuple records collapse to 2.0 M distinct tuples; a table for every record would be gigabytes to clear and to miss in),
 // is kept at most half full, and a record that finds no slot within 64 probes makes it grow before that record is tried again.
-int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 batch_words, u64 key_base, u64 n_tuple_bound) {
+// first_idx (device, optional): the records to look at are rec_off[first_idx[0 .. n-1]] instead of rec_off[0 .. n-1]
+int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 batch_words, u64 key_base, u64 n_tuple_bound,
+                  const u64* first_idx = nullptr) {
   if (n == 0) return 0;
   if (batch_words >= 0x7FFFFFF0ULL) return kamd::fail(-1, "kamd_pseudoalign: the record stream of one batch must stay below 2^31 words (use smaller batches)");
   DevState* dst = (DevState*)c->state.p;
@@ -2290,7 +2297,7 @@ int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 
   if (int rc = c->retry.ensure(2 * (bound + 1) * sizeof(u64), 0, c->stream)) return rc;
   u64* fail_a = c->retry.as<u64>();
   u64* fail_b = fail_a + bound + 1;
-  const u64* idx = nullptr;
+  const u64* idx = first_idx;
   u64 count = n;
   for (int round = 0; count; round++) {
     if (round > 40) return kamd::fail(-101, "absorb_tuples: the tuple table does not settle");
@@ -2335,7 +2342,7 @@ void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
   t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
-  t->em_fin_blocks = 1024; t->dedup_form = 2;
+  t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
@@ -2354,6 +2361,7 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.em_graph == 1 || n.em_graph == 2) t->em_graph = n.em_graph;
   if (n.em_row_lanes == 2 || n.em_row_lanes == 4 || n.em_row_lanes == 8) t->em_row_lanes = n.em_row_lanes;
   if (n.em_fin_blocks >= 64) t->em_fin_blocks = n.em_fin_blocks;
+  if (n.align_chunks != 0) t->align_chunks = n.align_chunks < 0 ? -1 : std::min(n.align_chunks, 64);
 }
 // experiments: the same knobs from the environment, read once when a context is created
 void tuning_from_env(kamd_tuning* t) {
@@ -2378,6 +2386,7 @@ void tuning_from_env(kamd_tuning* t) {
   onoff("KAMD_EM_GRAPH", &n.em_graph);
   geti("KAMD_EM_ROW_LANES", &n.em_row_lanes);
   geti("KAMD_EM_FIN_BLOCKS", &n.em_fin_blocks);
+  geti("KAMD_ALIGN_CHUNKS", &n.align_chunks);
   tuning_merge(t, n);
 }
 // the options of the run that the per-item logic reads from the device index
@@ -2408,7 +2417,8 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (c->state.ensure(sizeof(DevState), 0, c->stream)) { delete c; return -100; }
   memset(&c->host_state, 0, sizeof c->host_state);
   if (push_state(c)) { delete c; return -100; }
-  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) { delete c; return kamd::fail(-100, "hipEventCreate failed"); }
+  if (c->stats_a.ensure(sizeof(DevStatsA), 0, c->stream) || hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream) != hipSuccess) { delete c; return -100; }
   tuning_defaults(&c->tune);
   tuning_from_env(&c->tune);
   apply_tuning(c);
@@ -2436,6 +2446,11 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev3) (void)hipEventDestroy(c->ev3);
+  if (c->al_stream) { (void)hipStreamSynchronize(c->al_stream); (void)hipStreamDestroy(c->al_stream); }
+  if (c->al_ev_in) (void)hipEventDestroy(c->al_ev_in);
+  if (c->al_ev_out) (void)hipEventDestroy(c->al_ev_out);
+  for (hipEvent_t e : c->al_ev_chunk) if (e) (void)hipEventDestroy(e);
   if (c->ev_fin0) (void)hipEventDestroy(c->ev_fin0);
   if (c->ev_fin1) (void)hipEventDestroy(c->ev_fin1);
   if (c->ev_ab0) (void)hipEventDestroy(c->ev_ab0);
@@ -2452,7 +2467,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->sell_cache) sell_cache_free(c->sell_cache);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
-                  &c->retry, &c->ttable, &c->tstore, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
+                  &c->retry, &c->ttable, &c->tstore, &c->stats_a, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
@@ -2508,6 +2523,7 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   memset(&c->host_state, 0, sizeof c->host_state);
   c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f;
   if (int rc = tuples_clear(c)) return rc;
+  HIPC(hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream));
   return push_state(c);
 }
 
@@ -2519,6 +2535,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   memset(&c->host_state, 0, sizeof c->host_state);
   c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f;
   if (int rc = tuples_clear(c)) return rc;
+  HIPC(hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream));
   c->had_overflow_items = false;
   c->fq_batch_reads = 0; c->fq_batch_max_len = 0; c->fq_batch_files = 0;   // (units parsed but never packed belong to the abandoned run)
   return push_state(c);
@@ -2635,48 +2652,114 @@ __global__ void k_mark_overflow(u32* raw, int raw_stride, u64 n_items) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_items) raw[i * (u64)raw_stride] = RAW_OVERFLOW;
 }
+// Kernel A of items [first, first + n) of the batch, on stream s: raw records into the items' slots
 template <bool PAIRED, bool FILTER>
-int launch_align_v3(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
-                    AlignOut& out) {
+int launch_match_chunk(kamd_ctx* c, hipStream_t s, const u32* d_words, const uint16_t* d_len, u64 first, u64 n, int seq_words, int rec_words, u32* slots,
+                       int stride) {
   constexpr int WAVES = BLOCK / 64;
-  const int lane_words = seq_words * (PAIRED ? 2 : 1);
-  const int stride = 2 + V3_LIST_CAP + (FILTER ? 4 : 0);
-  // every item owns a fixed slot of the batch's record stream: raw record from k_match_v3, rewritten in place by k_classify.  The
-  // stream belongs to this batch only (absorb_tuples moves what is new into the tuple store afterwards)
-  const u64 cur_words = 0, cur_recs = 0;
-  if (int rc = c->stream_buf.ensure(n_items * (u64)stride * sizeof(u32), 0, c->stream)) return rc;
-  if (int rc = c->rec_off.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
-  out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
-  c->host_state.stream_words = n_items * (u64)stride;
-  c->host_state.n_recs = n_items;
-  if (int rc = push_state(c)) return rc;
+  constexpr int NM = PAIRED ? 2 : 1;
+  const int lane_words = seq_words * NM;
   size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * V3_LIST_CAP) * sizeof(u32);
   // diagnostic: unused LDS per block lowers the number of resident wavefronts (occupancy sensitivity; room for another stream's kernels)
   if (c->tune.lds_pad > 0 && lds_bytes <= 64 * 1024) lds_bytes = std::min<size_t>(64 * 1024, lds_bytes + (size_t)c->tune.lds_pad);
-  const u64 n_waves = (n_items + c->items_per_wave - 1) / c->items_per_wave;
-  u32* slots = c->stream_buf.as<u32>() + cur_words;
-  HIPC(hipEventRecord(c->ev0, c->stream));
+  const u64 n_waves = (n + c->items_per_wave - 1) / c->items_per_wave;
+  const u32* w = d_words + first * (u64)(rec_words * NM);
+  const uint16_t* l = d_len + first * NM;
+  u32* raw = slots + first * (u64)stride;
   if (lds_bytes > 64 * 1024) {
     // reads of more than ~480 bases (pairs) / ~980 (single): the kernel would hold too few wavefronts per CU (or none: the
     // CU has 160 KB) -- the reference has no length limit, so such batches take the HBM-resident path item by item
-    hipLaunchKernelGGL(k_mark_overflow, dim3(grid_for(n_items, BLOCK)), dim3(BLOCK), 0, c->stream, slots, stride, n_items);
+    hipLaunchKernelGGL(k_mark_overflow, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, raw, stride, n);
   } else {
 #define KAMD_LAUNCH_V3(DLV, TXT)                                                                                                         \
   do {                                                                                                                                  \
     HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, \
-                       d_len, n_items, seq_words, rec_words, c->items_per_wave, c->refill_min, slots, stride, (DevState*)c->state.p);  \
+    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, s, c->ix, w, l, n, seq_words, \
+                       rec_words, c->items_per_wave, c->refill_min, raw, stride, c->stats_a.as<DevStatsA>());                           \
   } while (0)
     const bool dl = c->ix.n_dbuckets != 0, txt = c->tune.text_verify == 1;
     if (dl) { if (txt) KAMD_LAUNCH_V3(true, true); else KAMD_LAUNCH_V3(true, false); }
     else { if (txt) KAMD_LAUNCH_V3(false, true); else KAMD_LAUNCH_V3(false, false); }
 #undef KAMD_LAUNCH_V3
   }
-  HIPC(hipEventRecord(c->ev1, c->stream));
-  const unsigned grid = (unsigned)std::min<u64>(grid_for(n_items, BLOCK), 256 * 6);
-  hipLaunchKernelGGL((k_classify<PAIRED, FILTER, V3_LIST_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots, stride, n_items, cur_words, cur_recs,
-                     c->recs_total, fd, out);
-  HIPC(hipEventRecord(c->ev2, c->stream));
+  HIPC(hipGetLastError());
+  return 0;
+}
+// While a batch is processed the context's work stream may be a side stream: kernel A's chunks run on the caller's stream, everything
+// that follows a chunk (classification, de-duplication, and the host synchronisations between them) on the side stream, so that
+// chunk k + 1 is matched while chunk k is classified and absorbed -- kernel A is bound by memory requests, the rest by atomics and
+// dependent gathers, and the two overlap well.  Leaving the scope joins the side stream back into the caller's.
+struct WorkStream {
+  kamd_ctx* c; hipStream_t user; bool swapped = false;
+  explicit WorkStream(kamd_ctx* ctx) : c(ctx), user(ctx->stream) {}
+  int fork() {
+    if (!c->al_stream) {
+      HIPC(hipStreamCreateWithFlags(&c->al_stream, hipStreamNonBlocking));
+      HIPC(hipEventCreateWithFlags(&c->al_ev_in, hipEventDisableTiming));
+      HIPC(hipEventCreateWithFlags(&c->al_ev_out, hipEventDisableTiming));
+    }
+    HIPC(hipEventRecord(c->al_ev_in, user));
+    HIPC(hipStreamWaitEvent(c->al_stream, c->al_ev_in, 0));
+    c->stream = c->al_stream; swapped = true;
+    return 0;
+  }
+  ~WorkStream() {
+    if (!swapped) return;
+    (void)hipEventRecord(c->al_ev_out, c->al_stream);
+    (void)hipStreamWaitEvent(user, c->al_ev_out, 0);
+    c->stream = user;
+  }
+};
+// One batch: kernel A in `chunks` launches on the caller's stream, every chunk classified and its tuple records absorbed as soon as
+// it is matched.  On return every item that is neither an overflow item nor one a positional filter changed is accounted for.
+template <bool PAIRED, bool FILTER>
+int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
+                AlignOut& out, u64 key_base) {
+  const int stride = 2 + V3_LIST_CAP + (FILTER ? 4 : 0);
+  // every item owns a fixed slot of the batch's record stream: raw record from k_match_v3, rewritten in place by k_classify.  The
+  // stream belongs to this batch only (absorb_tuples moves what is new into the tuple store)
+  if (int rc = c->stream_buf.ensure(n_items * (u64)stride * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->rec_off.ensure(n_items * sizeof(u64), 0, c->stream)) return rc;
+  out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+  c->host_state.stream_words = n_items * (u64)stride;
+  c->host_state.n_recs = n_items;
+  if (int rc = push_state(c)) return rc;
+  u32* slots = c->stream_buf.as<u32>();
+  int chunks = c->tune.align_chunks > 0 ? c->tune.align_chunks : (n_items >= (4u << 20) ? 8 : n_items >= (1u << 20) ? 4 : 1);
+  chunks = (int)std::min<u64>((u64)std::min(chunks, 64), std::max<u64>(1, n_items / 65536));
+  const u64 per = (n_items + chunks - 1) / chunks;
+  if (chunks > 1) {
+    if (c->al_ev_chunk.size() < (size_t)chunks) { const size_t o = c->al_ev_chunk.size(); c->al_ev_chunk.resize((size_t)chunks, nullptr); for (size_t i = o; i < c->al_ev_chunk.size(); i++) HIPC(hipEventCreateWithFlags(&c->al_ev_chunk[i], hipEventDisableTiming)); }
+    if (int rc = ws.fork()) return rc;   // (behind push_state and whatever produced the reads on the caller's stream)
+  }
+  HIPC(hipEventRecord(c->ev0, ws.user));
+  for (int k = 0; k < chunks; k++) {
+    const u64 first = (u64)k * per, n = std::min(per, n_items - first);
+    if (int rc = launch_match_chunk<PAIRED, FILTER>(c, ws.user, d_words, d_len, first, n, seq_words, rec_words, slots, stride)) return rc;
+    if (chunks > 1) HIPC(hipEventRecord(c->al_ev_chunk[k], ws.user));
+  }
+  HIPC(hipEventRecord(c->ev1, ws.user));
+  c->last_classify_ms = 0.f;
+  for (int k = 0; k < chunks; k++) {
+    const u64 first = (u64)k * per, n = std::min(per, n_items - first);
+    if (chunks > 1) HIPC(hipStreamWaitEvent(c->stream, c->al_ev_chunk[k], 0));
+    HIPC(hipEventRecord(c->ev2, c->stream));
+    const unsigned grid = (unsigned)std::min<u64>(grid_for(n, BLOCK), 256 * 6);
+    hipLaunchKernelGGL((k_classify<PAIRED, FILTER, V3_LIST_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots + first * (u64)stride, stride, n,
+                       first * (u64)stride, first, key_base + first, first, fd, out);
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(c->ev3, c->stream));
+    if (int rc = sync_state(c)) return rc;
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, c->ev2, c->ev3));
+    c->last_classify_ms += ms;
+    // the chunk's tuple records join the distinct tuples of the run (overflow items have no tuple record yet: see kamd_pseudoalign)
+    if (int rc = absorb_tuples(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>() + first, n, c->host_state.stream_words, key_base + first,
+                               c->host_state.st_multi - c->multi_before)) return rc;
+    c->multi_before = c->host_state.st_multi;
+  }
+  HIPC(hipEventSynchronize(c->ev1));
+  HIPC(hipEventElapsedTime(&c->last_align_ms, c->ev0, c->ev1));
   return 0;
 }
 template <bool PAIRED, bool FILTER>
@@ -2722,16 +2805,14 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   }
   AlignOut out{c->dense.as<u32>(), c->track_order ? c->dense_first.as<u64>() : nullptr, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->overflow_items.as<u64>(),
                c->explicit_items.as<u64>(), c->explicit_items_big.as<u64>(), (DevState*)c->state.p};
+  WorkStream ws(c);   // (from here to the end of the call the context's work stream may be the side stream)
   int rc = 0;
-  if (o->paired) rc = filter ? launch_align_v3<true, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
-                             : launch_align_v3<true, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
-  else rc = filter ? launch_align_v3<false, true>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out)
-                   : launch_align_v3<false, false>(c, d_words, d_len, n_items, seq_words, rec_words, fd, out);
+  if (o->paired) rc = filter ? align_batch<true, true>(c, ws, d_words, d_len, n_items, seq_words, rec_words, fd, out, key_base)
+                             : align_batch<true, false>(c, ws, d_words, d_len, n_items, seq_words, rec_words, fd, out, key_base);
+  else rc = filter ? align_batch<false, true>(c, ws, d_words, d_len, n_items, seq_words, rec_words, fd, out, key_base)
+                   : align_batch<false, false>(c, ws, d_words, d_len, n_items, seq_words, rec_words, fd, out, key_base);
   if (rc) return rc;
-  HIPC(hipGetLastError());
-  if (int rc2 = sync_state(c)) return rc2;
-  HIPC(hipEventElapsedTime(&c->last_align_ms, c->ev0, c->ev1));
-  HIPC(hipEventElapsedTime(&c->last_classify_ms, c->ev1, c->ev2));
+  // (every chunk of kernel A has completed: the record stream may be reallocated from here on)
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
     c->had_overflow_items = true;
@@ -2749,6 +2830,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc2 = sync_state(c)) return rc2;
     c->host_state.n_overflow = 0;
     if (int rc2 = push_state(c)) return rc2;
+    // their records (rec_off of an overflow item now points at its long record) join the distinct tuples
+    if (int rc2 = absorb_tuples(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), nov, c->host_state.stream_words, key_base,
+                                c->host_state.st_multi - c->multi_before, c->overflow_items.as<u64>())) return rc2;
+    c->multi_before = c->host_state.st_multi;
   }
   if (filter && (c->host_state.n_explicit || c->host_state.n_explicit_big)) {
     // second pass over the items whose set was changed: write the filtered sets as explicit records
@@ -2781,10 +2866,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     c->host_state.n_explicit = 0; c->host_state.n_explicit_big = 0;
     if (int rc2 = push_state(c)) return rc2;
   }
-  // the batch's tuple records join the distinct tuples of the run; its record stream is free again
-  if (int rc2 = absorb_tuples(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>(), c->host_state.n_recs, c->host_state.stream_words, key_base,
-                              c->host_state.st_multi - c->multi_before)) return rc2;
-  c->multi_before = c->host_state.st_multi;
+  // (the batch's tuple records have joined the distinct tuples of the run; its record stream is free again)
   c->recs_total += n_items;
   c->finalized = false;
   return 0;
@@ -2795,11 +2877,14 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
   HIPC(hipSetDevice(c->device));
   if (int rc = sync_state(c)) return rc;
   s->n_processed = c->host_state.st_processed; s->n_single = c->host_state.st_single; s->n_multi = c->host_state.st_multi;
-  s->n_probes = c->host_state.st_probes; s->n_bucket_reads = c->host_state.st_bucket_reads;
+  DevStatsA sa{};
+  HIPC(hipMemcpyAsync(&sa, c->stats_a.p, sizeof sa, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  s->n_probes = sa.probes; s->n_bucket_reads = sa.bucket_reads;
   s->n_distinct_tuples = c->n_distinct_tuples; s->n_stream_words = c->host_state.stream_words;
-  s->n_raw_words = c->host_state.st_raw_words;
-  s->n_text_hits = c->host_state.st_text_hits;
-  s->n_wave_iters = c->host_state.st_wave_iters; s->n_lane_iters = c->host_state.st_lane_iters;
+  s->n_raw_words = sa.raw_words;
+  s->n_text_hits = sa.text_hits;
+  s->n_wave_iters = sa.wave_iters; s->n_lane_iters = sa.lane_iters;
   return 0;
 }
 
