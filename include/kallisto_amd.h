@@ -126,8 +126,8 @@ typedef struct {
   int32_t em_split_len;        /* component-local form: a row / column with more entries is split over several lanes (1..64) */
   int32_t dedup_form;          /* record de-duplication: 1 = insert + verify launches, 2 = one launch (tag and owner in one CAS; default) */
   int32_t align_chunks;        /* kamd_pseudoalign: kernel A runs in this many launches, each classified and de-duplicated on a side stream while
-                                  the next is matched (1 = one launch, everything in sequence; -1 = by batch size: 8 from 4 M items, 4 from
-                                  1 M, else 1; default) */
+                                  the next is matched (default 1 = one launch, everything in sequence: the stages are all bound by the rate of
+                                  random memory requests and gain nothing from running side by side) */
   int32_t em_small_nnz;        /* component-local form: connected components of at most this many entries are packed into groups of about as
                                   many entries that ONE WAVEFRONT iterates (no block barrier inside a round); larger components keep
                                   workgroup-sized groups.  -1 = one size class only (every group a workgroup; the default: on the

@@ -17,10 +17,12 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
 #include <fstream>
 #include <memory>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -106,6 +108,18 @@ struct RawBlock { uint32_t lb, ub, ec; uint64_t pos_off; };
 
 }  // namespace
 
+// allocator whose resize() leaves new elements uninitialised: the three big tables of a flattened index file are filled by
+// parallel reads straight away (value-initialising 3 GB first costs a third of the load)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using BigVec = std::vector<T, NoInitAlloc<T>>;
+
 struct kamd_index {
   int32_t k = 0;
   uint64_t n_kmers = 0, n_unitigs = 0, n_long = 0, n_short = 0, n_abund = 0, dlist_size = 0;
@@ -123,8 +137,8 @@ struct kamd_index {
   std::vector<uint32_t> onlist_bits;
   uint64_t n_targets = 0;           // real targets (what abundance.tsv lists); target_lens also covers the D-list pseudo-targets
   uint64_t n_buckets = 0, pad_buckets = 0;
-  std::vector<uint64_t> table;
-  std::vector<uint32_t> slot_block, slot_dist;
+  BigVec<uint64_t> table;
+  BigVec<uint32_t> slot_block, slot_dist;
   std::vector<uint32_t> utext;          // 2-bit text of all unitigs, end to end (read packing), + 2 words of padding
   std::vector<uint64_t> unitig_gpos;    // first base of every unitig in it
   uint64_t text_bases = 0;
@@ -156,21 +170,55 @@ inline void for_each_kmer(const uint8_t* packed, uint64_t len, int k, F&& f) {
 // front-end that runs sample after sample against one index can write them once and read them back with plain reads.  Layout:
 // magic, format version, the scalars, then every array as {u64 count, bytes}; native endianness, for this machine's eyes only.
 namespace {
-const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '1'};
+const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '2'};
+// what the layout of the tables depends on, written behind the magic and compared on load
+const uint32_t FLAT_STAMP[4] = {(uint32_t)kamd::BUCKET_SLOTS, (uint32_t)sizeof(uint64_t) * 8u /* bytes per bucket */, 30u /* bits of a class id in the payload */, 13u /* kallisto index version */};
 struct FlatOut {
   FILE* f; bool ok = true;
   void raw(const void* p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
   template <class T> void scalar(const T& x) { raw(&x, sizeof x); }
-  template <class T> void vec(const std::vector<T>& v) { const uint64_t n = v.size(); scalar(n); raw(v.data(), n * sizeof(T)); }
+  template <class V> void vec(const V& v) { const uint64_t n = v.size(); scalar(n); raw(v.data(), n * sizeof(typename V::value_type)); }
 };
 struct FlatIn {
   FILE* f; bool ok = true;
+  struct Job { char* dst; uint64_t off, bytes; };
+  std::vector<Job> jobs;   // arrays of 16 MB and more: skipped in the stream, read afterwards by several threads (run_jobs)
   void raw(void* p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
   template <class T> void scalar(T& x) { raw(&x, sizeof x); }
-  template <class T> void vec(std::vector<T>& v) {
+  template <class V> void vec(V& v) {
+    typedef typename V::value_type T;
     uint64_t n = 0; scalar(n);
     if (!ok || n > (1ULL << 40) / sizeof(T)) { ok = false; return; }
-    v.resize(n); raw(v.data(), n * sizeof(T));
+    v.resize(n);
+    const uint64_t bytes = n * sizeof(T);
+    if (bytes >= (16u << 20)) {
+      const long at = ftell(f);
+      if (at < 0 || fseek(f, (long)bytes, SEEK_CUR) != 0) { ok = false; return; }
+      jobs.push_back(Job{(char*)v.data(), (uint64_t)at, bytes});
+    } else raw(v.data(), bytes);
+  }
+  void run_jobs(const char* path, int threads) {
+    if (!ok || jobs.empty()) return;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { ok = false; return; }
+    struct Piece { char* dst; uint64_t off, bytes; };
+    std::vector<Piece> pieces;
+    for (const Job& j : jobs) for (uint64_t a = 0; a < j.bytes; a += (8u << 20)) pieces.push_back(Piece{j.dst + a, j.off + a, std::min<uint64_t>(8u << 20, j.bytes - a)});
+    std::atomic<size_t> next{0}; std::atomic<bool> good{true};
+    std::vector<std::thread> th;
+    for (int t = 0; t < std::max(1, std::min(threads, 32)); t++) th.emplace_back([&] {
+      for (size_t i; (i = next++) < pieces.size();) {
+        uint64_t done = 0;
+        while (done < pieces[i].bytes) {
+          const ssize_t r = pread(fd, pieces[i].dst + done, pieces[i].bytes - done, (off_t)(pieces[i].off + done));
+          if (r <= 0) { good = false; return; }
+          done += (uint64_t)r;
+        }
+      }
+    });
+    for (auto& x : th) x.join();
+    ::close(fd);
+    if (!good) ok = false;
   }
 };
 template <class IO> void flat_fields(IO& io, kamd_index& x) {
@@ -181,12 +229,18 @@ template <class IO> void flat_fields(IO& io, kamd_index& x) {
   io.vec(x.blk_pos_off); io.vec(x.blk_posw); io.vec(x.blk_sense); io.vec(x.uec_ec); io.vec(x.ec_off); io.vec(x.ec_ids); io.vec(x.target_lens);
   io.vec(x.onlist_bits); io.vec(x.table); io.vec(x.slot_block); io.vec(x.slot_dist); io.vec(x.utext); io.vec(x.unitig_gpos); io.vec(x.dlist_keys); io.vec(x.dtable);
 }
-int load_flat(const char* path, kamd_index** out) {
+int load_flat(const char* path, int threads, kamd_index** out) {
   FILE* f = fopen(path, "rb");
   if (!f) return kamd::fail(-2, std::string("index input file could not be opened: ") + path);
   char magic[8];
   FlatIn in{f};
   in.raw(magic, 8);
+  uint32_t stamp[4] = {0, 0, 0, 0};
+  in.raw(stamp, sizeof stamp);
+  if (!in.ok || memcmp(magic, FLAT_MAGIC, 8) != 0 || memcmp(stamp, FLAT_STAMP, sizeof stamp) != 0) {
+    fclose(f);
+    return kamd::fail(-3, std::string("flattened index file is damaged or of another format version: ") + path);
+  }
   std::unique_ptr<kamd_index> ix(new kamd_index);
   flat_fields(in, *ix);
   uint64_t n_names = 0; in.scalar(n_names);
@@ -195,14 +249,43 @@ int load_flat(const char* path, kamd_index** out) {
     for (uint64_t i = 0; i < n_names && in.ok; i++) { uint32_t l = 0; in.scalar(l); if (l > (1u << 20)) { in.ok = false; break; } ix->target_names[i].resize(l); in.raw(&ix->target_names[i][0], l); }
   } else in.ok = false;
   fclose(f);
-  // the arrays must be consistent with the scalars the kernels trust
+  in.run_jobs(path, threads);
+  // the arrays must be consistent with the scalars -- and with each other -- the kernels trust: every length, and the largest value
+  // of every array that is used as an index (a truncated or stale file must not turn into out-of-bounds reads on the device)
   const uint64_t S = kamd::BUCKET_SLOTS, nb = ix->n_buckets + ix->pad_buckets;
-  if (!in.ok || memcmp(magic, FLAT_MAGIC, 8) != 0 || ix->k < 3 || ix->k > 31 || ix->table.size() != nb * 8 || ix->slot_block.size() != nb * S ||
-      ix->slot_dist.size() != nb * S || ix->unitig_len.size() != ix->n_unitigs || ix->unitig_blk_off.size() != ix->n_unitigs + 1 ||
-      ix->unitig_gpos.size() != ix->n_unitigs + 1 || ix->ec_off.empty() || ix->ec_off.back() != ix->ec_ids.size() ||
-      ix->target_lens.size() < ix->n_targets || ix->target_names.size() < ix->n_targets || ix->utext.size() < (ix->text_bases + 15) / 16 ||
-      ix->dtable.size() != (ix->n_dbuckets ? (ix->n_dbuckets + ix->dpad_buckets) * 8 : 0))
-    return kamd::fail(-3, std::string("flattened index file is damaged or of another format version: ") + path);
+  bool good = in.ok && ix->k >= 3 && ix->k <= 31 && ix->table.size() == nb * 8 && ix->slot_block.size() == nb * S && ix->slot_dist.size() == nb * S &&
+              ix->unitig_len.size() == ix->n_unitigs && ix->unitig_blk_off.size() == ix->n_unitigs + 1 && ix->unitig_gpos.size() == ix->n_unitigs + 1 &&
+              !ix->ec_off.empty() && ix->ec_off.back() == ix->ec_ids.size() && ix->target_lens.size() >= ix->n_targets + ix->dlist_size &&
+              ix->target_names.size() >= ix->n_targets && ix->utext.size() >= (ix->text_bases + 15) / 16 + 2 &&
+              ix->dtable.size() == (ix->n_dbuckets ? (ix->n_dbuckets + ix->dpad_buckets) * 8 : 0) && ix->onlist_bits.size() >= (ix->n_targets + 31) / 32;
+  if (good) {
+    const uint64_t n_blocks = ix->unitig_blk_off.back(), n_ecs = ix->ec_off.size() - 1, n_uec = ix->uec_ec.size(), n_tr = ix->n_targets + ix->dlist_size;
+    good = ix->blk_unitig.size() == n_blocks && ix->blk_lb.size() == n_blocks && ix->blk_ub.size() == n_blocks && ix->blk_ec.size() == n_blocks &&
+           ix->blk_uec.size() == n_blocks && ix->blk_pos_off.size() == n_blocks + 1 && ix->blk_posw.size() == ix->blk_pos_off.back() &&
+           ix->blk_sense.size() == ix->blk_pos_off.back() && n_uec <= kamd::UEC_MASK && n_ecs <= kamd::EC_ID_MASK && ix->dummy_uec < std::max<uint64_t>(n_uec, 1) &&
+           ix->dummy_slot < std::max<uint64_t>(nb * S, 1) && ix->unitig_gpos.back() <= ix->text_bases &&
+           (ix->dlist_size == 0 || ix->dlist_keys.size() == ix->dlist_size);
+    for (size_t i = 0; good && i + 1 < ix->ec_off.size(); i++) good = ix->ec_off[i] <= ix->ec_off[i + 1];
+    for (size_t i = 0; good && i + 1 < ix->unitig_blk_off.size(); i++) good = ix->unitig_blk_off[i] <= ix->unitig_blk_off[i + 1];
+    for (size_t i = 0; good && i + 1 < ix->blk_pos_off.size(); i++) good = ix->blk_pos_off[i] <= ix->blk_pos_off[i + 1];
+    for (size_t i = 0; good && i < ix->ec_ids.size(); i++) good = ix->ec_ids[i] < n_tr;
+    for (size_t i = 0; good && i < n_uec; i++) good = ix->uec_ec[i] < n_ecs;
+    for (size_t i = 0; good && i < n_blocks; i++) good = ix->blk_ec[i] < n_ecs && ix->blk_uec[i] < n_uec && ix->blk_unitig[i] < ix->n_unitigs && ix->blk_lb[i] <= ix->blk_ub[i];
+    if (good) {   // the per-slot block ids (0xFFFFFFFF = empty slot), in parallel: 4 bytes per slot of the big table
+      std::atomic<bool> ok2{true};
+      std::vector<std::thread> th;
+      const int nt = std::max(1, std::min(threads, 16));
+      for (int t = 0; t < nt; t++) th.emplace_back([&, t] {
+        const size_t a = ix->slot_block.size() * t / nt, e = ix->slot_block.size() * (t + 1) / nt;
+        bool g = true;
+        for (size_t i = a; i < e; i++) g = g && (ix->slot_block[i] == 0xFFFFFFFFu || ix->slot_block[i] < n_blocks);
+        if (!g) ok2 = false;
+      });
+      for (auto& x : th) x.join();
+      good = ok2;
+    }
+  }
+  if (!good) return kamd::fail(-3, std::string("flattened index file is damaged or of another format version: ") + path);
   *out = ix.release();
   return 0;
 }
@@ -214,6 +297,7 @@ extern "C" int kamd_index_save(const kamd_index* ix, const char* path) {
   if (!f) return kamd::fail(-2, std::string("kamd_index_save: could not open ") + path);
   FlatOut o{f};
   o.raw(FLAT_MAGIC, 8);
+  o.raw(FLAT_STAMP, sizeof FLAT_STAMP);
   flat_fields(o, const_cast<kamd_index&>(*ix));
   const uint64_t n_names = ix->target_names.size(); o.scalar(n_names);
   for (const std::string& nm : ix->target_names) { const uint32_t l = (uint32_t)nm.size(); o.scalar(l); o.raw(nm.data(), l); }
@@ -232,7 +316,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     char magic[8] = {0};
     const bool flat = f && fread(magic, 1, 8, f) == 8 && memcmp(magic, FLAT_MAGIC, 8) == 0;
     if (f) fclose(f);
-    if (flat) return load_flat(path, out);
+    if (flat) return load_flat(path, threads, out);
   }
   std::vector<uint8_t> buf;
   {

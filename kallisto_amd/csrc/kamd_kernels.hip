@@ -2725,7 +2725,9 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
   c->host_state.n_recs = n_items;
   if (int rc = push_state(c)) return rc;
   u32* slots = c->stream_buf.as<u32>();
-  int chunks = c->tune.align_chunks > 0 ? c->tune.align_chunks : (n_items >= (4u << 20) ? 8 : n_items >= (1u << 20) ? 4 : 1);
+  // (one launch by default: measured on config #3, 4 / 8 chunks overlap perfectly and gain nothing -- kernel A, k_classify and
+  // k_tup_absorb all live on the memory system's rate of random requests, so side by side they only share it; profiles/README.md)
+  int chunks = c->tune.align_chunks > 0 ? c->tune.align_chunks : 1;
   chunks = (int)std::min<u64>((u64)std::min(chunks, 64), std::max<u64>(1, n_items / 65536));
   const u64 per = (n_items + chunks - 1) / chunks;
   if (chunks > 1) {
@@ -3244,10 +3246,25 @@ extern "C" int kamd_ec_download(kamd_ctx* c, uint64_t* ec_off, uint32_t* ec_ids,
 extern "C" int kamd_ec_upload(kamd_ctx* c, const uint64_t* ec_off, const uint32_t* ec_ids, const uint32_t* counts, uint64_t n_ecs) {
   if (!c || !ec_off || (n_ecs && !ec_ids)) return kamd::fail(-1, "kamd_ec_upload: null argument");
   if (ec_off[0] != 0) return kamd::fail(-1, "kamd_ec_upload: ec_off[0] must be 0");
+  std::vector<std::pair<u64, u64>> by_hash((size_t)n_ecs);   // (content hash, class): equal classes end up next to each other
   for (u64 e = 0; e < n_ecs; e++) {
     if (ec_off[e + 1] <= ec_off[e]) return kamd::fail(-1, "kamd_ec_upload: empty equivalence class or offsets not increasing");
-    for (u64 j = ec_off[e] + 1; j < ec_off[e + 1]; j++)
-      if (ec_ids[j] <= ec_ids[j - 1]) return kamd::fail(-1, "kamd_ec_upload: the transcripts of an equivalence class must be sorted and distinct");
+    u64 h = kamd::mix64(ec_off[e + 1] - ec_off[e]);
+    for (u64 j = ec_off[e]; j < ec_off[e + 1]; j++) {
+      if (j > ec_off[e] && ec_ids[j] <= ec_ids[j - 1]) return kamd::fail(-1, "kamd_ec_upload: the transcripts of an equivalence class must be sorted and distinct");
+      if (c->has_index && ec_ids[j] >= c->n_targets) return kamd::fail(-1, "kamd_ec_upload: transcript id beyond the targets of the uploaded index");
+      h = kamd::mix64(h ^ ec_ids[j]);
+    }
+    by_hash[(size_t)e] = {h, e};
+  }
+  // two classes with the same transcripts would be two rows of one set for the EM (the reference keys its classes by content,
+  // ecmapinv: src/KmerIndex.cpp:1561-1600) and would race for the singleton slot of a transcript: refused
+  std::sort(by_hash.begin(), by_hash.end());
+  for (size_t i = 1; i < by_hash.size(); i++) {
+    if (by_hash[i].first != by_hash[i - 1].first) continue;
+    const u64 a = by_hash[i - 1].second, b = by_hash[i].second;
+    if (ec_off[a + 1] - ec_off[a] == ec_off[b + 1] - ec_off[b] && std::equal(ec_ids + ec_off[a], ec_ids + ec_off[a + 1], ec_ids + ec_off[b]))
+      return kamd::fail(-1, "kamd_ec_upload: equivalence classes " + std::to_string(std::min(a, b)) + " and " + std::to_string(std::max(a, b)) + " hold the same transcripts");
   }
   HIPC(hipSetDevice(c->device));
   const u64 nnz = ec_off[n_ecs];

@@ -425,3 +425,24 @@ def test_ec_state_is_bounded_by_the_distinct_classes(ka):
         assert ctx.finalize(download=True).multiset() == one
     finally:
         ctx.close()
+
+
+def test_ec_upload_refuses_what_the_em_cannot_take(ka):
+    """kamd_ec_upload (quant-tcc): classes must be sorted sets of transcripts of the uploaded index, and no two classes may be equal
+    (the reference keys its classes by content: a duplicate would be two rows of one set)."""
+    import kallisto_amd.api as A
+    meta, idx_path, r1, r2 = common.load_case("ref_test_pe")
+    index = ka.Index(idx_path)
+    ctx = ka.Context(0)
+    try:
+        ctx.upload(index)
+        T = index.num_targets
+        ctx.ec_upload([0, 1, 3], [0, 1, 2], [5, 7])                       # fine
+        with pytest.raises(A.KallistoAmdError, match="same transcripts"):
+            ctx.ec_upload([0, 2, 3, 5], [1, 2, 0, 1, 2], [1, 1, 1])       # classes 0 and 2 are both {1, 2}
+        with pytest.raises(A.KallistoAmdError, match="beyond the targets"):
+            ctx.ec_upload([0, 2], [0, T], [1])
+        with pytest.raises(A.KallistoAmdError, match="sorted and distinct"):
+            ctx.ec_upload([0, 2], [2, 1], [1])
+    finally:
+        ctx.close()

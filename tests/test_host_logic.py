@@ -263,3 +263,16 @@ def test_flattened_index_file_round_trip(case, tmp_path):
     open(flat, "wb").write(blob[: len(blob) // 2])
     with pytest.raises(api.KallistoAmdError):
         api.Index(flat)
+    # ... and so is one whose arrays no longer fit together: an index-valued entry beyond its range (here: a transcript id of an EC
+    # list set to 2^31), another layout stamp, another magic
+    v = a.view
+    import ctypes as C
+    ec_ids = np.ctypeslib.as_array(C.cast(v.ec_ids, C.POINTER(C.c_uint32)), shape=(int(v.ec_nnz),)).copy()
+    at = bytes(blob).find(ec_ids.tobytes())
+    assert at > 0
+    for patch_at, patch in ((at, (1 << 31).to_bytes(4, "little")), (8, b"\x07\x00\x00\x00"), (0, b"X")):
+        bad = bytearray(blob)
+        bad[patch_at:patch_at + len(patch)] = patch
+        open(flat, "wb").write(bad)
+        with pytest.raises(api.KallistoAmdError):
+            api.Index(flat)
