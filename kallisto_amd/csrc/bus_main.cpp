@@ -49,6 +49,11 @@ void usage_bus() {
             << "    --fr-stranded / --rf-stranded / --unstranded\n"
             << "    --union, --no-jump        As in quant\n"
             << "-t, --threads=INT             Host threads (default: 1)\n"
+            << "    --bus-per-read            output.bus with one record per pseudoaligned read (count 1), as the reference writes it; by default\n"
+            << "                              the records of a sample and class are collapsed into one with their number in `count` -- what\n"
+            << "                              `bustools sort` makes of the reference's file.  Either way the records are sorted by barcode and\n"
+            << "                              class, and matrix.ec lists the classes that occur, numbered in order of first appearance (the\n"
+            << "                              reference numbers the index's classes first; class ids are arbitrary on both sides)\n"
             << "    --verbose                 Print out progress information\n";
 }
 
@@ -66,7 +71,7 @@ int bus_main(int argc, char** argv) {
   if (argc == 2) { usage_bus(); return 0; }
   std::string index, output, technology, batch_file, val;
   std::vector<std::string> files;
-  bool paired = false, verbose = false, do_union = false, no_jump = false;
+  bool paired = false, verbose = false, do_union = false, no_jump = false, per_read = false;
   int strand = 0, threads = 1;
   uint64_t batch = 4u << 20;
   for (int i = 2; i < argc; i++) {
@@ -83,6 +88,7 @@ int bus_main(int argc, char** argv) {
     else if (a == "--unstranded") strand = 0;
     else if (a == "--union") do_union = true;
     else if (a == "--no-jump") no_jump = true;
+    else if (a == "--bus-per-read") per_read = true;
     else if (a == "--verbose") verbose = true;
     else if (a == "-l" || a == "--list" || a == "-b" || a == "--bam" || a == "-n" || a == "--num" || a == "--genomebam" || a == "-g" || a == "--gtf" ||
              a == "-c" || a == "--chromosomes" || a == "-T" || a == "--tag" || a == "--long" || a == "-P" || a == "--platform" || a == "-r" ||
@@ -240,8 +246,8 @@ int bus_main(int argc, char** argv) {
     for (const auto& bcs : per_barcode)
       for (const auto& ec_n : bcs.second) {
         uint64_t left = ec_n.second;
-        while (left) {   // `count` is 32 bits
-          BusRecord r{bcs.first, ~0ULL, ec_n.first, (uint32_t)std::min<uint64_t>(left, 0xFFFFFFFFu), 0, 0};
+        while (left) {   // `count` is 32 bits; --bus-per-read: one record per read, as BUSProcessor::processBuffer writes them (src/ProcessReads.cpp:1600-1640)
+          BusRecord r{bcs.first, ~0ULL, ec_n.first, per_read ? 1u : (uint32_t)std::min<uint64_t>(left, 0xFFFFFFFFu), 0, 0};
           of.write((const char*)&r, sizeof r);
           left -= r.count;
         }

@@ -112,6 +112,17 @@ def test_bus_bulk_matches_reference(case, tmp_path):
     for fn in ("matrix.cells", "matrix.sample.barcodes", "transcripts.txt") + (("flens.txt",) if "--paired" in meta["bus_flags"] else ()):
         assert open(os.path.join(out, fn)).read() == open(os.path.join(gold, fn)).read(), fn
     assert os.path.exists(os.path.join(out, "flens.txt")) == ("--paired" in meta["bus_flags"])
+    if case == CASES[0]:
+        # --bus-per-read: the reference's record stream -- one 32-byte record per pseudoaligned read, count 1 -- whose collapse is the above
+        (tmp_path / "per_read").mkdir()
+        _, out1 = _run_bus(meta, tmp_path / "per_read", extra=["--bus-per-read"])
+        hdr1, rec1 = _read_bus(os.path.join(out1, "output.bus"))
+        assert list(hdr1) == list(hdr) and len(rec1) == meta["n_records_reference"] and np.all(rec1["count"] == 1)
+        k1 = list(zip(rec1["bc"].tolist(), rec1["ec"].tolist()))
+        assert k1 == sorted(k1)
+        from collections import Counter
+        assert Counter(k1) == {k: int(n) for k, n in zip(keys, rec["count"].tolist())}
+        assert open(os.path.join(out1, "matrix.ec")).read() == open(os.path.join(out, "matrix.ec")).read()
 
 
 def _run_tcc(idx, ec, tcc, meta, gold, out):
