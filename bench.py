@@ -413,6 +413,8 @@ def main():
                     "beside the headline value, never as it")
     ap.add_argument("--end-to-end", type=int, default=8_000_000, help="run the C++ front-end from FASTQ files with this many pairs / reads (N = 1 only; 0 = skip)")
     ap.add_argument("--no-pinned-pipeline", action="store_true")
+    ap.add_argument("--multi-parity", action="store_true", help="N > 1: rank 0 also runs the reads of ALL ranks on its own (one context, no communicator) "
+                    "and the merged result of the ranks must equal it (EC multiset, flens identical; est_counts 1e-9; same EM rounds)")
     args = ap.parse_args()
 
     import torch
@@ -550,6 +552,42 @@ def main():
                  "note": "BASELINE config #4 is the strong case: the same 30 M pairs sharded over the GPUs; the EC merge (one all-reduce + "
                          "all-gathers) and the EM (partitioned by connected component, stop rule summed over the ranks) do not shrink with "
                          "1/N, so strong scaling is bounded by them" }
+    # ---- optional parity leg of the multi-rank flow: the merged result against one rank that sees every rank's reads ----
+    multi_parity = None
+    if world > 1 and args.multi_parity:
+        ctx.reset()
+        mres = ka.quant(ctx, opts, [(words[:n * per * rec], lens[:per * n], n, L)], download_ecs=True)   # collective: every rank calls it
+        if rank == 0:
+            try:
+                ctx1 = ka.Context(local)
+                ctx1.upload(index)
+                batches, keep = [], []
+                for r in range(world):   # rank r's reads: the same generator, the same seed, the same chunks
+                    simr = ReadSimulator(cat, tlens, dev, seed=1000 + r, read_len=L)
+                    wr = torch.empty(n * per * rec, dtype=torch.int32, device=dev); lr = torch.empty(n * per, dtype=torch.int16, device=dev)
+                    for s0 in range(0, n_gen, chunk):
+                        m = min(chunk, n_gen - s0)
+                        q1, q2 = simr.draw(m)
+                        if s0 >= n:
+                            break
+                        m = min(m, n - s0)
+                        inter = torch.stack([q1[:m], q2[:m]], 1).reshape(2 * m, L) if paired else q1[:m]
+                        w, l = ctx1.pack_reads(inter, L)
+                        wr[s0 * per * rec:(s0 + m) * per * rec] = w; lr[per * s0:per * (s0 + m)] = l
+                    keep.append((wr, lr)); batches.append((wr, lr, n, L))
+                sres = ka.quant(ctx1, opts, batches, download_ecs=True, comm=False)
+                big = sres.est_counts > 1e-6
+                rel = float(np.max(np.abs(mres.est_counts[big] - sres.est_counts[big]) / sres.est_counts[big])) if big.any() else 0.0
+                multi_parity = {"ranks": world, "items_per_rank": n, "ec_multiset_equal": bool(mres.ecs.multiset() == sres.ecs.multiset()),
+                                "flens_equal": bool(np.array_equal(mres.flens, sres.flens)), "n_processed": [int(mres.n_processed), int(sres.n_processed)],
+                                "est_counts_max_rel_err": rel, "em_rounds": [int(mres.em_rounds), int(sres.em_rounds)]}
+                multi_parity["ok"] = bool(multi_parity["ec_multiset_equal"] and multi_parity["flens_equal"] and rel <= 1e-9 and
+                                          mres.em_rounds == sres.em_rounds and mres.n_processed == sres.n_processed)
+                ctx1.close()
+                del keep, batches
+            except Exception as e:   # noqa: BLE001
+                multi_parity = {"ok": False, "error": str(e)}
+        fence()
     # ---- BASELINE config #5 (optional): B bootstrap replicates of the last step's ECs, replicate b on rank b % world ----
     boot = None
     if args.bootstraps > 0:
@@ -791,6 +829,8 @@ def main():
         except Exception as e:
             out["end_to_end"] = {"error": str(e)}
     if rank == 0:
+        if multi_parity is not None:
+            out["multi_rank_parity"] = multi_parity
         if boot is not None:
             out["bootstrap"] = boot
         if in_flight is not None:

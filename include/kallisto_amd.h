@@ -325,6 +325,7 @@ typedef struct {
  * records of several ranks have no input order). */
 int kamd_ec_track_order(kamd_ctx*, int on);
 int kamd_ec_finalize(kamd_ctx*, kamd_ec_result* out);
+int kamd_ec_finalize_result(kamd_ctx*, kamd_ec_result* out);   /* the result of the last kamd_ec_finalize (e.g. after kamd_quant_batches) */
 int kamd_ec_download(kamd_ctx*, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts);
 /* `quant-tcc` (src/main.cpp:2802-3220): the equivalence classes come from a file (KmerIndex::loadECsFromFile,
  * src/KmerIndex.cpp:1561-1600) and every sample / cell brings its own count vector (EM_lambda: `collection.counts[ec] = count`,
@@ -372,6 +373,25 @@ int kamd_bootstrap_batch(kamd_ctx*, const uint64_t* seeds, int32_t n_rep, const 
                          int32_t* rounds);
 /* seeds[b] = std::mt19937_64(seed)() for b = 0..n-1 (src/main.cpp:2746-2752) */
 void kamd_bootstrap_seeds(uint64_t seed, int32_t n, uint64_t* seeds);
+
+/* ---- the quant flow in one call (ProcessReads -> fragment-length model -> EMAlgorithm::run, src/main.cpp:2654-2730) ----
+ * For a caller whose reads already sit in HBM in the packed layout: the batches are pseudoaligned in order (fragment-length sample:
+ * the first 10 000 qualifying pairs of the input, src/ProcessReads.cpp:981-1017), with a communicator every rank passes its own
+ * shard and the EC state is merged (kamd_ec_allreduce) and the EM partitioned (kamd_em_run_comm); then kamd_ec_finalize, effective
+ * lengths, the EM with run(10000, 50), TPM.  Equivalent to calling those entry points one after the other; the EC result stays
+ * in the context (kamd_ec_download, kamd_bootstrap_batch). */
+typedef struct { const uint32_t* d_words; const uint16_t* d_len; uint64_t n_items; int32_t max_len; } kamd_batch;
+typedef struct {
+  uint64_t n_processed;          /* items of all ranks */
+  int32_t em_rounds;
+  uint32_t* flens;               /* [KAMD_MAX_FRAG_LEN], caller-provided: the fragment-length sample (zeros with -l) */
+  double* eff_lens;              /* [n_targets], caller-provided */
+  double* est_counts;            /* [n_targets], caller-provided */
+  double* alpha_before_zeroes;   /* [n_targets], caller-provided; nullable */
+  double* tpm;                   /* [n_targets], caller-provided; nullable */
+} kamd_quant_out;
+int kamd_quant_batches(kamd_ctx*, const kamd_quant_opts*, const kamd_batch* batches, uint64_t n_batches, const int32_t* target_lens,
+                       uint64_t n_targets, kamd_comm* comm /* nullable */, kamd_quant_out* out);
 
 /* ---- host-side helpers of the quant driver (FLD model, effective lengths; FP64 on the host, bit-exact) ---- */
 void kamd_mean_frag_lens_trunc(const uint32_t* flens, double* mean_fl_trunc);

@@ -74,6 +74,15 @@ class _FastqUnit(C.Structure):
                 ("first_bad_record", C.c_uint64)]
 
 
+class _Batch(C.Structure):
+    _fields_ = [("d_words", C.c_void_p), ("d_len", C.c_void_p), ("n_items", C.c_uint64), ("max_len", C.c_int32)]
+
+
+class _QuantOut(C.Structure):
+    _fields_ = [("n_processed", C.c_uint64), ("em_rounds", C.c_int32), ("flens", C.c_void_p), ("eff_lens", C.c_void_p), ("est_counts", C.c_void_p),
+                ("alpha_before_zeroes", C.c_void_p), ("tpm", C.c_void_p)]
+
+
 class _EcResult(C.Structure):
     _fields_ = [("n_ecs", C.c_uint64), ("nnz", C.c_uint64), ("n_pseudoaligned", C.c_uint64), ("d_ec_off", C.c_void_p),
                 ("d_ec_ids", C.c_void_p), ("d_counts", C.c_void_p)]
@@ -131,6 +140,7 @@ _SYMBOLS = {
     "kamd_em_run_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32)]),
     "kamd_ec_finalize": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
+    "kamd_ec_finalize_result": (C.c_int, [C.c_void_p, C.POINTER(_EcResult)]),
     "kamd_ec_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_ec_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "kamd_ec_set_counts": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -142,6 +152,7 @@ _SYMBOLS = {
                                  C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "kamd_bootstrap_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "kamd_bootstrap_seeds": (None, [C.c_uint64, C.c_int32, C.c_void_p]),
+    "kamd_quant_batches": (C.c_int, [C.c_void_p, C.POINTER(QuantOpts), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(_QuantOut)]),
     "kamd_mean_frag_lens_trunc": (None, [C.c_void_p, C.c_void_p]),
     "kamd_trunc_gaussian_fld": (None, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
     "kamd_eff_lens": (None, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -494,6 +505,11 @@ class Context:
         self.ec_result = res
         if not download:
             return None
+        return self.download_ecs()
+
+    def download_ecs(self):
+        """kamd_ec_download of the finalized result (self.ec_result)"""
+        res = self.ec_result
         ec_off = np.zeros(res.n_ecs + 1, np.uint64)
         ec_ids = np.zeros(max(res.nnz, 1), np.uint32)
         counts = np.zeros(max(res.n_ecs, 1), np.uint32)
@@ -814,51 +830,38 @@ def quant(ctx: Context, opts: QuantOpts, batches, download_ecs: bool = True, gro
     batches: iterable of (words, lens, n_items, max_len).  Several ranks (torch.distributed initialised, or `comm` given):
     every rank passes its own shard of the reads; the EC counts are merged inside the library (kamd_ec_allreduce: one
     all-reduce + all-gathers over RCCL) before the EM, which runs partitioned over the ranks (kamd_em_run_comm).
+    comm=False: this rank on its own, even inside an initialised process group.
     """
     index = ctx.index
     batches = list(batches)
     n_proc = 0
-    if comm is None and (group is not None or _dist_on()):
+    if comm is False:
+        comm = None
+    elif comm is None and (group is not None or _dist_on()):
         comm = getattr(ctx, "_comm", None)
         if comm is None:
             comm = ctx._comm = Comm.for_context(ctx, group)
-    multi = comm is not None
-    rank0 = (not multi) or _dist_rank_of(comm, group) == 0
-    estimate_fld = opts.fld == 0.0 and bool(opts.paired)
+    # the flow itself runs inside the library (kamd_quant_batches); this function only marshals
+    T = int(index.num_targets)
+    arr = (_Batch * max(len(batches), 1))()
+    for i, (words, lens, n_items, max_len) in enumerate(batches):
+        arr[i] = _Batch(words.data_ptr(), lens.data_ptr(), int(n_items), int(max_len))
     flens = np.zeros(MAX_FRAG_LEN, np.uint32)
-    used = 0
-    for bi, (words, lens, n_items, max_len) in enumerate(batches):
-        if bi == 0 and estimate_fld and rank0:
-            ctx.fld_prefetch(opts, words, lens, n_items, max_len)   # the FLD kernel of the first prefix runs underneath kernel A
-        ctx.pseudoalign(opts, words, lens, n_items, max_len)
-        n_proc += n_items
-        # FLD: the first 10000 qualifying pairs of the input in order, carried across batches until the sample is full
-        # (src/ProcessReads.cpp:981-1008: tlencount persists from batch to batch); rank 0's reads when several ranks run
-        if estimate_fld and used < 10000 and rank0:
-            flens, used = ctx.fld_from_batch(opts, words, lens, n_items, max_len, flens, used)
-    if multi:
-        n_proc = comm.sum_int(n_proc)
-    if opts.fld == 0.0:
-        if multi:
-            flens = comm.broadcast_np(flens, 0)
-        mft = mean_frag_lens_trunc(flens)
-    else:
-        mft = trunc_gaussian_fld(opts.fld, opts.sd)
-    if multi:
-        ctx.ec_allreduce(comm)
-    ecs = ctx.finalize(download=download_ecs)
-    eff = eff_lens(index.target_lens, mft)
-    if multi:
-        alpha, abz, rounds = ctx.em_run_comm(comm, eff)
-    else:
-        alpha, abz, rounds = ctx.em_run(eff)
-    tpm = counts_to_tpm(alpha, eff)
+    eff = np.zeros(T, np.float64); alpha = np.zeros(T, np.float64); abz = np.zeros(T, np.float64); tpm = np.zeros(T, np.float64)
+    tl = np.ascontiguousarray(index.target_lens, np.int32)
+    q = _QuantOut(0, 0, flens.ctypes.data, eff.ctypes.data, alpha.ctypes.data, abz.ctypes.data, tpm.ctypes.data)
+    _check(load_library().kamd_quant_batches(ctx._h, C.byref(opts), arr, len(batches), tl.ctypes.data, T, comm._h if comm is not None else None, C.byref(q)),
+           "kamd_quant_batches")
+    res = _EcResult()
+    _check(load_library().kamd_ec_finalize_result(ctx._h, C.byref(res)), "kamd_ec_finalize_result")
+    ctx.ec_result = res
+    ecs = ctx.download_ecs() if download_ecs else None
     n_aln = n_uniq = 0
     if ecs is not None:
         n_aln = int(ecs.counts.sum(dtype=np.uint64))
         sizes = np.diff(ecs.ec_off.astype(np.int64))
         n_uniq = int(ecs.counts[sizes == 1].sum(dtype=np.uint64))
-    return QuantResult(n_proc, n_aln, n_uniq, ecs, flens, eff, alpha, abz, tpm, rounds, ctx.stats())
+    return QuantResult(int(q.n_processed), n_aln, n_uniq, ecs, flens, eff, alpha, abz, tpm, int(q.em_rounds), ctx.stats())
 
 
 def _dist_rank_of(comm: Comm, group=None) -> int:

@@ -3229,6 +3229,13 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   return 0;
 }
 
+extern "C" int kamd_ec_finalize_result(kamd_ctx* c, kamd_ec_result* out) {
+  if (!c || !out) return kamd::fail(-1, "kamd_ec_finalize_result: null argument");
+  if (!c->finalized) return kamd::fail(-1, "kamd_ec_finalize_result: call kamd_ec_finalize first");
+  *out = c->result;
+  return 0;
+}
+
 extern "C" int kamd_ec_download(kamd_ctx* c, uint64_t* ec_off, uint32_t* ec_ids, uint32_t* counts) {
   if (!c || !c->finalized) return kamd::fail(-1, "kamd_ec_download: call kamd_ec_finalize first");
   HIPC(hipSetDevice(c->device));
@@ -4973,5 +4980,48 @@ extern "C" int kamd_em_run_comm(kamd_ctx* c, kamd_comm* m, const double* eff_len
   HIPC(hipMemcpyAsync(alpha, d, n_targets * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipMemcpyAsync(abz, d + n_targets, n_targets * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- the whole quant flow over batches resident in HBM (src/main.cpp:2654-2730: ProcessReads -> fragment lengths -> EMAlgorithm) ----
+// What a caller that already holds packed reads on the device does with the entry points above, in one call and without a
+// language binding's overhead between the stages: every batch pseudoaligned in order (the fragment-length sample taken from the
+// first 10 000 qualifying pairs on the way), the EC state merged over the communicator's ranks if there is one, the classes
+// resolved, effective lengths, the EM, TPM.
+extern "C" int kamd_quant_batches(kamd_ctx* c, const kamd_quant_opts* o, const kamd_batch* batches, uint64_t n_batches, const int32_t* target_lens,
+                                  uint64_t n_targets, kamd_comm* comm, kamd_quant_out* out) {
+  if (!c || !o || (n_batches && !batches) || !target_lens || !out || !out->flens || !out->eff_lens || !out->est_counts)
+    return kamd::fail(-1, "kamd_quant_batches: null argument");
+  if (comm && comm->ctx != c) return kamd::fail(-1, "kamd_quant_batches: communicator of another context");
+  if (n_targets != c->n_targets) return kamd::fail(-1, "kamd_quant_batches: n_targets differs from the uploaded index");
+  const bool multi = comm && (comm->world > 1 || comm->nccl);
+  const bool rank0 = !comm || comm->rank == 0;
+  const bool estimate = o->paired && o->fld == 0.0;
+  memset(out->flens, 0, KAMD_MAX_FRAG_LEN * sizeof(uint32_t));
+  uint64_t used = 0, n_proc = 0;
+  for (uint64_t b = 0; b < n_batches; b++) {
+    const kamd_batch& B = batches[b];
+    if (b == 0 && estimate && rank0) if (int rc = kamd_fld_prefetch(c, o, B.d_words, B.d_len, B.n_items, B.max_len)) return rc;   // runs underneath kernel A
+    if (int rc = kamd_pseudoalign(c, o, B.d_words, B.d_len, B.n_items, B.max_len)) return rc;
+    n_proc += B.n_items;
+    // the first 10000 qualifying pairs of the input in order, carried across batches until the sample is full
+    // (src/ProcessReads.cpp:981-1008: tlencount persists from batch to batch); rank 0's reads when several ranks run
+    if (estimate && used < 10000 && rank0) if (int rc = kamd_fld_from_batch(c, o, B.d_words, B.d_len, B.n_items, B.max_len, out->flens, &used)) return rc;
+  }
+  if (multi) {
+    if (int rc = kamd_comm_sum_u64_host(c, comm, &n_proc, 1)) return rc;
+    if (estimate) if (int rc = kamd_comm_broadcast_host(c, comm, out->flens, KAMD_MAX_FRAG_LEN * sizeof(uint32_t), 0)) return rc;
+    if (int rc = kamd_ec_allreduce(c, comm)) return rc;
+  }
+  std::vector<double> mft(KAMD_MAX_FRAG_LEN);
+  if (o->fld == 0.0) kamd_mean_frag_lens_trunc(out->flens, mft.data());
+  else kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, o->fld, o->sd, mft.data());
+  if (int rc = kamd_ec_finalize(c, nullptr)) return rc;
+  kamd_eff_lens(target_lens, n_targets, mft.data(), out->eff_lens);
+  int32_t rounds = 0;
+  if (multi) { if (int rc = kamd_em_run_comm(c, comm, out->eff_lens, n_targets, 10000, 50, out->est_counts, out->alpha_before_zeroes, &rounds)) return rc; }
+  else if (int rc = kamd_em_run(c, nullptr, nullptr, nullptr, nullptr, 0, out->eff_lens, n_targets, 10000, 50, out->est_counts, out->alpha_before_zeroes, &rounds)) return rc;
+  if (out->tpm) kamd_counts_to_tpm(out->est_counts, out->eff_lens, n_targets, out->tpm);
+  out->n_processed = n_proc; out->em_rounds = rounds;
   return 0;
 }
