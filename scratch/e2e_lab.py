@@ -48,6 +48,8 @@ def main():
                 fo.write(open(p, "rb").read())
     print(f"wrote 2 x {os.path.getsize(f1)/1e9:.2f} GB in {time.time()-t0:.1f}s", flush=True)
     del sim; torch.cuda.empty_cache()
+    if len(sys.argv) > 3 and sys.argv[3] == "files-only":
+        return
     exe = os.path.join(B.ROOT, "kallisto_amd", "kallisto_amd_quant")
     def run(tag, files, cnt, threads=64, env=None, extra=()):
         e = dict(os.environ); e.update(env or {})
@@ -63,8 +65,6 @@ def main():
         rate = cnt / max(tm.get("reads", wall) - tm.get("idx", 0), 1e-9) / 1e6
         print(f"== {tag}: rc={p.returncode} wall={wall:.2f}s input->ECs {rate:.1f} M pairs/s", flush=True)
         for l in lines: print("   ", l[:400], flush=True)
-    for k in sys.argv[3:] if len(sys.argv) > 3 else []:
-        pass
     run("plain t64 (capped to the cgroup)", [f1, f2], n)
     run("plain t64 again", [f1, f2], n)
     run("plain KAMD_CPUS=12", [f1, f2], n, env={"KAMD_CPUS": "12"})
