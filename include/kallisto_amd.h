@@ -167,7 +167,8 @@ int kamd_pack_reads_device(kamd_ctx*, const char* d_seqs, const uint64_t* d_off,
  * sequence; a trailing '\r' is dropped as kseq does), and packs the sequences as kamd_pack_reads would: single-end -> item j =
  * record j, paired -> items 2j / 2j + 1 = record j of file 0 / file 1.  status != 0: the unit is NOT packed and the caller must
  * read this input with a general FASTA/FASTQ reader instead (multi-line records, FASTA, junk between records ...).
- * d_text[f]: device pointers, 16-byte aligned; n_bytes[f] < 2^32.  Runs on the context stream and synchronises it once.
+ * d_text[f]: device pointers, 16-byte aligned, readable up to 32 bytes behind n_bytes[f] (the packer loads whole dwords);
+ * n_bytes[f] < 2^32.  Runs on the context stream and synchronises it once.
  * A unit is what one host-to-device copy brings (tens of MB); a *batch* -- what kamd_pseudoalign is called on -- should be millions of
  * reads, so parsing and packing are separate: kamd_fastq_unit_parse checks a unit and notes where its sequences are (the text must
  * stay in place until the batch is packed), kamd_fastq_batch_pack packs the reads of all units parsed since the last batch, in

@@ -1372,15 +1372,53 @@ __global__ __launch_bounds__(BLOCK) void k_fq_records(FqFiles F, u64 n_records, 
     if (bad) { atomicAdd(&res->n_bad, bad); atomicMin(&res->first_bad, first); }
   }
 }
-__global__ void k_fq_pack(const u64* __restrict__ recs, u64 n_reads, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
-  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u64 r = gid / (u64)rec_words;
-  int w = (int)(gid % (u64)rec_words);
+// 2-bit codes and "not ACGT" flags of four bases held in one dword (byte i -> bits 2i.. of *code, bit i of the result), branch-free:
+// for A C G T (either case) the code is ((c >> 1) ^ (c >> 2)) & 3 = 0 1 2 3; anything else gets code 0 and its flag
+__device__ __forceinline__ u32 pack4(u32 w, u32* code) {
+  const u32 u = w & 0xDFDFDFDFu;   // (KmerIterator.cpp:12 masks with 0xDF)
+  auto eq = [](u32 x, u32 c) { const u32 y = x ^ (c * 0x01010101u); const u32 t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu; return ~(t | y | 0x7F7F7F7Fu); };   // 0x80 per equal byte
+  const u32 ok = eq(u, 'A') | eq(u, 'C') | eq(u, 'G') | eq(u, 'T');
+  const u32 c2 = ((w >> 1) ^ (w >> 2)) & 0x03030303u & ((ok >> 7) * 3u);   // codes of the valid bytes, 0 elsewhere
+  *code = (c2 & 3u) | ((c2 >> 6) & 0xCu) | ((c2 >> 12) & 0x30u) | ((c2 >> 18) & 0xC0u);
+  const u32 bad = ~ok & 0x80808080u;
+  return ((bad >> 7) & 1u) | ((bad >> 14) & 2u) | ((bad >> 21) & 4u) | ((bad >> 28) & 8u);
+}
+// One thread per 32 bases of a read: eight dwords of text in, two sequence words and one mask word out (the packed buffer was zeroed:
+// padding words stay 0, the has-N flag is OR-ed in by the rare thread that meets a base that is not ACGT).  The bytes behind a read's
+// end that the last thread loads belong to the record's '+' and quality lines -- always inside the text.
+__global__ __launch_bounds__(BLOCK) void k_fq_pack(const u64* __restrict__ recs, u64 n_reads, int groups, int seq_words, int rec_words, u32* out,
+                                                   uint16_t* out_len) {
+  const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 r = gid / (u64)groups;
+  const int g = (int)(gid % (u64)groups);
   if (r >= n_reads) return;
   const u64 rw = recs[r];
   const int L = (int)(rw >> 48);
-  out[gid] = pack_word_of(reinterpret_cast<const char*>((uintptr_t)(rw & 0xFFFFFFFFFFFFULL)), L, w, seq_words);
-  if (w == 0) out_len[r] = (uint16_t)L;
+  if (g == 0) out_len[r] = (uint16_t)L;
+  const int b0 = g * 32;
+  if (b0 >= L) return;
+  const char* p = reinterpret_cast<const char*>((uintptr_t)(rw & 0xFFFFFFFFFFFFULL)) + b0;
+  u32 lo = 0, hi = 0, mask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u32 w;
+    __builtin_memcpy(&w, p + 4 * j, 4);   // (unaligned: the hardware takes it as one load in the default access mode)
+    u32 code;
+    const u32 bad = pack4(w, &code);
+    if (j < 4) lo |= code << (8 * j); else hi |= code << (8 * (j - 4));
+    mask |= bad << (4 * j);
+  }
+  const int left = L - b0;   // bases of this group that belong to the read
+  if (left < 32) {
+    const u64 keep = (1ULL << (2 * left)) - 1;
+    lo &= (u32)keep; hi &= (u32)(keep >> 32);
+    mask &= (1u << left) - 1u;
+  }
+  u32* o = out + r * (u64)rec_words;
+  o[2 * g] = lo;
+  if (left > 16) o[2 * g + 1] = hi;
+  o[seq_words + g] = mask;
+  if (mask) atomicOr(&o[seq_words - 1], kamd::REC_FLAG_HAS_N);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2630,8 +2668,10 @@ extern "C" int kamd_fastq_batch_pack(kamd_ctx* c, kamd_fastq_unit* out) {
   const u64 total = n_reads * (u64)rec_words;
   if (int rc = c->fq_words.ensure(total * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->fq_len.ensure(n_reads * sizeof(uint16_t), 0, c->stream)) return rc;
-  hipLaunchKernelGGL(k_fq_pack, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)c->fq_recs.as<u64>(), n_reads, seq_words, rec_words,
-                     c->fq_words.as<u32>(), c->fq_len.as<uint16_t>());
+  const int groups = (out->max_len + 31) / 32;
+  HIPC(hipMemsetAsync(c->fq_words.p, 0, total * sizeof(u32), c->stream));
+  hipLaunchKernelGGL(k_fq_pack, dim3(grid_for(n_reads * (u64)groups, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)c->fq_recs.as<u64>(), n_reads, groups, seq_words,
+                     rec_words, c->fq_words.as<u32>(), c->fq_len.as<uint16_t>());
   HIPC(hipGetLastError());
   out->d_words = c->fq_words.as<u32>(); out->d_len = c->fq_len.as<uint16_t>();
   c->fq_batch_reads = 0; c->fq_batch_max_len = 0; c->fq_batch_files = 0;

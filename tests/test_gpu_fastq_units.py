@@ -67,6 +67,24 @@ def test_batch_of_several_units(ctx):
     assert ctx.fastq_batch_pack()[2] == 0                 # nothing left
 
 
+def test_every_byte_value_as_a_base(ctx):
+    """lower case is read like upper case, everything that is not ACGT is a masked base with code 0 -- for every byte value a FASTQ
+    sequence line can hold, at every position of a 32-base group"""
+    alphabet = bytes(b for b in range(1, 256) if b not in (10, 13))        # no line ends
+    reads = []
+    for shift in range(33):
+        body = (b"ACGT" * 9)[:shift] + alphabet
+        if body[0:1] in (b"@", b"+", b">"):                                 # (not as the first character: kseq would take it for a header)
+            body = b"A" + body
+        reads.append(body)
+    reads += [b"acgtnACGTN" * 7, b"a", b"n", b"tT" * 16, b"gG" * 16 + b"c"]
+    text = _fastq_bytes(reads, tricky_quals=False)
+    w, l, n, mx, st, _ = ctx.fastq_unit_pack([text], len(reads))
+    assert st == 0 and n == len(reads)
+    ew, el, emx = _expect(ctx, reads)
+    assert mx == emx and np.array_equal(l.cpu().numpy(), el) and np.array_equal(w.cpu().numpy(), ew)
+
+
 def test_tiny_and_unaligned_sizes(ctx):
     for n in [1, 2, 3, 17, 255, 256, 257]:
         reads = _reads(n, 100 + n, lo=1, hi=40)
