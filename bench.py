@@ -465,7 +465,8 @@ def main():
     words = torch.empty(n_gen * per * rec, dtype=torch.int32, device=dev)
     lens = torch.empty(n_gen * per, dtype=torch.int16, device=dev)
     chunk = 2_000_000
-    sample = None      # first pairs: CPU baseline + parity
+    sample = None      # first pairs: CPU baseline
+    psample = None     # first pairs: parity against the reference (independent of the CPU baseline)
     e2e_sample = None  # first pairs: front-end from FASTQ
     tail_sample = None # last pairs: parity of the tail
     want_head = 0
@@ -474,7 +475,9 @@ def main():
             want_head = max(want_head, min(args.cpu_sample, n_gen))
         if args.end_to_end:
             want_head = max(want_head, min(args.end_to_end, n_gen))
-    want_tail = min(args.parity_sample, n_gen) if (rank == 0 and world == 1 and not args.no_cpu_baseline and args.parity_sample) else 0
+        if args.parity_sample:
+            want_head = max(want_head, min(args.parity_sample, n_gen))
+    want_tail = min(args.parity_sample, n_gen) if (rank == 0 and world == 1 and args.parity_sample) else 0
     head1, head2, have_head = [], [], 0
     t0 = time.time()
     for s in range(0, n_gen, chunk):
@@ -497,6 +500,9 @@ def main():
         if args.cpu_sample and not args.no_cpu_baseline:
             k = min(args.cpu_sample, n_gen)
             sample = (h1[:k], h2[:k] if paired else None)
+        if args.parity_sample:
+            k = min(args.parity_sample, n_gen)
+            psample = (h1[:k], h2[:k] if paired else None)
         if args.end_to_end:
             k = min(args.end_to_end, n_gen)
             e2e_sample = (h1[:k], h2[:k] if paired else None)
@@ -796,13 +802,14 @@ def main():
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": rate_unit, "cores": threads, "kind": "reference",
                                    "sample": f"failed: {e}"}
+    if rank == 0 and world == 1 and psample is not None:
         # parity gate: the same reads through the HIP path and through the unmodified reference at -t 1
-        ks = min(k, args.parity_sample)
+        ks = psample[0].shape[0]
         log(f"parity: reference `dump_ec quant -t 1` on the first {ks} {unit_name} ...")
         try:
             ctx.reset()
             gres = ka.quant(ctx, opts, [(words[:ks * per * rec], lens[:per * ks], ks, L)], download_ecs=True)
-            out["parity_check"] = reference_parity(idx_path, sample[0][:ks], sample[1][:ks] if paired else None, gres, cli_extra)
+            out["parity_check"] = reference_parity(idx_path, psample[0], psample[1] if paired else None, gres, cli_extra)
         except Exception as e:
             out["parity_check"] = {"ok": False, "error": str(e)}
         if tail_sample is not None:

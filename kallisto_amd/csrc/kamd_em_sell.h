@@ -6,7 +6,7 @@
 // thousand entries), so the fixed cost per row pass dominates (measured on config #3: ~7 000 wavefront instructions per
 // group and round for 9 300 entry visits).  Here every direction of a group becomes a SLICED ELLPACK matrix instead:
 //   * the segments (rows, resp. columns) are renumbered by decreasing length and cut into slices of 64 lanes; lane l of a
-//     slice walks its segment's entries at ell[j * 64 + l], j < width of the slice (the longest segment in it); shorter
+//     slice walks its segment's entries j < width of the slice (the longest segment in it; four trips to a 64-bit word, below); shorter
 //     segments are padded with a sentinel index whose value is 0.0.  One trip of the inner loop = 64 entries, no row
 //     pointers, no reductions, and the lengths inside a slice are nearly equal because of the sort;
 //   * a segment with more than 64 entries is SPLIT over nv = min(64, ceil(len / 64)) adjacent lanes of one slice
@@ -28,6 +28,10 @@ namespace kamd_em_sell {
 static const uint32_t SELL_LANES = 64;
 static const uint32_t SELL_PAD = 0xFFFFu;         // padding entry in the u16 streams (mapped to the zero slot when a group is loaded)
 static const uint32_t SELL_META_WORDS = 64;       // u32 words of lane metadata in front of a slice that has split segments
+// The entries of a slice are stored four trips to a 64-bit word: lane l's entries j = 4q .. 4q + 3 are the u16 quarters of word
+// q * 64 + l, so the kernel fetches four indices with ONE conflict-free 8-byte LDS read per lane (an index read per entry was a
+// quarter of the kernel's LDS instructions).  A slice therefore occupies quad_width(width) * 64 u16; the trips beyond `width` hold padding.
+KAMD_HD uint32_t quad_width(uint32_t width) { return (width + 3u) & ~3u; }
 // lane metadata: segment id | reach << 16 (lanes below that belong to the same segment) | LAST << 23 | ACTIVE << 24
 static const uint32_t META_LAST = 1u << 23, META_ACTIVE = 1u << 24;
 
@@ -141,7 +145,7 @@ KAMD_HD LayoutSize layout_group(const uint32_t* len, uint32_t n, uint32_t cap, S
     }
     const uint32_t first_seg = has_meta ? 0u : n_split + (lo - split_lanes);
     sink.slice(si, off | (has_meta ? DESC_META : 0u), width | (first_seg << 16));
-    off += (has_meta ? 2 * SELL_META_WORDS : 0u) + width * SELL_LANES;
+    off += (has_meta ? 2 * SELL_META_WORDS : 0u) + quad_width(width) * SELL_LANES;
   }
 #undef hist
 #undef start
@@ -189,7 +193,7 @@ KAMD_HD uint64_t entry_pos(const uint32_t* desc, uint32_t lane, uint32_t vlen, u
   const uint32_t ln = lane + v, s = ln / SELL_LANES;
   const uint32_t d0 = desc[2 * s];
   const uint64_t base = (uint64_t)(d0 & ~DESC_META) + ((d0 & DESC_META) ? 2 * SELL_META_WORDS : 0u);
-  return base + (uint64_t)j * SELL_LANES + (ln % SELL_LANES);
+  return base + (uint64_t)(j / 4) * (4 * SELL_LANES) + (uint64_t)(ln % SELL_LANES) * 4 + (j % 4);
 }
 
 inline int from_csr_plan(const kamd_em_local::Plan& C, uint64_t budget_bytes, Plan* P, uint32_t cap = SELL_LANES) {
@@ -260,7 +264,7 @@ inline void host_pass(const uint32_t* desc, uint32_t n_slices, const uint16_t* e
     double lane_sum[SELL_LANES];
     for (uint32_t l = 0; l < SELL_LANES; l++) {
       double S = 0.0;
-      for (uint32_t j = 0; j < width; j++) { const uint32_t ix = e[j * SELL_LANES + l]; S += src[ix == SELL_PAD ? zero : ix]; }
+      for (uint32_t j = 0; j < width; j++) { const uint32_t ix = e[(j / 4) * (4 * SELL_LANES) + l * 4 + (j % 4)]; S += src[ix == SELL_PAD ? zero : ix]; }
       lane_sum[l] = S;
     }
     if (!has_meta) {

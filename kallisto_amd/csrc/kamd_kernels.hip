@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/kallisto_amd.h"
@@ -2199,6 +2200,8 @@ struct kamd_ctx {
   float last_finalize_ms = 0.f; u64 last_fin_records = 0, last_fin_stream_words = 0, last_fin_cand_words = 0;
   hipStream_t em_stream = nullptr;
   hipStream_t em_side_stream = nullptr; hipEvent_t em_ev_fork = nullptr, em_ev_join = nullptr;   // component-local EM: the small size class runs beside the large one
+  void* em_pin = nullptr; size_t em_pin_bytes = 0;   // component-local EM: pinned, mapped host memory (change counts the kernels publish, result staging)
+  DBuf em_clk;                                       // diagnostic phase clocks (KAMD_EM_CLK)
   int items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
@@ -2497,6 +2500,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->em_side_stream) { (void)hipStreamSynchronize(c->em_side_stream); (void)hipStreamDestroy(c->em_side_stream); }
   if (c->em_ev_fork) (void)hipEventDestroy(c->em_ev_fork);
   if (c->em_ev_join) (void)hipEventDestroy(c->em_ev_join);
+  if (c->em_pin) (void)hipHostFree(c->em_pin);
+  c->em_clk.release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
@@ -3543,34 +3548,61 @@ struct EmSellDev {
   const u64* cw; const double* single; const double* eff;
 };
 constexpr int EMS_MAX_BLOCK = 1024;
-// sum over the lane's entries of one slice
-__device__ __forceinline__ double ems_slice_sum(const uint16_t* e, u32 width, const double* src) {
+// sum over the lane's entries of one slice; e: the lane's first 64-bit word of four u16 indices (kamd_em_sell.h: word q of the lane at e + q * 64)
+// EXP != 0: timing experiments (KAMD_EM_EXP, results are garbage): 1 = gathers at conflict-free addresses (indices still loaded),
+// 3 = no gathers (indices only); 4 (no divisions) and 5 (no block barriers) are applied by the caller
+template <int EXP>
+__device__ __forceinline__ double ems_slice_sum(const u64* e, u32 width, const double* src, u32 n_src) {
+  const u32 cf = (u32)lane_id() % n_src;   // (experiments only)
+  u32 sink = 0;
+  auto val_at = [&](u32 ix) -> double {
+    if constexpr (EXP == 1) { sink += ix; return src[cf]; }
+    else if constexpr (EXP == 3) return __hiloint2double(0x3ff00000, (int)ix);
+    else return src[ix];
+  };
   double S = 0.0;
   u32 j = 0;
   for (; j + 8 <= width; j += 8) {
-    u32 ix[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) ix[q] = e[(size_t)(j + q) * 64];
-    double v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = src[ix[q]];
-#pragma unroll
-    for (int q = 0; q < 8; q++) S += v[q];
+    const u64 w0 = e[(size_t)(j >> 2) * 64], w1 = e[(size_t)((j >> 2) + 1) * 64];
+    const u32 a0 = (u32)w0, a1 = (u32)(w0 >> 32), b0 = (u32)w1, b1 = (u32)(w1 >> 32);
+    const double v0 = val_at(a0 & 0xFFFFu), v1 = val_at(a0 >> 16), v2 = val_at(a1 & 0xFFFFu), v3 = val_at(a1 >> 16);
+    const double v4 = val_at(b0 & 0xFFFFu), v5 = val_at(b0 >> 16), v6 = val_at(b1 & 0xFFFFu), v7 = val_at(b1 >> 16);
+    S += v0; S += v1; S += v2; S += v3; S += v4; S += v5; S += v6; S += v7;
   }
-  for (; j + 4 <= width; j += 4) {
-    const u32 i0 = e[(size_t)j * 64], i1 = e[(size_t)(j + 1) * 64], i2 = e[(size_t)(j + 2) * 64], i3 = e[(size_t)(j + 3) * 64];
-    const double v0 = src[i0], v1 = src[i1], v2 = src[i2], v3 = src[i3];
-    S += v0; S += v1; S += v2; S += v3;
+  if (j < width) {   // 1 .. 7 entries left: one or two words; a word's trips beyond the width hold padding (the zero slot) and are not read
+    const u32 rem = width - j;
+    const u64 w0 = e[(size_t)(j >> 2) * 64];
+    const u64 w1 = rem > 4 ? e[(size_t)((j >> 2) + 1) * 64] : 0ULL;
+    const u32 a0 = (u32)w0, a1 = (u32)(w0 >> 32), b0 = (u32)w1, b1 = (u32)(w1 >> 32);
+    const double v0 = val_at(a0 & 0xFFFFu);
+    const double v1 = rem > 1 ? val_at(a0 >> 16) : 0.0;
+    const double v2 = rem > 2 ? val_at(a1 & 0xFFFFu) : 0.0;
+    const double v3 = rem > 3 ? val_at(a1 >> 16) : 0.0;
+    S += v0;
+    if (rem > 1) S += v1;
+    if (rem > 2) S += v2;
+    if (rem > 3) S += v3;
+    if (rem > 4) {
+      const double v4 = val_at(b0 & 0xFFFFu);
+      const double v5 = rem > 5 ? val_at(b0 >> 16) : 0.0;
+      const double v6 = rem > 6 ? val_at(b1 & 0xFFFFu) : 0.0;
+      S += v4;
+      if (rem > 5) S += v5;
+      if (rem > 6) S += v6;
+    }
   }
-  for (; j < width; j++) S += src[e[(size_t)j * 64]];
+  if constexpr (EXP != 0) { if (sink == 0xFFFFFFFFu) S += 1.0; }
   return S;
 }
 // One team of NW wavefronts iterates one group out of its own piece of LDS.  WAVE_TEAM: the team is a single wavefront (several
 // teams share a workgroup), so the two hand-overs of a round -- g after the rows pass, a / alpha after the columns pass -- need no
 // block barrier: a wavefront's LDS operations complete in order, the fence only keeps the compiler from moving them.
-template <bool WAVE_TEAM>
-__device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsigned char* smem, u32 tid, u32 nthr, double* alpha, double* a,
-                                                 int n_rounds, int clamp, int* s_hist) {
+// alpha_in / a_in -> alpha_out / a_out (the same vectors, or the other half of a ping-pong pair: the input then stays what it was, the
+// checkpoint a speculative chunk is replayed from).  clk: diagnostic, phase clocks of every wavefront in round EMS_CLK_ROUND.
+constexpr int EMS_CLK_ROUND = 8, EMS_CLK_WORDS = 16;
+template <bool WAVE_TEAM, int EXP = 0>
+__device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsigned char* smem, u32 tid, u32 nthr, const double* alpha, const double* a,
+                                                 double* alpha_out, double* a_out, int n_rounds, int clamp, int* s_hist, long long* clk = nullptr) {
   namespace L = kamd_em_sell;
   const int lane = lane_id();
   const u32 wv = WAVE_TEAM ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = WAVE_TEAM ? 1u : nthr >> 6;
@@ -3579,7 +3611,7 @@ __device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsi
   const u64 re0 = P.rell_base[g], ce0 = P.cell_base[g];
   const u32 nru = (u32)(P.rell_base[g + 1] - re0), ncu = (u32)(P.cell_base[g + 1] - ce0);
   auto team_sync = [] {
-    if (WAVE_TEAM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (WAVE_TEAM || EXP == 5) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     else __syncthreads();
   };
   // the layout kamd_em_sell::group_bytes() prices
@@ -3604,13 +3636,19 @@ __device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsi
   team_sync();
   double* al = s_al0; double* av = s_a0; double* aln = s_al1; double* avn = s_a1;
   for (int r = 0; r < n_rounds; r++) {
+    const bool tick = clk && r == EMS_CLK_ROUND && lane == 0;
+    long long w0 = 0;
+    if (tick) { clk[0] = clock64(); w0 = wall_clock64(); }
     // rows: S_e over the row's transcripts, then g_e = count_e / S_e (rows the reference skips get 0: count 0, :133-135;
     // denom below denorm_min, :156-158)
     for (u32 s = wv; s < nrs; s += NW) {
       const u32 d0 = s_rdesc[2 * s], d1 = s_rdesc[2 * s + 1];
       const bool meta = (d0 & L::DESC_META) != 0;
       const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
-      double S = ems_slice_sum(s_rell + off + (meta ? 2 * L::SELL_META_WORDS : 0u) + lane, width, av);
+      const bool tk = tick && s == wv;
+      if (tk) clk[12] = clock64();
+      double S = ems_slice_sum<EXP>(reinterpret_cast<const u64*>(s_rell + off + (meta ? 2 * L::SELL_META_WORDS : 0u)) + lane, width, av, nT);
+      if (tk) { clk[13] = clock64(); clk[14] = (long long)(width | (meta ? 0x10000u : 0u)); }
       u32 seg = (d1 >> 16) + (u32)lane; bool fin = seg < nR;
       if (meta) {
         const u32 w = reinterpret_cast<const u32*>(s_rell + off)[lane];
@@ -3620,65 +3658,106 @@ __device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsi
       if (fin) {
         const u64 cwv = s_cw[seg];
         const u32 cnt = (u32)cwv, wc = (u32)(cwv >> 32);
-        s_g[seg] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+        if constexpr (EXP == 4) s_g[seg] = (double)cnt * S;
+        else s_g[seg] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
       }
+      if (tk) clk[15] = clock64();
     }
+    if (tick) clk[1] = clock64();
     team_sync();
+    if (tick) clk[2] = clock64();
     // columns: next_t = single_t + a_t * sum of g over the transcript's rows, and the convergence test of :176-199
     int ch = 0;
     for (u32 s = wv; s < ncs; s += NW) {
       const u32 d0 = s_cdesc[2 * s], d1 = s_cdesc[2 * s + 1];
       const bool meta = (d0 & L::DESC_META) != 0;
       const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
-      double acc = ems_slice_sum(s_cell + off + (meta ? 2 * L::SELL_META_WORDS : 0u) + lane, width, s_g);
+      const bool tk = tick && s == wv;
+      if (tk) clk[8] = clock64();
+      double acc = ems_slice_sum<EXP>(reinterpret_cast<const u64*>(s_cell + off + (meta ? 2 * L::SELL_META_WORDS : 0u)) + lane, width, s_g, nR);
+      if (tk) { clk[9] = clock64(); clk[10] = (long long)(width | (meta ? 0x10000u : 0u)); }
       u32 seg = (d1 >> 16) + (u32)lane; bool fin = seg < nT;
       if (meta) {
         const u32 w = reinterpret_cast<const u32*>(s_cell + off)[lane];
         acc = pm_scan_seg(acc, (int)((w >> 16) & 0x7Fu), lane);
         seg = w & 0xFFFFu; fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
       }
+      bool chg = false;
       if (fin) {
         const double at = av[seg], cur = al[seg];
         const double nx = s_single[seg] + at * acc;
-        if (nx > 1e-2 && (fabs(nx - cur) / nx) > 1e-2) ++ch;
+        // :177-179 `fabs(next - alpha) / next > 1e-2`, without the division unless the quotient is within 1e-7 of the threshold (the
+        // quotient's rounding error is 1e-16: outside that band the product test decides the same way as the reference's quotient)
+        const double dd = fabs(nx - cur);
+        bool moved = dd > 1.0000001e-2 * nx;
+        if (dd > 0.9999999e-2 * nx && !moved) moved = dd / nx > 1e-2;
+        chg = nx > 1e-2 && moved;
         aln[seg] = nx;
-        avn[seg] = nx / s_eff[seg];
+        if constexpr (EXP == 4) avn[seg] = nx * s_eff[seg];
+        else avn[seg] = nx / s_eff[seg];
       }
+      ch += __popcll(__ballot(chg));   // (wave-uniform: a scalar count, no cross-lane reduction)
+      if (tk) clk[11] = clock64();
     }
-    if (__ballot(ch != 0)) {
-      int wsum = ch;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
-      if (lane == 0) atomicAdd(&s_hist[r], wsum);
-    }
+    if (ch && lane == 0) atomicAdd(&s_hist[r], ch);
+    if (tick) clk[3] = clock64();
     team_sync();
+    if (tick) { clk[4] = clock64(); clk[5] = (long long)(nrs | (ncs << 16)); clk[6] = (long long)(nru | ((u64)ncu << 32)); clk[7] = wall_clock64() - w0; }
     double* t1 = al; al = aln; aln = t1;
     double* t2 = av; av = avn; avn = t2;
   }
-  for (u32 i = tid; i < nT; i += nthr) { alpha[t0 + i] = al[i]; a[t0 + i] = av[i]; }
+  for (u32 i = tid; i < nT; i += nthr) { alpha_out[t0 + i] = al[i]; a_out[t0 + i] = av[i]; }
+}
+// The stop rule of EMAlgorithm::run (:202-205) on the change counts of the PREVIOUS chunk of rounds: a chunk that was launched
+// speculatively behind the one the run stops in has nothing to do (its input stays the checkpoint the host replays from).
+// Block 0 also hands the previous chunk's counts to the host (pinned, mapped memory the host polls: no stream synchronisation per chunk).
+struct EmsPrev { const int* hist; int n; int base; int min_rounds; int* host_hist; int* host_seq; int seq; };
+__device__ __forceinline__ bool ems_prev_stopped(const EmsPrev& v, int* s_flag) {
+  if (!v.hist) return false;
+  if (threadIdx.x < 64) {
+    const int i = (int)threadIdx.x;
+    const int h = i < v.n ? v.hist[i] : 1;
+    const bool stop = i < v.n && h == 0 && v.base + i > v.min_rounds;
+    const u64 m = __ballot(stop);
+    if (blockIdx.x == 0 && v.host_hist) {
+      if (i < v.n) v.host_hist[i] = h;
+      __threadfence_system();
+      if (i == 0) __hip_atomic_store(v.host_seq, v.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (i == 0) *s_flag = m != 0;
+  }
+  __syncthreads();
+  return *s_flag != 0;
 }
 // one workgroup per group (the large size class, or every group when there is only one class): groups g_first + blockIdx.x
-__global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, u32 g_first, double* alpha, double* a, int n_rounds, int clamp, int* hist) {
+template <bool CLK, int EXP = 0>
+__global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, u32 g_first, const double* alpha, const double* a, double* alpha_out, double* a_out,
+                                                           int n_rounds, int clamp, int* hist, EmsPrev prev, long long* clk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
   __shared__ int s_hist[EML_MAX_ROUNDS];
+  __shared__ int s_stop;
+  if (ems_prev_stopped(prev, &s_stop)) return;
   if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
   __syncthreads();
-  ems_group_rounds<false>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, n_rounds, clamp, s_hist);
+  ems_group_rounds<false, EXP>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist,
+                          CLK ? clk + ((size_t)blockIdx.x * (EMS_MAX_BLOCK / 64) + (threadIdx.x >> 6)) * EMS_CLK_WORDS : nullptr);
   __syncthreads();
   if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 // one WAVEFRONT per group (the small size class): the wavefronts of a workgroup run their groups independently -- no block barrier
 // inside the rounds, so a CU holds a few dozen groups at different points of their rounds and the LDS pipe always has work
 constexpr int EMS_WAVE_TEAMS = 4;   // groups per workgroup
-__global__ __launch_bounds__(64 * EMS_WAVE_TEAMS) void k_em_sell_wave(EmSellDev P, u32 n_small, u32 team_bytes, double* alpha, double* a, int n_rounds,
-                                                                        int clamp, int* hist) {
+__global__ __launch_bounds__(64 * EMS_WAVE_TEAMS) void k_em_sell_wave(EmSellDev P, u32 n_small, u32 team_bytes, const double* alpha, const double* a,
+                                                                        double* alpha_out, double* a_out, int n_rounds, int clamp, int* hist, EmsPrev prev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
   __shared__ int s_hist[EML_MAX_ROUNDS];
+  __shared__ int s_stop;
+  if (ems_prev_stopped(prev, &s_stop)) return;
   if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
   __syncthreads();
   const u32 team = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const u32 g = blockIdx.x * EMS_WAVE_TEAMS + team;
-  if (g < n_small) ems_group_rounds<true>(P, g, ems_smem + (size_t)team * team_bytes, (u32)lane_id(), 64u, alpha, a, n_rounds, clamp, s_hist);
+  if (g < n_small) ems_group_rounds<true>(P, g, ems_smem + (size_t)team * team_bytes, (u32)lane_id(), 64u, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist);
   __syncthreads();
   if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
@@ -3735,7 +3814,7 @@ __device__ kamd_em_sell::LayoutSize sell_layout_wave(const u32* __restrict__ len
       if ((pos % L::SELL_LANES) + nv > L::SELL_LANES) {   // does not fit: close the slice, the rest of its lanes stay inactive
         sink.meta(off, lane, mw);
         if (lane == 0) sink.slice(closed, off | L::DESC_META, width);
-        off += 2 * L::SELL_META_WORDS + width * L::SELL_LANES; ++closed; width = 0; mw = 0;
+        off += 2 * L::SELL_META_WORDS + L::quad_width(width) * L::SELL_LANES; ++closed; width = 0; mw = 0;
         pos = (pos / L::SELL_LANES + 1) * L::SELL_LANES;
       }
       if (Sink::wants_segments && lane == b) sink.seg(c0 + b, n_split, pos, nv, vl);
@@ -3749,7 +3828,7 @@ __device__ kamd_em_sell::LayoutSize sell_layout_wave(const u32* __restrict__ len
       if (pos % L::SELL_LANES == 0) {                        // exactly full
         sink.meta(off, lane, mw);
         if (lane == 0) sink.slice(closed, off | L::DESC_META, width);
-        off += 2 * L::SELL_META_WORDS + width * L::SELL_LANES; ++closed; width = 0; mw = 0;
+        off += 2 * L::SELL_META_WORDS + L::quad_width(width) * L::SELL_LANES; ++closed; width = 0; mw = 0;
       }
     }
   }
@@ -3781,13 +3860,13 @@ __device__ kamd_em_sell::LayoutSize sell_layout_wave(const u32* __restrict__ len
     if (p >= split_lanes && p < total_lanes) mw = (n_split + (p - split_lanes)) | L::META_LAST | L::META_ACTIVE;
     sink.meta(off, lane, mw);
     if (lane == 0) sink.slice(closed, off | L::DESC_META, width);
-    off += 2 * L::SELL_META_WORDS + width * L::SELL_LANES; ++closed;
+    off += 2 * L::SELL_META_WORDS + L::quad_width(width) * L::SELL_LANES; ++closed;
   }
   for (u32 s0 = closed; s0 < n_slices; s0 += 64) {
     const u32 si = s0 + (u32)lane;
     u32 w = 0;
     if (si < n_slices) w = len_at(si * L::SELL_LANES);
-    const u32 mine = w * L::SELL_LANES;
+    const u32 mine = L::quad_width(w) * L::SELL_LANES;
     const u32 incl = wave_incl_scan(mine);
     if (si < n_slices) sink.slice(si, off + (incl - mine), w | ((n_split + (si * L::SELL_LANES - split_lanes)) << 16));
     off += (u32)__shfl((int)incl, 63, 64);
@@ -3874,7 +3953,7 @@ __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
 // target_small entries (P->n_small of them, first), the others in groups of about `target` entries.
 int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
                           const double* eff_lens, u64 T, u64 budget, u64 target, kamd_em_local::Plan* P, EmLocalDev* dev,
-                          kamd_em_local::BuildArgs* args_out = nullptr, u32 small_limit = 0, u64 target_small = 0) {
+                          kamd_em_local::BuildArgs* args_out = nullptr, u32 small_limit = 0, u64 target_small = 0, bool host_maps = true) {
   namespace L = kamd_em_local;
   if (nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
   // component labels (smallest transcript id of the component): min-label propagation + pointer jumping
@@ -3982,11 +4061,13 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   hipLaunchKernelGGL(k_eml_step<7>, dim3(grid_for(ng, BLOCK)), dim3(BLOCK), 0, c->stream, A, (u64)ng);
   hipLaunchKernelGGL(k_eml_step<8>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   HIPC(hipGetLastError());
-  // what the host needs for the final scatter
-  P->tr_id.resize(M); P->single_all.resize(T);
-  if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), A.tr_id, M * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipMemcpyAsync(P->single_all.data(), A.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+  // what the host needs for the final scatter (a single rank scatters on the device: em_sell_drive_async)
+  if (host_maps) {
+    P->tr_id.resize(M); P->single_all.resize(T);
+    if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), A.tr_id, M * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(P->single_all.data(), A.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
   *dev = EmLocalDev{(const u32*)(pb + p_rb), (const u32*)(pb + p_tb), (const u64*)(pb + p_zb), (const u32*)(pb + p_rp), (const u32*)(pb + p_cp),
                     (const uint16_t*)(pb + p_rt), (const uint16_t*)(pb + p_cr), (const u64*)(pb + p_cw), (const double*)(pb + p_sg),
                     (const double*)(pb + p_ef), (const u32*)(pb + p_id)};
@@ -4039,6 +4120,7 @@ struct SellCache {
   bool valid = false;
   const u64* d_ec_off = nullptr; const u32* d_ec_ids = nullptr; u64 n_ecs = 0, nnz = 0, T = 0, generation = 0;
   int split_len = 0, group_div = 0, small_nnz = 0;
+  bool host_maps = false;   // P.tr_id / P.single_all were read back (the host-side scatter of several ranks needs them)
   kamd_em_sell::Plan P;      // host part (tr_id, single_all, bases)
   EmSellDev dev{};           // device part, in ctx->ems_plan
   u32* row_final = nullptr; u32* mslot = nullptr; double* single_all = nullptr; double* d_eff = nullptr;   // in ctx->ems_maps
@@ -4047,12 +4129,12 @@ struct SellCache {
 // ---- the sliced-ELLPACK form: device plan + backend of kamd_em_local::run --------------------------------------------------
 struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0, team_bytes = 0; int block = 256;
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int exp = 0;   // exp: timing experiment (KAMD_EM_EXP)
+  double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr; double* d_out = nullptr;
   std::vector<double> h_alpha; int err = 0;
   const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
   EmSellGpu(kamd_ctx* ctx, const kamd_em_sell::Plan& p) : c(ctx), P(p) {}
-  int setup(int chunk, const double* d_eff_new);
+  int setup(int hist_ints, const double* d_eff_new, u64 T_out);
   void checkpoint() {
     if (err) return;
     if (hipMemcpyAsync(d_ck_alpha, d_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
@@ -4063,19 +4145,39 @@ struct EmSellGpu {
     if (hipMemcpyAsync(d_alpha, d_ck_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
         hipMemcpyAsync(d_a, d_ck_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
   }
+  // n rounds from (al_in, a_in) to (al_out, a_out) for every group; change counts of the rounds added to d_h (device, zeroed by the caller) if given
+  int launch(int n, int clamp, const double* al_in, const double* a_in, double* al_out, double* a_out, int* d_h, const EmsPrev& prev, long long* clk = nullptr) {
+    if (n <= 0 || n > EML_MAX_ROUNDS) return -104;
+    // the two size classes run side by side: small groups (one wavefront each) on a second stream, forked from and joined to the context stream
+    const u32 n_big = P.n_groups - P.n_small;
+    const bool fork = P.n_small && n_big;
+    if (fork && (hipEventRecord(ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return -104;
+    if (n_big) {
+#define KAMD_EMS_LAUNCH(C, E) hipLaunchKernelGGL((k_em_sell<C, E>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
+      if (clk) KAMD_EMS_LAUNCH(true, 0);
+      else switch (exp) {
+        case 1: KAMD_EMS_LAUNCH(false, 1); break;
+        case 3: KAMD_EMS_LAUNCH(false, 3); break;
+        case 4: KAMD_EMS_LAUNCH(false, 4); break;
+        case 5: KAMD_EMS_LAUNCH(false, 5); break;
+        default: KAMD_EMS_LAUNCH(false, 0);
+      }
+#undef KAMD_EMS_LAUNCH
+    }
+    EmsPrev prev_w = prev;
+    if (n_big) prev_w.host_hist = nullptr;   // (one kernel reports the previous chunk's counts to the host: the workgroup kernel if it runs)
+    if (P.n_small) hipLaunchKernelGGL(k_em_sell_wave, dim3((P.n_small + EMS_WAVE_TEAMS - 1) / EMS_WAVE_TEAMS), dim3(64 * EMS_WAVE_TEAMS), (size_t)EMS_WAVE_TEAMS * team_bytes,
+                                      fork ? side : c->stream, dev, P.n_small, (u32)team_bytes, al_in, a_in, al_out, a_out, n, clamp, d_h, prev_w);
+    if (hipGetLastError() != hipSuccess) return -104;
+    if (fork && (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(c->stream, ev_join, 0) != hipSuccess)) return -104;
+    return 0;
+  }
+  // the backend interface of kamd_em_local::run (several ranks): in place, the host reads the counts after every chunk
   void run(int n, int clamp, int* hist) {
     if (err || n <= 0) return;
     if (n > EML_MAX_ROUNDS) { err = -104; return; }
     if (hist && hipMemsetAsync(d_hist, 0, (size_t)n * sizeof(int), c->stream) != hipSuccess) { err = -104; return; }
-    // the two size classes run side by side: small groups (one wavefront each) on a second stream, forked from and joined to the context stream
-    const u32 n_big = P.n_groups - P.n_small;
-    const bool fork = P.n_small && n_big;
-    if (fork && (hipEventRecord(ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) { err = -104; return; }
-    if (n_big) hipLaunchKernelGGL(k_em_sell, dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
-    if (P.n_small) hipLaunchKernelGGL(k_em_sell_wave, dim3((P.n_small + EMS_WAVE_TEAMS - 1) / EMS_WAVE_TEAMS), dim3(64 * EMS_WAVE_TEAMS), (size_t)EMS_WAVE_TEAMS * team_bytes,
-                                      fork ? side : c->stream, dev, P.n_small, (u32)team_bytes, d_alpha, d_a, n, clamp, hist ? d_hist : nullptr);
-    if (hipGetLastError() != hipSuccess) { err = -104; return; }
-    if (fork && (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(c->stream, ev_join, 0) != hipSuccess)) { err = -104; return; }
+    if (int rc = launch(n, clamp, d_alpha, d_a, d_alpha, d_a, hist ? d_hist : nullptr, EmsPrev{})) { err = rc; return; }
     if (hist && part) {
       if (hipStreamSynchronize(c->stream) != hipSuccess) { err = -104; return; }
       if (part->cb(part->user, (int32_t*)d_hist, n)) { err = -103; return; }
@@ -4090,16 +4192,27 @@ struct EmSellGpu {
     return h_alpha;
   }
 };
-int EmSellGpu::setup(int chunk, const double* d_eff_new) {
+int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
   Carver sv;
-  const size_t o_al = sv.take(M * 8 + 8), o_a = sv.take(M * 8 + 8), o_cka = sv.take(M * 8 + 8), o_ckb = sv.take(M * 8 + 8), o_h = sv.take((size_t)chunk * 4 + 8);
+  // the two alpha vectors (and the two a vectors) lie back to back: a ping-pong pair, and one copy brings both to the host
+  const size_t o_al = sv.take(2 * M * 8 + 8), o_a = sv.take(2 * M * 8 + 8), o_h = sv.take((size_t)hist_ints * 4 + 8), o_out = sv.take(2 * T_out * 8 + 8);
   if (int rc = c->pm_b.ensure(sv.off, 0, c->stream)) return rc;
   char* sb = (char*)c->pm_b.p;
-  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = (double*)(sb + o_cka); d_ck_a = (double*)(sb + o_ckb); d_hist = (int*)(sb + o_h);
+  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = d_alpha + M; d_ck_a = d_a + M; d_hist = (int*)(sb + o_h); d_out = (double*)(sb + o_out);
   if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, d_eff_new, M, 1.0 / (double)P.T);
   HIPC(hipGetLastError());
   lds = (size_t)P.max_group_bytes;
-  if (P.n_groups > P.n_small) HIPC(hipFuncSetAttribute((const void*)k_em_sell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (P.n_groups > P.n_small) {
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (const char* e = getenv("KAMD_EM_EXP")) {
+      exp = atoi(e);
+      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+  }
   if (P.n_small) {
     team_bytes = ((size_t)P.max_small_bytes + 15) & ~(size_t)15;
     HIPC(hipFuncSetAttribute((const void*)k_em_sell_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(EMS_WAVE_TEAMS * team_bytes)));
@@ -4112,15 +4225,139 @@ int EmSellGpu::setup(int chunk, const double* d_eff_new) {
   }
   return 0;
 }
+// back to transcript space on the device: a transcript outside m-space keeps its singleton count from round 1 on (0 if in no set)
+__global__ void k_em_scatter(const u32* __restrict__ mslot, const double* __restrict__ single_all, const double* __restrict__ fin,
+                             const double* __restrict__ before, u64 T, int have_final, double* out_alpha, double* out_abz) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const u32 ms = mslot[t];
+  const double sa = single_all[t];
+  out_alpha[t] = ms != 0xFFFFFFFFu ? fin[ms] : sa;
+  out_abz[t] = have_final ? (ms != 0xFFFFFFFFu ? before[ms] : sa) : 0.0;
+}
+// hands the change counts of the LAST chunk a run can have to the host (no chunk follows it that would)
+__global__ void k_em_publish(EmsPrev prev) {
+  __shared__ int s_stop;
+  (void)ems_prev_stopped(prev, &s_stop);
+}
+// The loop control of EMAlgorithm::run (:112-223) for ONE rank, without a stream synchronisation per chunk of rounds: the chunks
+// ping-pong between two copies of (alpha, a) -- the input of a chunk IS the checkpoint it is replayed from --, chunk k + 1 is queued
+// while chunk k runs, evaluates the stop rule on chunk k's change counts itself (and returns at once if the run stops in k) and
+// publishes them to pinned host memory, which the host polls.  Then: replay up to the stop round, the final round with the clamp
+// (:212-221), the scatter to transcript space, ONE copy to the host.
+int em_sell_drive_async(kamd_ctx* c, EmSellGpu& B, const SellCache& K, u64 T, int n_iter, int min_rounds, double* alpha_out, double* abz_out, int* rounds_out) {
+  const int CH = EML_MAX_ROUNDS;
+  if (getenv("KAMD_EM_EXP")) { n_iter = std::min(n_iter, 1280); min_rounds = 1 << 30; }   // timing experiments: a fixed number of rounds, no stop
+  const int n_chunks = std::max(1, (n_iter + CH - 1) / CH);
+  // pinned, mapped host memory: change counts per chunk | sequence word | result staging
+  const size_t hist_ints = (size_t)(n_chunks + 1) * CH;
+  const size_t need = hist_ints * 4 + 256 + 2 * T * 8 + 256;
+  if (c->em_pin_bytes < need) {
+    if (c->em_pin) { HIPC(hipStreamSynchronize(c->stream)); HIPC(hipHostFree(c->em_pin)); c->em_pin = nullptr; c->em_pin_bytes = 0; }
+    HIPC(hipHostMalloc(&c->em_pin, need, hipHostMallocMapped));
+    c->em_pin_bytes = need;
+  }
+  int* h_hist = (int*)c->em_pin;
+  int* h_seq = h_hist + hist_ints;
+  double* h_out = (double*)((char*)c->em_pin + hist_ints * 4 + 256);
+  void* dp = nullptr;
+  HIPC(hipHostGetDevicePointer(&dp, c->em_pin, 0));
+  int* d_hh = (int*)dp; int* d_seq = d_hh + hist_ints;
+  __atomic_store_n(h_seq, 0, __ATOMIC_RELEASE);
+  HIPC(hipMemsetAsync(B.d_hist, 0, (size_t)n_chunks * CH * sizeof(int), c->stream));
+  double* al[2] = {B.d_alpha, B.d_ck_alpha};
+  double* av[2] = {B.d_a, B.d_ck_a};
+  auto prev_of = [&](int k) {   // what chunk k (or the publisher behind the last chunk) is told about chunk k - 1
+    if (k == 0) return EmsPrev{};
+    const int pb = (k - 1) * CH;
+    return EmsPrev{B.d_hist + (size_t)(k - 1) * CH, std::min(CH, n_iter - pb), pb, min_rounds, d_hh + (size_t)(k - 1) * CH, d_seq, k};
+  };
+  // diagnostic: KAMD_EM_CLK=<file> -> phase clocks of every wavefront in one round of the first chunk
+  const char* clk_path = getenv("KAMD_EM_CLK");
+  long long* d_clk = nullptr; size_t clk_words = 0;
+  if (clk_path && *clk_path && B.P.n_groups > B.P.n_small) {
+    clk_words = (size_t)(B.P.n_groups - B.P.n_small) * (EMS_MAX_BLOCK / 64) * EMS_CLK_WORDS;
+    if (int rc = c->em_clk.ensure(clk_words * 8, 0, c->stream)) return rc;
+    d_clk = c->em_clk.as<long long>();
+    HIPC(hipMemsetAsync(d_clk, 0, clk_words * 8, c->stream));
+  }
+  int launched = 0, decided = 0, stop = -1;
+  bool published_last = false;
+  for (;;) {
+    while (launched < n_chunks && launched < decided + 2) {
+      const int k = launched, base = k * CH, n = std::min(CH, n_iter - base);
+      if (int rc = B.launch(n, 0, al[k & 1], av[k & 1], al[(k + 1) & 1], av[(k + 1) & 1], B.d_hist + (size_t)k * CH, prev_of(k), k == 0 ? d_clk : nullptr))
+        return kamd::fail(rc, "kamd_em_run: the component-local EM failed to launch");
+      ++launched;
+    }
+    if (launched == n_chunks && decided == n_chunks - 1 && !published_last) {
+      hipLaunchKernelGGL(k_em_publish, dim3(1), dim3(64), 0, c->stream, prev_of(n_chunks));
+      HIPC(hipGetLastError());
+      published_last = true;
+    }
+    // wait until the counts of chunk `decided` have arrived
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (u64 spin = 1;; spin++) {
+        if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) >= decided + 1) break;
+        if ((spin & 4095) == 0) {
+          const hipError_t q = hipStreamQuery(c->stream);
+          if (q == hipSuccess) {   // everything queued has run
+            if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) >= decided + 1) break;
+            return kamd::fail(-104, "kamd_em_run: the change counts of a chunk never arrived");
+          }
+          if (q != hipErrorNotReady) return kamd::fail(-104, std::string("kamd_em_run: ") + hipGetErrorString(q));
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return kamd::fail(-104, "kamd_em_run: timed out waiting for a chunk of rounds");
+        }
+        __builtin_ia32_pause();
+      }
+    }
+    const int base = decided * CH, n = std::min(CH, n_iter - base);
+    const int* hh = h_hist + (size_t)decided * CH;
+    for (int i = 0; i < n; i++) if (hh[i] == 0 && base + i > min_rounds) { stop = base + i; break; }   // :202-205
+    if (stop >= 0) break;
+    if (++decided == n_chunks) break;   // the loop ran out: no final round
+  }
+  const double* fin; const double* before;
+  int rounds;
+  const bool have_final = stop >= 0;
+  if (have_final) {
+    const int s = decided, base = s * CH;
+    // (chunk s + 1, queued behind s, saw the stop and left its output -- the input of s -- alone)
+    if (int rc = B.launch(stop - base + 1, 0, al[s & 1], av[s & 1], al[(s + 1) & 1], av[(s + 1) & 1], nullptr, EmsPrev{})) return kamd::fail(rc, "kamd_em_run: replay failed to launch");
+    if (int rc = B.launch(1, 1, al[(s + 1) & 1], av[(s + 1) & 1], al[s & 1], av[s & 1], nullptr, EmsPrev{})) return kamd::fail(rc, "kamd_em_run: final round failed to launch");
+    before = al[(s + 1) & 1]; fin = al[s & 1];   // what the final round read is alpha_before_zeroes_
+    rounds = stop + 1;
+  } else {
+    fin = al[n_chunks & 1]; before = fin;
+    rounds = n_iter;
+  }
+  hipLaunchKernelGGL(k_em_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, K.mslot, K.single_all, fin, before, T, have_final ? 1 : 0, B.d_out, B.d_out + T);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(h_out, B.d_out, 2 * T * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  memcpy(alpha_out, h_out, T * 8);
+  if (abz_out) memcpy(abz_out, h_out + T, T * 8);
+  if (d_clk) {
+    std::vector<long long> hc(clk_words);
+    HIPC(hipMemcpy(hc.data(), d_clk, clk_words * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(clk_path, "wb")) {
+      const long long hdr[4] = {(long long)(B.P.n_groups - B.P.n_small), EMS_MAX_BLOCK / 64, EMS_CLK_WORDS, B.block};
+      fwrite(hdr, 8, 4, f); fwrite(hc.data(), 8, clk_words, f); fclose(f);
+    }
+  }
+  *rounds_out = rounds;
+  return 0;
+}
 // 0 = plan built (P: the host part; *dev: the device part), 1 = not applicable, < 0 = error
 int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
                          const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev, SellCache* cache,
-                         u32 small_limit = 0, u64 target_small = 0, u64 small_budget = 0) {
+                         u32 small_limit = 0, u64 target_small = 0, u64 small_budget = 0, bool host_maps = true) {
   namespace S = kamd_em_sell;
   kamd_em_local::Plan C;
   EmLocalDev cd{};
   kamd_em_local::BuildArgs A{};
-  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A, small_limit, target_small)) return rc;
+  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A, small_limit, target_small, host_maps)) return rc;
   const u32 ng = C.n_groups;
   const u64 R = C.row_base[ng], M = C.tr_base[ng];
   if (R >= 0xFFFFFFF0ULL || M >= 0xFFFFFFF0ULL) return 1;
@@ -4178,8 +4415,10 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   hipLaunchKernelGGL(k_sell_layout, dim3(grid_for(2 * (u64)ng, SELL_BUILD_WAVES)), dim3(64 * SELL_BUILD_WAVES), 0, c->stream, B);
   hipLaunchKernelGGL(k_sell_entries, dim3(grid_for(nseg, BLOCK)), dim3(BLOCK), 0, c->stream, B);
   HIPC(hipGetLastError());
-  P->tr_id.resize(M);
-  if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), B.tr_id_new, M * 4, hipMemcpyDeviceToHost, c->stream));
+  if (host_maps) {
+    P->tr_id.resize(M);
+    if (M) HIPC(hipMemcpyAsync(P->tr_id.data(), B.tr_id_new, M * 4, hipMemcpyDeviceToHost, c->stream));
+  }
   // the group bases live in the CSR plan's arena (pm_a), which other EM forms reuse: copy them next to the plan
   Carver bv;
   const size_t b_rb = bv.take((ng + 1) * 4), b_tb = bv.take((ng + 1) * 4), b_rf = bv.take(n_ecs * 4 + 8), b_ms = bv.take(T * 4 + 8), b_sa = bv.take(T * 8 + 8),
@@ -4214,7 +4453,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   const bool own = c->finalized && d_ec_off == (const u64*)c->result.d_ec_off && d_ec_ids == c->result.d_ec_ids;
   const bool hit = own && K.valid && K.d_ec_off == d_ec_off && K.d_ec_ids == d_ec_ids && K.n_ecs == n_ecs && K.nnz == nnz && K.T == T &&
                    K.generation == c->ec_generation && K.split_len == c->tune.em_split_len && K.group_div == c->tune.em_group_div &&
-                   K.small_nnz == c->tune.em_small_nnz;
+                   K.small_nnz == c->tune.em_small_nnz && (K.host_maps || !multi);
   if (hit) {
     HIPC(hipMemcpyAsync(K.d_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemsetAsync(K.single_all, 0, T * 8, c->stream));
@@ -4222,8 +4461,11 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
                        n_ecs, K.d_eff, T, K.row_final, K.mslot, const_cast<u64*>(K.dev.cw), const_cast<double*>(K.dev.single), const_cast<double*>(K.dev.eff),
                        K.single_all);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(K.P.single_all.data(), K.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    if (multi) {
+      K.P.single_all.resize(T);
+      HIPC(hipMemcpyAsync(K.P.single_all.data(), K.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+    }
   } else {
     K.valid = false;
     // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not, the
@@ -4244,7 +4486,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc >= 1; div *= 2) {
         const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
         prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K, small, small,
-                                   24 * 1024);
+                                   24 * 1024, multi);
         if (prc == 2) { small = 0; div /= 2; continue; }   // (same cut again, one class)
         if (target == 1024) break;
       }
@@ -4265,15 +4507,18 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
     if (not_applicable) return 1;
     if (own) {
       K.valid = true; K.d_ec_off = d_ec_off; K.d_ec_ids = d_ec_ids; K.n_ecs = n_ecs; K.nnz = nnz; K.T = T; K.generation = c->ec_generation;
-      K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div; K.small_nnz = c->tune.em_small_nnz;
+      K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div; K.small_nnz = c->tune.em_small_nnz; K.host_maps = multi;
     }
   }
   const kamd_em_sell::Plan& P = K.P;
   const int chunk = EML_MAX_ROUNDS;
   EmSellGpu B(c, P);
   B.dev = K.dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block; B.part = multi ? part : nullptr;
-  if (int rc = B.setup(chunk, K.dev.eff)) return rc;
-  const int r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);
+  const int n_chunks = std::max(1, (n_iter + chunk - 1) / chunk);
+  if (int rc = B.setup(multi ? chunk : n_chunks * chunk, K.dev.eff, multi ? 0 : T)) return rc;
+  int r = 0;
+  if (multi) r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);   // the change counts of a chunk are summed over the ranks before anyone reads them
+  else if (int rc = em_sell_drive_async(c, B, K, T, n_iter, min_rounds, alpha, abz, &r)) return rc;
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
   HIPC(hipEventRecord(c->ev1, c->stream));
   HIPC(hipEventSynchronize(c->ev1));
@@ -5050,7 +5295,23 @@ extern "C" int kamd_quant_batches(kamd_ctx* c, const kamd_quant_opts* o, const k
   }
   if (multi) {
     if (int rc = kamd_comm_sum_u64_host(c, comm, &n_proc, 1)) return rc;
-    if (estimate) if (int rc = kamd_comm_broadcast_host(c, comm, out->flens, KAMD_MAX_FRAG_LEN * sizeof(uint32_t), 0)) return rc;
+    if (estimate) {
+      // The sample is the first 10000 qualifying pairs of the INPUT; the ranks hold consecutive blocks of it (rank 0 the first).
+      // Rank 0's reads nearly always fill it; when they do not, the next rank continues the same sample over its own reads, and so
+      // on -- what one process reading all of the input does (src/ProcessReads.cpp:981-1008).  Every rank ends with the same sample.
+      std::vector<uint32_t> pack(KAMD_MAX_FRAG_LEN + 2);
+      for (int r = 0; r < comm->world; r++) {
+        if (r > 0 && comm->rank == r)
+          for (uint64_t b = 0; b < n_batches && used < 10000; b++)
+            if (int rc = kamd_fld_from_batch(c, o, batches[b].d_words, batches[b].d_len, batches[b].n_items, batches[b].max_len, out->flens, &used)) return rc;
+        memcpy(pack.data(), out->flens, KAMD_MAX_FRAG_LEN * sizeof(uint32_t));
+        pack[KAMD_MAX_FRAG_LEN] = (uint32_t)used; pack[KAMD_MAX_FRAG_LEN + 1] = (uint32_t)(used >> 32);
+        if (int rc = kamd_comm_broadcast_host(c, comm, pack.data(), pack.size() * sizeof(uint32_t), r)) return rc;
+        memcpy(out->flens, pack.data(), KAMD_MAX_FRAG_LEN * sizeof(uint32_t));
+        used = (uint64_t)pack[KAMD_MAX_FRAG_LEN] | ((uint64_t)pack[KAMD_MAX_FRAG_LEN + 1] << 32);
+        if (used >= 10000) break;
+      }
+    }
     if (int rc = kamd_ec_allreduce(c, comm)) return rc;
   }
   std::vector<double> mft(KAMD_MAX_FRAG_LEN);
