@@ -243,7 +243,12 @@ inline int build_plan_host(const uint64_t* ec_off, const uint32_t* ec_ids, const
 // Every step is a function of one index (a row, a transcript, a component root or a group) that only uses plain stores and
 // atomic adds, so a kernel is `step(blockIdx.x * blockDim.x + threadIdx.x, A)`; between the steps sit exclusive scans.  On
 // the host the steps run serially (build_plan_steps_host below), which is how tests/test_em_local.py checks them.  The order
-// of rows / transcripts inside a group comes from atomic cursors (any order is a valid plan).
+// of rows / transcripts inside a group comes from atomic cursors, and is then made CANONICAL by ranking (steps F2, G2, K2: a member's
+// final position is the number of members of its group with a smaller key -- one loop over the group per member, a few hundred each):
+// transcripts by id, rows by (first transcript, hash of the transcript set), a column's entries by row.  Any order is a valid plan, but the order of
+// the entries inside a column and the lanes a split segment lands on fix the association of the floating-point sums: with the
+// canonical order two runs over the same matrix give bit-identical abundances.  It also puts the rows and transcripts of a gene
+// family next to each other, so that the lanes of a slice often gather the same LDS word (a broadcast instead of a bank conflict).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KAMD_EML_ADD32(p, v) atomicAdd((p), (v))
 #else
@@ -275,6 +280,14 @@ struct BuildArgs {
   uint32_t* col_fill;     // [M]
   // the plan's arrays
   uint32_t* row_ptr; uint16_t* row_tr; uint32_t* col_ptr; uint16_t* col_row; uint64_t* cw; double* single; double* eff_m; uint32_t* tr_id;
+  // scratch of the canonical numbering (below): members of a group in arrival order, before they are ranked
+  uint32_t* tmp_tr_id;    // [M] transcript of an m-space slot as the atomic cursor handed the slots out
+  uint64_t* row_key;      // [R] (local index of the row's first transcript << 48 | 48 hash bits of the row's transcript set) of a row
+                          //     slot, in arrival order: a key of the row's CONTENT -- EC indices differ from run to run (kamd_ec_finalize
+                          //     emits the sets in the order its atomics hand out), the sets do not
+  uint32_t* row_e;        // [R] EC index of a row slot (the last tie-break, and where G2 finds the row)
+  uint16_t* col_row_tmp;  // [NZ] the transposed entries in arrival order
+  uint32_t* ent_col;      // [NZ] m-space slot of the column a transposed entry belongs to
 };
 KAMD_HD uint32_t eml_group_of(const BuildArgs& A, uint32_t root) {
   if (A.cum_big && A.c_nnz[root] > A.small_limit) return A.ng_small + (uint32_t)(A.cum_big[root] / A.target_big);
@@ -317,9 +330,17 @@ KAMD_HD void step_tr_f(uint64_t t, const BuildArgs& A) {
   if (t >= A.T || !A.in_multi[t]) return;
   const uint32_t g = eml_group_of(A, A.label[t]);
   const uint32_t l = KAMD_EML_ADD32(&A.tr_fill[g], 1u);
-  A.local_of[t] = l;
-  const uint64_t m = (uint64_t)A.tr_base[g] + l;
-  A.tr_id[m] = (uint32_t)t; A.single[m] = A.single_all[t]; A.eff_m[m] = A.eff[t];
+  A.tmp_tr_id[(uint64_t)A.tr_base[g] + l] = (uint32_t)t;
+}
+// F2 (per m-space slot in arrival order): the transcript's final slot = its rank by id among the group's transcripts
+KAMD_HD void step_m_f2(uint64_t i, uint32_t g, const BuildArgs& A) {
+  const uint32_t t = A.tmp_tr_id[i];
+  const uint32_t lo = A.tr_base[g], hi = A.tr_base[g + 1];
+  uint32_t rank = 0;
+  for (uint32_t j = lo; j < hi; j++) rank += A.tmp_tr_id[j] < t ? 1u : 0u;
+  A.local_of[t] = rank;
+  const uint64_t m = (uint64_t)lo + rank;
+  A.tr_id[m] = t; A.single[m] = A.single_all[t]; A.eff_m[m] = A.eff[t];
 }
 // G (per row): new row index, its length and count word
 KAMD_HD void step_rows_g(uint64_t e, const BuildArgs& A) {
@@ -328,8 +349,28 @@ KAMD_HD void step_rows_g(uint64_t e, const BuildArgs& A) {
   if (b - a < 2) return;
   const uint32_t g = eml_group_of(A, A.label[A.ec_ids[a]]);
   const uint32_t rn = A.row_base[g] + KAMD_EML_ADD32(&A.row_fill[g], 1u);
+  uint64_t h = 0x9E3779B97F4A7C15ULL;
+  for (uint64_t j = a; j < b; j++) { h ^= A.ec_ids[j]; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 29; }
+  A.row_key[rn] = ((uint64_t)A.local_of[A.ec_ids[a]] << 48) | (h >> 16);   // (after F2: local_of is final and < 65536)
+  A.row_e[rn] = (uint32_t)e;
+}
+// group that owns row slot i (slots are group-major): last g with row_base[g] <= i
+KAMD_HD uint32_t eml_group_of_row_slot(const BuildArgs& A, uint64_t i) {
+  uint32_t lo = 0, hi = A.n_groups;
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (A.row_base[mid] <= i) lo = mid; else hi = mid; }
+  return lo;
+}
+// G2 (per row slot in arrival order): the row's final index = its rank by (first transcript, set hash; EC index on a tie) among the group's rows;
+// its length and count word go there
+KAMD_HD void step_slot_g2(uint64_t i, uint32_t g, const BuildArgs& A) {
+  const uint64_t key = A.row_key[i];
+  const uint64_t e = A.row_e[i];
+  const uint32_t lo = A.row_base[g], hi = A.row_base[g + 1];
+  uint32_t rank = 0;
+  for (uint32_t j = lo; j < hi; j++) { const uint64_t kj = A.row_key[j]; rank += (kj < key || (kj == key && A.row_e[j] < e)) ? 1u : 0u; }
+  const uint32_t rn = lo + rank;
   A.row_new[e] = rn;
-  A.len_new[rn] = (uint32_t)(b - a);
+  A.len_new[rn] = (uint32_t)(A.ec_off[e + 1] - A.ec_off[e]);
   A.cw[rn] = (uint64_t)A.counts[e] | ((uint64_t)(A.wcounts ? A.wcounts[e] : A.counts[e]) << 32);
 }
 // (scan len_new -> row_abs)
@@ -374,8 +415,18 @@ KAMD_HD void step_rows_k(uint64_t e, const BuildArgs& A) {
   const uint32_t rl = A.row_new[e] - A.row_base[g];
   for (uint64_t j = a; j < b; j++) {
     const uint64_t m = (uint64_t)A.tr_base[g] + A.local_of[A.ec_ids[j]];
-    A.col_row[A.col_abs[m] + KAMD_EML_ADD32(&A.col_fill[m], 1u)] = (uint16_t)rl;
+    const uint64_t p = A.col_abs[m] + KAMD_EML_ADD32(&A.col_fill[m], 1u);
+    A.col_row_tmp[p] = (uint16_t)rl; A.ent_col[p] = (uint32_t)m;
   }
+}
+// K2 (per transposed entry in arrival order): its final place in the column = its rank by row (a row occurs once in a column)
+KAMD_HD void step_ent_k2(uint64_t p, const BuildArgs& A) {
+  const uint64_t m = A.ent_col[p];
+  const uint32_t v = A.col_row_tmp[p];
+  const uint64_t lo = A.col_abs[m], hi = A.col_abs[m + 1];
+  uint64_t rank = 0;
+  for (uint64_t q = lo; q < hi; q++) rank += A.col_row_tmp[q] < v ? 1u : 0u;
+  A.col_row[lo + rank] = (uint16_t)v;
 }
 
 // labels the way the device computes them (k_cc_*: min-label propagation): smallest transcript id of the component
@@ -450,14 +501,19 @@ inline int build_plan_steps_host(const uint64_t* ec_off, const uint32_t* ec_ids,
   A.row_new = row_new.data(); A.len_new = len_new.data(); A.col_cnt = col_cnt.data(); A.col_fill = col_fill.data();
   A.row_ptr = P->row_ptr.data(); A.row_tr = P->row_tr.data(); A.col_ptr = P->col_ptr.data(); A.col_row = P->col_row.data();
   A.cw = P->cw.data(); A.single = P->single.data(); A.eff_m = P->eff.data(); A.tr_id = P->tr_id.data();
+  std::vector<uint32_t> tmp_tr_id(M, 0), ent_col(NZ, 0); std::vector<uint64_t> row_key(R, 0); std::vector<uint16_t> col_row_tmp(NZ, 0); std::vector<uint32_t> row_e(R, 0);
+  A.row_e = row_e.data(); A.tmp_tr_id = tmp_tr_id.data(); A.row_key = row_key.data(); A.col_row_tmp = col_row_tmp.data(); A.ent_col = ent_col.data();
   for (uint64_t t = 0; t < T; t++) step_tr_f(t, A);
+  for (uint64_t m = 0; m < M; m++) step_m_f2(m, eml_group_of_slot(A, m), A);
   for (uint64_t e = 0; e < n_ecs; e++) step_rows_g(e, A);
+  for (uint64_t i = 0; i < R; i++) step_slot_g2(i, eml_group_of_row_slot(A, i), A);
   scan32(len_new, R, row_abs); A.row_abs = row_abs.data();
   for (uint64_t e = 0; e < n_ecs; e++) step_rows_i(e, A);
   scan32(col_cnt, M, col_abs); A.col_abs = col_abs.data();
   for (uint64_t m = 0; m < M; m++) step_m_j(m, eml_group_of_slot(A, m), A);   // (as the kernel does: the group by binary search)
   for (uint64_t g = 0; g < ng; g++) step_group_j(g, A);
   for (uint64_t e = 0; e < n_ecs; e++) step_rows_k(e, A);
+  for (uint64_t p = 0; p < NZ; p++) step_ent_k2(p, A);
   return 0;
 }
 

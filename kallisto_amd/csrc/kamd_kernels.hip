@@ -697,7 +697,8 @@ __global__ __launch_bounds__(BLOCK) void k_rec_dedup(const u32* __restrict__ str
       s = (h >> 1) & mask;
       bool placed = false;
       for (u32 probes = 0; probes < max_probe; probes++) {
-        const u64 old = atomicCAS(&table[s].tag, 0ULL, mine);
+        u64 old = table[s].tag;   // (plain load first, as in k_tup_absorb)
+        if (old == 0ULL) old = atomicCAS(&table[s].tag, 0ULL, mine);
         if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }   // (owner: read by the kernels after this one)
         if ((old >> 32) == (mine >> 32)) {
           const u64 ooff = (old & 0xFFFFFFFFULL) - 1;
@@ -748,7 +749,11 @@ __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ ba
       s = (h >> 1) & mask;
       bool placed = false;
       for (u32 probes = 0; probes < max_probe; probes++) {
-        const u64 old = atomicCAS(&table[s].tag, 0ULL, mine);
+        // nine records in ten find their tuple already in the table: a plain load sees the tag without the trip to the memory side
+        // that a device-scope atomic costs (a tag goes from 0 to its value once; a stale 0 from this XCD's L2 only means the
+        // compare-and-swap below is taken after all)
+        u64 old = table[s].tag;
+        if (old == 0ULL) old = atomicCAS(&table[s].tag, 0ULL, mine);
         if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }
         if ((old >> 32) == (mine >> 32)) {
           const u32* o = ((old & TAG_LOCAL) ? batch : store) + ((old & 0x7FFFFFFFULL) - 1);
@@ -3785,8 +3790,7 @@ __global__ void k_sell_lens(SellBuild B) {
 // kamd_em_sell::layout_group for one direction of one group by ONE WAVEFRONT (the header's version is what one thread -- or the CPU
 // emulation -- runs; one thread per group left the chip idle: 1009 threads, ~1 ms per pass).  Same layout rules: split segments
 // first, in the caller's order, never straddling a slice; then the others by decreasing length; a slice's width is its longest
-// lane; slices that hold split lanes carry a word of metadata per lane.  Which of two segments of EQUAL length comes first is
-// decided by an LDS atomic here (by index on the host) -- nothing depends on it: a segment's entries keep their order.
+// lane; slices that hold split lanes carry a word of metadata per lane.  Segments of EQUAL length keep the caller's order (as on the host).
 constexpr int SELL_BUILD_WAVES = 4;    // wavefronts (group directions) per block
 struct SellWaveScratch { u32 hist[kamd_em_sell::SELL_LANES + 1], start[kamd_em_sell::SELL_LANES + 1], cur[kamd_em_sell::SELL_LANES + 1]; };
 template <class Sink>
@@ -3841,10 +3845,23 @@ __device__ kamd_em_sell::LayoutSize sell_layout_wave(const u32* __restrict__ len
   if (Sink::wants_segments) {
     for (u32 c0 = 0; c0 < n; c0 += 64) {
       const u32 i = c0 + lane;
-      if (i < n) {
-        const u32 l = len[i];
-        if (l <= cap) { const u32 p = S.start[l] + atomicAdd(&S.cur[l], 1u); sink.seg(i, n_split + (p - split_lanes), p, 1u, l); }
+      // equal lengths keep the caller's order (the canonical numbering of kamd_em_local.h: neighbours in it are neighbours in a slice):
+      // a lane's place inside its length class = the class's count so far + the lanes below it in this step with the same length
+      const u32 l = i < n ? len[i] : 0u;
+      const bool act = i < n && l <= cap;
+      u64 same = __ballot(act);
+#pragma unroll
+      for (int b = 0; b < 7; b++) { const u64 bal = __ballot((l >> b) & 1u); same &= ((l >> b) & 1u) ? bal : ~bal; }
+      const u32 below = (u32)__popcll(same & ((1ULL << lane) - 1ULL)), cls = (u32)__popcll(same);
+      u32 base = 0;
+      if (act) base = S.cur[l];
+      __builtin_amdgcn_wave_barrier();
+      if (act) {
+        const u32 p = S.start[l] + base + below;
+        sink.seg(i, n_split + (p - split_lanes), p, 1u, l);
+        if (below + 1 == cls) S.cur[l] = base + cls;
       }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   // 3. the slice the split part left open takes the longest unsplit segments; then the plain slices, 64 at a time
@@ -3944,6 +3961,9 @@ __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   else if constexpr (S == 6) kamd_em_local::step_m_j(i, kamd_em_local::eml_group_of_slot(A, i), A);
   else if constexpr (S == 7) kamd_em_local::step_group_j(i, A);
   else if constexpr (S == 9) kamd_em_local::step_root_c(i, A);
+  else if constexpr (S == 10) kamd_em_local::step_m_f2(i, kamd_em_local::eml_group_of_slot(A, i), A);
+  else if constexpr (S == 11) kamd_em_local::step_slot_g2(i, kamd_em_local::eml_group_of_row_slot(A, i), A);
+  else if constexpr (S == 12) kamd_em_local::step_ent_k2(i, A);
   else kamd_em_local::step_rows_k(i, A);
 }
 // The plan built on the device: component labels by the kernels the partitioned EM uses, then the steps of
@@ -4041,6 +4061,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   const size_t p_rp = pv.take((R + ng) * 4 + 8), p_cp = pv.take((M + ng) * 4 + 8), p_rt = pv.take(NZ * 2 + 8), p_cr = pv.take(NZ * 2 + 8);
   const size_t p_cw = pv.take(R * 8 + 8), p_sg = pv.take(M * 8 + 8), p_ef = pv.take(M * 8 + 8), p_id = pv.take(M * 4 + 8);
   const size_t p_len = pv.take(R * 4 + 8), p_rabs = pv.take((R + 2) * 8), p_cc = pv.take(M * 4 + 8), p_cf = pv.take(M * 4 + 8), p_cabs = pv.take((M + 2) * 8);
+  const size_t p_tt = pv.take(M * 4 + 8), p_rk = pv.take(R * 8 + 8), p_crt = pv.take(NZ * 2 + 8), p_ec = pv.take(NZ * 4 + 8), p_re = pv.take(R * 4 + 8);   // scratch of the canonical numbering
   if (int rc = c->pm_a.ensure(pv.off, 0, c->stream)) return rc;
   char* pb = (char*)c->pm_a.p;
   HIPC(hipMemcpyAsync(pb + p_rb, P->row_base.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -4052,14 +4073,18 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   A.cw = (uint64_t*)(pb + p_cw); A.single = (double*)(pb + p_sg); A.eff_m = (double*)(pb + p_ef); A.tr_id = (u32*)(pb + p_id);
   A.len_new = (u32*)(pb + p_len); A.row_abs = (const uint64_t*)(pb + p_rabs); A.col_cnt = (u32*)(pb + p_cc); A.col_fill = (u32*)(pb + p_cf);
   A.col_abs = (const uint64_t*)(pb + p_cabs);
+  A.tmp_tr_id = (u32*)(pb + p_tt); A.row_key = (uint64_t*)(pb + p_rk); A.col_row_tmp = (uint16_t*)(pb + p_crt); A.ent_col = (u32*)(pb + p_ec); A.row_e = (u32*)(pb + p_re);
   hipLaunchKernelGGL(k_eml_step<3>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
+  hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
   hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
   if (int rc = exclusive_scan(c, A.len_new, R, (u64*)(pb + p_rabs), (u64*)(pb + p_rabs) + R)) return rc;
   hipLaunchKernelGGL(k_eml_step<5>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   if (int rc = exclusive_scan(c, A.col_cnt, M, (u64*)(pb + p_cabs), (u64*)(pb + p_cabs) + M)) return rc;
   hipLaunchKernelGGL(k_eml_step<6>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
   hipLaunchKernelGGL(k_eml_step<7>, dim3(grid_for(ng, BLOCK)), dim3(BLOCK), 0, c->stream, A, (u64)ng);
   hipLaunchKernelGGL(k_eml_step<8>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  hipLaunchKernelGGL(k_eml_step<12>, dim3(grid_for(NZ, BLOCK)), dim3(BLOCK), 0, c->stream, A, NZ);
   HIPC(hipGetLastError());
   // what the host needs for the final scatter (a single rank scatters on the device: em_sell_drive_async)
   if (host_maps) {

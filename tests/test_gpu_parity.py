@@ -271,6 +271,49 @@ def test_em_forms_agree_with_oracle(k, ka):
     common.assert_abundance_close(tiny(abz), tiny(abz_o), "alpha_before_zeroes", rel=1e-9, floor=1e-12)
 
 
+def test_em_is_bit_reproducible(ka):
+    """Two runs over the same matrix, each in a fresh context, give bit-identical abundances: the plan's numbering is canonical
+    (kamd_em_local.h steps F2 / G2 / K2, equal lengths in index order in the slices), so the association of every floating-point sum
+    is fixed -- the atomic cursors that hand out slots no longer show in the result.  Split rows / hub columns included (split length 8)."""
+    import torch
+    off, ids, cnt, eff, T = _gene_csr(300, 7)
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda()
+    outs = []
+    for rep in range(3):
+        ctx = ka.Context(0)
+        try:
+            ctx.tune(em_form="local", em_local_block=1024, em_group_div=64, em_split_len=8 if rep < 2 else 32)
+            outs.append(ctx.em_run(eff, csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32))))
+        finally:
+            ctx.close()
+    (a0, z0, r0), (a1, z1, r1), (a2, z2, r2) = outs
+    assert r0 == r1 == r2
+    assert np.array_equal(a0.view(np.uint64), a1.view(np.uint64)) and np.array_equal(z0.view(np.uint64), z1.view(np.uint64))
+    common.assert_abundance_close(a2, a0, "other split length")   # (another layout: equal to rounding, not to the bit)
+
+
+@pytest.mark.parametrize("case", ["human_pe", "mosaic_pe"])
+def test_quant_is_bit_reproducible(case, ka):
+    """The whole flow twice, in fresh contexts: est_counts and tpm identical to the bit (kamd_ec_finalize hands the classes out in the order
+    of its atomics, so the EC ids differ between the runs -- the EM plan orders rows by their content, not by their id)."""
+    meta, idx_path, r1, r2 = common.load_case(case)
+    reads = common.interleave(r1, r2)
+    index = ka.Index(idx_path)
+    outs = []
+    for rep in range(2):
+        ctx = ka.Context(0)
+        try:
+            ctx.upload(index)
+            words, lens, max_len = ctx.pack_reads_host(reads)
+            res = ka.quant(ctx, ka.QuantOpts(1, 0.0, 0.0, 0, 0), [(words, lens, len(r1), max_len)])
+            outs.append((res.est_counts.copy(), res.tpm.copy(), res.em_rounds))
+        finally:
+            ctx.close()
+    assert outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64))
+    assert np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
+
+
 @pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe_boot"), ("human_pe", "pe_boot")])
 def test_bootstrap_matches_reference(case, variant, ka, ctxs):
     """Bootstrap::run_em: the multinomial resample is bit-identical to libstdc++'s (same EC order as the reference at
