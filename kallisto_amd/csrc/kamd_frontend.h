@@ -254,7 +254,10 @@ class UnitFeeder {
     if (prepare(nf) != OK) return FAILED;
     start_consumers();
     // readers: what the caller allows, within the CPUs this process may keep busy minus the dispatcher, the consumer and the runtime's own threads
-    const int per_file = std::max(1, (std::min(io_threads, effective_cpus()) - 3) / nf);
+    // (the dispatcher, the consumer and the runtime's threads mostly wait: one CPU is left to them)
+    int spare = 1;
+    if (const char* e = getenv("KAMD_FQ_SPARE_CPUS")) spare = std::max(0, atoi(e));
+    const int per_file = std::max(1, (std::min(io_threads, effective_cpus()) - spare) / nf);
     std::unique_ptr<TextSource> src[2];
     for (int f = 0; f < nf; f++) {
       src[f].reset(new TextSource(f ? *f1 : f0, ring_[f], z_.ring, per_file, z_.block));

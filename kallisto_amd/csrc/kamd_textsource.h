@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "kamd_fastq.h"
+#include "kamd_pargzip.h"
 
 namespace kamd_io {
 
@@ -119,7 +120,18 @@ class TextSource {
       for (auto& b : blocks_) if (b.end - b.begin + 1 > cap_) { fail(path + ": ring smaller than a BGZF block"); return; }
       for (int t = 0; t < std::min<int>(threads, (int)blocks_.size()); t++) workers_.emplace_back([this] { bgzf_worker(); });
     } else {
-      workers_.emplace_back([this] { gzip_worker(); });
+      // an ordinary gzip file: block-parallel inflate (kamd_pargzip.h) when there are threads for it and the file is worth it;
+      // the one-thread zlib reader otherwise (KAMD_PARGZIP=0 forces it)
+      size_t min_bytes = 4u << 20;
+      if (const char* e = getenv("KAMD_PARGZIP_MIN_KB")) min_bytes = (size_t)std::max(0, atoi(e)) << 10;
+      const char* sw = getenv("KAMD_PARGZIP");
+      const bool par = threads >= 2 && fsize_ >= min_bytes && !(sw && atoi(sw) == 0);
+      if (par) {
+        void* p = mmap(nullptr, fsize_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (p == MAP_FAILED) { fail("could not map " + path); return; }
+        map_ = (const unsigned char*)p;
+        workers_.emplace_back([this, threads] { pargzip_worker(threads); });
+      } else workers_.emplace_back([this] { gzip_worker(); });
     }
   }
   ~TextSource() {
@@ -290,6 +302,49 @@ class TextSource {
       finish_block(i, count_range(b.begin, end));
     }
     if (dec) ld.free_(dec); else inflateEnd(&z);
+  }
+  // an ordinary gzip file by all the threads this source was given: kamd_pargzip.h decodes the stream block-parallel and hands the
+  // text over in order; this thread copies it into the ring (waiting for room) and counts its lines
+  void pargzip_worker(int threads) {
+    size_t chunk = 2u << 20;
+    if (const char* e = getenv("KAMD_PARGZIP_CHUNK_KB")) chunk = (size_t)std::max(4, atoi(e)) << 10;
+    const Libdeflate& ld = Libdeflate::get();
+    uint64_t head = 0; char last = '\n';
+    auto deliver = [&](const uint8_t* p, size_t n, uint64_t) -> bool {
+      while (n) {
+        size_t room;
+        {
+          std::unique_lock<std::mutex> lk(m_);
+          cv_.wait(lk, [&] { return stop_ || head - released_ < cap_; });
+          if (stop_) return false;
+          room = (size_t)std::min<uint64_t>(cap_ - (head - released_), blk_);
+        }
+        const size_t o = (size_t)(head % cap_);
+        const size_t a = std::min(std::min(room, cap_ - o), n);
+        memcpy(ring_ + o, p, a);
+        const uint64_t nl = count_newlines(ring_ + o, a);
+        last = (char)p[a - 1];
+        { std::lock_guard<std::mutex> g(m_); lines_ += nl; cums_.push_back(Cum{head, head + a, nl, lines_}); produced_ = head + a; }
+        head += a; p += a; n -= a;
+        cv_.notify_all();
+      }
+      return true;
+    };
+    pgz::ParGzip P(map_, (size_t)fsize_, threads, chunk, deliver, count_newlines, ld.ok() ? ld.crc32_ : nullptr);
+    if (!P.run()) {
+      { std::lock_guard<std::mutex> g(m_); if (stop_) return; }
+      fail(path_ + ": " + (P.error().empty() ? std::string("corrupt gzip stream") : P.error()));
+      return;
+    }
+    if (head && last != '\n') {   // the text does not end in a newline: one is appended
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return stop_ || head - released_ < cap_; });
+      if (stop_) return;
+      ring_[(size_t)(head % cap_)] = '\n';
+      ++lines_; cums_.push_back(Cum{head, head + 1, 1, lines_}); produced_ = ++head;
+    }
+    { std::lock_guard<std::mutex> g(m_); eof_ = true; }
+    cv_.notify_all();
   }
   // any gzip stream (concatenated members are one text, as gzread reads them): one thread, inflate straight into the ring
   void gzip_worker() {

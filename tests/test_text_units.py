@@ -153,3 +153,67 @@ def test_carriage_return_rule_of_kseq(tmp_path):
     open(p, "wb").write(b"@a\r\nA\r\n+\r\nI\r\n@b\r\n\r\n+\r\n\r\n")
     st, got, _, _ = _units(p, target=16)
     assert st == 0 and got == [b"A", b"\r"]
+
+
+# ---- block-parallel inflate of ordinary gzip files (kallisto_amd/csrc/kamd_pargzip.h) ----------------------------------------
+def _pargzip_env(monkeypatch, chunk_kb=16):
+    monkeypatch.setenv("KAMD_PARGZIP_MIN_KB", "0")
+    monkeypatch.setenv("KAMD_PARGZIP_CHUNK_KB", str(chunk_kb))
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("chunk_kb", [4, 64])
+def test_parallel_gzip_equals_the_text(tmp_path, monkeypatch, level, chunk_kb):
+    """A gzip file cut into chunks of 4 / 64 KiB of compressed bytes (dozens to hundreds of chunks: block starts found inside the
+    stream, symbols with markers, window resolution, in-order delivery, CRC-32 and length of the member checked) gives exactly the
+    reads of the text; the ring is smaller than the text, so the decoder also waits for the consumer."""
+    _pargzip_env(monkeypatch, chunk_kb)
+    reads = _reads(30000, 11 + level)
+    data = _fastq_bytes(reads, tricky_quals=True)
+    p = str(tmp_path / "r.fq.gz")
+    open(p, "wb").write(gzip.compress(data, level))
+    st, got, n, nu = _units(p, ring=1 << 19, target=1 << 16, threads=6, blk=1 << 13)
+    assert st == 0 and n == len(reads) and got == reads and nu > 10
+
+
+def test_parallel_gzip_stored_fixed_blocks_members_and_junk(tmp_path, monkeypatch):
+    """Blocks the block finder cannot recognise (stored, fixed Huffman: level 0 and Z_FIXED streams), several members, zero padding
+    and junk behind the last member: everything the parallel path does not cover goes through its serial decoder -- same text."""
+    import zlib
+    _pargzip_env(monkeypatch, 8)
+    reads = _reads(12000, 21)
+    data = _fastq_bytes(reads)
+    a, b, c = data[:len(data) // 3], data[len(data) // 3:2 * len(data) // 3], data[2 * len(data) // 3:]
+    def member(raw, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
+        return co.compress(raw) + co.flush()
+    blob = member(a, 0) + member(b, 6, zlib.Z_FIXED) + b"\0" * 37 + member(c, 6) + b"not a gzip member"
+    p = str(tmp_path / "mix.fq.gz")
+    open(p, "wb").write(blob)
+    st, got, n, _ = _units(p, ring=1 << 19, target=1 << 15, threads=4)
+    assert st == 0 and got == reads
+    # a text without the final newline, and the same through the parallel path as a paired input against a plain mate
+    open(p, "wb").write(gzip.compress(data[:-1], 6))
+    st, got, n, _ = _units(p, target=1 << 15, threads=4)
+    assert st == 0 and got == reads
+
+
+def test_parallel_gzip_reports_corruption(tmp_path, monkeypatch):
+    """A flipped byte in the middle of the deflate data, a wrong CRC in the trailer, a truncated file: an error, never a clean run."""
+    _pargzip_env(monkeypatch, 8)
+    reads = _reads(12000, 31)
+    blob = bytearray(gzip.compress(_fastq_bytes(reads), 6))
+    p = str(tmp_path / "bad.fq.gz")
+    for what in ("flip", "crc", "truncate"):
+        bad = bytearray(blob)
+        if what == "flip":
+            bad[len(bad) // 2] ^= 0x5A
+        elif what == "crc":
+            bad[-6] ^= 0xFF
+        else:
+            bad = bad[:len(bad) * 2 // 3]
+        open(p, "wb").write(bytes(bad))
+        st, got, _, _ = _units(p, target=1 << 15, threads=4)
+        # UnitCutter::IO_ERROR; a flipped byte may garble the text before the decoder meets an invalid code or the CRC: then the record
+        # check declines first (-11) and the general reader, which the front-end turns to, fails on the same file
+        assert st == -3 or (what == "flip" and st == -11), (what, st)
