@@ -32,7 +32,9 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <cstdlib>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -202,10 +204,24 @@ inline bool read_dynamic_header(Bits& b, Codes* C) {
 
 // ---- decoding: T = uint8_t (the window is known: the WIN bytes in front of out[0] are real text) or uint16_t (markers) ----------
 enum { D_STOP = 1, D_FINAL = 2, D_ERROR = -1 };
+// a growable array that is neither zeroed nor copied element-wise (the output of a chunk is tens of megabytes, written once)
+template <class T>
+struct RawBuf {
+  T* p = nullptr; size_t n = 0;
+  RawBuf() = default;
+  explicit RawBuf(size_t elems) { grow(elems); }
+  RawBuf(const RawBuf&) = delete; RawBuf& operator=(const RawBuf&) = delete;
+  RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  RawBuf& operator=(RawBuf&& o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~RawBuf() { free(p); }
+  void grow(size_t elems) { if (elems <= n) return; const size_t nn = std::max(elems, n + n / 2); T* q = (T*)realloc(p, nn * sizeof(T)); if (!q) throw std::bad_alloc(); p = q; n = nn; }
+  size_t size() const { return n; }
+  T* data() { return p; }
+};
 template <class T>
 struct Out {   // v[0 .. WIN): the window in front of the output; the output grows from v[WIN]
-  std::vector<T>* v; size_t o;
-  T* ensure(size_t more) { if (v->size() < o + more) v->resize(std::max(o + more, v->size() + v->size() / 2)); return v->data(); }
+  RawBuf<T>* v; size_t o;
+  T* ensure(size_t more) { v->grow(o + more); return v->data(); }
 };
 inline bool is_text(uint32_t c) { return c == 9 || c == 10 || c == 13 || (c >= 32 && c < 127); }
 // Decodes whole blocks from the reader's position until a block ends at or behind stop_bit (D_STOP), the final block ends (D_FINAL)
@@ -281,7 +297,9 @@ inline int inflate_blocks(Bits& b, Out<T>& O, uint64_t stop_bit, uint64_t* end_b
           if (dist > WIN) { rc_in = D_ERROR; break; }
           const T* s = out + o - dist; T* t = out + o;
           constexpr uint32_t W = 8 / sizeof(T);   // elements per 64-bit word
-          if (dist >= W) {   // word-wise, up to W - 1 elements too far (the room is there)
+          if (dist >= 2 * W) {   // 16 bytes at a time, up to 2 W - 1 elements too far (the room is there)
+            for (uint32_t i = 0; i < len; i += 2 * W) { uint64_t w0, w1; memcpy(&w0, s + i, 8); memcpy(&w1, s + i + W, 8); memcpy(t + i, &w0, 8); memcpy(t + i + W, &w1, 8); }
+          } else if (dist >= W) {
             for (uint32_t i = 0; i < len; i += W) { uint64_t w; memcpy(&w, s + i, 8); memcpy(t + i, &w, 8); }
           } else for (uint32_t i = 0; i < len; i++) t[i] = s[i];
           o += len;
@@ -303,7 +321,7 @@ inline int inflate_blocks(Bits& b, Out<T>& O, uint64_t stop_bit, uint64_t* end_b
 // symbols decode to text; ~0 if none.  (Stored and fixed-Huffman blocks carry nothing to recognise them by: a chunk that begins
 // with one is decoded by the serial path.)
 inline uint64_t find_block(const uint8_t* data, size_t n, uint64_t from_bit, uint64_t until_bit) {
-  std::vector<uint16_t> scratch(WIN + (1u << 17));
+  RawBuf<uint16_t> scratch(WIN + (1u << 17));
   for (uint64_t p = from_bit; p < until_bit; p++) {
     if ((p >> 3) + 8 >= n) break;
     // cheap filter on the first 13 bits: BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29
@@ -314,7 +332,7 @@ inline uint64_t find_block(const uint8_t* data, size_t n, uint64_t from_bit, uin
     Codes C;
     if (!read_dynamic_header(b, &C)) continue;   // (rejects at the code-length code's Kraft sum nearly always)
     // trial: the whole block must decode, to text
-    for (uint32_t i = 0; i < WIN; i++) scratch[i] = (uint16_t)(MARK | i);
+    for (uint32_t i = 0; i < WIN; i++) scratch.p[i] = (uint16_t)(MARK | i);
     Bits t(data, n, p);
     Out<uint16_t> O{&scratch, WIN};
     uint64_t eb = 0;
@@ -370,10 +388,11 @@ class ParGzip {
     int state = IDLE;
     bool start_known = false; uint64_t start_bit = ~0ULL;   // first block found at or behind the chunk's nominal start
     uint64_t end_bit = 0; int rc = D_ERROR;
-    std::vector<uint16_t> sym;    // WIN markers in front, then the symbols
+    RawBuf<uint16_t> sym;         // WIN markers in front, then the symbols (from the pool)
     size_t n_out = 0;
     std::vector<uint8_t> window;  // the WIN bytes in front of the chunk (set by the coordinator before conversion)
-    std::vector<uint8_t> bytes; uint64_t nl = 0; uint32_t crc = 0;
+    RawBuf<uint8_t> bytes; size_t n_bytes = 0; uint64_t nl = 0; uint32_t crc = 0;
+    bool computing = false;       // some thread is looking for the chunk's block start
   };
   uint64_t nominal_bit(size_t k) const { return k >= n_chunks_ ? (uint64_t)n_ * 8 : ((uint64_t)data_start_ + (uint64_t)k * C_) * 8; }
   // start of chunk k's first block (memoised; any thread)
@@ -381,13 +400,16 @@ class ParGzip {
     if (k >= n_chunks_) return ~0ULL;
     Chunk& c = *chunks_[k];
     {
-      std::lock_guard<std::mutex> lk(c.m);
+      std::unique_lock<std::mutex> lk(c.m);
+      if (c.computing) c.cv.wait(lk, [&] { return c.start_known; });
       if (c.start_known) return c.start_bit;
+      c.computing = true;
     }
     const uint64_t s = k == 0 ? (uint64_t)data_start_ * 8 : find_block(d_, n_, nominal_bit(k), nominal_bit(k + 1));
     std::lock_guard<std::mutex> lk(c.m);
-    if (!c.start_known) { c.start_bit = s; c.start_known = true; }
-    return c.start_bit;
+    c.start_bit = s; c.start_known = true;
+    c.cv.notify_all();
+    return s;
   }
   // the first chunk behind k that has a block start: where chunk k's decoder stops
   uint64_t stop_for(size_t k) {
@@ -400,8 +422,9 @@ class ParGzip {
     int rc = D_ERROR; uint64_t eb = 0;
     if (s != ~0ULL) {
       const uint64_t stop = stop_for(k);
-      c.sym.resize(WIN + 5 * C_ + (1u << 17));
-      for (uint32_t i = 0; i < WIN; i++) c.sym[i] = (uint16_t)(MARK | i);
+      c.sym = take_sym();
+      c.sym.grow(WIN + 5 * C_ + (1u << 17));
+      for (uint32_t i = 0; i < WIN; i++) c.sym.p[i] = (uint16_t)(MARK | i);
       Bits b(d_, n_, s);
       Out<uint16_t> O{&c.sym, WIN};
       rc = D_STOP;
@@ -415,16 +438,24 @@ class ParGzip {
   }
   void convert_chunk(size_t k) {
     Chunk& c = *chunks_[k];
-    c.bytes.resize(c.n_out);
+    c.bytes = take_bytes();
+    c.bytes.grow(c.n_out + 16);
+    c.n_bytes = c.n_out;
     const uint16_t* s = c.sym.data() + WIN; const uint8_t* w = c.window.data(); uint8_t* o = c.bytes.data();
     resolve(s, c.n_out, w, o);
     c.nl = count_nl_((const char*)o, c.n_out);
     c.crc = crc_of(o, c.n_out);
-    std::vector<uint16_t>().swap(c.sym);
+    give_sym(std::move(c.sym));
     std::lock_guard<std::mutex> lk(c.m);
     c.state = CONVERTED;
     c.cv.notify_all();
   }
+  // buffers go round: a decoded chunk's symbols and a converted chunk's bytes are tens of megabytes that would otherwise be mapped,
+  // faulted in and unmapped for every chunk
+  RawBuf<uint16_t> take_sym() { std::lock_guard<std::mutex> lk(pm_); if (sym_pool_.empty()) return RawBuf<uint16_t>(); RawBuf<uint16_t> b = std::move(sym_pool_.back()); sym_pool_.pop_back(); return b; }
+  void give_sym(RawBuf<uint16_t>&& b) { if (!b.p) return; std::lock_guard<std::mutex> lk(pm_); sym_pool_.push_back(std::move(b)); }
+  RawBuf<uint8_t> take_bytes() { std::lock_guard<std::mutex> lk(pm_); if (byte_pool_.empty()) return RawBuf<uint8_t>(); RawBuf<uint8_t> b = std::move(byte_pool_.back()); byte_pool_.pop_back(); return b; }
+  void give_bytes(RawBuf<uint8_t>&& b) { if (!b.p) return; std::lock_guard<std::mutex> lk(pm_); byte_pool_.push_back(std::move(b)); }
   // symbols -> bytes: 16 at a time when none of them is a marker
   static void resolve(const uint16_t* s, size_t n, const uint8_t* w, uint8_t* o) {
     size_t i = 0;
@@ -486,7 +517,7 @@ class ParGzip {
   }
   // serial decode from cur_bit_ (window known) until a block ends at or behind stop_bit / the member ends; the text is emitted
   int serial_until(uint64_t stop_bit, uint64_t* end_bit) {
-    std::vector<uint8_t> buf(WIN + (1u << 20));
+    RawBuf<uint8_t> buf(WIN + (1u << 20));
     Bits b(d_, n_, cur_bit_);
     uint64_t at = cur_bit_;
     for (;;) {
@@ -512,9 +543,9 @@ class ParGzip {
       const size_t j = pending.front(); pending.pop_front();
       Chunk& c = *chunks_[j];
       { std::unique_lock<std::mutex> lk(c.m); c.cv.wait(lk, [&] { return c.state == CONVERTED; }); }
-      fold(c.bytes.data(), c.bytes.size(), c.crc);
-      const bool ok = deliver_(c.bytes.data(), c.bytes.size(), c.nl);
-      std::vector<uint8_t>().swap(c.bytes); std::vector<uint8_t>().swap(c.window);
+      fold(c.bytes.data(), c.n_bytes, c.crc);
+      const bool ok = deliver_(c.bytes.data(), c.n_bytes, c.nl);
+      give_bytes(std::move(c.bytes)); std::vector<uint8_t>().swap(c.window);
       if (!ok) stopped_ = true;
       return ok;
     };
@@ -539,7 +570,7 @@ class ParGzip {
       const uint64_t s = c.start_bit;
       if (s == ~0ULL || s < cur_bit_ || c.rc == D_ERROR) {   // no block found in the chunk / already covered / the found one was none
         if (s != ~0ULL) ++st_.rejected;
-        std::vector<uint16_t>().swap(c.sym);
+        give_sym(std::move(c.sym));
         ++st_.chunks; ++k;
         continue;
       }
@@ -603,6 +634,7 @@ class ParGzip {
   std::mutex qm_; std::condition_variable qcv_;
   std::deque<size_t> conv_q_; size_t next_decode_ = 0, window_hi_ = 0; bool stop_ = false;
   std::vector<uint8_t> win_;
+  std::mutex pm_; std::vector<RawBuf<uint16_t>> sym_pool_; std::vector<RawBuf<uint8_t>> byte_pool_;
   uint64_t cur_bit_ = 0; uint32_t crc_ = 0; uint64_t member_out_ = 0;
   bool stopped_ = false;
   std::string error_;
