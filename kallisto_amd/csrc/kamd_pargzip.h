@@ -485,7 +485,15 @@ class ParGzip {
         if (!conv_q_.empty()) { k = conv_q_.front(); conv_q_.pop_front(); conv = true; }
         else { k = next_decode_++; conv = false; }
       }
-      if (conv) convert_chunk(k); else decode_chunk(k);
+      try {
+        if (conv) convert_chunk(k); else decode_chunk(k);
+      } catch (...) {   // (out of memory for a chunk's buffers): the coordinator gives up instead of waiting for this chunk for ever
+        Chunk& c = *chunks_[k];
+        fatal_ = true;
+        std::lock_guard<std::mutex> lk(c.m);
+        c.rc = D_ERROR; c.state = conv ? CONVERTED : DECODED; c.n_bytes = 0;
+        c.cv.notify_all();
+      }
     }
   }
   void stop_workers() {
@@ -543,6 +551,7 @@ class ParGzip {
       const size_t j = pending.front(); pending.pop_front();
       Chunk& c = *chunks_[j];
       { std::unique_lock<std::mutex> lk(c.m); c.cv.wait(lk, [&] { return c.state == CONVERTED; }); }
+      if (fatal_) { if (error_.empty()) error_ = "out of memory while inflating"; return false; }
       fold(c.bytes.data(), c.n_bytes, c.crc);
       const bool ok = deliver_(c.bytes.data(), c.n_bytes, c.nl);
       give_bytes(std::move(c.bytes)); std::vector<uint8_t>().swap(c.window);
@@ -567,6 +576,7 @@ class ParGzip {
       while (!pending.empty() && k >= pending.front() + ahead) if (!flush_one()) return false;
       allow_up_to((pending.empty() ? k : pending.front()) + ahead);
       { std::unique_lock<std::mutex> lk(c.m); c.cv.wait(lk, [&] { return c.state >= DECODED; }); }
+      if (fatal_) return fail("out of memory while inflating");
       const uint64_t s = c.start_bit;
       if (s == ~0ULL || s < cur_bit_ || c.rc == D_ERROR) {   // no block found in the chunk / already covered / the found one was none
         if (s != ~0ULL) ++st_.rejected;
@@ -637,6 +647,7 @@ class ParGzip {
   std::mutex pm_; std::vector<RawBuf<uint16_t>> sym_pool_; std::vector<RawBuf<uint8_t>> byte_pool_;
   uint64_t cur_bit_ = 0; uint32_t crc_ = 0; uint64_t member_out_ = 0;
   bool stopped_ = false;
+  std::atomic<bool> fatal_{false};
   std::string error_;
   Stats st_;
 };
