@@ -1016,12 +1016,26 @@ __global__ __launch_bounds__(BLOCK) void k_scan_local(const u32* __restrict__ in
   for (int j = 0; j < 8; j++) if (b0 + j < n) out[b0 + j] = excl + v[j];
   if (threadIdx.x == BLOCK - 1) block_sums[blockIdx.x] = woff + incl;
 }
-__global__ void k_scan_blocks(u64* block_sums, u64 nblocks, u64* total) {  // single thread block, serial over chunks
-  if (threadIdx.x == 0) {
-    u64 run = 0;
-    for (u64 i = 0; i < nblocks; i++) { u64 x = block_sums[i]; block_sums[i] = run; run += x; }
-    *total = run;
-  }
+// exclusive scan of the block sums by ONE block: every thread takes a run of consecutive sums (independent loads), the threads' totals
+// are scanned across the block, the run is written back.  (One thread walking the sums serially paid a global-memory round trip per
+// element: 40-100 us for the 300-1000 blocks of a step's scans.)
+__global__ __launch_bounds__(BLOCK) void k_scan_blocks(u64* block_sums, u64 nblocks, u64* total) {
+  __shared__ u64 wsum[BLOCK / 64];
+  const u64 per = (nblocks + BLOCK - 1) / BLOCK;
+  const u64 b0 = (u64)threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+  u64 run = 0;
+  for (u64 i = b0; i < b1; i++) run += block_sums[i];
+  u64 incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += t; }
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 63) wsum[w] = incl;
+  __syncthreads();
+  u64 woff = 0;
+  for (int j = 0; j < w; j++) woff += wsum[j];
+  u64 acc = woff + incl - run;
+  for (u64 i = b0; i < b1; i++) { const u64 x = block_sums[i]; block_sums[i] = acc; acc += x; }
+  if (threadIdx.x == BLOCK - 1) *total = woff + incl;
 }
 __global__ __launch_bounds__(BLOCK) void k_scan_add(u64* out, u64 n, const u64* block_sums) {
   const u64 b0 = (u64)blockIdx.x * SCAN_ELEMS + (u64)threadIdx.x * 8;
@@ -2096,24 +2110,47 @@ __global__ void k_cc_init(u32* label, u64 n) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) label[t] = (u32)t;
 }
-__global__ void k_cc_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, u32* label, int* changed) {
+// Connected components of the transcript / EC graph as a lock-free union-find in ONE pass over the rows (round 2 propagated minimum
+// labels row by row and jumped pointers until nothing changed: three or four iterations, each with a read-back of the "changed"
+// flag).  parent[x] <= x always: a union hooks the LARGER root under the smaller one with a compare-and-swap, so the root of a
+// component is its smallest transcript id -- the label the plan builder expects -- and paths only lead downwards (no cycles, whatever
+// the interleaving).  Reads of parent[] inside the pass are agent-scope atomic loads: the XCDs' L2s are not coherent with each other
+// within a kernel, and a find that kept seeing a stale "root" would retry its compare-and-swap for ever.
+__device__ __forceinline__ u32 cc_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 cc_find(u32* parent, u32 x) {
+  u32 p = cc_load(parent + x);
+  while (p != x) {
+    const u32 gp = cc_load(parent + p);
+    if (gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving (gp is an ancestor of x)
+    x = p; p = gp;
+  }
+  return x;
+}
+__global__ void k_cc_union(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, u32* parent) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_ecs) return;
   const u64 a = ec_off[e], b = ec_off[e + 1];
   if (b - a < 2) return;
-  u32 m = 0xFFFFFFFFu;
-  for (u64 j = a; j < b; j++) m = min(m, label[ec_ids[j]]);
-  bool ch = false;
-  for (u64 j = a; j < b; j++) { const u32 t = ec_ids[j]; if (label[t] > m) { atomicMin(&label[t], m); ch = true; } }
-  if (ch) *changed = 1;
+  u32 r0 = cc_find(parent, ec_ids[a]);
+  for (u64 j = a + 1; j < b; j++) {
+    u32 r1 = cc_find(parent, ec_ids[j]);
+    while (r0 != r1) {
+      const u32 hi = r0 > r1 ? r0 : r1, lo = r0 > r1 ? r1 : r0;
+      const u32 old = atomicCAS(parent + hi, hi, lo);
+      if (old == hi) { r0 = lo; break; }   // hooked
+      r0 = cc_find(parent, lo); r1 = cc_find(parent, old);   // hi had been hooked by someone else meanwhile: `old` is its new parent
+    }
+  }
 }
-__global__ void k_cc_jump(u32* label, u64 n) {  // label[t] <- label[label[t]] (labels are transcript ids, roots label themselves)
+__global__ void k_cc_flatten(u32* label, u64 n) {   // label[t] <- root of t (behind the kernel boundary plain loads see everything)
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   u32 l = label[t];
-  for (int i = 0; i < 8; i++) { const u32 ll = label[l]; if (ll == l) break; l = ll; }
+  for (;;) { const u32 ll = label[l]; if (ll == l) break; l = ll; }
   label[t] = l;
 }
+// component labels of the matrix into c->pt_label (label = smallest transcript id of the component; transcripts in no row label themselves)
+int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, u64 T);
 __device__ __forceinline__ u32 cc_owner(u32 label, u32 world) { return (u32)(kamd::mix64((u64)label + 0x51ULL) % world); }
 __global__ void k_part_sizes(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ label,
                              u32 rank, u32 world, u32* row_flag, u32* row_len) {
@@ -2284,7 +2321,7 @@ int exclusive_scan(kamd_ctx* c, const u32* sizes, u64 n, u64* out, u64* d_total)
   const u64 nblocks = std::max<u64>(1, (n + SCAN_ELEMS - 1) / SCAN_ELEMS);
   if (int rc = c->block_sums.ensure((nblocks + 2) * sizeof(u64), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblocks), dim3(BLOCK), 0, c->stream, sizes, n, out, c->block_sums.as<u64>());
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(64), 0, c->stream, c->block_sums.as<u64>(), nblocks, d_total);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(BLOCK), 0, c->stream, c->block_sums.as<u64>(), nblocks, d_total);
   hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblocks), dim3(BLOCK), 0, c->stream, out, n, c->block_sums.as<u64>());
   HIPC(hipGetLastError());
   return 0;
@@ -3966,6 +4003,14 @@ __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   else if constexpr (S == 12) kamd_em_local::step_ent_k2(i, A);
   else kamd_em_local::step_rows_k(i, A);
 }
+int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, u64 T) {
+  if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
+  hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
+  if (n_ecs) hipLaunchKernelGGL(k_cc_union, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, c->pt_label.as<u32>());
+  hipLaunchKernelGGL(k_cc_flatten, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
+  HIPC(hipGetLastError());
+  return 0;
+}
 // The plan built on the device: component labels by the kernels the partitioned EM uses, then the steps of
 // kamd_em_local.h with scans in between.  The host only sees the per-group sizes (budget check, bases) and, for the final
 // scatter, tr_id and the singleton counts.  0 = ok (P holds the host part, *dev the device part), 1 = not applicable.
@@ -3976,20 +4021,10 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
                           kamd_em_local::BuildArgs* args_out = nullptr, u32 small_limit = 0, u64 target_small = 0, bool host_maps = true) {
   namespace L = kamd_em_local;
   if (nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
-  // component labels (smallest transcript id of the component): min-label propagation + pointer jumping
+  // component labels (smallest transcript id of the component): one lock-free union-find pass, cc_labels
   if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
-  hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
-  for (int it = 0;; it++) {
-    HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_cc_rows, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, c->pt_label.as<u32>(), (int*)c->pt_hist.p);
-    hipLaunchKernelGGL(k_cc_jump, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
-    int changed = 0;
-    HIPC(hipMemcpyAsync(&changed, c->pt_hist.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    if (!changed) break;
-    if (it > 10000) return kamd::fail(-101, "kamd_em_run: component labelling did not converge");
-  }
+  if (int rc = cc_labels(c, d_ec_off, d_ec_ids, n_ecs, T)) return rc;
   // scratch: per transcript / per root ...
   Carver t1;
   const size_t o_inm = t1.take(T + 8), o_sall = t1.take(T * 8 + 8), o_cn = t1.take(T * 4 + 8), o_cr = t1.take(T * 4 + 8), o_ct = t1.take(T * 4 + 8);
@@ -4577,18 +4612,7 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
     HIPC(hipStreamSynchronize(c->stream));
     if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
     if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
-    for (int it = 0;; it++) {
-      HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(int), c->stream));
-      hipLaunchKernelGGL(k_cc_rows, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, (u64)n_ecs,
-                         c->pt_label.as<u32>(), (int*)c->pt_hist.p);
-      hipLaunchKernelGGL(k_cc_jump, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
-      int changed = 0;
-      HIPC(hipMemcpyAsync(&changed, c->pt_hist.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
-      if (!changed) break;
-      if (it > 10000) return kamd::fail(-101, "kamd_em_run_partitioned: component labelling did not converge");
-    }
+    if (int rc = cc_labels(c, (const u64*)d_ec_off, d_ec_ids, (u64)n_ecs, T)) return rc;
     for (DBuf* b : {&c->pt_flag, &c->pt_len}) if (int rc = b->ensure((n_ecs + 1) * sizeof(u32), 0, c->stream)) return rc;
     for (DBuf* b : {&c->pt_rowpos, &c->pt_nnzpos}) if (int rc = b->ensure((n_ecs + 2) * sizeof(u64), 0, c->stream)) return rc;
     hipLaunchKernelGGL(k_part_sizes, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)d_ec_off, d_ec_ids, (u64)n_ecs,
