@@ -286,6 +286,7 @@ struct BuildArgs {
                           //     slot, in arrival order: a key of the row's CONTENT -- EC indices differ from run to run (kamd_ec_finalize
                           //     emits the sets in the order its atomics hand out), the sets do not
   uint32_t* row_e;        // [R] EC index of a row slot (the last tie-break, and where G2 finds the row)
+  uint32_t* row_e_final;  // [R] EC index of the row at a FINAL row index (what the device's per-group builder walks); may be null
   uint16_t* col_row_tmp;  // [NZ] the transposed entries in arrival order
   uint32_t* ent_col;      // [NZ] m-space slot of the column a transposed entry belongs to
 };
@@ -367,9 +368,18 @@ KAMD_HD void step_slot_g2(uint64_t i, uint32_t g, const BuildArgs& A) {
   const uint64_t e = A.row_e[i];
   const uint32_t lo = A.row_base[g], hi = A.row_base[g + 1];
   uint32_t rank = 0;
-  for (uint32_t j = lo; j < hi; j++) { const uint64_t kj = A.row_key[j]; rank += (kj < key || (kj == key && A.row_e[j] < e)) ? 1u : 0u; }
+  uint32_t j = lo;
+  for (; j + 4 <= hi; j += 4) {   // (four independent loads per trip: the loop is bound by their latency)
+    const uint64_t k0 = A.row_key[j], k1 = A.row_key[j + 1], k2 = A.row_key[j + 2], k3 = A.row_key[j + 3];
+    rank += (k0 < key ? 1u : 0u) + (k1 < key ? 1u : 0u) + (k2 < key ? 1u : 0u) + (k3 < key ? 1u : 0u);
+    if (k0 == key || k1 == key || k2 == key || k3 == key)   // equal keys (the row itself, or a 48-bit hash collision): the EC index decides
+      rank += ((k0 == key && A.row_e[j] < e) ? 1u : 0u) + ((k1 == key && A.row_e[j + 1] < e) ? 1u : 0u) + ((k2 == key && A.row_e[j + 2] < e) ? 1u : 0u) +
+              ((k3 == key && A.row_e[j + 3] < e) ? 1u : 0u);
+  }
+  for (; j < hi; j++) { const uint64_t kj = A.row_key[j]; rank += (kj < key || (kj == key && A.row_e[j] < e)) ? 1u : 0u; }
   const uint32_t rn = lo + rank;
   A.row_new[e] = rn;
+  if (A.row_e_final) A.row_e_final[rn] = (uint32_t)e;
   A.len_new[rn] = (uint32_t)(A.ec_off[e + 1] - A.ec_off[e]);
   A.cw[rn] = (uint64_t)A.counts[e] | ((uint64_t)(A.wcounts ? A.wcounts[e] : A.counts[e]) << 32);
 }

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/kallisto_amd.h"
@@ -4003,6 +4004,82 @@ __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   else if constexpr (S == 12) kamd_em_local::step_ent_k2(i, A);
   else kamd_em_local::step_rows_k(i, A);
 }
+// ---- the second half of the plan (kamd_em_local.h steps I, J, K, K2 and the two scans between them) as ONE kernel, a workgroup per
+// group: after G2 a group's rows are consecutive and in their final order, its transcripts occupy a consecutive range of m-space, so
+// row offsets, column counts, column offsets, the transposed entries and their canonical order are all local to the group -- LDS
+// atomics and block scans instead of 2 x 4.7 M memory-side atomics (0.25 ms each), two device-wide scans and the ranking pass.
+// LDS: row offsets [nR + 1] | column offsets [nT + 1] | column cursors [nT] (u32), then per transposed entry its row and its column (u16).
+__device__ __forceinline__ void eml_block_excl_scan(u32* a, u32 n, u32* s_w) {   // in place; a[n] receives the total; s_w: one word per wavefront
+  const u32 nthr = blockDim.x, tid = threadIdx.x;
+  const u32 per = (n + nthr - 1) / nthr;
+  const u32 b0 = tid * per < n ? tid * per : n, b1 = b0 + per < n ? b0 + per : n;
+  u32 run = 0;
+  for (u32 i = b0; i < b1; i++) run += a[i];
+  u32 incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if (lane_id() >= d) incl += t; }
+  const u32 w = tid >> 6;
+  if (lane_id() == 63) s_w[w] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (u32 j = 0; j < w; j++) woff += s_w[j];
+  u32 acc = woff + incl - run;
+  for (u32 i = b0; i < b1; i++) { const u32 x = a[i]; a[i] = acc; acc += x; }
+  if (tid == nthr - 1) a[n] = woff + incl;
+  __syncthreads();
+}
+__global__ __launch_bounds__(BLOCK) void k_eml_group_build(kamd_em_local::BuildArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
+  __shared__ u32 s_w[BLOCK / 64];
+  const u32 g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const u32 r0 = A.row_base[g], nR = A.row_base[g + 1] - r0, t0 = A.tr_base[g], nT = A.tr_base[g + 1] - t0;
+  const u64 z0 = A.nz_base[g];
+  const u32 nnz = (u32)(A.nz_base[g + 1] - z0);
+  u32* s_roff = reinterpret_cast<u32*>(gb_smem);
+  u32* s_coff = s_roff + (nR + 1);
+  u32* s_cur = s_coff + (nT + 1);
+  uint16_t* s_erow = reinterpret_cast<uint16_t*>(s_cur + nT);
+  uint16_t* s_ecol = s_erow + ((nnz + 1) & ~1u);
+  // row offsets (relative to the group's first entry)
+  for (u32 r = tid; r < nR; r += nthr) s_roff[r] = A.len_new[r0 + r];
+  for (u32 l = tid; l <= nT; l += nthr) s_coff[l] = 0;
+  for (u32 l = tid; l < nT; l += nthr) s_cur[l] = 0;
+  __syncthreads();
+  eml_block_excl_scan(s_roff, nR, s_w);
+  for (u32 r = tid; r <= nR; r += nthr) A.row_ptr[(u64)r0 + r + g] = s_roff[r];   // (row r0 + r of group g sits at row_ptr[r0 + r + g]; the last one closes the group)
+  // the rows' entries (local transcript ids) and the column counts
+  for (u32 r = tid; r < nR; r += nthr) {
+    const u32 e = A.row_e_final[r0 + r];
+    const u64 a = A.ec_off[e];
+    const u32 len = s_roff[r + 1] - s_roff[r], at = s_roff[r];
+    for (u32 j = 0; j < len; j++) {
+      const u32 l = A.local_of[A.ec_ids[a + j]];
+      A.row_tr[z0 + at + j] = (uint16_t)l;
+      atomicAdd(&s_coff[l], 1u);
+    }
+  }
+  __syncthreads();
+  eml_block_excl_scan(s_coff, nT, s_w);
+  for (u32 l = tid; l <= nT; l += nthr) A.col_ptr[(u64)t0 + l + g] = s_coff[l];
+  // the transposed entries in arrival order ...
+  for (u32 r = tid; r < nR; r += nthr) {
+    const u32 len = s_roff[r + 1] - s_roff[r], at = s_roff[r];
+    for (u32 j = 0; j < len; j++) {
+      const u32 l = A.row_tr[z0 + at + j];   // (written by this thread above)
+      const u32 p = s_coff[l] + atomicAdd(&s_cur[l], 1u);
+      s_erow[p] = (uint16_t)r; s_ecol[p] = (uint16_t)l;
+    }
+  }
+  __syncthreads();
+  // ... and in their final one: a column's entries by row (a row occurs once in a column)
+  for (u32 p = tid; p < nnz; p += nthr) {
+    const u32 l = s_ecol[p], v = s_erow[p];
+    const u32 lo = s_coff[l], hi = s_coff[l + 1];
+    u32 rank = 0;
+    for (u32 q = lo; q < hi; q++) rank += s_erow[q] < v ? 1u : 0u;
+    A.col_row[z0 + lo + rank] = (uint16_t)v;
+  }
+}
 int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, u64 T) {
   if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
@@ -4096,7 +4173,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   const size_t p_rp = pv.take((R + ng) * 4 + 8), p_cp = pv.take((M + ng) * 4 + 8), p_rt = pv.take(NZ * 2 + 8), p_cr = pv.take(NZ * 2 + 8);
   const size_t p_cw = pv.take(R * 8 + 8), p_sg = pv.take(M * 8 + 8), p_ef = pv.take(M * 8 + 8), p_id = pv.take(M * 4 + 8);
   const size_t p_len = pv.take(R * 4 + 8), p_rabs = pv.take((R + 2) * 8), p_cc = pv.take(M * 4 + 8), p_cf = pv.take(M * 4 + 8), p_cabs = pv.take((M + 2) * 8);
-  const size_t p_tt = pv.take(M * 4 + 8), p_rk = pv.take(R * 8 + 8), p_crt = pv.take(NZ * 2 + 8), p_ec = pv.take(NZ * 4 + 8), p_re = pv.take(R * 4 + 8);   // scratch of the canonical numbering
+  const size_t p_tt = pv.take(M * 4 + 8), p_rk = pv.take(R * 8 + 8), p_crt = pv.take(NZ * 2 + 8), p_ec = pv.take(NZ * 4 + 8), p_re = pv.take(R * 4 + 8), p_ref = pv.take(R * 4 + 8);   // scratch of the canonical numbering
   if (int rc = c->pm_a.ensure(pv.off, 0, c->stream)) return rc;
   char* pb = (char*)c->pm_a.p;
   HIPC(hipMemcpyAsync(pb + p_rb, P->row_base.data(), (ng + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -4108,18 +4185,28 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   A.cw = (uint64_t*)(pb + p_cw); A.single = (double*)(pb + p_sg); A.eff_m = (double*)(pb + p_ef); A.tr_id = (u32*)(pb + p_id);
   A.len_new = (u32*)(pb + p_len); A.row_abs = (const uint64_t*)(pb + p_rabs); A.col_cnt = (u32*)(pb + p_cc); A.col_fill = (u32*)(pb + p_cf);
   A.col_abs = (const uint64_t*)(pb + p_cabs);
-  A.tmp_tr_id = (u32*)(pb + p_tt); A.row_key = (uint64_t*)(pb + p_rk); A.col_row_tmp = (uint16_t*)(pb + p_crt); A.ent_col = (u32*)(pb + p_ec); A.row_e = (u32*)(pb + p_re);
+  A.tmp_tr_id = (u32*)(pb + p_tt); A.row_key = (uint64_t*)(pb + p_rk); A.col_row_tmp = (uint16_t*)(pb + p_crt); A.ent_col = (u32*)(pb + p_ec); A.row_e = (u32*)(pb + p_re); A.row_e_final = (u32*)(pb + p_ref);
   hipLaunchKernelGGL(k_eml_step<3>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
   hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
   hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
-  if (int rc = exclusive_scan(c, A.len_new, R, (u64*)(pb + p_rabs), (u64*)(pb + p_rabs) + R)) return rc;
-  hipLaunchKernelGGL(k_eml_step<5>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
-  if (int rc = exclusive_scan(c, A.col_cnt, M, (u64*)(pb + p_cabs), (u64*)(pb + p_cabs) + M)) return rc;
-  hipLaunchKernelGGL(k_eml_step<6>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
-  hipLaunchKernelGGL(k_eml_step<7>, dim3(grid_for(ng, BLOCK)), dim3(BLOCK), 0, c->stream, A, (u64)ng);
-  hipLaunchKernelGGL(k_eml_step<8>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
-  hipLaunchKernelGGL(k_eml_step<12>, dim3(grid_for(NZ, BLOCK)), dim3(BLOCK), 0, c->stream, A, NZ);
+  // steps I, J, K, K2 and their scans: one workgroup per group out of LDS (k_eml_group_build); a group too large for that -- none
+  // that the EM kernel could hold -- takes the steps one by one
+  size_t gb_lds = 0;
+  for (u32 g = 0; g < ng; g++)
+    gb_lds = std::max(gb_lds, ((size_t)g_rows[g] + 1 + 2 * (size_t)g_tr[g] + 1) * 4 + (((size_t)g_nnz[g] + 1) & ~(size_t)1) * 4 + 16);
+  if (gb_lds <= 150 * 1024 && !getenv("KAMD_EM_PLAN_STEPS")) {   // (KAMD_EM_PLAN_STEPS: experiments / tests take the step kernels)
+    HIPC(hipFuncSetAttribute((const void*)k_eml_group_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gb_lds));
+    hipLaunchKernelGGL(k_eml_group_build, dim3(ng), dim3(BLOCK), gb_lds, c->stream, A);
+  } else {
+    if (int rc = exclusive_scan(c, A.len_new, R, (u64*)(pb + p_rabs), (u64*)(pb + p_rabs) + R)) return rc;
+    hipLaunchKernelGGL(k_eml_step<5>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+    if (int rc = exclusive_scan(c, A.col_cnt, M, (u64*)(pb + p_cabs), (u64*)(pb + p_cabs) + M)) return rc;
+    hipLaunchKernelGGL(k_eml_step<6>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
+    hipLaunchKernelGGL(k_eml_step<7>, dim3(grid_for(ng, BLOCK)), dim3(BLOCK), 0, c->stream, A, (u64)ng);
+    hipLaunchKernelGGL(k_eml_step<8>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+    hipLaunchKernelGGL(k_eml_step<12>, dim3(grid_for(NZ, BLOCK)), dim3(BLOCK), 0, c->stream, A, NZ);
+  }
   HIPC(hipGetLastError());
   // what the host needs for the final scatter (a single rank scatters on the device: em_sell_drive_async)
   if (host_maps) {
@@ -5363,11 +5450,16 @@ extern "C" int kamd_quant_batches(kamd_ctx* c, const kamd_quant_opts* o, const k
     }
     if (int rc = kamd_ec_allreduce(c, comm)) return rc;
   }
+  // the effective lengths only need the fragment-length sample: a quarter of a millisecond of host arithmetic, done while the device resolves the classes
   std::vector<double> mft(KAMD_MAX_FRAG_LEN);
-  if (o->fld == 0.0) kamd_mean_frag_lens_trunc(out->flens, mft.data());
-  else kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, o->fld, o->sd, mft.data());
-  if (int rc = kamd_ec_finalize(c, nullptr)) return rc;
-  kamd_eff_lens(target_lens, n_targets, mft.data(), out->eff_lens);
+  std::thread eff_thread([&] {
+    if (o->fld == 0.0) kamd_mean_frag_lens_trunc(out->flens, mft.data());
+    else kamd_trunc_gaussian_fld(0, KAMD_MAX_FRAG_LEN, o->fld, o->sd, mft.data());
+    kamd_eff_lens(target_lens, n_targets, mft.data(), out->eff_lens);
+  });
+  const int fin_rc = kamd_ec_finalize(c, nullptr);
+  eff_thread.join();
+  if (fin_rc) return fin_rc;
   int32_t rounds = 0;
   if (multi) { if (int rc = kamd_em_run_comm(c, comm, out->eff_lens, n_targets, 10000, 50, out->est_counts, out->alpha_before_zeroes, &rounds)) return rc; }
   else if (int rc = kamd_em_run(c, nullptr, nullptr, nullptr, nullptr, 0, out->eff_lens, n_targets, 10000, 50, out->est_counts, out->alpha_before_zeroes, &rounds)) return rc;
