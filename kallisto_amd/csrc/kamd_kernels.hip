@@ -2115,14 +2115,14 @@ __global__ void k_cc_init(u32* label, u64 n) {
 // labels row by row and jumped pointers until nothing changed: three or four iterations, each with a read-back of the "changed"
 // flag).  parent[x] <= x always: a union hooks the LARGER root under the smaller one with a compare-and-swap, so the root of a
 // component is its smallest transcript id -- the label the plan builder expects -- and paths only lead downwards (no cycles, whatever
-// the interleaving).  Reads of parent[] inside the pass are agent-scope atomic loads: the XCDs' L2s are not coherent with each other
-// within a kernel, and a find that kept seeing a stale "root" would retry its compare-and-swap for ever.
-__device__ __forceinline__ u32 cc_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the interleaving).  The walks use plain loads, which an XCD's L2 may serve with a value from before another XCD's update -- any value
+// parent[x] ever had is an ancestor of x, so a stale walk only ends at an ancestor that is no longer a root; the compare-and-swap
+// (executed at the memory side) then fails and returns the node's present parent, a strictly smaller id, and the union goes on from there.
 __device__ __forceinline__ u32 cc_find(u32* parent, u32 x) {
-  u32 p = cc_load(parent + x);
+  u32 p = parent[x];
   while (p != x) {
-    const u32 gp = cc_load(parent + p);
-    if (gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving (gp is an ancestor of x)
+    const u32 gp = parent[p];
+    if (gp != p) parent[x] = gp;   // path halving (gp is an ancestor of x; x is no root, so no compare-and-swap on it can succeed any more)
     x = p; p = gp;
   }
   return x;
@@ -2136,10 +2136,11 @@ __global__ void k_cc_union(const u64* __restrict__ ec_off, const u32* __restrict
   for (u64 j = a + 1; j < b; j++) {
     u32 r1 = cc_find(parent, ec_ids[j]);
     while (r0 != r1) {
-      const u32 hi = r0 > r1 ? r0 : r1, lo = r0 > r1 ? r1 : r0;
+      const bool first_hi = r0 > r1;
+      const u32 hi = first_hi ? r0 : r1, lo = first_hi ? r1 : r0;
       const u32 old = atomicCAS(parent + hi, hi, lo);
-      if (old == hi) { r0 = lo; break; }   // hooked
-      r0 = cc_find(parent, lo); r1 = cc_find(parent, old);   // hi had been hooked by someone else meanwhile: `old` is its new parent
+      if (old == hi) { r0 = lo; break; }          // hooked: hi was a root, lo is a node of the other tree (parent < child still holds)
+      if (first_hi) r0 = old; else r1 = old;       // hi has a parent by now: go on from it
     }
   }
 }
@@ -4028,6 +4029,43 @@ __device__ __forceinline__ void eml_block_excl_scan(u32* a, u32 n, u32* s_w) {  
   if (tid == nthr - 1) a[n] = woff + incl;
   __syncthreads();
 }
+// steps F2 / G2 (the canonical numbering) with the group's keys in LDS: one workgroup per group loads the keys its members were handed
+// out in arrival order and every thread ranks its members against them (all lanes read the same LDS word: a broadcast) -- the
+// per-member kernels walked the group's keys in global memory, a few hundred dependent-latency loads per member
+__global__ __launch_bounds__(BLOCK) void k_eml_rank_tr(kamd_em_local::BuildArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
+  u32* s_t = reinterpret_cast<u32*>(gb_smem);
+  const u32 g = blockIdx.x, lo = A.tr_base[g], n = A.tr_base[g + 1] - lo;
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) s_t[i] = A.tmp_tr_id[lo + i];
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    const u32 t = s_t[i];
+    u32 rank = 0;
+    for (u32 j = 0; j < n; j++) rank += s_t[j] < t ? 1u : 0u;
+    A.local_of[t] = rank;
+    const u64 m = (u64)lo + rank;
+    A.tr_id[m] = t; A.single[m] = A.single_all[t]; A.eff_m[m] = A.eff[t];
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_eml_rank_rows(kamd_em_local::BuildArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
+  const u32 g = blockIdx.x, lo = A.row_base[g], n = A.row_base[g + 1] - lo;
+  u64* s_k = reinterpret_cast<u64*>(gb_smem);
+  u32* s_e = reinterpret_cast<u32*>(s_k + n);
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) { s_k[i] = A.row_key[lo + i]; s_e[i] = A.row_e[lo + i]; }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    const u64 key = s_k[i];
+    const u32 e = s_e[i];
+    u32 rank = 0;
+    for (u32 j = 0; j < n; j++) { const u64 kj = s_k[j]; rank += (kj < key || (kj == key && s_e[j] < e)) ? 1u : 0u; }
+    const u32 rn = lo + rank;
+    A.row_new[e] = rn;
+    A.row_e_final[rn] = e;
+    A.len_new[rn] = (u32)(A.ec_off[(u64)e + 1] - A.ec_off[e]);
+    A.cw[rn] = (u64)A.counts[e] | ((u64)(A.wcounts ? A.wcounts[e] : A.counts[e]) << 32);
+  }
+}
 __global__ __launch_bounds__(BLOCK) void k_eml_group_build(kamd_em_local::BuildArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
   __shared__ u32 s_w[BLOCK / 64];
@@ -4186,10 +4224,20 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   A.len_new = (u32*)(pb + p_len); A.row_abs = (const uint64_t*)(pb + p_rabs); A.col_cnt = (u32*)(pb + p_cc); A.col_fill = (u32*)(pb + p_cf);
   A.col_abs = (const uint64_t*)(pb + p_cabs);
   A.tmp_tr_id = (u32*)(pb + p_tt); A.row_key = (uint64_t*)(pb + p_rk); A.col_row_tmp = (uint16_t*)(pb + p_crt); A.ent_col = (u32*)(pb + p_ec); A.row_e = (u32*)(pb + p_re); A.row_e_final = (u32*)(pb + p_ref);
+  // the canonical numbering: members are handed slots by atomic cursors (steps F, G), then ranked inside their group -- out of LDS
+  // when the group's keys fit (always, for groups the EM kernel can hold), by the per-member step kernels otherwise
+  size_t rk_lds = 0;
+  for (u32 g = 0; g < ng; g++) rk_lds = std::max(rk_lds, std::max((size_t)g_tr[g] * 4, (size_t)g_rows[g] * 12) + 16);
+  const bool lds_rank = rk_lds <= 150 * 1024 && !getenv("KAMD_EM_PLAN_STEPS");
   hipLaunchKernelGGL(k_eml_step<3>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
-  hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
+  if (lds_rank) {
+    HIPC(hipFuncSetAttribute((const void*)k_eml_rank_tr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+    HIPC(hipFuncSetAttribute((const void*)k_eml_rank_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
+    hipLaunchKernelGGL(k_eml_rank_tr, dim3(ng), dim3(BLOCK), rk_lds, c->stream, A);
+  } else hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
   hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
-  hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
+  if (lds_rank) hipLaunchKernelGGL(k_eml_rank_rows, dim3(ng), dim3(BLOCK), rk_lds, c->stream, A);
+  else hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
   // steps I, J, K, K2 and their scans: one workgroup per group out of LDS (k_eml_group_build); a group too large for that -- none
   // that the EM kernel could hold -- takes the steps one by one
   size_t gb_lds = 0;
