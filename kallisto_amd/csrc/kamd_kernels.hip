@@ -4041,7 +4041,15 @@ __global__ __launch_bounds__(BLOCK) void k_eml_rank_tr(kamd_em_local::BuildArgs 
   for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
     const u32 t = s_t[i];
     u32 rank = 0;
-    for (u32 j = 0; j < n; j++) rank += s_t[j] < t ? 1u : 0u;
+    u32 j = 0;
+    for (; j + 8 <= n; j += 8) {
+      u32 k[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) k[q] = s_t[j + q];
+#pragma unroll
+      for (int q = 0; q < 8; q++) rank += k[q] < t ? 1u : 0u;
+    }
+    for (; j < n; j++) rank += s_t[j] < t ? 1u : 0u;
     A.local_of[t] = rank;
     const u64 m = (u64)lo + rank;
     A.tr_id[m] = t; A.single[m] = A.single_all[t]; A.eff_m[m] = A.eff[t];
@@ -4058,7 +4066,20 @@ __global__ __launch_bounds__(BLOCK) void k_eml_rank_rows(kamd_em_local::BuildArg
     const u64 key = s_k[i];
     const u32 e = s_e[i];
     u32 rank = 0;
-    for (u32 j = 0; j < n; j++) { const u64 kj = s_k[j]; rank += (kj < key || (kj == key && s_e[j] < e)) ? 1u : 0u; }
+    u32 j = 0;
+    for (; j + 8 <= n; j += 8) {   // eight independent LDS reads per trip (one at a time the loop waits out the LDS latency 600 times per row)
+      u64 k[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) k[q] = s_k[j + q];
+      bool tie = false;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { rank += k[q] < key ? 1u : 0u; tie = tie || k[q] == key; }
+      if (tie) {   // equal keys (the row itself, or a 48-bit hash collision): the EC index decides
+#pragma unroll
+        for (int q = 0; q < 8; q++) rank += (k[q] == key && s_e[j + q] < e) ? 1u : 0u;
+      }
+    }
+    for (; j < n; j++) { const u64 kj = s_k[j]; rank += (kj < key || (kj == key && s_e[j] < e)) ? 1u : 0u; }
     const u32 rn = lo + rank;
     A.row_new[e] = rn;
     A.row_e_final[rn] = e;
@@ -4114,7 +4135,15 @@ __global__ __launch_bounds__(BLOCK) void k_eml_group_build(kamd_em_local::BuildA
     const u32 l = s_ecol[p], v = s_erow[p];
     const u32 lo = s_coff[l], hi = s_coff[l + 1];
     u32 rank = 0;
-    for (u32 q = lo; q < hi; q++) rank += s_erow[q] < v ? 1u : 0u;
+    u32 q = lo;
+    for (; q + 8 <= hi; q += 8) {
+      u32 k[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) k[i] = s_erow[q + i];
+#pragma unroll
+      for (int i = 0; i < 8; i++) rank += k[i] < v ? 1u : 0u;
+    }
+    for (; q < hi; q++) rank += s_erow[q] < v ? 1u : 0u;
     A.col_row[z0 + lo + rank] = (uint16_t)v;
   }
 }
@@ -4774,8 +4803,11 @@ int em_run_impl(kamd_ctx* c, const uint64_t* d_ec_off, const uint32_t* d_ec_ids,
   }
   u64 nnz = 0;
   if (n_ecs) {
-    HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    if (c->finalized && d_ec_off == c->result.d_ec_off && n_ecs == c->result.n_ecs) nnz = c->result.nnz;   // (the context's own result: known since kamd_ec_finalize)
+    else {
+      HIPC(hipMemcpyAsync(&nnz, (const u64*)d_ec_off + n_ecs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+    }
   }
   if (n_ecs || spec) {   // the component-local form (kamd_em_local.h); over several ranks only its sliced-ELLPACK kernel
     if (c->tune.em_form == 3) {
