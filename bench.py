@@ -343,10 +343,14 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         have_flat = subprocess.run([exe, "flatten", "-i", idx_path, "-o", flat, "-t", str(threads)], stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL).returncode == 0
         flatten_s = time.time() - t0
-        runs = [("plain", idx_path, plain, n, {}), ("bgzf", idx_path, bg, n, {}), ("gzip", idx_path, gz, ngz, {}),
-                ("plain_host_parsed", idx_path, plain, n, {"KAMD_HOST_PARSE": "1"})]
+        # the rate legs measure the input path alone (KAMD_FQ_NO_OVERLAP: the input waits for the index, as the bulk of a large input does);
+        # the *_overlapped legs are the front-end as it runs by default: input read, copied and parsed while the index loads
+        seq = {"KAMD_FQ_NO_OVERLAP": "1"}
+        runs = [("plain", idx_path, plain, n, seq), ("bgzf", idx_path, bg, n, seq), ("gzip", idx_path, gz, ngz, seq),
+                ("plain_host_parsed", idx_path, plain, n, {"KAMD_HOST_PARSE": "1", **seq}), ("plain_overlapped", idx_path, plain, n, {})]
         if have_flat:
-            runs.append(("plain_flattened_index", flat, plain, n, {}))
+            runs.append(("plain_flattened_index", flat, plain, n, seq))
+            runs.append(("plain_flattened_index_overlapped", flat, plain, n, {}))
         for kind, ipath, files, cnt, env in runs:
             cmd = [exe, "quant", "-i", ipath, "-o", os.path.join(tmp, "out_" + kind), "-t", str(threads), "--plaintext", "--verbose", *extra, *files]
             t0 = time.time()
@@ -366,6 +370,10 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
                 elif line.startswith("[timing] total"):
                     tm["total_s"] = float(line.split()[-2])
             reads_s = tm.get("reads_done_s", wall) - tm.get("index_on_device_s", 0.0)
+            if kind.endswith("_overlapped"):   # (the window behind the index says nothing here: most of the input was handled under the index load)
+                out[kind] = {unit: cnt, "wall_s": round(wall, 2), **{k: round(v, 3) for k, v in tm.items()},
+                             "after_index_s": round(reads_s, 3), "whole_run_M_per_s": round(cnt / wall / 1e6, 3)}
+                continue
             out[kind] = {unit: cnt, "file_GB": round(sum(os.path.getsize(f) for f in files) / 1e9, 3), "wall_s": round(wall, 2),
                          **{k: round(v, 3) for k, v in tm.items()},
                          "input_to_ecs_M_per_s": round(cnt / max(reads_s, 1e-9) / 1e6, 3),
@@ -382,9 +390,11 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         except OSError:
             out["device_parser_equals_host_parser"] = None
         out["note"] = ("kallisto_amd_quant from FASTQ on local disk (page cache warm).  plain / bgzf / gzip: host threads move bytes into pinned rings "
-                       "(pread; block-parallel inflate; one inflate thread per file) and count newlines, lines / record check / 2-bit packing on the GPU; "
+                       "(pread; block-parallel inflate of BGZF and of ordinary gzip) and count newlines, lines / record check / 2-bit packing on the GPU; "
                        "plain_host_parsed: the general reader (KAMD_HOST_PARSE=1).  input_to_ecs = from index-on-device to the last pseudoalignment "
-                       "(reading, H2D, parsing, packing, pseudoalignment), whole_run = process start to exit (index load, EM, output files)")
+                       "(reading, H2D, parsing, packing, pseudoalignment) with the input held back until the index is on the device (KAMD_FQ_NO_OVERLAP: "
+                       "the input path alone); whole_run = process start to exit (index load, EM, output files).  *_overlapped: the default front-end, "
+                       "which reads, copies and parses the input while the index loads (after_index_s = what is left to do once the index is there)")
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

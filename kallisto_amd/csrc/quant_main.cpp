@@ -242,7 +242,17 @@ int main(int argc, char** argv) {
   uint32_t flens[KAMD_MAX_FRAG_LEN] = {0};
   uint64_t fld_used = 0, n_processed = 0;
   std::atomic<bool> fld_open{paired && opt.fld == 0.0};   // the fragment-length sample is still being collected (on GPU 0)
+  // The index is loaded and uploaded on a thread of its own while the input is already read, copied to the device and parsed (none of
+  // that needs the index): only the pseudoalignment of the first batch waits for it.  0 = loading, 1 = on every device, -1 = failed.
+  std::mutex ix_m; std::condition_variable ix_cv; int ix_state = 0; std::string ix_err;
+  auto index_ready = [&](std::string* err) -> bool {
+    std::unique_lock<std::mutex> lk(ix_m);
+    ix_cv.wait(lk, [&] { return ix_state != 0; });
+    if (ix_state < 0 && err) *err = ix_err;
+    return ix_state > 0;
+  };
   auto run_batch = [&](int g, PackedBatch& b, std::string& err) -> int {
+    if (!index_ready(&err)) return -1;
     const bool want_fld = g == 0 && paired && opt.fld == 0.0 && fld_used < 10000;
     int rc = 0;
     if (want_fld) rc = kamd_fld_prefetch(ctxs[g], &qo, b.d_words, b.d_len, b.n_items, b.max_len);   // runs underneath kernel A
@@ -264,31 +274,39 @@ int main(int argc, char** argv) {
     if (!getenv("KAMD_NO_FLAT_INDEX") && stat(opt.index.c_str(), &si) == 0 && stat(flat.c_str(), &sf) == 0 && sf.st_mtime >= si.st_mtime) index_path = flat;
   }
   kamd_index* idx = nullptr;
-  if (kamd_index_load(index_path.c_str(), opt.threads, &idx) != 0) { const std::string e = kamd_last_error(); prep.join(); std::cerr << "Error: " << e << std::endl; return 1; }
-  kamd_index_view v; KX(kamd_index_get_view(idx, &v));
-  const double index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
-  {
+  kamd_index_view v{};
+  double index_load_s = 0.0, index_ready_s = 0.0;
+  std::thread ix_thread([&] {
+    auto done = [&](int st, const std::string& e) { { std::lock_guard<std::mutex> lk(ix_m); ix_state = st; ix_err = e; } ix_cv.notify_all(); };
+    if (kamd_index_load(index_path.c_str(), opt.threads, &idx) != 0) { done(-1, kamd_last_error()); return; }
+    if (kamd_index_get_view(idx, &v) != 0) { done(-1, kamd_last_error()); return; }
+    index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
     std::vector<std::thread> th; std::vector<int> rcs((size_t)n_gpus, 0); std::vector<std::string> errs((size_t)n_gpus);
     for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {   // the index is replicated in every GPU's HBM
       rcs[g] = kamd_index_upload(ctxs[g], idx);
       if (rcs[g]) errs[g] = kamd_last_error();
     });
     for (auto& x : th) x.join();
-    prep.join();
-    for (int g = 0; g < n_gpus; g++) if (rcs[g]) { std::cerr << "Error: " << errs[g] << std::endl; return 1; }
-  }
-  const double index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  if (opt.verbose && index_path != opt.index) std::cerr << "[index] using the flattened tables of " << index_path << std::endl;
-  if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
-  // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
-  // (one GPU only: records merged from several GPUs have no input order -- like the reference at -t > 1)
-  if (opt.bootstrap > 0 && n_gpus == 1) KX(kamd_ec_track_order(ctx, 1));
+    for (int g = 0; g < n_gpus; g++) if (rcs[g]) { done(-1, errs[g]); return; }
+    // bootstrap replicates are multinomials over the count vector in EC-id order: ask for the reference's (-t 1) ids
+    // (one GPU only: records merged from several GPUs have no input order -- like the reference at -t > 1)
+    if (opt.bootstrap > 0 && n_gpus == 1 && kamd_ec_track_order(ctx, 1) != 0) { done(-1, kamd_last_error()); return; }
+    index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (opt.verbose && index_path != opt.index) std::cerr << "[index] using the flattened tables of " << index_path << std::endl;
+    if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
+    done(1, "");
+  });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } ix_join{ix_thread}, prep_join{prep};
+  prep.join();
+  // (measurements of the input path alone: KAMD_FQ_NO_OVERLAP makes the input wait for the index, as a very large input effectively does)
+  if (getenv("KAMD_FQ_NO_OVERLAP")) (void)index_ready(nullptr);
   std::cerr << "[quant] running in " << (paired ? "paired-end" : "single-end") << " mode" << std::endl;
   double pack_s = 0.0;
   MultiPipe pipe(devices, run_batch, pin_first);
   // the device parser declined the input: the run starts over with the general reader
   auto reset_run = [&]() -> int {
+    if (!index_ready(nullptr)) return -1;
     for (kamd_ctx* x : ctxs) if (int rc = kamd_ec_reset(x)) return rc;
     memset(flens, 0, sizeof flens); fld_used = 0; fld_open = paired && opt.fld == 0.0;
     return 0;
@@ -297,7 +315,9 @@ int main(int argc, char** argv) {
     std::cerr << "[quant] will process " << (paired ? "pair " : "file ") << (fi / (paired ? 2 : 1) + 1) << ": " << opt.files[fi] << std::endl;
     if (paired) std::cerr << "                             " << opt.files[fi + 1] << std::endl;
   }
-  if (feed_files(opt.files, paired, opt.batch, std::max(1, opt.threads), opt.threads, opt.verbose, pipe, n_processed, pack_s, &feeder, reset_run)) return 1;
+  const int feed_rc = feed_files(opt.files, paired, opt.batch, std::max(1, opt.threads), opt.threads, opt.verbose, pipe, n_processed, pack_s, &feeder, reset_run);
+  { std::string e; if (!index_ready(&e)) { std::cerr << "Error: " << e << std::endl; return 1; } }   // (also when there was no read to wait for it)
+  if (feed_rc) return 1;
   pipe.finish();
   if (pipe.failed()) { std::cerr << "Error: " << pipe.error() << std::endl; return 1; }
   if (opt.verbose) std::cerr << "[timing] reads parsed, packed and pseudoaligned after " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
