@@ -412,7 +412,35 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   // 3. nodes
   uint64_t n_nodes = c.get<uint64_t>();
   std::vector<std::vector<RawBlock>> ublocks(ix->n_unitigs);
-  std::unordered_map<std::vector<uint32_t>, uint32_t, VecHash> ec_of;
+  // transcript set -> id in order of first appearance: an open-addressing table of ids whose keys are the sets already stored in
+  // ec_ids / ec_off (no copy of a set per entry, no allocation per insertion)
+  std::vector<uint32_t> ec_tab(1u << 16, 0xFFFFFFFFu);
+  uint64_t ec_tab_used = 0;
+  auto ec_hash = [](const std::vector<uint32_t>& v) { uint64_t h = 0x9e3779b97f4a7c15ULL ^ v.size(); for (uint32_t x : v) h = kamd::mix64(h ^ x); return h; };
+  auto ec_intern = [&](const std::vector<uint32_t>& v) -> uint32_t {
+    if ((ec_tab_used + 1) * 2 > ec_tab.size()) {   // grow: re-insert the ids by the hash of their stored sets
+      std::vector<uint32_t> nt(ec_tab.size() * 4, 0xFFFFFFFFu);
+      std::vector<uint32_t> t;
+      for (uint32_t id : ec_tab) if (id != 0xFFFFFFFFu) {
+        t.assign(ix->ec_ids.begin() + ix->ec_off[id], ix->ec_ids.begin() + ix->ec_off[id + 1]);
+        uint64_t p = ec_hash(t) & (nt.size() - 1);
+        while (nt[p] != 0xFFFFFFFFu) p = (p + 1) & (nt.size() - 1);
+        nt[p] = id;
+      }
+      ec_tab.swap(nt);
+    }
+    uint64_t p = ec_hash(v) & (ec_tab.size() - 1);
+    for (;; p = (p + 1) & (ec_tab.size() - 1)) {
+      const uint32_t id = ec_tab[p];
+      if (id == 0xFFFFFFFFu) break;
+      const uint64_t a = ix->ec_off[id], n = ix->ec_off[id + 1] - a;
+      if (n == v.size() && std::equal(v.begin(), v.end(), ix->ec_ids.begin() + a)) return id;
+    }
+    const uint32_t id = (uint32_t)(ix->ec_off.size() - 1);
+    ix->ec_ids.insert(ix->ec_ids.end(), v.begin(), v.end()); ix->ec_off.push_back(ix->ec_ids.size());
+    ec_tab[p] = id; ++ec_tab_used;
+    return id;
+  };
   std::vector<uint32_t> set, tmp, posw_all; std::vector<uint8_t> sense_all;
   ix->ec_off.push_back(0);
   for (uint64_t i = 0; i < n_nodes; i++) {
@@ -446,9 +474,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
         bool smin = (mn & 0x7FFFFFFFu) == mn, smax = (mx & 0x7FFFFFFFu) == mx;
         sense_all.push_back(smin != smax ? 2 : (uint8_t)smin);
       }
-      auto ins = ec_of.emplace(set, (uint32_t)ec_of.size());
-      if (ins.second) { ix->ec_ids.insert(ix->ec_ids.end(), set.begin(), set.end()); ix->ec_off.push_back(ix->ec_ids.size()); }
-      rb.ec = ins.first->second;
+      rb.ec = ec_intern(set);
       bl.push_back(rb);
     }
     std::stable_sort(bl.begin(), bl.end(), [](const RawBlock& a, const RawBlock& b) { return a.lb < b.lb; });
@@ -526,7 +552,18 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers * 2 + S - 1) / S);  // load factor 0.5 over 3-slot buckets
   if (nb >= 0xFFFFFFF0ULL) return kamd::fail(-3, "index: too many k-mers for 32-bit bucket numbers");
   ix->n_buckets = nb;
-  std::vector<uint32_t> fill(nb + 1, 0);
+  // [0, n) in contiguous pieces, one per thread: the big arrays are first touched (and later scanned) by all threads
+  auto parallel_range = [&](uint64_t n, auto&& body) {
+    std::vector<std::thread> th;
+    const uint64_t per = (n + (uint64_t)threads - 1) / (uint64_t)threads;
+    for (int t = 0; t < threads; t++) {
+      const uint64_t a = std::min(n, per * (uint64_t)t), b = std::min(n, a + per);
+      if (a < b) th.emplace_back([&body, a, b] { body(a, b); });
+    }
+    for (auto& t : th) t.join();
+  };
+  BigVec<uint32_t> fill; fill.resize(nb + 1);
+  parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
   auto fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data());
   auto run_parallel = [&](auto&& body) {
     std::vector<std::thread> th;
@@ -553,25 +590,33 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   });
   tick("table: count pass");
   // placement: keys grouped by home bucket are laid down sequentially, never before their home (Robin Hood order)
-  std::vector<uint64_t> base(nb);
+  BigVec<uint64_t> base; base.resize(nb);
   uint64_t cursor = 0;
-  std::vector<uint8_t> cont(nb + 1, 0);
-  for (uint64_t b = 0; b < nb; b++) {
+  for (uint64_t b = 0; b < nb; b++) {   // (a running maximum: serial, but only 12 bytes per bucket go through it)
     cursor = std::max(cursor, b * S);
     base[b] = cursor;
     cursor += fill[b];
-    if (cursor > (b + 1) * S) cont[b] = 1;
   }
+  const uint64_t end_cursor = cursor;
   uint64_t total_buckets = std::max(nb, (cursor + S - 1) / S) + 1;
   ix->pad_buckets = total_buckets - nb;
-  std::vector<uint8_t> cont_all(total_buckets, 0);
-  for (uint64_t b = 0; b < nb; b++) cont_all[b] = cont[b];
-  for (uint64_t b = nb; b < total_buckets; b++) cont_all[b] = (cursor > (b + 1) * S);
-  ix->table.assign(total_buckets * 8, 0);
-  for (uint64_t b = 0; b < total_buckets; b++) for (uint64_t j = 0; j < S; j++) ix->table[8 * b + j] = kamd::KEY_EMPTY;
-  ix->slot_block.assign(total_buckets * S, 0xFFFFFFFFu);
-  ix->slot_dist.assign(total_buckets * S, 0);
-  std::fill(fill.begin(), fill.end(), 0);
+  // a bucket continues into the next one when keys homed at or before it spill past its slots: then all its slots are taken, and the
+  // key that lands in slot 0 carries the flag (set by the placement below)
+  auto bucket_continues = [&](uint64_t b) { const uint64_t reach = b + 1 < nb ? base[b + 1] : end_cursor; return reach > (b + 1) * S; };
+  // the tables are allocated untouched and initialised by all threads (value-initialising 3.3 GB on one thread was a third of the load)
+  ix->table.resize(total_buckets * 8);
+  ix->slot_block.resize(total_buckets * S);
+  ix->slot_dist.resize(total_buckets * S);
+  parallel_range(total_buckets, [&](uint64_t a, uint64_t b) {
+    for (uint64_t i = a; i < b; i++) {
+      uint64_t* w = ix->table.data() + 8 * i;
+      for (uint64_t j = 0; j < S; j++) w[j] = kamd::KEY_EMPTY;
+      for (uint64_t j = S; j < 8; j++) w[j] = 0;
+    }
+    std::fill(ix->slot_block.begin() + a * S, ix->slot_block.begin() + b * S, 0xFFFFFFFFu);
+    memset(ix->slot_dist.data() + a * S, 0, (b - a) * S * sizeof(uint32_t));
+  });
+  parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
   tick("table: layout + allocation");
   auto utext_atomic = reinterpret_cast<std::atomic<uint32_t>*>(ix->utext.data());
   run_parallel([&](uint64_t u) {
@@ -587,7 +632,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
       uint32_t lb = ix->blk_lb[cur], ub = ix->blk_ub[cur];
       uint32_t rem_f = ub - 1 - dist, rem_b = dist - lb;   // KmerIndex.cpp:1780-1789
       const uint64_t bk = slot / S, j = slot % S;
-      ix->table[8 * bk + j] = cn;
+      ix->table[8 * bk + j] = (j == 0 && bucket_continues(bk)) ? (cn | kamd::KEY_CONT) : cn;
       ix->table[8 * bk + S + j] = kamd::make_payload(rem_f, rem_b, ix->blk_uec[cur], f);
       reinterpret_cast<uint32_t*>(&ix->table[8 * bk + 2 * S])[j] = (uint32_t)(g0 + dist);
       ix->slot_block[slot] = (uint32_t)cur;
@@ -607,7 +652,6 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     }
     if (acc) utext_atomic[wi].fetch_or(acc, std::memory_order_relaxed);
   });
-  for (uint64_t b = 0; b < total_buckets; b++) if (cont_all[b]) ix->table[8 * b] |= kamd::KEY_CONT;
   tick("table: place pass");
   // ---- D-list table (same bucket layout, built serially: it is small) and the dummy hit ----
   if (ix->dlist_size) {
