@@ -162,6 +162,19 @@ inline void for_each_kmer(const uint8_t* packed, uint64_t len, int k, F&& f) {
     if (j + 1 >= (uint64_t)k) f((uint32_t)(j + 1 - k), v);
   }
 }
+// the same with the reverse complement rolled along (what kamd::revcomp_msb(v, k) gives): calls f(dist, fwd_value, rc_value)
+template <class F>
+inline void for_each_kmer_rc(const uint8_t* packed, uint64_t len, int k, F&& f) {
+  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const int top = 2 * (k - 1);
+  uint64_t v = 0, rc = 0;
+  for (uint64_t j = 0; j < len; j++) {
+    const uint64_t b = (packed[j >> 2] >> ((j & 3) << 1)) & 3;
+    v = ((v << 2) | b) & mask;
+    rc = (rc >> 2) | ((3 - b) << top);
+    if (j + 1 >= (uint64_t)k) f((uint32_t)(j + 1 - k), v, rc);
+  }
+}
 
 }  // namespace
 
@@ -565,29 +578,39 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   BigVec<uint32_t> fill; fill.resize(nb + 1);
   parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
   auto fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data());
-  auto run_parallel = [&](auto&& body) {
+  // all unitigs, handed out in runs of 256; every thread has a state of its own (make()), flushed when it runs out of work (drain())
+  auto run_parallel = [&](auto&& make, auto&& body, auto&& drain) {
     std::vector<std::thread> th;
     std::atomic<uint64_t> next{0};
     const uint64_t chunk = 256;
     for (int t = 0; t < threads; t++) th.emplace_back([&] {
+      auto st = make();
       for (;;) {
         uint64_t s = next.fetch_add(chunk);
         if (s >= ix->n_unitigs) break;
         uint64_t e = std::min(ix->n_unitigs, s + chunk);
-        for (uint64_t u = s; u < e; u++) body(u);
+        for (uint64_t u = s; u < e; u++) body(u, st);
       }
+      drain(st);
     });
     for (auto& t : th) t.join();
   };
-  auto canon_of = [&](uint64_t v, bool* fwd_is_canon) {
-    uint64_t rc = kamd::revcomp_msb(v, k);
-    *fwd_is_canon = v < rc;
-    return v < rc ? v : rc;
+  // Both passes touch a random cache line per k-mer (the bucket's counter; then the bucket's line of the 2.4 GB table and its two aux
+  // words): the k-mers go through a small ring, a line is prefetched when a k-mer enters it and used when it leaves, RING k-mers later
+  constexpr int RING = 16;
+  struct CountState { uint64_t hb[RING]; int n = 0, head = 0; };
+  auto count_one = [&](CountState& st, uint64_t hb) {
+    __builtin_prefetch(&fill[hb], 1, 0);
+    if (st.n == RING) { fill_atomic[st.hb[st.head]].fetch_add(1, std::memory_order_relaxed); st.hb[st.head] = hb; st.head = (st.head + 1) % RING; }
+    else st.hb[(st.head + st.n++) % RING] = hb;
   };
-  run_parallel([&](uint64_t u) {
-    auto count = [&](uint32_t, uint64_t v) { bool f; uint64_t cn = canon_of(v, &f); fill_atomic[kamd::home_bucket(cn, nb)].fetch_add(1, std::memory_order_relaxed); };
-    if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, count); else count(0, single_kmer(u));
-  });
+  run_parallel([] { return CountState(); },
+               [&](uint64_t u, CountState& st) {
+                 auto count = [&](uint32_t, uint64_t v, uint64_t rc) { count_one(st, kamd::home_bucket(v < rc ? v : rc, nb)); };
+                 if (u < ix->n_long) for_each_kmer_rc(units[u].data, units[u].len, k, count);
+                 else { const uint64_t v = single_kmer(u); count(0, v, kamd::revcomp_msb(v, k)); }
+               },
+               [&](CountState& st) { for (int i = 0; i < st.n; i++) fill_atomic[st.hb[(st.head + i) % RING]].fetch_add(1, std::memory_order_relaxed); });
   tick("table: count pass");
   // placement: keys grouped by home bucket are laid down sequentially, never before their home (Robin Hood order)
   BigVec<uint64_t> base; base.resize(nb);
@@ -619,26 +642,49 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
   tick("table: layout + allocation");
   auto utext_atomic = reinterpret_cast<std::atomic<uint32_t>*>(ix->utext.data());
-  run_parallel([&](uint64_t u) {
+  // stage 1: the k-mer's home bucket (counter + base prefetched); stage 2, RING k-mers later: its slot (table line and aux words
+  // prefetched); stage 3, RING k-mers later again: the stores
+  struct Pend1 { uint64_t cn, hb, payload; uint32_t gpos, block, dist; };
+  struct Pend2 { uint64_t cn, slot, payload; uint32_t gpos, block, dist; };
+  struct PlaceState { Pend1 a[RING]; Pend2 b[RING]; int na = 0, ha = 0, nb2 = 0, hb2 = 0; };
+  auto stage3 = [&](const Pend2& q) {
+    const uint64_t bk = q.slot / S, j = q.slot % S;
+    ix->table[8 * bk + j] = (j == 0 && bucket_continues(bk)) ? (q.cn | kamd::KEY_CONT) : q.cn;
+    ix->table[8 * bk + S + j] = q.payload;
+    reinterpret_cast<uint32_t*>(&ix->table[8 * bk + 2 * S])[j] = q.gpos;
+    ix->slot_block[q.slot] = q.block;
+    ix->slot_dist[q.slot] = q.dist;
+  };
+  auto stage2 = [&](PlaceState& st, const Pend1& p) {
+    const uint64_t slot = base[p.hb] + fill_atomic[p.hb].fetch_add(1, std::memory_order_relaxed);
+    __builtin_prefetch(&ix->table[8 * (slot / S)], 1, 0);
+    __builtin_prefetch(&ix->slot_block[slot], 1, 0);
+    __builtin_prefetch(&ix->slot_dist[slot], 1, 0);
+    const Pend2 q{p.cn, slot, p.payload, p.gpos, p.block, p.dist};
+    if (st.nb2 == RING) { stage3(st.b[st.hb2]); st.b[st.hb2] = q; st.hb2 = (st.hb2 + 1) % RING; }
+    else st.b[(st.hb2 + st.nb2++) % RING] = q;
+  };
+  auto stage1 = [&](PlaceState& st, const Pend1& p) {
+    __builtin_prefetch(&fill[p.hb], 1, 0);
+    __builtin_prefetch(&base[p.hb], 0, 0);
+    if (st.na == RING) { stage2(st, st.a[st.ha]); st.a[st.ha] = p; st.ha = (st.ha + 1) % RING; }
+    else st.a[(st.ha + st.na++) % RING] = p;
+  };
+  run_parallel([] { return PlaceState(); },
+               [&](uint64_t u, PlaceState& st) {
     uint64_t b0 = ix->unitig_blk_off[u], b1 = ix->unitig_blk_off[u + 1];
     uint64_t cur = b0;
     const uint64_t g0 = ix->unitig_gpos[u];
-    auto place = [&](uint32_t dist, uint64_t v) {
+    auto place = [&](uint32_t dist, uint64_t v, uint64_t rc) {
       // block containing dist: BlockArray::get_block_at = last block with lb <= dist (BlockArray.hpp:306-322)
       if (b1 - b0 > 1) { while (cur + 1 < b1 && ix->blk_lb[cur + 1] <= dist) ++cur; }
-      bool f; uint64_t cn = canon_of(v, &f);
-      uint64_t hb = kamd::home_bucket(cn, nb);
-      uint64_t slot = base[hb] + fill_atomic[hb].fetch_add(1, std::memory_order_relaxed);
-      uint32_t lb = ix->blk_lb[cur], ub = ix->blk_ub[cur];
-      uint32_t rem_f = ub - 1 - dist, rem_b = dist - lb;   // KmerIndex.cpp:1780-1789
-      const uint64_t bk = slot / S, j = slot % S;
-      ix->table[8 * bk + j] = (j == 0 && bucket_continues(bk)) ? (cn | kamd::KEY_CONT) : cn;
-      ix->table[8 * bk + S + j] = kamd::make_payload(rem_f, rem_b, ix->blk_uec[cur], f);
-      reinterpret_cast<uint32_t*>(&ix->table[8 * bk + 2 * S])[j] = (uint32_t)(g0 + dist);
-      ix->slot_block[slot] = (uint32_t)cur;
-      ix->slot_dist[slot] = dist;
+      const bool f = v < rc; const uint64_t cn = f ? v : rc;
+      const uint32_t lb = ix->blk_lb[cur], ub = ix->blk_ub[cur];
+      const uint32_t rem_f = ub - 1 - dist, rem_b = dist - lb;   // KmerIndex.cpp:1780-1789
+      stage1(st, Pend1{cn, kamd::home_bucket(cn, nb), kamd::make_payload(rem_f, rem_b, ix->blk_uec[cur], f), (uint32_t)(g0 + dist), (uint32_t)cur, dist});
     };
-    if (u < ix->n_long) for_each_kmer(units[u].data, units[u].len, k, place); else place(0, single_kmer(u));
+    if (u < ix->n_long) for_each_kmer_rc(units[u].data, units[u].len, k, place);
+    else { const uint64_t v = single_kmer(u); place(0, v, kamd::revcomp_msb(v, k)); }
     // the unitig's bases into the text (neighbouring unitigs share words: atomic OR)
     const uint64_t len = ix->unitig_len[u];
     const uint64_t sk = u < ix->n_long ? 0 : single_kmer(u);
@@ -651,6 +697,12 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
       acc |= b << (2 * (g & 15));
     }
     if (acc) utext_atomic[wi].fetch_or(acc, std::memory_order_relaxed);
+  },
+               [&](PlaceState& st) {
+    for (int i = 0; i < st.na; i++) stage2(st, st.a[(st.ha + i) % RING]);
+    st.na = 0;
+    for (int i = 0; i < st.nb2; i++) stage3(st.b[(st.hb2 + i) % RING]);
+    st.nb2 = 0;
   });
   tick("table: place pass");
   // ---- D-list table (same bucket layout, built serially: it is small) and the dummy hit ----
