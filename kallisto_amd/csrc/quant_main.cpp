@@ -223,6 +223,27 @@ int main(int argc, char** argv) {
   // device contexts first (they do not need the index): the pinned text rings of the device-parse pipeline are allocated by a
   // second thread while the index is read and flattened (KmerIndex::load)
   const auto t_start = std::chrono::steady_clock::now();
+  // The index is read and flattened (pure host work, seconds) from the first moment on -- under the start of the HIP runtime, the
+  // creation of the contexts and the pinning of the text rings.  The flattened tables written by `kallisto_amd_quant flatten` are used
+  // when they lie beside the index (<index>.kamd, not older than it); the kallisto index stays the source of truth.
+  std::string index_path = opt.index;
+  {
+    struct stat si, sf;
+    const std::string flat = opt.index + ".kamd";
+    if (!getenv("KAMD_NO_FLAT_INDEX") && stat(opt.index.c_str(), &si) == 0 && stat(flat.c_str(), &sf) == 0 && sf.st_mtime >= si.st_mtime) index_path = flat;
+  }
+  kamd_index* idx = nullptr;
+  kamd_index_view v{};
+  double index_load_s = 0.0, index_ready_s = 0.0;
+  int load_rc = 0; std::string load_err;
+  const int load_threads = std::min(opt.threads, effective_cpus());
+  std::thread load_early([&] {
+    load_rc = kamd_index_load(index_path.c_str(), load_threads, &idx);
+    if (!load_rc) load_rc = kamd_index_get_view(idx, &v);
+    if (load_rc) load_err = kamd_last_error();
+    index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  });
+  struct EarlyJoiner { std::thread& t; ~EarlyJoiner() { if (t.joinable()) t.join(); } } load_join{load_early};
   // threads that wait for the GPU sleep instead of spinning: the host's CPUs belong to the readers (the runtime's default burns one
   // CPU per waiting thread, and a container's CPU quota is easily exceeded -- see effective_cpus())
   (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
@@ -265,22 +286,10 @@ int main(int argc, char** argv) {
   auto pin_first = [&] { return n_gpus > 1 && fld_open.load(); };
   UnitFeeder feeder(ctxs, devices, run_batch, pin_first);
   std::thread prep([&] { (void)feeder.prepare(paired ? 2 : 1); });
-  // index: the flattened tables written by `kallisto_amd_quant flatten` are used when they lie beside the index (<index>.kamd, not older
-  // than it); the kallisto index stays the source of truth
-  std::string index_path = opt.index;
-  {
-    struct stat si, sf;
-    const std::string flat = opt.index + ".kamd";
-    if (!getenv("KAMD_NO_FLAT_INDEX") && stat(opt.index.c_str(), &si) == 0 && stat(flat.c_str(), &sf) == 0 && sf.st_mtime >= si.st_mtime) index_path = flat;
-  }
-  kamd_index* idx = nullptr;
-  kamd_index_view v{};
-  double index_load_s = 0.0, index_ready_s = 0.0;
   std::thread ix_thread([&] {
     auto done = [&](int st, const std::string& e) { { std::lock_guard<std::mutex> lk(ix_m); ix_state = st; ix_err = e; } ix_cv.notify_all(); };
-    if (kamd_index_load(index_path.c_str(), opt.threads, &idx) != 0) { done(-1, kamd_last_error()); return; }
-    if (kamd_index_get_view(idx, &v) != 0) { done(-1, kamd_last_error()); return; }
-    index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    load_early.join();
+    if (load_rc) { done(-1, load_err); return; }
     std::cerr << "\n[index] k-mer length: " << v.k << "\n[index] number of targets: " << v.n_targets << "\n[index] number of k-mers: " << v.n_kmers << std::endl;
     std::vector<std::thread> th; std::vector<int> rcs((size_t)n_gpus, 0); std::vector<std::string> errs((size_t)n_gpus);
     for (int g = 0; g < n_gpus; g++) th.emplace_back([&, g] {   // the index is replicated in every GPU's HBM
@@ -443,8 +452,19 @@ int main(int argc, char** argv) {
   }
   h5.close();
   if (opt.verbose) std::cerr << "[timing] total " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " s" << std::endl;
+  const int exit_code = num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797
+  // (a profiler or tool attached to the process flushes its output from exit handlers: then the process leaves the ordinary way)
+  const char* preload = getenv("LD_PRELOAD");
+  const bool tool_attached = getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") ||
+                             (preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer") || strstr(preload, "asan")));
+  if (n_gpus == 1 && !tool_attached && !getenv("KAMD_SLOW_EXIT")) {
+    // every output file is written and closed: the process ends here instead of unmapping gigabytes of tables, destroying the
+    // context and unloading the runtime piece by piece (a fraction of a second that produces nothing)
+    std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+    _exit(exit_code);
+  }
   for (kamd_comm* m : comms) kamd_comm_destroy(m);
   for (kamd_ctx* x : ctxs) kamd_ctx_destroy(x);
   kamd_index_free(idx);
-  return num_pseudoaligned == 0 ? 1 : 0;  // src/main.cpp:2795-2797
+  return exit_code;
 }
