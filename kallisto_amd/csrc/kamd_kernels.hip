@@ -4472,6 +4472,17 @@ __global__ void k_em_publish(EmsPrev prev) {
 int em_sell_drive_async(kamd_ctx* c, EmSellGpu& B, const SellCache& K, u64 T, int n_iter, int min_rounds, double* alpha_out, double* abz_out, int* rounds_out) {
   const int CH = EML_MAX_ROUNDS;
   if (getenv("KAMD_EM_EXP")) { n_iter = std::min(n_iter, 1280); min_rounds = 1 << 30; }   // timing experiments: a fixed number of rounds, no stop
+  if (n_iter <= 0) {   // no round at all: the initial vector (alpha_ = 1/T), no final round
+    hipLaunchKernelGGL(k_em_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, K.mslot, K.single_all, B.d_alpha, B.d_alpha, T, 0, B.d_out, B.d_out + T);
+    HIPC(hipGetLastError());
+    std::vector<double> tmp(2 * T);
+    HIPC(hipMemcpyAsync(tmp.data(), B.d_out, 2 * T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    memcpy(alpha_out, tmp.data(), T * 8);
+    if (abz_out) memcpy(abz_out, tmp.data() + T, T * 8);
+    *rounds_out = 0;
+    return 0;
+  }
   const int n_chunks = std::max(1, (n_iter + CH - 1) / CH);
   // pinned, mapped host memory: change counts per chunk | sequence word | result staging
   const size_t hist_ints = (size_t)(n_chunks + 1) * CH;

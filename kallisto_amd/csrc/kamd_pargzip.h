@@ -405,7 +405,9 @@ class ParGzip {
       if (c.start_known) return c.start_bit;
       c.computing = true;
     }
-    const uint64_t s = k == 0 ? (uint64_t)data_start_ * 8 : find_block(d_, n_, nominal_bit(k), nominal_bit(k + 1));
+    uint64_t s = ~0ULL;
+    try { s = k == 0 ? (uint64_t)data_start_ * 8 : find_block(d_, n_, nominal_bit(k), nominal_bit(k + 1)); }
+    catch (...) { fatal_ = true; }   // (out of memory: "no block found" lets everyone waiting for this answer go on; the coordinator gives up)
     std::lock_guard<std::mutex> lk(c.m);
     c.start_bit = s; c.start_known = true;
     c.cv.notify_all();
