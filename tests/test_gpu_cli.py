@@ -99,6 +99,13 @@ def test_cli_matches_reference_cli(case, variant, tmp_path):
         p2 = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out2, "--plaintext", *cli, *gz], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p2.returncode == 0, p2.stderr.decode()
         assert open(os.path.join(out2, "abundance.tsv")).read() == open(os.path.join(out, "abundance.tsv")).read()
+        # ... and through the block-parallel inflate (files this small take the zlib reader unless told otherwise): chunks of 8 KiB of
+        # compressed bytes, so that block starts are searched, symbols carry markers and windows are resolved many times over
+        out3 = str(tmp_path / "out_pgz")
+        p3 = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out3, "--plaintext", "-t", "6", *cli, *gz], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            env=dict(os.environ, KAMD_PARGZIP_MIN_KB="0", KAMD_PARGZIP_CHUNK_KB="8"))
+        assert p3.returncode == 0, p3.stderr.decode()
+        assert open(os.path.join(out3, "abundance.tsv")).read() == open(os.path.join(out, "abundance.tsv")).read()
     if case == "ref_test_pe" and variant == "pe":
         # BASELINE config #1: the md5 the survey pinned for the reference's abundance.tsv
         md5 = hashlib.md5(open(os.path.join(out, "abundance.tsv"), "rb").read()).hexdigest()
