@@ -217,3 +217,28 @@ def test_parallel_gzip_reports_corruption(tmp_path, monkeypatch):
         # UnitCutter::IO_ERROR; a flipped byte may garble the text before the decoder meets an invalid code or the CRC: then the record
         # check declines first (-11) and the general reader, which the front-end turns to, fails on the same file
         assert st == -3 or (what == "flip" and st == -11), (what, st)
+
+
+def test_parallel_gzip_flush_points_and_many_members(tmp_path, monkeypatch):
+    """What parallel compressors write: empty stored blocks at sync / full flush points in the middle of the stream (pigz), and files made
+    of hundreds of small members (concatenated pieces): the parallel reader walks through all of it."""
+    import zlib
+    _pargzip_env(monkeypatch, 8)
+    reads = _reads(15000, 41)
+    data = _fastq_bytes(reads)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    blob = b""
+    step = 70000
+    for i, a in enumerate(range(0, len(data), step)):
+        blob += co.compress(data[a:a + step]) + co.flush(zlib.Z_FULL_FLUSH if i % 3 == 0 else zlib.Z_SYNC_FLUSH)
+    blob += co.flush()
+    p = str(tmp_path / "pigz.fq.gz")
+    open(p, "wb").write(blob)
+    st, got, n, _ = _units(p, ring=1 << 19, target=1 << 15, threads=5)
+    assert st == 0 and got == reads
+    # 300 members, cut anywhere (inside records too)
+    cuts = sorted(set(np.random.default_rng(3).integers(1, len(data) - 1, 299).tolist()))
+    blob = b"".join(gzip.compress(data[a:b], 4) for a, b in zip([0] + cuts, cuts + [len(data)]))
+    open(p, "wb").write(blob)
+    st, got, n, _ = _units(p, ring=1 << 19, target=1 << 15, threads=5)
+    assert st == 0 and got == reads
