@@ -53,6 +53,34 @@ inline uint64_t count_newlines(const char* p, size_t n) {
   static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
   return wide ? count_newlines_avx2(p, n) : count_newlines_sse2(p, n);
 }
+// copy + count in one pass over the source, the destination written with streaming stores (the ring is read next by the DMA engine, not by
+// a CPU: going through the cache would cost a read of every destination line before it is overwritten)
+__attribute__((target("avx2,popcnt"))) inline uint64_t copy_count_newlines_avx2(char* dst, const char* src, size_t n) {
+  uint64_t c = 0;
+  size_t i = 0;
+  // head: up to the destination's 32-byte boundary
+  const size_t head = std::min(n, (size_t)((32 - ((uintptr_t)dst & 31)) & 31));
+  if (head) { memcpy(dst, src, head); c += count_newlines_sse2(src, head); i = head; }
+  const __m256i nl = _mm256_set1_epi8('\n');
+  for (; i + 128 <= n; i += 128) {
+    const __m256i a0 = _mm256_loadu_si256((const __m256i*)(src + i)), a1 = _mm256_loadu_si256((const __m256i*)(src + i + 32));
+    const __m256i a2 = _mm256_loadu_si256((const __m256i*)(src + i + 64)), a3 = _mm256_loadu_si256((const __m256i*)(src + i + 96));
+    _mm256_stream_si256((__m256i*)(dst + i), a0); _mm256_stream_si256((__m256i*)(dst + i + 32), a1);
+    _mm256_stream_si256((__m256i*)(dst + i + 64), a2); _mm256_stream_si256((__m256i*)(dst + i + 96), a3);
+    const uint64_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a0, nl)), m1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a1, nl));
+    const uint64_t m2 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a2, nl)), m3 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a3, nl));
+    c += (uint64_t)__builtin_popcountll(m0 | (m1 << 32)) + (uint64_t)__builtin_popcountll(m2 | (m3 << 32));
+  }
+  _mm_sfence();
+  if (i < n) { memcpy(dst + i, src + i, n - i); c += count_newlines_sse2(src + i, n - i); }
+  return c;
+}
+inline uint64_t copy_count_newlines(char* dst, const char* src, size_t n) {
+  static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+  if (wide) return copy_count_newlines_avx2(dst, src, n);
+  memcpy(dst, src, n);
+  return count_newlines_sse2(dst, n);
+}
 // offset just behind the k-th (k >= 1) newline of [p, p + n); n if there are fewer
 inline size_t after_kth_newline(const char* p, size_t n, uint64_t k) {
   size_t i = 0;
@@ -117,7 +145,12 @@ class TextSource {
       pad_nl_ = last != '\n';
       const uint64_t text = fsize_ + (pad_nl_ ? 1 : 0);
       for (uint64_t o = 0; o < text; o += blk_) blocks_.push_back(Blk{o, std::min<uint64_t>(o + blk_, text), 0, 0, 0, false});
-      // (a reader only copies page-cache bytes and counts newlines at ~4-5 GB/s: a dozen saturate what the device takes over PCIe)
+      // The readers copy out of a mapping of the file (one pass: copy + count, streaming stores) unless KAMD_FQ_PREAD asks for read calls
+      // (the kernel's copy into the ring, then a second pass for the count)
+      if (!getenv("KAMD_FQ_PREAD")) {
+        void* p = mmap(nullptr, fsize_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (p != MAP_FAILED) { map_ = (const unsigned char*)p; (void)madvise(p, fsize_, MADV_SEQUENTIAL); }
+      }
       int cap = 16;
       if (const char* e = getenv("KAMD_FQ_PLAIN_THREADS")) cap = std::max(1, atoi(e));
       for (int t = 0; t < std::min<int>(std::min(threads, cap), (int)blocks_.size()); t++) workers_.emplace_back([this] { plain_worker(); });
@@ -278,6 +311,14 @@ class TextSource {
       uint64_t nl = 0;
       for (uint64_t pos = b.begin; pos < end;) {   // 256 KB at a time: the count reads what the copy just wrote while it is in L2
         const size_t o = (size_t)(pos % cap_), n = (size_t)std::min<uint64_t>(std::min<uint64_t>(end - pos, cap_ - o), 256u << 10);
+        if (map_) {
+#ifdef MADV_POPULATE_READ
+          if (populate_ok_ && madvise((void*)(map_ + (pos & ~(uint64_t)4095)), n + (size_t)(pos & 4095), MADV_POPULATE_READ) != 0) populate_ok_ = false;   // (one call maps the piece's pages; older kernels: page faults)
+#endif
+          nl += copy_count_newlines(ring_ + o, (const char*)map_ + pos, n);
+          pos += n;
+          continue;
+        }
         const ssize_t r = pread(fd_, ring_ + o, n, (off_t)pos);
         if (r <= 0) { fail("read error on " + path_); return; }
         nl += count_newlines(ring_ + o, (size_t)r);
@@ -431,6 +472,7 @@ class TextSource {
   Kind kind_ = PLAIN;
   bool pad_nl_ = false;
   const unsigned char* map_ = nullptr;
+  std::atomic<bool> populate_ok_{true};
   std::vector<Blk> blocks_;          // plain / BGZF: the whole file, known at open
   size_t next_claim_ = 0, next_done_ = 0;
   std::deque<Cum> cums_;             // counted blocks of the produced prefix that are not released yet
