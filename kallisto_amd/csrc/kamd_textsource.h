@@ -381,8 +381,7 @@ class TextSource {
         }
         const size_t o = (size_t)(head % cap_);
         const size_t a = std::min(std::min(room, cap_ - o), n);
-        memcpy(ring_ + o, p, a);
-        const uint64_t nl = count_newlines(ring_ + o, a);
+        const uint64_t nl = copy_count_newlines(ring_ + o, (const char*)p, a);   // (one pass, streaming stores: this thread handles every byte of the file)
         last = (char)p[a - 1];
         { std::lock_guard<std::mutex> g(m_); lines_ += nl; cums_.push_back(Cum{head, head + a, nl, lines_}); produced_ = head + a; }
         head += a; p += a; n -= a;
