@@ -95,4 +95,7 @@ int64_t io_units(const char* path0, const char* path1, uint64_t ring_bytes, uint
 }
 uint64_t io_count_newlines(const char* p, uint64_t n) { return kamd_io::count_newlines(p, (size_t)n); }
 uint64_t io_after_kth_newline(const char* p, uint64_t n, uint64_t k) { return (uint64_t)kamd_io::after_kth_newline(p, (size_t)n, k); }
+// copy + count in one pass (streaming stores where the CPU has AVX2): dst receives src, the newlines of src are returned
+uint64_t io_copy_count_newlines(char* dst, const char* src, uint64_t n) { return kamd_io::copy_count_newlines(dst, src, (size_t)n); }
+uint64_t io_count_newlines_sse2(const char* p, uint64_t n) { return kamd_io::count_newlines_sse2(p, (size_t)n); }
 }

@@ -41,6 +41,22 @@ def test_newline_counting_primitives():
             if 1 <= k <= len(pos):
                 assert L.io_after_kth_newline(b, C.c_uint64(n), C.c_uint64(k)) == pos[k - 1] + 1
         assert L.io_after_kth_newline(b, C.c_uint64(n), C.c_uint64(len(pos) + 1)) == n
+    # the wide (AVX2) count, the SSE2 count and the fused copy + count agree, at every alignment of source and destination
+    L.io_copy_count_newlines.restype = C.c_uint64
+    L.io_count_newlines_sse2.restype = C.c_uint64
+    a = rng.integers(0, 256, 70000, dtype=np.uint8)
+    a[rng.random(a.size) < 0.05] = 10
+    src = C.create_string_buffer(a.tobytes(), a.size)
+    dst = C.create_string_buffer(a.size + 64)
+    for so in (0, 1, 7, 31, 33):
+        for do in (0, 3, 32, 45):
+            for n in (0, 1, 31, 127, 128, 129, 4097, 60000):
+                want = int((a[so:so + n] == 10).sum())
+                sp = C.cast(C.addressof(src) + so, C.c_char_p); dp = C.cast(C.addressof(dst) + do, C.c_void_p)
+                assert L.io_count_newlines(sp, C.c_uint64(n)) == want and L.io_count_newlines_sse2(sp, C.c_uint64(n)) == want
+                C.memset(dst, 0, a.size + 64)
+                assert L.io_copy_count_newlines(dp, sp, C.c_uint64(n)) == want
+                assert dst.raw[do:do + n] == a[so:so + n].tobytes() and dst.raw[do + n:do + n + 8] == bytes(8)
 
 
 @pytest.mark.parametrize("threads", [1, 3, 8])
