@@ -247,3 +247,26 @@ int64_t emu_resolve(const kamd_index_view* v, const uint32_t* dense, const uint3
   return (int64_t)n;
 }
 }
+
+// every k-mer of every unitig looked up through the product's own probe (kamd_core.h probe_table): found, with its own text
+// position, offset on its unitig and a block of that unitig that covers it.  Returns the number of k-mers that fail (0 = all
+// good), -1 if the number of k-mers walked differs from the index's count.  *lines: bucket lines read in all.
+extern "C" int64_t emu_verify_table(const kamd_index_view* v, uint64_t* lines) {
+  const kamd::Table t{v->table, v->n_buckets};
+  uint64_t bad = 0, n = 0, ll = 0;
+  for (uint64_t u = 0; u < v->n_unitigs; u++) {
+    const uint64_t g0 = v->unitig_gpos[u], len = v->unitig_len[u];
+    for (uint64_t d = 0; d + (uint64_t)v->k <= len; d++) {
+      const uint32_t g = (uint32_t)(g0 + d);
+      const uint64_t cn = kamd::text_canon(v->utext, g, v->k);
+      uint32_t reads = 0;
+      const kamd::Probe p = kamd::probe_table(t, cn, true, &reads);
+      ++n; ll += reads;
+      if (!p.found || p.gpos != g || v->slot_dist[p.slot] != d) { ++bad; continue; }
+      const uint32_t blk = v->slot_block[p.slot];
+      if (v->blk_unitig[blk] != u || !(v->blk_lb[blk] <= d && d < v->blk_ub[blk])) ++bad;
+    }
+  }
+  if (lines) *lines = ll;
+  return n == v->n_kmers ? (int64_t)bad : -1;
+}

@@ -64,6 +64,21 @@ def test_flattened_index_matches_oracle_parse(case, idx):
 
 
 @pytest.mark.parametrize("case", common.CASES)
+def test_every_kmer_is_found_through_the_products_probe(case, idx):
+    """All k-mers of all unitigs looked up with kamd_core.h's probe_table in the tables kamd_index_load built (parallel first touch, prefetch
+    rings, continue flags set by the placement): found, own text position, own offset, a covering block of the own unitig.  (The same check
+    passed on the human-sized index of BASELINE config #3: 56 799 409 k-mers, 1.087 bucket lines per probe.)"""
+    import ctypes as C
+    from tests import emu_binding as E
+    e, _ = idx(case)
+    L = E.lib()
+    L.emu_verify_table.restype = C.c_int64
+    lines = C.c_uint64(0)
+    assert L.emu_verify_table(C.byref(e.view), C.byref(lines)) == 0
+    assert e.view.n_kmers <= lines.value <= 2 * e.view.n_kmers
+
+
+@pytest.mark.parametrize("case", common.CASES)
 def test_per_item_logic_matches_oracle(case, idx):
     """match() jump logic, k-mer table probe and intersectKmers per read/pair: identical sets AND identical hit counts."""
     e, o = idx(case)
