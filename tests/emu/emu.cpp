@@ -264,7 +264,18 @@ extern "C" int64_t emu_verify_table(const kamd_index_view* v, uint64_t* lines) {
       ++n; ll += reads;
       if (!p.found || p.gpos != g || v->slot_dist[p.slot] != d) { ++bad; continue; }
       const uint32_t blk = v->slot_block[p.slot];
-      if (v->blk_unitig[blk] != u || !(v->blk_lb[blk] <= d && d < v->blk_ub[blk])) ++bad;
+      if (v->blk_unitig[blk] != u || !(v->blk_lb[blk] <= d && d < v->blk_ub[blk])) { ++bad; continue; }
+      // the payload: strand, distance to the end of the block in either read direction (saturated at 16 bits), the block's set
+      const kamd::TextWords w = kamd::load_text(v->utext, g);
+      const int sh = (int)(g & 15u) * 2;
+      uint64_t x = ((uint64_t)w.a | ((uint64_t)w.b << 32)) >> sh;
+      if (sh + 2 * v->k > 64) x |= (uint64_t)w.c << (64 - sh);
+      x &= (1ULL << (2 * v->k)) - 1;
+      const uint64_t fwd = kamd::rev_bases64(x) >> (64 - 2 * v->k), rc = (~x) & ((1ULL << (2 * v->k)) - 1);
+      const bool fwd_canon = fwd < rc;
+      const kamd::Probe pf = kamd::probe_table(t, cn, fwd_canon, nullptr), pb = kamd::probe_table(t, cn, !fwd_canon, nullptr);
+      const uint32_t rem_f = std::min<uint32_t>(v->blk_ub[blk] - 1 - (uint32_t)d, 65535u), rem_b = std::min<uint32_t>((uint32_t)d - v->blk_lb[blk], 65535u);
+      if (!pf.strand || pb.strand || pf.dist != rem_f || pb.dist != rem_b || v->uec_ec[pf.uec] != v->blk_ec[blk]) ++bad;
     }
   }
   if (lines) *lines = ll;
