@@ -404,6 +404,62 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     head_of.emplace(kamd::revcomp_msb(v, k), (uint32_t)i);
   }
   tick("unitigs + head map");
+  // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
+  constexpr uint64_t S = kamd::BUCKET_SLOTS;
+  const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers * 2 + S - 1) / S);  // load factor 0.5 over 3-slot buckets
+  if (nb >= 0xFFFFFFF0ULL) return kamd::fail(-3, "index: too many k-mers for 32-bit bucket numbers");
+  ix->n_buckets = nb;
+  // [0, n) in contiguous pieces, one per thread: the big arrays are first touched (and later scanned) by all threads
+  auto parallel_range = [&](uint64_t n, auto&& body) {
+    std::vector<std::thread> th;
+    const uint64_t per = (n + (uint64_t)threads - 1) / (uint64_t)threads;
+    for (int t = 0; t < threads; t++) {
+      const uint64_t a = std::min(n, per * (uint64_t)t), b = std::min(n, a + per);
+      if (a < b) th.emplace_back([&body, a, b] { body(a, b); });
+    }
+    for (auto& t : th) t.join();
+  };
+  BigVec<uint32_t> fill; fill.resize(nb + 1);
+  auto fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data());
+  // all unitigs, handed out in runs of 256; every thread has a state of its own (make()), flushed when it runs out of work (drain())
+  auto run_parallel = [&](auto&& make, auto&& body, auto&& drain) {
+    std::vector<std::thread> th;
+    std::atomic<uint64_t> next{0};
+    const uint64_t chunk = 256;
+    for (int t = 0; t < threads; t++) th.emplace_back([&] {
+      auto st = make();
+      for (;;) {
+        uint64_t s = next.fetch_add(chunk);
+        if (s >= ix->n_unitigs) break;
+        uint64_t e = std::min(ix->n_unitigs, s + chunk);
+        for (uint64_t u = s; u < e; u++) body(u, st);
+      }
+      drain(st);
+    });
+    for (auto& t : th) t.join();
+  };
+  // Both passes touch a random cache line per k-mer (the bucket's counter; then the bucket's line of the 2.4 GB table and its two aux
+  // words): the k-mers go through a small ring, a line is prefetched when a k-mer enters it and used when it leaves, RING k-mers later
+  constexpr int RING = 16;
+  struct CountState { uint64_t hb[RING]; int n = 0, head = 0; };
+  auto count_one = [&](CountState& st, uint64_t hb) {
+    __builtin_prefetch(&fill[hb], 1, 0);
+    if (st.n == RING) { fill_atomic[st.hb[st.head]].fetch_add(1, std::memory_order_relaxed); st.hb[st.head] = hb; st.head = (st.head + 1) % RING; }
+    else st.hb[(st.head + st.n++) % RING] = hb;
+  };
+  // The count pass only needs the unitigs: it runs on the worker threads from here on, underneath the (serial) parsing of the node
+  // records, and is joined in front of the placement.
+  std::thread count_bg([&] {
+    parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
+    run_parallel([] { return CountState(); },
+                 [&](uint64_t u, CountState& st) {
+                   auto count = [&](uint32_t, uint64_t v, uint64_t rc) { count_one(st, kamd::home_bucket(v < rc ? v : rc, nb)); };
+                   if (u < ix->n_long) for_each_kmer_rc(units[u].data, units[u].len, k, count);
+                   else { const uint64_t v = single_kmer(u); count(0, v, kamd::revcomp_msb(v, k)); }
+                 },
+                 [&](CountState& st) { for (int i = 0; i < st.n; i++) fill_atomic[st.hb[(st.head + i) % RING]].fetch_add(1, std::memory_order_relaxed); });
+  });
+  struct BgJoin { std::thread& t; ~BgJoin() { if (t.joinable()) t.join(); } } count_join{count_bg};
   // skip minimizer index + BooPHF (KmerIndex.cpp:1368-1376)
   c.pos = pos1 + dbg_bytes;
   { uint64_t mphf = c.get<uint64_t>(); c.take(mphf); }
@@ -560,58 +616,9 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     ix->utext.assign((g + 15) / 16 + 2, 0);
   }
   tick("unitig text: layout");
-  // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
-  constexpr uint64_t S = kamd::BUCKET_SLOTS;
-  const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers * 2 + S - 1) / S);  // load factor 0.5 over 3-slot buckets
-  if (nb >= 0xFFFFFFF0ULL) return kamd::fail(-3, "index: too many k-mers for 32-bit bucket numbers");
-  ix->n_buckets = nb;
-  // [0, n) in contiguous pieces, one per thread: the big arrays are first touched (and later scanned) by all threads
-  auto parallel_range = [&](uint64_t n, auto&& body) {
-    std::vector<std::thread> th;
-    const uint64_t per = (n + (uint64_t)threads - 1) / (uint64_t)threads;
-    for (int t = 0; t < threads; t++) {
-      const uint64_t a = std::min(n, per * (uint64_t)t), b = std::min(n, a + per);
-      if (a < b) th.emplace_back([&body, a, b] { body(a, b); });
-    }
-    for (auto& t : th) t.join();
-  };
-  BigVec<uint32_t> fill; fill.resize(nb + 1);
-  parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
-  auto fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data());
-  // all unitigs, handed out in runs of 256; every thread has a state of its own (make()), flushed when it runs out of work (drain())
-  auto run_parallel = [&](auto&& make, auto&& body, auto&& drain) {
-    std::vector<std::thread> th;
-    std::atomic<uint64_t> next{0};
-    const uint64_t chunk = 256;
-    for (int t = 0; t < threads; t++) th.emplace_back([&] {
-      auto st = make();
-      for (;;) {
-        uint64_t s = next.fetch_add(chunk);
-        if (s >= ix->n_unitigs) break;
-        uint64_t e = std::min(ix->n_unitigs, s + chunk);
-        for (uint64_t u = s; u < e; u++) body(u, st);
-      }
-      drain(st);
-    });
-    for (auto& t : th) t.join();
-  };
-  // Both passes touch a random cache line per k-mer (the bucket's counter; then the bucket's line of the 2.4 GB table and its two aux
-  // words): the k-mers go through a small ring, a line is prefetched when a k-mer enters it and used when it leaves, RING k-mers later
-  constexpr int RING = 16;
-  struct CountState { uint64_t hb[RING]; int n = 0, head = 0; };
-  auto count_one = [&](CountState& st, uint64_t hb) {
-    __builtin_prefetch(&fill[hb], 1, 0);
-    if (st.n == RING) { fill_atomic[st.hb[st.head]].fetch_add(1, std::memory_order_relaxed); st.hb[st.head] = hb; st.head = (st.head + 1) % RING; }
-    else st.hb[(st.head + st.n++) % RING] = hb;
-  };
-  run_parallel([] { return CountState(); },
-               [&](uint64_t u, CountState& st) {
-                 auto count = [&](uint32_t, uint64_t v, uint64_t rc) { count_one(st, kamd::home_bucket(v < rc ? v : rc, nb)); };
-                 if (u < ix->n_long) for_each_kmer_rc(units[u].data, units[u].len, k, count);
-                 else { const uint64_t v = single_kmer(u); count(0, v, kamd::revcomp_msb(v, k)); }
-               },
-               [&](CountState& st) { for (int i = 0; i < st.n; i++) fill_atomic[st.hb[(st.head + i) % RING]].fetch_add(1, std::memory_order_relaxed); });
-  tick("table: count pass");
+  // (the count pass of the k-mer table has been running since the unitigs were read)
+  count_bg.join();
+  tick("table: count pass (rest)");
   // placement: keys grouped by home bucket are laid down sequentially, never before their home (Robin Hood order)
   BigVec<uint64_t> base; base.resize(nb);
   uint64_t cursor = 0;
