@@ -218,3 +218,41 @@ def test_cli_several_ranks_on_one_device(case, variant, tmp_path):
                 _, brows = _table(os.path.join(out, f"bs_abundance_{b}.tsv"))
                 assert len(brows) == len(grows)
                 assert abs(sum(float(r[3]) for r in brows) - ginfo["n_pseudoaligned"]) < 1e-6 * ginfo["n_pseudoaligned"] + 1e-3
+
+
+BOUND = os.path.join(ROOT, "oracle", "_ref", "quant_bound")
+
+
+@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("yeast_se", "se")])
+def test_reference_reader_and_writers_bound_to_the_library(case, variant, tmp_path):
+    """INTEGRATION.md, compiled and run: oracle/_ref/quant_bound is the REFERENCE's FastqSequenceReader, option struct and
+    plaintext writers (linked from the reference's own objects) with the four seams replaced by calls into libkallisto_amd.so
+    (oracle/ref_harness/quant_bound.cpp).  Its abundance.tsv must be the reference's: byte for byte on BASELINE config #1 (the md5
+    the survey pinned), within 1e-4 on the single-end case."""
+    if not os.path.exists(BOUND):
+        pytest.skip("oracle/_ref/quant_bound not built (make -C oracle ref_bound needs /root/reference)")
+    meta, idx_path, r1, r2 = common.load_case(case)
+    extra = meta["variants"][variant]
+    f1 = str(tmp_path / "r_1.fq")
+    _fastq(f1, r1)
+    files = [f1]
+    if r2 is not None and "--single" not in extra:
+        f2 = str(tmp_path / "r_2.fq")
+        _fastq(f2, r2)
+        files.append(f2)
+    out = str(tmp_path / "out")
+    p = subprocess.run([BOUND, "quant", "-i", idx_path, "-o", out, "-t", "4", *extra, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    gold = os.path.join(common.case_dir(case), "cli_" + variant)
+    if case == "ref_test_pe":
+        assert hashlib.md5(open(os.path.join(out, "abundance.tsv"), "rb").read()).hexdigest() == "0bd5087aba9db4b681073bb84de3fe5f"
+    h, rows = _table(os.path.join(out, "abundance.tsv"))
+    gh, grows = _table(os.path.join(gold, "abundance.tsv"))
+    assert h == gh and len(rows) == len(grows)
+    for a, b in zip(rows, grows):
+        assert a[:3] == b[:3], (a, b)
+    est = np.array([float(r[3]) for r in rows]); gest = np.array([float(r[3]) for r in grows])
+    common.assert_abundance_close(est, gest, "est_counts", rel=1e-4, floor=1e-5)
+    info, ginfo = json.load(open(os.path.join(out, "run_info.json"))), json.load(open(os.path.join(gold, "run_info.json")))
+    for k in ("n_targets", "n_processed", "n_pseudoaligned", "n_unique", "p_pseudoaligned", "p_unique", "index_version", "k-mer length"):
+        assert info[k] == ginfo[k], k
