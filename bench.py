@@ -425,7 +425,15 @@ def main():
     ap.add_argument("--no-pinned-pipeline", action="store_true")
     ap.add_argument("--multi-parity", action="store_true", help="N > 1: rank 0 also runs the reads of ALL ranks on its own (one context, no communicator) "
                     "and the merged result of the ranks must equal it (EC multiset, flens identical; est_counts 1e-9; same EM rounds)")
+    ap.add_argument("--table-layout", default=None, choices=["wide", "compact", "auto"],
+                    help="layout of the k-mer table (KAMD_TABLE_LAYOUT; default: the library's, wide): compact = four quotiented 16-byte slots per "
+                         "line instead of three 20-byte ones (kamd_core.h)")
+    ap.add_argument("--table-load", type=float, default=None, help="load factor of the compact table (KAMD_TABLE_LOAD, default 0.6)")
     args = ap.parse_args()
+    if args.table_layout:
+        os.environ["KAMD_TABLE_LAYOUT"] = args.table_layout
+    if args.table_load:
+        os.environ["KAMD_TABLE_LOAD"] = str(args.table_load)
 
     import torch
     import torch.distributed as dist
@@ -748,6 +756,9 @@ def main():
                              f"REDUCED {args.workload} genes={genes} {unit_name}={n} (not the BASELINE configuration)"),
                 f"{unit_name}_per_gpu": n, "read_len": L, "paired": paired, "targets": int(index.num_targets),
                 "kmers": int(index.num_kmers),
+                "kmer_table": {"layout": "compact" if index.view.table_layout else "wide", "slots_per_line": int(index.view.slots_per_bucket),
+                               "bytes": int((index.view.n_buckets + index.view.pad_buckets) * 64),
+                               "load": round(index.num_kmers / float(index.view.slots_per_bucket * index.view.n_buckets), 3)},
                 "parallelism": (f"{world} ranks, one per GPU: reads sharded; in the library (RCCL): one all-reduce of the dense EC count vector + "
                                 f"all-gathers of the tuple records, then the EM partitioned over the ranks by connected component"
                                 if world > 1 else "1 GPU"),

@@ -35,7 +35,8 @@ class _View(C.Structure):
                                            "blk_pos_off", "blk_posw", "blk_sense", "target_lens", "onlist_bits")] +
                 [("onlist_words", C.c_uint64), ("dtable", C.c_void_p), ("n_dbuckets", C.c_uint64), ("dpad_buckets", C.c_uint64),
                  ("dummy_slot", C.c_uint64), ("dummy_uec", C.c_uint32), ("dummy_strand", C.c_uint32),
-                 ("utext", C.c_void_p), ("utext_words", C.c_uint64), ("text_bases", C.c_uint64), ("unitig_gpos", C.c_void_p)])
+                 ("utext", C.c_void_p), ("utext_words", C.c_uint64), ("text_bases", C.c_uint64), ("unitig_gpos", C.c_void_p)] +
+                [(n, C.c_uint32) for n in ("table_layout", "slots_per_bucket", "tag_q", "tag_dsh", "tag_w")])
 
 
 class QuantOpts(C.Structure):

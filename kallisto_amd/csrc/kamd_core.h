@@ -45,6 +45,26 @@ namespace kamd {
 //   Keys are laid out in home-bucket order (Robin-Hood linear probing at bucket granularity), so a lookup reads the home
 //   bucket and follows continue flags; at load <= 0.5 that is 1.0x bucket reads.
 // ---------------------------------------------------------------------------------------------------------------
+//
+// The COMPACT layout (LAYOUT_COMPACT; chosen when the index is loaded, kamd_index.cpp) holds the same information in 16-byte
+// slots, FOUR per 64-byte line, so that a GENCODE-sized table shrinks from 43 to 21-29 bytes per k-mer.  It is exact -- no
+// fingerprint that a second read would have to verify -- by quotienting: kmer_hash32 below is a bijection of the low 32 bits
+// of the key for every value of the high bits (xor with a function of the high bits, odd multiplications, xor-shifts), and
+// fastrange is monotone in the hash, so the keys of one home bucket have consecutive hashes and (high bits of the key, low
+// q bits of the hash), q = ceil(log2(2^32 / n_buckets)), identify a key within its home bucket.
+//   slot    = {w0, w1}; bucket = slots 0..3 = words {w0, w1} x 4
+//   w0      = tag[tagw-1:0] | uec << tagw,   tag = hash & (2^q - 1) | (key >> 32) << q | displacement << (q + max(0, 2k - 32))
+//             displacement (3 bits) = buckets between the slot's bucket and the key's home, 0..6; 7 marks an empty slot (w0 =
+//             all ones).  A lookup in bucket home + d compares with the tag of displacement d: one 64-bit compare per slot.
+//   w1      = rem_f[15:0] | rem_b[31:16] | gpos[61:32] | fwd_is_canon[62] | continue flag of the bucket[63] (slot 0 only)
+//   The builder refuses the layout (and the loader falls back to the wide one unless it was asked for by name) when a field
+//   does not fit: tagw + bits(uec) <= 64, text positions < 2^30.
+// ---------------------------------------------------------------------------------------------------------------
+static const int LAYOUT_WIDE = 0, LAYOUT_COMPACT = 1;
+static const int COMPACT_SLOTS = 4;
+static const uint32_t COMPACT_MAX_DISP = 6;     // displacement 7 = empty
+static const uint64_t COMPACT_CONT = 1ULL << 63, COMPACT_FWD = 1ULL << 62;
+static const uint32_t COMPACT_GPOS_MASK = 0x3FFFFFFFu;
 static const uint64_t KEY_MASK = (1ULL << 62) - 1;
 static const uint64_t KEY_EMPTY = KEY_MASK;
 static const uint64_t KEY_CONT = 1ULL << 63;
@@ -67,12 +87,20 @@ KAMD_HD uint32_t kmer_hash32(uint64_t canon) {
   uint32_t x = (lo ^ h) * 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x;
 }
-KAMD_HD uint64_t home_bucket(uint64_t canon, uint64_t n_buckets) {
+KAMD_HD uint64_t bucket_of_hash(uint32_t h, uint64_t n_buckets) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return (uint64_t)__umulhi(kmer_hash32(canon), (uint32_t)n_buckets);
+  return (uint64_t)__umulhi(h, (uint32_t)n_buckets);
 #else
-  return ((uint64_t)kmer_hash32(canon) * (uint32_t)n_buckets) >> 32;
+  return ((uint64_t)h * (uint32_t)n_buckets) >> 32;
 #endif
+}
+KAMD_HD uint64_t home_bucket(uint64_t canon, uint64_t n_buckets) { return bucket_of_hash(kmer_hash32(canon), n_buckets); }
+// compact layout: q for a table of n_buckets home buckets -- the hashes of one bucket are at most ceil(2^32 / n) consecutive values
+KAMD_HD uint32_t compact_q_of(uint64_t n_buckets) {
+  const uint64_t span = ((1ULL << 32) + n_buckets - 1) / n_buckets;
+  uint32_t q = 0;
+  while ((1ULL << q) < span) ++q;
+  return q;
 }
 KAMD_HD uint64_t make_payload(uint32_t rem_f, uint32_t rem_b, uint32_t uec, bool fwd_is_canon) {
   if (rem_f > REM_CAP) rem_f = REM_CAP;
@@ -169,6 +197,8 @@ struct Table {
   bool dummy_strand = false;
   bool partial = false;   // match(..., partial): single-end reads (src/ProcessReads.cpp:1058)
   bool no_jump = false;   // --no-jump: every k-mer of the read is looked up (KmerIndex.cpp:1776)
+  // layout of `slots` (the D-list table is always wide): LAYOUT_COMPACT with its shifts -- q, shift of the displacement, width of the tag
+  uint8_t layout = LAYOUT_WIDE, q = 0, dsh = 0, tagw = 0;
 };
 struct Probe {
   bool found;
@@ -217,7 +247,43 @@ KAMD_HD int match_bucket(const BucketLine& L, uint64_t canon, bool is_fwd_canon,
   p.gpos = gp;
   return BUCKET_FOUND;
 }
+// compact layout: the tag a key carries in a slot `disp` buckets beyond its home
+KAMD_HD uint64_t compact_tag(const Table& t, uint64_t canon, uint32_t hash, uint32_t disp) {
+  return (uint64_t)(hash & ((1u << t.q) - 1u)) | ((canon >> 32) << t.q) | ((uint64_t)disp << t.dsh);
+}
+KAMD_HD int match_bucket_compact(const BucketLine& L, const Table& t, uint64_t tag, bool is_fwd_canon, uint64_t b, Probe& p) {
+  p.found = false; p.strand = false; p.uec = NO_UEC; p.dist = 0; p.slot = 0; p.gpos = 0;
+  const uint64_t tm = (1ULL << t.tagw) - 1ULL;
+  uint64_t w0 = 0, w1 = 0; int hit = -1;
+  if ((L.k0 & tm) == tag) { w0 = L.k0; w1 = L.k1; hit = 0; }
+  else if ((L.k2 & tm) == tag) { w0 = L.k2; w1 = L.p0; hit = 1; }
+  else if ((L.p1 & tm) == tag) { w0 = L.p1; w1 = L.p2; hit = 2; }
+  else if ((L.g01 & tm) == tag) { w0 = L.g01; w1 = L.g2; hit = 3; }
+  // Not here.  The key may sit further on when keys homed at or before this bucket spill past it (the continue flag: the bucket is
+  // full then) AND the key in the last slot is not homed beyond the key looked for: keys lie in the order of their homes, so a last
+  // slot whose displacement is smaller than the lookup's closes the run of the lookup's home bucket.
+  if (hit < 0) return ((L.k1 & COMPACT_CONT) && ((L.g01 & tm) >> t.dsh) >= (tag >> t.dsh)) ? BUCKET_CONTINUE : BUCKET_ABSENT;
+  const bool fwd_is_canon = (w1 & COMPACT_FWD) != 0;
+  p.found = true;
+  p.strand = (is_fwd_canon == fwd_is_canon);
+  p.uec = (uint32_t)(w0 >> t.tagw);
+  p.dist = p.strand ? (uint32_t)(w1 & 0xFFFF) : (uint32_t)((w1 >> 16) & 0xFFFF);
+  p.slot = b * COMPACT_SLOTS + (uint64_t)hit;
+  p.gpos = (uint32_t)(w1 >> 32) & COMPACT_GPOS_MASK;
+  return BUCKET_FOUND;
+}
+KAMD_HD Probe probe_table_compact(const Table& t, uint64_t canon, bool is_fwd_canon, uint32_t* bucket_reads) {
+  Probe p;
+  const uint32_t h = kmer_hash32(canon);
+  const uint64_t home = bucket_of_hash(h, t.n_buckets);
+  for (uint32_t d = 0;; d++) {
+    const BucketLine L = load_bucket(t.slots, home + d);
+    if (bucket_reads) ++*bucket_reads;
+    if (match_bucket_compact(L, t, compact_tag(t, canon, h, d), is_fwd_canon, home + d, p) != BUCKET_CONTINUE || d == COMPACT_MAX_DISP) return p;
+  }
+}
 KAMD_HD Probe probe_table(const Table& t, uint64_t canon, bool is_fwd_canon, uint32_t* bucket_reads) {
+  if (t.layout == LAYOUT_COMPACT) return probe_table_compact(t, canon, is_fwd_canon, bucket_reads);
   Probe p;
   uint64_t b = home_bucket(canon, t.n_buckets);
   for (;;) {

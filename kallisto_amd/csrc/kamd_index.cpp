@@ -137,6 +137,8 @@ struct kamd_index {
   std::vector<uint32_t> onlist_bits;
   uint64_t n_targets = 0;           // real targets (what abundance.tsv lists); target_lens also covers the D-list pseudo-targets
   uint64_t n_buckets = 0, pad_buckets = 0;
+  // layout of `table` (kamd_core.h): LAYOUT_WIDE with BUCKET_SLOTS slots per bucket, or LAYOUT_COMPACT with COMPACT_SLOTS and its shifts
+  uint32_t layout = kamd::LAYOUT_WIDE, slots = kamd::BUCKET_SLOTS, tag_q = 0, tag_dsh = 0, tag_w = 0;
   BigVec<uint64_t> table;
   BigVec<uint32_t> slot_block, slot_dist;
   std::vector<uint32_t> utext;          // 2-bit text of all unitigs, end to end (read packing), + 2 words of padding
@@ -183,7 +185,7 @@ inline void for_each_kmer_rc(const uint8_t* packed, uint64_t len, int k, F&& f) 
 // front-end that runs sample after sample against one index can write them once and read them back with plain reads.  Layout:
 // magic, format version, the scalars, then every array as {u64 count, bytes}; native endianness, for this machine's eyes only.
 namespace {
-const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '2'};
+const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '3'};
 // what the layout of the tables depends on, written behind the magic and compared on load
 const uint32_t FLAT_STAMP[4] = {(uint32_t)kamd::BUCKET_SLOTS, (uint32_t)sizeof(uint64_t) * 8u /* bytes per bucket */, 30u /* bits of a class id in the payload */, 13u /* kallisto index version */};
 struct FlatOut {
@@ -238,9 +240,24 @@ template <class IO> void flat_fields(IO& io, kamd_index& x) {
   io.scalar(x.k); io.scalar(x.n_kmers); io.scalar(x.n_unitigs); io.scalar(x.n_long); io.scalar(x.n_short); io.scalar(x.n_abund); io.scalar(x.dlist_size);
   io.scalar(x.n_targets); io.scalar(x.n_buckets); io.scalar(x.pad_buckets); io.scalar(x.text_bases);
   io.scalar(x.n_dbuckets); io.scalar(x.dpad_buckets); io.scalar(x.dummy_slot); io.scalar(x.dummy_uec); io.scalar(x.dummy_strand);
+  io.scalar(x.layout); io.scalar(x.slots); io.scalar(x.tag_q); io.scalar(x.tag_dsh); io.scalar(x.tag_w);
   io.vec(x.unitig_len); io.vec(x.unitig_blk_off); io.vec(x.blk_unitig); io.vec(x.blk_lb); io.vec(x.blk_ub); io.vec(x.blk_ec); io.vec(x.blk_uec);
   io.vec(x.blk_pos_off); io.vec(x.blk_posw); io.vec(x.blk_sense); io.vec(x.uec_ec); io.vec(x.ec_off); io.vec(x.ec_ids); io.vec(x.target_lens);
   io.vec(x.onlist_bits); io.vec(x.table); io.vec(x.slot_block); io.vec(x.slot_dist); io.vec(x.utext); io.vec(x.unitig_gpos); io.vec(x.dlist_keys); io.vec(x.dtable);
+}
+uint32_t bits_of(uint64_t n) { uint32_t b = 0; while (b < 64 && (n >> b)) ++b; return b; }   // bits that hold the values 0..n
+// the shifts of the compact layout for a table of nb home buckets; false: a field does not fit (kamd_core.h)
+bool compact_shifts(int k, uint64_t nb, uint64_t n_uec, uint64_t text_bases, uint32_t* q, uint32_t* dsh, uint32_t* w) {
+  *q = kamd::compact_q_of(nb);
+  *dsh = *q + (uint32_t)std::max(0, 2 * k - 32);
+  *w = *dsh + 3;
+  return *w + bits_of(n_uec) <= 64 && text_bases <= kamd::COMPACT_GPOS_MASK;
+}
+bool layout_is_consistent(const kamd_index& x) {
+  if (x.layout == kamd::LAYOUT_WIDE) return x.slots == (uint32_t)kamd::BUCKET_SLOTS;
+  if (x.layout != kamd::LAYOUT_COMPACT || x.slots != (uint32_t)kamd::COMPACT_SLOTS || x.n_buckets < 16) return false;
+  uint32_t q, dsh, w;
+  return compact_shifts(x.k, x.n_buckets, x.uec_ec.size(), x.text_bases, &q, &dsh, &w) && q == x.tag_q && dsh == x.tag_dsh && w == x.tag_w;
 }
 int load_flat(const char* path, int threads, kamd_index** out) {
   FILE* f = fopen(path, "rb");
@@ -265,8 +282,8 @@ int load_flat(const char* path, int threads, kamd_index** out) {
   in.run_jobs(path, threads);
   // the arrays must be consistent with the scalars -- and with each other -- the kernels trust: every length, and the largest value
   // of every array that is used as an index (a truncated or stale file must not turn into out-of-bounds reads on the device)
-  const uint64_t S = kamd::BUCKET_SLOTS, nb = ix->n_buckets + ix->pad_buckets;
-  bool good = in.ok && ix->k >= 3 && ix->k <= 31 && ix->table.size() == nb * 8 && ix->slot_block.size() == nb * S && ix->slot_dist.size() == nb * S &&
+  const uint64_t S = ix->slots, nb = ix->n_buckets + ix->pad_buckets;
+  bool good = in.ok && ix->k >= 3 && ix->k <= 31 && layout_is_consistent(*ix) && ix->table.size() == nb * 8 && ix->slot_block.size() == nb * S && ix->slot_dist.size() == nb * S &&
               ix->unitig_len.size() == ix->n_unitigs && ix->unitig_blk_off.size() == ix->n_unitigs + 1 && ix->unitig_gpos.size() == ix->n_unitigs + 1 &&
               !ix->ec_off.empty() && ix->ec_off.back() == ix->ec_ids.size() && ix->target_lens.size() >= ix->n_targets + ix->dlist_size &&
               ix->target_names.size() >= ix->n_targets && ix->utext.size() >= (ix->text_bases + 15) / 16 + 2 &&
@@ -327,7 +344,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   {   // a file written by kamd_index_save?
     FILE* f = path ? fopen(path, "rb") : nullptr;
     char magic[8] = {0};
-    const bool flat = f && fread(magic, 1, 8, f) == 8 && memcmp(magic, FLAT_MAGIC, 8) == 0;
+    const bool flat = f && fread(magic, 1, 8, f) == 8 && memcmp(magic, FLAT_MAGIC, 7) == 0;   // (any version: load_flat refuses the others by name)
     if (f) fclose(f);
     if (flat) return load_flat(path, threads, out);
   }
@@ -405,10 +422,21 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   }
   tick("unitigs + head map");
   // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
-  constexpr uint64_t S = kamd::BUCKET_SLOTS;
-  const uint64_t nb = std::max<uint64_t>(16, (ix->n_kmers * 2 + S - 1) / S);  // load factor 0.5 over 3-slot buckets
-  if (nb >= 0xFFFFFFF0ULL) return kamd::fail(-3, "index: too many k-mers for 32-bit bucket numbers");
-  ix->n_buckets = nb;
+  // The layout (kamd_core.h): wide = 3 slots of 20 bytes per line at a load of 0.5; compact = 4 slots of 16 bytes at KAMD_TABLE_LOAD
+  // (0.6).  KAMD_TABLE_LAYOUT = wide (default) | compact (an error when a field does not fit) | auto (compact when it fits).
+  int want_compact = 0;   // 0 wide, 1 compact, 2 auto
+  if (const char* e = getenv("KAMD_TABLE_LAYOUT")) {
+    if (!strcmp(e, "compact")) want_compact = 1;
+    else if (!strcmp(e, "auto")) want_compact = 2;
+    else if (strcmp(e, "wide") != 0 && *e) return kamd::fail(-1, std::string("KAMD_TABLE_LAYOUT: wide, compact or auto expected, not ") + e);
+  }
+  double compact_load = 0.6;
+  if (const char* e = getenv("KAMD_TABLE_LOAD")) { const double x = atof(e); if (x >= 0.2 && x <= 0.9) compact_load = x; }
+  bool compact = want_compact != 0;
+  const uint64_t nb_wide = std::max<uint64_t>(16, (ix->n_kmers * 2 + kamd::BUCKET_SLOTS - 1) / kamd::BUCKET_SLOTS);  // load factor 0.5 over 3-slot buckets
+  uint64_t S = compact ? kamd::COMPACT_SLOTS : kamd::BUCKET_SLOTS;
+  uint64_t nb = compact ? std::max<uint64_t>(16, (uint64_t)((double)ix->n_kmers / compact_load / (double)S) + 1) : nb_wide;
+  if (std::max(nb, nb_wide) >= 0xF0000000ULL) return kamd::fail(-3, "index: too many k-mers for 32-bit bucket numbers");
   // [0, n) in contiguous pieces, one per thread: the big arrays are first touched (and later scanned) by all threads
   auto parallel_range = [&](uint64_t n, auto&& body) {
     std::vector<std::thread> th;
@@ -449,7 +477,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   };
   // The count pass only needs the unitigs: it runs on the worker threads from here on, underneath the (serial) parsing of the node
   // records, and is joined in front of the placement.
-  std::thread count_bg([&] {
+  auto count_pass = [&] {   // (for the table size `nb` of the moment)
     parallel_range(nb + 1, [&](uint64_t a, uint64_t b) { memset(fill.data() + a, 0, (b - a) * sizeof(uint32_t)); });
     run_parallel([] { return CountState(); },
                  [&](uint64_t u, CountState& st) {
@@ -458,7 +486,8 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
                    else { const uint64_t v = single_kmer(u); count(0, v, kamd::revcomp_msb(v, k)); }
                  },
                  [&](CountState& st) { for (int i = 0; i < st.n; i++) fill_atomic[st.hb[(st.head + i) % RING]].fetch_add(1, std::memory_order_relaxed); });
-  });
+  };
+  std::thread count_bg(count_pass);
   struct BgJoin { std::thread& t; ~BgJoin() { if (t.joinable()) t.join(); } } count_join{count_bg};
   // skip minimizer index + BooPHF (KmerIndex.cpp:1368-1376)
   c.pos = pos1 + dbg_bytes;
@@ -620,13 +649,36 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   count_bg.join();
   tick("table: count pass (rest)");
   // placement: keys grouped by home bucket are laid down sequentially, never before their home (Robin Hood order)
-  BigVec<uint64_t> base; base.resize(nb);
+  BigVec<uint64_t> base;
   uint64_t cursor = 0;
-  for (uint64_t b = 0; b < nb; b++) {   // (a running maximum: serial, but only 12 bytes per bucket go through it)
-    cursor = std::max(cursor, b * S);
-    base[b] = cursor;
-    cursor += fill[b];
+  uint32_t tag_q = 0, tag_dsh = 0, tag_w = 0;
+  for (;;) {
+    // the compact layout must hold the class ids and the text positions beside the tag, and a key at most COMPACT_MAX_DISP buckets from
+    // its home: otherwise the wide layout (auto), or a larger table (an eighth more buckets) and the count pass again
+    auto recount = [&] { fill.resize(nb + 1); fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data()); count_pass(); };
+    if (compact && !compact_shifts(k, nb, ix->uec_ec.size(), ix->text_bases, &tag_q, &tag_dsh, &tag_w)) {
+      if (want_compact == 1) return kamd::fail(-3, "index: the compact k-mer table cannot hold this index (class ids / text positions too wide); use KAMD_TABLE_LAYOUT=wide or auto");
+      compact = false; S = kamd::BUCKET_SLOTS; nb = nb_wide;
+      recount();
+    }
+    base.resize(nb);
+    cursor = 0;
+    uint64_t max_disp = 0;
+    for (uint64_t b = 0; b < nb; b++) {   // (a running maximum: serial, but only 12 bytes per bucket go through it)
+      cursor = std::max(cursor, b * S);
+      base[b] = cursor;
+      cursor += fill[b];
+      if (fill[b]) max_disp = std::max(max_disp, (cursor - 1) / S - b);
+    }
+    if (!compact || max_disp <= kamd::COMPACT_MAX_DISP) break;
+    nb += nb / 8 + 1;
+    recount();
   }
+  ix->n_buckets = nb;
+  ix->layout = compact ? kamd::LAYOUT_COMPACT : kamd::LAYOUT_WIDE; ix->slots = (uint32_t)S;
+  ix->tag_q = compact ? tag_q : 0; ix->tag_dsh = compact ? tag_dsh : 0; ix->tag_w = compact ? tag_w : 0;
+  kamd::Table ktab{nullptr, nb};
+  ktab.layout = (uint8_t)ix->layout; ktab.q = (uint8_t)ix->tag_q; ktab.dsh = (uint8_t)ix->tag_dsh; ktab.tagw = (uint8_t)ix->tag_w;
   const uint64_t end_cursor = cursor;
   uint64_t total_buckets = std::max(nb, (cursor + S - 1) / S) + 1;
   ix->pad_buckets = total_buckets - nb;
@@ -640,8 +692,11 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   parallel_range(total_buckets, [&](uint64_t a, uint64_t b) {
     for (uint64_t i = a; i < b; i++) {
       uint64_t* w = ix->table.data() + 8 * i;
-      for (uint64_t j = 0; j < S; j++) w[j] = kamd::KEY_EMPTY;
-      for (uint64_t j = S; j < 8; j++) w[j] = 0;
+      if (compact) { for (uint64_t j = 0; j < 4; j++) { w[2 * j] = ~0ULL; w[2 * j + 1] = 0; } }   // displacement 7 = empty
+      else {
+        for (uint64_t j = 0; j < S; j++) w[j] = kamd::KEY_EMPTY;
+        for (uint64_t j = S; j < 8; j++) w[j] = 0;
+      }
     }
     std::fill(ix->slot_block.begin() + a * S, ix->slot_block.begin() + b * S, 0xFFFFFFFFu);
     memset(ix->slot_dist.data() + a * S, 0, (b - a) * S * sizeof(uint32_t));
@@ -656,9 +711,17 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   struct PlaceState { Pend1 a[RING]; Pend2 b[RING]; int na = 0, ha = 0, nb2 = 0, hb2 = 0; };
   auto stage3 = [&](const Pend2& q) {
     const uint64_t bk = q.slot / S, j = q.slot % S;
-    ix->table[8 * bk + j] = (j == 0 && bucket_continues(bk)) ? (q.cn | kamd::KEY_CONT) : q.cn;
-    ix->table[8 * bk + S + j] = q.payload;
-    reinterpret_cast<uint32_t*>(&ix->table[8 * bk + 2 * S])[j] = q.gpos;
+    if (compact) {
+      const uint32_t h = kamd::kmer_hash32(q.cn);
+      const uint64_t uec = (q.payload >> 32) & 0x7FFFFFFFULL;
+      ix->table[8 * bk + 2 * j] = kamd::compact_tag(ktab, q.cn, h, (uint32_t)(bk - kamd::bucket_of_hash(h, nb))) | (uec << ix->tag_w);
+      ix->table[8 * bk + 2 * j + 1] = (q.payload & 0xFFFFFFFFULL) | ((uint64_t)q.gpos << 32) | ((q.payload >> 63) ? kamd::COMPACT_FWD : 0ULL) |
+                                      ((j == 0 && bucket_continues(bk)) ? kamd::COMPACT_CONT : 0ULL);
+    } else {
+      ix->table[8 * bk + j] = (j == 0 && bucket_continues(bk)) ? (q.cn | kamd::KEY_CONT) : q.cn;
+      ix->table[8 * bk + S + j] = q.payload;
+      reinterpret_cast<uint32_t*>(&ix->table[8 * bk + 2 * S])[j] = q.gpos;
+    }
     ix->slot_block[q.slot] = q.block;
     ix->slot_dist[q.slot] = q.dist;
   };
@@ -714,6 +777,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   tick("table: place pass");
   // ---- D-list table (same bucket layout, built serially: it is small) and the dummy hit ----
   if (ix->dlist_size) {
+    constexpr uint64_t S = kamd::BUCKET_SLOTS;   // (the D-list table is always of the wide layout)
     const uint64_t nd = ix->dlist_size, ndb = std::max<uint64_t>(16, (nd * 2 + S - 1) / S);
     std::vector<std::pair<uint64_t, uint64_t>> byhome(nd);   // (home bucket, key)
     for (uint64_t i = 0; i < nd; i++) byhome[i] = {kamd::home_bucket(ix->dlist_keys[i], ndb), ix->dlist_keys[i]};
@@ -737,7 +801,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
         if (reach > (b + 1) * S) ix->dtable[8 * b] |= kamd::KEY_CONT;
       }
     }
-    const kamd::Table mt{ix->table.data(), nb};
+    kamd::Table mt = ktab; mt.slots = ix->table.data();
     const kamd::Probe pd = kamd::probe_table(mt, ix->dlist_keys[0], true, nullptr);
     if (!pd.found) return kamd::fail(-3, "index: Dummy k-mer not found in graph");   // KmerIndex.cpp:1398-1401
     ix->dummy_slot = pd.slot; ix->dummy_uec = pd.uec; ix->dummy_strand = pd.strand ? 1 : 0;
@@ -755,6 +819,7 @@ extern "C" int kamd_index_get_view(const kamd_index* ix, kamd_index_view* v) {
   v->n_uec = ix->uec_ec.size(); v->n_ecs = ix->ec_off.size() - 1; v->ec_nnz = ix->ec_ids.size();
   v->n_targets = ix->n_targets; v->dlist_size = ix->dlist_size;
   v->n_buckets = ix->n_buckets; v->pad_buckets = ix->pad_buckets;
+  v->table_layout = ix->layout; v->slots_per_bucket = ix->slots; v->tag_q = ix->tag_q; v->tag_dsh = ix->tag_dsh; v->tag_w = ix->tag_w;
   v->table = ix->table.data(); v->slot_block = ix->slot_block.data(); v->slot_dist = ix->slot_dist.data();
   v->uec_ec = ix->uec_ec.data(); v->ec_off = ix->ec_off.data(); v->ec_ids = ix->ec_ids.data();
   v->unitig_blk_off = ix->unitig_blk_off.data(); v->unitig_len = ix->unitig_len.data();

@@ -55,6 +55,7 @@ constexpr int EXPLICIT_HITS = 256;   // distinct (block, strand) pairs of a mate
 
 struct DevIndex {
   const u64* table; u64 n_buckets;
+  int table_layout; u32 tag_q, tag_dsh, tag_w;   // kamd_core.h: LAYOUT_WIDE, or LAYOUT_COMPACT with its shifts
   const u32* slot_block; const u32* slot_dist;
   const u32* uec_ec;
   const u64* ec_off; const u32* ec_ids; const uint8_t* ec_nonempty;
@@ -74,6 +75,7 @@ struct DevIndex {
 // the k-mer table(s) as the per-item logic sees them; partial = match()'s `partial` argument = single-end reads
 __host__ __device__ inline kamd::Table make_table(const DevIndex& ix, bool partial) {
   kamd::Table t{(const uint64_t*)ix.table, ix.n_buckets};
+  t.layout = (uint8_t)ix.table_layout; t.q = (uint8_t)ix.tag_q; t.dsh = (uint8_t)ix.tag_dsh; t.tagw = (uint8_t)ix.tag_w;
   t.dslots = (const uint64_t*)ix.dtable; t.n_dbuckets = ix.n_dbuckets; t.dummy_uec = ix.dummy_uec; t.dummy_slot = ix.dummy_slot;
   t.dummy_strand = ix.dummy_strand != 0; t.partial = partial && !ix.union_mode;   // --union: match(..., partial = false) (KmerIndex.cpp:1704)
   t.no_jump = ix.no_jump != 0;
@@ -274,7 +276,7 @@ constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
 // More than V3_LIST_CAP distinct classes (0.5 % of config #3's pairs): the item goes to the overflow kernel, as before.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int V3_LIST_CAP = 8;
-template <bool PAIRED, bool FILTER, bool DL, bool TEXT>
+template <bool PAIRED, bool FILTER, bool DL, bool TEXT, int LAYOUT>
 __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                     u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
                                                     u32* raw, int raw_stride, DevStatsA* st) {
@@ -351,7 +353,10 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
       const bool use_text = TEXT && kamd::text_applies(ms);
       const kamd::Table pt = DL ? kamd::phase_table(t, ms.phase) : t;
       const u32 tpos = use_text ? kamd::text_pos_of(ms) : 0u;
-      const uint64_t bucket = kamd::home_bucket(canon, pt.n_buckets) + ms.disp;
+      // (compact layout: the D-list table keeps the wide one, so the phase decides)
+      const bool compact = LAYOUT == kamd::LAYOUT_COMPACT && (!DL || ms.phase != kamd::PH_DLIST);
+      const u32 khash = kamd::kmer_hash32(canon);
+      const uint64_t bucket = kamd::bucket_of_hash(khash, pt.n_buckets) + ms.disp;
       kamd::TextWords tw{0u, 0u, 0u};
       kamd::BucketLine bl{0, 0, 0, 0, 0, 0, 0, 0};
       if (use_text) tw = kamd::load_text(ix.utext, tpos);
@@ -361,6 +366,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
       if (use_text) {
         if (kamd::text_canon_of(tw, tpos, k) == canon) { p.found = true; p.strand = ms.um_strand; p.uec = ms.um_uec; ++text_hits; }   // (only uec is looked at in these phases)
         else { ms.text_tried = true; feed = false; }
+      } else if (compact) {
+        if (kamd::match_bucket_compact(bl, pt, kamd::compact_tag(pt, canon, khash, ms.disp), fc, bucket, p) == kamd::BUCKET_CONTINUE &&
+            ms.disp < kamd::COMPACT_MAX_DISP) { ++ms.disp; feed = false; }
       } else if (kamd::match_bucket(bl, canon, fc, bucket, p) == kamd::BUCKET_CONTINUE) { ++ms.disp; feed = false; }
       if (feed) {
         if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only
@@ -2574,7 +2582,8 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   c->index_allocs.clear();
   DevIndex d{};
   d.k = v.k; d.n_buckets = v.n_buckets; d.n_ecs = v.n_ecs;
-  const u64 slots = (v.n_buckets + v.pad_buckets) * KAMD_SLOTS_PER_BUCKET;
+  d.table_layout = (int)v.table_layout; d.tag_q = v.tag_q; d.tag_dsh = v.tag_dsh; d.tag_w = v.tag_w;
+  const u64 slots = (v.n_buckets + v.pad_buckets) * v.slots_per_bucket;
   if (int rc = upload(c, (const u64*)v.table, (size_t)(v.n_buckets + v.pad_buckets) * 8, &d.table)) return rc;
   if (int rc = upload(c, v.slot_block, slots, &d.slot_block)) return rc;
   if (int rc = upload(c, v.slot_dist, slots, &d.slot_dist)) return rc;
@@ -2760,16 +2769,19 @@ int launch_match_chunk(kamd_ctx* c, hipStream_t s, const u32* d_words, const uin
     // CU has 160 KB) -- the reference has no length limit, so such batches take the HBM-resident path item by item
     hipLaunchKernelGGL(k_mark_overflow, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, s, raw, stride, n);
   } else {
-#define KAMD_LAUNCH_V3(DLV, TXT)                                                                                                         \
+#define KAMD_LAUNCH_V3L(DLV, TXT, LAY)                                                                                                   \
   do {                                                                                                                                  \
-    HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, s, c->ix, w, l, n, seq_words, \
+    HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT, LAY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT, LAY>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, s, c->ix, w, l, n, seq_words, \
                        rec_words, c->items_per_wave, c->refill_min, raw, stride, c->stats_a.as<DevStatsA>());                           \
   } while (0)
+#define KAMD_LAUNCH_V3(DLV, TXT)                                                                                                         \
+  do { if (c->ix.table_layout == kamd::LAYOUT_COMPACT) KAMD_LAUNCH_V3L(DLV, TXT, kamd::LAYOUT_COMPACT); else KAMD_LAUNCH_V3L(DLV, TXT, kamd::LAYOUT_WIDE); } while (0)
     const bool dl = c->ix.n_dbuckets != 0, txt = c->tune.text_verify == 1;
     if (dl) { if (txt) KAMD_LAUNCH_V3(true, true); else KAMD_LAUNCH_V3(true, false); }
     else { if (txt) KAMD_LAUNCH_V3(false, true); else KAMD_LAUNCH_V3(false, false); }
 #undef KAMD_LAUNCH_V3
+#undef KAMD_LAUNCH_V3L
   }
   HIPC(hipGetLastError());
   return 0;

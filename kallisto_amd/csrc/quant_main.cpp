@@ -239,6 +239,11 @@ int main(int argc, char** argv) {
   const int load_threads = std::min(opt.threads, effective_cpus());
   std::thread load_early([&] {
     load_rc = kamd_index_load(index_path.c_str(), load_threads, &idx);
+    if (load_rc && index_path != opt.index) {   // a flattened file picked up beside the index that does not load (another format version, damaged): the index itself
+      if (opt.verbose) std::cerr << "[index] " << index_path << " ignored: " << kamd_last_error() << std::endl;
+      index_path = opt.index;
+      load_rc = kamd_index_load(index_path.c_str(), load_threads, &idx);
+    }
     if (!load_rc) load_rc = kamd_index_get_view(idx, &v);
     if (load_rc) load_err = kamd_last_error();
     index_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -303,6 +308,8 @@ int main(int argc, char** argv) {
     if (opt.bootstrap > 0 && n_gpus == 1 && kamd_ec_track_order(ctx, 1) != 0) { done(-1, kamd_last_error()); return; }
     index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (opt.verbose && index_path != opt.index) std::cerr << "[index] using the flattened tables of " << index_path << std::endl;
+    if (opt.verbose) std::cerr << "[index] k-mer table: " << (v.table_layout ? "compact" : "wide") << " layout, " << v.slots_per_bucket << " slots per 64-byte line, "
+                               << (v.n_buckets + v.pad_buckets) * 64 / 1000000 << " MB, load " << (double)v.n_kmers / (double)(v.n_buckets * v.slots_per_bucket) << std::endl;
     if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;
     done(1, "");
   });

@@ -11,6 +11,7 @@
 // the k-mer table(s) of the host view as the per-item logic sees them (mirrors make_table of kamd_kernels.hip)
 static kamd::Table emu_table(const kamd_index_view* v, bool partial, bool no_jump = false) {
   kamd::Table t{v->table, v->n_buckets};
+  t.layout = (uint8_t)v->table_layout; t.q = (uint8_t)v->tag_q; t.dsh = (uint8_t)v->tag_dsh; t.tagw = (uint8_t)v->tag_w;
   t.dslots = v->dtable; t.n_dbuckets = v->n_dbuckets; t.dummy_uec = v->dummy_uec; t.dummy_slot = v->dummy_slot;
   t.dummy_strand = v->dummy_strand != 0; t.partial = partial; t.no_jump = no_jump;
   return t;
@@ -101,8 +102,12 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
             } else { st.text_tried = true; continue; }
           } else if (use_text) {   // as kernel A v3: one bucket per step, a continue flag costs another step
             const Table pt = phase_table(t, st.phase);
-            const uint64_t b = home_bucket(canon, pt.n_buckets) + st.disp;
-            if (match_bucket(load_bucket(pt.slots, b), canon, fc, b, p) == BUCKET_CONTINUE) { ++st.disp; continue; }
+            const uint32_t h = kmer_hash32(canon);
+            const uint64_t b = bucket_of_hash(h, pt.n_buckets) + st.disp;
+            if (pt.layout == LAYOUT_COMPACT) {   // (the D-list table is wide: phase_table hands it out with layout 0)
+              if (match_bucket_compact(load_bucket(pt.slots, b), pt, compact_tag(pt, canon, h, st.disp), fc, b, p) == BUCKET_CONTINUE &&
+                  st.disp < COMPACT_MAX_DISP) { ++st.disp; continue; }
+            } else if (match_bucket(load_bucket(pt.slots, b), canon, fc, b, p) == BUCKET_CONTINUE) { ++st.disp; continue; }
             if (st.phase != PH_DLIST) ++*probes;
           } else {
             p = probe_table(phase_table(t, st.phase), canon, fc, nullptr);
@@ -252,7 +257,7 @@ int64_t emu_resolve(const kamd_index_view* v, const uint32_t* dense, const uint3
 // position, offset on its unitig and a block of that unitig that covers it.  Returns the number of k-mers that fail (0 = all
 // good), -1 if the number of k-mers walked differs from the index's count.  *lines: bucket lines read in all.
 extern "C" int64_t emu_verify_table(const kamd_index_view* v, uint64_t* lines) {
-  const kamd::Table t{v->table, v->n_buckets};
+  const kamd::Table t = emu_table(v, false);
   uint64_t bad = 0, n = 0, ll = 0;
   for (uint64_t u = 0; u < v->n_unitigs; u++) {
     const uint64_t g0 = v->unitig_gpos[u], len = v->unitig_len[u];

@@ -14,14 +14,33 @@ from tests import common, emu_binding as E
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def idx():
+def _load_with_layout(path, layout, load=None):
+    """kamd_index_load with KAMD_TABLE_LAYOUT (and KAMD_TABLE_LOAD) set for the call: the k-mer table's layout is chosen at load time."""
+    old = {k: os.environ.get(k) for k in ("KAMD_TABLE_LAYOUT", "KAMD_TABLE_LOAD")}
+    os.environ["KAMD_TABLE_LAYOUT"] = layout
+    if load is not None:
+        os.environ["KAMD_TABLE_LOAD"] = str(load)
+    try:
+        return E.EmuIndex(path)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# every test that takes `idx` runs on both layouts of the k-mer table (kamd_core.h): wide = 3 slots of 20 bytes per line (the default),
+# compact = 4 quotiented slots of 16 bytes
+@pytest.fixture(scope="module", params=["wide", "compact"])
+def idx(request):
     cache = {}
 
     def get(case):
         if case not in cache:
             p = common.load_case(case)[1]
-            cache[case] = (E.EmuIndex(p), O.Index(p))
+            cache[case] = (_load_with_layout(p, request.param), O.Index(p))
+            assert cache[case][0].view.table_layout == (1 if request.param == "compact" else 0)
         return cache[case]
     return get
 
@@ -39,8 +58,12 @@ def test_flattened_index_matches_oracle_parse(case, idx):
     mine = {tuple(ec_ids[ec_off[i]:ec_off[i + 1]].tolist()) for i in range(v.n_ecs)}
     theirs = {tuple(o.ec(i)) for i in range(o.num_ecs)}
     assert mine == theirs
-    # table invariants: every k-mer placed once, load factor <= 0.5 over 3-slot buckets (words 0..2 of each 64-byte bucket)
     table = _np(v.table, (v.n_buckets + v.pad_buckets) * 8, np.uint64).reshape(-1, 8)
+    if v.table_layout == 1:
+        _check_compact_table(case, v, table)
+        return
+    # table invariants: every k-mer placed once, load factor <= 0.5 over 3-slot buckets (words 0..2 of each 64-byte bucket)
+    assert v.slots_per_bucket == 3
     keys = table[:, 0:3] & np.uint64((1 << 62) - 1)
     used = keys != np.uint64((1 << 62) - 1)
     assert int(used.sum()) == v.n_kmers
@@ -61,6 +84,63 @@ def test_flattened_index_matches_oracle_parse(case, idx):
         for x in bases[g:g + kk][::-1]:
             rc = (rc << 2) | (3 - int(x))
         assert min(fwd, rc) == int(keys[b, j]), (case, b, j)
+
+
+def _kmer_hash32(canon):
+    """kamd_core.h kmer_hash32, restated"""
+    M = 0xFFFFFFFF
+    lo, hi = canon & M, canon >> 32
+    h = (hi * 0x9E3779B1) & M
+    h ^= h >> 15
+    x = ((lo ^ h) * 0x85EBCA6B) & M
+    x ^= x >> 13
+    x = (x * 0xC2B2AE35) & M
+    x ^= x >> 16
+    return x
+
+
+def _check_compact_table(case, v, table):
+    """The compact layout decoded here, independently of kamd_core.h: four {w0, w1} slots per line; w0 = tag | class << tag_w, the tag =
+    low tag_q bits of the hash | key bits above 32 | displacement from the home bucket (7 = empty); w1 = rem_f | rem_b | text position |
+    forward-is-canonical | continue flag.  Every k-mer once; a sample of slots re-derived from the unitig text."""
+    from kallisto_amd.api import _np
+    assert v.slots_per_bucket == 4
+    q, dsh, tw = int(v.tag_q), int(v.tag_dsh), int(v.tag_w)
+    kk = int(v.k)
+    assert dsh == q + max(0, 2 * kk - 32) and tw == dsh + 3
+    span = -(-(1 << 32) // int(v.n_buckets))
+    assert (1 << q) >= span and (q == 0 or (1 << (q - 1)) < span)
+    w0, w1 = table[:, 0::2], table[:, 1::2]
+    disp = (w0 >> np.uint64(dsh)) & np.uint64(7)
+    used = disp != np.uint64(7)
+    assert np.all(w0[~used] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert int(used.sum()) == v.n_kmers
+    assert int(disp[used].max(initial=0)) <= 6
+    assert int((w0[used] >> np.uint64(tw)).max(initial=0)) < v.n_uec
+    # a bucket whose continue flag is set is full, and the flag sits in slot 0 only
+    cont = (w1[:, 0] >> np.uint64(63)) != 0
+    assert np.all(used[cont].all(axis=1)) and not np.any((w1[:, 1:] >> np.uint64(63)) != 0)
+    text = _np(v.utext, v.utext_words, np.uint32)
+    bases = ((text[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).reshape(-1).astype(np.uint64)
+    sel = np.argwhere(used)[:: max(1, int(used.sum()) // 4000)]
+    for b, j in sel:
+        a, c = int(w0[b, j]), int(w1[b, j])
+        g = (c >> 32) & 0x3FFFFFFF
+        fwd = 0
+        for x in bases[g:g + kk]:
+            fwd = (fwd << 2) | int(x)
+        rc = 0
+        for x in bases[g:g + kk][::-1]:
+            rc = (rc << 2) | (3 - int(x))
+        canon = min(fwd, rc)
+        assert ((c >> 62) & 1) == (1 if fwd < rc else 0), (case, b, j)
+        h = _kmer_hash32(canon)
+        home = (h * int(v.n_buckets)) >> 32
+        d = int(b) - home
+        assert 0 <= d <= 6
+        assert (a & ((1 << tw) - 1)) == ((h & ((1 << q) - 1)) | ((canon >> 32) << q) | (d << dsh)), (case, b, j)
+        # reachable: every bucket from the home up to the one before carries the continue flag
+        assert all(cont[home + i] for i in range(d)), (case, b, j)
 
 
 @pytest.mark.parametrize("case", common.CASES)
@@ -225,21 +305,27 @@ def test_index_loader_refuses_damaged_files(case, tmp_path):
     assert L.kamd_index_load(str(tmp_path / "missing.idx").encode(), 2, C.byref(h)) != 0
 
 
+@pytest.mark.parametrize("layout", ["wide", "compact"])
 @pytest.mark.parametrize("case", ["human_pe", "dlist_pe", "tiny_k7_se"])
-def test_flattened_index_file_round_trip(case, tmp_path):
+def test_flattened_index_file_round_trip(case, layout, tmp_path, monkeypatch):
     """kamd_index_save / kamd_index_load on the saved file: every table of the view, the scalars and the target names come back
     bit-identical (the front-end's `flatten` sub-command and `-i index.kamd`)."""
     import ctypes as C
     import subprocess
     from kallisto_amd import api
     idx_path = common.load_case(case)[1]
+    monkeypatch.setenv("KAMD_TABLE_LAYOUT", layout)
     a = api.Index(idx_path)
     flat = str(tmp_path / "index.kamd")
     a.save(flat)
+    monkeypatch.setenv("KAMD_TABLE_LAYOUT", "wide")   # (a flattened file carries its layout: the variable only speaks to the builder)
     b = api.Index(flat)
+    monkeypatch.setenv("KAMD_TABLE_LAYOUT", layout)
     va, vb = a.view, b.view
-    sizes = {"table": (va.n_buckets + va.pad_buckets) * 8 * 8, "slot_block": (va.n_buckets + va.pad_buckets) * 3 * 4,
-             "slot_dist": (va.n_buckets + va.pad_buckets) * 3 * 4, "uec_ec": va.n_uec * 4, "ec_off": (va.n_ecs + 1) * 8, "ec_ids": va.ec_nnz * 4,
+    S = va.slots_per_bucket
+    assert (va.table_layout, S) == ((1, 4) if layout == "compact" else (0, 3))
+    sizes = {"table": (va.n_buckets + va.pad_buckets) * 8 * 8, "slot_block": (va.n_buckets + va.pad_buckets) * S * 4,
+             "slot_dist": (va.n_buckets + va.pad_buckets) * S * 4, "uec_ec": va.n_uec * 4, "ec_off": (va.n_ecs + 1) * 8, "ec_ids": va.ec_nnz * 4,
              "unitig_blk_off": (va.n_unitigs + 1) * 8, "unitig_len": va.n_unitigs * 4, "blk_unitig": va.n_blocks * 4, "blk_lb": va.n_blocks * 4,
              "blk_ub": va.n_blocks * 4, "blk_ec": va.n_blocks * 4, "blk_pos_off": va.n_blocks * 8, "blk_sense": va.n_blocks,
              "onlist_bits": va.onlist_words * 4, "utext": va.utext_words * 4, "unitig_gpos": (va.n_unitigs + 1) * 8,
@@ -285,9 +371,41 @@ def test_flattened_index_file_round_trip(case, tmp_path):
     ec_ids = np.ctypeslib.as_array(C.cast(v.ec_ids, C.POINTER(C.c_uint32)), shape=(int(v.ec_nnz),)).copy()
     at = bytes(blob).find(ec_ids.tobytes())
     assert at > 0
-    for patch_at, patch in ((at, (1 << 31).to_bytes(4, "little")), (8, b"\x07\x00\x00\x00"), (0, b"X")):
+    for patch_at, patch in ((at, (1 << 31).to_bytes(4, "little")), (8, b"\x07\x00\x00\x00"), (0, b"X"), (7, b"2")):   # (7: the previous format version)
         bad = bytearray(blob)
         bad[patch_at:patch_at + len(patch)] = patch
         open(flat, "wb").write(bad)
         with pytest.raises(api.KallistoAmdError):
             api.Index(flat)
+
+
+@pytest.mark.parametrize("load", [0.3, 0.75, 0.9])
+@pytest.mark.parametrize("case", ["human_pe", "dlist_pe"])
+def test_compact_table_at_other_loads(case, load):
+    """KAMD_TABLE_LOAD: a sparse table, and dense ones where keys sit several buckets from home -- beyond six the builder takes a larger
+    table and counts again (a slot's displacement field holds 0..6).  Every k-mer is still found with its own payload."""
+    import ctypes as C
+    e = _load_with_layout(common.load_case(case)[1], "compact", load)
+    v = e.view
+    assert v.table_layout == 1 and v.n_kmers <= 4 * v.n_buckets
+    if load <= 0.75:
+        assert abs(v.n_kmers / (4.0 * v.n_buckets) - load) < 0.02
+    L = E.lib()
+    L.emu_verify_table.restype = C.c_int64
+    lines = C.c_uint64(0)
+    assert L.emu_verify_table(C.byref(v), C.byref(lines)) == 0
+    assert 1.0 <= lines.value / v.n_kmers < 2.5
+    e.close()
+
+
+def test_table_layout_variable():
+    """KAMD_TABLE_LAYOUT: `auto` takes the compact layout when its fields fit (all fixtures), anything else than wide / compact / auto is an error."""
+    p = common.load_case("ref_test_pe")[1]
+    e = _load_with_layout(p, "auto")
+    assert e.view.table_layout == 1
+    e.close()
+    with pytest.raises(RuntimeError, match="KAMD_TABLE_LAYOUT"):
+        _load_with_layout(p, "dense")
+    e = _load_with_layout(p, "wide")
+    assert (e.view.table_layout, e.view.slots_per_bucket, e.view.tag_w) == (0, 3, 0)
+    e.close()
