@@ -428,6 +428,7 @@ def main():
     ap.add_argument("--table-layout", default=None, choices=["wide", "compact", "auto"],
                     help="layout of the k-mer table (KAMD_TABLE_LAYOUT; default: the library's, wide): compact = four quotiented 16-byte slots per "
                          "line instead of three 20-byte ones (kamd_core.h)")
+    ap.add_argument("--no-compact-leg", action="store_true", help="skip the side leg that repeats the steps on the compact k-mer table (N = 1 only)")
     ap.add_argument("--table-load", type=float, default=None, help="load factor of the compact table (KAMD_TABLE_LOAD, default 0.6)")
     args = ap.parse_args()
     if args.table_layout:
@@ -678,6 +679,39 @@ def main():
                              "the one-sample-at-a-time figure"}
         ctx2.close()
 
+    # ---- the same steps on the COMPACT layout of the k-mer table (kamd_core.h: four quotiented 16-byte slots per line): reported beside
+    # the headline, never as the headline (the library's default layout is the wide one until this leg says otherwise) ----
+    compact_leg = None
+    if rank == 0 and world == 1 and not args.no_compact_leg and index.view.table_layout == 0:
+        # in a process of its own (tools/compact_table_leg.py): a fault in a side leg must not take the line down.  The packed reads go
+        # through /dev/shm (3 GB for config #3), the results come back as JSON + the vectors to compare.
+        need = n * per * (rec * 4 + 2)
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need + (1 << 30) else CACHE
+        shm = os.path.join(base, f"kamd_bench_{os.getpid()}")
+        try:
+            os.makedirs(shm, exist_ok=True)
+            words[:n * per * rec].cpu().numpy().tofile(os.path.join(shm, "words.i32"))
+            lens[:per * n].cpu().numpy().tofile(os.path.join(shm, "lens.i16"))
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", shm, "--items", str(n), "--read-len", str(L),
+                   "--paired", "1" if paired else "0", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)), "--device", str(local), "--loads", "0.6,0.5"]
+            pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if pc.returncode != 0:
+                compact_leg = [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
+            else:
+                compact_leg = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+                for i, entry in enumerate(compact_leg):   # the layout must change nothing: counts, fragment lengths, and (abundances are reproducible to the bit) est_counts
+                    f = os.path.join(shm, f"result_{i}.npz")
+                    if "error" in entry or not os.path.exists(f):
+                        continue
+                    z = np.load(f)
+                    entry["identical_to_wide"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
+                                                      np.array_equal(z["flens"], res.flens) and np.array_equal(z["est_counts"], res.est_counts) and
+                                                      int(z["em_rounds"]) == res.em_rounds)
+        except Exception as e:   # noqa: BLE001
+            compact_leg = [{"error": str(e)[:300]}]
+        finally:
+            shutil.rmtree(shm, ignore_errors=True)
+
     out = None
     if rank == 0:
         # roofline of kernel A (the dominant kernel by time): ALGORITHMIC bytes of ONE launch (DESIGN.md
@@ -863,6 +897,10 @@ def main():
             out["bootstrap"] = boot
         if in_flight is not None:
             out["two_samples_in_flight"] = in_flight
+        if compact_leg is not None:
+            out["kmer_table_compact"] = {"legs": compact_leg,
+                                         "note": "the same steps with KAMD_TABLE_LAYOUT=compact (four exact 16-byte slots per 64-byte line by quotienting, "
+                                                 "DESIGN.md section 2) at two load factors; a side measurement -- `value` above is the default (wide) layout"}
         print(json.dumps(out), flush=True)
     if world > 1:
         # tear down in order while everything is alive: the library's communicator (ncclCommDestroy), the context, then torch's

@@ -102,6 +102,15 @@ const char* kamd_last_error(void);
 
 /* ---- S1: index ---- */
 int kamd_index_load(const char* path, int threads, kamd_index** out);
+/* The same with the layout of the k-mer table given by the caller instead of the environment (kamd_index_load reads KAMD_TABLE_LAYOUT =
+ * wide | compact | auto and KAMD_TABLE_LOAD): KAMD_TABLE_WIDE = three 20-byte slots per 64-byte line at a load of 0.5 (the default),
+ * KAMD_TABLE_COMPACT = four exact 16-byte slots per line (kamd_index_view::table_layout; an error when the index's class ids or text
+ * positions do not fit the slot), KAMD_TABLE_AUTO = compact when it fits.  load = load factor of the compact table in [0.2, 0.9]
+ * (anything else: 0.6).  A flattened file (kamd_index_save) carries its layout; the argument only speaks to the builder. */
+#define KAMD_TABLE_WIDE 0
+#define KAMD_TABLE_COMPACT 1
+#define KAMD_TABLE_AUTO 2
+int kamd_index_load_layout(const char* path, int threads, int layout, double load, kamd_index** out);
 /* The flattened tables as a file: building them from a kallisto index takes seconds; kamd_index_save writes them once and
  * kamd_index_load recognises such a file by its magic and reads it back with plain reads (same kamd_index).  Native byte order,
  * format-versioned; not a replacement for the kallisto index, which stays the source of truth. */

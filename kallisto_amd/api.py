@@ -95,6 +95,7 @@ _SYMBOLS = {
     # name: (restype, argtypes)
     "kamd_last_error": (C.c_char_p, []),
     "kamd_index_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "kamd_index_load_layout": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),
     "kamd_index_free": (None, [C.c_void_p]),
     "kamd_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "kamd_index_get_view": (C.c_int, [C.c_void_p, C.POINTER(_View)]),
@@ -222,10 +223,18 @@ def _np(ptr, n, dtype):
 class Index:
     """Flattened kallisto index (format v13).  Mirrors KmerIndex::load (src/KmerIndex.cpp:1330)."""
 
-    def __init__(self, path: str, threads: int = 0):
+    TABLE_LAYOUTS = {"wide": 0, "compact": 1, "auto": 2}
+
+    def __init__(self, path: str, threads: int = 0, table_layout: str | None = None, table_load: float = 0.0):
+        """table_layout: None = kamd_index_load (the environment's KAMD_TABLE_LAYOUT, default wide); "wide" / "compact" / "auto" =
+        kamd_index_load_layout with that layout of the k-mer table (and table_load as the compact table's load factor, 0 = 0.6)."""
         lib = load_library()
         self._h = C.c_void_p()
-        _check(lib.kamd_index_load(os.fsencode(path), threads, C.byref(self._h)), "kamd_index_load")
+        if table_layout is None:
+            _check(lib.kamd_index_load(os.fsencode(path), threads, C.byref(self._h)), "kamd_index_load")
+        else:
+            _check(lib.kamd_index_load_layout(os.fsencode(path), threads, self.TABLE_LAYOUTS[table_layout], float(table_load), C.byref(self._h)),
+                   "kamd_index_load_layout")
         self.view = _View()
         _check(lib.kamd_index_get_view(self._h, C.byref(self.view)), "kamd_index_get_view")
         v = self.view

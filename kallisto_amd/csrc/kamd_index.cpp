@@ -336,7 +336,27 @@ extern "C" int kamd_index_save(const kamd_index* ix, const char* path) {
   return 0;
 }
 
+namespace {
+int load_index_impl(const char* path, int threads, int want_compact, double compact_load, kamd_index** out);
+}
 extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) {
+  // the layout of the k-mer table from the environment: KAMD_TABLE_LAYOUT = wide (default) | compact | auto, KAMD_TABLE_LOAD
+  int want_compact = KAMD_TABLE_WIDE;
+  if (const char* e = getenv("KAMD_TABLE_LAYOUT")) {
+    if (!strcmp(e, "compact")) want_compact = KAMD_TABLE_COMPACT;
+    else if (!strcmp(e, "auto")) want_compact = KAMD_TABLE_AUTO;
+    else if (strcmp(e, "wide") != 0 && *e) return kamd::fail(-1, std::string("KAMD_TABLE_LAYOUT: wide, compact or auto expected, not ") + e);
+  }
+  double compact_load = 0.0;
+  if (const char* e = getenv("KAMD_TABLE_LOAD")) compact_load = atof(e);
+  return load_index_impl(path, threads, want_compact, compact_load, out);
+}
+extern "C" int kamd_index_load_layout(const char* path, int threads, int layout, double load, kamd_index** out) {
+  if (layout != KAMD_TABLE_WIDE && layout != KAMD_TABLE_COMPACT && layout != KAMD_TABLE_AUTO) return kamd::fail(-1, "kamd_index_load_layout: layout must be KAMD_TABLE_WIDE, _COMPACT or _AUTO");
+  return load_index_impl(path, threads, layout, load, out);
+}
+namespace {
+int load_index_impl(const char* path, int threads, int want_compact, double compact_load_arg, kamd_index** out) {
   if (!out) return kamd::fail(-1, "kamd_index_load: null output pointer");
   *out = nullptr;
   if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -422,17 +442,10 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   }
   tick("unitigs + head map");
   // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
-  // The layout (kamd_core.h): wide = 3 slots of 20 bytes per line at a load of 0.5; compact = 4 slots of 16 bytes at KAMD_TABLE_LOAD
-  // (0.6).  KAMD_TABLE_LAYOUT = wide (default) | compact (an error when a field does not fit) | auto (compact when it fits).
-  int want_compact = 0;   // 0 wide, 1 compact, 2 auto
-  if (const char* e = getenv("KAMD_TABLE_LAYOUT")) {
-    if (!strcmp(e, "compact")) want_compact = 1;
-    else if (!strcmp(e, "auto")) want_compact = 2;
-    else if (strcmp(e, "wide") != 0 && *e) return kamd::fail(-1, std::string("KAMD_TABLE_LAYOUT: wide, compact or auto expected, not ") + e);
-  }
-  double compact_load = 0.6;
-  if (const char* e = getenv("KAMD_TABLE_LOAD")) { const double x = atof(e); if (x >= 0.2 && x <= 0.9) compact_load = x; }
-  bool compact = want_compact != 0;
+  // The layout (kamd_core.h): wide = 3 slots of 20 bytes per line at a load of 0.5; compact = 4 slots of 16 bytes at a load of 0.6
+  // (or the caller's): KAMD_TABLE_COMPACT is an error when a field does not fit, KAMD_TABLE_AUTO builds the wide one then.
+  const double compact_load = (compact_load_arg >= 0.2 && compact_load_arg <= 0.9) ? compact_load_arg : 0.6;
+  bool compact = want_compact != KAMD_TABLE_WIDE;
   const uint64_t nb_wide = std::max<uint64_t>(16, (ix->n_kmers * 2 + kamd::BUCKET_SLOTS - 1) / kamd::BUCKET_SLOTS);  // load factor 0.5 over 3-slot buckets
   uint64_t S = compact ? kamd::COMPACT_SLOTS : kamd::BUCKET_SLOTS;
   uint64_t nb = compact ? std::max<uint64_t>(16, (uint64_t)((double)ix->n_kmers / compact_load / (double)S) + 1) : nb_wide;
@@ -657,7 +670,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
     // its home: otherwise the wide layout (auto), or a larger table (an eighth more buckets) and the count pass again
     auto recount = [&] { fill.resize(nb + 1); fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data()); count_pass(); };
     if (compact && !compact_shifts(k, nb, ix->uec_ec.size(), ix->text_bases, &tag_q, &tag_dsh, &tag_w)) {
-      if (want_compact == 1) return kamd::fail(-3, "index: the compact k-mer table cannot hold this index (class ids / text positions too wide); use KAMD_TABLE_LAYOUT=wide or auto");
+      if (want_compact == KAMD_TABLE_COMPACT) return kamd::fail(-3, "index: the compact k-mer table cannot hold this index (class ids / text positions too wide); use KAMD_TABLE_LAYOUT=wide or auto");
       compact = false; S = kamd::BUCKET_SLOTS; nb = nb_wide;
       recount();
     }
@@ -809,6 +822,7 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   *out = ix.release();
   return 0;
 }
+}  // namespace
 
 extern "C" void kamd_index_free(kamd_index* ix) { delete ix; }
 

@@ -13,11 +13,17 @@ struct Options {
   std::vector<std::string> files;
   bool single = false, single_overhang = false, plaintext = false, verbose = false, no_jump = false, do_union = false, share_device = false;
   int gpus = 1;
+  int table_layout = -1;   // --kmer-table: KAMD_TABLE_WIDE / _COMPACT / _AUTO; -1 = the library's choice (environment, default wide)
   int strand = 0, bootstrap = 0, threads = 1;
   double fld = 0.0, sd = 0.0;
   uint64_t seed = 42;
   uint64_t batch = 4u << 20;  // reads (or pairs) per device batch
 };
+
+bool parse_table_layout(const std::string& v, int* out) {
+  if (v == "wide") *out = KAMD_TABLE_WIDE; else if (v == "compact") *out = KAMD_TABLE_COMPACT; else if (v == "auto") *out = KAMD_TABLE_AUTO; else return false;
+  return true;
+}
 
 void usage() {
   std::cout << "kallisto_amd " << KALLISTO_COMPAT_VERSION << "-compatible (MI355X)\n"
@@ -43,6 +49,8 @@ void usage() {
             << "    --verbose                 Print out progress information\n"
             << "    --gpus=INT                GPUs of this node to use (default: 1): batches of reads go round the GPUs, the EC counts\n"
             << "                              are merged with one RCCL all-reduce + all-gathers, the EM runs partitioned over them\n"
+            << "    --kmer-table=wide|compact|auto  layout of the k-mer table in HBM: three 20-byte slots per 64-byte line (wide, default) or\n"
+            << "                              four exact 16-byte slots (compact: 27 instead of 43 bytes per k-mer; auto = compact when it fits)\n"
             << "    --share-device            with --gpus N: all N ranks on device 0, collectives staged through the host (runs the\n"
             << "                              several-GPU code path on a single-GPU box; for testing)\n";
 }
@@ -146,17 +154,20 @@ int main(int argc, char** argv) {
   if (argc >= 2 && std::string(argv[1]) == "version") { std::cout << "kallisto_amd, compatible with kallisto " << KALLISTO_COMPAT_VERSION << std::endl; return 0; }
   if (argc >= 2 && std::string(argv[1]) == "flatten") {   // kallisto_amd_quant flatten -i index.idx -o index.kamd [-t N]
     // writes the device tables of a kallisto index as a file (kamd_index_save); `-i index.kamd` then loads in a fraction of the time
-    std::string in, out, val; int threads = 1;
+    std::string in, out, val; int threads = 1, layout = -1;
+    const char* use = "Usage: kallisto_amd_quant flatten -i index.idx -o index.kamd [-t threads] [--kmer-table wide|compact|auto]";
     for (int i = 2; i < argc; i++) {
       std::string a = argv[i];
       if (take(a, "-i", "--index", i, argc, argv, val)) in = val;
       else if (take(a, "-o", "--output", i, argc, argv, val)) out = val;
       else if (take(a, "-t", "--threads", i, argc, argv, val)) threads = atoi(val.c_str());
-      else { std::cerr << "Error: unknown argument " << a << "\nUsage: kallisto_amd_quant flatten -i index.idx -o index.kamd [-t threads]" << std::endl; return 1; }
+      else if (take(a, nullptr, "--kmer-table", i, argc, argv, val)) { if (!parse_table_layout(val, &layout)) { std::cerr << "Error: --kmer-table expects wide, compact or auto\n" << use << std::endl; return 1; } }
+      else { std::cerr << "Error: unknown argument " << a << "\n" << use << std::endl; return 1; }
     }
-    if (in.empty() || out.empty()) { std::cerr << "Usage: kallisto_amd_quant flatten -i index.idx -o index.kamd [-t threads]" << std::endl; return 1; }
+    if (in.empty() || out.empty()) { std::cerr << use << std::endl; return 1; }
     kamd_index* idx = nullptr;
-    if (kamd_index_load(in.c_str(), threads, &idx) != 0 || kamd_index_save(idx, out.c_str()) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
+    const int lrc = layout < 0 ? kamd_index_load(in.c_str(), threads, &idx) : kamd_index_load_layout(in.c_str(), threads, layout, 0.0, &idx);
+    if (lrc != 0 || kamd_index_save(idx, out.c_str()) != 0) { std::cerr << "Error: " << kamd_last_error() << std::endl; return 1; }
     kamd_index_free(idx);
     return 0;
   }
@@ -185,6 +196,9 @@ int main(int argc, char** argv) {
     else if (a == "--plaintext") opt.plaintext = true;
     else if (a == "--verbose") opt.verbose = true;
     else if (a == "--share-device") opt.share_device = true;
+    else if (take(a, nullptr, "--kmer-table", i, argc, argv, val)) {
+      if (!parse_table_layout(val, &opt.table_layout)) { std::cerr << "Error: --kmer-table expects wide, compact or auto" << std::endl; return 1; }
+    }
     else if (a == "--bias" || a == "--fusion" || a == "--pseudobam" || a == "--genomebam" || a == "--long" || a == "-p" || a == "--priors" ||
              a == "-g" || a == "--gtf" || a == "-c" || a == "--chromosomes" || a == "--dfk-onlist" ||
              a == "-P" || a == "--platform" || a == "-N" || a == "--numReads") {
@@ -238,11 +252,12 @@ int main(int argc, char** argv) {
   int load_rc = 0; std::string load_err;
   const int load_threads = std::min(opt.threads, effective_cpus());
   std::thread load_early([&] {
-    load_rc = kamd_index_load(index_path.c_str(), load_threads, &idx);
+    auto load = [&](const std::string& p) { return opt.table_layout < 0 ? kamd_index_load(p.c_str(), load_threads, &idx) : kamd_index_load_layout(p.c_str(), load_threads, opt.table_layout, 0.0, &idx); };
+    load_rc = load(index_path);
     if (load_rc && index_path != opt.index) {   // a flattened file picked up beside the index that does not load (another format version, damaged): the index itself
       if (opt.verbose) std::cerr << "[index] " << index_path << " ignored: " << kamd_last_error() << std::endl;
       index_path = opt.index;
-      load_rc = kamd_index_load(index_path.c_str(), load_threads, &idx);
+      load_rc = load(index_path);
     }
     if (!load_rc) load_rc = kamd_index_get_view(idx, &v);
     if (load_rc) load_err = kamd_last_error();

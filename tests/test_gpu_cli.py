@@ -278,8 +278,10 @@ def test_compact_kmer_table_changes_nothing(case, variant, tmp_path):
         _fastq(f2, r2)
         files.append(f2)
     out, out_w = str(tmp_path / "out"), str(tmp_path / "out_wide")
-    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", *cli, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       env=dict(os.environ, KAMD_TABLE_LAYOUT="compact"))
+    # (by the environment variable -- what scratch/r3_call34.sh did on the MI355X -- for the verified six, by the option for the others)
+    by_flag = (case, variant) not in VERIFIED_BYTE_EQUAL
+    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", *(["--kmer-table", "compact"] if by_flag else []), *cli, *files],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=os.environ if by_flag else dict(os.environ, KAMD_TABLE_LAYOUT="compact"))
     assert p.returncode == 0, p.stderr.decode()
     assert "k-mer table: compact layout, 4 slots" in p.stderr.decode()
     pw = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out_w, "--plaintext", "--verbose", *cli, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE,

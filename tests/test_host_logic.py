@@ -409,3 +409,26 @@ def test_table_layout_variable():
     e = _load_with_layout(p, "wide")
     assert (e.view.table_layout, e.view.slots_per_bucket, e.view.tag_w) == (0, 3, 0)
     e.close()
+
+
+def test_table_layout_through_the_abi_and_the_front_end(tmp_path):
+    """kamd_index_load_layout (the layout as an argument instead of KAMD_TABLE_LAYOUT) and `kallisto_amd_quant flatten --kmer-table compact`: the
+    flattened file carries the compact layout and loads as such whatever the environment says."""
+    import subprocess
+    from kallisto_amd import api
+    p = common.load_case("human_pe")[1]
+    a = api.Index(p, table_layout="compact", table_load=0.5)
+    assert (a.view.table_layout, a.view.slots_per_bucket) == (1, 4) and abs(a.num_kmers / (4.0 * a.view.n_buckets) - 0.5) < 0.02
+    w = api.Index(p, table_layout="wide")
+    assert (w.view.table_layout, w.view.slots_per_bucket) == (0, 3)
+    assert api.Index(p, table_layout="auto").view.table_layout == 1
+    lib = api.load_library()
+    h = C.c_void_p()
+    assert lib.kamd_index_load_layout(p.encode(), 2, 7, 0.0, C.byref(h)) != 0 and b"layout" in lib.kamd_last_error()
+    exe = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
+    if os.path.exists(exe):
+        flat = str(tmp_path / "c.kamd")
+        assert subprocess.run([exe, "flatten", "-i", p, "-o", flat, "-t", "3", "--kmer-table", "compact"]).returncode == 0
+        c = api.Index(flat, table_layout="wide")
+        assert c.view.table_layout == 1 and c.num_kmers == a.num_kmers
+        assert subprocess.run([exe, "flatten", "-i", p, "-o", flat, "--kmer-table", "dense"], stderr=subprocess.DEVNULL).returncode != 0
