@@ -258,3 +258,51 @@ def test_parallel_gzip_flush_points_and_many_members(tmp_path, monkeypatch):
     open(p, "wb").write(blob)
     st, got, n, _ = _units(p, ring=1 << 19, target=1 << 15, threads=5)
     assert st == 0 and got == reads
+
+
+def _random_gzip_case(seed):
+    """A random FASTQ text (constant / random / narrow qualities, short or long names, read lengths from a random range) compressed in a random
+    way: level, strategy, flush points, several members, a small window."""
+    import zlib
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(200, 6000))
+    lo = int(rng.integers(1, 60)); hi = lo + int(rng.integers(1, 250))
+    acgt = np.frombuffer(b"ACGTN", np.uint8)
+    qmode = int(rng.integers(0, 3))
+    reads, parts = [], []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        s = bytes(acgt[rng.integers(0, 5 if rng.random() < 0.02 else 4, L)])
+        q = b"I" * L if qmode == 0 else bytes(rng.integers(33, 74, L, dtype=np.uint8)) if qmode == 1 else bytes(rng.integers(35, 40, L, dtype=np.uint8))
+        name = b"@r%d" % i if rng.random() < 0.5 else b"@inst:%d:%d:%d %d:N:0" % (rng.integers(1, 99), rng.integers(1, 9999), rng.integers(1, 99999), rng.integers(1, 3))
+        reads.append(s); parts.append(name + b"\n" + s + b"\n+\n" + q + b"\n")
+    data = b"".join(parts)
+    level = int(rng.integers(1, 10))
+    strat = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE][int(rng.integers(0, 4))] if rng.random() < 0.3 else zlib.Z_DEFAULT_STRATEGY
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, int(rng.integers(1, 10)), strat); blob = co.compress(data) + co.flush()
+    elif mode == 1:
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strat); blob = b""; step = int(rng.integers(1000, 200000))
+        for a in range(0, len(data), step):
+            blob += co.compress(data[a:a + step]) + co.flush([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_PARTIAL_FLUSH][int(rng.integers(0, 3))])
+        blob += co.flush()
+    elif mode == 2:
+        k = int(rng.integers(2, 40)); cuts = sorted(set(rng.integers(1, len(data) - 1, k).tolist()))
+        blob = b"".join(gzip.compress(data[a:b], int(rng.integers(0, 10))) for a, b in zip([0] + cuts, cuts + [len(data)]))
+    else:
+        co = zlib.compressobj(level, zlib.DEFLATED, 16 + int(rng.integers(9, 16)), 8, strat); blob = co.compress(data) + co.flush()
+    knobs = dict(chunk_kb=int(rng.choice([1, 2, 3, 4, 8, 16, 64, 256])), threads=int(rng.integers(1, 9)), ring=1 << int(rng.integers(18, 23)),
+                 target=1 << int(rng.integers(13, 17)), blk=1 << int(rng.integers(12, 15)))
+    return reads, data, blob, knobs
+
+
+@pytest.mark.parametrize("seed", range(7000, 7024))
+def test_parallel_gzip_random_streams(tmp_path, monkeypatch, seed):
+    """Two dozen random streams and reader shapes (the same generator ran 1 900 larger cases offline without a difference): exactly the text's reads."""
+    reads, data, blob, k = _random_gzip_case(seed)
+    _pargzip_env(monkeypatch, k["chunk_kb"])
+    p = str(tmp_path / "f.fq.gz")
+    open(p, "wb").write(blob)
+    st, got, n, _ = _units(p, ring=k["ring"], target=k["target"], threads=k["threads"], blk=k["blk"], cap=max(1 << 24, 2 * len(data)))
+    assert st == 0 and got == reads, (seed, st, k)
