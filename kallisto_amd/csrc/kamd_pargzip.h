@@ -40,6 +40,9 @@
 #include <thread>
 #include <vector>
 
+#ifndef KAMD_PGZ_TIME
+#define KAMD_PGZ_TIME(i)   // (a measuring harness defines this as a scoped timer of phase i: 0 decode, 1 resolve, 2 newline count, 3 CRC, 4 block search)
+#endif
 namespace kamd_io {
 namespace pgz {
 
@@ -406,7 +409,7 @@ class ParGzip {
       c.computing = true;
     }
     uint64_t s = ~0ULL;
-    try { s = k == 0 ? (uint64_t)data_start_ * 8 : find_block(d_, n_, nominal_bit(k), nominal_bit(k + 1)); }
+    try { KAMD_PGZ_TIME(4); s = k == 0 ? (uint64_t)data_start_ * 8 : find_block(d_, n_, nominal_bit(k), nominal_bit(k + 1)); }
     catch (...) { fatal_ = true; }   // (out of memory: "no block found" lets everyone waiting for this answer go on; the coordinator gives up)
     std::lock_guard<std::mutex> lk(c.m);
     c.start_bit = s; c.start_known = true;
@@ -430,6 +433,7 @@ class ParGzip {
       Bits b(d_, n_, s);
       Out<uint16_t> O{&c.sym, WIN};
       rc = D_STOP;
+      KAMD_PGZ_TIME(0);
       if (k != 0) rc = inflate_blocks<uint16_t>(b, O, s + 1, &eb, true);   // the found block itself: must be text (the finder tried it already)
       if (rc == D_STOP) rc = inflate_blocks<uint16_t>(b, O, stop, &eb, false);
       c.n_out = O.o - WIN;
@@ -444,9 +448,9 @@ class ParGzip {
     c.bytes.grow(c.n_out + 16);
     c.n_bytes = c.n_out;
     const uint16_t* s = c.sym.data() + WIN; const uint8_t* w = c.window.data(); uint8_t* o = c.bytes.data();
-    resolve(s, c.n_out, w, o);
-    c.nl = count_nl_((const char*)o, c.n_out);
-    c.crc = crc_of(o, c.n_out);
+    { KAMD_PGZ_TIME(1); resolve(s, c.n_out, w, o); }
+    { KAMD_PGZ_TIME(2); c.nl = count_nl_ ? count_nl_((const char*)o, c.n_out) : 0; }
+    { KAMD_PGZ_TIME(3); c.crc = crc_of(o, c.n_out); }
     give_sym(std::move(c.sym));
     std::lock_guard<std::mutex> lk(c.m);
     c.state = CONVERTED;
@@ -458,18 +462,29 @@ class ParGzip {
   void give_sym(RawBuf<uint16_t>&& b) { if (!b.p) return; std::lock_guard<std::mutex> lk(pm_); sym_pool_.push_back(std::move(b)); }
   RawBuf<uint8_t> take_bytes() { std::lock_guard<std::mutex> lk(pm_); if (byte_pool_.empty()) return RawBuf<uint8_t>(); RawBuf<uint8_t> b = std::move(byte_pool_.back()); byte_pool_.pop_back(); return b; }
   void give_bytes(RawBuf<uint8_t>&& b) { if (!b.p) return; std::lock_guard<std::mutex> lk(pm_); byte_pool_.push_back(std::move(b)); }
-  // symbols -> bytes: 16 at a time when none of them is a marker
+  // symbols -> bytes.  FASTQ text keeps its markers for ever (the constant parts of a record are copied from the record before, and so on back
+  // into the unknown window: half of all symbols in a file with constant quality lines), so the general case is a table look-up without a
+  // branch: tab[v] = v for a literal byte, tab[MARK | i] = window[i] -- 64 KiB per worker thread, the upper half rewritten per chunk.  Runs of
+  // sixteen symbols without a marker are packed in one go.
   static void resolve(const uint16_t* s, size_t n, const uint8_t* w, uint8_t* o) {
+    static thread_local std::unique_ptr<uint8_t[]> tab_holder;
+    if (!tab_holder) { tab_holder.reset(new uint8_t[1u << 16]); for (uint32_t v = 0; v < 0x8000u; v++) tab_holder[v] = (uint8_t)v; }
+    uint8_t* const tab = tab_holder.get();
+    memcpy(tab + MARK, w, WIN);
     size_t i = 0;
 #if defined(__SSE2__)
     const __m128i mk = _mm_set1_epi16((short)0x8000);
     for (; i + 16 <= n; i += 16) {
       const __m128i a = _mm_loadu_si128((const __m128i*)(s + i)), b = _mm_loadu_si128((const __m128i*)(s + i + 8));
       if (_mm_movemask_epi8(_mm_and_si128(_mm_or_si128(a, b), mk)) == 0) _mm_storeu_si128((__m128i*)(o + i), _mm_packus_epi16(a, b));
-      else for (size_t j = i; j < i + 16; j++) { const uint16_t v = s[j]; o[j] = v & MARK ? w[v & 0x7FFF] : (uint8_t)v; }
+      else {
+        const uint16_t* q = s + i; uint8_t* t = o + i;
+        t[0] = tab[q[0]]; t[1] = tab[q[1]]; t[2] = tab[q[2]]; t[3] = tab[q[3]]; t[4] = tab[q[4]]; t[5] = tab[q[5]]; t[6] = tab[q[6]]; t[7] = tab[q[7]];
+        t[8] = tab[q[8]]; t[9] = tab[q[9]]; t[10] = tab[q[10]]; t[11] = tab[q[11]]; t[12] = tab[q[12]]; t[13] = tab[q[13]]; t[14] = tab[q[14]]; t[15] = tab[q[15]];
+      }
     }
 #endif
-    for (; i < n; i++) { const uint16_t v = s[i]; o[i] = v & MARK ? w[v & 0x7FFF] : (uint8_t)v; }
+    for (; i < n; i++) o[i] = tab[s[i]];
   }
   uint32_t crc_of(const uint8_t* p, size_t n) const {
     if (crc_fn_) return crc_fn_(0, p, n);
@@ -523,7 +538,7 @@ class ParGzip {
     if (!n) return true;
     fold(p, n, crc_of(p, n));
     slide_window(p, n);
-    return deliver_(p, n, count_nl_((const char*)p, n));
+    return deliver_(p, n, count_nl_ ? count_nl_((const char*)p, n) : 0);
   }
   // serial decode from cur_bit_ (window known) until a block ends at or behind stop_bit / the member ends; the text is emitted
   int serial_until(uint64_t stop_bit, uint64_t* end_bit) {

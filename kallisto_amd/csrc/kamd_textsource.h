@@ -389,7 +389,7 @@ class TextSource {
       }
       return true;
     };
-    pgz::ParGzip P(map_, (size_t)fsize_, threads, chunk, deliver, count_newlines, ld.ok() ? ld.crc32_ : nullptr);
+    pgz::ParGzip P(map_, (size_t)fsize_, threads, chunk, deliver, nullptr /* the copy into the ring counts */, ld.ok() ? ld.crc32_ : nullptr);
     if (!P.run()) {
       { std::lock_guard<std::mutex> g(m_); if (stop_) return; }
       fail(path_ + ": " + (P.error().empty() ? std::string("corrupt gzip stream") : P.error()));
