@@ -78,7 +78,8 @@ struct Bits {
 };
 
 // ---- Huffman decoding tables (two levels) ----------------------------------------------------------------------------------
-struct Ent { uint16_t val; uint8_t bits; uint8_t op; };   // op: 0 literal, 1 base + (op >> 4) extra bits, 2 end of block, 3 sub-table (val = offset, op >> 4 = its bits), 15 invalid
+struct Ent { uint16_t val; uint8_t bits; uint8_t op; };   // op: 0 literal, 1 base + (op >> 4) extra bits, 2 end of block, 3 sub-table (val = offset, op >> 4 = its bits),
+                                                          // 4 two literals (val = first | second << 8, bits = both codes), 15 invalid.  (op & 11) == 0: literal(s)
 static const int LIT_PB = 11, DIST_PB = 8;
 struct Table { std::vector<Ent> e; int pb = 0; };
 
@@ -140,6 +141,21 @@ inline bool build_table(const uint8_t* lens, int n, int kind, Table* T) {
       const Ent ptr = T->e[p];
       const int sb = ptr.op >> 4;
       for (uint32_t k = hi; k < (1u << sb); k += 1u << (len - pb)) T->e[(size_t)ptr.val + k] = en;
+    }
+  }
+  // Literal/length table: where the index bits behind a literal's code hold the whole code of another literal, the entry yields both.
+  // Decoding a literal is a chain of dependent steps (look up, shift, look up ...): text whose frequent symbols have codes of two or three
+  // bits -- the bases of a FASTQ file -- takes half as many steps.  (The bits behind the first code index the table with zeros above them: an
+  // entry whose code is no longer than the bits that are known is the entry every completion of the index would give.)
+  if (kind == 0) {
+    Ent single[1u << LIT_PB];
+    memcpy(single, T->e.data(), sizeof single);
+    for (uint32_t k = 0; k < (1u << pb); k++) {
+      const Ent a = single[k];
+      if (a.op != 0 || a.bits >= pb) continue;
+      const Ent b2 = single[k >> a.bits];
+      if (b2.op != 0 || a.bits + b2.bits > pb) continue;
+      T->e[k] = Ent{(uint16_t)(a.val | (b2.val << 8)), (uint8_t)(a.bits + b2.bits), 4};
     }
   }
   return true;
@@ -261,47 +277,71 @@ inline int inflate_blocks(Bits& b, Out<T>& O, uint64_t stop_bit, uint64_t* end_b
       Bits r = b;
       size_t o = O.o;
       T* out = O.ensure(1u << 16);
-      size_t lim = O.v->size() - 320;   // room for three literals and one match (plus what the word-wise copy writes too far) is checked once per iteration
+      size_t lim = O.v->size() - 320;   // room for six literals (one more is written behind them) and one match (plus what the word-wise copy writes too far) is checked once per iteration
       int rc_in = 0;
-      for (;;) {
+      // The look-up of the next symbol is issued as early as its bits are known: behind the last literal of a run, and in front of a
+      // match's copy (the table load and the copy's loads and stores then run side by side).  A length / distance code and its extra
+      // bits leave the bit buffer in one shift; the extra bits are cut out of a saved copy, off the chain that leads to the next look-up.
+#define KAMD_PGZ_LOOKUP(E)                                                                                                           \
+      {                                                                                                                              \
+        E = lt[r.buf & ((1u << LIT_PB) - 1)];                                                                                        \
+        if (__builtin_expect(((E).op & 15) == 3, 0)) E = lt[(size_t)(E).val + ((r.buf >> LIT_PB) & ((1u << ((E).op >> 4)) - 1))];   \
+      }
+      // both bytes of a literal entry are stored, the output advances by one or two (what lies behind is overwritten by what comes next)
+#define KAMD_PGZ_LITS(E)                                                                                                             \
+      {                                                                                                                              \
+        if (ascii_only && (!is_text((E).val & 0xFF) || ((E).op == 4 && !is_text((E).val >> 8)))) { rc_in = D_ERROR; break; }        \
+        r.drop((E).bits);                                                                                                            \
+        out[o] = (T)((E).val & 0xFF); out[o + 1] = (T)((E).val >> 8);                                                               \
+        o += 1 + ((E).op >> 2);                                                                                                      \
+      }
+      r.refill();
+      Ent e;
+      KAMD_PGZ_LOOKUP(e)
+      for (;;) {   // e: the entry of the next symbol; at least 56 - 30 bits behind it in the buffer
         if (__builtin_expect(o > lim, 0)) { O.o = o; out = O.ensure(1u << 16); lim = O.v->size() - 320; }
-        r.refill();
-        Ent e = lt[r.buf & ((1u << LIT_PB) - 1)];
-        if (__builtin_expect((e.op & 15) == 3, 0)) e = lt[(size_t)e.val + ((r.buf >> LIT_PB) & ((1u << (e.op >> 4)) - 1))];
-        if ((e.op & 15) == 0) {   // literals: up to three per refill (3 x 15 bits)
-          if (ascii_only && !is_text(e.val)) { rc_in = D_ERROR; break; }
-          r.drop(e.bits); out[o++] = (T)e.val;
-          e = lt[r.buf & ((1u << LIT_PB) - 1)];
-          if (__builtin_expect((e.op & 15) == 3, 0)) e = lt[(size_t)e.val + ((r.buf >> LIT_PB) & ((1u << (e.op >> 4)) - 1))];
-          if ((e.op & 15) == 0) {
-            if (ascii_only && !is_text(e.val)) { rc_in = D_ERROR; break; }
-            r.drop(e.bits); out[o++] = (T)e.val;
-            e = lt[r.buf & ((1u << LIT_PB) - 1)];
-            if (__builtin_expect((e.op & 15) == 3, 0)) e = lt[(size_t)e.val + ((r.buf >> LIT_PB) & ((1u << (e.op >> 4)) - 1))];
-            if ((e.op & 15) == 0) {
-              if (ascii_only && !is_text(e.val)) { rc_in = D_ERROR; break; }
-              r.drop(e.bits); out[o++] = (T)e.val;
+        if ((e.op & 11) == 0) {   // literals: up to three look-ups per refill (3 x 15 bits), each one literal or two
+          KAMD_PGZ_LITS(e)
+          KAMD_PGZ_LOOKUP(e)
+          if ((e.op & 11) == 0) {
+            KAMD_PGZ_LITS(e)
+            KAMD_PGZ_LOOKUP(e)
+            if ((e.op & 11) == 0) {
+              KAMD_PGZ_LITS(e)
               if (__builtin_expect(r.over != 0, 0) && r.eof()) { rc_in = D_ERROR; break; }   // (zeros invented behind the end of the data decode to literals for ever)
+              r.refill();
+              KAMD_PGZ_LOOKUP(e)
               continue;
             }
           }
-          r.refill();
+          r.refill();   // (e was looked up in bits that were valid already: refilling only adds bits above them)
         }
         const int op = e.op & 15;
         if (__builtin_expect(op == 1, 1)) {
-          r.drop(e.bits);
-          const uint32_t len = (uint32_t)e.val + r.take(e.op >> 4);
+          const uint64_t saved_l = r.buf;
+          const int xl = e.op >> 4;
+          r.drop(e.bits + xl);
+          const uint32_t len = (uint32_t)e.val + (uint32_t)((saved_l >> e.bits) & ((1u << xl) - 1));
           if (!has_dist) { rc_in = D_ERROR; break; }
           Ent d = dt[r.buf & ((1u << DIST_PB) - 1)];
           if (__builtin_expect((d.op & 15) == 3, 0)) d = dt[(size_t)d.val + ((r.buf >> DIST_PB) & ((1u << (d.op >> 4)) - 1))];
           if ((d.op & 15) != 1) { rc_in = D_ERROR; break; }
-          r.drop(d.bits);
-          const uint32_t dist = (uint32_t)d.val + r.take(d.op >> 4);
+          const uint64_t saved_d = r.buf;
+          const int xd = d.op >> 4;
+          r.drop(d.bits + xd);
+          const uint32_t dist = (uint32_t)d.val + (uint32_t)((saved_d >> d.bits) & ((1u << xd) - 1));
           if (dist > WIN) { rc_in = D_ERROR; break; }
+          r.refill();
+          KAMD_PGZ_LOOKUP(e)
           const T* s = out + o - dist; T* t = out + o;
           constexpr uint32_t W = 8 / sizeof(T);   // elements per 64-bit word
-          if (dist >= 2 * W) {   // 16 bytes at a time, up to 2 W - 1 elements too far (the room is there)
-            for (uint32_t i = 0; i < len; i += 2 * W) { uint64_t w0, w1; memcpy(&w0, s + i, 8); memcpy(&w1, s + i + W, 8); memcpy(t + i, &w0, 8); memcpy(t + i + W, &w1, 8); }
+          if (dist >= 2 * W) {   // 16 bytes at a time, up to 4 W - 1 elements too far (the room is there)
+            // zlib turns the bases of a FASTQ file into matches of ten symbols on average: the first 32 bytes go without a look at the
+            // length (no loop whose trip count the branch predictor would have to guess), only longer matches loop
+            { uint64_t w0, w1; memcpy(&w0, s, 8); memcpy(&w1, s + W, 8); memcpy(t, &w0, 8); memcpy(t + W, &w1, 8); }
+            { uint64_t w0, w1; memcpy(&w0, s + 2 * W, 8); memcpy(&w1, s + 3 * W, 8); memcpy(t + 2 * W, &w0, 8); memcpy(t + 3 * W, &w1, 8); }
+            if (__builtin_expect(len > 4 * W, 0))
+              for (uint32_t i = 4 * W; i < len; i += 2 * W) { uint64_t w0, w1; memcpy(&w0, s + i, 8); memcpy(&w1, s + i + W, 8); memcpy(t + i, &w0, 8); memcpy(t + i + W, &w1, 8); }
           } else if (dist >= W) {
             for (uint32_t i = 0; i < len; i += W) { uint64_t w; memcpy(&w, s + i, 8); memcpy(t + i, &w, 8); }
           } else for (uint32_t i = 0; i < len; i++) t[i] = s[i];
@@ -310,6 +350,8 @@ inline int inflate_blocks(Bits& b, Out<T>& O, uint64_t stop_bit, uint64_t* end_b
         else { rc_in = D_ERROR; break; }
         if (__builtin_expect(r.over != 0, 0) && r.eof()) { rc_in = D_ERROR; break; }
       }
+#undef KAMD_PGZ_LITS
+#undef KAMD_PGZ_LOOKUP
       b = r;
       if (rc_in) return rc_in;
       O.o = o;
