@@ -302,7 +302,7 @@ def write_bgzf(src, dst, procs):
         fo.write(_bgzf_block(b""))
 
 
-def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, gz_items=2_000_000):
+def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, gz_items=4_000_000):
     """The C++ front-end (kallisto_amd/kallisto_amd_quant) from FASTQ files on disk: plain text, BGZF and gzip.  Wall-clock per stage
     from its --verbose timing lines; never part of `value`."""
     exe = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
@@ -390,7 +390,7 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         except OSError:
             out["device_parser_equals_host_parser"] = None
         out["note"] = ("kallisto_amd_quant from FASTQ on local disk (page cache warm).  plain / bgzf / gzip: host threads move bytes into pinned rings "
-                       "(pread; block-parallel inflate of BGZF and of ordinary gzip) and count newlines, lines / record check / 2-bit packing on the GPU; "
+                       "(copies out of a mapping of the file; block-parallel inflate of BGZF and of ordinary gzip) and count newlines, lines / record check / 2-bit packing on the GPU; "
                        "plain_host_parsed: the general reader (KAMD_HOST_PARSE=1).  input_to_ecs = from index-on-device to the last pseudoalignment "
                        "(reading, H2D, parsing, packing, pseudoalignment) with the input held back until the index is on the device (KAMD_FQ_NO_OVERLAP: "
                        "the input path alone); whole_run = process start to exit (index load, EM, output files).  *_overlapped: the default front-end, "

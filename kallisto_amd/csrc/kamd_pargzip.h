@@ -417,7 +417,15 @@ class ParGzip {
     const size_t ds = gzip_header(d_, n_, 0);
     if (!ds) { error_ = "not a gzip stream"; return false; }
     data_start_ = ds;
-    n_chunks_ = (n_ - ds + C_ - 1) / C_;
+    // the first chunks are an eighth of the size (two rounds of the workers): the text starts to flow after milliseconds instead of after
+    // the time a whole chunk takes -- what a small file consists of
+    small_ = C_ >= (1u << 16) ? C_ / 8 : C_;
+    n_small_ = small_ < C_ ? (size_t)(2 * T_) : 0;
+    {
+      const size_t bytes = n_ - ds;
+      if (bytes <= n_small_ * small_) n_chunks_ = (bytes + small_ - 1) / small_;
+      else n_chunks_ = n_small_ + (bytes - n_small_ * small_ + C_ - 1) / C_;
+    }
     chunks_.resize(n_chunks_);
     for (auto& c : chunks_) c.reset(new Chunk);
     for (int t = 0; t < T_; t++) workers_.emplace_back([this] { worker(); });
@@ -439,7 +447,11 @@ class ParGzip {
     RawBuf<uint8_t> bytes; size_t n_bytes = 0; uint64_t nl = 0; uint32_t crc = 0;
     bool computing = false;       // some thread is looking for the chunk's block start
   };
-  uint64_t nominal_bit(size_t k) const { return k >= n_chunks_ ? (uint64_t)n_ * 8 : ((uint64_t)data_start_ + (uint64_t)k * C_) * 8; }
+  uint64_t nominal_bit(size_t k) const {
+    if (k >= n_chunks_) return (uint64_t)n_ * 8;
+    const uint64_t off = k <= n_small_ ? (uint64_t)k * small_ : (uint64_t)n_small_ * small_ + (uint64_t)(k - n_small_) * C_;
+    return ((uint64_t)data_start_ + off) * 8;
+  }
   // start of chunk k's first block (memoised; any thread)
   uint64_t start_of(size_t k) {
     if (k >= n_chunks_) return ~0ULL;
@@ -470,7 +482,7 @@ class ParGzip {
     if (s != ~0ULL) {
       const uint64_t stop = stop_for(k);
       c.sym = take_sym();
-      c.sym.grow(WIN + 5 * C_ + (1u << 17));
+      c.sym.grow(WIN + 5 * (k < n_small_ ? small_ : C_) + (1u << 17));
       for (uint32_t i = 0; i < WIN; i++) c.sym.p[i] = (uint16_t)(MARK | i);
       Bits b(d_, n_, s);
       Out<uint16_t> O{&c.sym, WIN};
@@ -697,7 +709,7 @@ class ParGzip {
   std::function<bool(const uint8_t*, size_t, uint64_t)> deliver_;
   uint64_t (*count_nl_)(const char*, size_t);
   uint32_t (*crc_fn_)(uint32_t, const void*, size_t);
-  size_t data_start_ = 0, n_chunks_ = 0;
+  size_t data_start_ = 0, n_chunks_ = 0, small_ = 0, n_small_ = 0;
   std::vector<std::unique_ptr<Chunk>> chunks_;
   std::vector<std::thread> workers_;
   std::mutex qm_; std::condition_variable qcv_;

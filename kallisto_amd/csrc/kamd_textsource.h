@@ -494,7 +494,9 @@ class UnitCutter {
   UnitCutter(TextSource* s0, TextSource* s1, uint64_t target_bytes, uint64_t max_bytes) : n_(s1 ? 2 : 1), target_(target_bytes), max_(max_bytes) { s_[0] = s0; s_[1] = s1; }
   int next(UnitCut& u) {
     if (done_) return DONE;
-    uint64_t want = target_, t_new = 0;
+    // the first units are small (a sixteenth of the target, doubling): the copy to the device and its parser start while the readers are
+    // still at the head of the files
+    uint64_t want = std::min<uint64_t>(target_, std::max<uint64_t>(target_ / 16, 1u << 16) << std::min<uint64_t>(units_, 8)), t_new = 0;
     bool at_end = false;
     for (;;) {
       uint64_t bnd = 0;
@@ -524,6 +526,7 @@ class UnitCutter {
     for (int f = 0; f < n_; f++) { u.begin[f] = pos_[f]; pos_[f] = u.end[f]; }
     u.n_records = (t_new - lines_) / 4;
     lines_ = t_new;
+    ++units_;
     return UNIT;
   }
  private:
@@ -544,7 +547,7 @@ class UnitCutter {
   TextSource* s_[2];
   int n_;
   uint64_t target_, max_;
-  uint64_t pos_[2] = {0, 0}, lines_ = 0;
+  uint64_t pos_[2] = {0, 0}, lines_ = 0, units_ = 0;
   bool done_ = false;
 };
 
