@@ -682,35 +682,21 @@ def main():
     # ---- the same steps on the COMPACT layout of the k-mer table (kamd_core.h: four quotiented 16-byte slots per line): reported beside
     # the headline, never as the headline (the library's default layout is the wide one until this leg says otherwise) ----
     compact_leg = None
+    compact_dir = None
     if rank == 0 and world == 1 and not args.no_compact_leg and index.view.table_layout == 0:
-        # in a process of its own (tools/compact_table_leg.py): a fault in a side leg must not take the line down.  The packed reads go
-        # through /dev/shm (3 GB for config #3), the results come back as JSON + the vectors to compare.
+        # The leg runs in a process of its own (tools/compact_table_leg.py), as the very last thing before the line is printed: a fault in a
+        # side leg must not take the line down.  The packed reads go through /dev/shm (3 GB for config #3) -- written here, while they exist.
         need = n * per * (rec * 4 + 2)
         base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need + (1 << 30) else CACHE
-        shm = os.path.join(base, f"kamd_bench_{os.getpid()}")
+        compact_dir = os.path.join(base, f"kamd_bench_{os.getpid()}")
         try:
-            os.makedirs(shm, exist_ok=True)
-            words[:n * per * rec].cpu().numpy().tofile(os.path.join(shm, "words.i32"))
-            lens[:per * n].cpu().numpy().tofile(os.path.join(shm, "lens.i16"))
-            cmd = [sys.executable, os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", shm, "--items", str(n), "--read-len", str(L),
-                   "--paired", "1" if paired else "0", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)), "--device", str(local), "--loads", "0.6,0.5"]
-            pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-            if pc.returncode != 0:
-                compact_leg = [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
-            else:
-                compact_leg = json.loads(pc.stdout.decode().strip().splitlines()[-1])
-                for i, entry in enumerate(compact_leg):   # the layout must change nothing: counts, fragment lengths, and (abundances are reproducible to the bit) est_counts
-                    f = os.path.join(shm, f"result_{i}.npz")
-                    if "error" in entry or not os.path.exists(f):
-                        continue
-                    z = np.load(f)
-                    entry["identical_to_wide"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
-                                                      np.array_equal(z["flens"], res.flens) and np.array_equal(z["est_counts"], res.est_counts) and
-                                                      int(z["em_rounds"]) == res.em_rounds)
+            os.makedirs(compact_dir, exist_ok=True)
+            words[:n * per * rec].cpu().numpy().tofile(os.path.join(compact_dir, "words.i32"))
+            lens[:per * n].cpu().numpy().tofile(os.path.join(compact_dir, "lens.i16"))
         except Exception as e:   # noqa: BLE001
-            compact_leg = [{"error": str(e)[:300]}]
-        finally:
-            shutil.rmtree(shm, ignore_errors=True)
+            compact_leg = [{"error": "reads not handed over: " + str(e)[:300]}]
+            shutil.rmtree(compact_dir, ignore_errors=True)
+            compact_dir = None
 
     out = None
     if rank == 0:
@@ -890,6 +876,28 @@ def main():
             out["end_to_end"]["host"] = {"cpus_available": effective_cpus(), "processors_visible": os.cpu_count()}
         except Exception as e:
             out["end_to_end"] = {"error": str(e)}
+    if rank == 0 and compact_dir is not None:
+        log("compact k-mer table: the same steps in a child process ...")
+        try:
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", compact_dir, "--items", str(n), "--read-len", str(L),
+                   "--paired", "1" if paired else "0", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)), "--device", str(local), "--loads", "0.6,0.5"]
+            pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if pc.returncode != 0:
+                compact_leg = [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
+            else:
+                compact_leg = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+                for i, entry in enumerate(compact_leg):   # the layout must change nothing: counts, fragment lengths, and (abundances are reproducible to the bit) est_counts
+                    f = os.path.join(compact_dir, f"result_{i}.npz")
+                    if "error" in entry or not os.path.exists(f):
+                        continue
+                    z = np.load(f)
+                    entry["identical_to_wide"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
+                                                      np.array_equal(z["flens"], res.flens) and np.array_equal(z["est_counts"], res.est_counts) and
+                                                      int(z["em_rounds"]) == res.em_rounds)
+        except Exception as e:   # noqa: BLE001
+            compact_leg = [{"error": str(e)[:300]}]
+        finally:
+            shutil.rmtree(compact_dir, ignore_errors=True)
     if rank == 0:
         if multi_parity is not None:
             out["multi_rank_parity"] = multi_parity
