@@ -432,3 +432,20 @@ def test_table_layout_through_the_abi_and_the_front_end(tmp_path):
         c = api.Index(flat, table_layout="wide")
         assert c.view.table_layout == 1 and c.num_kmers == a.num_kmers
         assert subprocess.run([exe, "flatten", "-i", p, "-o", flat, "--kmer-table", "dense"], stderr=subprocess.DEVNULL).returncode != 0
+
+
+@pytest.mark.parametrize("case", ["human_pe", "dlist_pe", "mosaic_pe"])
+def test_dense_compact_table_through_the_kernels_stepper(case):
+    """A compact table as dense as the builder lets it be (keys up to six buckets from home, long runs of continue flags): kernel A's
+    one-line-per-step walk (stepper + unitig text, as k_match_v3 runs it) and the straight-line matcher give the sets of the wide table."""
+    meta, p, r1, r2 = common.load_case(case)
+    paired = r2 is not None
+    words, l16, max_len = E.pack(common.interleave(r1, r2))
+    w = _load_with_layout(p, "wide")
+    c = _load_with_layout(p, "compact", 0.9)
+    assert c.view.table_layout == 1
+    for mode in (0, 1 | 4, 1 | 2 | 4):
+        a, pa = E.tuples(w, words, l16, len(r1), paired, max_len, mode, stride=80)
+        b, pb = E.tuples(c, words, l16, len(r1), paired, max_len, mode, stride=80)
+        assert pa == pb and np.array_equal(a, b), mode
+    w.close(); c.close()
