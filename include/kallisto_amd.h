@@ -79,7 +79,7 @@ typedef struct {
   /* layout of `table` (kallisto_amd/csrc/kamd_core.h): 0 = wide, KAMD_SLOTS_PER_BUCKET slots of 20 bytes per line as described above;
    * 1 = compact, four 16-byte slots per line {tag | class, rem_f | rem_b | text position | flags}, exact by quotienting
    * (tag_q low bits of the k-mer's hash, its bits above 32 and the displacement from the home bucket; tag_w bits in all, the
-   * displacement at bit tag_dsh).  The D-list table is always wide.  The layout is chosen when the index is loaded:
+   * displacement in bits [tag_dsh, tag_w): three or four of them, all ones = empty slot).  The D-list table is always wide.  The layout is chosen when the index is loaded:
    * KAMD_TABLE_LAYOUT=wide (default) | compact | auto (compact when its fields fit), KAMD_TABLE_LOAD = load factor of the compact
    * table (default 0.6; the wide one is built at 0.5).  slot index = b * slots_per_bucket + j. */
   uint32_t table_layout, slots_per_bucket, tag_q, tag_dsh, tag_w;

@@ -54,15 +54,15 @@ namespace kamd {
 // q bits of the hash), q = ceil(log2(2^32 / n_buckets)), identify a key within its home bucket.
 //   slot    = {w0, w1}; bucket = slots 0..3 = words {w0, w1} x 4
 //   w0      = tag[tagw-1:0] | uec << tagw,   tag = hash & (2^q - 1) | (key >> 32) << q | displacement << (q + max(0, 2k - 32))
-//             displacement (3 bits) = buckets between the slot's bucket and the key's home, 0..6; 7 marks an empty slot (w0 =
-//             all ones).  A lookup in bucket home + d compares with the tag of displacement d: one 64-bit compare per slot.
+//             displacement (4 bits when the class ids leave room for them, else 3) = buckets between the slot's bucket and the key's
+//             home, 0..14 (0..6); all ones marks an empty slot (w0 = all ones).  A lookup in bucket home + d compares with the tag of
+//             displacement d: one 64-bit compare per slot.
 //   w1      = rem_f[15:0] | rem_b[31:16] | gpos[61:32] | fwd_is_canon[62] | continue flag of the bucket[63] (slot 0 only)
 //   The builder refuses the layout (and the loader falls back to the wide one unless it was asked for by name) when a field
 //   does not fit: tagw + bits(uec) <= 64, text positions < 2^30.
 // ---------------------------------------------------------------------------------------------------------------
 static const int LAYOUT_WIDE = 0, LAYOUT_COMPACT = 1;
 static const int COMPACT_SLOTS = 4;
-static const uint32_t COMPACT_MAX_DISP = 6;     // displacement 7 = empty
 static const uint64_t COMPACT_CONT = 1ULL << 63, COMPACT_FWD = 1ULL << 62;
 static const uint32_t COMPACT_GPOS_MASK = 0x3FFFFFFFu;
 static const uint64_t KEY_MASK = (1ULL << 62) - 1;
@@ -200,6 +200,8 @@ struct Table {
   // layout of `slots` (the D-list table is always wide): LAYOUT_COMPACT with its shifts -- q, shift of the displacement, width of the tag
   uint8_t layout = LAYOUT_WIDE, q = 0, dsh = 0, tagw = 0;
 };
+// compact layout: the farthest a key may lie from its home bucket (the displacement field's all-ones value marks an empty slot)
+KAMD_HD uint32_t compact_max_disp(const Table& t) { return (1u << (t.tagw - t.dsh)) - 2u; }
 struct Probe {
   bool found;
   bool strand;      // read k-mer equals the unitig's forward text (const_UnitigMap::strand)
@@ -276,10 +278,11 @@ KAMD_HD Probe probe_table_compact(const Table& t, uint64_t canon, bool is_fwd_ca
   Probe p;
   const uint32_t h = kmer_hash32(canon);
   const uint64_t home = bucket_of_hash(h, t.n_buckets);
+  const uint32_t max_disp = compact_max_disp(t);
   for (uint32_t d = 0;; d++) {
     const BucketLine L = load_bucket(t.slots, home + d);
     if (bucket_reads) ++*bucket_reads;
-    if (match_bucket_compact(L, t, compact_tag(t, canon, h, d), is_fwd_canon, home + d, p) != BUCKET_CONTINUE || d == COMPACT_MAX_DISP) return p;
+    if (match_bucket_compact(L, t, compact_tag(t, canon, h, d), is_fwd_canon, home + d, p) != BUCKET_CONTINUE || d == max_disp) return p;
   }
 }
 KAMD_HD Probe probe_table(const Table& t, uint64_t canon, bool is_fwd_canon, uint32_t* bucket_reads) {

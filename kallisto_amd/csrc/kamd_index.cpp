@@ -250,7 +250,7 @@ uint32_t bits_of(uint64_t n) { uint32_t b = 0; while (b < 64 && (n >> b)) ++b; r
 bool compact_shifts(int k, uint64_t nb, uint64_t n_uec, uint64_t text_bases, uint32_t* q, uint32_t* dsh, uint32_t* w) {
   *q = kamd::compact_q_of(nb);
   *dsh = *q + (uint32_t)std::max(0, 2 * k - 32);
-  *w = *dsh + 3;
+  *w = *dsh + (*dsh + 4 + bits_of(n_uec) <= 64 ? 4 : 3);   // the displacement: four bits when the class ids leave room for them
   return *w + bits_of(n_uec) <= 64 && text_bases <= kamd::COMPACT_GPOS_MASK;
 }
 bool layout_is_consistent(const kamd_index& x) {
@@ -666,8 +666,9 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   uint64_t cursor = 0;
   uint32_t tag_q = 0, tag_dsh = 0, tag_w = 0;
   for (;;) {
-    // the compact layout must hold the class ids and the text positions beside the tag, and a key at most COMPACT_MAX_DISP buckets from
-    // its home: otherwise the wide layout (auto), or a larger table (an eighth more buckets) and the count pass again
+    // the compact layout must hold the class ids and the text positions beside the tag, and a key no farther from its home than the
+    // displacement field can say (14 or 6 buckets): otherwise the wide layout (auto), or a larger table (a sixteenth more buckets) and the
+    // count pass again
     auto recount = [&] { fill.resize(nb + 1); fill_atomic = reinterpret_cast<std::atomic<uint32_t>*>(fill.data()); count_pass(); };
     if (compact && !compact_shifts(k, nb, ix->uec_ec.size(), ix->text_bases, &tag_q, &tag_dsh, &tag_w)) {
       if (want_compact == KAMD_TABLE_COMPACT) return kamd::fail(-3, "index: the compact k-mer table cannot hold this index (class ids / text positions too wide); use KAMD_TABLE_LAYOUT=wide or auto");
@@ -683,8 +684,8 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
       cursor += fill[b];
       if (fill[b]) max_disp = std::max(max_disp, (cursor - 1) / S - b);
     }
-    if (!compact || max_disp <= kamd::COMPACT_MAX_DISP) break;
-    nb += nb / 8 + 1;
+    if (!compact || max_disp <= (1u << (tag_w - tag_dsh)) - 2u) break;
+    nb += nb / 16 + 1;
     recount();
   }
   ix->n_buckets = nb;
@@ -705,7 +706,7 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   parallel_range(total_buckets, [&](uint64_t a, uint64_t b) {
     for (uint64_t i = a; i < b; i++) {
       uint64_t* w = ix->table.data() + 8 * i;
-      if (compact) { for (uint64_t j = 0; j < 4; j++) { w[2 * j] = ~0ULL; w[2 * j + 1] = 0; } }   // displacement 7 = empty
+      if (compact) { for (uint64_t j = 0; j < 4; j++) { w[2 * j] = ~0ULL; w[2 * j + 1] = 0; } }   // displacement all ones = empty
       else {
         for (uint64_t j = 0; j < S; j++) w[j] = kamd::KEY_EMPTY;
         for (uint64_t j = S; j < 8; j++) w[j] = 0;

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
         else { ms.text_tried = true; feed = false; }
       } else if (compact) {
         if (kamd::match_bucket_compact(bl, pt, kamd::compact_tag(pt, canon, khash, ms.disp), fc, bucket, p) == kamd::BUCKET_CONTINUE &&
-            ms.disp < kamd::COMPACT_MAX_DISP) { ++ms.disp; feed = false; }
+            ms.disp < kamd::compact_max_disp(pt)) { ++ms.disp; feed = false; }
       } else if (kamd::match_bucket(bl, canon, fc, bucket, p) == kamd::BUCKET_CONTINUE) { ++ms.disp; feed = false; }
       if (feed) {
         if (!DL || ms.phase != kamd::PH_DLIST) ++probes;   // dbg.find calls of match(); the D-list scan is counted as bucket reads only

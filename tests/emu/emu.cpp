@@ -106,7 +106,7 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
             const uint64_t b = bucket_of_hash(h, pt.n_buckets) + st.disp;
             if (pt.layout == LAYOUT_COMPACT) {   // (the D-list table is wide: phase_table hands it out with layout 0)
               if (match_bucket_compact(load_bucket(pt.slots, b), pt, compact_tag(pt, canon, h, st.disp), fc, b, p) == BUCKET_CONTINUE &&
-                  st.disp < COMPACT_MAX_DISP) { ++st.disp; continue; }
+                  st.disp < compact_max_disp(pt)) { ++st.disp; continue; }
             } else if (match_bucket(load_bucket(pt.slots, b), canon, fc, b, p) == BUCKET_CONTINUE) { ++st.disp; continue; }
             if (st.phase != PH_DLIST) ++*probes;
           } else {

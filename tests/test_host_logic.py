@@ -107,15 +107,16 @@ def _check_compact_table(case, v, table):
     assert v.slots_per_bucket == 4
     q, dsh, tw = int(v.tag_q), int(v.tag_dsh), int(v.tag_w)
     kk = int(v.k)
-    assert dsh == q + max(0, 2 * kk - 32) and tw == dsh + 3
+    db = tw - dsh   # bits of the displacement: four when the class ids leave room for them
+    assert dsh == q + max(0, 2 * kk - 32) and db == (4 if dsh + 4 + max(int(v.n_uec), 1).bit_length() <= 64 else 3)
     span = -(-(1 << 32) // int(v.n_buckets))
     assert (1 << q) >= span and (q == 0 or (1 << (q - 1)) < span)
     w0, w1 = table[:, 0::2], table[:, 1::2]
-    disp = (w0 >> np.uint64(dsh)) & np.uint64(7)
-    used = disp != np.uint64(7)
+    disp = (w0 >> np.uint64(dsh)) & np.uint64((1 << db) - 1)
+    used = disp != np.uint64((1 << db) - 1)
     assert np.all(w0[~used] == np.uint64(0xFFFFFFFFFFFFFFFF))
     assert int(used.sum()) == v.n_kmers
-    assert int(disp[used].max(initial=0)) <= 6
+    assert int(disp[used].max(initial=0)) <= (1 << db) - 2
     assert int((w0[used] >> np.uint64(tw)).max(initial=0)) < v.n_uec
     # a bucket whose continue flag is set is full, and the flag sits in slot 0 only
     cont = (w1[:, 0] >> np.uint64(63)) != 0
@@ -137,7 +138,7 @@ def _check_compact_table(case, v, table):
         h = _kmer_hash32(canon)
         home = (h * int(v.n_buckets)) >> 32
         d = int(b) - home
-        assert 0 <= d <= 6
+        assert 0 <= d <= (1 << db) - 2
         assert (a & ((1 << tw) - 1)) == ((h & ((1 << q) - 1)) | ((canon >> 32) << q) | (d << dsh)), (case, b, j)
         # reachable: every bucket from the home up to the one before carries the continue flag
         assert all(cont[home + i] for i in range(d)), (case, b, j)
@@ -382,8 +383,8 @@ def test_flattened_index_file_round_trip(case, layout, tmp_path, monkeypatch):
 @pytest.mark.parametrize("load", [0.3, 0.75, 0.9])
 @pytest.mark.parametrize("case", ["human_pe", "dlist_pe"])
 def test_compact_table_at_other_loads(case, load):
-    """KAMD_TABLE_LOAD: a sparse table, and dense ones where keys sit several buckets from home -- beyond six the builder takes a larger
-    table and counts again (a slot's displacement field holds 0..6).  Every k-mer is still found with its own payload."""
+    """KAMD_TABLE_LOAD: a sparse table, and dense ones where keys sit several buckets from home -- beyond what the displacement field
+    can say (14 buckets, or 6 when the class ids leave it three bits) the builder takes a larger table and counts again.  Every k-mer is still found with its own payload."""
     import ctypes as C
     e = _load_with_layout(common.load_case(case)[1], "compact", load)
     v = e.view
@@ -436,7 +437,7 @@ def test_table_layout_through_the_abi_and_the_front_end(tmp_path):
 
 @pytest.mark.parametrize("case", ["human_pe", "dlist_pe", "mosaic_pe"])
 def test_dense_compact_table_through_the_kernels_stepper(case):
-    """A compact table as dense as the builder lets it be (keys up to six buckets from home, long runs of continue flags): kernel A's
+    """A compact table as dense as the builder lets it be (keys many buckets from home, long runs of continue flags): kernel A's
     one-line-per-step walk (stepper + unitig text, as k_match_v3 runs it) and the straight-line matcher give the sets of the wide table."""
     meta, p, r1, r2 = common.load_case(case)
     paired = r2 is not None
