@@ -880,7 +880,7 @@ def main():
         log("compact k-mer table: the same steps in a child process ...")
         try:
             cmd = [sys.executable, os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", compact_dir, "--items", str(n), "--read-len", str(L),
-                   "--paired", "1" if paired else "0", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)), "--device", str(local), "--loads", "0.6,0.5"]
+                   "--paired", "1" if paired else "0", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)), "--device", str(local), "--loads", "0.6,0.5,0.7"]
             pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             if pc.returncode != 0:
                 compact_leg = [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
@@ -908,7 +908,7 @@ def main():
         if compact_leg is not None:
             out["kmer_table_compact"] = {"legs": compact_leg,
                                          "note": "the same steps with KAMD_TABLE_LAYOUT=compact (four exact 16-byte slots per 64-byte line by quotienting, "
-                                                 "DESIGN.md section 2) at two load factors; a side measurement -- `value` above is the default (wide) layout"}
+                                                 "DESIGN.md section 2) at three load factors; a side measurement -- `value` above is the default (wide) layout"}
         print(json.dumps(out), flush=True)
     if world > 1:
         # tear down in order while everything is alive: the library's communicator (ncclCommDestroy), the context, then torch's

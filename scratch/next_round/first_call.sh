@@ -11,11 +11,11 @@ export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gpu_cli.py -x -q -k "compact or bound" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
 FAST="--steps 5 --warmup 2 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg"
 timeout 200 python bench.py $FAST > $O/c3_wide.json 2> $O/c3_wide.err
-for load in 0.5 0.6 0.65; do
+for load in 0.5 0.6 0.7; do
   timeout 200 python bench.py $FAST --table-layout compact --table-load $load > $O/c3_compact_$load.json 2> $O/c3_compact_$load.err
 done
 timeout 600 python bench.py $FAST --genes 46000 > $O/gc_wide.json 2> $O/gc_wide.err
-for load in 0.6 0.5; do
+for load in 0.6 0.5 0.7 0.75; do
   timeout 300 python bench.py $FAST --genes 46000 --table-layout compact --table-load $load > $O/gc_compact_$load.json 2> $O/gc_compact_$load.err
 done
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_compact -- python /root/repo/bench.py $FAST --steps 2 --warmup 1 --table-layout compact > /dev/null 2>&1; cp $(find /tmp/prof_compact -name "*kernel_stats.csv" | head -1) /root/repo/$O/compact_kernel_stats.csv 2>/dev/null )
