@@ -295,6 +295,8 @@ void usage_tcc() {
             << "-f, --fragment-file=FILE      File containing fragment length distribution(s) (flens.txt)\n"
             << "-l, --fragment-length=DOUBLE  Estimated average fragment length\n"
             << "-s, --sd=DOUBLE               Estimated standard deviation of fragment length\n"
+            << "-g, --genemap=FILE            File for mapping transcripts to genes (transcript, gene[, common name] per line):\n"
+            << "                              gene-level sums beside every output (matrix.abundance.gene[.tpm].mtx, genes.txt, abundance.gene*.tsv)\n"
             << "    --matrix-to-files         Also write abundance_N.tsv for every row of the matrix\n"
             << "-b, --bootstrap-samples=INT   Number of bootstrap samples (default: 0; plaintext, with --matrix-to-files)\n"
             << "    --seed=INT                Seed for the bootstrap sampling (default: 42)\n"
@@ -314,7 +316,7 @@ void write_sparse(const std::string& path, const std::vector<std::vector<std::pa
 
 int tcc_main(int argc, char** argv) {
   if (argc == 2) { usage_tcc(); return 0; }
-  std::string index, output, ec_file, fld_file, tcc_file, val;
+  std::string index, output, ec_file, fld_file, tcc_file, genemap, val;
   double fld = 0.0, sd = 0.0;
   int bootstrap = 0, threads = 1;
   uint64_t seed = 42;
@@ -333,8 +335,9 @@ int tcc_main(int argc, char** argv) {
     else if (take(a, "-t", "--threads", i, argc, argv, val)) threads = atoi(val.c_str());
     else if (a == "--matrix-to-files") matrix_to_files = true;
     else if (a == "--plaintext") {}
-    else if (a == "--matrix-to-directories" || a == "-T" || a == "--txnames" || a == "--long" || a == "-P" || a == "--platform" || a == "-g" ||
-             a == "--genemap" || a == "-G" || a == "--gtf" || a == "-p" || a == "--priors") {
+    else if (take(a, "-g", "--genemap", i, argc, argv, val)) genemap = val;
+    else if (a == "--matrix-to-directories" || a == "-T" || a == "--txnames" || a == "--long" || a == "-P" || a == "--platform" ||
+             a == "-G" || a == "--gtf" || a.rfind("--gtf=", 0) == 0 || a == "-p" || a == "--priors" || a.rfind("--priors=", 0) == 0) {
       std::cerr << "Error: option " << a << " is outside the GPU quant-tcc path; use the reference kallisto for it" << std::endl; return 1;
     } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage_tcc(); return 1; }
     else pos.push_back(a);
@@ -349,6 +352,7 @@ int tcc_main(int argc, char** argv) {
   else { tcc_file = pos[0]; if (stat(tcc_file.c_str(), &st) != 0) { std::cerr << "Error: transcript-compatibility counts file not found " << tcc_file << std::endl; ok = false; } }
   if (ec_file.empty()) { std::cerr << "Error: equivalence class file must be supplied (-e)" << std::endl; ok = false; }
   else if (stat(ec_file.c_str(), &st) != 0) { std::cerr << "Error: equivalence class file not found " << ec_file << std::endl; ok = false; }
+  if (!genemap.empty() && stat(genemap.c_str(), &st) != 0) { std::cerr << "Error: file for mapping transcripts to genes not found " << genemap << std::endl; ok = false; }
   if (!fld_file.empty() && stat(fld_file.c_str(), &st) != 0) { std::cerr << "Error: fragment length distribution file not found " << fld_file << std::endl; ok = false; }
   if ((fld != 0.0 || sd != 0.0) && !fld_file.empty()) { std::cerr << "Error: cannot supply mean or sd while also supplying a fragment length distribution file" << std::endl; ok = false; }
   if ((fld != 0.0 && sd == 0.0) || (sd != 0.0 && fld == 0.0)) { std::cerr << "Error: cannot supply mean/sd without supplying both -l and -s" << std::endl; ok = false; }
@@ -469,6 +473,17 @@ int tcc_main(int argc, char** argv) {
   }
 
   { std::ofstream of(output + "/transcripts.txt"); for (uint64_t t = 0; t < T; t++) of << kamd_index_target_name(idx, t) << "\n"; }
+  // -g: transcripts -> genes (Transcriptome::parseGeneMap, src/GeneModel.cpp:580-632); gene-level sums beside every transcript-level output
+  GeneMap genes;
+  const bool gene_level = !genemap.empty();
+  if (gene_level) {
+    std::vector<std::string> names(T);
+    for (uint64_t t = 0; t < T; t++) names[t] = kamd_index_target_name(idx, t);
+    std::string err;
+    if (!parse_genemap(genemap, names, &genes, &err)) { std::cerr << err << std::endl; return 1; }
+  }
+  std::vector<std::vector<std::pair<int32_t, double>>> gab_m(gene_level ? rows.size() : 0), gtpm_m(gene_level ? rows.size() : 0);
+  std::vector<double> gc, gc_tpm;
   kamd_ctx* ctx = nullptr;
   KX(kamd_ctx_create(0, nullptr, &ctx));
   KX(kamd_ec_upload(ctx, ec_off.data(), ec_ids.data(), nullptr, n_ecs));   // the EC matrix goes to the device once
@@ -508,12 +523,16 @@ int tcc_main(int argc, char** argv) {
       KX(kamd_em_run(ctx, nullptr, nullptr, nullptr, nullptr, 0, eff.data(), T, 10000, 50, alpha.data(), abz.data(), &rounds));
     } else std::fill(alpha.begin(), alpha.end(), 0.0);   // nothing to distribute: the EM's result is all zeros
     kamd_counts_to_tpm(alpha.data(), eff.data(), T, tpm.data());
+    if (gene_level) gene_sums(genes, alpha, tpm, &gc, &gc_tpm);
     if (is_matrix) {
       for (uint64_t t = 0; t < T; t++)
         if (alpha[t] > 0.0) { ab_m[id].push_back({(int32_t)t, alpha[t]}); tpm_m[id].push_back({(int32_t)t, tpm[t]}); if (calc_eff) eff_m[id].push_back({(int32_t)t, eff[t]}); }
+      if (gene_level)
+        for (size_t g = 0; g < gc.size(); g++) if (gc[g] > 0.0) { gab_m[id].push_back({(int32_t)g, gc[g]}); gtpm_m[id].push_back({(int32_t)g, gc_tpm[g]}); }
       if (matrix_to_files) {
         const std::string suffix = "_" + std::to_string(id + 1);
         write_abundance(output + "/abundance" + suffix + ".tsv", idx, vt, alpha, eff);
+        if (gene_level) write_abundance_gene(output + "/abundance.gene" + suffix + ".tsv", genes, gc, gc_tpm);
         if (bootstrap > 0) {
           std::vector<uint64_t> seeds(bootstrap);
           kamd_bootstrap_seeds(seed, bootstrap, seeds.data());
@@ -527,6 +546,7 @@ int tcc_main(int argc, char** argv) {
       }
     } else {
       write_abundance(output + "/abundance.tsv", idx, vt, alpha, eff);
+      if (gene_level) write_abundance_gene(output + "/abundance.gene.tsv", genes, gc, gc_tpm);
       if (bootstrap > 0) {
         std::vector<uint64_t> seeds(bootstrap);
         kamd_bootstrap_seeds(seed, bootstrap, seeds.data());
@@ -544,6 +564,11 @@ int tcc_main(int argc, char** argv) {
     write_sparse(output + "/matrix.abundance.mtx", ab_m, T);
     write_sparse(output + "/matrix.abundance.tpm.mtx", tpm_m, T);
     if (calc_eff) write_sparse(output + "/matrix.efflens.mtx", eff_m, T);
+    if (gene_level) {
+      write_sparse(output + "/matrix.abundance.gene.mtx", gab_m, genes.name.size());
+      write_sparse(output + "/matrix.abundance.gene.tpm.mtx", gtpm_m, genes.name.size());
+      write_gene_names(output + "/genes.txt", genes);
+    }
   }
   if (calc_eff) {
     { std::ofstream of(output + "/matrix.fld.tsv"); for (size_t j = 0; j < fld_m.size(); j++) of << j << "\t" << fld_m[j].first << "\t" << fld_m[j].second << "\n"; }   // writeFLD

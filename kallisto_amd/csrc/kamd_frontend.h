@@ -33,6 +33,7 @@
 #include "../../include/kallisto_amd.h"
 #include "kamd_fastq.h"
 #include "kamd_textsource.h"
+#include "kamd_genes.h"
 
 namespace kamd_fe {
 using namespace kamd_io;

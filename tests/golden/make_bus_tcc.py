@@ -42,7 +42,23 @@ CASES = {
     "yeast_se_noeff": ("yeast_se", [0.0, 1.0], ["--rf-stranded"], []),
     "mosaic_pe_union": ("mosaic_pe", [0.0, 0.5, 1.0], ["--paired", "--union"], []),
     "dlist_pe_nojump": ("dlist_pe", [0.0, 0.5, 1.0], ["--paired", "--no-jump"], []),
+    # -g: gene-level sums ("@file" = a file of the case's directory: genemap.txt, written below)
+    "human_pe_genes": ("human_pe", [0.0, 0.6, 1.0], ["--paired"], ["--matrix-to-files", "-g", "@genemap.txt"]),
 }
+
+
+def write_genemap(path, names):
+    """transcript -> gene: three transcripts per gene, every other gene with a common name, every tenth transcript in no gene, the lines
+    not in transcript order (genes are numbered in order of first appearance in the file)."""
+    lines = []
+    for i, n in enumerate(names):
+        if i % 10 == 9:
+            continue
+        g = i // 3
+        lines.append("%s\tG%04d%s" % (n, g, "\tgene%d" % g if g % 2 == 0 else ""))
+    lines = lines[len(lines) // 2:] + lines[:len(lines) // 2]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n\n")
 
 
 def write_fastq(path, reads):
@@ -149,11 +165,14 @@ def main():
             n_samples = len(cuts) - 1
             write_tcc(os.path.join(dst, "tcc.mtx"), rec2, len(used), n_samples)
             tcc_out = os.path.join(dst, "tcc_out")
+            if "@genemap.txt" in tcc_flags:
+                write_genemap(os.path.join(dst, "genemap.txt"), [l.strip() for l in open(os.path.join(bus_out, "transcripts.txt"))])
+            tcc_run_flags = [os.path.join(dst, a[1:]) if a.startswith("@") else a for a in tcc_flags]
             fld_args = []
             if "-l" not in tcc_flags and paired:
                 fld_args = ["-f", os.path.join(dst, "flens.txt")]
             p = subprocess.run([KALLISTO, "quant-tcc", "-t", "1", "-i", idx, "-e", os.path.join(dst, "matrix.ec"), "-o", tcc_out, *fld_args,
-                                *tcc_flags, os.path.join(dst, "tcc.mtx")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                                *tcc_run_flags, os.path.join(dst, "tcc.mtx")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert p.returncode == 0, p.stderr.decode()
         json.dump({"fixture": fixture, "cuts": cuts, "bus_flags": bus_flags, "tcc_flags": tcc_flags, "bus_header": list(hdr),
                    "n_records_reference": int(len(rec)), "fld_file": bool(fld_args),

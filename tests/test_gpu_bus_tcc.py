@@ -127,17 +127,19 @@ def test_bus_bulk_matches_reference(case, tmp_path):
         assert Counter((bc, ecs1[e]) for bc, e in k1) == Counter({(bc, ecs[e]): int(n) for (bc, e), n in zip(keys, rec["count"].tolist())})
 
 
-def _run_tcc(idx, ec, tcc, meta, gold, out):
+def _run_tcc(idx, ec, tcc, meta, gold, out, case_dir=None):
     fld = ["-f", os.path.join(gold, "flens.txt")] if meta["fld_file"] else []
-    p = subprocess.run([EXE, "quant-tcc", "-i", idx, "-e", ec, "-o", out, *fld, *meta["tcc_flags"], tcc], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    flags = [os.path.join(case_dir or gold, a[1:]) if a.startswith("@") else a for a in meta["tcc_flags"]]   # "@file": a file of the case's directory (-g genemap)
+    p = subprocess.run([EXE, "quant-tcc", "-i", idx, "-e", ec, "-o", out, *fld, *flags, tcc], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()
 
 
 def _compare_tcc_out(out, ref, what):
     assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
-    for fn in ("matrix.abundance.mtx", "matrix.abundance.tpm.mtx"):
-        common.assert_abundance_close(_mtx(os.path.join(out, fn)), _mtx(os.path.join(ref, fn)), f"{what} {fn}", rel=1e-4, floor=1e-5)
-    for fn in ("matrix.fld.tsv", "transcript_lengths.txt", "transcripts.txt"):
+    for fn in ("matrix.abundance.mtx", "matrix.abundance.tpm.mtx", "matrix.abundance.gene.mtx", "matrix.abundance.gene.tpm.mtx"):
+        if os.path.exists(os.path.join(ref, fn)):   # (the gene-level pair: only with -g)
+            common.assert_abundance_close(_mtx(os.path.join(out, fn)), _mtx(os.path.join(ref, fn)), f"{what} {fn}", rel=1e-4, floor=1e-5)
+    for fn in ("matrix.fld.tsv", "transcript_lengths.txt", "transcripts.txt", "genes.txt"):
         if os.path.exists(os.path.join(ref, fn)):
             assert open(os.path.join(out, fn)).read() == open(os.path.join(ref, fn)).read(), fn
     if os.path.exists(os.path.join(ref, "matrix.efflens.mtx")):
@@ -149,9 +151,10 @@ def _compare_tcc_out(out, ref, what):
         rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(out, fn))]
         grows = [l.rstrip("\n").split("\t") for l in open(os.path.join(ref, fn))]
         assert rows[0] == grows[0] and len(rows) == len(grows)
+        gene_file = ".gene" in fn   # gene_id, gene_name, est_counts, tpm  instead of  target_id, length, eff_length, est_counts, tpm
         for a, b in zip(rows[1:], grows[1:]):
-            assert a[:3] == b[:3], (fn, a, b)
-        for col, name in ((3, "est_counts"), (4, "tpm")):
+            assert a[:2 if gene_file else 3] == b[:2 if gene_file else 3], (fn, a, b)
+        for col, name in ((2, "est_counts"), (3, "tpm")) if gene_file else ((3, "est_counts"), (4, "tpm")):
             common.assert_abundance_close(np.array([float(r[col]) for r in rows[1:]]), np.array([float(r[col]) for r in grows[1:]]),
                                           f"{what} {fn} {name}", rel=1e-4, floor=1e-5)
 
@@ -187,7 +190,7 @@ def test_bus_then_quant_tcc_chain(case, tmp_path):
     gold2 = gold
     if meta["fld_file"]:                                   # the chain uses its own flens.txt (identical to the reference's, see above)
         gold2 = bus
-    _run_tcc(idx, os.path.join(bus, "matrix.ec"), tcc, meta2, gold2, out)
+    _run_tcc(idx, os.path.join(bus, "matrix.ec"), tcc, meta2, gold2, out, case_dir=gold)
     _compare_tcc_out(out, os.path.join(gold, "tcc_out"), case + " chain")
 
 

@@ -450,3 +450,37 @@ def test_dense_compact_table_through_the_kernels_stepper(case):
         b, pb = E.tuples(c, words, l16, len(r1), paired, max_len, mode, stride=80)
         assert pa == pb and np.array_equal(a, b), mode
     w.close(); c.close()
+
+
+def test_gene_level_outputs_of_quant_tcc(tmp_path):
+    """`quant-tcc -g` on the host side (kamd_genes.h through tests/emu): the mapping file parsed like Transcriptome::parseGeneMap (genes numbered
+    in order of first appearance, transcripts without a line in no gene), sums in transcript order, the reference's two writers.  Input: the
+    reference's own transcript-level abundance_1.tsv of the golden case; expected: its abundance.gene_1.tsv and genes.txt."""
+    gold = os.path.join(common.GOLDEN, "bus_tcc", "human_pe_genes")
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(gold, "tcc_out", "abundance_1.tsv"))][1:]
+    names = [r[0] for r in rows]
+    alpha = np.array([float(r[3]) for r in rows]); tpm = np.array([float(r[4]) for r in rows])
+    L = E.lib()
+    L.fe_gene_outputs.restype = C.c_int64
+    tsv, nm = str(tmp_path / "g.tsv"), str(tmp_path / "genes.txt")
+    trg = np.zeros(len(names), np.int32)
+    err = C.create_string_buffer(512)
+    ng = L.fe_gene_outputs(os.path.join(gold, "genemap.txt").encode(), "\n".join(names).encode(), C.c_uint64(len(names)), alpha.ctypes.data_as(C.c_void_p),
+                           tpm.ctypes.data_as(C.c_void_p), tsv.encode(), nm.encode(), trg.ctypes.data_as(C.c_void_p), err, C.c_uint64(512))
+    assert ng == 223, err.value
+    assert open(nm).read() == open(os.path.join(gold, "tcc_out", "genes.txt")).read()
+    got = [l.rstrip("\n").split("\t") for l in open(tsv)]
+    want = [l.rstrip("\n").split("\t") for l in open(os.path.join(gold, "tcc_out", "abundance.gene_1.tsv"))]
+    assert got[0] == want[0] and [g[:2] for g in got] == [w[:2] for w in want]
+    for col in (2, 3):   # the inputs were printed with six digits: sums agree to five
+        a, b = np.array([float(g[col]) for g in got[1:]]), np.array([float(w[col]) for w in want[1:]])
+        assert np.all(np.abs(a - b) <= 2e-5 * np.maximum(np.abs(b), 1e-3)), col
+    assert (trg[9::10] == -1).all() and (trg >= -1).all() and trg.max() == ng - 1   # every tenth transcript is in no gene
+    # the reference's two errors
+    bad = str(tmp_path / "bad.txt")
+    open(bad, "w").write(names[0] + "\n")
+    assert L.fe_gene_outputs(bad.encode(), "\n".join(names).encode(), C.c_uint64(len(names)), alpha.ctypes.data_as(C.c_void_p), tpm.ctypes.data_as(C.c_void_p),
+                             tsv.encode(), nm.encode(), None, err, C.c_uint64(512)) == -1 and b"No gene associated with transcript" in err.value
+    open(bad, "w").write("no_such_transcript\tG1\n")
+    assert L.fe_gene_outputs(bad.encode(), "\n".join(names).encode(), C.c_uint64(len(names)), alpha.ctypes.data_as(C.c_void_p), tpm.ctypes.data_as(C.c_void_p),
+                             tsv.encode(), nm.encode(), None, err, C.c_uint64(512)) == -1 and b"Invalid transcript" in err.value
