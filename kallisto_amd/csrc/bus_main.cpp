@@ -298,6 +298,7 @@ void usage_tcc() {
             << "-g, --genemap=FILE            File for mapping transcripts to genes (transcript, gene[, common name] per line):\n"
             << "                              gene-level sums beside every output (matrix.abundance.gene[.tpm].mtx, genes.txt, abundance.gene*.tsv)\n"
             << "    --matrix-to-files         Also write abundance_N.tsv for every row of the matrix\n"
+            << "    --matrix-to-directories   ... as abundance_N/abundance.tsv, a directory per row\n"
             << "-b, --bootstrap-samples=INT   Number of bootstrap samples (default: 0; plaintext, with --matrix-to-files)\n"
             << "    --seed=INT                Seed for the bootstrap sampling (default: 42)\n"
             << "    --plaintext               Accepted (all output is plaintext)\n"
@@ -320,7 +321,7 @@ int tcc_main(int argc, char** argv) {
   double fld = 0.0, sd = 0.0;
   int bootstrap = 0, threads = 1;
   uint64_t seed = 42;
-  bool matrix_to_files = false;
+  bool matrix_to_files = false, matrix_to_dirs = false;
   std::vector<std::string> pos;
   for (int i = 2; i < argc; i++) {
     std::string a = argv[i];
@@ -334,9 +335,10 @@ int tcc_main(int argc, char** argv) {
     else if (take(a, "-d", "--seed", i, argc, argv, val)) seed = strtoull(val.c_str(), nullptr, 10);
     else if (take(a, "-t", "--threads", i, argc, argv, val)) threads = atoi(val.c_str());
     else if (a == "--matrix-to-files") matrix_to_files = true;
+    else if (a == "--matrix-to-directories") matrix_to_files = matrix_to_dirs = true;   // (implies the files, src/main.cpp:499-502)
     else if (a == "--plaintext") {}
     else if (take(a, "-g", "--genemap", i, argc, argv, val)) genemap = val;
-    else if (a == "--matrix-to-directories" || a == "-T" || a == "--txnames" || a == "--long" || a == "-P" || a == "--platform" ||
+    else if (a == "-T" || a == "--txnames" || a == "--long" || a == "-P" || a == "--platform" ||
              a == "-G" || a == "--gtf" || a.rfind("--gtf=", 0) == 0 || a == "-p" || a == "--priors" || a.rfind("--priors=", 0) == 0) {
       std::cerr << "Error: option " << a << " is outside the GPU quant-tcc path; use the reference kallisto for it" << std::endl; return 1;
     } else if (!a.empty() && a[0] == '-') { std::cerr << "Error: unknown option " << a << std::endl; usage_tcc(); return 1; }
@@ -530,17 +532,30 @@ int tcc_main(int argc, char** argv) {
       if (gene_level)
         for (size_t g = 0; g < gc.size(); g++) if (gc[g] > 0.0) { gab_m[id].push_back({(int32_t)g, gc[g]}); gtpm_m[id].push_back({(int32_t)g, gc_tpm[g]}); }
       if (matrix_to_files) {
-        const std::string suffix = "_" + std::to_string(id + 1);
-        write_abundance(output + "/abundance" + suffix + ".tsv", idx, vt, alpha, eff);
-        if (gene_level) write_abundance_gene(output + "/abundance.gene" + suffix + ".tsv", genes, gc, gc_tpm);
+        // abundance_N.tsv beside the matrices, or (--matrix-to-directories) abundance_N/abundance.tsv (src/main.cpp:3061-3087)
+        std::string dir = output + "/", suffix = "_" + std::to_string(id + 1);
+        if (matrix_to_dirs) {
+          dir = output + "/abundance_" + std::to_string(id + 1);
+          struct stat sd;
+          if (stat(dir.c_str(), &sd) == 0) { if (!S_ISDIR(sd.st_mode)) { std::cerr << "Error: file " << dir << " exists and is not a directory" << std::endl; return 1; } }
+          else if (mkdir(dir.c_str(), 0777) == -1) { std::cerr << "Error: could not create directory " << dir << std::endl; return 1; }
+          dir += "/"; suffix = "";
+        }
+        write_abundance(dir + "abundance" + suffix + ".tsv", idx, vt, alpha, eff);
+        if (gene_level) write_abundance_gene(dir + "abundance.gene" + suffix + ".tsv", genes, gc, gc_tpm);
         if (bootstrap > 0) {
           std::vector<uint64_t> seeds(bootstrap);
           kamd_bootstrap_seeds(seed, bootstrap, seeds.data());
-          std::vector<double> res((size_t)bootstrap * T, 0.0), a(T);
+          std::vector<double> res((size_t)bootstrap * T, 0.0), a(T), at(T), bgc, bgt;
           if (total > 0) KX(kamd_bootstrap_batch(ctx, seeds.data(), bootstrap, eff.data(), T, res.data(), nullptr));
           for (int b = 0; b < bootstrap; b++) {
             a.assign(res.begin() + (size_t)b * T, res.begin() + (size_t)(b + 1) * T);
-            write_abundance(output + "/bs_abundance" + suffix + "_" + std::to_string(b) + ".tsv", idx, vt, a, eff);
+            write_abundance(dir + "bs_abundance" + suffix + "_" + std::to_string(b) + ".tsv", idx, vt, a, eff);
+            if (gene_level) {   // the replicate's gene-level sums (src/main.cpp:3143-3146)
+              kamd_counts_to_tpm(a.data(), eff.data(), T, at.data());
+              gene_sums(genes, a, at, &bgc, &bgt);
+              write_abundance_gene(dir + "bs_abundance.gene" + suffix + "_" + std::to_string(b) + ".tsv", genes, bgc, bgt);
+            }
           }
         }
       }

@@ -44,6 +44,8 @@ CASES = {
     "dlist_pe_nojump": ("dlist_pe", [0.0, 0.5, 1.0], ["--paired", "--no-jump"], []),
     # -g: gene-level sums ("@file" = a file of the case's directory: genemap.txt, written below)
     "human_pe_genes": ("human_pe", [0.0, 0.6, 1.0], ["--paired"], ["--matrix-to-files", "-g", "@genemap.txt"]),
+    # a directory per sample, with gene-level files of the bootstrap replicates in it
+    "ref_test_pe_dirs_boot": ("ref_test_pe", [0.0, 0.45, 1.0], ["--paired"], ["--matrix-to-directories", "-g", "@genemap.txt", "-b", "2", "--seed", "7", "--plaintext"]),
 }
 
 
@@ -178,7 +180,8 @@ def main():
                    "n_records_reference": int(len(rec)), "fld_file": bool(fld_args),
                    "reference": "pachterlab/kallisto v0.51.1, oracle/_ref/kallisto (unmodified sources), -t 1"},
                   open(os.path.join(dst, "case.json"), "w"), indent=1)
-        print(name, "samples", len(cuts) - 1, "records", len(rec), "classes used", len(used), sorted(os.listdir(tcc_out)))
+        print(name, "samples", len(cuts) - 1, "records", len(rec), "classes used", len(used),
+              sorted(os.path.relpath(os.path.join(d, f), tcc_out) for d, _, fs in os.walk(tcc_out) for f in fs))
 
 
 if __name__ == "__main__":

@@ -134,8 +134,12 @@ def _run_tcc(idx, ec, tcc, meta, gold, out, case_dir=None):
     assert p.returncode == 0, p.stderr.decode()
 
 
+def _files_below(d):
+    return sorted(os.path.relpath(os.path.join(r, f), d) for r, _, fs in os.walk(d) for f in fs)
+
+
 def _compare_tcc_out(out, ref, what):
-    assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+    assert _files_below(out) == _files_below(ref)   # (--matrix-to-directories: the per-sample files sit in abundance_N/)
     for fn in ("matrix.abundance.mtx", "matrix.abundance.tpm.mtx", "matrix.abundance.gene.mtx", "matrix.abundance.gene.tpm.mtx"):
         if os.path.exists(os.path.join(ref, fn)):   # (the gene-level pair: only with -g)
             common.assert_abundance_close(_mtx(os.path.join(out, fn)), _mtx(os.path.join(ref, fn)), f"{what} {fn}", rel=1e-4, floor=1e-5)
@@ -145,13 +149,13 @@ def _compare_tcc_out(out, ref, what):
     if os.path.exists(os.path.join(ref, "matrix.efflens.mtx")):
         a, b = _mtx(os.path.join(out, "matrix.efflens.mtx")), _mtx(os.path.join(ref, "matrix.efflens.mtx"))
         assert np.array_equal(a, b)                      # printed with 6 digits from bit-identical doubles
-    for fn in sorted(os.listdir(ref)):
+    for fn in _files_below(ref):
         if not fn.endswith(".tsv") or fn == "matrix.fld.tsv":
             continue
         rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(out, fn))]
         grows = [l.rstrip("\n").split("\t") for l in open(os.path.join(ref, fn))]
         assert rows[0] == grows[0] and len(rows) == len(grows)
-        gene_file = ".gene" in fn   # gene_id, gene_name, est_counts, tpm  instead of  target_id, length, eff_length, est_counts, tpm
+        gene_file = ".gene" in os.path.basename(fn)   # gene_id, gene_name, est_counts, tpm  instead of  target_id, length, eff_length, est_counts, tpm
         for a, b in zip(rows[1:], grows[1:]):
             assert a[:2 if gene_file else 3] == b[:2 if gene_file else 3], (fn, a, b)
         for col, name in ((2, "est_counts"), (3, "tpm")) if gene_file else ((3, "est_counts"), (4, "tpm")):
