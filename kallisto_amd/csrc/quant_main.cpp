@@ -45,7 +45,8 @@ void usage() {
             << "    --no-jump                 Look up every k-mer of a read (no jumping); not with a strand option\n"
             << "-l, --fragment-length=DOUBLE  Estimated average fragment length\n"
             << "-s, --sd=DOUBLE               Estimated standard deviation of fragment length\n"
-            << "-t, --threads=INT             Host threads for index loading (default: 1)\n"
+            << "-t, --threads=INT             Host threads: the readers of the input files (FASTQ text into pinned memory, gzip / BGZF\n"
+            << "                              inflate) and the index loader (default: 1, as the reference; give it the CPUs there are)\n"
             << "    --verbose                 Print out progress information\n"
             << "    --gpus=INT                GPUs of this node to use (default: 1): batches of reads go round the GPUs, the EC counts\n"
             << "                              are merged with one RCCL all-reduce + all-gathers, the EM runs partitioned over them\n"
