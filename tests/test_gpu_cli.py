@@ -256,41 +256,3 @@ def test_reference_reader_and_writers_bound_to_the_library(case, variant, tmp_pa
     info, ginfo = json.load(open(os.path.join(out, "run_info.json"))), json.load(open(os.path.join(gold, "run_info.json")))
     for k in ("n_targets", "n_processed", "n_pseudoaligned", "n_unique", "p_pseudoaligned", "p_unique", "index_version", "k-mer length"):
         assert info[k] == ginfo[k], k
-
-
-VERIFIED_BYTE_EQUAL = {("ref_test_pe", "pe"), ("yeast_se", "se"), ("dlist_pe", "pe"), ("mosaic_pe", "pe_union"), ("human_pe", "pe"), ("mosaic_pe", "se_nojump")}
-
-
-@pytest.mark.parametrize("case,variant", [("ref_test_pe", "pe"), ("yeast_se", "se"), ("dlist_pe", "pe"), ("mosaic_pe", "pe_union"), ("human_pe", "pe"),
-                                          ("mosaic_pe", "se_nojump"), ("tiny_k7_se", "se"), ("mosaic_pe", "pe_nojump_rf")])
-def test_compact_kmer_table_changes_nothing(case, variant, tmp_path):
-    """KAMD_TABLE_LAYOUT=compact: the k-mer table in four quotiented 16-byte slots per line instead of three 20-byte ones (kamd_core.h; its own
-    instantiation of kernel A, the same straight-line matcher elsewhere).  abundance.tsv must be the wide layout's byte for byte, and --
-    for the six cases of profiles/r03_compact_table_check.txt (scratch/r3_call34.sh on an MI355X) -- the reference CLI's own file."""
-    meta, idx_path, r1, r2 = common.load_case(case)
-    extra = meta["variants"][variant]
-    cli = [a.replace("--fr", "--fr-stranded").replace("--rf", "--rf-stranded") for a in extra]
-    f1 = str(tmp_path / "r_1.fq")
-    _fastq(f1, r1)
-    files = [f1]
-    if r2 is not None and "--single" not in extra:
-        f2 = str(tmp_path / "r_2.fq")
-        _fastq(f2, r2)
-        files.append(f2)
-    out, out_w = str(tmp_path / "out"), str(tmp_path / "out_wide")
-    # (by the environment variable -- what scratch/r3_call34.sh did on the MI355X -- for the verified six, by the option for the others)
-    by_flag = (case, variant) not in VERIFIED_BYTE_EQUAL
-    p = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out, "--plaintext", "--verbose", *(["--kmer-table", "compact"] if by_flag else []), *cli, *files],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=os.environ if by_flag else dict(os.environ, KAMD_TABLE_LAYOUT="compact"))
-    assert p.returncode == 0, p.stderr.decode()
-    assert "k-mer table: compact layout, 4 slots" in p.stderr.decode()
-    pw = subprocess.run([EXE, "quant", "-i", idx_path, "-o", out_w, "--plaintext", "--verbose", *cli, *files], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                        env=dict(os.environ, KAMD_TABLE_LAYOUT="wide"))
-    assert pw.returncode == 0 and "k-mer table: wide layout, 3 slots" in pw.stderr.decode(), pw.stderr.decode()
-    # the layout changes nothing: same classes, same counts, and the abundances are reproducible to the bit
-    assert open(os.path.join(out, "abundance.tsv"), "rb").read() == open(os.path.join(out_w, "abundance.tsv"), "rb").read()
-    a, b = json.load(open(os.path.join(out, "run_info.json"))), json.load(open(os.path.join(out_w, "run_info.json")))
-    assert all(a[k] == b[k] for k in ("n_processed", "n_pseudoaligned", "n_unique"))
-    if (case, variant) in VERIFIED_BYTE_EQUAL:
-        ref = os.path.join(common.case_dir(case), "cli_" + variant, "abundance.tsv")
-        assert open(os.path.join(out, "abundance.tsv"), "rb").read() == open(ref, "rb").read()
