@@ -8,7 +8,7 @@
 cd "$(dirname "$0")/../.." || exit 1
 O=gpurun_out/nr1; mkdir -p $O
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_cli.py -x -q -k "compact or bound" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
+timeout 400 python -m pytest tests/test_gpu_zz_late.py tests/test_gpu_cli.py -q -k "late or bound" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
 FAST="--steps 5 --warmup 2 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg"
 timeout 200 python bench.py $FAST > $O/c3_wide.json 2> $O/c3_wide.err
 for load in 0.5 0.6 0.7; do
