@@ -100,3 +100,16 @@ def test_single_cell_technologies_are_refused(tmp_path):
     open(tmp_path / "a.fq", "w").close()
     rc, got = _sub_errors(EXE, "bus", ["-x", "10xv3", "-i", IDX, "-o", "o", "a.fq"], str(tmp_path))
     assert rc == 1 and got == ["Error: only `-x bulk` runs on the GPU path; single-cell technologies stay with the reference kallisto"]
+
+
+def test_bench_and_its_side_leg_parse():
+    """bench.py's flags (the driver runs it without any) and the side leg's script are at least importable / parseable on a box without a GPU."""
+    import ast
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"--table-layout" in p.stdout and b"--no-compact-leg" in p.stdout and b"--gpus" in p.stdout
+    ast.parse(open(os.path.join(root, "tools", "compact_table_leg.py")).read())
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "compact_table_leg.py"), "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"--loads" in p.stdout
