@@ -400,6 +400,32 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def compact_table_leg(idx_path, compact_dir, n, L, paired, steps, warmup, device, res, script=None, loads="0.6,0.5,0.7"):
+    """The steps of the headline on the compact k-mer table, in a child process (tools/compact_table_leg.py) that finds the packed reads in
+    compact_dir; `res` = the headline's result, which every leg must reproduce (counts, fragment lengths, est_counts to the bit, EM rounds).
+    Returns the list of legs; never raises; removes compact_dir."""
+    try:
+        cmd = [sys.executable, script or os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", compact_dir, "--items", str(n),
+               "--read-len", str(L), "--paired", "1" if paired else "0", "--steps", str(steps), "--warmup", str(warmup), "--device", str(device), "--loads", loads]
+        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if pc.returncode != 0:
+            return [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
+        legs = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+        for i, entry in enumerate(legs):   # the layout must change nothing
+            f = os.path.join(compact_dir, f"result_{i}.npz")
+            if "error" in entry or not os.path.exists(f):
+                continue
+            z = np.load(f)
+            entry["identical_to_wide"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
+                                              np.array_equal(z["flens"], res.flens) and np.array_equal(z["est_counts"], res.est_counts) and
+                                              int(z["em_rounds"]) == res.em_rounds)
+        return legs
+    except Exception as e:   # noqa: BLE001  (a side leg must not take the line down)
+        return [{"error": str(e)[:300]}]
+    finally:
+        shutil.rmtree(compact_dir, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -878,26 +904,7 @@ def main():
             out["end_to_end"] = {"error": str(e)}
     if rank == 0 and compact_dir is not None:
         log("compact k-mer table: the same steps in a child process ...")
-        try:
-            cmd = [sys.executable, os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", compact_dir, "--items", str(n), "--read-len", str(L),
-                   "--paired", "1" if paired else "0", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 1)), "--device", str(local), "--loads", "0.6,0.5,0.7"]
-            pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-            if pc.returncode != 0:
-                compact_leg = [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
-            else:
-                compact_leg = json.loads(pc.stdout.decode().strip().splitlines()[-1])
-                for i, entry in enumerate(compact_leg):   # the layout must change nothing: counts, fragment lengths, and (abundances are reproducible to the bit) est_counts
-                    f = os.path.join(compact_dir, f"result_{i}.npz")
-                    if "error" in entry or not os.path.exists(f):
-                        continue
-                    z = np.load(f)
-                    entry["identical_to_wide"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
-                                                      np.array_equal(z["flens"], res.flens) and np.array_equal(z["est_counts"], res.est_counts) and
-                                                      int(z["em_rounds"]) == res.em_rounds)
-        except Exception as e:   # noqa: BLE001
-            compact_leg = [{"error": str(e)[:300]}]
-        finally:
-            shutil.rmtree(compact_dir, ignore_errors=True)
+        compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res)
     if rank == 0:
         if multi_parity is not None:
             out["multi_rank_parity"] = multi_parity

@@ -113,3 +113,32 @@ def test_bench_and_its_side_leg_parse():
     ast.parse(open(os.path.join(root, "tools", "compact_table_leg.py")).read())
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "compact_table_leg.py"), "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0 and b"--loads" in p.stdout
+
+
+def test_bench_compact_leg_glue(tmp_path):
+    """bench.compact_table_leg with a stand-in for the child: the legs come back with `identical_to_wide`, a failing child becomes an error entry,
+    the hand-over directory is removed either way."""
+    import sys
+    import types
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    res = types.SimpleNamespace(n_pseudoaligned=9, n_unique=4, flens=np.arange(1000, dtype=np.uint32), est_counts=np.array([1.5, 0.0, 2.25]), em_rounds=52)
+    fake = tmp_path / "child.py"
+    fake.write_text("import sys, json, os, numpy as np\n"
+                    "d = sys.argv[sys.argv.index('--dir') + 1]\n"
+                    "assert os.path.exists(os.path.join(d, 'words.i32'))\n"
+                    "for i, ec in enumerate(([1.5, 0.0, 2.25], [1.5, 0.0, 2.5])):\n"
+                    "    np.savez(os.path.join(d, 'result_%d.npz' % i), n_pseudoaligned=9, n_unique=4, flens=np.arange(1000, dtype=np.uint32), est_counts=np.array(ec), em_rounds=52)\n"
+                    "print('noise')\n"
+                    "print(json.dumps([{'layout': 'compact', 'load': 0.6}, {'layout': 'compact', 'load': 0.5}, {'layout': 'compact', 'error': 'x'}]))\n")
+    d = tmp_path / "hand"
+    d.mkdir(); (d / "words.i32").write_bytes(b"\0" * 8)
+    legs = bench.compact_table_leg("idx", str(d), 10, 100, True, 2, 1, 0, res, script=str(fake))
+    assert [e.get("identical_to_wide") for e in legs] == [True, False, None] and not d.exists()
+    d.mkdir()
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys\nsys.stderr.write('boom')\nsys.exit(3)\n")
+    legs = bench.compact_table_leg("idx", str(d), 10, 100, True, 2, 1, 0, res, script=str(bad))
+    assert len(legs) == 1 and "rc 3" in legs[0]["error"] and "boom" in legs[0]["error"] and not d.exists()
