@@ -443,8 +443,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=200_000,
                     help="pairs of the CPU sample that also go through the reference at -t 1 for the parity gate")
-    ap.add_argument("--bootstraps", type=int, default=0,
-                    help="BASELINE config #5: also time B bootstrap replicates (multinomial resample + EM), split over the ranks")
+    ap.add_argument("--bootstraps", type=int, default=None,
+                    help="BASELINE config #5: also time B bootstrap replicates (multinomial resample + EM), split over the ranks "
+                         "(default: 100 on one GPU -- about a second --, 0 on several)")
     ap.add_argument("--in-flight", type=int, default=1, help="2: also measure two samples in flight on one GPU (two contexts / streams); reported "
                     "beside the headline value, never as it")
     ap.add_argument("--end-to-end", type=int, default=8_000_000, help="run the C++ front-end from FASTQ files with this many pairs / reads (N = 1 only; 0 = skip)")
@@ -486,6 +487,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.bootstraps is None:
+        args.bootstraps = 100 if world == 1 else 0
     paired = args.workload == "human"
     genes = args.genes or (20000 if args.workload == "human" else 6000)
     n_default = 30_000_000 if paired else 10_000_000
@@ -642,28 +645,33 @@ def main():
     # ---- BASELINE config #5 (optional): B bootstrap replicates of the last step's ECs, replicate b on rank b % world ----
     boot = None
     if args.bootstraps > 0:
-        import kallisto_amd.api as A
-        ctx.reset()
-        res = ka.quant(ctx, opts, [(words[:n * per * rec], lens[:per * n], n, L)], download_ecs=False)
-        seeds = A.bootstrap_seeds(42, args.bootstraps)
-        mine = [b for b in range(args.bootstraps) if b % world == rank]
-        fence()
-        tb = time.perf_counter()
-        rounds_b = []
-        if mine:
-            _, rb = ctx.bootstrap_batch(seeds[mine], res.eff_lens)   # one multinomial launch, EMs on the cached plan
-            rounds_b = [int(x) for x in rb]
-        fence()
-        tb = time.perf_counter() - tb
-        if world > 1:
-            t = torch.tensor([tb], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tb = float(t.item())
-        boot = {"replicates": args.bootstraps, "seconds": round(tb, 4), "replicates_per_s": round(args.bootstraps / tb, 3),
-                "ms_per_replicate_per_gpu": round(tb / max(len(mine), 1) * 1e3, 2),
-                "em_rounds_first": rounds_b[:3], "note": "Bootstrap::run_em per replicate: multinomial resample of the EC counts "
-                "(N = pseudoaligned pairs draws, libstdc++ semantics; all replicates of a rank drawn in one launch) + EM run(10000, 50) on "
-                "the cached plan of the EC matrix; replicate b runs on rank b % world (every rank holds the merged ECs)"}
+        try:
+            import kallisto_amd.api as A
+            ctx.reset()
+            res = ka.quant(ctx, opts, [(words[:n * per * rec], lens[:per * n], n, L)], download_ecs=False)
+            seeds = A.bootstrap_seeds(42, args.bootstraps)
+            mine = [b for b in range(args.bootstraps) if b % world == rank]
+            fence()
+            tb = time.perf_counter()
+            rounds_b = []
+            if mine:
+                _, rb = ctx.bootstrap_batch(seeds[mine], res.eff_lens)   # one multinomial launch, EMs on the cached plan
+                rounds_b = [int(x) for x in rb]
+            fence()
+            tb = time.perf_counter() - tb
+            if world > 1:
+                t = torch.tensor([tb], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tb = float(t.item())
+            boot = {"replicates": args.bootstraps, "seconds": round(tb, 4), "replicates_per_s": round(args.bootstraps / tb, 3),
+                    "ms_per_replicate_per_gpu": round(tb / max(len(mine), 1) * 1e3, 2),
+                    "em_rounds_first": rounds_b[:3], "note": "Bootstrap::run_em per replicate: multinomial resample of the EC counts "
+                    "(N = pseudoaligned pairs draws, libstdc++ semantics; all replicates of a rank drawn in one launch) + EM run(10000, 50) on "
+                    "the cached plan of the EC matrix; replicate b runs on rank b % world (every rank holds the merged ECs)"}
+        except Exception as e:   # noqa: BLE001  (world == 1: a side leg; with several ranks every rank must reach the collectives, so it is left to fail there)
+            if world > 1:
+                raise
+            boot = {"error": str(e)[:300]}
 
     # ---- optional: two samples in flight on one GPU (the EM of one is LDS-bound, the pseudoalignment of the next is bound by
     # memory requests) -- a second context on its own stream, two host threads, each runs full quants; NOT the headline value ----
