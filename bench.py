@@ -426,6 +426,36 @@ def compact_table_leg(idx_path, compact_dir, n, L, paired, steps, warmup, device
         shutil.rmtree(compact_dir, ignore_errors=True)
 
 
+def bench_line_digest(d):
+    """the figures of a bench line (value, step time, break-down, roofline fraction, CPU baseline, parity verdicts) without its prose"""
+    keep = {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "breakdown_ms", "counters")}
+    keep["workload"] = (d.get("config") or {}).get("workload")
+    keep["roofline"] = {k: (d.get("roofline") or {}).get(k) for k in ("kernel", "achieved", "peak", "frac", "launch_ms")}
+    cb = d.get("cpu_baseline") or {}
+    keep["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    for k in ("parity_check", "parity_check_tail"):
+        pcheck = d.get(k)
+        if isinstance(pcheck, dict):
+            keep[k] = {kk: vv for kk, vv in pcheck.items() if not isinstance(vv, (list, dict)) or kk == "n_pseudoaligned"}
+    return keep
+
+
+def config2_leg(timeout_s=900):
+    """BASELINE config #2 (yeast-like transcriptome, 10 M single-end reads, --single -l 200 -s 20) as a child run of this script: its line, cut
+    down to the figures, for the line of config #3.  Never raises."""
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "yeast", "--steps", "5", "--warmup", "2", "--end-to-end", "0", "--no-pinned-pipeline",
+               "--no-compact-leg", "--no-config2", "--bootstraps", "0"]
+        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        if pc.returncode != 0:
+            return {"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}
+        keep = bench_line_digest(json.loads(pc.stdout.decode().strip().splitlines()[-1]))
+        keep["command"] = "python bench.py " + " ".join(cmd[2:])
+        return keep
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -455,6 +485,7 @@ def main():
     ap.add_argument("--table-layout", default=None, choices=["wide", "compact", "auto"],
                     help="layout of the k-mer table (KAMD_TABLE_LAYOUT; default: the library's, wide): compact = four quotiented 16-byte slots per "
                          "line instead of three 20-byte ones (kamd_core.h)")
+    ap.add_argument("--no-config2", action="store_true", help="skip the child run of BASELINE config #2 (yeast, single-end) that the default one-GPU run of config #3 appends")
     ap.add_argument("--no-compact-leg", action="store_true", help="skip the side leg that repeats the steps on the compact k-mer table (N = 1 only)")
     ap.add_argument("--table-load", type=float, default=None, help="load factor of the compact table (KAMD_TABLE_LOAD, default 0.6)")
     args = ap.parse_args()
@@ -919,6 +950,9 @@ def main():
     if rank == 0 and compact_dir is not None:
         log("compact k-mer table: the same steps in a child process ...")
         compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res)
+    if rank == 0 and world == 1 and args.workload == "human" and not args.no_config2 and genes == 20000 and n_arg == n_default:
+        log("BASELINE config #2 (yeast, single-end) as a child run ...")
+        out["config2"] = config2_leg()
     if rank == 0:
         if multi_parity is not None:
             out["multi_rank_parity"] = multi_parity

@@ -142,3 +142,18 @@ def test_bench_compact_leg_glue(tmp_path):
     bad.write_text("import sys\nsys.stderr.write('boom')\nsys.exit(3)\n")
     legs = bench.compact_table_leg("idx", str(d), 10, 100, True, 2, 1, 0, res, script=str(bad))
     assert len(legs) == 1 and "rc 3" in legs[0]["error"] and "boom" in legs[0]["error"] and not d.exists()
+
+
+def test_bench_line_digest_on_a_kept_line():
+    """The digest bench.py makes of its child run of config #2, applied to a line kept under profiles/."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    d = json.load(open(os.path.join(root, "profiles", "r03_bench_config2_yeast.json")))
+    k = bench.bench_line_digest(d)
+    assert k["value"] == d["value"] and k["unit"] == "M reads/s" and "config #2" in k["workload"]
+    assert k["roofline"]["frac"] == d["roofline"]["frac"] and k["cpu_baseline"]["kind"] == "reference"
+    assert k["parity_check"]["ec_multiset_equal"] is True and k["parity_check_tail"]["ok"] is True
+    assert len(json.dumps(k)) < 4000
