@@ -489,6 +489,9 @@ def main():
     ap.add_argument("--no-compact-leg", action="store_true", help="skip the side leg that repeats the steps on the compact k-mer table (N = 1 only)")
     ap.add_argument("--table-load", type=float, default=None, help="load factor of the compact table (KAMD_TABLE_LOAD, default 0.6)")
     args = ap.parse_args()
+    t_start = time.time()
+    # the two appended child runs (compact-table legs, config #2) only start while the whole run is inside this many seconds (KAMD_BENCH_BUDGET_S)
+    budget_s = float(os.environ.get("KAMD_BENCH_BUDGET_S", "420"))
     if args.table_layout:
         os.environ["KAMD_TABLE_LAYOUT"] = args.table_layout
     if args.table_load:
@@ -948,11 +951,18 @@ def main():
         except Exception as e:
             out["end_to_end"] = {"error": str(e)}
     if rank == 0 and compact_dir is not None:
-        log("compact k-mer table: the same steps in a child process ...")
-        compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res)
+        if time.time() - t_start > budget_s - 60:
+            compact_leg = [{"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S)"}]
+            shutil.rmtree(compact_dir, ignore_errors=True)
+        else:
+            log("compact k-mer table: the same steps in a child process ...")
+            compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res)
     if rank == 0 and world == 1 and args.workload == "human" and not args.no_config2 and genes == 20000 and n_arg == n_default:
-        log("BASELINE config #2 (yeast, single-end) as a child run ...")
-        out["config2"] = config2_leg()
+        if time.time() - t_start > budget_s - 45:
+            out["config2"] = {"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S)"}
+        else:
+            log("BASELINE config #2 (yeast, single-end) as a child run ...")
+            out["config2"] = config2_leg(timeout_s=max(60.0, budget_s + 120 - (time.time() - t_start)))
     if rank == 0:
         if multi_parity is not None:
             out["multi_rank_parity"] = multi_parity
