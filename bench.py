@@ -400,14 +400,14 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def compact_table_leg(idx_path, compact_dir, n, L, paired, steps, warmup, device, res, script=None, loads="0.6,0.5,0.7"):
+def compact_table_leg(idx_path, compact_dir, n, L, paired, steps, warmup, device, res, script=None, loads="0.6,0.5,0.7", timeout_s=600):
     """The steps of the headline on the compact k-mer table, in a child process (tools/compact_table_leg.py) that finds the packed reads in
     compact_dir; `res` = the headline's result, which every leg must reproduce (counts, fragment lengths, est_counts to the bit, EM rounds).
     Returns the list of legs; never raises; removes compact_dir."""
     try:
         cmd = [sys.executable, script or os.path.join(ROOT, "tools", "compact_table_leg.py"), "--index", idx_path, "--dir", compact_dir, "--items", str(n),
                "--read-len", str(L), "--paired", "1" if paired else "0", "--steps", str(steps), "--warmup", str(warmup), "--device", str(device), "--loads", loads]
-        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         if pc.returncode != 0:
             return [{"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}]
         legs = json.loads(pc.stdout.decode().strip().splitlines()[-1])
@@ -956,7 +956,8 @@ def main():
             shutil.rmtree(compact_dir, ignore_errors=True)
         else:
             log("compact k-mer table: the same steps in a child process ...")
-            compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res)
+            compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res,
+                                            timeout_s=max(60.0, budget_s + 120 - (time.time() - t_start)))
     if rank == 0 and world == 1 and args.workload == "human" and not args.no_config2 and genes == 20000 and n_arg == n_default:
         if time.time() - t_start > budget_s - 45:
             out["config2"] = {"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S)"}
