@@ -106,7 +106,8 @@ int kamd_index_load(const char* path, int threads, kamd_index** out);
  * wide | compact | auto and KAMD_TABLE_LOAD): KAMD_TABLE_WIDE = three 20-byte slots per 64-byte line at a load of 0.5 (the default),
  * KAMD_TABLE_COMPACT = four exact 16-byte slots per line (kamd_index_view::table_layout; an error when the index's class ids or text
  * positions do not fit the slot), KAMD_TABLE_AUTO = compact when it fits.  load = load factor of the compact table in [0.2, 0.9]
- * (anything else: 0.6).  A flattened file (kamd_index_save) carries its layout; the argument only speaks to the builder. */
+ * (anything else: 0.6).  A flattened file (kamd_index_save) carries its layout: asking for KAMD_TABLE_WIDE or _COMPACT (here, or through
+ * KAMD_TABLE_LAYOUT) and naming a flattened file of the other layout is an error (-3); _AUTO takes what the file holds. */
 #define KAMD_TABLE_WIDE 0
 #define KAMD_TABLE_COMPACT 1
 #define KAMD_TABLE_AUTO 2
@@ -115,6 +116,10 @@ int kamd_index_load_layout(const char* path, int threads, int layout, double loa
  * kamd_index_load recognises such a file by its magic and reads it back with plain reads (same kamd_index).  Native byte order,
  * format-versioned; not a replacement for the kallisto index, which stays the source of truth. */
 int kamd_index_save(const kamd_index*, const char* path);
+/* 1 when flat_path is a flattened file of this format version written from exactly the kallisto index at index_path (the file records the
+ * index's size and a hash of its first and last 64 KiB), 0 when it is not, cannot be read, or does not say.  What a front-end asks before
+ * it picks up `<index>.kamd` beside an index: modification times alone survive `cp -p` / `rsync -t` of a different index. */
+int kamd_flat_index_matches(const char* flat_path, const char* index_path);
 void kamd_index_free(kamd_index*);
 int kamd_index_get_view(const kamd_index*, kamd_index_view* out);
 const char* kamd_index_target_name(const kamd_index*, uint64_t i);
@@ -314,6 +319,10 @@ int kamd_comm_unique_id(void* id128);
 int kamd_comm_create_rccl(kamd_ctx*, int32_t rank, int32_t world, const void* id128, kamd_comm** out);
 int kamd_comm_create_callbacks(kamd_ctx*, int32_t rank, int32_t world, const kamd_comm_callbacks*, void* user, kamd_comm** out);
 void kamd_comm_destroy(kamd_comm*);
+/* what the communicator is: its rank and world as created, the number of ranks the transport itself reports (ncclCommCount on the
+ * RCCL backend; the world it was told for callbacks), backend 0 = none (a world of one without RCCL), 1 = RCCL, 2 = callbacks.
+ * Any pointer may be null. */
+int kamd_comm_info(const kamd_comm*, int32_t* rank, int32_t* world, int32_t* ranks_seen, int32_t* backend);
 /* merge the EC state of all ranks: ONE all-reduce (sum) of the dense count vector + an all-gather of the de-duplicated tuple
  * records and of the explicit-set records; afterwards every rank holds the state of the whole input (call kamd_ec_finalize
  * next, on every rank).  Not with kamd_ec_track_order. */

@@ -132,10 +132,12 @@ _SYMBOLS = {
     "kamd_ec_explicit_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kamd_ec_explicit_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "kamd_ec_explicit_replace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "kamd_flat_index_matches": (C.c_int, [C.c_char_p, C.c_char_p]),
     "kamd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "kamd_comm_create_rccl": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "kamd_comm_create_callbacks": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "kamd_comm_destroy": (None, [C.c_void_p]),
+    "kamd_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "kamd_ec_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kamd_comm_broadcast_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "kamd_comm_sum_u64_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -371,7 +373,11 @@ class Context:
                 keep.append((pad.to(dev), len(t)))
             else:
                 assert t.dtype == torch.uint8 and t.is_cuda
-                keep.append((t, t.numel()))
+                # the ABI wants the text readable up to 32 bytes behind n_bytes (k_fq_pack loads whole groups of 32 bases): a caller's
+                # exactly-sized tensor is copied into a padded one rather than read past its allocation
+                pad = torch.zeros(t.numel() + 64, dtype=torch.uint8, device=t.device)
+                pad[:t.numel()] = t.reshape(-1)
+                keep.append((pad, t.numel()))
         ptrs = (C.c_void_p * 2)(*[k[0].data_ptr() for k in keep], *([None] * (2 - len(keep))))
         nb = (C.c_uint64 * 2)(*[k[1] for k in keep], *([0] * (2 - len(keep))))
         return keep, ptrs, nb
@@ -747,7 +753,40 @@ class Comm:
         dist.broadcast_object_list(box, src=0, group=group)
         if not box[1]:
             return cls.over_process_group(ctx, group)
-        return cls.rccl(ctx, rank, world, box[0])
+        # every rank runs ncclCommInitRank on its context's device (kamd_comm_create_rccl sets it first); the ranks then agree -- through
+        # the process group, not through the communicator under test -- that all of them hold a communicator that counts `world` ranks
+        # and sums correctly.  Otherwise all of them drop it and take the callbacks: no rank may be left alone in a collective.
+        comm, err = None, ""
+        try:
+            comm = cls.rccl(ctx, rank, world, box[0])
+            seen = comm.info()["ranks_seen"]
+            if seen != world:
+                err = f"ncclCommCount says {seen} ranks, the process group has {world}"
+        except KallistoAmdError as e:
+            err = str(e)
+        flags = [None] * world
+        dist.all_gather_object(flags, err, group=group)
+        if not any(flags):
+            try:
+                if comm.sum_int(rank + 1) != world * (world + 1) // 2:
+                    err = "the all-reduce over the new communicator returned a wrong sum"
+            except KallistoAmdError as e:
+                err = str(e)
+            dist.all_gather_object(flags, err, group=group)
+        if any(flags):
+            if rank == 0:
+                print(f"[kallisto_amd] RCCL communicator inside the library unusable ({next(f for f in flags if f)}); using torch.distributed "
+                      f"callbacks", file=sys.stderr)
+            if comm is not None:
+                comm.close()
+            return cls.over_process_group(ctx, group)
+        return comm
+
+    def info(self) -> dict:
+        """rank / world as created, ranks the transport itself counts (ncclCommCount), backend name"""
+        r, w, seen, b = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _check(load_library().kamd_comm_info(self._h, C.byref(r), C.byref(w), C.byref(seen), C.byref(b)), "kamd_comm_info")
+        return {"rank": r.value, "world": w.value, "ranks_seen": seen.value, "backend": {0: "none", 1: "rccl", 2: "callbacks"}[b.value]}
 
     def broadcast_np(self, arr: np.ndarray, root: int = 0) -> np.ndarray:
         a = np.ascontiguousarray(arr).copy()

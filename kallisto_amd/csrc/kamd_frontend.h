@@ -289,7 +289,10 @@ class UnitFeeder {
         G.bufs[bi].busy = true;
       }
       Buf& b = G.bufs[bi];
-      if (hipSetDevice(devs_[g]) != hipSuccess) { error_ = "hipSetDevice failed"; rc = FAILED; break; }
+      // a buffer that is marked busy but never queued has no consumer to clear it: drain() below would wait for it for ever (a lost
+      // device would hang the process instead of ending it with the error) -- every failure path hands the buffer back first
+      auto give_back = [&] { { std::lock_guard<std::mutex> lk(G.m); G.bufs[bi].busy = false; } G.cv.notify_all(); };
+      if (hipSetDevice(devs_[g]) != hipSuccess) { error_ = "hipSetDevice failed"; rc = FAILED; give_back(); break; }
       bool ok = true;
       for (int f = 0; f < nf && ok; f++) {
         const char* p[2]; size_t n[2];
@@ -300,10 +303,12 @@ class UnitFeeder {
         bytes += b.n_bytes[f];
       }
       if (ok) ok = hipEventRecord(b.copied, G.copy) == hipSuccess;
-      if (!ok) { error_ = "copy of a unit of text to the device failed"; rc = FAILED; break; }
+      if (!ok) { error_ = "copy of a unit of text to the device failed"; rc = FAILED; give_back(); break; }
       b.n_records = u.n_records; b.n_files = nf;
       b.seq = tracker_.add(u.end);
-      { std::lock_guard<std::mutex> lk(G.m); G.queue.push_back(bi); G.copies.push_back(bi); }
+      // (the releaser gets the unit's sequence number and event by value: by the time it looks, the consumer may have released the buffer
+      // and this thread recorded the next unit in it -- it must complete THIS unit's number, or the ring is never released)
+      { std::lock_guard<std::mutex> lk(G.m); G.queue.push_back(bi); G.copies.push_back(Copy{bi, b.seq, b.copied}); }
       G.cv.notify_all();
       n_items += u.n_records; ++units;
       if (verbose) std::cerr << "[quant] processed " << n_items << (nf == 2 ? " pairs" : " reads") << std::endl;
@@ -320,7 +325,8 @@ class UnitFeeder {
 
  private:
   struct Buf { char* d[2] = {nullptr, nullptr}; uint64_t n_bytes[2] = {0, 0}, n_records = 0, seq = 0; int n_files = 1; hipEvent_t copied = nullptr; bool busy = false; };
-  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue, copies; std::mutex m; std::condition_variable cv; std::thread th, rel;
+  struct Copy { int bi; uint64_t seq; hipEvent_t copied; };
+  struct Gpu { std::vector<Buf> bufs; hipStream_t copy = nullptr; std::deque<int> queue; std::deque<Copy> copies; std::mutex m; std::condition_variable cv; std::thread th, rel;
                double busy_s = 0.0, copy_wait_s = 0.0, parse_s = 0.0, run_s = 0.0; };
   // the rings are released in input order, whatever order the GPUs' copies complete in
   struct Tracker {
@@ -353,20 +359,21 @@ class UnitFeeder {
     Gpu& G = *gpus_[g];
     (void)hipSetDevice(devs_[g]);
     for (;;) {
-      int bi;
+      Copy cp;
       {
         std::unique_lock<std::mutex> lk(G.m);
         G.cv.wait(lk, [&] { return !G.copies.empty(); });
-        bi = G.copies.front(); G.copies.pop_front();
+        cp = G.copies.front(); G.copies.pop_front();
       }
-      if (bi < 0) return;
-      if (hipEventSynchronize(G.bufs[bi].copied) != hipSuccess) set_state(FAILED, "copy of a unit of text to the device failed");
-      tracker_.complete(G.bufs[bi].seq);
+      if (cp.bi < 0) return;
+      // (an event recorded again for a later unit of the same copy stream completes no earlier than this unit's copy did)
+      if (hipEventSynchronize(cp.copied) != hipSuccess) set_state(FAILED, "copy of a unit of text to the device failed");
+      tracker_.complete(cp.seq);
     }
   }
   void stop_consumers() {
     if (!started_) return;
-    for (auto& G : gpus_) { { std::lock_guard<std::mutex> lk(G->m); G->queue.push_back(-1); G->copies.push_back(-1); } G->cv.notify_all(); }
+    for (auto& G : gpus_) { { std::lock_guard<std::mutex> lk(G->m); G->queue.push_back(-1); G->copies.push_back(Copy{-1, 0, nullptr}); } G->cv.notify_all(); }
     for (auto& G : gpus_) { if (G->th.joinable()) G->th.join(); if (G->rel.joinable()) G->rel.join(); }
     started_ = false;
     device_s = copy_wait_s = parse_s = run_s = 0.0;

@@ -149,6 +149,9 @@ struct kamd_index {
   uint64_t n_dbuckets = 0, dpad_buckets = 0;
   std::vector<uint64_t> dtable;
   uint64_t dummy_slot = 0; uint32_t dummy_uec = 0, dummy_strand = 0;
+  // identity of the kallisto index these tables were built from (size in bytes, hash of its first and last 64 KiB): written into a
+  // flattened file so that one picked up beside an index can be tied to that index (kamd_flat_index_matches); 0 / 0 = unknown
+  uint64_t src_size = 0, src_hash = 0;
 };
 
 namespace {
@@ -185,9 +188,41 @@ inline void for_each_kmer_rc(const uint8_t* packed, uint64_t len, int k, F&& f) 
 // front-end that runs sample after sample against one index can write them once and read them back with plain reads.  Layout:
 // magic, format version, the scalars, then every array as {u64 count, bytes}; native endianness, for this machine's eyes only.
 namespace {
-const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '3'};
+const char FLAT_MAGIC[8] = {'K', 'A', 'M', 'D', 'F', 'L', 'T', '4'};   // 4: the source index's identity behind the stamp
 // what the layout of the tables depends on, written behind the magic and compared on load
 const uint32_t FLAT_STAMP[4] = {(uint32_t)kamd::BUCKET_SLOTS, (uint32_t)sizeof(uint64_t) * 8u /* bytes per bucket */, 30u /* bits of a class id in the payload */, 13u /* kallisto index version */};
+// identity of a kallisto index file: FNV-1a over its size and its first and last 64 KiB (header, k, start of the graph; transcript names and
+// lengths at the end) -- cheap enough for every start of the front-end, and what a replaced index changes even when its mtime is kept
+const size_t SRC_HASH_SPAN = 64u << 10;
+uint64_t fnv1a(uint64_t h, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; } return h; }
+uint64_t source_hash(const uint8_t* data, uint64_t size) {
+  uint64_t h = fnv1a(0xcbf29ce484222325ULL, &size, sizeof size);
+  const size_t head = (size_t)std::min<uint64_t>(size, SRC_HASH_SPAN);
+  h = fnv1a(h, data, head);
+  if (size > head) { const size_t tail = (size_t)std::min<uint64_t>(size - head, SRC_HASH_SPAN); h = fnv1a(h, data + size - tail, tail); }
+  return h ? h : 1;
+}
+bool source_identity_of_file(const char* path, uint64_t* size, uint64_t* hash) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  bool ok = fseek(f, 0, SEEK_END) == 0;
+  const long sz = ok ? ftell(f) : -1;
+  ok = ok && sz >= 0;
+  std::vector<uint8_t> b;
+  if (ok) {
+    const uint64_t n = (uint64_t)sz;
+    const size_t head = (size_t)std::min<uint64_t>(n, SRC_HASH_SPAN), tail = n > head ? (size_t)std::min<uint64_t>(n - head, SRC_HASH_SPAN) : 0;
+    b.resize(head + tail);
+    ok = fseek(f, 0, SEEK_SET) == 0 && fread(b.data(), 1, head, f) == head && (tail == 0 || (fseek(f, (long)(n - tail), SEEK_SET) == 0 && fread(b.data() + head, 1, tail, f) == tail));
+    if (ok) {   // the same bytes source_hash() sees when it is given the whole file
+      uint64_t h = fnv1a(0xcbf29ce484222325ULL, &n, sizeof n);
+      h = fnv1a(h, b.data(), head + tail);
+      *size = n; *hash = h ? h : 1;
+    }
+  }
+  fclose(f);
+  return ok;
+}
 struct FlatOut {
   FILE* f; bool ok = true;
   void raw(const void* p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
@@ -272,6 +307,7 @@ int load_flat(const char* path, int threads, kamd_index** out) {
     return kamd::fail(-3, std::string("flattened index file is damaged or of another format version: ") + path);
   }
   std::unique_ptr<kamd_index> ix(new kamd_index);
+  in.scalar(ix->src_size); in.scalar(ix->src_hash);
   flat_fields(in, *ix);
   uint64_t n_names = 0; in.scalar(n_names);
   if (in.ok && n_names < (1ULL << 32)) {
@@ -328,6 +364,7 @@ extern "C" int kamd_index_save(const kamd_index* ix, const char* path) {
   FlatOut o{f};
   o.raw(FLAT_MAGIC, 8);
   o.raw(FLAT_STAMP, sizeof FLAT_STAMP);
+  o.scalar(ix->src_size); o.scalar(ix->src_hash);
   flat_fields(o, const_cast<kamd_index&>(*ix));
   const uint64_t n_names = ix->target_names.size(); o.scalar(n_names);
   for (const std::string& nm : ix->target_names) { const uint32_t l = (uint32_t)nm.size(); o.scalar(l); o.raw(nm.data(), l); }
@@ -336,8 +373,21 @@ extern "C" int kamd_index_save(const kamd_index* ix, const char* path) {
   return 0;
 }
 
+extern "C" int kamd_flat_index_matches(const char* flat_path, const char* index_path) {
+  if (!flat_path || !index_path) return kamd::fail(-1, "kamd_flat_index_matches: null argument");
+  FILE* f = fopen(flat_path, "rb");
+  if (!f) return 0;
+  char magic[8]; uint32_t stamp[4]; uint64_t id[2] = {0, 0};
+  const bool head_ok = fread(magic, 1, 8, f) == 8 && fread(stamp, 1, sizeof stamp, f) == sizeof stamp && fread(id, 1, sizeof id, f) == sizeof id;
+  fclose(f);
+  if (!head_ok || memcmp(magic, FLAT_MAGIC, 8) != 0 || memcmp(stamp, FLAT_STAMP, sizeof stamp) != 0 || id[1] == 0) return 0;
+  uint64_t size = 0, hash = 0;
+  if (!source_identity_of_file(index_path, &size, &hash)) return 0;
+  return size == id[0] && hash == id[1] ? 1 : 0;
+}
+
 namespace {
-int load_index_impl(const char* path, int threads, int want_compact, double compact_load, kamd_index** out);
+int load_index_impl(const char* path, int threads, int want_compact, double compact_load, kamd_index** out, bool layout_requested);
 }
 extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) {
   // the layout of the k-mer table from the environment: KAMD_TABLE_LAYOUT = wide (default) | compact | auto, KAMD_TABLE_LOAD
@@ -349,14 +399,14 @@ extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) 
   }
   double compact_load = 0.0;
   if (const char* e = getenv("KAMD_TABLE_LOAD")) compact_load = atof(e);
-  return load_index_impl(path, threads, want_compact, compact_load, out);
+  return load_index_impl(path, threads, want_compact, compact_load, out, getenv("KAMD_TABLE_LAYOUT") != nullptr && *getenv("KAMD_TABLE_LAYOUT"));
 }
 extern "C" int kamd_index_load_layout(const char* path, int threads, int layout, double load, kamd_index** out) {
   if (layout != KAMD_TABLE_WIDE && layout != KAMD_TABLE_COMPACT && layout != KAMD_TABLE_AUTO) return kamd::fail(-1, "kamd_index_load_layout: layout must be KAMD_TABLE_WIDE, _COMPACT or _AUTO");
-  return load_index_impl(path, threads, layout, load, out);
+  return load_index_impl(path, threads, layout, load, out, true);
 }
 namespace {
-int load_index_impl(const char* path, int threads, int want_compact, double compact_load_arg, kamd_index** out) {
+int load_index_impl(const char* path, int threads, int want_compact, double compact_load_arg, kamd_index** out, bool layout_requested) {
   if (!out) return kamd::fail(-1, "kamd_index_load: null output pointer");
   *out = nullptr;
   if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -366,7 +416,18 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
     char magic[8] = {0};
     const bool flat = f && fread(magic, 1, 8, f) == 8 && memcmp(magic, FLAT_MAGIC, 7) == 0;   // (any version: load_flat refuses the others by name)
     if (f) fclose(f);
-    if (flat) return load_flat(path, threads, out);
+    if (flat) {
+      if (int rc = load_flat(path, threads, out)) return rc;
+      // a flattened file carries its layout: a caller that named one (kamd_index_load_layout, KAMD_TABLE_LAYOUT) and is handed the
+      // other must hear about it -- the compact table is asked for to fit a footprint, the wide one to reproduce a measurement
+      const uint32_t have = (*out)->layout;
+      if (layout_requested && ((want_compact == KAMD_TABLE_COMPACT && have != kamd::LAYOUT_COMPACT) || (want_compact == KAMD_TABLE_WIDE && have != kamd::LAYOUT_WIDE))) {
+        delete *out; *out = nullptr;
+        return kamd::fail(-3, std::string("flattened index file holds the ") + (have == kamd::LAYOUT_COMPACT ? "compact" : "wide") + " k-mer table but the " +
+                          (want_compact == KAMD_TABLE_COMPACT ? "compact" : "wide") + " one was asked for (flatten the kallisto index with that layout, or load the index itself): " + path);
+      }
+      return 0;
+    }
   }
   std::vector<uint8_t> buf;
   {
@@ -379,6 +440,7 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   }
   Cursor c{buf.data(), buf.size()};
   std::unique_ptr<kamd_index> ix(new kamd_index);
+  ix->src_size = buf.size(); ix->src_hash = source_hash(buf.data(), buf.size());
   // KAMD_INDEX_TIMING=1: seconds per phase on stderr
   const bool timing = getenv("KAMD_INDEX_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();

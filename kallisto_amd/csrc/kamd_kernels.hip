@@ -5255,6 +5255,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -5273,6 +5274,7 @@ int rccl_load() {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
   a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
@@ -5412,6 +5414,22 @@ extern "C" int kamd_comm_create_callbacks(kamd_ctx* c, int32_t rank, int32_t wor
   m->ctx = c; m->device = c->device; m->rank = rank; m->world = world; m->cb = *cb; m->user = user; m->use_cb = true;
   c->comms.push_back(m);
   *out = m;
+  return 0;
+}
+extern "C" int kamd_comm_info(const kamd_comm* m, int32_t* rank, int32_t* world, int32_t* ranks_seen, int32_t* backend) {
+  if (!m) return kamd::fail(-1, "kamd_comm_info: null argument");
+  if (rank) *rank = m->rank;
+  if (world) *world = m->world;
+  if (backend) *backend = m->nccl ? 1 : m->use_cb ? 2 : 0;
+  if (ranks_seen) {
+    *ranks_seen = m->world;
+    if (m->nccl && g_rccl.CommCount) {
+      int n = 0;
+      const ncclResult_t r = g_rccl.CommCount(m->nccl, &n);
+      if (r) return rccl_fail(r, "ncclCommCount");
+      *ranks_seen = n;
+    }
+  }
   return 0;
 }
 extern "C" void kamd_comm_destroy(kamd_comm* m) {

@@ -240,12 +240,17 @@ int main(int argc, char** argv) {
   const auto t_start = std::chrono::steady_clock::now();
   // The index is read and flattened (pure host work, seconds) from the first moment on -- under the start of the HIP runtime, the
   // creation of the contexts and the pinning of the text rings.  The flattened tables written by `kallisto_amd_quant flatten` are used
-  // when they lie beside the index (<index>.kamd, not older than it); the kallisto index stays the source of truth.
+  // when they lie beside the index (<index>.kamd) and say they were written from it; the kallisto index stays the source of truth.
   std::string index_path = opt.index;
   {
     struct stat si, sf;
     const std::string flat = opt.index + ".kamd";
-    if (!getenv("KAMD_NO_FLAT_INDEX") && stat(opt.index.c_str(), &si) == 0 && stat(flat.c_str(), &sf) == 0 && sf.st_mtime >= si.st_mtime) index_path = flat;
+    // ... and only when the file says it was written from exactly this index (size + hash of its head and tail: a replaced index keeps
+    // neither, whatever its mtime); a stale or foreign .kamd is ignored and the index itself is flattened
+    if (!getenv("KAMD_NO_FLAT_INDEX") && stat(opt.index.c_str(), &si) == 0 && stat(flat.c_str(), &sf) == 0) {
+      if (kamd_flat_index_matches(flat.c_str(), opt.index.c_str()) == 1) index_path = flat;
+      else std::cerr << "[index] " << flat << " was not written from " << opt.index << " (or by another version): ignored" << std::endl;
+    }
   }
   kamd_index* idx = nullptr;
   kamd_index_view v{};
@@ -256,7 +261,7 @@ int main(int argc, char** argv) {
     auto load = [&](const std::string& p) { return opt.table_layout < 0 ? kamd_index_load(p.c_str(), load_threads, &idx) : kamd_index_load_layout(p.c_str(), load_threads, opt.table_layout, 0.0, &idx); };
     load_rc = load(index_path);
     if (load_rc && index_path != opt.index) {   // a flattened file picked up beside the index that does not load (another format version, damaged): the index itself
-      if (opt.verbose) std::cerr << "[index] " << index_path << " ignored: " << kamd_last_error() << std::endl;
+      std::cerr << "[index] " << index_path << " ignored: " << kamd_last_error() << std::endl;
       index_path = opt.index;
       load_rc = load(index_path);
     }
@@ -323,7 +328,7 @@ int main(int argc, char** argv) {
     // (one GPU only: records merged from several GPUs have no input order -- like the reference at -t > 1)
     if (opt.bootstrap > 0 && n_gpus == 1 && kamd_ec_track_order(ctx, 1) != 0) { done(-1, kamd_last_error()); return; }
     index_ready_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    if (opt.verbose && index_path != opt.index) std::cerr << "[index] using the flattened tables of " << index_path << std::endl;
+    if (index_path != opt.index) std::cerr << "[index] using the flattened tables of " << index_path << std::endl;
     if (opt.verbose) std::cerr << "[index] k-mer table: " << (v.table_layout ? "compact" : "wide") << " layout, " << v.slots_per_bucket << " slots per 64-byte line, "
                                << (v.n_buckets + v.pad_buckets) * 64 / 1000000 << " MB, load " << (double)v.n_kmers / (double)(v.n_buckets * v.slots_per_bucket) << std::endl;
     if (opt.verbose) std::cerr << "[timing] index file read + flattened in " << index_load_s << " s, on the device after " << index_ready_s << " s" << std::endl;

@@ -73,3 +73,34 @@ def test_merge_is_identity_without_process_group():
     o = torch.tensor([0], dtype=torch.int64)
     w2, o2 = merge_ec_state(d, w, o)
     assert torch.equal(w, w2) and torch.equal(o, o2) and d.tolist() == [0, 1, 2, 3, 4]
+
+
+def _bare_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KAMD_BENCH_SHARE_GPU",
+                                                           "KAMD_BENCH_BACKEND", "KAMD_COMM")}
+    env.update(extra)
+    return env
+
+
+def test_bench_self_launch_refuses_without_enough_gpus():
+    """`python bench.py --gpus 2` from a bare shell is its own launcher; on a box with fewer GPUs than ranks it says so (exit code 2, nothing
+    on stdout) instead of exiting with 'launch with torch.distributed.run' as it did through round 3."""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=_bare_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300)
+    assert p.returncode == 2, p.stderr.decode()[-2000:]
+    assert b"GPU(s)" in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="GPU present: test_gpu_multirank runs the real thing")
+def test_bench_self_launch_starts_ranks_and_reports_their_failure():
+    """no GPU here: the launcher must start both ranks under torch.distributed.run (they die at the device), find no result line, and
+    return a non-zero exit code with nothing on stdout -- never hang, never print a half line"""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genes", "50", "--pairs", "1000"], cwd=ROOT,
+                       env=_bare_env(KAMD_BENCH_SHARE_GPU="1", KAMD_BENCH_LAUNCH_TIMEOUT_S="240"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0 and not p.stdout.strip()
+    err = p.stderr.decode()
+    assert "launching 2 ranks" in err and "no result line from the ranks" in err

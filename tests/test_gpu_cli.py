@@ -176,6 +176,47 @@ def test_cli_with_a_flattened_index(tmp_path):
     common.assert_abundance_close(np.array([float(r[3]) for r in outs[1]]), np.array([float(r[3]) for r in outs[0]]), "est_counts", rel=1e-9, floor=1e-9)
 
 
+def test_cli_picks_up_only_its_own_flattened_index(tmp_path):
+    """`<index>.kamd` beside an index is used when -- and only when -- the file says it was written from that index (size + hash of head and
+    tail, kamd_flat_index_matches).  A .kamd of ANOTHER index dropped beside it with a newer mtime (what `cp -p` / a restored artifact
+    leaves behind) must be ignored: the run quantifies against the index that was named.  Both runs leave through the ordinary teardown
+    (KAMD_SLOW_EXIT=1: kamd_ctx_destroy / kamd_index_free instead of the front-end's _exit shortcut) and must still exit 0."""
+    import shutil
+    meta, idx_path, r1, r2 = common.load_case("human_pe")
+    other_idx = common.load_case("yeast_se")[1]
+    f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    _fastq(f1, r1); _fastq(f2, r2)
+    idx = str(tmp_path / "index.idx")
+    shutil.copy(idx_path, idx)
+    env = dict(os.environ, KAMD_SLOW_EXIT="1")
+
+    def run(name):
+        out = str(tmp_path / name)
+        p = subprocess.run([EXE, "quant", "-i", idx, "-o", out, "--plaintext", f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()
+        return _table(os.path.join(out, "abundance.tsv"))[1], p.stderr.decode()
+    base, err = run("plain")
+    assert "flattened tables" not in err
+    assert subprocess.run([EXE, "flatten", "-i", idx, "-o", idx + ".kamd"]).returncode == 0
+    own, err = run("own")
+    assert "using the flattened tables of" in err
+    assert [r[:3] for r in own] == [r[:3] for r in base]
+    common.assert_abundance_close(np.array([float(r[3]) for r in own]), np.array([float(r[3]) for r in base]), "est_counts", rel=1e-9, floor=1e-9)
+    assert subprocess.run([EXE, "flatten", "-i", other_idx, "-o", idx + ".kamd"]).returncode == 0    # a foreign file, newer than the index
+    foreign, err = run("foreign")
+    assert "ignored" in err and "using the flattened tables of" not in err
+    assert [r[:3] for r in foreign] == [r[:3] for r in base]
+    common.assert_abundance_close(np.array([float(r[3]) for r in foreign]), np.array([float(r[3]) for r in base]), "est_counts", rel=1e-9, floor=1e-9)
+    # --kmer-table compact with a wide .kamd beside the index: the compact table is built from the index itself
+    assert subprocess.run([EXE, "flatten", "-i", idx, "-o", idx + ".kamd"]).returncode == 0
+    out = str(tmp_path / "compact")
+    p = subprocess.run([EXE, "quant", "-i", idx, "-o", out, "--plaintext", "--verbose", "--kmer-table", "compact", f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()
+    assert "was asked for" in p.stderr.decode() and "ignored" in p.stderr.decode()
+    rows = _table(os.path.join(out, "abundance.tsv"))[1]
+    assert [r[:3] for r in rows] == [r[:3] for r in base]
+
+
 @pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("human_pe", "pe_l180"), ("ref_test_pe", "pe_boot"), ("yeast_se", "se"), ("mosaic_pe", "pe_union"),
                                           ("mosaic_pe", "pe_nojump_rf"), ("mosaic_pe", "se_union_overhang"), ("dlist_pe", "pe")])
 def test_cli_several_ranks_on_one_device(case, variant, tmp_path):

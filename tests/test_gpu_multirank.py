@@ -124,26 +124,39 @@ def test_rccl_world_of_one():
 
 
 def test_bench_two_ranks_on_one_gpu_with_parity(tmp_path):
-    """bench.py --gpus 2 with both ranks on the one GPU of the box (KAMD_BENCH_SHARE_GPU=1, collectives as callbacks over gloo): the
-    multi-rank flow of the bench end to end -- reads sharded, kamd_ec_allreduce, kamd_em_run_comm, both scaling modes -- and its parity
-    leg: the merged result must be what ONE rank computes from all ranks' reads (EC multiset and flens identical, same EM rounds)."""
+    """`python bench.py --gpus 2` from a bare shell (no launcher around it: the script starts its own ranks under torch.distributed.run) with
+    both ranks on the one GPU of the box (KAMD_BENCH_SHARE_GPU=1, collectives as callbacks over gloo): the multi-rank flow of the bench end
+    to end -- reads sharded, kamd_ec_allreduce, kamd_em_run_comm, both scaling modes -- and its parity leg: the merged result must be what
+    ONE rank computes from all ranks' reads (EC multiset and flens identical, same EM rounds).  Exactly one line comes back."""
     import json
-    import socket
     import subprocess
     import sys
     import bench
     if not os.path.exists(bench.REF_BIN):
         pytest.skip("oracle/_ref/kallisto not built: cannot create the index of the bench workload")
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, KAMD_BENCH_SHARE_GPU="1", KAMD_BENCH_BACKEND="gloo", KAMD_BENCH_CACHE=str(tmp_path / "cache"))
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genes", "1500", "--pairs", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--multi-parity"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    env = dict(os.environ, KAMD_BENCH_SHARE_GPU="1", KAMD_BENCH_CACHE=str(tmp_path / "cache"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KAMD_BENCH_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genes", "1500", "--pairs", "400000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--multi-parity"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    out = p.stdout.decode()
-    line = json.loads(out[out.index('{"metric"'):out.rindex("}") + 1])
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["other_scaling"]["scaling"] == "strong"
     assert "callbacks" in line["config"]["collective_backend"] and "gloo" in line["config"]["collective_backend"]     # the transport actually used
+    assert line["config"]["n_ranks_seen"] == 2 and line["config"]["launcher"].startswith("self")
     mp = line["multi_rank_parity"]
     assert mp["ok"], mp
     assert mp["ranks"] == 2 and mp["ec_multiset_equal"] and mp["flens_equal"] and mp["em_rounds"][0] == mp["em_rounds"][1]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """without the share-one-GPU switch the self-launcher must say why it cannot start instead of hanging in a rendezvous"""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KAMD_BENCH_SHARE_GPU")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 2 and b"GPU(s)" in p.stderr and not p.stdout.strip()

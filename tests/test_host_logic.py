@@ -319,9 +319,24 @@ def test_flattened_index_file_round_trip(case, layout, tmp_path, monkeypatch):
     a = api.Index(idx_path)
     flat = str(tmp_path / "index.kamd")
     a.save(flat)
-    monkeypatch.setenv("KAMD_TABLE_LAYOUT", "wide")   # (a flattened file carries its layout: the variable only speaks to the builder)
+    # a flattened file carries its layout: with no layout named it loads as what it is; naming the OTHER layout is an error, not a silent
+    # hand-over of the wrong table (the compact one is asked for to fit a footprint)
+    monkeypatch.delenv("KAMD_TABLE_LAYOUT")
     b = api.Index(flat)
+    other = "wide" if layout == "compact" else "compact"
+    monkeypatch.setenv("KAMD_TABLE_LAYOUT", other)
+    with pytest.raises(api.KallistoAmdError, match="was asked for"):
+        api.Index(flat)
+    monkeypatch.setenv("KAMD_TABLE_LAYOUT", "auto")
+    assert api.Index(flat).view.table_layout == a.view.table_layout
     monkeypatch.setenv("KAMD_TABLE_LAYOUT", layout)
+    assert api.Index(flat).view.table_layout == a.view.table_layout
+    # the file knows which kallisto index it was written from (what the front-end asks before it picks up <index>.kamd beside an index)
+    L = api.load_library()
+    assert L.kamd_flat_index_matches(flat.encode(), idx_path.encode()) == 1
+    other_idx = common.load_case("yeast_se" if case != "yeast_se" else "human_pe")[1]
+    assert L.kamd_flat_index_matches(flat.encode(), other_idx.encode()) == 0
+    assert L.kamd_flat_index_matches(idx_path.encode(), idx_path.encode()) == 0 and L.kamd_flat_index_matches(str(tmp_path / "none").encode(), idx_path.encode()) == 0
     va, vb = a.view, b.view
     S = va.slots_per_bucket
     assert (va.table_layout, S) == ((1, 4) if layout == "compact" else (0, 3))
