@@ -127,6 +127,153 @@ def write_fastq_fast(path, reads: np.ndarray):
         f.write(line.tobytes())
 
 
+class FastqSpool:
+    """The WHOLE input of a run as FASTQ files, written while the reads are generated on the device: the text of a chunk is assembled
+    there (`@r<9 digits>`, the read, `+`, L x `I`: what write_fastq_fast writes), copied to the host and appended by one writer thread per
+    file.  These files are what the reference reads in the full-size parity leg and what the front-end reads in the full-size end-to-end legs."""
+
+    def __init__(self, directory: str, paired: bool, L: int):
+        import queue
+        import threading
+        os.makedirs(directory, exist_ok=True)
+        self.dir, self.L, self.n = directory, L, 0
+        self.files = [os.path.join(directory, f"full_{i + 1}.fq") for i in range(2 if paired else 1)]
+        self.rec_bytes = 2 + 9 + 1 + L + 1 + 2 + L + 1
+        self.error = None
+        self._q = [queue.Queue(maxsize=2) for _ in self.files]
+        self._th = [threading.Thread(target=self._writer, args=(i,), daemon=True) for i in range(len(self.files))]
+        for t in self._th:
+            t.start()
+        self._tmpl = None
+
+    def _writer(self, i):
+        try:
+            with open(self.files[i], "wb") as f:
+                while True:
+                    a = self._q[i].get()
+                    if a is None:
+                        return
+                    f.write(memoryview(a.numpy()).cast("B"))
+        except Exception as e:   # noqa: BLE001
+            self.error = str(e)
+            while self._q[i].get() is not None:
+                pass
+
+    def add(self, mates):
+        """mates: the (m, L) uint8 device tensors of this chunk, one per file"""
+        import torch
+        m, L, dev = mates[0].shape[0], self.L, mates[0].device
+        if self._tmpl is None or self._tmpl.shape[0] < m:
+            t = torch.empty((m, self.rec_bytes), dtype=torch.uint8, device=dev)
+            t[:, 0] = ord("@"); t[:, 1] = ord("r"); t[:, 11] = 10; t[:, 12 + L] = 10; t[:, 13 + L] = ord("+"); t[:, 14 + L] = 10
+            t[:, 15 + L:15 + 2 * L] = ord("I"); t[:, 15 + 2 * L] = 10
+            self._tmpl = t
+            self._pow = (10 ** torch.arange(8, -1, -1, device=dev, dtype=torch.int64))[None, :]
+        ids = torch.arange(self.n, self.n + m, device=dev, dtype=torch.int64)[:, None]
+        digits = ((ids // self._pow) % 10 + 48).to(torch.uint8)
+        for i, r in enumerate(mates):
+            t = self._tmpl[:m]
+            t[:, 2:11] = digits
+            t[:, 12:12 + L] = r
+            self._q[i].put(t.cpu())     # (a copy: the template is reused for the next mate / chunk)
+        self.n += m
+
+    def close(self):
+        for q in self._q:
+            q.put(None)
+        for t in self._th:
+            t.join()
+        self._tmpl = None
+        if self.error:
+            raise RuntimeError("writing the full-size FASTQ files failed: " + self.error)
+        return self.files
+
+    def remove(self):
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+class FullSizeParity:
+    """BASELINE config #3 at its FULL size against the unmodified reference: every pair of the run goes through
+    `oracle/_ref/dump_ec quant -t <cores>` (the reference's ProcessReads on all cores, then its single-threaded EMAlgorithm::run), and
+      * the EC multiset of the WHOLE run must equal the GPU's (EC counts do not depend on the number of threads: MinCollector::increaseCount
+        under the mutex of MasterProcessor::update, src/ProcessReads.cpp:424-481, src/MinCollector.cpp:251-269);
+      * the reference's EM on ITS ECs (src/EMAlgorithm.h:112-223; effective lengths from the fragment-length sample of the run in input
+        order = the -t 1 sample, which the prefix parity check pins, handed over with --flens because a multi-threaded run's own sample
+        depends on the schedule) must stop in the same round as the GPU's and agree on est_counts / TPM within BASELINE.json's 1e-4.
+    start() launches the reference in the background (about 0.5 min of all cores + 1.5 min of one), finish() waits and compares."""
+
+    def __init__(self, idx_path, files, res, threads, extra=()):
+        from oracle import oracle as O
+        self.res, self.threads, self.t0 = res, threads, time.time()
+        self.tmp = os.path.join(CACHE, f"full_parity_{os.getpid()}")
+        os.makedirs(self.tmp, exist_ok=True)
+        fl = os.path.join(self.tmp, "gpu.flens")
+        with open(fl, "w") as f:
+            for i, c in enumerate(np.asarray(res.flens).tolist()):
+                if c:
+                    f.write(f"{i} {c}\n")
+        self.out, self.err = open(os.path.join(self.tmp, "ref.out"), "wb"), open(os.path.join(self.tmp, "ref.err"), "wb")
+        cmd = [os.path.join(O.REF_DIR, "dump_ec"), "quant", idx_path, str(threads), *extra, "--flens", fl, *files]
+        self.proc = subprocess.Popen(cmd, stdout=self.out, stderr=self.err)
+        # beside it, on one more core: the oracle's restatement of EMAlgorithm::run (oracle/kallisto_oracle.c ko_em_run) on the GPU's OWN
+        # equivalence classes and effective lengths -- same matrix, so the tolerance is the association of FP64 sums: 1e-9
+        import threading
+        self.oracle_em = {}
+
+        def _oracle_em():
+            try:
+                t0 = time.time()
+                alpha, _, rounds = O.em_run(res.ecs.ec_off, res.ecs.ec_ids, res.ecs.counts, res.eff_lens, len(res.eff_lens))
+                big = alpha > 1e-6
+                rel = float(np.max(np.abs(res.est_counts[big] - alpha[big]) / alpha[big])) if big.any() else 0.0
+                small = float(np.max(np.abs(res.est_counts[~big] - alpha[~big]))) if (~big).any() else 0.0
+                self.oracle_em = {"rounds": [int(res.em_rounds), int(rounds)], "est_counts_max_rel_err": rel, "max_abs_err_below_1e-6": small,
+                                  "seconds": round(time.time() - t0, 1), "ok": bool(int(rounds) == int(res.em_rounds) and rel <= 1e-9 and small <= 1e-12)}
+            except Exception as e:   # noqa: BLE001
+                self.oracle_em = {"ok": False, "error": str(e)[:200]}
+        self._th = threading.Thread(target=_oracle_em, daemon=True)
+        self._th.start()
+
+    def finish(self, timeout_s=1200.0):
+        from oracle import oracle as O
+        try:
+            try:
+                rc = self.proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()
+                self.proc.wait()
+                return {"ok": False, "error": f"the reference did not finish within {timeout_s:.0f} s"}
+            ref_s = time.time() - self.t0
+            self.out.close(); self.err.close()
+            if rc != 0:
+                return {"ok": False, "error": f"dump_ec exit code {rc}: " + open(self.err.name, errors="replace").read()[-300:]}
+            ref = O.parse_ref_dump(open(self.out.name).read(), open(self.err.name, errors="replace").read())
+            res = self.res
+            gm = res.ecs.multiset()
+            rep = O.ref_parity_report(ref, gm, res.flens, res.eff_lens, res.est_counts, res.alpha_before_zeroes)
+            # (flens_equal compares with the sample the reference drew itself at -t > 1: schedule-dependent, reported, not gated)
+            out = {"pairs_or_reads": int(res.n_processed), "reference": f"oracle/_ref/dump_ec quant -t {self.threads} --flens <the run's sample in input order> "
+                   "(unmodified reference: ProcessReads on all cores, EMAlgorithm::run on its own ECs)",
+                   "n_processed_ref": int(ref["nproc"]), "n_ecs": [len(gm), len(ref["ecs"])], "ec_multiset_equal": bool(gm == ref["ecs"]),
+                   "n_pseudoaligned": [int(res.n_pseudoaligned), int(sum(ref["ecs"].values()))],
+                   "eff_length_equal": rep["eff_length_equal"], "em_rounds": [int(res.em_rounds), ref["rounds"]],
+                   "est_counts_max_rel_err_tpm_ge_1e-3": rep["est_counts_max_rel_err_tpm_ge_1e-3"],
+                   "tpm_max_rel_err_tpm_ge_1e-3": rep["tpm_max_rel_err_tpm_ge_1e-3"], "tpm_max_abs_err_below_floor": rep["tpm_max_abs_err_below_floor"],
+                   "zero_pattern_equal": rep["zero_pattern_equal"], "own_sample_of_the_threaded_reference_equal": rep["flens_equal"],
+                   "reference_seconds": round(ref_s, 1), "tolerance": "EC multiset and eff_length identical, same EM round count, est_counts / tpm <= 1e-4"}
+            self._th.join(timeout=max(1.0, timeout_s - (time.time() - self.t0)))
+            out["oracle_em_on_the_gpus_ecs"] = self.oracle_em or {"ok": False, "error": "did not finish"}
+            out["ok"] = bool(out["oracle_em_on_the_gpus_ecs"].get("ok") and
+                             out["ec_multiset_equal"] and out["eff_length_equal"] and out["em_rounds"][0] == out["em_rounds"][1] and
+                             int(ref["nproc"]) == int(res.n_processed) and rep["est_counts_max_rel_err_tpm_ge_1e-3"] <= 1e-4 and
+                             rep["tpm_max_rel_err_tpm_ge_1e-3"] <= 1e-4 and rep["tpm_max_abs_err_below_floor"] <= 1e-7 and rep["zero_pattern_equal"])
+            return out
+        except Exception as e:   # noqa: BLE001
+            return {"ok": False, "error": str(e)[:300]}
+        finally:
+            shutil.rmtree(self.tmp, ignore_errors=True)
+
+
 def cpu_reference_baseline(idx_path, r1: np.ndarray, r2, threads: int, extra=()):
     """Time the unmodified reference on the host cores: `kallisto quant -t threads` on the sample.  The clock starts when
     the index has been loaded (the '[quant] running in' line) and stops at process exit; the stage markers the reference
@@ -302,7 +449,7 @@ def write_bgzf(src, dst, procs):
         fo.write(_bgzf_block(b""))
 
 
-def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, gz_items=4_000_000):
+def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, gz_items=4_000_000, full_files=None, full_items=0):
     """The C++ front-end (kallisto_amd/kallisto_amd_quant) from FASTQ files on disk: plain text, BGZF and gzip.  Wall-clock per stage
     from its --verbose timing lines; never part of `value`."""
     exe = os.path.join(ROOT, "kallisto_amd", "kallisto_amd_quant")
@@ -351,6 +498,11 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         if have_flat:
             runs.append(("plain_flattened_index", flat, plain, n, seq))
             runs.append(("plain_flattened_index_overlapped", flat, plain, n, {}))
+        if full_files:   # the configuration the metric names, all of it, from files (the bench's FastqSpool wrote them)
+            runs.append(("plain_full_size", idx_path, full_files, full_items, seq))
+            runs.append(("plain_full_size_overlapped", idx_path, full_files, full_items, {}))
+            if have_flat:
+                runs.append(("plain_full_size_flattened_index_overlapped", flat, full_files, full_items, {}))
         for kind, ipath, files, cnt, env in runs:
             cmd = [exe, "quant", "-i", ipath, "-o", os.path.join(tmp, "out_" + kind), "-t", str(threads), "--plaintext", "--verbose", *extra, *files]
             t0 = time.time()
@@ -433,7 +585,7 @@ def bench_line_digest(d):
     keep["roofline"] = {k: (d.get("roofline") or {}).get(k) for k in ("kernel", "achieved", "peak", "frac", "launch_ms")}
     cb = d.get("cpu_baseline") or {}
     keep["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
-    for k in ("parity_check", "parity_check_tail"):
+    for k in ("parity_check", "parity_check_tail", "parity_check_full_size"):
         pcheck = d.get(k)
         if isinstance(pcheck, dict):
             keep[k] = {kk: vv for kk, vv in pcheck.items() if not isinstance(vv, (list, dict)) or kk == "n_pseudoaligned"}
@@ -549,6 +701,10 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the child run of BASELINE config #2 (yeast, single-end) that the default one-GPU run of config #3 appends")
     ap.add_argument("--no-compact-leg", action="store_true", help="skip the side leg that repeats the steps on the compact k-mer table (N = 1 only)")
     ap.add_argument("--table-load", type=float, default=None, help="load factor of the compact table (KAMD_TABLE_LOAD, default 0.6)")
+    ap.add_argument("--full-parity", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1: the WHOLE input also goes through the unmodified reference (written as FASTQ while it is generated; oracle/_ref/dump_ec on all "
+                         "cores in the background): EC multiset of the whole run, EM round count and abundances at full size; the same files feed the full-size "
+                         "end-to-end legs.  auto = on for the full BASELINE configuration, off for reduced ones")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "LOCAL_RANK" not in os.environ:
         # `python bench.py --gpus N` from a bare shell: this process becomes the launcher of its own N ranks
@@ -625,10 +781,21 @@ def main():
             want_head = max(want_head, min(args.parity_sample, n_gen))
     want_tail = min(args.parity_sample, n_gen) if (rank == 0 and world == 1 and args.parity_sample) else 0
     head1, head2, have_head = [], [], 0
+    spool = None
+    full_size = genes == (20000 if paired else 6000) and n_arg == n_default
+    if rank == 0 and world == 1 and (args.full_parity == "on" or (args.full_parity == "auto" and full_size)) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
+        need = n_gen * per * (2 * L + 16) + (8 << 30)
+        os.makedirs(CACHE, exist_ok=True)
+        if shutil.disk_usage(CACHE).free > need:
+            spool = FastqSpool(os.path.join(CACHE, f"full_{os.getpid()}"), paired, L)
+        else:
+            log(f"full-size parity skipped: {shutil.disk_usage(CACHE).free / 1e9:.0f} GB free under {CACHE}, {need / 1e9:.0f} GB wanted")
     t0 = time.time()
     for s in range(0, n_gen, chunk):
         m = min(chunk, n_gen - s)
         r1, r2 = sim.draw(m)
+        if spool is not None:
+            spool.add([r1, r2] if paired else [r1])
         inter = torch.stack([r1, r2], 1).reshape(2 * m, L) if paired else r1  # mate 1, mate 2 interleaved (ProcessReads.cpp:1034-1041)
         w, l = ctx.pack_reads(inter, L)
         words[s * per * rec:(s + m) * per * rec] = w
@@ -654,8 +821,15 @@ def main():
             e2e_sample = (h1[:k], h2[:k] if paired else None)
         del head1, head2
     torch.cuda.synchronize()
+    full_files = None
+    if spool is not None:
+        try:
+            full_files = spool.close()
+        except Exception as e:   # noqa: BLE001
+            log(str(e))
+            spool.remove(); spool = None
     log(f"{n_gen} synthetic {'PE' if paired else 'SE'}-{L} {'pairs' if paired else 'reads'} generated + packed on the device in "
-        f"{time.time()-t0:.1f}s ({words.numel()*4/1e9:.2f} GB in HBM)")
+        f"{time.time()-t0:.1f}s ({words.numel()*4/1e9:.2f} GB in HBM)" + (f"; the whole input also written as FASTQ ({sum(os.path.getsize(f) for f in full_files)/1e9:.1f} GB)" if full_files else ""))
 
     opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0) if paired else ka.QuantOpts(0, 200.0, 20.0, 0, 0)
     cli_extra = [] if paired else ["--single", "-l", "200", "-s", "20"]
@@ -976,14 +1150,27 @@ def main():
                                    "sample": f"first {k} {unit_name} of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
                                              f"--plaintext {' '.join(cli_extra)}`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
                                              f"{cb['index_load_s']:.1f}s excluded)",
+                                   "index_load_seconds": round(cb["index_load_s"], 2),
+                                   "whole_run_value_including_index_load": round(k / (cb["seconds"] + cb["index_load_s"]) / 1e6, 4),
                                    "pseudoalign_seconds": round(cb["pseudoalign_s"], 2), "em_seconds": round(cb["em_s"], 2),
                                    "pseudoalign_only_value": round(k / max(cb["pseudoalign_s"], 1e-9) / 1e6, 4),
                                    "projected_value_at_full_size": round(n / (n / k * cb["pseudoalign_s"] + cb["em_s"] + (cb["seconds"] - cb["pseudoalign_s"] - cb["em_s"])) / 1e6, 4),
+                                   "projected_whole_run_value_at_full_size": round(n / (n / k * cb["pseudoalign_s"] + cb["em_s"] + (cb["seconds"] - cb["pseudoalign_s"] - cb["em_s"]) + cb["index_load_s"]) / 1e6, 4),
                                    "note": "the reference's EM is single-threaded and independent of the read count; projected_value_at_full_size "
                                            f"scales the threaded pseudoalignment stage to the {n} {unit_name} of the GPU workload and keeps the EM and output time"}
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": rate_unit, "cores": threads, "kind": "reference",
                                    "sample": f"failed: {e}"}
+    full_parity = None
+    if rank == 0 and world == 1 and full_files is not None:
+        # the whole input through the unmodified reference, in the background from here on (all cores for about half a minute, then one)
+        log(f"full-size parity: reference `dump_ec quant -t {min(effective_cpus(), 64)}` on all {n} {unit_name}, in the background ...")
+        try:
+            ctx.reset()
+            fres = ka.quant(ctx, opts, [(words[:n * per * rec], lens[:per * n], n, L)], download_ecs=True)
+            full_parity = FullSizeParity(idx_path, full_files, fres, min(effective_cpus(), 64), cli_extra)
+        except Exception as e:   # noqa: BLE001
+            out["parity_check_full_size"] = {"ok": False, "error": str(e)[:300]}
     if rank == 0 and world == 1 and psample is not None:
         # parity gate: the same reads through the HIP path and through the unmodified reference at -t 1
         ks = psample[0].shape[0]
@@ -1007,16 +1194,6 @@ def main():
             out["pinned_pipeline"]["unit"] = rate_unit
         except Exception as e:
             out["pinned_pipeline"] = {"error": str(e)}
-    if rank == 0 and world == 1 and e2e_sample is not None:
-        log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {unit_name}) ...")
-        ctx.close()   # the front-end is its own process on the same GPU
-        del words, lens
-        torch.cuda.empty_cache()
-        try:
-            out["end_to_end"] = end_to_end(idx_path, e2e_sample[0], e2e_sample[1], paired, min(effective_cpus(), 64), cli_extra)
-            out["end_to_end"]["host"] = {"cpus_available": effective_cpus(), "processors_visible": os.cpu_count()}
-        except Exception as e:
-            out["end_to_end"] = {"error": str(e)}
     if rank == 0 and compact_dir is not None:
         if time.time() - t_start > budget_s - 60:
             compact_leg = [{"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S)"}]
@@ -1031,6 +1208,24 @@ def main():
         else:
             log("BASELINE config #2 (yeast, single-end) as a child run ...")
             out["config2"] = config2_leg(timeout_s=max(60.0, budget_s + 120 - (time.time() - t_start)))
+    if rank == 0 and world == 1 and e2e_sample is not None:
+        log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {unit_name}) ...")
+        if full_parity is not None:   # (the reference's single-threaded EM may still be running: the end-to-end legs want the host to themselves)
+            log("full-size parity: waiting for the reference ...")
+            out["parity_check_full_size"] = full_parity.finish()
+            full_parity = None
+        ctx.close()   # the front-end is its own process on the same GPU
+        del words, lens
+        torch.cuda.empty_cache()
+        try:
+            out["end_to_end"] = end_to_end(idx_path, e2e_sample[0], e2e_sample[1], paired, min(effective_cpus(), 64), cli_extra, full_files=full_files, full_items=n)
+            out["end_to_end"]["host"] = {"cpus_available": effective_cpus(), "processors_visible": os.cpu_count()}
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)}
+    if full_parity is not None:
+        out["parity_check_full_size"] = full_parity.finish()
+    if spool is not None:
+        spool.remove()
     if rank == 0:
         if multi_parity is not None:
             out["multi_rank_parity"] = multi_parity

@@ -298,11 +298,34 @@ def ref_index(fasta: str, out_idx: str, threads: int = 8, k: int = 31) -> None:
                            fasta], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def ref_dump_quant(idx: str, files, threads: int = 1, extra=()):
-    """Run the reference through the dump_ec harness; returns dict(nproc, ecs, flens, tr=[(len, eff, alpha, abz)], bs)."""
-    cmd = [os.path.join(REF_DIR, "dump_ec"), "quant", idx, str(threads), *extra, *files]
-    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
-    res = {"nproc": 0, "ecs": {}, "flens": np.zeros(MAX_FRAG_LEN, np.uint32), "tr": [], "bs": {}}
+def ref_dump_quant(idx: str, files, threads: int = 1, extra=(), no_em: bool = False, flens=None):
+    """Run the reference through the dump_ec harness; returns dict(nproc, ecs, flens, tr=[(len, eff, alpha, abz)], bs, rounds).
+    no_em: stop behind ProcessReads (ECs and flens only).  flens (array of MAX_FRAG_LEN counts): the reference's EM runs on its own
+    ECs with this fragment-length sample instead of the one it drew (a multi-threaded run's own sample is schedule-dependent)."""
+    import re
+    import tempfile
+    cmd = [os.path.join(REF_DIR, "dump_ec"), "quant", idx, str(threads), *extra]
+    tmp = None
+    if no_em:
+        cmd.append("--no-em")
+    if flens is not None:
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".flens", delete=False)
+        for i, c in enumerate(np.asarray(flens).tolist()):
+            if c:
+                tmp.write(f"{i} {c}\n")
+        tmp.close()
+        cmd += ["--flens", tmp.name]
+    try:
+        pc = subprocess.run([*cmd, *files], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    finally:
+        if tmp is not None:
+            os.unlink(tmp.name)
+    return parse_ref_dump(pc.stdout.decode(), pc.stderr.decode(errors="replace"))
+
+
+def parse_ref_dump(out: str, err: str = "") -> dict:
+    import re
+    res = {"nproc": 0, "ecs": {}, "flens": np.zeros(MAX_FRAG_LEN, np.uint32), "tr": [], "bs": {}, "rounds": None}
     for line in out.splitlines():
         f = line.split()
         if f[0] == "NPROC":
@@ -315,6 +338,9 @@ def ref_dump_quant(idx: str, files, threads: int = 1, extra=()):
             res["tr"].append((int(f[2]), float(f[3]), float(f[4]), float(f[5])))
         elif f[0] == "BS":
             res["bs"].setdefault(int(f[1]), []).append(float(f[3]))
+    m = re.search(r"Expectation-Maximization algorithm ran for ([0-9,]+) rounds", err)
+    if m:
+        res["rounds"] = int(m.group(1).replace(",", ""))
     return res
 
 

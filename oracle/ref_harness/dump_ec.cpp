@@ -4,7 +4,7 @@
 // compiles from /root/reference where it lies).  It exposes the reference's intermediate results, which the
 // `kallisto` CLI never prints, so that the C restatement (oracle/kallisto_oracle.c) and the HIP path can be pinned:
 //
-//   dump_ec quant   <index> <threads> [--single -l L -s S] [--fr|--rf] [--boot B --seed S] <fastq> [<fastq2>]
+//   dump_ec quant   <index> <threads> [--single -l L -s S] [--fr|--rf] [--boot B --seed S] [--no-em] [--flens FILE] <fastq> [<fastq2>]
 //        runs exactly what main.cpp:2632-2689 runs (KmerIndex::load -> ProcessReads -> FLD -> EMAlgorithm::run)
 //        and prints
 //          NPROC <n>                               (ProcessReads return value)
@@ -13,6 +13,13 @@
 //          FLEN <len> <count>                      (non-zero entries of collection.flens)
 //          TR <i> <length> <eff_len %.17g> <alpha %.17g> <alpha_before_zeroes %.17g>
 //          BS <b> <i> <alpha %.17g>                (bootstrap replicates, Bootstrap::run_em, main.cpp:2744-2782)
+//        --no-em: stops behind ProcessReads (NPROC, EC and FLEN lines only) -- the EC multiset does not depend on the number of
+//        threads, so a full-size input can be pseudoaligned on all cores without waiting for the single-threaded EM
+//        --flens FILE ("<len> <count>" per line): the reference's EM runs on ITS OWN equivalence classes but with this fragment-length
+//        sample in place of the one ProcessReads drew (the FLEN lines still print the reference's own).  With more than one thread the
+//        reference's sample -- the first 10 000 qualifying pairs to reach the mutex -- depends on the schedule; handing it the -t 1
+//        sample (which a prefix run pins) makes effective lengths and abundances of a multi-threaded full-size run comparable.
+//        (EMAlgorithm::run's round count goes to stderr, as in the CLI: "... ran for 1,372 rounds".)
 //
 //   dump_ec perread <index> <reads.txt> [--single]
 //        reads.txt: one read per line, or "read1<TAB>read2".  For every line calls KmerIndex::match on each mate and
@@ -48,6 +55,8 @@ static int run_quant(int argc, char** argv) {
   opt.threads = atoi(argv[3]);
   opt.output = "/tmp/dump_ec_out";
   int boot = 0;
+  bool no_em = false;
+  std::string flens_file;
   for (int i = 4; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--single") opt.single_end = true;
@@ -59,6 +68,8 @@ static int run_quant(int argc, char** argv) {
     else if (a == "--no-jump") opt.no_jump = true;
     else if (a == "--union") opt.do_union = true;
     else if (a == "--boot") boot = atoi(argv[++i]);
+    else if (a == "--no-em") no_em = true;
+    else if (a == "--flens") flens_file = argv[++i];
     else if (a == "--seed") opt.seed = strtoull(argv[++i], nullptr, 10);
     else opt.files.push_back(a);
   }
@@ -69,6 +80,31 @@ static int run_quant(int argc, char** argv) {
   MinCollector collection(index, opt);
   MasterProcessor MP(index, opt, collection, model);
   int64_t nproc = ProcessReads(MP, opt);
+
+  printf("NPROC %lld\n", (long long)nproc);
+  {
+    std::map<std::vector<uint32_t>, uint64_t> m;
+    for (auto& e : index.ecmapinv) {
+      std::vector<uint32_t> v;
+      for (auto t : e.first) v.push_back(t);
+      m[v] += collection.counts[e.second];
+    }
+    for (auto& kv : m) {
+      printf("EC ");
+      for (size_t i = 0; i < kv.first.size(); i++) printf("%s%u", i ? "," : "", kv.first[i]);
+      printf(" %llu\n", (unsigned long long)kv.second);
+    }
+  }
+  for (size_t i = 0; i < collection.flens.size(); i++)
+    if (collection.flens[i]) printf("FLEN %zu %u\n", i, collection.flens[i]);
+  if (no_em) return 0;
+  if (!flens_file.empty()) {
+    std::ifstream ff(flens_file);
+    if (!ff) { fprintf(stderr, "dump_ec: cannot read %s\n", flens_file.c_str()); return 2; }
+    std::fill(collection.flens.begin(), collection.flens.end(), 0u);
+    size_t len; uint32_t cnt;
+    while (ff >> len >> cnt) if (len < collection.flens.size()) collection.flens[len] = cnt;
+  }
 
   std::vector<uint32_t> fld;
   if (opt.fld == 0.0) {
@@ -82,20 +118,6 @@ static int run_quant(int argc, char** argv) {
   EMAlgorithm em(collection.counts, index, collection, fl_means, opt);
   em.run(10000, 50, true, false);
 
-  printf("NPROC %lld\n", (long long)nproc);
-  std::map<std::vector<uint32_t>, uint64_t> m;
-  for (auto& e : index.ecmapinv) {
-    std::vector<uint32_t> v;
-    for (auto t : e.first) v.push_back(t);
-    m[v] += collection.counts[e.second];
-  }
-  for (auto& kv : m) {
-    printf("EC ");
-    for (size_t i = 0; i < kv.first.size(); i++) printf("%s%u", i ? "," : "", kv.first[i]);
-    printf(" %llu\n", (unsigned long long)kv.second);
-  }
-  for (size_t i = 0; i < collection.flens.size(); i++)
-    if (collection.flens[i]) printf("FLEN %zu %u\n", i, collection.flens[i]);
   for (size_t i = 0; i < em.alpha_.size(); i++)
     printf("TR %zu %u %.17g %.17g %.17g\n", i, index.target_lens_[i], em.eff_lens_[i], em.alpha_[i],
            i < em.alpha_before_zeroes_.size() ? em.alpha_before_zeroes_[i] : -1.0);

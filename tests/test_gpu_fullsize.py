@@ -7,7 +7,10 @@ conservation laws of the algorithm:
     TPM sums to 1e6, a bootstrap resample keeps N;
   * a 20 k-pair prefix against the oracle, bit-exact;
   * a 200 k-pair prefix against the UNMODIFIED REFERENCE at -t 1 (oracle/_ref/dump_ec, prebuilt, travels with the snapshot):
-    EC multiset, flens and eff_length identical, est_counts / TPM within 1e-4 -- the tolerance BASELINE.json states.
+    EC multiset, flens and eff_length identical, est_counts / TPM within 1e-4 -- the tolerance BASELINE.json states;
+  * ALL 30 M pairs against the unmodified reference on all cores (bench.FullSizeParity): the EC multiset of the whole run identical, the
+    reference's EM on its 618 k ECs stops in the same round and agrees within 1e-4, the oracle's EM on the GPU's own ECs within 1e-9;
+  * the last 200 k pairs as the final batch of a run over all of them against the reference (bench.tail_parity).
 The index is built by the reference binary (oracle/_ref/kallisto, travels with the repo); skipped when it is absent."""
 import os
 
@@ -37,16 +40,27 @@ def world():
     words = torch.empty(n * 2 * rec, dtype=torch.int32, device=dev)
     lens = torch.empty(n * 2, dtype=torch.int16, device=dev)
     prefix = None
+    # the whole input as FASTQ too (13 GB), when the reference harness is here and the disk has room: test_whole_run_against_reference
+    import shutil
+    spool = None
+    os.makedirs(bench.CACHE, exist_ok=True)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")) and shutil.disk_usage(bench.CACHE).free > n * 2 * 216 + (8 << 30):
+        spool = bench.FastqSpool(os.path.join(bench.CACHE, f"fullsize_test_{os.getpid()}"), True, L)
     for s in range(0, n, 2_000_000):
         r1, r2 = sim.draw(2_000_000)
+        if spool is not None:
+            spool.add([r1, r2])
         if s == 0:
             prefix = (r1[:200_000].cpu().numpy(), r2[:200_000].cpu().numpy())
         w, l = ctx.pack_reads(torch.stack([r1, r2], 1).reshape(-1, L), L)
         words[s * 2 * rec:(s + 2_000_000) * 2 * rec] = w
         lens[2 * s:2 * (s + 2_000_000)] = l
     del sim
-    yield dict(ka=ka, ctx=ctx, index=index, idx_path=idx_path, words=words, lens=lens, n=n, L=L, rec=rec, prefix=prefix)
+    files = spool.close() if spool is not None else None
+    yield dict(ka=ka, ctx=ctx, index=index, idx_path=idx_path, words=words, lens=lens, n=n, L=L, rec=rec, prefix=prefix, files=files)
     ctx.close()
+    if spool is not None:
+        spool.remove()
 
 
 def _run(w, ranges):
@@ -128,3 +142,44 @@ def test_prefix_against_reference(world):
     assert rep["tpm_max_abs_err_below_floor"] <= 1e-7 and rep["zero_pattern_equal"], rep
     assert rep["ok"]
 
+
+
+def test_whole_run_against_reference(world):
+    """BASELINE config #3 at full size: every one of the 30 M pairs through the unmodified reference (dump_ec on all cores; its EM with the
+    run's input-order fragment-length sample, src/EMAlgorithm.h:112-223): EC multiset of the WHOLE run, effective lengths and EM round
+    count identical, est_counts / TPM within 1e-4; and the oracle's EM on the GPU's own equivalence classes within 1e-9."""
+    import bench
+    w = world
+    if w["files"] is None:
+        pytest.skip("oracle/_ref/dump_ec not built or no room for 13 GB of FASTQ")
+    ctx, ka, n = w["ctx"], w["ka"], w["n"]
+    ctx.reset()
+    res = ka.quant(ctx, ka.QuantOpts(1, 0.0, 0.0, 0, 0), [(w["words"], w["lens"], n, w["L"])], download_ecs=True)
+    rep = bench.FullSizeParity(w["idx_path"], w["files"], res, min(bench.effective_cpus(), 64)).finish()
+    assert rep.get("ec_multiset_equal") and rep["n_processed_ref"] == n, rep
+    assert rep["eff_length_equal"] and rep["em_rounds"][0] == rep["em_rounds"][1] and rep["em_rounds"][0] > 50, rep
+    assert rep["est_counts_max_rel_err_tpm_ge_1e-3"] <= 1e-4 and rep["tpm_max_rel_err_tpm_ge_1e-3"] <= 1e-4 and rep["zero_pattern_equal"], rep
+    assert rep["oracle_em_on_the_gpus_ecs"]["ok"], rep
+    assert rep["ok"], rep
+
+
+def test_tail_against_reference(world):
+    """the LAST 200 k pairs of the 30 M, pseudoaligned as the final batch of a run over all of them (record stream recycled, tuple table
+    regrown): whole run minus the run without them must be the reference's EC multiset of those pairs at -t 1"""
+    import bench
+    import torch
+    from kallisto_amd.synth_gpu import ReadSimulator
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
+        pytest.skip("oracle/_ref/dump_ec not built")
+    w = world
+    ctx, ka, n, L, rec = w["ctx"], w["ka"], w["n"], w["L"], w["rec"]
+    # the last chunk's reads again (same generator, same seed, same chunks as the fixture)
+    cat, tlens, _ = bench.prepare_workload("human", 20000, True)
+    sim = ReadSimulator(cat, tlens, torch.device("cuda", 0), seed=4242, read_len=L)
+    for s in range(0, n, 2_000_000):
+        r1, r2 = sim.draw(2_000_000)
+    k = 200_000
+    t1, t2 = r1[-k:].cpu().numpy(), r2[-k:].cpu().numpy()
+    del sim, r1, r2
+    rep = bench.tail_parity(ctx, ka.QuantOpts(1, 0.0, 0.0, 0, 0), w["idx_path"], w["words"], w["lens"], n, 2, rec, L, t1, t2)
+    assert rep["ok"] and rep["counts_never_decrease"] and rep["ec_multiset_equal"], rep
