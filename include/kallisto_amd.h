@@ -154,6 +154,8 @@ typedef struct {
                                   workgroup-sized groups.  -1 = one size class only (every group a workgroup; the default: on the
                                   human-sized workload most entries sit in components of more than a thousand entries, the two kernels
                                   side by side were slower -- profiles/README.md) */
+  int32_t em_reg_slices;       /* component-local form: 1 (default) = a wavefront keeps the index words and segment constants of its first slice
+                                  per direction in registers for the rounds of a launch (split lengths up to 32), 2 = everything from LDS */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);

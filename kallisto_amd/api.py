@@ -54,7 +54,7 @@ class _Stats(C.Structure):
 class Tuning(C.Structure):
     """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
     _fields_ = [(n, C.c_int32) for n in ("text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
-                                         "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form", "align_chunks", "em_small_nnz")]
+                                         "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form", "align_chunks", "em_small_nnz", "em_reg_slices")]
 
 
 EM_FORMS = {"streamed": 1, "csr": 2, "local": 3}

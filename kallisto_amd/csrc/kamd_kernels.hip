@@ -2435,7 +2435,7 @@ void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
   t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
-  t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1;
+  t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1; t->em_reg_slices = 1;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
@@ -2455,6 +2455,7 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.em_row_lanes == 2 || n.em_row_lanes == 4 || n.em_row_lanes == 8) t->em_row_lanes = n.em_row_lanes;
   if (n.em_fin_blocks >= 64) t->em_fin_blocks = n.em_fin_blocks;
   if (n.align_chunks != 0) t->align_chunks = n.align_chunks < 0 ? -1 : std::min(n.align_chunks, 64);
+  if (n.em_reg_slices == 1 || n.em_reg_slices == 2) t->em_reg_slices = n.em_reg_slices;
 }
 // experiments: the same knobs from the environment, read once when a context is created
 void tuning_from_env(kamd_tuning* t) {
@@ -2474,6 +2475,7 @@ void tuning_from_env(kamd_tuning* t) {
   geti("KAMD_EM_SMALL_NNZ", &n.em_small_nnz);
   geti("KAMD_DEDUP_FORM", &n.dedup_form);
   geti("KAMD_EM_SPLIT_LEN", &n.em_split_len);
+  onoff("KAMD_EM_REG", &n.em_reg_slices);
   geti("KAMD_EM_K", &n.em_entries_per_lane);
   onoff("KAMD_EM_WINDOWED", &n.em_windowed);
   onoff("KAMD_EM_GRAPH", &n.em_graph);
@@ -3764,6 +3766,202 @@ __device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsi
   }
   for (u32 i = tid; i < nT; i += nthr) { alpha_out[t0 + i] = al[i]; a_out[t0 + i] = av[i]; }
 }
+// ---- the same rounds with every wavefront's FIRST slice of each direction held in registers ------------------------------------------
+// Between two barriers a wavefront of k_em_sell used to walk a chain of dependent LDS trips for its slice: descriptor -> index words ->
+// gathers -> (metadata word -> scan) -> segment constants -> store; every trip costs 200-350 clocks under load, and with 9 + 4.4 slices
+// per group most of the 16 wavefronts had nothing to do while the slowest one set the pace (profiles/r03_em_phase_clocks.txt: slowest
+// wavefront 2 330 / 3 770 clocks per pass, mean 1 080).  Nothing on that chain but the gathered values changes from round to round: a
+// wavefront owns the same slices for the whole launch.  So the index words of the slice (W x 64 bits per lane: em_split_len <= 4 W
+// entries), its metadata word and the constants of the segment a lane finishes (count and weight count of a row; single, eff and the
+// lane's own alpha / a of a transcript) are loaded ONCE per launch, and a pass is: issue the gathers, add, (segmented scan), finish,
+// store -- one LDS round trip.  That makes short slices cheap, so the split length can fall (8: every wavefront of the workgroup owns
+// a slice in both passes and walks at most two index words).  Slices beyond the first of a wavefront (a group with more than 16 per
+// direction) take the LDS path above.  The sums are formed in the same order as there: identical bits.
+template <int NQ>
+__device__ __forceinline__ double ems_reg_sum(const u64* w, const double* src) {
+  // gathers in batches of two index words (eight values in flight per lane: sixteen registers), added in entry order
+  double S = 0.0;
+#pragma unroll
+  for (int q0 = 0; q0 < NQ; q0 += 2) {
+    constexpr int B = 2;
+    double v[4 * B];
+#pragma unroll
+    for (int q = 0; q < B; q++) {
+      if (q0 + q >= NQ) break;
+      u32 lo = (u32)w[q0 + q], hi = (u32)(w[q0 + q] >> 32);
+      // (opaque to the optimiser: otherwise the gather addresses, which do not change from round to round, are hoisted out of the
+      // round loop into registers of their own -- 64 of them for W = 8 -- and the kernel spills; unpacking them again is three VALU
+      // operations per gather next to an LDS round trip)
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      v[4 * q] = src[lo & 0xFFFFu]; v[4 * q + 1] = src[lo >> 16]; v[4 * q + 2] = src[hi & 0xFFFFu]; v[4 * q + 3] = src[hi >> 16];
+    }
+#pragma unroll
+    for (int i = 0; i < 4 * B; i++) if (q0 + i / 4 < NQ) S += v[i];   // (entries beyond the slice's width point at the zero slot: + 0.0 changes no bit of a sum >= 0)
+  }
+  return S;
+}
+template <int W, int NQ = 1>
+__device__ __forceinline__ double ems_reg_slice_sum(const u64* w, u32 nq, const double* src) {   // nq: words in use, wave-uniform, 1 .. W
+  if constexpr (NQ >= W) return ems_reg_sum<W>(w, src);
+  else { if (nq <= (u32)NQ) return ems_reg_sum<NQ>(w, src); return ems_reg_slice_sum<W, NQ + 1>(w, nq, src); }
+}
+// the LDS path of ems_group_rounds_reg (slices beyond a wavefront's first): one index word at a time -- few registers, rarely run
+__device__ __forceinline__ double ems_slice_sum_narrow(const u64* e, u32 width, const double* src) {
+  double S = 0.0;
+  for (u32 j = 0; j < width; j += 4) {   // (entries beyond the width point at the zero slot)
+    const u64 w = e[(size_t)(j >> 2) * 64];
+    const u32 lo = (u32)w, hi = (u32)(w >> 32);
+    const double v0 = src[lo & 0xFFFFu], v1 = src[lo >> 16], v2 = src[hi & 0xFFFFu], v3 = src[hi >> 16];
+    S += v0; S += v1; S += v2; S += v3;
+  }
+  return S;
+}
+template <int W>
+__device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, unsigned char* smem, u32 tid, u32 nthr, const double* alpha, const double* a,
+                                                     double* alpha_out, double* a_out, int n_rounds, int clamp, int* s_hist, long long* clk = nullptr) {
+  namespace L = kamd_em_sell;
+  const int lane = lane_id();
+  const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = nthr >> 6;
+  const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
+  const u32 rs0 = P.rslice_base[g], nrs = P.rslice_base[g + 1] - rs0, cs0 = P.cslice_base[g], ncs = P.cslice_base[g + 1] - cs0;
+  const u64 re0 = P.rell_base[g], ce0 = P.cell_base[g];
+  const u32 nru = (u32)(P.rell_base[g + 1] - re0), ncu = (u32)(P.cell_base[g + 1] - ce0);
+  // the layout kamd_em_sell::group_bytes() prices (the same as ems_group_rounds)
+  double* s_al0 = reinterpret_cast<double*>(smem);
+  double* s_a0 = s_al0 + (nT + 1); double* s_al1 = s_a0 + (nT + 1); double* s_a1 = s_al1 + (nT + 1);
+  double* s_single = s_a1 + (nT + 1); double* s_eff = s_single + nT; double* s_g = s_eff + nT;
+  u64* s_cw = reinterpret_cast<u64*>(s_g + (nR + 1));
+  u32* s_rdesc = reinterpret_cast<u32*>(s_cw + nR); u32* s_cdesc = s_rdesc + 2 * nrs;
+  uint16_t* s_rell = reinterpret_cast<uint16_t*>(s_cdesc + 2 * ncs); uint16_t* s_cell = s_rell + ((nru + 1) & ~1u);
+  for (u32 i = tid; i < nT; i += nthr) {
+    double al = alpha[t0 + i], av = a[t0 + i];
+    if (clamp && al < 1e-7 / 10.0) { al = 0.0; av = 0.0; }   // the final round reads alpha < alpha_limit / 10 as 0 (:212-221)
+    s_al0[i] = al; s_a0[i] = av; s_single[i] = P.single[t0 + i]; s_eff[i] = P.eff[t0 + i];
+  }
+  for (u32 i = tid; i < nR; i += nthr) s_cw[i] = P.cw[r0 + i];
+  for (u32 i = tid; i < 2 * nrs; i += nthr) s_rdesc[i] = P.rdesc[2 * (u64)rs0 + i];
+  for (u32 i = tid; i < 2 * ncs; i += nthr) s_cdesc[i] = P.cdesc[2 * (u64)cs0 + i];
+  for (u32 i = tid; i < nru; i += nthr) { const uint16_t v = P.rell[re0 + i]; s_rell[i] = v == (uint16_t)L::SELL_PAD ? (uint16_t)nT : v; }
+  for (u32 i = tid; i < ncu; i += nthr) { const uint16_t v = P.cell[ce0 + i]; s_cell[i] = v == (uint16_t)L::SELL_PAD ? (uint16_t)nR : v; }
+  if (tid == 0) { s_al0[nT] = s_a0[nT] = 0.0; s_g[nR] = 0.0; }
+  __syncthreads();
+  // ---- this wavefront's own slices: everything that does not change from round to round goes into registers ----
+  struct Own { u64 w[W]; u32 nq, seg; int reach; bool has, meta, fin; };
+  auto take = [&](const u32* desc, const uint16_t* ell, u32 n_slices, u32 n_segs, u32 zero) {
+    Own o;
+    o.has = wv < n_slices; o.nq = 1; o.seg = 0; o.reach = 0; o.meta = false; o.fin = false;
+    if (o.has && (((desc[2 * wv + 1] & 0xFFFFu) + 3u) >> 2) > (u32)W) o.has = false;   // a slice wider than the registers hold: the LDS path takes it
+    const u64 padw = (u64)zero * 0x0001000100010001ULL;
+#pragma unroll
+    for (int q = 0; q < W; q++) o.w[q] = padw;
+    if (o.has) {
+      const u32 d0 = desc[2 * wv], d1 = desc[2 * wv + 1];
+      o.meta = (d0 & L::DESC_META) != 0;
+      const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
+      o.nq = (u32)__builtin_amdgcn_readfirstlane((int)((width + 3u) >> 2));
+      const u64* e = reinterpret_cast<const u64*>(ell + off + (o.meta ? 2 * L::SELL_META_WORDS : 0u)) + lane;
+#pragma unroll
+      for (int q = 0; q < W; q++) if ((u32)q < o.nq) o.w[q] = e[(size_t)q * 64];
+      o.seg = (d1 >> 16) + (u32)lane; o.fin = o.seg < n_segs;
+      if (o.meta) {
+        const u32 w = reinterpret_cast<const u32*>(ell + off)[lane];
+        o.reach = (int)((w >> 16) & 0x7Fu); o.seg = w & 0xFFFFu; o.fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
+      }
+      if (!o.fin) o.seg = 0;
+    }
+    return o;
+  };
+  const Own ro = take(s_rdesc, s_rell, nrs, nR, nT);
+  const Own co = take(s_cdesc, s_cell, ncs, nT, nR);
+  u32 r_cnt = 0, r_wc = 0;
+  if (ro.fin) { const u64 cwv = s_cw[ro.seg]; r_cnt = (u32)cwv; r_wc = (u32)(cwv >> 32); }
+  double c_single = 0.0, c_eff = 1.0, c_at = 0.0, c_cur = 0.0;
+  if (co.fin) { c_single = s_single[co.seg]; c_eff = s_eff[co.seg]; c_at = s_a0[co.seg]; c_cur = s_al0[co.seg]; }
+  const u32 r_next = ro.has ? wv + NW : wv, c_next = co.has ? wv + NW : wv;   // first slice of this wavefront on the LDS path
+  // alpha and a are updated IN PLACE: the rows pass only reads a, the columns pass reads and writes a[t] / alpha[t] in the one lane that
+  // finishes transcript t, and a barrier lies between the passes on either side -- so the gather addresses are the same in every round
+  // (the second copies the LDS layout prices stay unused)
+  double* const al = s_al0; double* const av = s_a0;
+  (void)s_al1; (void)s_a1;
+  for (int r = 0; r < n_rounds; r++) {
+    const bool tick = clk && r == EMS_CLK_ROUND && lane == 0;
+    long long w0 = 0;
+    if (tick) { clk[0] = clock64(); w0 = wall_clock64(); }
+    // rows: S_e over the row's transcripts, then g_e = count_e / S_e (rows the reference skips get 0: count 0, :133-135;
+    // denom below denorm_min, :156-158)
+    if (ro.has) {
+      if (tick) clk[12] = clock64();
+      double S = ems_reg_slice_sum<W>(ro.w, ro.nq, av);
+      if (tick) { clk[13] = clock64(); clk[14] = (long long)((ro.nq * 4u) | (ro.meta ? 0x10000u : 0u)); }
+      if (ro.meta) S = pm_scan_seg(S, ro.reach, lane);
+      if (ro.fin) s_g[ro.seg] = (r_cnt == 0 || (double)r_wc * S < 4.9406564584124654e-324) ? 0.0 : (double)r_cnt / S;
+      if (tick) clk[15] = clock64();
+    }
+    for (u32 s = r_next; s < nrs; s += NW) {
+      const u32 d0 = s_rdesc[2 * s], d1 = s_rdesc[2 * s + 1];
+      const bool meta = (d0 & L::DESC_META) != 0;
+      const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
+      double S = ems_slice_sum_narrow(reinterpret_cast<const u64*>(s_rell + off + (meta ? 2 * L::SELL_META_WORDS : 0u)) + lane, width, av);
+      u32 seg = (d1 >> 16) + (u32)lane; bool fin = seg < nR;
+      if (meta) {
+        const u32 w = reinterpret_cast<const u32*>(s_rell + off)[lane];
+        S = pm_scan_seg(S, (int)((w >> 16) & 0x7Fu), lane);
+        seg = w & 0xFFFFu; fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
+      }
+      if (fin) {
+        const u64 cwv = s_cw[seg];
+        const u32 cnt = (u32)cwv, wc = (u32)(cwv >> 32);
+        s_g[seg] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+      }
+    }
+    if (tick) clk[1] = clock64();
+    __syncthreads();
+    if (tick) clk[2] = clock64();
+    // columns: next_t = single_t + a_t * sum of g over the transcript's rows, and the convergence test of :176-199
+    int ch = 0;
+    auto finish_col = [&](u32 seg, double at, double cur, double single, double eff, double acc, double& nx_out, double& a_out_v) {
+      const double nx = single + at * acc;
+      // :177-179 `fabs(next - alpha) / next > 1e-2`, without the division unless the quotient is within 1e-7 of the threshold (the
+      // quotient's rounding error is 1e-16: outside that band the product test decides the same way as the reference's quotient)
+      const double dd = fabs(nx - cur);
+      bool moved = dd > 1.0000001e-2 * nx;
+      if (dd > 0.9999999e-2 * nx && !moved) moved = dd / nx > 1e-2;
+      nx_out = nx; a_out_v = nx / eff;
+      al[seg] = nx; av[seg] = a_out_v;
+      return nx > 1e-2 && moved;
+    };
+    if (co.has) {
+      if (tick) clk[8] = clock64();
+      double acc = ems_reg_slice_sum<W>(co.w, co.nq, s_g);
+      if (tick) { clk[9] = clock64(); clk[10] = (long long)((co.nq * 4u) | (co.meta ? 0x10000u : 0u)); }
+      if (co.meta) acc = pm_scan_seg(acc, co.reach, lane);
+      bool chg = false;
+      if (co.fin) chg = finish_col(co.seg, c_at, c_cur, c_single, c_eff, acc, c_cur, c_at);
+      ch += __popcll(__ballot(chg));
+      if (tick) clk[11] = clock64();
+    }
+    for (u32 s = c_next; s < ncs; s += NW) {
+      const u32 d0 = s_cdesc[2 * s], d1 = s_cdesc[2 * s + 1];
+      const bool meta = (d0 & L::DESC_META) != 0;
+      const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
+      double acc = ems_slice_sum_narrow(reinterpret_cast<const u64*>(s_cell + off + (meta ? 2 * L::SELL_META_WORDS : 0u)) + lane, width, s_g);
+      u32 seg = (d1 >> 16) + (u32)lane; bool fin = seg < nT;
+      if (meta) {
+        const u32 w = reinterpret_cast<const u32*>(s_cell + off)[lane];
+        acc = pm_scan_seg(acc, (int)((w >> 16) & 0x7Fu), lane);
+        seg = w & 0xFFFFu; fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
+      }
+      bool chg = false;
+      if (fin) { double nx, an; chg = finish_col(seg, av[seg], al[seg], s_single[seg], s_eff[seg], acc, nx, an); }
+      ch += __popcll(__ballot(chg));
+    }
+    if (ch && lane == 0) atomicAdd(&s_hist[r], ch);
+    if (tick) clk[3] = clock64();
+    __syncthreads();
+    if (tick) { clk[4] = clock64(); clk[5] = (long long)(nrs | (ncs << 16)); clk[6] = (long long)(nru | ((u64)ncu << 32)); clk[7] = wall_clock64() - w0; }
+  }
+  for (u32 i = tid; i < nT; i += nthr) { alpha_out[t0 + i] = al[i]; a_out[t0 + i] = av[i]; }
+}
 // The stop rule of EMAlgorithm::run (:202-205) on the change counts of the PREVIOUS chunk of rounds: a chunk that was launched
 // speculatively behind the one the run stops in has nothing to do (its input stays the checkpoint the host replays from).
 // Block 0 also hands the previous chunk's counts to the host (pinned, mapped memory the host polls: no stream synchronisation per chunk).
@@ -3786,8 +3984,10 @@ __device__ __forceinline__ bool ems_prev_stopped(const EmsPrev& v, int* s_flag) 
   return *s_flag != 0;
 }
 // one workgroup per group (the large size class, or every group when there is only one class): groups g_first + blockIdx.x
-template <bool CLK, int EXP = 0>
-__global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, u32 g_first, const double* alpha, const double* a, double* alpha_out, double* a_out,
+// W > 0: the register-resident form (ems_group_rounds_reg) for split lengths up to 4 W; W = 0: everything out of LDS
+// (two workgroups of 16 wavefronts per CU = 8 wavefronts per SIMD = 64 VGPRs: the register-resident forms are held to that)
+template <bool CLK, int EXP = 0, int W = 0>
+__global__ __launch_bounds__(EMS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(W >= 4 ? 4 : 8))) void k_em_sell(EmSellDev P, u32 g_first, const double* alpha, const double* a, double* alpha_out, double* a_out,
                                                            int n_rounds, int clamp, int* hist, EmsPrev prev, long long* clk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
   __shared__ int s_hist[EML_MAX_ROUNDS];
@@ -3795,8 +3995,9 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) void k_em_sell(EmSellDev P, u32 g_fi
   if (ems_prev_stopped(prev, &s_stop)) return;
   if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
   __syncthreads();
-  ems_group_rounds<false, EXP>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist,
-                          CLK ? clk + ((size_t)blockIdx.x * (EMS_MAX_BLOCK / 64) + (threadIdx.x >> 6)) * EMS_CLK_WORDS : nullptr);
+  long long* my_clk = CLK ? clk + ((size_t)blockIdx.x * (EMS_MAX_BLOCK / 64) + (threadIdx.x >> 6)) * EMS_CLK_WORDS : nullptr;
+  if constexpr (W > 0) ems_group_rounds_reg<W>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
+  else ems_group_rounds<false, EXP>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
   __syncthreads();
   if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
@@ -4366,6 +4567,7 @@ struct SellCache {
 struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0, team_bytes = 0; int block = 256;
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int exp = 0;   // exp: timing experiment (KAMD_EM_EXP)
+  int reg_words = 0;   // index words per lane and direction the kernel keeps in registers (0: the form that reads everything from LDS)
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr; double* d_out = nullptr;
   std::vector<double> h_alpha; int err = 0;
   const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
@@ -4390,7 +4592,11 @@ struct EmSellGpu {
     if (fork && (hipEventRecord(ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return -104;
     if (n_big) {
 #define KAMD_EMS_LAUNCH(C, E) hipLaunchKernelGGL((k_em_sell<C, E>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
-      if (clk) KAMD_EMS_LAUNCH(true, 0);
+#define KAMD_EMS_LAUNCH_REG(C, W) hipLaunchKernelGGL((k_em_sell<C, 0, W>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
+      if (reg_words == 2) { if (clk) KAMD_EMS_LAUNCH_REG(true, 2); else KAMD_EMS_LAUNCH_REG(false, 2); }
+      else if (reg_words == 4) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4); else KAMD_EMS_LAUNCH_REG(false, 4); }
+      else if (reg_words == 8) { if (clk) KAMD_EMS_LAUNCH_REG(true, 8); else KAMD_EMS_LAUNCH_REG(false, 8); }
+      else if (clk) KAMD_EMS_LAUNCH(true, 0);
       else switch (exp) {
         case 1: KAMD_EMS_LAUNCH(false, 1); break;
         case 3: KAMD_EMS_LAUNCH(false, 3); break;
@@ -4399,6 +4605,7 @@ struct EmSellGpu {
         default: KAMD_EMS_LAUNCH(false, 0);
       }
 #undef KAMD_EMS_LAUNCH
+#undef KAMD_EMS_LAUNCH_REG
     }
     EmsPrev prev_w = prev;
     if (n_big) prev_w.host_hist = nullptr;   // (one kernel reports the previous chunk's counts to the host: the workgroup kernel if it runs)
@@ -4438,9 +4645,22 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
   if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, d_eff_new, M, 1.0 / (double)P.T);
   HIPC(hipGetLastError());
   lds = (size_t)P.max_group_bytes;
+  // the register-resident form holds the index words of a wavefront's slices in registers: 2 / 4 / 8 words for split lengths up to
+  // 8 / 16 / 32 (a longer split length, a timing experiment or KAMD_EM_REG=0 take the form that reads everything from LDS)
+  reg_words = 0;
+  {
+    const int cap = std::min(64, std::max(1, c->tune.em_split_len));
+    if (c->tune.em_reg_slices == 1 && !getenv("KAMD_EM_EXP")) reg_words = cap <= 8 ? 2 : cap <= 16 ? 4 : cap <= 32 ? 8 : 0;
+  }
   if (P.n_groups > P.n_small) {
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (const char* e = getenv("KAMD_EM_EXP")) {
       exp = atoi(e);
       HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -211,7 +211,8 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
-@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local_one_class", "local_small40", "local_all_small", "hub"])
+@pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
+                               "local_all_small", "hub"])
 def test_em_forms_agree_with_oracle(k, ka):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -224,8 +225,10 @@ def test_em_forms_agree_with_oracle(k, ka):
     tune = {}
     if isinstance(k, str) and k.startswith("local"):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
+        # (blocks of 256 lanes = 4 wavefronts on groups of a dozen slices: most slices take the LDS path of the register-resident kernel,
+        # the first of every wavefront its registers; split lengths 8 / 16 / 32 = 2 / 4 / 8 index words per lane in registers)
         tune = dict(em_form="local", em_local_block={"local": 256, "local512": 512}.get(k, 1024), em_group_div=64,
-                    em_split_len=8 if k == "local1024s8" else 32)
+                    em_split_len={"local1024s8": 8, "local1024s16": 16}.get(k, 32), em_reg_slices=k != "local_lds_only")
         # size classes of the groups: the default (one class: every group a workgroup), components of <= 384 entries one wavefront
         # each, a limit that splits this matrix's components between the two kernels, and everything in wavefront-sized groups
         if k == "local_one_class":
@@ -286,6 +289,16 @@ def test_em_is_bit_reproducible(ka):
             outs.append(ctx.em_run(eff, csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32))))
         finally:
             ctx.close()
+    # the register-resident kernel and the one that reads everything from LDS form every sum in the same order: identical bits
+    for split in (8, 32):
+        ctx = ka.Context(0)
+        try:
+            ctx.tune(em_form="local", em_local_block=1024, em_group_div=64, em_split_len=split, em_reg_slices=False)
+            a_l, z_l, r_l = ctx.em_run(eff, csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32)))
+        finally:
+            ctx.close()
+        a_r, z_r, r_r = outs[0] if split == 8 else outs[2]
+        assert r_l == r_r and np.array_equal(a_l.view(np.uint64), a_r.view(np.uint64)) and np.array_equal(z_l.view(np.uint64), z_r.view(np.uint64)), split
     (a0, z0, r0), (a1, z1, r1), (a2, z2, r2) = outs
     assert r0 == r1 == r2
     assert np.array_equal(a0.view(np.uint64), a1.view(np.uint64)) and np.array_equal(z0.view(np.uint64), z1.view(np.uint64))
