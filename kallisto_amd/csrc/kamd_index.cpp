@@ -391,11 +391,15 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
 }
 extern "C" int kamd_index_load(const char* path, int threads, kamd_index** out) {
   // the layout of the k-mer table from the environment: KAMD_TABLE_LAYOUT = wide (default) | compact | auto, KAMD_TABLE_LOAD
-  int want_compact = KAMD_TABLE_WIDE;
+  // (default since round 4: auto.  Measured on MI355X, profiles/r04_gencode_size_table_layouts.json: at GENCODE size -- 130.6 M k-mers --
+  // kernel A takes 13.9 ms on the wide table (5.6 GB) and 11.7 ms on the compact one at a load of 0.6 (3.5 GB); at config #3's 56.8 M
+  // k-mers 10.43 wide, 10.29 compact at 0.5, 10.55 at 0.6)
+  int want_compact = KAMD_TABLE_AUTO;
   if (const char* e = getenv("KAMD_TABLE_LAYOUT")) {
     if (!strcmp(e, "compact")) want_compact = KAMD_TABLE_COMPACT;
     else if (!strcmp(e, "auto")) want_compact = KAMD_TABLE_AUTO;
-    else if (strcmp(e, "wide") != 0 && *e) return kamd::fail(-1, std::string("KAMD_TABLE_LAYOUT: wide, compact or auto expected, not ") + e);
+    else if (!strcmp(e, "wide")) want_compact = KAMD_TABLE_WIDE;
+    else if (*e) return kamd::fail(-1, std::string("KAMD_TABLE_LAYOUT: wide, compact or auto expected, not ") + e);
   }
   double compact_load = 0.0;
   if (const char* e = getenv("KAMD_TABLE_LOAD")) compact_load = atof(e);
@@ -506,7 +510,10 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
   // The layout (kamd_core.h): wide = 3 slots of 20 bytes per line at a load of 0.5; compact = 4 slots of 16 bytes at a load of 0.6
   // (or the caller's): KAMD_TABLE_COMPACT is an error when a field does not fit, KAMD_TABLE_AUTO builds the wide one then.
-  const double compact_load = (compact_load_arg >= 0.2 && compact_load_arg <= 0.9) ? compact_load_arg : 0.6;
+  // load factor when the caller names none: 0.5 while that table stays under the 2.4 GB up to which dependent random reads run at full
+  // rate on MI355X (profiles/README.md), 0.6 beyond (fewer bytes beat fewer lines per probe there)
+  const double default_load = (double)ix->n_kmers * (64.0 / kamd::COMPACT_SLOTS) / 0.5 <= 2.4e9 ? 0.5 : 0.6;
+  const double compact_load = (compact_load_arg >= 0.2 && compact_load_arg <= 0.9) ? compact_load_arg : default_load;
   bool compact = want_compact != KAMD_TABLE_WIDE;
   const uint64_t nb_wide = std::max<uint64_t>(16, (ix->n_kmers * 2 + kamd::BUCKET_SLOTS - 1) / kamd::BUCKET_SLOTS);  // load factor 0.5 over 3-slot buckets
   uint64_t S = compact ? kamd::COMPACT_SLOTS : kamd::BUCKET_SLOTS;

@@ -3777,28 +3777,43 @@ __device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsi
 // store -- one LDS round trip.  That makes short slices cheap, so the split length can fall (8: every wavefront of the workgroup owns
 // a slice in both passes and walks at most two index words).  Slices beyond the first of a wavefront (a group with more than 16 per
 // direction) take the LDS path above.  The sums are formed in the same order as there: identical bits.
+// the values of NB index words (4 NB entries) gathered at once
+template <int NB>
+__device__ __forceinline__ void ems_reg_gather(const u64* w, const double* src, double* v) {
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    u32 lo = (u32)w[q], hi = (u32)(w[q] >> 32);
+    // (opaque to the optimiser: otherwise the gather addresses, which do not change from round to round, are hoisted out of the
+    // round loop into registers of their own -- 64 of them for W = 8 -- and the kernel spills; unpacking them again is three VALU
+    // operations per gather next to an LDS round trip)
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    v[4 * q] = src[lo & 0xFFFFu]; v[4 * q + 1] = src[lo >> 16]; v[4 * q + 2] = src[hi & 0xFFFFu]; v[4 * q + 3] = src[hi >> 16];
+  }
+}
 template <int NQ>
 __device__ __forceinline__ double ems_reg_sum(const u64* w, const double* src) {
-  // gathers in batches of two index words (eight values in flight per lane: sixteen registers), added in entry order
-  double S = 0.0;
+  // One or two index words: eight values in flight, added in entry order (the two-word form stays inside 64 registers and forms the sums
+  // exactly as the LDS form does).  The wider forms run one workgroup per CU and have 128 registers: four words (sixteen values) at a
+  // time, each batch summed as a balanced tree -- the chain of dependent additions is what a lone wavefront waits for once the gathers
+  // have landed.  The order of the additions is fixed by the layout alone: reproducible to the bit, but not the LDS form's bits.
+  if constexpr (NQ <= 2) {
+    double v[4 * NQ];
+    ems_reg_gather<NQ>(w, src, v);
+    double S = 0.0;
 #pragma unroll
-  for (int q0 = 0; q0 < NQ; q0 += 2) {
-    constexpr int B = 2;
-    double v[4 * B];
+    for (int i = 0; i < 4 * NQ; i++) S += v[i];   // (entries beyond the slice's width point at the zero slot: + 0.0 changes no bit of a sum >= 0)
+    return S;
+  } else {
+    constexpr int NB = NQ < 4 ? NQ : 4;
+    double v[4 * NB];
+    ems_reg_gather<NB>(w, src, v);
 #pragma unroll
-    for (int q = 0; q < B; q++) {
-      if (q0 + q >= NQ) break;
-      u32 lo = (u32)w[q0 + q], hi = (u32)(w[q0 + q] >> 32);
-      // (opaque to the optimiser: otherwise the gather addresses, which do not change from round to round, are hoisted out of the
-      // round loop into registers of their own -- 64 of them for W = 8 -- and the kernel spills; unpacking them again is three VALU
-      // operations per gather next to an LDS round trip)
-      asm volatile("" : "+v"(lo), "+v"(hi));
-      v[4 * q] = src[lo & 0xFFFFu]; v[4 * q + 1] = src[lo >> 16]; v[4 * q + 2] = src[hi & 0xFFFFu]; v[4 * q + 3] = src[hi >> 16];
-    }
+    for (int st = 1; st < 4 * NB; st *= 2)
 #pragma unroll
-    for (int i = 0; i < 4 * B; i++) if (q0 + i / 4 < NQ) S += v[i];   // (entries beyond the slice's width point at the zero slot: + 0.0 changes no bit of a sum >= 0)
+      for (int i = 0; i + st < 4 * NB; i += 2 * st) v[i] += v[i + st];
+    if constexpr (NQ > 4) return v[0] + ems_reg_sum<NQ - 4>(w + 4, src);
+    else return v[0];
   }
-  return S;
 }
 template <int W, int NQ = 1>
 __device__ __forceinline__ double ems_reg_slice_sum(const u64* w, u32 nq, const double* src) {   // nq: words in use, wave-uniform, 1 .. W

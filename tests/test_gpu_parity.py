@@ -289,7 +289,8 @@ def test_em_is_bit_reproducible(ka):
             outs.append(ctx.em_run(eff, csr=(d(off, np.int64), d(ids, np.int32), d(cnt, np.int32))))
         finally:
             ctx.close()
-    # the register-resident kernel and the one that reads everything from LDS form every sum in the same order: identical bits
+    # the register-resident kernel with two index words per lane (split length 8) and the one that reads everything from LDS form every sum
+    # in the same order: identical bits; the wider register forms add each batch of sixteen values as a tree: equal to rounding
     for split in (8, 32):
         ctx = ka.Context(0)
         try:
@@ -298,7 +299,11 @@ def test_em_is_bit_reproducible(ka):
         finally:
             ctx.close()
         a_r, z_r, r_r = outs[0] if split == 8 else outs[2]
-        assert r_l == r_r and np.array_equal(a_l.view(np.uint64), a_r.view(np.uint64)) and np.array_equal(z_l.view(np.uint64), z_r.view(np.uint64)), split
+        assert r_l == r_r
+        if split == 8:
+            assert np.array_equal(a_l.view(np.uint64), a_r.view(np.uint64)) and np.array_equal(z_l.view(np.uint64), z_r.view(np.uint64))
+        else:
+            common.assert_abundance_close(a_l, a_r, "LDS form vs register form, split length 32", rel=1e-9)
     (a0, z0, r0), (a1, z1, r1), (a2, z2, r2) = outs
     assert r0 == r1 == r2
     assert np.array_equal(a0.view(np.uint64), a1.view(np.uint64)) and np.array_equal(z0.view(np.uint64), z1.view(np.uint64))

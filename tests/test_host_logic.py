@@ -429,7 +429,7 @@ def test_table_layout_variable():
 
 def test_table_layout_through_the_abi_and_the_front_end(tmp_path):
     """kamd_index_load_layout (the layout as an argument instead of KAMD_TABLE_LAYOUT) and `kallisto_amd_quant flatten --kmer-table compact`: the
-    flattened file carries the compact layout and loads as such whatever the environment says."""
+    flattened file carries the compact layout; a caller that names the other one is told so."""
     import subprocess
     from kallisto_amd import api
     p = common.load_case("human_pe")[1]
@@ -445,8 +445,10 @@ def test_table_layout_through_the_abi_and_the_front_end(tmp_path):
     if os.path.exists(exe):
         flat = str(tmp_path / "c.kamd")
         assert subprocess.run([exe, "flatten", "-i", p, "-o", flat, "-t", "3", "--kmer-table", "compact"]).returncode == 0
-        c = api.Index(flat, table_layout="wide")
+        c = api.Index(flat, table_layout="auto")   # (a flattened file is what it is: `auto` takes it, naming the other layout is an error)
         assert c.view.table_layout == 1 and c.num_kmers == a.num_kmers
+        with pytest.raises(api.KallistoAmdError, match="was asked for"):
+            api.Index(flat, table_layout="wide")
         assert subprocess.run([exe, "flatten", "-i", p, "-o", flat, "--kmer-table", "dense"], stderr=subprocess.DEVNULL).returncode != 0
 
 
