@@ -143,8 +143,9 @@ typedef struct {
   int32_t em_row_lanes;        /* CSR form: lanes per row, 2 / 4 (default) / 8 */
   int32_t em_fin_blocks;       /* CSR form: blocks of the final pass (default 1024) */
   int32_t em_local_block;      /* component-local form: threads per workgroup, 128 / 256 / 512 / 1024 (default) */
-  int32_t em_group_div;        /* component-local form: groups hold about nnz / (CUs x this) entries (default 4) */
-  int32_t em_split_len;        /* component-local form: a row / column with more entries is split over several lanes (1..64) */
+  int32_t em_group_div;        /* component-local form: groups hold about nnz / (CUs x this) entries; -1 (default) = the smallest divisor whose
+                                  groups stay under ~10 000 entries (one 16-wavefront workgroup per CU, two rounds of workgroups on config #3) */
+  int32_t em_split_len;        /* component-local form: a row / column with more entries is split over several lanes (1..64; default 16) */
   int32_t dedup_form;          /* record de-duplication: 1 = insert + verify launches, 2 = one launch (tag and owner in one CAS; default) */
   int32_t align_chunks;        /* kamd_pseudoalign: kernel A runs in this many launches, each classified and de-duplicated on a side stream while
                                   the next is matched (default 1 = one launch, everything in sequence: the stages are all bound by the rate of

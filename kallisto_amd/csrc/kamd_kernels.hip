@@ -2234,6 +2234,7 @@ struct kamd_ctx {
   struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0; bool valid = false; } fld_pending;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
+  DevState* state_pin = nullptr;   // pinned staging of the read-backs (sync_state)
   u64 tcap = 0, ccap = 0;        // slots of the tuple table (persistent over the batches of a run) / the candidate table
   DBuf tstore;                   // the tuple store: the distinct tuple records of the run, compact
   bool ttable_clean = false;     // the tuple table holds no entries (just initialised)
@@ -2267,8 +2268,12 @@ namespace { void comm_detach_all(kamd_ctx* c); }
 namespace {
 
 int sync_state(kamd_ctx* c) {
-  HIPC(hipMemcpyAsync(&c->host_state, c->state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+  // through pinned memory: a device-to-host copy into pageable memory is staged by the runtime (a few tens of microseconds per call, and a
+  // step reads its sizes back about twenty times); into pinned memory it is one DMA and the wait for it
+  if (!c->state_pin) HIPC(hipHostMalloc((void**)&c->state_pin, sizeof(DevState), hipHostMallocDefault));
+  HIPC(hipMemcpyAsync(c->state_pin, c->state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  memcpy(&c->host_state, c->state_pin, sizeof(DevState));
   return 0;
 }
 int push_state(kamd_ctx* c) {
@@ -2434,7 +2439,7 @@ namespace {
 void tuning_defaults(kamd_tuning* t) {
   memset(t, 0, sizeof *t);
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
-  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = 4; t->em_split_len = 32; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
+  t->em_form = 3; t->em_local_block = 1024; t->em_group_div = -1; t->em_split_len = 16; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1; t->em_reg_slices = 1;
 }
 // 0 = keep; values outside a field's range are ignored
@@ -2448,6 +2453,7 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.em_local_block == 128 || n.em_local_block == 256 || n.em_local_block == 512 || n.em_local_block == 1024) t->em_local_block = n.em_local_block;
   if (n.em_split_len >= 1 && n.em_split_len <= 64) t->em_split_len = n.em_split_len;
   if (n.em_group_div >= 1 && n.em_group_div <= 1024) t->em_group_div = n.em_group_div;
+  else if (n.em_group_div < 0) t->em_group_div = -1;
   if (n.em_small_nnz != 0) t->em_small_nnz = n.em_small_nnz < 0 ? -1 : std::min(n.em_small_nnz, 4096);
   if (n.em_entries_per_lane != 0) t->em_entries_per_lane = n.em_entries_per_lane < 0 ? -1 : n.em_entries_per_lane;
   if (n.em_windowed == 1 || n.em_windowed == 2) t->em_windowed = n.em_windowed;
@@ -2555,6 +2561,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->em_ev_fork) (void)hipEventDestroy(c->em_ev_fork);
   if (c->em_ev_join) (void)hipEventDestroy(c->em_ev_join);
   if (c->em_pin) (void)hipHostFree(c->em_pin);
+  if (c->state_pin) (void)hipHostFree(c->state_pin);
   c->em_clk.release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
@@ -3766,39 +3773,41 @@ __device__ __forceinline__ void ems_group_rounds(const EmSellDev& P, u32 g, unsi
   }
   for (u32 i = tid; i < nT; i += nthr) { alpha_out[t0 + i] = al[i]; a_out[t0 + i] = av[i]; }
 }
-// ---- the same rounds with every wavefront's FIRST slice of each direction held in registers ------------------------------------------
+// ---- the same rounds with every wavefront's first slices of each direction held in registers ------------------------------------------
 // Between two barriers a wavefront of k_em_sell used to walk a chain of dependent LDS trips for its slice: descriptor -> index words ->
-// gathers -> (metadata word -> scan) -> segment constants -> store; every trip costs 200-350 clocks under load, and with 9 + 4.4 slices
-// per group most of the 16 wavefronts had nothing to do while the slowest one set the pace (profiles/r03_em_phase_clocks.txt: slowest
-// wavefront 2 330 / 3 770 clocks per pass, mean 1 080).  Nothing on that chain but the gathered values changes from round to round: a
-// wavefront owns the same slices for the whole launch.  So the index words of the slice (W x 64 bits per lane: em_split_len <= 4 W
-// entries), its metadata word and the constants of the segment a lane finishes (count and weight count of a row; single, eff and the
-// lane's own alpha / a of a transcript) are loaded ONCE per launch, and a pass is: issue the gathers, add, (segmented scan), finish,
-// store -- one LDS round trip.  That makes short slices cheap, so the split length can fall (8: every wavefront of the workgroup owns
-// a slice in both passes and walks at most two index words).  Slices beyond the first of a wavefront (a group with more than 16 per
-// direction) take the LDS path above.  The sums are formed in the same order as there: identical bits.
-// the values of NB index words (4 NB entries) gathered at once
+// gathers -> (metadata word -> scan) -> segment constants -> store, and most of the 16 wavefronts had nothing to do while the slowest
+// set the pace (profiles/r03_em_phase_clocks.txt).  Nothing on that chain but the gathered values changes from round to round: a
+// wavefront owns the same slices for the whole launch.  So the index words of a slice (W x 64 bits per lane: em_split_len <= 4 W
+// entries), its metadata and the constants of the segment a lane finishes (count and weight count of a row; single, eff and the lane's
+// own alpha / a of a transcript) are loaded ONCE per launch, and a pass is: issue the gathers, add, (segmented scan), finish, store --
+// one LDS round trip.  With the slices in registers the kernel is bound by the vector instructions it issues (a wave64 instruction
+// occupies its SIMD for four clocks; profiles/README.md, round 4: SIMD clocks = 4 x instructions explains the phase clocks), so the
+// rest of this form is an instruction diet:
+//   * the 16-bit indices are turned into LDS BYTE ADDRESSES of the gathered value when they are loaded (the arrays lie in the first
+//     64 KB of the workgroup's LDS, checked per group): a gather is `and` / `shift` + ds_read_b64 with the array's base in the
+//     instruction's offset field instead of unpack + shift-add + read;
+//   * the segmented scan of a slice with split segments runs only the steps some lane of the slice needs (a mask computed once per
+//     launch: most split segments span two or three lanes, a step costs seven instructions);
+//   * NS slices per wavefront and direction live in registers (groups of ~10 000 entries have 17-22 row slices for 16 wavefronts).
+// Slices beyond those take the LDS path.  Two index words per lane (split length 8) form the sums exactly as the LDS form does; the
+// wider forms add each batch of sixteen values as a balanced tree.
 template <int NB>
-__device__ __forceinline__ void ems_reg_gather(const u64* w, const double* src, double* v) {
+__device__ __forceinline__ void ems_reg_gather(const u64* w, const unsigned char* lds0, double* v) {
 #pragma unroll
   for (int q = 0; q < NB; q++) {
     u32 lo = (u32)w[q], hi = (u32)(w[q] >> 32);
     // (opaque to the optimiser: otherwise the gather addresses, which do not change from round to round, are hoisted out of the
-    // round loop into registers of their own -- 64 of them for W = 8 -- and the kernel spills; unpacking them again is three VALU
-    // operations per gather next to an LDS round trip)
+    // round loop into registers of their own and the kernel spills)
     asm volatile("" : "+v"(lo), "+v"(hi));
-    v[4 * q] = src[lo & 0xFFFFu]; v[4 * q + 1] = src[lo >> 16]; v[4 * q + 2] = src[hi & 0xFFFFu]; v[4 * q + 3] = src[hi >> 16];
+    v[4 * q] = *reinterpret_cast<const double*>(lds0 + (lo & 0xFFFFu)); v[4 * q + 1] = *reinterpret_cast<const double*>(lds0 + (lo >> 16));
+    v[4 * q + 2] = *reinterpret_cast<const double*>(lds0 + (hi & 0xFFFFu)); v[4 * q + 3] = *reinterpret_cast<const double*>(lds0 + (hi >> 16));
   }
 }
 template <int NQ>
-__device__ __forceinline__ double ems_reg_sum(const u64* w, const double* src) {
-  // One or two index words: eight values in flight, added in entry order (the two-word form stays inside 64 registers and forms the sums
-  // exactly as the LDS form does).  The wider forms run one workgroup per CU and have 128 registers: four words (sixteen values) at a
-  // time, each batch summed as a balanced tree -- the chain of dependent additions is what a lone wavefront waits for once the gathers
-  // have landed.  The order of the additions is fixed by the layout alone: reproducible to the bit, but not the LDS form's bits.
+__device__ __forceinline__ double ems_reg_sum(const u64* w, const unsigned char* lds0) {
   if constexpr (NQ <= 2) {
     double v[4 * NQ];
-    ems_reg_gather<NQ>(w, src, v);
+    ems_reg_gather<NQ>(w, lds0, v);
     double S = 0.0;
 #pragma unroll
     for (int i = 0; i < 4 * NQ; i++) S += v[i];   // (entries beyond the slice's width point at the zero slot: + 0.0 changes no bit of a sum >= 0)
@@ -3806,21 +3815,43 @@ __device__ __forceinline__ double ems_reg_sum(const u64* w, const double* src) {
   } else {
     constexpr int NB = NQ < 4 ? NQ : 4;
     double v[4 * NB];
-    ems_reg_gather<NB>(w, src, v);
+    ems_reg_gather<NB>(w, lds0, v);
 #pragma unroll
     for (int st = 1; st < 4 * NB; st *= 2)
 #pragma unroll
       for (int i = 0; i + st < 4 * NB; i += 2 * st) v[i] += v[i + st];
-    if constexpr (NQ > 4) return v[0] + ems_reg_sum<NQ - 4>(w + 4, src);
+    if constexpr (NQ > 4) return v[0] + ems_reg_sum<NQ - 4>(w + 4, lds0);
     else return v[0];
   }
 }
 template <int W, int NQ = 1>
-__device__ __forceinline__ double ems_reg_slice_sum(const u64* w, u32 nq, const double* src) {   // nq: words in use, wave-uniform, 1 .. W
-  if constexpr (NQ >= W) return ems_reg_sum<W>(w, src);
-  else { if (nq <= (u32)NQ) return ems_reg_sum<NQ>(w, src); return ems_reg_slice_sum<W, NQ + 1>(w, nq, src); }
+__device__ __forceinline__ double ems_reg_slice_sum(const u64* w, u32 nq, const unsigned char* lds0) {   // nq: words in use, wave-uniform, 1 .. W
+  if constexpr (NQ >= W) return ems_reg_sum<W>(w, lds0);
+  else { if (nq <= (u32)NQ) return ems_reg_sum<NQ>(w, lds0); return ems_reg_slice_sum<W, NQ + 1>(w, nq, lds0); }
 }
-// the LDS path of ems_group_rounds_reg (slices beyond a wavefront's first): one index word at a time -- few registers, rarely run
+// pm_scan_seg with the steps no lane of the wavefront needs left out (steps: bit i set = step i has a lane that adds; wave-uniform)
+__device__ __forceinline__ u32 pm_scan_seg_steps(int reach, int lane) {
+  const int r = lane & 15;
+  u32 m = 0;
+  if (__ballot(reach >= 1 && r >= 1)) m |= 1u;
+  if (__ballot(reach >= 2 && r >= 2)) m |= 2u;
+  if (__ballot(reach >= 4 && r >= 4)) m |= 4u;
+  if (__ballot(reach >= 8 && r >= 8)) m |= 8u;
+  if (__ballot((lane & 16) && reach > r)) m |= 16u;
+  if (__ballot(lane >= 32 && reach > lane - 32)) m |= 32u;
+  return m;
+}
+__device__ __forceinline__ double pm_scan_seg_masked(double y, int reach, int lane, u32 steps) {
+  const int r = lane & 15;
+  if (steps & 1u) { const double t = pm_dpp<0x111, 0xF>(y); if (reach >= 1 && r >= 1) y += t; }
+  if (steps & 2u) { const double t = pm_dpp<0x112, 0xF>(y); if (reach >= 2 && r >= 2) y += t; }
+  if (steps & 4u) { const double t = pm_dpp<0x114, 0xF>(y); if (reach >= 4 && r >= 4) y += t; }
+  if (steps & 8u) { const double t = pm_dpp<0x118, 0xF>(y); if (reach >= 8 && r >= 8) y += t; }
+  if (steps & 16u) { const double t = pm_dpp<0x142, 0xA>(y); if ((lane & 16) && reach > r) y += t; }
+  if (steps & 32u) { const double t = pm_dpp<0x143, 0xC>(y); if (lane >= 32 && reach > lane - 32) y += t; }
+  return y;
+}
+// the LDS path of ems_group_rounds_reg (slices beyond a wavefront's registers): one index word at a time -- few registers, rarely run
 __device__ __forceinline__ double ems_slice_sum_narrow(const u64* e, u32 width, const double* src) {
   double S = 0.0;
   for (u32 j = 0; j < width; j += 4) {   // (entries beyond the width point at the zero slot)
@@ -3831,7 +3862,7 @@ __device__ __forceinline__ double ems_slice_sum_narrow(const u64* e, u32 width, 
   }
   return S;
 }
-template <int W>
+template <int W, int NS>
 __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, unsigned char* smem, u32 tid, u32 nthr, const double* alpha, const double* a,
                                                      double* alpha_out, double* a_out, int n_rounds, int clamp, int* s_hist, long long* clk = nullptr) {
   namespace L = kamd_em_sell;
@@ -3841,13 +3872,19 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
   const u32 rs0 = P.rslice_base[g], nrs = P.rslice_base[g + 1] - rs0, cs0 = P.cslice_base[g], ncs = P.cslice_base[g + 1] - cs0;
   const u64 re0 = P.rell_base[g], ce0 = P.cell_base[g];
   const u32 nru = (u32)(P.rell_base[g + 1] - re0), ncu = (u32)(P.cell_base[g + 1] - ce0);
-  // the layout kamd_em_sell::group_bytes() prices (the same as ems_group_rounds)
-  double* s_al0 = reinterpret_cast<double*>(smem);
-  double* s_a0 = s_al0 + (nT + 1); double* s_al1 = s_a0 + (nT + 1); double* s_a1 = s_al1 + (nT + 1);
-  double* s_single = s_a1 + (nT + 1); double* s_eff = s_single + nT; double* s_g = s_eff + nT;
-  u64* s_cw = reinterpret_cast<u64*>(s_g + (nR + 1));
+  // the layout kamd_em_sell::group_bytes() prices, in another order: the two gathered arrays (a, then g) come first, so that their byte
+  // addresses fit 16 bits for every group of up to ~8 000 rows + transcripts (what is left of the priced bytes stays unused: alpha and
+  // a are updated in place here -- the rows pass only reads a, the columns pass reads and writes a[t] / alpha[t] in the one lane that
+  // finishes transcript t, and a barrier lies between the passes on either side)
+  double* s_a0 = reinterpret_cast<double*>(smem);
+  double* s_g = s_a0 + (nT + 1);
+  double* s_al0 = s_g + (nR + 1);
+  double* s_single = s_al0 + (nT + 1); double* s_eff = s_single + nT;
+  u64* s_cw = reinterpret_cast<u64*>(s_eff + nT);
   u32* s_rdesc = reinterpret_cast<u32*>(s_cw + nR); u32* s_cdesc = s_rdesc + 2 * nrs;
   uint16_t* s_rell = reinterpret_cast<uint16_t*>(s_cdesc + 2 * ncs); uint16_t* s_cell = s_rell + ((nru + 1) & ~1u);
+  const u32 a_off = 0u, g_off = (nT + 1) * 8u;
+  const bool near = g_off + (nR + 1) * 8u <= 0x10000u;   // both gathered arrays inside the first 64 KB: byte addresses fit the 16-bit entries
   for (u32 i = tid; i < nT; i += nthr) {
     double al = alpha[t0 + i], av = a[t0 + i];
     if (clamp && al < 1e-7 / 10.0) { al = 0.0; av = 0.0; }   // the final round reads alpha < alpha_limit / 10 as 0 (:212-221)
@@ -3861,56 +3898,70 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
   if (tid == 0) { s_al0[nT] = s_a0[nT] = 0.0; s_g[nR] = 0.0; }
   __syncthreads();
   // ---- this wavefront's own slices: everything that does not change from round to round goes into registers ----
-  struct Own { u64 w[W]; u32 nq, seg; int reach; bool has, meta, fin; };
-  auto take = [&](const u32* desc, const uint16_t* ell, u32 n_slices, u32 n_segs, u32 zero) {
+  struct Own { u64 w[W]; u32 nq, seg, steps; int reach; bool has, meta, fin; };
+  auto take = [&](const u32* desc, const uint16_t* ell, u32 s, u32 n_slices, u32 n_segs, u32 zero, u32 base_off) {
     Own o;
-    o.has = wv < n_slices; o.nq = 1; o.seg = 0; o.reach = 0; o.meta = false; o.fin = false;
-    if (o.has && (((desc[2 * wv + 1] & 0xFFFFu) + 3u) >> 2) > (u32)W) o.has = false;   // a slice wider than the registers hold: the LDS path takes it
-    const u64 padw = (u64)zero * 0x0001000100010001ULL;
+    o.has = near && s < n_slices; o.nq = 1; o.seg = 0; o.reach = 0; o.meta = false; o.fin = false; o.steps = 0;
+    if (o.has && (((desc[2 * s + 1] & 0xFFFFu) + 3u) >> 2) > (u32)W) o.has = false;   // a slice wider than the registers hold: the LDS path takes it
+    const u64 padw = (u64)(base_off + zero * 8u) * 0x0001000100010001ULL;
 #pragma unroll
     for (int q = 0; q < W; q++) o.w[q] = padw;
     if (o.has) {
-      const u32 d0 = desc[2 * wv], d1 = desc[2 * wv + 1];
+      const u32 d0 = desc[2 * s], d1 = desc[2 * s + 1];
       o.meta = (d0 & L::DESC_META) != 0;
       const u32 off = d0 & ~L::DESC_META, width = d1 & 0xFFFFu;
       o.nq = (u32)__builtin_amdgcn_readfirstlane((int)((width + 3u) >> 2));
       const u64* e = reinterpret_cast<const u64*>(ell + off + (o.meta ? 2 * L::SELL_META_WORDS : 0u)) + lane;
 #pragma unroll
-      for (int q = 0; q < W; q++) if ((u32)q < o.nq) o.w[q] = e[(size_t)q * 64];
+      for (int q = 0; q < W; q++) if ((u32)q < o.nq) {
+        // index -> byte address of the value: four 16-bit fields of a word, no carry between them (base + 8 x index < 2^16)
+        const u64 ix4 = e[(size_t)q * 64];
+        o.w[q] = ((ix4 & 0x1FFF1FFF1FFF1FFFULL) << 3) + (u64)base_off * 0x0001000100010001ULL;
+      }
       o.seg = (d1 >> 16) + (u32)lane; o.fin = o.seg < n_segs;
       if (o.meta) {
         const u32 w = reinterpret_cast<const u32*>(ell + off)[lane];
         o.reach = (int)((w >> 16) & 0x7Fu); o.seg = w & 0xFFFFu; o.fin = (w & L::META_ACTIVE) && (w & L::META_LAST);
+        o.steps = pm_scan_seg_steps(o.reach, lane);
       }
       if (!o.fin) o.seg = 0;
     }
     return o;
   };
-  const Own ro = take(s_rdesc, s_rell, nrs, nR, nT);
-  const Own co = take(s_cdesc, s_cell, ncs, nT, nR);
-  u32 r_cnt = 0, r_wc = 0;
-  if (ro.fin) { const u64 cwv = s_cw[ro.seg]; r_cnt = (u32)cwv; r_wc = (u32)(cwv >> 32); }
-  double c_single = 0.0, c_eff = 1.0, c_at = 0.0, c_cur = 0.0;
-  if (co.fin) { c_single = s_single[co.seg]; c_eff = s_eff[co.seg]; c_at = s_a0[co.seg]; c_cur = s_al0[co.seg]; }
-  const u32 r_next = ro.has ? wv + NW : wv, c_next = co.has ? wv + NW : wv;   // first slice of this wavefront on the LDS path
-  // alpha and a are updated IN PLACE: the rows pass only reads a, the columns pass reads and writes a[t] / alpha[t] in the one lane that
-  // finishes transcript t, and a barrier lies between the passes on either side -- so the gather addresses are the same in every round
-  // (the second copies the LDS layout prices stay unused)
+  Own ro[NS], co[NS];
+  u32 r_cnt[NS], r_wc[NS];
+  double c_single[NS], c_eff[NS], c_at[NS], c_cur[NS];
+  u32 r_next = wv, c_next = wv;   // first slice of this wavefront on the LDS path
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    ro[k] = take(s_rdesc, s_rell, wv + (u32)k * NW, nrs, nR, nT, a_off);
+    co[k] = take(s_cdesc, s_cell, wv + (u32)k * NW, ncs, nT, nR, g_off);
+    // (register slices are a prefix of the wavefront's slices: the LDS path starts behind the last one held)
+    if (ro[k].has && r_next == wv + (u32)k * NW) r_next += NW; else ro[k].has = false;
+    if (co[k].has && c_next == wv + (u32)k * NW) c_next += NW; else co[k].has = false;
+    r_cnt[k] = 0; r_wc[k] = 0; c_single[k] = 0.0; c_eff[k] = 1.0; c_at[k] = 0.0; c_cur[k] = 0.0;
+    if (ro[k].has && ro[k].fin) { const u64 cwv = s_cw[ro[k].seg]; r_cnt[k] = (u32)cwv; r_wc[k] = (u32)(cwv >> 32); }
+    if (co[k].has && co[k].fin) { c_single[k] = s_single[co[k].seg]; c_eff[k] = s_eff[co[k].seg]; c_at[k] = s_a0[co[k].seg]; c_cur[k] = s_al0[co[k].seg]; }
+  }
   double* const al = s_al0; double* const av = s_a0;
-  (void)s_al1; (void)s_a1;
+  const unsigned char* const lds0 = smem;
   for (int r = 0; r < n_rounds; r++) {
     const bool tick = clk && r == EMS_CLK_ROUND && lane == 0;
     long long w0 = 0;
     if (tick) { clk[0] = clock64(); w0 = wall_clock64(); }
     // rows: S_e over the row's transcripts, then g_e = count_e / S_e (rows the reference skips get 0: count 0, :133-135;
     // denom below denorm_min, :156-158)
-    if (ro.has) {
-      if (tick) clk[12] = clock64();
-      double S = ems_reg_slice_sum<W>(ro.w, ro.nq, av);
-      if (tick) { clk[13] = clock64(); clk[14] = (long long)((ro.nq * 4u) | (ro.meta ? 0x10000u : 0u)); }
-      if (ro.meta) S = pm_scan_seg(S, ro.reach, lane);
-      if (ro.fin) s_g[ro.seg] = (r_cnt == 0 || (double)r_wc * S < 4.9406564584124654e-324) ? 0.0 : (double)r_cnt / S;
-      if (tick) clk[15] = clock64();
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      if (ro[k].has) {
+        const bool tk = tick && k == 0;
+        if (tk) clk[12] = clock64();
+        double S = ems_reg_slice_sum<W>(ro[k].w, ro[k].nq, lds0);
+        if (tk) { clk[13] = clock64(); clk[14] = (long long)((ro[k].nq * 4u) | (ro[k].meta ? 0x10000u : 0u)); }
+        if (ro[k].meta) S = pm_scan_seg_masked(S, ro[k].reach, lane, ro[k].steps);
+        if (ro[k].fin) s_g[ro[k].seg] = (r_cnt[k] == 0 || (double)r_wc[k] * S < 4.9406564584124654e-324) ? 0.0 : (double)r_cnt[k] / S;
+        if (tk) clk[15] = clock64();
+      }
     }
     for (u32 s = r_next; s < nrs; s += NW) {
       const u32 d0 = s_rdesc[2 * s], d1 = s_rdesc[2 * s + 1];
@@ -3945,15 +3996,19 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
       al[seg] = nx; av[seg] = a_out_v;
       return nx > 1e-2 && moved;
     };
-    if (co.has) {
-      if (tick) clk[8] = clock64();
-      double acc = ems_reg_slice_sum<W>(co.w, co.nq, s_g);
-      if (tick) { clk[9] = clock64(); clk[10] = (long long)((co.nq * 4u) | (co.meta ? 0x10000u : 0u)); }
-      if (co.meta) acc = pm_scan_seg(acc, co.reach, lane);
-      bool chg = false;
-      if (co.fin) chg = finish_col(co.seg, c_at, c_cur, c_single, c_eff, acc, c_cur, c_at);
-      ch += __popcll(__ballot(chg));
-      if (tick) clk[11] = clock64();
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      if (co[k].has) {
+        const bool tk = tick && k == 0;
+        if (tk) clk[8] = clock64();
+        double acc = ems_reg_slice_sum<W>(co[k].w, co[k].nq, lds0);
+        if (tk) { clk[9] = clock64(); clk[10] = (long long)((co[k].nq * 4u) | (co[k].meta ? 0x10000u : 0u)); }
+        if (co[k].meta) acc = pm_scan_seg_masked(acc, co[k].reach, lane, co[k].steps);
+        bool chg = false;
+        if (co[k].fin) chg = finish_col(co[k].seg, c_at[k], c_cur[k], c_single[k], c_eff[k], acc, c_cur[k], c_at[k]);
+        ch += __popcll(__ballot(chg));
+        if (tk) clk[11] = clock64();
+      }
     }
     for (u32 s = c_next; s < ncs; s += NW) {
       const u32 d0 = s_cdesc[2 * s], d1 = s_cdesc[2 * s + 1];
@@ -4011,7 +4066,7 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(W
   if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
   __syncthreads();
   long long* my_clk = CLK ? clk + ((size_t)blockIdx.x * (EMS_MAX_BLOCK / 64) + (threadIdx.x >> 6)) * EMS_CLK_WORDS : nullptr;
-  if constexpr (W > 0) ems_group_rounds_reg<W>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
+  if constexpr (W > 0) ems_group_rounds_reg<W, (W == 4 ? 2 : 1)>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
   else ems_group_rounds<false, EXP>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
   __syncthreads();
   if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
@@ -4965,11 +5020,17 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       // one wavefront iterates (k_em_sell_wave); the larger ones to workgroup-sized groups as before.  A small group must fit a
       // wavefront's share of a CU's LDS (24 KB: six or more workgroups of four per CU), else the classes are dropped.
       u32 small = c->tune.em_small_nnz > 0 ? (u32)c->tune.em_small_nnz : 0u;
-      for (u64 div = (u64)std::max(1, c->tune.em_group_div); div <= 1024 && prc >= 1; div *= 2) {
+      // em_group_div < 0 (the default): as few groups per CU as the LDS allows -- one workgroup of 16 wavefronts per CU iterating a group
+      // of up to ~10 000 entries (12 bytes of LDS per entry) beats two half-sized ones: every wavefront then owns a slice in both passes
+      // of a round, and a round costs the same few LDS round trips whatever the size (measured on config #3, profiles/README.md round 4:
+      // 505 groups 8.5 ms, 757 groups 9.6, 1009 groups 10.1).  The group count stays a little under a multiple of the CU count.
+      const bool auto_div = c->tune.em_group_div < 0;
+      const u64 div0 = auto_div ? std::max<u64>(1, (nnz + (u64)c->n_cus * 10000 - 1) / ((u64)c->n_cus * 10000)) : (u64)c->tune.em_group_div;
+      for (u64 div = div0; div <= 1024 && prc >= 1; div = auto_div ? div + 1 : div * 2) {
         const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
         prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K, small, small,
                                    24 * 1024, multi);
-        if (prc == 2) { small = 0; div /= 2; continue; }   // (same cut again, one class)
+        if (prc == 2) { small = 0; div = auto_div ? div - 1 : div / 2; continue; }   // (same cut again, one class)
         if (target == 1024) break;
       }
       if (prc == 2) prc = 1;
