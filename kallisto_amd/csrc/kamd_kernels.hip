@@ -1266,47 +1266,6 @@ __global__ __launch_bounds__(FLD_RANK_BLOCK) void k_fld_emit(const int32_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// read packer (ASCII -> 2-bit + non-ACGT mask), one thread per output word
-// ------------------------------------------------------------------------------------------------------------------
-// word w of the packed record of a read s[0..L)
-__device__ __forceinline__ u32 pack_word_of(const char* __restrict__ s, int L, int w, int seq_words) {
-  u32 v = 0;
-  if (w == seq_words - 1) {   // flag word (kamd_core.h REC_FLAG_HAS_N): the bases never reach the last sequence word
-    for (int i = 0; i < L; i++) {
-      unsigned char ch = (unsigned char)s[i] & 0xDF;
-      if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) { v = kamd::REC_FLAG_HAS_N; break; }
-    }
-  } else if (w < seq_words) {
-    for (int j = 0; j < 16; j++) {
-      int i = w * 16 + j;
-      if (i >= L) break;
-      unsigned char ch = (unsigned char)s[i] & 0xDF;
-      u32 code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
-      v |= code << (2 * j);
-    }
-  } else {
-    const int mw = w - seq_words;
-    for (int j = 0; j < 32; j++) {
-      int i = mw * 32 + j;
-      if (i >= L) break;
-      unsigned char ch = (unsigned char)s[i] & 0xDF;
-      if (!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) v |= 1u << j;
-    }
-  }
-  return v;
-}
-__global__ void k_pack_reads(const char* __restrict__ seqs, const u64* __restrict__ off, const int32_t* __restrict__ len,
-                             u64 n_reads, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
-  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u64 r = gid / (u64)rec_words;
-  int w = (int)(gid % (u64)rec_words);
-  if (r >= n_reads) return;
-  const int L = len[r];
-  out[gid] = pack_word_of(seqs + off[r], L, w, seq_words);
-  if (w == 0) out_len[r] = (uint16_t)L;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // FASTQ text resident in HBM -> packed reads (kamd_fq_core.h; the parsing half of FastqSequenceReader::fetchSequences,
 // src/ProcessReads.cpp:3128-3267 + kseq_read src/kseq.h:174-215, for strict 4-line records).  A unit of text starts at a record
 // and holds whole records; per file:
@@ -1442,6 +1401,42 @@ __global__ __launch_bounds__(BLOCK) void k_fq_pack(const u64* __restrict__ recs,
     const u64 keep = (1ULL << (2 * left)) - 1;
     lo &= (u32)keep; hi &= (u32)(keep >> 32);
     mask &= (1u << left) - 1u;
+  }
+  u32* o = out + r * (u64)rec_words;
+  o[2 * g] = lo;
+  if (left > 16) o[2 * g + 1] = hi;
+  o[seq_words + g] = mask;
+  if (mask) atomicOr(&o[seq_words - 1], kamd::REC_FLAG_HAS_N);
+}
+
+// kamd_pack_reads_device: reads given as {offset, length} into one buffer of ASCII bases -- the scheme of k_fq_pack (one thread per 32
+// bases, dword loads, branch-free codes) instead of one thread per output word that walked its 16 / 32 bases byte by byte and, for the
+// flag word, the whole read (9.7 ms per 2 M PE-100 pairs, 86 G scalar instructions: profiles/r03_pmc_sq_tcc_per_kernel.csv).  Nothing
+// lies behind the last read of the buffer, so the dwords of a read's last, partial group are only loaded as far as the read goes (its
+// final bytes one by one).  The output buffer was zeroed by the caller.
+__global__ __launch_bounds__(BLOCK) void k_pack_reads(const char* __restrict__ seqs, const u64* __restrict__ off, const int32_t* __restrict__ len,
+                                                      u64 n_reads, int groups, int seq_words, int rec_words, u32* out, uint16_t* out_len) {
+  const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 r = gid / (u64)groups;
+  const int g = (int)(gid % (u64)groups);
+  if (r >= n_reads) return;
+  const int L = min(len[r], groups * 32);   // (a length beyond max_len is the caller's error: nothing behind max_len is read or written)
+  if (g == 0) out_len[r] = (uint16_t)len[r];
+  const int b0 = g * 32;
+  if (b0 >= L) return;
+  const char* p = seqs + off[r] + b0;
+  const int left = L - b0;   // bases of this group that belong to the read
+  u32 lo = 0, hi = 0, mask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u32 w = 0x41414141u;   // 'A': code 0, no flag -- what the bytes behind the read's end count as
+    const int have = left - 4 * j;
+    if (have >= 4) __builtin_memcpy(&w, p + 4 * j, 4);   // (unaligned: the hardware takes it as one load in the default access mode)
+    else if (have > 0) for (int b = 0; b < have; b++) w = (w & ~(0xFFu << (8 * b))) | ((u32)(unsigned char)p[4 * j + b] << (8 * b));
+    u32 code;
+    const u32 bad = pack4(w, &code);
+    if (j < 4) lo |= code << (8 * j); else hi |= code << (8 * (j - 4));
+    mask |= bad << (4 * j);
   }
   u32* o = out + r * (u64)rec_words;
   o[2 * g] = lo;
@@ -2655,8 +2650,10 @@ extern "C" int kamd_pack_reads_device(kamd_ctx* c, const char* d_seqs, const uin
   const int rec_words = (int)kamd_packed_record_words(max_len);
   const u64 total = n_reads * (u64)rec_words;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, c->stream, d_seqs, (const u64*)d_off, d_len,
-                     (u64)n_reads, seq_words, rec_words, d_out_words, d_out_len);
+  const int groups = (max_len + 31) / 32;
+  HIPC(hipMemsetAsync(d_out_words, 0, total * sizeof(u32), c->stream));   // padding words and the has-N flag start from 0
+  hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(n_reads * (u64)groups, BLOCK)), dim3(BLOCK), 0, c->stream, d_seqs, (const u64*)d_off, d_len,
+                     (u64)n_reads, groups, seq_words, rec_words, d_out_words, d_out_len);
   HIPC(hipGetLastError());
   return 0;
 }

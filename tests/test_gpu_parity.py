@@ -79,6 +79,33 @@ def test_device_packer_equals_host_packer(ka, ctxs):
     assert torch.equal(hw, dw) and torch.equal(hl, dl)
 
 
+def test_device_packer_on_ragged_reads(ka, ctxs):
+    """kamd_pack_reads_device (one thread per 32 bases, dword loads) against the host packer on reads of every length 1 .. 150 with bases
+    that are not ACGT (and lower case) scattered in, the buffer sized exactly: the last read ends at the allocation's last byte."""
+    import ctypes as C
+    import torch
+    index, ctx = ctxs("human_pe")
+    rng = np.random.default_rng(11)
+    reads = []
+    for L in list(range(1, 151)) * 3 + [150, 1, 33, 64, 97]:
+        r = rng.choice(np.frombuffer(b"ACGTacgtNnRY.", np.uint8), L, p=[.2, .2, .2, .2, .04, .04, .04, .04, .01, .01, .005, .005, .01])
+        reads.append(r.tobytes())
+    max_len = 150
+    hw, hl, _ = ctx.pack_reads_host(reads, max_len)
+    lens = np.array([len(r) for r in reads], np.int32)
+    off = np.zeros(len(reads), np.uint64); off[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+    buf = torch.from_numpy(np.frombuffer(b"".join(reads), np.uint8).copy()).cuda()     # exactly sized
+    d_off = torch.from_numpy(off.view(np.int64)).cuda(); d_len = torch.from_numpy(lens).cuda()
+    rec = ka.packed_record_words(max_len)
+    words = torch.full((len(reads) * rec,), -1, dtype=torch.int32, device="cuda")     # (the packer must not rely on a zeroed buffer)
+    l16 = torch.empty(len(reads), dtype=torch.int16, device="cuda")
+    rc = ka.load_library().kamd_pack_reads_device(ctx._h, C.c_void_p(buf.data_ptr()), C.c_void_p(d_off.data_ptr()), C.c_void_p(d_len.data_ptr()), len(reads), max_len,
+                                                  C.c_void_p(words.data_ptr()), C.c_void_p(l16.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(hw, words) and torch.equal(hl, l16)
+
+
 def test_batches_and_idempotence(ka, ctxs):
     """Splitting the reads into batches must not change the EC multiset; re-finalizing must not either."""
     meta, idx_path, r1, r2 = common.load_case("human_pe")
