@@ -785,12 +785,12 @@ __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ ba
   if (is_owner) list[blk_base + my] = s;
 }
 // the records that opened a slot in the last k_tup_absorb move from the batch's stream into the store
-__global__ __launch_bounds__(BLOCK) void k_tup_store(const u32* __restrict__ batch, u32* store, TSlot* table, const u64* __restrict__ list, u64 first_new,
+__global__ __launch_bounds__(BLOCK) void k_tup_store(const u32* __restrict__ batch, u32* store, TSlot* table, u64* list, u64 first_new,
                                                      u64 n_new, DevState* st) {
   __shared__ u32 wsum[BLOCK / 64]; __shared__ u64 blk_base;
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 s = 0, off = 0; u32 need = 0;
-  if (i < n_new) { s = list[first_new + i]; off = table[s].owner; need = batch[off + 1] + 2u; }
+  if (i < n_new) { s = list[first_new + i] & 0xFFFFFFFFULL; off = table[s].owner; need = batch[off + 1] + 2u; }
   const u32 incl = wave_incl_scan(need);
   if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
   __syncthreads();
@@ -803,19 +803,22 @@ __global__ __launch_bounds__(BLOCK) void k_tup_store(const u32* __restrict__ bat
   for (u32 j = 0; j < need; j++) store[dst + j] = batch[off + j];
   table[s].owner = dst;
   table[s].tag = (table[s].tag & 0xFFFFFFFF00000000ULL) | (dst + 1);   // (dst + 1 < 2^31: checked by the host)
+  // the list entry carries the record's place in the store beside the slot: the kernels that walk the distinct tuples (k_bound_tuples,
+  // k_resolve) start on the record at once instead of going list -> slot -> record, one dependent random read less per tuple
+  list[first_new + i] = s | (dst << 32);
 }
 // a larger table: every distinct tuple (all of them in the store by now) takes a slot of the new one, the list follows
 __global__ void k_tup_rehash(const u32* __restrict__ store, const TSlot* __restrict__ old, TSlot* nu, u64 mask, u64* list, u64 n) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const TSlot o = old[list[i]];
+  const TSlot o = old[list[i] & 0xFFFFFFFFULL];
   const u32 m = store[o.owner + 1];
   const u64 h = rec_hash(store + o.owner + 1, m + 1, 1);
   const u64 tag = (h & 0xFFFFFFFF00000000ULL) | (o.owner + 1);
   u64 s = (h >> 1) & mask;
   while (atomicCAS(&nu[s].tag, 0ULL, tag) != 0ULL) s = (s + 1) & mask;
   nu[s].owner = o.owner; nu[s].count = o.count; nu[s].first = o.first;
-  list[i] = s;
+  list[i] = s | (o.owner << 32);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -827,7 +830,7 @@ __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, cons
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 b = 0;
   if (i < n) {
-    const u64 off = table[list[i]].owner;
+    const u64 off = list[i] >> 32;   // (the record's place in the store rides in the list entry: k_tup_store)
     const u32 m = stream[off + 1];
     const kamd::SetTables stt{(const uint64_t*)ix.ec_off, ix.ec_ids};
     b = kamd::set_size_bound(stt, stream + off + 2, (int)m, ix.union_mode != 0) + 2;   // smallest set / sum of the sets (--union)
@@ -887,9 +890,11 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
   u64 my_off = 0; u32 my_sz = 0xFFFFFFFFu;
   bool small = false;   // m <= TUPLE_CAP and every set has <= RES_LANES members: the all-pairs path below
   if (valid) {
-    sl = table[list[gid]];
-    m = stream[sl.owner + 1];
-    es = stream + sl.owner + 2;
+    const u64 le = list[gid];
+    const u64 owner = le >> 32;     // (the record's place in the store rides in the list entry: the slot -- count, first occurrence -- is
+    sl = table[le & 0xFFFFFFFFULL];  //  only needed when the record is written, its load runs beside the chain record -> offsets -> members)
+    m = stream[owner + 1];
+    es = stream + owner + 2;
     if (m <= (u32)RES_LANES) {
       if ((u32)sub < m) { const u32 e = es[sub]; my_off = ix.ec_off[e]; my_sz = (u32)(ix.ec_off[e + 1] - my_off); }
     } else {
@@ -988,7 +993,7 @@ __global__ void k_resolve_union(DevIndex ix, const u32* __restrict__ stream, con
   const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n) return;
   const u64 base_words = st->cand_words, base_recs = st->cand_recs;
-  const TSlot sl = table[list[gid]];
+  const TSlot sl = table[list[gid] & 0xFFFFFFFFULL];
   const u32 m = stream[sl.owner + 1];
   kamd::EcList ecs; ecs.e = const_cast<u32*>(stream + sl.owner + 2); ecs.cap = (int)m; ecs.n = (int)m; ecs.overflow = false;
   u32 cur_small[TUPLE_CAP];
@@ -1078,7 +1083,7 @@ __global__ void k_set_last(u64* ec_off, u64 n, const u64* total) { if (threadIdx
 __global__ void k_tuple_export_size(const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n, DevState* st) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 b = 0;
-  if (i < n) b = (u64)stream[table[list[i]].owner + 1] + 2;
+  if (i < n) b = (u64)stream[(list[i] >> 32) + 1] + 2;
   b = wave_sum64(b);
   if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
 }
@@ -1087,7 +1092,7 @@ __global__ void k_tuple_export_offsets(const u32* __restrict__ stream, const TSl
                                        u64* out_off, DevState* st) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const TSlot sl = table[list[i]];
+  const TSlot sl = table[list[i] & 0xFFFFFFFFULL];
   const u32 m = stream[sl.owner + 1];
   u64 off = atomicAdd(&st->cand_words, (u64)m + 2);
   u64 r = atomicAdd(&st->cand_recs, 1ULL);
@@ -2407,7 +2412,7 @@ int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 
       if (c->host_state.ts_words + new_words >= 0x7FFFFFF0ULL) return kamd::fail(-101, "absorb_tuples: more than 2^31 words of distinct tuples");
       if (int rc = c->tstore.ensure((c->host_state.ts_words + new_words + 2) * sizeof(u32), c->host_state.ts_words * sizeof(u32), c->stream)) return rc;
       hipLaunchKernelGGL(k_tup_store, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, c->stream, batch, c->tstore.as<u32>(), c->ttable.as<TSlot>(),
-                         (const u64*)c->list.as<u64>(), tl_before, n_new, dst);
+                         c->list.as<u64>(), tl_before, n_new, dst);
       HIPC(hipGetLastError());
       c->host_state.ts_words += new_words;   // (k_tup_store advances the device copy by the same amount)
     }
@@ -3800,15 +3805,18 @@ __device__ __forceinline__ void ems_reg_gather(const u64* w, const unsigned char
     v[4 * q + 2] = *reinterpret_cast<const double*>(lds0 + (hi & 0xFFFFu)); v[4 * q + 3] = *reinterpret_cast<const double*>(lds0 + (hi >> 16));
   }
 }
-template <int NQ>
-__device__ __forceinline__ double ems_reg_sum(const u64* w, const unsigned char* lds0) {
-  if constexpr (NQ <= 2) {
-    double v[4 * NQ];
-    ems_reg_gather<NQ>(w, lds0, v);
-    double S = 0.0;
+// TREE: batches of four words summed as balanced trees (the forms with 128 registers); else batches of two words added in entry order --
+// what the LDS form computes, bit for bit, inside 64 registers
+template <int NQ, bool TREE>
+__device__ __forceinline__ double ems_reg_sum(const u64* w, const unsigned char* lds0, double S = 0.0) {
+  if constexpr (!TREE) {
+    constexpr int NB = NQ < 2 ? NQ : 2;
+    double v[4 * NB];
+    ems_reg_gather<NB>(w, lds0, v);
 #pragma unroll
-    for (int i = 0; i < 4 * NQ; i++) S += v[i];   // (entries beyond the slice's width point at the zero slot: + 0.0 changes no bit of a sum >= 0)
-    return S;
+    for (int i = 0; i < 4 * NB; i++) S += v[i];   // (entries beyond the slice's width point at the zero slot: + 0.0 changes no bit of a sum >= 0)
+    if constexpr (NQ > 2) return ems_reg_sum<NQ - 2, false>(w + 2, lds0, S);
+    else return S;
   } else {
     constexpr int NB = NQ < 4 ? NQ : 4;
     double v[4 * NB];
@@ -3817,14 +3825,14 @@ __device__ __forceinline__ double ems_reg_sum(const u64* w, const unsigned char*
     for (int st = 1; st < 4 * NB; st *= 2)
 #pragma unroll
       for (int i = 0; i + st < 4 * NB; i += 2 * st) v[i] += v[i + st];
-    if constexpr (NQ > 4) return v[0] + ems_reg_sum<NQ - 4>(w + 4, lds0);
-    else return v[0];
+    if constexpr (NQ > 4) return ems_reg_sum<NQ - 4, true>(w + 4, lds0, S + v[0]);
+    else return S + v[0];
   }
 }
-template <int W, int NQ = 1>
+template <int W, bool TREE, int NQ = 1>
 __device__ __forceinline__ double ems_reg_slice_sum(const u64* w, u32 nq, const unsigned char* lds0) {   // nq: words in use, wave-uniform, 1 .. W
-  if constexpr (NQ >= W) return ems_reg_sum<W>(w, lds0);
-  else { if (nq <= (u32)NQ) return ems_reg_sum<NQ>(w, lds0); return ems_reg_slice_sum<W, NQ + 1>(w, nq, lds0); }
+  if constexpr (NQ >= W) return ems_reg_sum<W, TREE>(w, lds0);
+  else { if (nq <= (u32)NQ) return ems_reg_sum<NQ, TREE>(w, lds0); return ems_reg_slice_sum<W, TREE, NQ + 1>(w, nq, lds0); }
 }
 // pm_scan_seg with the steps no lane of the wavefront needs left out (steps: bit i set = step i has a lane that adds; wave-uniform)
 __device__ __forceinline__ u32 pm_scan_seg_steps(int reach, int lane) {
@@ -3863,6 +3871,7 @@ template <int W, int NS>
 __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, unsigned char* smem, u32 tid, u32 nthr, const double* alpha, const double* a,
                                                      double* alpha_out, double* a_out, int n_rounds, int clamp, int* s_hist, long long* clk = nullptr) {
   namespace L = kamd_em_sell;
+  constexpr bool TREE = W >= 8 || (W == 4 && NS == 2);   // (the forms that run with 128 registers, one workgroup per CU)
   const int lane = lane_id();
   const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = nthr >> 6;
   const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
@@ -3953,7 +3962,7 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
       if (ro[k].has) {
         const bool tk = tick && k == 0;
         if (tk) clk[12] = clock64();
-        double S = ems_reg_slice_sum<W>(ro[k].w, ro[k].nq, lds0);
+        double S = ems_reg_slice_sum<W, TREE>(ro[k].w, ro[k].nq, lds0);
         if (tk) { clk[13] = clock64(); clk[14] = (long long)((ro[k].nq * 4u) | (ro[k].meta ? 0x10000u : 0u)); }
         if (ro[k].meta) S = pm_scan_seg_masked(S, ro[k].reach, lane, ro[k].steps);
         if (ro[k].fin) s_g[ro[k].seg] = (r_cnt[k] == 0 || (double)r_wc[k] * S < 4.9406564584124654e-324) ? 0.0 : (double)r_cnt[k] / S;
@@ -3998,7 +4007,7 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
       if (co[k].has) {
         const bool tk = tick && k == 0;
         if (tk) clk[8] = clock64();
-        double acc = ems_reg_slice_sum<W>(co[k].w, co[k].nq, lds0);
+        double acc = ems_reg_slice_sum<W, TREE>(co[k].w, co[k].nq, lds0);
         if (tk) { clk[9] = clock64(); clk[10] = (long long)((co[k].nq * 4u) | (co[k].meta ? 0x10000u : 0u)); }
         if (co[k].meta) acc = pm_scan_seg_masked(acc, co[k].reach, lane, co[k].steps);
         bool chg = false;
@@ -4053,8 +4062,8 @@ __device__ __forceinline__ bool ems_prev_stopped(const EmsPrev& v, int* s_flag) 
 // one workgroup per group (the large size class, or every group when there is only one class): groups g_first + blockIdx.x
 // W > 0: the register-resident form (ems_group_rounds_reg) for split lengths up to 4 W; W = 0: everything out of LDS
 // (two workgroups of 16 wavefronts per CU = 8 wavefronts per SIMD = 64 VGPRs: the register-resident forms are held to that)
-template <bool CLK, int EXP = 0, int W = 0>
-__global__ __launch_bounds__(EMS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(W >= 4 ? 4 : 8))) void k_em_sell(EmSellDev P, u32 g_first, const double* alpha, const double* a, double* alpha_out, double* a_out,
+template <bool CLK, int EXP = 0, int W = 0, int NS = 1>
+__global__ __launch_bounds__(EMS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu((W >= 8 || (W == 4 && NS == 2)) ? 4 : 8))) void k_em_sell(EmSellDev P, u32 g_first, const double* alpha, const double* a, double* alpha_out, double* a_out,
                                                            int n_rounds, int clamp, int* hist, EmsPrev prev, long long* clk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ems_smem[];
   __shared__ int s_hist[EML_MAX_ROUNDS];
@@ -4063,7 +4072,7 @@ __global__ __launch_bounds__(EMS_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(W
   if (threadIdx.x < EML_MAX_ROUNDS) s_hist[threadIdx.x] = 0;
   __syncthreads();
   long long* my_clk = CLK ? clk + ((size_t)blockIdx.x * (EMS_MAX_BLOCK / 64) + (threadIdx.x >> 6)) * EMS_CLK_WORDS : nullptr;
-  if constexpr (W > 0) ems_group_rounds_reg<W, (W == 4 ? 2 : 1)>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
+  if constexpr (W > 0) ems_group_rounds_reg<W, NS>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
   else ems_group_rounds<false, EXP>(P, g_first + blockIdx.x, ems_smem, threadIdx.x, blockDim.x, alpha, a, alpha_out, a_out, n_rounds, clamp, s_hist, my_clk);
   __syncthreads();
   if (hist && (int)threadIdx.x < n_rounds && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
@@ -4659,10 +4668,10 @@ struct EmSellGpu {
     if (fork && (hipEventRecord(ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return -104;
     if (n_big) {
 #define KAMD_EMS_LAUNCH(C, E) hipLaunchKernelGGL((k_em_sell<C, E>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
-#define KAMD_EMS_LAUNCH_REG(C, W) hipLaunchKernelGGL((k_em_sell<C, 0, W>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
-      if (reg_words == 2) { if (clk) KAMD_EMS_LAUNCH_REG(true, 2); else KAMD_EMS_LAUNCH_REG(false, 2); }
-      else if (reg_words == 4) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4); else KAMD_EMS_LAUNCH_REG(false, 4); }
-      else if (reg_words == 8) { if (clk) KAMD_EMS_LAUNCH_REG(true, 8); else KAMD_EMS_LAUNCH_REG(false, 8); }
+#define KAMD_EMS_LAUNCH_REG(C, W, NS) hipLaunchKernelGGL((k_em_sell<C, 0, W, NS>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
+      if (reg_words == 2) { if (clk) KAMD_EMS_LAUNCH_REG(true, 2, 1); else KAMD_EMS_LAUNCH_REG(false, 2, 1); }
+      else if (reg_words == 4) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4, 2); else KAMD_EMS_LAUNCH_REG(false, 4, 2); }
+      else if (reg_words == 8) { if (clk) KAMD_EMS_LAUNCH_REG(true, 8, 1); else KAMD_EMS_LAUNCH_REG(false, 8, 1); }
       else if (clk) KAMD_EMS_LAUNCH(true, 0);
       else switch (exp) {
         case 1: KAMD_EMS_LAUNCH(false, 1); break;
@@ -4724,8 +4733,8 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (const char* e = getenv("KAMD_EM_EXP")) {

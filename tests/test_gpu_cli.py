@@ -208,7 +208,7 @@ def test_cli_picks_up_only_its_own_flattened_index(tmp_path):
     assert [r[:3] for r in foreign] == [r[:3] for r in base]
     common.assert_abundance_close(np.array([float(r[3]) for r in foreign]), np.array([float(r[3]) for r in base]), "est_counts", rel=1e-9, floor=1e-9)
     # --kmer-table compact with a wide .kamd beside the index: the compact table is built from the index itself
-    assert subprocess.run([EXE, "flatten", "-i", idx, "-o", idx + ".kamd"]).returncode == 0
+    assert subprocess.run([EXE, "flatten", "-i", idx, "-o", idx + ".kamd", "--kmer-table", "wide"]).returncode == 0
     out = str(tmp_path / "compact")
     p = subprocess.run([EXE, "quant", "-i", idx, "-o", out, "--plaintext", "--verbose", "--kmer-table", "compact", f1, f2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()
