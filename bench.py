@@ -2,7 +2,7 @@
 """bench.py -- the BASELINE.json metric on MI355X: M paired-end reads/s pseudoaligned + quantified against a
 human-transcriptome-sized index (BASELINE.json configs[2]; configs[3] is the same workload on N GPUs).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1 from a bare shell: the script launches its own N ranks, self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One *step* = one full `kallisto quant` pass over this rank's batch of synthetic read pairs already resident in HBM in
@@ -24,8 +24,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   parity_check_tail  -- the last pairs of the input, pseudoaligned as the final batch of a run over ALL pairs (record stream grown and
                         reallocated, de-duplication table regrown): EC counts of the whole run minus those of the run without them must
                         equal the reference's EC multiset of those pairs
+  parity_check_full_size -- ALL pairs of the run through the unmodified reference on all cores (written as FASTQ while they are generated):
+                        EC multiset of the whole run, effective lengths and EM round count identical, est_counts / TPM <= 1e-4; the oracle's
+                        EM on the GPU's own equivalence classes <= 1e-9 (FullSizeParity; runs in the background of the other legs)
   pinned_pipeline    -- packed reads in pinned host memory -> H2D on a copy stream -> pseudoalignment, double buffered
-  end_to_end         -- the C++ front-end from FASTQ files (plain / BGZF / gzip), input -> ECs and whole-run rates, index load stated
+  end_to_end         -- the C++ front-end from FASTQ files (plain / BGZF / gzip; 8 M pairs, and plain_full_size*: all 30 M), input -> ECs
+                        and whole-run rates, index load stated
   bootstrap          -- (--bootstraps B) BASELINE config #5: B replicates of multinomial resample + EM
 `--workload yeast` is BASELINE config #2 (10 M single-end reads, ~6 k transcripts).
 """
