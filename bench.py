@@ -892,6 +892,8 @@ def main():
                 ctx1 = ka.Context(local)
                 ctx1.upload(index)
                 batches, keep = [], []
+                want_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")) and n * world <= 2_000_000
+                host1, host2 = [], []   # every rank's reads on the host too, in input order, for the reference (small runs only)
                 for r in range(world):   # rank r's reads: the same generator, the same seed, the same chunks
                     simr = ReadSimulator(cat, tlens, dev, seed=1000 + r, read_len=L)
                     wr = torch.empty(n * per * rec, dtype=torch.int32, device=dev); lr = torch.empty(n * per, dtype=torch.int16, device=dev)
@@ -904,6 +906,8 @@ def main():
                         inter = torch.stack([q1[:m], q2[:m]], 1).reshape(2 * m, L) if paired else q1[:m]
                         w, l = ctx1.pack_reads(inter, L)
                         wr[s0 * per * rec:(s0 + m) * per * rec] = w; lr[per * s0:per * (s0 + m)] = l
+                        if want_ref:
+                            host1.append(q1[:m].cpu().numpy()); host2.append(q2[:m].cpu().numpy())
                     keep.append((wr, lr)); batches.append((wr, lr, n, L))
                 sres = ka.quant(ctx1, opts, batches, download_ecs=True, comm=False)
                 big = sres.est_counts > 1e-6
@@ -913,6 +917,18 @@ def main():
                                 "est_counts_max_rel_err": rel, "em_rounds": [int(mres.em_rounds), int(sres.em_rounds)]}
                 multi_parity["ok"] = bool(multi_parity["ec_multiset_equal"] and multi_parity["flens_equal"] and rel <= 1e-9 and
                                           mres.em_rounds == sres.em_rounds and mres.n_processed == sres.n_processed)
+                if want_ref:
+                    # ... and the MERGED result of the ranks against the unmodified reference run on all ranks' reads in input order
+                    # (dump_ec quant -t 1: MasterProcessor::update, src/ProcessReads.cpp:424-481, is the merge kamd_ec_allreduce replaces)
+                    try:
+                        rp = reference_parity(idx_path, np.concatenate(host1), np.concatenate(host2) if paired else None, mres, cli_extra)
+                        multi_parity["merged_vs_reference"] = {k: rp[k] for k in ("ok", "ec_multiset_equal", "flens_equal", "eff_length_equal", "est_counts_max_rel_err_tpm_ge_1e-3",
+                                                                                  "tpm_max_rel_err_tpm_ge_1e-3", "zero_pattern_equal", "sample", "reference_seconds") if k in rp}
+                        multi_parity["ok"] = bool(multi_parity["ok"] and rp["ok"])
+                    except Exception as e:   # noqa: BLE001
+                        multi_parity["merged_vs_reference"] = {"ok": False, "error": str(e)[:300]}
+                        multi_parity["ok"] = False
+                    del host1, host2
                 ctx1.close()
                 del keep, batches
             except Exception as e:   # noqa: BLE001

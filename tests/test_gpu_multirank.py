@@ -149,6 +149,10 @@ def test_bench_two_ranks_on_one_gpu_with_parity(tmp_path):
     mp = line["multi_rank_parity"]
     assert mp["ok"], mp
     assert mp["ranks"] == 2 and mp["ec_multiset_equal"] and mp["flens_equal"] and mp["em_rounds"][0] == mp["em_rounds"][1]
+    # the merged result of the two ranks against the unmodified reference on both ranks' reads (800 k pairs, 9 k transcripts)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
+        mr = mp["merged_vs_reference"]
+        assert mr["ok"] and mr["ec_multiset_equal"] and mr["flens_equal"] and mr["eff_length_equal"], mr
 
 
 def test_bench_refuses_more_ranks_than_gpus():
