@@ -572,7 +572,7 @@ def compact_table_leg(idx_path, compact_dir, n, L, paired, steps, warmup, device
             if "error" in entry or not os.path.exists(f):
                 continue
             z = np.load(f)
-            entry["identical_to_wide"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
+            entry["identical_to_headline"] = bool(int(z["n_pseudoaligned"]) == res.n_pseudoaligned and int(z["n_unique"]) == res.n_unique and
                                               np.array_equal(z["flens"], res.flens) and np.array_equal(z["est_counts"], res.est_counts) and
                                               int(z["em_rounds"]) == res.em_rounds)
         return legs
@@ -1009,7 +1009,7 @@ def main():
     # the headline, never as the headline (the library's default layout is the wide one until this leg says otherwise) ----
     compact_leg = None
     compact_dir = None
-    if rank == 0 and world == 1 and not args.no_compact_leg and index.view.table_layout == 0:
+    if rank == 0 and world == 1 and not args.no_compact_leg:
         # The leg runs in a process of its own (tools/compact_table_leg.py), as the very last thing before the line is printed: a fault in a
         # side leg must not take the line down.  The packed reads go through /dev/shm (3 GB for config #3) -- written here, while they exist.
         need = n * per * (rec * 4 + 2)
@@ -1221,6 +1221,7 @@ def main():
         else:
             log("compact k-mer table: the same steps in a child process ...")
             compact_leg = compact_table_leg(idx_path, compact_dir, n, L, paired, args.steps, max(args.warmup, 1), local, res,
+                                            loads="0.6,0.5,0.7" if index.view.table_layout == 0 else "wide,0.6",
                                             timeout_s=max(60.0, budget_s + 120 - (time.time() - t_start)))
     if rank == 0 and world == 1 and args.workload == "human" and not args.no_config2 and genes == 20000 and n_arg == n_default:
         if time.time() - t_start > budget_s - 45:
@@ -1254,9 +1255,10 @@ def main():
         if in_flight is not None:
             out["two_samples_in_flight"] = in_flight
         if compact_leg is not None:
-            out["kmer_table_compact"] = {"legs": compact_leg,
-                                         "note": "the same steps with KAMD_TABLE_LAYOUT=compact (four exact 16-byte slots per 64-byte line by quotienting, "
-                                                 "DESIGN.md section 2) at three load factors; a side measurement -- `value` above is the default (wide) layout"}
+            out["kmer_table_layouts"] = {"legs": compact_leg,
+                                         "note": "the same steps on the other layouts of the k-mer table (wide = three 20-byte slots per 64-byte line at a load of 0.5; "
+                                                 "compact = four exact 16-byte slots by quotienting, DESIGN.md section 2, at other load factors); a side measurement -- "
+                                                 "`value` above is the library's default (auto: compact, load 0.5 under 2.4 GB)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         # tear down in order while everything is alive: the library's communicator (ncclCommDestroy), the context, then torch's

@@ -116,7 +116,7 @@ def test_bench_and_its_side_leg_parse():
 
 
 def test_bench_compact_leg_glue(tmp_path):
-    """bench.compact_table_leg with a stand-in for the child: the legs come back with `identical_to_wide`, a failing child becomes an error entry,
+    """bench.compact_table_leg with a stand-in for the child: the legs come back with `identical_to_headline`, a failing child becomes an error entry,
     the hand-over directory is removed either way."""
     import sys
     import types
@@ -136,7 +136,7 @@ def test_bench_compact_leg_glue(tmp_path):
     d = tmp_path / "hand"
     d.mkdir(); (d / "words.i32").write_bytes(b"\0" * 8)
     legs = bench.compact_table_leg("idx", str(d), 10, 100, True, 2, 1, 0, res, script=str(fake))
-    assert [e.get("identical_to_wide") for e in legs] == [True, False, None] and not d.exists()
+    assert [e.get("identical_to_headline") for e in legs] == [True, False, None] and not d.exists()
     d.mkdir()
     bad = tmp_path / "bad.py"
     bad.write_text("import sys\nsys.stderr.write('boom')\nsys.exit(3)\n")

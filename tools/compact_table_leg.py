@@ -47,10 +47,12 @@ def main():
     assert words.numel() == n * per * rec and lens.numel() == n * per
     opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0) if paired else ka.QuantOpts(0, 200.0, 20.0, 0, 0)
     out = []
-    for i, load in enumerate(float(x) for x in a.loads.split(",")):
-        entry = {"layout": "compact", "load_asked": load}
+    for i, tok in enumerate(a.loads.split(",")):   # a load factor of the compact table, or "wide"
+        wide = tok.strip() == "wide"
+        load = 0.5 if wide else float(tok)
+        entry = {"layout": "wide" if wide else "compact", "load_asked": load}
         try:
-            os.environ["KAMD_TABLE_LAYOUT"] = "compact"
+            os.environ["KAMD_TABLE_LAYOUT"] = "wide" if wide else "compact"
             os.environ["KAMD_TABLE_LOAD"] = str(load)
             t0 = time.time()
             index = ka.Index(a.index)
@@ -58,8 +60,8 @@ def main():
             v = index.view
             entry.update({"slots_per_line": int(v.slots_per_bucket), "table_bytes": int((v.n_buckets + v.pad_buckets) * 64),
                           "load": round(index.num_kmers / float(v.slots_per_bucket * v.n_buckets), 3), "tag_bits": int(v.tag_w)})
-            if v.table_layout != 1:
-                raise RuntimeError("the loader did not build the compact layout")
+            if v.table_layout != (0 if wide else 1):
+                raise RuntimeError("the loader did not build the layout asked for")
             ctx = ka.Context(a.device)
             ctx.upload(index)
 
