@@ -106,7 +106,7 @@ int kamd_index_load(const char* path, int threads, kamd_index** out);
  * wide | compact | auto -- auto when unset -- and KAMD_TABLE_LOAD): KAMD_TABLE_WIDE = three 20-byte slots per 64-byte line at a load of 0.5,
  * KAMD_TABLE_COMPACT = four exact 16-byte slots per line (kamd_index_view::table_layout; an error when the index's class ids or text
  * positions do not fit the slot), KAMD_TABLE_AUTO = compact when it fits (the default).  load = load factor of the compact table in [0.2, 0.9]
- * (anything else: 0.5 while that table stays under 2.4 GB, 0.6 beyond).  A flattened file (kamd_index_save) carries its layout: asking for KAMD_TABLE_WIDE or _COMPACT (here, or through
+ * (anything else: 0.4 or 0.5 while that table stays under 2.4 GB, 0.6 beyond).  A flattened file (kamd_index_save) carries its layout: asking for KAMD_TABLE_WIDE or _COMPACT (here, or through
  * KAMD_TABLE_LAYOUT) and naming a flattened file of the other layout is an error (-3); _AUTO takes what the file holds. */
 #define KAMD_TABLE_WIDE 0
 #define KAMD_TABLE_COMPACT 1

@@ -510,9 +510,11 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   // ---- k-mer table: two passes over all k-mers (count per home bucket, then place), no transient copy ----
   // The layout (kamd_core.h): wide = 3 slots of 20 bytes per line at a load of 0.5; compact = 4 slots of 16 bytes at a load of 0.6
   // (or the caller's): KAMD_TABLE_COMPACT is an error when a field does not fit, KAMD_TABLE_AUTO builds the wide one then.
-  // load factor when the caller names none: 0.5 while that table stays under the 2.4 GB up to which dependent random reads run at full
-  // rate on MI355X (profiles/README.md), 0.6 beyond (fewer bytes beat fewer lines per probe there)
-  const double default_load = (double)ix->n_kmers * (64.0 / kamd::COMPACT_SLOTS) / 0.5 <= 2.4e9 ? 0.5 : 0.6;
+  // load factor when the caller names none: the sparsest of 0.4 / 0.5 whose table stays under the 2.4 GB up to which dependent random
+  // reads run at full rate on MI355X (fewer continue flags: 9.57 / 9.90 / 10.53 bucket lines per pair of config #3 at 0.4 / 0.5 / 0.6,
+  // kernel A 10.13 / 10.26 / 10.55 ms; profiles/README.md), 0.6 beyond (fewer bytes beat fewer lines per probe there)
+  const double bytes_at_1 = (double)ix->n_kmers * (64.0 / kamd::COMPACT_SLOTS);
+  const double default_load = bytes_at_1 / 0.4 <= 2.4e9 ? 0.4 : bytes_at_1 / 0.5 <= 2.4e9 ? 0.5 : 0.6;
   const double compact_load = (compact_load_arg >= 0.2 && compact_load_arg <= 0.9) ? compact_load_arg : default_load;
   bool compact = want_compact != KAMD_TABLE_WIDE;
   const uint64_t nb_wide = std::max<uint64_t>(16, (ix->n_kmers * 2 + kamd::BUCKET_SLOTS - 1) / kamd::BUCKET_SLOTS);  // load factor 0.5 over 3-slot buckets

@@ -3874,7 +3874,6 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
                                                      double* alpha_out, double* a_out, int n_rounds, int clamp, int* s_hist, long long* clk = nullptr) {
   namespace L = kamd_em_sell;
   constexpr bool TREE = W >= 8 || (W == 4 && NS == 2);   // (the forms that run with 128 registers, one workgroup per CU)
-  constexpr bool LEAN = W == 4 && NS == 1;                // (64 registers, two workgroups per CU: the segment constants stay in LDS)
   const int lane = lane_id();
   const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), NW = nthr >> 6;
   const u32 r0 = P.row_base[g], nR = P.row_base[g + 1] - r0, t0 = P.tr_base[g], nT = P.tr_base[g + 1] - t0;
@@ -3949,10 +3948,8 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
     if (ro[k].has && r_next == wv + (u32)k * NW) r_next += NW; else ro[k].has = false;
     if (co[k].has && c_next == wv + (u32)k * NW) c_next += NW; else co[k].has = false;
     r_cnt[k] = 0; r_wc[k] = 0; c_single[k] = 0.0; c_eff[k] = 1.0; c_at[k] = 0.0; c_cur[k] = 0.0;
-    if constexpr (!LEAN) {
-      if (ro[k].has && ro[k].fin) { const u64 cwv = s_cw[ro[k].seg]; r_cnt[k] = (u32)cwv; r_wc[k] = (u32)(cwv >> 32); }
-      if (co[k].has && co[k].fin) { c_single[k] = s_single[co[k].seg]; c_eff[k] = s_eff[co[k].seg]; c_at[k] = s_a0[co[k].seg]; c_cur[k] = s_al0[co[k].seg]; }
-    }
+    if (ro[k].has && ro[k].fin) { const u64 cwv = s_cw[ro[k].seg]; r_cnt[k] = (u32)cwv; r_wc[k] = (u32)(cwv >> 32); }
+    if (co[k].has && co[k].fin) { c_single[k] = s_single[co[k].seg]; c_eff[k] = s_eff[co[k].seg]; c_at[k] = s_a0[co[k].seg]; c_cur[k] = s_al0[co[k].seg]; }
   }
   double* const al = s_al0; double* const av = s_a0;
   const unsigned char* const lds0 = smem;
@@ -3970,11 +3967,7 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
         double S = ems_reg_slice_sum<W, TREE>(ro[k].w, ro[k].nq, lds0);
         if (tk) { clk[13] = clock64(); clk[14] = (long long)((ro[k].nq * 4u) | (ro[k].meta ? 0x10000u : 0u)); }
         if (ro[k].meta) S = pm_scan_seg_masked(S, ro[k].reach, lane, ro[k].steps);
-        if (ro[k].fin) {
-          u32 cnt = r_cnt[k], wc = r_wc[k];
-          if constexpr (LEAN) { const u64 cwv = s_cw[ro[k].seg]; cnt = (u32)cwv; wc = (u32)(cwv >> 32); }
-          s_g[ro[k].seg] = (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
-        }
+        if (ro[k].fin) s_g[ro[k].seg] = (r_cnt[k] == 0 || (double)r_wc[k] * S < 4.9406564584124654e-324) ? 0.0 : (double)r_cnt[k] / S;
         if (tk) clk[15] = clock64();
       }
     }
@@ -4020,10 +4013,7 @@ __device__ __forceinline__ void ems_group_rounds_reg(const EmSellDev& P, u32 g, 
         if (tk) { clk[9] = clock64(); clk[10] = (long long)((co[k].nq * 4u) | (co[k].meta ? 0x10000u : 0u)); }
         if (co[k].meta) acc = pm_scan_seg_masked(acc, co[k].reach, lane, co[k].steps);
         bool chg = false;
-        if (co[k].fin) {
-          if constexpr (LEAN) { double nx, an; chg = finish_col(co[k].seg, av[co[k].seg], al[co[k].seg], s_single[co[k].seg], s_eff[co[k].seg], acc, nx, an); }
-          else chg = finish_col(co[k].seg, c_at[k], c_cur[k], c_single[k], c_eff[k], acc, c_cur[k], c_at[k]);
-        }
+        if (co[k].fin) chg = finish_col(co[k].seg, c_at[k], c_cur[k], c_single[k], c_eff[k], acc, c_cur[k], c_at[k]);
         ch += __popcll(__ballot(chg));
         if (tk) clk[11] = clock64();
       }
@@ -4356,7 +4346,10 @@ __global__ __launch_bounds__(BLOCK) void k_eml_rank_tr(kamd_em_local::BuildArgs 
     A.tr_id[m] = t; A.single[m] = A.single_all[t]; A.eff_m[m] = A.eff[t];
   }
 }
-__global__ __launch_bounds__(BLOCK) void k_eml_rank_rows(kamd_em_local::BuildArgs A) {
+// (1024 lanes per group: the ranking is quadratic in the group's rows -- 1 240 of them in the groups of ~9 300 entries round 4 made the
+// default -- and a workgroup of 256 lanes took 255 us for it)
+constexpr int EML_RANK_BLOCK = 1024;
+__global__ __launch_bounds__(EML_RANK_BLOCK) void k_eml_rank_rows(kamd_em_local::BuildArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
   const u32 g = blockIdx.x, lo = A.row_base[g], n = A.row_base[g + 1] - lo;
   u64* s_k = reinterpret_cast<u64*>(gb_smem);
@@ -4566,7 +4559,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
     hipLaunchKernelGGL(k_eml_rank_tr, dim3(ng), dim3(BLOCK), rk_lds, c->stream, A);
   } else hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
   hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
-  if (lds_rank) hipLaunchKernelGGL(k_eml_rank_rows, dim3(ng), dim3(BLOCK), rk_lds, c->stream, A);
+  if (lds_rank) hipLaunchKernelGGL(k_eml_rank_rows, dim3(ng), dim3(EML_RANK_BLOCK), rk_lds, c->stream, A);
   else hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
   // steps I, J, K, K2 and their scans: one workgroup per group out of LDS (k_eml_group_build); a group too large for that -- none
   // that the EM kernel could hold -- takes the steps one by one
@@ -4656,7 +4649,6 @@ struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0, team_bytes = 0; int block = 256;
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int exp = 0;   // exp: timing experiment (KAMD_EM_EXP)
   int reg_words = 0;   // index words per lane and direction the kernel keeps in registers (0: the form that reads everything from LDS)
-  bool lean = false;   // four-word form in 64 registers (one slice per wavefront and direction, constants from LDS): two workgroups per CU
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr; double* d_out = nullptr;
   std::vector<double> h_alpha; int err = 0;
   const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
@@ -4683,7 +4675,6 @@ struct EmSellGpu {
 #define KAMD_EMS_LAUNCH(C, E) hipLaunchKernelGGL((k_em_sell<C, E>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
 #define KAMD_EMS_LAUNCH_REG(C, W, NS) hipLaunchKernelGGL((k_em_sell<C, 0, W, NS>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
       if (reg_words == 2) { if (clk) KAMD_EMS_LAUNCH_REG(true, 2, 1); else KAMD_EMS_LAUNCH_REG(false, 2, 1); }
-      else if (reg_words == 4 && lean) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4, 1); else KAMD_EMS_LAUNCH_REG(false, 4, 1); }
       else if (reg_words == 4) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4, 2); else KAMD_EMS_LAUNCH_REG(false, 4, 2); }
       else if (reg_words == 8) { if (clk) KAMD_EMS_LAUNCH_REG(true, 8, 1); else KAMD_EMS_LAUNCH_REG(false, 8, 1); }
       else if (clk) KAMD_EMS_LAUNCH(true, 0);
@@ -4741,7 +4732,6 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
   {
     const int cap = std::min(64, std::max(1, c->tune.em_split_len));
     if (c->tune.em_reg_slices == 1 && !getenv("KAMD_EM_EXP")) reg_words = cap <= 8 ? 2 : cap <= 16 ? 4 : cap <= 32 ? 8 : 0;
-    if (const char* e = getenv("KAMD_EM_LEAN")) lean = atoi(e) != 0;   // (experiment)
   }
   if (P.n_groups > P.n_small) {
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -4750,8 +4740,6 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (const char* e = getenv("KAMD_EM_EXP")) {
