@@ -2233,6 +2233,11 @@ struct kamd_ctx {
   // kamd_fld_prefetch: the first prefix of a batch, launched on a side stream so that it overlaps kernel A
   hipStream_t fld_stream = nullptr; hipEvent_t fld_ev = nullptr, fld_ev_in = nullptr;
   struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0; bool valid = false; } fld_pending;
+  // a prefetch that waits for kernel A of the same batch to finish (launched by align_batch behind kernel A: the fragment-length kernels then
+  // run beside k_classify / k_tup_absorb, which leave most of the memory system's request rate unused, instead of underneath kernel A, which
+  // lives on it)
+  struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0, comp = 0; bool valid = false; } fld_deferred;
+  int fld_after_a = 1;
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   DevState* state_pin = nullptr;   // pinned staging of the read-backs (sync_state)
@@ -2524,6 +2529,7 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (c->stats_a.ensure(sizeof(DevStatsA), 0, c->stream) || hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream) != hipSuccess) { delete c; return -100; }
   tuning_defaults(&c->tune);
   tuning_from_env(&c->tune);
+  if (const char* e = getenv("KAMD_FLD_AFTER_A")) c->fld_after_a = atoi(e) != 0;   // (experiment: 0 = the prefetch runs underneath kernel A, as through round 3)
   apply_tuning(c);
   *out = c;
   return 0;
@@ -2826,6 +2832,7 @@ struct WorkStream {
 };
 // One batch: kernel A in `chunks` launches on the caller's stream, every chunk classified and its tuple records absorbed as soon as
 // it is matched.  On return every item that is neither an overflow item nor one a positional filter changed is accounted for.
+int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l, u64 n, int seq_words, int rec_words, hipStream_t s);
 template <bool PAIRED, bool FILTER>
 int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
                 AlignOut& out, u64 key_base) {
@@ -2855,6 +2862,18 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
     if (chunks > 1) HIPC(hipEventRecord(c->al_ev_chunk[k], ws.user));
   }
   HIPC(hipEventRecord(c->ev1, ws.user));
+  if (c->fld_deferred.valid && !(c->fld_deferred.w == d_words && c->fld_deferred.l == d_len && c->fld_deferred.n <= n_items)) c->fld_deferred.valid = false;   // (another batch: stale)
+  if (c->fld_deferred.valid) {
+    // the deferred fragment-length prefetch of this batch: its kernels start when kernel A has finished and run beside what follows
+    c->fld_deferred.valid = false;
+    const auto& q = c->fld_deferred;
+    const FilterDev ffd{q.so, 0, 0, q.strand, q.comp};
+    HIPC(hipStreamWaitEvent(c->fld_stream, c->ev1, 0));
+    if (int rc = fld_launch(c, ffd, q.w, q.l, q.n, (q.max_len + 15) / 16 + 1, (int)kamd_packed_record_words(q.max_len), c->fld_stream)) return rc;
+    HIPC(hipEventRecord(c->fld_ev, c->fld_stream));
+    c->fld_pending.w = q.w; c->fld_pending.l = q.l; c->fld_pending.n = q.n; c->fld_pending.max_len = q.max_len;
+    c->fld_pending.strand = q.strand; c->fld_pending.so = q.so; c->fld_pending.valid = true;
+  }
   c->last_classify_ms = 0.f;
   for (int k = 0; k < chunks; k++) {
     const u64 first = (u64)k * per, n = std::min(per, n_items - first);
@@ -3062,6 +3081,11 @@ extern "C" int kamd_fld_prefetch(kamd_ctx* c, const kamd_quant_opts* o, const ui
   if (c->fld_pending.valid) { HIPC(hipStreamSynchronize(c->fld_stream)); c->fld_pending.valid = false; }
   const FilterDev fd{o->single_overhang, 0, 0, o->strand, c->ix.comprehensive};
   const u64 n = std::min<u64>(FLD_FIRST_CHUNK, n_items);
+  if (c->fld_after_a) {   // launched by the kamd_pseudoalign call on the same batch, behind its kernel A (align_batch)
+    c->fld_deferred.w = d_words; c->fld_deferred.l = d_len; c->fld_deferred.n = n; c->fld_deferred.max_len = max_len;
+    c->fld_deferred.strand = o->strand; c->fld_deferred.so = o->single_overhang; c->fld_deferred.comp = c->ix.comprehensive; c->fld_deferred.valid = true;
+    return 0;
+  }
   HIPC(hipEventRecord(c->fld_ev_in, c->stream));            // the reads were produced on the context stream
   HIPC(hipStreamWaitEvent(c->fld_stream, c->fld_ev_in, 0));
   if (int rc = fld_launch(c, fd, d_words, d_len, n, (max_len + 15) / 16 + 1, (int)kamd_packed_record_words(max_len), c->fld_stream)) return rc;
@@ -3081,6 +3105,7 @@ extern "C" int kamd_fld_from_batch(kamd_ctx* c, const kamd_quant_opts* o, const 
   HIPC(hipSetDevice(c->device));
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
+  c->fld_deferred.valid = false;   // (a prefetch that no kamd_pseudoalign call picked up is dropped: the sample is computed here)
   u64 found = n_used ? *n_used : 0, done = 0;  // continues a sample started on earlier batches
   const u64 found0 = found;
   // the sample is the first 10000 qualifying pairs: start with a prefix that suffices when a few per cent of the pairs
