@@ -3024,7 +3024,8 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
 }
 
 namespace {
-constexpr u64 FLD_FIRST_CHUNK = 1048576;   // ~20 000 qualifying pairs at config #3's rate: one pass, with a margin for sparser data
+// ~20 000 qualifying pairs at config #3's rate: one pass, with a margin for sparser data (KAMD_FLD_FIRST_CHUNK: experiments)
+const u64 FLD_FIRST_CHUNK = [] { const char* e = getenv("KAMD_FLD_FIRST_CHUNK"); const long long v = e ? atoll(e) : 0; return v >= 65536 ? (u64)v : (u64)1048576; }();
 constexpr int FLD_CAP_SMALL = 64;   // list entries per item in global scratch (an LDS list of TUPLE_CAP entries sends too many items to
                                     // the re-run, which costs ~1 ms per launch however few they are)
 // buffers for a prefix of n items + k_fld_first / k_fld / k_fld_rank + the copy of the ranked sample, all on stream s (no synchronisation)
