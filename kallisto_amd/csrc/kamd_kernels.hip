@@ -742,7 +742,7 @@ __global__ __launch_bounds__(BLOCK) void k_rec_dedup(const u32* __restrict__ str
 constexpr u64 TAG_LOCAL = 0x80000000ULL;   // the tag's offset refers to the batch's stream (the record is not in the store yet)
 __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ batch, const u32* __restrict__ store, const u64* __restrict__ rec_off,
                                                       const u64* __restrict__ idx, u64 n, TSlot* table, u64 mask, u64* list, u64 key_base, int track,
-                                                      u32 max_probe, u64* fail, DevState* st) {
+                                                      u32 max_probe, u64* fail, DevState* st, u32 fixed_stride = 0, u64 item0 = 0) {
   __shared__ u32 blk_n, blk_words; __shared__ u64 blk_base;
   if (threadIdx.x == 0) { blk_n = 0; blk_words = 0; }
   __syncthreads();
@@ -750,7 +750,9 @@ __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ ba
   bool is_owner = false; u64 s = 0; u32 my = 0, m = 0;
   if (i < n) {
     const u64 r = idx ? idx[i] : i;
-    const u64 off = rec_off[r];
+    // (kernel A's records sit in fixed slots -- record r of the chunk at (item0 + r) x stride, what k_classify wrote into rec_off --: the
+    // main pass computes the place instead of loading it, one dependent load less in a chain of three)
+    const u64 off = fixed_stride ? (item0 + r) * (u64)fixed_stride : rec_off[r];
     if (off != ~0ULL && batch[off] != 0u) {
       m = batch[off + 1];
       const u64 h = rec_hash(batch + off + 1, m + 1, 1);
@@ -2381,7 +2383,7 @@ int tuples_resize(kamd_ctx* c, u64 cap) {
 // is kept at most half full, and a record that finds no slot within 64 probes makes it grow before that record is tried again.
 // first_idx (device, optional): the records to look at are rec_off[first_idx[0 .. n-1]] instead of rec_off[0 .. n-1]
 int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 batch_words, u64 key_base, u64 n_tuple_bound,
-                  const u64* first_idx = nullptr) {
+                  const u64* first_idx = nullptr, u32 fixed_stride = 0, u64 item0 = 0) {
   if (n == 0) return 0;
   if (batch_words >= 0x7FFFFFF0ULL) return kamd::fail(-1, "kamd_pseudoalign: the record stream of one batch must stay below 2^31 words (use smaller batches)");
   DevState* dst = (DevState*)c->state.p;
@@ -2410,7 +2412,8 @@ int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 
     if (int rc = push_state(c)) return rc;
     hipLaunchKernelGGL(k_tup_absorb, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), rec_off, idx, count,
                        c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base,
-                       (c->track_order ? 1 : 0) | (getenv("KAMD_DEBUG_ABSORB") ? (atoi(getenv("KAMD_DEBUG_ABSORB")) & 6) : 0), 64u, fail_a, dst);
+                       (c->track_order ? 1 : 0) | (getenv("KAMD_DEBUG_ABSORB") ? (atoi(getenv("KAMD_DEBUG_ABSORB")) & 6) : 0), 64u, fail_a, dst,
+                       fixed_stride, item0);
     HIPC(hipGetLastError());
     c->ttable_clean = false;
     if (int rc = sync_state(c)) return rc;
@@ -2890,7 +2893,7 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
     c->last_classify_ms += ms;
     // the chunk's tuple records join the distinct tuples of the run (overflow items have no tuple record yet: see kamd_pseudoalign)
     if (int rc = absorb_tuples(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>() + first, n, c->host_state.stream_words, key_base + first,
-                               c->host_state.st_multi - c->multi_before)) return rc;
+                               c->host_state.st_multi - c->multi_before, nullptr, (u32)stride, first)) return rc;
     c->multi_before = c->host_state.st_multi;
   }
   HIPC(hipEventSynchronize(c->ev1));
