@@ -179,7 +179,10 @@ class FastqSpool:
             t = self._tmpl[:m]
             t[:, 2:11] = digits
             t[:, 12:12 + L] = r
-            self._q[i].put(t.cpu())     # (a copy: the template is reused for the next mate / chunk)
+            host = t.cpu()              # (a copy: the template is reused for the next mate / chunk ...
+            if host.data_ptr() == t.data_ptr():
+                host = host.clone()     #  ... also when the reads were generated on the CPU, where .cpu() is the tensor itself)
+            self._q[i].put(host)
         self.n += m
 
     def close(self):

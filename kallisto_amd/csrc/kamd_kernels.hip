@@ -2240,6 +2240,7 @@ struct kamd_ctx {
   // lives on it)
   struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0, comp = 0; bool valid = false; } fld_deferred;
   int fld_after_a = 1;
+  int debug_absorb = 0;   // KAMD_DEBUG_ABSORB (read once in kamd_ctx_create): timing experiments of k_tup_absorb, results wrong
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   DevState* state_pin = nullptr;   // pinned staging of the read-backs (sync_state)
@@ -2412,7 +2413,7 @@ int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 
     if (int rc = push_state(c)) return rc;
     hipLaunchKernelGGL(k_tup_absorb, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), rec_off, idx, count,
                        c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base,
-                       (c->track_order ? 1 : 0) | (getenv("KAMD_DEBUG_ABSORB") ? (atoi(getenv("KAMD_DEBUG_ABSORB")) & 6) : 0), 64u, fail_a, dst,
+                       (c->track_order ? 1 : 0) | c->debug_absorb, 64u, fail_a, dst,
                        fixed_stride, item0);
     HIPC(hipGetLastError());
     c->ttable_clean = false;
@@ -2532,6 +2533,7 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (c->stats_a.ensure(sizeof(DevStatsA), 0, c->stream) || hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream) != hipSuccess) { delete c; return -100; }
   tuning_defaults(&c->tune);
   tuning_from_env(&c->tune);
+  if (const char* e = getenv("KAMD_DEBUG_ABSORB")) c->debug_absorb = atoi(e) & 6;
   if (const char* e = getenv("KAMD_FLD_AFTER_A")) c->fld_after_a = atoi(e) != 0;   // (experiment: 0 = the prefetch runs underneath kernel A, as through round 3)
   apply_tuning(c);
   *out = c;

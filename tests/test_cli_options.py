@@ -157,3 +157,26 @@ def test_bench_line_digest_on_a_kept_line():
     assert k["roofline"]["frac"] == d["roofline"]["frac"] and k["cpu_baseline"]["kind"] == "reference"
     assert k["parity_check"]["ec_multiset_equal"] is True and k["parity_check_tail"]["ok"] is True
     assert len(json.dumps(k)) < 4000
+
+
+def test_fastq_spool_writes_what_write_fastq_fast_writes(tmp_path):
+    """bench.FastqSpool (the whole input of a run as FASTQ, text assembled chunk by chunk where the reads are generated) against
+    bench.write_fastq_fast on the same reads: byte-identical files, ids continue over the chunks."""
+    import numpy as np
+    import torch
+    import bench
+    rng = np.random.default_rng(3)
+    L = 37
+    r1 = rng.choice(np.frombuffer(b"ACGTN", np.uint8), (1000, L))
+    r2 = rng.choice(np.frombuffer(b"ACGTN", np.uint8), (1000, L))
+    sp = bench.FastqSpool(str(tmp_path / "spool"), True, L)
+    for a, b in ((0, 300), (300, 301), (301, 1000)):
+        sp.add([torch.from_numpy(r1[a:b].copy()), torch.from_numpy(r2[a:b].copy())])
+    f1, f2 = sp.close()
+    bench.write_fastq_fast(str(tmp_path / "w1.fq"), r1)
+    bench.write_fastq_fast(str(tmp_path / "w2.fq"), r2)
+    assert open(f1, "rb").read() == open(tmp_path / "w1.fq", "rb").read()
+    assert open(f2, "rb").read() == open(tmp_path / "w2.fq", "rb").read()
+    assert sp.n == 1000 and os.path.getsize(f1) == 1000 * sp.rec_bytes
+    sp.remove()
+    assert not os.path.exists(f1)
