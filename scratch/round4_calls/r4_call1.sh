@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, call 1: (1) the new GPU tests (self-launched two-rank bench, flattened-index pick-up + slow exit, the late tests of round 3),
 # (2) the default bench line with the full-size parity leg, (3) GENCODE-sized index: wide vs compact at three loads + kernel stats + FETCH_SIZE
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c1; mkdir -p $O
 export TMPDIR=/tmp
 df -h /tmp /dev/shm | tail -2; free -g | head -2; nproc

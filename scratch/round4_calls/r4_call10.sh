@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 10: the fragment-length prefetch behind kernel A (beside k_classify / k_tup_absorb) instead of underneath it
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c10; mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cli.py -q -x -k "quant_matches or batches or cli_matches or several_ranks or fld or reference_reader" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log

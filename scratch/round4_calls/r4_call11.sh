@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 11: size of the fragment-length prefix (behind kernel A)
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c11; mkdir -p $O
 export TMPDIR=/tmp
 FAST="--steps 10 --warmup 3 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg --no-config2 --bootstraps 0 --full-parity off"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 12: run-to-run spread of kernel A on one box (same build, same flags), and table loads 0.4 / 0.45 / 0.5
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c12; mkdir -p $O
 export TMPDIR=/tmp
 FAST="--steps 10 --warmup 3 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg --no-config2 --bootstraps 0 --full-parity off"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 13: k_tup_absorb computes the record offsets of the main pass instead of loading them
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c13; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cli.py tests/test_gpu_bus_tcc.py -q -x > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log

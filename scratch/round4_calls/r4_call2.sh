@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 2: the register-resident EM kernel: parity tests, then timings against the LDS-only form over split length / group divisor
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c2; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multirank.py -q -x -k "em or two_ranks or bootstrap or reproducible" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/tests.log

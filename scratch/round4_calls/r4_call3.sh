@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 3: register-resident EM kernel with tree sums in the wide forms: group size x split length; compact table default
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c3; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "em_ or reproducible" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/tests.log

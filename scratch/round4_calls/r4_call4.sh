@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 4: EM register form with byte addresses / masked scans / two slices per wavefront; auto group divisor; pinned read-backs
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c4; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multirank.py -q -x -k "em_ or reproducible or bootstrap or two_ranks or quant_matches" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/tests.log

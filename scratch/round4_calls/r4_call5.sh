@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 5: the whole GPU suite (regression check of the round's changes so far) + PMC counters of the register-resident EM kernel
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c5; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -q -x -m gpu > $O/tests.log 2>&1; echo "tests rc=$?"; tail -6 $O/tests.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 6: the whole GPU suite after the round's kernel changes + the step time with the tuple list carrying the store offsets
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c6; mkdir -p $O
 export TMPDIR=/tmp
 FAST="--steps 10 --warmup 3 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg --no-config2 --bootstraps 0 --full-parity off"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 7: what k_tup_absorb's time is made of (timing experiments, results wrong): no count atomic / no verification read / neither
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c7; mkdir -p $O
 export TMPDIR=/tmp
 FAST="--steps 5 --warmup 2 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg --no-config2 --bootstraps 0 --full-parity off"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, call 8: (1) a full bench line with parity legs on the GENCODE-sized index; (2) two ranks on one GPU on the human-sized index with
 # the merged result against the reference; (3) kernel A launch-shape sweep on the compact table
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c8; mkdir -p $O
 export TMPDIR=/tmp
 FAST="--steps 5 --warmup 2 --no-cpu-baseline --parity-sample 0 --end-to-end 0 --no-pinned-pipeline --no-compact-leg --no-config2 --bootstraps 0 --full-parity off"

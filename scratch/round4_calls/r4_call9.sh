@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 9: the four-word EM kernel in 64 registers (constants from LDS, one slice per wavefront and direction): two workgroups per CU
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 R=$(pwd); O=$R/gpurun_out/r4c9; mkdir -p $O
 export TMPDIR=/tmp
 KAMD_EM_LEAN=1 timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "em_ or reproducible or quant_matches or bootstrap" > $O/tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/tests.log
