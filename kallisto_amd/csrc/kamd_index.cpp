@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <fstream>
 #include <memory>
 #include <string>
@@ -110,11 +111,31 @@ struct RawBlock { uint32_t lb, ub, ec; uint64_t pos_off; };
 
 // allocator whose resize() leaves new elements uninitialised: the three big tables of a flattened index file are filled by
 // parallel reads straight away (value-initialising 3 GB first costs a third of the load)
+// Large blocks (the k-mer table and its two aux arrays: gigabytes that are then written at random) come straight from mmap and are
+// advised to use transparent huge pages: with 4 KB pages the first touch of 3.4 GB is 0.85 M page faults and the placement pass misses
+// the TLB on nearly every k-mer (measured in the 8-CPU build container, human-sized index: "layout + allocation" 1.97 -> 0.35 s,
+// "place pass" 1.77 -> 1.1 s).  Where the kernel's THP mode is `never` the advice is ignored and nothing changes.
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
   template <class U> struct rebind { typedef NoInitAlloc<U> other; };
   NoInitAlloc() = default;
   template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  static constexpr size_t HUGE_FROM = 8u << 20, HUGE_PAGE = 2u << 20;
+  static size_t mapped_bytes(size_t n) { return (n * sizeof(T) + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1); }
+  T* allocate(size_t n) {
+    if (n * sizeof(T) >= HUGE_FROM) {
+      void* p = mmap(nullptr, mapped_bytes(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (p == MAP_FAILED) throw std::bad_alloc();
+      static const bool thp = getenv("KAMD_NO_THP") == nullptr;
+      if (thp) (void)madvise(p, mapped_bytes(n), MADV_HUGEPAGE);
+      return static_cast<T*>(p);
+    }
+    return std::allocator<T>::allocate(n);
+  }
+  void deallocate(T* p, size_t n) {
+    if (n * sizeof(T) >= HUGE_FROM) { (void)munmap(p, mapped_bytes(n)); return; }
+    std::allocator<T>::deallocate(p, n);
+  }
   template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
   template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
 };
@@ -413,7 +434,19 @@ namespace {
 int load_index_impl(const char* path, int threads, int want_compact, double compact_load_arg, kamd_index** out, bool layout_requested) {
   if (!out) return kamd::fail(-1, "kamd_index_load: null output pointer");
   *out = nullptr;
-  if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  if (threads <= 0) {
+    // the CPUs this process may keep busy, not the host's processors: a container routinely shows all of them while its cgroup grants a
+    // fraction (cpu.max), and four times as many builder threads as CPUs made the load slower, not faster
+    threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0}; long long period = 0;
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+        const long long quota = atoll(q);
+        if (quota > 0) threads = (int)std::max<long long>(1, std::min<long long>(threads, (quota + period / 2) / period));
+      }
+      fclose(f);
+    }
+  }
   threads = std::min(threads, 64);
   {   // a file written by kamd_index_save?
     FILE* f = path ? fopen(path, "rb") : nullptr;
