@@ -113,8 +113,10 @@ struct RawBlock { uint32_t lb, ub, ec; uint64_t pos_off; };
 // parallel reads straight away (value-initialising 3 GB first costs a third of the load)
 // Large blocks (the k-mer table and its two aux arrays: gigabytes that are then written at random) come straight from mmap and are
 // advised to use transparent huge pages: with 4 KB pages the first touch of 3.4 GB is 0.85 M page faults and the placement pass misses
-// the TLB on nearly every k-mer (measured in the 8-CPU build container, human-sized index: "layout + allocation" 1.97 -> 0.35 s,
-// "place pass" 1.77 -> 1.1 s).  Where the kernel's THP mode is `never` the advice is ignored and nothing changes.
+// the TLB on nearly every k-mer.  Measured on the pool's boxes (human-sized index, 16 CPUs, scratch/round4_calls/r4_call15.sh): "layout +
+// allocation" 0.36 -> 0.09 s, the whole load 1.05-1.19 -> 0.86-0.89 s, a flattened file 0.22-0.30 -> 0.07 s; in the 8-CPU build container
+// the placement pass goes from 1.85 to 1.17 s while the sandbox's huge-page faults cost what they save.  Where the kernel's THP mode is
+// `never` the advice is ignored and nothing changes; KAMD_NO_THP=1 leaves it out.
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
   template <class U> struct rebind { typedef NoInitAlloc<U> other; };

@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_reads(const char* __restrict__ s
   const u64 r = gid / (u64)groups;
   const int g = (int)(gid % (u64)groups);
   if (r >= n_reads) return;
-  const int L = min(len[r], groups * 32);   // (a length beyond max_len is the caller's error: nothing behind max_len is read or written)
+  const int L = min(len[r], (seq_words - 1) * 16);   // (a length beyond max_len is the caller's error: nothing behind the record's sequence words is read or written)
   if (g == 0) out_len[r] = (uint16_t)len[r];
   const int b0 = g * 32;
   if (b0 >= L) return;
