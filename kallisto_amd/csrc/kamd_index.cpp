@@ -97,6 +97,19 @@ bool roaring_native(const uint8_t* b, size_t n, std::vector<uint32_t>& out) {
   return false;
 }
 
+// smallest and largest member of a set without materialising it (position sets: only the two are used, and most hold one element)
+bool roaring_minmax(const uint8_t* b, size_t n, std::vector<uint32_t>& scratch, uint32_t* mn, uint32_t* mx) {
+  if (n >= 5 && b[0] == 1) {   // the native array form: cardinality, then the members in increasing order
+    uint32_t card; memcpy(&card, b + 1, 4);
+    if (card == 0 || 5 + (size_t)card * 4 > n) return false;
+    memcpy(mn, b + 5, 4); memcpy(mx, b + 5 + (size_t)(card - 1) * 4, 4);
+    return true;
+  }
+  if (!roaring_native(b, n, scratch) || scratch.empty()) return false;
+  *mn = scratch.front(); *mx = scratch.back();
+  return true;
+}
+
 struct VecHash {
   size_t operator()(const std::vector<uint32_t>& v) const {
     uint64_t h = 0x9e3779b97f4a7c15ULL ^ v.size();
@@ -685,8 +698,8 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
       for (uint64_t t = 0; t < vsz; t++) {
         uint64_t s2 = c.get<uint64_t>();
         const uint8_t* pp = c.take(s2);
-        if (!pp || !roaring_native(pp, s2, tmp) || tmp.empty()) return kamd::fail(-3, "index: bad position set");
-        uint32_t mn = tmp.front(), mx = tmp.back();
+        uint32_t mn = 0, mx = 0;
+        if (!pp || !roaring_minmax(pp, s2, tmp, &mn, &mx)) return kamd::fail(-3, "index: bad position set");
         posw_all.push_back(mn);
         bool smin = (mn & 0x7FFFFFFFu) == mn, smax = (mx & 0x7FFFFFFFu) == mx;
         sense_all.push_back(smin != smax ? 2 : (uint8_t)smin);
