@@ -703,7 +703,7 @@ def main():
     ap.add_argument("--multi-parity", action="store_true", help="N > 1: rank 0 also runs the reads of ALL ranks on its own (one context, no communicator) "
                     "and the merged result of the ranks must equal it (EC multiset, flens identical; est_counts 1e-9; same EM rounds)")
     ap.add_argument("--table-layout", default=None, choices=["wide", "compact", "auto"],
-                    help="layout of the k-mer table (KAMD_TABLE_LAYOUT; default: the library's, wide): compact = four quotiented 16-byte slots per "
+                    help="layout of the k-mer table (KAMD_TABLE_LAYOUT; default: the library's, auto = compact when it fits): compact = four quotiented 16-byte slots per "
                          "line instead of three 20-byte ones (kamd_core.h)")
     ap.add_argument("--no-config2", action="store_true", help="skip the child run of BASELINE config #2 (yeast, single-end) that the default one-GPU run of config #3 appends")
     ap.add_argument("--no-compact-leg", action="store_true", help="skip the side leg that repeats the steps on the compact k-mer table (N = 1 only)")

@@ -228,8 +228,8 @@ class Index:
     TABLE_LAYOUTS = {"wide": 0, "compact": 1, "auto": 2}
 
     def __init__(self, path: str, threads: int = 0, table_layout: str | None = None, table_load: float = 0.0):
-        """table_layout: None = kamd_index_load (the environment's KAMD_TABLE_LAYOUT, default wide); "wide" / "compact" / "auto" =
-        kamd_index_load_layout with that layout of the k-mer table (and table_load as the compact table's load factor, 0 = 0.6)."""
+        """table_layout: None = kamd_index_load (the environment's KAMD_TABLE_LAYOUT, default auto: compact when it fits); "wide" / "compact" / "auto" =
+        kamd_index_load_layout with that layout of the k-mer table (and table_load as the compact table's load factor, 0 = the library's choice)."""
         lib = load_library()
         self._h = C.c_void_p()
         if table_layout is None:

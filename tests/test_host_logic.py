@@ -30,8 +30,8 @@ def _load_with_layout(path, layout, load=None):
                 os.environ[k] = v
 
 
-# every test that takes `idx` runs on both layouts of the k-mer table (kamd_core.h): wide = 3 slots of 20 bytes per line (the default),
-# compact = 4 quotiented slots of 16 bytes
+# every test that takes `idx` runs on both layouts of the k-mer table (kamd_core.h): wide = 3 slots of 20 bytes per line,
+# compact = 4 quotiented slots of 16 bytes (the default since round 4)
 @pytest.fixture(scope="module", params=["wide", "compact"])
 def idx(request):
     cache = {}
