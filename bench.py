@@ -625,7 +625,8 @@ def self_launch(n_gpus: int) -> int:
     a smoke test of the flow, never a reported number)."""
     import socket
     share = os.environ.get("KAMD_BENCH_SHARE_GPU") == "1"
-    if not share:
+    script = os.environ.get("KAMD_BENCH_LAUNCH_SCRIPT")   # (tests: a stand-in for this file, started the same way; no GPUs asked for)
+    if not share and not script:
         import torch
         have = torch.cuda.device_count()
         if have < n_gpus:
@@ -646,7 +647,7 @@ def self_launch(n_gpus: int) -> int:
         if share:
             env.setdefault("KAMD_BENCH_BACKEND", "gloo")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-port", str(port), script or os.path.abspath(__file__)] + sys.argv[1:]
         log(f"launching {n_gpus} ranks: {' '.join(cmd[1:8])} bench.py {' '.join(sys.argv[1:])}" + (f"  [{extra}]" if extra else ""))
         pc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
         try:

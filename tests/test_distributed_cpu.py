@@ -104,3 +104,41 @@ def test_bench_self_launch_starts_ranks_and_reports_their_failure():
     assert p.returncode != 0 and not p.stdout.strip()
     err = p.stderr.decode()
     assert "launching 2 ranks" in err and "no result line from the ranks" in err
+
+
+def _stub(tmp_path, body):
+    p = tmp_path / "stub_rank.py"
+    p.write_text("import json, os, sys\nrank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n" + body)
+    return str(p)
+
+
+def test_bench_self_launch_passes_rank_zeros_line_through(tmp_path):
+    """the launcher half of `python bench.py --gpus N` with a stand-in for the ranks: N processes get RANK / WORLD_SIZE / MASTER_* from
+    torch.distributed.run on 127.0.0.1, rank 0's ONE line reaches stdout and nothing else does, exit code 0"""
+    import json
+    import subprocess
+    stub = _stub(tmp_path, "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ.get('KAMD_BENCH_LAUNCHER') == 'self'\n"
+                           "print('noise from rank', rank)\n"
+                           "if rank == 0: print(json.dumps({'metric': 'stub', 'n_gpus': world, 'argv': sys.argv[1:]}))\n")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2"], cwd=ROOT, env=_bare_env(KAMD_BENCH_LAUNCH_SCRIPT=stub),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["argv"] == ["--gpus", "3", "--steps", "2"]
+
+
+def test_bench_self_launch_retries_with_the_process_groups_collectives(tmp_path):
+    """ranks that die with the library's own RCCL communicator (no KAMD_COMM in their environment) are started once more with
+    KAMD_COMM=callbacks, and that attempt's line is the one that comes back"""
+    import json
+    import subprocess
+    stub = _stub(tmp_path, "if os.environ.get('KAMD_COMM') != 'callbacks': sys.exit(7)\n"
+                           "if rank == 0: print(json.dumps({'metric': 'stub', 'transport': os.environ['KAMD_COMM']}))\n")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=_bare_env(KAMD_BENCH_LAUNCH_SCRIPT=stub),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["transport"] == "callbacks"
+    assert "no result line from the ranks" in p.stderr.decode()
