@@ -92,10 +92,14 @@ def prepare_workload(name: str, genes: int, is_builder: bool):
     if not os.path.exists(done):
         if is_builder:
             t0 = time.time()
-            seqs = synth.human_like(n_genes=genes, seed=2) if name == "human" else synth.yeast_like(n_tr=genes, seed=1)
+            bg = np.zeros(0, np.uint8)
+            if name == "stress":
+                seqs, bg = synth.human_stress(n_genes=genes, seed=7)
+            else:
+                seqs = synth.human_like(n_genes=genes, seed=2) if name == "human" else synth.yeast_like(n_tr=genes, seed=1)
             lens = np.array([len(s) for s in seqs], np.int64)
             cat = np.concatenate(seqs)
-            np.savez(npz, cat=cat, lens=lens)
+            np.savez(npz, cat=cat, lens=lens, bg=bg)
             log(f"synthetic transcriptome: {len(seqs)} transcripts, {cat.size/1e6:.1f} Mbp in {time.time()-t0:.0f}s")
             if not os.path.exists(REF_BIN):
                 raise RuntimeError(f"{REF_BIN} missing: the index is built by the reference binary (make -C oracle ref)")
@@ -112,11 +116,20 @@ def prepare_workload(name: str, genes: int, is_builder: bool):
         else:
             wait_for(done)
     z = np.load(npz)
+    prepare_workload.background = z["bg"] if "bg" in z.files and z["bg"].size else None   # (stress: what off-transcriptome fragments are drawn from)
     return z["cat"], z["lens"], idx
 
 
-def write_fastq_fast(path, reads: np.ndarray):
+def write_fastq_fast(path, reads: np.ndarray, mate: int = 0):
+    """the reads as FASTQ.  Default: records as a sequencer writes them (kallisto_amd/synth_fastq.py: variable-length Illumina headers of 63-65 bytes, binned
+    quality strings that fall off towards the 3' end) -- rounds 1-4 wrote fixed 216-byte records with 11-byte headers and 100 x `I`, which flatters
+    every byte-bound rate (20 % fewer bytes per pair) and the inflaters (constant quality lines are one long match); KAMD_BENCH_FASTQ=regular
+    brings that form back for comparisons"""
     n, L = reads.shape
+    if os.environ.get("KAMD_BENCH_FASTQ", "realistic") != "regular":
+        from kallisto_amd import synth_fastq
+        synth_fastq.write_fastq(path, reads, mate)
+        return
     ids = np.char.zfill(np.arange(n).astype("U9"), 9).astype("S9")
     line = np.zeros((n, 2 + 9 + 1 + L + 1 + 2 + L + 1), np.uint8)
     line[:, 0] = ord("@"); line[:, 1] = ord("r")
@@ -143,6 +156,8 @@ class FastqSpool:
         self.dir, self.L, self.n = directory, L, 0
         self.files = [os.path.join(directory, f"full_{i + 1}.fq") for i in range(2 if paired else 1)]
         self.rec_bytes = 2 + 9 + 1 + L + 1 + 2 + L + 1
+        self.realistic = os.environ.get("KAMD_BENCH_FASTQ", "realistic") != "regular"   # (write_fastq_fast: records as a sequencer writes them)
+        self._ft = None
         self.error = None
         self._q = [queue.Queue(maxsize=2) for _ in self.files]
         self._th = [threading.Thread(target=self._writer, args=(i,), daemon=True) for i in range(len(self.files))]
@@ -167,6 +182,14 @@ class FastqSpool:
         """mates: the (m, L) uint8 device tensors of this chunk, one per file"""
         import torch
         m, L, dev = mates[0].shape[0], self.L, mates[0].device
+        if self.realistic:
+            if self._ft is None:
+                from kallisto_amd import synth_fastq
+                self._ft = [synth_fastq.FastqText(L, i, dev) for i in range(len(mates))]
+            for i, r in enumerate(mates):
+                self._q[i].put(self._ft[i].text(r, self.n).cpu())
+            self.n += m
+            return
         if self._tmpl is None or self._tmpl.shape[0] < m:
             t = torch.empty((m, self.rec_bytes), dtype=torch.uint8, device=dev)
             t[:, 0] = ord("@"); t[:, 1] = ord("r"); t[:, 11] = 10; t[:, 12 + L] = 10; t[:, 13 + L] = ord("+"); t[:, 14 + L] = 10
@@ -191,6 +214,7 @@ class FastqSpool:
         for t in self._th:
             t.join()
         self._tmpl = None
+        self._ft = None
         if self.error:
             raise RuntimeError("writing the full-size FASTQ files failed: " + self.error)
         return self.files
@@ -221,7 +245,30 @@ class FullSizeParity:
                     f.write(f"{i} {c}\n")
         self.out, self.err = open(os.path.join(self.tmp, "ref.out"), "wb"), open(os.path.join(self.tmp, "ref.err"), "wb")
         cmd = [os.path.join(O.REF_DIR, "dump_ec"), "quant", idx_path, str(threads), *extra, "--flens", fl, *files]
-        self.proc = subprocess.Popen(cmd, stdout=self.out, stderr=self.err)
+        self.proc = subprocess.Popen(cmd, stdout=self.out, stderr=subprocess.PIPE)
+        # the reference's own stage markers on stderr, time-stamped as they arrive: index loaded = ProcessReads announces itself
+        # ("[quant] finding pseudoalignments ..."), pseudoalignment finished = that line's " done", EM finished = "... ran for N rounds"
+        self.clock = {"start": self.t0}
+        import threading
+
+        def _pump():
+            seen = b""
+            while True:
+                chunk = self.proc.stderr.read1(65536) if hasattr(self.proc.stderr, "read1") else self.proc.stderr.read(4096)
+                if not chunk:
+                    break
+                now = time.time()
+                self.err.write(chunk)
+                seen = (seen + chunk)[-1 << 16:]
+                if "loaded" not in self.clock and b"[quant] finding pseudoalignments" in seen:
+                    self.clock["loaded"] = now
+                if "loaded" in self.clock and "aligned" not in self.clock and b" done" in seen[seen.find(b"[quant] finding pseudoalignments"):]:
+                    self.clock["aligned"] = now
+                if "em" not in self.clock and b"Expectation-Maximization algorithm ran for" in seen:
+                    self.clock["em"] = now
+            self.clock["end"] = time.time()
+        self._pump = threading.Thread(target=_pump, daemon=True)
+        self._pump.start()
         # beside it, on one more core: the oracle's restatement of EMAlgorithm::run (oracle/kallisto_oracle.c ko_em_run) on the GPU's OWN
         # equivalence classes and effective lengths -- same matrix, so the tolerance is the association of FP64 sums: 1e-9
         import threading
@@ -251,6 +298,7 @@ class FullSizeParity:
                 self.proc.wait()
                 return {"ok": False, "error": f"the reference did not finish within {timeout_s:.0f} s"}
             ref_s = time.time() - self.t0
+            self._pump.join(timeout=30.0)
             self.out.close(); self.err.close()
             if rc != 0:
                 return {"ok": False, "error": f"dump_ec exit code {rc}: " + open(self.err.name, errors="replace").read()[-300:]}
@@ -268,6 +316,10 @@ class FullSizeParity:
                    "tpm_max_rel_err_tpm_ge_1e-3": rep["tpm_max_rel_err_tpm_ge_1e-3"], "tpm_max_abs_err_below_floor": rep["tpm_max_abs_err_below_floor"],
                    "zero_pattern_equal": rep["zero_pattern_equal"], "own_sample_of_the_threaded_reference_equal": rep["flens_equal"],
                    "reference_seconds": round(ref_s, 1), "tolerance": "EC multiset and eff_length identical, same EM round count, est_counts / tpm <= 1e-4"}
+            ck = self.clock
+            if all(k in ck for k in ("loaded", "aligned", "em", "end")):
+                out["reference_stage_seconds"] = {"index_load": round(ck["loaded"] - ck["start"], 2), "pseudoalign": round(ck["aligned"] - ck["loaded"], 2),
+                                                  "em": round(ck["em"] - ck["aligned"], 2), "output": round(ck["end"] - ck["em"], 2), "threads": self.threads}
             self._th.join(timeout=max(1.0, timeout_s - (time.time() - self.t0)))
             out["oracle_em_on_the_gpus_ecs"] = self.oracle_em or {"ok": False, "error": "did not finish"}
             out["ok"] = bool(out["oracle_em_on_the_gpus_ecs"].get("ok") and
@@ -292,7 +344,7 @@ def cpu_reference_baseline(idx_path, r1: np.ndarray, r2, threads: int, extra=())
     write_fastq_fast(files[0], r1)
     if r2 is not None:
         files.append(os.path.join(tmp, "s_2.fq"))
-        write_fastq_fast(files[1], r2)
+        write_fastq_fast(files[1], r2, 1)
     out = os.path.join(tmp, "out")
     cmd = [REF_BIN, "quant", "-i", idx_path, "-o", out, "-t", str(threads), "--plaintext", *extra, *files]
     t_start = time.time()
@@ -331,7 +383,7 @@ def _ref_dump(idx_path, r1, r2, extra=()):
         write_fastq_fast(files[0], r1)
         if r2 is not None:
             files.append(os.path.join(tmp, "p_2.fq"))
-            write_fastq_fast(files[1], r2)
+            write_fastq_fast(files[1], r2, 1)
         return O.ref_dump_quant(idx_path, files, threads=1, extra=extra)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -472,9 +524,8 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         t0 = time.time()
         write_fastq_fast(f1, r1)
         if paired:
-            write_fastq_fast(f2, r2)
+            write_fastq_fast(f2, r2, 1)
         plain = [f1, f2] if paired else [f1]
-        per = os.path.getsize(f1) // n
         # the same reads as BGZF (block-parallel inflate) and, a subset, as one ordinary gzip member per file (`gzip -1`)
         bg = [os.path.join(tmp, f"b_{i + 1}.fq.gz") for i in range(len(plain))]
         for src, dst in zip(plain, bg):
@@ -484,8 +535,10 @@ def end_to_end(idx_path, r1: np.ndarray, r2, paired: bool, threads: int, extra, 
         procs = []
         for i, src in enumerate(plain):
             g = os.path.join(tmp, f"g_{i + 1}.fq")
-            with open(src, "rb") as fi, open(g, "wb") as fo:
-                fo.write(fi.read(per * ngz))
+            if ngz == n:
+                shutil.copyfile(src, g)
+            else:   # (records have variable lengths: the first ngz of them written again)
+                write_fastq_fast(g, (r1, r2)[i][:ngz], i)
             procs.append(subprocess.Popen(["gzip", "-1", "-f", g]))
             gz.append(g + ".gz")
         for p in procs:
@@ -615,6 +668,24 @@ def config2_leg(timeout_s=900):
         return {"error": str(e)[:300]}
 
 
+def stress_leg(timeout_s=900, pairs=8_000_000):
+    """The stress workload (synth.human_stress + off-transcriptome reads + quality tails) as a child run of this script with ALL its pairs through
+    the unmodified reference (FullSizeParity): its line, cut down to the figures, for the line of config #3.  Never raises."""
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--pairs", str(pairs), "--steps", "3", "--warmup", "1", "--end-to-end", "0",
+               "--no-pinned-pipeline", "--no-compact-leg", "--no-config2", "--no-stress-leg", "--bootstraps", "0", "--full-parity", "on"]
+        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        if pc.returncode != 0:
+            return {"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}
+        d = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+        keep = bench_line_digest(d)
+        keep["roofline_em"] = {k: (d.get("roofline_em") or {}).get(k) for k in ("kernel", "bound", "achieved", "peak", "frac", "launch_ms", "rounds", "nnz", "rows")}
+        keep["command"] = "python bench.py " + " ".join(cmd[2:])
+        return keep
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)[:300]}
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N ...` without a launcher around it: run the same command line as N ranks of one node under
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <a free one>` (one process per
@@ -684,8 +755,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=None, help="read pairs (reads) per GPU per step; default: BASELINE config #3: 30 M "
                     "(human), config #2: 10 M single-end reads (yeast)")
-    ap.add_argument("--workload", default="human", choices=["human", "yeast"],
-                    help="human = BASELINE configs #3/#4/#5 (paired-end); yeast = config #2 (single-end, -l 200 -s 20)")
+    ap.add_argument("--workload", default="human", choices=["human", "yeast", "stress"],
+                    help="human = BASELINE configs #3/#4/#5 (paired-end); yeast = config #2 (single-end, -l 200 -s 20); stress = the human-sized "
+                         "workload with the structure of a real transcriptome (synth.human_stress: repeat families in the UTRs, paralog families, poly-A "
+                         "tails -> one connected component with half of the EC matrix) and the reads the other workloads lack: 12 %% off-transcriptome "
+                         "pairs, a 3' quality tail of errors")
+    ap.add_argument("--no-stress-leg", action="store_true", help="skip the child run of the stress workload that the default one-GPU run of config #3 appends")
     ap.add_argument("--genes", type=int, default=None, help="scale of the synthetic transcriptome (default: full config)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --pairs per GPU (default); strong = --pairs in total, sharded over the GPUs (BASELINE config #4). "
@@ -751,8 +826,9 @@ def main():
 
     if args.bootstraps is None:
         args.bootstraps = 100 if world == 1 else 0
-    paired = args.workload == "human"
-    genes = args.genes or (20000 if args.workload == "human" else 6000)
+    paired = args.workload != "yeast"
+    stress = args.workload == "stress"
+    genes = args.genes or (20000 if paired else 6000)
     n_default = 30_000_000 if paired else 10_000_000
     n_arg = args.pairs or n_default
     # weak: n_arg per GPU; strong: n_arg in total.  Each rank generates max(weak, strong) share once and both modes run on prefixes.
@@ -769,7 +845,11 @@ def main():
 
     # ---- this rank's reads, generated on the device and packed into the 2-bit layout (resident in HBM) ----
     L = 100
-    sim = ReadSimulator(cat, tlens, dev, seed=1000 + rank, read_len=L)
+    def make_sim(seed):
+        if stress:   # 12 % of the pairs from the background (random sequence + copies of the repeat families), errors 0.2 % rising to 5 % (7.5 % on mate 2) at the 3' end
+            return ReadSimulator(cat, tlens, dev, seed=seed, read_len=L, err=0.002, background=prepare_workload.background, off_frac=0.12, tail_err=0.05)
+        return ReadSimulator(cat, tlens, dev, seed=seed, read_len=L)
+    sim = make_sim(1000 + rank)
     rec = ka.packed_record_words(L)
     per = 2 if paired else 1
     words = torch.empty(n_gen * per * rec, dtype=torch.int32, device=dev)
@@ -779,9 +859,21 @@ def main():
     psample = None     # first pairs: parity against the reference (independent of the CPU baseline)
     e2e_sample = None  # first pairs: front-end from FASTQ
     tail_sample = None # last pairs: parity of the tail
+    spool = None
+    full_size = genes == (20000 if paired else 6000) and n_arg == n_default
+    if rank == 0 and world == 1 and (args.full_parity == "on" or (args.full_parity == "auto" and full_size)) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
+        need = n_gen * per * (2 * L + 70) + (8 << 30)
+        os.makedirs(CACHE, exist_ok=True)
+        if shutil.disk_usage(CACHE).free > need:
+            spool = FastqSpool(os.path.join(CACHE, f"full_{os.getpid()}"), paired, L)
+        else:
+            log(f"full-size parity skipped: {shutil.disk_usage(CACHE).free / 1e9:.0f} GB free under {CACHE}, {need / 1e9:.0f} GB wanted")
+    # the CPU baseline: the reference's own stage clocks of the full-size run when there is one (it runs anyway, in the background of the
+    # parity legs); a run of its own on a sample of the first pairs otherwise
+    cpu_from_full = spool is not None and not args.no_cpu_baseline
     want_head = 0
     if rank == 0 and world == 1:
-        if args.cpu_sample and not args.no_cpu_baseline:
+        if args.cpu_sample and not args.no_cpu_baseline and not cpu_from_full:
             want_head = max(want_head, min(args.cpu_sample, n_gen))
         if args.end_to_end:
             want_head = max(want_head, min(args.end_to_end, n_gen))
@@ -789,15 +881,6 @@ def main():
             want_head = max(want_head, min(args.parity_sample, n_gen))
     want_tail = min(args.parity_sample, n_gen) if (rank == 0 and world == 1 and args.parity_sample) else 0
     head1, head2, have_head = [], [], 0
-    spool = None
-    full_size = genes == (20000 if paired else 6000) and n_arg == n_default
-    if rank == 0 and world == 1 and (args.full_parity == "on" or (args.full_parity == "auto" and full_size)) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
-        need = n_gen * per * (2 * L + 16) + (8 << 30)
-        os.makedirs(CACHE, exist_ok=True)
-        if shutil.disk_usage(CACHE).free > need:
-            spool = FastqSpool(os.path.join(CACHE, f"full_{os.getpid()}"), paired, L)
-        else:
-            log(f"full-size parity skipped: {shutil.disk_usage(CACHE).free / 1e9:.0f} GB free under {CACHE}, {need / 1e9:.0f} GB wanted")
     t0 = time.time()
     for s in range(0, n_gen, chunk):
         m = min(chunk, n_gen - s)
@@ -818,7 +901,7 @@ def main():
         del r1, r2, inter, w, l
     if want_head:
         h1, h2 = np.concatenate(head1), np.concatenate(head2)
-        if args.cpu_sample and not args.no_cpu_baseline:
+        if args.cpu_sample and not args.no_cpu_baseline and not cpu_from_full:
             k = min(args.cpu_sample, n_gen)
             sample = (h1[:k], h2[:k] if paired else None)
         if args.parity_sample:
@@ -899,7 +982,7 @@ def main():
                 want_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")) and n * world <= 2_000_000
                 host1, host2 = [], []   # every rank's reads on the host too, in input order, for the reference (small runs only)
                 for r in range(world):   # rank r's reads: the same generator, the same seed, the same chunks
-                    simr = ReadSimulator(cat, tlens, dev, seed=1000 + r, read_len=L)
+                    simr = make_sim(1000 + r)
                     wr = torch.empty(n * per * rec, dtype=torch.int32, device=dev); lr = torch.empty(n * per, dtype=torch.int16, device=dev)
                     for s0 in range(0, n_gen, chunk):
                         m = min(chunk, n_gen - s0)
@@ -1045,7 +1128,7 @@ def main():
         em_bytes = pr["em_nnz"] * 20 + pr["em_necs"] * 12 + T * 24
         em_round_ms = float(np.mean(em_ms)) / max(int(em_iters[-1]), 1)
         em_ach = em_bytes / (em_round_ms * 1e-3) / 1e9
-        local_form = pr["em_k"] < 0
+        local_form = pr["em_k"] < 0 and not pr["em_giant_nnz"]   # (the hybrid streams half of the matrix from HBM / MALL every round: priced against HBM)
         if local_form:
             # component-local form: the matrix sits in LDS for the rounds of a launch; a round gathers one FP64 value and reads one
             # 16-bit index per entry and direction out of LDS -- the bound is the LDS pipe, HBM only sees the per-launch load / store
@@ -1063,7 +1146,8 @@ def main():
                        "lds_bytes_per_workgroup": pr["em_lds"]}
         else:
             layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 16 + T * 56
-            em_roof = {"kernel": "EM round (k_pm_rows_pass + k_pm_cols_pass)" if pr["em_k"] else "EM round (k_em_rows + k_em_seg + k_em_final)",
+            em_roof = {"kernel": "EM round, hybrid: k_em_sell on the components that fit, k_gi_rows + k_gi_cols (+ fix-ups) on the oversized ones beside it" if pr["em_giant_nnz"] else
+                                 "EM round (k_pm_rows_pass + k_pm_cols_pass)" if pr["em_k"] else "EM round (k_em_rows + k_em_seg + k_em_final)",
                        "bound": "hbm", "achieved": round(em_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(em_ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(em_bytes),
                        "layout_bytes_per_round": int(layout_bytes), "launch_ms": round(em_round_ms, 5), "rounds": int(em_iters[-1]),
@@ -1091,7 +1175,8 @@ def main():
         except Exception as e:   # diagnostic only
             ceiling = {"error": str(e)}
         out = {
-            "metric": "M paired-end reads/sec quantified (human txome index)" if paired else "M single-end reads/sec quantified (yeast-sized index)",
+            "metric": ("M paired-end reads/sec quantified (human txome index, stress workload)" if stress else "M paired-end reads/sec quantified (human txome index)") if paired
+                      else "M single-end reads/sec quantified (yeast-sized index)",
             "value": round(total_items / elapsed / 1e6, 4),
             "unit": "M read pairs/s" if paired else "M reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1099,13 +1184,17 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64+f64", "data": "synthetic",
             "config": {
-                "workload": ((f"BASELINE config #{3 if world == 1 else 4}: synthetic human-like transcriptome ({index.num_targets} transcripts, "
+                "workload": ((f"STRESS (not a BASELINE configuration; VERDICT r4 #1): human-sized synthetic transcriptome with real structure ({index.num_targets} transcripts, "
+                              f"{index.num_kmers} k-mers, k={index.k}: 4 repeat families in the terminal exons of 30 % of the genes, 3 x 200 paralog genes, poly-A tails on 3 % "
+                              f"of the transcripts; index built by the reference `kallisto index`), {n} PE-{L} read pairs per GPU resident in HBM, 12 % of them "
+                              f"off-transcriptome, errors 0.2 % rising to 5 / 7.5 % at the 3' end, full quant per step" if stress else
+                              f"BASELINE config #{3 if world == 1 else 4}: synthetic human-like transcriptome ({index.num_targets} transcripts, "
                               f"{index.num_kmers} k-mers, k={index.k}; index built by the reference `kallisto index`), "
                               f"{n} PE-{L} read pairs per GPU resident in HBM (2-bit packed), full quant per step"
                               if paired else
                               f"BASELINE config #2: synthetic yeast-like transcriptome ({index.num_targets} transcripts, {index.num_kmers} k-mers, "
                               f"k={index.k}), {n} SE-{L} reads per GPU resident in HBM, --single -l 200 -s 20, full quant per step")
-                             if genes == (20000 if paired else 6000) and n_arg == n_default else
+                             if (genes == (20000 if paired else 6000) and n_arg == n_default) or stress else
                              f"REDUCED {args.workload} genes={genes} {unit_name}={n} (not the BASELINE configuration)"),
                 f"{unit_name}_per_gpu": n, "read_len": L, "paired": paired, "targets": int(index.num_targets),
                 "kmers": int(index.num_kmers),
@@ -1130,7 +1219,15 @@ def main():
                          "single_set_pairs": st["n_single"], "multi_set_pairs": st["n_multi"],
                          "distinct_tuples": st["n_distinct_tuples"], "final_ecs": int(ctx.ec_result.n_ecs),
                          "ec_state_bytes": int(32 * pr["tuple_table_slots"] + 4 * pr["tuple_store_words"] + 12 * index.num_ecs),
-                         "em_rounds": res.em_rounds},
+                         "em_rounds": res.em_rounds,
+                         "pseudoaligned_share": round(res.n_pseudoaligned / max(res.n_processed, 1), 4),
+                         "overflow_items": pr["n_overflow_items"], "overflow_share": round(pr["n_overflow_items"] / max(n, 1), 5), "overflow_kernel_ms": round(pr["overflow_ms"], 3),
+                         "em_largest_component_nnz": pr["em_max_comp_nnz"],
+                         "em_form": ("hybrid: k_em_sell on the components that fit + streamed kernels on the oversized ones" if pr["em_giant_nnz"] else
+                                     "component-local (k_em_sell)") if pr["em_k"] < 0 else ("streamed" if pr["em_k"] > 0 else "csr"),
+                         "em_oversized": {"nnz": pr["em_giant_nnz"], "rows": pr["em_giant_rows"], "transcripts": pr["em_giant_tr"], "chunks_per_direction": pr["em_giant_chunks"],
+                                          "compute_units_reserved": pr["em_giant_cus"]} if pr["em_giant_nnz"] else None,
+                         "em_plan_ms": round(pr["em_plan_ms"], 3)},
             # dominant kernel by time: kernel A
             "roofline": {"kernel": {3: "k_match_v3"}[pr["kernel_a_version"]], "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1233,11 +1330,37 @@ def main():
         else:
             log("BASELINE config #2 (yeast, single-end) as a child run ...")
             out["config2"] = config2_leg(timeout_s=max(60.0, budget_s + 120 - (time.time() - t_start)))
+    def attach_full(fp):
+        """the full-size leg's verdict, and the CPU baseline from the clocks of that very run"""
+        out["parity_check_full_size"] = fp
+        st_ = fp.get("reference_stage_seconds")
+        if cpu_from_full and st_ and "cpu_baseline" not in out:
+            work = st_["pseudoalign"] + st_["em"] + st_["output"]
+            out["cpu_baseline"] = {"value": round(n / work / 1e6, 4), "unit": rate_unit, "cores": st_["threads"], "kind": "reference", "processors_visible": os.cpu_count(),
+                                   "sample": f"ALL {n} {unit_name} of the run as uncompressed FASTQ through the unmodified reference (oracle/_ref/dump_ec quant -t {st_['threads']} = "
+                                             f"KmerIndex::load, ProcessReads on all cores, EMAlgorithm::run single-threaded; the run of parity_check_full_size, in the background of the "
+                                             f"other parity legs, which keep one or two cores busy), clock from index-loaded to exit ({work:.1f}s; index load {st_['index_load']:.1f}s excluded)",
+                                   "index_load_seconds": st_["index_load"], "pseudoalign_seconds": st_["pseudoalign"], "em_seconds": st_["em"],
+                                   "whole_run_value_including_index_load": round(n / (work + st_["index_load"]) / 1e6, 4),
+                                   "pseudoalign_only_value": round(n / max(st_["pseudoalign"], 1e-9) / 1e6, 4),
+                                   "note": "measured at the full size of the configuration, not projected from a sample (VERDICT r4); the reference's EM is single-threaded"}
+        elif cpu_from_full and "cpu_baseline" not in out:
+            out["cpu_baseline"] = {"value": None, "unit": rate_unit, "cores": min(effective_cpus(), 64), "kind": "reference", "sample": "failed: " + str(fp.get("error", "no stage clocks"))[:200]}
+    if rank == 0 and world == 1 and args.workload == "human" and not args.no_stress_leg and genes == 20000 and n_arg == n_default:
+        if time.time() - t_start > budget_s - 30:
+            out["stress"] = {"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S)"}
+        else:
+            log("stress workload (real transcriptome structure, off-transcriptome reads) as a child run ...")
+            if full_parity is not None:   # (both want every core: the stress leg runs the reference on all of its pairs too)
+                log("full-size parity: waiting for the reference ...")
+                attach_full(full_parity.finish())
+                full_parity = None
+            out["stress"] = stress_leg(timeout_s=max(120.0, budget_s + 360 - (time.time() - t_start)))
     if rank == 0 and world == 1 and e2e_sample is not None:
         log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {unit_name}) ...")
         if full_parity is not None:   # (the reference's single-threaded EM may still be running: the end-to-end legs want the host to themselves)
             log("full-size parity: waiting for the reference ...")
-            out["parity_check_full_size"] = full_parity.finish()
+            attach_full(full_parity.finish())
             full_parity = None
         ctx.close()   # the front-end is its own process on the same GPU
         del words, lens
@@ -1248,7 +1371,7 @@ def main():
         except Exception as e:
             out["end_to_end"] = {"error": str(e)}
     if full_parity is not None:
-        out["parity_check_full_size"] = full_parity.finish()
+        attach_full(full_parity.finish())
     if spool is not None:
         spool.remove()
     if rank == 0:

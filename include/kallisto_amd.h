@@ -157,6 +157,15 @@ typedef struct {
                                   side by side were slower -- profiles/README.md) */
   int32_t em_reg_slices;       /* component-local form: 1 (default) = a wavefront keeps the index words and segment constants of its first slice
                                   per direction in registers for the rounds of a launch (split lengths up to 32), 2 = everything from LDS */
+  int32_t em_hybrid;           /* component-local form on a matrix with connected components beyond a workgroup's LDS (repeat families, poly-A
+                                  classes: one such component holds half of a real transcriptome's entries): 1 (default) = hybrid -- the
+                                  components that fit keep the LDS form, the oversized ones are iterated BESIDE it by streamed kernels (two
+                                  launches per round over flagged entry streams in HBM, on compute units of their own), one stop rule over
+                                  both; 2 = off: such a matrix takes the streamed form as a whole (rounds 1-4) */
+  int32_t em_giant_cus;        /* hybrid: compute units reserved for the streamed kernels (CU masks of the two streams); -1 (default) = in
+                                  proportion to the oversized components' share of the entries, 32..192; 0 in kamd_ctx_tune = keep */
+  int32_t em_giant_nnz;        /* hybrid: a component with more entries than this is "oversized"; -1 (default) = 6000, halved while the
+                                  remaining components still do not fit their groups */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);
@@ -272,6 +281,16 @@ typedef struct {
   uint64_t n_distinct_tuples;  /* entries of the tuple table; */
   uint64_t tuple_store_words;  /* u32 words of distinct tuple records kept; */
   uint64_t tuple_table_slots;  /* slots of the table (32 bytes each): what the EC state costs in HBM, whatever the number of reads */
+  uint64_t last_em_max_comp_nnz;   /* component-local form: entries of the largest connected component of the last kamd_em_run's matrix */
+  uint64_t last_em_giant_nnz;      /* hybrid: entries of the components iterated by the streamed kernels (0: everything fitted the LDS form), */
+  uint64_t last_em_giant_rows;     /* their rows, */
+  uint64_t last_em_giant_tr;       /* their transcripts, */
+  uint32_t last_em_giant_chunks;   /* wavefront chunks per direction of those kernels, */
+  int32_t last_em_giant_cus;       /* compute units reserved for them (0: no CU masks -- the two forms shared the chip) */
+  float last_em_plan_ms;           /* host time of the plan set-up of the last kamd_em_run (component labels, groups, layouts; 0 when cached) */
+  uint64_t n_overflow_items;       /* since kamd_ec_reset: items kernel A handed to k_pseudoalign_overflow (more than 8 distinct (unitig, set)
+                                      classes, or reads beyond the LDS budget), */
+  float overflow_ms;               /* and that kernel's time (HIP events) */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

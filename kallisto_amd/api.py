@@ -54,7 +54,8 @@ class _Stats(C.Structure):
 class Tuning(C.Structure):
     """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
     _fields_ = [(n, C.c_int32) for n in ("text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
-                                         "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form", "align_chunks", "em_small_nnz", "em_reg_slices")]
+                                         "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form", "align_chunks", "em_small_nnz", "em_reg_slices",
+                                         "em_hybrid", "em_giant_cus", "em_giant_nnz")]
 
 
 EM_FORMS = {"streamed": 1, "csr": 2, "local": 3}
@@ -67,7 +68,10 @@ class _Profile(C.Structure):
                 ("last_em_k", C.c_int32), ("last_em_grid", C.c_uint32), ("last_em_lds", C.c_uint32),
                 ("last_em_plan_cached", C.c_int32), ("last_finalize_ms", C.c_float), ("last_fin_records", C.c_uint64),
                 ("last_fin_stream_words", C.c_uint64), ("last_fin_cand_words", C.c_uint64), ("absorb_ms", C.c_float),
-                ("n_distinct_tuples", C.c_uint64), ("tuple_store_words", C.c_uint64), ("tuple_table_slots", C.c_uint64)]
+                ("n_distinct_tuples", C.c_uint64), ("tuple_store_words", C.c_uint64), ("tuple_table_slots", C.c_uint64),
+                ("last_em_max_comp_nnz", C.c_uint64), ("last_em_giant_nnz", C.c_uint64), ("last_em_giant_rows", C.c_uint64),
+                ("last_em_giant_tr", C.c_uint64), ("last_em_giant_chunks", C.c_uint32), ("last_em_giant_cus", C.c_int32),
+                ("last_em_plan_ms", C.c_float), ("n_overflow_items", C.c_uint64), ("overflow_ms", C.c_float)]
 
 
 class _FastqUnit(C.Structure):
@@ -459,7 +463,10 @@ class Context:
                 "em_plan_cached": int(p.last_em_plan_cached), "finalize_ms": float(p.last_finalize_ms),
                 "fin_records": int(p.last_fin_records), "fin_stream_words": int(p.last_fin_stream_words),
                 "fin_cand_words": int(p.last_fin_cand_words), "absorb_ms": float(p.absorb_ms), "n_distinct_tuples": int(p.n_distinct_tuples),
-                "tuple_store_words": int(p.tuple_store_words), "tuple_table_slots": int(p.tuple_table_slots)}
+                "tuple_store_words": int(p.tuple_store_words), "tuple_table_slots": int(p.tuple_table_slots),
+                "em_max_comp_nnz": int(p.last_em_max_comp_nnz), "em_giant_nnz": int(p.last_em_giant_nnz), "em_giant_rows": int(p.last_em_giant_rows),
+                "em_giant_tr": int(p.last_em_giant_tr), "em_giant_chunks": int(p.last_em_giant_chunks), "em_giant_cus": int(p.last_em_giant_cus),
+                "em_plan_ms": float(p.last_em_plan_ms), "n_overflow_items": int(p.n_overflow_items), "overflow_ms": float(p.overflow_ms)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

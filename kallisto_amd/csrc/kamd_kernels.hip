@@ -2264,6 +2264,13 @@ struct kamd_ctx {
   hipStream_t em_side_stream = nullptr; hipEvent_t em_ev_fork = nullptr, em_ev_join = nullptr;   // component-local EM: the small size class runs beside the large one
   void* em_pin = nullptr; size_t em_pin_bytes = 0;   // component-local EM: pinned, mapped host memory (change counts the kernels publish, result staging)
   DBuf em_clk;                                       // diagnostic phase clocks (KAMD_EM_CLK)
+  // hybrid EM (components beyond a workgroup's LDS beside the LDS form): the two sub-matrices, the streamed plan's arenas, its vectors
+  DBuf hy_sub, hy_a, hy_b, hy_x, hy_maps;
+  hipStream_t hy_sell_stream = nullptr, hy_giant_stream = nullptr; int hy_sell_cus = -1;   // hy_sell_stream carries a CU mask of hy_sell_cus units
+  hipEvent_t hy_ev_sell = nullptr, hy_ev_giant = nullptr;
+  uint64_t last_em_max_comp_nnz = 0, last_em_giant_nnz = 0, last_em_giant_rows = 0, last_em_giant_tr = 0;
+  uint32_t last_em_giant_chunks = 0; int last_em_giant_cus = 0; float last_em_plan_ms = 0.f;
+  uint64_t overflow_total = 0; float overflow_ms = 0.f; hipEvent_t ev_ov0 = nullptr, ev_ov1 = nullptr;   // since kamd_ec_reset: items of the overflow kernel, its time
   int items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
   bool track_order = false;  // kamd_ec_track_order: finalize emits the sets in first-occurrence order
@@ -2452,6 +2459,7 @@ void tuning_defaults(kamd_tuning* t) {
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
   t->em_form = 3; t->em_local_block = 1024; t->em_group_div = -1; t->em_split_len = 16; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1; t->em_reg_slices = 1;
+  t->em_hybrid = 1; t->em_giant_cus = -1; t->em_giant_nnz = -1;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
@@ -2473,6 +2481,9 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.em_fin_blocks >= 64) t->em_fin_blocks = n.em_fin_blocks;
   if (n.align_chunks != 0) t->align_chunks = n.align_chunks < 0 ? -1 : std::min(n.align_chunks, 64);
   if (n.em_reg_slices == 1 || n.em_reg_slices == 2) t->em_reg_slices = n.em_reg_slices;
+  if (n.em_hybrid == 1 || n.em_hybrid == 2) t->em_hybrid = n.em_hybrid;
+  if (n.em_giant_cus != 0) t->em_giant_cus = n.em_giant_cus < 0 ? -1 : n.em_giant_cus;
+  if (n.em_giant_nnz != 0) t->em_giant_nnz = n.em_giant_nnz < 0 ? -1 : std::max(n.em_giant_nnz, 8);
 }
 // experiments: the same knobs from the environment, read once when a context is created
 void tuning_from_env(kamd_tuning* t) {
@@ -2499,6 +2510,9 @@ void tuning_from_env(kamd_tuning* t) {
   geti("KAMD_EM_ROW_LANES", &n.em_row_lanes);
   geti("KAMD_EM_FIN_BLOCKS", &n.em_fin_blocks);
   geti("KAMD_ALIGN_CHUNKS", &n.align_chunks);
+  onoff("KAMD_EM_HYBRID", &n.em_hybrid);
+  geti("KAMD_EM_GIANT_CUS", &n.em_giant_cus);
+  geti("KAMD_EM_GIANT_NNZ", &n.em_giant_nnz);
   tuning_merge(t, n);
 }
 // the options of the run that the per-item logic reads from the device index
@@ -2576,6 +2590,13 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->em_pin) (void)hipHostFree(c->em_pin);
   if (c->state_pin) (void)hipHostFree(c->state_pin);
   c->em_clk.release();
+  if (c->hy_sell_stream) { (void)hipStreamSynchronize(c->hy_sell_stream); (void)hipStreamDestroy(c->hy_sell_stream); }
+  if (c->hy_giant_stream) { (void)hipStreamSynchronize(c->hy_giant_stream); (void)hipStreamDestroy(c->hy_giant_stream); }
+  if (c->hy_ev_sell) (void)hipEventDestroy(c->hy_ev_sell);
+  if (c->hy_ev_giant) (void)hipEventDestroy(c->hy_ev_giant);
+  if (c->ev_ov0) (void)hipEventDestroy(c->ev_ov0);
+  if (c->ev_ov1) (void)hipEventDestroy(c->ev_ov1);
+  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps}) b->release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
@@ -2639,7 +2660,7 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   if (int rc = c->dense_first.ensure(std::max<u64>(v.n_ecs, 1) * sizeof(u64), 0, c->stream)) return rc;
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(v.n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f;
+  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f; c->overflow_total = 0; c->overflow_ms = 0.f;
   if (int rc = tuples_clear(c)) return rc;
   HIPC(hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream));
   return push_state(c);
@@ -2962,12 +2983,16 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
     out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
     const u64 ov_base = 0;   // (record indices of the batch)
+    if (!c->ev_ov0) { HIPC(hipEventCreate(&c->ev_ov0)); HIPC(hipEventCreate(&c->ev_ov1)); }
+    HIPC(hipEventRecord(c->ev_ov0, c->stream));
     if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
                      else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
     else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
            else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
     HIPC(hipGetLastError());
+    HIPC(hipEventRecord(c->ev_ov1, c->stream));
     if (int rc2 = sync_state(c)) return rc2;
+    { float ms = 0.f; HIPC(hipEventElapsedTime(&ms, c->ev_ov0, c->ev_ov1)); c->overflow_ms += ms; c->overflow_total += nov; }
     c->host_state.n_overflow = 0;
     if (int rc2 = push_state(c)) return rc2;
     // their records (rec_off of an overflow item now points at its long record) join the distinct tuples
@@ -3513,8 +3538,10 @@ void pm_enqueue_round(const PmPlan& P, hipStream_t s, int parity) {
 // returns 0 = plan built (the rounds can be enqueued with pm_enqueue_round), 1 = not applicable (the caller uses the CSR
 // form), < 0 = error.  Needs col_cnt / em_coloff / em_single / em_eff of the caller (k_em_prepare + scan) and a zeroed col_fill.
 int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u32* counts, const u32* wcounts, u64 n_ecs, u64 T,
-                      const u32* col_cnt, u32* col_fill, PmPlan* P) {
+                      const u32* col_cnt, u32* col_fill, PmPlan* P, DBuf* arena_a = nullptr, DBuf* arena_b = nullptr, int n_cus_for = 0) {
   if (n_ecs == 0) return 1;
+  DBuf& ar_a = arena_a ? *arena_a : c->pm_a;   // (the hybrid keeps the streamed plan of the oversized components in arenas of its own: pm_a / pm_b
+  DBuf& ar_b = arena_b ? *arena_b : c->pm_b;   //  hold the LDS form's plan and vectors at the same time)
   if (c->n_cus == 0) {
     int v = 0;
     HIPC(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -3525,8 +3552,8 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   const size_t o_hist = s1.take((T + 1) * 4), o_fill = s1.take((T + 1) * 4), o_mflag = s1.take(T * 4);
   const size_t o_start = s1.take((T + 2) * 8), o_rpos = s1.take((n_ecs + 1) * 8), o_mpos = s1.take((T + 1) * 8);
   const size_t o_len = s1.take((n_ecs + 1) * 4), o_roff = s1.take((n_ecs + 2) * 8);
-  if (int rc = c->pm_a.ensure(s1.off, 0, c->stream)) return rc;
-  char* b1 = (char*)c->pm_a.p;
+  if (int rc = ar_a.ensure(s1.off, 0, c->stream)) return rc;
+  char* b1 = (char*)ar_a.p;
   u32* hist = (u32*)(b1 + o_hist); u32* fill = (u32*)(b1 + o_fill); u32* mflag = (u32*)(b1 + o_mflag);
   u64* start = (u64*)(b1 + o_start); u64* rpos = (u64*)(b1 + o_rpos); u64* mpos = (u64*)(b1 + o_mpos);
   u32* len_sorted = (u32*)(b1 + o_len); u64* roff = (u64*)(b1 + o_roff);
@@ -3548,7 +3575,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   int K = PM_KS[sizeof(PM_KS) / sizeof(PM_KS[0]) - 1];
   bool k_forced = false;
   if (c->tune.em_entries_per_lane > 0) { for (int k : PM_KS) if (k == c->tune.em_entries_per_lane) { K = k; k_forced = true; } }
-  if (!k_forced) for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 12) { K = k; break; }
+  if (!k_forced) for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)(n_cus_for > 0 ? n_cus_for : c->n_cus) * 12) { K = k; break; }
   const u32 chunk = 64u * (u32)K;
   const u64 n_chunks64 = (NZ + chunk - 1) / chunk;
   if (n_chunks64 >= 0x7FFFFFF0ULL) return 1;
@@ -3569,8 +3596,8 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   size_t o_vec[6];
   for (int j = 0; j < 6; j++) o_vec[j] = s2.take((M + 1) * 8);
   const size_t o_single = s2.take(M * 8), o_eff = s2.take(M * 8), o_nfix = s2.take(64);
-  if (int rc = c->pm_b.ensure(s2.off, 0, c->stream)) return rc;
-  char* b2 = (char*)c->pm_b.p;
+  if (int rc = ar_b.ensure(s2.off, 0, c->stream)) return rc;
+  char* b2 = (char*)ar_b.p;
   u32* rs = (u32*)(b2 + o_rs + front); u32* cs = (u32*)(b2 + o_cs + front);
   HIPC(hipMemsetAsync(b2 + o_rs, 0, front, c->stream));
   HIPC(hipMemsetAsync(b2 + o_cs, 0, front, c->stream));
@@ -4472,6 +4499,16 @@ __global__ __launch_bounds__(BLOCK) void k_eml_group_build(kamd_em_local::BuildA
     A.col_row[z0 + lo + rank] = (uint16_t)v;
   }
 }
+// the largest connected component (entries, rows, transcripts: three maxima) -- what decides at once whether a matrix can take the
+// component-local form as a whole; stats[0..2], zeroed by the caller
+struct CompStats { u32 max_nnz, max_rows, max_tr, pad; };
+__global__ void k_comp_stats(const u32* __restrict__ c_nnz, const u32* __restrict__ c_rows, const u32* __restrict__ c_tr, u64 T, u32* stats) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 v0 = r < T ? c_nnz[r] : 0u, v1 = (r < T && c_rows) ? c_rows[r] : 0u, v2 = (r < T && c_tr) ? c_tr[r] : 0u;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { v0 = max(v0, (u32)__shfl_down(v0, d, 64)); v1 = max(v1, (u32)__shfl_down(v1, d, 64)); v2 = max(v2, (u32)__shfl_down(v2, d, 64)); }
+  if (lane_id() == 0) { if (v0) atomicMax(&stats[0], v0); if (v1) atomicMax(&stats[1], v1); if (v2) atomicMax(&stats[2], v2); }
+}
 int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, u64 T) {
   if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
@@ -4487,7 +4524,8 @@ int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, 
 // target_small entries (P->n_small of them, first), the others in groups of about `target` entries.
 int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
                           const double* eff_lens, u64 T, u64 budget, u64 target, kamd_em_local::Plan* P, EmLocalDev* dev,
-                          kamd_em_local::BuildArgs* args_out = nullptr, u32 small_limit = 0, u64 target_small = 0, bool host_maps = true) {
+                          kamd_em_local::BuildArgs* args_out = nullptr, u32 small_limit = 0, u64 target_small = 0, bool host_maps = true,
+                          CompStats* comp_out = nullptr) {
   namespace L = kamd_em_local;
   if (nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
   // component labels (smallest transcript id of the component): one lock-free union-find pass, cc_labels
@@ -4514,6 +4552,11 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   A.c_tr = (u32*)(tb + o_ct); A.cum_nnz = (const uint64_t*)(tb + o_cum); A.local_of = (u32*)(tb + o_loc); A.row_new = (u32*)(tb + o_rnew);
   hipLaunchKernelGGL(k_eml_step<0>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   hipLaunchKernelGGL(k_eml_step<1>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
+  // the largest component, read back with the entry count below (same synchronisation)
+  CompStats cst{};
+  HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(CompStats), c->stream));
+  hipLaunchKernelGGL(k_comp_stats, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A.c_nnz, A.c_rows, A.c_tr, T, (u32*)c->pt_hist.p);
+  HIPC(hipMemcpyAsync(&cst, c->pt_hist.p, sizeof(CompStats), hipMemcpyDeviceToHost, c->stream));
   u64 NZ = 0;
   u32 ng = 0;
   P->n_small = 0;
@@ -4527,6 +4570,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
     HIPC(hipMemcpyAsync(&nz2[1], (u64*)(tb + o_cumb) + T, 8, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     NZ = nz2[0] + nz2[1];
+    if (comp_out) *comp_out = cst;
     if (NZ == 0) return 1;
     A.target_big = A.target_nnz; A.target_nnz = std::max<u64>(1, target_small); A.cum_big = (const uint64_t*)(tb + o_cumb);
     A.ng_small = nz2[0] ? (u32)((nz2[0] - 1) / A.target_nnz + 1) : 0u;
@@ -4536,9 +4580,11 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
     if (int rc = exclusive_scan(c, A.c_nnz, T, (u64*)(tb + o_cum), (u64*)(tb + o_cum) + T)) return rc;
     HIPC(hipMemcpyAsync(&NZ, (u64*)(tb + o_cum) + T, 8, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
+    if (comp_out) *comp_out = cst;
     if (NZ == 0) return 1;
     ng = (u32)((NZ - 1) / A.target_nnz + 1);
   }
+  if (comp_out) *comp_out = cst;
   if ((u64)ng > ng_max) return kamd::fail(-105, "kamd_em_run: component-local EM: more groups than entries allow");
   A.n_groups = ng;
   HIPC(hipMemsetAsync(tb + o_gr, 0, t1.off - o_gr, c->stream));
@@ -4665,6 +4711,190 @@ __global__ void k_sell_refresh(const u64* __restrict__ ec_off, const u32* __rest
   }
   if (i < T && mslot[i] != SELL_NONE) eff_m[mslot[i]] = eff[i];
 }
+
+// ---- hybrid EM: the connected components that do not fit a workgroup's LDS, iterated BESIDE the component-local form ----------------
+// A real transcriptome has repeat families and poly-A classes: equivalence classes of hundreds to thousands of transcripts that chain
+// unrelated genes into ONE connected component with half of the matrix's entries (the reference ships --ec-max-size for them,
+// src/main.cpp:2151).  EMAlgorithm::run (src/EMAlgorithm.h:112-223) costs the same per entry whatever the graph looks like; the LDS form
+// cannot hold such a component.  So the matrix is split by component: what fits keeps k_em_sell, the oversized components become a
+// sub-matrix in the flagged-stream layout of the streamed form (em_streamed_setup) and are iterated by two launches per round on a
+// stream of their own, on compute units the LDS kernel's stream is masked away from.  Both sides speak the protocol of EmSellGpu::launch:
+// n rounds from an input state that stays intact (the checkpoint) to an output state, per-round change counts added to ONE history, the
+// stop rule of the previous chunk applied by every kernel (a chunk queued behind the one the run stops in does nothing).  The kernel
+// bodies are the streamed form's (pm_wave_load / pm_wave_pass / pm_fix); only the loop control differs: no EmState, the round's
+// vectors are kernel arguments, and what changes from chunk to chunk sits in a descriptor in device memory so that the 64 rounds of
+// a chunk are ONE hipGraph replayed for every chunk (4 launches per round at 3.5 us of host time each would otherwise bind the host).
+struct GiDesc { const int* prev_hist; int prev_n, prev_base, min_rounds, pad; int* hist; };
+__global__ void k_gi_set_desc(GiDesc* d, GiDesc v) { if (threadIdx.x == 0) *d = v; }
+__device__ __forceinline__ bool gi_stopped(const GiDesc* d, int* s_flag) {
+  if (threadIdx.x < 64) {
+    const int i = (int)threadIdx.x;
+    const int* ph = d->prev_hist;
+    bool stop = false;
+    if (ph) { const int n = d->prev_n; const int h = i < n ? ph[i] : 1; stop = i < n && h == 0 && d->prev_base + i > d->min_rounds; }   // :202-205
+    const u64 m = __ballot(stop);
+    if (i == 0) *s_flag = m != 0;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+struct GiColEmit {   // PmColEmit without the clamped copy (the final round's clamp is a pass of its own, k_gi_clamp)
+  const double* alpha_cur; const double* a_cur; const double* single; const double* eff; double* alpha_nx; double* a_nx; int* ch; int clamp;
+  struct Ctx { double al, at, sg, ef; };
+  __device__ __forceinline__ Ctx load(u32 m) const { return Ctx{alpha_cur[m], a_cur[m], single[m], eff[m]}; }
+  __device__ __forceinline__ void finish(u32 m, const Ctx& x, double acc) const {
+    const double al = (clamp && x.al < 1e-7 / 10.0) ? 0.0 : x.al;
+    const double nx = x.sg + x.at * acc;
+    if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ++*ch;
+    alpha_nx[m] = nx;
+    a_nx[m] = nx / x.ef;
+  }
+};
+__device__ __forceinline__ void gi_count_changes(int ch, int* lds_ch, int* slot) {
+  if (threadIdx.x == 0) *lds_ch = 0;
+  __syncthreads();
+  if (__ballot(ch != 0)) {
+    int wsum = ch;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d, 64);
+    if (lane_id() == 0) atomicAdd(lds_ch, wsum);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && *lds_ch && slot) atomicAdd(slot, *lds_ch);
+}
+template <int K, int PRE, bool WIN>
+__global__ __launch_bounds__(PM_BLOCK) void k_gi_rows(PmArgs A, const double* a_src, const GiDesc* desc) {
+  __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
+  __shared__ int s_stop;
+  const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
+  PmWave<K> w;
+  if (c < A.rows.n_chunks) pm_wave_load<K>(A.rows, c, w);
+  if (gi_stopped(desc, &s_stop)) return;
+  if (c >= A.rows.n_chunks) return;
+  const PmRowEmit em{A.cw, A.g};
+  pm_wave_pass<K, PRE, WIN>(A.rows, c, w, a_src, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+}
+template <int K, int PRE, bool WIN>
+__global__ __launch_bounds__(PM_BLOCK) void k_gi_cols(PmArgs A, const double* al_src, const double* a_src, double* al_dst, double* a_dst, int round, int clamp,
+                                                      const GiDesc* desc) {
+  __shared__ double lds_sums[(PM_BLOCK / 64) * PM_LDS_SLOTS];
+  __shared__ int lds_ch;
+  __shared__ int s_stop;
+  const u32 c = __builtin_amdgcn_readfirstlane(blockIdx.x * (PM_BLOCK / 64) + (threadIdx.x >> 6));
+  PmWave<K> w;
+  if (c < A.cols.n_chunks) pm_wave_load<K>(A.cols, c, w);
+  if (gi_stopped(desc, &s_stop)) return;
+  int ch = 0;
+  const GiColEmit em{al_src, a_src, A.single, A.eff, al_dst, a_dst, &ch, clamp};
+  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE, WIN>(A.cols, c, w, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  int* hist = desc->hist;
+  gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
+}
+__global__ __launch_bounds__(PM_BLOCK) void k_gi_rows_fix(PmArgs A, const GiDesc* desc) {
+  __shared__ int s_stop;
+  if (gi_stopped(desc, &s_stop)) return;
+  const PmRowEmit em{A.cw, A.g};
+  pm_fix(A.rows, blockIdx.x * PM_BLOCK + threadIdx.x, em);
+}
+__global__ __launch_bounds__(PM_BLOCK) void k_gi_cols_fix(PmArgs A, const double* al_src, const double* a_src, double* al_dst, double* a_dst, int round, int clamp,
+                                                          const GiDesc* desc) {
+  __shared__ int lds_ch;
+  __shared__ int s_stop;
+  if (gi_stopped(desc, &s_stop)) return;
+  int ch = 0;
+  const GiColEmit em{al_src, a_src, A.single, A.eff, al_dst, a_dst, &ch, clamp};
+  pm_fix(A.cols, blockIdx.x * PM_BLOCK + threadIdx.x, em);
+  int* hist = desc->hist;
+  gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
+}
+// the final round reads a with the clamp applied (alpha < alpha_limit / 10 -> 0, :212-221); ac[M] = 0 stays the row stream's sentinel
+__global__ void k_gi_clamp(const double* __restrict__ al, const double* __restrict__ a, double* ac, u32 M, const GiDesc* desc) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) ac[i] = al[i] < 1e-7 / 10.0 ? 0.0 : a[i];
+  else if (i == M) ac[i] = 0.0;
+}
+__global__ void k_gi_zero_tail(double* p0, double* p1, double* p2, double* p3, double* p4, u32 M) {   // sentinels of the scratch vectors
+  if (threadIdx.x == 0 && blockIdx.x == 0) { p0[M] = 0.0; p1[M] = 0.0; p2[M] = 0.0; p3[M] = 0.0; p4[M] = 0.0; }
+}
+// the oversized components' transcripts back in transcript space (behind k_em_scatter, which left them at 0)
+__global__ void k_gi_scatter(u64 T, const u32* __restrict__ mflag, const u64* __restrict__ mpos, const double* __restrict__ fin, const double* __restrict__ before,
+                             int have_final, double* out_alpha, double* out_abz) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T || !mflag[t]) return;
+  const u64 m = mpos[t];
+  out_alpha[t] = fin[m];
+  out_abz[t] = have_final ? before[m] : 0.0;
+}
+struct GiantPart {
+  PmPlan plan;
+  double* G_al[2] = {nullptr, nullptr}; double* G_a[2] = {nullptr, nullptr};   // the ping-pong state of the chunks (chunk k: [k & 1] -> [(k + 1) & 1])
+  double* S_al[2] = {nullptr, nullptr}; double* S_a[2] = {nullptr, nullptr};   // what the rounds inside a chunk alternate between
+  double* ac = nullptr;
+  GiDesc* desc = nullptr;
+  hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
+  hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  bool use_graph = true;
+  u64 nnz = 0, rows = 0; int cus = 0;
+  void drop_graphs() {
+    for (int i = 0; i < 2; i++) {
+      if (gexec[i]) (void)hipGraphExecDestroy(gexec[i]);
+      if (graph[i]) (void)hipGraphDestroy(graph[i]);
+      gexec[i] = nullptr; graph[i] = nullptr;
+    }
+  }
+};
+template <int K>
+void gi_round(const GiantPart& G, hipStream_t s, int round, int clamp, const double* al_src, const double* a_src, double* al_dst, double* a_dst) {
+  const PmPlan& P = G.plan;
+  const unsigned grid = grid_for(P.n_chunks, PM_BLOCK / 64);
+  constexpr int PRE_R = (K + 5) / 6 < 2 ? 2 : (K + 5) / 6;
+  constexpr int PRE_C = K / 16 + 1;
+  if (P.windowed) hipLaunchKernelGGL((k_gi_rows<K, PRE_R, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, a_src, G.desc);
+  else hipLaunchKernelGGL((k_gi_rows<K, PRE_R, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, a_src, G.desc);
+  if (P.n_fix[0]) hipLaunchKernelGGL(k_gi_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, G.desc);
+  if (P.windowed) hipLaunchKernelGGL((k_gi_cols<K, PRE_C, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc);
+  else hipLaunchKernelGGL((k_gi_cols<K, PRE_C, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc);
+  if (P.n_fix[1]) hipLaunchKernelGGL(k_gi_cols_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc);
+}
+// n rounds from state [pin] to state [pout]; the rounds in between alternate between the two scratch states, so the input stays intact
+void gi_enqueue_rounds(const GiantPart& G, hipStream_t s, int n, int clamp, int pin, int pout) {
+  const u32 M = G.plan.args.M;
+  for (int i = 0; i < n; i++) {
+    const double* al_src = i == 0 ? G.G_al[pin] : G.S_al[(i - 1) & 1];
+    const double* a_src = i == 0 ? G.G_a[pin] : G.S_a[(i - 1) & 1];
+    double* al_dst = i == n - 1 ? G.G_al[pout] : G.S_al[i & 1];
+    double* a_dst = i == n - 1 ? G.G_a[pout] : G.S_a[i & 1];
+    if (clamp) {
+      hipLaunchKernelGGL(k_gi_clamp, dim3(grid_for((u64)M + 1, BLOCK)), dim3(BLOCK), 0, s, al_src, a_src, G.ac, M, G.desc);
+      a_src = G.ac;
+    }
+    switch (G.plan.k) {
+      case 8: gi_round<8>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+      case 12: gi_round<12>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+      case 16: gi_round<16>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+      case 20: gi_round<20>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+      case 24: gi_round<24>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+      case 28: gi_round<28>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+      default: gi_round<32>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
+    }
+  }
+}
+// one chunk on the oversized components' stream (the caller has made that stream wait for the context stream and joins it afterwards)
+int gi_launch_chunk(GiantPart& G, int n, int clamp, int pin, int pout, int* d_h, const EmsPrev& prev) {
+  const GiDesc v{prev.hist, prev.n, prev.base, prev.min_rounds, 0, d_h};
+  hipLaunchKernelGGL(k_gi_set_desc, dim3(1), dim3(64), 0, G.stream, G.desc, v);
+  if (G.use_graph && n == EML_MAX_ROUNDS && !clamp && pin != pout) {
+    if (!G.gexec[pin]) {
+      HIPC(hipStreamBeginCapture(G.stream, hipStreamCaptureModeThreadLocal));
+      gi_enqueue_rounds(G, G.stream, n, 0, pin, pout);
+      HIPC(hipStreamEndCapture(G.stream, &G.graph[pin]));
+      HIPC(hipGraphInstantiate(&G.gexec[pin], G.graph[pin], nullptr, nullptr, 0));
+    }
+    HIPC(hipGraphLaunch(G.gexec[pin], G.stream));
+  } else gi_enqueue_rounds(G, G.stream, n, clamp, pin, pout);
+  HIPC(hipGetLastError());
+  return 0;
+}
 struct SellCache {
   bool valid = false;
   const u64* d_ec_off = nullptr; const u32* d_ec_ids = nullptr; u64 n_ecs = 0, nnz = 0, T = 0, generation = 0;
@@ -4673,9 +4903,13 @@ struct SellCache {
   kamd_em_sell::Plan P;      // host part (tr_id, single_all, bases)
   EmSellDev dev{};           // device part, in ctx->ems_plan
   u32* row_final = nullptr; u32* mslot = nullptr; double* single_all = nullptr; double* d_eff = nullptr;   // in ctx->ems_maps
+  bool hybrid = false;       // G holds the streamed plan of the components beyond a workgroup's LDS; P / dev the others (never cached: valid stays false)
+  GiantPart G;
+  ~SellCache() { G.drop_graphs(); }
 };
 
 // ---- the sliced-ELLPACK form: device plan + backend of kamd_em_local::run --------------------------------------------------
+__global__ void k_em_publish(EmsPrev prev);
 struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0, team_bytes = 0; int block = 256;
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int exp = 0;   // exp: timing experiment (KAMD_EM_EXP)
@@ -4683,6 +4917,10 @@ struct EmSellGpu {
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr; double* d_out = nullptr;
   std::vector<double> h_alpha; int err = 0;
   const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
+  GiantPart* gi = nullptr;             // hybrid: the oversized components, iterated on gi->stream beside the groups
+  hipStream_t sell_stream = nullptr;   // hybrid: the stream of k_em_sell (masked away from the compute units left to gi); null: the context stream
+  hipEvent_t ev_sell = nullptr;
+  int gi_par(const double* al) const { return al == d_alpha ? 0 : 1; }   // which half of the ping-pong pair a vector of the groups is
   EmSellGpu(kamd_ctx* ctx, const kamd_em_sell::Plan& p) : c(ctx), P(p) {}
   int setup(int hist_ints, const double* d_eff_new, u64 T_out);
   void checkpoint() {
@@ -4701,10 +4939,21 @@ struct EmSellGpu {
     // the two size classes run side by side: small groups (one wavefront each) on a second stream, forked from and joined to the context stream
     const u32 n_big = P.n_groups - P.n_small;
     const bool fork = P.n_small && n_big;
-    if (fork && (hipEventRecord(ev_fork, c->stream) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess)) return -104;
+    hipStream_t ss = (gi && sell_stream && n_big) ? sell_stream : c->stream;   // where k_em_sell runs
+    if ((fork || gi) && hipEventRecord(ev_fork, c->stream) != hipSuccess) return -104;
+    if (fork && hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return -104;
+    if (gi) {
+      // nobody else hands the previous chunk's counts to the host when there is no group at all
+      if (!n_big && !P.n_small && prev.hist && prev.host_hist) hipLaunchKernelGGL(k_em_publish, dim3(1), dim3(64), 0, c->stream, prev);
+      if (hipStreamWaitEvent(gi->stream, ev_fork, 0) != hipSuccess) return -104;
+      if (ss != c->stream && hipStreamWaitEvent(ss, ev_fork, 0) != hipSuccess) return -104;
+      // the oversized components first: their kernels are many and short, the groups' one launch then fills the compute units left to it
+      if (int rc = gi_launch_chunk(*gi, n, clamp, gi_par(al_in), gi_par(al_out), d_h, prev)) return rc;
+      if (hipEventRecord(gi->ev, gi->stream) != hipSuccess) return -104;
+    }
     if (n_big) {
-#define KAMD_EMS_LAUNCH(C, E) hipLaunchKernelGGL((k_em_sell<C, E>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
-#define KAMD_EMS_LAUNCH_REG(C, W, NS) hipLaunchKernelGGL((k_em_sell<C, 0, W, NS>), dim3(n_big), dim3(block), lds, c->stream, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
+#define KAMD_EMS_LAUNCH(C, E) hipLaunchKernelGGL((k_em_sell<C, E>), dim3(n_big), dim3(block), lds, ss, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
+#define KAMD_EMS_LAUNCH_REG(C, W, NS) hipLaunchKernelGGL((k_em_sell<C, 0, W, NS>), dim3(n_big), dim3(block), lds, ss, dev, P.n_small, al_in, a_in, al_out, a_out, n, clamp, d_h, prev, clk)
       if (reg_words == 2) { if (clk) KAMD_EMS_LAUNCH_REG(true, 2, 1); else KAMD_EMS_LAUNCH_REG(false, 2, 1); }
       else if (reg_words == 4) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4, 2); else KAMD_EMS_LAUNCH_REG(false, 4, 2); }
       else if (reg_words == 8) { if (clk) KAMD_EMS_LAUNCH_REG(true, 8, 1); else KAMD_EMS_LAUNCH_REG(false, 8, 1); }
@@ -4725,6 +4974,10 @@ struct EmSellGpu {
                                       fork ? side : c->stream, dev, P.n_small, (u32)team_bytes, al_in, a_in, al_out, a_out, n, clamp, d_h, prev_w);
     if (hipGetLastError() != hipSuccess) return -104;
     if (fork && (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(c->stream, ev_join, 0) != hipSuccess)) return -104;
+    if (gi) {
+      if (ss != c->stream && (hipEventRecord(ev_sell, ss) != hipSuccess || hipStreamWaitEvent(c->stream, ev_sell, 0) != hipSuccess)) return -104;
+      if (hipStreamWaitEvent(c->stream, gi->ev, 0) != hipSuccess) return -104;
+    }
     return 0;
   }
   // the backend interface of kamd_em_local::run (several ranks): in place, the host reads the counts after every chunk
@@ -4781,13 +5034,20 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
       HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
   }
+  if (gi && !c->em_ev_fork) {
+    HIPC(hipEventCreateWithFlags(&c->em_ev_fork, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&c->em_ev_join, hipEventDisableTiming));
+  }
+  if (gi) ev_fork = c->em_ev_fork;
   if (P.n_small) {
     team_bytes = ((size_t)P.max_small_bytes + 15) & ~(size_t)15;
     HIPC(hipFuncSetAttribute((const void*)k_em_sell_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(EMS_WAVE_TEAMS * team_bytes)));
     if (!c->em_side_stream) {
       HIPC(hipStreamCreateWithFlags(&c->em_side_stream, hipStreamNonBlocking));
-      HIPC(hipEventCreateWithFlags(&c->em_ev_fork, hipEventDisableTiming));
-      HIPC(hipEventCreateWithFlags(&c->em_ev_join, hipEventDisableTiming));
+      if (!c->em_ev_fork) {
+        HIPC(hipEventCreateWithFlags(&c->em_ev_fork, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&c->em_ev_join, hipEventDisableTiming));
+      }
     }
     side = c->em_side_stream; ev_fork = c->em_ev_fork; ev_join = c->em_ev_join;
   }
@@ -4818,6 +5078,8 @@ int em_sell_drive_async(kamd_ctx* c, EmSellGpu& B, const SellCache& K, u64 T, in
   if (getenv("KAMD_EM_EXP")) { n_iter = std::min(n_iter, 1280); min_rounds = 1 << 30; }   // timing experiments: a fixed number of rounds, no stop
   if (n_iter <= 0) {   // no round at all: the initial vector (alpha_ = 1/T), no final round
     hipLaunchKernelGGL(k_em_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, K.mslot, K.single_all, B.d_alpha, B.d_alpha, T, 0, B.d_out, B.d_out + T);
+    if (B.gi) hipLaunchKernelGGL(k_gi_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, B.gi->plan.mflag, B.gi->plan.mpos, B.gi->G_al[0], B.gi->G_al[0], 0,
+                                 B.d_out, B.d_out + T);
     HIPC(hipGetLastError());
     std::vector<double> tmp(2 * T);
     HIPC(hipMemcpyAsync(tmp.data(), B.d_out, 2 * T * 8, hipMemcpyDeviceToHost, c->stream));
@@ -4912,6 +5174,8 @@ int em_sell_drive_async(kamd_ctx* c, EmSellGpu& B, const SellCache& K, u64 T, in
     rounds = n_iter;
   }
   hipLaunchKernelGGL(k_em_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, K.mslot, K.single_all, fin, before, T, have_final ? 1 : 0, B.d_out, B.d_out + T);
+  if (B.gi) hipLaunchKernelGGL(k_gi_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, B.gi->plan.mflag, B.gi->plan.mpos, B.gi->G_al[B.gi_par(fin)],
+                               B.gi->G_al[B.gi_par(before)], have_final ? 1 : 0, B.d_out, B.d_out + T);
   HIPC(hipGetLastError());
   HIPC(hipMemcpyAsync(h_out, B.d_out, 2 * T * 8, hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -4931,12 +5195,12 @@ int em_sell_drive_async(kamd_ctx* c, EmSellGpu& B, const SellCache& K, u64 T, in
 // 0 = plan built (P: the host part; *dev: the device part), 1 = not applicable, < 0 = error
 int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
                          const double* eff_lens, u64 T, u64 lds_budget, u64 target, kamd_em_sell::Plan* P, EmSellDev* dev, SellCache* cache,
-                         u32 small_limit = 0, u64 target_small = 0, u64 small_budget = 0, bool host_maps = true) {
+                         u32 small_limit = 0, u64 target_small = 0, u64 small_budget = 0, bool host_maps = true, CompStats* comp_out = nullptr) {
   namespace S = kamd_em_sell;
   kamd_em_local::Plan C;
   EmLocalDev cd{};
   kamd_em_local::BuildArgs A{};
-  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A, small_limit, target_small, host_maps)) return rc;
+  if (int rc = em_local_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, ~0ULL, target, &C, &cd, &A, small_limit, target_small, host_maps, comp_out)) return rc;
   const u32 ng = C.n_groups;
   const u64 R = C.row_base[ng], M = C.tr_base[ng];
   if (R >= 0xFFFFFFF0ULL || M >= 0xFFFFFFF0ULL) return 1;
@@ -5016,6 +5280,200 @@ int em_sell_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, 
   return 0;
 }
 void sell_cache_free(SellCache* k) { delete k; }
+// ---- hybrid plan: split the matrix by component size, the LDS form on what fits, the streamed layout on the rest ---------------------
+__global__ void k_hy_comp_nnz(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ label, u32* c_nnz) {
+  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  if (b - a >= 2) atomicAdd(&c_nnz[label[ec_ids[a]]], (u32)(b - a));
+}
+// a row (singleton rows included: they are the constant term of a transcript of that component) goes with its component
+__global__ void k_hy_sizes(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ label,
+                           const u32* __restrict__ c_nnz, u32 lim, u32* flag_s, u32* len_s, u32* flag_g, u32* len_g) {
+  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  const bool any = b > a;
+  const bool giant = any && c_nnz[label[ec_ids[a]]] > lim;
+  flag_s[e] = any && !giant ? 1u : 0u; len_s[e] = any && !giant ? (u32)(b - a) : 0u;
+  flag_g[e] = giant ? 1u : 0u; len_g[e] = giant ? (u32)(b - a) : 0u;
+}
+// the maps of a plan without groups (every multi-transcript row went to the oversized side): no slot, the singleton counts
+__global__ void k_hy_single(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts, u64 n_ecs, double* single_all) {
+  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs) return;
+  const u64 a = ec_off[e];
+  if (ec_off[e + 1] - a == 1) single_all[ec_ids[a]] = (double)counts[e];
+}
+// the stream k_em_sell runs on in the hybrid: a CU mask keeps it off the compute units left to the oversized components' kernels, which
+// therefore find free units whenever they are launched (a k_em_sell workgroup holds its unit's whole register file for a chunk of 64
+// rounds: 16 wavefronts x 124 registers -- nothing else fits beside it).  Mask bits: the low n_sell of the device's units (the driver
+// deals consecutive bits round-robin over the XCDs, so both sides get units on every XCD).  KAMD_EM_CUMASK=0: no mask (experiments).
+int hy_streams(kamd_ctx* c, int n_sell_cus) {
+  if (!c->hy_giant_stream) {
+    HIPC(hipStreamCreateWithFlags(&c->hy_giant_stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&c->hy_ev_giant, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&c->hy_ev_sell, hipEventDisableTiming));
+  }
+  const char* e = getenv("KAMD_EM_CUMASK");
+  const bool want_mask = !(e && atoi(e) == 0) && n_sell_cus > 0 && n_sell_cus < c->n_cus;
+  const int want = want_mask ? n_sell_cus : 0;
+  if (c->hy_sell_cus != want) {
+    if (c->hy_sell_stream) { HIPC(hipStreamSynchronize(c->hy_sell_stream)); HIPC(hipStreamDestroy(c->hy_sell_stream)); c->hy_sell_stream = nullptr; }
+    if (want) {
+      std::vector<uint32_t> mask((size_t)(c->n_cus + 31) / 32, 0u);
+      for (int b = 0; b < want; b++) mask[(size_t)b >> 5] |= 1u << (b & 31);
+      if (hipExtStreamCreateWithCUMask(&c->hy_sell_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        c->hy_sell_stream = nullptr;   // no masks on this runtime: the two forms share the chip
+        c->hy_sell_cus = 0;
+        return 0;
+      }
+    }
+    c->hy_sell_cus = want;
+  }
+  return 0;
+}
+// the component-local plan of a sub-matrix, with a bounded search for the group size (the cut only helps while no single component is
+// the problem).  0 = built, 1 = not applicable, < 0 = error
+int em_sell_plan_search(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
+                        const double* eff_lens, u64 T, u64 lds_budget, int n_cus, bool multi, SellCache& K, CompStats* cst) {
+  u32 small = c->tune.em_small_nnz > 0 ? (u32)c->tune.em_small_nnz : 0u;
+  // em_group_div < 0 (the default): as few groups per CU as the LDS allows -- one workgroup of 16 wavefronts per CU iterating a group
+  // of up to ~10 000 entries (12 bytes of LDS per entry) beats two half-sized ones: every wavefront then owns a slice in both passes
+  // of a round, and a round costs the same few LDS round trips whatever the size (measured on config #3, profiles/README.md round 4:
+  // 505 groups 8.5 ms, 757 groups 9.6, 1009 groups 10.1).  The group count stays a little under a multiple of the CU count.
+  const bool auto_div = c->tune.em_group_div < 0;
+  const u64 ncu = (u64)std::max(1, n_cus);
+  const u64 div0 = auto_div ? std::max<u64>(1, (nnz + ncu * 10000 - 1) / (ncu * 10000)) : (u64)c->tune.em_group_div;
+  int prc = 1, tries = 0;
+  for (u64 div = div0; div <= 1024 && prc >= 1; ) {
+    const u64 target = std::max<u64>(1024, (nnz + ncu * div - 1) / (ncu * div));
+    prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K, small, small,
+                               24 * 1024, multi, cst);
+    if (prc == 2) { small = 0; continue; }   // (same cut again, one size class)
+    if (prc <= 0 || target == 1024) break;
+    // a component that cannot fit a workgroup whatever the cut (kamd_em_sell.h group_bytes: 4 bytes of index per entry and direction pair,
+    // 16 per row, 48 per transcript at the least; 16-bit local indices): stop at once -- every further cut repeats a full device set-up
+    if (cst && ((u64)cst->max_nnz * 4 + (u64)cst->max_rows * 16 > lds_budget || cst->max_rows > 65000 || cst->max_tr > 65000)) break;
+    if (++tries >= 5) break;
+    div = auto_div && tries == 1 ? div + 1 : div * 2;   // one step of the fine search (two half-sized components at a group's end), then geometric
+  }
+  return prc == 2 ? 1 : prc;
+}
+// 0 = K holds the hybrid plan (K.hybrid, K.G), 1 = not applicable, < 0 = error
+int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
+                    const double* eff_lens, u64 T, u64 lds_budget, SellCache& K) {
+  if (n_ecs == 0 || nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
+  GiantPart& G = K.G;
+  G.drop_graphs();
+  // component labels and the entries of every component
+  if (int rc = cc_labels(c, d_ec_off, d_ec_ids, n_ecs, T)) return rc;
+  Carver cv;
+  const size_t o_lab = cv.take(T * 4 + 8);   // the labels of the WHOLE matrix (the plan of the side that fits computes its own into pt_label)
+  const size_t o_cn = cv.take(T * 4 + 8), o_fs = cv.take(n_ecs * 4 + 8), o_ls = cv.take(n_ecs * 4 + 8), o_fg = cv.take(n_ecs * 4 + 8), o_lg = cv.take(n_ecs * 4 + 8);
+  const size_t o_rs = cv.take((n_ecs + 2) * 8), o_zs = cv.take((n_ecs + 2) * 8), o_rg = cv.take((n_ecs + 2) * 8), o_zg = cv.take((n_ecs + 2) * 8);
+  // the two sub-matrices (between them every row of the matrix once)
+  const size_t o_off_s = cv.take((n_ecs + 2) * 8), o_off_g = cv.take((n_ecs + 2) * 8), o_ids_s = cv.take(nnz * 4 + 8), o_ids_g = cv.take(nnz * 4 + 8);
+  const size_t o_cnt_s = cv.take(n_ecs * 4 + 8), o_cnt_g = cv.take(n_ecs * 4 + 8), o_wc_s = cv.take(n_ecs * 4 + 8), o_wc_g = cv.take(n_ecs * 4 + 8);
+  if (int rc = c->hy_sub.ensure(cv.off, 0, c->stream)) return rc;
+  char* hb = (char*)c->hy_sub.p;
+  u32* c_nnz = (u32*)(hb + o_cn);
+  u32* flag_s = (u32*)(hb + o_fs); u32* len_s = (u32*)(hb + o_ls); u32* flag_g = (u32*)(hb + o_fg); u32* len_g = (u32*)(hb + o_lg);
+  u64* rpos_s = (u64*)(hb + o_rs); u64* zpos_s = (u64*)(hb + o_zs); u64* rpos_g = (u64*)(hb + o_rg); u64* zpos_g = (u64*)(hb + o_zg);
+  u64* off_s = (u64*)(hb + o_off_s); u64* off_g = (u64*)(hb + o_off_g); u32* ids_s = (u32*)(hb + o_ids_s); u32* ids_g = (u32*)(hb + o_ids_g);
+  u32* cnt_s = (u32*)(hb + o_cnt_s); u32* cnt_g = (u32*)(hb + o_cnt_g); u32* wc_s = (u32*)(hb + o_wc_s); u32* wc_g = (u32*)(hb + o_wc_g);
+  u32* label = (u32*)(hb + o_lab);
+  HIPC(hipMemcpyAsync(label, c->pt_label.p, T * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPC(hipMemsetAsync(c_nnz, 0, T * 4, c->stream));
+  hipLaunchKernelGGL(k_hy_comp_nnz, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, label, c_nnz);
+  HIPC(hipGetLastError());
+  u32 lim = c->tune.em_giant_nnz > 0 ? (u32)c->tune.em_giant_nnz : 6000u;
+  for (int attempt = 0; attempt < 4; attempt++, lim = std::max(lim / 2, 8u)) {
+    hipLaunchKernelGGL(k_hy_sizes, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, label, c_nnz, lim,
+                       flag_s, len_s, flag_g, len_g);
+    if (int rc = exclusive_scan(c, flag_s, n_ecs, rpos_s, rpos_s + n_ecs)) return rc;
+    if (int rc = exclusive_scan(c, len_s, n_ecs, zpos_s, zpos_s + n_ecs)) return rc;
+    if (int rc = exclusive_scan(c, flag_g, n_ecs, rpos_g, rpos_g + n_ecs)) return rc;
+    if (int rc = exclusive_scan(c, len_g, n_ecs, zpos_g, zpos_g + n_ecs)) return rc;
+    u64 tot[4] = {0, 0, 0, 0};   // rows / entries of the side that fits, of the oversized side
+    HIPC(hipMemcpyAsync(&tot[0], rpos_s + n_ecs, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(&tot[1], zpos_s + n_ecs, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(&tot[2], rpos_g + n_ecs, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(&tot[3], zpos_g + n_ecs, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    const u64 n_s = tot[0], nnz_s = tot[1], n_g = tot[2], nnz_g = tot[3];
+    if (n_g == 0) continue;   // nothing above this limit, and the whole matrix did not fit: a lower limit
+    hipLaunchKernelGGL(k_part_copy, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, flag_s, rpos_s, zpos_s,
+                       off_s, ids_s, cnt_s, wc_s);
+    hipLaunchKernelGGL(k_part_copy, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, flag_g, rpos_g, zpos_g,
+                       off_g, ids_g, cnt_g, wc_g);
+    HIPC(hipMemcpyAsync(off_s + n_s, zpos_s + n_ecs, 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPC(hipMemcpyAsync(off_g + n_g, zpos_g + n_ecs, 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPC(hipGetLastError());
+    // compute units: the oversized side's share of the entries, 32 .. 192 of 256, a multiple of 8 (one unit more or less on every XCD)
+    int g_cus = c->tune.em_giant_cus > 0 ? c->tune.em_giant_cus : (int)((double)c->n_cus * (double)nnz_g / (double)std::max<u64>(nnz_s + nnz_g, 1) + 0.5);
+    g_cus = std::min(std::max(g_cus, c->n_cus / 8), c->n_cus * 3 / 4) / 8 * 8;
+    if (g_cus <= 0 || g_cus >= c->n_cus) g_cus = c->n_cus / 2;
+    if (int rc = hy_streams(c, c->n_cus - g_cus)) return rc;
+    const int sell_cus = c->hy_sell_cus > 0 ? c->hy_sell_cus : c->n_cus;
+    // the side that fits: the component-local plan over its rows (groups sized for the compute units it gets)
+    CompStats cst{};
+    int prc = n_s ? em_sell_plan_search(c, off_s, ids_s, cnt_s, wc_s, n_s, nnz_s, eff_lens, T, lds_budget, sell_cus, false, K, &cst) : 1;
+    if (prc < 0) return prc;
+    if (prc == 1 && cst.max_nnz == 0) {
+      // no row with two transcripts on that side: a plan without groups -- its transcripts keep their singleton counts
+      K.P = kamd_em_sell::Plan{};
+      K.P.T = T; K.P.row_base.assign(1, 0); K.P.tr_base.assign(1, 0);
+      K.dev = EmSellDev{};
+      Carver mv;
+      const size_t m_ms = mv.take(T * 4 + 8), m_sa = mv.take(T * 8 + 8);
+      if (int rc = c->hy_maps.ensure(mv.off, 0, c->stream)) return rc;
+      char* mb = (char*)c->hy_maps.p;
+      HIPC(hipMemsetAsync(mb + m_ms, 0xFF, T * 4, c->stream));
+      HIPC(hipMemsetAsync(mb + m_sa, 0, T * 8, c->stream));
+      if (n_s) hipLaunchKernelGGL(k_hy_single, dim3(grid_for(n_s, BLOCK)), dim3(BLOCK), 0, c->stream, off_s, ids_s, cnt_s, n_s, (double*)(mb + m_sa));
+      HIPC(hipGetLastError());
+      K.mslot = (u32*)(mb + m_ms); K.single_all = (double*)(mb + m_sa); K.row_final = nullptr; K.d_eff = nullptr;
+      prc = 0;
+    }
+    if (prc == 1) continue;   // some component under the limit still does not fit its group: a lower limit
+    // the oversized side: the streamed form's layout (kept rows, m-space, flagged entry streams) in arenas of its own
+    for (DBuf* b : {&c->em_eff, &c->em_single}) if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
+    if (int rc = c->em_colcnt.ensure(3 * (T + 1) * sizeof(u32), 0, c->stream)) return rc;
+    if (int rc = c->em_coloff.ensure((T + 2) * sizeof(u64), 0, c->stream)) return rc;
+    u32* col_cnt = c->em_colcnt.as<u32>();
+    u32* col_fill = col_cnt + (T + 1);
+    HIPC(hipMemcpyAsync(c->em_eff.p, eff_lens, T * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemsetAsync(col_cnt, 0, 2 * (T + 1) * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(c->em_single.p, 0, T * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_g, BLOCK)), dim3(BLOCK), 0, c->stream, off_g, ids_g, cnt_g, n_g, col_cnt, c->em_single.as<double>());
+    if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
+    G.plan = PmPlan{};
+    const int src = em_streamed_setup(c, off_g, ids_g, cnt_g, wc_g, n_g, T, col_cnt, col_fill, &G.plan, &c->hy_a, &c->hy_b, g_cus);
+    if (src < 0) return src;
+    if (src != 0) return 1;
+    const PmArgs& A = G.plan.args;
+    const u64 M1 = (u64)A.M + 1;
+    Carver xv;
+    size_t o_v[5];
+    for (int j = 0; j < 5; j++) o_v[j] = xv.take(M1 * 8);
+    const size_t o_desc = xv.take(sizeof(GiDesc));
+    if (int rc = c->hy_x.ensure(xv.off, 0, c->stream)) return rc;
+    char* xb = (char*)c->hy_x.p;
+    G.G_al[0] = A.alpha0; G.G_al[1] = A.alpha1; G.G_a[0] = A.a0; G.G_a[1] = A.a1;   // (k_pm_minit: alpha0 = 1 / T, a0 = alpha0 / eff; the sentinels [M] = 0)
+    G.S_al[0] = (double*)(xb + o_v[0]); G.S_al[1] = (double*)(xb + o_v[1]); G.S_a[0] = (double*)(xb + o_v[2]); G.S_a[1] = (double*)(xb + o_v[3]);
+    G.ac = (double*)(xb + o_v[4]); G.desc = (GiDesc*)(xb + o_desc);
+    hipLaunchKernelGGL(k_gi_zero_tail, dim3(1), dim3(64), 0, c->stream, G.S_al[0], G.S_al[1], G.S_a[0], G.S_a[1], G.ac, A.M);
+    HIPC(hipGetLastError());
+    G.stream = c->hy_giant_stream; G.ev = c->hy_ev_giant; G.use_graph = c->tune.em_graph != 2;
+    G.nnz = nnz_g; G.rows = A.R; G.cus = c->hy_sell_cus > 0 ? c->n_cus - c->hy_sell_cus : 0;
+    K.hybrid = true;
+    c->last_em_giant_nnz = c->last_em_nnz_multi; c->last_em_giant_rows = A.R; c->last_em_giant_tr = A.M; c->last_em_giant_chunks = G.plan.n_chunks; c->last_em_giant_cus = G.cus;
+    return 0;
+  }
+  return 1;
+}
 // part (several ranks, each with the rows of the components it owns): the per-round change counts of a chunk are summed over the
 // ranks on the device before the host looks at them (the only coupling between components is the stop rule), and "this form does
 // not apply" is agreed on by all ranks, so that every rank issues the same collectives.
@@ -5034,6 +5492,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
                    K.generation == c->ec_generation && K.split_len == c->tune.em_split_len && K.group_div == c->tune.em_group_div &&
                    K.small_nnz == c->tune.em_small_nnz && (K.host_maps || !multi);
   if (hit) {
+    c->last_em_plan_ms = 0.f;
     HIPC(hipMemcpyAsync(K.d_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemsetAsync(K.single_all, 0, T * 8, c->stream));
     hipLaunchKernelGGL(k_sell_refresh, dim3(grid_for(std::max<u64>(n_ecs, T), BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, d_counts, d_wcounts,
@@ -5046,9 +5505,12 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       HIPC(hipStreamSynchronize(c->stream));
     }
   } else {
-    K.valid = false;
-    // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not, the
-    // cut is halved, and a single component beyond the CU's 160 KB makes the form not applicable)
+    const auto plan_t0 = std::chrono::steady_clock::now();
+    K.valid = false; K.hybrid = false;
+    c->last_em_giant_nnz = 0; c->last_em_giant_rows = 0; c->last_em_giant_tr = 0; c->last_em_giant_chunks = 0; c->last_em_giant_cus = 0;
+    // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not fit, the
+    // cut is refined a few times; a single component beyond the CU's 160 KB sends the oversized components to the streamed kernels
+    // beside the groups -- the hybrid, em_hybrid_setup -- or, with several ranks, the whole matrix to the streamed form)
     const u64 lds_budget = 160 * 1024 - 2048;
     int prc = 1;
     if (multi && n_ecs == 0) {   // a rank that owns no component still takes part in the collectives: an empty plan
@@ -5056,29 +5518,17 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       K.P.T = T; K.P.row_base.assign(1, 0); K.P.tr_base.assign(1, 0); K.P.single_all.assign(T, 0.0);
       K.dev = EmSellDev{};
       prc = 0;
-    } else
-    {
-      // two size classes (em_small_nnz > 0): components of at most em_small_nnz entries go to groups of about that many entries, which
-      // one wavefront iterates (k_em_sell_wave); the larger ones to workgroup-sized groups as before.  A small group must fit a
-      // wavefront's share of a CU's LDS (24 KB: six or more workgroups of four per CU), else the classes are dropped.
-      u32 small = c->tune.em_small_nnz > 0 ? (u32)c->tune.em_small_nnz : 0u;
-      // em_group_div < 0 (the default): as few groups per CU as the LDS allows -- one workgroup of 16 wavefronts per CU iterating a group
-      // of up to ~10 000 entries (12 bytes of LDS per entry) beats two half-sized ones: every wavefront then owns a slice in both passes
-      // of a round, and a round costs the same few LDS round trips whatever the size (measured on config #3, profiles/README.md round 4:
-      // 505 groups 8.5 ms, 757 groups 9.6, 1009 groups 10.1).  The group count stays a little under a multiple of the CU count.
-      const bool auto_div = c->tune.em_group_div < 0;
-      const u64 div0 = auto_div ? std::max<u64>(1, (nnz + (u64)c->n_cus * 10000 - 1) / ((u64)c->n_cus * 10000)) : (u64)c->tune.em_group_div;
-      for (u64 div = div0; div <= 1024 && prc >= 1; div = auto_div ? div + 1 : div * 2) {
-        const u64 target = std::max<u64>(1024, (nnz + (u64)c->n_cus * div - 1) / ((u64)c->n_cus * div));
-        prc = em_sell_setup_device(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, target, &K.P, &K.dev, &K, small, small,
-                                   24 * 1024, multi);
-        if (prc == 2) { small = 0; div = auto_div ? div - 1 : div / 2; continue; }   // (same cut again, one class)
-        if (target == 1024) break;
+    } else {
+      CompStats cst{};
+      prc = em_sell_plan_search(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, c->n_cus, multi, K, &cst);
+      c->last_em_max_comp_nnz = cst.max_nnz;
+      if (prc == 1 && !multi && c->tune.em_hybrid != 2 && cst.max_nnz > 0) {
+        prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K);
+        if (prc == 1) K.hybrid = false;
       }
-      if (prc == 2) prc = 1;
     }
     if (prc < 0) return prc;
-    bool not_applicable = prc == 1 || (!multi && K.P.n_groups == 0);
+    bool not_applicable = prc == 1 || (!multi && K.P.n_groups == 0 && !K.hybrid);
     if (multi) {
       int flag = not_applicable ? 1 : 0;
       if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
@@ -5090,7 +5540,8 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       not_applicable = flag != 0;
     }
     if (not_applicable) return 1;
-    if (own) {
+    c->last_em_plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - plan_t0).count();
+    if (own && !K.hybrid) {
       K.valid = true; K.d_ec_off = d_ec_off; K.d_ec_ids = d_ec_ids; K.n_ecs = n_ecs; K.nnz = nnz; K.T = T; K.generation = c->ec_generation;
       K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div; K.small_nnz = c->tune.em_small_nnz; K.host_maps = multi;
     }
@@ -5099,6 +5550,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   const int chunk = EML_MAX_ROUNDS;
   EmSellGpu B(c, P);
   B.dev = K.dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block; B.part = multi ? part : nullptr;
+  if (K.hybrid) { B.gi = &K.G; B.sell_stream = c->hy_sell_stream; B.ev_sell = c->hy_ev_sell; }
   const int n_chunks = std::max(1, (n_iter + chunk - 1) / chunk);
   if (int rc = B.setup(multi ? chunk : n_chunks * chunk, K.dev.eff, multi ? 0 : T)) return rc;
   int r = 0;
@@ -5466,6 +5918,10 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_finalize_ms = c->last_finalize_ms; p->last_fin_records = c->last_fin_records; p->last_fin_stream_words = c->last_fin_stream_words;
   p->last_fin_cand_words = c->last_fin_cand_words;
   p->absorb_ms = c->last_absorb_ms; p->n_distinct_tuples = c->n_distinct_tuples; p->tuple_store_words = c->host_state.ts_words; p->tuple_table_slots = c->tcap;
+  p->last_em_max_comp_nnz = c->last_em_max_comp_nnz; p->last_em_giant_nnz = c->last_em_giant_nnz; p->last_em_giant_rows = c->last_em_giant_rows;
+  p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_giant_cus = c->last_em_giant_cus;
+  p->last_em_plan_ms = c->last_em_plan_ms;
+  p->n_overflow_items = c->overflow_total; p->overflow_ms = c->overflow_ms;
   return 0;
 }
 

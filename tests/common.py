@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["ref_test_pe", "yeast_se", "human_pe", "tiny_k7_se", "dlist_pe", "mosaic_pe"]
+CASES = ["ref_test_pe", "yeast_se", "human_pe", "tiny_k7_se", "dlist_pe", "mosaic_pe", "stress_pe"]
 MAX_FRAG_LEN = 1000
 
 

@@ -235,6 +235,19 @@ def main():
                    "bases -- the case where --no-jump differs from the default.  (--single --union without --single-overhang is "
                    "not a variant: the reference itself dies there with 'Index not present in SparseVector' -- the union holds "
                    "transcripts that the first mapping k-mer's set does not, and findPosition looks them up in it.)")
+    # 7. the structure a real transcriptome has (synth.human_stress): repeat-family copies in terminal exons, paralog families, poly-A
+    #    tails -- equivalence classes of hundreds of transcripts, reads with more than eight distinct (unitig, set) classes -- and reads
+    #    the benches of rounds 1-4 never saw: 12 % off-transcriptome pairs (background with copies of the same repeats: partial k-mer
+    #    matches), a 3' quality tail of substitution errors
+    seqs, bg = synth.human_stress(n_genes=150, seed=7, n_repeat_families=2, paralog_members=30, polya_frac=0.05, background_mbp=0.2)
+    fa = os.path.join(tmp, "st.fa")
+    synth.write_fasta(fa, seqs)
+    r1, r2 = synth.simulate_reads(seqs, 6000, 100, paired=True, err=0.002, n_frac=0.005, seed=41, background=bg, off_frac=0.12, tail_err=0.05)
+    se = ["--single", "-l", "200", "-s", "25"]
+    make_case("stress_pe", fa, [bytes(x) for x in r1], [bytes(x) for x in r2],
+              {"pe": [], "pe_union": ["--union"], "pe_rf": ["--rf"], "se": se, "pe_nojump": ["--no-jump"], "pe_boot": ["--boot", "2", "--seed", "11"]},
+              note="synth.human_stress(150 genes, seed=7: 2 repeat families in 30 % of the genes' terminal exons, 3 x 30 paralog genes, 5 % poly-A tails); "
+                   "simulate_reads(6000 PE-100, seed=41, 12 % off-transcriptome pairs from a background with repeat copies, 3' quality tail up to 5 %)")
     shutil.rmtree(tmp)
 
 

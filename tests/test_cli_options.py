@@ -159,12 +159,16 @@ def test_bench_line_digest_on_a_kept_line():
     assert len(json.dumps(k)) < 4000
 
 
-def test_fastq_spool_writes_what_write_fastq_fast_writes(tmp_path):
+@pytest.mark.parametrize("form", ["realistic", "regular"])
+def test_fastq_spool_writes_what_write_fastq_fast_writes(tmp_path, monkeypatch, form):
     """bench.FastqSpool (the whole input of a run as FASTQ, text assembled chunk by chunk where the reads are generated) against
-    bench.write_fastq_fast on the same reads: byte-identical files, ids continue over the chunks."""
+    bench.write_fastq_fast on the same reads: byte-identical files, record names continue over the chunks -- in the default form (records as a
+    sequencer writes them: variable-length Illumina headers, quality strings with a 3' tail; kallisto_amd/synth_fastq.py) and in the fixed-size
+    form of rounds 1-4.  The realistic records are read back by the oracle's FASTQ reader: four lines each, both mates named alike."""
     import numpy as np
     import torch
     import bench
+    monkeypatch.setenv("KAMD_BENCH_FASTQ", form)
     rng = np.random.default_rng(3)
     L = 37
     r1 = rng.choice(np.frombuffer(b"ACGTN", np.uint8), (1000, L))
@@ -174,9 +178,18 @@ def test_fastq_spool_writes_what_write_fastq_fast_writes(tmp_path):
         sp.add([torch.from_numpy(r1[a:b].copy()), torch.from_numpy(r2[a:b].copy())])
     f1, f2 = sp.close()
     bench.write_fastq_fast(str(tmp_path / "w1.fq"), r1)
-    bench.write_fastq_fast(str(tmp_path / "w2.fq"), r2)
+    bench.write_fastq_fast(str(tmp_path / "w2.fq"), r2, 1)
     assert open(f1, "rb").read() == open(tmp_path / "w1.fq", "rb").read()
     assert open(f2, "rb").read() == open(tmp_path / "w2.fq", "rb").read()
-    assert sp.n == 1000 and os.path.getsize(f1) == 1000 * sp.rec_bytes
+    assert sp.n == 1000
+    lines1, lines2 = open(f1, "rb").read().split(b"\n"), open(f2, "rb").read().split(b"\n")
+    assert len(lines1) == 4001 and lines1[-1] == b""
+    assert [bytes(x) for x in r1] == lines1[1::4] and [bytes(x) for x in r2] == lines2[1::4]
+    if form == "regular":
+        assert os.path.getsize(f1) == 1000 * sp.rec_bytes
+    else:
+        assert all(h.startswith(b"@A00587:") for h in lines1[0:4000:4]) and len({len(h) for h in lines1[0:4000:4]}) > 1   # variable-length headers
+        assert [h.split(b" ")[0] for h in lines1[0:4000:4]] == [h.split(b" ")[0] for h in lines2[0:4000:4]]             # mates named alike
+        assert all(len(q) == L for q in lines1[3::4]) and len(set(lines1[3::4])) > 100                                      # real quality strings
     sp.remove()
     assert not os.path.exists(f1)

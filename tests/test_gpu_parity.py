@@ -238,8 +238,37 @@ def _gene_csr(n_genes, seed):
     return _gene_matrix(n_genes, seed)
 
 
+def _hybrid_csr(n_genes, seed, n_chained=500):
+    """What a real transcriptome's EC matrix looks like: thousands of gene-sized components that fit a workgroup's LDS and
+    ONE component beyond it -- the first n_chained genes chained by repeat-family rows (classes of 20 .. 400 transcripts from unrelated genes,
+    low counts), poly-A-like rows of more than a thousand transcripts and a few hub transcripts -- with about half of the entries."""
+    off, ids, cnt, eff, T = _gene_csr(n_genes, seed)
+    rng = np.random.default_rng(seed + 100)
+    iso_hi = int(ids[off[:-1].astype(np.int64)].max()) + 1
+    lim = max(64, int(iso_hi * n_chained / n_genes))      # transcripts of the chained genes: ids below lim (genes are contiguous in transcript space)
+    rows, counts = [], []
+    for _ in range(400):
+        m = int(rng.integers(20, 400))
+        rows.append(np.sort(rng.choice(lim, min(m, lim), replace=False))); counts.append(int(rng.integers(0, 6)))
+    for _ in range(12):
+        rows.append(np.sort(rng.choice(lim, min(int(rng.integers(1000, 3000)), lim), replace=False))); counts.append(int(rng.integers(1, 4)))
+    for h in rng.choice(lim, 3, replace=False):
+        for o in rng.choice(lim, min(1500, lim - 1), replace=False):
+            if o != h:
+                rows.append(np.sort(np.array([h, o]))); counts.append(int(rng.integers(0, 3)))
+    ids2 = np.concatenate([ids] + [r.astype(np.uint32) for r in rows])
+    off2 = np.concatenate([off, off[-1] + np.cumsum([len(r) for r in rows]).astype(np.uint64)])
+    cnt2 = np.concatenate([cnt, np.array(counts, np.uint32)])
+    order = rng.permutation(len(cnt2))                   # rows in any order, as kamd_ec_finalize emits them
+    lens = np.diff(off2.astype(np.int64))
+    starts = off2[:-1].astype(np.int64)
+    ids3 = np.concatenate([ids2[starts[i]:starts[i] + lens[i]] for i in order])
+    off3 = np.zeros(len(order) + 1, np.uint64); off3[1:] = np.cumsum(lens[order])
+    return off3, ids3, cnt2[order], eff, T
+
+
 @pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
-                               "local_all_small", "hub"])
+                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8"])
 def test_em_forms_agree_with_oracle(k, ka):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -266,7 +295,20 @@ def test_em_forms_agree_with_oracle(k, ka):
             tune["em_small_nnz"] = 4096
         k = "local"
     elif k == "hub":
+        tune = dict(em_form="local")                      # one component, far beyond a workgroup's LDS: all of it on the hybrid's streamed side, no group at all
+    elif k == "hub_streamed":
+        tune = dict(em_form="local", em_hybrid=False)     # the hybrid switched off: the streamed form takes the whole matrix (rounds 1-4)
+    elif isinstance(k, str) and k.startswith("hybrid"):
+        # "one component beyond LDS + thousands of small ones": the small ones in k_em_sell, the oversized one beside them
+        off, ids, cnt, eff, T = _hybrid_csr(3000, 11)
         tune = dict(em_form="local")
+        if k == "hybrid_nograph":
+            tune["em_graph"] = False                      # the chunks' rounds launched one by one
+        elif k == "hybrid_lim60":
+            tune["em_giant_nnz"] = 60                     # most gene-sized components on the streamed side too
+        elif k == "hybrid_k8":
+            tune["em_entries_per_lane"] = 8               # short chunks: the long rows / hub columns cross many of them (fix-up launches)
+        k = "hybrid"
     else:
         tune = dict(em_form="csr" if k == "csr" else "streamed")
         if isinstance(k, str) and k[0] == "w":
@@ -287,7 +329,12 @@ def test_em_forms_agree_with_oracle(k, ka):
         assert prof["em_k"] in (-1, -2)                    # the local form ran (kamd_profile.last_em_k)
         assert prof["em_grid"] > 1                         # ... over several groups
     elif k == "hub":
-        assert prof["em_k"] > 0 or prof["em_k"] == -2      # the streamed form took over, or the one group fitted
+        assert prof["em_k"] == -2 and prof["em_giant_nnz"] > 0 and prof["em_grid"] == 0   # the hybrid, everything on its streamed side
+    elif k == "hub_streamed":
+        assert prof["em_k"] > 0 and prof["em_giant_nnz"] == 0
+    elif k == "hybrid":
+        assert prof["em_k"] == -2 and prof["em_grid"] > 1      # groups in k_em_sell ...
+        assert prof["em_giant_nnz"] > 20000 and prof["em_max_comp_nnz"] > 20000   # ... and the oversized component beside them
     else:
         assert (prof["em_k"] == 0) == (k == "csr")
     if isinstance(k, int):
