@@ -95,6 +95,7 @@ struct DevState {
   u64 exp_words, exp_recs;       // explicit transcript-set stream
   u64 cand_words, cand_recs;     // candidate transcript-set stream
   u64 tl_n, ts_words, tl_fail;   // distinct tuples so far (entries of the tuple list), words of the tuple store, records of a batch that found no slot
+  u64 n_big;                     // kamd_ec_finalize: distinct tuples whose smallest set has more than RES_LANES members (k_resolve_big's work list)
 };
 
 // counters of kernel A (their own struct: chunks of kernel A run on one stream while another copies DevState to and fro)
@@ -110,6 +111,9 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, d, 64); if (lane_id() >= d) v += t; }
   return v;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+  return ((u64)(u32)__shfl((int)(v >> 32), src, 64) << 32) | (u32)__shfl((int)v, src, 64);
 }
 __device__ __forceinline__ u64 wave_sum64(u64 v) {
 #pragma unroll
@@ -828,19 +832,30 @@ __global__ void k_tup_rehash(const u32* __restrict__ store, const TSlot* __restr
 // resolve: candidates = transcript sets of (a) index sets with a non-zero dense count, (b) distinct tuples
 // ------------------------------------------------------------------------------------------------------------------
 // upper bound of the candidate stream size: sum over candidates of (smallest list + 2)
+constexpr u32 RES_BIG_MIN = 16;   // (= RES_LANES) a tuple whose smallest set has more members goes to k_resolve_big
 __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list, u64 n,
-                               u32* per_tuple, DevState* st) {
+                               u32* per_tuple, u32* big_idx, DevState* st) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 b = 0;
+  bool big = false;
   if (i < n) {
     const u64 off = list[i] >> 32;   // (the record's place in the store rides in the list entry: k_tup_store)
     const u32 m = stream[off + 1];
     const kamd::SetTables stt{(const uint64_t*)ix.ec_off, ix.ec_ids};
     b = kamd::set_size_bound(stt, stream + off + 2, (int)m, ix.union_mode != 0) + 2;   // smallest set / sum of the sets (--union)
     per_tuple[i] = (u32)b;   // the tuple's slot in the candidate stream (k_resolve writes there: no allocation at run time)
+    big = big_idx && !ix.union_mode && b - 2 > RES_BIG_MIN;
   }
   b = wave_sum64(b);
   if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
+  // the work list of k_resolve_big: one atomic per wavefront
+  const u64 bm = __ballot(big);
+  if (bm) {
+    u64 base = 0;
+    if (lane_id() == 0) base = atomicAdd(&st->n_big, (u64)__popcll(bm));
+    base = ((u64)__shfl((int)(base >> 32), 0, 64) << 32) | (u32)__shfl((int)base, 0, 64);
+    if (big) big_idx[base + __popcll(bm & ((1ULL << lane_id()) - 1ULL))] = (u32)i;
+  }
 }
 __global__ void k_bound_singles(DevIndex ix, const u32* __restrict__ dense, DevState* st) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -925,6 +940,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
       small = mx <= (u32)RES_LANES && m <= (u32)TUPLE_CAP;   // (tuples of the overflow kernel can have more sets: serial path)
     }
   }
+  if (valid && nb > RES_BIG_MIN) return;   // k_resolve_big's (the whole 16-lane group leaves: nb is uniform in it; no barrier follows)
   u32 total = 0, first_mask = 0, x0 = 0;
   if (small) {
     // all pairs in registers: lane c holds candidate c of the smallest set, lane i member i of every other set (<= 12 loads
@@ -985,6 +1001,162 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
     if (c0 == 0) { gm = first_mask; x = x0; } else gm = chunk_mask(c0, &x);
     if ((gm >> sub) & 1u) cand[out_off + 2 + written + __popc(gm & ((1u << sub) - 1))] = x;
     written += (u32)__popc(gm);
+  }
+}
+
+// (b') tuples whose smallest set is LARGE (more than 16 members): repeat-family and poly-A classes of a real transcriptome -- a few
+// hundred to a few thousand transcripts per set, eight or more sets per tuple.  k_resolve's scheme (16 lanes, every candidate of the
+// smallest set binary-searched in every other set in global memory, once to count and once to write) costs nb x (m - 1) x log2|set|
+// DEPENDENT random reads per tuple: 145 ms for the 0.97 M tuples of 4 M stress pairs.  Here ONE WAVEFRONT takes a tuple and keeps the
+// running intersection in LDS: the smallest set is loaded once (coalesced), every other set streams through LDS in tiles of 1024 ids
+// (coalesced, independent loads) and the survivors are looked up in the tile by binary search IN LDS -- both lists are sorted, so only the
+// survivors inside the tile's id range are looked at -- then compacted; once 64 or fewer survive they are searched in the remaining
+// sets directly.  Global traffic is the sum of the sets' sizes, read once, instead of a dependent chain per candidate.
+constexpr int RB_WAVES = 4, RB_CAND = 4096, RB_TILE = 1024;
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list,
+                                                               const u32* __restrict__ big_idx, u64 n_big, const u64* __restrict__ slot_off, u32* cand,
+                                                               u64* cand_off, u64* cand_key, const DevState* st) {
+  __shared__ u32 s_cand_all[RB_WAVES][RB_CAND];
+  __shared__ u32 s_tile_all[RB_WAVES][RB_TILE];
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  const u64 bi = (u64)blockIdx.x * RB_WAVES + w;
+  if (bi >= n_big) return;
+  u32* s_cand = s_cand_all[w];
+  u32* s_tile = s_tile_all[w];
+  const u64 base_words = st->cand_words, base_recs = st->cand_recs;
+  const u64 gid = big_idx[bi];
+  const u64 le = list[gid];
+  const u64 owner = le >> 32;
+  const u32 m = stream[owner + 1];
+  const u32* es = stream + owner + 2;
+  // the smallest set (first wins on ties, as in k_resolve)
+  u32 bsz = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+  for (u32 j = lane; j < m; j += 64) {
+    const u32 e = es[j] & kamd::EC_ID_MASK;
+    const u32 sz = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]);
+    if (sz < bsz) { bsz = sz; bj = j; }
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 s2 = __shfl_xor(bsz, d, 64), j2 = __shfl_xor(bj, d, 64);
+    if (s2 < bsz || (s2 == bsz && j2 < bj)) { bsz = s2; bj = j2; }
+  }
+  const u32 best = bj, nb = bsz;
+  const u32* base = ix.ec_ids + ix.ec_off[es[best] & kamd::EC_ID_MASK];
+  const u64 out_off = base_words + slot_off[gid];
+  u32 cnt = 0;
+  if (nb > (u32)RB_CAND) {
+    // beyond the LDS buffer (no index we built has such a set): 64 candidates per step, searched in global memory, written at once --
+    // the tuple's slot holds nb ids
+    for (u32 c0 = 0; c0 < nb; c0 += 64) {
+      const u32 c = c0 + lane;
+      bool ok = c < nb;
+      const u32 x = ok ? base[c] : 0u;
+      if (ok) ok = onlisted(ix.onlist_bits, x);
+      for (u32 j = 0; j < m; j++) {
+        if (j == best) continue;
+        const u32 e = es[j] & kamd::EC_ID_MASK;
+        if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+      }
+      const u64 bm = __ballot(ok);
+      if (ok) cand[out_off + 2 + cnt + __popcll(bm & ((1ULL << lane) - 1ULL))] = x;
+      cnt += (u32)__popcll(bm);
+    }
+  } else {
+    // the on-listed members of the smallest set, compacted into LDS
+    for (u32 c0 = 0; c0 < nb; c0 += 64) {
+      const u32 c = c0 + lane;
+      const u32 x = c < nb ? base[c] : 0u;
+      const bool ok = c < nb && onlisted(ix.onlist_bits, x);
+      const u64 bm = __ballot(ok);
+      if (ok) s_cand[cnt + __popcll(bm & ((1ULL << lane) - 1ULL))] = x;
+      cnt += (u32)__popcll(bm);
+    }
+    wave_lds_sync();
+    u32 j = 0;
+    for (; j < m && cnt > 64; j++) {
+      if (j == best) continue;
+      const u32 e = es[j] & kamd::EC_ID_MASK;
+      const u32* B = ix.ec_ids + ix.ec_off[e];
+      const u32 nB = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]);
+      // the set streams through LDS; bit 31 of a survivor marks "found in this set"
+      u32 a = 0;   // survivors below a are smaller than everything still to come of B
+      for (u32 t0 = 0; t0 < nB && a < cnt; t0 += RB_TILE) {
+        const u32 tn = min((u32)RB_TILE, nB - t0);
+        for (u32 i = lane; i < tn; i += 64) s_tile[i] = B[t0 + i];
+        wave_lds_sync();
+        const u32 lo_v = s_tile[0], hi_v = s_tile[tn - 1];
+        // survivors in [lo_v, hi_v]: [a2, b2) (uniform searches over the sorted survivors; LDS broadcast reads)
+        u32 l = a, h = cnt;
+        while (l < h) { const u32 mid = (l + h) >> 1; if ((s_cand[mid] & 0x7FFFFFFFu) < lo_v) l = mid + 1; else h = mid; }
+        const u32 a2 = l;
+        h = cnt;
+        while (l < h) { const u32 mid = (l + h) >> 1; if ((s_cand[mid] & 0x7FFFFFFFu) <= hi_v) l = mid + 1; else h = mid; }
+        const u32 b2 = l;
+        for (u32 i = a2 + lane; i < b2; i += 64) {
+          const u32 x = s_cand[i] & 0x7FFFFFFFu;
+          u32 lo = 0, hi = tn;
+          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (s_tile[mid] < x) lo = mid + 1; else hi = mid; }
+          if (lo < tn && s_tile[lo] == x) s_cand[i] = x | 0x80000000u;
+        }
+        a = b2;
+        wave_lds_sync();
+      }
+      // keep the marked ones (in place: a chunk's writes land at or below its own reads)
+      u32 kept = 0;
+      for (u32 c0 = 0; c0 < cnt; c0 += 64) {
+        const u32 c = c0 + lane;
+        const u32 v = c < cnt ? s_cand[c] : 0u;
+        const bool ok = c < cnt && (v >> 31);
+        const u64 bm = __ballot(ok);
+        wave_lds_sync();
+        if (ok) s_cand[kept + __popcll(bm & ((1ULL << lane) - 1ULL))] = v & 0x7FFFFFFFu;
+        kept += (u32)__popcll(bm);
+        wave_lds_sync();
+      }
+      cnt = kept;
+    }
+    // 64 or fewer survivors and sets j .. m - 1 still to go: all (survivor, set) pairs at once -- one binary search in global memory per
+    // lane and round instead of one round per set (a read that pseudoaligns collapses to a handful of transcripts after the first
+    // intersection: taking the remaining 6-15 sets one after the other was a chain of 60-150 dependent reads per tuple)
+    if (cnt && j < m) {
+      const u32 R = (m - j) - ((best >= j) ? 1u : 0u);
+      if (R) {
+        if ((u32)lane < 64u) s_tile[lane] = 0u;   // dead flags of the survivors
+        wave_lds_sync();
+        const u32 P = cnt * R;
+        for (u32 p = lane; p < P; p += 64) {
+          const u32 ci = p % cnt, r = p / cnt;
+          u32 jr = j + r;
+          if (best >= j && jr >= best) ++jr;
+          const u32 e = es[jr] & kamd::EC_ID_MASK;
+          if (!set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), s_cand[ci])) s_tile[ci] = 1u;
+        }
+        wave_lds_sync();
+        const u32 x = (u32)lane < cnt ? s_cand[lane] : 0u;
+        const bool ok = (u32)lane < cnt && s_tile[lane] == 0u;
+        const u64 bm = __ballot(ok);
+        wave_lds_sync();
+        if (ok) s_cand[__popcll(bm & ((1ULL << lane) - 1ULL))] = x;
+        cnt = (u32)__popcll(bm);
+        wave_lds_sync();
+      }
+    }
+    for (u32 i = lane; i < cnt; i += 64) cand[out_off + 2 + i] = s_cand[i];
+  }
+  if (lane == 0) {
+    if (cnt == 0) cand_off[base_recs + gid] = ~0ULL;   // empty intersection: not pseudoaligned (MinCollector.cpp:200-202)
+    else {
+      const TSlot sl = table[le & 0xFFFFFFFFULL];
+      cand[out_off] = (u32)sl.count; cand[out_off + 1] = cnt; cand_off[base_recs + gid] = out_off;
+      if (cand_key) cand_key[base_recs + gid] = sl.first;
+    }
   }
 }
 
@@ -1503,10 +1675,18 @@ __device__ __forceinline__ double em_clamped(const double* alpha, const double* 
 __global__ void k_em_prepare(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts,
                              u64 n_ecs, u32* col_cnt, double* single) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_ecs) return;
-  const u64 a = ec_off[e], b = ec_off[e + 1];
-  if (b - a == 1) { single[ec_ids[a]] = (double)counts[e]; return; }  // :119-123 (a transcript has at most one singleton set)
-  for (u64 j = a; j < b; j++) atomicAdd(&col_cnt[ec_ids[j]], 1u);
+  u64 a = 0, b = 0;
+  if (e < n_ecs) { a = ec_off[e]; b = ec_off[e + 1]; }
+  if (b - a == 1) single[ec_ids[a]] = (double)counts[e];  // :119-123 (a transcript has at most one singleton set)
+  const bool longrow = b - a > 64;
+  if (b - a >= 2 && !longrow) for (u64 j = a; j < b; j++) atomicAdd(&col_cnt[ec_ids[j]], 1u);
+  u64 m = __ballot(longrow);   // (rows of thousands of transcripts: the wavefront takes them together)
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const u64 ra = shfl_u64(a, src), rb = shfl_u64(b, src);
+    for (u64 j = ra + (u64)lane_id(); j < rb; j += 64) atomicAdd(&col_cnt[ec_ids[j]], 1u);
+  }
 }
 __global__ void k_em_transpose(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs,
                                const u64* __restrict__ col_off, u32* col_fill, u32* col_row) {
@@ -1678,6 +1858,8 @@ __global__ __launch_bounds__(BLOCK) void k_em_final(const u64* __restrict__ seg_
 constexpr u32 PM_END = 0x80000000u;
 constexpr u32 PM_NONE = 0xFFFFFFFFu;
 constexpr u32 PM_HEAVY = 0x80000000u;
+constexpr u32 PM_LONG = 0x40000000u;      // head word: the crossing segment has more than 64 * PM_HEAD entries before the chunk, at most PM_LOOP_MAX: the chunk re-reads them in a loop
+constexpr u32 PM_LOOP_MAX = 32768;
 constexpr int PM_BLOCK = 256;         // 4 wavefronts = 4 chunks per block
 constexpr int PM_HEAD = 4;            // a crossing segment with <= 64 * PM_HEAD entries before the chunk is re-read by the chunk
 constexpr int PM_LDS_SLOTS = 512;     // segment sums staged per wavefront and window
@@ -1796,8 +1978,13 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   const u32 sb = w.sb;
   const u32 hd = w.hd;
   const bool heavy = (hd & PM_HEAVY) != 0;
-  const u32 hlen = heavy ? 0u : hd;
+  const bool longhead = !heavy && (hd & PM_LONG) != 0;
+  const u32 hlen = heavy ? 0u : (hd & ~PM_LONG);
   // lane l holds the entries 64 * (i + 1) - l before the chunk
+  // A LONG head (a row / column of hundreds to thousands of entries that crosses into the chunk: repeat-family and poly-A classes, hub
+  // transcripts) is re-read in a loop, 64 entries per trip -- the trips are independent, so the chunk pays one more latency and a few
+  // dozen issue slots, where the fix-up launch it replaces cost a kernel boundary and a launch per direction and round (4.7 + 4.6 us
+  // each on the stress workload: 4 launches per round -> 2).  The entries are summed lane-strided, then across the lanes: a fixed order.
   auto head_sum = [&](void) -> double {
     double hv[PM_HEAD];
 #pragma unroll
@@ -1805,6 +1992,16 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
     double hs = 0.0;
 #pragma unroll
     for (int i = 0; i < PM_HEAD; i++) hs += (u32)(64 * (i + 1) - lane) <= hlen ? hv[i] : 0.0;
+    if (longhead) {
+      const u32* before = s.stream + (u64)c * (64 * K);   // entry i of the head (counted backwards from the chunk) at before[-1 - i]
+      u32 i = 64 * PM_HEAD + (u32)lane;
+      for (; i + 192 < hlen; i += 256) {   // four independent gathers per trip
+        const u32 i0 = before[-1 - (long)i], i1 = before[-1 - (long)(i + 64)], i2 = before[-1 - (long)(i + 128)], i3 = before[-1 - (long)(i + 192)];
+        const double v0 = src[i0 & ~PM_END], v1 = src[i1 & ~PM_END], v2 = src[i2 & ~PM_END], v3 = src[i3 & ~PM_END];
+        hs += v0; hs += v1; hs += v2; hs += v3;
+      }
+      for (; i < hlen; i += 64) hs += src[before[-1 - (long)i] & ~PM_END];
+    }
     return hs;
   };
   const u32 skip = heavy ? 1u : 0u;   // a heavy crossing segment's end is finished by pm_fix
@@ -2070,7 +2267,7 @@ __global__ void k_pm_minit(u64 n_tr, const u32* __restrict__ mflag, const u64* _
 }
 // per chunk: the segment its first entry belongs to (binary search in the segment offsets) and how it is completed
 __global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 chunk, u32 n_chunks, u32* seg_base, u32* head,
-                            u32* fix_first, u32* n_fix, u32* max_ends) {
+                            u32* fix_first, u32* n_fix, u32* max_ends, int no_long) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_chunks) return;
   const u64 c0 = (u64)c * chunk, c1 = c0 + chunk;
@@ -2078,9 +2275,10 @@ __global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 
   while (hi - lo > 1) { const u64 mid = (lo + hi) / 2; if (off[mid] <= c0) lo = mid; else hi = mid; }
   const u64 hs = off[lo], se = off[lo + 1];
   const u64 hl = c0 - hs;  // entries of the segment before the chunk
-  const bool is_heavy = hl > 64ULL * PM_HEAD;
+  const bool is_long = hl > 64ULL * PM_HEAD && hl <= (u64)PM_LOOP_MAX && !no_long;
+  const bool is_heavy = hl > 64ULL * PM_HEAD && !is_long;
   seg_base[c] = (u32)lo;
-  head[c] = hl == 0 ? 0u : (is_heavy ? PM_HEAVY : (u32)hl);
+  head[c] = hl == 0 ? 0u : (is_heavy ? PM_HEAVY : (is_long ? (PM_LONG | (u32)hl) : (u32)hl));
   const bool fix = is_heavy && se <= c1;
   fix_first[c] = fix ? (u32)(hs / chunk) : PM_NONE;
   if (fix) atomicAdd(n_fix, 1u);
@@ -2138,21 +2336,43 @@ __device__ __forceinline__ u32 cc_find(u32* parent, u32 x) {
   }
   return x;
 }
+__device__ __forceinline__ void cc_union_pair(u32* parent, u32 x, u32 y) {
+  u32 r0 = cc_find(parent, x), r1 = cc_find(parent, y);
+  while (r0 != r1) {
+    const bool first_hi = r0 > r1;
+    const u32 hi = first_hi ? r0 : r1, lo = first_hi ? r1 : r0;
+    const u32 old = atomicCAS(parent + hi, hi, lo);
+    if (old == hi) break;                          // hooked: hi was a root, lo is a node of the other tree (parent < child still holds)
+    if (first_hi) r0 = old; else r1 = old;         // hi has a parent by now: go on from it
+  }
+}
+// one thread per row; a row of more than 64 transcripts (repeat-family and poly-A classes hold thousands: one thread walking such a row
+// was 1.3 ms of the kernel on the stress workload) is taken by the whole wavefront afterwards, 64 members per trip -- unions commute
 __global__ void k_cc_union(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, u32* parent) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_ecs) return;
-  const u64 a = ec_off[e], b = ec_off[e + 1];
-  if (b - a < 2) return;
-  u32 r0 = cc_find(parent, ec_ids[a]);
-  for (u64 j = a + 1; j < b; j++) {
-    u32 r1 = cc_find(parent, ec_ids[j]);
-    while (r0 != r1) {
-      const bool first_hi = r0 > r1;
-      const u32 hi = first_hi ? r0 : r1, lo = first_hi ? r1 : r0;
-      const u32 old = atomicCAS(parent + hi, hi, lo);
-      if (old == hi) { r0 = lo; break; }          // hooked: hi was a root, lo is a node of the other tree (parent < child still holds)
-      if (first_hi) r0 = old; else r1 = old;       // hi has a parent by now: go on from it
+  u64 a = 0, b = 0;
+  if (e < n_ecs) { a = ec_off[e]; b = ec_off[e + 1]; }
+  const bool longrow = b - a > 64;
+  if (b - a >= 2 && !longrow) {
+    u32 r0 = cc_find(parent, ec_ids[a]);
+    for (u64 j = a + 1; j < b; j++) {
+      u32 r1 = cc_find(parent, ec_ids[j]);
+      while (r0 != r1) {
+        const bool first_hi = r0 > r1;
+        const u32 hi = first_hi ? r0 : r1, lo = first_hi ? r1 : r0;
+        const u32 old = atomicCAS(parent + hi, hi, lo);
+        if (old == hi) { r0 = lo; break; }          // hooked: hi was a root, lo is a node of the other tree (parent < child still holds)
+        if (first_hi) r0 = old; else r1 = old;       // hi has a parent by now: go on from it
+      }
     }
+  }
+  u64 m = __ballot(longrow);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const u64 ra = shfl_u64(a, src), rb = shfl_u64(b, src);
+    const u32 t0 = ec_ids[ra];
+    for (u64 j = ra + 1 + (u64)lane_id(); j < rb; j += 64) cc_union_pair(parent, t0, ec_ids[j]);
   }
 }
 __global__ void k_cc_flatten(u32* label, u64 n) {   // label[t] <- root of t (behind the kernel boundary plain loads see everything)
@@ -2218,7 +2438,8 @@ struct kamd_ctx {
   std::vector<void*> index_allocs;
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
-  DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums, tup_bound, tup_off;
+  DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums, tup_bound, tup_off, tup_big;
+  u64 last_fin_big = 0;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
@@ -2270,6 +2491,8 @@ struct kamd_ctx {
   hipEvent_t hy_ev_sell = nullptr, hy_ev_giant = nullptr;
   uint64_t last_em_max_comp_nnz = 0, last_em_giant_nnz = 0, last_em_giant_rows = 0, last_em_giant_tr = 0;
   uint32_t last_em_giant_chunks = 0; int last_em_giant_cus = 0; float last_em_plan_ms = 0.f;
+  const uint32_t* labels_override = nullptr;   // em_local_setup_device takes these component labels instead of computing them (the hybrid's sub-matrix: same components)
+  bool em_prefer_hybrid = false;               // the last matrix of this context needed the hybrid: the next plan starts there
   uint64_t overflow_total = 0; float overflow_ms = 0.f; hipEvent_t ev_ov0 = nullptr, ev_ov1 = nullptr;   // since kamd_ec_reset: items of the overflow kernel, its time
   int items_per_wave = 1024, refill_min = 8;   // (copies of tune.*, see apply_tuning)
   kamd_tuning tune{};
@@ -2605,7 +2828,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->sell_cache) sell_cache_free(c->sell_cache);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
-                  &c->retry, &c->ttable, &c->tstore, &c->stats_a, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->clist, &c->sizes, &c->explicit_items,
+                  &c->retry, &c->ttable, &c->tstore, &c->stats_a, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->tup_big, &c->clist, &c->sizes, &c->explicit_items,
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
@@ -2672,7 +2895,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(c->n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f;
+  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f; c->overflow_total = 0; c->overflow_ms = 0.f;
   if (int rc = tuples_clear(c)) return rc;
   HIPC(hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream));
   c->had_overflow_items = false;
@@ -3290,14 +3513,15 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   DevState* dst = (DevState*)c->state.p;
   const u64 n_t = c->n_distinct_tuples;   // (the batches' tuple records were absorbed as they came: absorb_tuples)
   // size bound of the candidate stream
-  c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0;
+  c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0; c->host_state.n_big = 0;
   if (int rc = push_state(c)) return rc;
   hipLaunchKernelGGL(k_bound_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(), dst);
   if (int rc = c->tup_bound.ensure((n_t + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->tup_off.ensure((n_t + 2) * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->tup_big.ensure((n_t + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (n_t) {
     hipLaunchKernelGGL(k_bound_tuples, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
-                       c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_bound.as<u32>(), dst);
+                       c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_bound.as<u32>(), c->tup_big.as<u32>(), dst);
     if (int rc = exclusive_scan(c, c->tup_bound.as<u32>(), n_t, c->tup_off.as<u64>(), c->tup_off.as<u64>() + n_t)) return rc;
   }
   HIPC(hipGetLastError());
@@ -3320,9 +3544,17 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
     hipLaunchKernelGGL(k_resolve_union, dim3(grid_for(n_t, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
                        c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
                        cand_key, big ? c->overflow_scratch.as<u32>() : nullptr, dst);
-  } else if (n_t) hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
-                              c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
-                              cand_key, dst);
+  } else if (n_t) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_t * RES_LANES, RES_BLOCK)), dim3(RES_BLOCK), 0, c->stream, c->ix, c->tstore.as<u32>(),
+                       c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
+                       cand_key, dst);
+    // the tuples whose smallest set is large (k_bound_tuples listed them): one wavefront each, the intersection out of LDS
+    const u64 n_big = c->host_state.n_big;
+    if (n_big) hipLaunchKernelGGL(k_resolve_big, dim3(grid_for(n_big, RB_WAVES)), dim3(64 * RB_WAVES), 0, c->stream, c->ix, c->tstore.as<u32>(),
+                                  c->ttable.as<TSlot>(), c->list.as<u64>(), c->tup_big.as<u32>(), n_big, c->tup_off.as<u64>(), c->cand.as<u32>(),
+                                  c->cand_off.as<u64>(), cand_key, dst);
+    c->last_fin_big = n_big;
+  }
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
   // the tuples' slots and record numbers follow what k_cand_singles allocated
@@ -3629,7 +3861,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
     d.lane_word = lw;
     hipLaunchKernelGGL(k_pm_lanes, dim3(grid_for(n_chunks, PM_BLOCK / 64)), dim3(PM_BLOCK), 0, c->stream, d.stream, chunk / 64, n_chunks, lw);
     hipLaunchKernelGGL(k_pm_chunks, dim3(grid_for(n_chunks, BLOCK)), dim3(BLOCK), 0, c->stream, s == 0 ? roff : coff, s == 0 ? R : M, NZ, chunk,
-                       n_chunks, sb, hd, ff, (u32*)(b2 + o_nfix) + s, (u32*)(b2 + o_nfix) + 2);
+                       n_chunks, sb, hd, ff, (u32*)(b2 + o_nfix) + s, (u32*)(b2 + o_nfix) + 2, getenv("KAMD_EM_NO_LONG_HEADS") ? 1 : 0);
   }
   HIPC(hipGetLastError());
   PmArgs& A = P->args;
@@ -4531,7 +4763,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   // component labels (smallest transcript id of the component): one lock-free union-find pass, cc_labels
   if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
   if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
-  if (int rc = cc_labels(c, d_ec_off, d_ec_ids, n_ecs, T)) return rc;
+  if (!c->labels_override) if (int rc = cc_labels(c, d_ec_off, d_ec_ids, n_ecs, T)) return rc;
   // scratch: per transcript / per root ...
   Carver t1;
   const size_t o_inm = t1.take(T + 8), o_sall = t1.take(T * 8 + 8), o_cn = t1.take(T * 4 + 8), o_cr = t1.take(T * 4 + 8), o_ct = t1.take(T * 4 + 8);
@@ -4547,7 +4779,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   HIPC(hipMemcpyAsync(tb + o_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
   L::BuildArgs A{};
   A.ec_off = (const uint64_t*)d_ec_off; A.ec_ids = d_ec_ids; A.counts = d_counts; A.wcounts = d_wcounts; A.n_ecs = n_ecs;
-  A.eff = (const double*)(tb + o_eff); A.T = T; A.label = c->pt_label.as<u32>(); A.target_nnz = std::max<u64>(1, target);
+  A.eff = (const double*)(tb + o_eff); A.T = T; A.label = c->labels_override ? c->labels_override : c->pt_label.as<u32>(); A.target_nnz = std::max<u64>(1, target);
   A.in_multi = (uint8_t*)(tb + o_inm); A.single_all = (double*)(tb + o_sall); A.c_nnz = (u32*)(tb + o_cn); A.c_rows = (u32*)(tb + o_cr);
   A.c_tr = (u32*)(tb + o_ct); A.cum_nnz = (const uint64_t*)(tb + o_cum); A.local_of = (u32*)(tb + o_loc); A.row_new = (u32*)(tb + o_rnew);
   hipLaunchKernelGGL(k_eml_step<0>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
@@ -4724,20 +4956,17 @@ __global__ void k_sell_refresh(const u64* __restrict__ ec_off, const u32* __rest
 // bodies are the streamed form's (pm_wave_load / pm_wave_pass / pm_fix); only the loop control differs: no EmState, the round's
 // vectors are kernel arguments, and what changes from chunk to chunk sits in a descriptor in device memory so that the 64 rounds of
 // a chunk are ONE hipGraph replayed for every chunk (4 launches per round at 3.5 us of host time each would otherwise bind the host).
-struct GiDesc { const int* prev_hist; int prev_n, prev_base, min_rounds, pad; int* hist; };
-__global__ void k_gi_set_desc(GiDesc* d, GiDesc v) { if (threadIdx.x == 0) *d = v; }
-__device__ __forceinline__ bool gi_stopped(const GiDesc* d, int* s_flag) {
-  if (threadIdx.x < 64) {
-    const int i = (int)threadIdx.x;
-    const int* ph = d->prev_hist;
-    bool stop = false;
-    if (ph) { const int n = d->prev_n; const int h = i < n ? ph[i] : 1; stop = i < n && h == 0 && d->prev_base + i > d->min_rounds; }   // :202-205
-    const u64 m = __ballot(stop);
-    if (i == 0) *s_flag = m != 0;
-  }
-  __syncthreads();
-  return *s_flag != 0;
+struct GiDesc { int* hist; int stopped; int pad; };   // this chunk's per-round change counts (null: not wanted); the run stopped in the previous chunk
+// one launch in front of a chunk: where its change counts go, and the stop rule of EMAlgorithm::run (:202-205) on the counts of the PREVIOUS
+// chunk, evaluated ONCE here -- every kernel of the chunk then reads one word (a chunk queued behind the one the run stops in does nothing)
+__global__ void k_gi_set_desc(GiDesc* d, EmsPrev prev, int* hist) {
+  const int i = (int)threadIdx.x;
+  bool stop = false;
+  if (prev.hist && i < 64) { const int h = i < prev.n ? prev.hist[i] : 1; stop = i < prev.n && h == 0 && prev.base + i > prev.min_rounds; }
+  const u64 m = __ballot(stop);
+  if (i == 0) { d->hist = hist; d->stopped = m != 0 ? 1 : 0; d->pad = 0; }
 }
+__device__ __forceinline__ bool gi_stopped(const GiDesc* d, int*) { return d->stopped != 0; }
 struct GiColEmit {   // PmColEmit without the clamped copy (the final round's clamp is a pass of its own, k_gi_clamp)
   const double* alpha_cur; const double* a_cur; const double* single; const double* eff; double* alpha_nx; double* a_nx; int* ch; int clamp;
   struct Ctx { double al, at, sg, ef; };
@@ -4881,8 +5110,7 @@ void gi_enqueue_rounds(const GiantPart& G, hipStream_t s, int n, int clamp, int 
 }
 // one chunk on the oversized components' stream (the caller has made that stream wait for the context stream and joins it afterwards)
 int gi_launch_chunk(GiantPart& G, int n, int clamp, int pin, int pout, int* d_h, const EmsPrev& prev) {
-  const GiDesc v{prev.hist, prev.n, prev.base, prev.min_rounds, 0, d_h};
-  hipLaunchKernelGGL(k_gi_set_desc, dim3(1), dim3(64), 0, G.stream, G.desc, v);
+  hipLaunchKernelGGL(k_gi_set_desc, dim3(1), dim3(64), 0, G.stream, G.desc, prev, d_h);
   if (G.use_graph && n == EML_MAX_ROUNDS && !clamp && pin != pout) {
     if (!G.gexec[pin]) {
       HIPC(hipStreamBeginCapture(G.stream, hipStreamCaptureModeThreadLocal));
@@ -5003,10 +5231,11 @@ struct EmSellGpu {
 int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
   Carver sv;
   // the two alpha vectors (and the two a vectors) lie back to back: a ping-pong pair, and one copy brings both to the host
-  const size_t o_al = sv.take(2 * M * 8 + 8), o_a = sv.take(2 * M * 8 + 8), o_h = sv.take((size_t)hist_ints * 4 + 8), o_out = sv.take(2 * T_out * 8 + 8);
+  const u64 Mp = M ? M : 1;   // (a plan without groups -- the hybrid with everything on its streamed side -- still has two distinct halves: gi_par tells them apart)
+  const size_t o_al = sv.take(2 * Mp * 8 + 8), o_a = sv.take(2 * Mp * 8 + 8), o_h = sv.take((size_t)hist_ints * 4 + 8), o_out = sv.take(2 * T_out * 8 + 8);
   if (int rc = c->pm_b.ensure(sv.off, 0, c->stream)) return rc;
   char* sb = (char*)c->pm_b.p;
-  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = d_alpha + M; d_ck_a = d_a + M; d_hist = (int*)(sb + o_h); d_out = (double*)(sb + o_out);
+  d_alpha = (double*)(sb + o_al); d_a = (double*)(sb + o_a); d_ck_alpha = d_alpha + Mp; d_ck_a = d_a + Mp; d_hist = (int*)(sb + o_h); d_out = (double*)(sb + o_out);
   if (M) hipLaunchKernelGGL(k_eml_init, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, d_alpha, d_a, d_eff_new, M, 1.0 / (double)P.T);
   HIPC(hipGetLastError());
   lds = (size_t)P.max_group_bytes;
@@ -5283,9 +5512,24 @@ void sell_cache_free(SellCache* k) { delete k; }
 // ---- hybrid plan: split the matrix by component size, the LDS form on what fits, the streamed layout on the rest ---------------------
 __global__ void k_hy_comp_nnz(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ label, u32* c_nnz) {
   const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_ecs) return;
-  const u64 a = ec_off[e], b = ec_off[e + 1];
-  if (b - a >= 2) atomicAdd(&c_nnz[label[ec_ids[a]]], (u32)(b - a));
+  u32 root = 0xFFFFFFFFu, len = 0;
+  if (e < n_ecs) {
+    const u64 a = ec_off[e], b = ec_off[e + 1];
+    if (b - a >= 2) { root = label[ec_ids[a]]; len = (u32)(b - a); }
+  }
+  // the rows of one oversized component are tens of thousands of adds to ONE address (~12 ns each at the memory side): the lanes of a
+  // wavefront that share the leader's component add once; the others (gene-sized components: all different) take the plain atomic
+  const bool act = len != 0;
+  const u64 am = __ballot(act);
+  if (!am) return;
+  const int leader = __ffsll((long long)am) - 1;
+  const u32 lroot = (u32)__shfl((int)root, leader, 64);
+  const bool with_leader = act && root == lroot;
+  u32 v = with_leader ? len : 0u;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += (u32)__shfl_down((int)v, d, 64);
+  if (lane_id() == 0 && v) atomicAdd(&c_nnz[lroot], v);
+  if (act && !with_leader) atomicAdd(&c_nnz[root], len);
 }
 // a row (singleton rows included: they are the constant term of a transcript of that component) goes with its component
 __global__ void k_hy_sizes(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u32* __restrict__ label,
@@ -5363,7 +5607,7 @@ int em_sell_plan_search(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, c
 }
 // 0 = K holds the hybrid plan (K.hybrid, K.G), 1 = not applicable, < 0 = error
 int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                    const double* eff_lens, u64 T, u64 lds_budget, SellCache& K) {
+                    const double* eff_lens, u64 T, u64 lds_budget, SellCache& K, bool first_try = false) {
   if (n_ecs == 0 || nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
   GiantPart& G = K.G;
   G.drop_graphs();
@@ -5388,7 +5632,18 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
   HIPC(hipMemsetAsync(c_nnz, 0, T * 4, c->stream));
   hipLaunchKernelGGL(k_hy_comp_nnz, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, label, c_nnz);
   HIPC(hipGetLastError());
+  {
+    CompStats cs{};
+    if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
+    HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(CompStats), c->stream));
+    hipLaunchKernelGGL(k_comp_stats, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c_nnz, (const u32*)nullptr, (const u32*)nullptr, T, (u32*)c->pt_hist.p);
+    HIPC(hipMemcpyAsync(&cs, c->pt_hist.p, sizeof(CompStats), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    c->last_em_max_comp_nnz = cs.max_nnz;
+    if (cs.max_nnz == 0) return 1;
+  }
   u32 lim = c->tune.em_giant_nnz > 0 ? (u32)c->tune.em_giant_nnz : 6000u;
+  if (c->last_em_max_comp_nnz <= lim && first_try) return 1;   // (asked first because the last matrix needed it: this one has nothing oversized at the first limit)
   for (int attempt = 0; attempt < 4; attempt++, lim = std::max(lim / 2, 8u)) {
     hipLaunchKernelGGL(k_hy_sizes, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_ec_off, d_ec_ids, n_ecs, label, c_nnz, lim,
                        flag_s, len_s, flag_g, len_g);
@@ -5419,7 +5674,9 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     const int sell_cus = c->hy_sell_cus > 0 ? c->hy_sell_cus : c->n_cus;
     // the side that fits: the component-local plan over its rows (groups sized for the compute units it gets)
     CompStats cst{};
+    c->labels_override = label;   // (the components of the side that fits are components of the whole matrix)
     int prc = n_s ? em_sell_plan_search(c, off_s, ids_s, cnt_s, wc_s, n_s, nnz_s, eff_lens, T, lds_budget, sell_cus, false, K, &cst) : 1;
+    c->labels_override = nullptr;
     if (prc < 0) return prc;
     if (prc == 1 && cst.max_nnz == 0) {
       // no row with two transcripts on that side: a plan without groups -- its transcripts keep their singleton counts
@@ -5519,12 +5776,21 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       K.dev = EmSellDev{};
       prc = 0;
     } else {
-      CompStats cst{};
-      prc = em_sell_plan_search(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, c->n_cus, multi, K, &cst);
-      c->last_em_max_comp_nnz = cst.max_nnz;
-      if (prc == 1 && !multi && c->tune.em_hybrid != 2 && cst.max_nnz > 0) {
-        prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K);
-        if (prc == 1) K.hybrid = false;
+      const bool may_hybrid = !multi && c->tune.em_hybrid != 2 && n_ecs > 0;
+      if (may_hybrid && c->em_prefer_hybrid) {   // the context's last matrix needed the hybrid (bootstrap replicates, the steps of a bench): start there
+        prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K, true);
+        if (prc < 0) return prc;
+        if (prc == 1) { K.hybrid = false; c->em_prefer_hybrid = false; }
+      }
+      if (prc == 1) {
+        CompStats cst{};
+        prc = em_sell_plan_search(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, c->n_cus, multi, K, &cst);
+        c->last_em_max_comp_nnz = cst.max_nnz;
+        if (prc == 1 && may_hybrid && cst.max_nnz > 0) {
+          prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K);
+          if (prc == 1) K.hybrid = false;
+          else if (prc == 0) c->em_prefer_hybrid = true;
+        }
       }
     }
     if (prc < 0) return prc;

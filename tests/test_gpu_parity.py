@@ -268,8 +268,8 @@ def _hybrid_csr(n_genes, seed, n_chained=500):
 
 
 @pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
-                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8"])
-def test_em_forms_agree_with_oracle(k, ka):
+                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix"])
+def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
     with more segment ends than LDS slots, forced), the CSR form, and the component-local LDS form (workgroup sizes, split length) on a matrix
@@ -279,6 +279,12 @@ def test_em_forms_agree_with_oracle(k, ka):
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
+    if isinstance(k, str) and k.endswith("_fix"):
+        # rows / columns that cross into a chunk with more than 256 entries are re-read by the chunk in a loop (round 5); the fix-up launches
+        # they needed before remain for segments beyond 32 768 entries -- forced here for all of them
+        monkeypatch.setenv("KAMD_EM_NO_LONG_HEADS", "1")
+        k = k[:-4]
+        k = int(k) if k.isdigit() else k
     if isinstance(k, str) and k.startswith("local"):
         off, ids, cnt, eff, T = _gene_csr(300, 7)
         # (blocks of 256 lanes = 4 wavefronts on groups of a dozen slices: most slices take the LDS path of the register-resident kernel,
