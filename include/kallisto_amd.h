@@ -162,8 +162,9 @@ typedef struct {
                                   components that fit keep the LDS form, the oversized ones are iterated BESIDE it by streamed kernels (two
                                   launches per round over flagged entry streams in HBM, on compute units of their own), one stop rule over
                                   both; 2 = off: such a matrix takes the streamed form as a whole (rounds 1-4) */
-  int32_t em_giant_cus;        /* hybrid: compute units reserved for the streamed kernels (CU masks of the two streams); -1 (default) = in
-                                  proportion to the oversized components' share of the entries, 32..192; 0 in kamd_ctx_tune = keep */
+  int32_t em_giant_cus;        /* hybrid: compute units reserved for the streamed kernels (a CU mask keeps k_em_sell's stream off them); -1 (default) =
+                                  none, the two forms share the chip (measured faster: the streamed side is the critical path and finds free units
+                                  once the groups' launch of a chunk has drained); 0 in kamd_ctx_tune = keep */
   int32_t em_giant_nnz;        /* hybrid: a component with more entries than this is "oversized"; -1 (default) = 6000, halved while the
                                   remaining components still do not fit their groups */
 } kamd_tuning;

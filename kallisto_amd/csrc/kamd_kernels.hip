@@ -95,7 +95,7 @@ struct DevState {
   u64 exp_words, exp_recs;       // explicit transcript-set stream
   u64 cand_words, cand_recs;     // candidate transcript-set stream
   u64 tl_n, ts_words, tl_fail;   // distinct tuples so far (entries of the tuple list), words of the tuple store, records of a batch that found no slot
-  u64 n_big;                     // kamd_ec_finalize: distinct tuples whose smallest set has more than RES_LANES members (k_resolve_big's work list)
+  u64 n_big, n_huge;             // kamd_ec_finalize: distinct tuples whose smallest set has 17 .. 1024 / more than 1024 members (k_resolve_big's work lists)
 };
 
 // counters of kernel A (their own struct: chunks of kernel A run on one stream while another copies DevState to and fro)
@@ -837,7 +837,7 @@ __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, cons
                                u32* per_tuple, u32* big_idx, DevState* st) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 b = 0;
-  bool big = false;
+  bool big = false, huge = false;
   if (i < n) {
     const u64 off = list[i] >> 32;   // (the record's place in the store rides in the list entry: k_tup_store)
     const u32 m = stream[off + 1];
@@ -845,16 +845,23 @@ __global__ void k_bound_tuples(DevIndex ix, const u32* __restrict__ stream, cons
     b = kamd::set_size_bound(stt, stream + off + 2, (int)m, ix.union_mode != 0) + 2;   // smallest set / sum of the sets (--union)
     per_tuple[i] = (u32)b;   // the tuple's slot in the candidate stream (k_resolve writes there: no allocation at run time)
     big = big_idx && !ix.union_mode && b - 2 > RES_BIG_MIN;
+    huge = big && b - 2 > 1024;   // (= RB_CAND_BIG)
   }
   b = wave_sum64(b);
   if (lane_id() == 0 && b) atomicAdd(&st->bound_words, b);
-  // the work list of k_resolve_big: one atomic per wavefront
-  const u64 bm = __ballot(big);
+  // the work lists of k_resolve_big (the second one grows from the end of the same array): one atomic per wavefront and list
+  const u64 bm = __ballot(big && !huge), hm = __ballot(huge);
   if (bm) {
     u64 base = 0;
     if (lane_id() == 0) base = atomicAdd(&st->n_big, (u64)__popcll(bm));
-    base = ((u64)__shfl((int)(base >> 32), 0, 64) << 32) | (u32)__shfl((int)base, 0, 64);
-    if (big) big_idx[base + __popcll(bm & ((1ULL << lane_id()) - 1ULL))] = (u32)i;
+    base = shfl_u64(base, 0);
+    if (big && !huge) big_idx[base + __popcll(bm & ((1ULL << lane_id()) - 1ULL))] = (u32)i;
+  }
+  if (hm) {
+    u64 base = 0;
+    if (lane_id() == 0) base = atomicAdd(&st->n_huge, (u64)__popcll(hm));
+    base = shfl_u64(base, 0);
+    if (huge) big_idx[n - 1 - (base + __popcll(hm & ((1ULL << lane_id()) - 1ULL)))] = (u32)i;
   }
 }
 __global__ void k_bound_singles(DevIndex ix, const u32* __restrict__ dense, DevState* st) {
@@ -868,20 +875,52 @@ __global__ void k_bound_singles(DevIndex ix, const u32* __restrict__ dense, DevS
 __global__ void k_cand_singles(DevIndex ix, const u32* __restrict__ dense, const u64* __restrict__ dense_first, u32* cand,
                                u64* cand_off, u64* cand_key, DevState* st) {
   u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ix.n_ecs || dense[e] == 0) return;
-  const u32* ids = ix.ec_ids + ix.ec_off[e];
-  const u32 n = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]);
-  u32 keep = 0;
-  for (u32 j = 0; j < n; j++) keep += onlisted(ix.onlist_bits, ids[j]);
-  if (keep == 0) return;
-  u64 off = atomicAdd(&st->cand_words, (u64)keep + 2);
-  u64 r = atomicAdd(&st->cand_recs, 1ULL);
-  u32* w = cand + off;
-  w[0] = dense[e]; w[1] = keep;
-  u32 o = 0;
-  for (u32 j = 0; j < n; j++) if (onlisted(ix.onlist_bits, ids[j])) w[2 + o++] = ids[j];
-  cand_off[r] = off;
-  if (cand_key) cand_key[r] = dense_first[e];
+  const bool have = e < ix.n_ecs && dense[e] != 0;
+  const u32* ids = nullptr; u32 n = 0;
+  if (have) { ids = ix.ec_ids + ix.ec_off[e]; n = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]); }
+  const bool longset = n > 64;
+  if (have && !longset) {
+    u32 keep = 0;
+    for (u32 j = 0; j < n; j++) keep += onlisted(ix.onlist_bits, ids[j]);
+    if (keep) {
+      u64 off = atomicAdd(&st->cand_words, (u64)keep + 2);
+      u64 r = atomicAdd(&st->cand_recs, 1ULL);
+      u32* w = cand + off;
+      w[0] = dense[e]; w[1] = keep;
+      u32 o = 0;
+      for (u32 j = 0; j < n; j++) if (onlisted(ix.onlist_bits, ids[j])) w[2 + o++] = ids[j];
+      cand_off[r] = off;
+      if (cand_key) cand_key[r] = dense_first[e];
+    }
+  }
+  // sets of more than 64 transcripts (thousands: poly-A and repeat-family classes) are copied by the whole wavefront
+  u64 m = __ballot(longset);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const u64 se = shfl_u64(e, src);
+    const u32* sid = ix.ec_ids + ix.ec_off[se];
+    const u32 sn = (u32)__shfl((int)n, src, 64);
+    u32 keep = 0;
+    for (u32 j = lane_id(); j < sn; j += 64) keep += onlisted(ix.onlist_bits, sid[j]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) keep += (u32)__shfl_xor((int)keep, d, 64);
+    if (keep == 0) continue;
+    u64 off = 0, r = 0;
+    if (lane_id() == 0) { off = atomicAdd(&st->cand_words, (u64)keep + 2); r = atomicAdd(&st->cand_recs, 1ULL); }
+    off = shfl_u64(off, 0); r = shfl_u64(r, 0);
+    u32* w = cand + off;
+    if (lane_id() == 0) { w[0] = dense[se]; w[1] = keep; cand_off[r] = off; if (cand_key) cand_key[r] = dense_first[se]; }
+    u32 o = 0;
+    for (u32 j0 = 0; j0 < sn; j0 += 64) {
+      const u32 j = j0 + lane_id();
+      const u32 x = j < sn ? sid[j] : 0u;
+      const bool ok = j < sn && onlisted(ix.onlist_bits, x);
+      const u64 bm = __ballot(ok);
+      if (ok) w[2 + o + __popcll(bm & ((1ULL << lane_id()) - 1ULL))] = x;
+      o += (u32)__popcll(bm);
+    }
+  }
 }
 // (b) one 16-lane group per distinct tuple (4 tuples per wavefront): intersect the m sorted sets; 16 candidates of the
 //     smallest set per step, membership by binary search in the others, survivors compacted with ballot + popcount
@@ -1012,35 +1051,48 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
 // (coalesced, independent loads) and the survivors are looked up in the tile by binary search IN LDS -- both lists are sorted, so only the
 // survivors inside the tile's id range are looked at -- then compacted; once 64 or fewer survive they are searched in the remaining
 // sets directly.  Global traffic is the sum of the sets' sizes, read once, instead of a dependent chain per candidate.
-constexpr int RB_WAVES = 4, RB_CAND = 4096, RB_TILE = 1024;
+constexpr int RB_WAVES = 4, RB_TILE = 1024, RB_MAXSETS = 256;
+constexpr u32 RB_CAND_BIG = 1024, RB_CAND_HUGE = 4096;   // two launches: smallest set of 17..1024 members (8 KB of LDS per wavefront: 20 wavefronts per CU), of more
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+template <int CAND>
 __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, const u32* __restrict__ stream, const TSlot* table, const u64* list,
                                                                const u32* __restrict__ big_idx, u64 n_big, const u64* __restrict__ slot_off, u32* cand,
                                                                u64* cand_off, u64* cand_key, const DevState* st) {
-  __shared__ u32 s_cand_all[RB_WAVES][RB_CAND];
+  __shared__ u32 s_cand_all[RB_WAVES][CAND];
   __shared__ u32 s_tile_all[RB_WAVES][RB_TILE];
+  __shared__ u32 s_meta_all[RB_WAVES][3 * RB_MAXSETS];   // offsets (two words) and sizes of the tuple's sets; size 0xFFFFFFFF = taken
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const u64 bi = (u64)blockIdx.x * RB_WAVES + w;
   if (bi >= n_big) return;
   u32* s_cand = s_cand_all[w];
   u32* s_tile = s_tile_all[w];
+  u32* s_off = s_meta_all[w];
+  u32* s_offh = s_off + RB_MAXSETS;
+  u32* s_sz = s_off + 2 * RB_MAXSETS;
   const u64 base_words = st->cand_words, base_recs = st->cand_recs;
   const u64 gid = big_idx[bi];
   const u64 le = list[gid];
   const u64 owner = le >> 32;
   const u32 m = stream[owner + 1];
   const u32* es = stream + owner + 2;
-  // the smallest set (first wins on ties, as in k_resolve)
+  const u64 out_off = base_words + slot_off[gid];
+  u32 cnt = 0;
+  // offset and size of every set in one round of loads per 64 sets, kept in LDS (a pair whose mates run through a repeat or a poly-A
+  // stretch has more than a hundred distinct classes); tuples of more than RB_MAXSETS sets and smallest sets beyond the LDS buffer
+  // take the plain path below
+  const bool lds_meta = m <= (u32)RB_MAXSETS;
   u32 bsz = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
   for (u32 j = lane; j < m; j += 64) {
     const u32 e = es[j] & kamd::EC_ID_MASK;
-    const u32 sz = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]);
-    if (sz < bsz) { bsz = sz; bj = j; }
+    const u64 off = ix.ec_off[e];
+    const u32 sz = (u32)(ix.ec_off[e + 1] - off);
+    if (lds_meta) { s_off[j] = (u32)off; s_offh[j] = (u32)(off >> 32); s_sz[j] = sz; }
+    if (sz < bsz) { bsz = sz; bj = j; }   // (first wins on ties, as in k_resolve)
   }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1048,12 +1100,9 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
     if (s2 < bsz || (s2 == bsz && j2 < bj)) { bsz = s2; bj = j2; }
   }
   const u32 best = bj, nb = bsz;
-  const u32* base = ix.ec_ids + ix.ec_off[es[best] & kamd::EC_ID_MASK];
-  const u64 out_off = base_words + slot_off[gid];
-  u32 cnt = 0;
-  if (nb > (u32)RB_CAND) {
-    // beyond the LDS buffer (no index we built has such a set): 64 candidates per step, searched in global memory, written at once --
-    // the tuple's slot holds nb ids
+  if (!lds_meta || nb > (u32)CAND) {
+    // 64 candidates per step, searched in global memory, written at once (the tuple's slot holds nb ids)
+    const u32* base = ix.ec_ids + ix.ec_off[es[best] & kamd::EC_ID_MASK];
     for (u32 c0 = 0; c0 < nb; c0 += 64) {
       const u32 c = c0 + lane;
       bool ok = c < nb;
@@ -1069,6 +1118,10 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
       cnt += (u32)__popcll(bm);
     }
   } else {
+    wave_lds_sync();
+    const u32* base = ix.ec_ids + ((u64)s_off[best] | ((u64)s_offh[best] << 32));
+    wave_lds_sync();
+    if (lane == 0) s_sz[best] = 0xFFFFFFFFu;
     // the on-listed members of the smallest set, compacted into LDS
     for (u32 c0 = 0; c0 < nb; c0 += 64) {
       const u32 c = c0 + lane;
@@ -1079,20 +1132,27 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
       cnt += (u32)__popcll(bm);
     }
     wave_lds_sync();
-    u32 j = 0;
-    for (; j < m && cnt > 64; j++) {
-      if (j == best) continue;
-      const u32 e = es[j] & kamd::EC_ID_MASK;
-      const u32* B = ix.ec_ids + ix.ec_off[e];
-      const u32 nB = (u32)(ix.ec_off[e + 1] - ix.ec_off[e]);
-      // the set streams through LDS; bit 31 of a survivor marks "found in this set"
+    // while more than 64 survive: the smallest set not yet taken streams through LDS (both lists are sorted: only the survivors inside a
+    // tile's id range are looked up in it, by binary search in LDS); bit 31 of a survivor marks "found in this set"
+    while (cnt > 64) {
+      u32 ks = 0xFFFFFFFFu, kj = 0xFFFFFFFFu;
+      for (u32 j = lane; j < m; j += 64) { const u32 sz = s_sz[j]; if (sz < ks) { ks = sz; kj = j; } }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u32 s2 = __shfl_xor(ks, d, 64), j2 = __shfl_xor(kj, d, 64);
+        if (s2 < ks || (s2 == ks && j2 < kj)) { ks = s2; kj = j2; }
+      }
+      if (ks == 0xFFFFFFFFu) break;   // every set taken
+      const u32* B = ix.ec_ids + ((u64)s_off[kj] | ((u64)s_offh[kj] << 32));
+      const u32 nB = ks;
+      wave_lds_sync();
+      if (lane == 0) s_sz[kj] = 0xFFFFFFFFu;
       u32 a = 0;   // survivors below a are smaller than everything still to come of B
       for (u32 t0 = 0; t0 < nB && a < cnt; t0 += RB_TILE) {
         const u32 tn = min((u32)RB_TILE, nB - t0);
         for (u32 i = lane; i < tn; i += 64) s_tile[i] = B[t0 + i];
         wave_lds_sync();
         const u32 lo_v = s_tile[0], hi_v = s_tile[tn - 1];
-        // survivors in [lo_v, hi_v]: [a2, b2) (uniform searches over the sorted survivors; LDS broadcast reads)
         u32 l = a, h = cnt;
         while (l < h) { const u32 mid = (l + h) >> 1; if ((s_cand[mid] & 0x7FFFFFFFu) < lo_v) l = mid + 1; else h = mid; }
         const u32 a2 = l;
@@ -1122,31 +1182,35 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
       }
       cnt = kept;
     }
-    // 64 or fewer survivors and sets j .. m - 1 still to go: all (survivor, set) pairs at once -- one binary search in global memory per
-    // lane and round instead of one round per set (a read that pseudoaligns collapses to a handful of transcripts after the first
-    // intersection: taking the remaining 6-15 sets one after the other was a chain of 60-150 dependent reads per tuple)
-    if (cnt && j < m) {
-      const u32 R = (m - j) - ((best >= j) ? 1u : 0u);
-      if (R) {
-        if ((u32)lane < 64u) s_tile[lane] = 0u;   // dead flags of the survivors
-        wave_lds_sync();
-        const u32 P = cnt * R;
-        for (u32 p = lane; p < P; p += 64) {
-          const u32 ci = p % cnt, r = p / cnt;
-          u32 jr = j + r;
-          if (best >= j && jr >= best) ++jr;
-          const u32 e = es[jr] & kamd::EC_ID_MASK;
-          if (!set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), s_cand[ci])) s_tile[ci] = 1u;
-        }
-        wave_lds_sync();
-        const u32 x = (u32)lane < cnt ? s_cand[lane] : 0u;
-        const bool ok = (u32)lane < cnt && s_tile[lane] == 0u;
-        const u64 bm = __ballot(ok);
-        wave_lds_sync();
-        if (ok) s_cand[__popcll(bm & ((1ULL << lane) - 1ULL))] = x;
-        cnt = (u32)__popcll(bm);
-        wave_lds_sync();
+    // 64 or fewer survivors: all (survivor, remaining set) pairs at once -- one binary search in global memory per lane and round
+    // instead of one round per set (a read that pseudoaligns collapses to a handful of transcripts after the first intersection:
+    // taking the remaining sets one after the other was a chain of a dozen dependent reads per set and tuple)
+    wave_lds_sync();
+    u32 R = 0;
+    for (u32 j0 = 0; j0 < m; j0 += 64) {   // the sets not yet taken, compacted behind the survivors' dead flags
+      const u32 j = j0 + lane;
+      const bool open = j < m && s_sz[j] != 0xFFFFFFFFu;
+      const u64 bm = __ballot(open);
+      if (open) s_tile[64 + R + __popcll(bm & ((1ULL << lane) - 1ULL))] = j;
+      R += (u32)__popcll(bm);
+    }
+    if (cnt && R) {
+      s_tile[lane] = 0u;   // dead flags of the survivors
+      wave_lds_sync();
+      const u32 P = cnt * R;
+      for (u32 p = lane; p < P; p += 64) {
+        const u32 ci = p % cnt, jr = s_tile[64 + p / cnt];
+        const u64 off = (u64)s_off[jr] | ((u64)s_offh[jr] << 32);
+        if (!set_contains(ix.ec_ids + off, s_sz[jr], s_cand[ci])) s_tile[ci] = 1u;
       }
+      wave_lds_sync();
+      const u32 x = (u32)lane < cnt ? s_cand[lane] : 0u;
+      const bool ok = (u32)lane < cnt && s_tile[lane] == 0u;
+      const u64 bm = __ballot(ok);
+      wave_lds_sync();
+      if (ok) s_cand[__popcll(bm & ((1ULL << lane) - 1ULL))] = x;
+      cnt = (u32)__popcll(bm);
+      wave_lds_sync();
     }
     for (u32 i = lane; i < cnt; i += 64) cand[out_off + 2 + i] = s_cand[i];
   }
@@ -3513,7 +3577,7 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
   DevState* dst = (DevState*)c->state.p;
   const u64 n_t = c->n_distinct_tuples;   // (the batches' tuple records were absorbed as they came: absorb_tuples)
   // size bound of the candidate stream
-  c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0; c->host_state.n_big = 0;
+  c->host_state.bound_words = 0; c->host_state.cand_words = 0; c->host_state.cand_recs = 0; c->host_state.n_big = 0; c->host_state.n_huge = 0;
   if (int rc = push_state(c)) return rc;
   hipLaunchKernelGGL(k_bound_singles, dim3(grid_for(c->n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, c->ix, c->dense.as<u32>(), dst);
   if (int rc = c->tup_bound.ensure((n_t + 1) * sizeof(u32), 0, c->stream)) return rc;
@@ -3549,11 +3613,16 @@ extern "C" int kamd_ec_finalize(kamd_ctx* c, kamd_ec_result* out) {
                        c->ttable.as<TSlot>(), c->list.as<u64>(), n_t, c->tup_off.as<u64>(), c->cand.as<u32>(), c->cand_off.as<u64>(),
                        cand_key, dst);
     // the tuples whose smallest set is large (k_bound_tuples listed them): one wavefront each, the intersection out of LDS
-    const u64 n_big = c->host_state.n_big;
-    if (n_big) hipLaunchKernelGGL(k_resolve_big, dim3(grid_for(n_big, RB_WAVES)), dim3(64 * RB_WAVES), 0, c->stream, c->ix, c->tstore.as<u32>(),
+    const u64 n_big = c->host_state.n_big, n_huge = c->host_state.n_huge;
+    if (n_big) hipLaunchKernelGGL(k_resolve_big<(int)RB_CAND_BIG>, dim3(grid_for(n_big, RB_WAVES)), dim3(64 * RB_WAVES), 0, c->stream, c->ix, c->tstore.as<u32>(),
                                   c->ttable.as<TSlot>(), c->list.as<u64>(), c->tup_big.as<u32>(), n_big, c->tup_off.as<u64>(), c->cand.as<u32>(),
                                   c->cand_off.as<u64>(), cand_key, dst);
-    c->last_fin_big = n_big;
+    if (n_huge) hipLaunchKernelGGL(k_resolve_big<(int)RB_CAND_HUGE>, dim3(grid_for(n_huge, RB_WAVES)), dim3(64 * RB_WAVES), 0, c->stream, c->ix, c->tstore.as<u32>(),
+                                   c->ttable.as<TSlot>(), c->list.as<u64>(), c->tup_big.as<u32>() + (n_t - n_huge), n_huge, c->tup_off.as<u64>(), c->cand.as<u32>(),
+                                   c->cand_off.as<u64>(), cand_key, dst);
+    c->last_fin_big = n_big + n_huge;
+    if (getenv("KAMD_DEBUG_FIN")) fprintf(stderr, "[kamd] finalize: %llu distinct tuples, smallest set 17..1024: %llu, beyond: %llu\n", (unsigned long long)n_t,
+                                          (unsigned long long)n_big, (unsigned long long)n_huge);
   }
   HIPC(hipGetLastError());
   if (int rc = sync_state(c)) return rc;
@@ -5667,10 +5736,15 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     HIPC(hipMemcpyAsync(off_g + n_g, zpos_g + n_ecs, 8, hipMemcpyDeviceToDevice, c->stream));
     HIPC(hipGetLastError());
     // compute units: the oversized side's share of the entries, 32 .. 192 of 256, a multiple of 8 (one unit more or less on every XCD)
-    int g_cus = c->tune.em_giant_cus > 0 ? c->tune.em_giant_cus : (int)((double)c->n_cus * (double)nnz_g / (double)std::max<u64>(nnz_s + nnz_g, 1) + 0.5);
-    g_cus = std::min(std::max(g_cus, c->n_cus / 8), c->n_cus * 3 / 4) / 8 * 8;
-    if (g_cus <= 0 || g_cus >= c->n_cus) g_cus = c->n_cus / 2;
-    if (int rc = hy_streams(c, c->n_cus - g_cus)) return rc;
+    // (measured on the stress workload, profiles/README.md round 5: the mask COSTS time -- 50.1 against 43.9 ms at 4 M pairs, 167 against 142 ms
+    // at 30 M: the streamed side is the critical path whatever the groups do, and its kernels find free units as soon as the groups' first
+    // launch of a chunk has drained -- so the default is no mask; em_giant_cus > 0 reserves that many units)
+    int g_cus = c->tune.em_giant_cus > 0 ? c->tune.em_giant_cus : 0;
+    if (g_cus > 0) {
+      g_cus = std::min(std::max(g_cus, c->n_cus / 8), c->n_cus * 3 / 4) / 8 * 8;
+      if (g_cus <= 0 || g_cus >= c->n_cus) g_cus = c->n_cus / 2;
+    }
+    if (int rc = hy_streams(c, g_cus > 0 ? c->n_cus - g_cus : 0)) return rc;
     const int sell_cus = c->hy_sell_cus > 0 ? c->hy_sell_cus : c->n_cus;
     // the side that fits: the component-local plan over its rows (groups sized for the compute units it gets)
     CompStats cst{};
@@ -5707,7 +5781,7 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_g, BLOCK)), dim3(BLOCK), 0, c->stream, off_g, ids_g, cnt_g, n_g, col_cnt, c->em_single.as<double>());
     if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
     G.plan = PmPlan{};
-    const int src = em_streamed_setup(c, off_g, ids_g, cnt_g, wc_g, n_g, T, col_cnt, col_fill, &G.plan, &c->hy_a, &c->hy_b, g_cus);
+    const int src = em_streamed_setup(c, off_g, ids_g, cnt_g, wc_g, n_g, T, col_cnt, col_fill, &G.plan, &c->hy_a, &c->hy_b, g_cus > 0 ? g_cus : 0);
     if (src < 0) return src;
     if (src != 0) return 1;
     const PmArgs& A = G.plan.args;
