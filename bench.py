@@ -704,7 +704,8 @@ def self_launch(n_gpus: int) -> int:
             print(f"bench.py: --gpus {n_gpus} but this node shows {have} GPU(s) (KAMD_BENCH_SHARE_GPU=1 puts all ranks on GPU 0 over gloo: a "
                   f"smoke test only)", file=sys.stderr)
             return 2
-    limit = float(os.environ.get("KAMD_BENCH_LAUNCH_TIMEOUT_S", "1500"))
+    # two attempts must fit the driver's 1 800 s: 700 s each by default (a full N-GPU line takes about 3 minutes on one GPU's worth of work per rank)
+    limit = float(os.environ.get("KAMD_BENCH_LAUNCH_TIMEOUT_S", "700"))
     attempts = [{}] if (share or os.environ.get("KAMD_COMM") == "callbacks") else [{}, {"KAMD_COMM": "callbacks"}]
     rc = 1
     for extra in attempts:
@@ -776,6 +777,8 @@ def main():
                     "beside the headline value, never as it")
     ap.add_argument("--end-to-end", type=int, default=8_000_000, help="run the C++ front-end from FASTQ files with this many pairs / reads (N = 1 only; 0 = skip)")
     ap.add_argument("--no-pinned-pipeline", action="store_true")
+    ap.add_argument("--no-multi-sample-parity", action="store_true", help="N > 1: skip the default parity leg (the merged result of the ranks on the first --parity-sample "
+                    "pairs of every rank against the reference at -t 1) and the cpu_baseline it yields")
     ap.add_argument("--multi-parity", action="store_true", help="N > 1: rank 0 also runs the reads of ALL ranks on its own (one context, no communicator) "
                     "and the merged result of the ranks must equal it (EC multiset, flens identical; est_counts 1e-9; same EM rounds)")
     ap.add_argument("--table-layout", default=None, choices=["wide", "compact", "auto"],
@@ -969,8 +972,39 @@ def main():
                  "note": "BASELINE config #4 is the strong case: the same 30 M pairs sharded over the GPUs; the EC merge (one all-reduce + "
                          "all-gathers) and the EM (partitioned by connected component, stop rule summed over the ranks) do not shrink with "
                          "1/N, so strong scaling is bounded by them" }
-    # ---- optional parity leg of the multi-rank flow: the merged result against one rank that sees every rank's reads ----
+    # ---- N > 1, no flags: the MERGED result of the ranks on a bounded sample (the first --parity-sample pairs of every rank, in rank order = the
+    # input order of one process reading all of them) against the unmodified reference at -t 1 (MasterProcessor::update, src/ProcessReads.cpp:424-481,
+    # is the merge kamd_ec_allreduce replaces), and the CPU baseline from that very run -- so that a scaling line carries a parity verdict and a
+    # cpu_baseline like the one-GPU line does.  --multi-parity is the heavier leg below (every read of every rank).
     multi_parity = None
+    sample_cpu = None
+    if world > 1 and not args.multi_parity and args.parity_sample and not args.no_multi_sample_parity:
+        n_par = min(n, args.parity_sample)
+        ctx.reset()
+        mres = ka.quant(ctx, opts, [(words[:n_par * per * rec], lens[:per * n_par], n_par, L)], download_ecs=True)   # collective: every rank calls it
+        if rank == 0:
+            try:
+                if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
+                    raise RuntimeError("oracle/_ref/dump_ec not built")
+                host1, host2 = [], []
+                for r in range(world):   # rank r's first pairs: the same generator, the same seed, the same first chunk
+                    q1, q2 = make_sim(1000 + r).draw(min(chunk, n_gen))
+                    host1.append(q1[:n_par].cpu().numpy()); host2.append(q2[:n_par].cpu().numpy())
+                    del q1, q2
+                rp = reference_parity(idx_path, np.concatenate(host1), np.concatenate(host2) if paired else None, mres, cli_extra)
+                multi_parity = {"ranks": world, "items_per_rank": n_par, "what": "the merged result of the ranks on the first pairs of every rank against the unmodified "
+                                "reference (dump_ec quant -t 1) on those pairs in rank order; --multi-parity also compares all reads of all ranks with one rank that sees them",
+                                **{k: rp[k] for k in ("ok", "ec_multiset_equal", "flens_equal", "eff_length_equal", "est_counts_max_rel_err_tpm_ge_1e-3",
+                                                      "tpm_max_rel_err_tpm_ge_1e-3", "zero_pattern_equal", "sample", "reference_seconds", "n_pseudoaligned", "em_rounds_gpu") if k in rp}}
+                sample_cpu = {"value": round(rp["sample"] / max(rp["reference_seconds"], 1e-9) / 1e6, 4), "unit": "M read pairs/s" if paired else "M reads/s", "cores": 1,
+                              "kind": "reference", "processors_visible": os.cpu_count(),
+                              "sample": f"the multi_rank_parity sample: {rp['sample']} {'pairs' if paired else 'reads'} ({n_par} per rank) as uncompressed FASTQ through the unmodified reference at "
+                                        f"-t 1 (oracle/_ref/dump_ec quant: index load, ProcessReads, EMAlgorithm::run; {rp['reference_seconds']:.1f} s in all), on rank 0's host while the other "
+                                        f"ranks wait -- one thread, because the parity leg needs the deterministic fragment-length sample; the one-GPU line reports the reference on all cores"}
+                del host1, host2
+            except Exception as e:   # noqa: BLE001
+                multi_parity = {"ok": False, "error": str(e)[:300]}
+        fence()
     if world > 1 and args.multi_parity:
         ctx.reset()
         mres = ka.quant(ctx, opts, [(words[:n * per * rec], lens[:per * n], n, L)], download_ecs=True)   # collective: every rank calls it
@@ -1212,7 +1246,14 @@ def main():
             "breakdown_ms": {"pseudoalign_kernel": round(a_ms, 3), "classify_kernel": round(float(np.mean(cls_ms)), 3),
                              "kernel_a_version": pr["kernel_a_version"], "tuple_dedup": round(float(np.mean(abs_ms)), 3),
                              "ec_finalize": round(float(np.mean(fin_ms)), 3), "em": round(float(np.mean(em_ms)), 3),
-                             "em_rounds": int(em_iters[-1]), "step_total": round(elapsed / args.steps * 1e3, 3)},
+                             "em_rounds": int(em_iters[-1]), "step_total": round(elapsed / args.steps * 1e3, 3),
+                             **({"ec_merge": round(float(np.mean([p_["merge_ms"] for p_ in profs])), 3),
+                                 "em_collectives": round(float(np.mean([p_["em_collective_ms"] for p_ in profs])), 3),
+                                 "em_collectives_n": int(profs[-1]["em_collectives"]),
+                                 "collective_ms": round(float(np.mean([p_["merge_ms"] + p_["em_collective_ms"] for p_ in profs])), 3),
+                                 "collective_note": "ec_merge = kamd_ec_allreduce (one all-gather of sizes, the all-reduce of the dense counts, the all-gathers of the records and "
+                                                    "their de-duplication; HIP events on rank 0); em_collectives = host wall time inside the EM's all-reduces (one per chunk of 64 rounds + the "
+                                                    "final sum)"} if world > 1 else {})},
             "counters": {"probes_per_pair": round(st["n_probes"] / n, 3),
                          "bucket_reads_per_pair": round(st["n_bucket_reads"] / n, 3), "text_answers_per_pair": round(st["n_text_hits"] / n, 3),
                          "lane_utilisation": round(st["n_lane_iters"] / max(64 * st["n_wave_iters"], 1), 4),
@@ -1375,6 +1416,8 @@ def main():
     if spool is not None:
         spool.remove()
     if rank == 0:
+        if sample_cpu is not None and "cpu_baseline" not in out:
+            out["cpu_baseline"] = sample_cpu
         if multi_parity is not None:
             out["multi_rank_parity"] = multi_parity
         if boot is not None:

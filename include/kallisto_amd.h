@@ -292,6 +292,11 @@ typedef struct {
   uint64_t n_overflow_items;       /* since kamd_ec_reset: items kernel A handed to k_pseudoalign_overflow (more than 8 distinct (unitig, set)
                                       classes, or reads beyond the LDS budget), */
   float overflow_ms;               /* and that kernel's time (HIP events) */
+  float last_merge_ms;             /* several ranks: the last kamd_ec_allreduce (one all-gather of sizes, the all-reduce of the dense counts, the all-gathers
+                                      of the records, their de-duplication; HIP events) */
+  float em_collective_ms;          /* several ranks: host wall time inside the collectives of the last kamd_em_run_comm (one all-reduce per chunk of 64
+                                      rounds for the stop rule + the final sum of the abundance vectors; the host waits for each) */
+  uint32_t em_collectives;         /* ... and their number */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

@@ -71,7 +71,8 @@ class _Profile(C.Structure):
                 ("n_distinct_tuples", C.c_uint64), ("tuple_store_words", C.c_uint64), ("tuple_table_slots", C.c_uint64),
                 ("last_em_max_comp_nnz", C.c_uint64), ("last_em_giant_nnz", C.c_uint64), ("last_em_giant_rows", C.c_uint64),
                 ("last_em_giant_tr", C.c_uint64), ("last_em_giant_chunks", C.c_uint32), ("last_em_giant_cus", C.c_int32),
-                ("last_em_plan_ms", C.c_float), ("n_overflow_items", C.c_uint64), ("overflow_ms", C.c_float)]
+                ("last_em_plan_ms", C.c_float), ("n_overflow_items", C.c_uint64), ("overflow_ms", C.c_float),
+                ("last_merge_ms", C.c_float), ("em_collective_ms", C.c_float), ("em_collectives", C.c_uint32)]
 
 
 class _FastqUnit(C.Structure):
@@ -466,7 +467,8 @@ class Context:
                 "tuple_store_words": int(p.tuple_store_words), "tuple_table_slots": int(p.tuple_table_slots),
                 "em_max_comp_nnz": int(p.last_em_max_comp_nnz), "em_giant_nnz": int(p.last_em_giant_nnz), "em_giant_rows": int(p.last_em_giant_rows),
                 "em_giant_tr": int(p.last_em_giant_tr), "em_giant_chunks": int(p.last_em_giant_chunks), "em_giant_cus": int(p.last_em_giant_cus),
-                "em_plan_ms": float(p.last_em_plan_ms), "n_overflow_items": int(p.n_overflow_items), "overflow_ms": float(p.overflow_ms)}
+                "em_plan_ms": float(p.last_em_plan_ms), "n_overflow_items": int(p.n_overflow_items), "overflow_ms": float(p.overflow_ms),
+                "merge_ms": float(p.last_merge_ms), "em_collective_ms": float(p.em_collective_ms), "em_collectives": int(p.em_collectives)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):
@@ -764,6 +766,19 @@ class Comm:
         # the process group, not through the communicator under test -- that all of them hold a communicator that counts `world` ranks
         # and sums correctly.  Otherwise all of them drop it and take the callbacks: no rank may be left alone in a collective.
         comm, err = None, ""
+        # a watchdog over ncclCommInitRank and the first collective: a rank that never comes back from them cannot be cancelled (the call is inside
+        # the library), but it can end its process -- the launcher then takes the other ranks down, and bench.py's self_launch starts the run again
+        # with the collectives carried by torch.distributed (KAMD_COMM=callbacks) instead of waiting out its whole time limit on a hang
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("KAMD_COMM_INIT_TIMEOUT_S", "180"))
+
+        def _watch():
+            if not done.wait(limit):
+                print(f"[kallisto_amd] rank {rank}: the RCCL communicator did not come up within {limit:.0f} s (KAMD_COMM_INIT_TIMEOUT_S); giving up "
+                      f"(exit code 3)", file=sys.stderr, flush=True)
+                os._exit(3)
+        threading.Thread(target=_watch, daemon=True).start()
         try:
             comm = cls.rccl(ctx, rank, world, box[0])
             seen = comm.info()["ranks_seen"]
@@ -780,6 +795,7 @@ class Comm:
             except KallistoAmdError as e:
                 err = str(e)
             dist.all_gather_object(flags, err, group=group)
+        done.set()
         if any(flags):
             if rank == 0:
                 print(f"[kallisto_amd] RCCL communicator inside the library unusable ({next(f for f in flags if f)}); using torch.distributed "

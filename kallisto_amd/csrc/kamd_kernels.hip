@@ -2555,6 +2555,7 @@ struct kamd_ctx {
   hipEvent_t hy_ev_sell = nullptr, hy_ev_giant = nullptr;
   uint64_t last_em_max_comp_nnz = 0, last_em_giant_nnz = 0, last_em_giant_rows = 0, last_em_giant_tr = 0;
   uint32_t last_em_giant_chunks = 0; int last_em_giant_cus = 0; float last_em_plan_ms = 0.f;
+  float last_merge_ms = 0.f, em_coll_ms = 0.f; uint32_t em_coll_n = 0; hipEvent_t ev_mg0 = nullptr, ev_mg1 = nullptr;   // several ranks: kamd_ec_allreduce (HIP events), the EM's collectives (host wall, the host waits for each)
   const uint32_t* labels_override = nullptr;   // em_local_setup_device takes these component labels instead of computing them (the hybrid's sub-matrix: same components)
   bool em_prefer_hybrid = false;               // the last matrix of this context needed the hybrid: the next plan starts there
   uint64_t overflow_total = 0; float overflow_ms = 0.f; hipEvent_t ev_ov0 = nullptr, ev_ov1 = nullptr;   // since kamd_ec_reset: items of the overflow kernel, its time
@@ -2881,6 +2882,8 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->hy_giant_stream) { (void)hipStreamSynchronize(c->hy_giant_stream); (void)hipStreamDestroy(c->hy_giant_stream); }
   if (c->hy_ev_sell) (void)hipEventDestroy(c->hy_ev_sell);
   if (c->hy_ev_giant) (void)hipEventDestroy(c->hy_ev_giant);
+  if (c->ev_mg0) (void)hipEventDestroy(c->ev_mg0);
+  if (c->ev_mg1) (void)hipEventDestroy(c->ev_mg1);
   if (c->ev_ov0) (void)hipEventDestroy(c->ev_ov0);
   if (c->ev_ov1) (void)hipEventDestroy(c->ev_ov1);
   for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps}) b->release();
@@ -6262,6 +6265,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_giant_cus = c->last_em_giant_cus;
   p->last_em_plan_ms = c->last_em_plan_ms;
   p->n_overflow_items = c->overflow_total; p->overflow_ms = c->overflow_ms;
+  p->last_merge_ms = c->last_merge_ms; p->em_collective_ms = c->em_coll_ms; p->em_collectives = c->em_coll_n;
   return 0;
 }
 
@@ -6471,19 +6475,23 @@ int comm_broadcast(kamd_comm* m, void* d_buf, u64 bytes, int root) {
 }
 // all-gather of variable-length record buffers (words + word offsets of the records): every rank's records concatenated in
 // rank order, offsets rebased.  Results in m->tmp_c (words) / m->tmp_d (offsets).
-int comm_gather_records(kamd_comm* m, const u32* d_words, u64 n_words, const u64* d_off, u64 n_recs, u64* tot_words, u64* tot_recs) {
+// sizes: {words, records} of every rank when the caller has exchanged them already (kamd_ec_allreduce: one all-gather for all the sizes of a
+// merge), else null: exchanged here
+int comm_gather_records(kamd_comm* m, const u32* d_words, u64 n_words, const u64* d_off, u64 n_recs, u64* tot_words, u64* tot_recs, const u64* sizes = nullptr) {
   kamd_ctx* c = m->ctx;
   const int W = m->world;
-  // sizes of every rank
   if (int rc = m->tmp_a.ensure((size_t)(2 + 2 * W) * sizeof(u64), 0, c->stream)) return rc;
-  u64 mine[2] = {n_words, n_recs};
-  u64* d_sizes = m->tmp_a.as<u64>();
-  HIPC(hipMemcpyAsync(d_sizes, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));   // `mine` is a stack buffer
-  if (int rc = comm_allgather(m, d_sizes, d_sizes + 2, sizeof mine)) return rc;
   std::vector<u64> all((size_t)2 * W);
-  HIPC(hipMemcpyAsync(all.data(), d_sizes + 2, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+  if (sizes) memcpy(all.data(), sizes, all.size() * sizeof(u64));
+  else {
+    u64 mine[2] = {n_words, n_recs};
+    u64* d_sizes = m->tmp_a.as<u64>();
+    HIPC(hipMemcpyAsync(d_sizes, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));   // `mine` is a stack buffer
+    if (int rc = comm_allgather(m, d_sizes, d_sizes + 2, sizeof mine)) return rc;
+    HIPC(hipMemcpyAsync(all.data(), d_sizes + 2, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
   u64 mw = 1, mr = 1, tw = 0, tr = 0;
   for (int r = 0; r < W; r++) { mw = std::max(mw, all[2 * r]); mr = std::max(mr, all[2 * r + 1]); tw += all[2 * r]; tr += all[2 * r + 1]; }
   // padded send buffers, one all-gather each
@@ -6512,7 +6520,15 @@ int comm_gather_records(kamd_comm* m, const u32* d_words, u64 n_words, const u64
   *tot_words = tw; *tot_recs = tr;
   return 0;
 }
-int comm_sum_cb(void* user, int32_t* d_counts, int32_t n) { return comm_allreduce((kamd_comm*)user, d_counts, (u64)n, 1); }
+// the stop rule's sum over the ranks (one per chunk of EM rounds); the host waits for it, so its wall time is the collective's cost
+int comm_sum_cb(void* user, int32_t* d_counts, int32_t n) {
+  kamd_comm* m = (kamd_comm*)user;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = comm_allreduce(m, d_counts, (u64)n, 1);
+  if (!rc && m->ctx && hipStreamSynchronize(m->ctx->stream) != hipSuccess) rc = kamd::fail(-100, "kamd_comm: stream error behind an all-reduce");
+  if (m->ctx) { m->ctx->em_coll_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); m->ctx->em_coll_n += 1; }
+  return rc;
+}
 }  // namespace
 
 extern "C" int kamd_comm_unique_id(void* id128) {
@@ -6583,33 +6599,51 @@ extern "C" int kamd_ec_allreduce(kamd_ctx* c, kamd_comm* m) {
   if (m->world == 1 && !m->nccl) return 0;
   if (c->track_order) return kamd::fail(-1, "kamd_ec_allreduce: merged records have no input order (kamd_ec_track_order is on)");
   HIPC(hipSetDevice(c->device));
-  // a rank that was handed no batch never saw the options of the run, but resolves the merged records like everybody else:
-  // --union (mate flags inside the tuple entries) is agreed on here
+  if (!c->ev_mg0) { HIPC(hipEventCreate(&c->ev_mg0)); HIPC(hipEventCreate(&c->ev_mg1)); }
+  HIPC(hipEventRecord(c->ev_mg0, c->stream));
+  // ONE fixed-size all-gather carries everything the ranks have to tell each other before the payloads move (round 4 took a host round trip
+  // per item): the --union flag -- a rank that was handed no batch never saw the options of the run, but resolves the merged records like
+  // everybody else --, and the sizes of its tuple records and of its explicit-set records
+  uint64_t nw = 0, nt = 0, ew = 0, er = 0; u64 tw = 0, tr = 0;
+  if (int rc = kamd_ec_tuples_export(c, &nw, &nt)) return rc;
+  if (int rc = kamd_ec_explicit_export(c, &ew, &er)) return rc;
+  const int W = m->world;
+  std::vector<u64> tsz((size_t)2 * W), esz((size_t)2 * W);
   {
-    uint64_t flags[1] = {c->ix.union_mode ? 1ULL : 0ULL};
-    if (int rc = kamd_comm_sum_u64_host(c, m, flags, 1)) return rc;
-    if (flags[0]) c->ix.union_mode = 1;
+    if (int rc = m->tmp_a.ensure((size_t)(1 + W) * 5 * sizeof(u64), 0, c->stream)) return rc;
+    u64 mine[5] = {c->ix.union_mode ? 1ULL : 0ULL, nw, nt, ew, er};
+    u64* d_sizes = m->tmp_a.as<u64>();
+    HIPC(hipMemcpyAsync(d_sizes, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));   // `mine` is a stack buffer
+    if (int rc = comm_allgather(m, d_sizes, d_sizes + 5, sizeof mine)) return rc;
+    std::vector<u64> all((size_t)5 * W);
+    HIPC(hipMemcpyAsync(all.data(), d_sizes + 5, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < W; r++) {
+      if (all[5 * r]) c->ix.union_mode = 1;
+      tsz[2 * r] = all[5 * r + 1]; tsz[2 * r + 1] = all[5 * r + 2]; esz[2 * r] = all[5 * r + 3]; esz[2 * r + 1] = all[5 * r + 4];
+    }
   }
   // (a) one all-reduce of the dense count vector over the index's transcript sets
   if (int rc = comm_allreduce(m, c->dense.p, c->n_ecs, 0)) return rc;
   // (b) the de-duplicated tuple records of every rank
-  uint64_t nw = 0, nt = 0; u64 tw = 0, tr = 0;
-  if (int rc = kamd_ec_tuples_export(c, &nw, &nt)) return rc;
   DBuf w, o;
-  if (int rc = w.ensure(std::max<u64>(nw, 1) * sizeof(u32), 0, c->stream)) return rc;
-  if (int rc = o.ensure(std::max<u64>(nt, 1) * sizeof(u64), 0, c->stream)) { w.release(); return rc; }
+  if (int rc = w.ensure(std::max<u64>(std::max(nw, ew), 1) * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = o.ensure(std::max<u64>(std::max(nt, er), 1) * sizeof(u64), 0, c->stream)) { w.release(); return rc; }
   int rc = kamd_ec_tuples_copy(c, w.as<u32>(), o.as<uint64_t>());
-  if (!rc) rc = comm_gather_records(m, w.as<u32>(), nw, o.as<u64>(), nt, &tw, &tr);
+  if (!rc) rc = comm_gather_records(m, w.as<u32>(), nw, o.as<u64>(), nt, &tw, &tr, tsz.data());
   if (!rc) rc = kamd_ec_tuples_replace(c, m->tmp_c.as<u32>(), tw, m->tmp_d.as<uint64_t>(), tr);
-  // (c) explicit-set records (positional filters): content-keyed, simply concatenated
-  uint64_t ew = 0, er = 0;
-  if (!rc) rc = kamd_ec_explicit_export(c, &ew, &er);
-  if (!rc) rc = w.ensure(std::max<u64>(ew, 1) * sizeof(u32), 0, c->stream);
-  if (!rc) rc = o.ensure(std::max<u64>(er, 1) * sizeof(u64), 0, c->stream);
-  if (!rc) rc = kamd_ec_explicit_copy(c, w.as<u32>(), o.as<uint64_t>());
-  if (!rc) rc = comm_gather_records(m, w.as<u32>(), ew, o.as<u64>(), er, &tw, &tr);
-  if (!rc) rc = kamd_ec_explicit_replace(c, m->tmp_c.as<u32>(), tw, m->tmp_d.as<uint64_t>(), tr);
+  // (c) explicit-set records (positional filters): content-keyed, simply concatenated; nothing moves when no rank has any
+  u64 e_all = 0;
+  for (int r = 0; r < W; r++) e_all += esz[2 * r + 1];
+  if (!rc && e_all) {
+    rc = kamd_ec_explicit_copy(c, w.as<u32>(), o.as<uint64_t>());
+    if (!rc) rc = comm_gather_records(m, w.as<u32>(), ew, o.as<u64>(), er, &tw, &tr, esz.data());
+    if (!rc) rc = kamd_ec_explicit_replace(c, m->tmp_c.as<u32>(), tw, m->tmp_d.as<uint64_t>(), tr);
+  }
+  if (!rc && hipEventRecord(c->ev_mg1, c->stream) != hipSuccess) rc = kamd::fail(-100, "kamd_ec_allreduce: event error");
   if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = kamd::fail(-100, "kamd_ec_allreduce: stream error");
+  if (!rc) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_mg0, c->ev_mg1) == hipSuccess) c->last_merge_ms = ms; }
   w.release(); o.release();
   return rc;
 }
@@ -6644,7 +6678,9 @@ extern "C" int kamd_em_run_comm(kamd_ctx* c, kamd_comm* m, const double* eff_len
   std::vector<double> abz_local;
   double* abz = alpha_before_zeroes;
   if (!abz) { abz_local.assign(n_targets, 0.0); abz = abz_local.data(); }
+  c->em_coll_ms = 0.f; c->em_coll_n = 0;
   if (int rc = kamd_em_run_partitioned(c, (uint32_t)m->rank, (uint32_t)m->world, comm_sum_cb, m, eff_lens, n_targets, n_iter, min_rounds, alpha, abz, rounds)) return rc;
+  const auto t_fin = std::chrono::steady_clock::now();
   // every transcript is non-zero on exactly one rank: the sum over the ranks is the result
   HIPC(hipSetDevice(c->device));
   if (int rc = m->tmp_a.ensure(2 * n_targets * sizeof(double), 0, c->stream)) return rc;
@@ -6656,6 +6692,7 @@ extern "C" int kamd_em_run_comm(kamd_ctx* c, kamd_comm* m, const double* eff_len
   HIPC(hipMemcpyAsync(alpha, d, n_targets * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipMemcpyAsync(abz, d + n_targets, n_targets * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  c->em_coll_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_fin).count(); c->em_coll_n += 1;
   return 0;
 }
 

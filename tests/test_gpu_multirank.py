@@ -146,6 +146,7 @@ def test_bench_two_ranks_on_one_gpu_with_parity(tmp_path):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["other_scaling"]["scaling"] == "strong"
     assert "callbacks" in line["config"]["collective_backend"] and "gloo" in line["config"]["collective_backend"]     # the transport actually used
     assert line["config"]["n_ranks_seen"] == 2 and line["config"]["launcher"].startswith("self")
+    assert line["breakdown_ms"]["collective_ms"] > 0 and line["breakdown_ms"]["em_collectives_n"] >= 1   # the collectives' share of a step is in the line
     mp = line["multi_rank_parity"]
     assert mp["ok"], mp
     assert mp["ranks"] == 2 and mp["ec_multiset_equal"] and mp["flens_equal"] and mp["em_rounds"][0] == mp["em_rounds"][1]
@@ -153,6 +154,30 @@ def test_bench_two_ranks_on_one_gpu_with_parity(tmp_path):
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec")):
         mr = mp["merged_vs_reference"]
         assert mr["ok"] and mr["ec_multiset_equal"] and mr["flens_equal"] and mr["eff_length_equal"], mr
+
+
+def test_bench_two_ranks_without_flags_carries_parity_and_cpu_baseline(tmp_path):
+    """`KAMD_BENCH_SHARE_GPU=1 python bench.py --gpus 2` with no parity / baseline flag at all -- what the driver's scaling run passes -- must print a
+    line with `roofline`, a `cpu_baseline` and a parity verdict: the merged result of the ranks on a bounded sample (here 100 k pairs per rank) against the
+    unmodified reference on those pairs in rank order."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    if not (os.path.exists(bench.REF_BIN) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "dump_ec"))):
+        pytest.skip("oracle/_ref not built")
+    env = dict(os.environ, KAMD_BENCH_SHARE_GPU="1", KAMD_BENCH_CACHE=str(tmp_path / "cache"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KAMD_BENCH_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genes", "1500", "--pairs", "300000", "--steps", "2", "--warmup", "1",
+                        "--parity-sample", "100000"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1])
+    assert line["n_gpus"] == 2 and line["roofline"]["frac"] > 0
+    mp = line["multi_rank_parity"]
+    assert mp["ok"] and mp["ec_multiset_equal"] and mp["flens_equal"] and mp["eff_length_equal"] and mp["sample"] == 200000, mp
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["value"] > 0 and cb["cores"] == 1, cb
 
 
 def test_bench_refuses_more_ranks_than_gpus():
