@@ -38,7 +38,7 @@ struct Cursor {
     return v;
   }
   const uint8_t* take(size_t len) {
-    if (pos + len > n) { bad = true; return nullptr; }
+    if (pos > n || len > n - pos) { bad = true; return nullptr; }   // (len comes from the file: no wrap-around)
     const uint8_t* r = p + pos; pos += len; return r;
   }
 };
@@ -515,20 +515,27 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   if (k < 3 || k > 31 || !(k & 1)) return kamd::fail(-3, "index: unsupported k (need odd k <= 31)");
   ix->k = k;
   ix->n_long = c.get<uint64_t>();
+  // (every count below comes from the file and sizes an allocation: bounded by what the rest of the file could hold, so that a damaged index
+  // ends in an error code and not in std::bad_alloc / std::length_error crossing the C ABI)
+  auto fits = [&](uint64_t count, uint64_t min_bytes_each) { return !c.bad && c.pos <= c.n && count <= (c.n - c.pos) / min_bytes_each; };
+  if (!fits(ix->n_long, 8)) return kamd::fail(-3, "index: bad unitig count");
   struct U { const uint8_t* data; uint64_t len; };
   std::vector<U> units;
   units.reserve(ix->n_long);
   uint64_t n_kmers = 0;
   for (uint64_t i = 0; i < ix->n_long; i++) {
     uint64_t len = c.get<uint64_t>();
+    if (c.bad || len < (uint64_t)k || len > 4 * (uint64_t)c.n) return kamd::fail(-3, "index: bad unitig record");
     const uint8_t* d = c.take((len + 3) / 4);
-    if (c.bad || len < (uint64_t)k) return kamd::fail(-3, "index: bad unitig record");
+    if (c.bad) return kamd::fail(-3, "index: bad unitig record");
     units.push_back({d, len});
     n_kmers += len - k + 1;
   }
   ix->n_short = c.get<uint64_t>();
+  if (!fits(ix->n_short, 8)) return kamd::fail(-3, "index: bad short/abundant unitig section");
   const uint8_t* short_p = c.take(ix->n_short * 8);
   ix->n_abund = c.get<uint64_t>();
+  if (!fits(ix->n_abund, 8)) return kamd::fail(-3, "index: bad short/abundant unitig section");
   const uint8_t* abund_p = c.take(ix->n_abund * 8);
   if (c.bad) return kamd::fail(-3, "index: bad short/abundant unitig section");
   ix->n_unitigs = ix->n_long + ix->n_short + ix->n_abund;
@@ -628,6 +635,7 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   // 2.2 D-list (KmerIndex.cpp:1386-1403)
   ix->dlist_size = c.get<uint64_t>();
   (void)c.get<uint64_t>();  // overhang: only used when the index is built
+  if (!fits(ix->dlist_size, 8)) return kamd::fail(-3, "index: truncated D-list");
   {
     const uint8_t* dl = c.take(ix->dlist_size * 8);
     if (ix->dlist_size && !dl) return kamd::fail(-3, "index: truncated D-list");
@@ -656,6 +664,9 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   // the position arrays together.  The serial parse took 0.45 of the load's 0.87 s on the pool's boxes; parsing in parallel with the
   // interning left serial inside the loop had been tried in round 3 and was slower.
   struct NodeExt { size_t head, body, end; };
+  // (the count comes from the file: every node record holds at least a head k-mer, its size word, an id and a flag -- a truncated or corrupt
+  // index must fail here with -3, not in a multi-gigabyte allocation)
+  if (c.bad || n_nodes > (c.n - std::min(c.pos, c.n)) / ((uint64_t)k + 4 + 5)) return kamd::fail(-3, "index: truncated node table");
   std::vector<NodeExt> ext(n_nodes);
   for (uint64_t i = 0; i < n_nodes; i++) {
     const uint8_t* hs = c.take((size_t)k);
@@ -794,7 +805,7 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   // stored for the real ones (num_trans -= d_list.size(), :1297).  The pseudo-targets keep ids [n_real, nt) in the
   // transcript sets (off-list); their length entries are 0 so that every id can index target_lens.
   const int64_t n_real = (int64_t)nt - (int64_t)ix->dlist_size;
-  if (n_real < 0) return kamd::fail(-3, "index: bad target count");
+  if (n_real < 0 || !fits((uint64_t)n_real, 4 + 8)) return kamd::fail(-3, "index: bad target count");   // (a length and a name record per real target)
   ix->n_targets = (uint64_t)n_real;
   ix->target_lens.assign((size_t)nt, 0);
   for (int64_t i = 0; i < n_real; i++) ix->target_lens[i] = c.get<int32_t>();

@@ -304,6 +304,19 @@ def test_index_loader_refuses_damaged_files(case, tmp_path):
         assert rc != 0 and L.kamd_last_error(), c
     h = C.c_void_p()
     assert L.kamd_index_load(str(tmp_path / "missing.idx").encode(), 2, C.byref(h)) != 0
+    # counts the loader sizes its tables by come from the file: an absurd 64-bit value anywhere must end in an error code or a clean load, never
+    # in an exception crossing the C ABI or an allocation of that size (the node count)
+    for pos in sorted(set(int(x) for x in rng.integers(8, len(data) - 8, 80))):
+        bad = bytearray(data)
+        bad[pos:pos + 8] = (1 << 44).to_bytes(8, "little")
+        p = str(tmp_path / "c.idx")
+        open(p, "wb").write(bytes(bad))
+        h = C.c_void_p()
+        rc = L.kamd_index_load(p.encode(), 2, C.byref(h))
+        if rc == 0:
+            L.kamd_index_free(h)
+        else:
+            assert L.kamd_last_error(), pos
 
 
 @pytest.mark.parametrize("layout", ["wide", "compact"])
