@@ -791,6 +791,102 @@ __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ ba
   __syncthreads();
   if (is_owner) list[blk_base + my] = s;
 }
+// The main pass of a batch (kernel A's records in their fixed slots), FOUR records per thread: the chain record -> hash -> slot -> owner's
+// record is a sequence of dependent random reads, and with one record per lane the kernel waited 89 % of its cycles on it (VERDICT r4:
+// 11 G dependent requests/s on a chip that serves 54 G independent ones).  Nine records in ten find their tuple in the table at the
+// first probe: that case runs here for four records at once in straight-line code -- the four record reads, the four tag reads and
+// the four owner reads are each in flight together --, everything else (an empty slot to claim, a collision, a tuple of more than four
+// sets) takes k_tup_absorb's loop, one record at a time, afterwards.  Thread t takes records t, t + T, t + 2T, t + 3T (T = threads of
+// the launch): every one of the four rounds reads consecutive slots.
+constexpr int ABS_Q = 4;
+__global__ __launch_bounds__(BLOCK) void k_tup_absorb4(const u32* __restrict__ batch, const u32* __restrict__ store, u64 n, TSlot* table, u64 mask, u64* list,
+                                                       u64 key_base, int track, u32 max_probe, u64* fail, DevState* st, u32 stride, u64 item0) {
+  __shared__ u32 blk_n, blk_words; __shared__ u64 blk_base;
+  if (threadIdx.x == 0) { blk_n = 0; blk_words = 0; }
+  __syncthreads();
+  const u64 T = (u64)gridDim.x * blockDim.x;
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 off[ABS_Q]; u32 w[ABS_Q][6]; bool live[ABS_Q], slow[ABS_Q];
+#pragma unroll
+  for (int q = 0; q < ABS_Q; q++) {
+    const u64 r = i + (u64)q * T;
+    live[q] = r < n;
+    off[q] = (item0 + (live[q] ? r : 0)) * (u64)stride;
+    const uint2* p = reinterpret_cast<const uint2*>(batch + off[q]);   // (slots of 14 words: 8-byte aligned)
+    const uint2 a = live[q] ? p[0] : make_uint2(0u, 0u);
+    const uint2 b = live[q] ? p[1] : make_uint2(0u, 0u), cc = live[q] ? p[2] : make_uint2(0u, 0u);
+    w[q][0] = a.x; w[q][1] = a.y; w[q][2] = b.x; w[q][3] = b.y; w[q][4] = cc.x; w[q][5] = cc.y;
+    live[q] = live[q] && a.x != 0u;
+    slow[q] = live[q] && a.y > 4u;
+  }
+  u64 h[ABS_Q], sl[ABS_Q], old[ABS_Q];
+#pragma unroll
+  for (int q = 0; q < ABS_Q; q++) {
+    const u32 m = w[q][1];
+    u64 x = kamd::mix64(1ULL ^ (0x9e3779b97f4a7c15ULL * ((u64)(m + 1) + 1)));   // rec_hash(words 1 .. m + 1, seed 1)
+    x = kamd::mix64(x ^ m);
+#pragma unroll
+    for (int j = 0; j < 4; j++) if ((u32)j < m) x = kamd::mix64(x ^ w[q][2 + j]);
+    h[q] = x | 1ULL;
+    sl[q] = (h[q] >> 1) & mask;
+    old[q] = (live[q] && !slow[q]) ? table[sl[q]].tag : 0ULL;
+  }
+  u32 ow[ABS_Q][5]; bool cand[ABS_Q];
+#pragma unroll
+  for (int q = 0; q < ABS_Q; q++) {
+    cand[q] = live[q] && !slow[q] && old[q] != 0ULL && (old[q] >> 32) == (h[q] >> 32);
+    const u32* o = ((old[q] & TAG_LOCAL) ? batch : store) + ((old[q] & 0x7FFFFFFFULL) - 1);
+    const u32 m = w[q][1];
+#pragma unroll
+    for (int j = 0; j < 5; j++) ow[q][j] = (cand[q] && (u32)j <= m) ? o[1 + j] : 0u;   // the owner's m and its first four sets
+  }
+#pragma unroll
+  for (int q = 0; q < ABS_Q; q++) {
+    if (!live[q] || slow[q]) continue;
+    bool same = cand[q] && ow[q][0] == w[q][1];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if ((u32)j < w[q][1]) same = same && ow[q][1 + j] == w[q][2 + j];
+    if (same) {
+      atomicAdd(&table[sl[q]].count, (u64)w[q][0]);
+      if (track & 1) atomicMin(&table[sl[q]].first, key_base + i + (u64)q * T);
+    } else slow[q] = true;
+  }
+  // the rest: k_tup_absorb's loop
+  u32 my[ABS_Q]; u64 own_s[ABS_Q]; bool is_owner[ABS_Q];
+#pragma unroll
+  for (int q = 0; q < ABS_Q; q++) {
+    is_owner[q] = false; my[q] = 0; own_s[q] = 0;
+    if (!slow[q]) continue;
+    const u64 r = i + (u64)q * T, o = off[q];
+    const u32 m = batch[o + 1];
+    const u64 hh = rec_hash(batch + o + 1, m + 1, 1);
+    const u64 mine = (hh & 0xFFFFFFFF00000000ULL) | TAG_LOCAL | (o + 1);   // o + 1 < 2^31 (checked by the host)
+    u64 s = (hh >> 1) & mask;
+    bool placed = false;
+    for (u32 probes = 0; probes < max_probe; probes++) {
+      u64 od = table[s].tag;
+      if (od == 0ULL) od = atomicCAS(&table[s].tag, 0ULL, mine);
+      if (od == 0ULL) { is_owner[q] = true; table[s].owner = o; placed = true; break; }
+      if ((od >> 32) == (mine >> 32)) {
+        const u32* ob = ((od & TAG_LOCAL) ? batch : store) + ((od & 0x7FFFFFFFULL) - 1);
+        bool same = ob[1] == m;
+        for (u32 j = 0; same && j < m; j++) same = ob[2 + j] == batch[o + 2 + j];
+        if (same) { placed = true; break; }
+      }
+      s = (s + 1) & mask;
+    }
+    if (placed) {
+      atomicAdd(&table[s].count, (u64)batch[o]);
+      if (track & 1) atomicMin(&table[s].first, key_base + r);
+    } else fail[atomicAdd(&st->tl_fail, 1ULL)] = r;
+    if (is_owner[q]) { own_s[q] = s; my[q] = atomicAdd(&blk_n, 1u); atomicAdd(&blk_words, m + 2u); }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_n) { blk_base = atomicAdd(&st->tl_n, (u64)blk_n); atomicAdd(&st->bound_words, (u64)blk_words); }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < ABS_Q; q++) if (is_owner[q]) list[blk_base + my[q]] = own_s[q];
+}
 // the records that opened a slot in the last k_tup_absorb move from the batch's stream into the store
 __global__ __launch_bounds__(BLOCK) void k_tup_store(const u32* __restrict__ batch, u32* store, TSlot* table, u64* list, u64 first_new,
                                                      u64 n_new, DevState* st) {
@@ -2706,6 +2802,12 @@ int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 
     const u64 tl_before = c->host_state.tl_n;
     c->host_state.tl_fail = 0; c->host_state.bound_words = 0;
     if (int rc = push_state(c)) return rc;
+    // (the main pass of a batch -- kernel A's records in fixed slots of at least six words -- four records per thread; retries, overflow
+    // items and gathered records one per thread)
+    if (!idx && fixed_stride >= 6 && (fixed_stride & 1) == 0 && !c->debug_absorb && !getenv("KAMD_ABSORB_ONE"))
+      hipLaunchKernelGGL(k_tup_absorb4, dim3(grid_for((count + ABS_Q - 1) / ABS_Q, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), count,
+                         c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base, c->track_order ? 1 : 0, 64u, fail_a, dst, fixed_stride, item0);
+    else
     hipLaunchKernelGGL(k_tup_absorb, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), rec_off, idx, count,
                        c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base,
                        (c->track_order ? 1 : 0) | c->debug_absorb, 64u, fail_a, dst,
