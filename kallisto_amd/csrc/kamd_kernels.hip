@@ -533,13 +533,20 @@ template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const u32* __restrict__ words,
                                                              const uint16_t* __restrict__ lens, const u64* items, u64 n,
                                                              int seq_words, int rec_words, u32* scratch, FilterDev fd,
-                                                             u64 rec_base, AlignOut out) {
+                                                             u64 rec_base, AlignOut out, int lds_cap) {
+  extern __shared__ u32 ov_lds[];
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 item = items[i];
   const int item_words = rec_words * (PAIRED ? 2 : 1);
-  // scratch of an item: the list, then as many words for the cursors of the --union merge
-  kamd::EcList ecs; ecs.e = scratch + i * (2 * TUPLE_CAP_BIG); ecs.cap = TUPLE_CAP_BIG; ecs.n = 0; ecs.overflow = false;
+  // scratch of an item: the list, then as many words for the cursors of the --union merge.  The list is a SORTED array kept by insertion
+  // (eclist_add: a scan and a shift per new set): in global scratch that is thousands of dependent memory accesses for an item with a
+  // hundred sets -- a pair inside a repeat family or a poly-A stretch; in LDS (lds_cap words per thread, an odd stride: the threads' lists
+  // start in different banks) it is ALU work.  lds_cap = the k-mers of an item (it cannot have more distinct sets), 0 = the global list
+  // (the default: launch_overflow says why).
+  kamd::EcList ecs; ecs.n = 0; ecs.overflow = false;
+  if (lds_cap > 0) { ecs.e = ov_lds + (size_t)threadIdx.x * (size_t)lds_cap; ecs.cap = lds_cap; }
+  else { ecs.e = scratch + i * (2 * TUPLE_CAP_BIG); ecs.cap = TUPLE_CAP_BIG; }
   u32* cur = scratch + i * (2 * TUPLE_CAP_BIG) + TUPLE_CAP_BIG;
   kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0;
   const kamd::Table t = make_table(ix, !PAIRED);
@@ -3317,9 +3324,18 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
 }
 template <bool PAIRED, bool FILTER>
 void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
-                     u64 rec_base, const AlignOut& out) {
-  hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
-                     c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out);
+                     u64 rec_base, const AlignOut& out, int max_len) {
+  // the list of an item in LDS when the k-mers of an item (an upper bound of its distinct sets) fit 64 KB per block of 64 threads
+  int lds_cap = (PAIRED ? 2 : 1) * std::max(1, max_len - (int)c->ix.k + 1);
+  lds_cap |= 1;
+  // (measured on the stress workload, round 5: the LDS list does NOT pay -- 5.9 against 5.1 ms at 4 M pairs, 37 against 33 ms at 30 M: the kernel's
+  // time is the divergence of 64 straight-line matchers in one wavefront and their dependent probes, not the list; at four wavefronts per CU the
+  // LDS form has less of the memory system in flight.  Kept behind KAMD_OVERFLOW_LDS_LIST=1; what these items need is kernel A's data-flow loop
+  // with a longer class list, DESIGN.md "not done")
+  if (lds_cap > TUPLE_CAP_BIG || (size_t)lds_cap * 64 * 4 > 64 * 1024 || !getenv("KAMD_OVERFLOW_LDS_LIST")) lds_cap = 0;
+  const size_t lds = (size_t)lds_cap * 64 * 4;
+  hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), lds, c->stream, c->ix, d_words, d_len,
+                     c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out, lds_cap);
 }
 }  // namespace
 
@@ -3377,10 +3393,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     const u64 ov_base = 0;   // (record indices of the batch)
     if (!c->ev_ov0) { HIPC(hipEventCreate(&c->ev_ov0)); HIPC(hipEventCreate(&c->ev_ov1)); }
     HIPC(hipEventRecord(c->ev_ov0, c->stream));
-    if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
-                     else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
-    else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out);
-           else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out); }
+    if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len);
+                     else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len); }
+    else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len);
+           else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len); }
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(c->ev_ov1, c->stream));
     if (int rc2 = sync_state(c)) return rc2;
