@@ -2764,6 +2764,8 @@ int tuples_clear(kamd_ctx* c) {
 }
 // the tuple table with `cap` slots; the distinct tuples it held move over (all of them are in the store)
 int tuples_resize(kamd_ctx* c, u64 cap) {
+  // (list entries pack the slot beside the record's offset, slot | offset << 32 -- k_tup_store --: a table beyond 2^32 slots cannot be addressed)
+  if (cap > (1ULL << 32)) return kamd::fail(-101, "absorb_tuples: the tuple table would need more than 2^32 slots");
   const u64 n = c->host_state.tl_n;
   DBuf nu;
   if (int rc = nu.ensure(cap * sizeof(TSlot), 0, c->stream)) return rc;
@@ -3287,7 +3289,10 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
     if (chunks > 1) HIPC(hipEventRecord(c->al_ev_chunk[k], ws.user));
   }
   HIPC(hipEventRecord(c->ev1, ws.user));
-  if (c->fld_deferred.valid && !(c->fld_deferred.w == d_words && c->fld_deferred.l == d_len && c->fld_deferred.n <= n_items)) c->fld_deferred.valid = false;   // (another batch: stale)
+  // (another batch, or the same buffers with other options -- ring buffers are reused --: stale.  ADVICE r4)
+  if (c->fld_deferred.valid && !(c->fld_deferred.w == d_words && c->fld_deferred.l == d_len && c->fld_deferred.n <= n_items &&
+                                 (c->fld_deferred.max_len + 15) / 16 + 1 == seq_words && c->fld_deferred.strand == fd.strand &&
+                                 c->fld_deferred.so == fd.single_overhang && c->fld_deferred.comp == c->ix.comprehensive)) c->fld_deferred.valid = false;
   if (c->fld_deferred.valid) {
     // the deferred fragment-length prefetch of this batch: its kernels start when kernel A has finished and run beside what follows
     c->fld_deferred.valid = false;
