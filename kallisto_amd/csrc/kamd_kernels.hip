@@ -2138,8 +2138,19 @@ __device__ __forceinline__ void pm_wave_load(const PmSide& s, u32 c, PmWave<K>& 
   w.hd = s.head[c];
   w.lw = s.lane_word[(u64)c * 64 + lane_id()];
 }
-template <int K, int PRE, bool WIN, class Emit>
-__device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& w, const double* __restrict__ src, double* lds, const Emit& em) {
+// where the value of an entry comes from: the vector in global memory, or -- the hybrid's oversized side -- a table in LDS for the HOT
+// targets (entries marked PM_HOT carry a slot of that table instead of an index; k_gih_mark)
+constexpr u32 PM_HOT = 0x40000000u;
+struct PmSrcGlobal {
+  const double* __restrict__ p;
+  __device__ __forceinline__ double operator()(u32 id) const { return p[id & ~PM_END]; }
+};
+struct PmSrcHot {
+  const double* __restrict__ p; const double* hot;
+  __device__ __forceinline__ double operator()(u32 id) const { const u32 x = id & ~PM_END; return (x & PM_HOT) ? hot[x & ~PM_HOT] : p[x]; }
+};
+template <int K, int PRE, bool WIN, class Emit, class Src>
+__device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& w, const Src& src, double* lds, const Emit& em) {
   const int lane = lane_id();
   u32 (&id)[K] = w.id;
   const u32 sb = w.sb;
@@ -2155,7 +2166,7 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   auto head_sum = [&](void) -> double {
     double hv[PM_HEAD];
 #pragma unroll
-    for (int i = 0; i < PM_HEAD; i++) hv[i] = src[w.hraw[i] & ~PM_END];
+    for (int i = 0; i < PM_HEAD; i++) hv[i] = src(w.hraw[i]);
     double hs = 0.0;
 #pragma unroll
     for (int i = 0; i < PM_HEAD; i++) hs += (u32)(64 * (i + 1) - lane) <= hlen ? hv[i] : 0.0;
@@ -2164,10 +2175,10 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
       u32 i = 64 * PM_HEAD + (u32)lane;
       for (; i + 192 < hlen; i += 256) {   // four independent gathers per trip
         const u32 i0 = before[-1 - (long)i], i1 = before[-1 - (long)(i + 64)], i2 = before[-1 - (long)(i + 128)], i3 = before[-1 - (long)(i + 192)];
-        const double v0 = src[i0 & ~PM_END], v1 = src[i1 & ~PM_END], v2 = src[i2 & ~PM_END], v3 = src[i3 & ~PM_END];
+        const double v0 = src(i0), v1 = src(i1), v2 = src(i2), v3 = src(i3);
         hs += v0; hs += v1; hs += v2; hs += v3;
       }
-      for (; i < hlen; i += 64) hs += src[before[-1 - (long)i] & ~PM_END];
+      for (; i < hlen; i += 64) hs += src(before[-1 - (long)i]);
     }
     return hs;
   };
@@ -2181,7 +2192,7 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
     // staged like the others and completed in place once the carry is known -- 6 instructions per entry instead of ~25
     double v[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = src[id[k] & ~PM_END];
+    for (int k = 0; k < K; k++) v[k] = src(id[k]);
     double hsum = head_sum();
     typename Emit::Ctx pre[PRE];
 #pragma unroll
@@ -2229,7 +2240,7 @@ __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& 
   for (u32 w0 = skip; w0 == skip || w0 < n_ends; w0 += PM_LDS_SLOTS) {
     double v[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) v[k] = src[id[k] & ~PM_END];
+    for (int k = 0; k < K; k++) v[k] = src(id[k]);
     double hsum = head_sum();
     typename Emit::Ctx pre[PRE];
 #pragma unroll
@@ -2330,7 +2341,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_rows_pass(PmArgs A, int parity)
   if (c >= A.rows.n_chunks) return;
   const PmRowEmit em{A.cw, A.g};
   const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
-  pm_wave_pass<K, PRE, WIN>(A.rows, c, w, a_cur, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  pm_wave_pass<K, PRE, WIN>(A.rows, c, w, PmSrcGlobal{a_cur}, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
 }
 template <int K, int PRE, bool WIN>
 __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity) {
@@ -2346,7 +2357,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_pm_cols_pass(PmArgs A, int parity)
   int ch = 0;
   const double* a_cur = now.fin ? (odd ? A.ac1 : A.ac0) : (odd ? A.a1 : A.a0);
   const PmColEmit em{odd ? A.alpha1 : A.alpha0, a_cur, A.single, A.eff, odd ? A.alpha0 : A.alpha1, odd ? A.a0 : A.a1, odd ? A.ac0 : A.ac1, &ch, now.fin};
-  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE, WIN>(A.cols, c, w, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE, WIN>(A.cols, c, w, PmSrcGlobal{A.g}, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
   pm_count_changes(ch, &lds_ch, &A.st[parity]);
 }
 // fix-up launches (only enqueued when a direction has heavy crossing segments)
@@ -2653,7 +2664,7 @@ struct kamd_ctx {
   void* em_pin = nullptr; size_t em_pin_bytes = 0;   // component-local EM: pinned, mapped host memory (change counts the kernels publish, result staging)
   DBuf em_clk;                                       // diagnostic phase clocks (KAMD_EM_CLK)
   // hybrid EM (components beyond a workgroup's LDS beside the LDS form): the two sub-matrices, the streamed plan's arenas, its vectors
-  DBuf hy_sub, hy_a, hy_b, hy_x, hy_maps;
+  DBuf hy_sub, hy_a, hy_b, hy_x, hy_maps, hy_hot;
   hipStream_t hy_sell_stream = nullptr, hy_giant_stream = nullptr; int hy_sell_cus = -1;   // hy_sell_stream carries a CU mask of hy_sell_cus units
   hipEvent_t hy_ev_sell = nullptr, hy_ev_giant = nullptr;
   uint64_t last_em_max_comp_nnz = 0, last_em_giant_nnz = 0, last_em_giant_rows = 0, last_em_giant_tr = 0;
@@ -2997,7 +3008,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev_mg1) (void)hipEventDestroy(c->ev_mg1);
   if (c->ev_ov0) (void)hipEventDestroy(c->ev_ov0);
   if (c->ev_ov1) (void)hipEventDestroy(c->ev_ov1);
-  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps}) b->release();
+  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps, &c->hy_hot}) b->release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
@@ -3936,6 +3947,8 @@ struct PmPlan {
   u32 n_chunks = 0;
   u32 n_fix[2] = {0, 0};     // heavy crossing segments per direction (0: no fix-up launch)
   const u32* mflag = nullptr; const u64* mpos = nullptr;   // transcript -> m-space
+  const u64* roff = nullptr; const u64* coff = nullptr;    // [R + 1] / [M + 1] entry offsets of the rows / columns (the hybrid picks its hot targets by length)
+  u32* rs = nullptr; u32* cs = nullptr; u64 nzpad = 0;     // the two entry streams (nzpad entries each)
 };
 constexpr int PM_KS[] = {8, 12, 16, 20, 24, 28, 32};
 template <int K>
@@ -4073,6 +4086,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   P->windowed = plan_words[2] > (u32)PM_LDS_SLOTS;
   if (c->tune.em_windowed == 1) P->windowed = true;
   P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos;
+  P->roff = roff; P->coff = coff; P->rs = rs; P->cs = cs; P->nzpad = nzpad;
   c->last_em_nnz_multi = NZ; c->last_em_nseg = n_chunks; c->last_em_necs = n_ecs; c->last_em_k = K;
   c->last_em_grid = grid_for(n_chunks, PM_BLOCK / 64);
   return 0;
@@ -5196,7 +5210,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_gi_rows(PmArgs A, const double* a_
   if (gi_stopped(desc, &s_stop)) return;
   if (c >= A.rows.n_chunks) return;
   const PmRowEmit em{A.cw, A.g};
-  pm_wave_pass<K, PRE, WIN>(A.rows, c, w, a_src, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  pm_wave_pass<K, PRE, WIN>(A.rows, c, w, PmSrcGlobal{a_src}, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
 }
 template <int K, int PRE, bool WIN>
 __global__ __launch_bounds__(PM_BLOCK) void k_gi_cols(PmArgs A, const double* al_src, const double* a_src, double* al_dst, double* a_dst, int round, int clamp,
@@ -5210,7 +5224,7 @@ __global__ __launch_bounds__(PM_BLOCK) void k_gi_cols(PmArgs A, const double* al
   if (gi_stopped(desc, &s_stop)) return;
   int ch = 0;
   const GiColEmit em{al_src, a_src, A.single, A.eff, al_dst, a_dst, &ch, clamp};
-  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE, WIN>(A.cols, c, w, A.g, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
+  if (c < A.cols.n_chunks) pm_wave_pass<K, PRE, WIN>(A.cols, c, w, PmSrcGlobal{A.g}, lds_sums + (threadIdx.x >> 6) * PM_LDS_SLOTS, em);
   int* hist = desc->hist;
   gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
 }
@@ -5230,6 +5244,81 @@ __global__ __launch_bounds__(PM_BLOCK) void k_gi_cols_fix(PmArgs A, const double
   pm_fix(A.cols, blockIdx.x * PM_BLOCK + threadIdx.x, em);
   int* hist = desc->hist;
   gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
+}
+// ---- the same passes with the HOT targets' values in LDS -------------------------------------------------------------------------------
+// An oversized component of a real transcriptome is made of long rows: at 30 M stress pairs 14.2 M entries, ten million of them in ~3 000
+// poly-A / repeat classes of thousands of transcripts -- which all gather the values of the same few thousand transcripts; and in the
+// other direction the columns of those transcripts gather the g of the same few thousand long rows.  A round was 28 M divergent 8-byte
+// gathers through the vector memory pipeline (one line per clock and CU: 39 + 46 us per round).  Here the values of up to GIH_HOT_CAP hot
+// targets per direction (columns / rows of at least a threshold length, chosen so that they fit) are loaded into LDS once per workgroup and
+// launch; the streams' entries that point at them carry PM_HOT | slot (k_gih_mark) and are read with ds_read_b64.  Workgroups are
+// persistent over the chunks (a wavefront takes chunks c, c + W, ...), so the table is loaded 512 times per launch, not once per chunk.
+constexpr int GIH_BLOCK = 512, GIH_HOT_CAP = 4096;
+template <int K, int PRE, bool WIN>
+__global__ __launch_bounds__(GIH_BLOCK) void k_gih_rows(PmArgs A, const double* a_src, const GiDesc* desc, const u32* __restrict__ hot_list, u32 n_hot) {
+  __shared__ double lds_hot[GIH_HOT_CAP];
+  __shared__ double lds_sums[(GIH_BLOCK / 64) * PM_LDS_SLOTS];
+  if (desc->stopped) return;
+  for (u32 i = threadIdx.x; i < n_hot; i += GIH_BLOCK) lds_hot[i] = a_src[hot_list[i]];
+  __syncthreads();
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), total = gridDim.x * (GIH_BLOCK / 64);
+  const PmRowEmit em{A.cw, A.g};
+  const PmSrcHot src{a_src, lds_hot};
+  for (u32 c = blockIdx.x * (GIH_BLOCK / 64) + wave; c < A.rows.n_chunks; c += total) {
+    PmWave<K> w;
+    pm_wave_load<K>(A.rows, c, w);
+    pm_wave_pass<K, PRE, WIN>(A.rows, c, w, src, lds_sums + wave * PM_LDS_SLOTS, em);
+  }
+}
+template <int K, int PRE, bool WIN>
+__global__ __launch_bounds__(GIH_BLOCK) void k_gih_cols(PmArgs A, const double* al_src, const double* a_src, double* al_dst, double* a_dst, int round, int clamp,
+                                                        const GiDesc* desc, const u32* __restrict__ hot_list, u32 n_hot) {
+  __shared__ double lds_hot[GIH_HOT_CAP];
+  __shared__ double lds_sums[(GIH_BLOCK / 64) * PM_LDS_SLOTS];
+  __shared__ int lds_ch;
+  if (desc->stopped) return;
+  for (u32 i = threadIdx.x; i < n_hot; i += GIH_BLOCK) lds_hot[i] = A.g[hot_list[i]];
+  __syncthreads();
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), total = gridDim.x * (GIH_BLOCK / 64);
+  int ch = 0;
+  const GiColEmit em{al_src, a_src, A.single, A.eff, al_dst, a_dst, &ch, clamp};
+  const PmSrcHot src{A.g, lds_hot};
+  for (u32 c = blockIdx.x * (GIH_BLOCK / 64) + wave; c < A.cols.n_chunks; c += total) {
+    PmWave<K> w;
+    pm_wave_load<K>(A.cols, c, w);
+    pm_wave_pass<K, PRE, WIN>(A.cols, c, w, src, lds_sums + wave * PM_LDS_SLOTS, em);
+  }
+  int* hist = desc->hist;
+  gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
+}
+// hot targets of one direction: segments (columns for the rows pass, rows for the columns pass) of at least `thr` entries.
+// counts[j] = segments of at least 32 << j entries, j < 8
+__global__ void k_gih_count(const u64* __restrict__ off, u64 n, u32* counts) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 len = i < n ? off[i + 1] - off[i] : 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u64 bm = __ballot(len >= (32ULL << j));
+    if (bm && lane_id() == 0) atomicAdd(&counts[j], (u32)__popcll(bm));
+  }
+}
+__global__ void k_gih_flag(const u64* __restrict__ off, u64 n, u32 thr, u32* flag) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = off[i + 1] - off[i] >= thr ? 1u : 0u;
+}
+__global__ void k_gih_list(const u32* __restrict__ flag, const u64* __restrict__ slot, u64 n, u32 cap, u32* hot_list, u32* hotslot) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool hot = flag[i] && slot[i] < cap;
+  hotslot[i] = hot ? (u32)slot[i] : 0xFFFFFFFFu;
+  if (hot) hot_list[slot[i]] = (u32)i;
+}
+// entries that point at a hot target carry its slot (the padding's sentinel index n stays what it is)
+__global__ void k_gih_mark(u32* stream, u64 n_entries, const u32* __restrict__ hotslot, u32 n) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_entries) return;
+  const u32 e = stream[i], x = e & ~PM_END;
+  if (x < n) { const u32 h = hotslot[x]; if (h != 0xFFFFFFFFu) stream[i] = (e & PM_END) | PM_HOT | h; }
 }
 // the final round reads a with the clamp applied (alpha < alpha_limit / 10 -> 0, :212-221); ac[M] = 0 stays the row stream's sentinel
 __global__ void k_gi_clamp(const double* __restrict__ al, const double* __restrict__ a, double* ac, u32 M, const GiDesc* desc) {
@@ -5259,6 +5348,8 @@ struct GiantPart {
   hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t gexec[2] = {nullptr, nullptr};
   bool use_graph = true;
   u64 nnz = 0, rows = 0; int cus = 0;
+  const u32* hot_t = nullptr; const u32* hot_r = nullptr; u32 n_hot_t = 0, n_hot_r = 0;   // hot transcripts (rows pass) / hot rows (columns pass); 0: the plain kernels
+  unsigned hot_grid = 0;
   void drop_graphs() {
     for (int i = 0; i < 2; i++) {
       if (gexec[i]) (void)hipGraphExecDestroy(gexec[i]);
@@ -5273,6 +5364,15 @@ void gi_round(const GiantPart& G, hipStream_t s, int round, int clamp, const dou
   const unsigned grid = grid_for(P.n_chunks, PM_BLOCK / 64);
   constexpr int PRE_R = (K + 5) / 6 < 2 ? 2 : (K + 5) / 6;
   constexpr int PRE_C = K / 16 + 1;
+  if (G.hot_grid) {   // the hot targets' values from LDS, persistent workgroups
+    if (P.windowed) hipLaunchKernelGGL((k_gih_rows<K, PRE_R, true>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, a_src, G.desc, G.hot_t, G.n_hot_t);
+    else hipLaunchKernelGGL((k_gih_rows<K, PRE_R, false>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, a_src, G.desc, G.hot_t, G.n_hot_t);
+    if (P.n_fix[0]) hipLaunchKernelGGL(k_gi_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, G.desc);
+    if (P.windowed) hipLaunchKernelGGL((k_gih_cols<K, PRE_C, true>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc, G.hot_r, G.n_hot_r);
+    else hipLaunchKernelGGL((k_gih_cols<K, PRE_C, false>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc, G.hot_r, G.n_hot_r);
+    if (P.n_fix[1]) hipLaunchKernelGGL(k_gi_cols_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc);
+    return;
+  }
   if (P.windowed) hipLaunchKernelGGL((k_gi_rows<K, PRE_R, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, a_src, G.desc);
   else hipLaunchKernelGGL((k_gi_rows<K, PRE_R, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, a_src, G.desc);
   if (P.n_fix[0]) hipLaunchKernelGGL(k_gi_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, G.desc);
@@ -5923,6 +6023,55 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     G.ac = (double*)(xb + o_v[4]); G.desc = (GiDesc*)(xb + o_desc);
     hipLaunchKernelGGL(k_gi_zero_tail, dim3(1), dim3(64), 0, c->stream, G.S_al[0], G.S_al[1], G.S_a[0], G.S_a[1], G.ac, A.M);
     HIPC(hipGetLastError());
+    // the hot targets of either direction into LDS (k_gih_*): columns / rows of at least `thr` entries, thr the smallest power of two from 32
+    // whose segments fit the table.  MEASURED SLOWER and therefore off unless KAMD_EM_HOT=1 (round 5, stress workload: EM 46.7 against 41.5 ms at
+    // 4 M pairs, 157 against 144 ms at 30 M, where 2 790 hot transcripts cover half of the rows pass's gathers and 806 hot rows a sixth of the
+    // columns pass's: k_gih_rows 44.8 us against k_gi_rows 39.2 per round) -- a round of the oversized component moves 170 MB per pass (a 4-byte
+    // index and a gathered line per entry) in ~40 us, i.e. it runs at the chip's effective bandwidth for this pattern, not at the vector memory
+    // pipeline's divergent-access rate; the persistent workgroups' lower occupancy costs more than the LDS hits save.
+    G.hot_grid = 0; G.n_hot_t = 0; G.n_hot_r = 0; G.hot_t = nullptr; G.hot_r = nullptr;
+    {
+      const char* he = getenv("KAMD_EM_HOT");
+      const bool want_hot = he && atoi(he) != 0;
+      if (want_hot && A.R < PM_HOT && A.M < PM_HOT) {
+        const u64 nmax = std::max<u64>(A.R, A.M);
+        Carver hv;
+        const size_t h_cnt = hv.take(2 * 8 * 4), h_flag = hv.take(nmax * 4 + 8), h_slot = hv.take((nmax + 2) * 8);
+        size_t h_hs[2], h_list[2];
+        for (int d = 0; d < 2; d++) { h_hs[d] = hv.take(nmax * 4 + 8); h_list[d] = hv.take((size_t)GIH_HOT_CAP * 4); }
+        if (int rc = c->hy_hot.ensure(hv.off, 0, c->stream)) return rc;
+        char* hb2 = (char*)c->hy_hot.p;
+        u32* d_cnt = (u32*)(hb2 + h_cnt);
+        HIPC(hipMemsetAsync(d_cnt, 0, 2 * 8 * 4, c->stream));
+        const u64* offs[2] = {G.plan.coff, G.plan.roff};   // rows pass gathers transcripts: hot by COLUMN length; columns pass gathers rows: by ROW length
+        const u64 ns[2] = {A.M, A.R};
+        for (int d = 0; d < 2; d++) hipLaunchKernelGGL(k_gih_count, dim3(grid_for(ns[d], BLOCK)), dim3(BLOCK), 0, c->stream, offs[d], ns[d], d_cnt + 8 * d);
+        u32 h_counts[16];
+        HIPC(hipMemcpyAsync(h_counts, d_cnt, sizeof h_counts, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        u32 n_hot[2] = {0, 0};
+        for (int d = 0; d < 2; d++) {
+          int j = 0;
+          while (j < 7 && h_counts[8 * d + j] > (u32)GIH_HOT_CAP) ++j;
+          n_hot[d] = std::min<u32>(h_counts[8 * d + j], (u32)GIH_HOT_CAP);
+          if (!n_hot[d]) continue;
+          u32* flag = (u32*)(hb2 + h_flag); u64* slot = (u64*)(hb2 + h_slot); u32* hs = (u32*)(hb2 + h_hs[d]); u32* list = (u32*)(hb2 + h_list[d]);
+          hipLaunchKernelGGL(k_gih_flag, dim3(grid_for(ns[d], BLOCK)), dim3(BLOCK), 0, c->stream, offs[d], ns[d], 32u << j, flag);
+          if (int rc = exclusive_scan(c, flag, ns[d], slot, slot + ns[d])) return rc;
+          hipLaunchKernelGGL(k_gih_list, dim3(grid_for(ns[d], BLOCK)), dim3(BLOCK), 0, c->stream, flag, slot, ns[d], (u32)GIH_HOT_CAP, list, hs);
+          hipLaunchKernelGGL(k_gih_mark, dim3(grid_for(G.plan.nzpad, BLOCK)), dim3(BLOCK), 0, c->stream, d == 0 ? G.plan.rs : G.plan.cs, G.plan.nzpad, hs, (u32)ns[d]);
+          if (d == 0) { G.hot_t = list; G.n_hot_t = n_hot[d]; } else { G.hot_r = list; G.n_hot_r = n_hot[d]; }
+        }
+        HIPC(hipGetLastError());
+        if (getenv("KAMD_DEBUG_FIN")) fprintf(stderr, "[kamd] hybrid: hot transcripts %u (columns >= 32: %u, >= 256: %u, >= 2048: %u of %u), hot rows %u (rows >= 32: %u, >= 256: %u, >= 2048: %u of %u)\n",
+                                              n_hot[0], h_counts[0], h_counts[3], h_counts[6], A.M, n_hot[1], h_counts[8], h_counts[11], h_counts[14], A.R);
+        if (n_hot[0] || n_hot[1]) {
+          if (!G.hot_t) G.hot_t = (const u32*)(hb2 + h_list[0]);   // (an empty table: n_hot = 0)
+          if (!G.hot_r) G.hot_r = (const u32*)(hb2 + h_list[1]);
+          G.hot_grid = (unsigned)std::min<u64>((u64)2 * c->n_cus, grid_for(G.plan.n_chunks, GIH_BLOCK / 64));
+        }
+      }
+    }
     G.stream = c->hy_giant_stream; G.ev = c->hy_ev_giant; G.use_graph = c->tune.em_graph != 2;
     G.nnz = nnz_g; G.rows = A.R; G.cus = c->hy_sell_cus > 0 ? c->n_cus - c->hy_sell_cus : 0;
     K.hybrid = true;

@@ -268,7 +268,7 @@ def _hybrid_csr(n_genes, seed, n_chained=500):
 
 
 @pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
-                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix"])
+                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_hot", "hybrid_k8_hot", "hub_hot", "hybrid_nograph_hot"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -279,6 +279,11 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
+    if isinstance(k, str) and k.endswith("_hot"):
+        # the oversized side with the values of its hot targets (long rows' transcripts, hub rows) in LDS and persistent workgroups -- the default
+        # from a million entries on, forced here on the small matrices
+        monkeypatch.setenv("KAMD_EM_HOT", "1")
+        k = k[:-4]
     if isinstance(k, str) and k.endswith("_fix"):
         # rows / columns that cross into a chunk with more than 256 entries are re-read by the chunk in a loop (round 5); the fix-up launches
         # they needed before remain for segments beyond 32 768 entries -- forced here for all of them
