@@ -297,6 +297,8 @@ typedef struct {
   float em_collective_ms;          /* several ranks: host wall time inside the collectives of the last kamd_em_run_comm (one all-reduce per chunk of 64
                                       rounds for the stop rule + the final sum of the abundance vectors; the host waits for each) */
   uint32_t em_collectives;         /* ... and their number */
+  uint64_t n_overflow_second_pass; /* of n_overflow_items: those kernel A's second pass (a list of 64 classes) took care of; the rest went to the
+                                      straight-line kernel */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

@@ -72,7 +72,7 @@ class _Profile(C.Structure):
                 ("last_em_max_comp_nnz", C.c_uint64), ("last_em_giant_nnz", C.c_uint64), ("last_em_giant_rows", C.c_uint64),
                 ("last_em_giant_tr", C.c_uint64), ("last_em_giant_chunks", C.c_uint32), ("last_em_giant_cus", C.c_int32),
                 ("last_em_plan_ms", C.c_float), ("n_overflow_items", C.c_uint64), ("overflow_ms", C.c_float),
-                ("last_merge_ms", C.c_float), ("em_collective_ms", C.c_float), ("em_collectives", C.c_uint32)]
+                ("last_merge_ms", C.c_float), ("em_collective_ms", C.c_float), ("em_collectives", C.c_uint32), ("n_overflow_second_pass", C.c_uint64)]
 
 
 class _FastqUnit(C.Structure):
@@ -468,7 +468,7 @@ class Context:
                 "em_max_comp_nnz": int(p.last_em_max_comp_nnz), "em_giant_nnz": int(p.last_em_giant_nnz), "em_giant_rows": int(p.last_em_giant_rows),
                 "em_giant_tr": int(p.last_em_giant_tr), "em_giant_chunks": int(p.last_em_giant_chunks), "em_giant_cus": int(p.last_em_giant_cus),
                 "em_plan_ms": float(p.last_em_plan_ms), "n_overflow_items": int(p.n_overflow_items), "overflow_ms": float(p.overflow_ms),
-                "merge_ms": float(p.last_merge_ms), "em_collective_ms": float(p.em_collective_ms), "em_collectives": int(p.em_collectives)}
+                "merge_ms": float(p.last_merge_ms), "em_collective_ms": float(p.em_collective_ms), "em_collectives": int(p.em_collectives), "n_overflow_second_pass": int(p.n_overflow_second_pass)}
 
     # ---- multi-GPU exchange: all-reduce of the dense EC count vector + all-gather of the tuple records ----
     def dense_counts(self):

@@ -568,8 +568,12 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   // load factor when the caller names none: the sparsest of 0.4 / 0.5 whose table stays under the 2.4 GB up to which dependent random
   // reads run at full rate on MI355X (fewer continue flags: 9.57 / 9.90 / 10.53 bucket lines per pair of config #3 at 0.4 / 0.5 / 0.6,
   // kernel A 10.13 / 10.26 / 10.55 ms; profiles/README.md), 0.6 beyond (fewer bytes beat fewer lines per probe there)
+  // The footprint is a property of the device (MI355X: 2.4 GB, measured with kamd_debug_random_lines_span -- 54 G lines/s up to there, 28 G/s at
+  // 3.6 GB; bench.py reports the live figure as random_line_ceiling), not of the library: KAMD_TABLE_KNEE_GB overrides it for another part.
+  double knee = 2.4e9;
+  if (const char* e = getenv("KAMD_TABLE_KNEE_GB")) { const double v = atof(e); if (v > 0.05 && v < 1024.0) knee = v * 1e9; }
   const double bytes_at_1 = (double)ix->n_kmers * (64.0 / kamd::COMPACT_SLOTS);
-  const double default_load = bytes_at_1 / 0.4 <= 2.4e9 ? 0.4 : bytes_at_1 / 0.5 <= 2.4e9 ? 0.5 : 0.6;
+  const double default_load = bytes_at_1 / 0.4 <= knee ? 0.4 : bytes_at_1 / 0.5 <= knee ? 0.5 : 0.6;
   const double compact_load = (compact_load_arg >= 0.2 && compact_load_arg <= 0.9) ? compact_load_arg : default_load;
   bool compact = want_compact != KAMD_TABLE_WIDE;
   const uint64_t nb_wide = std::max<uint64_t>(16, (ix->n_kmers * 2 + kamd::BUCKET_SLOTS - 1) / kamd::BUCKET_SLOTS);  // load factor 0.5 over 3-slot buckets

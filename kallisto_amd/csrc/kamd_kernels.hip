@@ -280,10 +280,14 @@ constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
 // More than V3_LIST_CAP distinct classes (0.5 % of config #3's pairs): the item goes to the overflow kernel, as before.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int V3_LIST_CAP = 8;
-template <bool PAIRED, bool FILTER, bool DL, bool TEXT, int LAYOUT>
+constexpr int V3_LIST_CAP_LONG = 64;   // the second pass over the items whose list overflowed (k_match_v3<..., V3_LIST_CAP_LONG> on an item list)
+// LCAP: class entries per item in LDS.  item_idx != null: the launch works on the items item_idx[0 .. n_items) of the batch (their raw records
+// go to slots 0 .. n_items of `raw`): the second pass over the items whose list overflowed in the first -- a pair inside a repeat family or a
+// poly-A stretch has dozens of distinct classes --, with the same data-flow matcher instead of 64 divergent straight-line ones per wavefront.
+template <bool PAIRED, bool FILTER, bool DL, bool TEXT, int LAYOUT, int LCAP = V3_LIST_CAP>
 __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                     u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
-                                                    u32* raw, int raw_stride, DevStatsA* st) {
+                                                    u32* raw, int raw_stride, DevStatsA* st, const u64* __restrict__ item_idx = nullptr) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   constexpr int WAVES = BLOCK / 64;
   constexpr int NM = PAIRED ? 2 : 1;
@@ -302,8 +306,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
 
   kamd::MatchState ms; ms.phase = kamd::PH_DONE; ms.w = 0; ms.w0 = 0; ms.w2 = 0; ms.dist = 0; ms.nextPos = 0;
   ms.um_uec = ms.um2_uec = kamd::NO_UEC; ms.um_gpos = 0; ms.um_strand = false; ms.text_tried = false; ms.disp = 0;
-  kamd::UecList ul{my_list, V3_LIST_CAP, 0, false, BLOCK};
+  kamd::UecList ul{my_list, LCAP, 0, false, BLOCK};
   kamd::MateFirst mf0{0, 0, -1, false}, mf1{0, 0, -1, false};
+  u64 my_item = 0;        // the lane's item in the batch (chunk0 + my_idx, or item_idx[chunk0 + my_idx])
   int mate = 0, len0 = 0, len1 = 0;
   bool n0 = false, n1 = false;   // has-N flags of the two mates
   u32 my_idx = 0;
@@ -325,7 +330,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
         if (my_idx >= chunk_n) exhausted = true;
         else {
           loading = true;
-          const u64 item = chunk0 + my_idx;
+          const u64 item = item_idx ? item_idx[chunk0 + my_idx] : chunk0 + my_idx;
+          my_item = item;
           const u32* src = words + item * item_words;
 #pragma unroll 4
           for (int j = 0; j < seq_words; j++)
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
     // key to the next bucket costs the lane another iteration, never the wavefront a second round trip
     if (have && busy) {
       const u32* base = my_words + (size_t)(mate ? seq_words : 0) * 64;
-      const u32* mplane = words + (chunk0 + my_idx) * (u64)item_words + (size_t)(mate ? rec_words : 0) + seq_words;
+      const u32* mplane = words + my_item * (u64)item_words + (size_t)(mate ? rec_words : 0) + seq_words;
       kamd::ReadView rv{base, mplane, mate ? len1 : len0, 64, 1, mate ? n1 : n0};
       bool fc;
       const uint64_t canon = kamd::window_canon(rv, ms.w, k, &fc);
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
       mate = 0;
       n0 = (my_words[(size_t)(seq_words - 1) * 64] & kamd::REC_FLAG_HAS_N) != 0;
       n1 = PAIRED ? (my_words[(size_t)(2 * seq_words - 1) * 64] & kamd::REC_FLAG_HAS_N) != 0 : false;
-      const u32* mplane = words + (chunk0 + my_idx) * (u64)item_words + seq_words;
+      const u32* mplane = words + my_item * (u64)item_words + seq_words;
       kamd::ReadView r0{my_words, mplane, len0, 64, 1, n0};
       kamd::match_init(ms, r0, k);
       if (ms.phase == kamd::PH_DONE && PAIRED) {
@@ -410,12 +416,16 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
     if (have && !busy) {
       u32* o = raw + (chunk0 + my_idx) * (u64)raw_stride;
       o[0] = (u32)ul.n | (ul.overflow ? RAW_OVERFLOW : 0u) | (mf0.n_hits > 0 ? RAW_HIT0 : 0u) | (mf1.n_hits > 0 ? RAW_HIT1 : 0u);
+      if constexpr (LCAP <= 16) {
 #pragma unroll
-      for (int j = 0; j < V3_LIST_CAP; j++) if (j < ul.n) o[1 + j] = my_list[(size_t)j * BLOCK];
+        for (int j = 0; j < LCAP; j++) if (j < ul.n) o[1 + j] = my_list[(size_t)j * BLOCK];
+      } else {
+        for (int j = 0; j < ul.n; j++) o[1 + j] = my_list[(size_t)j * BLOCK];
+      }
       raw_words += 1u + (u32)ul.n;
       if (FILTER) {
-        o[2 + V3_LIST_CAP] = (u32)mf0.slot; o[3 + V3_LIST_CAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
-        o[4 + V3_LIST_CAP] = (u32)mf1.slot; o[5 + V3_LIST_CAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
+        o[2 + LCAP] = (u32)mf0.slot; o[3 + LCAP] = (u32)(mf0.pos & 0xFFFF) | (mf0.strand ? 0x10000u : 0u);
+        o[4 + LCAP] = (u32)mf1.slot; o[5 + LCAP] = (u32)(mf1.pos & 0xFFFF) | (mf1.strand ? 0x10000u : 0u);
       }
       have = false;
     }
@@ -577,6 +587,61 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
   w[0] = 1u; w[1] = (u32)ecs.n;
   for (int j = 0; j < ecs.n; j++) w[2 + j] = ecs.e[j];
   out.rec_off[ridx] = off;
+  atomicAdd(&out.st->st_multi, 1ULL);
+}
+
+// The second pass's raw records (k_match_v3<..., V3_LIST_CAP_LONG> over the items whose list overflowed in the first) -> tuple records, with
+// k_pseudoalign_overflow's tail: the item's own record is redirected to a long record appended to the stream.  Items whose list overflowed
+// again (more than CAP distinct classes) are listed for the straight-line kernel.
+template <bool PAIRED, bool FILTER, int CAP>
+__global__ __launch_bounds__(64) void k_classify_long(DevIndex ix, const u32* __restrict__ raw, int stride, const u64* __restrict__ items, u64 n, u32* scratch,
+                                                      FilterDev fd, u64 rec_base, AlignOut out, u64* items_left) {
+  __shared__ u32 lds_ecs[64 * (CAP + 1)];   // (an odd stride: the threads' lists start in different banks)
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 item = items[i];
+  const u32* r = raw + i * (u64)stride;
+  const u32 h = r[0];
+  if (h & RAW_OVERFLOW) { const u64 k = atomicAdd(&out.st->n_overflow, 1ULL); items_left[k] = item; return; }
+  const int nc = (int)(h & 0xFFu);
+  kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * (CAP + 1); ecs.cap = CAP; ecs.n = 0; ecs.overflow = false;
+  bool ne0 = false, ne1 = false;
+  for (int j = 0; j < nc; j++) {
+    const u32 uec = r[1 + j];
+    const u32 ec = ix.uec_ecn[uec & 0x3FFFFFFFu];
+    if (ec & 0x80000000u) {   // the set is non-empty
+      if (uec & 0x40000000u) ne0 = true;
+      if (uec & 0x80000000u) ne1 = true;
+      const u32 id = ec & kamd::EC_ID_MASK;
+      kamd::eclist_add(ecs, ix.union_mode ? (id | (uec & 0xC0000000u)) : id);
+    }
+  }
+  kamd::MateInfo m0, m1;
+  m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
+  m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
+  m0.n_nonempty = ne0; m1.n_nonempty = ne1;
+  if (FILTER) {
+    m0.first_slot = r[2 + CAP]; m0.first_pos = (int)(r[3 + CAP] & 0xFFFF); m0.first_strand = (r[3 + CAP] >> 16) & 1u;
+    m1.first_slot = r[4 + CAP]; m1.first_pos = (int)(r[5 + CAP] & 0xFFFF); m1.first_strand = (r[5 + CAP] >> 16) & 1u;
+  }
+  if (!kamd::pair_is_mapped(m0, m1)) return;
+  if (FILTER) {
+    u32 kept = 0;
+    u32* cur = scratch + i * (u64)(2 * TUPLE_CAP_BIG) + TUPLE_CAP_BIG;
+    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept, cur);
+    if (oc == 1) return;
+    if (oc == 2) {
+      const u64 k = atomicAdd(&out.st->n_explicit_big, 1ULL);
+      out.explicit_items_big[k] = item;
+      atomicAdd(&out.st->exp_words, (u64)kept + 2);
+      return;
+    }
+  }
+  const u64 off = atomicAdd(&out.st->stream_words, (u64)ecs.n + 2);
+  u32* w = out.stream + off;
+  w[0] = 1u; w[1] = (u32)ecs.n;
+  for (int j = 0; j < ecs.n; j++) w[2 + j] = ecs.e[j];
+  out.rec_off[rec_base + item] = off;
   atomicAdd(&out.st->st_multi, 1ULL);
 }
 
@@ -2617,6 +2682,8 @@ struct kamd_ctx {
   u64 n_ecs = 0, n_targets = 0;
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums, tup_bound, tup_off, tup_big;
+  DBuf raw2, overflow_left, stats_b;   // the second pass over the items whose class list overflowed: its raw records, what overflows again, its counters
+  u64 overflow_second_total = 0;       // since kamd_ec_reset: overflow items the second pass took care of
   u64 last_fin_big = 0;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;
@@ -3017,7 +3084,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->sell_cache) sell_cache_free(c->sell_cache);
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
-                  &c->retry, &c->ttable, &c->tstore, &c->stats_a, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->tup_big, &c->clist, &c->sizes, &c->explicit_items,
+                  &c->retry, &c->ttable, &c->tstore, &c->stats_a, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->tup_big, &c->raw2, &c->overflow_left, &c->stats_b, &c->clist, &c->sizes, &c->explicit_items,
                   &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
@@ -3084,7 +3151,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipMemsetAsync(c->dense.p, 0, std::max<u64>(c->n_ecs, 1) * sizeof(u32), c->stream));
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(c->n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
-  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f; c->overflow_total = 0; c->overflow_ms = 0.f;
+  c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f; c->overflow_total = 0; c->overflow_ms = 0.f; c->overflow_second_total = 0;
   if (int rc = tuples_clear(c)) return rc;
   HIPC(hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream));
   c->had_overflow_items = false;
@@ -3340,7 +3407,7 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
 }
 template <bool PAIRED, bool FILTER>
 void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
-                     u64 rec_base, const AlignOut& out, int max_len) {
+                     u64 rec_base, const AlignOut& out, int max_len, const u64* items = nullptr) {
   // the list of an item in LDS when the k-mers of an item (an upper bound of its distinct sets) fit 64 KB per block of 64 threads
   int lds_cap = (PAIRED ? 2 : 1) * std::max(1, max_len - (int)c->ix.k + 1);
   lds_cap |= 1;
@@ -3351,7 +3418,49 @@ void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64
   if (lds_cap > TUPLE_CAP_BIG || (size_t)lds_cap * 64 * 4 > 64 * 1024 || !getenv("KAMD_OVERFLOW_LDS_LIST")) lds_cap = 0;
   const size_t lds = (size_t)lds_cap * 64 * 4;
   hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), lds, c->stream, c->ix, d_words, d_len,
-                     c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out, lds_cap);
+                     items ? items : (const u64*)c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out, lds_cap);
+}
+// The second pass of kernel A over the items whose class list overflowed: the data-flow matcher with a list of V3_LIST_CAP_LONG classes per
+// lane, reading the items through overflow_items[]; their records through k_classify_long.  Returns 0 = done (items whose list overflowed again
+// are in c->overflow_left, their number in host_state.n_overflow), 1 = not applicable (reads too long for the LDS layout: the caller takes the
+// straight-line kernel for all items), < 0 = error.
+template <bool PAIRED, bool FILTER>
+int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd, const AlignOut& out) {
+  constexpr int WAVES = BLOCK / 64;
+  constexpr int NM = PAIRED ? 2 : 1;
+  constexpr int LC = V3_LIST_CAP_LONG;
+  const int lane_words = seq_words * NM;
+  const size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * LC) * sizeof(u32);
+  if (lds_bytes > 96 * 1024) return 1;
+  const int stride2 = 2 + LC + (FILTER ? 4 : 0);
+  if (int rc = c->raw2.ensure(nov * (u64)stride2 * sizeof(u32), 0, c->stream)) return rc;
+  if (int rc = c->overflow_left.ensure(nov * sizeof(u64), 0, c->stream)) return rc;
+  if (int rc = c->stats_b.ensure(sizeof(DevStatsA), 0, c->stream)) return rc;
+  // (the probes of this pass are not kernel A's of the roofline: counters of their own)
+  HIPC(hipMemsetAsync(c->stats_b.p, 0, sizeof(DevStatsA), c->stream));
+  // items per wavefront: enough wavefronts for every CU, at least a wavefront's worth of items each
+  const int ipw = (int)std::min<u64>(1024, std::max<u64>(64, nov / ((u64)std::max(1, c->n_cus) * 8)));
+  const u64 n_waves = (nov + (u64)ipw - 1) / (u64)ipw;
+  u32* raw2 = c->raw2.as<u32>();
+#define KAMD_LAUNCH_V3L2(DLV, TXT, LAY)                                                                                                  \
+  do {                                                                                                                                  \
+    HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, nov, \
+                       seq_words, rec_words, ipw, std::min(c->refill_min, 8), raw2, stride2, c->stats_b.as<DevStatsA>(), (const u64*)c->overflow_items.as<u64>()); \
+  } while (0)
+#define KAMD_LAUNCH_V32(DLV, TXT)                                                                                                        \
+  do { if (c->ix.table_layout == kamd::LAYOUT_COMPACT) KAMD_LAUNCH_V3L2(DLV, TXT, kamd::LAYOUT_COMPACT); else KAMD_LAUNCH_V3L2(DLV, TXT, kamd::LAYOUT_WIDE); } while (0)
+  const bool dl = c->ix.n_dbuckets != 0, txt = c->tune.text_verify == 1;
+  if (dl) { if (txt) KAMD_LAUNCH_V32(true, true); else KAMD_LAUNCH_V32(true, false); }
+  else { if (txt) KAMD_LAUNCH_V32(false, true); else KAMD_LAUNCH_V32(false, false); }
+#undef KAMD_LAUNCH_V32
+#undef KAMD_LAUNCH_V3L2
+  c->host_state.n_overflow = 0;   // k_classify_long counts the items whose list overflowed again
+  if (int rc = push_state(c)) return rc;
+  hipLaunchKernelGGL((k_classify_long<PAIRED, FILTER, LC>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, (const u32*)raw2, stride2,
+                     (const u64*)c->overflow_items.as<u64>(), nov, c->overflow_scratch.as<u32>(), fd, 0ULL, out, c->overflow_left.as<u64>());
+  HIPC(hipGetLastError());
+  return sync_state(c);
 }
 }  // namespace
 
@@ -3401,7 +3510,15 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
     c->had_overflow_items = true;
-    if (int rc2 = c->overflow_scratch.ensure(nov * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
+    // Optionally the items go through kernel A's loop once more with a list of 64 classes (overflow_second_pass); what overflows again -- or every
+    // item by default -- takes the straight-line kernel.  The cursor scratch (2 x 1024 words per item) is only needed by the filters / --union
+    // in the second pass and by the straight-line kernel.
+    // MEASURED SLOWER, therefore opt-in (KAMD_OVERFLOW_SECOND_PASS=1; round 5): 41.5 against 33.0 ms for the 1.65 M such pairs of 30 M stress pairs,
+    // 0.74 against 0.62 ms on config #3 -- these items have a hundred probes and dozens of classes each, the 64-entry list is scanned per hit,
+    // and the kernel holds 8 wavefronts per CU with it instead of 24; what overflows again pays twice.
+    const bool try_second = getenv("KAMD_OVERFLOW_SECOND_PASS") && !getenv("KAMD_OVERFLOW_STRAIGHT");
+    const bool need_cursors = filter || c->ix.union_mode;
+    if (!try_second || need_cursors) if (int rc2 = c->overflow_scratch.ensure(nov * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
     const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
     if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
     if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
@@ -3409,10 +3526,25 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     const u64 ov_base = 0;   // (record indices of the batch)
     if (!c->ev_ov0) { HIPC(hipEventCreate(&c->ev_ov0)); HIPC(hipEventCreate(&c->ev_ov1)); }
     HIPC(hipEventRecord(c->ev_ov0, c->stream));
-    if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len);
-                     else launch_overflow<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len); }
-    else { if (filter) launch_overflow<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len);
-           else launch_overflow<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, ov_base, out, max_len); }
+    u64 n_straight = nov;
+    const u64* straight_items = nullptr;   // (null: all of overflow_items)
+    if (try_second) {
+      int sp = 1;
+      if (o->paired) sp = filter ? overflow_second_pass<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out)
+                                 : overflow_second_pass<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
+      else sp = filter ? overflow_second_pass<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out)
+                       : overflow_second_pass<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
+      if (sp < 0) return sp;
+      if (sp == 0) { n_straight = c->host_state.n_overflow; straight_items = c->overflow_left.as<u64>(); }
+    }
+    c->overflow_second_total += nov - n_straight;
+    if (n_straight) {
+      if (int rc2 = c->overflow_scratch.ensure(n_straight * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
+      if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items);
+                       else launch_overflow<true, false>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items); }
+      else { if (filter) launch_overflow<false, true>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items);
+             else launch_overflow<false, false>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items); }
+    }
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(c->ev_ov1, c->stream));
     if (int rc2 = sync_state(c)) return rc2;
@@ -6537,6 +6669,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_giant_cus = c->last_em_giant_cus;
   p->last_em_plan_ms = c->last_em_plan_ms;
   p->n_overflow_items = c->overflow_total; p->overflow_ms = c->overflow_ms;
+  p->n_overflow_second_pass = c->overflow_second_total;
   p->last_merge_ms = c->last_merge_ms; p->em_collective_ms = c->em_coll_ms; p->em_collectives = c->em_coll_n;
   return 0;
 }

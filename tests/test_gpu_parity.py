@@ -59,6 +59,35 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
     common.assert_abundance_close(tiny(res.alpha_before_zeroes), tiny(exp["abz"]), "alpha_before_zeroes", floor=1e-9)
 
 
+@pytest.mark.parametrize("case,variant", [("stress_pe", "pe"), ("stress_pe", "pe_rf"), ("stress_pe", "pe_union"), ("stress_pe", "se"), ("mosaic_pe", "pe_nojump"),
+                                          ("dlist_pe", "pe_nojump")])
+@pytest.mark.parametrize("path", ["second_pass", "straight"])
+def test_items_with_long_class_lists(case, variant, path, ka, ctxs, monkeypatch):
+    """Items with more than eight distinct (unitig, set) classes -- pairs inside repeat families and poly-A stretches (a fifth of the stress fixture's
+    mapped pairs), --no-jump runs -- leave kernel A's first pass unfinished.  Round 5: they go through the SAME data-flow matcher once more with a list
+    of 64 classes (k_match_v3<..., 64> over the item list, k_classify_long) when KAMD_OVERFLOW_SECOND_PASS=1 asks for it -- measured slower than the
+    straight-line kernel, which stays the default (DESIGN_HISTORY.md round 5).  Both must give the reference's classes, and the second pass must have taken items."""
+    if path == "second_pass":
+        monkeypatch.setenv("KAMD_OVERFLOW_SECOND_PASS", "1")
+    meta, idx_path, r1, r2 = common.load_case(case)
+    o = common.parse_variant(meta["variants"][variant])
+    exp = common.load_expected(case, variant)
+    index, ctx = ctxs(case)
+    reads = common.interleave(r1, r2 if o["paired"] else None)
+    words, lens, max_len = ctx.pack_reads_host(reads)
+    opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"])
+    ctx.reset()
+    res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
+    prof = ctx.profile()
+    assert res.ecs.multiset() == exp["ecs"] and np.array_equal(res.flens, exp["flens"])
+    common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
+    assert prof["n_overflow_items"] > 0, "the fixture no longer exercises the long-list path"
+    if path == "second_pass":
+        assert prof["n_overflow_second_pass"] > 0.5 * prof["n_overflow_items"], prof
+    else:
+        assert prof["n_overflow_second_pass"] == 0
+
+
 def test_single_end_needs_fragment_length(ka, ctxs):
     """CheckOptionsEM (src/main.cpp:1658-1688): --single requires -l and -s; the library refuses loudly."""
     meta, idx_path, r1, r2 = common.load_case("yeast_se")
