@@ -17,8 +17,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline           -- the dominant kernel by time, kernel A (k_match_v3): SURVEY.md 8(d)'s algorithmic bytes of the launch / its
                         HIP-event duration vs the 8 TB/s HBM peak; roofline_em: one EM round (LDS-resident: against the LDS pipe,
                         with the HBM-equivalent figure next to it); roofline_finalize: the EC resolution kernels
-  cpu_baseline       -- the unmodified reference (oracle/_ref/kallisto quant, built from /root/reference) on this box's host
-                        cores over a bounded sample of the same reads, same index file, split into pseudoalignment and EM seconds
+  cpu_baseline       -- the unmodified reference (oracle/_ref, built from /root/reference) on this box's host cores: the stage clocks of the
+                        full-size parity leg's own run (all pairs of the configuration, pseudoalignment and EM seconds); a run on a bounded sample of
+                        the same reads when that leg is off
   parity_check       -- the GPU path against the unmodified reference run deterministically (-t 1, oracle/_ref/dump_ec) on a
                         prefix of the same reads: EC multiset, flens, eff_length identical, est_counts / TPM <= 1e-4; `ok` gates on all
   parity_check_tail  -- the last pairs of the input, pseudoaligned as the final batch of a run over ALL pairs (record stream grown and
@@ -31,7 +32,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   end_to_end         -- the C++ front-end from FASTQ files (plain / BGZF / gzip; 8 M pairs, and plain_full_size*: all 30 M), input -> ECs
                         and whole-run rates, index load stated
   bootstrap          -- (--bootstraps B) BASELINE config #5: B replicates of multinomial resample + EM
-`--workload yeast` is BASELINE config #2 (10 M single-end reads, ~6 k transcripts).
+  stress             -- a child run of `--workload stress` (a transcriptome with repeat families, paralog families and poly-A tails; 12 % off-transcriptome
+                        pairs; a 3' quality tail) on 8 M pairs with ALL of them through the reference: its figures, parity verdict and CPU baseline
+  gencode_size       -- a child run on a GENCODE-sized index (46 000 genes: ~444 k transcripts), prefix and tail parity
+`--workload yeast` is BASELINE config #2 (10 M single-end reads, ~6 k transcripts); `--workload stress` the stress workload on its own.
+N > 1 (no flags needed): `multi_rank_parity` (the merged result of the ranks on 200 k pairs per rank against the reference), a `cpu_baseline`,
+`breakdown_ms.collective_ms`.
 """
 from __future__ import annotations
 
