@@ -1425,12 +1425,7 @@ def main():
                                    "note": "measured at the full size of the configuration, not projected from a sample (VERDICT r4); the reference's EM is single-threaded"}
         elif cpu_from_full and "cpu_baseline" not in out:
             out["cpu_baseline"] = {"value": None, "unit": rate_unit, "cores": min(effective_cpus(), 64), "kind": "reference", "sample": "failed: " + str(fp.get("error", "no stage clocks"))[:200]}
-    gencode_prep = None
     want_gencode = rank == 0 and world == 1 and args.workload == "human" and not args.no_gencode_leg and genes == 20000 and n_arg == n_default
-    if want_gencode and time.time() - t_start < budget_s - 120:
-        # the GENCODE-sized index is built by the reference (`kallisto index`, about a minute on these hosts) in the background of what follows: the
-        # full-size reference run is in its single-threaded EM by now and leaves the other cores idle
-        gencode_prep = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--prepare-only", "--genes", str(GENCODE_GENES)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if rank == 0 and world == 1 and args.workload == "human" and not args.no_stress_leg and genes == 20000 and n_arg == n_default:
         if time.time() - t_start > budget_s - 30:
             out["stress"] = {"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S)"}
@@ -1440,20 +1435,19 @@ def main():
                 log("full-size parity: waiting for the reference ...")
                 attach_full(full_parity.finish())
                 full_parity = None
-            if gencode_prep is not None:   # (the background index build had the cores the reference's single-threaded EM left idle; the stress leg wants them all)
-                try:
-                    gencode_prep.wait(timeout=300)
-                except subprocess.TimeoutExpired:
-                    pass
             out["stress"] = stress_leg(timeout_s=max(120.0, budget_s + 360 - (time.time() - t_start)))
     if want_gencode:
-        if gencode_prep is None or time.time() - t_start > budget_s + 60:
+        if time.time() - t_start > budget_s + 60:
             out["gencode_size"] = {"skipped": f"{time.time() - t_start:.0f} s into the run (budget {budget_s:.0f} s, KAMD_BENCH_BUDGET_S); builder-side figures: profiles/r05_bench_gencode_size.json"}
-            if gencode_prep is not None:
-                gencode_prep.kill()
         else:
+            # (its index is built by the reference inside the child, ~70 s on all cores: only once the full-size reference run -- whose stage clocks are
+            # the CPU baseline -- has finished; a first version prepared it in the background of that run's single-threaded EM and slowed it by 40 %)
+            if full_parity is not None:
+                log("full-size parity: waiting for the reference ...")
+                attach_full(full_parity.finish())
+                full_parity = None
             log("GENCODE-sized index (46 000 genes) as a child run ...")
-            out["gencode_size"] = gencode_leg(gencode_prep, timeout_s=max(120.0, budget_s + 420 - (time.time() - t_start)))
+            out["gencode_size"] = gencode_leg(None, timeout_s=max(120.0, budget_s + 480 - (time.time() - t_start)))
     if rank == 0 and world == 1 and e2e_sample is not None:
         log(f"end to end: kallisto_amd_quant from FASTQ ({e2e_sample[0].shape[0]} {unit_name}) ...")
         if full_parity is not None:   # (the reference's single-threaded EM may still be running: the end-to-end legs want the host to themselves)
