@@ -683,7 +683,9 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
   struct BlockTmp { uint32_t lb, ub; uint64_t set_off; uint32_t set_len; uint64_t hash; uint64_t pos_off; };   // offsets into the arena
   struct NodeTmp { uint32_t gid; uint32_t n_blocks; uint64_t first_block; };
   struct Arena { std::vector<BlockTmp> blocks; std::vector<uint32_t> sets, posw; std::vector<uint8_t> sense; std::string err; };
-  const int nth = std::max(1, std::min(threads, 32));
+  // (KAMD_INDEX_DECODE_THREADS: experiments -- the count pass of the k-mer table runs on `threads` workers in the background meanwhile)
+  int nth = std::max(1, std::min(threads, 32));
+  if (const char* e = getenv("KAMD_INDEX_DECODE_THREADS")) nth = std::max(1, std::min(atoi(e), 64));
   std::vector<Arena> arenas((size_t)nth);
   std::vector<NodeTmp> nodes(n_nodes);
   {
@@ -775,6 +777,8 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
       std::stable_sort(bl.begin(), bl.end(), [](const RawBlock& a, const RawBlock& b) { return a.lb < b.lb; });
     }
   }
+  // (the decode arenas hold every block's set, positions and senses once more: freed here, not at the end of the load -- ADVICE r4)
+  { std::vector<Arena>().swap(arenas); std::vector<NodeTmp>().swap(nodes); std::vector<NodeExt>().swap(ext); }
   tick("node records");
   // flatten blocks; assign (unitig, set) classes
   ix->unitig_blk_off.assign(ix->n_unitigs + 1, 0);
