@@ -378,11 +378,19 @@ class Context:
                 keep.append((pad.to(dev), len(t)))
             else:
                 assert t.dtype == torch.uint8 and t.is_cuda
-                # the ABI wants the text readable up to 32 bytes behind n_bytes (k_fq_pack loads whole groups of 32 bases): a caller's
-                # exactly-sized tensor is copied into a padded one rather than read past its allocation
-                pad = torch.zeros(t.numel() + 64, dtype=torch.uint8, device=t.device)
-                pad[:t.numel()] = t.reshape(-1)
-                keep.append((pad, t.numel()))
+                # the ABI wants the text readable up to 32 bytes behind n_bytes (k_fq_pack loads whole groups of 32 bases).  A tensor that is a
+                # view of a larger storage with that much behind it -- a unit cut out of a device text buffer -- is passed as it is; only an
+                # exactly-sized one is copied into a padded tensor rather than read past its allocation (the copy was unconditional,
+                # a device-to-device copy of every text unit)
+                n = t.numel()
+                flat = t.reshape(-1)
+                slack = flat.untyped_storage().nbytes() - (flat.storage_offset() + n) if flat.is_contiguous() else -1
+                if slack >= 32 and flat.data_ptr() % 16 == 0:
+                    keep.append((flat, n))
+                else:
+                    pad = torch.zeros(n + 64, dtype=torch.uint8, device=t.device)
+                    pad[:n] = flat
+                    keep.append((pad, n))
         ptrs = (C.c_void_p * 2)(*[k[0].data_ptr() for k in keep], *([None] * (2 - len(keep))))
         nb = (C.c_uint64 * 2)(*[k[1] for k in keep], *([0] * (2 - len(keep))))
         return keep, ptrs, nb

@@ -39,6 +39,27 @@ def test_single_unit_equals_host_packer(ctx, crlf):
     assert np.array_equal(l.cpu().numpy(), el) and np.array_equal(w.cpu().numpy(), ew)
 
 
+def test_unit_as_a_view_of_a_device_text_buffer(ctx):
+    """A unit handed over as a uint8 device tensor: an exactly-sized tensor is copied into a padded one (the packer reads up to 32 bytes behind the
+    text), a VIEW of a larger buffer -- what a front-end cuts out of its device text ring, here with junk behind the unit -- is passed as it is
+    (no device-to-device copy of the text).  Both give what the bytes give."""
+    import torch
+    reads = _reads(5000, 17, lo=1, hi=150, n_frac=0.05)
+    text = _fastq_bytes(reads)
+    ew, el, emx = _expect(ctx, reads)
+    exact = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    ring = torch.full((len(text) + 4096,), ord("A"), dtype=torch.uint8, device="cuda")
+    ring[:len(text)] = exact
+    for t in (exact, ring[:len(text)]):
+        w, l, n, mx, st, bad = ctx.fastq_unit_pack([t], len(reads))
+        assert st == 0 and n == len(reads) and mx == emx
+        assert np.array_equal(l.cpu().numpy(), el) and np.array_equal(w.cpu().numpy(), ew)
+    keep, ptrs, nb = ctx._fastq_texts([ring[:len(text)]])
+    assert keep[0][0].data_ptr() == ring.data_ptr()          # the view itself went down, not a copy
+    keep, ptrs, nb = ctx._fastq_texts([exact])
+    assert keep[0][0].data_ptr() != exact.data_ptr() or exact.untyped_storage().nbytes() >= len(text) + 32
+
+
 def test_paired_unit_interleaves_the_mates(ctx):
     r1, r2 = _reads(20000, 12), _reads(20000, 13, lo=30, hi=101)
     w, l, n, mx, st, _ = ctx.fastq_unit_pack([_fastq_bytes(r1), _fastq_bytes(r2, tricky_quals=False)], len(r1))
