@@ -736,8 +736,9 @@ def self_launch(n_gpus: int) -> int:
             print(f"bench.py: --gpus {n_gpus} but this node shows {have} GPU(s) (KAMD_BENCH_SHARE_GPU=1 puts all ranks on GPU 0 over gloo: a "
                   f"smoke test only)", file=sys.stderr)
             return 2
-    # two attempts must fit the driver's 1 800 s: 700 s each by default (a full N-GPU line takes about 3 minutes on one GPU's worth of work per rank)
-    limit = float(os.environ.get("KAMD_BENCH_LAUNCH_TIMEOUT_S", "700"))
+    # two attempts must fit the driver's 1 800 s: 850 s each by default (an N-GPU line is about a minute of index building, a minute of work per
+    # rank and, at N = 8, two to three minutes of the reference at -t 1 on the 1.6 M pairs of the default parity leg)
+    limit = float(os.environ.get("KAMD_BENCH_LAUNCH_TIMEOUT_S", "850"))
     attempts = [{}] if (share or os.environ.get("KAMD_COMM") == "callbacks") else [{}, {"KAMD_COMM": "callbacks"}]
     rc = 1
     for extra in attempts:
