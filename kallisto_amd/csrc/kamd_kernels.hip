@@ -4909,9 +4909,44 @@ __global__ void k_eml_init(double* alpha, double* a, const double* __restrict__ 
   if (m < M) { alpha[m] = a0; a[m] = a0 / eff_m[m]; }
 }
 // the data-parallel steps of kamd_em_local.h, one thread per index
+// step F (kamd_em_local.h step_tr_f) with the slot hand-out aggregated per wavefront: the transcripts of a gene are neighbours in
+// transcript space and belong to one group, so the 64 lanes of a wavefront used to queue 64 atomics on ONE group counter (~12 ns each at
+// the memory side: 163 us for config #3's 192 669 transcripts); here the lanes that share the leader's group take consecutive slots from
+// one atomic.  The order inside a group changes, the result does not: step F2 ranks the members (canonical numbering).
+__device__ __forceinline__ void eml_step_tr_f_wave(u64 t, const kamd_em_local::BuildArgs& A) {
+  const bool act = t < A.T && A.in_multi[t];
+  const u32 g = act ? kamd_em_local::eml_group_of(A, A.label[t]) : 0xFFFFFFFFu;
+  u64 m = __ballot(act);
+  const u64 lt = (1ULL << lane_id()) - 1ULL;
+  while (m) {
+    const int leader = __ffsll((long long)m) - 1;
+    const u32 lg = (u32)__shfl((int)g, leader, 64);
+    const u64 same = __ballot(act && g == lg);
+    u32 base = 0;
+    if (lane_id() == leader) base = atomicAdd(&A.tr_fill[lg], (u32)__popcll(same));
+    base = (u32)__shfl((int)base, leader, 64);
+    if (act && g == lg) A.tmp_tr_id[(u64)A.tr_base[lg] + base + (u32)__popcll(same & lt)] = (u32)t;
+    m &= ~same;
+  }
+}
+// step B (step_tr_b) the same way: one atomic per (wavefront, component) instead of one per transcript
+__device__ __forceinline__ void eml_step_tr_b_wave(u64 t, const kamd_em_local::BuildArgs& A) {
+  const bool act = t < A.T && A.in_multi[t];
+  const u32 r = act ? A.label[t] : 0xFFFFFFFFu;
+  u64 m = __ballot(act);
+  while (m) {
+    const int leader = __ffsll((long long)m) - 1;
+    const u32 lr = (u32)__shfl((int)r, leader, 64);
+    const u64 same = __ballot(act && r == lr);
+    if (lane_id() == leader) atomicAdd(&A.c_tr[lr], (u32)__popcll(same));
+    m &= ~same;
+  }
+}
 template <int S>
 __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (S == 1) { eml_step_tr_b_wave(i < n ? i : ~0ULL, A); return; }
+  if constexpr (S == 3) { eml_step_tr_f_wave(i < n ? i : ~0ULL, A); return; }
   if (i >= n) return;
   if constexpr (S == 0) kamd_em_local::step_rows_a(i, A);
   else if constexpr (S == 1) kamd_em_local::step_tr_b(i, A);
