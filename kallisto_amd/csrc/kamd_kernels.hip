@@ -5575,12 +5575,22 @@ int gi_launch_chunk(GiantPart& G, int n, int clamp, int pin, int pout, int* d_h,
   hipLaunchKernelGGL(k_gi_set_desc, dim3(1), dim3(64), 0, G.stream, G.desc, prev, d_h);
   if (G.use_graph && n == EML_MAX_ROUNDS && !clamp && pin != pout) {
     if (!G.gexec[pin]) {
-      HIPC(hipStreamBeginCapture(G.stream, hipStreamCaptureModeThreadLocal));
-      gi_enqueue_rounds(G, G.stream, n, 0, pin, pout);
-      HIPC(hipStreamEndCapture(G.stream, &G.graph[pin]));
-      HIPC(hipGraphInstantiate(&G.gexec[pin], G.graph[pin], nullptr, nullptr, 0));
+      // a capture that cannot be completed must not leave the stream capturing or a half-built graph behind: the chunk then goes out as
+      // plain launches (what use_graph == false does), for this and every later chunk of the plan
+      hipError_t e = hipStreamBeginCapture(G.stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        gi_enqueue_rounds(G, G.stream, n, 0, pin, pout);
+        e = hipStreamEndCapture(G.stream, &G.graph[pin]);   // (ends the capture on failure too)
+      }
+      if (e == hipSuccess) e = hipGraphInstantiate(&G.gexec[pin], G.graph[pin], nullptr, nullptr, 0);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        G.drop_graphs();
+        G.use_graph = false;
+      }
     }
-    HIPC(hipGraphLaunch(G.gexec[pin], G.stream));
+    if (G.use_graph) { HIPC(hipGraphLaunch(G.gexec[pin], G.stream)); }
+    else gi_enqueue_rounds(G, G.stream, n, clamp, pin, pout);
   } else gi_enqueue_rounds(G, G.stream, n, clamp, pin, pout);
   HIPC(hipGetLastError());
   return 0;
