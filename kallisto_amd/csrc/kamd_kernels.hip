@@ -5577,11 +5577,13 @@ int gi_launch_chunk(GiantPart& G, int n, int clamp, int pin, int pout, int* d_h,
     if (!G.gexec[pin]) {
       // a capture that cannot be completed must not leave the stream capturing or a half-built graph behind: the chunk then goes out as
       // plain launches (what use_graph == false does), for this and every later chunk of the plan
+      static const bool inject = getenv("KAMD_DEBUG_GRAPH_FAIL") != nullptr;   // (tests: the graph of the SECOND parity cannot be instantiated)
       hipError_t e = hipStreamBeginCapture(G.stream, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
         gi_enqueue_rounds(G, G.stream, n, 0, pin, pout);
         e = hipStreamEndCapture(G.stream, &G.graph[pin]);   // (ends the capture on failure too)
       }
+      if (e == hipSuccess && inject && G.gexec[pin ^ 1]) e = hipErrorOutOfMemory;
       if (e == hipSuccess) e = hipGraphInstantiate(&G.gexec[pin], G.graph[pin], nullptr, nullptr, 0);
       if (e != hipSuccess) {
         (void)hipGetLastError();

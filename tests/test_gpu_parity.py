@@ -297,7 +297,7 @@ def _hybrid_csr(n_genes, seed, n_chained=500):
 
 
 @pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
-                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_hot", "hybrid_k8_hot", "hub_hot", "hybrid_nograph_hot"])
+                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_hot", "hybrid_k8_hot", "hub_hot", "hybrid_nograph_hot", "hybrid_graphfail"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -313,6 +313,11 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
         # from a million entries on, forced here on the small matrices
         monkeypatch.setenv("KAMD_EM_HOT", "1")
         k = k[:-4]
+    if k == "hybrid_graphfail":
+        # the chunk graph of one ping-pong parity exists, the other one's cannot be instantiated: both are dropped, this chunk and the later ones go out
+        # as plain launches
+        monkeypatch.setenv("KAMD_DEBUG_GRAPH_FAIL", "1")
+        k = "hybrid"
     if isinstance(k, str) and k.endswith("_fix"):
         # rows / columns that cross into a chunk with more than 256 entries are re-read by the chunk in a loop (round 5); the fix-up launches
         # they needed before remain for segments beyond 32 768 entries -- forced here for all of them
