@@ -4942,6 +4942,43 @@ __device__ __forceinline__ void eml_step_tr_b_wave(u64 t, const kamd_em_local::B
     m &= ~same;
   }
 }
+// step G (step_rows_g) with the row slots of a group reserved per WORKGROUP: the rows of a group arrive from everywhere in EC order, so a wavefront
+// cannot aggregate them, and one returning atomic per row on the groups' few hundred counters serializes at the memory side (config #3: 618 012
+// rows on 505 counters, 193 us).  Here a workgroup counts its 4 096 rows per group in LDS, takes one range per (workgroup, group) and hands the
+// slots of the range out by the LDS ranks.  As with steps B / F the arrival order changes and the result does not (step G2 ranks the rows).
+constexpr int RG_BLOCK = 1024, RG_PER = 4, RG_BINS = 8192;
+__global__ __launch_bounds__(RG_BLOCK) void k_eml_rows_g(kamd_em_local::BuildArgs A) {
+  __shared__ u32 bin[RG_BINS];   // rows of this workgroup in the group, then the first slot of its range
+  const u32 tid = threadIdx.x;
+  for (u32 i = tid; i < A.n_groups; i += RG_BLOCK) bin[i] = 0;
+  __syncthreads();
+  u32 g[RG_PER], loc[RG_PER]; u64 key[RG_PER];
+  const u64 e0 = (u64)blockIdx.x * (RG_BLOCK * RG_PER) + tid;
+#pragma unroll
+  for (int j = 0; j < RG_PER; j++) {
+    const u64 e = e0 + (u64)j * RG_BLOCK;
+    g[j] = 0xFFFFFFFFu; loc[j] = 0; key[j] = 0;
+    if (e >= A.n_ecs) continue;
+    const u64 a = A.ec_off[e], b = A.ec_off[e + 1];
+    if (b - a < 2) continue;
+    const u32 first = A.ec_ids[a];
+    g[j] = kamd_em_local::eml_group_of(A, A.label[first]);
+    loc[j] = atomicAdd(&bin[g[j]], 1u);
+    u64 h = 0x9E3779B97F4A7C15ULL;   // (the row's content key, as step_rows_g computes it)
+    for (u64 q = a; q < b; q++) { h ^= A.ec_ids[q]; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 29; }
+    key[j] = ((u64)A.local_of[first] << 48) | (h >> 16);
+  }
+  __syncthreads();
+  for (u32 i = tid; i < A.n_groups; i += RG_BLOCK) { const u32 n = bin[i]; if (n) bin[i] = atomicAdd(&A.row_fill[i], n); }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RG_PER; j++) {
+    if (g[j] == 0xFFFFFFFFu) continue;
+    const u32 rn = A.row_base[g[j]] + bin[g[j]] + loc[j];
+    A.row_key[rn] = key[j];
+    A.row_e[rn] = (u32)(e0 + (u64)j * RG_BLOCK);
+  }
+}
 template <int S>
 __global__ void k_eml_step(kamd_em_local::BuildArgs A, u64 n) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -5111,12 +5148,23 @@ __global__ __launch_bounds__(BLOCK) void k_eml_group_build(kamd_em_local::BuildA
 // component-local form as a whole; stats[0..2], zeroed by the caller
 struct CompStats { u32 max_nnz, max_rows, max_tr, pad; };
 __global__ void k_comp_stats(const u32* __restrict__ c_nnz, const u32* __restrict__ c_rows, const u32* __restrict__ c_tr, u64 T, u32* stats) {
-  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u32 v0 = r < T ? c_nnz[r] : 0u, v1 = (r < T && c_rows) ? c_rows[r] : 0u, v2 = (r < T && c_tr) ? c_tr[r] : 0u;
+  // (grid-stride over at most COMP_STATS_BLOCKS workgroups, and a wavefront whose maximum is not above the published one skips the atomic: one
+  // atomic per wavefront on three words of one line was 3 010 serialized atomics per word for config #3's 192 669 transcripts -- 105 us)
+  u32 v0 = 0, v1 = 0, v2 = 0;
+  for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < T; r += (u64)gridDim.x * blockDim.x) {
+    v0 = max(v0, c_nnz[r]);
+    if (c_rows) v1 = max(v1, c_rows[r]);
+    if (c_tr) v2 = max(v2, c_tr[r]);
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { v0 = max(v0, (u32)__shfl_down(v0, d, 64)); v1 = max(v1, (u32)__shfl_down(v1, d, 64)); v2 = max(v2, (u32)__shfl_down(v2, d, 64)); }
-  if (lane_id() == 0) { if (v0) atomicMax(&stats[0], v0); if (v1) atomicMax(&stats[1], v1); if (v2) atomicMax(&stats[2], v2); }
+  if (lane_id() == 0) {
+    if (v0 > __atomic_load_n(&stats[0], __ATOMIC_RELAXED)) atomicMax(&stats[0], v0);
+    if (v1 > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], v1);
+    if (v2 > __atomic_load_n(&stats[2], __ATOMIC_RELAXED)) atomicMax(&stats[2], v2);
+  }
 }
+constexpr unsigned COMP_STATS_BLOCKS = 512;
 int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, u64 T) {
   if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
@@ -5163,7 +5211,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   // the largest component, read back with the entry count below (same synchronisation)
   CompStats cst{};
   HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(CompStats), c->stream));
-  hipLaunchKernelGGL(k_comp_stats, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A.c_nnz, A.c_rows, A.c_tr, T, (u32*)c->pt_hist.p);
+  hipLaunchKernelGGL(k_comp_stats, dim3(std::min<unsigned>(grid_for(T, BLOCK), COMP_STATS_BLOCKS)), dim3(BLOCK), 0, c->stream, A.c_nnz, A.c_rows, A.c_tr, T, (u32*)c->pt_hist.p);
   HIPC(hipMemcpyAsync(&cst, c->pt_hist.p, sizeof(CompStats), hipMemcpyDeviceToHost, c->stream));
   u64 NZ = 0;
   u32 ng = 0;
@@ -5243,7 +5291,8 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
     HIPC(hipFuncSetAttribute((const void*)k_eml_rank_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     hipLaunchKernelGGL(k_eml_rank_tr, dim3(ng), dim3(BLOCK), rk_lds, c->stream, A);
   } else hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
-  hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
+  if (A.n_groups <= (u32)RG_BINS && !getenv("KAMD_EM_PLAN_STEPS")) hipLaunchKernelGGL(k_eml_rows_g, dim3(grid_for(n_ecs, RG_BLOCK * RG_PER)), dim3(RG_BLOCK), 0, c->stream, A);
+  else hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   if (lds_rank) hipLaunchKernelGGL(k_eml_rank_rows, dim3(ng), dim3(EML_RANK_BLOCK), rk_lds, c->stream, A);
   else hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
   // steps I, J, K, K2 and their scans: one workgroup per group out of LDS (k_eml_group_build); a group too large for that -- none
@@ -6110,7 +6159,7 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     CompStats cs{};
     if (int rc = c->pt_hist.ensure(64, 0, c->stream)) return rc;
     HIPC(hipMemsetAsync(c->pt_hist.p, 0, sizeof(CompStats), c->stream));
-    hipLaunchKernelGGL(k_comp_stats, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c_nnz, (const u32*)nullptr, (const u32*)nullptr, T, (u32*)c->pt_hist.p);
+    hipLaunchKernelGGL(k_comp_stats, dim3(std::min<unsigned>(grid_for(T, BLOCK), COMP_STATS_BLOCKS)), dim3(BLOCK), 0, c->stream, c_nnz, (const u32*)nullptr, (const u32*)nullptr, T, (u32*)c->pt_hist.p);
     HIPC(hipMemcpyAsync(&cs, c->pt_hist.p, sizeof(CompStats), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     c->last_em_max_comp_nnz = cs.max_nnz;
