@@ -5148,7 +5148,7 @@ __global__ __launch_bounds__(BLOCK) void k_eml_group_build(kamd_em_local::BuildA
 // component-local form as a whole; stats[0..2], zeroed by the caller
 struct CompStats { u32 max_nnz, max_rows, max_tr, pad; };
 __global__ void k_comp_stats(const u32* __restrict__ c_nnz, const u32* __restrict__ c_rows, const u32* __restrict__ c_tr, u64 T, u32* stats) {
-  // (grid-stride over at most COMP_STATS_BLOCKS workgroups, and a wavefront whose maximum is not above the published one skips the atomic: one
+  // (grid-stride over at most COMP_STATS_BLOCKS workgroups, one atomic per workgroup and none if its maximum is not above the published one: one
   // atomic per wavefront on three words of one line was 3 010 serialized atomics per word for config #3's 192 669 transcripts -- 105 us)
   u32 v0 = 0, v1 = 0, v2 = 0;
   for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < T; r += (u64)gridDim.x * blockDim.x) {
@@ -5156,15 +5156,20 @@ __global__ void k_comp_stats(const u32* __restrict__ c_nnz, const u32* __restric
     if (c_rows) v1 = max(v1, c_rows[r]);
     if (c_tr) v2 = max(v2, c_tr[r]);
   }
+  __shared__ u32 red[3][BLOCK / 64];
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { v0 = max(v0, (u32)__shfl_down(v0, d, 64)); v1 = max(v1, (u32)__shfl_down(v1, d, 64)); v2 = max(v2, (u32)__shfl_down(v2, d, 64)); }
-  if (lane_id() == 0) {
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 0) { red[0][w] = v0; red[1][w] = v1; red[2][w] = v2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) { v0 = max(v0, red[0][i]); v1 = max(v1, red[1][i]); v2 = max(v2, red[2][i]); }
     if (v0 > __atomic_load_n(&stats[0], __ATOMIC_RELAXED)) atomicMax(&stats[0], v0);
     if (v1 > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], v1);
     if (v2 > __atomic_load_n(&stats[2], __ATOMIC_RELAXED)) atomicMax(&stats[2], v2);
   }
 }
-constexpr unsigned COMP_STATS_BLOCKS = 512;
+constexpr unsigned COMP_STATS_BLOCKS = 256;
 int cc_labels(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, u64 n_ecs, u64 T) {
   if (int rc = c->pt_label.ensure((T + 1) * sizeof(u32), 0, c->stream)) return rc;
   hipLaunchKernelGGL(k_cc_init, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, c->pt_label.as<u32>(), T);
