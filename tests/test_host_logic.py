@@ -514,3 +514,32 @@ def test_gene_level_outputs_of_quant_tcc(tmp_path):
     open(bad, "w").write("no_such_transcript\tG1\n")
     assert L.fe_gene_outputs(bad.encode(), "\n".join(names).encode(), C.c_uint64(len(names)), alpha.ctypes.data_as(C.c_void_p), tpm.ctypes.data_as(C.c_void_p),
                              tsv.encode(), nm.encode(), None, err, C.c_uint64(512)) == -1 and b"Invalid transcript" in err.value
+
+
+def test_ctypes_mirrors_match_the_header(tmp_path):
+    """The structures of include/kallisto_amd.h as the C compiler lays them out against their ctypes mirrors in kallisto_amd/api.py: same size, every field
+    at the same offset under the same name.  (The library writes kamd_profile / kamd_align_stats through the caller's pointer: a mirror that is a field short
+    is a write behind the end of a Python object.)"""
+    import ctypes
+    import subprocess
+    from kallisto_amd import api
+    pairs = [("kamd_index_view", api._View), ("kamd_quant_opts", api.QuantOpts), ("kamd_align_stats", api._Stats), ("kamd_tuning", api.Tuning),
+             ("kamd_profile", api._Profile), ("kamd_fastq_unit", api._FastqUnit), ("kamd_batch", api._Batch), ("kamd_quant_out", api._QuantOut),
+             ("kamd_ec_result", api._EcResult), ("kamd_comm_callbacks", api._CommCallbacks)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ['#include <stddef.h>', '#include <stdio.h>', '#include "kallisto_amd.h"', 'int main(void) {']
+    for cname, mirror in pairs:
+        src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            src.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src += ['  return 0;', '}']
+    c_file = tmp_path / "layout.c"
+    c_file.write_text("\n".join(src) + "\n")
+    exe = tmp_path / "layout"
+    p = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]       # (a field name the header does not have fails here)
+    got = dict(line.split() for line in subprocess.run([str(exe)], stdout=subprocess.PIPE, check=True).stdout.decode().splitlines())
+    for cname, mirror in pairs:
+        assert int(got[cname]) == ctypes.sizeof(mirror), (cname, got[cname], ctypes.sizeof(mirror))
+        for fname, _ in mirror._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, (cname, fname)
