@@ -543,3 +543,21 @@ def test_ctypes_mirrors_match_the_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(mirror), (cname, got[cname], ctypes.sizeof(mirror))
         for fname, _ in mirror._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, (cname, fname)
+
+
+def test_ctypes_bindings_cover_the_header_with_the_same_arity():
+    """every function include/kallisto_amd.h declares has a ctypes binding in kallisto_amd/api.py with as many arguments (and no binding names a function the
+    header does not declare)"""
+    import re
+    from kallisto_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = open(os.path.join(root, "include", "kallisto_amd.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    h = re.sub(r"//[^\n]*", "", h)
+    protos = {}
+    for m in re.finditer(r"\b(kamd_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(re.split(r",(?![^()]*\))", args))
+    assert len(protos) >= 60
+    assert set(protos) == set(api._SYMBOLS)
+    assert {k: len(v[1]) for k, v in api._SYMBOLS.items()} == protos
