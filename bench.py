@@ -658,16 +658,146 @@ def bench_line_digest(d):
     return keep
 
 
+CONTRACT_MAX_BYTES = 4096   # the driver keeps a bounded tail of stdout: the round-5 line (24.9 KB) did not survive it
+
+
+def _num(x, nd=5):
+    """a figure for the contract line: ints and bools as they are, floats rounded, everything else dropped"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        return float(f"{float(x):.{nd + 2}g}") if abs(float(x)) < 1 else round(float(x), nd)
+    return None
+
+
+def _figures(d, keys):
+    """the named keys of a block, numbers and short strings only (no prose: `note`, `launch`, nested tables stay in the detail file)"""
+    o = {}
+    for k in keys:
+        v = (d or {}).get(k)
+        if isinstance(v, str):
+            o[k] = v[:96]
+        elif v is not None or k in ("traffic", "value"):
+            o[k] = _num(v)
+    return o
+
+
+def _ok(block):
+    """verdict of a parity block: True / False, None when the leg did not run"""
+    if not isinstance(block, dict) or "ok" not in block:
+        return None
+    return bool(block["ok"])
+
+
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "launch_ms")
+
+
+def contract_line(out: dict, detail_path: str | None = None) -> str:
+    """THE line rank 0 prints: the contract's fields + `roofline` + `cpu_baseline` + verdicts, figures only, at most CONTRACT_MAX_BYTES bytes.
+    Everything else bench.py measures (notes, child legs, end-to-end table, layouts, counters) is the *detail* -- bench_detail.json beside this
+    file and stderr --, never this line (VERDICT r5 "next round" #1).  `out` is the detail dictionary."""
+    cfg = out.get("config") or {}
+    unit_key = next((k for k in cfg if k.endswith("_per_gpu")), "pairs_per_gpu")
+    line = {k: (out.get(k)[:120] if isinstance(out.get(k), str) else out.get(k))
+            for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload") or "")[:200], unit_key: cfg.get(unit_key), "read_len": cfg.get("read_len"),
+                      "targets": cfg.get("targets"), "kmers": cfg.get("kmers"), "parallelism": str(cfg.get("parallelism_short") or cfg.get("parallelism") or "")[:80],
+                      "n_ranks_seen": cfg.get("n_ranks_seen"), "collective_backend": cfg.get("collective_backend")}
+    rf = out.get("roofline") or {}
+    line["roofline"] = _figures(rf, ROOF_KEYS)
+    if isinstance(rf.get("random_line_ceiling"), dict) and "frac" in rf["random_line_ceiling"]:
+        line["roofline"]["frac_of_random_line_rate"] = _num(rf["random_line_ceiling"]["frac"])
+    for k in ("roofline_em", "roofline_finalize"):
+        if isinstance(out.get(k), dict):
+            line[k] = _figures(out[k], ROOF_KEYS + (("rounds", "nnz") if k == "roofline_em" else ()))
+            line[k]["kernel"] = str(out[k].get("kernel_short") or out[k].get("kernel") or "")[:48]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _figures(cb, ("value", "unit", "cores", "kind", "pseudoalign_seconds", "em_seconds", "index_load_seconds"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:160]
+    bd = out.get("breakdown_ms")
+    if isinstance(bd, dict):
+        line["breakdown_ms"] = {k: _num(v, 3) for k, v in list(bd.items())[:16] if isinstance(v, (int, float)) and not isinstance(v, bool)}
+    ct = out.get("counters") or {}
+    line["counters"] = {k: _num(ct.get(k), 4) for k in ("probes_per_pair", "bucket_reads_per_pair", "text_answers_per_pair", "lane_utilisation", "final_ecs", "em_rounds",
+                                                        "overflow_share") if k in ct}
+    st, gc, mp = out.get("stress"), out.get("gencode_size"), out.get("multi_rank_parity")
+    line["parity"] = {"prefix_ok": _ok(out.get("parity_check")), "tail_ok": _ok(out.get("parity_check_tail")), "full_size_ok": _ok(out.get("parity_check_full_size")),
+                      "stress_ok": (None if not isinstance(st, dict) or "value" not in st else
+                                    bool(all(_ok(st.get(k)) is not False for k in ("parity_check", "parity_check_tail", "parity_check_full_size")) and
+                                         any(_ok(st.get(k)) for k in ("parity_check", "parity_check_full_size")))),
+                      "gencode_ok": (None if not isinstance(gc, dict) or "value" not in gc else
+                                     bool(_ok(gc.get("parity_check")) and _ok(gc.get("parity_check_tail")) is not False)),
+                      **({"multi_rank_ok": _ok(mp)} if isinstance(mp, dict) else {})}
+    fp = out.get("parity_check_full_size")
+    if isinstance(fp, dict) and fp.get("ok") is not None:
+        line["parity"]["full_size"] = {k: fp.get(k) for k in ("pairs_or_reads", "n_ecs", "em_rounds") if k in fp}
+        line["parity"]["full_size"]["est_counts_max_rel_err"] = _num(fp.get("est_counts_max_rel_err_tpm_ge_1e-3"))
+    for k, leg in (("stress", st), ("gencode_size", gc), ("config2", out.get("config2"))):
+        if isinstance(leg, dict):
+            line[k] = ({"value": _num(leg.get("value")), "ms_per_step": _num(leg.get("ms_per_step"), 3), "unit": str(leg.get("unit") or "")[:24],
+                        "roofline_frac": _num((leg.get("roofline") or {}).get("frac")), "cpu_baseline": _num((leg.get("cpu_baseline") or {}).get("value"))}
+                       if "value" in leg else {"skipped": str(leg.get("skipped") or leg.get("error") or "")[:100]})
+    bs = out.get("bootstrap")
+    if isinstance(bs, dict):
+        line["bootstrap"] = _figures(bs, ("replicates", "seconds", "replicates_per_s")) if "seconds" in bs else {"error": str(bs.get("error"))[:100]}
+    if isinstance(out.get("other_scaling"), dict):
+        line["other_scaling"] = _figures(out["other_scaling"], ("scaling", "pairs_per_gpu", "value", "unit", "ms_per_step"))
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("counters", "config2", "bootstrap", "other_scaling", "roofline_finalize", "breakdown_ms", "roofline_em"):   # never reached with today's fields; a bound, not a plan
+        if len(text) <= CONTRACT_MAX_BYTES:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > CONTRACT_MAX_BYTES:
+        raise RuntimeError(f"contract line of {len(text)} bytes")
+    return text
+
+
+def write_detail(out: dict, path: str | None = None):
+    """the lab notebook: everything the run measured, as one JSON document in a file (and nothing of it on stdout).  Returns the path, relative to ROOT."""
+    path = path or os.environ.get("KAMD_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path + ".tmp", "w") as f:
+            json.dump(out, f, indent=1)
+        os.replace(path + ".tmp", path)
+        side = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(side) and os.path.dirname(os.path.abspath(path)) != side:
+            shutil.copyfile(path, os.path.join(side, os.path.basename(path)))
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        log(f"detail file not written: {e}")
+        return None
+
+
+def run_child(cmd, timeout_s):
+    """a child run of this script: its DETAIL document (the child writes it to a file of its own; its stdout carries only the short line)"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="kamd_bench_child_", suffix=".json")
+    os.close(fd)
+    try:
+        pc = subprocess.run(cmd + ["--detail-file", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        if pc.returncode != 0:
+            raise RuntimeError(f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:])
+        return json.load(open(path))
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
 def config2_leg(timeout_s=900):
     """BASELINE config #2 (yeast-like transcriptome, 10 M single-end reads, --single -l 200 -s 20) as a child run of this script: its line, cut
     down to the figures, for the line of config #3.  Never raises."""
     try:
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", "yeast", "--steps", "5", "--warmup", "2", "--end-to-end", "0", "--no-pinned-pipeline",
                "--no-compact-leg", "--no-config2", "--bootstraps", "0"]
-        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-        if pc.returncode != 0:
-            return {"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}
-        keep = bench_line_digest(json.loads(pc.stdout.decode().strip().splitlines()[-1]))
+        keep = bench_line_digest(run_child(cmd, timeout_s))
         keep["command"] = "python bench.py " + " ".join(cmd[2:])
         return keep
     except Exception as e:   # noqa: BLE001
@@ -680,10 +810,7 @@ def stress_leg(timeout_s=900, pairs=8_000_000):
     try:
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--pairs", str(pairs), "--steps", "3", "--warmup", "1", "--end-to-end", "0",
                "--no-pinned-pipeline", "--no-compact-leg", "--no-config2", "--no-stress-leg", "--bootstraps", "0", "--full-parity", "on"]
-        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-        if pc.returncode != 0:
-            return {"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}
-        d = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+        d = run_child(cmd, timeout_s)
         keep = bench_line_digest(d)
         keep["roofline_em"] = {k: (d.get("roofline_em") or {}).get(k) for k in ("kernel", "bound", "achieved", "peak", "frac", "launch_ms", "rounds", "nnz", "rows")}
         keep["command"] = "python bench.py " + " ".join(cmd[2:])
@@ -703,10 +830,7 @@ def gencode_leg(prep, timeout_s=600):
             prep.wait(timeout=timeout_s)
         cmd = [sys.executable, os.path.abspath(__file__), "--genes", str(GENCODE_GENES), "--steps", "3", "--warmup", "1", "--end-to-end", "0", "--no-pinned-pipeline",
                "--no-compact-leg", "--no-config2", "--no-stress-leg", "--no-gencode-leg", "--bootstraps", "0", "--full-parity", "off", "--no-cpu-baseline"]
-        pc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-        if pc.returncode != 0:
-            return {"error": f"rc {pc.returncode}: " + pc.stderr.decode(errors="replace")[-400:]}
-        d = json.loads(pc.stdout.decode().strip().splitlines()[-1])
+        d = run_child(cmd, timeout_s)
         keep = bench_line_digest(d)
         keep["config"] = {k: (d.get("config") or {}).get(k) for k in ("targets", "kmers", "kmer_table")}
         keep["roofline_em"] = {k: (d.get("roofline_em") or {}).get(k) for k in ("kernel", "bound", "achieved", "peak", "frac", "launch_ms", "rounds", "nnz", "rows", "groups")}
@@ -748,6 +872,7 @@ def self_launch(n_gpus: int) -> int:
         env = dict(os.environ)
         env.update(extra)
         env["KAMD_BENCH_LAUNCHER"] = "self"
+        env.setdefault("KAMD_COMM_INIT_TIMEOUT_S", "180")   # (the library's watchdog over ncclCommInitRank is opt-in: only ranks started here may end their process)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
             env.setdefault("KAMD_BENCH_BACKEND", "gloo")
@@ -811,7 +936,8 @@ def main():
                          "(default: 100 on one GPU -- about a second --, 0 on several)")
     ap.add_argument("--in-flight", type=int, default=1, help="2: also measure two samples in flight on one GPU (two contexts / streams); reported "
                     "beside the headline value, never as it")
-    ap.add_argument("--end-to-end", type=int, default=8_000_000, help="run the C++ front-end from FASTQ files with this many pairs / reads (N = 1 only; 0 = skip)")
+    ap.add_argument("--end-to-end", type=int, default=None, help="run the C++ front-end from FASTQ files with this many pairs / reads (N = 1 only; 0 = skip; default: 0, "
+                    "8 M with --extras)")
     ap.add_argument("--no-pinned-pipeline", action="store_true")
     ap.add_argument("--no-multi-sample-parity", action="store_true", help="N > 1: skip the default parity leg (the merged result of the ranks on the first --parity-sample "
                     "pairs of every rank against the reference at -t 1) and the cpu_baseline it yields")
@@ -827,7 +953,14 @@ def main():
                     help="N = 1: the WHOLE input also goes through the unmodified reference (written as FASTQ while it is generated; oracle/_ref/dump_ec on all "
                          "cores in the background): EC multiset of the whole run, EM round count and abundances at full size; the same files feed the full-size "
                          "end-to-end legs.  auto = on for the full BASELINE configuration, off for reduced ones")
+    ap.add_argument("--extras", action="store_true", help="N = 1: also run the side measurements that are not part of the line (they go to the detail file): the pinned pipeline, "
+                    "the other k-mer table layouts (tools/compact_table_leg.py), BASELINE config #2 as a child run, the C++ front-end from FASTQ files (--end-to-end, 8 M pairs)")
+    ap.add_argument("--detail-file", default=None, help="where the detail document goes (default: bench_detail.json beside this script, or $KAMD_BENCH_DETAIL)")
     args = ap.parse_args()
+    if not args.extras:
+        args.no_compact_leg = args.no_config2 = args.no_pinned_pipeline = True
+    if args.end_to_end is None:
+        args.end_to_end = 8_000_000 if args.extras else 0
     if args.gpus > 1 and "RANK" not in os.environ and "LOCAL_RANK" not in os.environ:
         # `python bench.py --gpus N` from a bare shell: this process becomes the launcher of its own N ranks
         raise SystemExit(self_launch(args.gpus))
@@ -1036,6 +1169,7 @@ def main():
                                 **{k: rp[k] for k in ("ok", "ec_multiset_equal", "flens_equal", "eff_length_equal", "est_counts_max_rel_err_tpm_ge_1e-3",
                                                       "tpm_max_rel_err_tpm_ge_1e-3", "zero_pattern_equal", "sample", "reference_seconds", "n_pseudoaligned", "em_rounds_gpu") if k in rp}}
                 sample_cpu = {"value": round(rp["sample"] / max(rp["reference_seconds"], 1e-9) / 1e6, 4), "unit": "M read pairs/s" if paired else "M reads/s", "cores": 1,
+                              "sample_short": f"{rp['sample']} {'pairs' if paired else 'reads'} ({n_par}/rank), unmodified reference `quant -t 1` incl. index load, rank 0's host",
                               "kind": "reference", "processors_visible": os.cpu_count(),
                               "sample": f"the multi_rank_parity sample: {rp['sample']} {'pairs' if paired else 'reads'} ({n_par} per rank) as uncompressed FASTQ through the unmodified reference at "
                                         f"-t 1 (oracle/_ref/dump_ec quant: index load, ProcessReads, EMAlgorithm::run; {rp['reference_seconds']:.1f} s in all), on rank 0's host while the other "
@@ -1207,7 +1341,7 @@ def main():
             # 16-bit index per entry and direction out of LDS -- the bound is the LDS pipe, HBM only sees the per-launch load / store
             lds_bytes = 2 * pr["em_nnz"] * (8 + 2)
             lds_peak = 256 * 256 * 2.4   # GB/s: 256 CUs x 256 B/clk (ds_read_b64: 64 banks x 4 B, MI355X_MICROARCH.md LDS section) x 2.4 GHz
-            em_roof = {"kernel": "EM round inside k_em_sell (component-local, sliced ELLPACK in LDS)", "bound": "lds",
+            em_roof = {"kernel": "EM round inside k_em_sell (component-local, sliced ELLPACK in LDS)", "kernel_short": "k_em_sell (one EM round)", "bound": "lds",
                        "achieved": round(lds_bytes / (em_round_ms * 1e-3) / 1e9, 2), "peak": round(lds_peak, 1), "unit": "GB/s",
                        "frac": round(lds_bytes / (em_round_ms * 1e-3) / 1e9 / lds_peak, 5), "traffic": None,
                        "algorithmic_lds_bytes_per_round": int(lds_bytes),
@@ -1221,6 +1355,7 @@ def main():
             layout_bytes = pr["em_nnz_multi"] * 24 + pr["em_necs"] * 16 + T * 56
             em_roof = {"kernel": "EM round, hybrid: k_em_sell on the components that fit, k_gi_rows + k_gi_cols (+ fix-ups) on the oversized ones beside it" if pr["em_giant_nnz"] else
                                  "EM round (k_pm_rows_pass + k_pm_cols_pass)" if pr["em_k"] else "EM round (k_em_rows + k_em_seg + k_em_final)",
+                       "kernel_short": "hybrid EM round (k_em_sell + oversized side)" if pr["em_giant_nnz"] else "k_pm_rows_pass+k_pm_cols_pass" if pr["em_k"] else "k_em_rows+k_em_seg+k_em_final",
                        "bound": "hbm", "achieved": round(em_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(em_ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(em_bytes),
                        "layout_bytes_per_round": int(layout_bytes), "launch_ms": round(em_round_ms, 5), "rounds": int(em_iters[-1]),
@@ -1229,7 +1364,8 @@ def main():
         # one 32-byte table slot per record) + kamd_ec_finalize (the distinct tuples resolved, candidate sets written, merged, emitted)
         f_ms = float(np.mean(fin_ms)) + float(np.mean(abs_ms))
         fin_bytes = (4 * st["n_stream_words"] + 8 * n + 32 * st["n_multi"]) + (2 * 4 * pr["tuple_store_words"] + 32 * pr["fin_records"] + 3 * 4 * pr["fin_cand_words"])
-        fin_roof = {"kernel": "tuple de-duplication (k_tup_absorb, k_tup_store) + kamd_ec_finalize (k_bound_tuples, k_resolve, k_cand_singles, merge, CSR)", "bound": "hbm",
+        fin_roof = {"kernel": "tuple de-duplication (k_tup_absorb, k_tup_store) + kamd_ec_finalize (k_bound_tuples, k_resolve, k_cand_singles, merge, CSR)",
+                    "kernel_short": "tuple dedup + kamd_ec_finalize", "bound": "hbm",
                     "achieved": round(fin_bytes / (f_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(fin_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": int(fin_bytes), "launch_ms": round(f_ms, 3),
@@ -1269,6 +1405,12 @@ def main():
                               f"k={index.k}), {n} SE-{L} reads per GPU resident in HBM, --single -l 200 -s 20, full quant per step")
                              if (genes == (20000 if paired else 6000) and n_arg == n_default) or stress else
                              f"REDUCED {args.workload} genes={genes} {unit_name}={n} (not the BASELINE configuration)"),
+                "workload_short": ((f"stress (not a BASELINE config): {n} PE-{L} pairs/GPU in HBM, human-sized index with repeat/paralog/poly-A structure, 12% off-transcriptome, full quant/step" if stress else
+                                    f"BASELINE config #{3 if world == 1 else 4}: {n} PE-{L} pairs/GPU resident in HBM (2-bit packed), human-like index by the reference's `kallisto index`, full quant/step" if paired else
+                                    f"BASELINE config #2: {n} SE-{L} reads/GPU resident in HBM, yeast-like index, --single -l 200 -s 20, full quant/step")
+                                   if (genes == (20000 if paired else 6000) and n_arg == n_default) or stress else
+                                   f"REDUCED {args.workload} genes={genes} {unit_name}={n} (not the BASELINE configuration)"),
+                "parallelism_short": f"{world} ranks (1/GPU): reads sharded, RCCL EC merge, EM by component" if world > 1 else "1 GPU",
                 f"{unit_name}_per_gpu": n, "read_len": L, "paired": paired, "targets": int(index.num_targets),
                 "kmers": int(index.num_kmers),
                 "kmer_table": {"layout": "compact" if index.view.table_layout else "wide", "slots_per_line": int(index.view.slots_per_bucket),
@@ -1351,6 +1493,7 @@ def main():
                                    "sample": f"first {k} {unit_name} of rank 0's reads as uncompressed FASTQ, `kallisto quant -t {threads} "
                                              f"--plaintext {' '.join(cli_extra)}`, clock from index-loaded to exit ({cb['seconds']:.1f}s; index load "
                                              f"{cb['index_load_s']:.1f}s excluded)",
+                                   "sample_short": f"first {k} {unit_name} of rank 0's reads, uncompressed FASTQ, unmodified reference `quant -t {threads}`, index load excluded",
                                    "index_load_seconds": round(cb["index_load_s"], 2),
                                    "whole_run_value_including_index_load": round(k / (cb["seconds"] + cb["index_load_s"]) / 1e6, 4),
                                    "pseudoalign_seconds": round(cb["pseudoalign_s"], 2), "em_seconds": round(cb["em_s"], 2),
@@ -1420,6 +1563,7 @@ def main():
                                    "sample": f"ALL {n} {unit_name} of the run as uncompressed FASTQ through the unmodified reference (oracle/_ref/dump_ec quant -t {st_['threads']} = "
                                              f"KmerIndex::load, ProcessReads on all cores, EMAlgorithm::run single-threaded; the run of parity_check_full_size, in the background of the "
                                              f"other parity legs, which keep one or two cores busy), clock from index-loaded to exit ({work:.1f}s; index load {st_['index_load']:.1f}s excluded)",
+                                   "sample_short": f"all {n} {unit_name} of the run, uncompressed FASTQ, unmodified reference `quant -t {st_['threads']}`, index load excluded",
                                    "index_load_seconds": st_["index_load"], "pseudoalign_seconds": st_["pseudoalign"], "em_seconds": st_["em"],
                                    "whole_run_value_including_index_load": round(n / (work + st_["index_load"]) / 1e6, 4),
                                    "pseudoalign_only_value": round(n / max(st_["pseudoalign"], 1e-9) / 1e6, 4),
@@ -1481,7 +1625,10 @@ def main():
                                          "note": "the same steps on the other layouts of the k-mer table (wide = three 20-byte slots per 64-byte line at a load of 0.5; "
                                                  "compact = four exact 16-byte slots by quotienting, DESIGN.md section 2, at other load factors); a side measurement -- "
                                                  "`value` above is the library's default (auto: compact when its fields fit, at the load factor kamd_index.cpp picks from the table's size -- config.kmer_table says which)"}
-        print(json.dumps(out), flush=True)
+        out["seconds_total"] = round(time.time() - t_start, 1)
+        detail = write_detail(out, args.detail_file)
+        log("detail: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "breakdown_ms") if k in out}) + (f"; everything else in {detail}" if detail else ""))
+        print(contract_line(out, detail), flush=True)
     if world > 1:
         # tear down in order while everything is alive: the library's communicator (ncclCommDestroy), the context, then torch's
         # process group; the interpreter's own shutdown order is not one a C++ runtime survives reliably, and the line is printed

@@ -774,36 +774,40 @@ class Comm:
         # the process group, not through the communicator under test -- that all of them hold a communicator that counts `world` ranks
         # and sums correctly.  Otherwise all of them drop it and take the callbacks: no rank may be left alone in a collective.
         comm, err = None, ""
-        # a watchdog over ncclCommInitRank and the first collective: a rank that never comes back from them cannot be cancelled (the call is inside
-        # the library), but it can end its process -- the launcher then takes the other ranks down, and bench.py's self_launch starts the run again
-        # with the collectives carried by torch.distributed (KAMD_COMM=callbacks) instead of waiting out its whole time limit on a hang
+        # OPT-IN watchdog over ncclCommInitRank and the first collective (KAMD_COMM_INIT_TIMEOUT_S, set by bench.py's self_launch for the ranks it starts;
+        # unset = no watchdog: a library user gets exceptions and the fall-back below, never a hard exit).  A rank that never comes back from those
+        # calls cannot be cancelled (the call is inside the library) but it can end its process: the launcher then takes the other ranks down and
+        # starts the run again with the collectives carried by torch.distributed (KAMD_COMM=callbacks) instead of waiting out its whole limit on a
+        # hang.  The watchdog is disarmed on EVERY way out of the guarded region (try / finally), exceptions included.
         import threading
         done = threading.Event()
-        limit = float(os.environ.get("KAMD_COMM_INIT_TIMEOUT_S", "180"))
-
-        def _watch():
-            if not done.wait(limit):
-                print(f"[kallisto_amd] rank {rank}: the RCCL communicator did not come up within {limit:.0f} s (KAMD_COMM_INIT_TIMEOUT_S); giving up "
-                      f"(exit code 3)", file=sys.stderr, flush=True)
-                os._exit(3)
-        threading.Thread(target=_watch, daemon=True).start()
-        try:
-            comm = cls.rccl(ctx, rank, world, box[0])
-            seen = comm.info()["ranks_seen"]
-            if seen != world:
-                err = f"ncclCommCount says {seen} ranks, the process group has {world}"
-        except KallistoAmdError as e:
-            err = str(e)
+        limit = float(os.environ.get("KAMD_COMM_INIT_TIMEOUT_S", "0") or 0)
+        if limit > 0:
+            def _watch():
+                if not done.wait(limit):
+                    print(f"[kallisto_amd] rank {rank}: the RCCL communicator did not come up within {limit:.0f} s (KAMD_COMM_INIT_TIMEOUT_S); giving up "
+                          f"(exit code 3)", file=sys.stderr, flush=True)
+                    os._exit(3)
+            threading.Thread(target=_watch, daemon=True).start()
         flags = [None] * world
-        dist.all_gather_object(flags, err, group=group)
-        if not any(flags):
+        try:
             try:
-                if comm.sum_int(rank + 1) != world * (world + 1) // 2:
-                    err = "the all-reduce over the new communicator returned a wrong sum"
-            except KallistoAmdError as e:
-                err = str(e)
+                comm = cls.rccl(ctx, rank, world, box[0])
+                seen = comm.info()["ranks_seen"]
+                if seen != world:
+                    err = f"ncclCommCount says {seen} ranks, the process group has {world}"
+            except (KallistoAmdError, OSError, RuntimeError) as e:
+                err = str(e) or type(e).__name__
             dist.all_gather_object(flags, err, group=group)
-        done.set()
+            if not any(flags):
+                try:
+                    if comm.sum_int(rank + 1) != world * (world + 1) // 2:
+                        err = "the all-reduce over the new communicator returned a wrong sum"
+                except (KallistoAmdError, OSError, RuntimeError) as e:
+                    err = str(e) or type(e).__name__
+                dist.all_gather_object(flags, err, group=group)
+        finally:
+            done.set()
         if any(flags):
             if rank == 0:
                 print(f"[kallisto_amd] RCCL communicator inside the library unusable ({next(f for f in flags if f)}); using torch.distributed "

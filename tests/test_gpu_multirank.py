@@ -138,12 +138,16 @@ def test_bench_two_ranks_on_one_gpu_with_parity(tmp_path):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KAMD_BENCH_BACKEND"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genes", "1500", "--pairs", "400000", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--multi-parity"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--no-cpu-baseline", "--multi-parity", "--detail-file", str(tmp_path / "detail.json")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["other_scaling"]["scaling"] == "strong"
+    assert len(lines) == 1 and len(lines[0]) < bench.CONTRACT_MAX_BYTES, lines
+    short = json.loads(lines[0])   # the contract line: figures only
+    assert short["n_gpus"] == 2 and short["value"] > 0 and short["config"]["n_ranks_seen"] == 2 and short["parity"]["multi_rank_ok"] is True
+    assert short["roofline"]["frac"] > 0 and short["other_scaling"]["scaling"] == "strong"
+    line = json.load(open(tmp_path / "detail.json"))   # the detail document of the same run
+    assert line["n_gpus"] == 2 and line["value"] == short["value"] and line["scaling"] == "weak" and line["other_scaling"]["scaling"] == "strong"
     assert "callbacks" in line["config"]["collective_backend"] and "gloo" in line["config"]["collective_backend"]     # the transport actually used
     assert line["config"]["n_ranks_seen"] == 2 and line["config"]["launcher"].startswith("self")
     assert line["breakdown_ms"]["collective_ms"] > 0 and line["breakdown_ms"]["em_collectives_n"] >= 1   # the collectives' share of a step is in the line
@@ -170,9 +174,14 @@ def test_bench_two_ranks_without_flags_carries_parity_and_cpu_baseline(tmp_path)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "KAMD_BENCH_BACKEND"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genes", "1500", "--pairs", "300000", "--steps", "2", "--warmup", "1",
-                        "--parity-sample", "100000"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--parity-sample", "100000", "--detail-file", str(tmp_path / "detail.json")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    line = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1])
+    text = [ln for ln in p.stdout.decode().splitlines() if ln.strip()][-1]
+    short = json.loads(text)
+    assert len(text) < bench.CONTRACT_MAX_BYTES and short["n_gpus"] == 2 and short["roofline"]["frac"] > 0 and short["parity"]["multi_rank_ok"] is True
+    assert short["cpu_baseline"]["kind"] == "reference" and short["cpu_baseline"]["value"] > 0 and short["cpu_baseline"]["cores"] == 1 and short["config"]["n_ranks_seen"] == 2
+    line = json.load(open(tmp_path / "detail.json"))
     assert line["n_gpus"] == 2 and line["roofline"]["frac"] > 0
     mp = line["multi_rank_parity"]
     assert mp["ok"] and mp["ec_multiset_equal"] and mp["flens_equal"] and mp["eff_length_equal"] and mp["sample"] == 200000, mp
