@@ -766,7 +766,7 @@ def write_detail(out: dict, path: str | None = None):
             json.dump(out, f, indent=1)
         os.replace(path + ".tmp", path)
         side = os.path.join(ROOT, "gpurun_out")
-        if os.path.isdir(side) and os.path.dirname(os.path.abspath(path)) != side:
+        if os.path.isdir(side) and os.path.dirname(os.path.abspath(path)) == os.path.abspath(ROOT):   # (the default place only: a child leg's temporary file is not evidence)
             shutil.copyfile(path, os.path.join(side, os.path.basename(path)))
         return os.path.relpath(path, ROOT)
     except OSError as e:

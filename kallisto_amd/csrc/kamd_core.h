@@ -1,6 +1,6 @@
 // kamd_core.h -- per-item logic of the pseudoalignment kernels, written once as host/device inline functions.
 //
-// The __global__ kernels in kamd_kernels.hip are thin wrappers (LDS staging, wave-aggregated output, atomics) around
+// The __global__ kernels in kamd_match.hip / kamd_ec.hip are thin wrappers (LDS staging, wave-aggregated output, atomics) around
 // the functions below.  They are also compilable for the host so that tests/emu can drive exactly the same logic on a
 // CPU-only box (hipcc cross-compiles here but there is no GPU); that emulation build is TEST infrastructure, the
 // product library never calls it.

@@ -4,7 +4,7 @@
 // The EC x transcript matrix is block diagonal over the connected components of the transcript/EC graph (gene families)
 // and the EM update never couples two components.  Components are therefore packed into GROUPS small enough for one
 // workgroup's LDS (local 16-bit indices in both directions) and a group iterates on its own: row pass, barrier, column
-// pass, barrier -- no kernel boundary and no global memory traffic per round (the streamed form of kamd_kernels.hip pays
+// pass, barrier -- no kernel boundary and no global memory traffic per round (the streamed form of kamd_em.hip pays
 // two kernel boundaries and two dependent global round trips per round: 25.5 us).
 // Only the stop rule "chcount == 0 && i > min_rounds" (:202-205) is global.  It is handled like kamd_em_run_partitioned
 // does across ranks: a chunk of rounds runs speculatively from a checkpoint while every group adds its per-round change
@@ -14,7 +14,7 @@
 //   * the plan (groups, local CSR in both directions) and a host reference builder for it,
 //   * the per-group round as host/device functions written for thread-strided execution,
 //   * the chunk / history / replay driver, templated on a backend (here: the serial CPU backend).
-// The device side: k_em_local in kamd_kernels.hip calls the same round functions on LDS copies of a group; its plan is
+// The device side: k_em_local in kamd_em.hip calls the same round functions on LDS copies of a group; its plan is
 // still built by build_plan_host() from a download of the CSR (slow: bring-up only).  Set-up kernels that build the same
 // plan in HBM are the next step; what they produce can be validated against build_plan_host().
 #pragma once

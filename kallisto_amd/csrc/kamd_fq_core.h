@@ -1,6 +1,6 @@
 // kamd_fq_core.h -- strict 4-line FASTQ text -> reads, the part of FastqSequenceReader::fetchSequences
 // (src/ProcessReads.cpp:3128-3267) that is kseq_read (src/kseq.h:174-215), written once as host/device inline functions:
-// the kernels of kamd_kernels.hip (k_fq_*) run them per tile / per record on text that already sits in HBM, tests/emu runs
+// the kernels of kamd_io.hip (k_fq_*) run them per tile / per record on text that already sits in HBM, tests/emu runs
 // them on the CPU.
 //
 // Scope: a *unit* of text that starts at the first byte of a record and consists of whole 4-line records

@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 
-// the k-mer table(s) of the host view as the per-item logic sees them (mirrors make_table of kamd_kernels.hip)
+// the k-mer table(s) of the host view as the per-item logic sees them (mirrors make_table of kamd_dev.h)
 static kamd::Table emu_table(const kamd_index_view* v, bool partial, bool no_jump = false) {
   kamd::Table t{v->table, v->n_buckets};
   t.layout = (uint8_t)v->table_layout; t.q = (uint8_t)v->tag_q; t.dsh = (uint8_t)v->tag_dsh; t.tagw = (uint8_t)v->tag_w;

@@ -1,6 +1,6 @@
 // tests/emu/fq_emu.cpp -- TEST INFRASTRUCTURE: the input side of the device FASTQ parser on a box without a GPU.  The host part
 // (kamd_textsource.h: TextSource, UnitCutter) is the product's own code; the device part (k_fq_count / k_fq_fill / k_fq_records of
-// kamd_kernels.hip) is restated serially over the same host/device functions of kamd_fq_core.h.  Never linked into the product.
+// kamd_io.hip) is restated serially over the same host/device functions of kamd_fq_core.h.  Never linked into the product.
 #include "../../kallisto_amd/csrc/kamd_fq_core.h"
 #include "../../kallisto_amd/csrc/kamd_textsource.h"
 
