@@ -1447,8 +1447,7 @@ def main():
                          "em_largest_component_nnz": pr["em_max_comp_nnz"],
                          "em_form": ("hybrid: k_em_sell on the components that fit + streamed kernels on the oversized ones" if pr["em_giant_nnz"] else
                                      "component-local (k_em_sell)") if pr["em_k"] < 0 else ("streamed" if pr["em_k"] > 0 else "csr"),
-                         "em_oversized": {"nnz": pr["em_giant_nnz"], "rows": pr["em_giant_rows"], "transcripts": pr["em_giant_tr"], "chunks_per_direction": pr["em_giant_chunks"],
-                                          "compute_units_reserved": pr["em_giant_cus"]} if pr["em_giant_nnz"] else None,
+                         "em_oversized": {"nnz": pr["em_giant_nnz"], "rows": pr["em_giant_rows"], "transcripts": pr["em_giant_tr"], "chunks_per_direction": pr["em_giant_chunks"]} if pr["em_giant_nnz"] else None,
                          "em_plan_ms": round(pr["em_plan_ms"], 3)},
             # dominant kernel by time: kernel A
             "roofline": {"kernel": {3: "k_match_v3"}[pr["kernel_a_version"]], "bound": "hbm",

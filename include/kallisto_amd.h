@@ -97,8 +97,13 @@ typedef struct {
                                With a strand option --union and --no-jump filter per hit (src/ProcessReads.cpp:62-82) */
 } kamd_quant_opts;
 
-/* ---- errors ---- */
+/* ---- errors, version ---- */
 const char* kamd_last_error(void);
+/* The structures of this header are passed by pointer and have grown from round to round (kamd_tuning, kamd_profile): a binding compiled against
+ * another version of the header must refuse to run rather than read or write beyond what it allocated.  kamd_abi_version() returns the
+ * KAMD_ABI_VERSION the library was built with; callers compare it with the one they were compiled against (kallisto_amd/api.py does at load). */
+#define KAMD_ABI_VERSION 6
+uint32_t kamd_abi_version(void);
 
 /* ---- S1: index ---- */
 int kamd_index_load(const char* path, int threads, kamd_index** out);
@@ -162,9 +167,10 @@ typedef struct {
                                   components that fit keep the LDS form, the oversized ones are iterated BESIDE it by streamed kernels (two
                                   launches per round over flagged entry streams in HBM, on compute units of their own), one stop rule over
                                   both; 2 = off: such a matrix takes the streamed form as a whole (rounds 1-4) */
-  int32_t em_giant_cus;        /* hybrid: compute units reserved for the streamed kernels (a CU mask keeps k_em_sell's stream off them); -1 (default) =
-                                  none, the two forms share the chip (measured faster: the streamed side is the critical path and finds free units
-                                  once the groups' launch of a chunk has drained); 0 in kamd_ctx_tune = keep */
+  int32_t overflow_second_pass; /* items whose class list overflowed kernel A's eight LDS entries (pairs inside repeat families, poly-A stretches, --no-jump
+                                  runs): 1 (default) = they go through kernel A's data-flow loop once more with an append-only list of up to 192 classes in
+                                  global memory (k_classify_long removes the duplicates), what overflows again takes the straight-line kernel; 2 = all of
+                                  them take the straight-line kernel k_pseudoalign_overflow (rounds 1-5) */
   int32_t em_giant_nnz;        /* hybrid: a component with more entries than this is "oversized"; -1 (default) = 6000, halved while the
                                   remaining components still do not fit their groups */
 } kamd_tuning;
@@ -287,7 +293,7 @@ typedef struct {
   uint64_t last_em_giant_rows;     /* their rows, */
   uint64_t last_em_giant_tr;       /* their transcripts, */
   uint32_t last_em_giant_chunks;   /* wavefront chunks per direction of those kernels, */
-  int32_t last_em_giant_cus;       /* compute units reserved for them (0: no CU masks -- the two forms shared the chip) */
+  int32_t last_em_graph_fallback;  /* hybrid: 1 = the hipGraph of a chunk's rounds could not be captured / instantiated and the chunks went out as plain launches */
   float last_em_plan_ms;           /* host time of the plan set-up of the last kamd_em_run (component labels, groups, layouts; 0 when cached) */
   uint64_t n_overflow_items;       /* since kamd_ec_reset: items kernel A handed to k_pseudoalign_overflow (more than 8 distinct (unitig, set)
                                       classes, or reads beyond the LDS budget), */
@@ -297,7 +303,7 @@ typedef struct {
   float em_collective_ms;          /* several ranks: host wall time inside the collectives of the last kamd_em_run_comm (one all-reduce per chunk of 64
                                       rounds for the stop rule + the final sum of the abundance vectors; the host waits for each) */
   uint32_t em_collectives;         /* ... and their number */
-  uint64_t n_overflow_second_pass; /* of n_overflow_items: those kernel A's second pass (a list of 64 classes) took care of; the rest went to the
+  uint64_t n_overflow_second_pass; /* of n_overflow_items: those kernel A's second pass (an append-only list of up to 192 classes) took care of; the rest went to the
                                       straight-line kernel */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);

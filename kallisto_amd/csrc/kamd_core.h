@@ -482,9 +482,25 @@ KAMD_HD uint32_t text_pos_of(const MatchState& st) {
 struct UecList {
   uint32_t* e; int cap; int n; bool overflow;
   int stride = 1;   // distance between consecutive entries (kernel A v3 keeps the lists thread-transposed in LDS)
+  // append mode (kernel A's pass over the items whose eight-entry list overflowed): the list lies in global memory and is never read back --
+  // a class equal to the one appended last (the common case: consecutive hits on one unitig) only merges its mate flag, anything else is
+  // appended, O(1) per hit; the duplicates that are not neighbours are removed when the classes are mapped to sets (k_classify_long)
+  bool append = false;
+  uint32_t last = NO_UEC, last_flags = 0;
 };
 KAMD_HD void ueclist_add(UecList& l, uint32_t uec, int mate) {
   const uint32_t flag = mate ? 0x80000000u : 0x40000000u;
+  if (l.append) {
+    if (l.n > 0 && l.last == uec) {
+      if (!(l.last_flags & flag)) { l.last_flags |= flag; l.e[(l.n - 1) * l.stride] = uec | l.last_flags; }
+      return;
+    }
+    if (l.n == l.cap) { l.overflow = true; return; }
+    l.e[l.n * l.stride] = uec | flag;
+    l.last = uec; l.last_flags = flag;
+    ++l.n;
+    return;
+  }
   for (int i = l.n - 1; i >= 0; --i)
     if ((l.e[i * l.stride] & 0x3FFFFFFFu) == uec) { l.e[i * l.stride] |= flag; return; }
   if (l.n == l.cap) { l.overflow = true; return; }

@@ -8,7 +8,7 @@ void tuning_defaults(kamd_tuning* t) {
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
   t->em_form = 3; t->em_local_block = 1024; t->em_group_div = -1; t->em_split_len = 16; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1; t->em_reg_slices = 1;
-  t->em_hybrid = 1; t->em_giant_cus = -1; t->em_giant_nnz = -1;
+  t->em_hybrid = 1; t->overflow_second_pass = 1; t->em_giant_nnz = -1;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
@@ -31,37 +31,44 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.align_chunks != 0) t->align_chunks = n.align_chunks < 0 ? -1 : std::min(n.align_chunks, 64);
   if (n.em_reg_slices == 1 || n.em_reg_slices == 2) t->em_reg_slices = n.em_reg_slices;
   if (n.em_hybrid == 1 || n.em_hybrid == 2) t->em_hybrid = n.em_hybrid;
-  if (n.em_giant_cus != 0) t->em_giant_cus = n.em_giant_cus < 0 ? -1 : n.em_giant_cus;
+  if (n.overflow_second_pass == 1 || n.overflow_second_pass == 2) t->overflow_second_pass = n.overflow_second_pass;
   if (n.em_giant_nnz != 0) t->em_giant_nnz = n.em_giant_nnz < 0 ? -1 : std::max(n.em_giant_nnz, 8);
 }
-// experiments: the same knobs from the environment, read once when a context is created
+// experiments: the same knobs from ONE environment variable, read once when a context is created --
+//   KAMD_TUNE="em_form=streamed,em_graph=0,items_per_wave=512"   (field names of kamd_tuning; on/off fields take 1 / 0; em_form also by name)
+// Unknown names are reported on stderr and ignored.
 void tuning_from_env(kamd_tuning* t) {
+  const char* e = getenv("KAMD_TUNE");
+  if (!e || !*e) return;
   kamd_tuning n; memset(&n, 0, sizeof n);
-  auto geti = [](const char* name, int32_t* dst) { if (const char* e = getenv(name)) *dst = atoi(e); };
-  auto onoff = [](const char* name, int32_t* dst) { if (const char* e = getenv(name)) *dst = atoi(e) != 0 ? 1 : 2; };
-  onoff("KAMD_TEXT_VERIFY", &n.text_verify);
-  geti("KAMD_ITEMS_PER_WAVE", &n.items_per_wave);
-  geti("KAMD_REFILL_MIN", &n.refill_min);
-  geti("KAMD_LDS_PAD", &n.lds_pad);
-  if (const char* e = getenv("KAMD_EM_FORM")) {
-    const std::string v(e);
-    n.em_form = v == "streamed" ? 1 : v == "csr" ? 2 : v == "local" ? 3 : atoi(e);
+  struct Field { const char* name; int32_t kamd_tuning::*p; bool onoff; };
+  static const Field fields[] = {
+    {"text_verify", &kamd_tuning::text_verify, true}, {"items_per_wave", &kamd_tuning::items_per_wave, false}, {"refill_min", &kamd_tuning::refill_min, false},
+    {"lds_pad", &kamd_tuning::lds_pad, false}, {"em_form", &kamd_tuning::em_form, false}, {"em_entries_per_lane", &kamd_tuning::em_entries_per_lane, false},
+    {"em_windowed", &kamd_tuning::em_windowed, true}, {"em_graph", &kamd_tuning::em_graph, true}, {"em_row_lanes", &kamd_tuning::em_row_lanes, false},
+    {"em_fin_blocks", &kamd_tuning::em_fin_blocks, false}, {"em_local_block", &kamd_tuning::em_local_block, false}, {"em_group_div", &kamd_tuning::em_group_div, false},
+    {"em_split_len", &kamd_tuning::em_split_len, false}, {"dedup_form", &kamd_tuning::dedup_form, false}, {"align_chunks", &kamd_tuning::align_chunks, false},
+    {"em_small_nnz", &kamd_tuning::em_small_nnz, false}, {"em_reg_slices", &kamd_tuning::em_reg_slices, true}, {"em_hybrid", &kamd_tuning::em_hybrid, true},
+    {"overflow_second_pass", &kamd_tuning::overflow_second_pass, true}, {"em_giant_nnz", &kamd_tuning::em_giant_nnz, false}};
+  std::string all(e);
+  for (size_t pos = 0; pos < all.size();) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    const std::string kv = all.substr(pos, end - pos);
+    pos = end + 1;
+    const size_t eq = kv.find('=');
+    if (eq == std::string::npos) continue;
+    const std::string key = kv.substr(0, eq), val = kv.substr(eq + 1);
+    bool known = false;
+    for (const Field& f : fields) {
+      if (key != f.name) continue;
+      known = true;
+      int32_t v = atoi(val.c_str());
+      if (key == "em_form") v = val == "streamed" ? 1 : val == "csr" ? 2 : val == "local" ? 3 : v;
+      n.*(f.p) = f.onoff ? (v != 0 ? 1 : 2) : v;
+    }
+    if (!known) fprintf(stderr, "[kallisto_amd] KAMD_TUNE: unknown field '%s' ignored\n", key.c_str());
   }
-  geti("KAMD_EM_LOCAL_BLOCK", &n.em_local_block);
-  geti("KAMD_EM_GROUP_DIV", &n.em_group_div);
-  geti("KAMD_EM_SMALL_NNZ", &n.em_small_nnz);
-  geti("KAMD_DEDUP_FORM", &n.dedup_form);
-  geti("KAMD_EM_SPLIT_LEN", &n.em_split_len);
-  onoff("KAMD_EM_REG", &n.em_reg_slices);
-  geti("KAMD_EM_K", &n.em_entries_per_lane);
-  onoff("KAMD_EM_WINDOWED", &n.em_windowed);
-  onoff("KAMD_EM_GRAPH", &n.em_graph);
-  geti("KAMD_EM_ROW_LANES", &n.em_row_lanes);
-  geti("KAMD_EM_FIN_BLOCKS", &n.em_fin_blocks);
-  geti("KAMD_ALIGN_CHUNKS", &n.align_chunks);
-  onoff("KAMD_EM_HYBRID", &n.em_hybrid);
-  geti("KAMD_EM_GIANT_CUS", &n.em_giant_cus);
-  geti("KAMD_EM_GIANT_NNZ", &n.em_giant_nnz);
   tuning_merge(t, n);
 }
 }  // namespace
@@ -93,6 +100,7 @@ int push_state(kamd_ctx* c) {
 // ======================================================================================================================
 // C ABI
 // ======================================================================================================================
+extern "C" uint32_t kamd_abi_version(void) { return KAMD_ABI_VERSION; }
 extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (!out) return kamd::fail(-1, "kamd_ctx_create: null output pointer");
   *out = nullptr;
@@ -111,8 +119,6 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   if (c->stats_a.ensure(sizeof(DevStatsA), 0, c->stream) || hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream) != hipSuccess) { delete c; return -100; }
   tuning_defaults(&c->tune);
   tuning_from_env(&c->tune);
-  if (const char* e = getenv("KAMD_DEBUG_ABSORB")) c->debug_absorb = atoi(e) & 6;
-  if (const char* e = getenv("KAMD_FLD_AFTER_A")) c->fld_after_a = atoi(e) != 0;   // (experiment: 0 = the prefetch runs underneath kernel A, as through round 3)
   apply_tuning(c);
   *out = c;
   return 0;
@@ -154,7 +160,6 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->em_pin) (void)hipHostFree(c->em_pin);
   if (c->state_pin) (void)hipHostFree(c->state_pin);
   c->em_clk.release();
-  if (c->hy_sell_stream) { (void)hipStreamSynchronize(c->hy_sell_stream); (void)hipStreamDestroy(c->hy_sell_stream); }
   if (c->hy_giant_stream) { (void)hipStreamSynchronize(c->hy_giant_stream); (void)hipStreamDestroy(c->hy_giant_stream); }
   if (c->hy_ev_sell) (void)hipEventDestroy(c->hy_ev_sell);
   if (c->hy_ev_giant) (void)hipEventDestroy(c->hy_ev_giant);
@@ -162,7 +167,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev_mg1) (void)hipEventDestroy(c->ev_mg1);
   if (c->ev_ov0) (void)hipEventDestroy(c->ev_ov0);
   if (c->ev_ov1) (void)hipEventDestroy(c->ev_ov1);
-  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps, &c->hy_hot}) b->release();
+  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps}) b->release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
@@ -310,7 +315,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_fin_cand_words = c->last_fin_cand_words;
   p->absorb_ms = c->last_absorb_ms; p->n_distinct_tuples = c->n_distinct_tuples; p->tuple_store_words = c->host_state.ts_words; p->tuple_table_slots = c->tcap;
   p->last_em_max_comp_nnz = c->last_em_max_comp_nnz; p->last_em_giant_nnz = c->last_em_giant_nnz; p->last_em_giant_rows = c->last_em_giant_rows;
-  p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_giant_cus = c->last_em_giant_cus;
+  p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_graph_fallback = c->last_em_graph_fallback;
   p->last_em_plan_ms = c->last_em_plan_ms;
   p->n_overflow_items = c->overflow_total; p->overflow_ms = c->overflow_ms;
   p->n_overflow_second_pass = c->overflow_second_total;

@@ -237,8 +237,6 @@ struct kamd_ctx {
   // run beside k_classify / k_tup_absorb, which leave most of the memory system's request rate unused, instead of underneath kernel A, which
   // lives on it)
   struct { const uint32_t* w = nullptr; const uint16_t* l = nullptr; u64 n = 0; int32_t max_len = 0, strand = 0, so = 0, comp = 0; bool valid = false; } fld_deferred;
-  int fld_after_a = 1;
-  int debug_absorb = 0;   // KAMD_DEBUG_ABSORB (read once in kamd_ctx_create): timing experiments of k_tup_absorb, results wrong
   DBuf pt_label, pt_flag, pt_len, pt_rowpos, pt_nnzpos, pt_off, pt_ids, pt_counts, pt_wcounts, pt_hist, pt_ck_alpha, pt_ck_a;
   DevState host_state{};
   DevState* state_pin = nullptr;   // pinned staging of the read-backs (sync_state)
@@ -263,11 +261,11 @@ struct kamd_ctx {
   void* em_pin = nullptr; size_t em_pin_bytes = 0;   // component-local EM: pinned, mapped host memory (change counts the kernels publish, result staging)
   DBuf em_clk;                                       // diagnostic phase clocks (KAMD_EM_CLK)
   // hybrid EM (components beyond a workgroup's LDS beside the LDS form): the two sub-matrices, the streamed plan's arenas, its vectors
-  DBuf hy_sub, hy_a, hy_b, hy_x, hy_maps, hy_hot;
-  hipStream_t hy_sell_stream = nullptr, hy_giant_stream = nullptr; int hy_sell_cus = -1;   // hy_sell_stream carries a CU mask of hy_sell_cus units
+  DBuf hy_sub, hy_a, hy_b, hy_x, hy_maps;
+  hipStream_t hy_giant_stream = nullptr;   // the oversized components' kernels (k_em_sell stays on the context stream)
   hipEvent_t hy_ev_sell = nullptr, hy_ev_giant = nullptr;
   uint64_t last_em_max_comp_nnz = 0, last_em_giant_nnz = 0, last_em_giant_rows = 0, last_em_giant_tr = 0;
-  uint32_t last_em_giant_chunks = 0; int last_em_giant_cus = 0; float last_em_plan_ms = 0.f;
+  uint32_t last_em_giant_chunks = 0; int last_em_graph_fallback = 0; float last_em_plan_ms = 0.f;
   float last_merge_ms = 0.f, em_coll_ms = 0.f; uint32_t em_coll_n = 0; hipEvent_t ev_mg0 = nullptr, ev_mg1 = nullptr;   // several ranks: kamd_ec_allreduce (HIP events), the EM's collectives (host wall, the host waits for each)
   const uint32_t* labels_override = nullptr;   // em_local_setup_device takes these component labels instead of computing them (the hybrid's sub-matrix: same components)
   bool em_prefer_hybrid = false;               // the last matrix of this context needed the hybrid: the next plan starts there

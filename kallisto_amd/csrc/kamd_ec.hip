@@ -148,7 +148,6 @@ __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ ba
         if (old == 0ULL) old = atomicCAS(&table[s].tag, 0ULL, mine);
         if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }
         if ((old >> 32) == (mine >> 32)) {
-          if (track & 4) { placed = true; break; }   // (timing experiment KAMD_DEBUG_ABSORB: no verification read -- wrong results)
           const u32* o = ((old & TAG_LOCAL) ? batch : store) + ((old & 0x7FFFFFFFULL) - 1);
           bool same = o[1] == m;
           for (u32 j = 0; same && j < m; j++) same = o[2 + j] == batch[off + 2 + j];
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void k_tup_absorb(const u32* __restrict__ ba
         s = (s + 1) & mask;
       }
       if (placed) {
-        if (!(track & 2)) atomicAdd(&table[s].count, (u64)batch[off]);   // (bit 1: timing experiment, no count atomic -- wrong results)
+        atomicAdd(&table[s].count, (u64)batch[off]);
         if (track & 1) atomicMin(&table[s].first, key_base + r);   // first occurrence: record indices follow the input order
       } else fail[atomicAdd(&st->tl_fail, 1ULL)] = r;
     }
@@ -932,13 +931,13 @@ int absorb_tuples(kamd_ctx* c, const u32* batch, const u64* rec_off, u64 n, u64 
     if (int rc = push_state(c)) return rc;
     // (the main pass of a batch -- kernel A's records in fixed slots of at least six words -- four records per thread; retries, overflow
     // items and gathered records one per thread)
-    if (!idx && fixed_stride >= 6 && (fixed_stride & 1) == 0 && !c->debug_absorb && !getenv("KAMD_ABSORB_ONE"))
+    if (!idx && fixed_stride >= 6 && (fixed_stride & 1) == 0)
       hipLaunchKernelGGL(k_tup_absorb4, dim3(grid_for((count + ABS_Q - 1) / ABS_Q, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), count,
                          c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base, c->track_order ? 1 : 0, 64u, fail_a, dst, fixed_stride, item0);
     else
     hipLaunchKernelGGL(k_tup_absorb, dim3(grid_for(count, BLOCK)), dim3(BLOCK), 0, c->stream, batch, (const u32*)c->tstore.as<u32>(), rec_off, idx, count,
                        c->ttable.as<TSlot>(), c->tcap - 1, c->list.as<u64>(), key_base,
-                       (c->track_order ? 1 : 0) | c->debug_absorb, 64u, fail_a, dst,
+                       c->track_order ? 1 : 0, 64u, fail_a, dst,
                        fixed_stride, item0);
     HIPC(hipGetLastError());
     c->ttable_clean = false;

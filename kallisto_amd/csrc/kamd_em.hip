@@ -349,16 +349,10 @@ __device__ __forceinline__ void pm_wave_load(const PmSide& s, u32 c, PmWave<K>& 
   w.hd = s.head[c];
   w.lw = s.lane_word[(u64)c * 64 + lane_id()];
 }
-// where the value of an entry comes from: the vector in global memory, or -- the hybrid's oversized side -- a table in LDS for the HOT
-// targets (entries marked PM_HOT carry a slot of that table instead of an index; k_gih_mark)
-constexpr u32 PM_HOT = 0x40000000u;
+// where the value of an entry comes from (the blocked passes of an oversized component read a block of the vector out of LDS instead)
 struct PmSrcGlobal {
   const double* __restrict__ p;
   __device__ __forceinline__ double operator()(u32 id) const { return p[id & ~PM_END]; }
-};
-struct PmSrcHot {
-  const double* __restrict__ p; const double* hot;
-  __device__ __forceinline__ double operator()(u32 id) const { const u32 x = id & ~PM_END; return (x & PM_HOT) ? hot[x & ~PM_HOT] : p[x]; }
 };
 template <int K, int PRE, bool WIN, class Emit, class Src>
 __device__ __forceinline__ void pm_wave_pass(const PmSide& s, u32 c, PmWave<K>& w, const Src& src, double* lds, const Emit& em) {
@@ -664,7 +658,9 @@ __global__ void k_pm_chunks(const u64* __restrict__ off, u64 n_seg, u64 nz, u32 
   while (hi - lo > 1) { const u64 mid = (lo + hi) / 2; if (off[mid] <= c0) lo = mid; else hi = mid; }
   const u64 hs = off[lo], se = off[lo + 1];
   const u64 hl = c0 - hs;  // entries of the segment before the chunk
-  const bool is_long = hl > 64ULL * PM_HEAD && hl <= (u64)PM_LOOP_MAX && !no_long;
+  // (a long head is only re-read by the chunk the segment ENDS in: a chunk wholly inside the segment would gather its hl preceding entries every
+  // round and throw the sum away -- O(L^2 / chunk) wasted gathers per long segment; such chunks are marked heavy and need nothing but their own sum)
+  const bool is_long = hl > 64ULL * PM_HEAD && hl <= (u64)PM_LOOP_MAX && !no_long && se <= c1;
   const bool is_heavy = hl > 64ULL * PM_HEAD && !is_long;
   seg_base[c] = (u32)lo;
   head[c] = hl == 0 ? 0u : (is_heavy ? PM_HEAVY : (is_long ? (PM_LONG | (u32)hl) : (u32)hl));
@@ -868,7 +864,7 @@ void pm_enqueue_round(const PmPlan& P, hipStream_t s, int parity) {
 // returns 0 = plan built (the rounds can be enqueued with pm_enqueue_round), 1 = not applicable (the caller uses the CSR
 // form), < 0 = error.  Needs col_cnt / em_coloff / em_single / em_eff of the caller (k_em_prepare + scan) and a zeroed col_fill.
 int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u32* counts, const u32* wcounts, u64 n_ecs, u64 T,
-                      const u32* col_cnt, u32* col_fill, PmPlan* P, DBuf* arena_a = nullptr, DBuf* arena_b = nullptr, int n_cus_for = 0) {
+                      const u32* col_cnt, u32* col_fill, PmPlan* P, DBuf* arena_a = nullptr, DBuf* arena_b = nullptr) {
   if (n_ecs == 0) return 1;
   DBuf& ar_a = arena_a ? *arena_a : c->pm_a;   // (the hybrid keeps the streamed plan of the oversized components in arenas of its own: pm_a / pm_b
   DBuf& ar_b = arena_b ? *arena_b : c->pm_b;   //  hold the LDS form's plan and vectors at the same time)
@@ -905,7 +901,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   int K = PM_KS[sizeof(PM_KS) / sizeof(PM_KS[0]) - 1];
   bool k_forced = false;
   if (c->tune.em_entries_per_lane > 0) { for (int k : PM_KS) if (k == c->tune.em_entries_per_lane) { K = k; k_forced = true; } }
-  if (!k_forced) for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)(n_cus_for > 0 ? n_cus_for : c->n_cus) * 12) { K = k; break; }
+  if (!k_forced) for (int k : PM_KS) if ((NZ + 64ULL * k - 1) / (64ULL * k) <= (u64)c->n_cus * 12) { K = k; break; }
   const u32 chunk = 64u * (u32)K;
   const u64 n_chunks64 = (NZ + chunk - 1) / chunk;
   if (n_chunks64 >= 0x7FFFFFF0ULL) return 1;
@@ -2047,14 +2043,14 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   // when the group's keys fit (always, for groups the EM kernel can hold), by the per-member step kernels otherwise
   size_t rk_lds = 0;
   for (u32 g = 0; g < ng; g++) rk_lds = std::max(rk_lds, std::max((size_t)g_tr[g] * 4, (size_t)g_rows[g] * 12) + 16);
-  const bool lds_rank = rk_lds <= 150 * 1024 && !getenv("KAMD_EM_PLAN_STEPS");
+  const bool lds_rank = rk_lds <= 150 * 1024;
   hipLaunchKernelGGL(k_eml_step<3>, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, A, T);
   if (lds_rank) {
     HIPC(hipFuncSetAttribute((const void*)k_eml_rank_tr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     HIPC(hipFuncSetAttribute((const void*)k_eml_rank_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk_lds));
     hipLaunchKernelGGL(k_eml_rank_tr, dim3(ng), dim3(BLOCK), rk_lds, c->stream, A);
   } else hipLaunchKernelGGL(k_eml_step<10>, dim3(grid_for(M, BLOCK)), dim3(BLOCK), 0, c->stream, A, M);
-  if (A.n_groups <= (u32)RG_BINS && !getenv("KAMD_EM_PLAN_STEPS")) hipLaunchKernelGGL(k_eml_rows_g, dim3(grid_for(n_ecs, RG_BLOCK * RG_PER)), dim3(RG_BLOCK), 0, c->stream, A);
+  if (A.n_groups <= (u32)RG_BINS) hipLaunchKernelGGL(k_eml_rows_g, dim3(grid_for(n_ecs, RG_BLOCK * RG_PER)), dim3(RG_BLOCK), 0, c->stream, A);
   else hipLaunchKernelGGL(k_eml_step<4>, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, A, n_ecs);
   if (lds_rank) hipLaunchKernelGGL(k_eml_rank_rows, dim3(ng), dim3(EML_RANK_BLOCK), rk_lds, c->stream, A);
   else hipLaunchKernelGGL(k_eml_step<11>, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, A, R);
@@ -2063,7 +2059,7 @@ int em_local_setup_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids,
   size_t gb_lds = 0;
   for (u32 g = 0; g < ng; g++)
     gb_lds = std::max(gb_lds, ((size_t)g_rows[g] + 1 + 2 * (size_t)g_tr[g] + 1) * 4 + (((size_t)g_nnz[g] + 1) & ~(size_t)1) * 4 + 16);
-  if (gb_lds <= 150 * 1024 && !getenv("KAMD_EM_PLAN_STEPS")) {   // (KAMD_EM_PLAN_STEPS: experiments / tests take the step kernels)
+  if (gb_lds <= 150 * 1024) {
     HIPC(hipFuncSetAttribute((const void*)k_eml_group_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gb_lds));
     hipLaunchKernelGGL(k_eml_group_build, dim3(ng), dim3(BLOCK), gb_lds, c->stream, A);
   } else {
@@ -2224,81 +2220,6 @@ __global__ __launch_bounds__(PM_BLOCK) void k_gi_cols_fix(PmArgs A, const double
   int* hist = desc->hist;
   gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
 }
-// ---- the same passes with the HOT targets' values in LDS -------------------------------------------------------------------------------
-// An oversized component of a real transcriptome is made of long rows: at 30 M stress pairs 14.2 M entries, ten million of them in ~3 000
-// poly-A / repeat classes of thousands of transcripts -- which all gather the values of the same few thousand transcripts; and in the
-// other direction the columns of those transcripts gather the g of the same few thousand long rows.  A round was 28 M divergent 8-byte
-// gathers through the vector memory pipeline (one line per clock and CU: 39 + 46 us per round).  Here the values of up to GIH_HOT_CAP hot
-// targets per direction (columns / rows of at least a threshold length, chosen so that they fit) are loaded into LDS once per workgroup and
-// launch; the streams' entries that point at them carry PM_HOT | slot (k_gih_mark) and are read with ds_read_b64.  Workgroups are
-// persistent over the chunks (a wavefront takes chunks c, c + W, ...), so the table is loaded 512 times per launch, not once per chunk.
-constexpr int GIH_BLOCK = 512, GIH_HOT_CAP = 4096;
-template <int K, int PRE, bool WIN>
-__global__ __launch_bounds__(GIH_BLOCK) void k_gih_rows(PmArgs A, const double* a_src, const GiDesc* desc, const u32* __restrict__ hot_list, u32 n_hot) {
-  __shared__ double lds_hot[GIH_HOT_CAP];
-  __shared__ double lds_sums[(GIH_BLOCK / 64) * PM_LDS_SLOTS];
-  if (desc->stopped) return;
-  for (u32 i = threadIdx.x; i < n_hot; i += GIH_BLOCK) lds_hot[i] = a_src[hot_list[i]];
-  __syncthreads();
-  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), total = gridDim.x * (GIH_BLOCK / 64);
-  const PmRowEmit em{A.cw, A.g};
-  const PmSrcHot src{a_src, lds_hot};
-  for (u32 c = blockIdx.x * (GIH_BLOCK / 64) + wave; c < A.rows.n_chunks; c += total) {
-    PmWave<K> w;
-    pm_wave_load<K>(A.rows, c, w);
-    pm_wave_pass<K, PRE, WIN>(A.rows, c, w, src, lds_sums + wave * PM_LDS_SLOTS, em);
-  }
-}
-template <int K, int PRE, bool WIN>
-__global__ __launch_bounds__(GIH_BLOCK) void k_gih_cols(PmArgs A, const double* al_src, const double* a_src, double* al_dst, double* a_dst, int round, int clamp,
-                                                        const GiDesc* desc, const u32* __restrict__ hot_list, u32 n_hot) {
-  __shared__ double lds_hot[GIH_HOT_CAP];
-  __shared__ double lds_sums[(GIH_BLOCK / 64) * PM_LDS_SLOTS];
-  __shared__ int lds_ch;
-  if (desc->stopped) return;
-  for (u32 i = threadIdx.x; i < n_hot; i += GIH_BLOCK) lds_hot[i] = A.g[hot_list[i]];
-  __syncthreads();
-  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), total = gridDim.x * (GIH_BLOCK / 64);
-  int ch = 0;
-  const GiColEmit em{al_src, a_src, A.single, A.eff, al_dst, a_dst, &ch, clamp};
-  const PmSrcHot src{A.g, lds_hot};
-  for (u32 c = blockIdx.x * (GIH_BLOCK / 64) + wave; c < A.cols.n_chunks; c += total) {
-    PmWave<K> w;
-    pm_wave_load<K>(A.cols, c, w);
-    pm_wave_pass<K, PRE, WIN>(A.cols, c, w, src, lds_sums + wave * PM_LDS_SLOTS, em);
-  }
-  int* hist = desc->hist;
-  gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
-}
-// hot targets of one direction: segments (columns for the rows pass, rows for the columns pass) of at least `thr` entries.
-// counts[j] = segments of at least 32 << j entries, j < 8
-__global__ void k_gih_count(const u64* __restrict__ off, u64 n, u32* counts) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 len = i < n ? off[i + 1] - off[i] : 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const u64 bm = __ballot(len >= (32ULL << j));
-    if (bm && lane_id() == 0) atomicAdd(&counts[j], (u32)__popcll(bm));
-  }
-}
-__global__ void k_gih_flag(const u64* __restrict__ off, u64 n, u32 thr, u32* flag) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = off[i + 1] - off[i] >= thr ? 1u : 0u;
-}
-__global__ void k_gih_list(const u32* __restrict__ flag, const u64* __restrict__ slot, u64 n, u32 cap, u32* hot_list, u32* hotslot) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const bool hot = flag[i] && slot[i] < cap;
-  hotslot[i] = hot ? (u32)slot[i] : 0xFFFFFFFFu;
-  if (hot) hot_list[slot[i]] = (u32)i;
-}
-// entries that point at a hot target carry its slot (the padding's sentinel index n stays what it is)
-__global__ void k_gih_mark(u32* stream, u64 n_entries, const u32* __restrict__ hotslot, u32 n) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_entries) return;
-  const u32 e = stream[i], x = e & ~PM_END;
-  if (x < n) { const u32 h = hotslot[x]; if (h != 0xFFFFFFFFu) stream[i] = (e & PM_END) | PM_HOT | h; }
-}
 // the final round reads a with the clamp applied (alpha < alpha_limit / 10 -> 0, :212-221); ac[M] = 0 stays the row stream's sentinel
 __global__ void k_gi_clamp(const double* __restrict__ al, const double* __restrict__ a, double* ac, u32 M, const GiDesc* desc) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2326,9 +2247,7 @@ struct GiantPart {
   hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
   hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t gexec[2] = {nullptr, nullptr};
   bool use_graph = true;
-  u64 nnz = 0, rows = 0; int cus = 0;
-  const u32* hot_t = nullptr; const u32* hot_r = nullptr; u32 n_hot_t = 0, n_hot_r = 0;   // hot transcripts (rows pass) / hot rows (columns pass); 0: the plain kernels
-  unsigned hot_grid = 0;
+  u64 nnz = 0, rows = 0;
   void drop_graphs() {
     for (int i = 0; i < 2; i++) {
       if (gexec[i]) (void)hipGraphExecDestroy(gexec[i]);
@@ -2343,15 +2262,6 @@ void gi_round(const GiantPart& G, hipStream_t s, int round, int clamp, const dou
   const unsigned grid = grid_for(P.n_chunks, PM_BLOCK / 64);
   constexpr int PRE_R = (K + 5) / 6 < 2 ? 2 : (K + 5) / 6;
   constexpr int PRE_C = K / 16 + 1;
-  if (G.hot_grid) {   // the hot targets' values from LDS, persistent workgroups
-    if (P.windowed) hipLaunchKernelGGL((k_gih_rows<K, PRE_R, true>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, a_src, G.desc, G.hot_t, G.n_hot_t);
-    else hipLaunchKernelGGL((k_gih_rows<K, PRE_R, false>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, a_src, G.desc, G.hot_t, G.n_hot_t);
-    if (P.n_fix[0]) hipLaunchKernelGGL(k_gi_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, G.desc);
-    if (P.windowed) hipLaunchKernelGGL((k_gih_cols<K, PRE_C, true>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc, G.hot_r, G.n_hot_r);
-    else hipLaunchKernelGGL((k_gih_cols<K, PRE_C, false>), dim3(G.hot_grid), dim3(GIH_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc, G.hot_r, G.n_hot_r);
-    if (P.n_fix[1]) hipLaunchKernelGGL(k_gi_cols_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, al_src, a_src, al_dst, a_dst, round, clamp, G.desc);
-    return;
-  }
   if (P.windowed) hipLaunchKernelGGL((k_gi_rows<K, PRE_R, true>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, a_src, G.desc);
   else hipLaunchKernelGGL((k_gi_rows<K, PRE_R, false>), dim3(grid), dim3(PM_BLOCK), 0, s, P.args, a_src, G.desc);
   if (P.n_fix[0]) hipLaunchKernelGGL(k_gi_rows_fix, dim3(grid_for(P.n_chunks, PM_BLOCK)), dim3(PM_BLOCK), 0, s, P.args, G.desc);
@@ -2389,7 +2299,7 @@ int gi_launch_chunk(GiantPart& G, int n, int clamp, int pin, int pout, int* d_h,
     if (!G.gexec[pin]) {
       // a capture that cannot be completed must not leave the stream capturing or a half-built graph behind: the chunk then goes out as
       // plain launches (what use_graph == false does), for this and every later chunk of the plan
-      static const bool inject = getenv("KAMD_DEBUG_GRAPH_FAIL") != nullptr;   // (tests: the graph of the SECOND parity cannot be instantiated)
+      const bool inject = getenv("KAMD_DEBUG_GRAPH_FAIL") != nullptr;   // (tests: the graph of the SECOND parity cannot be instantiated; read on every capture -- off the hot path)
       hipError_t e = hipStreamBeginCapture(G.stream, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
         gi_enqueue_rounds(G, G.stream, n, 0, pin, pout);
@@ -2430,13 +2340,12 @@ namespace {
 __global__ void k_em_publish(EmsPrev prev);
 struct EmSellGpu {
   kamd_ctx* c; const kamd_em_sell::Plan& P; EmSellDev dev{}; u64 M = 0; size_t lds = 0, team_bytes = 0; int block = 256;
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int exp = 0;   // exp: timing experiment (KAMD_EM_EXP)
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int reg_words = 0;   // index words per lane and direction the kernel keeps in registers (0: the form that reads everything from LDS)
   double* d_alpha = nullptr; double* d_a = nullptr; double* d_ck_alpha = nullptr; double* d_ck_a = nullptr; int* d_hist = nullptr; double* d_out = nullptr;
   std::vector<double> h_alpha; int err = 0;
   const EmPartition* part = nullptr;   // several ranks: the change counts of a chunk are summed over them before the host reads them
   GiantPart* gi = nullptr;             // hybrid: the oversized components, iterated on gi->stream beside the groups
-  hipStream_t sell_stream = nullptr;   // hybrid: the stream of k_em_sell (masked away from the compute units left to gi); null: the context stream
   hipEvent_t ev_sell = nullptr;
   int gi_par(const double* al) const { return al == d_alpha ? 0 : 1; }   // which half of the ping-pong pair a vector of the groups is
   EmSellGpu(kamd_ctx* ctx, const kamd_em_sell::Plan& p) : c(ctx), P(p) {}
@@ -2457,7 +2366,7 @@ struct EmSellGpu {
     // the two size classes run side by side: small groups (one wavefront each) on a second stream, forked from and joined to the context stream
     const u32 n_big = P.n_groups - P.n_small;
     const bool fork = P.n_small && n_big;
-    hipStream_t ss = (gi && sell_stream && n_big) ? sell_stream : c->stream;   // where k_em_sell runs
+    hipStream_t ss = c->stream;   // where k_em_sell runs
     if ((fork || gi) && hipEventRecord(ev_fork, c->stream) != hipSuccess) return -104;
     if (fork && hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return -104;
     if (gi) {
@@ -2476,13 +2385,7 @@ struct EmSellGpu {
       else if (reg_words == 4) { if (clk) KAMD_EMS_LAUNCH_REG(true, 4, 2); else KAMD_EMS_LAUNCH_REG(false, 4, 2); }
       else if (reg_words == 8) { if (clk) KAMD_EMS_LAUNCH_REG(true, 8, 1); else KAMD_EMS_LAUNCH_REG(false, 8, 1); }
       else if (clk) KAMD_EMS_LAUNCH(true, 0);
-      else switch (exp) {
-        case 1: KAMD_EMS_LAUNCH(false, 1); break;
-        case 3: KAMD_EMS_LAUNCH(false, 3); break;
-        case 4: KAMD_EMS_LAUNCH(false, 4); break;
-        case 5: KAMD_EMS_LAUNCH(false, 5); break;
-        default: KAMD_EMS_LAUNCH(false, 0);
-      }
+      else KAMD_EMS_LAUNCH(false, 0);
 #undef KAMD_EMS_LAUNCH
 #undef KAMD_EMS_LAUNCH_REG
     }
@@ -2534,7 +2437,7 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
   reg_words = 0;
   {
     const int cap = std::min(64, std::max(1, c->tune.em_split_len));
-    if (c->tune.em_reg_slices == 1 && !getenv("KAMD_EM_EXP")) reg_words = cap <= 8 ? 2 : cap <= 16 ? 4 : cap <= 32 ? 8 : 0;
+    if (c->tune.em_reg_slices == 1) reg_words = cap <= 8 ? 2 : cap <= 16 ? 4 : cap <= 32 ? 8 : 0;
   }
   if (P.n_groups > P.n_small) {
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2545,13 +2448,6 @@ int EmSellGpu::setup(int hist_ints, const double* d_eff_new, u64 T_out) {
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPC(hipFuncSetAttribute((const void*)k_em_sell<true, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (const char* e = getenv("KAMD_EM_EXP")) {
-      exp = atoi(e);
-      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIPC(hipFuncSetAttribute((const void*)k_em_sell<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
   }
   if (gi && !c->em_ev_fork) {
     HIPC(hipEventCreateWithFlags(&c->em_ev_fork, hipEventDisableTiming));
@@ -2594,7 +2490,6 @@ __global__ void k_em_publish(EmsPrev prev) {
 // (:212-221), the scatter to transcript space, ONE copy to the host.
 int em_sell_drive_async(kamd_ctx* c, EmSellGpu& B, const SellCache& K, u64 T, int n_iter, int min_rounds, double* alpha_out, double* abz_out, int* rounds_out) {
   const int CH = EML_MAX_ROUNDS;
-  if (getenv("KAMD_EM_EXP")) { n_iter = std::min(n_iter, 1280); min_rounds = 1 << 30; }   // timing experiments: a fixed number of rounds, no stop
   if (n_iter <= 0) {   // no round at all: the initial vector (alpha_ = 1/T), no final round
     hipLaunchKernelGGL(k_em_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, K.mslot, K.single_all, B.d_alpha, B.d_alpha, T, 0, B.d_out, B.d_out + T);
     if (B.gi) hipLaunchKernelGGL(k_gi_scatter, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, B.gi->plan.mflag, B.gi->plan.mpos, B.gi->G_al[0], B.gi->G_al[0], 0,
@@ -2841,32 +2736,13 @@ __global__ void k_hy_single(const u64* __restrict__ ec_off, const u32* __restric
   const u64 a = ec_off[e];
   if (ec_off[e + 1] - a == 1) single_all[ec_ids[a]] = (double)counts[e];
 }
-// the stream k_em_sell runs on in the hybrid: a CU mask keeps it off the compute units left to the oversized components' kernels, which
-// therefore find free units whenever they are launched (a k_em_sell workgroup holds its unit's whole register file for a chunk of 64
-// rounds: 16 wavefronts x 124 registers -- nothing else fits beside it).  Mask bits: the low n_sell of the device's units (the driver
-// deals consecutive bits round-robin over the XCDs, so both sides get units on every XCD).  KAMD_EM_CUMASK=0: no mask (experiments).
-int hy_streams(kamd_ctx* c, int n_sell_cus) {
+// the oversized components' kernels run on a stream of their own beside k_em_sell's (no CU mask: reserving compute units for them was measured
+// slower in round 5 -- the streamed side is the critical path and finds free units as soon as the groups' launch of a chunk has drained)
+int hy_streams(kamd_ctx* c) {
   if (!c->hy_giant_stream) {
     HIPC(hipStreamCreateWithFlags(&c->hy_giant_stream, hipStreamNonBlocking));
     HIPC(hipEventCreateWithFlags(&c->hy_ev_giant, hipEventDisableTiming));
     HIPC(hipEventCreateWithFlags(&c->hy_ev_sell, hipEventDisableTiming));
-  }
-  const char* e = getenv("KAMD_EM_CUMASK");
-  const bool want_mask = !(e && atoi(e) == 0) && n_sell_cus > 0 && n_sell_cus < c->n_cus;
-  const int want = want_mask ? n_sell_cus : 0;
-  if (c->hy_sell_cus != want) {
-    if (c->hy_sell_stream) { HIPC(hipStreamSynchronize(c->hy_sell_stream)); HIPC(hipStreamDestroy(c->hy_sell_stream)); c->hy_sell_stream = nullptr; }
-    if (want) {
-      std::vector<uint32_t> mask((size_t)(c->n_cus + 31) / 32, 0u);
-      for (int b = 0; b < want; b++) mask[(size_t)b >> 5] |= 1u << (b & 31);
-      if (hipExtStreamCreateWithCUMask(&c->hy_sell_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        c->hy_sell_stream = nullptr;   // no masks on this runtime: the two forms share the chip
-        c->hy_sell_cus = 0;
-        return 0;
-      }
-    }
-    c->hy_sell_cus = want;
   }
   return 0;
 }
@@ -2958,17 +2834,8 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     HIPC(hipMemcpyAsync(off_s + n_s, zpos_s + n_ecs, 8, hipMemcpyDeviceToDevice, c->stream));
     HIPC(hipMemcpyAsync(off_g + n_g, zpos_g + n_ecs, 8, hipMemcpyDeviceToDevice, c->stream));
     HIPC(hipGetLastError());
-    // compute units: the oversized side's share of the entries, 32 .. 192 of 256, a multiple of 8 (one unit more or less on every XCD)
-    // (measured on the stress workload, profiles/README.md round 5: the mask COSTS time -- 50.1 against 43.9 ms at 4 M pairs, 167 against 142 ms
-    // at 30 M: the streamed side is the critical path whatever the groups do, and its kernels find free units as soon as the groups' first
-    // launch of a chunk has drained -- so the default is no mask; em_giant_cus > 0 reserves that many units)
-    int g_cus = c->tune.em_giant_cus > 0 ? c->tune.em_giant_cus : 0;
-    if (g_cus > 0) {
-      g_cus = std::min(std::max(g_cus, c->n_cus / 8), c->n_cus * 3 / 4) / 8 * 8;
-      if (g_cus <= 0 || g_cus >= c->n_cus) g_cus = c->n_cus / 2;
-    }
-    if (int rc = hy_streams(c, g_cus > 0 ? c->n_cus - g_cus : 0)) return rc;
-    const int sell_cus = c->hy_sell_cus > 0 ? c->hy_sell_cus : c->n_cus;
+    if (int rc = hy_streams(c)) return rc;
+    const int sell_cus = c->n_cus;
     // the side that fits: the component-local plan over its rows (groups sized for the compute units it gets)
     CompStats cst{};
     c->labels_override = label;   // (the components of the side that fits are components of the whole matrix)
@@ -3004,7 +2871,7 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     hipLaunchKernelGGL(k_em_prepare, dim3(grid_for(n_g, BLOCK)), dim3(BLOCK), 0, c->stream, off_g, ids_g, cnt_g, n_g, col_cnt, c->em_single.as<double>());
     if (int rc = exclusive_scan(c, col_cnt, T, c->em_coloff.as<u64>(), c->em_coloff.as<u64>() + T)) return rc;
     G.plan = PmPlan{};
-    const int src = em_streamed_setup(c, off_g, ids_g, cnt_g, wc_g, n_g, T, col_cnt, col_fill, &G.plan, &c->hy_a, &c->hy_b, g_cus > 0 ? g_cus : 0);
+    const int src = em_streamed_setup(c, off_g, ids_g, cnt_g, wc_g, n_g, T, col_cnt, col_fill, &G.plan, &c->hy_a, &c->hy_b);
     if (src < 0) return src;
     if (src != 0) return 1;
     const PmArgs& A = G.plan.args;
@@ -3020,59 +2887,10 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     G.ac = (double*)(xb + o_v[4]); G.desc = (GiDesc*)(xb + o_desc);
     hipLaunchKernelGGL(k_gi_zero_tail, dim3(1), dim3(64), 0, c->stream, G.S_al[0], G.S_al[1], G.S_a[0], G.S_a[1], G.ac, A.M);
     HIPC(hipGetLastError());
-    // the hot targets of either direction into LDS (k_gih_*): columns / rows of at least `thr` entries, thr the smallest power of two from 32
-    // whose segments fit the table.  MEASURED SLOWER and therefore off unless KAMD_EM_HOT=1 (round 5, stress workload: EM 46.7 against 41.5 ms at
-    // 4 M pairs, 157 against 144 ms at 30 M, where 2 790 hot transcripts cover half of the rows pass's gathers and 806 hot rows a sixth of the
-    // columns pass's: k_gih_rows 44.8 us against k_gi_rows 39.2 per round) -- a round of the oversized component moves 170 MB per pass (a 4-byte
-    // index and a gathered line per entry) in ~40 us, i.e. it runs at the chip's effective bandwidth for this pattern, not at the vector memory
-    // pipeline's divergent-access rate; the persistent workgroups' lower occupancy costs more than the LDS hits save.
-    G.hot_grid = 0; G.n_hot_t = 0; G.n_hot_r = 0; G.hot_t = nullptr; G.hot_r = nullptr;
-    {
-      const char* he = getenv("KAMD_EM_HOT");
-      const bool want_hot = he && atoi(he) != 0;
-      if (want_hot && A.R < PM_HOT && A.M < PM_HOT) {
-        const u64 nmax = std::max<u64>(A.R, A.M);
-        Carver hv;
-        const size_t h_cnt = hv.take(2 * 8 * 4), h_flag = hv.take(nmax * 4 + 8), h_slot = hv.take((nmax + 2) * 8);
-        size_t h_hs[2], h_list[2];
-        for (int d = 0; d < 2; d++) { h_hs[d] = hv.take(nmax * 4 + 8); h_list[d] = hv.take((size_t)GIH_HOT_CAP * 4); }
-        if (int rc = c->hy_hot.ensure(hv.off, 0, c->stream)) return rc;
-        char* hb2 = (char*)c->hy_hot.p;
-        u32* d_cnt = (u32*)(hb2 + h_cnt);
-        HIPC(hipMemsetAsync(d_cnt, 0, 2 * 8 * 4, c->stream));
-        const u64* offs[2] = {G.plan.coff, G.plan.roff};   // rows pass gathers transcripts: hot by COLUMN length; columns pass gathers rows: by ROW length
-        const u64 ns[2] = {A.M, A.R};
-        for (int d = 0; d < 2; d++) hipLaunchKernelGGL(k_gih_count, dim3(grid_for(ns[d], BLOCK)), dim3(BLOCK), 0, c->stream, offs[d], ns[d], d_cnt + 8 * d);
-        u32 h_counts[16];
-        HIPC(hipMemcpyAsync(h_counts, d_cnt, sizeof h_counts, hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
-        u32 n_hot[2] = {0, 0};
-        for (int d = 0; d < 2; d++) {
-          int j = 0;
-          while (j < 7 && h_counts[8 * d + j] > (u32)GIH_HOT_CAP) ++j;
-          n_hot[d] = std::min<u32>(h_counts[8 * d + j], (u32)GIH_HOT_CAP);
-          if (!n_hot[d]) continue;
-          u32* flag = (u32*)(hb2 + h_flag); u64* slot = (u64*)(hb2 + h_slot); u32* hs = (u32*)(hb2 + h_hs[d]); u32* list = (u32*)(hb2 + h_list[d]);
-          hipLaunchKernelGGL(k_gih_flag, dim3(grid_for(ns[d], BLOCK)), dim3(BLOCK), 0, c->stream, offs[d], ns[d], 32u << j, flag);
-          if (int rc = exclusive_scan(c, flag, ns[d], slot, slot + ns[d])) return rc;
-          hipLaunchKernelGGL(k_gih_list, dim3(grid_for(ns[d], BLOCK)), dim3(BLOCK), 0, c->stream, flag, slot, ns[d], (u32)GIH_HOT_CAP, list, hs);
-          hipLaunchKernelGGL(k_gih_mark, dim3(grid_for(G.plan.nzpad, BLOCK)), dim3(BLOCK), 0, c->stream, d == 0 ? G.plan.rs : G.plan.cs, G.plan.nzpad, hs, (u32)ns[d]);
-          if (d == 0) { G.hot_t = list; G.n_hot_t = n_hot[d]; } else { G.hot_r = list; G.n_hot_r = n_hot[d]; }
-        }
-        HIPC(hipGetLastError());
-        if (getenv("KAMD_DEBUG_FIN")) fprintf(stderr, "[kamd] hybrid: hot transcripts %u (columns >= 32: %u, >= 256: %u, >= 2048: %u of %u), hot rows %u (rows >= 32: %u, >= 256: %u, >= 2048: %u of %u)\n",
-                                              n_hot[0], h_counts[0], h_counts[3], h_counts[6], A.M, n_hot[1], h_counts[8], h_counts[11], h_counts[14], A.R);
-        if (n_hot[0] || n_hot[1]) {
-          if (!G.hot_t) G.hot_t = (const u32*)(hb2 + h_list[0]);   // (an empty table: n_hot = 0)
-          if (!G.hot_r) G.hot_r = (const u32*)(hb2 + h_list[1]);
-          G.hot_grid = (unsigned)std::min<u64>((u64)2 * c->n_cus, grid_for(G.plan.n_chunks, GIH_BLOCK / 64));
-        }
-      }
-    }
     G.stream = c->hy_giant_stream; G.ev = c->hy_ev_giant; G.use_graph = c->tune.em_graph != 2;
-    G.nnz = nnz_g; G.rows = A.R; G.cus = c->hy_sell_cus > 0 ? c->n_cus - c->hy_sell_cus : 0;
+    G.nnz = nnz_g; G.rows = A.R;
     K.hybrid = true;
-    c->last_em_giant_nnz = c->last_em_nnz_multi; c->last_em_giant_rows = A.R; c->last_em_giant_tr = A.M; c->last_em_giant_chunks = G.plan.n_chunks; c->last_em_giant_cus = G.cus;
+    c->last_em_giant_nnz = c->last_em_nnz_multi; c->last_em_giant_rows = A.R; c->last_em_giant_tr = A.M; c->last_em_giant_chunks = G.plan.n_chunks;
     return 0;
   }
   return 1;
@@ -3110,7 +2928,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   } else {
     const auto plan_t0 = std::chrono::steady_clock::now();
     K.valid = false; K.hybrid = false;
-    c->last_em_giant_nnz = 0; c->last_em_giant_rows = 0; c->last_em_giant_tr = 0; c->last_em_giant_chunks = 0; c->last_em_giant_cus = 0;
+    c->last_em_giant_nnz = 0; c->last_em_giant_rows = 0; c->last_em_giant_tr = 0; c->last_em_giant_chunks = 0;
     // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not fit, the
     // cut is refined a few times; a single component beyond the CU's 160 KB sends the oversized components to the streamed kernels
     // beside the groups -- the hybrid, em_hybrid_setup -- or, with several ranks, the whole matrix to the streamed form)
@@ -3162,7 +2980,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   const int chunk = EML_MAX_ROUNDS;
   EmSellGpu B(c, P);
   B.dev = K.dev; B.M = P.tr_base[P.n_groups]; B.block = c->tune.em_local_block; B.part = multi ? part : nullptr;
-  if (K.hybrid) { B.gi = &K.G; B.sell_stream = c->hy_sell_stream; B.ev_sell = c->hy_ev_sell; }
+  if (K.hybrid) { B.gi = &K.G; B.ev_sell = c->hy_ev_sell; }
   const int n_chunks = std::max(1, (n_iter + chunk - 1) / chunk);
   if (int rc = B.setup(multi ? chunk : n_chunks * chunk, K.dev.eff, multi ? 0 : T)) return rc;
   int r = 0;
@@ -3176,6 +2994,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   c->last_em_nnz = nnz; c->last_em_k = -2; c->last_em_grid = P.n_groups; c->last_em_necs = n_ecs;
   c->last_em_lds = (uint32_t)P.max_group_bytes;
   c->last_em_plan_cached = hit ? 1 : 0;
+  c->last_em_graph_fallback = (K.hybrid && c->tune.em_graph != 2 && !K.G.use_graph) ? 1 : 0;
   if (rounds) *rounds = r;
   return 0;
 }

@@ -101,11 +101,12 @@ constexpr u32 RAW_OVERFLOW = 1u << 8, RAW_HIT0 = 1u << 9, RAW_HIT1 = 1u << 10;
 // More than V3_LIST_CAP distinct classes (0.5 % of config #3's pairs): the item goes to the overflow kernel, as before.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int V3_LIST_CAP = 8;
-constexpr int V3_LIST_CAP_LONG = 64;   // the second pass over the items whose list overflowed (k_match_v3<..., V3_LIST_CAP_LONG> on an item list)
-// LCAP: class entries per item in LDS.  item_idx != null: the launch works on the items item_idx[0 .. n_items) of the batch (their raw records
-// go to slots 0 .. n_items of `raw`): the second pass over the items whose list overflowed in the first -- a pair inside a repeat family or a
-// poly-A stretch has dozens of distinct classes --, with the same data-flow matcher instead of 64 divergent straight-line ones per wavefront.
-template <bool PAIRED, bool FILTER, bool DL, bool TEXT, int LAYOUT, int LCAP = V3_LIST_CAP>
+constexpr int V3_LIST_CAP_LONG = 192;   // the second pass over the items whose list overflowed (k_match_v3<..., V3_LIST_CAP_LONG, true> on an item list)
+// LCAP: class entries per item (in LDS; APPEND: in the item's raw record in global memory, appended, never scanned -- kamd_core.h UecList).
+// item_idx != null: the launch works on the items item_idx[0 .. n_items) of the batch (their raw records go to slots 0 .. n_items of `raw`):
+// the second pass over the items whose list overflowed in the first -- a pair inside a repeat family or a poly-A stretch has dozens of
+// distinct classes --, with the same data-flow matcher at the same occupancy instead of 64 divergent straight-line ones per wavefront.
+template <bool PAIRED, bool FILTER, bool DL, bool TEXT, int LAYOUT, int LCAP = V3_LIST_CAP, bool APPEND = false>
 __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __restrict__ words, const uint16_t* __restrict__ lens,
                                                     u64 n_items, int seq_words, int rec_words, int items_per_wave, int refill_min,
                                                     u32* raw, int raw_stride, DevStatsA* st, const u64* __restrict__ item_idx = nullptr) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
   const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   u32* wave_words = lds + (size_t)wv * 64 * lane_words;       // the wavefront's items, lane-transposed
   u32* my_words = wave_words + lane;                          // word j at my_words[j * 64]
-  u32* my_list = lds + (size_t)WAVES * 64 * lane_words + threadIdx.x;   // entry j at my_list[j * BLOCK]
+  u32* my_list = APPEND ? nullptr : lds + (size_t)WAVES * 64 * lane_words + threadIdx.x;   // entry j at my_list[j * BLOCK]
   const u64 wave_global = (u64)blockIdx.x * WAVES + wv;
   const u64 chunk0 = wave_global * (u64)items_per_wave;
   const u32 chunk_n = chunk0 < n_items ? (u32)min((u64)items_per_wave, n_items - chunk0) : 0u;
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
 
   kamd::MatchState ms; ms.phase = kamd::PH_DONE; ms.w = 0; ms.w0 = 0; ms.w2 = 0; ms.dist = 0; ms.nextPos = 0;
   ms.um_uec = ms.um2_uec = kamd::NO_UEC; ms.um_gpos = 0; ms.um_strand = false; ms.text_tried = false; ms.disp = 0;
-  kamd::UecList ul{my_list, LCAP, 0, false, BLOCK};
+  kamd::UecList ul{my_list, LCAP, 0, false, APPEND ? 1 : BLOCK};
+  ul.append = APPEND;
   kamd::MateFirst mf0{0, 0, -1, false}, mf1{0, 0, -1, false};
   u64 my_item = 0;        // the lane's item in the batch (chunk0 + my_idx, or item_idx[chunk0 + my_idx])
   int mate = 0, len0 = 0, len1 = 0;
@@ -216,7 +218,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
     // 3. lanes that fetched an item: its words are in LDS once the DMA loads have landed; start mate 1
     if (loading) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ul.n = 0; ul.overflow = false;
+      ul.n = 0; ul.overflow = false; ul.last = kamd::NO_UEC; ul.last_flags = 0;
+      if (APPEND) ul.e = raw + (chunk0 + my_idx) * (u64)raw_stride + 1;   // the item's classes go straight into its raw record
       mf0 = kamd::MateFirst{0, 0, -1, false}; mf1 = kamd::MateFirst{0, 0, -1, false};
       mate = 0;
       n0 = (my_words[(size_t)(seq_words - 1) * 64] & kamd::REC_FLAG_HAS_N) != 0;
@@ -237,11 +240,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
     if (have && !busy) {
       u32* o = raw + (chunk0 + my_idx) * (u64)raw_stride;
       o[0] = (u32)ul.n | (ul.overflow ? RAW_OVERFLOW : 0u) | (mf0.n_hits > 0 ? RAW_HIT0 : 0u) | (mf1.n_hits > 0 ? RAW_HIT1 : 0u);
-      if constexpr (LCAP <= 16) {
+      if constexpr (!APPEND) {
 #pragma unroll
         for (int j = 0; j < LCAP; j++) if (j < ul.n) o[1 + j] = my_list[(size_t)j * BLOCK];
-      } else {
-        for (int j = 0; j < ul.n; j++) o[1 + j] = my_list[(size_t)j * BLOCK];
       }
       raw_words += 1u + (u32)ul.n;
       if (FILTER) {
@@ -364,20 +365,14 @@ template <bool PAIRED, bool FILTER>
 __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const u32* __restrict__ words,
                                                              const uint16_t* __restrict__ lens, const u64* items, u64 n,
                                                              int seq_words, int rec_words, u32* scratch, FilterDev fd,
-                                                             u64 rec_base, AlignOut out, int lds_cap) {
-  extern __shared__ u32 ov_lds[];
+                                                             u64 rec_base, AlignOut out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 item = items[i];
   const int item_words = rec_words * (PAIRED ? 2 : 1);
-  // scratch of an item: the list, then as many words for the cursors of the --union merge.  The list is a SORTED array kept by insertion
-  // (eclist_add: a scan and a shift per new set): in global scratch that is thousands of dependent memory accesses for an item with a
-  // hundred sets -- a pair inside a repeat family or a poly-A stretch; in LDS (lds_cap words per thread, an odd stride: the threads' lists
-  // start in different banks) it is ALU work.  lds_cap = the k-mers of an item (it cannot have more distinct sets), 0 = the global list
-  // (the default: launch_overflow says why).
+  // scratch of an item: the list (a sorted array kept by insertion, eclist_add), then as many words for the cursors of the --union merge
   kamd::EcList ecs; ecs.n = 0; ecs.overflow = false;
-  if (lds_cap > 0) { ecs.e = ov_lds + (size_t)threadIdx.x * (size_t)lds_cap; ecs.cap = lds_cap; }
-  else { ecs.e = scratch + i * (2 * TUPLE_CAP_BIG); ecs.cap = TUPLE_CAP_BIG; }
+  ecs.e = scratch + i * (2 * TUPLE_CAP_BIG); ecs.cap = TUPLE_CAP_BIG;
   u32* cur = scratch + i * (2 * TUPLE_CAP_BIG) + TUPLE_CAP_BIG;
   kamd::MateInfo m0, m1; m1.n_hits = 0; m1.n_nonempty = 0;
   const kamd::Table t = make_table(ix, !PAIRED);
@@ -411,9 +406,10 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
   atomicAdd(&out.st->st_multi, 1ULL);
 }
 
-// The second pass's raw records (k_match_v3<..., V3_LIST_CAP_LONG> over the items whose list overflowed in the first) -> tuple records, with
-// k_pseudoalign_overflow's tail: the item's own record is redirected to a long record appended to the stream.  Items whose list overflowed
-// again (more than CAP distinct classes) are listed for the straight-line kernel.
+// The second pass's raw records (k_match_v3<..., V3_LIST_CAP_LONG, true> over the items whose list overflowed in the first: appended classes,
+// duplicates among them unless they were neighbours) -> tuple records, with k_pseudoalign_overflow's tail: the item's own record is
+// redirected to a long record appended to the stream.  The de-duplication happens here, in the sorted insertion into the item's set list
+// (LDS).  Items whose list overflowed again (more than CAP appended classes) are listed for the straight-line kernel.
 template <bool PAIRED, bool FILTER, int CAP>
 __global__ __launch_bounds__(64) void k_classify_long(DevIndex ix, const u32* __restrict__ raw, int stride, const u64* __restrict__ items, u64 n, u32* scratch,
                                                       FilterDev fd, u64 rec_base, AlignOut out, u64* items_left) {
@@ -820,21 +816,13 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
 }
 template <bool PAIRED, bool FILTER>
 void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
-                     u64 rec_base, const AlignOut& out, int max_len, const u64* items = nullptr) {
-  // the list of an item in LDS when the k-mers of an item (an upper bound of its distinct sets) fit 64 KB per block of 64 threads
-  int lds_cap = (PAIRED ? 2 : 1) * std::max(1, max_len - (int)c->ix.k + 1);
-  lds_cap |= 1;
-  // (measured on the stress workload, round 5: the LDS list does NOT pay -- 5.9 against 5.1 ms at 4 M pairs, 37 against 33 ms at 30 M: the kernel's
-  // time is the divergence of 64 straight-line matchers in one wavefront and their dependent probes, not the list; at four wavefronts per CU the
-  // LDS form has less of the memory system in flight.  Kept behind KAMD_OVERFLOW_LDS_LIST=1; what these items need is kernel A's data-flow loop
-  // with a longer class list, DESIGN.md "not done")
-  if (lds_cap > TUPLE_CAP_BIG || (size_t)lds_cap * 64 * 4 > 64 * 1024 || !getenv("KAMD_OVERFLOW_LDS_LIST")) lds_cap = 0;
-  const size_t lds = (size_t)lds_cap * 64 * 4;
-  hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), lds, c->stream, c->ix, d_words, d_len,
-                     items ? items : (const u64*)c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out, lds_cap);
+                     u64 rec_base, const AlignOut& out, const u64* items = nullptr) {
+  hipLaunchKernelGGL((k_pseudoalign_overflow<PAIRED, FILTER>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, d_words, d_len,
+                     items ? items : (const u64*)c->overflow_items.as<u64>(), nov, seq_words, rec_words, c->overflow_scratch.as<u32>(), fd, rec_base, out);
 }
-// The second pass of kernel A over the items whose class list overflowed: the data-flow matcher with a list of V3_LIST_CAP_LONG classes per
-// lane, reading the items through overflow_items[]; their records through k_classify_long.  Returns 0 = done (items whose list overflowed again
+// The second pass of kernel A over the items whose class list overflowed: the data-flow matcher with an append-only list of up to
+// V3_LIST_CAP_LONG classes per item in global memory (no list in LDS: kernel A's occupancy), reading the items through overflow_items[];
+// their records through k_classify_long.  Returns 0 = done (items whose list overflowed again
 // are in c->overflow_left, their number in host_state.n_overflow), 1 = not applicable (reads too long for the LDS layout: the caller takes the
 // straight-line kernel for all items), < 0 = error.
 template <bool PAIRED, bool FILTER>
@@ -843,7 +831,7 @@ int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len,
   constexpr int NM = PAIRED ? 2 : 1;
   constexpr int LC = V3_LIST_CAP_LONG;
   const int lane_words = seq_words * NM;
-  const size_t lds_bytes = ((size_t)WAVES * 64 * lane_words + (size_t)BLOCK * LC) * sizeof(u32);
+  const size_t lds_bytes = (size_t)WAVES * 64 * lane_words * sizeof(u32);
   if (lds_bytes > 96 * 1024) return 1;
   const int stride2 = 2 + LC + (FILTER ? 4 : 0);
   if (int rc = c->raw2.ensure(nov * (u64)stride2 * sizeof(u32), 0, c->stream)) return rc;
@@ -857,8 +845,8 @@ int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len,
   u32* raw2 = c->raw2.as<u32>();
 #define KAMD_LAUNCH_V3L2(DLV, TXT, LAY)                                                                                                  \
   do {                                                                                                                                  \
-    HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, nov, \
+    HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC, true>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, nov, \
                        seq_words, rec_words, ipw, std::min(c->refill_min, 8), raw2, stride2, c->stats_b.as<DevStatsA>(), (const u64*)c->overflow_items.as<u64>()); \
   } while (0)
 #define KAMD_LAUNCH_V32(DLV, TXT)                                                                                                        \
@@ -923,13 +911,12 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   if (c->host_state.n_overflow) {
     const u64 nov = c->host_state.n_overflow;
     c->had_overflow_items = true;
-    // Optionally the items go through kernel A's loop once more with a list of 64 classes (overflow_second_pass); what overflows again -- or every
-    // item by default -- takes the straight-line kernel.  The cursor scratch (2 x 1024 words per item) is only needed by the filters / --union
-    // in the second pass and by the straight-line kernel.
-    // MEASURED SLOWER, therefore opt-in (KAMD_OVERFLOW_SECOND_PASS=1; round 5): 41.5 against 33.0 ms for the 1.65 M such pairs of 30 M stress pairs,
-    // 0.74 against 0.62 ms on config #3 -- these items have a hundred probes and dozens of classes each, the 64-entry list is scanned per hit,
-    // and the kernel holds 8 wavefronts per CU with it instead of 24; what overflows again pays twice.
-    const bool try_second = getenv("KAMD_OVERFLOW_SECOND_PASS") && !getenv("KAMD_OVERFLOW_STRAIGHT");
+    // The items go through kernel A's loop once more with an append-only class list in global memory (overflow_second_pass); what overflows
+    // again -- or every item when the tuning says so, or when the reads are too long for the LDS layout -- takes the straight-line kernel.  The
+    // cursor scratch (2 x 1024 words per item) is only needed by the filters / --union in the second pass and by the straight-line kernel.
+    // (Round 5's second pass kept a SCANNED 64-entry list per lane in LDS: 8 wavefronts per CU instead of 24 and a scan per hit, 41.5 ms against
+    // the straight-line kernel's 33-37 for the 1.65 M such pairs of 30 M stress pairs; it was opt-in and is gone.)
+    const bool try_second = c->tune.overflow_second_pass != 2;
     const bool need_cursors = filter || c->ix.union_mode;
     if (!try_second || need_cursors) if (int rc2 = c->overflow_scratch.ensure(nov * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
     const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
@@ -953,10 +940,10 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     c->overflow_second_total += nov - n_straight;
     if (n_straight) {
       if (int rc2 = c->overflow_scratch.ensure(n_straight * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
-      if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items);
-                       else launch_overflow<true, false>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items); }
-      else { if (filter) launch_overflow<false, true>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items);
-             else launch_overflow<false, false>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, max_len, straight_items); }
+      if (o->paired) { if (filter) launch_overflow<true, true>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, straight_items);
+                       else launch_overflow<true, false>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, straight_items); }
+      else { if (filter) launch_overflow<false, true>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, straight_items);
+             else launch_overflow<false, false>(c, d_words, d_len, n_straight, seq_words, rec_words, fd, ov_base, out, straight_items); }
     }
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(c->ev_ov1, c->stream));
@@ -1023,8 +1010,8 @@ extern "C" int kamd_align_stats_get(kamd_ctx* c, kamd_align_stats* s) {
 }
 
 namespace {
-// ~20 000 qualifying pairs at config #3's rate: one pass, with a margin for sparser data (KAMD_FLD_FIRST_CHUNK: experiments)
-const u64 FLD_FIRST_CHUNK = [] { const char* e = getenv("KAMD_FLD_FIRST_CHUNK"); const long long v = e ? atoll(e) : 0; return v >= 65536 ? (u64)v : (u64)1048576; }();
+// ~20 000 qualifying pairs at config #3's rate: one pass, with a margin for sparser data
+constexpr u64 FLD_FIRST_CHUNK = 1048576;
 constexpr int FLD_CAP_SMALL = 64;   // list entries per item in global scratch (an LDS list of TUPLE_CAP entries sends too many items to
                                     // the re-run, which costs ~1 ms per launch however few they are)
 // buffers for a prefix of n items + k_fld_first / k_fld / k_fld_rank + the copy of the ranked sample, all on stream s (no synchronisation)
@@ -1079,19 +1066,11 @@ extern "C" int kamd_fld_prefetch(kamd_ctx* c, const kamd_quant_opts* o, const ui
     HIPC(hipEventCreateWithFlags(&c->fld_ev_in, hipEventDisableTiming));
   }
   if (c->fld_pending.valid) { HIPC(hipStreamSynchronize(c->fld_stream)); c->fld_pending.valid = false; }
-  const FilterDev fd{o->single_overhang, 0, 0, o->strand, c->ix.comprehensive};
   const u64 n = std::min<u64>(FLD_FIRST_CHUNK, n_items);
-  if (c->fld_after_a) {   // launched by the kamd_pseudoalign call on the same batch, behind its kernel A (align_batch)
-    c->fld_deferred.w = d_words; c->fld_deferred.l = d_len; c->fld_deferred.n = n; c->fld_deferred.max_len = max_len;
-    c->fld_deferred.strand = o->strand; c->fld_deferred.so = o->single_overhang; c->fld_deferred.comp = c->ix.comprehensive; c->fld_deferred.valid = true;
-    return 0;
-  }
-  HIPC(hipEventRecord(c->fld_ev_in, c->stream));            // the reads were produced on the context stream
-  HIPC(hipStreamWaitEvent(c->fld_stream, c->fld_ev_in, 0));
-  if (int rc = fld_launch(c, fd, d_words, d_len, n, (max_len + 15) / 16 + 1, (int)kamd_packed_record_words(max_len), c->fld_stream)) return rc;
-  HIPC(hipEventRecord(c->fld_ev, c->fld_stream));
-  c->fld_pending.w = d_words; c->fld_pending.l = d_len; c->fld_pending.n = n; c->fld_pending.max_len = max_len;
-  c->fld_pending.strand = o->strand; c->fld_pending.so = o->single_overhang; c->fld_pending.valid = true;
+  // launched by the kamd_pseudoalign call on the same batch, behind its kernel A (align_batch): the fragment-length kernels then run beside
+  // k_classify / the tuple de-duplication instead of underneath kernel A, which lives on the memory system's request rate
+  c->fld_deferred.w = d_words; c->fld_deferred.l = d_len; c->fld_deferred.n = n; c->fld_deferred.max_len = max_len;
+  c->fld_deferred.strand = o->strand; c->fld_deferred.so = o->single_overhang; c->fld_deferred.comp = c->ix.comprehensive; c->fld_deferred.valid = true;
   return 0;
 }
 

@@ -64,11 +64,9 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
 @pytest.mark.parametrize("path", ["second_pass", "straight"])
 def test_items_with_long_class_lists(case, variant, path, ka, ctxs, monkeypatch):
     """Items with more than eight distinct (unitig, set) classes -- pairs inside repeat families and poly-A stretches (a fifth of the stress fixture's
-    mapped pairs), --no-jump runs -- leave kernel A's first pass unfinished.  Round 5: they go through the SAME data-flow matcher once more with a list
-    of 64 classes (k_match_v3<..., 64> over the item list, k_classify_long) when KAMD_OVERFLOW_SECOND_PASS=1 asks for it -- measured slower than the
-    straight-line kernel, which stays the default (DESIGN_HISTORY.md round 5).  Both must give the reference's classes, and the second pass must have taken items."""
-    if path == "second_pass":
-        monkeypatch.setenv("KAMD_OVERFLOW_SECOND_PASS", "1")
+    mapped pairs), --no-jump runs -- leave kernel A's first pass unfinished.  Round 6: by default they go through the SAME data-flow matcher once more
+    with an append-only class list in global memory (k_match_v3<..., 192, true> over the item list; k_classify_long removes the duplicates); with
+    overflow_second_pass off all of them take the straight-line kernel.  Both must give the reference's classes, and the second pass must have taken items."""
     meta, idx_path, r1, r2 = common.load_case(case)
     o = common.parse_variant(meta["variants"][variant])
     exp = common.load_expected(case, variant)
@@ -76,9 +74,13 @@ def test_items_with_long_class_lists(case, variant, path, ka, ctxs, monkeypatch)
     reads = common.interleave(r1, r2 if o["paired"] else None)
     words, lens, max_len = ctx.pack_reads_host(reads)
     opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"])
-    ctx.reset()
-    res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
-    prof = ctx.profile()
+    ctx.tune(overflow_second_pass=(path == "second_pass"))
+    try:
+        ctx.reset()
+        res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
+        prof = ctx.profile()
+    finally:
+        ctx.tune(overflow_second_pass=True)   # (the contexts are shared between the tests)
     assert res.ecs.multiset() == exp["ecs"] and np.array_equal(res.flens, exp["flens"])
     common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
     assert prof["n_overflow_items"] > 0, "the fixture no longer exercises the long-list path"
@@ -297,7 +299,7 @@ def _hybrid_csr(n_genes, seed, n_chained=500):
 
 
 @pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
-                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_hot", "hybrid_k8_hot", "hub_hot", "hybrid_nograph_hot", "hybrid_graphfail"])
+                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_graphfail"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -308,11 +310,7 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     from oracle import oracle as O
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
-    if isinstance(k, str) and k.endswith("_hot"):
-        # the oversized side with the values of its hot targets (long rows' transcripts, hub rows) in LDS and persistent workgroups -- the default
-        # from a million entries on, forced here on the small matrices
-        monkeypatch.setenv("KAMD_EM_HOT", "1")
-        k = k[:-4]
+    graphfail = k == "hybrid_graphfail"
     if k == "hybrid_graphfail":
         # the chunk graph of one ping-pong parity exists, the other one's cannot be instantiated: both are dropped, this chunk and the later ones go out
         # as plain launches
@@ -378,6 +376,7 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     elif k == "hub_streamed":
         assert prof["em_k"] > 0 and prof["em_giant_nnz"] == 0
     elif k == "hybrid":
+        assert prof["em_graph_fallback"] == (1 if graphfail else 0)   # (the injected failure was seen and the plain launches took over)
         assert prof["em_k"] == -2 and prof["em_grid"] > 1      # groups in k_em_sell ...
         assert prof["em_giant_nnz"] > 20000 and prof["em_max_comp_nnz"] > 20000   # ... and the oversized component beside them
     else:
