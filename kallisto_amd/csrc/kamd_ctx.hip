@@ -211,6 +211,31 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   for (u64 u = 0; u < v.n_uec; u++) ecn[u] = v.uec_ec[u] | (ne[v.uec_ec[u]] ? 0x80000000u : 0u);
   if (int rc = upload(c, ecn.data(), v.n_uec, &d.uec_ecn)) return rc;
   if (int rc = upload(c, v.onlist_bits, v.onlist_words, &d.onlist_bits)) return rc;
+  {
+    // bitmaps of the large transcript sets (kamd_dev.h DevIndex): the largest first while they fit BM_MAX_BYTES
+    const u64 n_ids = v.n_targets + v.dlist_size;
+    const u32 stride = (u32)((n_ids + 31) / 32);
+    std::vector<std::pair<u64, u32>> big;   // (size, set)
+    for (u64 e = 0; e < v.n_ecs; e++) { const u64 sz = v.ec_off[e + 1] - v.ec_off[e]; if (sz > BM_MIN_MEMBERS) big.emplace_back(sz, (u32)e); }
+    std::sort(big.begin(), big.end(), [](const std::pair<u64, u32>& a, const std::pair<u64, u32>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    const size_t fit = stride ? BM_MAX_BYTES / ((size_t)stride * 4) : 0;
+    if (big.size() > fit) big.resize(fit);
+    d.bm_stride = stride; d.bm_min = big.empty() ? 0xFFFFFFFFu : BM_MIN_MEMBERS;
+    d.ec_bm_slot = nullptr; d.bm_words = nullptr;
+    if (!big.empty()) {
+      std::vector<u32> slot(v.n_ecs, BM_NONE), words(big.size() * (size_t)stride, 0u);
+      for (size_t s = 0; s < big.size(); s++) {
+        const u32 e = big[s].second;
+        slot[e] = (u32)s;
+        u32* w = words.data() + s * (size_t)stride;
+        for (u64 j = v.ec_off[e]; j < v.ec_off[e + 1]; j++) { const u32 x = v.ec_ids[j]; w[x >> 5] |= 1u << (x & 31); }
+      }
+      if (int rc = upload(c, slot.data(), slot.size(), &d.ec_bm_slot)) return rc;
+      if (int rc = upload(c, words.data(), words.size(), &d.bm_words)) return rc;
+      HIPC(hipStreamSynchronize(c->stream));   // (stack-owned staging buffers)
+    }
+    c->n_set_bitmaps = (u32)big.size();
+  }
   if (int rc = upload(c, (const u64*)v.unitig_blk_off, v.n_unitigs + 1, &d.unitig_blk_off)) return rc;
   if (int rc = upload(c, v.unitig_len, v.n_unitigs, &d.unitig_len)) return rc;
   if (int rc = upload(c, v.blk_unitig, v.n_blocks, &d.blk_unitig)) return rc;

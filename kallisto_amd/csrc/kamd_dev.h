@@ -50,6 +50,10 @@ struct DevIndex {
   const u64* ec_off; const u32* ec_ids; const uint8_t* ec_nonempty;
   const u32* uec_ecn;   // uec_ec with bit 31 = "the set is non-empty": one gather instead of two dependent ones in k_classify
   const u32* onlist_bits;
+  // the LARGE transcript sets (more than bm_min members: poly-A and repeat-family classes, a few hundred of them) also as bitmaps over the
+  // transcripts, bm_stride words each -- what the reference's Roaring containers are for such sets (src/MinCollector.cpp:425-496, `r &= ...`):
+  // membership is one bit test instead of a binary search.  ec_bm_slot[e] = the set's bitmap, or BM_NONE.  bm_min = 0xFFFFFFFF: none at all
+  const u32* ec_bm_slot; const u32* bm_words; u32 bm_stride, bm_min;
   u64 n_ecs; int k;
   // positional tables (findPosition / strand filters)
   const u64* unitig_blk_off; const u32* unitig_len; const u32* blk_unitig; const u32* blk_lb; const u32* blk_ub; const u32* blk_ec;
@@ -121,6 +125,15 @@ __device__ __forceinline__ bool set_contains(const u32* ids, u32 n, u32 x) {
   u32 lo = 0, hi = n;
   while (lo < hi) { u32 mid = (lo + hi) >> 1; if (ids[mid] < x) lo = mid + 1; else hi = mid; }
   return lo < n && ids[lo] == x;
+}
+constexpr u32 BM_NONE = 0xFFFFFFFFu;
+constexpr u32 BM_MIN_MEMBERS = 1024;          // sets with more members get a bitmap (kamd_index_upload) ...
+constexpr size_t BM_MAX_BYTES = 256u << 20;   // ... the largest first, while they fit this much HBM
+__device__ __forceinline__ bool bitmap_has(const DevIndex& ix, u32 slot, u32 x) { return (ix.bm_words[(u64)slot * ix.bm_stride + (x >> 5)] >> (x & 31)) & 1u; }
+// is transcript x a member of index set e (its ids at ec_ids + off, sz of them)?
+__device__ __forceinline__ bool set_has(const DevIndex& ix, u32 e, u64 off, u32 sz, u32 x) {
+  if (sz > ix.bm_min) { const u32 s = ix.ec_bm_slot[e]; if (s != BM_NONE) return bitmap_has(ix, s, x); }
+  return set_contains(ix.ec_ids + off, sz, x);
 }
 // f(tr) for every on-listed member of the item's transcript set (intersection of its sets, or the per-mate unions intersected
 // with --union), in increasing order; thread-serial.  cur: ecs.n words of scratch for the --union merge.
@@ -212,6 +225,7 @@ struct kamd_ctx {
   DevIndex ix{};
   std::vector<void*> index_allocs;
   u64 n_ecs = 0, n_targets = 0;
+  u32 n_set_bitmaps = 0;   // index sets that also exist as bitmaps (DevIndex::bm_words)
   DBuf dense, stream_buf, rec_off, overflow_items, overflow_scratch, state, rec_slot, retry, ttable, list;
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums, tup_bound, tup_off, tup_big;
   DBuf raw2, overflow_left, stats_b;   // the second pass over the items whose class list overflowed: its raw records, what overflows again, its counters

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
     for (u32 j = 0; j < m; j++) {
       if (j == best) continue;
       const u32 e = es[j];
-      if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+      if (ok) { const u64 o = ix.ec_off[e]; ok = set_has(ix, e, o, (u32)(ix.ec_off[e + 1] - o), x); }   // (a bit test when the set has a bitmap)
     }
     *x_out = x;
     return (u32)((__ballot(ok) >> gsh) & 0xFFFFu);
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
                                                                u64* cand_off, u64* cand_key, const DevState* st) {
   __shared__ u32 s_cand_all[RB_WAVES][CAND];
   __shared__ u32 s_tile_all[RB_WAVES][RB_TILE];
-  __shared__ u32 s_meta_all[RB_WAVES][3 * RB_MAXSETS];   // offsets (two words) and sizes of the tuple's sets; size 0xFFFFFFFF = taken
+  __shared__ u32 s_meta_all[RB_WAVES][4 * RB_MAXSETS];   // offsets (two words), sizes (0xFFFFFFFF = taken) and bitmap slots (BM_NONE = none) of the tuple's sets
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const u64 bi = (u64)blockIdx.x * RB_WAVES + w;
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
   u32* s_off = s_meta_all[w];
   u32* s_offh = s_off + RB_MAXSETS;
   u32* s_sz = s_off + 2 * RB_MAXSETS;
+  u32* s_bm = s_off + 3 * RB_MAXSETS;
   const u64 base_words = st->cand_words, base_recs = st->cand_recs;
   const u64 gid = big_idx[bi];
   const u64 le = list[gid];
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
     const u32 e = es[j] & kamd::EC_ID_MASK;
     const u64 off = ix.ec_off[e];
     const u32 sz = (u32)(ix.ec_off[e + 1] - off);
-    if (lds_meta) { s_off[j] = (u32)off; s_offh[j] = (u32)(off >> 32); s_sz[j] = sz; }
+    if (lds_meta) { s_off[j] = (u32)off; s_offh[j] = (u32)(off >> 32); s_sz[j] = sz; s_bm[j] = sz > ix.bm_min ? ix.ec_bm_slot[e] : BM_NONE; }
     if (sz < bsz) { bsz = sz; bj = j; }   // (first wins on ties, as in k_resolve)
   }
 #pragma unroll
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
       for (u32 j = 0; j < m; j++) {
         if (j == best) continue;
         const u32 e = es[j] & kamd::EC_ID_MASK;
-        if (ok) ok = set_contains(ix.ec_ids + ix.ec_off[e], (u32)(ix.ec_off[e + 1] - ix.ec_off[e]), x);
+        if (ok) { const u64 o = ix.ec_off[e]; ok = set_has(ix, e, o, (u32)(ix.ec_off[e + 1] - o), x); }
       }
       const u64 bm = __ballot(ok);
       if (ok) cand[out_off + 2 + cnt + __popcll(bm & ((1ULL << lane) - 1ULL))] = x;
@@ -604,6 +605,42 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
       cnt += (u32)__popcll(bm);
     }
     wave_lds_sync();
+    // The sets that exist as bitmaps (more than BM_MIN_MEMBERS members: the poly-A and repeat-family classes -- the same few hundred sets in
+    // every such tuple, so their bitmaps sit in L2) first, all of them at once: a survivor is tested against them bit by bit, four tests in
+    // flight, and drops out at the first set that lacks it.  Streaming a 3 500-member set through LDS and binary-searching the survivors in
+    // it cost 350 k look-ups per poly-A tuple (100 sets of 3 500 members): 52 ms for the 10 043 such tuples of 30 M stress pairs (round 5).
+    u32 nbm = 0;
+    for (u32 j0 = 0; j0 < m; j0 += 64) {
+      const u32 j = j0 + lane;
+      const bool has = j < m && s_sz[j] != 0xFFFFFFFFu && s_bm[j] != BM_NONE;
+      const u64 bmk = __ballot(has);
+      if (has) { s_tile[nbm + __popcll(bmk & ((1ULL << lane) - 1ULL))] = s_bm[j]; s_sz[j] = 0xFFFFFFFFu; }
+      nbm += (u32)__popcll(bmk);
+    }
+    wave_lds_sync();
+    if (nbm && cnt) {
+      u32 kept = 0;
+      for (u32 c0 = 0; c0 < cnt; c0 += 64) {
+        const u32 c = c0 + lane;
+        const u32 x = c < cnt ? s_cand[c] : 0u;
+        bool ok = c < cnt;
+        const u32* wp = ix.bm_words + (x >> 5);
+        const u32 bit = 1u << (x & 31);
+        for (u32 b = 0; b < nbm && __ballot(ok) != 0ULL; b += 4) {
+          const u32 s0 = s_tile[b], s1 = s_tile[min(b + 1, nbm - 1)], s2 = s_tile[min(b + 2, nbm - 1)], s3 = s_tile[min(b + 3, nbm - 1)];
+          if (ok) {
+            const u32 w0 = wp[(u64)s0 * ix.bm_stride], w1 = wp[(u64)s1 * ix.bm_stride], w2 = wp[(u64)s2 * ix.bm_stride], w3 = wp[(u64)s3 * ix.bm_stride];
+            ok = (w0 & w1 & w2 & w3 & bit) != 0u;
+          }
+        }
+        const u64 bmk = __ballot(ok);
+        wave_lds_sync();
+        if (ok) s_cand[kept + __popcll(bmk & ((1ULL << lane) - 1ULL))] = x;
+        kept += (u32)__popcll(bmk);
+        wave_lds_sync();
+      }
+      cnt = kept;
+    }
     // while more than 64 survive: the smallest set not yet taken streams through LDS (both lists are sorted: only the survivors inside a
     // tile's id range are looked up in it, by binary search in LDS); bit 31 of a survivor marks "found in this set"
     while (cnt > 64) {

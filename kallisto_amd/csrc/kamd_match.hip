@@ -410,56 +410,131 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
 // duplicates among them unless they were neighbours) -> tuple records, with k_pseudoalign_overflow's tail: the item's own record is
 // redirected to a long record appended to the stream.  The de-duplication happens here, in the sorted insertion into the item's set list
 // (LDS).  Items whose list overflowed again (more than CAP appended classes) are listed for the straight-line kernel.
+__device__ __forceinline__ void wave_lds_fence() {   // the wavefront's LDS writes are visible to its own later reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+constexpr int CL_WAVES = 4, CL_ITEMS = 8;   // k_classify_long: wavefronts per block, items a wavefront takes one after the other
 template <bool PAIRED, bool FILTER, int CAP>
-__global__ __launch_bounds__(64) void k_classify_long(DevIndex ix, const u32* __restrict__ raw, int stride, const u64* __restrict__ items, u64 n, u32* scratch,
-                                                      FilterDev fd, u64 rec_base, AlignOut out, u64* items_left) {
-  __shared__ u32 lds_ecs[64 * (CAP + 1)];   // (an odd stride: the threads' lists start in different banks)
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 item = items[i];
-  const u32* r = raw + i * (u64)stride;
-  const u32 h = r[0];
-  if (h & RAW_OVERFLOW) { const u64 k = atomicAdd(&out.st->n_overflow, 1ULL); items_left[k] = item; return; }
-  const int nc = (int)(h & 0xFFu);
-  kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * (CAP + 1); ecs.cap = CAP; ecs.n = 0; ecs.overflow = false;
-  bool ne0 = false, ne1 = false;
-  for (int j = 0; j < nc; j++) {
-    const u32 uec = r[1 + j];
-    const u32 ec = ix.uec_ecn[uec & 0x3FFFFFFFu];
-    if (ec & 0x80000000u) {   // the set is non-empty
-      if (uec & 0x40000000u) ne0 = true;
-      if (uec & 0x80000000u) ne1 = true;
-      const u32 id = ec & kamd::EC_ID_MASK;
-      kamd::eclist_add(ecs, ix.union_mode ? (id | (uec & 0xC0000000u)) : id);
+__global__ __launch_bounds__(64 * CL_WAVES) void k_classify_long(DevIndex ix, const u32* __restrict__ raw, int stride, const u64* __restrict__ items, u64 n, u32* scratch,
+                                                                 FilterDev fd, u64 rec_base, AlignOut out, u64* items_left) {
+  // One WAVEFRONT per item (round 6; a thread per item kept a sorted list by insertion -- 64 divergent insertion sorts per wavefront -- and paid two
+  // same-address atomics per item: 8.9 ms for the 440 k such items of 8 M stress pairs).  The item's appended classes (<= CAP = 3 per lane, with
+  // duplicates) are mapped to set ids, compacted, and ranked by counting: an entry is kept if no earlier entry has its id (the mate flags of all
+  // entries with that id are merged into it), and its place in the sorted record is the number of kept entries with a smaller id -- every lane
+  // reads the list out of LDS by broadcast, no sort network.  A wavefront takes CL_ITEMS items and allocates their records with ONE atomic.
+  static_assert(CAP <= 192, "three entries per lane");
+  __shared__ u32 s_in_all[CL_WAVES][CAP];
+  __shared__ u32 s_out_all[CL_WAVES][CL_ITEMS][CAP];
+  __shared__ u32 s_n_all[CL_WAVES][CL_ITEMS];   // sets of the item's record; 0 = no record
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+  u32* s_in = s_in_all[w];
+  const u64 i0 = ((u64)blockIdx.x * CL_WAVES + w) * CL_ITEMS;
+  constexpr u32 DUP = 0xFFFFFFFFu;
+  u32 total_words = 0, n_records = 0;
+  for (int q = 0; q < CL_ITEMS; q++) {
+    const u64 i = i0 + q;
+    if (lane == 0) s_n_all[w][q] = 0;
+    if (i >= n) continue;
+    const u64 item = items[i];
+    const u32* r = raw + i * (u64)stride;
+    const u32 h = r[0];
+    if (h & RAW_OVERFLOW) { if (lane == 0) { const u64 k = atomicAdd(&out.st->n_overflow, 1ULL); items_left[k] = item; } continue; }
+    const u32 nc = h & 0xFFu;
+    // classes -> non-empty sets, compacted into s_in (id | mate flags with --union)
+    u32 nv = 0;
+    bool ne0 = false, ne1 = false;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const u32 j = (u32)lane + 64u * t;
+      u32 v = 0; bool valid = false;
+      if (j < nc) {
+        const u32 uec = r[1 + j];
+        const u32 ec = ix.uec_ecn[uec & 0x3FFFFFFFu];
+        valid = (ec & 0x80000000u) != 0;   // the set is non-empty
+        v = (ec & kamd::EC_ID_MASK) | (ix.union_mode ? (uec & 0xC0000000u) : 0u);
+        ne0 = ne0 || (valid && (uec & 0x40000000u)); ne1 = ne1 || (valid && (uec & 0x80000000u));
+      }
+      const u64 bm = __ballot(valid);
+      if (valid) s_in[nv + __popcll(bm & ((1ULL << lane) - 1ULL))] = v;
+      nv += (u32)__popcll(bm);
     }
-  }
-  kamd::MateInfo m0, m1;
-  m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
-  m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
-  m0.n_nonempty = ne0; m1.n_nonempty = ne1;
-  if (FILTER) {
-    m0.first_slot = r[2 + CAP]; m0.first_pos = (int)(r[3 + CAP] & 0xFFFF); m0.first_strand = (r[3 + CAP] >> 16) & 1u;
-    m1.first_slot = r[4 + CAP]; m1.first_pos = (int)(r[5 + CAP] & 0xFFFF); m1.first_strand = (r[5 + CAP] >> 16) & 1u;
-  }
-  if (!kamd::pair_is_mapped(m0, m1)) return;
-  if (FILTER) {
-    u32 kept = 0;
-    u32* cur = scratch + i * (u64)(2 * TUPLE_CAP_BIG) + TUPLE_CAP_BIG;
-    const int oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept, cur);
-    if (oc == 1) return;
-    if (oc == 2) {
-      const u64 k = atomicAdd(&out.st->n_explicit_big, 1ULL);
-      out.explicit_items_big[k] = item;
-      atomicAdd(&out.st->exp_words, (u64)kept + 2);
-      return;
+    ne0 = __ballot(ne0) != 0ULL; ne1 = __ballot(ne1) != 0ULL;
+    wave_lds_fence();
+    // pass 1: first occurrences and merged flags
+    u32 x[3], fl[3]; bool first[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const u32 j = (u32)lane + 64u * t; x[t] = j < nv ? s_in[j] : DUP; fl[t] = 0; first[t] = j < nv; }
+    for (u32 k = 0; k < nv; k++) {
+      const u32 y = s_in[k], yid = y & kamd::EC_ID_MASK;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        if (yid == (x[t] & kamd::EC_ID_MASK) && x[t] != DUP) { fl[t] |= y & 0xC0000000u; if (k < (u32)lane + 64u * t) first[t] = false; }
+      }
     }
+    wave_lds_fence();
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const u32 j = (u32)lane + 64u * t; if (j < nv) s_in[j] = first[t] ? ((x[t] & kamd::EC_ID_MASK) | fl[t]) : DUP; }
+    wave_lds_fence();
+    // pass 2: the place of a kept entry = kept entries with a smaller id
+    u32 rank[3] = {0, 0, 0};
+    for (u32 k = 0; k < nv; k++) {
+      const u32 y = s_in[k];
+      if (y == DUP) continue;   // (wavefront-uniform: a broadcast read)
+      const u32 yid = y & kamd::EC_ID_MASK;
+#pragma unroll
+      for (int t = 0; t < 3; t++) rank[t] += yid < (x[t] & kamd::EC_ID_MASK) ? 1u : 0u;
+    }
+    u32 nd = 0;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const bool keep = first[t] && x[t] != DUP;
+      if (keep) s_out_all[w][q][rank[t]] = (x[t] & kamd::EC_ID_MASK) | fl[t];
+      nd += (u32)__popcll(__ballot(keep));
+    }
+    wave_lds_fence();
+    kamd::MateInfo m0, m1;
+    m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
+    m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
+    m0.n_nonempty = ne0; m1.n_nonempty = ne1;
+    if (FILTER) {
+      m0.first_slot = r[2 + CAP]; m0.first_pos = (int)(r[3 + CAP] & 0xFFFF); m0.first_strand = (r[3 + CAP] >> 16) & 1u;
+      m1.first_slot = r[4 + CAP]; m1.first_pos = (int)(r[5 + CAP] & 0xFFFF); m1.first_strand = (r[5 + CAP] >> 16) & 1u;
+    }
+    if (!kamd::pair_is_mapped(m0, m1)) continue;
+    if (FILTER) {   // (the positional filters walk the set thread-serially: lane 0, as in the straight-line kernel)
+      int oc = 0;
+      if (lane == 0) {
+        kamd::EcList ecs; ecs.e = s_out_all[w][q]; ecs.cap = CAP; ecs.n = (int)nd; ecs.overflow = false;
+        u32 kept = 0;
+        u32* cur = scratch + i * (u64)(2 * TUPLE_CAP_BIG) + TUPLE_CAP_BIG;
+        oc = filter_outcome(ix, fd, PAIRED, m0, m1, ecs, &kept, cur);
+        if (oc == 2) {
+          const u64 k = atomicAdd(&out.st->n_explicit_big, 1ULL);
+          out.explicit_items_big[k] = item;
+          atomicAdd(&out.st->exp_words, (u64)kept + 2);
+        }
+      }
+      oc = __shfl(oc, 0, 64);
+      if (oc != 0) continue;
+    }
+    if (lane == 0) s_n_all[w][q] = nd;
+    total_words += nd + 2; ++n_records;
   }
-  const u64 off = atomicAdd(&out.st->stream_words, (u64)ecs.n + 2);
-  u32* w = out.stream + off;
-  w[0] = 1u; w[1] = (u32)ecs.n;
-  for (int j = 0; j < ecs.n; j++) w[2 + j] = ecs.e[j];
-  out.rec_off[rec_base + item] = off;
-  atomicAdd(&out.st->st_multi, 1ULL);
+  if (n_records == 0) return;
+  u64 off = 0;
+  if (lane == 0) { off = atomicAdd(&out.st->stream_words, (u64)total_words); atomicAdd(&out.st->st_multi, (u64)n_records); }
+  off = shfl_u64(off, 0);
+  wave_lds_fence();
+  for (int q = 0; q < CL_ITEMS; q++) {
+    const u32 nd = s_n_all[w][q];
+    if (nd == 0) continue;
+    u32* wr = out.stream + off;
+    if (lane == 0) { wr[0] = 1u; wr[1] = nd; out.rec_off[rec_base + items[i0 + q]] = off; }
+    for (u32 j = lane; j < nd; j += 64) wr[2 + j] = s_out_all[w][q][j];
+    off += nd + 2;
+  }
 }
 
 // items whose transcript set was changed by a positional filter: write the filtered set as an explicit record
@@ -858,7 +933,7 @@ int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len,
 #undef KAMD_LAUNCH_V3L2
   c->host_state.n_overflow = 0;   // k_classify_long counts the items whose list overflowed again
   if (int rc = push_state(c)) return rc;
-  hipLaunchKernelGGL((k_classify_long<PAIRED, FILTER, LC>), dim3(grid_for(nov, 64)), dim3(64), 0, c->stream, c->ix, (const u32*)raw2, stride2,
+  hipLaunchKernelGGL((k_classify_long<PAIRED, FILTER, LC>), dim3(grid_for(nov, CL_WAVES * CL_ITEMS)), dim3(64 * CL_WAVES), 0, c->stream, c->ix, (const u32*)raw2, stride2,
                      (const u64*)c->overflow_items.as<u64>(), nov, c->overflow_scratch.as<u32>(), fd, 0ULL, out, c->overflow_left.as<u64>());
   HIPC(hipGetLastError());
   return sync_state(c);
