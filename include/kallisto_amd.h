@@ -173,6 +173,9 @@ typedef struct {
                                   them take the straight-line kernel k_pseudoalign_overflow (rounds 1-5) */
   int32_t em_giant_nnz;        /* hybrid: a component with more entries than this is "oversized"; -1 (default) = 6000, halved while the
                                   remaining components still do not fit their groups */
+  int32_t em_blocked;          /* hybrid: 1 (default) = the oversized components are iterated in 2-D blocks -- the gathered vector's block in LDS, 16-bit in-block
+                                  indices, partial sums per (segment, block) combined in a fixed order: three launches per round (k_gb_pass<0>, k_gb_pass<1>,
+                                  k_gb_finish); 2 = the streamed kernels k_gi_rows / k_gi_cols gather through the vector memory pipeline (round 5) */
 } kamd_tuning;
 int kamd_ctx_tune(kamd_ctx*, const kamd_tuning*);
 int kamd_ctx_get_tuning(const kamd_ctx*, kamd_tuning* out);
@@ -305,6 +308,8 @@ typedef struct {
   uint32_t em_collectives;         /* ... and their number */
   uint64_t n_overflow_second_pass; /* of n_overflow_items: those kernel A's second pass (an append-only list of up to 192 classes) took care of; the rest went to the
                                       straight-line kernel */
+  uint64_t last_em_giant_pieces;   /* hybrid, blocked form: partial sums per round over both directions (segments cut at block and chunk boundaries); 0 = the
+                                      streamed kernels ran */
 } kamd_profile;
 int kamd_profile_get(kamd_ctx*, kamd_profile* out);
 

@@ -55,7 +55,7 @@ class Tuning(C.Structure):
     """kamd_tuning: which of the equivalent kernels / EM forms run (0 = keep the current value; on/off fields: 1 on, 2 off)."""
     _fields_ = [(n, C.c_int32) for n in ("text_verify", "items_per_wave", "refill_min", "lds_pad", "em_form", "em_entries_per_lane", "em_windowed", "em_graph", "em_row_lanes",
                                          "em_fin_blocks", "em_local_block", "em_group_div", "em_split_len", "dedup_form", "align_chunks", "em_small_nnz", "em_reg_slices",
-                                         "em_hybrid", "overflow_second_pass", "em_giant_nnz")]
+                                         "em_hybrid", "overflow_second_pass", "em_giant_nnz", "em_blocked")]
 
 
 EM_FORMS = {"streamed": 1, "csr": 2, "local": 3}
@@ -73,7 +73,7 @@ class _Profile(C.Structure):
                 ("last_em_max_comp_nnz", C.c_uint64), ("last_em_giant_nnz", C.c_uint64), ("last_em_giant_rows", C.c_uint64),
                 ("last_em_giant_tr", C.c_uint64), ("last_em_giant_chunks", C.c_uint32), ("last_em_graph_fallback", C.c_int32),
                 ("last_em_plan_ms", C.c_float), ("n_overflow_items", C.c_uint64), ("overflow_ms", C.c_float),
-                ("last_merge_ms", C.c_float), ("em_collective_ms", C.c_float), ("em_collectives", C.c_uint32), ("n_overflow_second_pass", C.c_uint64)]
+                ("last_merge_ms", C.c_float), ("em_collective_ms", C.c_float), ("em_collectives", C.c_uint32), ("n_overflow_second_pass", C.c_uint64), ("last_em_giant_pieces", C.c_uint64)]
 
 
 class _FastqUnit(C.Structure):
@@ -479,7 +479,7 @@ class Context:
                 "fin_cand_words": int(p.last_fin_cand_words), "absorb_ms": float(p.absorb_ms), "n_distinct_tuples": int(p.n_distinct_tuples),
                 "tuple_store_words": int(p.tuple_store_words), "tuple_table_slots": int(p.tuple_table_slots),
                 "em_max_comp_nnz": int(p.last_em_max_comp_nnz), "em_giant_nnz": int(p.last_em_giant_nnz), "em_giant_rows": int(p.last_em_giant_rows),
-                "em_giant_tr": int(p.last_em_giant_tr), "em_giant_chunks": int(p.last_em_giant_chunks), "em_graph_fallback": int(p.last_em_graph_fallback),
+                "em_giant_tr": int(p.last_em_giant_tr), "em_giant_chunks": int(p.last_em_giant_chunks), "em_graph_fallback": int(p.last_em_graph_fallback), "em_giant_pieces": int(p.last_em_giant_pieces),
                 "em_plan_ms": float(p.last_em_plan_ms), "n_overflow_items": int(p.n_overflow_items), "overflow_ms": float(p.overflow_ms),
                 "merge_ms": float(p.last_merge_ms), "em_collective_ms": float(p.em_collective_ms), "em_collectives": int(p.em_collectives), "n_overflow_second_pass": int(p.n_overflow_second_pass)}
 

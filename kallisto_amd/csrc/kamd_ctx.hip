@@ -8,7 +8,7 @@ void tuning_defaults(kamd_tuning* t) {
   t->text_verify = 1; t->items_per_wave = 1024; t->refill_min = 8; t->lds_pad = -1;
   t->em_form = 3; t->em_local_block = 1024; t->em_group_div = -1; t->em_split_len = 16; t->em_small_nnz = -1; t->em_entries_per_lane = -1; t->em_windowed = 2; t->em_graph = 1; t->em_row_lanes = 4;
   t->em_fin_blocks = 1024; t->dedup_form = 2; t->align_chunks = -1; t->em_reg_slices = 1;
-  t->em_hybrid = 1; t->overflow_second_pass = 1; t->em_giant_nnz = -1;
+  t->em_hybrid = 1; t->overflow_second_pass = 1; t->em_giant_nnz = -1; t->em_blocked = 1;
 }
 // 0 = keep; values outside a field's range are ignored
 void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
@@ -32,6 +32,7 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.em_reg_slices == 1 || n.em_reg_slices == 2) t->em_reg_slices = n.em_reg_slices;
   if (n.em_hybrid == 1 || n.em_hybrid == 2) t->em_hybrid = n.em_hybrid;
   if (n.overflow_second_pass == 1 || n.overflow_second_pass == 2) t->overflow_second_pass = n.overflow_second_pass;
+  if (n.em_blocked == 1 || n.em_blocked == 2) t->em_blocked = n.em_blocked;
   if (n.em_giant_nnz != 0) t->em_giant_nnz = n.em_giant_nnz < 0 ? -1 : std::max(n.em_giant_nnz, 8);
 }
 // experiments: the same knobs from ONE environment variable, read once when a context is created --
@@ -49,7 +50,7 @@ void tuning_from_env(kamd_tuning* t) {
     {"em_fin_blocks", &kamd_tuning::em_fin_blocks, false}, {"em_local_block", &kamd_tuning::em_local_block, false}, {"em_group_div", &kamd_tuning::em_group_div, false},
     {"em_split_len", &kamd_tuning::em_split_len, false}, {"dedup_form", &kamd_tuning::dedup_form, false}, {"align_chunks", &kamd_tuning::align_chunks, false},
     {"em_small_nnz", &kamd_tuning::em_small_nnz, false}, {"em_reg_slices", &kamd_tuning::em_reg_slices, true}, {"em_hybrid", &kamd_tuning::em_hybrid, true},
-    {"overflow_second_pass", &kamd_tuning::overflow_second_pass, true}, {"em_giant_nnz", &kamd_tuning::em_giant_nnz, false}};
+    {"overflow_second_pass", &kamd_tuning::overflow_second_pass, true}, {"em_giant_nnz", &kamd_tuning::em_giant_nnz, false}, {"em_blocked", &kamd_tuning::em_blocked, true}};
   std::string all(e);
   for (size_t pos = 0; pos < all.size();) {
     size_t end = all.find(',', pos);
@@ -167,7 +168,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev_mg1) (void)hipEventDestroy(c->ev_mg1);
   if (c->ev_ov0) (void)hipEventDestroy(c->ev_ov0);
   if (c->ev_ov1) (void)hipEventDestroy(c->ev_ov1);
-  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps}) b->release();
+  for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps, &c->hy_gb[0], &c->hy_gb[1], &c->hy_gb[2], &c->hy_gb[3], &c->hy_gb[4], &c->hy_gb[5]}) b->release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
   if (c->fld_ev_in) (void)hipEventDestroy(c->fld_ev_in);
@@ -340,7 +341,7 @@ extern "C" int kamd_profile_get(kamd_ctx* c, kamd_profile* p) {
   p->last_fin_cand_words = c->last_fin_cand_words;
   p->absorb_ms = c->last_absorb_ms; p->n_distinct_tuples = c->n_distinct_tuples; p->tuple_store_words = c->host_state.ts_words; p->tuple_table_slots = c->tcap;
   p->last_em_max_comp_nnz = c->last_em_max_comp_nnz; p->last_em_giant_nnz = c->last_em_giant_nnz; p->last_em_giant_rows = c->last_em_giant_rows;
-  p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_graph_fallback = c->last_em_graph_fallback;
+  p->last_em_giant_tr = c->last_em_giant_tr; p->last_em_giant_chunks = c->last_em_giant_chunks; p->last_em_graph_fallback = c->last_em_graph_fallback; p->last_em_giant_pieces = c->last_em_giant_pieces;
   p->last_em_plan_ms = c->last_em_plan_ms;
   p->n_overflow_items = c->overflow_total; p->overflow_ms = c->overflow_ms;
   p->n_overflow_second_pass = c->overflow_second_total;

@@ -276,10 +276,11 @@ struct kamd_ctx {
   DBuf em_clk;                                       // diagnostic phase clocks (KAMD_EM_CLK)
   // hybrid EM (components beyond a workgroup's LDS beside the LDS form): the two sub-matrices, the streamed plan's arenas, its vectors
   DBuf hy_sub, hy_a, hy_b, hy_x, hy_maps;
+  DBuf hy_gb[6];   // the blocked form of the oversized components: two set-up scratch arenas, then per direction the entry stream and the pieces' arrays
   hipStream_t hy_giant_stream = nullptr;   // the oversized components' kernels (k_em_sell stays on the context stream)
   hipEvent_t hy_ev_sell = nullptr, hy_ev_giant = nullptr;
   uint64_t last_em_max_comp_nnz = 0, last_em_giant_nnz = 0, last_em_giant_rows = 0, last_em_giant_tr = 0;
-  uint32_t last_em_giant_chunks = 0; int last_em_graph_fallback = 0; float last_em_plan_ms = 0.f;
+  uint32_t last_em_giant_chunks = 0; uint64_t last_em_giant_pieces = 0; int last_em_graph_fallback = 0; float last_em_plan_ms = 0.f;
   float last_merge_ms = 0.f, em_coll_ms = 0.f; uint32_t em_coll_n = 0; hipEvent_t ev_mg0 = nullptr, ev_mg1 = nullptr;   // several ranks: kamd_ec_allreduce (HIP events), the EM's collectives (host wall, the host waits for each)
   const uint32_t* labels_override = nullptr;   // em_local_setup_device takes these component labels instead of computing them (the hybrid's sub-matrix: same components)
   bool em_prefer_hybrid = false;               // the last matrix of this context needed the hybrid: the next plan starts there

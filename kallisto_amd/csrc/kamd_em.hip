@@ -2238,6 +2238,345 @@ __global__ void k_gi_scatter(u64 T, const u32* __restrict__ mflag, const u64* __
   out_alpha[t] = fin[m];
   out_abz[t] = have_final ? before[m] : 0.0;
 }
+// ---- the oversized component in 2-D blocks: gathers out of LDS -------------------------------------------------------------------------
+// k_gi_rows / k_gi_cols gather one FP64 value per entry through the vector memory pipeline: a 64-byte line travels from L2 for 8 useful
+// bytes, and a round of a 14 M-entry component runs at L2's line rate (39 + 46 us, round 5).  Here the gathered vector is cut into blocks of
+// GB_B values that a workgroup holds in LDS: the entries of a direction are re-sorted by (block of the gathered index, segment), so that a
+// workgroup loads ONE block, then streams the 16-bit in-block indices of its share of that block's entries and gathers out of LDS.  A
+// segment (row / column) restricted to a block -- cut again where it crosses a chunk of 64 x GB_K entries -- is a PIECE; a piece's sum goes
+// to its slot of a partial-sum array in which the pieces of a segment are neighbours, in a fixed order.  Nothing is combined by atomics:
+//   k_gb_pass<0>  rows: block of a (copied into LDS)                              -> partial sums of the rows
+//   k_gb_pass<1>  columns: block of g, COMPUTED while it is loaded from the rows' partial sums (g_e = count_e / S_e), -> partial sums of the columns
+//   k_gb_finish   per transcript: next alpha from its partial sums, the convergence test, a = alpha / eff
+// three launches per round, every sum in a fixed order (bit-reproducible given the numbering of the rows).
+// Values per block, per direction.  Every workgroup fetches its whole block through a cold L2, and what the columns pass fetches per row of its
+// block are the row's partial sums: a long row (a poly-A class of 3 500 transcripts) has one per block of a it crosses, and the row blocks that
+// hold the long rows are the ones most workgroups work on -- so the blocks of a (rows pass) are LARGE, few pieces per long row, and the
+// blocks of g (columns pass) small (measured at 8 M stress pairs, columns pass: 32 us with 2 048-value blocks of a, 22 with 8 192).
+constexpr int GB_SHIFT_A = 13, GB_SHIFT_G = 11;             // blocks of a: 8 192 values (64 KB of LDS); blocks of g: 2 048 rows
+constexpr int GB_B = 1 << GB_SHIFT_A;                       // (the larger of the two: LDS is sized for it, and index GB_B is the zero slot the padding reads)
+constexpr int GB_PF = 4;                                   // chunks of a wavefront requested together
+constexpr int GB_K = 8, GB_CH = 64 * GB_K;                  // entries per lane and chunk (one 16-byte load), entries per chunk
+constexpr int GB_WAVES = 16, GB_THREADS = 64 * GB_WAVES;   // one workgroup per compute unit: 64 KB of block + 16 x 4 KB of piece sums
+constexpr uint16_t GB_END = 0x8000u, GB_PAD = (uint16_t)GB_B;   // entry = in-block index | GB_END on the last entry of a piece; padding reads the zero slot
+struct GbSide {
+  const uint16_t* stream;   // [n_chunks * GB_CH]; the chunks of a block are consecutive, a block starts on a chunk boundary
+  const u32* seg_base;      // [n_chunks] pieces that end in earlier chunks (= id of the chunk's first piece)
+  const u32* lane_word;     // [n_chunks * 64] as PmSide::lane_word
+  const u32* piece_slot;    // [n_pieces] where a piece's sum goes in `part`
+  double* part;             // [n_pieces]
+  const u32* slot_base;     // [n_seg + 1] the slots of a segment's pieces: slot_base[s] .. slot_base[s + 1]
+  const u32* wg_desc;       // [2 * n_wg] per workgroup: its work items wg_items[first .. end)
+  const u32* wg_items;      // [4 * n_items] block, first chunk, end chunk, rotation of the block's load: a workgroup loads the block, then its wavefronts take the chunks
+  u32 n_wg, n_chunks, n_pieces, n_seg, n_tgt;
+};
+struct GbArgs { GbSide rows, cols; const u64* cw; const double* single; const double* eff; u32 R, M; };
+template <int DIR>
+__global__ __launch_bounds__(GB_THREADS) void k_gb_pass(GbArgs A, const double* a_src, const GiDesc* desc) {
+  extern __shared__ __attribute__((aligned(16))) double gb_lds[];
+  double* s_val = gb_lds;                     // [GB_B + 1] the block of the gathered vector; [GB_B] = 0 is what the padding reads
+  double* s_sum = gb_lds + (GB_B + 2);        // [GB_WAVES][GB_CH] the sums of the pieces that end in a wavefront's chunk
+  if (desc->stopped) return;
+  const GbSide& S = DIR == 0 ? A.rows : A.cols;
+  constexpr int SH = DIR == 0 ? GB_SHIFT_A : GB_SHIFT_G, BV = 1 << SH;   // values of a block in this direction
+  const int lane = lane_id();
+  const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 it0 = S.wg_desc[2 * blockIdx.x], it1 = S.wg_desc[2 * blockIdx.x + 1];
+  for (u32 it = it0; it < it1; it++) {
+  const u32 blk = S.wg_items[4 * it], c0 = S.wg_items[4 * it + 1], c1 = S.wg_items[4 * it + 2], rot = S.wg_items[4 * it + 3];
+  const u32 base = blk << SH;
+  if (it != it0) __syncthreads();   // (the block and the piece sums of the item before are done with)
+  // the wavefront's first GB_PF chunks (all of them, at the sizes of a transcriptome) are on their way while the block is loaded: loading the
+  // block is up to three dependent memory latencies from a cold L2, and what follows it is then LDS work only
+  u32 c = c0 + wv;
+  uint4 raw[GB_PF]; u32 lw[GB_PF], sb[GB_PF], ps[GB_PF];
+  auto request = [&](u32 cf) {
+#pragma unroll
+    for (int i = 0; i < GB_PF; i++) {
+      const u32 cc = cf + (u32)i * GB_WAVES;
+      raw[i] = make_uint4(0, 0, 0, 0); lw[i] = 0; sb[i] = 0;
+      if (cc < c1) { raw[i] = reinterpret_cast<const uint4*>(S.stream + (u64)cc * GB_CH)[lane]; lw[i] = S.lane_word[(u64)cc * 64 + lane]; sb[i] = S.seg_base[cc]; }
+    }
+#pragma unroll
+    for (int i = 0; i < GB_PF; i++) ps[i] = cf + (u32)i * GB_WAVES < c1 ? S.piece_slot[sb[i] + lane] : 0u;   // (the slots of a chunk's first 64 pieces; the array is padded by 64 entries)
+  };
+  request(c);
+  constexpr int PER = BV / GB_THREADS;   // values of the block per thread
+  if (DIR == 0) {
+    double v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const u32 i = (threadIdx.x + (u32)k * GB_THREADS + rot) & (BV - 1); v[k] = base + i < A.M ? a_src[base + i] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < PER; k++) s_val[(threadIdx.x + (u32)k * GB_THREADS + rot) & (BV - 1)] = v[k];
+  } else {
+    // g of the block's rows from the rows' partial sums (in slot order); rows the reference skips get 0: count 0 (:133-135), denom below
+    // denorm_min (:156-158).  THREE dependent loads for the whole block (every one of them reads what the launch before wrote on other XCDs:
+    // ~2 us each): all offsets and count words; the first four partial sums of every row; then the rows of more than four pieces -- long
+    // rows cut at block and chunk boundaries, a few hundred per block -- one per thread out of a list in LDS, all of a row's slots at once.
+    const GbSide& Rw = A.rows;
+    auto g_of = [](u64 w, double S) -> double {
+      const u32 cnt = (u32)w, wc = (u32)(w >> 32);
+      return (cnt == 0 || (double)wc * S < 4.9406564584124654e-324) ? 0.0 : (double)cnt / S;
+    };
+    u32* s_ln = reinterpret_cast<u32*>(s_sum);          // [0] = rows listed; then per listed row {index in the block, first slot, slots} ...
+    u64* s_lw = reinterpret_cast<u64*>(s_sum) + 4096;   // ... and its count word (the piece sums' region, 64 KB, is idle while the block is loaded)
+    constexpr u32 LIST_CAP = 2048;                       // (rows beyond that are summed by their own thread, slot after slot)
+    if (threadIdx.x == 0) s_ln[0] = 0u;
+    u32 s0[PER], s1[PER]; u64 w[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u32 r = base + ((threadIdx.x + (u32)k * GB_THREADS + rot) & (BV - 1));
+      const bool in = r < A.R;
+      s0[k] = in ? Rw.slot_base[r] : 0u; s1[k] = in ? Rw.slot_base[r + 1] : 0u; w[k] = in ? A.cw[r] : 0ULL;
+    }
+    double p[PER][4];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) p[k][i] = s0[k] + i < s1[k] ? Rw.part[s0[k] + i] : 0.0;
+    }
+    __syncthreads();   // (the list's counter)
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u32 np = s1[k] - s0[k], i = (threadIdx.x + (u32)k * GB_THREADS + rot) & (BV - 1);
+      u32 at = LIST_CAP;
+      if (np > 4u) at = atomicAdd(&s_ln[0], 1u);
+      if (np > 4u && at < LIST_CAP) {
+        s_ln[1 + 3 * at] = i; s_ln[2 + 3 * at] = s0[k]; s_ln[3 + 3 * at] = np; s_lw[at] = w[k];
+      } else if (np > 4u) {
+        double S = p[k][0] + p[k][1]; S += p[k][2]; S += p[k][3];
+        for (u32 q = s0[k] + 4; q < s1[k]; q++) S += Rw.part[q];
+        s_val[i] = g_of(w[k], S);
+      } else {
+        double S = p[k][0];
+        if (np > 1u) S += p[k][1];
+        if (np > 2u) S += p[k][2];
+        if (np > 3u) S += p[k][3];
+        s_val[i] = np ? g_of(w[k], S) : 0.0;
+      }
+    }
+    __syncthreads();
+    const u32 n_long = min(s_ln[0], LIST_CAP);
+    for (u32 q = threadIdx.x; q < n_long; q += GB_THREADS) {
+      const u32 i = s_ln[1 + 3 * q], f = s_ln[2 + 3 * q], np = s_ln[3 + 3 * q];
+      double S = 0.0;
+      for (u32 j0 = 0; j0 < np; j0 += 32) {
+        double x[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) x[j] = j0 + j < np ? Rw.part[f + j0 + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) if (j0 + j < np) S += x[j];
+      }
+      s_val[i] = g_of(s_lw[q], S);
+    }
+    __syncthreads();   // (the list lies where the wavefronts' piece sums go)
+  }
+  if (threadIdx.x == 0) s_val[GB_B] = 0.0;
+  __syncthreads();
+  double* sums = s_sum + (size_t)wv * GB_CH;
+  for (; c < c1; c += GB_PF * GB_WAVES) {
+#pragma unroll
+    for (int i = 0; i < GB_PF; i++) {
+      const u32 cc = c + (u32)i * GB_WAVES;
+      if (cc >= c1) break;
+      const uint4 rw = raw[i];
+      const u32 e[GB_K] = {rw.x & 0xFFFFu, rw.x >> 16, rw.y & 0xFFFFu, rw.y >> 16, rw.z & 0xFFFFu, rw.z >> 16, rw.w & 0xFFFFu, rw.w >> 16};
+      double v[GB_K];
+#pragma unroll
+      for (int k = 0; k < GB_K; k++) v[k] = s_val[e[k] & 0x3FFFu];
+      const u32 ebase = lw[i] & 0xFFFu, ne = (lw[i] >> 12) & 0x3Fu;
+      const int reach = (int)(lw[i] >> 18);
+      const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)(ebase + ne), 63);
+      double run = 0.0;
+      double* slot = sums + ebase;
+#pragma unroll
+      for (int k = 0; k < GB_K; k++) {
+        run += v[k];
+        if (e[k] & GB_END) { *slot++ = run; run = 0.0; }
+      }
+      const double y = pm_scan_seg(run, reach, lane);
+      const double carry = pm_dpp<0x138, 0xF>(y);   // wave_shr:1 (lane 0 gets 0): what the lanes below hold of the lane's first piece
+      if (ne) sums[ebase] += carry;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if ((u32)lane < n_ends) S.part[ps[i]] = sums[lane];
+      for (u32 t = lane + 64; t < n_ends; t += 64) S.part[S.piece_slot[sb[i] + t]] = sums[t];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (c + GB_PF * GB_WAVES < c1) request(c + GB_PF * GB_WAVES);
+  }
+  }
+}
+// next alpha of every transcript of the oversized components from the columns' partial sums (GiColEmit::finish)
+__global__ __launch_bounds__(BLOCK) void k_gb_finish(GbArgs A, const double* al_src, const double* a_src, double* al_dst, double* a_dst, int round, int clamp,
+                                                     const GiDesc* desc) {
+  __shared__ int lds_ch;
+  if (desc->stopped) return;
+  const u32 m = blockIdx.x * BLOCK + threadIdx.x;
+  int ch = 0;
+  if (m < A.M) {
+    const GbSide& C = A.cols;
+    const u32 s0 = C.slot_base[m], s1 = C.slot_base[m + 1];
+    const double xal = al_src[m], xat = a_src[m], sg = A.single[m], ef = A.eff[m];
+    double acc = C.part[s0];
+    for (u32 q = s0 + 1; q < s1; q += 4) {   // (four loads in flight, added in slot order)
+      const double p0 = C.part[q], p1 = q + 1 < s1 ? C.part[q + 1] : 0.0, p2 = q + 2 < s1 ? C.part[q + 2] : 0.0, p3 = q + 3 < s1 ? C.part[q + 3] : 0.0;
+      acc += p0; if (q + 1 < s1) acc += p1; if (q + 2 < s1) acc += p2; if (q + 3 < s1) acc += p3;
+    }
+    const double al = (clamp && xal < 1e-7 / 10.0) ? 0.0 : xal;
+    const double nx = sg + xat * acc;
+    if (nx > 1e-2 && (fabs(nx - al) / nx) > 1e-2) ++ch;
+    al_dst[m] = nx;
+    a_dst[m] = nx / ef;
+  }
+  int* hist = desc->hist;
+  gi_count_changes(ch, &lds_ch, hist ? hist + round : nullptr);
+}
+// ---- plan of the blocked form (once per matrix) ----
+// entries of segment s: ids[off[s] .. off[s + 1]) (index | PM_END); 8 lanes per segment
+__global__ void k_gb_count(const u64* __restrict__ off, const u32* __restrict__ ids, u64 n_seg, int shift, u32* cnt) {
+  const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+  const int sub = threadIdx.x & 7;
+  if (s >= n_seg) return;
+  for (u64 j = off[s] + sub; j < off[s + 1]; j += 8) atomicAdd(&cnt[(u64)((ids[j] & ~PM_END) >> shift) * n_seg + s], 1u);
+}
+// ORDERED: the entries of a segment come in increasing index order (rows: the transcripts of a class are sorted), so the place of an entry
+// in its run follows from its place in the segment -- the run is born sorted; else the places are handed out by an atomic and the run is
+// sorted afterwards (columns: the streamed plan's column entries lie in the order of its own atomics); info[pos] = the run of the entry there
+template <bool ORDERED>
+__global__ void k_gb_scatter(const u64* __restrict__ off, const u32* __restrict__ ids, u64 n_seg, const u32* __restrict__ cnt, const u64* __restrict__ sub_off,
+                             const u64* __restrict__ blk_shift, int shift, u32* fill, uint16_t* stream, u32* info) {
+  const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+  const int sub = threadIdx.x & 7;
+  if (s >= n_seg) return;
+  const u64 o0 = off[s];
+  for (u64 j = o0 + sub; j < off[s + 1]; j += 8) {
+    const u32 x = ids[j] & ~PM_END, b = x >> shift;
+    const u64 key = (u64)b * n_seg + s;
+    u64 pos;
+    if (ORDERED) {
+      u64 before = 0;
+      for (u32 q = 0; q < b; q++) before += cnt[(u64)q * n_seg + s];
+      pos = sub_off[key] + blk_shift[b] + (j - o0 - before);
+    } else {
+      pos = sub_off[key] + blk_shift[b] + atomicAdd(&fill[key], 1u);
+      info[pos] = (u32)key;
+    }
+    stream[pos] = (uint16_t)(x & ((1u << shift) - 1u));
+  }
+}
+// every (block, segment) run in increasing index order (the indices of a run are distinct): the place of an entry = the entries of its run
+// that are smaller.  k_gb_sort_small: one thread per entry for runs of up to GB_SORT_SMALL entries; k_gb_sort_big: one wavefront per longer
+// run, tiles of the run staged in LDS.  Both write the sorted copy `out` (every position of the stream exactly once between them).
+constexpr int GB_SORT_SMALL = 64;
+__global__ __launch_bounds__(BLOCK) void k_gb_sort_small(const uint16_t* __restrict__ stream, const u32* __restrict__ info, const u32* __restrict__ cnt, const u64* __restrict__ sub_off,
+                                                         const u64* __restrict__ blk_shift, u64 n_seg, u64 n_pos, uint16_t* out) {
+  const u64 p = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n_pos) return;
+  const uint16_t x = stream[p];
+  if (x == GB_PAD) { out[p] = x; return; }
+  const u64 key = info[p];
+  const u32 len = cnt[key];
+  if (len > (u32)GB_SORT_SMALL) return;   // k_gb_sort_big's
+  const u64 st = sub_off[key] + blk_shift[key / n_seg];
+  u32 rank = 0;
+  for (u32 k = 0; k < len; k++) rank += stream[st + k] < x ? 1u : 0u;
+  out[st + rank] = x;
+}
+__global__ __launch_bounds__(BLOCK) void k_gb_sort_big(const uint16_t* __restrict__ stream, const u32* __restrict__ cnt, const u64* __restrict__ sub_off, const u64* __restrict__ blk_shift,
+                                                       u64 n_seg, u64 n_keys, uint16_t* out) {
+  // the indices of a run are distinct and below GB_B: the run as a bitmap in LDS (one bit per index), read back in increasing order -- a
+  // constant few hundred cycles per run whatever its length (ranking by counting was n^2 / 64 compares per wavefront: 8 ms at 8 M stress pairs)
+  constexpr int WORDS = GB_B / 32, PER_LANE = WORDS / 64;
+  __shared__ u32 s_bm[BLOCK / 64][WORDS];
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
+  const u64 key = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  const u32 len = key < n_keys ? cnt[key] : 0u;
+  const u64 start = len ? sub_off[key] + blk_shift[key / n_seg] : 0ULL;
+  u64 big = __ballot(len > (u32)GB_SORT_SMALL);
+  u32* bm = s_bm[wv];
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const u32 n = (u32)__shfl((int)len, src, 64);
+    const u64 st = shfl_u64(start, src);
+    const uint16_t* p = stream + st;
+#pragma unroll
+    for (int q = 0; q < PER_LANE; q++) bm[lane * PER_LANE + q] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (u32 i = lane; i < n; i += 64) { const u32 x = p[i]; atomicOr(&bm[x >> 5], 1u << (x & 31)); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u32 w[PER_LANE], pc = 0;
+#pragma unroll
+    for (int q = 0; q < PER_LANE; q++) { w[q] = bm[lane * PER_LANE + q]; pc += (u32)__popc(w[q]); }
+    u32 o = pm_scan_incl(pc) - pc;
+#pragma unroll
+    for (int q = 0; q < PER_LANE; q++) {
+      u32 word = w[q];
+      while (word) { const int bit = __ffs((int)word) - 1; word &= word - 1; out[st + o++] = (uint16_t)((lane * PER_LANE + q) * 32 + bit); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+// per (block, segment) run: its pieces (one per chunk it touches): END flags, the pieces' slots (seg-major numbering) at the positions of their last entries
+__global__ void k_gb_piece_count(const u32* __restrict__ cnt, const u64* __restrict__ sub_off, const u64* __restrict__ blk_shift, u64 n_seg, u32 n_blk, u32* pc) {
+  const u64 key = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= n_seg * (u64)n_blk) return;
+  const u32 len = cnt[key];
+  const u64 b = key / n_seg, s = key % n_seg;
+  u32 np = 0;
+  if (len) { const u64 st = sub_off[key] + blk_shift[b]; np = (u32)((st + len - 1) / GB_CH - st / GB_CH) + 1u; }
+  pc[s * n_blk + b] = np;
+}
+__global__ void k_gb_piece_ends(const u32* __restrict__ cnt, const u64* __restrict__ sub_off, const u64* __restrict__ blk_shift, u64 n_seg, u32 n_blk,
+                                const u64* __restrict__ slot_scan, uint16_t* stream, u32* end_slot) {
+  const u64 key = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= n_seg * (u64)n_blk) return;
+  const u32 len = cnt[key];
+  if (!len) return;
+  const u64 b = key / n_seg, s = key % n_seg;
+  const u64 st = sub_off[key] + blk_shift[b], last = st + len - 1;
+  u32 slot = (u32)slot_scan[s * n_blk + b];
+  for (u64 c = st / GB_CH; c <= last / GB_CH; c++) {
+    const u64 p = min((c + 1) * GB_CH - 1, last);
+    stream[p] |= GB_END;
+    end_slot[p] = slot++;
+  }
+}
+__global__ void k_gb_slot_base(const u64* __restrict__ slot_scan, u64 n_seg, u32 n_blk, u64 total, u32* slot_base) {
+  const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n_seg) slot_base[s] = (u32)slot_scan[s * n_blk];
+  else if (s == n_seg) slot_base[s] = (u32)total;
+}
+// per chunk (one wavefront): PmSide-style lane words and the number of pieces that end in it
+__global__ __launch_bounds__(BLOCK) void k_gb_lanes(const uint16_t* __restrict__ stream, u32 n_chunks, u32* lane_word, u32* chunk_ends) {
+  const u32 c = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = lane_id();
+  const uint16_t* p = stream + (u64)c * GB_CH + (u64)lane * GB_K;
+  u32 ne = 0;
+  for (int i = 0; i < GB_K; i++) ne += (p[i] & GB_END) ? 1u : 0u;
+  const u32 incl = pm_scan_incl(ne);
+  const u64 heads = __ballot(ne > 0);
+  const u64 below = heads & ((2ULL << lane) - 1ULL);
+  const u32 reach = below ? (u32)(lane - (63 - __clzll((long long)below))) : (u32)(lane + 1);
+  lane_word[(u64)c * 64 + lane] = (incl - ne) | (ne << 12) | (reach << 18);
+  if (lane == 63) chunk_ends[c] = incl;
+}
+__global__ __launch_bounds__(BLOCK) void k_gb_piece_slot(const uint16_t* __restrict__ stream, const u32* __restrict__ lane_word, const u64* __restrict__ seg_base64, u32 n_chunks,
+                                                         const u32* __restrict__ end_slot, u32* piece_slot, u32* seg_base) {
+  const u32 c = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const int lane = lane_id();
+  const u64 p0 = (u64)c * GB_CH + (u64)lane * GB_K;
+  u32 id = (u32)seg_base64[c] + (lane_word[(u64)c * 64 + lane] & 0xFFFu);
+  for (int i = 0; i < GB_K; i++) if (stream[p0 + i] & GB_END) piece_slot[id++] = end_slot[p0 + i];
+  if (lane == 0) seg_base[c] = (u32)seg_base64[c];
+}
+struct GbPlan { GbArgs args{}; bool valid = false; };
 struct GiantPart {
   PmPlan plan;
   double* G_al[2] = {nullptr, nullptr}; double* G_a[2] = {nullptr, nullptr};   // the ping-pong state of the chunks (chunk k: [k & 1] -> [(k + 1) & 1])
@@ -2248,6 +2587,7 @@ struct GiantPart {
   hipGraph_t graph[2] = {nullptr, nullptr}; hipGraphExec_t gexec[2] = {nullptr, nullptr};
   bool use_graph = true;
   u64 nnz = 0, rows = 0;
+  GbPlan gb;   // the same rounds in 2-D blocks with the gathers out of LDS (gb.valid), three launches per round instead of k_gi_rows / k_gi_cols
   void drop_graphs() {
     for (int i = 0; i < 2; i++) {
       if (gexec[i]) (void)hipGraphExecDestroy(gexec[i]);
@@ -2256,6 +2596,155 @@ struct GiantPart {
     }
   }
 };
+// builds one direction of the blocked form from the streamed plan's segments (off, ids); 0 = ok, 1 = not applicable, < 0 = error
+int gb_setup_side(kamd_ctx* c, const u64* off, const u32* ids, u64 n_seg, u64 n_tgt, int dir, GbSide* out) {
+  const int shift = dir == 0 ? GB_SHIFT_A : GB_SHIFT_G;
+  const u64 n_blk = (n_tgt + (1ULL << shift) - 1) >> shift;
+  const u64 n_keys = n_blk * n_seg;
+  if (n_blk == 0 || n_seg == 0 || n_keys >= 0x7FFFFFF0ULL || n_blk > 4096) return 1;
+  DBuf& t1 = c->hy_gb[0]; DBuf& t2 = c->hy_gb[1]; DBuf& ps = c->hy_gb[2 + dir]; DBuf& pq = c->hy_gb[4 + dir];
+  Carver v1;
+  const size_t o_cnt = v1.take(n_keys * 4), o_fill = v1.take(n_keys * 4), o_sub = v1.take((n_keys + 2) * 8), o_shift = v1.take(n_blk * 8);
+  const size_t o_pc = v1.take(n_keys * 4), o_sscan = v1.take((n_keys + 2) * 8);
+  if (int rc = t1.ensure(v1.off, 0, c->stream)) return rc;
+  char* b1 = (char*)t1.p;
+  u32* cnt = (u32*)(b1 + o_cnt); u32* fill = (u32*)(b1 + o_fill); u64* sub_off = (u64*)(b1 + o_sub); u64* blk_shift = (u64*)(b1 + o_shift);
+  u32* pc = (u32*)(b1 + o_pc); u64* slot_scan = (u64*)(b1 + o_sscan);
+  HIPC(hipMemsetAsync(cnt, 0, o_sub - o_cnt, c->stream));   // cnt + fill
+  hipLaunchKernelGGL(k_gb_count, dim3(grid_for(n_seg * 8, BLOCK)), dim3(BLOCK), 0, c->stream, off, ids, n_seg, shift, cnt);
+  if (int rc = exclusive_scan(c, cnt, n_keys, sub_off, sub_off + n_keys)) return rc;
+  std::vector<u64> start(n_blk + 1);
+  for (u64 b = 0; b <= n_blk; b++) HIPC(hipMemcpyAsync(&start[b], sub_off + b * n_seg, 8, hipMemcpyDeviceToHost, c->stream));   // (b == n_blk: the total)
+  HIPC(hipStreamSynchronize(c->stream));
+  std::vector<u64> shift_h(n_blk), chunk0(n_blk + 1, 0);
+  for (u64 b = 0; b < n_blk; b++) {
+    const u64 len = start[b + 1] - start[b];
+    chunk0[b + 1] = chunk0[b] + (len + GB_CH - 1) / GB_CH;
+    shift_h[b] = chunk0[b] * GB_CH - start[b];   // (never negative: the padding only moves blocks up)
+  }
+  const u64 n_chunks = chunk0[n_blk];
+  if (n_chunks == 0 || n_chunks >= 0x7FFFFFF0ULL / 64) return 1;
+  const u64 nzpad = n_chunks * GB_CH;
+  HIPC(hipMemcpyAsync(blk_shift, shift_h.data(), n_blk * 8, hipMemcpyHostToDevice, c->stream));
+  // Work lists.  ONE workgroup per compute unit at most (128 KB of LDS each: one more than the units would run as a second round of the launch
+  // and double its time); every block at least one workgroup, the rest dealt by the blocks' share of the chunks (largest remainders first), so
+  // that a workgroup loads ONE block (loading a block is three dependent memory latencies in the columns pass: a second one per workgroup was
+  // measured at +7 us per launch).  Workgroup i runs on XCD i % 8 (round-robin dispatch): the workgroups of a block get indices of one residue
+  // while that residue has free slots, so that a block's values are fetched into few of the eight L2s (they start cold at every launch).
+  std::vector<u32> desc, items;
+  {
+    std::vector<u64> parts(n_blk, 0), rem(n_blk, 0);
+    u64 used = 0, nonempty = 0;
+    for (u64 b = 0; b < n_blk; b++) if (chunk0[b + 1] > chunk0[b]) ++nonempty;
+    const u64 budget = std::max<u64>(nonempty, std::min<u64>((u64)c->n_cus, n_chunks));
+    for (u64 b = 0; b < n_blk; b++) {
+      const u64 nc = chunk0[b + 1] - chunk0[b];
+      if (!nc) continue;
+      parts[b] = std::min<u64>(nc, std::max<u64>(1, nc * budget / n_chunks));
+      rem[b] = nc * budget % n_chunks;
+      used += parts[b];
+    }
+    while (used > budget) {   // (blocks that were lifted to one workgroup: take from the largest)
+      u64 best = 0; for (u64 b = 1; b < n_blk; b++) if (parts[b] > parts[best]) best = b;
+      if (parts[best] <= 1) break;
+      --parts[best]; --used;
+    }
+    while (used < budget) {
+      u64 best = n_blk; for (u64 b = 0; b < n_blk; b++) if (parts[b] && parts[b] < chunk0[b + 1] - chunk0[b] && (best == n_blk || rem[b] > rem[best])) best = b;
+      if (best == n_blk) break;
+      ++parts[best]; rem[best] = 0; ++used;
+    }
+    // consecutive workgroup indices per block: round-robin dispatch spreads a block's workgroups over the eight XCDs (grouping them on one XCD
+    // was measured SLOWER, 29 against 22 us: they all read the same lines at the same time).  For the same reason every workgroup of a block
+    // starts loading the block at a different place (the item's fourth word: a rotation of the index).
+    for (u64 b = 0; b < n_blk; b++) {
+      const u64 nc = chunk0[b + 1] - chunk0[b];
+      for (u64 p = 0; p < parts[b]; p++) {
+        desc.push_back((u32)(items.size() / 4));
+        items.push_back((u32)b); items.push_back((u32)(chunk0[b] + nc * p / parts[b])); items.push_back((u32)(chunk0[b] + nc * (p + 1) / parts[b]));
+        items.push_back((u32)((p * (1ULL << shift) / parts[b]) & ~63ULL));
+        desc.push_back((u32)(items.size() / 4));
+      }
+    }
+  }
+  const u32 n_wg = (u32)(desc.size() / 2);
+  Carver vs;
+  const size_t o_stream = vs.take(nzpad * 2 + 64), o_lane = vs.take(n_chunks * 64 * 4), o_sb = vs.take(n_chunks * 4), o_wg = vs.take(desc.size() * 4 + 16), o_it = vs.take(items.size() * 4 + 16);
+  if (int rc = ps.ensure(vs.off, 0, c->stream)) return rc;
+  char* bs = (char*)ps.p;
+  uint16_t* stream = (uint16_t*)(bs + o_stream); u32* lane_word = (u32*)(bs + o_lane); u32* seg_base = (u32*)(bs + o_sb); u32* wg_desc = (u32*)(bs + o_wg); u32* wg_items = (u32*)(bs + o_it);
+  Carver v2;
+  const size_t o_tmp = v2.take(nzpad * 2 + 64), o_es = v2.take(nzpad * 4), o_ce = v2.take(n_chunks * 4), o_sb64 = v2.take((n_chunks + 2) * 8);
+  if (int rc = t2.ensure(v2.off, 0, c->stream)) return rc;
+  char* b2 = (char*)t2.p;
+  uint16_t* tmp = (uint16_t*)(b2 + o_tmp); u32* end_slot = (u32*)(b2 + o_es); u32* chunk_ends = (u32*)(b2 + o_ce); u64* seg_base64 = (u64*)(b2 + o_sb64);
+  HIPC(hipMemsetD16Async((hipDeviceptr_t)stream, (unsigned short)GB_PAD, nzpad, c->stream));
+  HIPC(hipMemcpyAsync(wg_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (!items.empty()) HIPC(hipMemcpyAsync(wg_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if (dir == 0) {
+    hipLaunchKernelGGL(k_gb_scatter<true>, dim3(grid_for(n_seg * 8, BLOCK)), dim3(BLOCK), 0, c->stream, off, ids, n_seg, (const u32*)cnt, (const u64*)sub_off, (const u64*)blk_shift,
+                       shift, fill, stream, (u32*)nullptr);
+  } else {
+    u32* info = end_slot;   // (the pieces' slots are written there later: the runs' keys are done with by then)
+    hipLaunchKernelGGL(k_gb_scatter<false>, dim3(grid_for(n_seg * 8, BLOCK)), dim3(BLOCK), 0, c->stream, off, ids, n_seg, (const u32*)cnt, (const u64*)sub_off, (const u64*)blk_shift,
+                       shift, fill, stream, info);
+    hipLaunchKernelGGL(k_gb_sort_small, dim3(grid_for(nzpad, BLOCK)), dim3(BLOCK), 0, c->stream, (const uint16_t*)stream, (const u32*)info, (const u32*)cnt, (const u64*)sub_off,
+                       (const u64*)blk_shift, n_seg, nzpad, tmp);
+    hipLaunchKernelGGL(k_gb_sort_big, dim3(grid_for(n_keys, BLOCK)), dim3(BLOCK), 0, c->stream, (const uint16_t*)stream, (const u32*)cnt, (const u64*)sub_off, (const u64*)blk_shift,
+                       n_seg, n_keys, tmp);
+    HIPC(hipMemcpyAsync(stream, tmp, nzpad * 2, hipMemcpyDeviceToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(k_gb_piece_count, dim3(grid_for(n_keys, BLOCK)), dim3(BLOCK), 0, c->stream, (const u32*)cnt, (const u64*)sub_off, (const u64*)blk_shift, n_seg, (u32)n_blk, pc);
+  HIPC(hipGetLastError());
+  if (int rc = exclusive_scan(c, pc, n_keys, slot_scan, slot_scan + n_keys)) return rc;
+  u64 n_pieces = 0;
+  HIPC(hipMemcpyAsync(&n_pieces, slot_scan + n_keys, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));   // (desc / shift are host vectors: the copies above have completed too)
+  if (n_pieces == 0 || n_pieces >= 0x7FFFFFF0ULL) return 1;
+  Carver vq;
+  const size_t o_ps = vq.take((n_pieces + 64) * 4), o_part = vq.take(n_pieces * 8), o_slb = vq.take((n_seg + 2) * 4);
+  if (int rc = pq.ensure(vq.off, 0, c->stream)) return rc;
+  char* bq = (char*)pq.p;
+  u32* piece_slot = (u32*)(bq + o_ps); double* part = (double*)(bq + o_part); u32* slot_base = (u32*)(bq + o_slb);
+  hipLaunchKernelGGL(k_gb_piece_ends, dim3(grid_for(n_keys, BLOCK)), dim3(BLOCK), 0, c->stream, (const u32*)cnt, (const u64*)sub_off, (const u64*)blk_shift, n_seg, (u32)n_blk,
+                     (const u64*)slot_scan, stream, end_slot);
+  hipLaunchKernelGGL(k_gb_slot_base, dim3(grid_for(n_seg + 1, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)slot_scan, n_seg, (u32)n_blk, n_pieces, slot_base);
+  hipLaunchKernelGGL(k_gb_lanes, dim3(grid_for(n_chunks, BLOCK / 64)), dim3(BLOCK), 0, c->stream, (const uint16_t*)stream, (u32)n_chunks, lane_word, chunk_ends);
+  HIPC(hipGetLastError());
+  if (int rc = exclusive_scan(c, chunk_ends, n_chunks, seg_base64, seg_base64 + n_chunks)) return rc;
+  hipLaunchKernelGGL(k_gb_piece_slot, dim3(grid_for(n_chunks, BLOCK / 64)), dim3(BLOCK), 0, c->stream, (const uint16_t*)stream, (const u32*)lane_word, (const u64*)seg_base64,
+                     (u32)n_chunks, (const u32*)end_slot, piece_slot, seg_base);
+  HIPC(hipMemsetAsync(part, 0, n_pieces * 8, c->stream));
+  HIPC(hipMemsetAsync(piece_slot + n_pieces, 0, 64 * 4, c->stream));
+  HIPC(hipGetLastError());
+  out->stream = stream; out->seg_base = seg_base; out->lane_word = lane_word; out->piece_slot = piece_slot; out->part = part; out->slot_base = slot_base; out->wg_desc = wg_desc; out->wg_items = wg_items;
+  out->n_wg = n_wg; out->n_chunks = (u32)n_chunks; out->n_pieces = (u32)n_pieces; out->n_seg = (u32)n_seg; out->n_tgt = (u32)n_tgt;
+  return 0;
+}
+constexpr size_t GB_LDS_BYTES = (size_t)(GB_B + 1) * 8 + 8 + (size_t)GB_WAVES * GB_CH * 8;
+// the blocked form of the oversized components on top of their streamed plan (G.plan); 0 = G.gb is valid, 1 = not applicable, < 0 = error
+int gb_setup(kamd_ctx* c, GiantPart& G) {
+  G.gb.valid = false;
+  const PmPlan& P = G.plan;
+  const PmArgs& A = P.args;
+  if (P.nzpad == 0 || A.R < 2 || A.M < 2) return 1;
+  GbArgs ga{};
+  if (int rc = gb_setup_side(c, P.roff, P.rs, A.R, A.M, 0, &ga.rows)) return rc;
+  if (int rc = gb_setup_side(c, P.coff, P.cs, A.M, A.R, 1, &ga.cols)) return rc;
+  ga.cw = A.cw; ga.single = A.single; ga.eff = A.eff; ga.R = A.R; ga.M = A.M;
+  HIPC(hipFuncSetAttribute((const void*)k_gb_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS_BYTES));
+  HIPC(hipFuncSetAttribute((const void*)k_gb_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS_BYTES));
+  G.gb.args = ga; G.gb.valid = true;
+  if (getenv("KAMD_DEBUG_FIN")) fprintf(stderr, "[kamd] blocked EM: R %u M %u nnz %llu; rows: %u chunks, %u pieces, %u workgroups; columns: %u chunks, %u pieces, %u workgroups\n", A.R, A.M,
+                                        (unsigned long long)P.nzpad, ga.rows.n_chunks, ga.rows.n_pieces, ga.rows.n_wg, ga.cols.n_chunks, ga.cols.n_pieces, ga.cols.n_wg);
+  return 0;
+}
+void gb_round(const GiantPart& G, hipStream_t s, int round, int clamp, const double* al_src, const double* a_src, double* al_dst, double* a_dst) {
+  const GbArgs& A = G.gb.args;
+  hipLaunchKernelGGL(k_gb_pass<0>, dim3(A.rows.n_wg), dim3(GB_THREADS), GB_LDS_BYTES, s, A, a_src, G.desc);
+  hipLaunchKernelGGL(k_gb_pass<1>, dim3(A.cols.n_wg), dim3(GB_THREADS), GB_LDS_BYTES, s, A, a_src, G.desc);
+  hipLaunchKernelGGL(k_gb_finish, dim3(grid_for(A.M, BLOCK)), dim3(BLOCK), 0, s, A, al_src, a_src, al_dst, a_dst, round, clamp, G.desc);
+}
 template <int K>
 void gi_round(const GiantPart& G, hipStream_t s, int round, int clamp, const double* al_src, const double* a_src, double* al_dst, double* a_dst) {
   const PmPlan& P = G.plan;
@@ -2281,6 +2770,7 @@ void gi_enqueue_rounds(const GiantPart& G, hipStream_t s, int n, int clamp, int 
       hipLaunchKernelGGL(k_gi_clamp, dim3(grid_for((u64)M + 1, BLOCK)), dim3(BLOCK), 0, s, al_src, a_src, G.ac, M, G.desc);
       a_src = G.ac;
     }
+    if (G.gb.valid) { gb_round(G, s, i, clamp, al_src, a_src, al_dst, a_dst); continue; }
     switch (G.plan.k) {
       case 8: gi_round<8>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
       case 12: gi_round<12>(G, s, i, clamp, al_src, a_src, al_dst, a_dst); break;
@@ -2887,6 +3377,9 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     G.ac = (double*)(xb + o_v[4]); G.desc = (GiDesc*)(xb + o_desc);
     hipLaunchKernelGGL(k_gi_zero_tail, dim3(1), dim3(64), 0, c->stream, G.S_al[0], G.S_al[1], G.S_a[0], G.S_a[1], G.ac, A.M);
     HIPC(hipGetLastError());
+    G.gb.valid = false;
+    if (c->tune.em_blocked != 2) { const int brc = gb_setup(c, G); if (brc < 0) return brc; }
+    c->last_em_giant_pieces = G.gb.valid ? (u64)G.gb.args.rows.n_pieces + G.gb.args.cols.n_pieces : 0;
     G.stream = c->hy_giant_stream; G.ev = c->hy_ev_giant; G.use_graph = c->tune.em_graph != 2;
     G.nnz = nnz_g; G.rows = A.R;
     K.hybrid = true;
@@ -2928,7 +3421,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   } else {
     const auto plan_t0 = std::chrono::steady_clock::now();
     K.valid = false; K.hybrid = false;
-    c->last_em_giant_nnz = 0; c->last_em_giant_rows = 0; c->last_em_giant_tr = 0; c->last_em_giant_chunks = 0;
+    c->last_em_giant_nnz = 0; c->last_em_giant_rows = 0; c->last_em_giant_tr = 0; c->last_em_giant_chunks = 0; c->last_em_giant_pieces = 0;
     // groups of nnz / (CUs x div) entries; a group must fit a workgroup's LDS (components are not split: if one does not fit, the
     // cut is refined a few times; a single component beyond the CU's 160 KB sends the oversized components to the streamed kernels
     // beside the groups -- the hybrid, em_hybrid_setup -- or, with several ranks, the whole matrix to the streamed form)

@@ -299,7 +299,7 @@ def _hybrid_csr(n_genes, seed, n_chained=500):
 
 
 @pytest.mark.parametrize("k", [None, 8, 16, 28, 32, "w8", "w24", "csr", "local", "local512", "local1024s8", "local1024s16", "local_lds_only", "local_one_class", "local_small40",
-                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_graphfail"])
+                               "local_all_small", "hub", "hub_streamed", "hybrid", "hybrid_nograph", "hybrid_lim60", "hybrid_k8", "8_fix", "hybrid_k8_fix", "hybrid_graphfail", "hub_plain", "hybrid_plain", "hybrid_lim60_plain"])
 def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     """The EM forms against the oracle's EMAlgorithm::run restatement: the streamed form (default and forced chunk sizes:
     64 x 8 entries makes the long rows / hub columns span many chunks -> fix-up launches; "wK": the general pass for chunks
@@ -311,6 +311,9 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
     off, ids, cnt, eff, T = _family_csr(400, 7)
     tune = {}
     graphfail = k == "hybrid_graphfail"
+    plain = isinstance(k, str) and k.endswith("_plain")   # the oversized components by the streamed kernels k_gi_rows / k_gi_cols instead of the 2-D blocked form (round 6's default)
+    if plain:
+        k = k[:-6]
     if k == "hybrid_graphfail":
         # the chunk graph of one ping-pong parity exists, the other one's cannot be instantiated: both are dropped, this chunk and the later ones go out
         # as plain launches
@@ -360,6 +363,8 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
         if isinstance(k, int):
             tune["em_entries_per_lane"] = k
     alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
+    if plain:
+        tune["em_blocked"] = False
     ctx = ka.Context(0)
     try:
         ctx.tune(**tune)
@@ -373,12 +378,14 @@ def test_em_forms_agree_with_oracle(k, ka, monkeypatch):
         assert prof["em_grid"] > 1                         # ... over several groups
     elif k == "hub":
         assert prof["em_k"] == -2 and prof["em_giant_nnz"] > 0 and prof["em_grid"] == 0   # the hybrid, everything on its streamed side
+        assert (prof["em_giant_pieces"] > 0) == (not plain)
     elif k == "hub_streamed":
         assert prof["em_k"] > 0 and prof["em_giant_nnz"] == 0
     elif k == "hybrid":
         assert prof["em_graph_fallback"] == (1 if graphfail else 0)   # (the injected failure was seen and the plain launches took over)
         assert prof["em_k"] == -2 and prof["em_grid"] > 1      # groups in k_em_sell ...
         assert prof["em_giant_nnz"] > 20000 and prof["em_max_comp_nnz"] > 20000   # ... and the oversized component beside them
+        assert (prof["em_giant_pieces"] > 0) == (not plain and not graphfail or graphfail)   # the blocked form by default
     else:
         assert (prof["em_k"] == 0) == (k == "csr")
     if isinstance(k, int):
