@@ -178,7 +178,7 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   for (void* p : c->index_allocs) (void)hipFree(p);
   for (DBuf* b : {&c->dense, &c->stream_buf, &c->rec_off, &c->overflow_items, &c->overflow_scratch, &c->state, &c->rec_slot,
                   &c->retry, &c->ttable, &c->tstore, &c->stats_a, &c->list, &c->cand, &c->cand_off, &c->cand_slot, &c->ctable, &c->tup_bound, &c->tup_off, &c->tup_big, &c->raw2, &c->overflow_left, &c->stats_b, &c->clist, &c->sizes, &c->explicit_items,
-                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
+                  &c->explicit_items_big, &c->exp_stream, &c->exp_off, &c->exp_scratch, &c->bs_cp, &c->bs_samp, &c->raw, &c->dense_first, &c->exp_key, &c->cand_key, &c->ec_first, &c->pm_a, &c->pm_b, &c->pm_rank, &c->eml_tmp, &c->ems_tmp, &c->ems_plan, &c->ems_maps, &c->fld_tl, &c->fld_card, &c->fld_scratch, &c->fld_items, &c->fld_cand,
                   &c->block_sums, &c->ec_off, &c->ec_ids, &c->ec_counts, &c->em_alpha, &c->em_next, &c->em_eff,
                   &c->em_state, &c->em_cn, &c->em_colcnt, &c->em_coloff, &c->em_colrow,
                   &c->em_segoff, &c->em_segt, &c->em_partial, &c->em_a0, &c->em_a1, &c->em_single, &c->em_actflag, &c->em_actpos, &c->em_active, &c->pt_label, &c->pt_flag, &c->pt_len,

@@ -234,7 +234,7 @@ struct kamd_ctx {
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;
   DBuf em_alpha, em_next, em_eff, em_state, em_cn, em_colcnt, em_coloff, em_colrow, em_segoff, em_segt, em_partial, em_a0, em_a1, em_single, em_actflag, em_actpos, em_active;
-  DBuf pm_a, pm_b;               // streamed EM: re-layout arenas
+  DBuf pm_a, pm_b, pm_rank;      // streamed EM: re-layout arenas, scratch of the rows' stable renumbering
   DBuf eml_tmp, ems_tmp, ems_plan, ems_maps;   // component-local EM: set-up scratch, sliced-ELLPACK plan, what a replicate re-uses
   SellCache* sell_cache = nullptr;   // plan of the finalized matrix, kept for bootstrap replicates (allocated on first use)
   u64 ec_generation = 0;         // bumped whenever the finalized EC result is rebuilt (plans of an older result are stale)

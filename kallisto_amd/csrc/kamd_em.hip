@@ -593,16 +593,76 @@ __global__ void k_pm_flags(const u64* __restrict__ ec_off, const u32* __restrict
   if (i < n_ecs) { const u64 a = ec_off[i]; if (ec_off[i + 1] - a >= 2) atomicAdd(&hist[ec_ids[a]], 1u); }   // sets are sorted: first = smallest
   if (i < n_tr) mflag[i] = col_cnt[i] ? 1u : 0u;
 }
-__global__ void k_pm_rank(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, const u64* __restrict__ start, u32* fill,
-                          u64* rpos, u32* len_sorted) {
-  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+// The new number of a kept row: rows ordered by the bucket of their smallest transcript (4096 buckets over the transcripts: rows of one gene
+// become neighbours, the gathers of a wavefront fall into few lines and a row block of the blocked form holds few genes' rows), rows of one
+// bucket by a 48-bit hash of their CONTENT (the set of transcripts; equal sets do not occur).  The numbering -- and with it the order of every
+// floating-point sum of the streamed and blocked forms -- is therefore a function of the matrix alone, whatever order kamd_ec_finalize's
+// atomics emitted the classes in (until round 5 the place inside a group came from an atomic counter: abundances of an oversized component
+// differed in the last bits from run to run).  A least-significant-digit radix sort of the rows by that 60-bit key, 12 bits per pass; a pass
+// is a STABLE counting sort: one wavefront per tile of PM_RANK_TILE rows counts its rows per digit (k_pm_radix_hist), a scan over (digit, tile)
+// gives every tile's first place in every digit, k_pm_radix_place walks the tile in order, 64 rows at a time.  Rows that are not kept (fewer
+// than two transcripts) carry the largest key and end up behind the R kept ones.
+constexpr int PM_RANK_BUCKETS = 4096, PM_RANK_TILE = 1024, PM_RANK_PASSES = 5;
+__global__ void k_pm_rowkey(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, u64 n_ecs, u64 n_tr, u64* key) {
+  const u64 e = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / 8;   // 8 lanes per row
+  const int sub = threadIdx.x & 7;
   if (e >= n_ecs) return;
-  const u64 a = ec_off[e], l = ec_off[e + 1] - a;
-  if (l < 2) return;
-  const u32 t0 = ec_ids[a];
-  const u64 r = start[t0] + atomicAdd(&fill[t0], 1u);
+  const u64 a = ec_off[e], b = ec_off[e + 1];
+  u64 h = 0;
+  for (u64 j = a + sub; j < b; j += 8) h += kamd::mix64((u64)ec_ids[j] + 0x9e3779b97f4a7c15ULL);   // (a sum: the same for any order of the members)
+  h += shfl_u64(h, lane_id() ^ 1); h += shfl_u64(h, lane_id() ^ 2); h += shfl_u64(h, lane_id() ^ 4);
+  if (sub == 0) key[e] = b - a >= 2 ? (((u64)ec_ids[a] * PM_RANK_BUCKETS / n_tr) << 48) | (kamd::mix64(h) >> 16) : ~0ULL;
+}
+__device__ __forceinline__ u32 pm_radix_digit(u64 k, int pass) { return (u32)(k >> (12 * pass)) & (PM_RANK_BUCKETS - 1); }
+// order_in == null: the identity (first pass)
+__global__ __launch_bounds__(64) void k_pm_radix_hist(const u64* __restrict__ key, const u32* __restrict__ order_in, u64 n, int pass, u32 n_tiles, u32* hist) {
+  __shared__ u32 s_cnt[PM_RANK_BUCKETS];
+  const int lane = lane_id();
+  for (int i = lane; i < PM_RANK_BUCKETS; i += 64) s_cnt[i] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const u64 p0 = (u64)blockIdx.x * PM_RANK_TILE;
+  for (u32 i = lane; i < (u32)PM_RANK_TILE; i += 64) {
+    const u64 p = p0 + i;
+    if (p < n) atomicAdd(&s_cnt[pm_radix_digit(key[order_in ? order_in[p] : p], pass)], 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = lane; i < PM_RANK_BUCKETS; i += 64) hist[(u64)i * n_tiles + blockIdx.x] = s_cnt[i];
+}
+__global__ __launch_bounds__(64) void k_pm_radix_place(const u64* __restrict__ key, const u32* __restrict__ order_in, u64 n, int pass, u32 n_tiles,
+                                                       const u64* __restrict__ first, u32* order_out) {
+  __shared__ u32 s_cnt[PM_RANK_BUCKETS];   // rows of the tile placed so far, per digit
+  const int lane = lane_id();
+  for (int i = lane; i < PM_RANK_BUCKETS; i += 64) s_cnt[i] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const u64 p0 = (u64)blockIdx.x * PM_RANK_TILE;
+  for (u32 i0 = 0; i0 < (u32)PM_RANK_TILE; i0 += 64) {
+    const u64 p = p0 + i0 + lane;
+    const bool in = p < n;
+    const u32 e = in ? (order_in ? order_in[p] : (u32)p) : 0u;
+    const u32 dg = in ? pm_radix_digit(key[e], pass) : 0xFFFFFFFFu;
+    // the lanes of one digit, in lane order: one leader per distinct digit and trip
+    u64 todo = __ballot(in);
+    u32 before = 0, same_total = 0;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const u32 ld = (u32)__shfl((int)dg, leader, 64);
+      const u64 same = __ballot(dg == ld);
+      if (dg == ld) { before = (u32)__popcll(same & ((1ULL << lane) - 1ULL)); same_total = (u32)__popcll(same); }
+      todo &= ~same;
+    }
+    if (in) order_out[first[(u64)dg * n_tiles + blockIdx.x] + s_cnt[dg] + before] = e;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (in && before == 0) s_cnt[dg] += same_total;   // (the first lane of every digit)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+// the sorted order -> the kept rows' new numbers and lengths (the R kept rows come first)
+__global__ void k_pm_rank_emit(const u64* __restrict__ ec_off, const u32* __restrict__ order, u64 R, u64* rpos, u32* len_sorted) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const u32 e = order[r];
   rpos[e] = r;
-  len_sorted[r] = (u32)l;
+  len_sorted[r] = (u32)(ec_off[e + 1] - ec_off[e]);
 }
 // kept row e -> entries of the row stream, its count word and offset; 8 lanes per row
 __global__ void k_pm_rows(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ counts,
@@ -880,10 +940,11 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   const size_t o_len = s1.take((n_ecs + 1) * 4), o_roff = s1.take((n_ecs + 2) * 8);
   if (int rc = ar_a.ensure(s1.off, 0, c->stream)) return rc;
   char* b1 = (char*)ar_a.p;
-  u32* hist = (u32*)(b1 + o_hist); u32* fill = (u32*)(b1 + o_fill); u32* mflag = (u32*)(b1 + o_mflag);
+  u32* hist = (u32*)(b1 + o_hist); u32* mflag = (u32*)(b1 + o_mflag);
   u64* start = (u64*)(b1 + o_start); u64* rpos = (u64*)(b1 + o_rpos); u64* mpos = (u64*)(b1 + o_mpos);
   u32* len_sorted = (u32*)(b1 + o_len); u64* roff = (u64*)(b1 + o_roff);
-  HIPC(hipMemsetAsync(hist, 0, (o_mflag - o_hist), c->stream));   // hist + fill
+  (void)o_fill;
+  HIPC(hipMemsetAsync(hist, 0, (o_mflag - o_hist), c->stream));
   hipLaunchKernelGGL(k_pm_flags, dim3(grid_for(std::max(n_ecs, T), BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, col_cnt, T, hist,
                      mflag);
   if (int rc = exclusive_scan(c, hist, T, start, start + T)) return rc;
@@ -894,7 +955,27 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   HIPC(hipMemcpyAsync(&NZ, c->em_coloff.as<u64>() + T, 8, hipMemcpyDeviceToHost, c->stream));   // non-zeros of the kept rows
   HIPC(hipStreamSynchronize(c->stream));
   if (NZ == 0 || R == 0 || M == 0 || R >= 0x7FFFFFF0ULL || M >= 0x7FFFFFF0ULL || NZ >= (1ULL << 40)) return 1;
-  hipLaunchKernelGGL(k_pm_rank, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, start, fill, rpos, len_sorted);
+  {
+    if (n_ecs >= 0xFFFFFFF0ULL) return 1;
+    const u32 n_tiles = (u32)((n_ecs + PM_RANK_TILE - 1) / PM_RANK_TILE);
+    const u64 n_cells = (u64)PM_RANK_BUCKETS * n_tiles;
+    Carver rv;
+    const size_t o_key = rv.take(n_ecs * 8), o_oa = rv.take(n_ecs * 4), o_ob = rv.take(n_ecs * 4), o_h = rv.take(n_cells * 4), o_f = rv.take((n_cells + 2) * 8);
+    if (int rc = c->pm_rank.ensure(rv.off, 0, c->stream)) return rc;
+    char* rb = (char*)c->pm_rank.p;
+    u64* key = (u64*)(rb + o_key); u32* ord[2] = {(u32*)(rb + o_oa), (u32*)(rb + o_ob)}; u32* rhist = (u32*)(rb + o_h); u64* rfirst = (u64*)(rb + o_f);
+    hipLaunchKernelGGL(k_pm_rowkey, dim3(grid_for(n_ecs * 8, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, ec_ids, n_ecs, T, key);
+    const u32* in = nullptr;
+    for (int pass = 0; pass < PM_RANK_PASSES; pass++) {
+      u32* out = ord[pass & 1];
+      hipLaunchKernelGGL(k_pm_radix_hist, dim3(n_tiles), dim3(64), 0, c->stream, (const u64*)key, in, n_ecs, pass, n_tiles, rhist);
+      if (int rc = exclusive_scan(c, rhist, n_cells, rfirst, rfirst + n_cells)) return rc;
+      hipLaunchKernelGGL(k_pm_radix_place, dim3(n_tiles), dim3(64), 0, c->stream, (const u64*)key, in, n_ecs, pass, n_tiles, (const u64*)rfirst, out);
+      in = out;
+    }
+    hipLaunchKernelGGL(k_pm_rank_emit, dim3(grid_for(R, BLOCK)), dim3(BLOCK), 0, c->stream, ec_off, in, R, rpos, len_sorted);
+    HIPC(hipGetLastError());
+  }
   if (int rc = exclusive_scan(c, len_sorted, R, roff, roff + R)) return rc;   // roff[R] = NZ
   // entries per lane: the smallest K whose chunks fit the chip in one go at 12 wavefronts per CU (measured on config #3:
   // 28.0 us per round at K = 24 / 3038 chunks against 32.7 at K = 20 / 3646 and 32.5 at K = 16 / 4557, same box)
