@@ -700,10 +700,11 @@ __global__ void k_pm_minit(u64 n_tr, const u32* __restrict__ mflag, const u64* _
                            const double* __restrict__ single, const double* __restrict__ eff, u64 M, u64* coff, double* single_m,
                            double* eff_m, double* alpha0, double* alpha1, double* a0, double* a1, double* ac0, double* ac1) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) { coff[M] = col_off[n_tr]; alpha0[M] = alpha1[M] = a0[M] = a1[M] = ac0[M] = ac1[M] = 0.0; }
+  if (t == 0) { if (coff) coff[M] = col_off[n_tr]; alpha0[M] = alpha1[M] = a0[M] = a1[M] = ac0[M] = ac1[M] = 0.0; }
   if (t >= n_tr || !mflag[t]) return;
   const u64 m = mpos[t];
-  coff[m] = col_off[t]; single_m[m] = single[t]; eff_m[m] = eff[t];
+  if (coff) coff[m] = col_off[t];   // (null: a cached plan gets new counts and effective lengths, its layout stays)
+  single_m[m] = single[t]; eff_m[m] = eff[t];
   const double al = 1.0 / (double)n_tr;
   alpha0[m] = al; a0[m] = al / eff[t]; alpha1[m] = 0.0; a1[m] = 0.0;
   ac0[m] = al < 1e-7 / 10.0 ? 0.0 : al / eff[t]; ac1[m] = 0.0;
@@ -895,6 +896,7 @@ struct PmPlan {
   const u32* mflag = nullptr; const u64* mpos = nullptr;   // transcript -> m-space
   const u64* roff = nullptr; const u64* coff = nullptr;    // [R + 1] / [M + 1] entry offsets of the rows / columns (the hybrid picks its hot targets by length)
   u32* rs = nullptr; u32* cs = nullptr; u64 nzpad = 0;     // the two entry streams (nzpad entries each)
+  const u64* rpos = nullptr;                               // row of the source matrix -> kept row (rows of fewer than two transcripts: unset)
 };
 constexpr int PM_KS[] = {8, 12, 16, 20, 24, 28, 32};
 template <int K>
@@ -1052,7 +1054,7 @@ int em_streamed_setup(kamd_ctx* c, const u64* ec_off, const u32* ec_ids, const u
   P->n_fix[0] = plan_words[0]; P->n_fix[1] = plan_words[1];
   P->windowed = plan_words[2] > (u32)PM_LDS_SLOTS;
   if (c->tune.em_windowed == 1) P->windowed = true;
-  P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos;
+  P->k = K; P->n_chunks = n_chunks; P->mflag = mflag; P->mpos = mpos; P->rpos = rpos;
   P->roff = roff; P->coff = coff; P->rs = rs; P->cs = cs; P->nzpad = nzpad;
   c->last_em_nnz_multi = NZ; c->last_em_nseg = n_chunks; c->last_em_necs = n_ecs; c->last_em_k = K;
   c->last_em_grid = grid_for(n_chunks, PM_BLOCK / 64);
@@ -2900,8 +2902,16 @@ struct SellCache {
   kamd_em_sell::Plan P;      // host part (tr_id, single_all, bases)
   EmSellDev dev{};           // device part, in ctx->ems_plan
   u32* row_final = nullptr; u32* mslot = nullptr; double* single_all = nullptr; double* d_eff = nullptr;   // in ctx->ems_maps
-  bool hybrid = false;       // G holds the streamed plan of the components beyond a workgroup's LDS; P / dev the others (never cached: valid stays false)
+  bool hybrid = false;       // G holds the streamed plan of the components beyond a workgroup's LDS; P / dev the others
   GiantPart G;
+  // what a cached hybrid plan needs to take new counts (a bootstrap replicate): the split of the rows into the two sub-matrices (arrays in ctx->hy_sub)
+  struct HyKeep {
+    const u32* flag_s = nullptr; const u32* flag_g = nullptr; const u64* rpos_s = nullptr; const u64* rpos_g = nullptr;
+    const u64* off_s = nullptr; const u64* off_g = nullptr; const u32* ids_s = nullptr; const u32* ids_g = nullptr;
+    u32* cnt_s = nullptr; u32* cnt_g = nullptr; u32* wc_s = nullptr; u32* wc_g = nullptr;
+    u64 n_s = 0, n_g = 0; bool no_groups = false;
+  } hy;
+  int giant_nnz_t = 0, blocked_t = 0, hybrid_t = 0;   // tuning the cached plan was built under
   ~SellCache() { G.drop_graphs(); }
 };
 }  // namespace kamdi
@@ -3464,10 +3474,53 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     G.stream = c->hy_giant_stream; G.ev = c->hy_ev_giant; G.use_graph = c->tune.em_graph != 2;
     G.nnz = nnz_g; G.rows = A.R;
     K.hybrid = true;
+    K.hy.flag_s = flag_s; K.hy.flag_g = flag_g; K.hy.rpos_s = rpos_s; K.hy.rpos_g = rpos_g; K.hy.off_s = off_s; K.hy.off_g = off_g; K.hy.ids_s = ids_s; K.hy.ids_g = ids_g;
+    K.hy.cnt_s = cnt_s; K.hy.cnt_g = cnt_g; K.hy.wc_s = wc_s; K.hy.wc_g = wc_g; K.hy.n_s = n_s; K.hy.n_g = n_g; K.hy.no_groups = K.row_final == nullptr;
     c->last_em_giant_nnz = c->last_em_nnz_multi; c->last_em_giant_rows = A.R; c->last_em_giant_tr = A.M; c->last_em_giant_chunks = G.plan.n_chunks;
     return 0;
   }
   return 1;
+}
+// ---- a cached hybrid plan takes new counts (bootstrap replicates: Bootstrap::run_em, src/Bootstrap.cpp:4-14 -- same matrix, resampled counts) ----
+__global__ void k_hy_counts(const u32* __restrict__ counts, const u32* __restrict__ wcounts, u64 n_ecs, const u32* __restrict__ row_flag, const u64* __restrict__ row_pos,
+                            u32* out_counts, u32* out_wcounts) {
+  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ecs || !row_flag[e]) return;
+  out_counts[row_pos[e]] = counts[e]; out_wcounts[row_pos[e]] = wcounts[e];
+}
+// the oversized side: count words of its kept rows, singleton counts of its transcripts (transcript space)
+__global__ void k_gi_refresh(const u64* __restrict__ off, const u32* __restrict__ ids, const u32* __restrict__ counts, const u32* __restrict__ wcounts, u64 n,
+                             const u64* __restrict__ rpos, u64* cw, double* single_t) {
+  const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const u64 a = off[e], len = off[e + 1] - a;
+  if (len == 1) single_t[ids[a]] = (double)counts[e];
+  else if (len >= 2) cw[rpos[e]] = (u64)counts[e] | ((u64)wcounts[e] << 32);
+}
+int em_hybrid_refresh(kamd_ctx* c, SellCache& K, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, const double* eff_lens, u64 T) {
+  const SellCache::HyKeep& H = K.hy;
+  GiantPart& G = K.G;
+  const PmArgs& A = G.plan.args;
+  hipLaunchKernelGGL(k_hy_counts, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_counts, d_wcounts, n_ecs, H.flag_s, H.rpos_s, H.cnt_s, H.wc_s);
+  hipLaunchKernelGGL(k_hy_counts, dim3(grid_for(n_ecs, BLOCK)), dim3(BLOCK), 0, c->stream, d_counts, d_wcounts, n_ecs, H.flag_g, H.rpos_g, H.cnt_g, H.wc_g);
+  // the side that fits
+  HIPC(hipMemsetAsync(K.single_all, 0, T * 8, c->stream));
+  if (H.no_groups) { if (H.n_s) hipLaunchKernelGGL(k_hy_single, dim3(grid_for(H.n_s, BLOCK)), dim3(BLOCK), 0, c->stream, H.off_s, H.ids_s, (const u32*)H.cnt_s, H.n_s, K.single_all); }
+  else {
+    HIPC(hipMemcpyAsync(K.d_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_sell_refresh, dim3(grid_for(std::max<u64>(H.n_s, T), BLOCK)), dim3(BLOCK), 0, c->stream, H.off_s, H.ids_s, (const u32*)H.cnt_s, (const u32*)H.wc_s,
+                       H.n_s, K.d_eff, T, K.row_final, K.mslot, const_cast<u64*>(K.dev.cw), const_cast<double*>(K.dev.single), const_cast<double*>(K.dev.eff), K.single_all);
+  }
+  // the oversized side: count words, singleton counts and effective lengths in m-space, the vectors back at alpha = 1 / T
+  for (DBuf* b : {&c->em_eff, &c->em_single}) if (int rc = b->ensure(T * sizeof(double), 0, c->stream)) return rc;
+  HIPC(hipMemcpyAsync(c->em_eff.p, eff_lens, T * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipMemsetAsync(c->em_single.p, 0, T * sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_gi_refresh, dim3(grid_for(H.n_g, BLOCK)), dim3(BLOCK), 0, c->stream, H.off_g, H.ids_g, (const u32*)H.cnt_g, (const u32*)H.wc_g, H.n_g, G.plan.rpos,
+                     const_cast<u64*>(A.cw), c->em_single.as<double>());
+  hipLaunchKernelGGL(k_pm_minit, dim3(grid_for(T, BLOCK)), dim3(BLOCK), 0, c->stream, T, G.plan.mflag, G.plan.mpos, (const u64*)nullptr, (const double*)c->em_single.as<double>(),
+                     (const double*)c->em_eff.as<double>(), (u64)A.M, (u64*)nullptr, const_cast<double*>(A.single), const_cast<double*>(A.eff), A.alpha0, A.alpha1, A.a0, A.a1, A.ac0, A.ac1);
+  HIPC(hipGetLastError());
+  return 0;
 }
 // part (several ranks, each with the rows of the components it owns): the per-round change counts of a chunk are summed over the
 // ranks on the device before the host looks at them (the only coupling between components is the stop rule), and "this form does
@@ -3485,8 +3538,12 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   const bool own = c->finalized && d_ec_off == (const u64*)c->result.d_ec_off && d_ec_ids == c->result.d_ec_ids;
   const bool hit = own && K.valid && K.d_ec_off == d_ec_off && K.d_ec_ids == d_ec_ids && K.n_ecs == n_ecs && K.nnz == nnz && K.T == T &&
                    K.generation == c->ec_generation && K.split_len == c->tune.em_split_len && K.group_div == c->tune.em_group_div &&
-                   K.small_nnz == c->tune.em_small_nnz && (K.host_maps || !multi);
-  if (hit) {
+                   K.small_nnz == c->tune.em_small_nnz && (K.host_maps || !multi) &&
+                   (!K.hybrid || (!multi && K.giant_nnz_t == c->tune.em_giant_nnz && K.blocked_t == c->tune.em_blocked && K.hybrid_t == c->tune.em_hybrid));
+  if (hit && K.hybrid) {
+    c->last_em_plan_ms = 0.f;
+    if (int rc = em_hybrid_refresh(c, K, d_counts, d_wcounts, n_ecs, eff_lens, T)) return rc;
+  } else if (hit) {
     c->last_em_plan_ms = 0.f;
     HIPC(hipMemcpyAsync(K.d_eff, eff_lens, T * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemsetAsync(K.single_all, 0, T * 8, c->stream));
@@ -3545,7 +3602,8 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
     }
     if (not_applicable) return 1;
     c->last_em_plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - plan_t0).count();
-    if (own && !K.hybrid) {
+    if (own) {
+      K.giant_nnz_t = c->tune.em_giant_nnz; K.blocked_t = c->tune.em_blocked; K.hybrid_t = c->tune.em_hybrid;
       K.valid = true; K.d_ec_off = d_ec_off; K.d_ec_ids = d_ec_ids; K.n_ecs = n_ecs; K.nnz = nnz; K.T = T; K.generation = c->ec_generation;
       K.split_len = c->tune.em_split_len; K.group_div = c->tune.em_group_div; K.small_nnz = c->tune.em_small_nnz; K.host_maps = multi;
     }
