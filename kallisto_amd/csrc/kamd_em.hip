@@ -2931,16 +2931,28 @@ struct EmSellGpu {
   int gi_par(const double* al) const { return al == d_alpha ? 0 : 1; }   // which half of the ping-pong pair a vector of the groups is
   EmSellGpu(kamd_ctx* ctx, const kamd_em_sell::Plan& p) : c(ctx), P(p) {}
   int setup(int hist_ints, const double* d_eff_new, u64 T_out);
+  // (the in-place interface of kamd_em_local::run works on state 0 of the oversized side's ping-pong pair, state 1 is its checkpoint)
   void checkpoint() {
     if (err) return;
     if (hipMemcpyAsync(d_ck_alpha, d_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
         hipMemcpyAsync(d_ck_a, d_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+    if (gi && !err) {
+      const size_t gb = ((size_t)gi->plan.args.M + 1) * 8;
+      if (hipMemcpyAsync(gi->G_al[1], gi->G_al[0], gb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+          hipMemcpyAsync(gi->G_a[1], gi->G_a[0], gb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+    }
   }
   void restore() {
     if (err) return;
     if (hipMemcpyAsync(d_alpha, d_ck_alpha, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
         hipMemcpyAsync(d_a, d_ck_a, M * 8, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+    if (gi && !err) {
+      const size_t gb = ((size_t)gi->plan.args.M + 1) * 8;
+      if (hipMemcpyAsync(gi->G_al[0], gi->G_al[1], gb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+          hipMemcpyAsync(gi->G_a[0], gi->G_a[1], gb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) err = -104;
+    }
   }
+  std::vector<double> h_gi_cur, h_gi_prev; int host_reads = 0;   // the oversized side's alpha at the last two host_alpha() calls (final / before the final round)
   // n rounds from (al_in, a_in) to (al_out, a_out) for every group; change counts of the rounds added to d_h (device, zeroed by the caller) if given
   int launch(int n, int clamp, const double* al_in, const double* a_in, double* al_out, double* a_out, int* d_h, const EmsPrev& prev, long long* clk = nullptr) {
     if (n <= 0 || n > EML_MAX_ROUNDS) return -104;
@@ -2997,7 +3009,13 @@ struct EmSellGpu {
   }
   const std::vector<double>& host_alpha() {
     h_alpha.resize(M);
-    if (!err && (hipMemcpyAsync(h_alpha.data(), d_alpha, M * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    if (gi && !err) {
+      h_gi_prev.swap(h_gi_cur);
+      h_gi_cur.resize(gi->plan.args.M);
+      if (hipMemcpyAsync(h_gi_cur.data(), gi->G_al[0], (size_t)gi->plan.args.M * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) err = -104;
+    }
+    ++host_reads;
+    if (!err && ((M && hipMemcpyAsync(h_alpha.data(), d_alpha, M * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
                  hipStreamSynchronize(c->stream) != hipSuccess)) err = -104;
     return h_alpha;
   }
@@ -3356,7 +3374,7 @@ int em_sell_plan_search(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, c
 }
 // 0 = K holds the hybrid plan (K.hybrid, K.G), 1 = not applicable, < 0 = error
 int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const u32* d_counts, const u32* d_wcounts, u64 n_ecs, u64 nnz,
-                    const double* eff_lens, u64 T, u64 lds_budget, SellCache& K, bool first_try = false) {
+                    const double* eff_lens, u64 T, u64 lds_budget, SellCache& K, bool first_try = false, bool host_maps = false) {
   if (n_ecs == 0 || nnz >= (1ULL << 32) || T >= 0xFFFFFFF0ULL || n_ecs >= 0xFFFFFFF0ULL) return 1;
   GiantPart& G = K.G;
   G.drop_graphs();
@@ -3420,7 +3438,7 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
     // the side that fits: the component-local plan over its rows (groups sized for the compute units it gets)
     CompStats cst{};
     c->labels_override = label;   // (the components of the side that fits are components of the whole matrix)
-    int prc = n_s ? em_sell_plan_search(c, off_s, ids_s, cnt_s, wc_s, n_s, nnz_s, eff_lens, T, lds_budget, sell_cus, false, K, &cst) : 1;
+    int prc = n_s ? em_sell_plan_search(c, off_s, ids_s, cnt_s, wc_s, n_s, nnz_s, eff_lens, T, lds_budget, sell_cus, host_maps, K, &cst) : 1;
     c->labels_override = nullptr;
     if (prc < 0) return prc;
     if (prc == 1 && cst.max_nnz == 0) {
@@ -3437,6 +3455,11 @@ int em_hybrid_setup(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, const
       if (n_s) hipLaunchKernelGGL(k_hy_single, dim3(grid_for(n_s, BLOCK)), dim3(BLOCK), 0, c->stream, off_s, ids_s, cnt_s, n_s, (double*)(mb + m_sa));
       HIPC(hipGetLastError());
       K.mslot = (u32*)(mb + m_ms); K.single_all = (double*)(mb + m_sa); K.row_final = nullptr; K.d_eff = nullptr;
+      if (host_maps) {   // (several ranks scatter on the host: the singleton counts there too)
+        K.P.single_all.resize(T);
+        HIPC(hipMemcpyAsync(K.P.single_all.data(), K.single_all, T * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+      }
       prc = 0;
     }
     if (prc == 1) continue;   // some component under the limit still does not fit its group: a lower limit
@@ -3571,9 +3594,10 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
       K.dev = EmSellDev{};
       prc = 0;
     } else {
-      const bool may_hybrid = !multi && c->tune.em_hybrid != 2 && n_ecs > 0;
+      // (several ranks: the rank that owns an oversized component runs the hybrid on its rows like one rank would; kamd_em_local::run drives it)
+      const bool may_hybrid = c->tune.em_hybrid != 2 && n_ecs > 0;
       if (may_hybrid && c->em_prefer_hybrid) {   // the context's last matrix needed the hybrid (bootstrap replicates, the steps of a bench): start there
-        prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K, true);
+        prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K, true, multi);
         if (prc < 0) return prc;
         if (prc == 1) { K.hybrid = false; c->em_prefer_hybrid = false; }
       }
@@ -3582,7 +3606,7 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
         prc = em_sell_plan_search(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, c->n_cus, multi, K, &cst);
         c->last_em_max_comp_nnz = cst.max_nnz;
         if (prc == 1 && may_hybrid && cst.max_nnz > 0) {
-          prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K);
+          prc = em_hybrid_setup(c, d_ec_off, d_ec_ids, d_counts, d_wcounts, n_ecs, nnz, eff_lens, T, lds_budget, K, false, multi);
           if (prc == 1) K.hybrid = false;
           else if (prc == 0) c->em_prefer_hybrid = true;
         }
@@ -3616,7 +3640,22 @@ int em_sell_run_device(kamd_ctx* c, const u64* d_ec_off, const u32* d_ec_ids, co
   const int n_chunks = std::max(1, (n_iter + chunk - 1) / chunk);
   if (int rc = B.setup(multi ? chunk : n_chunks * chunk, K.dev.eff, multi ? 0 : T)) return rc;
   int r = 0;
-  if (multi) r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);   // the change counts of a chunk are summed over the ranks before anyone reads them
+  if (multi) {
+    r = kamd_em_local::run(B, P, n_iter, min_rounds, chunk, alpha, abz);   // the change counts of a chunk are summed over the ranks before anyone reads them
+    if (K.hybrid && !B.err) {
+      // the oversized components' transcripts (kamd_em_local::run scattered the groups' and left these at their singleton counts)
+      const PmPlan& GP = K.G.plan;
+      std::vector<u32> mflag(T); std::vector<u64> mpos(T);
+      HIPC(hipMemcpyAsync(mflag.data(), GP.mflag, T * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipMemcpyAsync(mpos.data(), GP.mpos, T * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      const bool have_final = B.host_reads >= 2;   // (the state before the final round was read, then the final one)
+      for (u64 t = 0; t < T; t++) if (mflag[t]) {
+        alpha[t] = B.h_gi_cur[mpos[t]];
+        if (abz) abz[t] = have_final ? B.h_gi_prev[mpos[t]] : 0.0;
+      }
+    }
+  }
   else if (int rc = em_sell_drive_async(c, B, K, T, n_iter, min_rounds, alpha, abz, &r)) return rc;
   if (B.err) return kamd::fail(B.err, "kamd_em_run: the component-local EM failed on the device");
   HIPC(hipEventRecord(c->ev1, c->stream));

@@ -73,7 +73,61 @@ def _worker(rank, world, port, case, variant, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("human_pe", "pe_rf"), ("yeast_se", "se")])
+def _hybrid_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kallisto_amd as ka
+        from tests.test_gpu_parity import _hybrid_csr, _distinct_rows
+        off, ids, cnt, eff, T = _distinct_rows(*_hybrid_csr(3000, 11))
+        ctx = ka.Context(0)
+        ctx.tune(em_form="local")
+        ctx.ec_upload(off, ids, cnt)
+        comm = ka.Comm.over_process_group(ctx)
+        alpha, abz, rounds = ctx.em_run_comm(comm, eff)
+        prof = ctx.profile()
+        alpha1, abz1, rounds1 = ctx.em_run(eff)       # one rank, the hybrid on the whole matrix
+        prof1 = ctx.profile()
+        comm.close()
+        q.put((rank, alpha, abz, rounds, prof["em_k"], prof["em_giant_nnz"], alpha1, abz1, rounds1, prof1["em_giant_nnz"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_hybrid_em():
+    """a matrix with ONE component beyond a workgroup's LDS under kamd_em_run_comm.  Components are dealt to the ranks by hash(label): the
+    rank that owns the oversized one runs the hybrid (LDS groups + blocked / streamed kernels for that component) on its rows, the other rank the plain
+    component-local form; until round 5 every rank fell back to the whole-matrix streamed form.  Same rounds and abundances as one rank and as the oracle."""
+    from oracle import oracle as O
+    from tests.test_gpu_parity import _hybrid_csr, _distinct_rows
+    off, ids, cnt, eff, T = _distinct_rows(*_hybrid_csr(3000, 11))
+    alpha_o, abz_o, rounds_o = O.em_run(off, ids, cnt, eff, T)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = {g[0]: g for g in got}
+    assert sum(1 for r in (0, 1) if res[r][5] > 20000) == 1, [res[r][5] for r in (0, 1)]   # exactly one rank iterated the oversized component beside its groups
+    for r in (0, 1):
+        _, alpha, abz, rounds, em_k, giant, alpha1, abz1, rounds1, giant1 = res[r]
+        assert em_k == -2 and giant1 > 20000
+        assert rounds == rounds1 == rounds_o
+        common.assert_abundance_close(alpha, alpha_o, "two ranks vs oracle", rel=1e-9)
+        common.assert_abundance_close(alpha, alpha1, "two ranks vs one", rel=1e-9)
+        tiny = lambda x: np.where(np.abs(x) < 1e-200, 0.0, x)
+        common.assert_abundance_close(tiny(abz), tiny(abz1), "alpha_before_zeroes", rel=1e-9, floor=1e-12)
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("human_pe", "pe_rf"), ("yeast_se", "se"), ("stress_pe", "pe")])
 def test_two_ranks_one_gpu(case, variant):
     exp = common.load_expected(case, variant)
     ctx = mp.get_context("spawn")
