@@ -35,7 +35,7 @@ with open('$O/r06_lds_counters.txt','w') as fo:
         fo.write("%s launches=%d %s conflict_share=%.3f\n"%(k,calls[k],d,(bc/act if act else 0.0)))
 PY
 rm -rf $O/pmc_*
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --parity-sample 0 --no-stress-leg --no-gencode-leg --full-parity off --detail-file /tmp/d2.json > /dev/null 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --parity-sample 0 --no-stress-leg --no-gencode-leg --full-parity off --bootstraps 0 --detail-file /tmp/d2.json > /dev/null 2>&1
 S=$(find $O/trace -name '*kernel_stats.csv' | head -1)
 python - "$S" <<PY
 import csv,sys
