@@ -70,86 +70,37 @@ __global__ __launch_bounds__(VERIFY_BLOCK) void k_rec_verify(const u32* __restri
 // of the 32 bits -- : next slot).  Exact, no second pass, no per-record slot array, no retries.
 // max_probe: give up after that many slots (counted in st->n_retry; the host then repeats the run with a larger table) -- lets the
 // table be sized for the EXPECTED number of distinct records instead of the number of records.
-// Records of more than REC_LONG words (candidate sets of poly-A and repeat-family classes: thousands of transcripts) are hashed and compared by
-// the whole wavefront -- a thread that walks 3 500 words alone holds its wavefront for hundreds of microseconds (k_rec_dedup 9.8 ms per 30 M
-// stress pairs, round 6).  Their hash is another function of the content than rec_hash (lane-strided chains folded across the lanes); a record
-// takes one path or the other by its length alone, so equal records always meet under the same hash.
-constexpr u32 REC_LONG = 64;
-__device__ __forceinline__ u64 rec_hash_wave(const u32* w, u32 n, u64 seed) {   // all 64 lanes call it with the same arguments
-  const int lane = lane_id();
-  u64 h = kamd::mix64(seed ^ (0x9e3779b97f4a7c15ULL * (n + 1)) ^ ((u64)lane << 32));
-  for (u32 i = lane; i < n; i += 64) h = kamd::mix64(h ^ w[i]);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const u64 o = shfl_u64(h, lane ^ d); h = kamd::mix64(h ^ (o + (u64)d)) ^ kamd::mix64(o ^ (h + (u64)d)); }   // (symmetric in the pair: every lane ends with the same value)
-  return shfl_u64(h, 0) | 1ULL;
-}
 __global__ __launch_bounds__(BLOCK) void k_rec_dedup(const u32* __restrict__ stream, const u64* __restrict__ rec_off, u64 r0, u64 n, TSlot* table,
                                                      u64 mask, u64* list, const u64* __restrict__ keys, int track, u32 max_probe, DevState* st) {
   __shared__ u32 blk_n; __shared__ u64 blk_base;
   if (threadIdx.x == 0) blk_n = 0;
   __syncthreads();
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = lane_id();
   bool is_owner = false; u64 s = 0; u32 my = 0;
-  u64 off = ~0ULL; u32 m = 0; bool live = false;
   if (i < n) {
-    off = rec_off[r0 + i];
-    live = off != ~0ULL && stream[off] != 0u;
-    if (live) m = stream[off + 1];
-  }
-  if (live && m <= REC_LONG) {
     const u64 r = r0 + i;
-    const u64 h = rec_hash(stream + off + 1, m + 1, 1);
-    const u64 mine = (h & 0xFFFFFFFF00000000ULL) | (off + 1);   // off + 1 < 2^32 (checked by the host), so the word is never 0
-    s = (h >> 1) & mask;
-    bool placed = false;
-    for (u32 probes = 0; probes < max_probe; probes++) {
-      u64 old = table[s].tag;   // (plain load first, as in k_tup_absorb)
-      if (old == 0ULL) old = atomicCAS(&table[s].tag, 0ULL, mine);
-      if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }   // (owner: read by the kernels after this one)
-      if ((old >> 32) == (mine >> 32)) {
-        const u64 ooff = (old & 0xFFFFFFFFULL) - 1;
-        bool same = stream[ooff + 1] == m;
-        for (u32 j = 0; same && j < m; j++) same = stream[ooff + 2 + j] == stream[off + 2 + j];
-        if (same) { placed = true; break; }
+    const u64 off = rec_off[r];
+    if (off != ~0ULL && stream[off] != 0u) {
+      const u32 m = stream[off + 1];
+      const u64 h = rec_hash(stream + off + 1, m + 1, 1);
+      const u64 mine = (h & 0xFFFFFFFF00000000ULL) | (off + 1);   // off + 1 < 2^32 (checked by the host), so the word is never 0
+      s = (h >> 1) & mask;
+      bool placed = false;
+      for (u32 probes = 0; probes < max_probe; probes++) {
+        u64 old = table[s].tag;   // (plain load first, as in k_tup_absorb)
+        if (old == 0ULL) old = atomicCAS(&table[s].tag, 0ULL, mine);
+        if (old == 0ULL) { is_owner = true; table[s].owner = off; placed = true; break; }   // (owner: read by the kernels after this one)
+        if ((old >> 32) == (mine >> 32)) {
+          const u64 ooff = (old & 0xFFFFFFFFULL) - 1;
+          bool same = stream[ooff + 1] == m;
+          for (u32 j = 0; same && j < m; j++) same = stream[ooff + 2 + j] == stream[off + 2 + j];
+          if (same) { placed = true; break; }
+        }
+        s = (s + 1) & mask;
       }
-      s = (s + 1) & mask;
-    }
-    if (placed) {
-      atomicAdd(&table[s].count, (u64)stream[off]);
-      if (track) atomicMin(&table[s].first, keys ? keys[r] : r);   // first occurrence: record indices follow the input order
-    } else atomicAdd(&st->n_retry, 1ULL);
-  }
-  // the long records of the wavefront, one after the other, all lanes on each
-  u64 todo = __ballot(live && m > REC_LONG);
-  while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const u64 loff = shfl_u64(off, src);
-    const u32 lm = (u32)__shfl((int)m, src, 64);
-    const u64 h = rec_hash_wave(stream + loff + 1, lm + 1, 1);
-    const u64 mine = (h & 0xFFFFFFFF00000000ULL) | (loff + 1);
-    u64 ls = (h >> 1) & mask;
-    int outcome = 0;   // 1 = this record owns the slot, 2 = merged into an equal record's slot
-    for (u32 probes = 0; probes < max_probe && !outcome; probes++) {
-      u64 old = 0;
-      if (lane == 0) { old = table[ls].tag; if (old == 0ULL) old = atomicCAS(&table[ls].tag, 0ULL, mine); }
-      old = shfl_u64(old, 0);
-      if (old == 0ULL) { outcome = 1; break; }
-      if ((old >> 32) == (mine >> 32)) {
-        const u64 ooff = (old & 0xFFFFFFFFULL) - 1;
-        bool same = stream[ooff + 1] == lm;
-        for (u32 j = lane; same && j < lm; j += 64) same = stream[ooff + 2 + j] == stream[loff + 2 + j];
-        if (__ballot(!same) == 0ULL) { outcome = 2; break; }
-      }
-      ls = (ls + 1) & mask;
-    }
-    if (lane == src) {
-      if (outcome) {
-        if (outcome == 1) { is_owner = true; table[ls].owner = loff; }
-        s = ls;
-        atomicAdd(&table[ls].count, (u64)stream[loff]);
-        if (track) atomicMin(&table[ls].first, keys ? keys[r0 + i] : r0 + i);
+      if (placed) {
+        atomicAdd(&table[s].count, (u64)stream[off]);
+        if (track) atomicMin(&table[s].first, keys ? keys[r] : r);   // first occurrence: record indices follow the input order
       } else atomicAdd(&st->n_retry, 1ULL);
     }
   }
