@@ -116,6 +116,15 @@ __device__ __forceinline__ u64 wave_sum64(u64 v) {
 
 __device__ __forceinline__ u64 rec_hash(const u32* w, u32 n, u64 seed) {
   u64 h = kamd::mix64(seed ^ (0x9e3779b97f4a7c15ULL * (n + 1)));
+  if (n > 64) {
+    // long records (candidate sets of thousands of transcripts): four interleaved chains -- one chain is 3 500 dependent multiplies for a poly-A
+    // class, and the thread's wavefront waits for it (k_rec_dedup 9.8 ms per 30 M stress pairs).  A record takes this form by its length alone.
+    u64 h0 = h, h1 = h ^ 0x9e3779b97f4a7c15ULL, h2 = h ^ 0xc2b2ae3d27d4eb4fULL, h3 = h ^ 0x165667b19e3779f9ULL;
+    u32 i = 0;
+    for (; i + 4 <= n; i += 4) { h0 = kamd::mix64(h0 ^ w[i]); h1 = kamd::mix64(h1 ^ w[i + 1]); h2 = kamd::mix64(h2 ^ w[i + 2]); h3 = kamd::mix64(h3 ^ w[i + 3]); }
+    for (; i < n; i++) h0 = kamd::mix64(h0 ^ w[i]);
+    return kamd::mix64(kamd::mix64(h0 ^ (h1 + 1)) ^ kamd::mix64(h2 ^ (h3 + 3))) | 1ULL;
+  }
   for (u32 i = 0; i < n; i++) h = kamd::mix64(h ^ w[i]);
   return h | 1ULL;  // 0 is the empty tag
 }
@@ -127,7 +136,7 @@ __device__ __forceinline__ bool set_contains(const u32* ids, u32 n, u32 x) {
   return lo < n && ids[lo] == x;
 }
 constexpr u32 BM_NONE = 0xFFFFFFFFu;
-constexpr u32 BM_MIN_MEMBERS = 1024;          // sets with more members get a bitmap (kamd_index_upload) ...
+constexpr u32 BM_MIN_MEMBERS = 128;           // sets with more members get a bitmap (kamd_index_upload) ...
 constexpr size_t BM_MAX_BYTES = 256u << 20;   // ... the largest first, while they fit this much HBM
 __device__ __forceinline__ bool bitmap_has(const DevIndex& ix, u32 slot, u32 x) { return (ix.bm_words[(u64)slot * ix.bm_stride + (x >> 5)] >> (x & 31)) & 1u; }
 // is transcript x a member of index set e (its ids at ec_ids + off, sz of them)?

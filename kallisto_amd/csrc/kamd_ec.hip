@@ -619,24 +619,34 @@ __global__ __launch_bounds__(64 * RB_WAVES) void k_resolve_big(DevIndex ix, cons
     }
     wave_lds_sync();
     if (nbm && cnt) {
+      // four survivors per lane and trip, four sets per step: sixteen bit tests in flight (a tuple of a hundred poly-A sets and 3 500 survivors was
+      // 55 x 35 dependent steps with one survivor per lane)
       u32 kept = 0;
-      for (u32 c0 = 0; c0 < cnt; c0 += 64) {
-        const u32 c = c0 + lane;
-        const u32 x = c < cnt ? s_cand[c] : 0u;
-        bool ok = c < cnt;
-        const u32* wp = ix.bm_words + (x >> 5);
-        const u32 bit = 1u << (x & 31);
-        for (u32 b = 0; b < nbm && __ballot(ok) != 0ULL; b += 4) {
-          const u32 s0 = s_tile[b], s1 = s_tile[min(b + 1, nbm - 1)], s2 = s_tile[min(b + 2, nbm - 1)], s3 = s_tile[min(b + 3, nbm - 1)];
-          if (ok) {
-            const u32 w0 = wp[(u64)s0 * ix.bm_stride], w1 = wp[(u64)s1 * ix.bm_stride], w2 = wp[(u64)s2 * ix.bm_stride], w3 = wp[(u64)s3 * ix.bm_stride];
-            ok = (w0 & w1 & w2 & w3 & bit) != 0u;
-          }
+      for (u32 c0 = 0; c0 < cnt; c0 += 256) {
+        u32 x[4]; bool ok[4]; const u32* wp[4]; u32 bit[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 c = c0 + 64u * q + lane;
+          ok[q] = c < cnt;
+          x[q] = ok[q] ? s_cand[c] : 0u;
+          wp[q] = ix.bm_words + (x[q] >> 5); bit[q] = 1u << (x[q] & 31);
         }
-        const u64 bmk = __ballot(ok);
-        wave_lds_sync();
-        if (ok) s_cand[kept + __popcll(bmk & ((1ULL << lane) - 1ULL))] = x;
-        kept += (u32)__popcll(bmk);
+        for (u32 b = 0; b < nbm && __ballot(ok[0] || ok[1] || ok[2] || ok[3]) != 0ULL; b += 4) {
+          const u64 o0 = (u64)s_tile[b] * ix.bm_stride, o1 = (u64)s_tile[min(b + 1, nbm - 1)] * ix.bm_stride;
+          const u64 o2 = (u64)s_tile[min(b + 2, nbm - 1)] * ix.bm_stride, o3 = (u64)s_tile[min(b + 3, nbm - 1)] * ix.bm_stride;
+          u32 w[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) w[q] = ok[q] ? (wp[q][o0] & wp[q][o1] & wp[q][o2] & wp[q][o3]) : 0u;
+#pragma unroll
+          for (int q = 0; q < 4; q++) ok[q] = ok[q] && (w[q] & bit[q]) != 0u;
+        }
+        wave_lds_sync();   // (every lane has read its four survivors: the compaction below writes at or below them)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u64 bmk = __ballot(ok[q]);
+          if (ok[q]) s_cand[kept + __popcll(bmk & ((1ULL << lane) - 1ULL))] = x[q];
+          kept += (u32)__popcll(bmk);
+        }
         wave_lds_sync();
       }
       cnt = kept;
