@@ -994,6 +994,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (a bench policy, not the library's: a rank that never comes back from ncclCommInitRank ends its process after this long instead of holding
+        # the launcher until its own time limit; the library arms the watchdog only when the variable is set)
+        os.environ.setdefault("KAMD_COMM_INIT_TIMEOUT_S", "300")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

@@ -482,15 +482,37 @@ __global__ __launch_bounds__(RES_BLOCK) void k_resolve(DevIndex ix, const u32* _
   }
   // classify the candidates of the smallest set: membership in every other set (binary search) and the on-list mask;
   // `mask_of(c0)` is recomputed in the write pass except for the first 16 candidates
+  // The sets of the tuple sixteen at a time: lane j of the group fetches set j's offset, size and bitmap slot (one round of loads for sixteen sets
+  // -- a lane walking the sets one after the other paid four dependent latencies per set: 16 ms per 30 M stress pairs, whose tuples have dozens of
+  // sets), then every candidate lane tests all of the batch's bitmap sets at once and searches the batch's short lists one after the other.
   auto chunk_mask = [&](u32 c0, u32* x_out) -> u32 {
     const u32 c = c0 + sub;
     bool ok = c < nb;
     const u32 x = ok ? base[c] : 0;
     if (ok) ok = onlisted(ix.onlist_bits, x);
-    for (u32 j = 0; j < m; j++) {
-      if (j == best) continue;
-      const u32 e = es[j];
-      if (ok) { const u64 o = ix.ec_off[e]; ok = set_has(ix, e, o, (u32)(ix.ec_off[e + 1] - o), x); }   // (a bit test when the set has a bitmap)
+    for (u32 j0 = 0; j0 < m; j0 += RES_LANES) {
+      if (((__ballot(ok) >> gsh) & 0xFFFFu) == 0u) break;   // (no candidate of the group is left)
+      const u32 jj = j0 + sub;
+      const bool vj = jj < m && jj != best;
+      u64 o = 0; u32 sz = 0, slot = BM_NONE;
+      if (vj) { const u32 e = es[jj]; o = ix.ec_off[e]; sz = (u32)(ix.ec_off[e + 1] - o); if (sz > ix.bm_min) slot = ix.ec_bm_slot[e]; }
+      u32 w[RES_LANES];
+#pragma unroll
+      for (int t = 0; t < RES_LANES; t++) {
+        const u32 st = __shfl(slot, t, RES_LANES);
+        w[t] = (ok && st != BM_NONE) ? ix.bm_words[(u64)st * ix.bm_stride + (x >> 5)] : 0xFFFFFFFFu;
+      }
+      u32 all = 0xFFFFFFFFu;
+#pragma unroll
+      for (int t = 0; t < RES_LANES; t++) all &= w[t];
+      ok = ok && ((all >> (x & 31)) & 1u);
+#pragma unroll
+      for (int t = 0; t < RES_LANES; t++) {
+        const u32 st = __shfl(slot, t, RES_LANES), zt = __shfl(sz, t, RES_LANES);
+        const u64 ot = __shfl(o, t, RES_LANES);
+        const bool vt = __shfl((int)vj, t, RES_LANES) != 0;
+        if (vt && st == BM_NONE && ok) ok = set_contains(ix.ec_ids + ot, zt, x);
+      }
     }
     *x_out = x;
     return (u32)((__ballot(ok) >> gsh) & 0xFFFFu);
