@@ -188,6 +188,14 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   delete c;
 }
 
+namespace {
+// bitmap of large set which[blockIdx.x]: one bit per member (kamd_dev.h DevIndex::bm_words)
+__global__ void k_bm_fill(const u64* __restrict__ ec_off, const u32* __restrict__ ec_ids, const u32* __restrict__ which, u32 stride, u32* words) {
+  const u32 e = which[blockIdx.x];
+  u32* w = words + (u64)blockIdx.x * stride;
+  for (u64 j = ec_off[e] + threadIdx.x; j < ec_off[e + 1]; j += blockDim.x) { const u32 x = ec_ids[j]; atomicOr(&w[x >> 5], 1u << (x & 31)); }
+}
+}  // namespace
 extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
   if (!c || !hix) return kamd::fail(-1, "kamd_index_upload: null argument");
   HIPC(hipSetDevice(c->device));
@@ -224,15 +232,23 @@ extern "C" int kamd_index_upload(kamd_ctx* c, const kamd_index* hix) {
     d.bm_stride = stride; d.bm_min = big.empty() ? 0xFFFFFFFFu : BM_MIN_MEMBERS;
     d.ec_bm_slot = nullptr; d.bm_words = nullptr;
     if (!big.empty()) {
-      std::vector<u32> slot(v.n_ecs, BM_NONE), words(big.size() * (size_t)stride, 0u);
-      for (size_t s = 0; s < big.size(); s++) {
-        const u32 e = big[s].second;
-        slot[e] = (u32)s;
-        u32* w = words.data() + s * (size_t)stride;
-        for (u64 j = v.ec_off[e]; j < v.ec_off[e + 1]; j++) { const u32 x = v.ec_ids[j]; w[x >> 5] |= 1u << (x & 31); }
-      }
+      // (the bits are set on the device from the sets already uploaded: a stress-like index has 8 000 such sets, 200 MB of bitmaps -- nothing of that
+      // is built on the host or crosses the link)
+      std::vector<u32> slot(v.n_ecs, BM_NONE), which(big.size());
+      for (size_t s = 0; s < big.size(); s++) { slot[big[s].second] = (u32)s; which[s] = big[s].second; }
+      const u32* d_which = nullptr; const u32* d_words = nullptr;
       if (int rc = upload(c, slot.data(), slot.size(), &d.ec_bm_slot)) return rc;
-      if (int rc = upload(c, words.data(), words.size(), &d.bm_words)) return rc;
+      if (int rc = upload(c, which.data(), which.size(), &d_which)) return rc;
+      {
+        void* p = nullptr;
+        HIPC(hipMalloc(&p, big.size() * (size_t)stride * 4));
+        c->index_allocs.push_back(p);
+        HIPC(hipMemsetAsync(p, 0, big.size() * (size_t)stride * 4, c->stream));
+        d_words = (const u32*)p;
+      }
+      hipLaunchKernelGGL(k_bm_fill, dim3((unsigned)big.size()), dim3(256), 0, c->stream, d.ec_off, d.ec_ids, d_which, stride, const_cast<u32*>(d_words));
+      HIPC(hipGetLastError());
+      d.bm_words = d_words;
       HIPC(hipStreamSynchronize(c->stream));   // (stack-owned staging buffers)
     }
     c->n_set_bitmaps = (u32)big.size();
