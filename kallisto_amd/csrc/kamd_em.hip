@@ -2338,7 +2338,7 @@ __global__ void k_gi_scatter(u64 T, const u32* __restrict__ mflag, const u64* __
 // blocks of g (columns pass) small (measured at 8 M stress pairs, columns pass: 32 us with 2 048-value blocks of a, 22 with 8 192).
 constexpr int GB_SHIFT_A = 13, GB_SHIFT_G = 11;             // blocks of a: 8 192 values (64 KB of LDS); blocks of g: 2 048 rows
 constexpr int GB_B = 1 << GB_SHIFT_A;                       // (the larger of the two: LDS is sized for it, and index GB_B is the zero slot the padding reads)
-constexpr int GB_PF = 4;                                   // chunks of a wavefront requested together
+constexpr int GB_PF = 4;                                   // chunks of a wavefront requested together (8 was measured no faster: 15.9 against 14.7 us for the rows pass at 30 M stress pairs)
 constexpr int GB_K = 8, GB_CH = 64 * GB_K;                  // entries per lane and chunk (one 16-byte load), entries per chunk
 constexpr int GB_WAVES = 16, GB_THREADS = 64 * GB_WAVES;   // one workgroup per compute unit: 64 KB of block + 16 x 4 KB of piece sums
 constexpr uint16_t GB_END = 0x8000u, GB_PAD = (uint16_t)GB_B;   // entry = in-block index | GB_END on the last entry of a piece; padding reads the zero slot
@@ -2372,13 +2372,13 @@ __global__ __launch_bounds__(GB_THREADS) void k_gb_pass(GbArgs A, const double* 
   // the wavefront's first GB_PF chunks (all of them, at the sizes of a transcriptome) are on their way while the block is loaded: loading the
   // block is up to three dependent memory latencies from a cold L2, and what follows it is then LDS work only
   u32 c = c0 + wv;
-  uint4 raw[GB_PF]; u32 lw[GB_PF], sb[GB_PF], ps[GB_PF];
+  uint4 raw[GB_PF]; u32 sb[GB_PF], ps[GB_PF];
   auto request = [&](u32 cf) {
 #pragma unroll
     for (int i = 0; i < GB_PF; i++) {
       const u32 cc = cf + (u32)i * GB_WAVES;
-      raw[i] = make_uint4(0, 0, 0, 0); lw[i] = 0; sb[i] = 0;
-      if (cc < c1) { raw[i] = reinterpret_cast<const uint4*>(S.stream + (u64)cc * GB_CH)[lane]; lw[i] = S.lane_word[(u64)cc * 64 + lane]; sb[i] = S.seg_base[cc]; }
+      raw[i] = make_uint4(0, 0, 0, 0); sb[i] = 0;
+      if (cc < c1) { raw[i] = reinterpret_cast<const uint4*>(S.stream + (u64)cc * GB_CH)[lane]; sb[i] = S.seg_base[cc]; }
     }
 #pragma unroll
     for (int i = 0; i < GB_PF; i++) ps[i] = cf + (u32)i * GB_WAVES < c1 ? S.piece_slot[sb[i] + lane] : 0u;   // (the slots of a chunk's first 64 pieces; the array is padded by 64 entries)
@@ -2443,12 +2443,12 @@ __global__ __launch_bounds__(GB_THREADS) void k_gb_pass(GbArgs A, const double* 
     for (u32 q = threadIdx.x; q < n_long; q += GB_THREADS) {
       const u32 i = s_ln[1 + 3 * q], f = s_ln[2 + 3 * q], np = s_ln[3 + 3 * q];
       double S = 0.0;
-      for (u32 j0 = 0; j0 < np; j0 += 32) {
-        double x[32];
+      for (u32 j0 = 0; j0 < np; j0 += 16) {
+        double x[16];
 #pragma unroll
-        for (int j = 0; j < 32; j++) x[j] = j0 + j < np ? Rw.part[f + j0 + j] : 0.0;
+        for (int j = 0; j < 16; j++) x[j] = j0 + j < np ? Rw.part[f + j0 + j] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 32; j++) if (j0 + j < np) S += x[j];
+        for (int j = 0; j < 16; j++) if (j0 + j < np) S += x[j];
       }
       s_val[i] = g_of(s_lw[q], S);
     }
@@ -2467,9 +2467,15 @@ __global__ __launch_bounds__(GB_THREADS) void k_gb_pass(GbArgs A, const double* 
       double v[GB_K];
 #pragma unroll
       for (int k = 0; k < GB_K; k++) v[k] = s_val[e[k] & 0x3FFFu];
-      const u32 ebase = lw[i] & 0xFFFu, ne = (lw[i] >> 12) & 0x3Fu;
-      const int reach = (int)(lw[i] >> 18);
-      const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)(ebase + ne), 63);
+      // pieces that end in the lanes below / in this lane, and the distance to the nearest lane at or below that holds an end: from the END flags (a
+      // stored word per lane and chunk -- PmSide::lane_word -- was a quarter of the bytes a launch pulls through the cold L2s)
+      const u32 ne = ((rw.x >> 15) & 1u) + (rw.x >> 31) + ((rw.y >> 15) & 1u) + (rw.y >> 31) + ((rw.z >> 15) & 1u) + (rw.z >> 31) + ((rw.w >> 15) & 1u) + (rw.w >> 31);
+      const u32 incl = pm_scan_incl(ne);
+      const u32 ebase = incl - ne;
+      const u64 heads = __ballot(ne > 0);
+      const u64 below = heads & ((2ULL << lane) - 1ULL);
+      const int reach = below ? lane - (63 - __clzll((long long)below)) : lane + 1;
+      const u32 n_ends = (u32)__builtin_amdgcn_readlane((int)incl, 63);
       double run = 0.0;
       double* slot = sums + ebase;
 #pragma unroll
