@@ -2404,7 +2404,6 @@ __global__ __launch_bounds__(GB_THREADS) void k_gb_pass(GbArgs A, const double* 
     u32* s_ln = reinterpret_cast<u32*>(s_sum);          // [0] = rows listed; then per listed row {index in the block, first slot, slots} ...
     u64* s_lw = reinterpret_cast<u64*>(s_sum) + 4096;   // ... and its count word (the piece sums' region, 64 KB, is idle while the block is loaded)
     constexpr u32 LIST_CAP = 2048;                       // (rows beyond that are summed by their own thread, slot after slot)
-    if (threadIdx.x == 0) s_ln[0] = 0u;
     u32 s0[PER], s1[PER]; u64 w[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -2412,32 +2411,37 @@ __global__ __launch_bounds__(GB_THREADS) void k_gb_pass(GbArgs A, const double* 
       const bool in = r < A.R;
       s0[k] = in ? Rw.slot_base[r] : 0u; s1[k] = in ? Rw.slot_base[r + 1] : 0u; w[k] = in ? A.cw[r] : 0ULL;
     }
-    double p[PER][4];
+    // (ONE load per row here: the first slot.  Rows of several pieces -- one in six -- go to the list: a predicated load per further slot and row
+    // made every wavefront request the same lines four times over; the columns pass issued four times the L2 requests of the rows pass,
+    // profiles/r06_gb_counters.txt)
+    double p0[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) p0[k] = s1[k] > s0[k] ? Rw.part[s0[k]] : 0.0;
+    // the rows of several pieces are listed IN ROW ORDER (ballot + per-wavefront counts, no atomic cursor): neighbours in the list are neighbours
+    // in the partial-sum array, so the list's loads fall into few lines
+    u32* s_wc = s_ln + 1 + 3 * LIST_CAP;   // [PER * GB_WAVES] listed rows per (k, wavefront)
+    u64 mm[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) p[k][i] = s0[k] + i < s1[k] ? Rw.part[s0[k] + i] : 0.0;
+      mm[k] = __ballot(s1[k] - s0[k] > 1u);
+      if (lane == 0) s_wc[k * GB_WAVES + wv] = (u32)__popcll(mm[k]);
     }
-    __syncthreads();   // (the list's counter)
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
       const u32 np = s1[k] - s0[k], i = (threadIdx.x + (u32)k * GB_THREADS + rot) & (BV - 1);
-      u32 at = LIST_CAP;
-      if (np > 4u) at = atomicAdd(&s_ln[0], 1u);
-      if (np > 4u && at < LIST_CAP) {
-        s_ln[1 + 3 * at] = i; s_ln[2 + 3 * at] = s0[k]; s_ln[3 + 3 * at] = np; s_lw[at] = w[k];
-      } else if (np > 4u) {
-        double S = p[k][0] + p[k][1]; S += p[k][2]; S += p[k][3];
-        for (u32 q = s0[k] + 4; q < s1[k]; q++) S += Rw.part[q];
-        s_val[i] = g_of(w[k], S);
-      } else {
-        double S = p[k][0];
-        if (np > 1u) S += p[k][1];
-        if (np > 2u) S += p[k][2];
-        if (np > 3u) S += p[k][3];
-        s_val[i] = np ? g_of(w[k], S) : 0.0;
-      }
+      if (np > 1u) {
+        u32 at = (u32)__popcll(mm[k] & ((1ULL << lane) - 1ULL));
+        for (u32 q = 0; q < (u32)k * GB_WAVES + wv; q++) at += s_wc[q];
+        if (at < LIST_CAP) { s_ln[1 + 3 * at] = i; s_ln[2 + 3 * at] = s0[k]; s_ln[3 + 3 * at] = np; s_lw[at] = w[k]; }
+        else {
+          double S = p0[k];
+          for (u32 q = s0[k] + 1; q < s1[k]; q++) S += Rw.part[q];
+          s_val[i] = g_of(w[k], S);
+        }
+      } else s_val[i] = np ? g_of(w[k], p0[k]) : 0.0;
     }
+    if (threadIdx.x == 0) { u32 tot = 0; for (u32 q = 0; q < (u32)PER * GB_WAVES; q++) tot += s_wc[q]; s_ln[0] = tot; }
     __syncthreads();
     const u32 n_long = min(s_ln[0], LIST_CAP);
     for (u32 q = threadIdx.x; q < n_long; q += GB_THREADS) {
