@@ -67,6 +67,8 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
   const uint64_t sw = (uint64_t)(max_len + 15) / 16 + 1, rec = kamd_packed_record_words(max_len);
   const Table t = emu_table(v, !paired, (use_stepper & 2) != 0);   // bit 1 of use_stepper: --no-jump
   const bool use_text = (use_stepper & 4) != 0;                     // bit 2: the unitig text in front of the table (kernel A v3)
+  const bool append = (use_stepper & 8) != 0;                       // bit 3: the append-only class list of kernel A's second pass (round 6): duplicates
+                                                                    // stay in the list unless they are neighbours, uecs_to_ecs removes them
   use_stepper &= 1;
   std::vector<uint8_t> nonempty(v->n_ecs);
   for (uint64_t e = 0; e < v->n_ecs; e++) nonempty[e] = v->ec_off[e + 1] > v->ec_off[e];
@@ -85,6 +87,7 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
       mapped = pair_is_mapped(m[0], m[1]);
     } else {
       UecList ul{uecbuf, 1024, 0, false};
+      ul.append = append;
       MateFirst mf[2] = {{0, 0, -1, false}, {0, 0, -1, false}};
       for (int mate = 0; mate < (paired ? 2 : 1); mate++) {
         uint64_t r = paired ? 2 * i + mate : i;
@@ -117,6 +120,7 @@ extern "C" int64_t emu_tuples(const kamd_index_view* v, const uint32_t* words, c
         }
       }
       bool ne0, ne1;
+      if (append) { probes[2] += (uint64_t)ul.n; if (ul.overflow) return -2; }
       uecs_to_ecs(ul.e, ul.n, v->uec_ec, nonempty.data(), ecs, &ne0, &ne1);
       MateInfo a, b; a.n_hits = mf[0].n_hits; a.n_nonempty = ne0; b.n_hits = mf[1].n_hits; b.n_nonempty = ne1;
       mapped = pair_is_mapped(a, b);

@@ -98,12 +98,13 @@ def tuples(ix: EmuIndex, words, l16, n_items, paired, max_len, use_stepper, stri
     L = lib()
     L.emu_tuples.restype = C.c_int64
     out = np.zeros(n_items * stride, np.uint32)
-    pr = (C.c_uint64 * 2)(0, 0)   # [0] dbg.find calls, [1] of them answered from the unitig text (use_stepper & 4)
+    pr = (C.c_uint64 * 3)(0, 0, 0)   # [0] dbg.find calls, [1] of them answered from the unitig text (use_stepper & 4), [2] appended classes (use_stepper & 8)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     r = L.emu_tuples(C.byref(ix.view), p(words), p(l16), C.c_uint64(n_items), int(paired), C.c_int32(max_len), int(use_stepper),
                      p(out), C.c_uint64(stride), pr)
     assert r == 0
     tuples.last_text_hits = int(pr[1])
+    tuples.last_appended = int(pr[2])
     return out.reshape(n_items, stride), int(pr[0])
 
 

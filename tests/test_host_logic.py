@@ -214,6 +214,11 @@ def test_resumable_state_machine_equals_match(case, no_jump, idx):
     assert pt == pa and np.array_equal(a, t)
     if not no_jump and case in ("ref_test_pe", "human_pe", "yeast_se"):
         assert E.tuples.last_text_hits > 0
+    # kernel A's second pass (round 6): the class list append-only -- a class equal to the one appended last merges, anything else is appended,
+    # duplicates that are not neighbours stay until the classes are mapped to sets: same sets, same probes, and never more list entries than probes
+    ap, pp = E.tuples(e, words, l16, len(r1), paired, max_len, 1 | 2 * no_jump | 4 | 8, stride=80)
+    assert pp == pa and np.array_equal(a, ap)
+    assert 0 < E.tuples.last_appended <= pp
     if no_jump and case == "mosaic_pe":
         c, pc = E.tuples(e, words, l16, len(r1), paired, max_len, 0, stride=80)
         assert pa > pc and not np.array_equal(a, c)   # the flag does something on this case
