@@ -131,8 +131,8 @@ const char* kamd_index_target_name(const kamd_index*, uint64_t i);
 
 /* ---- context ---- */
 /* Tuning knobs: which of the equivalent kernels / EM forms run and how they are shaped.  None of them changes a result.
- * kamd_ctx_create sets the defaults (environment variables of the same names in upper case with a KAMD_ prefix, e.g.
- * KAMD_TEXT_VERIFY, KAMD_EM_FORM, are read once there, for experiments); kamd_ctx_tune overrides them for the following calls.
+ * kamd_ctx_create sets the defaults (one environment variable, KAMD_TUNE="field=value,field=value" over the field names below, is
+ * read once there, for experiments: INTEGRATION.md section 8); kamd_ctx_tune overrides them for the following calls.
  * 0 in a field = keep the current value; on/off fields use 1 = on, 2 = off. */
 typedef struct {
   int32_t text_verify;         /* kernel A: jump / middle / back-off windows are compared with the unitig text first (default on) */
