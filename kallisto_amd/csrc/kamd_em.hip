@@ -2530,15 +2530,29 @@ __global__ __launch_bounds__(BLOCK) void k_gb_finish(GbArgs A, const double* al_
 }
 // ---- plan of the blocked form (once per matrix) ----
 // entries of segment s: ids[off[s] .. off[s + 1]) (index | PM_END); 8 lanes per segment
+// (a lane takes a contiguous eighth of the segment and adds once per change of block: a long row, whose entries are sorted, is a handful of
+// atomics instead of one per entry on the same few counters)
 __global__ void k_gb_count(const u64* __restrict__ off, const u32* __restrict__ ids, u64 n_seg, int shift, u32* cnt) {
   const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / 8;
-  const int sub = threadIdx.x & 7;
+  const u64 sub = threadIdx.x & 7;
   if (s >= n_seg) return;
-  for (u64 j = off[s] + sub; j < off[s + 1]; j += 8) atomicAdd(&cnt[(u64)((ids[j] & ~PM_END) >> shift) * n_seg + s], 1u);
+  const u64 a = off[s], len = off[s + 1] - a;
+  const u64 j0 = a + len * sub / 8, j1 = a + len * (sub + 1) / 8;
+  u32 run = 0, cur = 0xFFFFFFFFu;
+  for (u64 j = j0; j < j1; j++) {
+    const u32 b = (ids[j] & ~PM_END) >> shift;
+    if (b != cur) { if (run) atomicAdd(&cnt[(u64)cur * n_seg + s], run); cur = b; run = 0; }
+    ++run;
+  }
+  if (run) atomicAdd(&cnt[(u64)cur * n_seg + s], run);
 }
 // ORDERED: the entries of a segment come in increasing index order (rows: the transcripts of a class are sorted), so the place of an entry
 // in its run follows from its place in the segment -- the run is born sorted; else the places are handed out by an atomic and the run is
 // sorted afterwards (columns: the streamed plan's column entries lie in the order of its own atomics); info[pos] = the run of the entry there
+__global__ void k_gb_block_starts(const u64* __restrict__ sub_off, u64 n_seg, u64 n_blk, u64* out) {   // where every block's runs begin (out[n_blk]: the total)
+  const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= n_blk) out[b] = sub_off[b * n_seg];
+}
 template <bool ORDERED>
 __global__ void k_gb_scatter(const u64* __restrict__ off, const u32* __restrict__ ids, u64 n_seg, const u32* __restrict__ cnt, const u64* __restrict__ sub_off,
                              const u64* __restrict__ blk_shift, int shift, u32* fill, uint16_t* stream, u32* info) {
@@ -2707,7 +2721,8 @@ int gb_setup_side(kamd_ctx* c, const u64* off, const u32* ids, u64 n_seg, u64 n_
   hipLaunchKernelGGL(k_gb_count, dim3(grid_for(n_seg * 8, BLOCK)), dim3(BLOCK), 0, c->stream, off, ids, n_seg, shift, cnt);
   if (int rc = exclusive_scan(c, cnt, n_keys, sub_off, sub_off + n_keys)) return rc;
   std::vector<u64> start(n_blk + 1);
-  for (u64 b = 0; b <= n_blk; b++) HIPC(hipMemcpyAsync(&start[b], sub_off + b * n_seg, 8, hipMemcpyDeviceToHost, c->stream));   // (b == n_blk: the total)
+  hipLaunchKernelGGL(k_gb_block_starts, dim3(grid_for(n_blk + 1, BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)sub_off, n_seg, n_blk, slot_scan);   // (slot_scan: scratch until the pieces are counted)
+  HIPC(hipMemcpyAsync(start.data(), slot_scan, (n_blk + 1) * 8, hipMemcpyDeviceToHost, c->stream));   // (entry n_blk: the total)
   HIPC(hipStreamSynchronize(c->stream));
   std::vector<u64> shift_h(n_blk), chunk0(n_blk + 1, 0);
   for (u64 b = 0; b < n_blk; b++) {
