@@ -222,6 +222,8 @@ KAMD_HD BucketLine load_bucket(const uint64_t* slots, uint64_t b) {
   BucketLine L;
 #if defined(__HIP_DEVICE_COMPILE__)
   // four 16-byte loads of one 64-byte line, issued back to back
+  // (non-temporal loads of the line were measured: 14.8 against 9.0-9.5 ms for kernel A on config #3 -- the four 16-byte loads of a line no longer
+  // merge; round 6)
   const kamd_u64x2 s0 = ((const kamd_u64x2*)bp)[0];
   const kamd_u64x2 s1 = ((const kamd_u64x2*)bp)[1];
   const kamd_u64x2 s2 = ((const kamd_u64x2*)bp)[2];
