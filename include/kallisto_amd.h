@@ -405,7 +405,9 @@ int kamd_ec_set_counts(kamd_ctx*, const uint32_t* counts);
 
 /* ---- S3: EM ---- */
 /* Runs EMAlgorithm(counts, ...).run(n_iter, min_rounds) (src/EMAlgorithm.h:26-48,95-223) on the finalized EC result
- * (d_ec_off == NULL) or on a caller-provided device CSR.  d_weight_counts: the counts the weights w = count/eff_len are
+ * (d_ec_off == NULL) or on a caller-provided device CSR in the form kamd_ec_finalize emits: the transcript ids of a class ascending and
+ * distinct, no two classes with the same transcripts (kamd_ec_upload checks a host CSR for exactly that; a device CSR is not checked).
+ * d_weight_counts: the counts the weights w = count/eff_len are
  * computed from (tc_.counts; NULL = d_counts -- they only differ in bootstraps).  eff_lens: host [n_targets].
  * Outputs (host): alpha, alpha_before_zeroes (nullable) [n_targets], rounds ("ran for i rounds"). */
 int kamd_em_run(kamd_ctx*, const uint64_t* d_ec_off, const uint32_t* d_ec_ids, const uint32_t* d_counts,
