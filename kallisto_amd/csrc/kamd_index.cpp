@@ -481,18 +481,32 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
       return 0;
     }
   }
-  std::vector<uint8_t> buf;
+  // the file as a read-only mapping (a copy into a zero-filled vector was 0.1-0.15 s of the 0.8 s for a human-sized index); a file that cannot
+  // be mapped (a pipe, a file system without mmap) is read
+  struct FileBytes {
+    const uint8_t* p = nullptr; size_t n = 0; bool mapped = false; std::vector<uint8_t> copy;
+    ~FileBytes() { if (mapped && p) munmap(const_cast<uint8_t*>(p), n); }
+  } buf;
   {
-    std::ifstream in(path, std::ios::binary | std::ios::ate);
-    if (!in) return kamd::fail(-2, std::string("index input file could not be opened: ") + path);
-    std::streamsize sz = in.tellg();
-    in.seekg(0);
-    buf.resize((size_t)sz);
-    if (!in.read((char*)buf.data(), sz)) return kamd::fail(-2, "index: short read");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return kamd::fail(-2, std::string("index input file could not be opened: ") + path);
+    const off_t sz = lseek(fd, 0, SEEK_END);
+    void* m = sz > 0 ? mmap(nullptr, (size_t)sz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0) : MAP_FAILED;
+    if (m != MAP_FAILED) { buf.p = (const uint8_t*)m; buf.n = (size_t)sz; buf.mapped = true; (void)madvise(m, (size_t)sz, MADV_SEQUENTIAL); }
+    close(fd);
+    if (!buf.mapped) {
+      std::ifstream in(path, std::ios::binary | std::ios::ate);
+      if (!in) return kamd::fail(-2, std::string("index input file could not be opened: ") + path);
+      std::streamsize rsz = in.tellg();
+      in.seekg(0);
+      buf.copy.resize((size_t)rsz);
+      if (rsz > 0 && !in.read((char*)buf.copy.data(), rsz)) return kamd::fail(-2, "index: short read");
+      buf.p = buf.copy.data(); buf.n = buf.copy.size();
+    }
   }
-  Cursor c{buf.data(), buf.size()};
+  Cursor c{buf.p, buf.n};
   std::unique_ptr<kamd_index> ix(new kamd_index);
-  ix->src_size = buf.size(); ix->src_hash = source_hash(buf.data(), buf.size());
+  ix->src_size = buf.n; ix->src_hash = source_hash(buf.p, buf.n);
   // KAMD_INDEX_TIMING=1: seconds per phase on stderr
   const bool timing = getenv("KAMD_INDEX_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
