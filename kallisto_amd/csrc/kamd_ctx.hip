@@ -31,7 +31,7 @@ void tuning_merge(kamd_tuning* t, const kamd_tuning& n) {
   if (n.align_chunks != 0) t->align_chunks = n.align_chunks < 0 ? -1 : std::min(n.align_chunks, 64);
   if (n.em_reg_slices == 1 || n.em_reg_slices == 2) t->em_reg_slices = n.em_reg_slices;
   if (n.em_hybrid == 1 || n.em_hybrid == 2) t->em_hybrid = n.em_hybrid;
-  if (n.overflow_second_pass == 1 || n.overflow_second_pass == 2) t->overflow_second_pass = n.overflow_second_pass;
+  if (n.overflow_second_pass >= 1 && n.overflow_second_pass <= 3) t->overflow_second_pass = n.overflow_second_pass;
   if (n.em_blocked == 1 || n.em_blocked == 2) t->em_blocked = n.em_blocked;
   if (n.em_giant_nnz != 0) t->em_giant_nnz = n.em_giant_nnz < 0 ? -1 : std::max(n.em_giant_nnz, 8);
 }
@@ -50,7 +50,7 @@ void tuning_from_env(kamd_tuning* t) {
     {"em_fin_blocks", &kamd_tuning::em_fin_blocks, false}, {"em_local_block", &kamd_tuning::em_local_block, false}, {"em_group_div", &kamd_tuning::em_group_div, false},
     {"em_split_len", &kamd_tuning::em_split_len, false}, {"dedup_form", &kamd_tuning::dedup_form, false}, {"align_chunks", &kamd_tuning::align_chunks, false},
     {"em_small_nnz", &kamd_tuning::em_small_nnz, false}, {"em_reg_slices", &kamd_tuning::em_reg_slices, true}, {"em_hybrid", &kamd_tuning::em_hybrid, true},
-    {"overflow_second_pass", &kamd_tuning::overflow_second_pass, true}, {"em_giant_nnz", &kamd_tuning::em_giant_nnz, false}, {"em_blocked", &kamd_tuning::em_blocked, true}};
+    {"overflow_second_pass", &kamd_tuning::overflow_second_pass, false}, {"em_giant_nnz", &kamd_tuning::em_giant_nnz, false}, {"em_blocked", &kamd_tuning::em_blocked, true}};
   std::string all(e);
   for (size_t pos = 0; pos < all.size();) {
     size_t end = all.find(',', pos);
@@ -66,6 +66,7 @@ void tuning_from_env(kamd_tuning* t) {
       known = true;
       int32_t v = atoi(val.c_str());
       if (key == "em_form") v = val == "streamed" ? 1 : val == "csr" ? 2 : val == "local" ? 3 : v;
+      if (key == "overflow_second_pass" && v == 0) v = 2;   // (1 = beside the absorption, 3 = after it, 0 / 2 = off)
       n.*(f.p) = f.onoff ? (v != 0 ? 1 : 2) : v;
     }
     if (!known) fprintf(stderr, "[kallisto_amd] KAMD_TUNE: unknown field '%s' ignored\n", key.c_str());
@@ -168,6 +169,10 @@ extern "C" void kamd_ctx_destroy(kamd_ctx* c) {
   if (c->ev_mg1) (void)hipEventDestroy(c->ev_mg1);
   if (c->ev_ov0) (void)hipEventDestroy(c->ev_ov0);
   if (c->ev_ov1) (void)hipEventDestroy(c->ev_ov1);
+  if (c->ov_stream) { (void)hipStreamSynchronize(c->ov_stream); (void)hipStreamDestroy(c->ov_stream); }
+  for (hipEvent_t e : {c->ov_ev_in, c->ov_ev_done, c->ov_ev_t0, c->ov_ev_t1}) if (e) (void)hipEventDestroy(e);
+  if (c->ov_pin) (void)hipHostFree(c->ov_pin);
+  c->ov_state.release();
   for (DBuf* b : {&c->hy_sub, &c->hy_a, &c->hy_b, &c->hy_x, &c->hy_maps, &c->hy_gb[0], &c->hy_gb[1], &c->hy_gb[2], &c->hy_gb[3], &c->hy_gb[4], &c->hy_gb[5]}) b->release();
   if (c->fld_stream) { (void)hipStreamSynchronize(c->fld_stream); (void)hipStreamDestroy(c->fld_stream); }
   if (c->fld_ev) (void)hipEventDestroy(c->fld_ev);
@@ -286,6 +291,7 @@ extern "C" int kamd_ec_reset(kamd_ctx* c) {
   HIPC(hipMemsetAsync(c->dense_first.p, 0xFF, std::max<u64>(c->n_ecs, 1) * sizeof(u64), c->stream));
   memset(&c->host_state, 0, sizeof c->host_state);
   c->finalized = false; c->exp_words_done = 0; c->recs_total = 0; c->multi_before = 0; c->last_absorb_ms = 0.f; c->overflow_total = 0; c->overflow_ms = 0.f; c->overflow_second_total = 0;
+  if (c->ov_side_pending) { (void)hipStreamSynchronize(c->ov_stream); c->ov_side_pending = false; }   // (a batch that failed between the side launch and its join)
   if (int rc = tuples_clear(c)) return rc;
   HIPC(hipMemsetAsync(c->stats_a.p, 0, sizeof(DevStatsA), c->stream));
   c->had_overflow_items = false;

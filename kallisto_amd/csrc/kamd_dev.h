@@ -239,6 +239,10 @@ struct kamd_ctx {
   DBuf cand, cand_off, cand_slot, ctable, clist, sizes, block_sums, tup_bound, tup_off, tup_big;
   DBuf raw2, overflow_left, stats_b;   // the second pass over the items whose class list overflowed: its raw records, what overflows again, its counters
   u64 overflow_second_total = 0;       // since kamd_ec_reset: overflow items the second pass took care of
+  // the second pass BESIDE the absorption of the batch's other tuple records (kamd_match.hip, overflow_side_launch): a stream of its own, counters of its
+  // own (a DevState that only its kernels touch: push_state / sync_state move the main one wholesale), two pinned images (what it starts from, what it ended with)
+  DBuf ov_state; DevState* ov_pin = nullptr; hipStream_t ov_stream = nullptr; hipEvent_t ov_ev_in = nullptr, ov_ev_done = nullptr, ov_ev_t0 = nullptr, ov_ev_t1 = nullptr;
+  bool ov_side_pending = false;
   u64 last_fin_big = 0;
   DBuf explicit_items, explicit_items_big, exp_stream, exp_off, exp_scratch, bs_cp, bs_samp, raw, dense_first, exp_key, cand_key, ec_first;
   DBuf ec_off, ec_ids, ec_counts;

@@ -433,13 +433,31 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_classify_long(DevIndex ix, co
   const u64 i0 = ((u64)blockIdx.x * CL_WAVES + w) * CL_ITEMS;
   constexpr u32 DUP = 0xFFFFFFFFu;
   u32 total_words = 0, n_records = 0;
+  // every load of the wavefront's items first (header, appended classes, their sets: three dependent rounds for all CL_ITEMS items together instead of
+  // one after the other per item -- the kernel is a few thousand wavefronts waiting on exactly these)
+  u32 hq[CL_ITEMS], uq[CL_ITEMS][3], eq[CL_ITEMS][3];
+#pragma unroll
+  for (int q = 0; q < CL_ITEMS; q++) hq[q] = i0 + q < n ? raw[(i0 + q) * (u64)stride] : RAW_OVERFLOW;
+#pragma unroll
+  for (int q = 0; q < CL_ITEMS; q++) {
+    const u32 nc = (hq[q] & RAW_OVERFLOW) ? 0u : (hq[q] & 0xFFu);
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const u32 j = (u32)lane + 64u * t; uq[q][t] = j < nc ? raw[(i0 + q) * (u64)stride + 1 + j] : 0u; }
+  }
+#pragma unroll
+  for (int q = 0; q < CL_ITEMS; q++) {
+    const u32 nc = (hq[q] & RAW_OVERFLOW) ? 0u : (hq[q] & 0xFFu);
+#pragma unroll
+    for (int t = 0; t < 3; t++) { const u32 j = (u32)lane + 64u * t; eq[q][t] = j < nc ? ix.uec_ecn[uq[q][t] & 0x3FFFFFFFu] : 0u; }
+  }
+#pragma unroll
   for (int q = 0; q < CL_ITEMS; q++) {
     const u64 i = i0 + q;
     if (lane == 0) s_n_all[w][q] = 0;
     if (i >= n) continue;
     const u64 item = items[i];
     const u32* r = raw + i * (u64)stride;
-    const u32 h = r[0];
+    const u32 h = hq[q];
     if (h & RAW_OVERFLOW) { if (lane == 0) { const u64 k = atomicAdd(&out.st->n_overflow, 1ULL); items_left[k] = item; } continue; }
     const u32 nc = h & 0xFFu;
     // classes -> non-empty sets, compacted into s_in (id | mate flags with --union)
@@ -450,8 +468,8 @@ __global__ __launch_bounds__(64 * CL_WAVES) void k_classify_long(DevIndex ix, co
       const u32 j = (u32)lane + 64u * t;
       u32 v = 0; bool valid = false;
       if (j < nc) {
-        const u32 uec = r[1 + j];
-        const u32 ec = ix.uec_ecn[uec & 0x3FFFFFFFu];
+        const u32 uec = uq[q][t];
+        const u32 ec = eq[q][t];
         valid = (ec & 0x80000000u) != 0;   // the set is non-empty
         v = (ec & kamd::EC_ID_MASK) | (ix.union_mode ? (uec & 0xC0000000u) : 0u);
         ne0 = ne0 || (valid && (uec & 0x40000000u)); ne1 = ne1 || (valid && (uec & 0x80000000u));
@@ -823,6 +841,8 @@ struct WorkStream {
 // it is matched.  On return every item that is neither an overflow item nor one a positional filter changed is accounted for.
 int fld_launch(kamd_ctx* c, const FilterDev& fd, const u32* w, const uint16_t* l, u64 n, int seq_words, int rec_words, hipStream_t s);
 template <bool PAIRED, bool FILTER>
+int overflow_side_launch(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd, AlignOut& out);
+template <bool PAIRED, bool FILTER>
 int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t* d_len, u64 n_items, int seq_words, int rec_words, const FilterDev& fd,
                 AlignOut& out, u64 key_base) {
   const int stride = 2 + V3_LIST_CAP + (FILTER ? 4 : 0);
@@ -880,6 +900,11 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, c->ev2, c->ev3));
     c->last_classify_ms += ms;
+    // (one chunk: every overflow item of the batch is known -- their second pass starts here, beside the absorption; kamd_pseudoalign joins it)
+    if (chunks == 1 && c->host_state.n_overflow && c->tune.overflow_second_pass == 1 && !FILTER && !c->ix.union_mode) {
+      const int sr = overflow_side_launch<PAIRED, FILTER>(c, d_words, d_len, c->host_state.n_overflow, seq_words, rec_words, fd, out);
+      if (sr < 0) return sr;
+    }
     // the chunk's tuple records join the distinct tuples of the run (overflow items have no tuple record yet: see kamd_pseudoalign)
     if (int rc = absorb_tuples(c, c->stream_buf.as<u32>(), c->rec_off.as<u64>() + first, n, c->host_state.stream_words, key_base + first,
                                c->host_state.st_multi - c->multi_before, nullptr, (u32)stride, first)) return rc;
@@ -900,8 +925,11 @@ void launch_overflow(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64
 // their records through k_classify_long.  Returns 0 = done (items whose list overflowed again
 // are in c->overflow_left, their number in host_state.n_overflow), 1 = not applicable (reads too long for the LDS layout: the caller takes the
 // straight-line kernel for all items), < 0 = error.
+// `s`: the stream the two kernels are launched on; `side`: they count into out.st, a DevState of their own that the caller has initialised and will
+// read back itself (overflow_side_launch) -- no host synchronisation here.
 template <bool PAIRED, bool FILTER>
-int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd, const AlignOut& out) {
+int overflow_second_pass(kamd_ctx* c, hipStream_t s, bool side, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd,
+                         const AlignOut& out) {
   constexpr int WAVES = BLOCK / 64;
   constexpr int NM = PAIRED ? 2 : 1;
   constexpr int LC = V3_LIST_CAP_LONG;
@@ -913,15 +941,16 @@ int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len,
   if (int rc = c->overflow_left.ensure(nov * sizeof(u64), 0, c->stream)) return rc;
   if (int rc = c->stats_b.ensure(sizeof(DevStatsA), 0, c->stream)) return rc;
   // (the probes of this pass are not kernel A's of the roofline: counters of their own)
-  HIPC(hipMemsetAsync(c->stats_b.p, 0, sizeof(DevStatsA), c->stream));
+  HIPC(hipMemsetAsync(c->stats_b.p, 0, sizeof(DevStatsA), s));
   // items per wavefront: enough wavefronts for every CU, at least a wavefront's worth of items each
-  const int ipw = (int)std::min<u64>(1024, std::max<u64>(64, nov / ((u64)std::max(1, c->n_cus) * 8)));
+  // (8 / 16 / 32 wavefronts per CU measured alike on config #3 -- 0.15 M items -- and on 1.65 M stress items, 32 ahead by 1 %)
+  const int ipw = (int)std::min<u64>(1024, std::max<u64>(64, nov / ((u64)std::max(1, c->n_cus) * 32)));
   const u64 n_waves = (nov + (u64)ipw - 1) / (u64)ipw;
   u32* raw2 = c->raw2.as<u32>();
 #define KAMD_LAUNCH_V3L2(DLV, TXT, LAY)                                                                                                  \
   do {                                                                                                                                  \
     HIPC(hipFuncSetAttribute((const void*)k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC, true>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, c->stream, c->ix, d_words, d_len, nov, \
+    hipLaunchKernelGGL((k_match_v3<PAIRED, FILTER, DLV, TXT, LAY, LC, true>), dim3(grid_for(n_waves, WAVES)), dim3(BLOCK), lds_bytes, s, c->ix, d_words, d_len, nov, \
                        seq_words, rec_words, ipw, std::min(c->refill_min, 8), raw2, stride2, c->stats_b.as<DevStatsA>(), (const u64*)c->overflow_items.as<u64>()); \
   } while (0)
 #define KAMD_LAUNCH_V32(DLV, TXT)                                                                                                        \
@@ -931,12 +960,64 @@ int overflow_second_pass(kamd_ctx* c, const u32* d_words, const uint16_t* d_len,
   else { if (txt) KAMD_LAUNCH_V32(false, true); else KAMD_LAUNCH_V32(false, false); }
 #undef KAMD_LAUNCH_V32
 #undef KAMD_LAUNCH_V3L2
-  c->host_state.n_overflow = 0;   // k_classify_long counts the items whose list overflowed again
-  if (int rc = push_state(c)) return rc;
-  hipLaunchKernelGGL((k_classify_long<PAIRED, FILTER, LC>), dim3(grid_for(nov, CL_WAVES * CL_ITEMS)), dim3(64 * CL_WAVES), 0, c->stream, c->ix, (const u32*)raw2, stride2,
+  if (!side) {
+    c->host_state.n_overflow = 0;   // k_classify_long counts the items whose list overflowed again
+    if (int rc = push_state(c)) return rc;
+  }
+  hipLaunchKernelGGL((k_classify_long<PAIRED, FILTER, LC>), dim3(grid_for(nov, CL_WAVES * CL_ITEMS)), dim3(64 * CL_WAVES), 0, s, c->ix, (const u32*)raw2, stride2,
                      (const u64*)c->overflow_items.as<u64>(), nov, c->overflow_scratch.as<u32>(), fd, 0ULL, out, c->overflow_left.as<u64>());
   HIPC(hipGetLastError());
-  return sync_state(c);
+  return side ? 0 : sync_state(c);
+}
+// The second pass BESIDE the absorption of the batch's other tuple records (called from align_batch when k_classify has counted the overflow items, before
+// absorb_tuples): the pass is a few wavefronts per CU waiting on long chains of dependent probes (0.8 + 0.5 ms for the 0.15 M such pairs of config #3's
+// 30 M), the absorption is memory-side atomics -- side by side they cost the longer of the two.  Its kernels run on c->ov_stream and count into
+// c->ov_state (stream_words continues the batch's, the rest starts at zero); kamd_pseudoalign joins (overflow_side_join) before it looks at the counters.
+// Not with the positional filters / --union (their cursors and counters stay on the one-stream path).  Returns 1 = not applicable, < 0 = error.
+template <bool PAIRED, bool FILTER>
+int overflow_side_launch(kamd_ctx* c, const u32* d_words, const uint16_t* d_len, u64 nov, int seq_words, int rec_words, const FilterDev& fd, AlignOut& out) {
+  if ((size_t)(BLOCK / 64) * 64 * seq_words * (PAIRED ? 2 : 1) * sizeof(u32) > 96 * 1024) return 1;   // (overflow_second_pass's own test: reads too long)
+  if (!c->ov_stream) {
+    HIPC(hipStreamCreateWithFlags(&c->ov_stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&c->ov_ev_in, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&c->ov_ev_done, hipEventDisableTiming));
+    HIPC(hipEventCreate(&c->ov_ev_t0)); HIPC(hipEventCreate(&c->ov_ev_t1));
+    HIPC(hipHostMalloc((void**)&c->ov_pin, 2 * sizeof(DevState), hipHostMallocDefault));
+  }
+  // every buffer the pass appends to, before the absorption takes its pointers (growing one moves it)
+  const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
+  if (int rc = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc;
+  if (int rc = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc;
+  if (int rc = c->ov_state.ensure(sizeof(DevState), 0, c->stream)) return rc;
+  out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+  memset(&c->ov_pin[0], 0, sizeof(DevState));
+  c->ov_pin[0].stream_words = w;
+  HIPC(hipMemcpyAsync(c->ov_state.p, &c->ov_pin[0], sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+  HIPC(hipEventRecord(c->ov_ev_in, c->stream));
+  HIPC(hipStreamWaitEvent(c->ov_stream, c->ov_ev_in, 0));
+  AlignOut out2 = out;
+  out2.st = (DevState*)c->ov_state.p;
+  HIPC(hipEventRecord(c->ov_ev_t0, c->ov_stream));
+  const int sp = overflow_second_pass<PAIRED, FILTER>(c, c->ov_stream, true, d_words, d_len, nov, seq_words, rec_words, fd, out2);
+  if (sp != 0) return sp;   // (1 cannot happen: tested above)
+  HIPC(hipEventRecord(c->ov_ev_t1, c->ov_stream));
+  HIPC(hipMemcpyAsync(&c->ov_pin[1], c->ov_state.p, sizeof(DevState), hipMemcpyDeviceToHost, c->ov_stream));
+  HIPC(hipEventRecord(c->ov_ev_done, c->ov_stream));
+  c->ov_side_pending = true;
+  return 0;
+}
+// ... and its end: the pass's counters join the context's (host and device); returns the number of items whose list overflowed again
+int overflow_side_join(kamd_ctx* c, u64 nov, u64* n_again) {
+  HIPC(hipEventSynchronize(c->ov_ev_done));
+  c->ov_side_pending = false;
+  const DevState& e = c->ov_pin[1];
+  c->host_state.stream_words = e.stream_words;
+  c->host_state.st_multi += e.st_multi;
+  c->host_state.n_overflow = 0;
+  *n_again = e.n_overflow;
+  float ms = 0.f;
+  HIPC(hipEventElapsedTime(&ms, c->ov_ev_t0, c->ov_ev_t1));
+  c->overflow_ms += ms; c->overflow_total += nov;
+  return push_state(c);
 }
 }  // namespace
 
@@ -993,22 +1074,29 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     // the straight-line kernel's 33-37 for the 1.65 M such pairs of 30 M stress pairs; it was opt-in and is gone.)
     const bool try_second = c->tune.overflow_second_pass != 2;
     const bool need_cursors = filter || c->ix.union_mode;
+    const bool beside = c->ov_side_pending;   // align_batch started the second pass beside the absorption of the batch's other records
     if (!try_second || need_cursors) if (int rc2 = c->overflow_scratch.ensure(nov * 2 * TUPLE_CAP_BIG * sizeof(u32), 0, c->stream)) return rc2;
-    const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
-    if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
-    if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
-    out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+    if (!beside) {
+      const u64 w = c->host_state.stream_words, r = c->host_state.n_recs;
+      if (int rc2 = c->stream_buf.ensure((w + nov * (TUPLE_CAP_BIG + 2)) * sizeof(u32), w * sizeof(u32), c->stream)) return rc2;
+      if (int rc2 = c->rec_off.ensure((r + nov) * sizeof(u64), r * sizeof(u64), c->stream)) return rc2;
+      out.stream = c->stream_buf.as<u32>(); out.rec_off = c->rec_off.as<u64>();
+    }
     const u64 ov_base = 0;   // (record indices of the batch)
     if (!c->ev_ov0) { HIPC(hipEventCreate(&c->ev_ov0)); HIPC(hipEventCreate(&c->ev_ov1)); }
-    HIPC(hipEventRecord(c->ev_ov0, c->stream));
     u64 n_straight = nov;
     const u64* straight_items = nullptr;   // (null: all of overflow_items)
-    if (try_second) {
+    if (beside) {
+      if (int rc2 = overflow_side_join(c, nov, &n_straight)) return rc2;
+      straight_items = c->overflow_left.as<u64>();
+    }
+    HIPC(hipEventRecord(c->ev_ov0, c->stream));
+    if (try_second && !beside) {
       int sp = 1;
-      if (o->paired) sp = filter ? overflow_second_pass<true, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out)
-                                 : overflow_second_pass<true, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
-      else sp = filter ? overflow_second_pass<false, true>(c, d_words, d_len, nov, seq_words, rec_words, fd, out)
-                       : overflow_second_pass<false, false>(c, d_words, d_len, nov, seq_words, rec_words, fd, out);
+      if (o->paired) sp = filter ? overflow_second_pass<true, true>(c, c->stream, false, d_words, d_len, nov, seq_words, rec_words, fd, out)
+                                 : overflow_second_pass<true, false>(c, c->stream, false, d_words, d_len, nov, seq_words, rec_words, fd, out);
+      else sp = filter ? overflow_second_pass<false, true>(c, c->stream, false, d_words, d_len, nov, seq_words, rec_words, fd, out)
+                       : overflow_second_pass<false, false>(c, c->stream, false, d_words, d_len, nov, seq_words, rec_words, fd, out);
       if (sp < 0) return sp;
       if (sp == 0) { n_straight = c->host_state.n_overflow; straight_items = c->overflow_left.as<u64>(); }
     }
@@ -1023,7 +1111,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(c->ev_ov1, c->stream));
     if (int rc2 = sync_state(c)) return rc2;
-    { float ms = 0.f; HIPC(hipEventElapsedTime(&ms, c->ev_ov0, c->ev_ov1)); c->overflow_ms += ms; c->overflow_total += nov; }
+    { float ms = 0.f; HIPC(hipEventElapsedTime(&ms, c->ev_ov0, c->ev_ov1)); c->overflow_ms += ms; if (!beside) c->overflow_total += nov; }
     c->host_state.n_overflow = 0;
     if (int rc2 = push_state(c)) return rc2;
     // their records (rec_off of an overflow item now points at its long record) join the distinct tuples

@@ -61,12 +61,14 @@ def test_quant_matches_reference(case, variant, ka, ctxs):
 
 @pytest.mark.parametrize("case,variant", [("stress_pe", "pe"), ("stress_pe", "pe_rf"), ("stress_pe", "pe_union"), ("stress_pe", "se"), ("mosaic_pe", "pe_nojump"),
                                           ("dlist_pe", "pe_nojump")])
-@pytest.mark.parametrize("path", ["second_pass", "straight"])
+@pytest.mark.parametrize("path", ["second_pass", "second_pass_after", "straight"])
 def test_items_with_long_class_lists(case, variant, path, ka, ctxs, monkeypatch):
     """Items with more than eight distinct (unitig, set) classes -- pairs inside repeat families and poly-A stretches (a fifth of the stress fixture's
     mapped pairs), --no-jump runs -- leave kernel A's first pass unfinished.  Round 6: by default they go through the SAME data-flow matcher once more
     with an append-only class list in global memory (k_match_v3<..., 192, true> over the item list; k_classify_long removes the duplicates); with
-    overflow_second_pass off all of them take the straight-line kernel.  Both must give the reference's classes, and the second pass must have taken items."""
+    overflow_second_pass off all of them take the straight-line kernel.  The second pass runs BESIDE the absorption of the batch's other tuple records (a
+    stream and counters of its own; plain paired / single-end runs) or after it (overflow_second_pass=3, and always with filters / --union).  All must give
+    the reference's classes, and the second pass must have taken items."""
     meta, idx_path, r1, r2 = common.load_case(case)
     o = common.parse_variant(meta["variants"][variant])
     exp = common.load_expected(case, variant)
@@ -74,7 +76,7 @@ def test_items_with_long_class_lists(case, variant, path, ka, ctxs, monkeypatch)
     reads = common.interleave(r1, r2 if o["paired"] else None)
     words, lens, max_len = ctx.pack_reads_host(reads)
     opts = ka.QuantOpts(o["paired"], o["fld"], o["sd"], o["single_overhang"], o["strand"], o["no_jump"], o["union"])
-    ctx.tune(overflow_second_pass=(path == "second_pass"))
+    ctx.tune(overflow_second_pass={"second_pass": 1, "second_pass_after": 3, "straight": 2}[path])
     try:
         ctx.reset()
         res = ka.quant(ctx, opts, [(words, lens, len(r1), max_len)])
@@ -84,7 +86,7 @@ def test_items_with_long_class_lists(case, variant, path, ka, ctxs, monkeypatch)
     assert res.ecs.multiset() == exp["ecs"] and np.array_equal(res.flens, exp["flens"])
     common.assert_abundance_close(res.est_counts, exp["alpha"], "est_counts")
     assert prof["n_overflow_items"] > 0, "the fixture no longer exercises the long-list path"
-    if path == "second_pass":
+    if path != "straight":
         assert prof["n_overflow_second_pass"] > 0.5 * prof["n_overflow_items"], prof
     else:
         assert prof["n_overflow_second_pass"] == 0
