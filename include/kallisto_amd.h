@@ -169,7 +169,9 @@ typedef struct {
                                   both; 2 = off: such a matrix takes the streamed form as a whole (rounds 1-4) */
   int32_t overflow_second_pass; /* items whose class list overflowed kernel A's eight LDS entries (pairs inside repeat families, poly-A stretches, --no-jump
                                   runs): 1 (default) = they go through kernel A's data-flow loop once more with an append-only list of up to 192 classes in
-                                  global memory (k_classify_long removes the duplicates), what overflows again takes the straight-line kernel; 2 = all of
+                                  global memory (k_classify_long removes the duplicates), what overflows again takes the straight-line kernel -- the pass
+                                  runs on a stream of its own beside the absorption of the batch's other tuple records (one launch of kernel A per batch, no
+                                  positional filter, no --union; otherwise after it); 3 = the same pass, always after the absorption; 2 = all of
                                   them take the straight-line kernel k_pseudoalign_overflow (rounds 1-5) */
   int32_t em_giant_nnz;        /* hybrid: a component with more entries than this is "oversized"; -1 (default) = 6000, halved while the
                                   remaining components still do not fit their groups */
