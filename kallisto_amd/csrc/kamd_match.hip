@@ -265,11 +265,23 @@ __global__ __launch_bounds__(BLOCK) void k_match_v3(DevIndex ix, const u32* __re
 // wavefronts x 5 counters was most of kernel A v1's time).  Each item's slot of the stream is rewritten IN PLACE as a
 // tuple record [1, m, e0..] (or [0, ..] when the item is not a tuple), so no stream allocation is needed at all; counts
 // of single-set items go through an LDS cache that absorbs the hot sets before touching the dense vector.
+__device__ __forceinline__ void wave_lds_fence() {   // the wavefront's LDS writes are visible to its own later reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 constexpr int DENSE_CACHE = 2048;
+constexpr int CLS_MAX_STRIDE = 2 + V3_LIST_CAP + 4;   // words of a raw record with the positional filters' four
+// The slots travel through LDS (end of round 6): a wavefront's 64 slots are one contiguous run of 64 x stride words, read and written back with
+// 16-byte accesses (40 lines per wavefront each way).  Before, every thread read and rewrote its own slot word by word -- up to ten 4-byte
+// accesses each way at a stride of 40 bytes, every one of them 40 line requests per wavefront -- and the kernel ran at the memory system's request
+// rate, not its bandwidth.  The item's set list is built in the slot's own words 2 .. 2 + CAP (the raw classes are in registers by then), so the
+// kernel needs no second LDS array; a slot stride of 10 / 14 words is a 2-way bank conflict.  A wavefront synchronises with itself only.
 template <bool PAIRED, bool FILTER, int CAP>   // CAP: class entries of a raw record (12: kernel A v2, 8: v3)
 __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict__ slots, int stride, u64 n_items, u64 slot_base,
                                                     u64 rec_base, u64 key_base, u64 item_base, FilterDev fd, AlignOut out) {
-  __shared__ u32 lds_ecs[BLOCK * CAP];
+  static_assert(2 + CAP + 4 <= CLS_MAX_STRIDE, "slot stride");
+  __shared__ __attribute__((aligned(16))) u32 lds_slots[BLOCK * CLS_MAX_STRIDE];
   __shared__ u32 cache_key[DENSE_CACHE];
   __shared__ u32 cache_cnt[DENSE_CACHE];
   __shared__ u32 cache_min[DENSE_CACHE];  // smallest item index (within this launch) that hit the cached set
@@ -278,13 +290,24 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
   if (threadIdx.x < 3) blk_stats[threadIdx.x] = 0u;
   __syncthreads();
   u32 s_single = 0, s_multi = 0, s_proc = 0;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+  u32* ws = lds_slots + (size_t)wv * 64 * stride;
+  const bool al16 = ((uintptr_t)slots & 15) == 0;   // (a wavefront's run starts at a multiple of 256 x stride bytes)
   for (u64 tile = blockIdx.x; tile * BLOCK < n_items; tile += gridDim.x) {
-    const u64 item = tile * BLOCK + threadIdx.x;
-    if (item >= n_items) continue;
-    kamd::EcList ecs; ecs.e = lds_ecs + threadIdx.x * CAP; ecs.cap = CAP; ecs.n = 0; ecs.overflow = false;
-    kamd::MateInfo m0, m1;
-    m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
-    u32* r = slots + item * (u64)stride;
+    const u64 wave_item0 = tile * BLOCK + (u64)wv * 64;
+    if (wave_item0 >= n_items) continue;   // (wavefront-uniform)
+    const u32 nwords = (u32)std::min<u64>(64, n_items - wave_item0) * (u32)stride;
+    u32* gsl = slots + wave_item0 * (u64)stride;
+    if (al16) {
+      for (u32 k = (u32)lane * 4; k < nwords; k += 256) {
+        if (k + 4 <= nwords) *reinterpret_cast<uint4*>(ws + k) = *reinterpret_cast<const uint4*>(gsl + k);
+        else for (u32 j = k; j < nwords; j++) ws[j] = gsl[j];
+      }
+    } else for (u32 k = (u32)lane; k < nwords; k += 64) ws[k] = gsl[k];
+    wave_lds_fence();
+    const u64 item = wave_item0 + (u64)lane;
+    if (item < n_items) {
+    u32* r = ws + lane * stride;
     const u32 h = r[0];
     const int n = (int)(h & 0xFFu);
     u32 uecs[CAP];
@@ -293,6 +316,13 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     u32 ec[CAP];
 #pragma unroll
     for (int j = 0; j < CAP; j++) ec[j] = j < n ? ix.uec_ecn[uecs[j] & 0x3FFFFFFFu] : 0u;   // independent loads, issued together
+    kamd::EcList ecs; ecs.e = r + 2; ecs.cap = CAP; ecs.n = 0; ecs.overflow = false;   // (the record's own place: [1, m, e0 ..])
+    kamd::MateInfo m0, m1;
+    m0.first_slot = m1.first_slot = 0; m0.first_pos = m1.first_pos = -1; m0.first_strand = m1.first_strand = false;
+    if (FILTER) {   // (words 2 + CAP ..: behind the list)
+      m0.first_slot = r[2 + CAP]; m0.first_pos = (int)(r[3 + CAP] & 0xFFFF); m0.first_strand = (r[3 + CAP] >> 16) & 1u;
+      m1.first_slot = r[4 + CAP]; m1.first_pos = (int)(r[5 + CAP] & 0xFFFF); m1.first_strand = (r[5 + CAP] >> 16) & 1u;
+    }
     bool ne0 = false, ne1 = false;
 #pragma unroll
     for (int j = 0; j < CAP; j++) {
@@ -306,10 +336,6 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
     ecs.overflow = (h & RAW_OVERFLOW) != 0;
     m0.n_hits = (h & RAW_HIT0) ? 1 : 0; m1.n_hits = (h & RAW_HIT1) ? 1 : 0;
     m0.n_nonempty = ne0; m1.n_nonempty = ne1;
-    if (FILTER) {
-      m0.first_slot = r[2 + CAP]; m0.first_pos = (int)(r[3 + CAP] & 0xFFFF); m0.first_strand = (r[3 + CAP] >> 16) & 1u;
-      m1.first_slot = r[4 + CAP]; m1.first_pos = (int)(r[5 + CAP] & 0xFFFF); m1.first_strand = (r[5 + CAP] >> 16) & 1u;
-    }
     // classify: 0 unmapped, 1 single set, 2 tuple, 3 overflow, 4 explicit set (positional filter changed it)
     int kind = 0;
     if (ecs.overflow) kind = 3;
@@ -335,14 +361,20 @@ __global__ __launch_bounds__(BLOCK) void k_classify(DevIndex ix, u32* __restrict
       if (old == 0xFFFFFFFFu || old == e) { atomicAdd(&cache_cnt[hh], 1u); atomicMin(&cache_min[hh], (u32)item); }
       else { atomicAdd(&out.dense_counts[e], 1u); if (out.dense_first) atomicMin(&out.dense_first[e], key_base + item); }
     }
-    if (kind == 2) {
-      ++s_multi;
-      r[1] = (u32)ecs.n;
-      for (int j = 0; j < ecs.n; j++) r[2 + j] = ecs.e[j];
-    }
+    if (kind == 2) { ++s_multi; r[1] = (u32)ecs.n; }   // (the sets are in place)
     r[0] = kind == 2 ? 1u : 0u;  // record count: 0 = not a tuple record (skipped by the de-duplication)
-    out.rec_off[rec_base + item] = slot_base + item * (u64)stride;
-    if (kind == 3) { u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item_base + item; }
+    // (the slot's place is only looked up for the overflow items -- through rec_off until the second pass redirects it to a long record --: every
+    // other record of the batch is found by its item number, absorb_tuples' fixed stride)
+    if (kind == 3) { out.rec_off[rec_base + item] = slot_base + item * (u64)stride; u64 i = atomicAdd(&out.st->n_overflow, 1ULL); out.overflow_items[i] = item_base + item; }
+    }
+    wave_lds_fence();
+    if (al16) {
+      for (u32 k = (u32)lane * 4; k < nwords; k += 256) {
+        if (k + 4 <= nwords) *reinterpret_cast<uint4*>(gsl + k) = *reinterpret_cast<const uint4*>(ws + k);
+        else for (u32 j = k; j < nwords; j++) gsl[j] = ws[j];
+      }
+    } else for (u32 k = (u32)lane; k < nwords; k += 64) gsl[k] = ws[k];
+    wave_lds_fence();   // (the next tile's loads overwrite the run)
   }
   // flush: block-level statistics and the cached single-set counts
   const u64 w_single = wave_sum64((u64)s_single), w_multi = wave_sum64((u64)s_multi), w_proc = wave_sum64((u64)s_proc);
@@ -410,11 +442,6 @@ __global__ __launch_bounds__(64) void k_pseudoalign_overflow(DevIndex ix, const 
 // duplicates among them unless they were neighbours) -> tuple records, with k_pseudoalign_overflow's tail: the item's own record is
 // redirected to a long record appended to the stream.  The de-duplication happens here, in the sorted insertion into the item's set list
 // (LDS).  Items whose list overflowed again (more than CAP appended classes) are listed for the straight-line kernel.
-__device__ __forceinline__ void wave_lds_fence() {   // the wavefront's LDS writes are visible to its own later reads
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 constexpr int CL_WAVES = 4, CL_ITEMS = 8;   // k_classify_long: wavefronts per block, items a wavefront takes one after the other
 template <bool PAIRED, bool FILTER, int CAP>
 __global__ __launch_bounds__(64 * CL_WAVES) void k_classify_long(DevIndex ix, const u32* __restrict__ raw, int stride, const u64* __restrict__ items, u64 n, u32* scratch,
@@ -891,7 +918,8 @@ int align_batch(kamd_ctx* c, WorkStream& ws, const u32* d_words, const uint16_t*
     const u64 first = (u64)k * per, n = std::min(per, n_items - first);
     if (chunks > 1) HIPC(hipStreamWaitEvent(c->stream, c->al_ev_chunk[k], 0));
     HIPC(hipEventRecord(c->ev2, c->stream));
-    const unsigned grid = (unsigned)std::min<u64>(grid_for(n, BLOCK), 256 * 6);
+    // (persistent blocks: as many as are resident at once -- 38 KB of LDS each, four per CU -- so that none starts when the others are done)
+    const unsigned grid = (unsigned)std::min<u64>(grid_for(n, BLOCK), (u64)std::max(1, c->n_cus) * 4);
     hipLaunchKernelGGL((k_classify<PAIRED, FILTER, V3_LIST_CAP>), dim3(grid), dim3(BLOCK), 0, c->stream, c->ix, slots + first * (u64)stride, stride, n,
                        first * (u64)stride, first, key_base + first, first, fd, out);
     HIPC(hipGetLastError());
