@@ -1070,6 +1070,7 @@ extern "C" int kamd_pseudoalign(kamd_ctx* c, const kamd_quant_opts* o, const uin
   if (max_len <= 0 || max_len > 65535) return kamd::fail(-1, "kamd_pseudoalign: max_len must be in [1, 65535]");
   if (n_items == 0) return 0;
   HIPC(hipSetDevice(c->device));
+  if (c->ov_side_pending) { HIPC(hipStreamSynchronize(c->ov_stream)); c->ov_side_pending = false; }   // (left by a call that failed before its join)
   const int seq_words = (max_len + 15) / 16 + 1;
   const int rec_words = (int)kamd_packed_record_words(max_len);
   // positional filters (ProcessReads.cpp:1095-1145): has_mean_fl is set by -l only, and while the reads are processed
