@@ -114,6 +114,8 @@ extern "C" int kamd_ctx_create(int device, void* hip_stream, kamd_ctx** out) {
   kamd_ctx* c = new kamd_ctx;
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
+  // (the launch shapes of k_classify and of kernel A's second pass follow the CU count from the first batch on -- the EM used to look it up, after them)
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256; c->n_cus = v; }
   if (c->state.ensure(sizeof(DevState), 0, c->stream)) { delete c; return -100; }
   memset(&c->host_state, 0, sizeof c->host_state);
   if (push_state(c)) { delete c; return -100; }
