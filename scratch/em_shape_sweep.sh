@@ -1,12 +1,12 @@
 #!/bin/bash
-cd /root/repo; O=gpurun_out/lab; mkdir -p $O
-for v in "8 1024 4" "16 1024 4" "24 1024 4" "32 1024 4" "48 1024 4" "16 512 8" "32 512 8" "16 1024 8" "32 1024 2"; do
+# EM time of config #3 against split length, workgroup size and groups per CU (KAMD_TUNE=em_split_len=..,em_local_block=..,em_group_div=..)
+Q="--no-gencode-leg --no-stress-leg --no-cpu-baseline --full-parity off --no-config2 --bootstraps 0 --steps 6 --warmup 2 --parity-sample 0"
+for v in "16 1024 -1" "16 1024 3" "16 1024 4" "16 512 3" "16 512 4" "8 1024 -1" "32 1024 -1" "16 512 -1" "16 1024 6" "16 512 6"; do
   set -- $v
-  KAMD_EM_SPLIT_LEN=$1 KAMD_EM_LOCAL_BLOCK=$2 KAMD_EM_GROUP_DIV=$3 timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --parity-sample 0 > $O/v.json 2> $O/v.err
-  python - "$v" <<'PY'
-import json,sys
+  KAMD_TUNE=em_split_len=$1,em_local_block=$2,em_group_div=$3 timeout 300 python bench.py $Q --detail-file /tmp/d.json 2>/dev/null | python -c "
+import sys, json
 try:
-    d=json.load(open('/root/repo/gpurun_out/lab/v.json')); print(sys.argv[1], d['breakdown_ms']['em'], d['ms_per_step'], d['roofline_em']['groups'], d['roofline_em']['lds_bytes_per_workgroup'])
-except Exception as e: print(sys.argv[1], 'failed', e)
-PY
+    d = json.loads(sys.stdin.read().strip().splitlines()[-1]); dd = json.load(open('/tmp/d.json')); r = dd.get('roofline_em', {})
+    print('split/block/div $v:', 'em', d['breakdown_ms']['em'], 'step', d['ms_per_step'], 'rounds', d['breakdown_ms']['em_rounds'], 'groups', r.get('groups'), 'lds', r.get('lds_bytes_per_workgroup'), 'plan', dd['counters'].get('em_plan_ms'))
+except Exception as e: print('$v failed', e)"
 done
