@@ -139,14 +139,18 @@ def test_device_packer_on_ragged_reads(ka, ctxs):
     assert torch.equal(hw, words) and torch.equal(hl, l16)
 
 
-def test_batches_and_idempotence(ka, ctxs):
-    """Splitting the reads into batches must not change the EC multiset; re-finalizing must not either."""
-    meta, idx_path, r1, r2 = common.load_case("human_pe")
-    exp = common.load_expected("human_pe", "pe")
-    index, ctx = ctxs("human_pe")
+@pytest.mark.parametrize("case", ["human_pe", "stress_pe"])
+def test_batches_and_idempotence(case, ka, ctxs):
+    """Splitting the reads into batches must not change the EC multiset; re-finalizing must not either.  On the stress fixture every batch but the
+    first has items with long class lists: kernel A's second pass runs beside the absorption of each batch (a stream and counters of its own, joined
+    before the next batch) while the record stream grows from batch to batch."""
+    meta, idx_path, r1, r2 = common.load_case(case)
+    exp = common.load_expected(case, "pe")
+    index, ctx = ctxs(case)
     opts = ka.QuantOpts(1, 0.0, 0.0, 0, 0)
     n = len(r1)
     cuts = [0, 1, 257, 1000, n]
+    ctx.reset()
     for a, b in zip(cuts[:-1], cuts[1:]):
         words, lens, max_len = ctx.pack_reads_host(common.interleave(r1[a:b], r2[a:b]), 100)
         ctx.pseudoalign(opts, words, lens, b - a, max_len)
@@ -155,6 +159,9 @@ def test_batches_and_idempotence(ka, ctxs):
     assert e1.multiset() == exp["ecs"] == e2.multiset()
     st = ctx.stats()
     assert st["n_processed"] == n and st["n_bucket_reads"] + st["n_text_hits"] >= st["n_probes"] > 0
+    if case == "stress_pe":
+        prof = ctx.profile()
+        assert prof["n_overflow_items"] > 0 and prof["n_overflow_second_pass"] > 0.5 * prof["n_overflow_items"], prof
 
 
 @pytest.mark.parametrize("case,variant", [("human_pe", "pe"), ("mosaic_pe", "pe_union_fr"), ("yeast_se", "se")])
