@@ -565,8 +565,23 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
     return raw >> (64 - 2 * k);
   };
   // head k-mer (forward text) -> unitig id, to attach node records (KmerIndex.cpp:1420-1428 uses dbg.find(head))
-  std::unordered_map<uint64_t, uint32_t> head_of;
-  head_of.reserve(ix->n_unitigs * 2);
+  // (a flat open-addressing table at a load of at most a half: a std::unordered_map of a million nodes cost 0.1 s to fill and as much again to free)
+  struct HeadMap {
+    std::vector<uint64_t> key; std::vector<uint32_t> val; uint64_t mask = 0;
+    enum : uint32_t { NONE = 0xFFFFFFFFu };
+    void init(uint64_t n) { uint64_t cap = 16; while (cap < 2 * n) cap <<= 1; key.assign(cap, 0); val.assign(cap, NONE); mask = cap - 1; }
+    void emplace(uint64_t k, uint32_t v) {   // (the first value of a key stays, as with std::unordered_map::emplace)
+      uint64_t s = kamd::mix64(k) & mask;
+      while (val[s] != NONE) { if (key[s] == k) return; s = (s + 1) & mask; }
+      key[s] = k; val[s] = v;
+    }
+    const uint32_t* find(uint64_t k) const {
+      uint64_t s = kamd::mix64(k) & mask;
+      while (val[s] != NONE) { if (key[s] == k) return &val[s]; s = (s + 1) & mask; }
+      return nullptr;
+    }
+  } head_of;
+  head_of.init(ix->n_unitigs * 2);
   for (uint64_t i = 0; i < ix->n_unitigs; i++) {
     uint64_t v = 0;
     if (i < ix->n_long) {
@@ -713,13 +728,13 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
         const uint8_t* hs = c.p + ext[i].head;
         uint64_t head = 0;
         for (int j = 0; j < k; j++) { uint64_t ch = hs[j]; uint64_t x = (ch & 4) >> 1; head = (head << 2) | (x + ((x ^ (ch & 2)) >> 1)); }
-        auto it = head_of.find(head);
-        if (it == head_of.end()) { A.err = "Corrupted index; unitig not found"; break; }
+        const uint32_t* it = head_of.find(head);
+        if (!it) { A.err = "Corrupted index; unitig not found"; break; }
         Cursor nc{c.p, ext[i].end, ext[i].body};
         (void)nc.get<uint32_t>();  // Node::id: only a sort key in the reference
         const uint8_t flag = nc.get<uint8_t>();
         const uint64_t nb = flag == 0 ? 0 : (flag == 1 ? 1 : nc.get<uint64_t>());
-        nodes[i] = NodeTmp{it->second, 0, A.blocks.size()};
+        nodes[i] = NodeTmp{*it, 0, A.blocks.size()};
         for (uint64_t b = 0; b < nb; b++) {
           BlockTmp bt; bt.lb = nc.get<uint32_t>(); bt.ub = nc.get<uint32_t>(); bt.pos_off = A.posw.size();
           const uint64_t sz = nc.get<uint64_t>();
@@ -1022,6 +1037,7 @@ int load_index_impl(const char* path, int threads, int want_compact, double comp
     if (!pd.found) return kamd::fail(-3, "index: Dummy k-mer not found in graph");   // KmerIndex.cpp:1398-1401
     ix->dummy_slot = pd.slot; ix->dummy_uec = pd.uec; ix->dummy_strand = pd.strand ? 1 : 0;
   }
+  tick("D-list table + dummy hit");
   *out = ix.release();
   return 0;
 }
