@@ -808,7 +808,7 @@ def stress_leg(timeout_s=900, pairs=8_000_000):
     """The stress workload (synth.human_stress + off-transcriptome reads + quality tails) as a child run of this script with ALL its pairs through
     the unmodified reference (FullSizeParity): its line, cut down to the figures, for the line of config #3.  Never raises."""
     try:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--pairs", str(pairs), "--steps", "3", "--warmup", "1", "--end-to-end", "0",
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--pairs", str(pairs), "--steps", "6", "--warmup", "2", "--end-to-end", "0",
                "--no-pinned-pipeline", "--no-compact-leg", "--no-config2", "--no-stress-leg", "--bootstraps", "0", "--full-parity", "on"]
         d = run_child(cmd, timeout_s)
         keep = bench_line_digest(d)
@@ -828,7 +828,7 @@ def gencode_leg(prep, timeout_s=600):
     try:
         if prep is not None:
             prep.wait(timeout=timeout_s)
-        cmd = [sys.executable, os.path.abspath(__file__), "--genes", str(GENCODE_GENES), "--steps", "3", "--warmup", "1", "--end-to-end", "0", "--no-pinned-pipeline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--genes", str(GENCODE_GENES), "--steps", "6", "--warmup", "2", "--end-to-end", "0", "--no-pinned-pipeline",
                "--no-compact-leg", "--no-config2", "--no-stress-leg", "--no-gencode-leg", "--bootstraps", "0", "--full-parity", "off", "--no-cpu-baseline"]
         d = run_child(cmd, timeout_s)
         keep = bench_line_digest(d)
@@ -910,8 +910,8 @@ def self_launch(n_gpus: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed steps (a step of config #3 is 27 ms: ten of them are a quarter of a second of a run that takes minutes)")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed steps in front (the first step of a context allocates; the next two still settle by 1-2 %%)")
     ap.add_argument("--pairs", type=int, default=None, help="read pairs (reads) per GPU per step; default: BASELINE config #3: 30 M "
                     "(human), config #2: 10 M single-end reads (yeast)")
     ap.add_argument("--workload", default="human", choices=["human", "yeast", "stress"],
